@@ -1,0 +1,157 @@
+"""ctypes binding of libd3p_hip.so (C-ABI declared in include/d3p_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``d3p_amd._lib.build()`` with
+``hipcc --offload-arch=gfx950``.  There is no CPU fallback: if the shared object is missing, or no
+HIP device is visible, every compute entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libd3p_hip.so")
+_SRC = [os.path.join(_HERE, "csrc", f) for f in ("d3p_rng.hip", "d3p_dpvi.hip")]
+_DEPS = _SRC + [os.path.join(_HERE, "csrc", f) for f in ("d3p_device.h", "d3p_host.h")] + [
+    os.path.join(os.path.dirname(_HERE), "include", "d3p_hip.h")]
+
+D3P_BATCH_EXPLICIT, D3P_BATCH_FEISTEL, D3P_BATCH_POISSON = 0, 1, 2
+
+
+class D3PError(RuntimeError):
+    pass
+
+
+class LogregModel(C.Structure):
+    _fields_ = [("d", C.c_int32), ("intercept", C.c_int32), ("prior_w", C.c_float),
+                ("prior_b", C.c_float), ("lik_scale", C.c_float), ("inv_obs", C.c_float)]
+
+
+class DpsviHyper(C.Structure):
+    _fields_ = [("clip", C.c_float), ("dp_scale", C.c_float), ("lr", C.c_float),
+                ("b1", C.c_float), ("b2", C.c_float), ("adam_eps", C.c_float)]
+
+
+class DpsviState(C.Structure):
+    _fields_ = [("rng_key", C.c_void_p), ("key_slot", C.c_int32), ("params", C.c_void_p),
+                ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("step", C.c_void_p)]
+
+
+class BatchSource(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("B", C.c_uint32), ("q", C.c_float), ("suppress", C.c_int32),
+                ("batch_key", C.c_void_p), ("batch_index", C.c_void_p), ("mask", C.c_void_p),
+                ("n_rows", C.c_uint64), ("row_lo", C.c_uint64), ("row_hi", C.c_uint64)]
+
+
+def build(force=False, verbose=False):
+    """Compile libd3p_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    if not force and os.path.exists(_SO) and all(
+            os.path.getmtime(_SO) >= os.path.getmtime(p) for p in _DEPS):
+        return _SO
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", _SO] + _SRC
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _SO
+
+
+_V, _U64, _U32, _I32, _F, _SZ = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_float, C.c_size_t
+_PM, _PH, _PS, _PB = C.POINTER(LogregModel), C.POINTER(DpsviHyper), C.POINTER(DpsviState), C.POINTER(BatchSource)
+
+# name -> (restype, argtypes); every symbol include/d3p_hip.h declares
+SIGNATURES = {
+    "d3p_abi_version": (C.c_int, []),
+    "d3p_last_error": (C.c_char_p, []),
+    "d3p_device_count": (C.c_int, []),
+    "d3p_rng_split": (C.c_int, [_V, _V, C.c_int, _V]),
+    "d3p_rng_fold_in": (C.c_int, [_V, _V, _U32, _V]),
+    "d3p_rng_random_bits": (C.c_int, [_V, _V, C.c_int, _U64, _V]),
+    "d3p_rng_uniform": (C.c_int, [_V, _V, _U64, _F, _F, _V]),
+    "d3p_rng_normal": (C.c_int, [_V, _V, _U64, _V]),
+    "d3p_rng_randint": (C.c_int, [_V, _V, _U64, _I32, _I32, _V]),
+    "d3p_tf_split": (C.c_int, [_V, _V, C.c_int, _V]),
+    "d3p_tf_fold_in": (C.c_int, [_V, _V, _U32, _V]),
+    "d3p_tf_random_bits": (C.c_int, [_V, _V, _U64, _V]),
+    "d3p_tf_uniform": (C.c_int, [_V, _V, _U64, _F, _F, _V]),
+    "d3p_tf_normal": (C.c_int, [_V, _V, _U64, _V]),
+    "d3p_feistel_sample": (C.c_int, [_V, _V, _U32, _U32, _V]),
+    "d3p_feistel_from_constants": (C.c_int, [_V, _V, _U32, _U32, _V]),
+    "d3p_poisson_select_rng": (C.c_int, [_V, C.c_int, _V, _F, _U32, _U32, C.c_int, _V, _V, _V, _SZ]),
+    "d3p_perturb_apply": (C.c_int, [_V, _V, _V, _U64, _F, _F, _V, _F, _V]),
+    "d3p_poisson_select_workspace": (_SZ, [_U32]),
+    "d3p_poisson_select": (C.c_int, [_V, _V, _F, _U32, _U32, C.c_int, _V, _V, _V, _SZ]),
+    "d3p_take_rows": (C.c_int, [_V, _V, _U64, _U32, _V, _U32, _V, _V]),
+    "d3p_logreg_px_grads_workspace": (_SZ, [_PM, _U32]),
+    "d3p_logreg_px_grads": (C.c_int, [_V, _PM, _V, _V, _V, _V, _U32, _V, _V, _V, _V, _V, _V, _SZ]),
+    "d3p_clip_rows": (C.c_int, [_V, _V, _U32, _U32, _F]),
+    "d3p_full_norm": (C.c_int, [_V, _V, _U64, _V, _V, _SZ]),
+    "d3p_combine": (C.c_int, [_V, _V, _V, _U32, _U32, _V, _V]),
+    "d3p_perturb": (C.c_int, [_V, _V, _V, C.POINTER(C.c_int32), C.c_int, _F, _F, _V, _F, _V, _V]),
+    "d3p_adam_step": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _F, _F, _F, _F]),
+    "d3p_sgd_step": (C.c_int, [_V, _V, _V, _V, _U32, _F]),
+    "d3p_dpvi_logreg_workspace": (_SZ, [_PM, _PB]),
+    "d3p_dpvi_logreg_local_sums": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _V, _V, _V, _SZ]),
+    "d3p_dpvi_logreg_finalize": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _V, _V, _SZ]),
+    "d3p_dpvi_logreg_run": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _U32, _V, _V, _SZ]),
+    "d3p_dpvi_logreg_time_main_kernel": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _V, _SZ, C.c_int,
+                                                   C.POINTER(C.c_float)]),
+    "d3p_synth_logreg": (C.c_int, [_V, _U32, _U64, _U64, _I32, _V, _V]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libd3p_hip.so and attach signatures (no GPU required for this step)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise D3PError(
+                f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  d3p_amd has no CPU fallback.")
+        lib = C.CDLL(_SO)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.d3p_abi_version() != 1:
+            raise D3PError("libd3p_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+_device_checked = False
+
+
+def require_device():
+    """Fail loudly unless torch sees a ROCm device and the library can reach it."""
+    global _device_checked
+    if _device_checked:
+        return
+    import torch
+    if not torch.cuda.is_available():
+        raise D3PError("d3p_amd needs a ROCm GPU (MI355X / gfx950): torch.cuda.is_available() is "
+                       "False and there is no CPU fallback.")
+    if load().d3p_device_count() <= 0:
+        raise D3PError("libd3p_hip.so sees no HIP device")
+    _device_checked = True
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().d3p_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(msg)
+        raise D3PError(f"libd3p_hip error {rc}: {msg}")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device address of a torch tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())

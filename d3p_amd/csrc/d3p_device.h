@@ -1,0 +1,189 @@
+// Device-side primitives shared by the gfx950 kernels: ChaCha20 block, threefry2x32, the
+// bits->uniform->normal transforms and wave64 reductions.  gfx950 only: wavefront = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define D3P_WAVE 64
+
+#define D3P_TAG_SPLIT 0x00000001u
+#define D3P_TAG_FOLD 0x00000002u
+
+#define D3P_NORMAL_LO (-0.99999994f)  // np.nextafter(float32(-1), 0): d3p/random/__init__.py:78
+#define D3P_SQRT2 1.41421354f         // float32(sqrt(2)):            d3p/random/__init__.py:81
+#define D3P_HALF_LOG_2PI 0.918938533204672742f
+
+namespace d3p {
+
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r)
+{
+    // v_alignbit_b32: ({x,x} >> (32-r)) = rotate left by r
+    return __builtin_amdgcn_alignbit(x, x, 32 - r);
+}
+
+#define D3P_QR(a, b, c, d)                \
+    a += b; d ^= a; d = d3p::rotl32(d, 16); \
+    c += d; b ^= c; b = d3p::rotl32(b, 12); \
+    a += b; d ^= a; d = d3p::rotl32(d, 8);  \
+    c += d; b ^= c; b = d3p::rotl32(b, 7);
+
+// RFC 8439 2.3 block function; `in` and `out` are 16 registers each.
+__device__ __forceinline__ void chacha20_block(const uint32_t (&in)[16], uint32_t (&out)[16])
+{
+    uint32_t x0 = in[0], x1 = in[1], x2 = in[2], x3 = in[3], x4 = in[4], x5 = in[5], x6 = in[6],
+             x7 = in[7], x8 = in[8], x9 = in[9], x10 = in[10], x11 = in[11], x12 = in[12],
+             x13 = in[13], x14 = in[14], x15 = in[15];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        D3P_QR(x0, x4, x8, x12) D3P_QR(x1, x5, x9, x13) D3P_QR(x2, x6, x10, x14) D3P_QR(x3, x7, x11, x15)
+        D3P_QR(x0, x5, x10, x15) D3P_QR(x1, x6, x11, x12) D3P_QR(x2, x7, x8, x13) D3P_QR(x3, x4, x9, x14)
+    }
+    out[0] = x0 + in[0]; out[1] = x1 + in[1]; out[2] = x2 + in[2]; out[3] = x3 + in[3];
+    out[4] = x4 + in[4]; out[5] = x5 + in[5]; out[6] = x6 + in[6]; out[7] = x7 + in[7];
+    out[8] = x8 + in[8]; out[9] = x9 + in[9]; out[10] = x10 + in[10]; out[11] = x11 + in[11];
+    out[12] = x12 + in[12]; out[13] = x13 + in[13]; out[14] = x14 + in[14]; out[15] = x15 + in[15];
+}
+
+__device__ __forceinline__ void load_key(const uint32_t* __restrict__ key, uint32_t (&s)[16])
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = key[i];
+}
+
+// Block `blk` of the keystream of `key` (random_bits domain: nonce untouched).
+__device__ __forceinline__ void keystream_block(const uint32_t (&key)[16], uint32_t blk, uint32_t (&out)[16])
+{
+    uint32_t in[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) in[i] = key[i];
+    in[12] += blk;
+    chacha20_block(in, out);
+}
+
+// Child key derivation shared by split (tag 1, ctr_add = i) and fold_in (tag 2, data): the child
+// key is words 0..7 of the parent's block at (counter + ctr_add, nonce ^ (data, 0, tag)); child
+// counter/nonce are zero.  Layout is this build's own (parity unpinned).
+__device__ __forceinline__ void derive_child(const uint32_t (&parent)[16], uint32_t ctr_add, uint32_t data,
+                                             uint32_t tag, uint32_t (&child)[16])
+{
+    uint32_t in[16], blk[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) in[i] = parent[i];
+    in[12] += ctr_add;
+    in[13] ^= data;
+    in[15] ^= tag;
+    chacha20_block(in, blk);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) child[i] = parent[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) child[4 + i] = blk[i];
+    child[12] = child[13] = child[14] = child[15] = 0u;
+}
+
+// threefry2x32-20 (Random123), as used by jax.random.
+__device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t& o0,
+                                             uint32_t& o1)
+{
+    const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
+    uint32_t x0 = c0 + k0, x1 = c1 + k1;
+#define D3P_TF_R(r) x0 += x1; x1 = d3p::rotl32(x1, r); x1 ^= x0;
+    D3P_TF_R(13) D3P_TF_R(15) D3P_TF_R(26) D3P_TF_R(6)
+    x0 += k1; x1 += k2 + 1u;
+    D3P_TF_R(17) D3P_TF_R(29) D3P_TF_R(16) D3P_TF_R(24)
+    x0 += k2; x1 += k0 + 2u;
+    D3P_TF_R(13) D3P_TF_R(15) D3P_TF_R(26) D3P_TF_R(6)
+    x0 += k0; x1 += k1 + 3u;
+    D3P_TF_R(17) D3P_TF_R(29) D3P_TF_R(16) D3P_TF_R(24)
+    x0 += k1; x1 += k2 + 4u;
+    D3P_TF_R(13) D3P_TF_R(15) D3P_TF_R(26) D3P_TF_R(6)
+    x0 += k2; x1 += k0 + 5u;
+#undef D3P_TF_R
+    o0 = x0;
+    o1 = x1;
+}
+
+// Word j of jax's threefry_2x32(key, iota(n)): counts are split in two halves (odd n zero-padded).
+__device__ __forceinline__ uint32_t tf_iota_word(uint32_t k0, uint32_t k1, uint64_t n, uint64_t j)
+{
+    const uint64_t half = (n + 1) >> 1;
+    uint32_t a, b;
+    if (j < half) {
+        const uint64_t c1 = j + half;
+        threefry2x32(k0, k1, (uint32_t)j, c1 < n ? (uint32_t)c1 : 0u, a, b);
+        return a;
+    }
+    threefry2x32(k0, k1, (uint32_t)(j - half), (uint32_t)j, a, b);
+    return b;
+}
+
+// jax.random.uniform's float32 construction: (bits >> 9) | 0x3f800000, minus 1, affine, clamp at lo.
+__device__ __forceinline__ float bits_to_uniform(uint32_t bits, float lo, float hi)
+{
+    const float f = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, bits, 9)) - 1.0f;
+    const float scale = hi - lo;
+    const float r = __fadd_rn(__fmul_rn(f, scale), lo);
+    return fmaxf(lo, r);
+}
+
+// float32 erf_inv (Giles' single-precision polynomial, the form XLA lowers lax.erf_inv to).
+__device__ __forceinline__ float erfinv_f32(float x)
+{
+    float w = -__logf(__fmaf_rn(-x, x, 1.0f));
+    float p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = __fmaf_rn(p, w, 3.43273939e-07f);
+        p = __fmaf_rn(p, w, -3.5233877e-06f);
+        p = __fmaf_rn(p, w, -4.39150654e-06f);
+        p = __fmaf_rn(p, w, 0.00021858087f);
+        p = __fmaf_rn(p, w, -0.00125372503f);
+        p = __fmaf_rn(p, w, -0.00417768164f);
+        p = __fmaf_rn(p, w, 0.246640727f);
+        p = __fmaf_rn(p, w, 1.50140941f);
+    } else {
+        w = __fsqrt_rn(w) - 3.0f;
+        p = -0.000200214257f;
+        p = __fmaf_rn(p, w, 0.000100950558f);
+        p = __fmaf_rn(p, w, 0.00134934322f);
+        p = __fmaf_rn(p, w, -0.00367342844f);
+        p = __fmaf_rn(p, w, 0.00573950773f);
+        p = __fmaf_rn(p, w, -0.0076224613f);
+        p = __fmaf_rn(p, w, 0.00943887047f);
+        p = __fmaf_rn(p, w, 1.00167406f);
+        p = __fmaf_rn(p, w, 2.83297682f);
+    }
+    return p * x;
+}
+
+// d3p.random.normal / jax.random.normal transform of one 32-bit word.
+__device__ __forceinline__ float bits_to_normal(uint32_t bits)
+{
+    return D3P_SQRT2 * erfinv_f32(bits_to_uniform(bits, D3P_NORMAL_LO, 1.0f));
+}
+
+// ---- wave64 all-reduce (sum): 4 DPP steps inside each row of 16 lanes, then the 4 row sums are
+// read through SGPRs.  Fixed order => bitwise reproducible.  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+__device__ __forceinline__ float softplus_f(float t) { return fmaxf(t, 0.0f) + log1pf(__expf(-fabsf(t))); }
+__device__ __forceinline__ float sigmoid_f(float t) { return 1.0f / (1.0f + __expf(-t)); }
+
+}  // namespace d3p

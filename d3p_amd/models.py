@@ -1,0 +1,109 @@
+"""Declarative stand-ins for the NumPyro objects the reference passes to DPSVI.
+
+numpyro / jax cannot be imported in this build, so "tracing the model once" is
+replaced by a small model specification whose flat parameter layout is exactly what tracing the
+reference's model + ``numpyro.infer.autoguide.AutoDiagonalNormal`` yields:
+
+    params = {'auto_loc': (D,), 'auto_scale': (D,)}     D = number of latent scalars
+
+Reference workloads covered: README.md:89-99 (logistic regression, no intercept, prior N(0, 4))
+and examples/logistic_regression.py:49-66 (with intercept, prior N(0, 1)).
+"""
+import math
+
+import torch
+
+
+class LogisticRegression:
+    """w ~ Normal(0, prior_scale)^d [, intercept ~ Normal(0, intercept_prior_scale)];
+    ys ~ Bernoulli(logits = xs @ w + intercept) inside ``plate('batch', N, batch_size)``.
+
+    Call signature of the reference models: ``model(xs, ys, N)`` / ``model(batch_X, batch_y,
+    num_obs_total=)``; the total count is taken from the keyword ``N`` or ``num_obs_total``."""
+
+    def __init__(self, d=None, prior_scale=1.0, intercept=False, intercept_prior_scale=1.0):
+        self.d = d
+        self.prior_scale = float(prior_scale)
+        self.intercept = bool(intercept)
+        self.intercept_prior_scale = float(intercept_prior_scale)
+
+    def latent_dim(self, d):
+        return d + (1 if self.intercept else 0)
+
+    def site_names(self):
+        return ("w", "intercept") if self.intercept else ("w",)
+
+    @staticmethod
+    def num_obs_total(args, kwargs):
+        for k in ("N", "num_obs_total"):
+            if kwargs.get(k) is not None:
+                return float(kwargs[k])
+        if len(args) >= 3 and args[2] is not None:
+            return float(args[2])
+        return None
+
+
+class init_to_uniform:
+    """numpyro.infer.init_to_uniform(radius=2): auto_loc ~ U(-radius, radius).  The draw uses the
+    threefry key of ``DPSVI.init`` (numpyro's exact key plumbing is unpinned)."""
+
+    def __init__(self, radius=2.0):
+        self.radius = float(radius)
+
+
+class init_to_value:
+    def __init__(self, values):
+        self.values = values
+
+
+class AutoDiagonalNormal:
+    """numpyro.infer.autoguide.AutoDiagonalNormal: q(z) = Normal(auto_loc, auto_scale), with
+    auto_scale constrained by softplus (unconstrained value optimised), init_scale 0.1."""
+
+    def __init__(self, model, init_loc_fn=None, init_scale=0.1):
+        if init_scale <= 0:
+            raise ValueError("Expected init_scale > 0. but got {}".format(init_scale))
+        self.model = model
+        self.init_loc_fn = init_loc_fn if init_loc_fn is not None else init_to_uniform()
+        self.init_scale = float(init_scale)
+
+    def unconstrained_init_scale(self):
+        # softplus^-1(init_scale)
+        return math.log(math.expm1(self.init_scale))
+
+
+class Trace_ELBO:
+    """Marker for numpyro.infer.Trace_ELBO (num_particles = 1)."""
+
+    def __init__(self, num_particles=1):
+        if num_particles != 1:
+            raise NotImplementedError("only num_particles=1 is supported")
+        self.num_particles = 1
+
+
+class Adam:
+    """numpyro.optim.Adam(step_size, b1=0.9, b2=0.999, eps=1e-8)."""
+
+    def __init__(self, step_size, b1=0.9, b2=0.999, eps=1e-8):
+        self.step_size, self.b1, self.b2, self.eps = float(step_size), float(b1), float(b2), float(eps)
+
+    def init(self, params: torch.Tensor):
+        dev = params.device
+        return (torch.zeros((), dtype=torch.int32, device=dev), params,
+                torch.zeros_like(params), torch.zeros_like(params))
+
+    def get_params(self, optim_state):
+        return optim_state[1]
+
+
+class SGD:
+    """numpyro.optim.SGD(step_size) (used by the reference's tests, tests/test_dpsvi.py:57)."""
+
+    def __init__(self, step_size):
+        self.step_size = float(step_size)
+
+    def init(self, params):
+        return (torch.zeros((), dtype=torch.int32, device=params.device), params)
+
+    def get_params(self, optim_state):
+        return optim_state[1]

@@ -1,0 +1,114 @@
+"""Non-cryptographic rng_suite for debugging: threefry2x32 in jax.random's array layout.
+
+Mirror of ``d3p.random.debug`` (reference d3p/random/debug.py:34-80), which wraps ``jax.random``.
+Keys are (2,) ``torch.uint32`` CUDA tensors.  Importing this module warns, as the reference does
+(d3p/random/debug.py:48-53).
+"""
+import secrets
+import warnings
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import check, ptr, stream_ptr
+
+PRNGState = torch.Tensor
+KeyRandomnessInBytes = 4
+RNG_KIND = 1  # threefry iota stream
+
+warnings.warn(
+    "d3p is currently using a non-cryptographic random number generator!\n"
+    "This is intended for debugging only! Please make sure to switch to using d3p_amd.random to"
+    " ensure privacy guarantees hold!",
+    stacklevel=2,
+)
+
+_FLOATS = (torch.float16, torch.bfloat16, torch.float32, torch.float64)
+
+
+def PRNGKey(seed: Optional[int] = None) -> PRNGState:
+    """d3p/random/debug.py:56-66; jax.random.PRNGKey(seed) = [seed >> 32, seed & 0xffffffff]."""
+    _lib.require_device()
+    if seed is None:
+        seed = int.from_bytes(secrets.token_bytes(KeyRandomnessInBytes), "big", signed=False)
+    seed = int(seed)
+    words = np.array([(seed >> 32) & 0xFFFFFFFF, seed & 0xFFFFFFFF], dtype=np.uint32)
+    return torch.from_numpy(words.view(np.int32).copy()).cuda().view(torch.uint32)
+
+
+def _key(key):
+    if not isinstance(key, torch.Tensor) or not key.is_cuda or key.numel() != 2 or key.element_size() != 4:
+        raise TypeError("debug rng key must be a CUDA tensor of 2 32-bit words")
+    return key.contiguous()
+
+
+def _numel(shape):
+    n = 1
+    for s in tuple(shape):
+        n *= int(s)
+    return n
+
+
+def split(key, num: int = 2):
+    key = _key(key)
+    out = torch.empty((num, 2), dtype=torch.uint32, device=key.device)
+    check(_lib.load().d3p_tf_split(stream_ptr(), ptr(key), int(num), ptr(out)))
+    return out
+
+
+def fold_in(key, data: int):
+    key = _key(key)
+    out = torch.empty(2, dtype=torch.uint32, device=key.device)
+    check(_lib.load().d3p_tf_fold_in(stream_ptr(), ptr(key), int(data) & 0xFFFFFFFF, ptr(out)))
+    return out
+
+
+def random_bits(key, bit_width: int, shape: Sequence[int]):
+    """d3p/random/debug.py:69-71 (32-bit words on the device path)."""
+    if bit_width != 32:
+        raise _lib.D3PError("debug random_bits: only bit_width 32 is implemented on the device path")
+    key = _key(key)
+    shape = tuple(shape)
+    n = _numel(shape)
+    out = torch.empty(max(n, 1), dtype=torch.uint32, device=key.device)
+    check(_lib.load().d3p_tf_random_bits(stream_ptr(), ptr(key), n, ptr(out)))
+    return out[:n].reshape(shape)
+
+
+def _check_float(dtype, what):
+    if dtype not in _FLOATS and dtype is not float and dtype is not None:
+        raise ValueError(f"dtype argument to `{what}` must be a float dtype, got {dtype}")
+    if dtype not in (torch.float32, float, None):
+        raise _lib.D3PError(f"`{what}`: only float32 is implemented on the device path")
+
+
+def uniform(key, shape: Sequence[int] = (), dtype=torch.float32, minval=0.0, maxval=1.0):
+    _check_float(dtype, "uniform")
+    key = _key(key)
+    shape = tuple(shape)
+    n = _numel(shape)
+    out = torch.empty(max(n, 1), dtype=torch.float32, device=key.device)
+    check(_lib.load().d3p_tf_uniform(stream_ptr(), ptr(key), n, float(minval), float(maxval), ptr(out)))
+    return out[:n].reshape(shape)
+
+
+def normal(key, shape: Sequence[int] = (), dtype=torch.float32):
+    _check_float(dtype, "normal")
+    key = _key(key)
+    shape = tuple(shape)
+    n = _numel(shape)
+    out = torch.empty(max(n, 1), dtype=torch.float32, device=key.device)
+    check(_lib.load().d3p_tf_normal(stream_ptr(), ptr(key), n, ptr(out)))
+    return out[:n].reshape(shape)
+
+
+def randint(key, shape, minval, maxval, dtype=torch.int32):
+    raise _lib.D3PError("d3p_amd.random.debug.randint is not implemented yet (jax.random.randint layout); "
+                        "use d3p_amd.random for with-replacement sampling")
+
+
+def convert_to_jax_rng_key(rng_key):
+    """d3p/random/debug.py:74-80: identity."""
+    return rng_key

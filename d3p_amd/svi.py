@@ -1,0 +1,501 @@
+"""DP-VI with per-example gradient clipping and Gaussian perturbation on MI355X.
+
+Mirror of ``d3p.svi`` (reference d3p/svi.py): ``DPSVI``, ``DPSVIState``, ``full_norm``,
+``clip_gradient``, ``normalize_gradient`` with the same names, argument order, return tuples and
+exceptions.  ``DPSVI.update`` runs the fused HIP path (per-example gradient -> clip -> sum ->
+noise -> Adam, the B x P gradient tensor is never materialised); the five stage methods the
+reference's tests call directly (tests/test_dpsvi.py:128-129, :158-159, :171, :185, :199-202)
+are kept and operate on materialised device tensors through their own kernels.
+"""
+import ctypes as C
+from typing import Any, NamedTuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import random as strong_rng
+from ._lib import BatchSource, DpsviHyper, DpsviState, LogregModel, check, ptr, stream_ptr
+from .models import (SGD, Adam, AutoDiagonalNormal, LogisticRegression, init_to_uniform, init_to_value)
+from .util import example_count
+
+PRNGState = Any
+
+
+class DPSVIState(NamedTuple):
+    """d3p/svi.py:37-40."""
+    optim_state: Any
+    rng_key: PRNGState
+    observation_scale: float
+
+
+# ------------------------------------------------------------------ pytree helpers (jax.tree_util order)
+def _tree_flatten(tree):
+    if tree is None:
+        return [], ("none",)
+    if isinstance(tree, dict):
+        keys = sorted(tree)
+        leaves, defs = [], []
+        for k in keys:
+            l, d = _tree_flatten(tree[k])
+            leaves += l
+            defs.append((k, d, len(l)))
+        return leaves, ("dict", defs)
+    if isinstance(tree, (tuple, list)):
+        leaves, defs = [], []
+        for x in tree:
+            l, d = _tree_flatten(x)
+            leaves += l
+            defs.append((d, len(l)))
+        return leaves, ("tuple" if isinstance(tree, tuple) else "list", defs)
+    return [tree], ("leaf",)
+
+
+def _tree_unflatten(treedef, leaves):
+    kind = treedef[0]
+    if kind == "none":
+        return None
+    if kind == "leaf":
+        return leaves[0]
+    out, pos = [], 0
+    if kind == "dict":
+        d = {}
+        for k, sub, n in treedef[1]:
+            d[k] = _tree_unflatten(sub, leaves[pos:pos + n])
+            pos += n
+        return d
+    for sub, n in treedef[1]:
+        out.append(_tree_unflatten(sub, leaves[pos:pos + n]))
+        pos += n
+    return tuple(out) if kind == "tuple" else out
+
+
+def _as_device_f32(x, device=None):
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        t = torch.as_tensor(np.asarray(x, dtype=np.float32))
+    if not t.is_cuda:
+        t = t.cuda() if device is None else t.to(device)
+    return t.to(torch.float32)
+
+
+# ------------------------------------------------------------------ module-level gradient manipulators
+def full_norm(vector_parts, ord=2):
+    """d3p/svi.py:68-87: norm over all leaves of a tree treated as one vector (0. if empty)."""
+    if ord != 2:
+        raise NotImplementedError("only the 2-norm is implemented on the device path")
+    leaves, _ = _tree_flatten(vector_parts)
+    if len(leaves) == 0:
+        return 0.0
+    _lib.require_device()
+    flat = [_as_device_f32(g).reshape(-1) for g in leaves]
+    v = torch.cat(flat) if len(flat) > 1 else flat[0].contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=v.device)
+    check(_lib.load().d3p_full_norm(stream_ptr(), ptr(v), v.numel(), ptr(out), None, 0))
+    return out[0]
+
+
+def _clip_flat_rows(rows: torch.Tensor, c: float) -> torch.Tensor:
+    check(_lib.load().d3p_clip_rows(stream_ptr(), ptr(rows), rows.shape[0], rows.shape[1], float(c)))
+    return rows
+
+
+def clip_gradient(gradient_parts, c):
+    """d3p/svi.py:106-124: scale every leaf by 1/max(1, ||g||/c); c == 0 -> ValueError."""
+    if c == 0.0:
+        raise ValueError("The clipping threshold must be greater than 0.")
+    leaves, treedef = _tree_flatten(gradient_parts)
+    if len(leaves) == 0:
+        return gradient_parts
+    _lib.require_device()
+    flat = [_as_device_f32(g) for g in leaves]
+    row = torch.cat([g.reshape(-1) for g in flat]).reshape(1, -1).contiguous()
+    if np.isinf(c):
+        return _tree_unflatten(treedef, flat)
+    _clip_flat_rows(row, c)
+    out, pos = [], 0
+    for g in flat:
+        out.append(row[0, pos:pos + g.numel()].reshape(g.shape))
+        pos += g.numel()
+    return _tree_unflatten(treedef, out)
+
+
+def normalize_gradient(gradient_parts, ord=2):
+    """d3p/svi.py:90-103."""
+    norm = full_norm(gradient_parts, ord=ord)
+    leaves, treedef = _tree_flatten(gradient_parts)
+    inv = 1.0 / norm
+    return _tree_unflatten(treedef, [_as_device_f32(g) * inv for g in leaves])
+
+
+# ------------------------------------------------------------------ DPSVI
+class DPSVI:
+    """Differentially-private SVI (d3p/svi.py:127-498) for the model families of d3p_amd.models.
+
+    :param model: a ``d3p_amd.models.LogisticRegression`` specification (stands in for the NumPyro
+        model function; numpyro is not importable in this build).
+    :param guide: ``d3p_amd.models.AutoDiagonalNormal(model)``.
+    :param optim: ``d3p_amd.models.Adam`` / ``SGD``.
+    :param per_example_loss: ``d3p_amd.models.Trace_ELBO()``.
+    :param clipping_threshold: C, must be finite (ValueError otherwise, svi.py:187-188).
+    :param dp_scale: sigma of the Gaussian mechanism.
+    :param rng_suite: ``d3p_amd.random`` (default, ChaCha20) or ``d3p_amd.random.debug``.
+    :param clip_unscaled_observations: svi.py:159-164.
+    :param static_kwargs: constant model arguments, e.g. ``N=`` / ``num_obs_total=``.
+    """
+
+    def __init__(self, model, guide, optim, per_example_loss, clipping_threshold, dp_scale,
+                 rng_suite=strong_rng, clip_unscaled_observations=True, **static_kwargs):
+        self._clipping_threshold = clipping_threshold
+        self._dp_scale = dp_scale
+        self._rng_suite = rng_suite
+        self._clip_unscaled_observations = clip_unscaled_observations
+        if not np.isfinite(clipping_threshold):
+            raise ValueError("clipping_threshold must be finite!")
+        self.model = model
+        self.guide = guide
+        self.optim = optim
+        self.loss = per_example_loss
+        self.static_kwargs = static_kwargs
+        self._ws = {}
+
+    # ---------------------------------------------------------------- state helpers (svi.py:192-211)
+    @staticmethod
+    def _update_state_rng(dp_svi_state, rng_key):
+        return DPSVIState(dp_svi_state.optim_state, rng_key, dp_svi_state.observation_scale)
+
+    @staticmethod
+    def _update_state_optim_state(dp_svi_state, optim_state):
+        return DPSVIState(optim_state, dp_svi_state.rng_key, dp_svi_state.observation_scale)
+
+    def _split_rng_key(self, dp_svi_state, count=1):
+        split_keys = self._rng_suite.split(dp_svi_state.rng_key, count + 1)
+        return DPSVI._update_state_rng(dp_svi_state, split_keys[0]), split_keys[1:]
+
+    # ---------------------------------------------------------------- model plumbing
+    def _require_logreg(self):
+        if not isinstance(self.model, LogisticRegression) or not isinstance(self.guide, AutoDiagonalNormal):
+            raise _lib.D3PError("DPSVI: model must be d3p_amd.models.LogisticRegression with an "
+                                "AutoDiagonalNormal guide (the model families built so far)")
+
+    def _model_struct(self, d, kwargs, observation_scale):
+        kw = dict(self.static_kwargs)
+        kw.update(kwargs)
+        n_total = LogisticRegression.num_obs_total((), kw)
+        # a per-example batch has size 1, so plate(N, 1) scales the likelihood by N (svi.py:277)
+        lik_scale = 1.0 if n_total is None else n_total
+        m = self.model
+        return LogregModel(int(d), int(m.intercept), m.prior_scale, m.intercept_prior_scale,
+                           float(lik_scale), 1.0 / float(observation_scale))
+
+    def _hyper(self):
+        o = self.optim
+        if isinstance(o, Adam):
+            return DpsviHyper(float(self._clipping_threshold), float(self._dp_scale), o.step_size, o.b1, o.b2, o.eps)
+        return DpsviHyper(float(self._clipping_threshold), float(self._dp_scale), getattr(o, "step_size", 0.0),
+                          0.9, 0.999, 1e-8)
+
+    def _workspace(self, nbytes, device, tag="ws"):
+        buf = self._ws.get(tag)
+        if buf is None or buf.numel() < nbytes or buf.device != device:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._ws[tag] = buf
+        return buf
+
+    # ---------------------------------------------------------------- init (svi.py:213-236)
+    def init(self, rng_key, *args, **kwargs):
+        self._require_logreg()
+        _lib.require_device()
+        X = args[0]
+        d = int(X.shape[1])
+        D = self.model.latent_dim(d)
+        jax_rng_key = self._rng_suite.convert_to_jax_rng_key(rng_key)
+        fn = self.guide.init_loc_fn
+        if isinstance(fn, init_to_uniform):
+            loc = _dbg_uniform(jax_rng_key, D, -fn.radius, fn.radius)
+        elif isinstance(fn, init_to_value):
+            loc = _as_device_f32(fn.values, X.device).reshape(D).clone()
+        else:
+            raise ValueError("unsupported init_loc_fn")
+        unc = torch.full((D,), self.guide.unconstrained_init_scale(), dtype=torch.float32, device=X.device)
+        params = torch.cat([loc, unc]).contiguous()
+        optim_state = self.optim.init(params)
+
+        observation_scale = 1.0
+        if self._clip_unscaled_observations:
+            kw = dict(self.static_kwargs)
+            kw.update(kwargs)
+            n_total = LogisticRegression.num_obs_total(args, kw)
+            # get_observations_scale on a one-element batch: plate(N, subsample_size=1) -> N (svi.py:225-234)
+            observation_scale = 1.0 if n_total is None else n_total
+        return DPSVIState(optim_state, rng_key, observation_scale)
+
+    def get_params(self, svi_state):
+        """Constrained parameters (numpyro SVI.get_params): auto_scale = softplus(unconstrained)."""
+        p = self.optim.get_params(svi_state.optim_state)
+        D = p.numel() // 2
+        return {"auto_loc": p[:D].clone(), "auto_scale": torch.nn.functional.softplus(p[D:])}
+
+    # ---------------------------------------------------------------- stage 1 (svi.py:238-308)
+    def _compute_per_example_gradients(self, dp_svi_state, step_rng_key, *args, mask=True, **kwargs):
+        self._require_logreg()
+        _lib.require_device()
+        lib = _lib.load()
+        X = args[0].contiguous()
+        y = args[1].contiguous().to(torch.float32)
+        B, d = X.shape
+        D = self.model.latent_dim(d)
+        jax_rng_key = self._rng_suite.convert_to_jax_rng_key(step_rng_key).contiguous()
+        params = self.optim.get_params(dp_svi_state.optim_state).contiguous()
+        model = self._model_struct(d, kwargs, dp_svi_state.observation_scale)
+        mask_t = None
+        if not isinstance(mask, bool):
+            mask_t = mask.to(torch.uint8).contiguous()
+        elif mask is False:
+            mask_t = torch.zeros(B, dtype=torch.uint8, device=X.device)
+        px_loss = torch.empty(B, dtype=torch.float32, device=X.device)
+        px_grads = torch.empty((B, 2 * D), dtype=torch.float32, device=X.device)
+        meta = torch.empty(2, dtype=torch.float32, device=X.device)
+        ws = self._workspace(lib.d3p_logreg_px_grads_workspace(C.byref(model), B), X.device, "px")
+        eps = kwargs.get("_eps")
+        check(lib.d3p_logreg_px_grads(stream_ptr(), C.byref(model), ptr(params), ptr(X), ptr(y), ptr(mask_t), B,
+                                      ptr(eps), ptr(jax_rng_key), ptr(px_loss), ptr(px_grads), ptr(meta),
+                                      ptr(ws), ws.numel()))
+        grads = {"auto_loc": px_grads[:, :D], "auto_scale": px_grads[:, D:]}
+        return dp_svi_state, px_loss, grads, meta[0], meta[1]
+
+    # ---------------------------------------------------------------- stage 2 (svi.py:310-325)
+    def _clip_gradients(self, dp_svi_state, px_grads):
+        if self._clipping_threshold == 0.0:
+            raise ValueError("The clipping threshold must be greater than 0.")
+        _lib.require_device()
+        leaves, treedef = _tree_flatten(px_grads)
+        flat = [_as_device_f32(g) for g in leaves]
+        B = flat[0].shape[0]
+        rows = torch.cat([g.reshape(B, -1) for g in flat], dim=1).contiguous()
+        _clip_flat_rows(rows, self._clipping_threshold)
+        out, pos = [], 0
+        for g in flat:
+            w = g[0].numel()
+            out.append(rows[:, pos:pos + w].reshape(g.shape))
+            pos += w
+        return dp_svi_state, _tree_unflatten(treedef, out)
+
+    # ---------------------------------------------------------------- stage 3 (svi.py:327-348)
+    def _combine_gradients(self, px_clipped_grads, px_loss):
+        _lib.require_device()
+        lib = _lib.load()
+        leaves, treedef = _tree_flatten(px_clipped_grads)
+        px_loss = _as_device_f32(px_loss).contiguous()
+        B = px_loss.shape[0]
+        loss = torch.empty(1, dtype=torch.float32, device=px_loss.device)
+        outs = []
+        for k, g in enumerate(leaves):
+            g = _as_device_f32(g, px_loss.device)
+            rows = g.reshape(g.shape[0], -1).contiguous()
+            avg = torch.empty(rows.shape[1], dtype=torch.float32, device=rows.device)
+            check(lib.d3p_combine(stream_ptr(), ptr(rows), ptr(px_loss) if k == 0 else None, rows.shape[0],
+                                  rows.shape[1], ptr(avg), ptr(loss) if k == 0 else None))
+            outs.append(avg.reshape(g.shape[1:]))
+        if not leaves:
+            check(lib.d3p_combine(stream_ptr(), ptr(px_loss.reshape(B, 1)), ptr(px_loss), B, 1,
+                                  ptr(torch.empty(1, device=px_loss.device)), ptr(loss)))
+        return loss[0], _tree_unflatten(treedef, outs)
+
+    # ---------------------------------------------------------------- stage 4 (svi.py:350-377)
+    def _perturb_and_reassemble_gradients(self, dp_svi_state, step_rng_key, avg_clipped_grads, num_elements,
+                                          batch_mask_scaling_factor):
+        _lib.require_device()
+        lib = _lib.load()
+        leaves, treedef = _tree_flatten(avg_clipped_grads)
+        dev = step_rng_key.device
+        if isinstance(num_elements, torch.Tensor) or isinstance(batch_mask_scaling_factor, torch.Tensor):
+            meta = torch.stack([_as_device_f32(num_elements, dev).reshape(()),
+                                _as_device_f32(batch_mask_scaling_factor, dev).reshape(())]).contiguous()
+        else:
+            meta = torch.tensor([float(num_elements), float(batch_mask_scaling_factor)], dtype=torch.float32,
+                                device=dev)
+        obs_scale = float(dp_svi_state.observation_scale)
+        per_site_rngs = self._rng_suite.split(step_rng_key, len(leaves))  # svi.py:491
+        outs = []
+        for g, site_rng in zip(leaves, per_site_rngs):
+            g = _as_device_f32(g, dev).contiguous()
+            noise = self._rng_suite.normal(site_rng, g.shape).contiguous()  # svi.py:487
+            out = torch.empty_like(g)
+            check(lib.d3p_perturb_apply(stream_ptr(), ptr(g), ptr(noise), g.numel(), float(self._dp_scale),
+                                        float(self._clipping_threshold), ptr(meta), obs_scale, ptr(out)))
+            outs.append(out)
+        return dp_svi_state, _tree_unflatten(treedef, outs)
+
+    @staticmethod
+    def perturbation_function(rng_suite, rng, values, perturbation_scale):
+        """d3p/svi.py:470-498: each leaf += normal(site_key) * perturbation_scale."""
+        _lib.require_device()
+        lib = _lib.load()
+        leaves, treedef = _tree_flatten(values)
+        if isinstance(perturbation_scale, torch.Tensor):
+            perturbation_scale = float(perturbation_scale)
+        meta = torch.tensor([1.0, 1.0], dtype=torch.float32, device=rng.device)
+        per_site_rngs = rng_suite.split(rng, len(leaves))
+        outs = []
+        for g, site_rng in zip(leaves, per_site_rngs):
+            g = _as_device_f32(g, rng.device).contiguous()
+            noise = rng_suite.normal(site_rng, g.shape).contiguous()
+            out = torch.empty_like(g)
+            check(lib.d3p_perturb_apply(stream_ptr(), ptr(g), ptr(noise), g.numel(), float(perturbation_scale), 1.0,
+                                        ptr(meta), 1.0, ptr(out)))
+            outs.append(out)
+        return _tree_unflatten(treedef, outs)
+
+    # ---------------------------------------------------------------- stage 5 (svi.py:379-393)
+    def _apply_gradient(self, dp_svi_state, perturbed_grads):
+        _lib.require_device()
+        lib = _lib.load()
+        leaves, _ = _tree_flatten(perturbed_grads)
+        g = torch.cat([_as_device_f32(l).reshape(-1) for l in leaves]).contiguous()
+        st = dp_svi_state.optim_state
+        step = st[0].clone()
+        params = st[1].clone()
+        if isinstance(self.optim, Adam):
+            m, v = st[2].clone(), st[3].clone()
+            o = self.optim
+            check(lib.d3p_adam_step(stream_ptr(), ptr(params), ptr(m), ptr(v), ptr(step), ptr(g), params.numel(),
+                                    o.step_size, o.b1, o.b2, o.eps))
+            new = (step, params, m, v)
+        elif isinstance(self.optim, SGD):
+            check(lib.d3p_sgd_step(stream_ptr(), ptr(params), ptr(step), ptr(g), params.numel(),
+                                   self.optim.step_size))
+            new = (step, params)
+        else:
+            raise _lib.D3PError("unsupported optimiser")
+        return self._update_state_optim_state(dp_svi_state, new)
+
+    # ---------------------------------------------------------------- update (svi.py:395-434)
+    def _fusable(self):
+        return (isinstance(self.model, LogisticRegression) and isinstance(self.guide, AutoDiagonalNormal)
+                and isinstance(self.optim, Adam) and self._rng_suite is strong_rng)
+
+    def update(self, svi_state, *args, mask=True, **kwargs):
+        """One DP-VI step on a batch; returns ``(new_state, loss)`` (svi.py:395-434)."""
+        if self._fusable():
+            return self._update_fused(svi_state, *args, mask=mask, **kwargs)
+        return self._update_staged(svi_state, *args, mask=mask, **kwargs)
+
+    def _update_staged(self, svi_state, *args, mask=True, **kwargs):
+        """The reference's five-stage composition, literally (svi.py:413-434)."""
+        svi_state, update_rng_keys = self._split_rng_key(svi_state, 2)
+        gradient_rng_key, perturbation_rng_key = update_rng_keys[0], update_rng_keys[1]
+        svi_state, px_losses, px_grads, num_elements, factor = self._compute_per_example_gradients(
+            svi_state, gradient_rng_key, *args, mask=mask, **kwargs)
+        svi_state, px_clipped_grads = self._clip_gradients(svi_state, px_grads)
+        loss, avg_clipped_grads = self._combine_gradients(px_clipped_grads, px_losses)
+        svi_state, perturbed_grads = self._perturb_and_reassemble_gradients(
+            svi_state, perturbation_rng_key, avg_clipped_grads, num_elements, factor)
+        svi_state = self._apply_gradient(svi_state, perturbed_grads)
+        return svi_state, loss
+
+    def _state_struct(self, keybuf, slot, optim_state):
+        step, params, m, v = optim_state
+        return DpsviState(keybuf.data_ptr(), int(slot), params.data_ptr(), m.data_ptr(), v.data_ptr(),
+                          step.data_ptr())
+
+    def _update_fused(self, svi_state, *args, mask=True, _eps=None, _grad_out=None, **kwargs):
+        _lib.require_device()
+        lib = _lib.load()
+        X = args[0].contiguous()
+        y = args[1].contiguous().to(torch.float32)
+        B, d = X.shape
+        D = self.model.latent_dim(d)
+        dev = X.device
+        model = self._model_struct(d, kwargs, svi_state.observation_scale)
+        hyper = self._hyper()
+        step, params, m, v = (t.clone() for t in svi_state.optim_state)
+        keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
+        keybuf[0].copy_(svi_state.rng_key.reshape(16))
+        mask_t = None
+        if not isinstance(mask, bool):
+            mask_t = mask.to(torch.uint8).contiguous()
+        elif mask is False:
+            mask_t = torch.zeros(B, dtype=torch.uint8, device=dev)
+        src = BatchSource(_lib.D3P_BATCH_EXPLICIT, B, 0.0, 0, None, None,
+                          None if mask_t is None else mask_t.data_ptr(), B, 0, B)
+        st = self._state_struct(keybuf, 0, (step, params, m, v))
+        ws = self._workspace(lib.d3p_dpvi_logreg_workspace(C.byref(model), C.byref(src)), dev)
+        sums = torch.empty(2 * D + 2, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        s = stream_ptr()
+        check(lib.d3p_dpvi_logreg_local_sums(s, C.byref(model), C.byref(hyper), C.byref(st), C.byref(src), ptr(X),
+                                             ptr(y), ptr(_eps), ptr(sums), ptr(ws), ws.numel()))
+        check(lib.d3p_dpvi_logreg_finalize(s, C.byref(model), C.byref(hyper), C.byref(st), C.byref(src), ptr(sums),
+                                           ptr(loss), ptr(_grad_out), ptr(ws), ws.numel()))
+        new_state = DPSVIState((step, params, m, v), keybuf[1].reshape(4, 4), svi_state.observation_scale)
+        return new_state, loss[0]
+
+    # ---------------------------------------------------------------- fused multi-step loop
+    def run_steps(self, svi_state, get_batch, batchifier_state, first_batch, num_steps, **kwargs):
+        """``num_steps`` x (get_batch(i, batchifier_state) -> update) for i = first_batch..., enqueued
+        back to back on the device: the body of the reference's ``jit(lax.fori_loop(...))`` epoch
+        (examples/logistic_regression.py:149-160).  ``get_batch`` must come from
+        ``subsample_batchify_data`` (without replacement) or ``poisson_batchify_data``.
+        Returns ``(new_state, losses[num_steps])``."""
+        if not self._fusable():
+            raise _lib.D3PError("run_steps needs LogisticRegression + AutoDiagonalNormal + Adam + d3p_amd.random")
+        info = getattr(get_batch, "source", None)
+        if info is None or info.rng_suite is not strong_rng:
+            raise _lib.D3PError("run_steps: get_batch must come from d3p_amd.minibatch with rng_suite=d3p_amd.random")
+        _lib.require_device()
+        lib = _lib.load()
+        X, y = info.dataset[0], info.dataset[1]
+        if not (X.is_contiguous() and y.is_contiguous() and X.dtype == torch.float32 and y.dtype == torch.float32):
+            raise _lib.D3PError("run_steps: dataset arrays must be contiguous float32 CUDA tensors")
+        N, d = X.shape
+        dev = X.device
+        model = self._model_struct(d, kwargs, svi_state.observation_scale)
+        hyper = self._hyper()
+        step, params, m, v = (t.clone() for t in svi_state.optim_state)
+        keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
+        keybuf[0].copy_(svi_state.rng_key.reshape(16))
+        bkey = batchifier_state.contiguous()
+        bidx = torch.tensor([int(first_batch)], dtype=torch.int32, device=dev)
+        src = BatchSource(info.kind, info.batch_size, float(info.q), int(info.suppress), bkey.data_ptr(),
+                          bidx.data_ptr(), None, N, 0, N)
+        st = self._state_struct(keybuf, 0, (step, params, m, v))
+        ws = self._workspace(lib.d3p_dpvi_logreg_workspace(C.byref(model), C.byref(src)), dev)
+        losses = torch.empty(max(num_steps, 1), dtype=torch.float32, device=dev)
+        check(lib.d3p_dpvi_logreg_run(stream_ptr(), C.byref(model), C.byref(hyper), C.byref(st), C.byref(src),
+                                      ptr(X), ptr(y), int(num_steps), ptr(losses), ptr(ws), ws.numel()))
+        new_key = keybuf[num_steps & 1].reshape(4, 4)
+        return DPSVIState((step, params, m, v), new_key, svi_state.observation_scale), losses[:num_steps]
+
+    # ---------------------------------------------------------------- evaluate / accounting
+    def evaluate(self, svi_state, *args, **kwargs):
+        """d3p/svi.py:436-449 (held-out ELBO) -- SURVEY 8(f) rank 2, not built yet."""
+        raise NotImplementedError("DPSVI.evaluate is scheduled after the hot path (SURVEY.md 8(f))")
+
+    def _validate_epochs_and_iter(self, num_epochs, num_iter, q):
+        """d3p/svi.py:451-456."""
+        if num_epochs is not None:
+            num_iter = num_epochs / q
+        if num_iter is None:
+            raise ValueError("A value must be supplied for either num_iter or num_epochs")
+        return num_iter
+
+    def get_epsilon(self, target_delta, q, num_epochs=None, num_iter=None):
+        """d3p/svi.py:458-462; needs the optional `fourier_accountant` package."""
+        num_iter = self._validate_epochs_and_iter(num_epochs, num_iter, q)
+        from fourier_accountant.compute_eps import get_epsilon_R
+        return get_epsilon_R(target_delta, self._dp_scale, q, ncomp=num_iter)
+
+    def get_delta(self, target_epsilon, q, num_epochs=None, num_iter=None):
+        """d3p/svi.py:464-468; needs the optional `fourier_accountant` package."""
+        num_iter = self._validate_epochs_and_iter(num_epochs, num_iter, q)
+        from fourier_accountant.compute_delta import get_delta_R
+        return get_delta_R(target_epsilon, self._dp_scale, q, ncomp=num_iter)
+
+
+def _dbg_uniform(jax_key, n, lo, hi):
+    """uniform(lo, hi) from a threefry key without importing the warning-emitting debug module."""
+    out = torch.empty(max(n, 1), dtype=torch.float32, device=jax_key.device)
+    check(_lib.load().d3p_tf_uniform(stream_ptr(), ptr(jax_key.contiguous()), n, float(lo), float(hi), ptr(out)))
+    return out[:n]

@@ -1,0 +1,257 @@
+/*
+ * d3p_hip.h -- C-ABI of libd3p_hip.so: the MI355X (gfx950) hot path of d3p's DP-VI update step.
+ *
+ * The reference (DPBayes/d3p 0.2.0) is pure Python; it has no FFI boundary of its own
+ * (SURVEY.md F5).  Each entry point below replaces one Python-level call on the hot path and
+ * cites it (file:line relative to the reference root).  INTEGRATION.md shows the ctypes stub a
+ * d3p maintainer would add to route the reference's modules through this library.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no torch / HIP types in signatures
+ *     (`stream` is a hipStream_t passed as void*, NULL = the default stream).
+ *   - Every `*_dev` / device pointer is a raw device address (e.g. torch.Tensor.data_ptr()).
+ *     The caller owns all memory; the library allocates nothing and keeps no references.
+ *   - All calls are asynchronous on `stream`; nothing synchronises the device.
+ *   - Return value: 0 = D3P_OK, negative = error; d3p_last_error() returns a thread-local
+ *     message for the last failing call on this thread.
+ *   - ChaCha20 keys ("PRNGState", d3p/random/__init__.py:28) are 16 x uint32 RFC 8439 states:
+ *     [0..3] constants, [4..11] key, [12] counter, [13..15] nonce (layout: DESIGN.md section 3).
+ *   - Threefry keys (d3p/random/debug.py, and the per-example guide noise) are 2 x uint32.
+ */
+#ifndef D3P_HIP_H
+#define D3P_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3P_OK 0
+#define D3P_E_INVALID_ARG (-1)
+#define D3P_E_HIP (-2)
+#define D3P_E_UNSUPPORTED (-3)
+#define D3P_E_WORKSPACE (-4)
+
+#define D3P_ABI_VERSION 1
+
+int d3p_abi_version(void);
+const char* d3p_last_error(void);
+/* Number of visible HIP devices (<= 0: none; the Python layer refuses to run without one). */
+int d3p_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * rng_suite: ChaCha20 CSPRNG -- replaces chacha.random as aliased by d3p/random/__init__.py:28-32
+ * and the functions d3p adds on top (:50-155).
+ * ------------------------------------------------------------------------------------------- */
+/* split(key, num) -> num keys   (d3p/random/__init__.py:29; svi.py:210, :491) */
+int d3p_rng_split(void* stream, const uint32_t* key_dev, int num, uint32_t* out_keys_dev);
+/* fold_in(key, data)            (d3p/random/__init__.py:30; minibatch.py:115, :207, :230) */
+int d3p_rng_fold_in(void* stream, const uint32_t* key_dev, uint32_t data, uint32_t* out_key_dev);
+/* random_bits(key, bit_width in {8,16,32,64}, shape) -> `count` elements
+ * (d3p/random/__init__.py:31; util.py:240-242).  out_dev must hold
+ * ceil(count*bit_width/512) * 64 bytes (whole ChaCha blocks are written). */
+int d3p_rng_random_bits(void* stream, const uint32_t* key_dev, int bit_width, uint64_t count,
+                        void* out_dev);
+/* uniform(key, shape, float32, minval, maxval)  (d3p/random/__init__.py:32, :80; minibatch.py:34) */
+int d3p_rng_uniform(void* stream, const uint32_t* key_dev, uint64_t n, float minval, float maxval,
+                    float* out_dev);
+/* normal(key, shape, float32) = sqrt(2) * erf_inv(uniform(nextafter(-1,0), 1))
+ * (d3p/random/__init__.py:50-81; svi.py:487) */
+int d3p_rng_normal(void* stream, const uint32_t* key_dev, uint64_t n, float* out_dev);
+/* randint(key, shape, minval, maxval, int32): masked rejection sampling
+ * (d3p/random/__init__.py:84-146; minibatch.py:208) */
+int d3p_rng_randint(void* stream, const uint32_t* key_dev, uint64_t n, int32_t minval,
+                    int32_t maxval, int32_t* out_dev);
+
+/* ---------------------------------------------------------------------------------------------
+ * debug rng_suite: threefry2x32 in jax.random's array layout -- replaces d3p/random/debug.py:34-80.
+ * The same generator produces the per-example guide noise (svi.py:259, :289-290).
+ * ------------------------------------------------------------------------------------------- */
+int d3p_tf_split(void* stream, const uint32_t* key_dev, int num, uint32_t* out_keys_dev);
+int d3p_tf_fold_in(void* stream, const uint32_t* key_dev, uint32_t data, uint32_t* out_key_dev);
+int d3p_tf_random_bits(void* stream, const uint32_t* key_dev, uint64_t n_words, uint32_t* out_dev);
+int d3p_tf_uniform(void* stream, const uint32_t* key_dev, uint64_t n, float minval, float maxval,
+                   float* out_dev);
+int d3p_tf_normal(void* stream, const uint32_t* key_dev, uint64_t n, float* out_dev);
+
+/* ---------------------------------------------------------------------------------------------
+ * Minibatch samplers
+ * ------------------------------------------------------------------------------------------- */
+/* sample_from_array(key, arange(capacity), n, 0): 10-round Feistel permutation with cycle walking,
+ * evaluated at positions 0..n-1 (d3p/util.py:216-301; minibatch.py:231, :289). */
+int d3p_feistel_sample(void* stream, const uint32_t* key_dev, uint32_t capacity, uint32_t n,
+                       uint32_t* out_idx_dev);
+
+/* Same permutation from explicit round constants rc_dev[30] = rng_suite.random_bits(key, 32, (10, 3))
+ * (util.py:240-242), so that any rng_suite (e.g. d3p.random.debug) can drive the sampler. */
+int d3p_feistel_from_constants(void* stream, const uint32_t* rc_dev, uint32_t capacity, uint32_t n,
+                               uint32_t* out_idx_dev);
+
+/* poisson_sample_idxs + truncate/suppress bookkeeping (d3p/minibatch.py:29-39, :119-124).
+ * Element j is selected iff uniform word j <= q.  out_idx_dev[cutoff]: selected indices in
+ * descending order, then unselected indices in descending order (stable argsort reversed).
+ * out_counts_dev[0] = number selected, [1] = valid count after truncate (suppress=0) or
+ * suppress (suppress=1).  Rank r of `world` generates only keystream words of rows
+ * [row_lo, row_hi) when those are passed (0, N for a single GPU). */
+size_t d3p_poisson_select_workspace(uint32_t N);
+int d3p_poisson_select(void* stream, const uint32_t* key_dev, float q, uint32_t N, uint32_t cutoff,
+                       int suppress, uint32_t* out_idx_dev, uint32_t* out_counts_dev,
+                       void* workspace_dev, size_t workspace_bytes);
+/* rng_kind 0: key_dev is a ChaCha state (d3p.random); 1: a threefry key (d3p.random.debug). */
+int d3p_poisson_select_rng(void* stream, int rng_kind, const uint32_t* key_dev, float q, uint32_t N,
+                           uint32_t cutoff, int suppress, uint32_t* out_idx_dev,
+                           uint32_t* out_counts_dev, void* workspace_dev, size_t workspace_bytes);
+
+/* jnp.take(a, idx, axis=0) for a row-major table (minibatch.py:126-129, :210, :233, :306).
+ * If valid_count_dev != NULL, output rows >= *valid_count_dev are zero-filled (the mask multiply
+ * of minibatch.py:127-129).  row_bytes must be a multiple of 4. */
+int d3p_take_rows(void* stream, const void* table_dev, uint64_t n_rows, uint32_t row_bytes,
+                  const uint32_t* idx_dev, uint32_t n, const uint32_t* valid_count_dev,
+                  void* out_dev);
+
+/* ---------------------------------------------------------------------------------------------
+ * DP-VI stages on materialised (B x P) per-example gradients.  The reference's tests call these
+ * five stages directly (tests/test_dpsvi.py:128-129, :158-159, :171, :185, :199-202).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t d;         /* feature columns of X */
+    int32_t intercept; /* 0/1; latent dimension D = d + intercept; P = 2*D */
+    float prior_w;     /* prior std of w   (README.md:93; examples/logistic_regression.py:61) */
+    float prior_b;     /* prior std of the intercept (examples/logistic_regression.py:62) */
+    float lik_scale;   /* plate scale = num_obs_total (examples/logistic_regression.py:65) */
+    float inv_obs;     /* 1 / observation_scale (svi.py:278) */
+} d3p_logreg_model;
+
+/* _compute_per_example_gradients for the logistic-regression + AutoDiagonalNormal workload
+ * (svi.py:238-308).  params_dev = [auto_loc (D) | auto_scale unconstrained (D)].
+ * Noise source: eps_dev (B x D, "parity mode") or, if NULL, generated on chip from the threefry
+ * key jax_key_dev exactly as svi.py:289-290 + numpyro's handlers would.
+ * mask_dev: B bytes (0/1) or NULL.  Outputs: px_loss_dev[B], px_grads_dev[B x P],
+ * meta_dev[0] = num_elements, meta_dev[1] = batch_mask_scaling_factor (svi.py:305). */
+size_t d3p_logreg_px_grads_workspace(const d3p_logreg_model* model, uint32_t B);
+int d3p_logreg_px_grads(void* stream, const d3p_logreg_model* model, const float* params_dev,
+                        const float* X_dev, const float* y_dev, const uint8_t* mask_dev, uint32_t B,
+                        const float* eps_dev, const uint32_t* jax_key_dev, float* px_loss_dev,
+                        float* px_grads_dev, float* meta_dev, void* workspace_dev,
+                        size_t workspace_bytes);
+
+/* _clip_gradients: every row scaled by 1/max(1, ||row||_2 / c) in place (svi.py:68-124, :310-325).
+ * c == 0 -> D3P_E_INVALID_ARG (the reference raises ValueError, svi.py:119-120). */
+int d3p_clip_rows(void* stream, float* px_grads_dev, uint32_t B, uint32_t P, float c);
+
+/* full_norm of a flat vector (svi.py:68-87) -> out_dev[0]. n == 0 gives 0. */
+int d3p_full_norm(void* stream, const float* v_dev, uint64_t n, float* out_dev, void* workspace_dev,
+                  size_t workspace_bytes);
+
+/* _combine_gradients: column means over the padded batch and mean loss (svi.py:327-348). */
+int d3p_combine(void* stream, const float* px_grads_dev, const float* px_loss_dev, uint32_t B,
+                uint32_t P, float* avg_dev, float* loss_dev);
+
+/* _perturb_and_reassemble_gradients + perturbation_function (svi.py:350-377, :470-498):
+ * out = (avg + normal(site_key) * dp_scale * c / n) * obs_scale * factor with one key per site
+ * from split(key, n_sites); meta_dev = {n, factor} as produced above. */
+int d3p_perturb(void* stream, const uint32_t* key_dev, const float* avg_dev,
+                const int32_t* site_sizes_host, int n_sites, float dp_scale, float c,
+                const float* meta_dev, float obs_scale, float* out_dev,
+                uint32_t* site_keys_dev /* scratch: n_sites x 16 words */);
+
+/* The same with the standard-normal draws supplied (noise_dev[n], from any rng_suite.normal):
+ * out = (avg + noise * dp_scale * c / meta[0]) * obs_scale * meta[1]  (svi.py:365-375, :487-488). */
+int d3p_perturb_apply(void* stream, const float* avg_dev, const float* noise_dev, uint64_t n,
+                      float dp_scale, float c, const float* meta_dev, float obs_scale, float* out_dev);
+
+/* numpyro.optim.Adam step (svi.py:379-393; examples/logistic_regression.py:141).
+ * step_dev: int32 device counter (incremented). */
+int d3p_adam_step(void* stream, float* params_dev, float* m_dev, float* v_dev, int32_t* step_dev,
+                  const float* grads_dev, uint32_t P, float lr, float b1, float b2, float eps);
+
+/* numpyro.optim.SGD step (tests/test_dpsvi.py:57): params -= lr * grads; step_dev incremented. */
+int d3p_sgd_step(void* stream, float* params_dev, int32_t* step_dev, const float* grads_dev, uint32_t P,
+                 float lr);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused DPSVI.update (svi.py:395-434) -- the north-star path.
+ * per-example gradient -> joint L2 clip -> sum, X read once, B x P never materialised.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    float clip;      /* clipping_threshold C (svi.py:182) */
+    float dp_scale;  /* sigma (svi.py:183) */
+    float lr, b1, b2, adam_eps;
+} d3p_dpsvi_hyper;
+
+/* Device-resident training state (DPSVIState, svi.py:37-40, plus Adam moments).  All pointers
+ * are device addresses owned by the caller. */
+typedef struct {
+    uint32_t* rng_key;   /* 2 x 16 words: ping-pong ChaCha state keys */
+    int32_t key_slot;    /* host value: which of the two slots holds the current key at entry; a
+                            call that performs k updates leaves it in slot (key_slot + k) & 1 */
+    float* params;       /* P = 2D: [auto_loc | auto_scale unconstrained] */
+    float* adam_m;       /* P */
+    float* adam_v;       /* P */
+    int32_t* step;       /* optimiser step counter i (numpyro _NumPyroOptim state) */
+} d3p_dpsvi_state;
+
+/* Where a step's batch comes from. */
+#define D3P_BATCH_EXPLICIT 0 /* X/y ARE the batch (B rows), optional mask: DPSVI.update(state, X, y, mask=) */
+#define D3P_BATCH_FEISTEL 1  /* subsample_batchify_data get_batch(i, key) fused in (minibatch.py:217-237) */
+#define D3P_BATCH_POISSON 2  /* poisson_batchify_data get_batch(i, key) fused in (minibatch.py:103-131) */
+
+typedef struct {
+    int32_t kind;            /* D3P_BATCH_* */
+    uint32_t B;              /* batch size (FEISTEL), max_batch_size (POISSON), rows (EXPLICIT) */
+    float q;                 /* POISSON sampling rate */
+    int32_t suppress;        /* POISSON: handle_oversized_batch == "suppress" */
+    const uint32_t* batch_key; /* batchifier state key (16 words, device); NULL for EXPLICIT */
+    uint32_t* batch_index;   /* device counter i, fold_in(key, i); incremented per step */
+    const uint8_t* mask;     /* EXPLICIT only: B bytes or NULL */
+    uint64_t n_rows;         /* N: rows of the full (global) table */
+    uint64_t row_lo, row_hi; /* rows held by this rank: X_dev/y_dev point at row_lo (0, N on 1 GPU) */
+} d3p_batch_source;
+
+size_t d3p_dpvi_logreg_workspace(const d3p_logreg_model* model, const d3p_batch_source* src);
+
+/* Phase 1 (per rank): key schedule, minibatch indices, fused per-example gradient / clip / sum.
+ * sums_dev[P + 2] = [sum_i c_i g_i (P) | sum_i masked loss_i | number of valid examples] over
+ * the examples whose rows this rank holds.  eps_dev: optional B x D parity-mode noise. */
+int d3p_dpvi_logreg_local_sums(void* stream, const d3p_logreg_model* model,
+                               const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                               const d3p_batch_source* src, const float* X_dev, const float* y_dev,
+                               const float* eps_dev, float* sums_dev, void* workspace_dev,
+                               size_t workspace_bytes);
+
+/* Phase 2 (replicated): mean, Gaussian mechanism (noise added ONCE, after any all-reduce of
+ * sums_dev), rescale, Adam, advance keys/counters.  loss_dev[0] receives the batch loss
+ * (svi.py:342, :306); grad_out_dev (P, optional) the perturbed gradient. */
+int d3p_dpvi_logreg_finalize(void* stream, const d3p_logreg_model* model,
+                             const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                             const d3p_batch_source* src, const float* sums_dev, float* loss_dev,
+                             float* grad_out_dev, void* workspace_dev, size_t workspace_bytes);
+
+/* Single-GPU convenience: `num_steps` x (phase 1 + phase 2) enqueued back to back, i.e. the body of
+ * the reference's jit(fori_loop(update)) epoch (examples/logistic_regression.py:149-160).
+ * losses_dev: num_steps floats (or NULL). */
+int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                        const d3p_dpsvi_state* state, const d3p_batch_source* src,
+                        const float* X_dev, const float* y_dev, uint32_t num_steps,
+                        float* losses_dev, void* workspace_dev, size_t workspace_bytes);
+
+/* Times only the dominant kernel (fused gradient/clip/sum) of one step with HIP events on `stream`:
+ * returns the average duration in microseconds over `reps` launches in *avg_us (host pointer).
+ * Synchronises the stream; measurement tooling for bench.py, not part of the training path. */
+int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model,
+                                     const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                                     const d3p_batch_source* src, const float* X_dev,
+                                     const float* y_dev, void* workspace_dev, size_t workspace_bytes,
+                                     int reps, float* avg_us);
+
+/* Synthetic workload of SURVEY 8(d) / examples/logistic_regression.py:88-104, generated on device:
+ * X[r][c] and y[r] are pure functions of (seed, global row, column). */
+int d3p_synth_logreg(void* stream, uint32_t seed, uint64_t row0, uint64_t n_rows, int32_t d,
+                     float* X_dev, float* y_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3P_HIP_H */

@@ -1,0 +1,653 @@
+/*
+ * d3p_oracle.c -- CPU restatement of the d3p DP-VI hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the checker for the HIP path in d3p_amd/csrc.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+ * package (d3p_amd/) never imports, links or calls anything in oracle/.
+ *
+ * Every function cites the reference lines (relative to /root/reference) it restates.
+ *
+ * PARITY STATUS
+ *   pinned   : ChaCha20 block function (RFC 8439 2.3.2 / A.1 vectors, OpenSSL cross-check),
+ *              threefry2x32 + jax.random split/random_bits/normal layout (Random123 KATs and
+ *              values published in the JAX documentation / test-suite),
+ *              Feistel sampler arithmetic (d3p/util.py:229-301, fully specified there),
+ *              clip / mean / perturbation-scale arithmetic (known-answer tests of
+ *              tests/test_dpsvi.py, tests/test_gradient_manipulators.py).
+ *   UNPINNED : the key/nonce/counter layout of chacha.random (PyPI jax-chacha-prng >=1,<2 is
+ *              not vendored in the reference and not installed here; no reference test holds
+ *              a known-answer vector for split / fold_in / random_bits / uniform).  The layout
+ *              below is THIS BUILD'S OWN, documented in DESIGN.md ("parity unpinned").
+ *              Also unpinned: numpyro's AutoDiagonalNormal parametrisation and Trace_ELBO /
+ *              seed-handler key plumbing (numpyro is absent); restated from its published
+ *              behaviour and flagged where used.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define D3P_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * ChaCha20 block function, RFC 8439 section 2.3 (20 rounds, 32-bit counter, 96-bit nonce).
+ * State layout (16 x u32): [0..3] "expand 32-byte k", [4..11] key, [12] counter, [13..15] nonce.
+ * Replaces: chacha.random / chacha.cipher of jax-chacha-prng (d3p/random/__init__.py:25-32).
+ * ---------------------------------------------------------------------------------------- */
+static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+#define QR(a, b, c, d)                 \
+    a += b; d ^= a; d = rotl32(d, 16); \
+    c += d; b ^= c; b = rotl32(b, 12); \
+    a += b; d ^= a; d = rotl32(d, 8);  \
+    c += d; b ^= c; b = rotl32(b, 7);
+
+D3P_API void d3po_chacha20_block(const uint32_t in[16], uint32_t out[16])
+{
+    uint32_t x[16];
+    memcpy(x, in, sizeof(x));
+    for (int i = 0; i < 10; ++i) {
+        QR(x[0], x[4], x[8], x[12]) QR(x[1], x[5], x[9], x[13])
+        QR(x[2], x[6], x[10], x[14]) QR(x[3], x[7], x[11], x[15])
+        QR(x[0], x[5], x[10], x[15]) QR(x[1], x[6], x[11], x[12])
+        QR(x[2], x[7], x[8], x[13]) QR(x[3], x[4], x[9], x[14])
+    }
+    for (int i = 0; i < 16; ++i) out[i] = x[i] + in[i];
+}
+
+/* Build's own key layout (PARITY UNPINNED, see header).
+ * PRNGKey(seed) (d3p/random/__init__.py:35-47): 32 seed bytes -> key words little-endian as in
+ * RFC 8439 2.3; counter = 0; nonce = 0.  (int seeds are reduced mod 2^256 and serialised
+ * big-endian to 32 bytes, shorter byte strings are right-padded with zeros: host side.) */
+D3P_API void d3po_key_from_bytes(const uint8_t seed[32], uint32_t state[16])
+{
+    state[0] = 0x61707865u; state[1] = 0x3320646eu; state[2] = 0x79622d32u; state[3] = 0x6b206574u;
+    for (int i = 0; i < 8; ++i)
+        state[4 + i] = (uint32_t)seed[4 * i] | ((uint32_t)seed[4 * i + 1] << 8) |
+                       ((uint32_t)seed[4 * i + 2] << 16) | ((uint32_t)seed[4 * i + 3] << 24);
+    state[12] = state[13] = state[14] = state[15] = 0;
+}
+
+#define D3P_TAG_SPLIT 0x00000001u
+#define D3P_TAG_FOLD 0x00000002u
+
+/* child key = first 8 words of the block of (parent, counter += i, nonce ^= (data, 0, tag));
+ * child counter and nonce are reset to zero, so random_bits (nonce tag 0), split (tag 1) and
+ * fold_in (tag 2) draw from disjoint (nonce, counter) domains of the parent key. */
+static void derive_child(const uint32_t parent[16], uint32_t ctr_add, uint32_t data, uint32_t tag,
+                         uint32_t child[16])
+{
+    uint32_t in[16], blk[16];
+    memcpy(in, parent, sizeof(in));
+    in[12] += ctr_add;
+    in[13] ^= data;
+    in[15] ^= tag;
+    d3po_chacha20_block(in, blk);
+    memcpy(child, parent, 4 * sizeof(uint32_t));
+    memcpy(child + 4, blk, 8 * sizeof(uint32_t));
+    child[12] = child[13] = child[14] = child[15] = 0;
+}
+
+/* rng_suite.split (d3p/random/__init__.py:29; call sites svi.py:210, :491) */
+D3P_API void d3po_split(const uint32_t key[16], int num, uint32_t* out /* num x 16 */)
+{
+    for (int i = 0; i < num; ++i) derive_child(key, (uint32_t)i, 0u, D3P_TAG_SPLIT, out + 16 * i);
+}
+
+/* rng_suite.fold_in (d3p/random/__init__.py:30; call sites minibatch.py:115, :207, :230) */
+D3P_API void d3po_fold_in(const uint32_t key[16], uint32_t data, uint32_t out[16])
+{
+    derive_child(key, 0u, data, D3P_TAG_FOLD, out);
+}
+
+/* rng_suite.random_bits, 32-bit words (d3p/random/__init__.py:31): keystream word j is word
+ * (j mod 16) of the block with counter key[12] + j/16. */
+D3P_API void d3po_random_words(const uint32_t key[16], uint64_t first_word, uint64_t n_words,
+                               uint32_t* out)
+{
+    uint32_t in[16], blk[16];
+    memcpy(in, key, sizeof(in));
+    uint64_t cur_blk = (uint64_t)-1;
+    for (uint64_t j = 0; j < n_words; ++j) {
+        uint64_t w = first_word + j, b = w >> 4;
+        if (b != cur_blk) {
+            in[12] = key[12] + (uint32_t)b;
+            d3po_chacha20_block(in, blk);
+            cur_blk = b;
+        }
+        out[j] = blk[w & 15];
+    }
+}
+
+/* random_bits for bit_width 8/16/32/64: element e of the flat output is taken little-endian
+ * from the keystream bytes (width 8/16: low bits of a word first; width 64: lo word first). */
+D3P_API int d3po_random_bits(const uint32_t key[16], int bit_width, uint64_t count, void* out)
+{
+    if (bit_width != 8 && bit_width != 16 && bit_width != 32 && bit_width != 64) return -1;
+    uint64_t n_words = (count * (uint64_t)bit_width + 31) / 32;
+    uint32_t* w = (uint32_t*)malloc((n_words ? n_words : 1) * sizeof(uint32_t));
+    if (!w) return -2;
+    d3po_random_words(key, 0, n_words, w);
+    for (uint64_t e = 0; e < count; ++e) {
+        switch (bit_width) {
+        case 8: ((uint8_t*)out)[e] = (uint8_t)(w[e >> 2] >> (8 * (e & 3))); break;
+        case 16: ((uint16_t*)out)[e] = (uint16_t)(w[e >> 1] >> (16 * (e & 1))); break;
+        case 32: ((uint32_t*)out)[e] = w[e]; break;
+        default: ((uint64_t*)out)[e] = (uint64_t)w[2 * e] | ((uint64_t)w[2 * e + 1] << 32);
+        }
+    }
+    free(w);
+    return 0;
+}
+
+/* bits -> float32 in [lo, hi), the jax.random.uniform construction that chacha.random.uniform
+ * mirrors (d3p/random/__init__.py:32, :80): mantissa bits | 1.0f, minus 1, affine, clamp at lo. */
+static inline float bits_to_uniform(uint32_t bits, float lo, float hi)
+{
+    union { uint32_t u; float f; } c;
+    c.u = (bits >> 9) | 0x3f800000u;
+    float f = c.f - 1.0f;
+    float scale = hi - lo;
+    float r = f * scale + lo; /* -ffp-contract=off: separate mul and add */
+    return r < lo ? lo : r;
+}
+
+D3P_API void d3po_uniform(const uint32_t key[16], uint64_t n, float lo, float hi, float* out)
+{
+    uint32_t in[16], blk[16];
+    memcpy(in, key, sizeof(in));
+    for (uint64_t j = 0; j < n; ++j) {
+        if ((j & 15) == 0) {
+            in[12] = key[12] + (uint32_t)(j >> 4);
+            d3po_chacha20_block(in, blk);
+        }
+        out[j] = bits_to_uniform(blk[j & 15], lo, hi);
+    }
+}
+
+/* float32 erf_inv as lowered by XLA for jax.lax.erf_inv (d3p/random/__init__.py:81): M. Giles,
+ * "Approximating the erfinv function", single-precision polynomial; +-inf at |x| == 1. */
+D3P_API float d3po_erfinv_f32(float x)
+{
+    float w = -log1pf(-x * x);
+    float p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = fmaf(p, w, 3.43273939e-07f);
+        p = fmaf(p, w, -3.5233877e-06f);
+        p = fmaf(p, w, -4.39150654e-06f);
+        p = fmaf(p, w, 0.00021858087f);
+        p = fmaf(p, w, -0.00125372503f);
+        p = fmaf(p, w, -0.00417768164f);
+        p = fmaf(p, w, 0.246640727f);
+        p = fmaf(p, w, 1.50140941f);
+    } else {
+        w = sqrtf(w) - 3.0f;
+        p = -0.000200214257f;
+        p = fmaf(p, w, 0.000100950558f);
+        p = fmaf(p, w, 0.00134934322f);
+        p = fmaf(p, w, -0.00367342844f);
+        p = fmaf(p, w, 0.00573950773f);
+        p = fmaf(p, w, -0.0076224613f);
+        p = fmaf(p, w, 0.00943887047f);
+        p = fmaf(p, w, 1.00167406f);
+        p = fmaf(p, w, 2.83297682f);
+    }
+    if (fabsf(x) == 1.0f) return x * INFINITY;
+    return p * x;
+}
+
+#define D3P_NORMAL_LO (-0.99999994f) /* np.nextafter(-1f, 0f): d3p/random/__init__.py:78 */
+#define D3P_SQRT2 1.41421354f        /* np.float32(np.sqrt(2)): d3p/random/__init__.py:81 */
+
+static inline float bits_to_normal(uint32_t bits)
+{
+    return D3P_SQRT2 * d3po_erfinv_f32(bits_to_uniform(bits, D3P_NORMAL_LO, 1.0f));
+}
+
+/* d3p.random.normal / _normal (d3p/random/__init__.py:50-81) */
+D3P_API void d3po_normal(const uint32_t key[16], uint64_t n, float* out)
+{
+    uint32_t in[16], blk[16];
+    memcpy(in, key, sizeof(in));
+    for (uint64_t j = 0; j < n; ++j) {
+        if ((j & 15) == 0) {
+            in[12] = key[12] + (uint32_t)(j >> 4);
+            d3po_chacha20_block(in, blk);
+        }
+        out[j] = bits_to_normal(blk[j & 15]);
+    }
+}
+
+/* d3p.random._randint for 32-bit dtypes (d3p/random/__init__.py:108-146).  delta, the float32
+ * log2 at :125 and the masked rejection loop (:130-143) are restated literally; since a lane
+ * that was accepted never changes again the all-lanes while_loop equals per-lane iteration. */
+D3P_API int d3po_randint32(const uint32_t key_in[16], uint64_t n, int32_t minval, int32_t maxval,
+                           int32_t* out)
+{
+    uint32_t delta = (uint32_t)(maxval - 1 - minval);
+    float l2 = log2f((float)delta) + 1.0f;          /* jnp.log2(jnp.float32(delta)) + 1 */
+    uint32_t lg;
+    if (!(l2 > 0.0f)) lg = 0;                        /* udtype(-inf) / udtype(nan) -> 0 on XLA:CPU */
+    else if (l2 >= 32.0f) lg = 32;
+    else lg = (uint32_t)l2;
+    if (lg > 32) lg = 32;
+    uint32_t bitmask = (lg >= 32) ? 0xffffffffu : ((1u << lg) - 1u);
+    uint32_t* u = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    uint32_t* nu = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    if (!u || !nu) { free(u); free(nu); return -2; }
+    uint32_t key[16], ks[32];
+    memcpy(key, key_in, sizeof(key));
+    d3po_split(key, 2, ks);
+    memcpy(key, ks, sizeof(key));
+    d3po_random_words(ks + 16, 0, n, u);
+    for (uint64_t j = 0; j < n; ++j) u[j] &= bitmask;
+    for (int round = 0; round < 4096; ++round) {
+        int any = 0;
+        for (uint64_t j = 0; j < n; ++j) any |= (u[j] > delta);
+        if (!any) break;
+        d3po_split(key, 2, ks);
+        memcpy(key, ks, sizeof(key));
+        d3po_random_words(ks + 16, 0, n, nu);
+        for (uint64_t j = 0; j < n; ++j)
+            if (u[j] > delta) u[j] = nu[j] & bitmask;
+    }
+    for (uint64_t j = 0; j < n; ++j) out[j] = (int32_t)u[j] + minval;
+    free(u); free(nu);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * threefry2x32-20 and the jax.random (<= 0.4.10, non-partitionable) array layouts.
+ * Used for (i) d3p.random.debug (d3p/random/debug.py:34-80), (ii) the per-example guide noise
+ * eps_i, which the reference draws from JAX's default PRNG (d3p/svi.py:259, :289-290;
+ * README.md:49-50).  Pinned by Random123 KATs and JAX-published values (tests/test_oracle_pins).
+ * ---------------------------------------------------------------------------------------- */
+D3P_API void d3po_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t out[2])
+{
+    static const int R[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+    uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+    uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+    for (int i = 0; i < 5; ++i) {
+        for (int r = 0; r < 4; ++r) {
+            x0 += x1;
+            x1 = rotl32(x1, R[i & 1][r]);
+            x1 ^= x0;
+        }
+        x0 += ks[(i + 1) % 3];
+        x1 += ks[(i + 2) % 3] + (uint32_t)(i + 1);
+    }
+    out[0] = x0;
+    out[1] = x1;
+}
+
+/* jax threefry_2x32(key, iota(n))[j]: the count array is split in halves (padded to even). */
+static inline uint32_t tf_iota_word(uint32_t k0, uint32_t k1, uint64_t n, uint64_t j)
+{
+    uint64_t half = (n + 1) / 2;
+    uint32_t o[2];
+    if (j < half) {
+        uint64_t c1 = j + half;
+        d3po_threefry2x32(k0, k1, (uint32_t)j, (c1 < n) ? (uint32_t)c1 : 0u, o);
+        return o[0];
+    }
+    d3po_threefry2x32(k0, k1, (uint32_t)(j - half), (uint32_t)j, o);
+    return o[1];
+}
+
+D3P_API void d3po_tf_random_words(const uint32_t key[2], uint64_t n, uint32_t* out)
+{
+    for (uint64_t j = 0; j < n; ++j) out[j] = tf_iota_word(key[0], key[1], n, j);
+}
+
+D3P_API void d3po_tf_split(const uint32_t key[2], int num, uint32_t* out /* num x 2 */)
+{
+    d3po_tf_random_words(key, 2 * (uint64_t)num, out);
+}
+
+D3P_API void d3po_tf_fold_in(const uint32_t key[2], uint32_t data, uint32_t out[2])
+{
+    d3po_threefry2x32(key[0], key[1], 0u, data, out);
+}
+
+D3P_API void d3po_tf_uniform(const uint32_t key[2], uint64_t n, float lo, float hi, float* out)
+{
+    for (uint64_t j = 0; j < n; ++j)
+        out[j] = bits_to_uniform(tf_iota_word(key[0], key[1], n, j), lo, hi);
+}
+
+D3P_API void d3po_tf_normal(const uint32_t key[2], uint64_t n, float* out)
+{
+    for (uint64_t j = 0; j < n; ++j) out[j] = bits_to_normal(tf_iota_word(key[0], key[1], n, j));
+}
+
+/* Key of the guide's `_auto_latent` sample for the example at batch position p
+ * (d3p/svi.py:289-290 px_rng_keys = jax.random.split(jax_rng_key, B); numpyro Trace_ELBO:
+ * model_seed, guide_seed = split(px_key); numpyro.handlers.seed: key, sample_key = split(key)).
+ * UNPINNED against numpyro (absent); the threefry arithmetic itself is pinned. */
+D3P_API void d3po_px_sample_key(const uint32_t jax_key[2], uint32_t B, uint32_t p, uint32_t out[2])
+{
+    uint32_t px[2], s[4];
+    px[0] = tf_iota_word(jax_key[0], jax_key[1], 2ull * B, 2ull * p);
+    px[1] = tf_iota_word(jax_key[0], jax_key[1], 2ull * B, 2ull * p + 1);
+    d3po_tf_split(px, 2, s); /* guide_seed = s[2..3] */
+    uint32_t g[2] = {s[2], s[3]};
+    d3po_tf_split(g, 2, s);  /* sample key = s[2..3] */
+    out[0] = s[2];
+    out[1] = s[3];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Feistel sampler: d3p/util.py:216-301 (verbatim uint32 arithmetic).
+ * ---------------------------------------------------------------------------------------- */
+static inline int bit_length_u32(uint32_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+D3P_API void d3po_feistel_constants(const uint32_t key[16], uint32_t rc[30])
+{
+    d3po_random_words(key, 0, 30, rc);            /* util.py:240-242 */
+    for (int j = 0; j < 10; ++j) rc[3 * j] |= 1u; /* util.py:245-246 */
+}
+
+D3P_API uint32_t d3po_feistel_permute(const uint32_t rc[30], uint32_t capacity, uint32_t position)
+{
+    int bits = bit_length_u32(capacity - 1); /* util.py:230 */
+    int bits_lower = bits >> 1, bits_upper = bits - bits_lower;
+    uint32_t mask_lower = (1u << bits_lower) - 1u, mask_upper = (1u << bits_upper) - 1u;
+    uint32_t x = position;
+    do {
+        for (int j = 0; j < 10; ++j) { /* util.py:273-285 */
+            const uint32_t* k = rc + 3 * j;
+            uint32_t xu = x >> bits_lower, xl = x & mask_lower;
+            uint32_t yu = xl ^ ((((xu * k[1]) >> bits_upper) ^ k[2]) & mask_lower);
+            uint32_t yl = (xu * k[0]) & mask_upper;
+            x = (yu << bits_upper) | yl;
+        }
+    } while (x >= capacity); /* util.py:291-296 */
+    return x;
+}
+
+D3P_API void d3po_feistel_sample(const uint32_t key[16], uint32_t capacity, uint32_t n, uint32_t* out)
+{
+    uint32_t rc[30];
+    d3po_feistel_constants(key, rc);
+    for (uint32_t p = 0; p < n; ++p) out[p] = d3po_feistel_permute(rc, capacity, p);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Poisson selection: d3p/minibatch.py:29-39 (+ :119-124).  argsort of the boolean selectors is
+ * stable, so [::-1] yields the selected indices in DESCENDING order followed by the unselected
+ * ones in descending order; the first `cutoff` of them are returned.  counts[0] = raw number
+ * selected (:35), counts[1] = after truncate / suppress (:119-122).
+ * ---------------------------------------------------------------------------------------- */
+D3P_API void d3po_poisson_select(const uint32_t key[16], float q, uint32_t N, uint32_t cutoff,
+                                 int suppress, uint32_t* idx_out, uint32_t counts[2])
+{
+    float* u = (float*)malloc((N ? N : 1) * sizeof(float));
+    d3po_uniform(key, N, 0.0f, 1.0f, u);
+    uint32_t nsel = 0, w = 0;
+    for (uint32_t j = 0; j < N; ++j) nsel += (u[j] <= q);
+    for (int64_t j = (int64_t)N - 1; j >= 0 && w < cutoff; --j)
+        if (u[j] <= q) idx_out[w++] = (uint32_t)j;
+    for (int64_t j = (int64_t)N - 1; j >= 0 && w < cutoff; --j)
+        if (!(u[j] <= q)) idx_out[w++] = (uint32_t)j;
+    counts[0] = nsel;
+    counts[1] = suppress ? (nsel <= cutoff ? nsel : 0u) : (nsel < cutoff ? nsel : cutoff);
+    free(u);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * DP-VI update for Bayesian logistic regression + AutoDiagonalNormal guide.
+ *
+ * Model (README.md:89-97, examples/logistic_regression.py:49-66): w ~ N(0, prior_w^2 I_d),
+ * optional intercept ~ N(0, prior_b^2); y_i ~ Bernoulli(logits = x_i.w + b) inside
+ * plate(N, subsample_size=batch).  Guide: numpyro AutoDiagonalNormal over the D = d (+1) latents,
+ * unconstrained params auto_loc (D) and auto_scale_unc (D) with scale = softplus(unc)
+ * (UNPINNED numpyro >= 0.8 behaviour).  Per-example loss as wrapped at d3p/svi.py:271-281 for a
+ * batch of one example (plate scale = N):
+ *     L_i = inv_obs * ( logq(z_i) - logp(z_i) - lik_scale * loglik(y_i | x_i, z_i) ) * mask_i
+ * with z_i = loc + scale * eps_i.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t d;          /* feature columns of X */
+    int32_t intercept;  /* 0/1: latent D = d + intercept */
+    float prior_w;      /* prior std of w */
+    float prior_b;      /* prior std of the intercept */
+    float lik_scale;    /* plate scale N (num_obs_total) */
+    float inv_obs;      /* 1 / observation_scale (svi.py:278) */
+} d3po_logreg_spec;
+
+static inline float softplus_f(float t) { return fmaxf(t, 0.0f) + log1pf(expf(-fabsf(t))); }
+static inline float sigmoid_f(float t) { return 1.0f / (1.0f + expf(-t)); }
+
+#define HALF_LOG_2PI 0.918938533204672742f
+
+/* One example: loss and gradient wrt (auto_loc, auto_scale_unc); grad has 2*D entries
+ * [d/dloc (D) | d/dunc (D)] = tree_flatten order of {auto_loc, auto_scale} (svi.py:490). */
+D3P_API float d3po_logreg_px_loss_grad(const d3po_logreg_spec* sp, const float* loc, const float* unc,
+                                       const float* x, float y, const float* eps, float mask,
+                                       float* grad /* 2*D or NULL */)
+{
+    const int d = sp->d, D = sp->d + (sp->intercept ? 1 : 0);
+    double t = 0.0, lq = 0.0, lp = 0.0; /* accumulate in double: the oracle is the accurate side */
+    for (int j = 0; j < D; ++j) {
+        float s = softplus_f(unc[j]);
+        float z = fmaf(s, eps[j], loc[j]);
+        float ps = (j < d) ? sp->prior_w : sp->prior_b;
+        float xv = (j < d) ? x[j] : 1.0f;
+        t += (double)xv * (double)z;
+        lq += -0.5 * (double)eps[j] * (double)eps[j] - log((double)s) - (double)HALF_LOG_2PI;
+        lp += -0.5 * ((double)z / ps) * ((double)z / ps) - log((double)ps) - (double)HALF_LOG_2PI;
+    }
+    float tf = (float)t;
+    double loglik = (double)y * t - (double)softplus_f(tf);
+    double L = (double)sp->inv_obs * ((lq - lp) - (double)sp->lik_scale * loglik) * mask;
+    if (grad) {
+        float A = sp->inv_obs * sp->lik_scale * (sigmoid_f(tf) - y);
+        for (int j = 0; j < D; ++j) {
+            float s = softplus_f(unc[j]);
+            float sg = sigmoid_f(unc[j]);
+            float z = fmaf(s, eps[j], loc[j]);
+            float ps = (j < d) ? sp->prior_w : sp->prior_b;
+            float xv = (j < d) ? x[j] : 1.0f;
+            float g = sp->inv_obs * z / (ps * ps) + A * xv;
+            float h = (g * eps[j] - sp->inv_obs / s) * sg;
+            grad[j] = g * mask;
+            grad[D + j] = h * mask;
+        }
+    }
+    return (float)L;
+}
+
+/* svi.py:238-308 -- materialise px_losses (B) and px_grads (B x 2D) like jax.vmap does.
+ * Xb: B x d gathered rows, yb: B, eps: B x D, mask: B floats (0/1) or NULL (= all valid).
+ * Returns num_elements; *factor = B/n (0 if n == 0) (svi.py:305); losses are rescaled by
+ * obs_scale * factor (svi.py:306). */
+D3P_API int d3po_logreg_px_grads(const d3po_logreg_spec* sp, const float* loc, const float* unc,
+                                 const float* Xb, const float* yb, const float* eps,
+                                 const float* mask, int B, float* px_loss, float* px_grads,
+                                 float* factor)
+{
+    const int D = sp->d + (sp->intercept ? 1 : 0);
+    int n = 0;
+    for (int i = 0; i < B; ++i) n += (mask ? (mask[i] != 0.0f) : 1);
+    float f = (n == 0) ? 0.0f : (float)B / (float)n;
+    float obs = 1.0f / sp->inv_obs;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < B; ++i) {
+        float m = mask ? mask[i] : 1.0f;
+        float L = d3po_logreg_px_loss_grad(sp, loc, unc, Xb + (size_t)i * sp->d, yb[i],
+                                           eps + (size_t)i * D, m, px_grads + (size_t)i * 2 * D);
+        px_loss[i] = L * obs * f;
+    }
+    *factor = f;
+    return n;
+}
+
+/* svi.py:68-87 full_norm over a flat row; svi.py:106-124 clip_gradient; svi.py:310-325 vmapped.
+ * Returns -1 (the reference raises ValueError) when c == 0. */
+D3P_API int d3po_clip_rows(float* px_grads, int B, int P, float c)
+{
+    if (c == 0.0f) return -1;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < B; ++i) {
+        float* g = px_grads + (size_t)i * P;
+        double ss = 0.0;
+        for (int j = 0; j < P; ++j) ss += (double)g[j] * (double)g[j];
+        float norm = (float)sqrt(ss);
+        float scale = 1.0f / fmaxf(1.0f, norm / c);
+        for (int j = 0; j < P; ++j) g[j] *= scale;
+    }
+    return 0;
+}
+
+D3P_API float d3po_full_norm(const float* v, uint64_t n)
+{
+    double ss = 0.0;
+    for (uint64_t j = 0; j < n; ++j) ss += (double)v[j] * (double)v[j];
+    return (float)sqrt(ss);
+}
+
+/* svi.py:327-348: mean over the (padded) batch axis of every column, and of the losses. */
+D3P_API float d3po_combine(const float* px_grads, const float* px_loss, int B, int P, float* avg)
+{
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < P; ++j) {
+        double s = 0.0;
+        for (int i = 0; i < B; ++i) s += (double)px_grads[(size_t)i * P + j];
+        avg[j] = (float)(s / B);
+    }
+    double l = 0.0;
+    for (int i = 0; i < B; ++i) l += (double)px_loss[i];
+    return (float)(l / B);
+}
+
+/* svi.py:350-377 + perturbation_function svi.py:470-498.  `site_sizes` lists the sites in
+ * tree_flatten order; site k uses split(key, n_sites)[k] (svi.py:491) and normal(site_key, shape)
+ * (svi.py:487).  scale = dp_scale * C / n (svi.py:365-366); the result is multiplied by
+ * obs_scale * factor (svi.py:375).  n == 0 reproduces the reference's inf/NaN. */
+D3P_API void d3po_perturb(const uint32_t key[16], const float* avg, const int32_t* site_sizes,
+                          int n_sites, float dp_scale, float c, float num_elements, float obs_scale,
+                          float factor, float* out)
+{
+    uint32_t* ks = (uint32_t*)malloc((size_t)n_sites * 16 * sizeof(uint32_t));
+    d3po_split(key, n_sites, ks);
+    float scale = dp_scale * (c / num_elements);
+    size_t off = 0;
+    for (int k = 0; k < n_sites; ++k) {
+        float* z = (float*)malloc(((size_t)site_sizes[k] + 1) * sizeof(float));
+        d3po_normal(ks + 16 * k, (uint64_t)site_sizes[k], z);
+        for (int j = 0; j < site_sizes[k]; ++j)
+            out[off + j] = (avg[off + j] + z[j] * scale) * obs_scale * factor;
+        off += (size_t)site_sizes[k];
+        free(z);
+    }
+    free(ks);
+}
+
+/* numpyro.optim.Adam == jax.example_libraries.optimizers.adam(step, 0.9, 0.999, 1e-8)
+ * (svi.py:379-393; examples/logistic_regression.py:141).  `i` is the step count before the update. */
+D3P_API void d3po_adam(float* x, float* m, float* v, const float* g, int P, int i, float lr, float b1,
+                       float b2, float eps)
+{
+    float c1 = 1.0f - powf(b1, (float)(i + 1)), c2 = 1.0f - powf(b2, (float)(i + 1));
+    for (int j = 0; j < P; ++j) {
+        m[j] = (1.0f - b1) * g[j] + b1 * m[j];
+        v[j] = (1.0f - b2) * g[j] * g[j] + b2 * v[j];
+        float mhat = m[j] / c1, vhat = v[j] / c2;
+        x[j] = x[j] - lr * mhat / (sqrtf(vhat) + eps);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * One full DPSVI.update (svi.py:395-434) on an explicit batch, following the reference dataflow
+ * stage by stage (materialised B x P like jax.vmap).  Used by the parity tests and as bench.py's
+ * cpu_baseline ("port").  params = [loc (D) | unc (D)], adam m/v same layout.
+ * Keys: state_key -> split(.,3) = next, gradient, perturbation (svi.py:208-211, :413-414);
+ * jax key = random_bits(gradient_key, 32, (2,)) (random/__init__.py:155).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    float clip;      /* clipping_threshold */
+    float dp_scale;  /* sigma */
+    float lr, b1, b2, adam_eps;
+} d3po_dpsvi_hyper;
+
+D3P_API float d3po_logreg_update(const d3po_logreg_spec* sp, const d3po_dpsvi_hyper* hy,
+                                 uint32_t state_key[16], float* params, float* adam_m, float* adam_v,
+                                 int32_t* adam_step, const float* Xb, const float* yb,
+                                 const float* mask, int B, const float* eps_ext /* B x D or NULL */,
+                                 float* scratch /* B*(2D) + B + B*D + 4D floats */,
+                                 float* grad_out /* 2D or NULL */)
+{
+    const int D = sp->d + (sp->intercept ? 1 : 0), P = 2 * D;
+    uint32_t ks[48], jaxkey[2];
+    d3po_split(state_key, 3, ks);
+    d3po_random_words(ks + 16, 0, 2, jaxkey);
+    float* px_grads = scratch;
+    float* px_loss = px_grads + (size_t)B * P;
+    float* eps = px_loss + B;
+    float* avg = eps + (size_t)B * D;
+    float* pert = avg + P;
+    if (eps_ext) {
+        memcpy(eps, eps_ext, (size_t)B * D * sizeof(float));
+    } else {
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < B; ++i) {
+            uint32_t sk[2];
+            d3po_px_sample_key(jaxkey, (uint32_t)B, (uint32_t)i, sk);
+            d3po_tf_normal(sk, (uint64_t)D, eps + (size_t)i * D);
+        }
+    }
+    float factor;
+    int n = d3po_logreg_px_grads(sp, params, params + D, Xb, yb, eps, mask, B, px_loss, px_grads,
+                                 &factor);
+    d3po_clip_rows(px_grads, B, P, hy->clip);
+    float loss = d3po_combine(px_grads, px_loss, B, P, avg);
+    int32_t sites[2] = {D, D};
+    d3po_perturb(ks + 32, avg, sites, 2, hy->dp_scale, hy->clip, (float)n, 1.0f / sp->inv_obs, factor,
+                 pert);
+    if (grad_out) memcpy(grad_out, pert, (size_t)P * sizeof(float));
+    d3po_adam(params, adam_m, adam_v, pert, P, *adam_step, hy->lr, hy->b1, hy->b2, hy->adam_eps);
+    *adam_step += 1;
+    memcpy(state_key, ks, 16 * sizeof(uint32_t));
+    return loss;
+}
+
+/* Synthetic logistic-regression table, element (r, c) a pure function of (seed, r, c) so that any
+ * shard can be regenerated (mirrors examples/logistic_regression.py:88-104 in
+ * distribution): X[r][c] = normal from threefry2x32((seed, 0x58), (r, c))[0];
+ * w_true[c], b_true from key (seed, 0x57); y[r] = 1 if u(r) < sigmoid(x_r.w + b) with
+ * u(r) = uniform from threefry2x32((seed, 0x59), (r, 0))[0]. */
+D3P_API void d3po_synth_wtrue(uint32_t seed, int d, float* w_true /* d + 1 */)
+{
+    for (int c = 0; c <= d; ++c) {
+        uint32_t o[2];
+        d3po_threefry2x32(seed, 0x57u, (uint32_t)c, 0u, o);
+        w_true[c] = bits_to_normal(o[0]);
+    }
+}
+
+D3P_API void d3po_synth_logreg(uint32_t seed, uint64_t row0, uint64_t nrows, int d, float* X, float* y)
+{
+    float* w = (float*)malloc(((size_t)d + 1) * sizeof(float));
+    d3po_synth_wtrue(seed, d, w);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)nrows; ++i) {
+        uint64_t r = row0 + (uint64_t)i;
+        double t = (double)w[d];
+        for (int c = 0; c < d; ++c) {
+            uint32_t o[2];
+            d3po_threefry2x32(seed, 0x58u, (uint32_t)r, (uint32_t)c, o);
+            float xv = bits_to_normal(o[0]);
+            X[(size_t)i * d + c] = xv;
+            t += (double)xv * (double)w[c];
+        }
+        uint32_t o[2];
+        d3po_threefry2x32(seed, 0x59u, (uint32_t)r, 0u, o);
+        float u = bits_to_uniform(o[0], 0.0f, 1.0f);
+        y[i] = (u < sigmoid_f((float)t)) ? 1.0f : 0.0f;
+    }
+    free(w);
+}

@@ -1,0 +1,334 @@
+"""numpy-facing wrappers around oracle/libd3p_oracle.so (the CPU restatement in d3p_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under d3p_amd/ imports this module.  Parity status (what is pinned
+against published vectors and what is this build's own layout) is stated in d3p_oracle.c's header.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libd3p_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "d3p_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libd3p_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+class LogregSpec(C.Structure):
+    _fields_ = [("d", C.c_int32), ("intercept", C.c_int32), ("prior_w", C.c_float),
+                ("prior_b", C.c_float), ("lik_scale", C.c_float), ("inv_obs", C.c_float)]
+
+
+class Hyper(C.Structure):
+    _fields_ = [("clip", C.c_float), ("dp_scale", C.c_float), ("lr", C.c_float),
+                ("b1", C.c_float), ("b2", C.c_float), ("adam_eps", C.c_float)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.d3po_erfinv_f32.restype = C.c_float
+        _lib.d3po_erfinv_f32.argtypes = [C.c_float]
+        _lib.d3po_feistel_permute.restype = C.c_uint32
+        _lib.d3po_full_norm.restype = C.c_float
+        _lib.d3po_combine.restype = C.c_float
+        _lib.d3po_logreg_px_loss_grad.restype = C.c_float
+        _lib.d3po_logreg_update.restype = C.c_float
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint32))
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+# ------------------------------------------------------------------ ChaCha20 suite
+def chacha20_block(state):
+    s = _u32(state).reshape(16)
+    out = np.empty(16, np.uint32)
+    lib().d3po_chacha20_block(_p(s), _p(out))
+    return out
+
+
+def seed_to_bytes(seed):
+    """PRNGKey seed handling (d3p/random/__init__.py:35-47): int / bytes / uint32 array -> 32 bytes."""
+    if isinstance(seed, (int, np.integer)):
+        return (int(seed) % (1 << 256)).to_bytes(32, "big")
+    if isinstance(seed, (bytes, bytearray)):
+        if len(seed) > 32:
+            raise ValueError("seed must be at most 256 bit")
+        return bytes(seed).ljust(32, b"\0")
+    a = np.asarray(seed, dtype=np.uint32).ravel()
+    if a.size > 8:
+        raise ValueError("seed must be at most 256 bit")
+    return np.concatenate([a, np.zeros(8 - a.size, np.uint32)]).astype("<u4").tobytes()
+
+
+def PRNGKey(seed):
+    b = np.frombuffer(seed_to_bytes(seed), dtype=np.uint8).copy()
+    out = np.empty(16, np.uint32)
+    lib().d3po_key_from_bytes(_p(b), _p(out))
+    return out.reshape(4, 4)
+
+
+def split(key, num=2):
+    out = np.empty((num, 16), np.uint32)
+    lib().d3po_split(_p(_u32(key).reshape(16)), C.c_int(num), _p(out))
+    return out.reshape(num, 4, 4)
+
+
+def fold_in(key, data):
+    out = np.empty(16, np.uint32)
+    lib().d3po_fold_in(_p(_u32(key).reshape(16)), C.c_uint32(int(data) & 0xFFFFFFFF), _p(out))
+    return out.reshape(4, 4)
+
+
+_UINT = {8: np.uint8, 16: np.uint16, 32: np.uint32, 64: np.uint64}
+
+
+def random_bits(key, bit_width, shape):
+    n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
+    out = np.empty(max(n, 1), _UINT[bit_width])
+    rc = lib().d3po_random_bits(_p(_u32(key).reshape(16)), C.c_int(bit_width), C.c_uint64(n), _p(out))
+    if rc:
+        raise ValueError("bad bit width")
+    return out[:n].reshape(shape)
+
+
+def uniform(key, shape=(), minval=0.0, maxval=1.0):
+    n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
+    out = np.empty(max(n, 1), np.float32)
+    lib().d3po_uniform(_p(_u32(key).reshape(16)), C.c_uint64(n), C.c_float(minval), C.c_float(maxval),
+                       _p(out))
+    return out[:n].reshape(shape)
+
+
+def normal(key, shape=()):
+    n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
+    out = np.empty(max(n, 1), np.float32)
+    lib().d3po_normal(_p(_u32(key).reshape(16)), C.c_uint64(n), _p(out))
+    return out[:n].reshape(shape)
+
+
+def randint(key, shape, minval, maxval):
+    n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
+    out = np.empty(max(n, 1), np.int32)
+    lib().d3po_randint32(_p(_u32(key).reshape(16)), C.c_uint64(n), C.c_int32(minval),
+                         C.c_int32(maxval), _p(out))
+    return out[:n].reshape(shape)
+
+
+def convert_to_jax_rng_key(key):
+    return random_bits(key, 32, (2,))
+
+
+def erfinv_f32(x):
+    x = _f32(x)
+    return np.array([lib().d3po_erfinv_f32(C.c_float(float(v))) for v in x.ravel()],
+                    np.float32).reshape(x.shape)
+
+
+# ------------------------------------------------------------------ threefry (jax.random layouts)
+def threefry2x32(k0, k1, c0, c1):
+    out = np.empty(2, np.uint32)
+    lib().d3po_threefry2x32(C.c_uint32(k0), C.c_uint32(k1), C.c_uint32(c0), C.c_uint32(c1), _p(out))
+    return out
+
+
+def tf_random_words(key, n):
+    out = np.empty(max(n, 1), np.uint32)
+    lib().d3po_tf_random_words(_p(_u32(key)), C.c_uint64(n), _p(out))
+    return out[:n]
+
+
+def tf_split(key, num=2):
+    out = np.empty((num, 2), np.uint32)
+    lib().d3po_tf_split(_p(_u32(key)), C.c_int(num), _p(out))
+    return out
+
+
+def tf_fold_in(key, data):
+    out = np.empty(2, np.uint32)
+    lib().d3po_tf_fold_in(_p(_u32(key)), C.c_uint32(int(data) & 0xFFFFFFFF), _p(out))
+    return out
+
+
+def tf_uniform(key, n, lo=0.0, hi=1.0):
+    out = np.empty(max(n, 1), np.float32)
+    lib().d3po_tf_uniform(_p(_u32(key)), C.c_uint64(n), C.c_float(lo), C.c_float(hi), _p(out))
+    return out[:n]
+
+
+def tf_normal(key, n):
+    out = np.empty(max(n, 1), np.float32)
+    lib().d3po_tf_normal(_p(_u32(key)), C.c_uint64(n), _p(out))
+    return out[:n]
+
+
+def px_sample_key(jax_key, B, p):
+    out = np.empty(2, np.uint32)
+    lib().d3po_px_sample_key(_p(_u32(jax_key)), C.c_uint32(B), C.c_uint32(p), _p(out))
+    return out
+
+
+def px_eps(jax_key, B, D):
+    """eps (B x D): the guide's per-example standard-normal draws (svi.py:289-290 + numpyro plumbing)."""
+    return np.stack([tf_normal(px_sample_key(jax_key, B, p), D) for p in range(B)])
+
+
+# ------------------------------------------------------------------ samplers
+def feistel_constants(key):
+    rc = np.empty(30, np.uint32)
+    lib().d3po_feistel_constants(_p(_u32(key).reshape(16)), _p(rc))
+    return rc
+
+
+def feistel_sample(key, capacity, n):
+    out = np.empty(max(n, 1), np.uint32)
+    lib().d3po_feistel_sample(_p(_u32(key).reshape(16)), C.c_uint32(capacity), C.c_uint32(n), _p(out))
+    return out[:n]
+
+
+def poisson_select(key, q, N, cutoff, suppress=False):
+    idx = np.empty(max(cutoff, 1), np.uint32)
+    counts = np.empty(2, np.uint32)
+    lib().d3po_poisson_select(_p(_u32(key).reshape(16)), C.c_float(q), C.c_uint32(N),
+                              C.c_uint32(cutoff), C.c_int(int(suppress)), _p(idx), _p(counts))
+    return idx[:cutoff], int(counts[0]), int(counts[1])
+
+
+# ------------------------------------------------------------------ DP-VI stages (logistic regression)
+def logreg_spec(d, intercept=False, prior_w=1.0, prior_b=1.0, lik_scale=1.0, obs_scale=1.0):
+    return LogregSpec(d, int(intercept), prior_w, prior_b, lik_scale, 1.0 / obs_scale)
+
+
+def logreg_px_grads(spec, loc, unc, Xb, yb, eps, mask=None):
+    B = Xb.shape[0]
+    D = spec.d + spec.intercept
+    Xb, yb, eps, loc, unc = _f32(Xb), _f32(yb), _f32(eps), _f32(loc), _f32(unc)
+    m = None if mask is None else _f32(mask)
+    px_loss = np.empty(B, np.float32)
+    px_grads = np.empty((B, 2 * D), np.float32)
+    factor = C.c_float()
+    n = lib().d3po_logreg_px_grads(C.byref(spec), _p(loc), _p(unc), _p(Xb), _p(yb), _p(eps),
+                                   None if m is None else _p(m), C.c_int(B), _p(px_loss),
+                                   _p(px_grads), C.byref(factor))
+    return px_loss, px_grads, n, factor.value
+
+
+def clip_rows(px_grads, c):
+    g = _f32(px_grads).copy()
+    rc = lib().d3po_clip_rows(_p(g), C.c_int(g.shape[0]), C.c_int(g.shape[1]), C.c_float(c))
+    if rc:
+        raise ValueError("The clipping threshold must be greater than 0.")
+    return g
+
+
+def full_norm(parts):
+    if parts is None:
+        return 0.0
+    if isinstance(parts, np.ndarray):
+        parts = [parts]
+    flat = [np.asarray(a, np.float32).ravel() for a in _leaves(parts)]
+    if not flat:
+        return 0.0
+    v = np.ascontiguousarray(np.concatenate(flat))
+    return float(lib().d3po_full_norm(_p(v), C.c_uint64(v.size)))
+
+
+def _leaves(t):
+    if t is None:
+        return []
+    if isinstance(t, dict):
+        return [l for k in sorted(t) for l in _leaves(t[k])]
+    if isinstance(t, (list, tuple)):
+        return [l for x in t for l in _leaves(x)]
+    return [t]
+
+
+def combine(px_grads, px_loss):
+    g, l = _f32(px_grads), _f32(px_loss)
+    avg = np.empty(g.shape[1], np.float32)
+    loss = lib().d3po_combine(_p(g), _p(l), C.c_int(g.shape[0]), C.c_int(g.shape[1]), _p(avg))
+    return float(loss), avg
+
+
+def perturb(key, avg, site_sizes, dp_scale, clip, num_elements, obs_scale, factor):
+    avg = _f32(avg)
+    sizes = np.ascontiguousarray(np.asarray(site_sizes, np.int32))
+    out = np.empty_like(avg)
+    lib().d3po_perturb(_p(_u32(key).reshape(16)), _p(avg), _p(sizes), C.c_int(sizes.size),
+                       C.c_float(dp_scale), C.c_float(clip), C.c_float(num_elements),
+                       C.c_float(obs_scale), C.c_float(factor), _p(out))
+    return out
+
+
+def adam(x, m, v, g, i, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
+    x, m, v, g = _f32(x).copy(), _f32(m).copy(), _f32(v).copy(), _f32(g)
+    lib().d3po_adam(_p(x), _p(m), _p(v), _p(g), C.c_int(x.size), C.c_int(i), C.c_float(lr),
+                    C.c_float(b1), C.c_float(b2), C.c_float(eps))
+    return x, m, v
+
+
+class LogregState:
+    """Mutable mirror of DPSVIState for the oracle's full update (svi.py:37-40)."""
+
+    def __init__(self, key, D, loc0=None, unc0=None):
+        self.key = _u32(key).reshape(16).copy()
+        self.params = np.zeros(2 * D, np.float32)
+        if loc0 is not None:
+            self.params[:D] = loc0
+        if unc0 is not None:
+            self.params[D:] = unc0
+        self.m = np.zeros(2 * D, np.float32)
+        self.v = np.zeros(2 * D, np.float32)
+        self.step = C.c_int32(0)
+
+
+def logreg_update(spec, hyper, st, Xb, yb, mask=None, eps=None):
+    """One DPSVI.update (svi.py:395-434); returns (loss, perturbed_grads)."""
+    B = Xb.shape[0]
+    D = spec.d + spec.intercept
+    Xb, yb = _f32(Xb), _f32(yb)
+    m = None if mask is None else _f32(mask)
+    e = None if eps is None else _f32(eps)
+    scratch = np.empty(B * 2 * D + B + B * D + 4 * D, np.float32)
+    grad = np.empty(2 * D, np.float32)
+    loss = lib().d3po_logreg_update(C.byref(spec), C.byref(hyper), _p(st.key), _p(st.params), _p(st.m),
+                                    _p(st.v), C.byref(st.step), _p(Xb), _p(yb),
+                                    None if m is None else _p(m), C.c_int(B),
+                                    None if e is None else _p(e), _p(scratch), _p(grad))
+    return float(loss), grad
+
+
+def synth_logreg(seed, row0, nrows, d):
+    X = np.empty((nrows, d), np.float32)
+    y = np.empty(nrows, np.float32)
+    lib().d3po_synth_logreg(C.c_uint32(seed), C.c_uint64(row0), C.c_uint64(nrows), C.c_int(d), _p(X), _p(y))
+    return X, y
+
+
+def synth_wtrue(seed, d):
+    w = np.empty(d + 1, np.float32)
+    lib().d3po_synth_wtrue(C.c_uint32(seed), C.c_int(d), _p(w))
+    return w

@@ -1,0 +1,413 @@
+"""DP-VI update step: HIP kernels vs the CPU oracle, and the reference's tests/test_dpsvi.py and
+tests/test_gradient_manipulators.py re-expressed against the d3p_amd surface.
+
+Floating-point tolerance (stated once): per-example quantities agree with the oracle to
+rtol 2e-5 (float32 dot products of length d accumulate in a different order; the oracle
+accumulates in float64); batch-level gradients after the sum over B examples to
+rtol 1e-4 / atol 1e-6 * max|g|.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PX_RTOL, PX_ATOL = 2e-5, 2e-6
+G_RTOL = 1e-4
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def close(a, b, rtol=G_RTOL, atol_rel=1e-6):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol_rel * max(1e-30, np.abs(b).max()))
+
+
+@pytest.fixture(scope="module")
+def rng(gpu):
+    import d3p_amd.random as r
+    return r
+
+
+def make_problem(B, d, icpt, seed, N=1000, mask_frac=None):
+    r = np.random.default_rng(seed)
+    D = d + int(icpt)
+    X = r.normal(size=(B, d)).astype(np.float32)
+    y = (r.random(B) < 0.5).astype(np.float32)
+    loc = (r.normal(size=D) * 0.3).astype(np.float32)
+    unc = (r.normal(size=D) * 0.5 - 1.0).astype(np.float32)
+    mask = None
+    if mask_frac is not None:
+        mask = (r.random(B) < mask_frac)
+    return X, y, loc, unc, mask
+
+
+def make_svi(d, icpt, N, C=1.0, sigma=1.0, prior=1.0, lr=1e-3, rng_suite=None, unscale=True, optim=None):
+    from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
+    from d3p_amd.svi import DPSVI
+    import d3p_amd.random as strong
+    model = LogisticRegression(d, prior_scale=prior, intercept=icpt, intercept_prior_scale=2.0 * prior)
+    guide = AutoDiagonalNormal(model)
+    return DPSVI(model, guide, optim or Adam(lr), Trace_ELBO(), C, sigma, rng_suite=rng_suite or strong,
+                 clip_unscaled_observations=unscale, N=N)
+
+
+def state_with(svi, key, loc, unc):
+    from d3p_amd.svi import DPSVIState
+    params = torch.tensor(np.concatenate([loc, unc]), device="cuda")
+    return DPSVIState(svi.optim.init(params), key, float(svi.static_kwargs["N"]) if svi._clip_unscaled_observations else 1.0)
+
+
+# --------------------------------------------------------------------------- stage 1 vs oracle
+@pytest.mark.parametrize("B,d,icpt", [(7, 8, False), (13, 5, True), (64, 512, False), (33, 520, False),
+                                      (9, 130, True), (5, 1024, False), (3, 1, False), (4, 1, True), (6, 2048, False)])
+@pytest.mark.parametrize("onchip", [False, True])
+def test_px_grads_vs_oracle(rng, O, B, d, icpt, onchip):
+    N = 1000
+    X, y, loc, unc, mask = make_problem(B, d, icpt, B * 1000 + d, N, mask_frac=0.8)
+    D = d + int(icpt)
+    svi = make_svi(d, icpt, N, prior=1.5)
+    key = rng.PRNGKey(B + d)
+    st = state_with(svi, key, loc, unc)
+    Xt, yt, mt = torch.tensor(X).cuda(), torch.tensor(y).cuda(), torch.tensor(mask).cuda()
+    jax_key = O.convert_to_jax_rng_key(O.PRNGKey(B + d))
+    eps = O.px_eps(jax_key, B, D) if onchip else np.random.default_rng(1).normal(size=(B, D)).astype(np.float32)
+    kw = {} if onchip else {"_eps": torch.tensor(eps).cuda()}
+    _, px_loss, px_grads, n, f = svi._compute_per_example_gradients(st, key, Xt, yt, mask=mt, **kw)
+    spec = O.logreg_spec(d, icpt, 1.5, 3.0, lik_scale=N, obs_scale=N)
+    eL, eG, en, ef = O.logreg_px_grads(spec, loc, unc, X, y, eps, mask.astype(np.float32))
+    assert float(n) == en and abs(float(f) - ef) < 1e-6
+    G = np.concatenate([np_(px_grads["auto_loc"]), np_(px_grads["auto_scale"])], axis=1)
+    scale = np.abs(eG).max()
+    np.testing.assert_allclose(G, eG, rtol=PX_RTOL, atol=PX_ATOL * scale)
+    np.testing.assert_allclose(np_(px_loss), eL, rtol=PX_RTOL, atol=PX_ATOL * np.abs(eL).max())
+    # masked rows are exactly zero (reference tests/test_dpsvi.py:137-144)
+    assert np.all(G[~mask] == 0) and np.all(np_(px_loss)[~mask] == 0)
+    assert not np.allclose(G[mask], 0)
+
+
+# --------------------------------------------------------------------------- reference tests/test_dpsvi.py
+class TestReferenceDPSVI:
+    batch_size, num_elements, num_obs_total = 10, 8, 100
+    dp_scale, clipping_threshold = 1.0, 2.0
+
+    def setup_method(self, _):
+        import d3p_amd.random as strong
+        from d3p_amd.models import SGD
+        from d3p_amd.svi import DPSVI
+        self.rng_suite = strong
+        self.rng = strong.PRNGKey(9782346)
+        self.mask = torch.arange(self.batch_size, device="cuda") < self.num_elements
+        self.rescale_factor = self.batch_size / self.num_elements
+        self.px_grads = (torch.ones((self.batch_size, 10000), device="cuda"),
+                         torch.ones((self.batch_size, 10000), device="cuda"))
+        self.masked_px_grads = tuple(g * self.mask.reshape(-1, 1) for g in self.px_grads)
+        self.px_loss = torch.arange(self.batch_size, dtype=torch.float32, device="cuda") * self.mask
+        self.svi = DPSVI(None, None, SGD(1.0), None, self.clipping_threshold, self.dp_scale,
+                         num_obs_total=self.num_obs_total, rng_suite=self.rng_suite)
+
+    def _logreg_svi(self, unscale=True):
+        from d3p_amd.models import SGD, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
+        from d3p_amd.svi import DPSVI
+        model = LogisticRegression()
+        return DPSVI(model, AutoDiagonalNormal(model), SGD(1.0), Trace_ELBO(), self.clipping_threshold,
+                     self.dp_scale, rng_suite=self.rng_suite, clip_unscaled_observations=unscale,
+                     num_obs_total=self.num_obs_total)
+
+    def test_init(self):  # tests/test_dpsvi.py:64-86
+        svi = self._logreg_svi()
+        batch = (torch.zeros((self.batch_size, 3), device="cuda"), torch.zeros(self.batch_size, device="cuda"))
+        st = svi.init(self.rng, *batch)
+        assert st.observation_scale == self.num_obs_total
+        assert torch.equal(st.rng_key, self.rng)
+        p = svi.get_params(st)
+        assert tuple(p["auto_loc"].shape) == (3,) and torch.allclose(p["auto_scale"], torch.full((3,), 0.1, device="cuda"))
+        assert float(p["auto_loc"].abs().max()) <= 2.0
+
+    def test_init_no_unscaling(self):  # tests/test_dpsvi.py:88-110
+        svi = self._logreg_svi(unscale=False)
+        batch = (torch.zeros((self.batch_size, 3), device="cuda"), torch.zeros(self.batch_size, device="cuda"))
+        st = svi.init(self.rng, *batch)
+        assert st.observation_scale == 1.0 and torch.equal(st.rng_key, self.rng)
+
+    def test_compute_px_gradients_masking(self):  # tests/test_dpsvi.py:112-144
+        svi = self._logreg_svi()
+        batch = (torch.ones((self.batch_size, 3), device="cuda"), torch.ones(self.batch_size, device="cuda"))
+        st = svi.init(self.rng, *batch)
+        new_st, px_losses, px_grads, num_elements, factor = svi._compute_per_example_gradients(
+            st, st.rng_key, *batch, mask=self.mask)
+        assert new_st.observation_scale == st.observation_scale
+        assert float(num_elements) == self.num_elements
+        assert abs(float(factor) - self.batch_size / self.num_elements) < 1e-6
+        ne = self.num_elements
+        assert not np.allclose(np_(px_losses)[:ne], 0) and np.allclose(np_(px_losses)[ne:], 0)
+        for site in ("auto_loc", "auto_scale"):
+            g = np_(px_grads[site])
+            assert not np.allclose(g[:ne], 0) and np.allclose(g[ne:], 0)
+
+    def test_px_gradient_clipping(self):  # tests/test_dpsvi.py:146-173
+        from d3p_amd.svi import DPSVIState, full_norm
+        st = DPSVIState(None, self.rng, 0.8)
+        px_grads = (torch.tensor([1.0, 0.0], device="cuda").repeat_interleave(10).reshape(2, 10),
+                    torch.tensor([0.0, 1.0], device="cuda").repeat_interleave(2).reshape(2, 2))
+        norms = [float(full_norm(tuple(g[i] for g in px_grads))) for i in range(2)]
+        assert np.allclose(norms, (np.sqrt(10), np.sqrt(2)))
+        new_st, clipped = self.svi._clip_gradients(st, px_grads)
+        assert new_st == st and isinstance(clipped, tuple) and len(clipped) == 2
+        assert [tuple(c.shape) for c in clipped] == [(2, 10), (2, 2)]
+        cn = [float(full_norm(tuple(g[i] for g in clipped))) for i in range(2)]
+        assert np.allclose(cn, [2.0, np.sqrt(2)])
+        _, cg = self.svi._combine_gradients(clipped, torch.ones(2, device="cuda"))
+        assert float(full_norm(cg)) < self.clipping_threshold
+
+    def test_px_gradient_aggregation(self):  # tests/test_dpsvi.py:175-191
+        np.random.seed(0)
+        px = [np.random.normal(1, 1, size=(self.batch_size, 10000)).astype(np.float32) for _ in range(2)]
+        loss, grads = self.svi._combine_gradients([torch.tensor(p).cuda() for p in px], self.px_loss)
+        assert np.allclose(float(loss), np_(self.px_loss).mean())
+        for g, p in zip(grads, px):
+            assert np.allclose(np_(g), p.mean(axis=0), atol=1e-6)
+
+    def test_dp_noise_perturbation(self):  # tests/test_dpsvi.py:193-216
+        from d3p_amd.svi import DPSVIState
+        st = DPSVIState(None, self.rng, 0.3)
+        grads = tuple(g.mean(dim=0) for g in self.px_grads)
+        masked = tuple(g.mean(dim=0) for g in self.masked_px_grads)
+        new_st, pert = self.svi._perturb_and_reassemble_gradients(st, self.rng, masked, self.num_elements,
+                                                                 self.rescale_factor)
+        assert new_st.optim_state is st.optim_state and isinstance(pert, tuple)
+        expected_std = self.dp_scale * (self.clipping_threshold / self.num_elements) * 0.3 * self.rescale_factor
+        assert abs(expected_std - 0.09375) < 1e-9
+        for p, site in zip(pert, grads):
+            assert p.shape == site.shape
+            assert abs(float(p.std()) - expected_std) < 1e-2
+            assert abs(float(site.mean()) * 0.3 - float(p.mean())) < 5e-3
+
+    def test_dp_noise_not_deterministic_over_rngs_and_sites(self):  # tests/test_dpsvi.py:218-258
+        from d3p_amd.svi import DPSVIState
+        st = DPSVIState(None, self.rng, 0.3)
+        k1, k2 = self.rng_suite.split(self.rng)
+        grads = tuple(g.mean(dim=0) for g in self.px_grads)
+        _, a = self.svi._perturb_and_reassemble_gradients(st, k1, grads, self.num_elements, self.rescale_factor)
+        _, b = self.svi._perturb_and_reassemble_gradients(st, k2, grads, self.num_elements, self.rescale_factor)
+        assert not any(torch.allclose(x, y) for x, y in zip(a, b))
+        assert not torch.allclose(a[0], a[1])
+
+    def test_perturbation_matches_oracle(self, O):
+        from d3p_amd.svi import DPSVIState
+        st = DPSVIState(None, self.rng, 0.3)
+        avg = [np.linspace(-1, 1, 1000).astype(np.float32), np.linspace(2, 3, 37).astype(np.float32)]
+        _, pert = self.svi._perturb_and_reassemble_gradients(st, self.rng, [torch.tensor(a).cuda() for a in avg],
+                                                             self.num_elements, self.rescale_factor)
+        exp = O.perturb(O.PRNGKey(9782346), np.concatenate(avg), [1000, 37], self.dp_scale, self.clipping_threshold,
+                        self.num_elements, 0.3, self.rescale_factor)
+        np.testing.assert_allclose(np.concatenate([np_(p) for p in pert]), exp, rtol=1e-5, atol=1e-7)
+
+
+# --------------------------------------------------------------------------- tests/test_gradient_manipulators.py
+def test_gradient_manipulators(gpu):
+    from d3p_amd.svi import clip_gradient, full_norm, normalize_gradient
+    t = lambda *a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    tree = ([t(1, 2), torch.zeros((0,), device="cuda")], {"a": t(3, 4, 5).reshape(3, 1), "b": (t(6), t(7, 8, 9, 10))})
+    assert abs(float(full_norm(tree)) - 16.613247) < 1e-5   # sqrt(276), tests/test_gradient_manipulators.py:70-79
+    for empty in (None, [], ()):
+        assert full_norm(empty) == 0.0                       # :62-68
+    with pytest.raises(ValueError):
+        clip_gradient(tree, 0.0)                             # :101-103
+    for c in (100.0, float("inf")):                          # identity when C >= norm (:81-99)
+        out = clip_gradient(tree, c)
+        assert abs(float(full_norm(out)) - 16.613247) < 1e-5
+    out = clip_gradient(tree, 3.0)
+    assert float(full_norm(out)) <= 3.0 + 1e-6
+    assert torch.allclose(out[1]["b"][1] / out[1]["b"][1][0], t(7, 8, 9, 10) / 7)   # direction preserved
+    assert abs(float(full_norm(normalize_gradient(tree))) - 1.0) < 1e-6              # :105-109
+
+
+def test_constructor_validation(gpu):
+    from d3p_amd.models import SGD
+    from d3p_amd.svi import DPSVI
+    with pytest.raises(ValueError):
+        DPSVI(None, None, SGD(1.0), None, float("inf"), 1.0)   # svi.py:187-188
+    svi = DPSVI(None, None, SGD(1.0), None, 1.0, 1.0)
+    with pytest.raises(ValueError):
+        svi.get_epsilon(1e-5, 0.01)                            # svi.py:454-455
+
+
+# --------------------------------------------------------------------------- fused update vs oracle
+@pytest.mark.parametrize("B,d,icpt,masked", [(16, 8, False, False), (16, 8, True, True), (50, 512, False, True),
+                                             (256, 512, False, False), (37, 100, True, True), (8, 1024, False, False)])
+@pytest.mark.parametrize("onchip", [False, True])
+def test_fused_update_vs_oracle(rng, O, B, d, icpt, masked, onchip):
+    N = 5000
+    X, y, loc, unc, mask = make_problem(B, d, icpt, 17 * B + d, N, mask_frac=0.7 if masked else None)
+    D = d + int(icpt)
+    svi = make_svi(d, icpt, N, C=0.7, sigma=1.3, prior=1.5, lr=1e-2)
+    key = rng.PRNGKey(4242)
+    st = state_with(svi, key, loc, unc)
+    Xt, yt = torch.tensor(X).cuda(), torch.tensor(y).cuda()
+    mt = torch.tensor(mask).cuda() if masked else True
+    eps = None if onchip else np.random.default_rng(2).normal(size=(B, D)).astype(np.float32)
+    gout = torch.empty(2 * D, device="cuda")
+    new_st, loss = svi._update_fused(st, Xt, yt, mask=mt, _eps=None if onchip else torch.tensor(eps).cuda(), _grad_out=gout)
+
+    spec = O.logreg_spec(d, icpt, 1.5, 3.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(0.7, 1.3, 1e-2, 0.9, 0.999, 1e-8)
+    ost = O.LogregState(O.PRNGKey(4242), D, loc, unc)
+    eloss, egrad = O.logreg_update(spec, hy, ost, X, y, None if not masked else mask.astype(np.float32), eps)
+    close(np_(gout), egrad)
+    assert abs(float(loss) - eloss) <= 2e-5 * abs(eloss) + 1e-6
+    assert np.array_equal(np_(new_st.rng_key).ravel(), ost.key)          # next state key: bit-exact
+    step, params, m, v = new_st.optim_state
+    assert int(step) == 1
+    close(np_(m), ost.m)
+    close(np_(v), ost.v, rtol=2e-4)
+    np.testing.assert_allclose(np_(params), ost.params, rtol=1e-5, atol=1e-6)
+    # the input state is untouched (functional update like the reference)
+    assert int(st.optim_state[0]) == 0 and np.array_equal(np_(st.optim_state[1]), np.concatenate([loc, unc]))
+
+
+def test_fused_equals_staged_pipeline(rng):
+    """update() (fused kernels) and the reference's literal five-stage composition agree."""
+    B, d, N = 128, 512, 10**5
+    X, y, loc, unc, mask = make_problem(B, d, False, 3, N, mask_frac=0.9)
+    svi = make_svi(d, False, N, C=1.0, sigma=1.0)
+    key = rng.PRNGKey(77)
+    st = state_with(svi, key, loc, unc)
+    Xt, yt, mt = torch.tensor(X).cuda(), torch.tensor(y).cuda(), torch.tensor(mask).cuda()
+    s1, l1 = svi._update_fused(st, Xt, yt, mask=mt)
+    s2, l2 = svi._update_staged(st, Xt, yt, mask=mt)
+    assert torch.equal(s1.rng_key, s2.rng_key)
+    assert abs(float(l1) - float(l2)) <= 2e-5 * abs(float(l2))
+    np.testing.assert_allclose(np_(s1.optim_state[1]), np_(s2.optim_state[1]), rtol=1e-5, atol=1e-6)
+    close(np_(s1.optim_state[2]), np_(s2.optim_state[2]))
+
+
+def test_empty_batch_gives_nan_like_reference(rng):
+    """n == 0 -> sensitivity inf, inf * 0 = NaN gradients (svi.py:305, :365, :375)."""
+    B, d = 8, 16
+    X, y, loc, unc, _ = make_problem(B, d, False, 5)
+    svi = make_svi(d, False, 100)
+    st = state_with(svi, rng.PRNGKey(1), loc, unc)
+    gout = torch.empty(2 * d, device="cuda")
+    _, loss = svi._update_fused(st, torch.tensor(X).cuda(), torch.tensor(y).cuda(),
+                                mask=torch.zeros(B, dtype=torch.bool, device="cuda"), _grad_out=gout)
+    assert float(loss) == 0.0 and bool(torch.isnan(gout).all())
+
+
+def test_update_is_deterministic_full_size(rng):
+    """BASELINE config 2 shape: bitwise-reproducible step (fixed reduction order, no float atomics)."""
+    B, d, N = 4096, 512, 10**6
+    X, y, loc, unc, _ = make_problem(B, d, False, 9, N)
+    svi = make_svi(d, False, N)
+    st = state_with(svi, rng.PRNGKey(5), loc, unc)
+    Xt, yt = torch.tensor(X).cuda(), torch.tensor(y).cuda()
+    outs = []
+    for _ in range(3):
+        g = torch.empty(2 * d, device="cuda")
+        s, l = svi._update_fused(st, Xt, yt, _grad_out=g)
+        outs.append((np_(g).copy(), float(l), np_(s.optim_state[1]).copy()))
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and o[1] == outs[0][1] and np.array_equal(o[2], outs[0][2])
+
+
+def test_full_size_update_vs_oracle(rng, O):
+    """BASELINE config 2 per-step shape (B=4096, d=512, AutoDiagonalNormal) against the oracle."""
+    B, d, N = 4096, 512, 10**6
+    X, y, loc, unc, _ = make_problem(B, d, False, 10, N)
+    svi = make_svi(d, False, N, C=1.0, sigma=1.0, lr=1e-3)
+    st = state_with(svi, rng.PRNGKey(0), loc, unc)
+    g = torch.empty(2 * d, device="cuda")
+    s, loss = svi._update_fused(st, torch.tensor(X).cuda(), torch.tensor(y).cuda(), _grad_out=g)
+    spec = O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    ost = O.LogregState(O.PRNGKey(0), d, loc, unc)
+    eloss, egrad = O.logreg_update(spec, O.Hyper(1.0, 1.0, 1e-3, 0.9, 0.999, 1e-8), ost, X, y)
+    close(np_(g), egrad)
+    assert abs(float(loss) - eloss) <= 2e-5 * abs(eloss)
+    np.testing.assert_allclose(np_(s.optim_state[1]), ost.params, rtol=1e-5, atol=1e-6)
+    # size-independent property: the noise-free part is bounded by the clipping threshold
+    svi0 = make_svi(d, False, N, C=1.0, sigma=0.0)
+    g0 = torch.empty(2 * d, device="cuda")
+    svi0._update_fused(st, torch.tensor(X).cuda(), torch.tensor(y).cuda(), _grad_out=g0)
+    assert float(g0.norm()) / N <= 1.0 + 1e-5    # ||mean of clipped|| * obs_scale / N <= C
+
+
+# --------------------------------------------------------------------------- fused multi-step loop
+@pytest.mark.parametrize("sampler", ["feistel", "poisson"])
+def test_run_steps_vs_oracle(rng, O, sampler):
+    from d3p_amd.minibatch import poisson_batchify_data, subsample_batchify_data
+    N, d, B, steps = 3000, 64, 48, 6
+    r = np.random.default_rng(0)
+    X = r.normal(size=(N, d)).astype(np.float32)
+    y = (r.random(N) < 0.5).astype(np.float32)
+    loc = np.zeros(d, np.float32)
+    unc = np.full(d, -2.0, np.float32)
+    Xt, yt = torch.tensor(X).cuda(), torch.tensor(y).cuda()
+    svi = make_svi(d, False, N, C=1.0, sigma=0.5, lr=1e-2)
+    st = state_with(svi, rng.PRNGKey(100), loc, unc)
+    bkey = rng.PRNGKey(200)
+    q = B / N
+    if sampler == "feistel":
+        init, get_batch = subsample_batchify_data((Xt, yt), B)
+        maxB = B
+    else:
+        maxB = 70
+        init, get_batch = poisson_batchify_data((Xt, yt), q, maxB)
+    nb, bstate = init(bkey)
+    first = 2
+    new_st, losses = svi.run_steps(st, get_batch, bstate, first, steps)
+
+    spec = O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.5, 1e-2, 0.9, 0.999, 1e-8)
+    ost = O.LogregState(O.PRNGKey(100), d, loc, unc)
+    elosses = []
+    for t in range(steps):
+        bk = O.fold_in(O.PRNGKey(200), first + t)
+        if sampler == "feistel":
+            idx = O.feistel_sample(bk, N, B)
+            mask = None
+        else:
+            idx, nsel, nvalid = O.poisson_select(bk, np.float32(q), N, maxB)
+            mask = (np.arange(maxB) < nvalid).astype(np.float32)
+        el, _ = O.logreg_update(spec, hy, ost, X[idx], y[idx], mask)
+        elosses.append(el)
+    np.testing.assert_allclose(np_(losses), elosses, rtol=5e-5)
+    assert np.array_equal(np_(new_st.rng_key).ravel(), ost.key)
+    assert int(new_st.optim_state[0]) == steps
+    np.testing.assert_allclose(np_(new_st.optim_state[1]), ost.params, rtol=2e-4, atol=2e-5)
+    # the API-parity path (get_batch + update, one step at a time) walks the same trajectory
+    st2 = st
+    for t in range(steps):
+        out = get_batch(first + t, bstate)
+        (bx, by), m = (out, True) if sampler == "feistel" else out
+        st2, l2 = svi.update(st2, bx, by, mask=m)
+        assert abs(float(l2) - elosses[t]) <= 5e-5 * abs(elosses[t])
+    assert torch.equal(st2.rng_key, new_st.rng_key)
+    np.testing.assert_allclose(np_(st2.optim_state[1]), np_(new_st.optim_state[1]), rtol=1e-5, atol=1e-6)
+
+
+def test_staged_update_with_debug_rng_suite(gpu, O):
+    """rng_suite=d3p_amd.random.debug routes DPSVI through the threefry suite (d3p/random/debug.py)."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import d3p_amd.random.debug as dbg
+    B, d, N = 32, 24, 400
+    X, y, loc, unc, _ = make_problem(B, d, False, 21, N)
+    svi = make_svi(d, False, N, rng_suite=dbg)
+    st = state_with(svi, dbg.PRNGKey(3), loc, unc)
+    s1, l1 = svi.update(st, torch.tensor(X).cuda(), torch.tensor(y).cuda())
+    keys = O.tf_split([0, 3], 3)
+    assert np.array_equal(np_(s1.rng_key), keys[0])
+    eps = O.px_eps(keys[1], B, d)
+    spec = O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    L, G, n, f = O.logreg_px_grads(spec, loc, unc, X, y, eps)
+    G = O.clip_rows(G, 1.0)
+    eloss, avg = O.combine(G, L)
+    assert abs(float(l1) - eloss) <= 2e-5 * abs(eloss)
+    sk = O.tf_split(keys[2], 2)
+    noise = np.concatenate([O.tf_normal(sk[0], d), O.tf_normal(sk[1], d)])
+    g = (avg + noise * (1.0 * 1.0 / B)) * N * 1.0
+    x, m, v = O.adam(np.concatenate([loc, unc]), np.zeros(2 * d), np.zeros(2 * d), g, 0)
+    np.testing.assert_allclose(np_(s1.optim_state[1]), x, rtol=1e-5, atol=1e-6)
