@@ -10,8 +10,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libd3p_hip.so")
-_SRC = [os.path.join(_HERE, "csrc", f) for f in ("d3p_rng.hip", "d3p_dpvi.hip")]
-_DEPS = _SRC + [os.path.join(_HERE, "csrc", f) for f in ("d3p_device.h", "d3p_host.h")] + [
+_SRC = [os.path.join(_HERE, "csrc", f) for f in ("d3p_rng.hip", "d3p_dpvi.hip", "d3p_stages.hip")]
+_DEPS = _SRC + [os.path.join(_HERE, "csrc", f) for f in ("d3p_device.h", "d3p_host.h", "d3p_logreg_kernel.h")] + [
     os.path.join(os.path.dirname(_HERE), "include", "d3p_hip.h")]
 
 D3P_BATCH_EXPLICIT, D3P_BATCH_FEISTEL, D3P_BATCH_POISSON = 0, 1, 2
@@ -94,7 +94,7 @@ SIGNATURES = {
     "d3p_dpvi_logreg_finalize": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _V, _V, _SZ]),
     "d3p_dpvi_logreg_run": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _U32, _V, _V, _SZ]),
     "d3p_dpvi_logreg_time_main_kernel": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _V, _SZ, C.c_int,
-                                                   C.POINTER(C.c_float)]),
+                                                   C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "d3p_synth_logreg": (C.c_int, [_V, _U32, _U64, _U64, _I32, _V, _V]),
 }
 
@@ -109,6 +109,9 @@ def load():
             raise D3PError(
                 f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  d3p_amd has no CPU fallback.")
+        # torch bundles its own libamdhip64; import it first so that the loader binds this
+        # library to the SAME HIP runtime instance (two runtimes in one process do not share a device)
+        import torch  # noqa: F401
         lib = C.CDLL(_SO)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -121,7 +121,7 @@ __device__ __forceinline__ float bits_to_uniform(uint32_t bits, float lo, float 
 {
     const float f = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, bits, 9)) - 1.0f;
     const float scale = hi - lo;
-    const float r = __fadd_rn(__fmul_rn(f, scale), lo);
+    const float r = __fmaf_rn(f, scale, lo);
     return fmaxf(lo, r);
 }
 
@@ -156,6 +156,46 @@ __device__ __forceinline__ float erfinv_f32(float x)
     return p * x;
 }
 
+// Same function with the rare tail polynomial (|x| > 0.9966, 0.34 % of draws) behind a wave-uniform
+// branch: identical arithmetic per lane, but a wave only pays for the tail when one of its lanes
+// needs it.  All 64 lanes must call it together.
+__device__ __forceinline__ float erfinv_f32_wu(float x)
+{
+    // 1 - x^2 >= 2^-23 for every x this is called with, so the raw v_log_f32 (no denormal pre-scaling)
+    // is exact enough: w = -ln2 * log2(1 - x^2)
+    const float w = -0.693147182f * __builtin_amdgcn_logf(__fmaf_rn(-x, x, 1.0f));
+    const float wc = w - 2.5f;
+    float p = 2.81022636e-08f;
+    p = __fmaf_rn(p, wc, 3.43273939e-07f);
+    p = __fmaf_rn(p, wc, -3.5233877e-06f);
+    p = __fmaf_rn(p, wc, -4.39150654e-06f);
+    p = __fmaf_rn(p, wc, 0.00021858087f);
+    p = __fmaf_rn(p, wc, -0.00125372503f);
+    p = __fmaf_rn(p, wc, -0.00417768164f);
+    p = __fmaf_rn(p, wc, 0.246640727f);
+    p = __fmaf_rn(p, wc, 1.50140941f);
+    const bool tail = !(w < 5.0f);
+    if (__builtin_amdgcn_ballot_w64(tail) != 0ull) {
+        const float wt = __fsqrt_rn(w) - 3.0f;
+        float q = -0.000200214257f;
+        q = __fmaf_rn(q, wt, 0.000100950558f);
+        q = __fmaf_rn(q, wt, 0.00134934322f);
+        q = __fmaf_rn(q, wt, -0.00367342844f);
+        q = __fmaf_rn(q, wt, 0.00573950773f);
+        q = __fmaf_rn(q, wt, -0.0076224613f);
+        q = __fmaf_rn(q, wt, 0.00943887047f);
+        q = __fmaf_rn(q, wt, 1.00167406f);
+        q = __fmaf_rn(q, wt, 2.83297682f);
+        p = tail ? q : p;
+    }
+    return p * x;
+}
+
+__device__ __forceinline__ float bits_to_normal_wu(uint32_t bits)
+{
+    return D3P_SQRT2 * erfinv_f32_wu(bits_to_uniform(bits, D3P_NORMAL_LO, 1.0f));
+}
+
 // d3p.random.normal / jax.random.normal transform of one 32-bit word.
 __device__ __forceinline__ float bits_to_normal(uint32_t bits)
 {
@@ -183,7 +223,9 @@ __device__ __forceinline__ float wave_sum(float v)
     return (r0 + r1) + (r2 + r3);
 }
 
-__device__ __forceinline__ float softplus_f(float t) { return fmaxf(t, 0.0f) + log1pf(__expf(-fabsf(t))); }
+// softplus(t) = max(t, 0) + log(1 + exp(-|t|)); exp(-|t|) is in (0, 1], so log(1 + e) via v_log_f32 has an
+// absolute error of ~1e-7 (relative to values >= ln 2 * e): inside the stated float32 tolerance.
+__device__ __forceinline__ float softplus_f(float t) { return fmaxf(t, 0.0f) + __logf(1.0f + __expf(-fabsf(t))); }
 __device__ __forceinline__ float sigmoid_f(float t) { return 1.0f / (1.0f + __expf(-t)); }
 
 }  // namespace d3p

@@ -1,0 +1,326 @@
+// Stage-level DP-VI API on materialised tensors (the five stages the reference's tests call
+// directly), optimiser steps and the synthetic-table generator.
+#include "d3p_logreg_kernel.h"
+
+namespace d3p {
+
+__device__ __forceinline__ void adam_update(float& x, float& m, float& v, float g, int i, const d3p_dpsvi_hyper& h)
+{
+    // jax.example_libraries.optimizers.adam as wrapped by numpyro.optim.Adam
+    m = (1.0f - h.b1) * g + h.b1 * m;
+    v = (1.0f - h.b2) * g * g + h.b2 * v;
+    const float mhat = m / (1.0f - powf(h.b1, (float)(i + 1)));
+    const float vhat = v / (1.0f - powf(h.b2, (float)(i + 1)));
+    x = x - h.lr * mhat / (sqrtf(vhat) + h.adam_eps);
+}
+
+// ------------------------------------------------------------------------------------------
+// stage-level kernels on materialised tensors (API parity with the reference's five stages)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_mask_meta(const uint8_t* __restrict__ mask, uint32_t B, float* __restrict__ meta)
+{
+    __shared__ float lds[256];
+    float s = 0.f;
+    for (uint32_t i = threadIdx.x; i < B; i += 256) s += mask ? (mask[i] != 0 ? 1.f : 0.f) : 1.f;
+    lds[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) lds[threadIdx.x] += lds[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float n = lds[0];
+        meta[0] = n;
+        meta[1] = (n == 0.f) ? 0.f : (float)B / n;
+    }
+}
+
+__global__ void k_clip_rows(float* __restrict__ g, uint32_t B, uint32_t P, float c)
+{
+    const uint32_t row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float* r = g + (size_t)row * P;
+    float ss = 0.f;
+    for (uint32_t j = lane; j < P; j += 64) ss = __fmaf_rn(r[j], r[j], ss);
+    ss = wave_sum(ss);
+    const float scale = 1.0f / fmaxf(1.0f, __fsqrt_rn(ss) / c);  // svi.py:121-122
+    for (uint32_t j = lane; j < P; j += 64) r[j] *= scale;
+}
+
+__global__ void __launch_bounds__(256)
+k_combine(const float* __restrict__ g, const float* __restrict__ px_loss, uint32_t B, uint32_t P, float* __restrict__ avg,
+          float* __restrict__ loss)
+{
+    __shared__ float lds[256];
+    const int c = threadIdx.x % D3P_FIN_COLS, rg = threadIdx.x / D3P_FIN_COLS;
+    const uint32_t col = blockIdx.x * D3P_FIN_COLS + c;
+    const float tot = column_sum(g, B, P, col, col < P, c, rg, lds);
+    if (rg == 0 && col < P) avg[col] = tot / (float)B;
+    if (blockIdx.x == 0 && px_loss && loss) {
+        const float l = block_sum_column(px_loss, B, 1, 0, lds);
+        if (threadIdx.x == 0) *loss = l / (float)B;
+    }
+}
+
+__global__ void k_full_norm(const float* __restrict__ v, uint64_t n, float* __restrict__ out)
+{
+    __shared__ float lds[256];
+    float ss = 0.f;
+    for (uint64_t j = threadIdx.x; j < n; j += 256) ss = __fmaf_rn(v[j], v[j], ss);
+    lds[threadIdx.x] = ss;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) lds[threadIdx.x] += lds[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = __fsqrt_rn(lds[0]);
+}
+
+__global__ void k_perturb_site(const uint32_t* __restrict__ site_key, const float* __restrict__ avg, uint32_t n_site,
+                               float dp_scale, float c, const float* __restrict__ meta, float obs_scale,
+                               float* __restrict__ out)
+{
+    // one thread = one ChaCha block = 16 consecutive elements of the site
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (16ull * b >= n_site) return;
+    uint32_t k[16], o[16];
+    load_key(site_key, k);
+    keystream_block(k, b, o);
+    const float n = meta[0], factor = meta[1];
+    const float scale = dp_scale * (c / n);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t e = 16u * b + w;
+        if (e < n_site) out[e] = (avg[e] + bits_to_normal(o[w]) * scale) * obs_scale * factor;
+    }
+}
+
+__global__ void k_perturb_apply(const float* __restrict__ avg, const float* __restrict__ noise, uint64_t n,
+                                float dp_scale, float c, const float* __restrict__ meta, float obs_scale,
+                                float* __restrict__ out)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float scale = dp_scale * (c / meta[0]);
+    out[e] = (avg[e] + noise[e] * scale) * obs_scale * meta[1];
+}
+
+__global__ void k_adam(float* __restrict__ x, float* __restrict__ m, float* __restrict__ v, const int32_t* __restrict__ step,
+                       const float* __restrict__ g, uint32_t P, d3p_dpsvi_hyper h)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P) return;
+    float xx = x[j], mm = m[j], vv = v[j];
+    adam_update(xx, mm, vv, g[j], *step, h);
+    x[j] = xx;
+    m[j] = mm;
+    v[j] = vv;
+}
+
+__global__ void k_incr_i32(int32_t* p) { *p += 1; }
+
+__global__ void k_sgd(float* __restrict__ x, const float* __restrict__ g, uint32_t P, float lr)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < P) x[j] = x[j] - lr * g[j];
+}
+
+// synthetic table: element (r, c) = f(seed, r, c)   
+__global__ void k_synth_logreg(uint32_t seed, uint64_t row0, uint64_t n_rows, int d, float* __restrict__ X,
+                               float* __restrict__ y)
+{
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= n_rows) return;
+    const uint64_t r = row0 + i;
+    float tp = 0.f;
+    uint32_t a, b;
+    for (int c = lane; c < d; c += 64) {
+        threefry2x32(seed, 0x58u, (uint32_t)r, (uint32_t)c, a, b);
+        const float xv = bits_to_normal(a);
+        X[i * (uint64_t)d + c] = xv;
+        threefry2x32(seed, 0x57u, (uint32_t)c, 0u, a, b);
+        tp = __fmaf_rn(xv, bits_to_normal(a), tp);
+    }
+    float t = wave_sum(tp);
+    if (lane == 0) {
+        threefry2x32(seed, 0x57u, (uint32_t)d, 0u, a, b);
+        t += bits_to_normal(a);
+        threefry2x32(seed, 0x59u, (uint32_t)r, 0u, a, b);
+        const float u = bits_to_uniform(a, 0.0f, 1.0f);
+        y[i] = (u < sigmoid_f(t)) ? 1.0f : 0.0f;
+    }
+}
+
+__global__ void k_px_keys(const uint32_t* __restrict__ jax_key, uint32_t B, uint32_t* __restrict__ skeys)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    uint32_t s0, s1;
+    px_sample_key(jax_key[0], jax_key[1], B, p, s0, s1);
+    skeys[2 * p] = s0;
+    skeys[2 * p + 1] = s1;
+}
+
+}  // namespace d3p
+
+using namespace d3p;
+
+extern "C" {
+
+static size_t px_ws_bytes(const d3p_logreg_model* model, uint32_t B)
+{
+    const size_t D = (size_t)model->d + (model->intercept ? 1 : 0);
+    return align_up(5 * D * sizeof(float), 256) + align_up(2 * (size_t)B * sizeof(uint32_t), 256);
+}
+
+size_t d3p_logreg_px_grads_workspace(const d3p_logreg_model* model, uint32_t B)
+{
+    return model ? px_ws_bytes(model, B) : 0;
+}
+
+int d3p_logreg_px_grads(void* stream, const d3p_logreg_model* model, const float* params_dev, const float* X_dev,
+                        const float* y_dev, const uint8_t* mask_dev, uint32_t B, const float* eps_dev,
+                        const uint32_t* jax_key_dev, float* px_loss_dev, float* px_grads_dev, float* meta_dev,
+                        void* workspace_dev, size_t workspace_bytes)
+{
+    D3P_REQUIRE(model && params_dev && X_dev && y_dev && px_loss_dev && px_grads_dev && meta_dev && workspace_dev,
+                "d3p_logreg_px_grads: null pointer");
+    D3P_REQUIRE(eps_dev || jax_key_dev, "d3p_logreg_px_grads: either eps_dev or jax_key_dev must be given");
+    D3P_REQUIRE(B >= 1, "d3p_logreg_px_grads: B must be >= 1");
+    D3P_REQUIRE(model->d >= 1 && model->prior_w > 0.f && model->prior_b > 0.f && model->inv_obs > 0.f,
+                "d3p_logreg_px_grads: bad model");
+    if (workspace_bytes < px_ws_bytes(model, B))
+        return fail(D3P_E_WORKSPACE, "d3p_logreg_px_grads: workspace too small (%zu < %zu)", workspace_bytes,
+                    px_ws_bytes(model, B));
+    hipStream_t s = (hipStream_t)stream;
+    const int D = model->d + (model->intercept ? 1 : 0);
+    float* pack = (float*)workspace_dev;
+    uint32_t* skeys = (uint32_t*)((char*)workspace_dev + align_up(5 * (size_t)D * sizeof(float), 256));
+    MainGeom g;
+    int rc = main_geometry(model, B, &g);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pack, dim3(cdiv(D, 256)), dim3(256), 0, s, *model, params_dev, pack);
+    hipLaunchKernelGGL(k_mask_meta, dim3(1), dim3(256), 0, s, mask_dev, B, meta_dev);
+    if (!eps_dev) hipLaunchKernelGGL(k_px_keys, dim3(cdiv(B, 256)), dim3(256), 0, s, jax_key_dev, B, skeys);
+    MainArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_model_scalars(model, &a);
+    a.X = X_dev;
+    a.y = y_dev;
+    a.mask = mask_dev;
+    a.skeys = skeys;
+    a.eps_ext = eps_dev;
+    a.pack = pack;
+    a.px_grads = px_grads_dev;
+    a.px_loss = px_loss_dev;
+    a.meta = meta_dev;
+    a.B = B;
+    a.row_lo = 0;
+    a.row_hi = B;
+    a.clip = 1.0f;
+    return launch_main<1>(s, g, a);
+}
+
+int d3p_clip_rows(void* stream, float* px_grads_dev, uint32_t B, uint32_t P, float c)
+{
+    D3P_REQUIRE(c != 0.0f, "The clipping threshold must be greater than 0.");  // svi.py:119-120
+    D3P_REQUIRE(px_grads_dev || B == 0 || P == 0, "d3p_clip_rows: null pointer");
+    if (B == 0 || P == 0) return D3P_OK;
+    hipLaunchKernelGGL(k_clip_rows, dim3(cdiv((uint64_t)B * 64, 256)), dim3(256), 0, (hipStream_t)stream, px_grads_dev,
+                       B, P, c);
+    return check_launch("d3p_clip_rows");
+}
+
+int d3p_full_norm(void* stream, const float* v_dev, uint64_t n, float* out_dev, void* workspace_dev,
+                  size_t workspace_bytes)
+{
+    (void)workspace_dev;
+    (void)workspace_bytes;
+    D3P_REQUIRE(out_dev && (v_dev || n == 0), "d3p_full_norm: null pointer");
+    hipLaunchKernelGGL(k_full_norm, dim3(1), dim3(256), 0, (hipStream_t)stream, v_dev, n, out_dev);
+    return check_launch("d3p_full_norm");
+}
+
+int d3p_combine(void* stream, const float* px_grads_dev, const float* px_loss_dev, uint32_t B, uint32_t P,
+                float* avg_dev, float* loss_dev)
+{
+    D3P_REQUIRE(px_grads_dev && avg_dev, "d3p_combine: null pointer");
+    D3P_REQUIRE(B >= 1 && P >= 1, "d3p_combine: empty input");
+    hipLaunchKernelGGL(k_combine, dim3(cdiv(P, D3P_FIN_COLS)), dim3(256), 0, (hipStream_t)stream, px_grads_dev,
+                       px_loss_dev, B, P, avg_dev, loss_dev);
+    return check_launch("d3p_combine");
+}
+
+int d3p_perturb(void* stream, const uint32_t* key_dev, const float* avg_dev, const int32_t* site_sizes_host,
+                int n_sites, float dp_scale, float c, const float* meta_dev, float obs_scale, float* out_dev,
+                uint32_t* site_keys_dev)
+{
+    D3P_REQUIRE(key_dev && avg_dev && site_sizes_host && meta_dev && out_dev && site_keys_dev,
+                "d3p_perturb: null pointer");
+    D3P_REQUIRE(n_sites >= 1, "d3p_perturb: need at least one site");
+    int rc = d3p_rng_split(stream, key_dev, n_sites, site_keys_dev);  // svi.py:491
+    if (rc) return rc;
+    size_t off = 0;
+    for (int k = 0; k < n_sites; ++k) {
+        const int32_t n = site_sizes_host[k];
+        D3P_REQUIRE(n >= 0, "d3p_perturb: negative site size");
+        if (n > 0)
+            hipLaunchKernelGGL(k_perturb_site, dim3(cdiv(cdiv(n, 16), 128)), dim3(128), 0, (hipStream_t)stream,
+                               (const uint32_t*)(site_keys_dev + 16 * k), avg_dev + off, (uint32_t)n, dp_scale, c,
+                               meta_dev, obs_scale, out_dev + off);
+        off += (size_t)n;
+    }
+    return check_launch("d3p_perturb");
+}
+
+int d3p_perturb_apply(void* stream, const float* avg_dev, const float* noise_dev, uint64_t n, float dp_scale, float c,
+                      const float* meta_dev, float obs_scale, float* out_dev)
+{
+    D3P_REQUIRE((avg_dev && noise_dev && out_dev) || n == 0, "d3p_perturb_apply: null pointer");
+    D3P_REQUIRE(meta_dev, "d3p_perturb_apply: null meta");
+    if (n == 0) return D3P_OK;
+    hipLaunchKernelGGL(k_perturb_apply, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, avg_dev, noise_dev, n,
+                       dp_scale, c, meta_dev, obs_scale, out_dev);
+    return check_launch("d3p_perturb_apply");
+}
+
+int d3p_adam_step(void* stream, float* params_dev, float* m_dev, float* v_dev, int32_t* step_dev,
+                  const float* grads_dev, uint32_t P, float lr, float b1, float b2, float eps)
+{
+    D3P_REQUIRE(params_dev && m_dev && v_dev && step_dev && grads_dev, "d3p_adam_step: null pointer");
+    d3p_dpsvi_hyper h;
+    h.clip = 1.f; h.dp_scale = 0.f; h.lr = lr; h.b1 = b1; h.b2 = b2; h.adam_eps = eps;
+    if (P > 0)
+        hipLaunchKernelGGL(k_adam, dim3(cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, params_dev, m_dev, v_dev,
+                           (const int32_t*)step_dev, grads_dev, P, h);
+    hipLaunchKernelGGL(k_incr_i32, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+    return check_launch("d3p_adam_step");
+}
+
+int d3p_sgd_step(void* stream, float* params_dev, int32_t* step_dev, const float* grads_dev, uint32_t P, float lr)
+{
+    D3P_REQUIRE(params_dev && step_dev && grads_dev, "d3p_sgd_step: null pointer");
+    if (P > 0)
+        hipLaunchKernelGGL(k_sgd, dim3(cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, params_dev, grads_dev, P, lr);
+    hipLaunchKernelGGL(k_incr_i32, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+    return check_launch("d3p_sgd_step");
+}
+
+int d3p_synth_logreg(void* stream, uint32_t seed, uint64_t row0, uint64_t n_rows, int32_t d, float* X_dev,
+                     float* y_dev)
+{
+    D3P_REQUIRE(X_dev && y_dev && d >= 1, "d3p_synth_logreg: bad arguments");
+    if (n_rows == 0) return D3P_OK;
+    // at most 2^31 threads per launch: chunk the rows
+    const uint64_t chunk = 1ull << 22;
+    for (uint64_t r = 0; r < n_rows; r += chunk) {
+        const uint64_t n = (n_rows - r < chunk) ? n_rows - r : chunk;
+        hipLaunchKernelGGL(k_synth_logreg, dim3(cdiv(n * 64, 256)), dim3(256), 0, (hipStream_t)stream, seed, row0 + r, n,
+                           d, X_dev + r * (uint64_t)d, y_dev + r);
+    }
+    return check_launch("d3p_synth_logreg");
+}
+
+}  // extern "C"

@@ -237,14 +237,18 @@ int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_d
                         const float* X_dev, const float* y_dev, uint32_t num_steps,
                         float* losses_dev, void* workspace_dev, size_t workspace_bytes);
 
-/* Times only the dominant kernel (fused gradient/clip/sum) of one step with HIP events on `stream`:
- * returns the average duration in microseconds over `reps` launches in *avg_us (host pointer).
+/* Times only the dominant kernel (fused gradient/clip/sum) of one step over `reps` launches on
+ * `stream` (host out-pointers):
+ *   *avg_us       device-side duration: every workgroup stamps the 100 MHz wall clock at entry and
+ *                 exit, duration = last exit - first entry (what rocprofv3's kernel trace reports);
+ *   *avg_event_us HIP start/stop events recorded around each launch (hipExtLaunchKernel); includes
+ *                 the ~4 us dispatch floor an empty kernel also shows (optional, may be NULL).
  * Synchronises the stream; measurement tooling for bench.py, not part of the training path. */
 int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model,
                                      const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                                      const d3p_batch_source* src, const float* X_dev,
                                      const float* y_dev, void* workspace_dev, size_t workspace_bytes,
-                                     int reps, float* avg_us);
+                                     int reps, float* avg_us, float* avg_event_us);
 
 /* Synthetic workload of SURVEY 8(d) / examples/logistic_regression.py:88-104, generated on device:
  * X[r][c] and y[r] are pure functions of (seed, global row, column). */

@@ -210,15 +210,18 @@ class TestReferenceDPSVI:
 def test_gradient_manipulators(gpu):
     from d3p_amd.svi import clip_gradient, full_norm, normalize_gradient
     t = lambda *a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    ones = lambda *shape: torch.ones(shape, device="cuda")
+    ref_tree = (ones(17, 2, 3), ones(2, 54), (ones(2, 3), ones(3, 4, 5)), ())
+    assert abs(float(full_norm(ref_tree)) - 16.613247) < 1e-5   # sqrt(276), tests/test_gradient_manipulators.py:70-79
     tree = ([t(1, 2), torch.zeros((0,), device="cuda")], {"a": t(3, 4, 5).reshape(3, 1), "b": (t(6), t(7, 8, 9, 10))})
-    assert abs(float(full_norm(tree)) - 16.613247) < 1e-5   # sqrt(276), tests/test_gradient_manipulators.py:70-79
+    assert abs(float(full_norm(tree)) - np.sqrt(385.0)) < 1e-5
     for empty in (None, [], ()):
         assert full_norm(empty) == 0.0                       # :62-68
     with pytest.raises(ValueError):
         clip_gradient(tree, 0.0)                             # :101-103
     for c in (100.0, float("inf")):                          # identity when C >= norm (:81-99)
         out = clip_gradient(tree, c)
-        assert abs(float(full_norm(out)) - 16.613247) < 1e-5
+        assert abs(float(full_norm(out)) - np.sqrt(385.0)) < 1e-5
     out = clip_gradient(tree, 3.0)
     assert float(full_norm(out)) <= 3.0 + 1e-6
     assert torch.allclose(out[1]["b"][1] / out[1]["b"][1][0], t(7, 8, 9, 10) / 7)   # direction preserved
