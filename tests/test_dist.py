@@ -1,0 +1,209 @@
+"""Multi-GPU path (d3p_amd/dist.py): row sharding, one all-reduce of [clipped sum | loss | count]
+per step, noise added once after the reduce.
+
+CPU part (world_size 2, gloo): the orchestration in d3p_amd.dist.run_steps is driven with an
+engine whose compute is the CPU oracle (test infrastructure only) and must reproduce the
+single-process trajectory.  GPU part: two "virtual ranks" with disjoint row ranges on one device,
+their partial sums added by hand, against the single-rank fused step.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N, D, B, STEPS = 600, 12, 40, 4
+
+
+def _problem():
+    r = np.random.default_rng(3)
+    X = r.normal(size=(N, D)).astype(np.float32)
+    y = (r.random(N) < 0.5).astype(np.float32)
+    return X, y
+
+
+class OracleEngine:
+    """Implements the engine interface of d3p_amd.dist with oracle/ as the compute."""
+
+    def __init__(self, O, X, y, lo, hi):
+        self.O, self.X, self.y, self.lo, self.hi = O, X, y, lo, hi
+        self.spec = O.logreg_spec(D, False, 1.0, 1.0, lik_scale=N, obs_scale=N)
+        self.hy = O.Hyper(1.0, 0.8, 1e-2, 0.9, 0.999, 1e-8)
+
+    def begin(self, state, batch_key, first_batch):
+        O = self.O
+        self.key = np.array(state["key"], np.uint32).reshape(4, 4)
+        self.params, self.m, self.v = (np.array(state[k], np.float32) for k in ("params", "m", "v"))
+        self.step = int(state["step"])
+        self.bkey, self.bi = np.array(batch_key, np.uint32).reshape(4, 4), int(first_batch)
+
+    def local_sums(self):
+        O = self.O
+        self.ks = O.split(self.key, 3)
+        jax_key = O.convert_to_jax_rng_key(self.ks[1])
+        idx = O.feistel_sample(O.fold_in(self.bkey, self.bi), N, B)           # every rank: same indices
+        mine = np.nonzero((idx >= self.lo) & (idx < self.hi))[0]              # positions whose rows I hold
+        sums = np.zeros(2 * D + 2, np.float32)
+        if mine.size:
+            eps = np.stack([O.tf_normal(O.px_sample_key(jax_key, B, int(p)), D) for p in mine])  # global positions
+            rows = idx[mine] - self.lo
+            L, G, n, f = O.logreg_px_grads(self.spec, self.params[:D], self.params[D:], self.X[rows], self.y[rows], eps)
+            G = O.clip_rows(G, self.hy.clip)
+            sums[:2 * D] = G.astype(np.float64).sum(axis=0)
+            sums[2 * D] = (L / (N * f)).astype(np.float64).sum()               # undo the obs_scale * factor rescale
+            sums[2 * D + 1] = mine.size
+        return torch.from_numpy(sums)
+
+    def finalize(self, sums):
+        O = self.O
+        s = sums.numpy()
+        n = float(s[2 * D + 1])
+        factor = 0.0 if n == 0 else B / n
+        avg = s[:2 * D] / B
+        g = O.perturb(self.ks[2], avg, [D, D], self.hy.dp_scale, self.hy.clip, n, N, factor)
+        self.params, self.m, self.v = O.adam(self.params, self.m, self.v, g, self.step, lr=self.hy.lr)
+        self.step += 1
+        self.bi += 1
+        self.key = self.ks[0]
+        return torch.tensor([s[2 * D] / B * N * factor])
+
+    def end(self):
+        return {"key": self.key, "params": self.params, "m": self.m, "v": self.v, "step": self.step}
+
+
+def _single_process_reference(O):
+    X, y = _problem()
+    spec = O.logreg_spec(D, False, 1.0, 1.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.8, 1e-2, 0.9, 0.999, 1e-8)
+    st = O.LogregState(O.PRNGKey(10), D, np.zeros(D, np.float32), np.full(D, -2.0, np.float32))
+    losses = []
+    for t in range(STEPS):
+        idx = O.feistel_sample(O.fold_in(O.PRNGKey(20), 5 + t), N, B)
+        losses.append(O.logreg_update(spec, hy, st, X[idx], y[idx])[0])
+    return st, np.array(losses)
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from d3p_amd.dist import run_steps, shard_rows
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    X, y = _problem()
+    lo, hi = shard_rows(N, rank, world)
+    eng = OracleEngine(O, X[lo:hi], y[lo:hi], lo, hi)
+    st0 = {"key": O.PRNGKey(10), "params": np.concatenate([np.zeros(D), np.full(D, -2.0)]), "m": np.zeros(2 * D),
+           "v": np.zeros(2 * D), "step": 0}
+    st, losses = run_steps(eng, st0, O.PRNGKey(20), 5, STEPS)
+    out[rank] = (st["params"].copy(), st["key"].copy(), st["step"], losses.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_single_process(O):
+    import torch.multiprocessing as mp
+    ref, ref_losses = _single_process_reference(O)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert set(out.keys()) == {0, 1}
+    p0, k0, s0, l0 = out[0]
+    p1, k1, s1, l1 = out[1]
+    assert np.array_equal(p0, p1) and np.array_equal(k0, k1) and s0 == s1 == STEPS   # replicas stay identical
+    assert np.array_equal(k0.ravel(), ref.key)
+    np.testing.assert_allclose(p0, ref.params, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(l0, ref_losses, rtol=1e-5)
+
+
+def test_single_rank_run_steps_skips_the_collective(O):
+    from d3p_amd.dist import run_steps
+    X, y = _problem()
+    eng = OracleEngine(O, X, y, 0, N)
+    st0 = {"key": O.PRNGKey(10), "params": np.concatenate([np.zeros(D), np.full(D, -2.0)]), "m": np.zeros(2 * D),
+           "v": np.zeros(2 * D), "step": 0}
+    st, losses = run_steps(eng, st0, O.PRNGKey(20), 5, STEPS)
+    ref, ref_losses = _single_process_reference(O)
+    np.testing.assert_allclose(st["params"], ref.params, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(losses.numpy(), ref_losses, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_virtual_ranks_on_one_gpu_match_single_rank(gpu, world):
+    """The real kernels with disjoint row ranges: summing the ranks' partial sums by hand and
+    finalising once reproduces the single-rank fused step (sharding + ownership logic)."""
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
+    from d3p_amd.svi import DPSVI, DPSVIState
+    n, d, Bg, steps = 5000, 64, 96, 3
+    r = np.random.default_rng(1)
+    X = torch.tensor(r.normal(size=(n, d)).astype(np.float32)).cuda()
+    y = torch.tensor((r.random(n) < 0.5).astype(np.float32)).cuda()
+    model = LogisticRegression(d)
+    svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-2), Trace_ELBO(), 1.0, 0.6, N=n)
+    params = torch.cat([torch.zeros(d), torch.full((d,), -2.0)]).cuda()
+    st0 = DPSVIState(svi.optim.init(params), rng.PRNGKey(10), float(n))
+    bkey = rng.PRNGKey(20)
+
+    single = ddist.HipEngine(svi, X, y, n, 0, n, L.D3P_BATCH_FEISTEL, Bg)
+    ref_state, ref_losses = ddist.run_steps(single, st0, bkey, 7, steps)
+
+    engines = []
+    for rk in range(world):
+        lo, hi = ddist.shard_rows(n, rk, world)
+        engines.append(ddist.HipEngine(svi, X[lo:hi].contiguous(), y[lo:hi].contiguous(), n, lo, hi,
+                                       L.D3P_BATCH_FEISTEL, Bg))
+    for e in engines:
+        e.begin(st0, bkey, 7)
+    losses = []
+    for _ in range(steps):
+        total = None
+        for e in engines:
+            s = e.local_sums().clone()
+            total = s if total is None else total + s          # what the all-reduce computes
+        assert float(total[-1]) == Bg                            # every example is owned by exactly one rank
+        outs = [e.finalize(total).clone() for e in engines]
+        assert all(torch.equal(o, outs[0]) for o in outs)
+        losses.append(outs[0])
+    finals = [e.end() for e in engines]
+    for f in finals:
+        assert torch.equal(f.rng_key, ref_state.rng_key)
+        assert torch.equal(f.optim_state[1], finals[0].optim_state[1])      # replicas bitwise identical
+        np.testing.assert_allclose(f.optim_state[1].cpu().numpy(), ref_state.optim_state[1].cpu().numpy(),
+                                   rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(torch.stack(losses).reshape(-1).cpu().numpy(), ref_losses.cpu().numpy(), rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_dist_run_steps_equals_svi_run_steps(gpu):
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    from d3p_amd.minibatch import subsample_batchify_data
+    from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
+    from d3p_amd.svi import DPSVI, DPSVIState
+    n, d, Bg, steps = 4000, 512, 256, 40
+    r = np.random.default_rng(2)
+    X = torch.tensor(r.normal(size=(n, d)).astype(np.float32)).cuda()
+    y = torch.tensor((r.random(n) < 0.5).astype(np.float32)).cuda()
+    model = LogisticRegression(d)
+    svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-3), Trace_ELBO(), 1.0, 1.0, N=n)
+    params = torch.cat([torch.zeros(d), torch.full((d,), -2.0)]).cuda()
+    st0 = DPSVIState(svi.optim.init(params), rng.PRNGKey(1), float(n))
+    bkey = rng.PRNGKey(2)
+    _, get_batch = subsample_batchify_data((X, y), Bg)
+    a_state, a_losses = svi.run_steps(st0, get_batch, bkey, 0, steps)       # batched key chain (32 + 8 steps)
+    eng = ddist.HipEngine(svi, X, y, n, 0, n, L.D3P_BATCH_FEISTEL, Bg)
+    b_state, b_losses = ddist.run_steps(eng, st0, bkey, 0, steps)           # one step per call
+    assert torch.equal(a_state.rng_key, b_state.rng_key)
+    assert int(a_state.optim_state[0]) == int(b_state.optim_state[0]) == steps
+    np.testing.assert_allclose(a_losses.cpu().numpy(), b_losses.cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(a_state.optim_state[1].cpu().numpy(), b_state.optim_state[1].cpu().numpy(),
+                               rtol=1e-5, atol=1e-6)

@@ -1,0 +1,162 @@
+"""Host-side logic and the C-ABI boundary, without a GPU: the shared library loads, exports every
+symbol include/d3p_hip.h declares, the Python surface validates arguments like the reference, and
+compute entry points fail loudly when no device is present (there is no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NO_GPU = not torch.cuda.is_available()
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import d3p_amd._lib as L
+    L.build()
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "d3p_hip.h")).read()
+    declared = set(re.findall(r"\b(d3p_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    raw = ctypes.CDLL(L._SO)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/d3p_hip.h but not exported"
+    assert declared == set(L.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
+    assert lib.d3p_abi_version() == 1
+    assert isinstance(lib.d3p_device_count(), int)
+
+
+def test_struct_layouts_match_the_header():
+    import d3p_amd._lib as L
+    assert ctypes.sizeof(L.LogregModel) == 24
+    assert ctypes.sizeof(L.DpsviHyper) == 24
+    assert ctypes.sizeof(L.DpsviState) == 48 and L.DpsviState.params.offset == 16
+    assert ctypes.sizeof(L.BatchSource) == 64 and L.BatchSource.batch_key.offset == 16
+    assert L.BatchSource.n_rows.offset == 40
+
+
+def test_error_codes_without_touching_the_device():
+    import d3p_amd._lib as L
+    lib = L.load()
+    assert lib.d3p_rng_split(None, None, 2, None) == -1
+    assert b"null pointer" in lib.d3p_last_error()
+    assert lib.d3p_clip_rows(None, None, 0, 0, 0.0) == -1          # svi.py:119-120
+    assert b"clipping threshold" in lib.d3p_last_error()
+    with pytest.raises(ValueError):
+        L.check(-1)
+    with pytest.raises(L.D3PError):
+        L.check(-2)
+    assert lib.d3p_poisson_select_workspace(10**6) > 10**6 // 8
+    m = L.LogregModel(512, 0, 1.0, 1.0, 1e6, 1e-6)
+    src = L.BatchSource(L.D3P_BATCH_FEISTEL, 4096, 0.0, 0, None, None, None, 10**6, 0, 10**6)
+    ws = lib.d3p_dpvi_logreg_workspace(ctypes.byref(m), ctypes.byref(src))
+    assert 8 * 2**20 < ws < 64 * 2**20
+
+
+@pytest.mark.skipif(not NO_GPU, reason="checks the no-device behaviour")
+def test_compute_fails_loudly_without_a_gpu():
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd.util import sample_from_array
+    with pytest.raises(L.D3PError, match="no CPU fallback"):
+        rng.PRNGKey(0)
+    with pytest.raises(L.D3PError):
+        sample_from_array(torch.zeros(4, 4), torch.zeros(10), 3)
+    with pytest.raises(L.D3PError):
+        from d3p_amd.svi import full_norm
+        full_norm([torch.ones(3)])
+
+
+def test_product_package_does_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "d3p_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "libd3p_oracle" not in text, f
+
+
+def test_seed_packing_matches_oracle_layout(O):
+    import d3p_amd.random as rng
+    for seed in (0, 7, 2**255 + 3, b"xyz", [1, 2, 3]):
+        assert np.array_equal(rng._state_words(seed).reshape(4, 4), O.PRNGKey(seed))
+    with pytest.raises(ValueError):
+        rng._state_words(bytes(40))
+
+
+def test_batchifier_argument_validation_and_counts():
+    """reference d3p/minibatch.py:75-91, :169-179, :192 and tests/test_minibatch.py:117-135, :242-250"""
+    from d3p_amd.minibatch import (batch_size_to_q, poisson_batchify_data, q_to_batch_size,
+                                   split_batchify_data, subsample_batchify_data)
+    data = (torch.zeros(105, 3), torch.zeros(105))
+    for factory in (subsample_batchify_data, split_batchify_data):
+        with pytest.raises(ValueError):
+            factory(data)
+        with pytest.raises(ValueError):
+            factory(data, batch_size=10, q=0.1)
+        with pytest.raises(ValueError):
+            factory(())
+        with pytest.raises(ValueError):
+            factory((torch.zeros(5, 2), torch.zeros(6)), batch_size=2)
+    init, _ = subsample_batchify_data(data, batch_size=10)
+    key = object()
+    assert init(key) == (10, key)                       # N // B, key returned unchanged
+    init, _ = subsample_batchify_data(data, q=0.1)
+    assert init(key)[0] == 10
+    with pytest.raises(ValueError):
+        poisson_batchify_data((), 0.1, 10)
+    with pytest.raises(ValueError):
+        poisson_batchify_data([torch.zeros(5)], 0.1, 10)          # must be a tuple
+    with pytest.raises(ValueError):
+        poisson_batchify_data(data, 1.5, 10)
+    with pytest.raises(ValueError):
+        poisson_batchify_data(data, 0.1, -1)
+    init, get_batch = poisson_batchify_data((torch.zeros(100, 2),), 0.1, 100)
+    assert init(key) == (10, key)
+    with pytest.raises(ZeroDivisionError):
+        poisson_batchify_data((torch.zeros(5, 2),), 0.1, 5)[0](key)   # int(q * N) == 0, as the reference
+    _, gb = poisson_batchify_data((torch.zeros(105, 1),), 0.3, 0.9)
+    assert gb.source.batch_size == 39                   # tests/test_minibatch.py:341-351
+    assert q_to_batch_size(0.1, 105) == 10 and batch_size_to_q(10, 100) == 0.1
+
+
+def test_dpsvi_constructor_and_accounting_validation():
+    from d3p_amd.models import SGD, AutoDiagonalNormal, LogisticRegression
+    from d3p_amd.svi import DPSVI, DPSVIState, clip_gradient, full_norm
+    with pytest.raises(ValueError):
+        DPSVI(None, None, SGD(1.0), None, float("inf"), 1.0)
+    with pytest.raises(ValueError):
+        DPSVI(None, None, SGD(1.0), None, float("nan"), 1.0)
+    svi = DPSVI(None, None, SGD(1.0), None, 1.0, 1.0, num_obs_total=100)
+    with pytest.raises(ValueError):
+        svi.get_epsilon(1e-5, 0.01)
+    assert svi._validate_epochs_and_iter(2, None, 0.01) == 200
+    assert full_norm(None) == 0.0 and full_norm([]) == 0.0 and full_norm(()) == 0.0
+    with pytest.raises(ValueError):
+        clip_gradient([torch.ones(2)], 0.0)
+    st = DPSVIState(None, "k", 3.0)
+    assert svi._update_state_rng(st, "k2") == DPSVIState(None, "k2", 3.0)
+    with pytest.raises(ValueError):
+        AutoDiagonalNormal(LogisticRegression(4), init_scale=0.0)
+    g = AutoDiagonalNormal(LogisticRegression(4))
+    assert abs(np.log1p(np.exp(g.unconstrained_init_scale())) - 0.1) < 1e-12
+
+
+def test_tree_flatten_order_is_jax_like():
+    from d3p_amd.svi import _tree_flatten, _tree_unflatten
+    tree = {"b": (1, [2, 3]), "a": 0, "c": None}
+    leaves, td = _tree_flatten(tree)
+    assert leaves == [0, 1, 2, 3]                        # dict keys sorted, None has no leaves
+    assert _tree_unflatten(td, [10, 11, 12, 13]) == {"a": 10, "b": (11, [12, 13]), "c": None}
+
+
+def test_shard_rows_partition():
+    from d3p_amd.dist import shard_rows
+    for n, w in [(10**8, 8), (1000003, 8), (7, 8), (100, 1), (5, 2)]:
+        parts = [shard_rows(n, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in parts]
+        assert max(sizes) - min(sizes) <= 1

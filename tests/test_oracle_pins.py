@@ -1,0 +1,284 @@
+"""Pins the CPU oracle (oracle/) before it is trusted as the checker of the HIP path.
+
+Sources of truth used here (none of them is this repository): RFC 8439, OpenSSL's chacha20,
+Random123 / JAX-published threefry values, scipy.special.erfinv (float64), torch autograd on an
+ELBO written with torch.distributions, and every known-answer test the reference holds for the
+path (tests/golden/external_vectors.json cites them).  What remains UNPINNED (the ChaCha key
+layout of jax-chacha-prng, numpyro's key plumbing) is stated in oracle/d3p_oracle.c's header.
+"""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.stats
+from scipy.special import erfinv
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EXT = json.load(open(os.path.join(HERE, "golden", "external_vectors.json")))
+
+
+def _state(key_bytes, counter, nonce_bytes):
+    st = np.zeros(16, np.uint32)
+    st[:4] = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574]
+    st[4:12] = np.frombuffer(key_bytes, "<u4")
+    st[12] = counter
+    st[13:16] = np.frombuffer(nonce_bytes, "<u4")
+    return st
+
+
+def test_chacha20_block_rfc8439(O):
+    v = EXT["rfc8439_2_3_2"]
+    out = O.chacha20_block(_state(bytes.fromhex(v["key_bytes"]), v["counter"], bytes.fromhex(v["nonce_bytes"])))
+    assert [f"{int(w):08x}" for w in out] == v["output_words"]
+    ks = O.chacha20_block(_state(bytes(32), 0, bytes(12))).astype("<u4").tobytes()
+    assert ks[:16].hex() == EXT["rfc8439_a1_1"]["keystream_prefix"]
+    # the keystream of PRNGKey(0) (zero key, counter 0, nonce 0) starts with the same bytes
+    assert O.random_bits(O.PRNGKey(0), 8, (16,)).tobytes().hex() == EXT["rfc8439_a1_1"]["keystream_prefix"]
+
+
+@pytest.mark.skipif(shutil.which("openssl") is None, reason="openssl not installed")
+def test_chacha20_keystream_vs_openssl(O):
+    r = np.random.default_rng(0)
+    for _ in range(3):
+        key = r.integers(0, 256, 32, dtype=np.uint8).tobytes()
+        nonce = r.integers(0, 256, 12, dtype=np.uint8).tobytes()
+        ctr = int(r.integers(0, 2**31))
+        st = _state(key, ctr, nonce).reshape(4, 4)
+        mine = O.random_bits(st, 32, (16 * 5,)).astype("<u4").tobytes()
+        iv = ctr.to_bytes(4, "little") + nonce
+        p = subprocess.run(["openssl", "enc", "-chacha20", "-K", key.hex(), "-iv", iv.hex()], input=bytes(len(mine)),
+                           capture_output=True)
+        if p.returncode != 0:
+            pytest.skip("openssl has no chacha20")
+        assert p.stdout == mine
+
+
+def test_threefry_and_jax_layouts(O):
+    for c in EXT["threefry2x32_20"]["cases"]:
+        k, ctr = [int(x, 16) for x in c["key"]], [int(x, 16) for x in c["ctr"]]
+        assert [f"{int(w):08x}" for w in O.threefry2x32(k[0], k[1], ctr[0], ctr[1])] == c["out"]
+    assert O.tf_split([0, 0], 2).tolist() == EXT["jax_split_prngkey0"]["value"]
+    assert O.tf_random_words([0, 1701], 3).tolist() == EXT["jax_random_bits_1701"]["value"]
+    assert abs(float(O.tf_normal([0, 0], 1)[0]) - EXT["jax_normal_prngkey0"]["value"]) < 1e-7
+    # jax fold_in(key, data) = threefry_2x32(key, [0, data])
+    assert O.tf_fold_in([7, 9], 5).tolist() == O.threefry2x32(7, 9, 0, 5).tolist()
+
+
+def test_erfinv_and_normal_against_float64(O):
+    u = np.concatenate([np.linspace(-0.999999, 0.999999, 20001), [np.nextafter(np.float32(-1), np.float32(0))]])
+    u = u.astype(np.float32)
+    got = O.erfinv_f32(u)
+    exp = erfinv(u.astype(np.float64))
+    assert np.max(np.abs(got - exp) / np.maximum(np.abs(exp), 1e-3)) < 1e-6
+    key = O.PRNGKey(3)
+    lo = np.nextafter(np.float32(-1), np.float32(0))
+    z = O.normal(key, (100000,))
+    t = np.sqrt(2.0) * erfinv(O.uniform(key, (100000,), lo, 1.0).astype(np.float64))
+    assert np.max(np.abs(z - t) / np.maximum(np.abs(t), 1e-3)) < 1e-6
+    assert scipy.stats.kstest(z, "norm").pvalue > 0.01 and abs(z.mean()) < 5 / np.sqrt(z.size)
+
+
+def test_random_bits_widths_are_views_of_one_keystream(O):
+    k = O.PRNGKey(11)
+    raw = O.random_bits(k, 8, (64,)).tobytes()
+    assert O.random_bits(k, 16, (32,)).astype("<u2").tobytes() == raw
+    assert O.random_bits(k, 32, (16,)).astype("<u4").tobytes() == raw
+    assert O.random_bits(k, 64, (8,)).astype("<u8").tobytes() == raw
+    # split / fold_in / random_bits never collide (domain separation by nonce tag)
+    kids = O.split(k, 4).reshape(4, 16)
+    assert len({bytes(c) for c in kids} | {bytes(O.fold_in(k, 0).ravel())}) == 5
+    assert not np.array_equal(kids[0, 4:12], O.random_bits(k, 32, (8,)))
+    assert np.all(kids[:, 12:] == 0) and np.all(kids[:, :4] == k.ravel()[:4])
+
+
+def test_prngkey_seed_forms(O):
+    assert np.array_equal(O.PRNGKey(5), O.PRNGKey((5).to_bytes(32, "big")))
+    assert np.array_equal(O.PRNGKey(b"ab"), O.PRNGKey(b"ab" + bytes(30)))
+    assert np.array_equal(O.PRNGKey(2**256 + 7), O.PRNGKey(7))
+    with pytest.raises(ValueError):
+        O.PRNGKey(bytes(33))
+
+
+def test_randint_reference_behaviour(O):
+    ka = EXT["d3p_known_answers"]["randint_single_value"]
+    assert np.all(O.randint(O.PRNGKey(1), (100,), ka["minval"], ka["maxval"]) == ka["value"])
+    x = O.randint(O.PRNGKey(2), (20000,), 0, 10)
+    assert x.min() == 0 and x.max() == 9
+    assert scipy.stats.chisquare(np.bincount(x, minlength=10)).pvalue > 0.01
+    x = O.randint(O.PRNGKey(3), (5000,), -5, 1 << 15)
+    assert x.min() >= -5 and x.max() < (1 << 15)
+
+
+def test_feistel_permutation_properties(O):
+    """reference tests/test_util.py:331-373 + the structural quirks of util.py:229-301"""
+    k = O.PRNGKey(0)
+    assert np.unique(O.feistel_sample(k, 10**6, 978)).size == 978
+    for n in (100, 99, 1):
+        s = O.feistel_sample(O.PRNGKey(n), 100, n)
+        assert np.unique(s).size == n and s.max() < 100
+    assert np.array_equal(np.sort(O.feistel_sample(k, 105, 105)), np.arange(105))
+    assert O.feistel_sample(k, 1, 1).tolist() == [0]
+    assert O.feistel_sample(k, 2, 2).tolist() == [0, 1]   # bits = 1: lower half empty -> identity
+    full = O.feistel_sample(O.PRNGKey(9), 1 << 12, 1 << 12)
+    assert np.array_equal(np.sort(full), np.arange(1 << 12))
+    assert not np.array_equal(full, np.arange(1 << 12))
+
+
+def test_poisson_select_semantics(O):
+    ka = EXT["d3p_known_answers"]
+    N, q = 100, 0.1
+    key = O.PRNGKey(0)
+    u = O.uniform(key, (N,))
+    sel = np.nonzero(u <= np.float32(q))[0]
+    idx, nsel, nvalid = O.poisson_select(key, q, N, N)
+    assert nsel == sel.size == nvalid
+    assert np.array_equal(idx[:nsel], sel[::-1])                      # descending selected indices
+    assert np.array_equal(idx[nsel:], np.setdiff1d(np.arange(N), sel)[::-1])
+    # argsort(bool)[::-1][:cutoff] with a stable sort (minibatch.py:37)
+    assert np.array_equal(idx, np.argsort(u <= np.float32(q), kind="stable")[::-1])
+    idx, nsel, nvalid = O.poisson_select(key, 0.9, N, 10)
+    assert nvalid == 10 and np.array_equal(idx, np.nonzero(O.uniform(key, (N,)) <= np.float32(0.9))[0][::-1][:10])
+    assert O.poisson_select(key, 0.9, N, 10, suppress=True)[2] == 0
+    assert N // int(q * N) == ka["poisson_num_batches"]["num_batches"]
+    pq = ka["poisson_quantile"]
+    assert int(scipy.stats.poisson(pq["N"] * pq["q"]).ppf(pq["mass"])) == pq["max_batch_size"]
+    sizes = [O.poisson_select(O.fold_in(key, i), q, N, N)[1] for i in range(1000)]
+    assert abs(np.mean(sizes) - q * N) < 4 * np.sqrt(q * (1 - q) * N / 1000)
+
+
+def test_gradient_manipulator_known_answers(O):
+    ka = EXT["d3p_known_answers"]
+    tree = [np.ones(s, np.float32) for s in ka["full_norm_tree"]["shapes"]] + [()]
+    assert abs(O.full_norm(tree) - ka["full_norm_tree"]["value"]) < 1e-5
+    assert O.full_norm(None) == 0 and O.full_norm([]) == 0 and O.full_norm(()) == 0
+    with pytest.raises(ValueError):
+        O.clip_rows(np.ones((2, 3), np.float32), 0.0)
+    c = ka["clip_norms"]
+    g = np.concatenate([np.repeat([1.0, 0.0], 10).reshape(2, 10), np.repeat([0.0, 1.0], 2).reshape(2, 2)], axis=1)
+    assert np.allclose(np.linalg.norm(g, axis=1), c["norms"])
+    assert np.allclose(np.linalg.norm(O.clip_rows(g, c["c"]), axis=1), c["clipped"])
+    big = np.full((3, 7), 5.0, np.float32)
+    assert np.array_equal(O.clip_rows(big, 1e9), big)      # identity when C >= norm
+    loss, avg = O.combine(g.astype(np.float32), np.array([1.0, 3.0], np.float32))
+    assert loss == 2.0 and np.allclose(avg, g.mean(axis=0))
+
+
+def test_perturbation_known_answer(O):
+    ka = EXT["d3p_known_answers"]["perturbation_std"]
+    avg = np.full(20000, 0.8, np.float32)
+    out = O.perturb(O.PRNGKey(9782346), avg, [10000, 10000], ka["dp_scale"], ka["c"], ka["num_elements"],
+                    ka["obs_scale"], ka["factor"])
+    for site in (out[:10000], out[10000:]):
+        assert abs(site.std() - ka["std"]) < 1e-2
+        assert abs(site.mean() - 0.8 * ka["obs_scale"] * ka["factor"]) < 5e-3
+    assert not np.allclose(out[:10000], out[10000:])        # different key per site (svi.py:491)
+    out2 = O.perturb(O.split(O.PRNGKey(9782346), 2)[1], avg, [10000, 10000], 1.0, 2.0, 8, 0.3, 1.25)
+    assert not np.allclose(out, out2)
+
+
+def test_masking_known_answer(O):
+    ka = EXT["d3p_known_answers"]["mask_factor"]
+    B, d, N = ka["batch"], 3, 100
+    spec = O.logreg_spec(d, False, lik_scale=N, obs_scale=N)
+    mask = (np.arange(B) < ka["num_elements"]).astype(np.float32)
+    r = np.random.default_rng(0)
+    L, G, n, f = O.logreg_px_grads(spec, np.zeros(d), np.full(d, -2.25), np.ones((B, d)), np.ones(B),
+                                   r.normal(size=(B, d)), mask)
+    assert n == ka["num_elements"] and abs(f - ka["factor"]) < 1e-7
+    assert np.all(L[8:] == 0) and np.all(G[8:] == 0) and not np.allclose(L[:8], 0) and not np.allclose(G[:8], 0)
+
+
+def test_logreg_gradient_vs_torch_autograd(O):
+    """The hand-derived per-example gradient equals autodiff of the ELBO written with
+    torch.distributions (AutoDiagonalNormal: z = loc + softplus(u) * eps)."""
+    import torch
+    import torch.distributions as dist
+    from torch.func import grad, vmap
+    for (d, icpt, N, pw, pb, unscale) in [(8, False, 1000, 4.0, 1.0, True), (5, True, 250, 1.0, 2.0, True),
+                                          (16, True, 100, 1.0, 1.0, False)]:
+        D, B = d + int(icpt), 7
+        r = np.random.default_rng(d)
+        X = r.normal(size=(B, d)).astype(np.float32)
+        y = (r.random(B) < 0.5).astype(np.float32)
+        eps = r.normal(size=(B, D)).astype(np.float32)
+        loc = (0.3 * r.normal(size=D)).astype(np.float32)
+        unc = r.normal(size=D).astype(np.float32)
+        mask = np.array([1, 1, 0, 1, 1, 1, 0], np.float32)
+        obs = float(N) if unscale else 1.0
+        spec = O.logreg_spec(d, icpt, pw, pb, lik_scale=N, obs_scale=obs)
+        L, G, n, f = O.logreg_px_grads(spec, loc, unc, X, y, eps, mask)
+
+        def px_loss(params, x, yv, e, m):
+            l, u = params
+            s = torch.nn.functional.softplus(u)
+            z = l + s * e
+            logq = dist.Normal(l, s).log_prob(z).sum()
+            ps = torch.cat([torch.full((d,), pw), torch.full((D - d,), pb)]).double()
+            logp = dist.Normal(torch.zeros(D).double(), ps).log_prob(z).sum()
+            logit = x @ z[:d] + (z[d] if icpt else 0.0)
+            ll = -torch.nn.functional.binary_cross_entropy_with_logits(logit, yv, reduction="sum")
+            return (1 / obs) * (-(logp + N * ll - logq)) * m
+
+        t = lambda a: torch.tensor(a, dtype=torch.float64)  # noqa: E731
+        params = (t(loc), t(unc))
+        gl, gu = vmap(grad(px_loss), in_dims=(None, 0, 0, 0, 0))(params, t(X), t(y), t(eps), t(mask))
+        Lt = vmap(px_loss, in_dims=(None, 0, 0, 0, 0))(params, t(X), t(y), t(eps), t(mask)) * obs * f
+        Gt = torch.cat([gl, gu], 1).numpy()
+        assert np.abs(G - Gt).max() / np.abs(Gt).max() < 1e-6
+        assert np.abs(L - Lt.numpy()).max() / np.abs(Lt.numpy()).max() < 1e-6
+
+
+def test_adam_matches_jax_optimizers_formula(O):
+    r = np.random.default_rng(1)
+    x, m, v = r.normal(size=9), np.zeros(9), np.zeros(9)
+    xs, ms, vs = x.astype(np.float32), m.astype(np.float32), v.astype(np.float32)
+    for i in range(4):
+        g = r.normal(size=9)
+        m = 0.1 * g + 0.9 * m
+        v = 0.001 * g * g + 0.999 * v
+        x = x - 1e-2 * (m / (1 - 0.9 ** (i + 1))) / (np.sqrt(v / (1 - 0.999 ** (i + 1))) + 1e-8)
+        xs, ms, vs = O.adam(xs, ms, vs, g.astype(np.float32), i, lr=1e-2)
+    assert np.allclose(xs, x, rtol=1e-5, atol=1e-6)
+
+
+def test_full_update_is_the_stage_composition(O):
+    """logreg_update == split -> px_grads -> clip -> combine -> perturb -> adam (svi.py:413-434)."""
+    B, d, N = 12, 6, 300
+    r = np.random.default_rng(4)
+    X = r.normal(size=(B, d)).astype(np.float32)
+    y = (r.random(B) < 0.5).astype(np.float32)
+    loc, unc = np.zeros(d, np.float32), np.full(d, -2.0, np.float32)
+    spec = O.logreg_spec(d, False, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    st = O.LogregState(O.PRNGKey(5), d, loc, unc)
+    loss, grad = O.logreg_update(spec, hy, st, X, y)
+    ks = O.split(O.PRNGKey(5), 3)
+    eps = O.px_eps(O.convert_to_jax_rng_key(ks[1]), B, d)
+    L, G, n, f = O.logreg_px_grads(spec, loc, unc, X, y, eps)
+    l2, avg = O.combine(O.clip_rows(G, 1.0), L)
+    g2 = O.perturb(ks[2], avg, [d, d], 0.7, 1.0, n, N, f)
+    assert abs(loss - l2) < 1e-6 * abs(l2) and np.allclose(grad, g2, rtol=1e-6)
+    assert np.array_equal(st.key, ks[0].ravel()) and st.step.value == 1
+    x2, _, _ = O.adam(np.concatenate([loc, unc]), np.zeros(2 * d), np.zeros(2 * d), g2, 0, lr=1e-2)
+    assert np.allclose(st.params, x2)
+
+
+def test_config1_simple_posterior_plumbing(O):
+    """BASELINE configs[0]-style plumbing on the CPU restatement: a few hundred DP-VI steps on a small
+    table move the variational mean towards the non-private optimum (no GPU involved)."""
+    N, d, B = 1000, 4, 100
+    X, y = O.synth_logreg(7, 0, N, d)
+    w = O.synth_wtrue(7, d)[:d]
+    spec = O.logreg_spec(d, False, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.1, 5e-2, 0.9, 0.999, 1e-8)
+    st = O.LogregState(O.PRNGKey(0), d, np.zeros(d, np.float32), np.full(d, -2.25, np.float32))
+    bkey = O.PRNGKey(1)
+    for i in range(300):
+        idx = O.feistel_sample(O.fold_in(bkey, i), N, B)
+        O.logreg_update(spec, hy, st, X[idx], y[idx])
+    loc = st.params[:d]
+    cos = float(loc @ w / (np.linalg.norm(loc) * np.linalg.norm(w)))
+    assert cos > 0.9
