@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist-loop", action="store_true",
+                    help="developer switch: use the stepwise data-parallel loop (d3p_amd.dist) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -107,7 +109,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
+    if world == 1 and not args.force_dist_loop:
         _, get_batch = subsample_batchify_data((X, y), Bg)
 
         def run(st, first, k):

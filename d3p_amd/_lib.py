@@ -92,6 +92,11 @@ SIGNATURES = {
     "d3p_dpvi_logreg_workspace": (_SZ, [_PM, _PB]),
     "d3p_dpvi_logreg_local_sums": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _V, _V, _V, _SZ]),
     "d3p_dpvi_logreg_finalize": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _V, _V, _SZ]),
+    "d3p_dpvi_logreg_begin": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _SZ]),
+    "d3p_dpvi_logreg_prepare": (C.c_int, [_V, _PM, _PH, _PS, _PB, _U32, _V, _SZ]),
+    "d3p_dpvi_logreg_step_sums": (C.c_int, [_V, _PM, _PH, _PS, _PB, _U32, _V, _V, _V, _V, _V, _SZ]),
+    "d3p_dpvi_logreg_step_finalize": (C.c_int, [_V, _PM, _PH, _PS, _PB, _U32, _V, _V, _V, _V, _SZ]),
+    "d3p_dpvi_logreg_end": (C.c_int, [_V, _PM, _PH, _PS, _PB, _U32, _V, _SZ]),
     "d3p_dpvi_logreg_run": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _U32, _V, _V, _SZ]),
     "d3p_dpvi_logreg_time_main_kernel": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _V, _SZ, C.c_int,
                                                    C.POINTER(C.c_float), C.POINTER(C.c_float)]),

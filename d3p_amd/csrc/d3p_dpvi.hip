@@ -980,6 +980,68 @@ int d3p_dpvi_logreg_finalize(void* stream, const d3p_logreg_model* model, const 
     return enqueue_sched_finish(c, 1);
 }
 
+/* ---- stepwise API for the data-parallel loop: begin -> [prepare(K) -> K x (step_sums -> all-reduce ->
+ *      step_finalize)]* -> end.  Per step only the fused kernel, the partial reduction and finalize are launched. */
+int d3p_dpvi_logreg_begin(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                          const d3p_dpsvi_state* state, const d3p_batch_source* src, void* workspace_dev,
+                          size_t workspace_bytes)
+{
+    Ctx c;
+    int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    return enqueue_sched_init(c);
+}
+
+int d3p_dpvi_logreg_prepare(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                            const d3p_dpsvi_state* state, const d3p_batch_source* src, uint32_t num_steps,
+                            void* workspace_dev, size_t workspace_bytes)
+{
+    Ctx c;
+    int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    D3P_REQUIRE(num_steps >= 1 && num_steps <= D3P_STEP_BATCH, "d3p_dpvi_logreg_prepare: 1 <= num_steps <= 32");
+    return enqueue_batch_prep(c, (int)num_steps);
+}
+
+int d3p_dpvi_logreg_step_sums(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                              const d3p_dpsvi_state* state, const d3p_batch_source* src, uint32_t t,
+                              const float* X_dev, const float* y_dev, const float* eps_dev, float* sums_dev,
+                              void* workspace_dev, size_t workspace_bytes)
+{
+    Ctx c;
+    int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    D3P_REQUIRE(X_dev && y_dev && sums_dev, "null data pointer");
+    D3P_REQUIRE(t < D3P_STEP_BATCH, "d3p_dpvi_logreg_step_sums: t must be < 32");
+    if ((rc = enqueue_main(c, (int)t, X_dev, y_dev, eps_dev, false))) return rc;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(cdiv(c.P + 2, 64)), dim3(64 * D3P_FIN_W), 0, c.s,
+                       (const float*)c.ws.partials, c.g.blocks, (uint32_t)(c.P + 2), sums_dev);
+    return check_launch("k_reduce_partials");
+}
+
+int d3p_dpvi_logreg_step_finalize(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                                  const d3p_dpsvi_state* state, const d3p_batch_source* src, uint32_t t,
+                                  const float* sums_dev, float* loss_dev, float* grad_out_dev, void* workspace_dev,
+                                  size_t workspace_bytes)
+{
+    Ctx c;
+    int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    D3P_REQUIRE(sums_dev, "null sums pointer");
+    D3P_REQUIRE(t < D3P_STEP_BATCH, "d3p_dpvi_logreg_step_finalize: t must be < 32");
+    return enqueue_finalize(c, (int)t, sums_dev, 1u, loss_dev, grad_out_dev);
+}
+
+int d3p_dpvi_logreg_end(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                        const d3p_dpsvi_state* state, const d3p_batch_source* src, uint32_t steps_done,
+                        void* workspace_dev, size_t workspace_bytes)
+{
+    Ctx c;
+    int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    return enqueue_sched_finish(c, (int)steps_done);
+}
+
 int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
                         const d3p_dpsvi_state* state, const d3p_batch_source* src, const float* X_dev,
                         const float* y_dev, uint32_t num_steps, float* losses_dev, void* workspace_dev,

@@ -50,7 +50,6 @@ class HipEngine:
         self.step, self.params, self.m, self.v = (t.clone() for t in state.optim_state)
         self.keybuf = torch.empty((2, 16), dtype=torch.uint32, device=self.dev)
         self.keybuf[0].copy_(state.rng_key.reshape(16))
-        self.slot = 0
         self.bkey = batch_key.contiguous()
         self.bidx = torch.tensor([int(first_batch)], dtype=torch.int32, device=self.dev)
         self.src = BatchSource(self.kind, self.B, self.q, int(self.suppress), self.bkey.data_ptr(),
@@ -61,27 +60,48 @@ class HipEngine:
         self.loss = torch.empty(1, dtype=torch.float32, device=self.dev)
         self.observation_scale = state.observation_scale
 
-    def _state(self):
-        return self.svi._state_struct(self.keybuf, self.slot, (self.step, self.params, self.m, self.v))
+        self.st = self.svi._state_struct(self.keybuf, 0, (self.step, self.params, self.m, self.v))
+        self._args = (C.byref(self.model), C.byref(self.hyper), C.byref(self.st), C.byref(self.src))
+        self.t = 0            # step inside the prepared batch
+        self.prepared = 0     # steps the current batch holds
+        self.done = 0
+        self.remaining = None
+        check(lib.d3p_dpvi_logreg_begin(stream_ptr(), *self._args, ptr(self.ws), self.ws.numel()))
+
+    STEP_BATCH = 32
+
+    def plan(self, num_steps):
+        """Tell the engine how many steps will follow so that it prepares keys/indices in batches."""
+        self.remaining = int(num_steps)
+
+    def _ensure_prepared(self):
+        if self.t >= self.prepared:
+            k = self.STEP_BATCH if self.remaining is None else max(1, min(self.STEP_BATCH, self.remaining))
+            check(_lib.load().d3p_dpvi_logreg_prepare(stream_ptr(), *self._args, k, ptr(self.ws), self.ws.numel()))
+            self.prepared, self.t = k, 0
 
     def local_sums(self):
-        st = self._state()
-        check(_lib.load().d3p_dpvi_logreg_local_sums(stream_ptr(), C.byref(self.model), C.byref(self.hyper),
-                                                     C.byref(st), C.byref(self.src), ptr(self.X), ptr(self.y), None,
-                                                     ptr(self.sums), ptr(self.ws), self.ws.numel()))
+        self._ensure_prepared()
+        check(_lib.load().d3p_dpvi_logreg_step_sums(stream_ptr(), *self._args, self.t, ptr(self.X), ptr(self.y), None,
+                                                    ptr(self.sums), ptr(self.ws), self.ws.numel()))
         return self.sums
 
     def finalize(self, sums):
-        st = self._state()
-        check(_lib.load().d3p_dpvi_logreg_finalize(stream_ptr(), C.byref(self.model), C.byref(self.hyper),
-                                                   C.byref(st), C.byref(self.src), ptr(sums), ptr(self.loss), None,
-                                                   ptr(self.ws), self.ws.numel()))
-        self.slot ^= 1
+        check(_lib.load().d3p_dpvi_logreg_step_finalize(stream_ptr(), *self._args, self.t, ptr(sums), ptr(self.loss),
+                                                        None, ptr(self.ws), self.ws.numel()))
+        self.t += 1
+        self.done += 1
+        if self.remaining is not None:
+            self.remaining -= 1
         return self.loss
 
     def end(self):
         from .svi import DPSVIState
-        return DPSVIState((self.step, self.params, self.m, self.v), self.keybuf[self.slot].reshape(4, 4).clone(),
+        # NOTE: the key chain ran ahead to the end of the prepared batch; `end` is only exact when every
+        # prepared step was consumed (run_steps plans the batches so that this holds).
+        assert self.t == self.prepared or self.done == 0, "unconsumed prepared steps"
+        check(_lib.load().d3p_dpvi_logreg_end(stream_ptr(), *self._args, self.done, ptr(self.ws), self.ws.numel()))
+        return DPSVIState((self.step, self.params, self.m, self.v), self.keybuf[self.done & 1].reshape(4, 4).clone(),
                           self.observation_scale)
 
 
@@ -92,6 +112,8 @@ def run_steps(engine, state, batch_key, first_batch, num_steps, group=None, coll
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     engine.begin(state, batch_key, first_batch)
+    if hasattr(engine, "plan"):
+        engine.plan(num_steps)
     losses = []
     for _ in range(int(num_steps)):
         sums = engine.local_sums()

@@ -229,6 +229,31 @@ int d3p_dpvi_logreg_finalize(void* stream, const d3p_logreg_model* model,
                              const d3p_batch_source* src, const float* sums_dev, float* loss_dev,
                              float* grad_out_dev, void* workspace_dev, size_t workspace_bytes);
 
+/* Stepwise form of the two phases for the data-parallel loop (d3p_amd/dist.py): the key schedule and
+ * the sampler are evaluated for up to 32 steps at once (`prepare`), so that each step only launches
+ * the fused kernel + partial reduction (`step_sums`), and -- after the caller's sum-all-reduce of
+ * sums_dev -- `step_finalize`.  `t` is the step index inside the prepared batch.
+ *   begin -> { prepare(K) -> K x [ step_sums(t) -> all-reduce -> step_finalize(t) ] }* -> end(total steps)
+ * `end` stores the key after `steps_done` updates in slot (key_slot + steps_done) & 1. */
+int d3p_dpvi_logreg_begin(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                          const d3p_dpsvi_state* state, const d3p_batch_source* src,
+                          void* workspace_dev, size_t workspace_bytes);
+int d3p_dpvi_logreg_prepare(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                            const d3p_dpsvi_state* state, const d3p_batch_source* src,
+                            uint32_t num_steps, void* workspace_dev, size_t workspace_bytes);
+int d3p_dpvi_logreg_step_sums(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                              const d3p_dpsvi_state* state, const d3p_batch_source* src, uint32_t t,
+                              const float* X_dev, const float* y_dev, const float* eps_dev,
+                              float* sums_dev, void* workspace_dev, size_t workspace_bytes);
+int d3p_dpvi_logreg_step_finalize(void* stream, const d3p_logreg_model* model,
+                                  const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                                  const d3p_batch_source* src, uint32_t t, const float* sums_dev,
+                                  float* loss_dev, float* grad_out_dev, void* workspace_dev,
+                                  size_t workspace_bytes);
+int d3p_dpvi_logreg_end(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                        const d3p_dpsvi_state* state, const d3p_batch_source* src,
+                        uint32_t steps_done, void* workspace_dev, size_t workspace_bytes);
+
 /* Single-GPU convenience: `num_steps` x (phase 1 + phase 2) enqueued back to back, i.e. the body of
  * the reference's jit(fori_loop(update)) epoch (examples/logistic_regression.py:149-160).
  * losses_dev: num_steps floats (or NULL). */

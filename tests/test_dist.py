@@ -162,6 +162,7 @@ def test_virtual_ranks_on_one_gpu_match_single_rank(gpu, world):
                                        L.D3P_BATCH_FEISTEL, Bg))
     for e in engines:
         e.begin(st0, bkey, 7)
+        e.plan(steps)
     losses = []
     for _ in range(steps):
         total = None
