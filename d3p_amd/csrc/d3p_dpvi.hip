@@ -28,29 +28,6 @@
 
 namespace d3p {
 
-// Per-step record produced by k_chain / k_sampler (device memory).
-struct StepSlot {
-    uint32_t next_key[16];   // split(state_key, 3)[0]: the state key after this step (pipelined path)
-    uint32_t grad_key[16];   // split(state_key, 3)[1]
-    uint32_t pert_key[16];   // split(state_key, 3)[2]
-    uint32_t batch_key[16];  // fold_in(batchifier_state, i)
-    uint32_t site_keys[2][16];  // split(perturbation_key, 2) (pipelined path)
-    uint32_t rc[32];         // Feistel round constants (pipelined path)
-    uint32_t jax_key[2];     // random_bits(gradient_key, 32, (2,))
-    uint32_t counts[2];      // [0] raw selected, [1] valid examples of the padded batch
-    int32_t adam_i;          // optimiser step index of this step
-    uint32_t batch_i;        // batch index of this step
-    float bc1, bc2;          // 1 - b1^(i+1), 1 - b2^(i+1)
-};
-
-// Running state of the key chain between batches.
-struct Sched {
-    uint32_t key[16];
-    int32_t adam_i;
-    uint32_t batch_i;
-    uint32_t pad[2];
-};
-
 struct Workspace {
     Sched* sched;
     StepSlot* slots;  // D3P_STEP_BATCH
@@ -59,6 +36,8 @@ struct Workspace {
     uint32_t* skeys;  // D3P_STEP_BATCH x 2B
     float* noise;     // D3P_STEP_BATCH x P
     float* eps;       // B x D: guide noise of the NEXT step, staged by k_carrier
+    long long* acc;   // 3 x D3P_ACC_R x (P + 2) fixed-point accumulators of the one-launch step
+    float* scratch_state;  // 3P + 4 floats: stand-in state for the timing entry point
     float* partials;  // max_blocks x (P + 2)
     unsigned long long* stamps;  // 2 x max_blocks
     void* poisson_ws;
@@ -79,6 +58,8 @@ static size_t carve(const d3p_logreg_model* m, const d3p_batch_source* src, char
     p = take(K * 2 * B * sizeof(uint32_t)); if (ws) ws->skeys = (uint32_t*)p;
     p = take(K * P * sizeof(float)); if (ws) ws->noise = (float*)p;
     p = take(B * D * sizeof(float)); if (ws) ws->eps = (float*)p;
+    p = take(3 * (size_t)D3P_ACC_R * (P + 2) * sizeof(long long)); if (ws) ws->acc = (long long*)p;
+    p = take((3 * P + 4) * sizeof(float)); if (ws) ws->scratch_state = (float*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * (P + 2) * sizeof(float)); if (ws) ws->partials = (float*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * 2 * sizeof(unsigned long long)); if (ws) ws->stamps = (unsigned long long*)p;
     size_t pb = 0;
@@ -338,33 +319,6 @@ struct FinalArgs {
     StepSlot* chain_slot;
     int chain_t, chain_last;
 };
-
-// One step of the serial key chain for step `t` of the next batch: (next, gradient, perturbation) =
-// split(chain_key, 3) (svi.py:208-211, :413-414).  `last` advances the batch counters of the schedule.
-__device__ __forceinline__ void chain_step(Sched* sched, StepSlot* slot, int t, int last)
-{
-    const int lane = threadIdx.x & 63;
-    uint32_t cur[16], child[16];
-    load_key(sched->key, cur);
-    const int32_t adam0 = sched->adam_i;
-    const uint32_t batch0 = sched->batch_i;
-    derive_child(cur, (uint32_t)(lane < 3 ? lane : 0), 0u, D3P_TAG_SPLIT, child);
-    if (lane == 1 || lane == 2) {
-        uint32_t* dst = lane == 1 ? slot->grad_key : slot->pert_key;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) dst[w] = child[w];
-    } else if (lane == 0) {
-#pragma unroll
-        for (int w = 0; w < 16; ++w) sched->key[w] = child[w];
-        if (last) {
-            sched->adam_i = adam0 + t + 1;
-            sched->batch_i = batch0 + (uint32_t)(t + 1);
-        }
-    } else if (lane == 3) {
-        slot->adam_i = adam0 + t;
-        slot->batch_i = batch0 + (uint32_t)t;
-    }
-}
 
 __device__ __forceinline__ void finalize_role(const FinalArgs& a, uint32_t blk, float (*lds)[64])
 {
@@ -917,6 +871,127 @@ static int run_pipelined(const Ctx& c, const float* X, const float* y, int n, fl
     return D3P_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// one launch per step (MODE 2)
+// ------------------------------------------------------------------------------------------
+static bool use_fused_step(const Ctx& c)
+{
+    return getenv("D3P_NO_FUSED_STEP") == nullptr && getenv("D3P_CARRIER") == nullptr;
+}
+
+static void fill_fuse_common(const Ctx& c, StepFuse* f, int g)
+{
+    const size_t PA = (size_t)c.P + 2;
+    f->acc_prev = c.ws.acc + (size_t)((g + 2) % 3) * D3P_ACC_R * PA;
+    f->acc_cur = c.ws.acc + (size_t)(g % 3) * D3P_ACC_R * PA;
+    f->acc_next = c.ws.acc + (size_t)((g + 1) % 3) * D3P_ACC_R * PA;
+    f->R = D3P_ACC_R;
+    f->params = c.st->params;
+    f->adam_m = c.st->adam_m;
+    f->adam_v = c.st->adam_v;
+    f->adam_step = c.st->step;
+    f->batch_index = c.src->kind == D3P_BATCH_EXPLICIT ? nullptr : c.src->batch_index;
+    f->dp_scale = c.h->dp_scale;
+    f->lr = c.h->lr;
+    f->b1 = c.h->b1;
+    f->b2 = c.h->b2;
+    f->adam_eps = c.h->adam_eps;
+    f->prior_w = c.m->prior_w;
+    f->prior_b = c.m->prior_b;
+    // gradient columns: every workgroup partial is bounded by 16 * C per step, sums by B * C -> 2^40 / C keeps
+    // B up to 2^22 inside int64 with a resolution of C * 2^-40
+    f->sg = 1099511627776.0 / (double)fabsf(c.h->clip);
+    f->inv_sg = 1.0 / f->sg;
+    // loss column: bound per example by inv_obs * (50 D + 1e3 * lik_scale); keep 2^61 of headroom
+    const double bound = (double)c.m->inv_obs * (50.0 * c.D + 1.0e3 * (double)c.m->lik_scale) * (double)c.src->B + 1.0;
+    int e = 0;
+    (void)frexp(bound, &e);
+    f->sl = ldexp(1.0, 61 - e);
+    f->inv_sl = 1.0 / f->sl;
+}
+
+// step `g` of the run (slot `t` of buffer `cur`); prev = slot of step g-1 (nullable for g == 0)
+static int enqueue_fused_step(const Ctx& c, int g, int t, const StepSlot* prev_slot, const float* prev_noise, const float* X,
+                              const float* y, float* prev_loss, StepSlot* chain_slot, int chain_t, int chain_last,
+                              bool flush_only, bool stamps = false, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
+{
+    MainArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_model_scalars(c.m, &a);
+    a.X = X;
+    a.y = y;
+    a.idx = c.src->kind == D3P_BATCH_EXPLICIT ? nullptr : c.ws.idx + (size_t)t * c.src->B;
+    a.mask = c.src->kind == D3P_BATCH_EXPLICIT ? c.src->mask : nullptr;
+    a.counts = c.ws.slots[t].counts;
+    a.skeys = c.ws.skeys + (size_t)t * 2 * c.src->B;
+    a.pack = c.ws.pack;
+    a.partials = c.ws.partials;
+    a.B = c.src->B;
+    a.row_lo = c.src->row_lo;
+    a.row_hi = c.src->row_hi;
+    a.clip = c.h->clip;
+    a.stamps = stamps ? c.ws.stamps : nullptr;
+    fill_fuse_common(c, &a.fuse, g);
+    a.fuse.apply_prev = prev_slot != nullptr;
+    a.fuse.prev_noise = prev_noise;
+    a.fuse.prev_meta = prev_slot ? reinterpret_cast<const StepMeta*>(&prev_slot->adam_i) : nullptr;
+    a.fuse.prev_loss_out = prev_loss;
+    a.fuse.flush_only = flush_only ? 1 : 0;
+    a.fuse.chain_sched = c.ws.sched;
+    a.fuse.chain_slot = chain_slot;
+    a.fuse.chain_t = chain_t;
+    a.fuse.chain_last = chain_last;
+    MainGeom g2 = c.g;
+    if (flush_only) g2.blocks = 1;
+    if (chain_slot) g2.blocks += 1;
+    return launch_main<2>(c.s, g2, a, e0, e1);
+}
+
+static int enqueue_sampler(const Ctx& c, int K);
+static int enqueue_chain(const Ctx& c, int K);
+
+static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_t num_steps, float* losses)
+{
+    int rc;
+    const size_t acc_bytes = 3 * (size_t)D3P_ACC_R * (c.P + 2) * sizeof(long long);
+    D3P_HIP_TRY(hipMemsetAsync(c.ws.acc, 0, acc_bytes, c.s));
+    const uint32_t n_batches = (num_steps + D3P_STEP_BATCH - 1) / D3P_STEP_BATCH;
+    auto batch_len = [&](uint32_t b) {
+        const uint32_t rem = num_steps - b * D3P_STEP_BATCH;
+        return (int)(rem < D3P_STEP_BATCH ? rem : D3P_STEP_BATCH);
+    };
+    Ctx cb[2] = {c, c};
+    cb[1].ws = c.ws2;
+    cb[1].ws.partials = c.ws.partials;
+    cb[1].ws.acc = c.ws.acc;
+    cb[1].ws.stamps = c.ws.stamps;
+    if (num_steps == 0) return D3P_OK;
+    if ((rc = enqueue_chain(cb[0], batch_len(0)))) return rc;
+    if ((rc = enqueue_sampler(cb[0], batch_len(0)))) return rc;
+    const StepSlot* prev_slot = nullptr;
+    const float* prev_noise = nullptr;
+    int g = 0;
+    for (uint32_t b = 0; b < n_batches; ++b) {
+        const int cur = (int)(b & 1), nxt = cur ^ 1;
+        const int K = batch_len(b), K_next = (b + 1 < n_batches) ? batch_len(b + 1) : 0;
+        for (int t = 0; t < K; ++t, ++g) {
+            StepSlot* cslot = (t < K_next) ? cb[nxt].ws.slots + t : nullptr;
+            if ((rc = enqueue_fused_step(cb[cur], g, t, prev_slot, prev_noise, X, y, (losses && g > 0) ? losses + g - 1 : nullptr,
+                                         cslot, t, t == K_next - 1, false)))
+                return rc;
+            prev_slot = cb[cur].ws.slots + t;
+            prev_noise = cb[cur].ws.noise + (size_t)t * c.P;
+        }
+        if (b + 1 < n_batches && (rc = enqueue_sampler(cb[nxt], K_next))) return rc;
+    }
+    // apply the update of the last step
+    const int last_buf = (int)((n_batches - 1) & 1);
+    if ((rc = enqueue_fused_step(cb[last_buf], g, 0, prev_slot, prev_noise, X, y, losses ? losses + g - 1 : nullptr, nullptr, 0, 0,
+                                 true)))
+        return rc;
+    return D3P_OK;
+}
+
 static int make_ctx(Ctx* c, void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
                     const d3p_dpsvi_state* state, const d3p_batch_source* src, void* workspace_dev,
                     size_t workspace_bytes)
@@ -1054,6 +1129,10 @@ int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_d
     D3P_REQUIRE(src->row_lo == 0 && src->row_hi == src->n_rows, "d3p_dpvi_logreg_run is the single-GPU path");
     if ((rc = enqueue_sched_init(c))) return rc;
     if (use_carrier(c)) return run_pipelined(c, X_dev, y_dev, (int)num_steps, losses_dev);
+    if (use_fused_step(c)) {
+        if ((rc = run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev))) return rc;
+        return enqueue_sched_finish(c, (int)num_steps);
+    }
     // The serial ChaCha key chain of batch b+1 (one wavefront, ~1.8 us per step) runs on an auxiliary stream
     // while the update steps of batch b run on `stream`; the two streams meet once per batch.  (Putting the
     // sampler there too made things slower: its workgroups delay the dispatch of the main kernel.)
@@ -1159,10 +1238,34 @@ int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model
     } else if ((rc = enqueue_batch_prep(c, 1))) {
         return rc;
     }
+    const bool fused = !staged && use_fused_step(c);
+    Ctx ct = c;  // the fused step applies an update in its prologue: let it work on a scratch copy of the state
+    d3p_dpsvi_state st_scratch = *c.st;
+    if (fused) {
+        const size_t P = (size_t)c.P;
+        D3P_HIP_TRY(hipMemcpyAsync(c.ws.scratch_state, c.st->params, P * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+        D3P_HIP_TRY(hipMemcpyAsync(c.ws.scratch_state + P, c.st->adam_m, P * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+        D3P_HIP_TRY(hipMemcpyAsync(c.ws.scratch_state + 2 * P, c.st->adam_v, P * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+        D3P_HIP_TRY(hipMemsetAsync(c.ws.acc, 0, 3 * (size_t)D3P_ACC_R * (P + 2) * sizeof(long long), c.s));
+        st_scratch.params = c.ws.scratch_state;
+        st_scratch.adam_m = c.ws.scratch_state + P;
+        st_scratch.adam_v = c.ws.scratch_state + 2 * P;
+        st_scratch.step = reinterpret_cast<int32_t*>(c.ws.scratch_state + 3 * P);
+        ct.st = &st_scratch;
+    }
+    d3p_batch_source src_scratch = *c.src;
+    if (fused) {
+        src_scratch.batch_index = reinterpret_cast<uint32_t*>(c.ws.scratch_state + 3 * c.P + 1);
+        ct.src = &src_scratch;
+    }
     auto launch = [&](bool stamps, hipEvent_t a0, hipEvent_t a1) {
+        if (fused)  // same accumulator rotation as step 1 of a run, previous step = slot 0
+            return enqueue_fused_step(ct, 1, 0, c.ws.slots, c.ws.noise, X_dev, y_dev, nullptr, nullptr, 0, 0, false, stamps, a0, a1);
         return staged ? enqueue_main_staged(c, 0, X_dev, y_dev, stamps, a0, a1)
                       : enqueue_main(c, 0, X_dev, y_dev, nullptr, stamps, a0, a1);
     };
+    if (fused)  // prime the accumulator the timed launches read as "previous step" with real sums
+        if ((rc = enqueue_fused_step(ct, 0, 0, nullptr, nullptr, X_dev, y_dev, nullptr, nullptr, 0, 0, false))) return rc;
     hipEvent_t e0, e1;
     D3P_HIP_TRY(hipEventCreate(&e0));
     D3P_HIP_TRY(hipEventCreate(&e1));

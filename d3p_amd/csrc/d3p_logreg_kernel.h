@@ -68,6 +68,125 @@ __device__ __forceinline__ void px_sample_key(uint32_t j0, uint32_t j1, uint32_t
     threefry2x32(g0, g1, 1u, 3u, b, o1);
 }
 
+struct d3p_logreg_model_view { float obs_scale; };
+
+#define D3P_ACC_R 8  // replicas of the fixed-point accumulator (one-launch step); compile-time so loads unroll
+
+// Per-step record produced by the key chain / sampler (device memory).
+struct StepSlot {
+    uint32_t next_key[16];   // split(state_key, 3)[0]: the state key after this step (ring path)
+    uint32_t grad_key[16];   // split(state_key, 3)[1]
+    uint32_t pert_key[16];   // split(state_key, 3)[2]
+    uint32_t batch_key[16];  // fold_in(batchifier_state, i)
+    uint32_t site_keys[2][16];  // split(perturbation_key, 2) (ring path)
+    uint32_t rc[32];         // Feistel round constants (ring path)
+    uint32_t jax_key[2];     // random_bits(gradient_key, 32, (2,))
+    uint32_t counts[2];      // [0] raw selected, [1] valid examples of the padded batch
+    int32_t adam_i;          // optimiser step index of this step      } these four words are read as
+    uint32_t batch_i;        // batch index of this step               } one block by the one-launch
+    float bc1, bc2;          // 1 - b1^(i+1), 1 - b2^(i+1)             } step kernel (StepMeta)
+};
+
+struct StepMeta {  // view of StepSlot::{adam_i, batch_i, bc1, bc2}
+    int32_t adam_i;
+    uint32_t batch_i;
+    float bc1, bc2;
+};
+
+// Running state of the key chain between batches.
+struct Sched {
+    uint32_t key[16];
+    int32_t adam_i;
+    uint32_t batch_i;
+    uint32_t pad[2];
+};
+
+// One step of the serial key chain for step `t` of the next batch: (next, gradient, perturbation) =
+// split(chain_key, 3) (svi.py:208-211, :413-414).  `last` advances the batch counters of the schedule.
+__device__ __forceinline__ void chain_step(Sched* sched, StepSlot* slot, int t, int last)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t cur[16], child[16];
+    load_key(sched->key, cur);
+    const int32_t adam0 = sched->adam_i;
+    const uint32_t batch0 = sched->batch_i;
+    derive_child(cur, (uint32_t)(lane < 3 ? lane : 0), 0u, D3P_TAG_SPLIT, child);
+    if (lane == 1 || lane == 2) {
+        uint32_t* dst = lane == 1 ? slot->grad_key : slot->pert_key;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) dst[w] = child[w];
+    } else if (lane == 0) {
+#pragma unroll
+        for (int w = 0; w < 16; ++w) sched->key[w] = child[w];
+        if (last) {
+            sched->adam_i = adam0 + t + 1;
+            sched->batch_i = batch0 + (uint32_t)(t + 1);
+        }
+    } else if (lane == 3) {
+        slot->adam_i = adam0 + t;
+        slot->batch_i = batch0 + (uint32_t)t;
+    }
+}
+
+// Arguments of the one-launch-per-step mode (MODE 2) of k_logreg_main: the cross-workgroup sum of the
+// clipped gradients goes through 64-bit FIXED-POINT integer atomics into R replicas (integer addition is
+// associative, so the result is the exact sum of the fp32 workgroup partials and bitwise reproducible,
+// unlike float atomics); the NEXT launch's prologue turns the pending sums into the parameter update.
+struct StepFuse {
+    long long* acc_prev;  // R x (P + 2): sums of the previous step (read in the prologue if apply_prev)
+    long long* acc_cur;   // R x (P + 2): this step's sums (zeroed by the previous launch)
+    long long* acc_next;  // R x (P + 2): zeroed here for the next launch
+    int R;
+    int apply_prev;
+    int flush_only;       // apply the pending sums and return (after the last step of a run)
+    float* params;
+    float* adam_m;
+    float* adam_v;
+    int32_t* adam_step;
+    uint32_t* batch_index;       // nullable
+    const float* prev_noise;     // P standard normals of the previous step
+    const StepMeta* prev_meta;   // bias corrections / counters of the previous step
+    float* prev_loss_out;        // nullable: loss of the previous step
+    float dp_scale, lr, b1, b2, adam_eps;
+    float prior_w, prior_b;
+    double sg, inv_sg;           // fixed-point scale of the gradient columns (2^40 / C) and its inverse
+    double sl, inv_sl;           // fixed-point scale of the loss column
+    // piggy-backed key-chain step of the next batch (extra workgroup), nullable
+    Sched* chain_sched;
+    StepSlot* chain_slot;
+    int chain_t, chain_last;
+};
+
+// Applies the pending sums of the previous step for column `col`: mean, Gaussian mechanism, rescale
+// (svi.py:343-346, :365-375), Adam (svi.py:379-393).  Every workgroup computes the same values from the
+// same inputs; returns the new unconstrained parameter.
+__device__ __forceinline__ float apply_pending_column(const StepFuse& f, const d3p_logreg_model_view& mv, int PA, int col,
+                                                      float n, float Bf, float clip, float bc1, float bc2, float& m_out,
+                                                      float& v_out)
+{
+    // all loads first (8 replica words + state + noise), then the arithmetic
+    long long r8[D3P_ACC_R];
+#pragma unroll
+    for (int r = 0; r < D3P_ACC_R; ++r) r8[r] = f.acc_prev[(size_t)r * PA + col];
+    float x = f.params[col], m = f.adam_m[col], v = f.adam_v[col];
+    const float z = f.prev_noise[col];
+    long long s = 0;
+#pragma unroll
+    for (int r = 0; r < D3P_ACC_R; ++r) s += r8[r];
+    const float tot = (float)((double)s * f.inv_sg);
+    const float factor = (n == 0.0f) ? 0.0f : Bf / n;  // svi.py:305
+    const float avg = tot / Bf;
+    const float scale = f.dp_scale * (clip / n);
+    const float g = (avg + z * scale) * mv.obs_scale * factor;
+    m = (1.0f - f.b1) * g + f.b1 * m;
+    v = (1.0f - f.b2) * g * g + f.b2 * v;
+    const float mhat = m / bc1, vhat = v / bc2;
+    x = x - f.lr * mhat / (sqrtf(vhat) + f.adam_eps);
+    m_out = m;
+    v_out = v;
+    return x;
+}
+
 struct MainArgs {
     const float* X;
     const float* y;
@@ -90,6 +209,7 @@ struct MainArgs {
     float inv_obs, lik_scale, obs_scale, clip;
     int dbg;  // developer ablation switches (0 in production)
     unsigned long long* stamps;  // nullable: per-workgroup {start, end} wall_clock64 (timing entry point)
+    StepFuse fuse;               // MODE 2 only
 };
 
 // Lane l of the wave that owns an example holds, for k < NK and i < V, the column pair
@@ -123,13 +243,124 @@ __global__ void __launch_bounds__(1024) k_logreg_main(MainArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = blockDim.x >> 6;
     const int D = a.D, half = a.half, P = 2 * D;
-    const uint32_t total_waves = gridDim.x * W;
+    const uint32_t total_waves = (gridDim.x - ((MODE == 2 && a.fuse.chain_slot) ? 1u : 0u)) * W;
     const uint32_t gw = blockIdx.x * W + wave;
 
     // ---- stage the derived parameter columns in LDS once per workgroup (5 x D floats)
     float* pk = lds;                       // [loc | s | sg | q | lc]
     float* red = lds + ((5 * D + 3) & ~3); // W x P reduction buffer (MODE 0) + 2W tail
-    for (int i = threadIdx.x; i < 5 * D; i += blockDim.x) pk[i] = a.pack[i];
+    // MODE 2 prologue, split in two so that its memory latency hides behind the eps generation:
+    // the loads are issued here, the arithmetic (and the LDS writes) happen right before the staging barrier.
+    long long pend_r8[D3P_ACC_R], pend_n8[D3P_ACC_R];
+    float pend_x = 0.f, pend_m = 0.f, pend_v = 0.f, pend_z = 0.f, pend_bc1 = 1.f, pend_bc2 = 1.f;
+    // Measured: keeping these loads in registers across the eps generation costs 12 extra VGPRs -> 128 VGPRs +
+    // scratch and a slower kernel (14.8 vs 12.5 us), so the prologue runs in order, before the row loads.
+    constexpr bool kLatePrologue = false;
+    const bool pend_fast = kLatePrologue && (MODE == 2) && a.fuse.apply_prev && (P <= (int)blockDim.x);
+    if (MODE == 2) {
+        const StepFuse& f = a.fuse;
+        const int PA = P + 2;
+        if (blockIdx.x == gridDim.x - 1 && f.chain_slot) {  // piggy-backed key-chain workgroup
+            if (threadIdx.x < 64) chain_step(f.chain_sched, f.chain_slot, f.chain_t, f.chain_last);
+            return;
+        }
+        // zero the accumulator of the NEXT launch (last read one launch ago, never touched in this one)
+        {
+            const int i = blockIdx.x * blockDim.x + threadIdx.x;
+            if (i < D3P_ACC_R * PA) f.acc_next[i] = 0;
+        }
+        if (f.apply_prev) {
+#pragma unroll
+            for (int r = 0; r < D3P_ACC_R; ++r) pend_n8[r] = f.acc_prev[(size_t)r * PA + P + 1];
+            pend_bc1 = f.prev_meta->bc1;
+            pend_bc2 = f.prev_meta->bc2;
+            if (pend_fast && (int)threadIdx.x < P) {
+                const int col = threadIdx.x;
+#pragma unroll
+                for (int r = 0; r < D3P_ACC_R; ++r) pend_r8[r] = f.acc_prev[(size_t)r * PA + col];
+                pend_x = f.params[col];
+                pend_m = f.adam_m[col];
+                pend_v = f.adam_v[col];
+                pend_z = f.prev_noise[col];
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < 5 * D; i += blockDim.x) pk[i] = a.pack[i];
+    }
+    auto pack_column = [&](int col, float x) {
+        const int site = col >= D, e = col - site * D;
+        if (site == 0) {
+            pk[e] = x;
+        } else {
+            const float sp = softplus_f(x), sgm = sigmoid_f(x);
+            const float ps = (e < a.d) ? a.fuse.prior_w : a.fuse.prior_b;
+            pk[D + e] = sp;
+            pk[2 * D + e] = sgm;
+            pk[3 * D + e] = a.inv_obs * sgm / sp;
+            pk[4 * D + e] = __logf(ps) - __logf(sp);
+        }
+    };
+    bool prologue_done = false;
+    auto finish_prologue = [&]() {
+        if (MODE != 2 || prologue_done) return;
+        prologue_done = true;
+        const StepFuse& f = a.fuse;
+        const int PA = P + 2;
+        if (!f.apply_prev) {  // no pending update: derive the columns from the parameters as they are
+            for (int col = threadIdx.x; col < P; col += blockDim.x) pack_column(col, f.params[col]);
+            return;
+        }
+        long long nll = 0;
+#pragma unroll
+        for (int r = 0; r < D3P_ACC_R; ++r) nll += pend_n8[r];
+        const float n = (float)nll, Bf = (float)a.B;
+        const float factor = (n == 0.0f) ? 0.0f : Bf / n;  // svi.py:305
+        d3p_logreg_model_view mv;
+        mv.obs_scale = a.obs_scale;
+        if (pend_fast) {
+            const int col = threadIdx.x;
+            if (col < P) {
+                long long sll = 0;
+#pragma unroll
+                for (int r = 0; r < D3P_ACC_R; ++r) sll += pend_r8[r];
+                const float tot = (float)((double)sll * f.inv_sg);
+                const float g = (tot / Bf + pend_z * (f.dp_scale * (a.clip / n))) * a.obs_scale * factor;
+                float x = pend_x, m = pend_m, v = pend_v;
+                m = (1.0f - f.b1) * g + f.b1 * m;
+                v = (1.0f - f.b2) * g * g + f.b2 * v;
+                x = x - f.lr * (m / pend_bc1) / (sqrtf(v / pend_bc2) + f.adam_eps);
+                if (blockIdx.x == 0) {  // one workgroup publishes the state
+                    f.params[col] = x;
+                    f.adam_m[col] = m;
+                    f.adam_v[col] = v;
+                }
+                pack_column(col, x);
+            }
+        } else {
+            for (int col = threadIdx.x; col < P; col += blockDim.x) {
+                float m, v;
+                const float x = apply_pending_column(f, mv, PA, col, n, Bf, a.clip, pend_bc1, pend_bc2, m, v);
+                if (blockIdx.x == 0) {
+                    f.params[col] = x;
+                    f.adam_m[col] = m;
+                    f.adam_v[col] = v;
+                }
+                pack_column(col, x);
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            long long lll = 0;
+#pragma unroll
+            for (int r = 0; r < D3P_ACC_R; ++r) lll += f.acc_prev[(size_t)r * PA + P];
+            if (f.prev_loss_out) *f.prev_loss_out = ((float)((double)lll * f.inv_sl) / Bf) * a.obs_scale * factor;
+            *f.adam_step = f.prev_meta->adam_i + 1;
+            if (f.batch_index) *f.batch_index = f.prev_meta->batch_i + 1u;
+        }
+    };
+    if (MODE == 2 && (a.fuse.flush_only || !kLatePrologue)) {
+        finish_prologue();
+        if (a.fuse.flush_only) return;
+    }
 
     int c0[NC], c1[NC];
     bool ok0[NC], ok1[NC];
@@ -160,7 +391,7 @@ __global__ void __launch_bounds__(1024) k_logreg_main(MainArgs a)
         L.y = 0.f;
 #pragma unroll
         for (int n = 0; n < NC; ++n) L.x0[n] = L.x1[n] = L.e0[n] = L.e1[n] = 0.f;
-        if (!L.live && MODE == 0) return;
+        if (!L.live && MODE != 1) return;
         if (!mine) return;  // MODE 1 writes zeros for rows it cannot read
         const size_t row = (size_t)((uint64_t)row_g - a.row_lo);
         const float* xrow = a.X + row * (size_t)a.d;
@@ -215,7 +446,7 @@ __global__ void __launch_bounds__(1024) k_logreg_main(MainArgs a)
     // The derived columns are first needed AFTER the noise of the first example has been generated,
     // so the staging barrier sits behind that phase (every wave passes exactly one of the two).
     bool staged = false;
-    if (!(p < a.B)) { __syncthreads(); staged = true; }
+    if (!(p < a.B)) { finish_prologue(); __syncthreads(); staged = true; }
 
     while (p < a.B) {
         const uint32_t pn = p + total_waves;
@@ -243,7 +474,7 @@ __global__ void __launch_bounds__(1024) k_logreg_main(MainArgs a)
             }
 
             D3P_STAMP(3)
-            if (!staged) { __syncthreads(); staged = true; }
+            if (!staged) { finish_prologue(); __syncthreads(); staged = true; }
             // ---- z = loc + s * eps, logit t = x . z   (derived columns come from LDS)
             float z0[NC], z1[NC];
             float tp = 0.f;
@@ -286,7 +517,7 @@ __global__ void __launch_bounds__(1024) k_logreg_main(MainArgs a)
             // L_i = inv_obs * ((logq - logp) - lik_scale * loglik)   (svi.py:278-281)
             const float L = a.inv_obs * (lp - a.lik_scale * (cur.y * t - sp));
 
-            if (MODE == 0) {
+            if (MODE != 1) {
                 // clip factor 1/max(1, ||g||/C) (svi.py:121-122) folded into the running sum (svi.py:343-346)
                 const float cf = 1.0f / fmaxf(1.0f, __fsqrt_rn(n2) / a.clip);
 #pragma unroll
@@ -309,13 +540,13 @@ __global__ void __launch_bounds__(1024) k_logreg_main(MainArgs a)
                 if (lane == 0) a.px_loss[p] = L * m * a.obs_scale * a.meta[1];  // svi.py:306
             }
         }
-        if (!staged) { __syncthreads(); staged = true; }  // example skipped before reaching the barrier
+        if (!staged) { finish_prologue(); __syncthreads(); staged = true; }  // example skipped before reaching the barrier
         cur = nxt;
         p = pn;
     }
 
     D3P_STAMP(5)
-    if (MODE == 0) {
+    if (MODE != 1) {
         // ---- workgroup reduction through LDS, one partial row per workgroup (fixed order)
         float* mine = red + (size_t)wave * P;
 #pragma unroll
@@ -327,16 +558,34 @@ __global__ void __launch_bounds__(1024) k_logreg_main(MainArgs a)
         if (lane == 0) { tail[2 * wave] = loss_acc; tail[2 * wave + 1] = n_acc; }
         __syncthreads();
         D3P_STAMP(6)
-        float* out = a.partials + (size_t)blockIdx.x * (P + 2);
-        for (int c = threadIdx.x; c < P; c += blockDim.x) {
-            float s = 0.f;
-            for (int w = 0; w < W; ++w) s += red[(size_t)w * P + c];
-            out[c] = s;
-        }
-        if (threadIdx.x < 2) {
-            float s = 0.f;
-            for (int w = 0; w < W; ++w) s += tail[2 * w + threadIdx.x];
-            out[P + threadIdx.x] = s;
+        if (MODE == 2) {
+            // fixed-point integer atomics: exact, order-independent sum of the workgroups' fp32 partials
+            long long* out = a.fuse.acc_cur + (size_t)(blockIdx.x % D3P_ACC_R) * (P + 2);
+            for (int c = threadIdx.x; c < P; c += blockDim.x) {
+                float s = 0.f;
+                for (int w = 0; w < W; ++w) s += red[(size_t)w * P + c];
+                atomicAdd(reinterpret_cast<unsigned long long*>(out + c),
+                          (unsigned long long)__double2ll_rn((double)s * a.fuse.sg));
+            }
+            if (threadIdx.x < 2) {
+                float s = 0.f;
+                for (int w = 0; w < W; ++w) s += tail[2 * w + threadIdx.x];
+                const double sc = threadIdx.x == 0 ? a.fuse.sl : 1.0;
+                atomicAdd(reinterpret_cast<unsigned long long*>(out + P + threadIdx.x),
+                          (unsigned long long)__double2ll_rn((double)s * sc));
+            }
+        } else {
+            float* out = a.partials + (size_t)blockIdx.x * (P + 2);
+            for (int c = threadIdx.x; c < P; c += blockDim.x) {
+                float s = 0.f;
+                for (int w = 0; w < W; ++w) s += red[(size_t)w * P + c];
+                out[c] = s;
+            }
+            if (threadIdx.x < 2) {
+                float s = 0.f;
+                for (int w = 0; w < W; ++w) s += tail[2 * w + threadIdx.x];
+                out[P + threadIdx.x] = s;
+            }
         }
     }
     if (a.stamps) {
@@ -432,7 +681,7 @@ static int launch_main(hipStream_t s, const MainGeom& g, const MainArgs& a, hipE
         hipLaunchKernelGGL((k_logreg_main<V_, NK_, MODE, F_, E_>), dim3(g.blocks), dim3(64 * g.W), g.lds, s, a);          \
     return check_launch("k_logreg_main")
 #define D3P_LAUNCH(V_, NK_) D3P_LAUNCH_F(V_, NK_, false, -1)
-    if (g.V == 4 && g.full && MODE == 0) {
+    if (g.V == 4 && g.full && MODE != 1) {
         if (a.eps_ext) {
             switch (g.NK) {
             case 1: D3P_LAUNCH_F(4, 1, true, 1);
