@@ -975,14 +975,19 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
         const int cur = (int)(b & 1), nxt = cur ^ 1;
         const int K = batch_len(b), K_next = (b + 1 < n_batches) ? batch_len(b + 1) : 0;
         for (int t = 0; t < K; ++t, ++g) {
-            StepSlot* cslot = (t < K_next) ? cb[nxt].ws.slots + t : nullptr;
+            static const bool no_piggy = getenv("D3P_NO_CHAIN_PIGGYBACK") != nullptr;
+            StepSlot* cslot = (!no_piggy && t < K_next) ? cb[nxt].ws.slots + t : nullptr;
             if ((rc = enqueue_fused_step(cb[cur], g, t, prev_slot, prev_noise, X, y, (losses && g > 0) ? losses + g - 1 : nullptr,
                                          cslot, t, t == K_next - 1, false)))
                 return rc;
             prev_slot = cb[cur].ws.slots + t;
             prev_noise = cb[cur].ws.noise + (size_t)t * c.P;
         }
-        if (b + 1 < n_batches && (rc = enqueue_sampler(cb[nxt], K_next))) return rc;
+        if (b + 1 < n_batches) {
+            static const bool no_piggy2 = getenv("D3P_NO_CHAIN_PIGGYBACK") != nullptr;
+            if (no_piggy2 && (rc = enqueue_chain(cb[nxt], K_next))) return rc;
+            if ((rc = enqueue_sampler(cb[nxt], K_next))) return rc;
+        }
     }
     // apply the update of the last step
     const int last_buf = (int)((n_batches - 1) & 1);
