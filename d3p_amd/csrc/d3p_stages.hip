@@ -118,6 +118,88 @@ __global__ void k_adam(float* __restrict__ x, float* __restrict__ m, float* __re
     v[j] = vv;
 }
 
+// ---- DPSVI.evaluate (svi.py:436-449): -ELBO of a batch with ONE guide draw
+// k_eval_latent: key plumbing, eps, z = loc + softplus(u) * eps, latent[D] = logq - logp summed -> lat[0]
+__global__ void __launch_bounds__(256) k_eval_latent(d3p_logreg_model m, const float* __restrict__ params,
+                                                     const uint32_t* __restrict__ jax_key, float* __restrict__ z,
+                                                     float* __restrict__ lat)
+{
+    __shared__ float red[256];
+    const int D = m.d + (m.intercept ? 1 : 0);
+    // rng_key_eval = split(key)[1]; guide_seed = split(.)[1]; sample key = split(.)[1]  (jax split(k, 2)[1] =
+    // (threefry(k, (0, 2))[1], threefry(k, (1, 3))[1]))
+    uint32_t k0 = jax_key[0], k1 = jax_key[1];
+#pragma unroll
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        uint32_t a, b0, b1;
+        threefry2x32(k0, k1, 0u, 2u, a, b0);
+        threefry2x32(k0, k1, 1u, 3u, a, b1);
+        k0 = b0;
+        k1 = b1;
+    }
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < D; e += 256) {
+        const float eps = bits_to_normal(tf_iota_word(k0, k1, (uint64_t)D, (uint64_t)e));
+        const float sc = softplus_f(params[D + e]);
+        const float ps = (e < m.d) ? m.prior_w : m.prior_b;
+        const float zz = __fmaf_rn(sc, eps, params[e]);
+        z[e] = zz;
+        acc += (-0.5f * eps * eps - logf(sc)) - (-0.5f * (zz / ps) * (zz / ps) - logf(ps));
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) lat[0] = red[0];
+}
+
+// one wavefront per example: loglik_i = y t - softplus(t), t = x . z (+ intercept)
+__global__ void k_eval_loglik(d3p_logreg_model m, const float* __restrict__ X, const float* __restrict__ y,
+                              const float* __restrict__ z, uint32_t B, float* __restrict__ ll)
+{
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= B) return;
+    float tp = 0.f;
+    for (int c = lane; c < m.d; c += 64) tp = __fmaf_rn(X[(size_t)i * m.d + c], z[c], tp);
+    float t = wave_sum(tp);
+    if (m.intercept) t += z[m.d];
+    if (lane == 0) ll[i] = y[i] * t - softplus_f(t);
+}
+
+__global__ void __launch_bounds__(256) k_eval_finish(d3p_logreg_model m, const float* __restrict__ ll, uint32_t B,
+                                                     const float* __restrict__ lat, float* __restrict__ loss)
+{
+    __shared__ float red[256];
+    float s = 0.f;
+    for (uint32_t i = threadIdx.x; i < B; i += 256) s += ll[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    // -ELBO = (logq - logp) - (N / B) * sum_i loglik_i
+    if (threadIdx.x == 0) *loss = lat[0] - (m.lik_scale / (float)B) * red[0];
+}
+
+// jax.random.randint layout for the debug suite (d3p/random/debug.py:39)
+__global__ void k_tf_randint(const uint32_t* __restrict__ key, uint64_t n, uint32_t minval, uint32_t span, uint32_t mult,
+                             int32_t* __restrict__ out)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t a, k10, k11, k20, k21;
+    threefry2x32(key[0], key[1], 0u, 2u, k10, k20);  // split(key, 2): counts [0,1 | 2,3]
+    threefry2x32(key[0], key[1], 1u, 3u, k11, k21);
+    (void)a;
+    const uint32_t hi = tf_iota_word(k10, k11, n, j), lo = tf_iota_word(k20, k21, n, j);
+    const uint32_t off = ((hi % span) * mult + (lo % span)) % span;
+    out[j] = (int32_t)(minval + off);
+}
+
 __global__ void k_incr_i32(int32_t* p) { *p += 1; }
 
 __global__ void k_sgd(float* __restrict__ x, const float* __restrict__ g, uint32_t P, float lr)
@@ -306,6 +388,46 @@ int d3p_sgd_step(void* stream, float* params_dev, int32_t* step_dev, const float
         hipLaunchKernelGGL(k_sgd, dim3(cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, params_dev, grads_dev, P, lr);
     hipLaunchKernelGGL(k_incr_i32, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
     return check_launch("d3p_sgd_step");
+}
+
+size_t d3p_logreg_evaluate_workspace(const d3p_logreg_model* model, uint32_t B)
+{
+    if (!model) return 0;
+    const size_t D = (size_t)model->d + (model->intercept ? 1 : 0);
+    return align_up(D * sizeof(float), 256) + align_up((size_t)B * sizeof(float), 256) + 256;
+}
+
+int d3p_logreg_evaluate(void* stream, const d3p_logreg_model* model, const float* params_dev, const float* X_dev,
+                        const float* y_dev, uint32_t B, const uint32_t* jax_key_dev, float* loss_dev, void* workspace_dev,
+                        size_t workspace_bytes)
+{
+    D3P_REQUIRE(model && params_dev && X_dev && y_dev && jax_key_dev && loss_dev && workspace_dev,
+                "d3p_logreg_evaluate: null pointer");
+    D3P_REQUIRE(B >= 1 && model->d >= 1 && model->prior_w > 0.f && model->prior_b > 0.f, "d3p_logreg_evaluate: bad arguments");
+    if (workspace_bytes < d3p_logreg_evaluate_workspace(model, B))
+        return fail(D3P_E_WORKSPACE, "d3p_logreg_evaluate: workspace too small");
+    const size_t D = (size_t)model->d + (model->intercept ? 1 : 0);
+    float* z = (float*)workspace_dev;
+    float* ll = (float*)((char*)workspace_dev + align_up(D * sizeof(float), 256));
+    float* lat = (float*)((char*)ll + align_up((size_t)B * sizeof(float), 256));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_eval_latent, dim3(1), dim3(256), 0, s, *model, params_dev, jax_key_dev, z, lat);
+    hipLaunchKernelGGL(k_eval_loglik, dim3(cdiv((uint64_t)B * 64, 256)), dim3(256), 0, s, *model, X_dev, y_dev,
+                       (const float*)z, B, ll);
+    hipLaunchKernelGGL(k_eval_finish, dim3(1), dim3(256), 0, s, *model, (const float*)ll, B, (const float*)lat, loss_dev);
+    return check_launch("d3p_logreg_evaluate");
+}
+
+int d3p_tf_randint(void* stream, const uint32_t* key_dev, uint64_t n, int32_t minval, int32_t maxval, int32_t* out_dev)
+{
+    D3P_REQUIRE(key_dev && (out_dev || n == 0), "d3p_tf_randint: null pointer");
+    if (n == 0) return D3P_OK;
+    const uint32_t span = (maxval <= minval) ? 1u : (uint32_t)maxval - (uint32_t)minval;
+    uint32_t mult = 65536u % span;
+    mult = (mult * mult) % span;
+    hipLaunchKernelGGL(k_tf_randint, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, key_dev, n, (uint32_t)minval,
+                       span, mult, out_dev);
+    return check_launch("d3p_tf_randint");
 }
 
 int d3p_synth_logreg(void* stream, uint32_t seed, uint64_t row0, uint64_t n_rows, int32_t d, float* X_dev,

@@ -105,8 +105,15 @@ def normal(key, shape: Sequence[int] = (), dtype=torch.float32):
 
 
 def randint(key, shape, minval, maxval, dtype=torch.int32):
-    raise _lib.D3PError("d3p_amd.random.debug.randint is not implemented yet (jax.random.randint layout); "
-                        "use d3p_amd.random for with-replacement sampling")
+    """jax.random.randint (d3p/random/debug.py:39), int32 on the device path."""
+    if dtype in _FLOATS or dtype is float:
+        raise TypeError(f"dtype argument to `randint` must be an integer dtype, got {dtype}")
+    key = _key(key)
+    shape = tuple(shape)
+    n = _numel(shape)
+    out = torch.empty(max(n, 1), dtype=torch.int32, device=key.device)
+    check(_lib.load().d3p_tf_randint(stream_ptr(), ptr(key), n, int(minval), int(maxval), ptr(out)))
+    return out[:n].reshape(shape)
 
 
 def convert_to_jax_rng_key(rng_key):

@@ -470,8 +470,22 @@ class DPSVI:
 
     # ---------------------------------------------------------------- evaluate / accounting
     def evaluate(self, svi_state, *args, **kwargs):
-        """d3p/svi.py:436-449 (held-out ELBO) -- SURVEY 8(f) rank 2, not built yet."""
-        raise NotImplementedError("DPSVI.evaluate is scheduled after the hot path (SURVEY.md 8(f))")
+        """ELBO loss of a batch at the current parameters (d3p/svi.py:436-449 -> numpyro SVI.evaluate)."""
+        self._require_logreg()
+        _lib.require_device()
+        lib = _lib.load()
+        X = args[0].contiguous()
+        y = args[1].contiguous().to(torch.float32)
+        B, d = X.shape
+        # we split to have the same seed as `update` given an svi_state (svi.py:446-447)
+        jax_rng_key = self._rng_suite.convert_to_jax_rng_key(self._rng_suite.split(svi_state.rng_key, 1)[0]).contiguous()
+        params = self.optim.get_params(svi_state.optim_state).contiguous()
+        model = self._model_struct(d, kwargs, 1.0)
+        ws = self._workspace(lib.d3p_logreg_evaluate_workspace(C.byref(model), B), X.device, "eval")
+        loss = torch.empty(1, dtype=torch.float32, device=X.device)
+        check(lib.d3p_logreg_evaluate(stream_ptr(), C.byref(model), ptr(params), ptr(X), ptr(y), B, ptr(jax_rng_key),
+                                      ptr(loss), ptr(ws), ws.numel()))
+        return loss[0]
 
     def _validate_epochs_and_iter(self, num_epochs, num_iter, q):
         """d3p/svi.py:451-456."""

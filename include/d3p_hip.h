@@ -75,6 +75,9 @@ int d3p_tf_random_bits(void* stream, const uint32_t* key_dev, uint64_t n_words, 
 int d3p_tf_uniform(void* stream, const uint32_t* key_dev, uint64_t n, float minval, float maxval,
                    float* out_dev);
 int d3p_tf_normal(void* stream, const uint32_t* key_dev, uint64_t n, float* out_dev);
+/* jax.random.randint(key, shape, minval, maxval, int32) (d3p/random/debug.py:39) */
+int d3p_tf_randint(void* stream, const uint32_t* key_dev, uint64_t n, int32_t minval, int32_t maxval,
+                   int32_t* out_dev);
 
 /* ---------------------------------------------------------------------------------------------
  * Minibatch samplers
@@ -136,6 +139,13 @@ int d3p_logreg_px_grads(void* stream, const d3p_logreg_model* model, const float
                         const float* eps_dev, const uint32_t* jax_key_dev, float* px_loss_dev,
                         float* px_grads_dev, float* meta_dev, void* workspace_dev,
                         size_t workspace_bytes);
+
+/* DPSVI.evaluate (svi.py:436-449): -ELBO of the batch (B rows) at the current parameters with one guide
+ * draw; jax_key_dev = convert_to_jax_rng_key(split(state.rng_key, 1)[0]); model->lik_scale = num_obs_total. */
+size_t d3p_logreg_evaluate_workspace(const d3p_logreg_model* model, uint32_t B);
+int d3p_logreg_evaluate(void* stream, const d3p_logreg_model* model, const float* params_dev,
+                        const float* X_dev, const float* y_dev, uint32_t B, const uint32_t* jax_key_dev,
+                        float* loss_dev, void* workspace_dev, size_t workspace_bytes);
 
 /* _clip_gradients: every row scaled by 1/max(1, ||row||_2 / c) in place (svi.py:68-124, :310-325).
  * c == 0 -> D3P_E_INVALID_ARG (the reference raises ValueError, svi.py:119-120). */

@@ -618,6 +618,58 @@ D3P_API float d3po_logreg_update(const d3po_logreg_spec* sp, const d3po_dpsvi_hy
     return loss;
 }
 
+/* DPSVI.evaluate (svi.py:436-449) -> numpyro SVI.evaluate: `_, key = split(rng_key)`; -Trace_ELBO on the whole
+ * batch with ONE guide draw: model_seed, guide_seed = split(key); sample key = split(guide_seed)[1]
+ * (numpyro.handlers.seed); plate(N, B) scales the likelihood by N / B.  (numpyro plumbing UNPINNED.) */
+D3P_API float d3po_logreg_evaluate(const d3po_logreg_spec* sp, const float* loc, const float* unc, const float* Xb,
+                                   const float* yb, int B, const uint32_t jax_key[2])
+{
+    const int d = sp->d, D = sp->d + (sp->intercept ? 1 : 0);
+    uint32_t s[4], k[2];
+    d3po_tf_split(jax_key, 2, s);
+    k[0] = s[2]; k[1] = s[3];                 /* rng_key_eval */
+    d3po_tf_split(k, 2, s);
+    k[0] = s[2]; k[1] = s[3];                 /* guide_seed */
+    d3po_tf_split(k, 2, s);
+    k[0] = s[2]; k[1] = s[3];                 /* key of the `_auto_latent` sample site */
+    float* eps = (float*)malloc((size_t)D * sizeof(float));
+    float* z = (float*)malloc((size_t)D * sizeof(float));
+    d3po_tf_normal(k, (uint64_t)D, eps);
+    double lq = 0.0, lp = 0.0;
+    for (int j = 0; j < D; ++j) {
+        float sc = softplus_f(unc[j]);
+        float ps = (j < d) ? sp->prior_w : sp->prior_b;
+        z[j] = fmaf(sc, eps[j], loc[j]);
+        lq += -0.5 * (double)eps[j] * eps[j] - log((double)sc) - (double)HALF_LOG_2PI;
+        lp += -0.5 * ((double)z[j] / ps) * ((double)z[j] / ps) - log((double)ps) - (double)HALF_LOG_2PI;
+    }
+    double ll = 0.0;
+    for (int i = 0; i < B; ++i) {
+        double t = sp->intercept ? (double)z[d] : 0.0;
+        for (int j = 0; j < d; ++j) t += (double)Xb[(size_t)i * d + j] * (double)z[j];
+        ll += (double)yb[i] * t - (double)softplus_f((float)t);
+    }
+    free(eps); free(z);
+    return (float)(-(lp + ((double)sp->lik_scale / B) * ll - lq));
+}
+
+/* jax.random.randint for 32-bit integers (d3p/random/debug.py:39 `randint = jrng.randint`), jax <= 0.4.10:
+ * k1, k2 = split(key); offset = ((bits(k1) % span) * (2^32 % span) + bits(k2) % span) % span, with
+ * 2^32 % span computed as ((2^16 % span)^2) % span in uint32.  (UNPINNED: restated from memory of jax/_src/random.py.) */
+D3P_API void d3po_tf_randint32(const uint32_t key[2], uint64_t n, int32_t minval, int32_t maxval, int32_t* out)
+{
+    uint32_t ks[4];
+    d3po_tf_split(key, 2, ks);
+    uint32_t span = (maxval <= minval) ? 1u : (uint32_t)maxval - (uint32_t)minval;
+    uint32_t mult = 65536u % span;
+    mult = (mult * mult) % span;
+    for (uint64_t j = 0; j < n; ++j) {
+        uint32_t hi = tf_iota_word(ks[0], ks[1], n, j), lo = tf_iota_word(ks[2], ks[3], n, j);
+        uint32_t off = ((hi % span) * mult + (lo % span)) % span;
+        out[j] = (int32_t)((uint32_t)minval + off);
+    }
+}
+
 /* Synthetic logistic-regression table, element (r, c) a pure function of (seed, r, c) so that any
  * shard can be regenerated (mirrors examples/logistic_regression.py:88-104 in
  * distribution): X[r][c] = normal from threefry2x32((seed, 0x58), (r, c))[0];

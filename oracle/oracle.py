@@ -47,6 +47,7 @@ def lib():
         _lib.d3po_combine.restype = C.c_float
         _lib.d3po_logreg_px_loss_grad.restype = C.c_float
         _lib.d3po_logreg_update.restype = C.c_float
+        _lib.d3po_logreg_evaluate.restype = C.c_float
     return _lib
 
 
@@ -319,6 +320,19 @@ def logreg_update(spec, hyper, st, Xb, yb, mask=None, eps=None):
                                     None if m is None else _p(m), C.c_int(B),
                                     None if e is None else _p(e), _p(scratch), _p(grad))
     return float(loss), grad
+
+
+def logreg_evaluate(spec, loc, unc, Xb, yb, jax_key):
+    """DPSVI.evaluate (svi.py:436-449): -ELBO of a batch with one guide draw; jax_key = convert(split(key, 1)[0])."""
+    Xb, yb, loc, unc = _f32(Xb), _f32(yb), _f32(loc), _f32(unc)
+    return float(lib().d3po_logreg_evaluate(C.byref(spec), _p(loc), _p(unc), _p(Xb), _p(yb), C.c_int(Xb.shape[0]),
+                                            _p(_u32(jax_key))))
+
+
+def tf_randint(key, n, minval, maxval):
+    out = np.empty(max(n, 1), np.int32)
+    lib().d3po_tf_randint32(_p(_u32(key)), C.c_uint64(n), C.c_int32(minval), C.c_int32(maxval), _p(out))
+    return out[:n]
 
 
 def synth_logreg(seed, row0, nrows, d):

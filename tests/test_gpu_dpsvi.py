@@ -414,3 +414,29 @@ def test_staged_update_with_debug_rng_suite(gpu, O):
     g = (avg + noise * (1.0 * 1.0 / B)) * N * 1.0
     x, m, v = O.adam(np.concatenate([loc, unc]), np.zeros(2 * d), np.zeros(2 * d), g, 0)
     np.testing.assert_allclose(np_(s1.optim_state[1]), x, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,d,icpt", [(40, 16, False), (25, 7, True), (300, 512, False)])
+def test_evaluate_vs_oracle(rng, O, B, d, icpt):
+    """DPSVI.evaluate (svi.py:436-449): -ELBO of the batch with one guide draw, key = split(state.rng_key, 1)[0]."""
+    N = 10**4
+    X, y, loc, unc, _ = make_problem(B, d, icpt, 31 * B + d, N)
+    svi = make_svi(d, icpt, N, prior=1.5)
+    st = state_with(svi, rng.PRNGKey(99), loc, unc)
+    got = float(svi.evaluate(st, torch.tensor(X).cuda(), torch.tensor(y).cuda()))
+    spec = O.logreg_spec(d, icpt, 1.5, 3.0, lik_scale=N, obs_scale=1.0)
+    jax_key = O.convert_to_jax_rng_key(O.split(O.PRNGKey(99), 1)[0])
+    exp = O.logreg_evaluate(spec, loc, unc, X, y, jax_key)
+    assert abs(got - exp) <= 2e-5 * abs(exp)
+    # independent float64 restatement of the ELBO with the oracle's eps
+    k = O.tf_split(O.tf_split(O.tf_split(jax_key, 2)[1], 2)[1], 2)[1]
+    D = d + int(icpt)
+    eps = O.tf_normal(k, D).astype(np.float64)
+    s = np.log1p(np.exp(unc.astype(np.float64)))
+    z = loc + s * eps
+    ps = np.array([1.5] * d + [3.0] * (D - d))
+    logq = np.sum(-0.5 * eps**2 - np.log(s) - 0.5 * np.log(2 * np.pi))
+    logp = np.sum(-0.5 * (z / ps)**2 - np.log(ps) - 0.5 * np.log(2 * np.pi))
+    t = X.astype(np.float64) @ z[:d] + (z[d] if icpt else 0.0)
+    ll = np.sum(y * t - np.logaddexp(0, t))
+    assert abs(exp - (-(logp + N / B * ll - logq))) <= 1e-5 * abs(exp)

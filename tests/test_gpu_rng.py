@@ -148,3 +148,19 @@ def test_debug_suite_matches_jax_layout(gpu, O):
     assert np.array_equal(np_(dbg.fold_in(dbg.PRNGKey(42), 9)), O.tf_fold_in([0, 42], 9))
     assert np.array_equal(np_(dbg.split(dbg.PRNGKey(42), 5)), O.tf_split([0, 42], 5))
     assert dbg.convert_to_jax_rng_key(key) is key
+
+
+def test_debug_randint(gpu, O):
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import d3p_amd.random.debug as dbg
+    key = dbg.PRNGKey(7)
+    for lo, hi, n in [(0, 100, 1000), (-5, 6, 333), (0, 1 << 20, 100), (3, 4, 10), (5, 5, 4)]:
+        got = np_(dbg.randint(key, (n,), lo, hi))
+        assert np.array_equal(got, O.tf_randint([0, 7], n, lo, hi))
+        assert got.min() >= lo and got.max() < max(hi, lo + 1)
+    x = np_(dbg.randint(key, (20000,), 0, 10))
+    assert x.min() == 0 and x.max() == 9 and scipy.stats.chisquare(np.bincount(x, minlength=10)).pvalue > 0.01
+    with pytest.raises(TypeError):
+        dbg.randint(key, (3,), 0, 5, dtype=torch.float32)
