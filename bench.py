@@ -115,7 +115,8 @@ def main():
         def run(st, first, k):
             return svi.run_steps(st, get_batch, bkey, first, k)
     else:
-        engine = ddist.HipEngine(svi, X, y, n_rows, lo, hi, L.D3P_BATCH_FEISTEL, Bg)
+        engine_cls = ddist.HipEngine if os.environ.get("D3P_DIST_TWO_PHASE") else ddist.FusedHipEngine
+        engine = engine_cls(svi, X, y, n_rows, lo, hi, L.D3P_BATCH_FEISTEL, Bg)
 
         def run(st, first, k):
             return ddist.run_steps(engine, st, bkey, first, k, collect_losses=False)
@@ -188,7 +189,7 @@ def main():
                                    "batch 4096 per GPU by Feistel subsampling w/o replacement, AutoDiagonalNormal, "
                                    "C=1, sigma=1, Adam 1e-3",
                        "rows": n_rows, "dim": d, "global_batch": Bg, "parallelism": f"dp{world}",
-                       "collective": "none" if world == 1 else "1 all-reduce(sum) of 2D+2 fp32 per step (RCCL)"},
+                       "collective": "none" if world == 1 else "1 all-reduce(sum) per step of the int64 fixed-point accumulator, 8 x (2D+2) words (RCCL)"},
             "final_loss": final_loss,
             "roofline": roofline,
             "cpu_baseline": cpu,

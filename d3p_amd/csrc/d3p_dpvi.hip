@@ -1122,6 +1122,74 @@ int d3p_dpvi_logreg_end(void* stream, const d3p_logreg_model* model, const d3p_d
     return enqueue_sched_finish(c, (int)steps_done);
 }
 
+/* ---- one-launch-per-step form of the data-parallel loop.  `buf` selects one of the two slot buffers
+ *      (alternate it per prepared batch so that the previous step's slot survives a batch boundary). */
+int d3p_dpvi_logreg_prepare_buf(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                                const d3p_dpsvi_state* state, const d3p_batch_source* src, uint32_t num_steps, int buf,
+                                void* workspace_dev, size_t workspace_bytes)
+{
+    Ctx c;
+    int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    D3P_REQUIRE(num_steps >= 1 && num_steps <= D3P_STEP_BATCH, "d3p_dpvi_logreg_prepare_buf: 1 <= num_steps <= 32");
+    D3P_REQUIRE(buf == 0 || buf == 1, "d3p_dpvi_logreg_prepare_buf: buf must be 0 or 1");
+    Ctx cb = c;
+    if (buf) {
+        cb.ws = c.ws2;
+        cb.ws.partials = c.ws.partials;
+        cb.ws.acc = c.ws.acc;
+        cb.ws.stamps = c.ws.stamps;
+    }
+    return enqueue_batch_prep(cb, (int)num_steps);
+}
+
+int d3p_dpvi_logreg_acc_layout(const d3p_logreg_model* model, const d3p_batch_source* src, size_t* offset_bytes,
+                               size_t* words_per_buffer)
+{
+    D3P_REQUIRE(model && src && offset_bytes && words_per_buffer, "d3p_dpvi_logreg_acc_layout: null pointer");
+    Workspace ws;
+    carve(model, src, (char*)nullptr + 256, &ws);  // offsets relative to a fake base
+    *offset_bytes = (size_t)((char*)ws.acc - ((char*)nullptr + 256));
+    *words_per_buffer = (size_t)D3P_ACC_R * (2 * ((size_t)model->d + (model->intercept ? 1 : 0)) + 2);
+    return D3P_OK;
+}
+
+int d3p_dpvi_logreg_acc_reset(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                              const d3p_dpsvi_state* state, const d3p_batch_source* src, void* workspace_dev,
+                              size_t workspace_bytes)
+{
+    Ctx c;
+    int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    D3P_HIP_TRY(hipMemsetAsync(c.ws.acc, 0, 3 * (size_t)D3P_ACC_R * (c.P + 2) * sizeof(long long), c.s));
+    return D3P_OK;
+}
+
+/* Fused step `g` (0-based since acc_reset) using slot `t` of buffer `buf`: applies the pending update of step
+ * g-1 (slot prev_t of prev_buf, sums in accumulator (g-1) % 3 -- all-reduced by the caller on N GPUs), then
+ * accumulates this rank's clipped sums into accumulator g % 3.  flush_only: only apply the pending update. */
+int d3p_dpvi_logreg_fused_step(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                               const d3p_dpsvi_state* state, const d3p_batch_source* src, uint32_t g, uint32_t t, int buf,
+                               int have_prev, uint32_t prev_t, int prev_buf, const float* X_dev, const float* y_dev,
+                               float* prev_loss_dev, int flush_only, void* workspace_dev, size_t workspace_bytes)
+{
+    Ctx c;
+    int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    D3P_REQUIRE(flush_only || (X_dev && y_dev), "null data pointer");
+    D3P_REQUIRE(t < D3P_STEP_BATCH && prev_t < D3P_STEP_BATCH, "slot index must be < 32");
+    Ctx cb[2] = {c, c};
+    cb[1].ws = c.ws2;
+    cb[1].ws.partials = c.ws.partials;
+    cb[1].ws.acc = c.ws.acc;
+    cb[1].ws.stamps = c.ws.stamps;
+    const Ctx& cur = cb[buf & 1];
+    const StepSlot* prev_slot = have_prev ? cb[prev_buf & 1].ws.slots + prev_t : nullptr;
+    const float* prev_noise = have_prev ? cb[prev_buf & 1].ws.noise + (size_t)prev_t * c.P : nullptr;
+    return enqueue_fused_step(cur, (int)g, (int)t, prev_slot, prev_noise, X_dev, y_dev, prev_loss_dev, nullptr, 0, 0,
+                              flush_only != 0);
+}
+
 int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
                         const d3p_dpsvi_state* state, const d3p_batch_source* src, const float* X_dev,
                         const float* y_dev, uint32_t num_steps, float* losses_dev, void* workspace_dev,

@@ -105,6 +105,65 @@ class HipEngine:
                           self.observation_scale)
 
 
+class FusedHipEngine(HipEngine):
+    """One kernel launch + one int64 all-reduce per step: the rank's clipped sums go into a fixed-point
+    accumulator (exact integer sums: every rank obtains bitwise identical totals under any reduction
+    order) and the update of step g is applied in the prologue of launch g+1."""
+
+    def begin(self, state, batch_key, first_batch):
+        super().begin(state, batch_key, first_batch)
+        lib = _lib.load()
+        off, words = C.c_size_t(), C.c_size_t()
+        check(lib.d3p_dpvi_logreg_acc_layout(C.byref(self.model), C.byref(self.src), C.byref(off), C.byref(words)))
+        self.acc = self.ws[off.value: off.value + 3 * words.value * 8].view(torch.int64).reshape(3, words.value)
+        check(lib.d3p_dpvi_logreg_acc_reset(stream_ptr(), *self._args, ptr(self.ws), self.ws.numel()))
+        self.g = 0
+        self.buf = 1            # flipped before the first prepare
+        self.prev = None        # (t, buf) of the previous step
+        self.losses = None
+
+    def plan(self, num_steps):
+        super().plan(num_steps)
+        self.losses = torch.zeros(max(int(num_steps), 1), dtype=torch.float32, device=self.dev)
+
+    def _ensure_prepared(self):
+        if self.t >= self.prepared:
+            k = self.STEP_BATCH if self.remaining is None else max(1, min(self.STEP_BATCH, self.remaining))
+            self.buf ^= 1
+            check(_lib.load().d3p_dpvi_logreg_prepare_buf(stream_ptr(), *self._args, k, self.buf, ptr(self.ws),
+                                                          self.ws.numel()))
+            self.prepared, self.t = k, 0
+
+    def _launch(self, flush):
+        have_prev = self.prev is not None
+        pt, pb = self.prev if have_prev else (0, 0)
+        loss_ptr = None
+        if have_prev and self.losses is not None and self.g - 1 < self.losses.numel():
+            loss_ptr = C.c_void_p(self.losses.data_ptr() + 4 * (self.g - 1))
+        check(_lib.load().d3p_dpvi_logreg_fused_step(stream_ptr(), *self._args, self.g, self.t if not flush else 0,
+                                                     self.buf, int(have_prev), pt, pb, ptr(self.X), ptr(self.y), loss_ptr,
+                                                     int(flush), ptr(self.ws), self.ws.numel()))
+
+    def local_sums(self):
+        self._ensure_prepared()
+        self._launch(False)
+        return self.acc[self.g % 3]
+
+    def finalize(self, sums):
+        self.prev = (self.t, self.buf)
+        self.g += 1
+        self.t += 1
+        self.done += 1
+        if self.remaining is not None:
+            self.remaining -= 1
+        return None            # the loss of this step is written by the next launch
+
+    def end(self):
+        if self.prev is not None:
+            self._launch(True)  # apply the update of the last step
+        return super().end()
+
+
 def run_steps(engine, state, batch_key, first_batch, num_steps, group=None, collect_losses=True):
     """num_steps x [local_sums -> all_reduce(SUM) -> finalize] on every rank of `group`.
 
@@ -120,7 +179,9 @@ def run_steps(engine, state, batch_key, first_batch, num_steps, group=None, coll
         if world > 1:
             dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)   # the ONLY data-path collective
         loss = engine.finalize(sums)                                   # noise added once, after the reduce
-        if collect_losses:
+        if collect_losses and loss is not None:
             losses.append(loss.clone())
     new_state = engine.end()
+    if getattr(engine, "losses", None) is not None and collect_losses:
+        return new_state, engine.losses[:int(num_steps)]
     return new_state, (torch.stack(losses).reshape(-1) if losses else None)

@@ -264,6 +264,28 @@ int d3p_dpvi_logreg_end(void* stream, const d3p_logreg_model* model, const d3p_d
                         const d3p_dpsvi_state* state, const d3p_batch_source* src,
                         uint32_t steps_done, void* workspace_dev, size_t workspace_bytes);
 
+/* One-launch-per-step form (what d3p_dpvi_logreg_run uses internally), exposed for the data-parallel loop:
+ * the cross-workgroup sums of a step live in a 64-bit FIXED-POINT accumulator (integer addition is
+ * associative: exact and bitwise reproducible, on one GPU and under any all-reduce order); the update of
+ * step g is applied in the prologue of launch g+1.  Accumulator g % 3 of the workspace (layout from
+ * d3p_dpvi_logreg_acc_layout: byte offset, int64 words per buffer; three consecutive buffers) is what the
+ * caller sum-all-reduces (int64) between launch g and launch g+1.
+ *   begin -> acc_reset -> { prepare_buf(K, buf) -> K x [ fused_step(g, t, buf, ...) -> all-reduce(acc[g % 3]) ] }*
+ *         -> fused_step(flush_only = 1) -> end(total steps) */
+int d3p_dpvi_logreg_prepare_buf(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                                const d3p_dpsvi_state* state, const d3p_batch_source* src,
+                                uint32_t num_steps, int buf, void* workspace_dev, size_t workspace_bytes);
+int d3p_dpvi_logreg_acc_layout(const d3p_logreg_model* model, const d3p_batch_source* src,
+                               size_t* offset_bytes, size_t* words_per_buffer);
+int d3p_dpvi_logreg_acc_reset(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                              const d3p_dpsvi_state* state, const d3p_batch_source* src,
+                              void* workspace_dev, size_t workspace_bytes);
+int d3p_dpvi_logreg_fused_step(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                               const d3p_dpsvi_state* state, const d3p_batch_source* src, uint32_t g,
+                               uint32_t t, int buf, int have_prev, uint32_t prev_t, int prev_buf,
+                               const float* X_dev, const float* y_dev, float* prev_loss_dev,
+                               int flush_only, void* workspace_dev, size_t workspace_bytes);
+
 /* Single-GPU convenience: `num_steps` x (phase 1 + phase 2) enqueued back to back, i.e. the body of
  * the reference's jit(fori_loop(update)) epoch (examples/logistic_regression.py:149-160).
  * losses_dev: num_steps floats (or NULL). */

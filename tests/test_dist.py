@@ -133,6 +133,59 @@ def test_single_rank_run_steps_skips_the_collective(O):
 
 # ------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_virtual_ranks_fused_engine(gpu, world):
+    """FusedHipEngine (one launch + one int64 all-reduce per step): adding the ranks' fixed-point accumulators
+    by hand reproduces the single-rank run; replicas stay bitwise identical."""
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
+    from d3p_amd.svi import DPSVI, DPSVIState
+    n, d, Bg, steps = 5000, 64, 96, 35          # 35 steps: crosses a prepared-batch boundary
+    r = np.random.default_rng(1)
+    X = torch.tensor(r.normal(size=(n, d)).astype(np.float32)).cuda()
+    y = torch.tensor((r.random(n) < 0.5).astype(np.float32)).cuda()
+    model = LogisticRegression(d)
+    svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-2), Trace_ELBO(), 1.0, 0.6, N=n)
+    params = torch.cat([torch.zeros(d), torch.full((d,), -2.0)]).cuda()
+    st0 = DPSVIState(svi.optim.init(params), rng.PRNGKey(10), float(n))
+    bkey = rng.PRNGKey(20)
+    single = ddist.HipEngine(svi, X, y, n, 0, n, L.D3P_BATCH_FEISTEL, Bg)
+    ref_state, ref_losses = ddist.run_steps(single, st0, bkey, 7, steps)
+    fused1 = ddist.FusedHipEngine(svi, X, y, n, 0, n, L.D3P_BATCH_FEISTEL, Bg)
+    f_state, f_losses = ddist.run_steps(fused1, st0, bkey, 7, steps)
+    assert torch.equal(f_state.rng_key, ref_state.rng_key) and int(f_state.optim_state[0]) == steps
+    np.testing.assert_allclose(f_losses.cpu().numpy(), ref_losses.cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(f_state.optim_state[1].cpu().numpy(), ref_state.optim_state[1].cpu().numpy(),
+                               rtol=2e-5, atol=2e-6)
+    engines = []
+    for rk in range(world):
+        lo, hi = ddist.shard_rows(n, rk, world)
+        engines.append(ddist.FusedHipEngine(svi, X[lo:hi].contiguous(), y[lo:hi].contiguous(), n, lo, hi,
+                                            L.D3P_BATCH_FEISTEL, Bg))
+    for e in engines:
+        e.begin(st0, bkey, 7)
+        e.plan(steps)
+    for _ in range(steps):
+        bufs = [e.local_sums() for e in engines]
+        total = torch.stack(bufs).sum(dim=0)                  # the int64 all-reduce
+        for e, b in zip(engines, bufs):
+            b.copy_(total)
+            e.finalize(b)
+    finals = [e.end() for e in engines]
+    for e, f in zip(engines, finals):
+        assert torch.equal(f.rng_key, ref_state.rng_key)
+        assert torch.equal(f.optim_state[1], finals[0].optim_state[1])      # bitwise identical replicas
+        assert torch.equal(e.losses, engines[0].losses)
+        # a different sharding groups the examples into different fp32 workgroup partials, so against the
+        # 1-rank run only tolerance-equality holds
+        np.testing.assert_allclose(f.optim_state[1].cpu().numpy(), f_state.optim_state[1].cpu().numpy(),
+                                   rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(e.losses.cpu().numpy(), fused1.losses.cpu().numpy(), rtol=2e-5)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_virtual_ranks_on_one_gpu_match_single_rank(gpu, world):
     """The real kernels with disjoint row ranges: summing the ranks' partial sums by hand and
