@@ -169,14 +169,17 @@ def run_steps(engine, state, batch_key, first_batch, num_steps, group=None, coll
 
     With world size 1 the all-reduce is skipped.  Returns (new_state, losses)."""
     import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    import os
+    initialised = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if initialised else 1
+    force = initialised and os.environ.get("D3P_FORCE_ALLREDUCE") is not None  # plumbing test on one rank
     engine.begin(state, batch_key, first_batch)
     if hasattr(engine, "plan"):
         engine.plan(num_steps)
     losses = []
     for _ in range(int(num_steps)):
         sums = engine.local_sums()
-        if world > 1:
+        if world > 1 or force:
             dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)   # the ONLY data-path collective
         loss = engine.finalize(sums)                                   # noise added once, after the reduce
         if collect_losses and loss is not None:
