@@ -77,6 +77,7 @@ SIGNATURES = {
     "d3p_tf_randint": (C.c_int, [_V, _V, _U64, _I32, _I32, _V]),
     "d3p_logreg_evaluate_workspace": (_SZ, [_PM, _U32]),
     "d3p_logreg_evaluate": (C.c_int, [_V, _PM, _V, _V, _V, _U32, _V, _V, _V, _SZ]),
+    "d3p_gmm_log_prob": (C.c_int, [_V, _V, _U32, _I32, _V, _V, _V, _I32, _V]),
     "d3p_feistel_sample": (C.c_int, [_V, _V, _U32, _U32, _V]),
     "d3p_feistel_from_constants": (C.c_int, [_V, _V, _U32, _U32, _V]),
     "d3p_poisson_select_rng": (C.c_int, [_V, C.c_int, _V, _F, _U32, _U32, C.c_int, _V, _V, _V, _SZ]),

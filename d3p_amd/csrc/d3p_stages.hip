@@ -200,6 +200,45 @@ __global__ void k_tf_randint(const uint32_t* __restrict__ key, uint64_t n, uint3
     out[j] = (int32_t)(minval + off);
 }
 
+// GaussianMixture.log_prob (d3p/gmm.py:71-86): one wavefront per row; lanes stride the event dimension,
+// the K component sums go through the fixed-order wave reduction, logsumexp over components is wave-uniform.
+template <int KMAX>
+__global__ void k_gmm_log_prob(const float* __restrict__ x, uint32_t B, int d, const float* __restrict__ locs,
+                               const float* __restrict__ scales, const float* __restrict__ pis, int K,
+                               float* __restrict__ out)
+{
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= B) return;
+    float comp[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) comp[k] = 0.f;
+    for (int j = lane; j < d; j += 64) {
+        const float xv = x[(size_t)i * d + j];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < K) {
+                const float sc = scales[(size_t)k * d + j];
+                const float z = (xv - locs[(size_t)k * d + j]) / sc;
+                comp[k] += -0.5f * z * z - logf(sc) - D3P_HALF_LOG_2PI;
+            }
+        }
+    }
+    float best = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+            comp[k] = wave_sum(comp[k]) + logf(pis[k]);
+            best = fmaxf(best, comp[k]);
+        }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) acc += expf(comp[k] - best);
+    if (lane == 0) out[i] = best + logf(acc);
+}
+
 __global__ void k_incr_i32(int32_t* p) { *p += 1; }
 
 __global__ void k_sgd(float* __restrict__ x, const float* __restrict__ g, uint32_t P, float lr)
@@ -428,6 +467,24 @@ int d3p_tf_randint(void* stream, const uint32_t* key_dev, uint64_t n, int32_t mi
     hipLaunchKernelGGL(k_tf_randint, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, key_dev, n, (uint32_t)minval,
                        span, mult, out_dev);
     return check_launch("d3p_tf_randint");
+}
+
+int d3p_gmm_log_prob(void* stream, const float* x_dev, uint32_t B, int32_t d, const float* locs_dev,
+                     const float* scales_dev, const float* pis_dev, int32_t K, float* out_dev)
+{
+    D3P_REQUIRE(x_dev && locs_dev && scales_dev && pis_dev && (out_dev || B == 0), "d3p_gmm_log_prob: null pointer");
+    D3P_REQUIRE(d >= 1 && K >= 1, "d3p_gmm_log_prob: d and K must be >= 1");
+    if (K > 64) return fail(D3P_E_UNSUPPORTED, "d3p_gmm_log_prob: at most 64 mixture components are supported (K = %d)", K);
+    if (B == 0) return D3P_OK;
+    const dim3 grid(cdiv((uint64_t)B * 64, 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (K <= 4)
+        hipLaunchKernelGGL(k_gmm_log_prob<4>, grid, block, 0, s, x_dev, B, d, locs_dev, scales_dev, pis_dev, K, out_dev);
+    else if (K <= 16)
+        hipLaunchKernelGGL(k_gmm_log_prob<16>, grid, block, 0, s, x_dev, B, d, locs_dev, scales_dev, pis_dev, K, out_dev);
+    else
+        hipLaunchKernelGGL(k_gmm_log_prob<64>, grid, block, 0, s, x_dev, B, d, locs_dev, scales_dev, pis_dev, K, out_dev);
+    return check_launch("d3p_gmm_log_prob");
 }
 
 int d3p_synth_logreg(void* stream, uint32_t seed, uint64_t row0, uint64_t n_rows, int32_t d, float* X_dev,

@@ -1,0 +1,51 @@
+"""Gaussian mixture density: mirror of ``d3p.gmm.GaussianMixture`` (reference d3p/gmm.py:26-107) for the part
+that is on the DP-VI path, ``log_prob``.  Sampling (``sample`` / ``sample_with_intermediates``) and the
+per-example-gradient kernel for the mixture model of examples/gaussian_mixture_model.py are not built yet
+(DESIGN.md section 9)."""
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+class GaussianMixture:
+    """Mixture of diagonal Gaussians with shared weights (d3p/gmm.py:53-69).
+
+    :param locs: (k, d) component locations.
+    :param scales: (k, d) component scales.
+    :param mixture_probabilities: (k,) weights; must lie on the simplex when ``validate_args`` is set."""
+
+    def __init__(self, locs, scales, mixture_probabilities, validate_args=None):
+        self.locs = torch.as_tensor(locs, dtype=torch.float32)
+        self.scales = torch.as_tensor(scales, dtype=torch.float32)
+        self.mixture_probabilities = torch.as_tensor(mixture_probabilities, dtype=torch.float32)
+        if self.locs.dim() == 1:
+            self.locs, self.scales = self.locs.reshape(-1, 1), self.scales.reshape(-1, 1)
+        self._validate_args = bool(validate_args)
+        if self._validate_args:
+            p = self.mixture_probabilities
+            if bool((p < 0).any()) or abs(float(p.sum()) - 1.0) > 1e-6:
+                raise ValueError("GaussianMixture: mixture_probabilities must lie on the simplex")
+            if bool((self.scales <= 0).any()):
+                raise ValueError("GaussianMixture: scales must be positive")
+        self.event_shape = tuple(self.locs.shape[1:])
+
+    @property
+    def num_components(self):
+        return self.mixture_probabilities.shape[-1]
+
+    def log_prob(self, value):
+        """logsumexp_k(log pi_k + sum_d log N(value_d; loc_kd, scale_kd)) (d3p/gmm.py:71-86) on the GPU."""
+        _lib.require_device()
+        x = torch.as_tensor(value, dtype=torch.float32)
+        single = x.dim() == len(self.event_shape)
+        k = self.locs.shape[0]
+        xs = x.reshape(-1, self.locs[0].numel()).cuda().contiguous()
+        locs = self.locs.reshape(k, -1).cuda().contiguous()
+        scales = self.scales.reshape(k, -1).cuda().contiguous()
+        pis = self.mixture_probabilities.cuda().contiguous()
+        out = torch.empty(xs.shape[0], dtype=torch.float32, device=xs.device)
+        check(_lib.load().d3p_gmm_log_prob(stream_ptr(), ptr(xs), xs.shape[0], xs.shape[1], ptr(locs), ptr(scales),
+                                           ptr(pis), k, ptr(out)))
+        batch_shape = tuple(x.shape[:x.dim() - len(self.event_shape)])
+        return out[0] if single else out.reshape(batch_shape)

@@ -147,6 +147,11 @@ int d3p_logreg_evaluate(void* stream, const d3p_logreg_model* model, const float
                         const float* X_dev, const float* y_dev, uint32_t B, const uint32_t* jax_key_dev,
                         float* loss_dev, void* workspace_dev, size_t workspace_bytes);
 
+/* GaussianMixture(locs, scales, pis).log_prob(x) for B rows of x (d3p/gmm.py:71-86; BASELINE config 3's
+ * density).  x: B x d, locs/scales: K x d, pis: K (a simplex; validated by the host layer), K <= 64. */
+int d3p_gmm_log_prob(void* stream, const float* x_dev, uint32_t B, int32_t d, const float* locs_dev,
+                     const float* scales_dev, const float* pis_dev, int32_t K, float* out_dev);
+
 /* _clip_gradients: every row scaled by 1/max(1, ||row||_2 / c) in place (svi.py:68-124, :310-325).
  * c == 0 -> D3P_E_INVALID_ARG (the reference raises ValueError, svi.py:119-120). */
 int d3p_clip_rows(void* stream, float* px_grads_dev, uint32_t B, uint32_t P, float c);

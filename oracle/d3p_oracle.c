@@ -670,6 +670,30 @@ D3P_API void d3po_tf_randint32(const uint32_t key[2], uint64_t n, int32_t minval
     }
 }
 
+/* GaussianMixture.log_prob (d3p/gmm.py:71-86): logsumexp_k( log pi_k + sum_d log N(x_d; mu_kd, sigma_kd) ) per row. */
+D3P_API void d3po_gmm_log_prob(const float* x, int B, int d, const float* locs, const float* scales, const float* pis,
+                               int K, float* out)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < B; ++i) {
+        double best = -INFINITY;
+        double* comp = (double*)malloc((size_t)K * sizeof(double));
+        for (int k = 0; k < K; ++k) {
+            double s = log((double)pis[k]);
+            for (int j = 0; j < d; ++j) {
+                double sc = scales[(size_t)k * d + j], z = ((double)x[(size_t)i * d + j] - locs[(size_t)k * d + j]) / sc;
+                s += -0.5 * z * z - log(sc) - (double)HALF_LOG_2PI;
+            }
+            comp[k] = s;
+            if (s > best) best = s;
+        }
+        double acc = 0.0;
+        for (int k = 0; k < K; ++k) acc += exp(comp[k] - best);
+        out[i] = (float)(best + log(acc));
+        free(comp);
+    }
+}
+
 /* Synthetic logistic-regression table, element (r, c) a pure function of (seed, r, c) so that any
  * shard can be regenerated (mirrors examples/logistic_regression.py:88-104 in
  * distribution): X[r][c] = normal from threefry2x32((seed, 0x58), (r, c))[0];

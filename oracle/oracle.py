@@ -335,6 +335,15 @@ def tf_randint(key, n, minval, maxval):
     return out[:n]
 
 
+def gmm_log_prob(x, locs, scales, pis):
+    """GaussianMixture(locs, scales, pis).log_prob(x) for rows of x (d3p/gmm.py:71-86)."""
+    x, locs, scales, pis = _f32(x), _f32(locs), _f32(scales), _f32(pis)
+    out = np.empty(x.shape[0], np.float32)
+    lib().d3po_gmm_log_prob(_p(x), C.c_int(x.shape[0]), C.c_int(x.shape[1]), _p(locs), _p(scales), _p(pis),
+                            C.c_int(locs.shape[0]), _p(out))
+    return out
+
+
 def synth_logreg(seed, row0, nrows, d):
     X = np.empty((nrows, d), np.float32)
     y = np.empty(nrows, np.float32)
