@@ -62,6 +62,12 @@ def main():
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sampler", choices=["feistel", "poisson"], default="feistel",
+                    help="feistel = subsample_batchify_data w/o replacement (headline); poisson = poisson_batchify_data "
+                         "with q = B/N and the 0.99-quantile padding of examples/logistic_regression.py:126-127")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="developer switch: run rank 0's share of an N-rank weak-scaling job on this GPU, without the "
+                         "collective (local cost of the data-parallel step)")
     ap.add_argument("--force-dist-loop", action="store_true",
                     help="developer switch: use the stepwise data-parallel loop (d3p_amd.dist) even with one rank")
     args = ap.parse_args()
@@ -71,7 +77,7 @@ def main():
     import d3p_amd._lib as L
     import d3p_amd.random as rng
     from d3p_amd import dist as ddist
-    from d3p_amd.minibatch import subsample_batchify_data
+    from d3p_amd.minibatch import poisson_batchify_data, subsample_batchify_data
     from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
     from d3p_amd.svi import DPSVI, DPSVIState
 
@@ -88,9 +94,12 @@ def main():
     L.require_device()
     lib = L.load()
 
-    d, Bg = args.dim, args.batch_per_gpu * world
-    n_rows = args.rows_per_gpu * world
-    lo, hi = ddist.shard_rows(n_rows, rank, world)
+    emu = args.emulate_world if args.emulate_world > 1 else 0
+    d, Bg = args.dim, args.batch_per_gpu * (emu or world)
+    n_rows = args.rows_per_gpu * (emu or world)
+    lo, hi = ddist.shard_rows(n_rows, rank, emu or world)
+    if emu:
+        args.force_dist_loop = True
     X = torch.empty((hi - lo, d), dtype=torch.float32, device=dev)
     y = torch.empty(hi - lo, dtype=torch.float32, device=dev)
     L.check(lib.d3p_synth_logreg(L.stream_ptr(), 123, lo, hi - lo, d, L.ptr(X), L.ptr(y)))
@@ -110,7 +119,10 @@ def main():
         torch.cuda.synchronize()
 
     if world == 1 and not args.force_dist_loop:
-        _, get_batch = subsample_batchify_data((X, y), Bg)
+        if args.sampler == "poisson":
+            _, get_batch = poisson_batchify_data((X, y), Bg / n_rows, 0.99)
+        else:
+            _, get_batch = subsample_batchify_data((X, y), Bg)
 
         def run(st, first, k):
             return svi.run_steps(st, get_batch, bkey, first, k)
@@ -186,7 +198,8 @@ def main():
             "ms_per_step": round(1000.0 * elapsed / args.steps, 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: logistic regression d=512, 1e6 rows per GPU (fp32, HBM-resident), "
-                                   "batch 4096 per GPU by Feistel subsampling w/o replacement, AutoDiagonalNormal, "
+                                   "batch 4096 per GPU by " + ("Feistel subsampling w/o replacement" if args.sampler == "feistel" else
+                                                          "Poisson sampling q = B/N padded to the 0.99 quantile") + ", AutoDiagonalNormal, "
                                    "C=1, sigma=1, Adam 1e-3",
                        "rows": n_rows, "dim": d, "global_batch": Bg, "parallelism": f"dp{world}",
                        "collective": "none" if world == 1 else "1 all-reduce(sum) per step of the int64 fixed-point accumulator, 8 x (2D+2) words (RCCL)"},

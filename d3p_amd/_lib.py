@@ -81,6 +81,7 @@ SIGNATURES = {
     "d3p_feistel_sample": (C.c_int, [_V, _V, _U32, _U32, _V]),
     "d3p_feistel_from_constants": (C.c_int, [_V, _V, _U32, _U32, _V]),
     "d3p_poisson_select_rng": (C.c_int, [_V, C.c_int, _V, _F, _U32, _U32, C.c_int, _V, _V, _V, _SZ]),
+    "d3p_poisson_select_batch": (C.c_int, [_V, C.c_int, _V, _SZ, _F, _U32, _U32, C.c_int, _V, _SZ, _V, _SZ, _U32, _V, _SZ]),
     "d3p_perturb_apply": (C.c_int, [_V, _V, _V, _U64, _F, _F, _V, _F, _V]),
     "d3p_poisson_select_workspace": (_SZ, [_U32]),
     "d3p_poisson_select": (C.c_int, [_V, _V, _F, _U32, _U32, C.c_int, _V, _V, _V, _SZ]),

@@ -34,6 +34,7 @@ struct Workspace {
     float* pack;      // [loc | s | sg | q | lc] x D
     uint32_t* idx;    // D3P_STEP_BATCH x B
     uint32_t* skeys;  // D3P_STEP_BATCH x 2B
+    uint32_t* plist;  // D3P_STEP_BATCH x B: dense owned-position lists
     float* noise;     // D3P_STEP_BATCH x P
     float* eps;       // B x D: guide noise of the NEXT step, staged by k_carrier
     long long* acc;   // 3 x D3P_ACC_R x (P + 2) fixed-point accumulators of the one-launch step
@@ -56,6 +57,7 @@ static size_t carve(const d3p_logreg_model* m, const d3p_batch_source* src, char
     p = take(5 * D * sizeof(float)); if (ws) ws->pack = (float*)p;
     p = take(K * B * sizeof(uint32_t)); if (ws) ws->idx = (uint32_t*)p;
     p = take(K * 2 * B * sizeof(uint32_t)); if (ws) ws->skeys = (uint32_t*)p;
+    p = take(K * B * sizeof(uint32_t)); if (ws) ws->plist = (uint32_t*)p;
     p = take(K * P * sizeof(float)); if (ws) ws->noise = (float*)p;
     p = take(B * D * sizeof(float)); if (ws) ws->eps = (float*)p;
     p = take(3 * (size_t)D3P_ACC_R * (P + 2) * sizeof(long long)); if (ws) ws->acc = (long long*)p;
@@ -63,7 +65,7 @@ static size_t carve(const d3p_logreg_model* m, const d3p_batch_source* src, char
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * (P + 2) * sizeof(float)); if (ws) ws->partials = (float*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * 2 * sizeof(unsigned long long)); if (ws) ws->stamps = (unsigned long long*)p;
     size_t pb = 0;
-    if (src->kind == D3P_BATCH_POISSON) pb = d3p_poisson_select_workspace((uint32_t)src->n_rows);
+    if (src->kind == D3P_BATCH_POISSON) pb = K * d3p_poisson_select_workspace((uint32_t)src->n_rows);
     p = take(pb); if (ws) { ws->poisson_ws = p; ws->poisson_bytes = pb; }
     if (ws2) {
         *ws2 = ws ? *ws : Workspace();
@@ -71,6 +73,7 @@ static size_t carve(const d3p_logreg_model* m, const d3p_batch_source* src, char
     p = take(K * sizeof(StepSlot)); if (ws2) ws2->slots = (StepSlot*)p;
     p = take(K * B * sizeof(uint32_t)); if (ws2) ws2->idx = (uint32_t*)p;
     p = take(K * 2 * B * sizeof(uint32_t)); if (ws2) ws2->skeys = (uint32_t*)p;
+    p = take(K * B * sizeof(uint32_t)); if (ws2) ws2->plist = (uint32_t*)p;
     p = take(K * P * sizeof(float)); if (ws2) ws2->noise = (float*)p;
     p = take(pb); if (ws2) ws2->poisson_ws = p;
     return off;
@@ -145,6 +148,7 @@ struct SamplerArgs {
     int kind;
     int D;
     float b1, b2;
+    uint64_t row_lo, row_hi;  // rows held by this rank: sample keys are only needed for those
 };
 
 __global__ void __launch_bounds__(256) k_sampler(SamplerArgs a)
@@ -184,12 +188,18 @@ __global__ void __launch_bounds__(256) k_sampler(SamplerArgs a)
         __syncthreads();
         const uint32_t p = blockIdx.x * blockDim.x + tid;
         if (p < a.B) {
-            if (a.kind == D3P_BATCH_FEISTEL)
-                a.idx[(size_t)t * a.B + p] = feistel_permute_dev(sh_rc, a.capacity, a.bits_lower, a.bits_upper, p);
-            uint32_t s0, s1;
-            px_sample_key(sh_jax[0], sh_jax[1], a.B, p, s0, s1);
-            a.skeys[((size_t)t * a.B + p) * 2] = s0;
-            a.skeys[((size_t)t * a.B + p) * 2 + 1] = s1;
+            bool owned = true;
+            if (a.kind == D3P_BATCH_FEISTEL) {
+                const uint32_t r = feistel_permute_dev(sh_rc, a.capacity, a.bits_lower, a.bits_upper, p);
+                a.idx[(size_t)t * a.B + p] = r;
+                owned = (uint64_t)r >= a.row_lo && (uint64_t)r < a.row_hi;
+            }
+            if (owned) {  // six dependent threefry calls: skipped for positions another rank processes
+                uint32_t s0, s1;
+                px_sample_key(sh_jax[0], sh_jax[1], a.B, p, s0, s1);
+                a.skeys[((size_t)t * a.B + p) * 2] = s0;
+                a.skeys[((size_t)t * a.B + p) * 2 + 1] = s1;
+            }
         }
         return;
     }
@@ -238,6 +248,49 @@ __global__ void __launch_bounds__(256) k_sampler(SamplerArgs a)
             if (e < a.D) dst[e] = bits_to_normal(o[w]);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// dense list of the batch positions a rank processes: valid (p < counts[1]) and row in [row_lo, row_hi).
+// One workgroup per step; positions stay in ascending order (deterministic).  Needed for Poisson batches
+// (padding) and for row-sharded multi-GPU runs, where only ~B / world of the global positions are owned.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_owned_list(StepSlot* __restrict__ slots, const uint32_t* __restrict__ idx, uint32_t B, uint64_t row_lo, uint64_t row_hi,
+             uint32_t* __restrict__ plist)
+{
+    __shared__ uint32_t part[1024];
+    const int t = blockIdx.y;
+    const uint32_t* ix = idx + (size_t)t * B;
+    uint32_t* out = plist + (size_t)t * B;
+    const uint32_t n_valid = slots[t].counts[1];
+    const uint32_t chunk = (B + 1023u) / 1024u;
+    const uint32_t p0 = threadIdx.x * chunk;
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < chunk; ++i) {
+        const uint32_t p = p0 + i;
+        if (p < B && p < n_valid) {
+            const uint64_t r = ix[p];
+            c += (r >= row_lo && r < row_hi) ? 1u : 0u;
+        }
+    }
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t w = part[threadIdx.x] - c;
+    for (uint32_t i = 0; i < chunk; ++i) {
+        const uint32_t p = p0 + i;
+        if (p < B && p < n_valid) {
+            const uint64_t r = ix[p];
+            if (r >= row_lo && r < row_hi) out[w++] = p;
+        }
+    }
+    if (threadIdx.x == 1023) slots[t].n_owned = part[1023];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -626,6 +679,12 @@ static inline int bit_length_u32(uint32_t v)
     return b;
 }
 
+static bool need_owned_list(const d3p_batch_source* src)
+{
+    if (src->kind == D3P_BATCH_EXPLICIT) return false;
+    return src->kind == D3P_BATCH_POISSON || src->row_lo != 0 || src->row_hi != src->n_rows;
+}
+
 struct Ctx {
     hipStream_t s;
     const d3p_logreg_model* m;
@@ -680,16 +739,22 @@ static int enqueue_sampler(const Ctx& c, int K)
     sa.D = c.D;
     sa.b1 = c.h->b1;
     sa.b2 = c.h->b2;
+    sa.row_lo = c.src->kind == D3P_BATCH_EXPLICIT ? 0 : c.src->row_lo;
+    sa.row_hi = c.src->kind == D3P_BATCH_EXPLICIT ? ~0ull : c.src->row_hi;
     hipLaunchKernelGGL(k_sampler, dim3(cdiv(c.src->B, 256) + 1, K), dim3(256), 0, c.s, sa);
     int rc = check_launch("k_sampler");
     if (rc) return rc;
-    if (c.src->kind == D3P_BATCH_POISSON) {
-        for (int t = 0; t < K; ++t) {
-            rc = d3p_poisson_select((void*)c.s, c.ws.slots[t].batch_key, c.src->q, (uint32_t)c.src->n_rows, c.src->B,
-                                    c.src->suppress, c.ws.idx + (size_t)t * c.src->B, c.ws.slots[t].counts,
-                                    c.ws.poisson_ws, c.ws.poisson_bytes);
-            if (rc) return rc;
-        }
+    if (c.src->kind == D3P_BATCH_POISSON) {  // all K draws in one set of launches (blockIdx.y = step)
+        rc = d3p_poisson_select_batch((void*)c.s, 0, c.ws.slots[0].batch_key, sizeof(StepSlot) / sizeof(uint32_t), c.src->q,
+                                      (uint32_t)c.src->n_rows, c.src->B, c.src->suppress, c.ws.idx, c.src->B,
+                                      c.ws.slots[0].counts, sizeof(StepSlot) / sizeof(uint32_t), (uint32_t)K,
+                                      c.ws.poisson_ws, c.ws.poisson_bytes);
+        if (rc) return rc;
+    }
+    if (need_owned_list(c.src)) {
+        hipLaunchKernelGGL(k_owned_list, dim3(1, K), dim3(1024), 0, c.s, c.ws.slots, (const uint32_t*)c.ws.idx, c.src->B,
+                           (uint64_t)c.src->row_lo, (uint64_t)c.src->row_hi, c.ws.plist);
+        if ((rc = check_launch("k_owned_list"))) return rc;
     }
     return D3P_OK;
 }
@@ -705,6 +770,10 @@ static int enqueue_main(const Ctx& c, int t, const float* X, const float* y, con
     a.idx = c.src->kind == D3P_BATCH_EXPLICIT ? nullptr : c.ws.idx + (size_t)t * c.src->B;
     a.mask = c.src->kind == D3P_BATCH_EXPLICIT ? c.src->mask : nullptr;
     a.counts = c.ws.slots[t].counts;
+    if (need_owned_list(c.src)) {
+        a.plist = c.ws.plist + (size_t)t * c.src->B;
+        a.n_list = &c.ws.slots[t].n_owned;
+    }
     a.skeys = c.ws.skeys + (size_t)t * 2 * c.src->B;
     a.eps_ext = eps;
     a.pack = c.ws.pack;
@@ -923,6 +992,10 @@ static int enqueue_fused_step(const Ctx& c, int g, int t, const StepSlot* prev_s
     a.idx = c.src->kind == D3P_BATCH_EXPLICIT ? nullptr : c.ws.idx + (size_t)t * c.src->B;
     a.mask = c.src->kind == D3P_BATCH_EXPLICIT ? c.src->mask : nullptr;
     a.counts = c.ws.slots[t].counts;
+    if (need_owned_list(c.src) && !flush_only) {
+        a.plist = c.ws.plist + (size_t)t * c.src->B;
+        a.n_list = &c.ws.slots[t].n_owned;
+    }
     a.skeys = c.ws.skeys + (size_t)t * 2 * c.src->B;
     a.pack = c.ws.pack;
     a.partials = c.ws.partials;
@@ -1009,6 +1082,16 @@ static int make_ctx(Ctx* c, void* stream, const d3p_logreg_model* model, const d
     carve(model, src, (char*)workspace_dev, &c->ws, &c->ws2);
     rc = main_geometry(model, src->B, &c->g);
     if (rc) return rc;
+    if (need_owned_list(src)) {
+        // a rank processes ~B * (rows held / rows total) positions (Poisson: <= B valid ones): size the grid for
+        // that, never beyond one workgroup per CU (waves loop over further items)
+        const double frac = (double)(src->row_hi - src->row_lo) / (double)(src->n_rows ? src->n_rows : 1);
+        const uint64_t expected = (uint64_t)((double)src->B * frac + 0.999);
+        uint32_t blocks = cdiv(expected > 0 ? expected : 1, c->g.W);
+        if (blocks > 256u) blocks = 256u;
+        if (blocks < 1u) blocks = 1u;
+        c->g.blocks = blocks;
+    }
     c->s = (hipStream_t)stream;
     c->m = model;
     c->h = hyper;

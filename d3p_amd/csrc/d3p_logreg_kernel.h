@@ -85,6 +85,8 @@ struct StepSlot {
     int32_t adam_i;          // optimiser step index of this step      } these four words are read as
     uint32_t batch_i;        // batch index of this step               } one block by the one-launch
     float bc1, bc2;          // 1 - b1^(i+1), 1 - b2^(i+1)             } step kernel (StepMeta)
+    uint32_t n_owned;        // entries of this step's owned-position list (k_owned_list)
+    uint32_t pad[3];
 };
 
 struct StepMeta {  // view of StepSlot::{adam_i, batch_i, bc1, bc2}
@@ -193,6 +195,8 @@ struct MainArgs {
     const uint32_t* idx;     // nullable: row = p
     const uint8_t* mask;     // nullable
     const uint32_t* counts;  // nullable: valid iff p < counts[1]
+    const uint32_t* plist;   // nullable: dense list of the batch positions this rank processes (valid and owned)
+    const uint32_t* n_list;  // number of entries of plist
     const uint32_t* skeys;   // B x 2 threefry sample keys (unused with eps_ext)
     const float* eps_ext;    // nullable: B x D
     const float* pack;       // 5 x D
@@ -440,18 +444,21 @@ __global__ void __launch_bounds__(1024) k_logreg_main(MainArgs a)
         }
     };
 
+    // items: either every batch position (k == p) or the entries of the dense owned-position list
+    const uint32_t n_items = a.plist ? *a.n_list : a.B;
+    auto pos = [&](uint32_t k) { return a.plist ? a.plist[k] : k; };
     ExLoad<NC> cur;
-    uint32_t p = gw;
-    if (p < a.B) issue(p, cur);
+    uint32_t p = gw;  // item index
+    if (p < n_items) issue(pos(p), cur);
     // The derived columns are first needed AFTER the noise of the first example has been generated,
     // so the staging barrier sits behind that phase (every wave passes exactly one of the two).
     bool staged = false;
-    if (!(p < a.B)) { finish_prologue(); __syncthreads(); staged = true; }
+    if (!(p < n_items)) { finish_prologue(); __syncthreads(); staged = true; }
 
-    while (p < a.B) {
+    while (p < n_items) {
         const uint32_t pn = p + total_waves;
         ExLoad<NC> nxt;
-        if (pn < a.B) issue(pn, nxt);  // prefetch: in flight while the current example computes
+        if (pn < n_items) issue(pos(pn), nxt);  // prefetch: in flight while the current example computes
 
         if (cur.live || MODE == 1) {
             // ---- guide noise eps_i (svi.py:289-290): parity mode reads it, otherwise threefry on chip

@@ -180,9 +180,13 @@ __global__ void k_feistel_from_rc(const uint32_t* __restrict__ rc_in, uint32_t c
 
 template <int RNG>  // 0: ChaCha20 keystream (d3p.random), 1: threefry iota stream (d3p.random.debug)
 __global__ void __launch_bounds__(D3P_PS_THREADS)
-k_poisson_flags(const uint32_t* __restrict__ key, float q, uint32_t N, uint16_t* __restrict__ flags,
-                uint32_t* __restrict__ wg_counts)
+k_poisson_flags(const uint32_t* __restrict__ key, size_t key_stride_words, float q, uint32_t N,
+                uint16_t* __restrict__ flags, uint32_t* __restrict__ wg_counts, size_t ws_stride_bytes)
 {
+    // blockIdx.y selects the step of a batch: every per-step array is `stride` apart
+    key += (size_t)blockIdx.y * key_stride_words;
+    flags = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(flags) + (size_t)blockIdx.y * ws_stride_bytes);
+    wg_counts = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(wg_counts) + (size_t)blockIdx.y * ws_stride_bytes);
     __shared__ uint32_t red[D3P_PS_THREADS / 64];
     const uint32_t t = blockIdx.x * D3P_PS_THREADS + threadIdx.x;
     const uint32_t n_chunks = (N + 15u) / 16u;
@@ -222,8 +226,12 @@ k_poisson_flags(const uint32_t* __restrict__ key, float q, uint32_t N, uint16_t*
 // wg_above[g] = number of selected elements in workgroups with a higher index than g.
 __global__ void __launch_bounds__(1024)
 k_poisson_scan(const uint32_t* __restrict__ wg_counts, uint32_t n_wg, uint32_t cutoff, int suppress,
-               uint32_t* __restrict__ wg_above, uint32_t* __restrict__ counts)
+               uint32_t* __restrict__ wg_above, uint32_t* __restrict__ counts, size_t ws_stride_bytes,
+               size_t counts_stride_words)
 {
+    wg_counts = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(wg_counts) + (size_t)blockIdx.y * ws_stride_bytes);
+    wg_above = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(wg_above) + (size_t)blockIdx.y * ws_stride_bytes);
+    counts += (size_t)blockIdx.y * counts_stride_words;
     __shared__ uint32_t part[1024];
     const uint32_t per = (n_wg + 1023u) / 1024u;
     // thread 0 owns the TOP `per` workgroups, thread 1 the next, ...
@@ -259,8 +267,13 @@ k_poisson_scan(const uint32_t* __restrict__ wg_counts, uint32_t n_wg, uint32_t c
 
 __global__ void __launch_bounds__(D3P_PS_THREADS)
 k_poisson_write(const uint16_t* __restrict__ flags, const uint32_t* __restrict__ wg_above,
-                const uint32_t* __restrict__ counts, uint32_t N, uint32_t cutoff, uint32_t* __restrict__ out_idx)
+                const uint32_t* __restrict__ counts, uint32_t N, uint32_t cutoff, uint32_t* __restrict__ out_idx,
+                size_t ws_stride_bytes, size_t counts_stride_words, size_t idx_stride_words)
 {
+    flags = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(flags) + (size_t)blockIdx.y * ws_stride_bytes);
+    wg_above = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(wg_above) + (size_t)blockIdx.y * ws_stride_bytes);
+    counts += (size_t)blockIdx.y * counts_stride_words;
+    out_idx += (size_t)blockIdx.y * idx_stride_words;
     __shared__ uint32_t wave_cnt[D3P_PS_THREADS / 64];
     const uint32_t t = blockIdx.x * D3P_PS_THREADS + threadIdx.x;
     const uint32_t n_chunks = (N + 15u) / 16u;
@@ -495,14 +508,25 @@ int d3p_poisson_select_rng(void* stream, int rng_kind, const uint32_t* key_dev, 
                            int suppress, uint32_t* out_idx_dev, uint32_t* out_counts_dev, void* workspace_dev,
                            size_t workspace_bytes)
 {
+    return d3p_poisson_select_batch(stream, rng_kind, key_dev, 0, q, N, cutoff, suppress, out_idx_dev, 0, out_counts_dev, 0,
+                                    1, workspace_dev, workspace_bytes);
+}
+
+int d3p_poisson_select_batch(void* stream, int rng_kind, const uint32_t* keys_dev, size_t key_stride_words, float q,
+                             uint32_t N, uint32_t cutoff, int suppress, uint32_t* out_idx_dev, size_t idx_stride_words,
+                             uint32_t* out_counts_dev, size_t counts_stride_words, uint32_t num_steps,
+                             void* workspace_dev, size_t workspace_bytes)
+{
     D3P_REQUIRE(rng_kind == 0 || rng_kind == 1, "d3p_poisson_select: rng_kind must be 0 (chacha) or 1 (threefry)");
-    D3P_REQUIRE(key_dev && out_counts_dev && workspace_dev, "d3p_poisson_select: null pointer");
+    D3P_REQUIRE(keys_dev && out_counts_dev && workspace_dev, "d3p_poisson_select: null pointer");
     D3P_REQUIRE(out_idx_dev || cutoff == 0, "d3p_poisson_select: null index buffer");
     D3P_REQUIRE(N >= 1, "d3p_poisson_select: N must be >= 1");
     D3P_REQUIRE(cutoff <= N, "d3p_poisson_select: cutoff must be <= N");
-    if (workspace_bytes < d3p_poisson_select_workspace(N))
+    D3P_REQUIRE(num_steps >= 1 && num_steps <= 65535, "d3p_poisson_select: 1 <= num_steps <= 65535");
+    const size_t per_step = d3p_poisson_select_workspace(N);
+    if (workspace_bytes < per_step * num_steps)
         return fail(D3P_E_WORKSPACE, "d3p_poisson_select: workspace too small (%zu < %zu)", workspace_bytes,
-                    d3p_poisson_select_workspace(N));
+                    per_step * num_steps);
     const size_t n_chunks = ((size_t)N + 15) / 16;
     const uint32_t n_wg = (uint32_t)((n_chunks + D3P_PS_THREADS - 1) / D3P_PS_THREADS);
     char* ws = (char*)workspace_dev;
@@ -510,15 +534,19 @@ int d3p_poisson_select_rng(void* stream, int rng_kind, const uint32_t* key_dev, 
     uint32_t* wg_counts = (uint32_t*)(ws + align_up(n_chunks * sizeof(uint16_t), 256));
     uint32_t* wg_above = (uint32_t*)((char*)wg_counts + align_up((n_wg + 1) * sizeof(uint32_t), 256));
     hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(n_wg, num_steps);
     if (rng_kind == 0)
-        hipLaunchKernelGGL(k_poisson_flags<0>, dim3(n_wg), dim3(D3P_PS_THREADS), 0, s, key_dev, q, N, flags, wg_counts);
+        hipLaunchKernelGGL(k_poisson_flags<0>, grid, dim3(D3P_PS_THREADS), 0, s, keys_dev, key_stride_words, q, N, flags,
+                           wg_counts, per_step);
     else
-        hipLaunchKernelGGL(k_poisson_flags<1>, dim3(n_wg), dim3(D3P_PS_THREADS), 0, s, key_dev, q, N, flags, wg_counts);
-    hipLaunchKernelGGL(k_poisson_scan, dim3(1), dim3(1024), 0, s, wg_counts, n_wg, cutoff, suppress, wg_above,
-                       out_counts_dev);
+        hipLaunchKernelGGL(k_poisson_flags<1>, grid, dim3(D3P_PS_THREADS), 0, s, keys_dev, key_stride_words, q, N, flags,
+                           wg_counts, per_step);
+    hipLaunchKernelGGL(k_poisson_scan, dim3(1, num_steps), dim3(1024), 0, s, (const uint32_t*)wg_counts, n_wg, cutoff, suppress,
+                       wg_above, out_counts_dev, per_step, counts_stride_words);
     if (cutoff > 0)
-        hipLaunchKernelGGL(k_poisson_write, dim3(n_wg), dim3(D3P_PS_THREADS), 0, s, flags, wg_above, out_counts_dev,
-                           N, cutoff, out_idx_dev);
+        hipLaunchKernelGGL(k_poisson_write, grid, dim3(D3P_PS_THREADS), 0, s, (const uint16_t*)flags,
+                           (const uint32_t*)wg_above, (const uint32_t*)out_counts_dev, N, cutoff, out_idx_dev, per_step,
+                           counts_stride_words, idx_stride_words);
     return check_launch("d3p_poisson_select");
 }
 

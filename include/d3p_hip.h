@@ -107,6 +107,14 @@ int d3p_poisson_select_rng(void* stream, int rng_kind, const uint32_t* key_dev, 
                            uint32_t cutoff, int suppress, uint32_t* out_idx_dev,
                            uint32_t* out_counts_dev, void* workspace_dev, size_t workspace_bytes);
 
+/* The same for `num_steps` independent draws in one set of launches (the fused run loop prepares 32 steps at
+ * once): step t uses the key at keys_dev + t * key_stride_words and writes out_idx_dev + t * idx_stride_words,
+ * out_counts_dev + t * counts_stride_words; the workspace is num_steps x d3p_poisson_select_workspace(N). */
+int d3p_poisson_select_batch(void* stream, int rng_kind, const uint32_t* keys_dev, size_t key_stride_words,
+                             float q, uint32_t N, uint32_t cutoff, int suppress, uint32_t* out_idx_dev,
+                             size_t idx_stride_words, uint32_t* out_counts_dev, size_t counts_stride_words,
+                             uint32_t num_steps, void* workspace_dev, size_t workspace_bytes);
+
 /* jnp.take(a, idx, axis=0) for a row-major table (minibatch.py:126-129, :210, :233, :306).
  * If valid_count_dev != NULL, output rows >= *valid_count_dev are zero-filled (the mask multiply
  * of minibatch.py:127-129).  row_bytes must be a multiple of 4. */
