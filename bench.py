@@ -167,7 +167,8 @@ def main():
                                                      C.byref(avg_us), C.byref(ev_us)))
         # per launch this rank processes its share of the global batch
         alg = algorithmic_bytes(Bg // world, d, P)
-        achieved = alg / (avg_us.value * 1e-6) / 1e9
+        # HIP start/stop events around each launch: the duration that agrees with rocprofv3's kernel trace
+        achieved = alg / (ev_us.value * 1e-6) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
@@ -175,12 +176,15 @@ def main():
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_logreg_main", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+        roofline = {"bound": "hbm", "kernel": "k_logreg_main<MODE 2> (one launch per DP-VI step)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(avg_us.value, 3),
-                    "avg_launch_us_hip_events": round(ev_us.value, 3),
-                    "timing": "device wall-clock stamps (first workgroup entry -> last exit) per launch, 200 launches; "
-                              "hip_events = hipExtLaunchKernel start/stop events (includes ~4 us dispatch floor)"}
+                    "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(ev_us.value, 3),
+                    "avg_launch_us_device_stamps": round(avg_us.value, 3),
+                    "co_bound": {"what": "VALU issue (eps generation: threefry2x32-20 + erf_inv)",
+                                 "valu_instr_per_launch": 3.2e6, "valu_floor_us": 5.5},
+                    "timing": "avg over 200 launches of the production launch (one-launch step incl. the key-chain "
+                              "workgroup) with HIP start/stop events (hipExtLaunchKernel) on the launch stream; "
+                              "device_stamps = first workgroup entry -> last compute workgroup exit (100 MHz clock)"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1415,8 +1415,9 @@ int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model
         ct.src = &src_scratch;
     }
     auto launch = [&](bool stamps, hipEvent_t a0, hipEvent_t a1) {
-        if (fused)  // same accumulator rotation as step 1 of a run, previous step = slot 0
-            return enqueue_fused_step(ct, 1, 0, c.ws.slots, c.ws.noise, X_dev, y_dev, nullptr, nullptr, 0, 0, false, stamps, a0, a1);
+        if (fused)  // same launch as step 1 of a run: previous step = slot 0, key-chain workgroup piggy-backed
+            return enqueue_fused_step(ct, 1, 0, c.ws.slots, c.ws.noise, X_dev, y_dev, nullptr, c.ws2.slots, 0, 0, false, stamps,
+                                      a0, a1);
         return staged ? enqueue_main_staged(c, 0, X_dev, y_dev, stamps, a0, a1)
                       : enqueue_main(c, 0, X_dev, y_dev, nullptr, stamps, a0, a1);
     };
