@@ -107,24 +107,28 @@ struct Sched {
 // split(chain_key, 3) (svi.py:208-211, :413-414).  `last` advances the batch counters of the schedule.
 __device__ __forceinline__ void chain_step(Sched* sched, StepSlot* slot, int t, int last)
 {
-    const int lane = threadIdx.x & 63;
-    uint32_t cur[16], child[16];
-    load_key(sched->key, cur);
+    // lanes 0-3 / 4-7 / 8-11 derive children 0 / 1 / 2 with the 4-lane ChaCha block (the call needs whole quads:
+    // it is made by the first 64 threads of a workgroup, lanes >= 12 compute a discarded fourth copy)
+    const int lane = threadIdx.x & 63, q = lane & 3, child = (lane >> 2) < 3 ? (lane >> 2) : 0;
     const int32_t adam0 = sched->adam_i;
     const uint32_t batch0 = sched->batch_i;
-    derive_child(cur, (uint32_t)(lane < 3 ? lane : 0), 0u, D3P_TAG_SPLIT, child);
-    if (lane == 1 || lane == 2) {
-        uint32_t* dst = lane == 1 ? slot->grad_key : slot->pert_key;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) dst[w] = child[w];
-    } else if (lane == 0) {
-#pragma unroll
-        for (int w = 0; w < 16; ++w) sched->key[w] = child[w];
-        if (last) {
+    uint32_t a, b;
+    derive_child_quad(sched->key, (uint32_t)child, D3P_TAG_SPLIT, 0u, a, b);
+    if (lane < 4) {          // next state key: only the key words and the (zero) counter/nonce change
+        sched->key[4 + q] = a;
+        sched->key[8 + q] = b;
+        sched->key[12 + q] = 0u;
+        if (lane == 0 && last) {
             sched->adam_i = adam0 + t + 1;
             sched->batch_i = batch0 + (uint32_t)(t + 1);
         }
-    } else if (lane == 3) {
+    } else if (lane < 12) {  // gradient key (child 1), perturbation key (child 2)
+        uint32_t* dst = lane < 8 ? slot->grad_key : slot->pert_key;
+        dst[q] = sched->key[q];  // constants row
+        dst[4 + q] = a;
+        dst[8 + q] = b;
+        dst[12 + q] = 0u;
+    } else if (lane == 12) {
         slot->adam_i = adam0 + t;
         slot->batch_i = batch0 + (uint32_t)t;
     }
