@@ -1004,6 +1004,7 @@ static int enqueue_fused_step(const Ctx& c, int g, int t, const StepSlot* prev_s
     a.row_hi = c.src->row_hi;
     a.clip = c.h->clip;
     a.stamps = stamps ? c.ws.stamps : nullptr;
+    if (const char* e = getenv("D3P_DBG")) a.dbg = atoi(e);
     fill_fuse_common(c, &a.fuse, g);
     a.fuse.apply_prev = prev_slot != nullptr;
     a.fuse.prev_noise = prev_noise;

@@ -345,15 +345,48 @@ __global__ void __launch_bounds__(1024) k_logreg_main(MainArgs a)
                 pack_column(col, x);
             }
         } else {
-            for (int col = threadIdx.x; col < P; col += blockDim.x) {
-                float m, v;
-                const float x = apply_pending_column(f, mv, PA, col, n, Bf, a.clip, pend_bc1, pend_bc2, m, v);
-                if (blockIdx.x == 0) {
-                    f.params[col] = x;
-                    f.adam_m[col] = m;
-                    f.adam_v[col] = v;
+            // Only the first PW waves (one per SIMD) run the prologue, CB columns per thread with all loads in
+            // flight together; the other waves go straight to their row loads and eps generation, so the
+            // prologue's memory latency hides behind their VALU work.  Flush launches use every wave.
+            constexpr int CB = 4;
+            const int PW = f.flush_only ? W : (W < 4 ? W : 4);
+            if (wave < PW) {
+                const int stride = 64 * PW;
+                for (int col0 = threadIdx.x; col0 < P; col0 += stride * CB) {
+                    long long r8[CB][D3P_ACC_R];
+                    float x[CB], m[CB], v[CB], z[CB];
+#pragma unroll
+                    for (int j = 0; j < CB; ++j) {
+                        const int col = col0 + j * stride;
+                        const int cc = col < P ? col : 0;
+#pragma unroll
+                        for (int r = 0; r < D3P_ACC_R; ++r) r8[j][r] = f.acc_prev[(size_t)r * PA + cc];
+                        x[j] = f.params[cc];
+                        m[j] = f.adam_m[cc];
+                        v[j] = f.adam_v[cc];
+                        z[j] = f.prev_noise[cc];
+                    }
+#pragma unroll
+                    for (int j = 0; j < CB; ++j) {
+                        const int col = col0 + j * stride;
+                        if (col < P) {
+                            long long sll = 0;
+#pragma unroll
+                            for (int r = 0; r < D3P_ACC_R; ++r) sll += r8[j][r];
+                            const float tot = (float)((double)sll * f.inv_sg);
+                            const float g = (tot / Bf + z[j] * (f.dp_scale * (a.clip / n))) * a.obs_scale * factor;
+                            const float mm = (1.0f - f.b1) * g + f.b1 * m[j];
+                            const float vv = (1.0f - f.b2) * g * g + f.b2 * v[j];
+                            const float xx = x[j] - f.lr * (mm / pend_bc1) / (sqrtf(vv / pend_bc2) + f.adam_eps);
+                            if (blockIdx.x == 0) {  // one workgroup publishes the state
+                                f.params[col] = xx;
+                                f.adam_m[col] = mm;
+                                f.adam_v[col] = vv;
+                            }
+                            pack_column(col, xx);
+                        }
+                    }
                 }
-                pack_column(col, x);
             }
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -367,6 +400,7 @@ __global__ void __launch_bounds__(1024) k_logreg_main(MainArgs a)
     };
     if (MODE == 2 && (a.fuse.flush_only || !kLatePrologue)) {
         finish_prologue();
+        D3P_STAMP(2)
         if (a.fuse.flush_only) return;
     }
 
