@@ -237,8 +237,10 @@ struct ExLoad {
 // FULL: every lane's column pairs exist (D == 2 * 64 * V * NK, no intercept) -> no guards at all.
 // EPS: where the guide noise comes from: 0 = generated on chip (threefry + erf_inv), 1 = read from
 // a.eps_ext (parity mode, or staged by the carrier kernel one step ahead), -1 = decided at run time.
+// NK == 1 (d <= 512): 1024-thread workgroups (<= 128 VGPRs); wider rows keep more columns per lane in registers,
+// so those variants are built for 512-thread workgroups (<= 256 VGPRs) and launched with at most 8 waves.
 template <int V, int NK, int MODE, bool FULL, int EPS>
-__global__ void __launch_bounds__(1024) k_logreg_main(MainArgs a)
+__global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const bool eps_from_mem = (EPS == 1) || (EPS < 0 && a.eps_ext != nullptr);
@@ -696,8 +698,8 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g)
                     2 * 64 * g->V * 8);
     // waves per workgroup (default 16 = one 1024-thread workgroup per CU at 4 waves/SIMD), reduced until
     // pack (5D) + reduction buffer (W x P) fit 64 KiB of LDS; one example per wave per pass.
-    int W = 16, epw = 1;
-    if (const char* e = getenv("D3P_MAIN_W")) { int v = atoi(e); if (v >= 1 && v <= 16) W = v; }
+    int W = g->NK == 1 ? 16 : 8, epw = 1;
+    if (const char* e = getenv("D3P_MAIN_W")) { int v = atoi(e); if (v >= 1 && v <= (g->NK == 1 ? 16 : 8)) W = v; }
     if (const char* e = getenv("D3P_MAIN_EPW")) { int v = atoi(e); if (v >= 1 && v <= 64) epw = v; }
     auto lds_bytes = [&](int w) { return (size_t)(((5 * D + 3) & ~3) + w * P + 2 * w) * sizeof(float); };
     while (W > 1 && lds_bytes(W) > 96 * 1024) W >>= 1;
