@@ -15,6 +15,8 @@ _DEPS = _SRC + [os.path.join(_HERE, "csrc", f) for f in ("d3p_device.h", "d3p_ho
     os.path.join(os.path.dirname(_HERE), "include", "d3p_hip.h")]
 
 D3P_BATCH_EXPLICIT, D3P_BATCH_FEISTEL, D3P_BATCH_POISSON = 0, 1, 2
+D3P_FAMILY_LOGREG, D3P_FAMILY_GAUSS_MEAN = 0, 1
+D3P_GUIDE_SOFTPLUS, D3P_GUIDE_EXP = 0, 1
 
 
 class D3PError(RuntimeError):
@@ -23,7 +25,8 @@ class D3PError(RuntimeError):
 
 class LogregModel(C.Structure):
     _fields_ = [("d", C.c_int32), ("intercept", C.c_int32), ("prior_w", C.c_float),
-                ("prior_b", C.c_float), ("lik_scale", C.c_float), ("inv_obs", C.c_float)]
+                ("prior_b", C.c_float), ("lik_scale", C.c_float), ("inv_obs", C.c_float),
+                ("family", C.c_int32), ("guide_transform", C.c_int32), ("lik_sigma", C.c_float)]
 
 
 class DpsviHyper(C.Structure):
@@ -132,7 +135,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.d3p_abi_version() != 1:
+        if lib.d3p_abi_version() != 2:
             raise D3PError("libd3p_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -421,7 +421,8 @@ __device__ __forceinline__ void finalize_role(const FinalArgs& a, uint32_t blk, 
         if (site == 0) {
             a.pack[e] = x;
         } else {
-            const float s = softplus_f(x), sg = sigmoid_f(x);
+            float s, sg;
+            guide_scale(a.m.guide_transform, x, s, sg);
             const float ps = (e < a.m.d) ? a.m.prior_w : a.m.prior_b;
             a.pack[D + e] = s;
             a.pack[2 * D + e] = sg;
@@ -1123,7 +1124,8 @@ int d3p_dpvi_logreg_local_sums(void* stream, const d3p_logreg_model* model, cons
     Ctx c;
     int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
     if (rc) return rc;
-    D3P_REQUIRE(X_dev && y_dev && sums_dev, "null data pointer");
+    D3P_REQUIRE(X_dev && sums_dev, "null data pointer");
+    if (int rcm = validate_model(model, y_dev, "d3p_dpvi_logreg")) return rcm;
     if ((rc = enqueue_sched_init(c))) return rc;
     if ((rc = enqueue_batch_prep(c, 1))) return rc;
     if ((rc = enqueue_main(c, 0, X_dev, y_dev, eps_dev, false))) return rc;
@@ -1175,7 +1177,8 @@ int d3p_dpvi_logreg_step_sums(void* stream, const d3p_logreg_model* model, const
     Ctx c;
     int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
     if (rc) return rc;
-    D3P_REQUIRE(X_dev && y_dev && sums_dev, "null data pointer");
+    D3P_REQUIRE(X_dev && sums_dev, "null data pointer");
+    if (int rcm = validate_model(model, y_dev, "d3p_dpvi_logreg")) return rcm;
     D3P_REQUIRE(t < D3P_STEP_BATCH, "d3p_dpvi_logreg_step_sums: t must be < 32");
     if ((rc = enqueue_main(c, (int)t, X_dev, y_dev, eps_dev, false))) return rc;
     hipLaunchKernelGGL(k_reduce_partials, dim3(cdiv(c.P + 2, 64)), dim3(64 * D3P_FIN_W), 0, c.s,
@@ -1260,7 +1263,9 @@ int d3p_dpvi_logreg_fused_step(void* stream, const d3p_logreg_model* model, cons
     Ctx c;
     int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
     if (rc) return rc;
-    D3P_REQUIRE(flush_only || (X_dev && y_dev), "null data pointer");
+    D3P_REQUIRE(flush_only || X_dev, "null data pointer");
+    if (!flush_only)
+        if (int rcm = validate_model(model, y_dev, "d3p_dpvi_logreg_fused_step")) return rcm;
     D3P_REQUIRE(t < D3P_STEP_BATCH && prev_t < D3P_STEP_BATCH, "slot index must be < 32");
     Ctx cb[2] = {c, c};
     cb[1].ws = c.ws2;
@@ -1282,7 +1287,8 @@ int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_d
     Ctx c;
     int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
     if (rc) return rc;
-    D3P_REQUIRE(X_dev && y_dev, "null data pointer");
+    D3P_REQUIRE(X_dev, "null data pointer");
+    if (int rcm = validate_model(model, y_dev, "d3p_dpvi_logreg_run")) return rcm;
     D3P_REQUIRE(src->row_lo == 0 && src->row_hi == src->n_rows, "d3p_dpvi_logreg_run is the single-GPU path");
     if ((rc = enqueue_sched_init(c))) return rc;
     if (use_carrier(c)) return run_pipelined(c, X_dev, y_dev, (int)num_steps, losses_dev);
@@ -1386,7 +1392,8 @@ int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model
     Ctx c;
     int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
     if (rc) return rc;
-    D3P_REQUIRE(X_dev && y_dev && avg_us && reps >= 1, "bad arguments");
+    D3P_REQUIRE(X_dev && avg_us && reps >= 1, "bad arguments");
+    if (int rcm = validate_model(model, y_dev, "d3p_dpvi_logreg_time_main_kernel")) return rcm;
     if ((rc = enqueue_sched_init(c))) return rc;
     const bool staged = use_carrier(c);
     if (staged) {

@@ -40,6 +40,26 @@ inline int check_launch(const char* what)
         if (!(cond)) return d3p::fail(D3P_E_INVALID_ARG, "%s", msg);   \
     } while (0)
 
+// model spec checks shared by every entry point that takes a d3p_logreg_model; labels are only read by
+// the Bernoulli family
+inline int validate_model(const d3p_logreg_model* m, const void* y_dev, const char* what)
+{
+    if (!m) return fail(D3P_E_INVALID_ARG, "%s: null model", what);
+    if (!(m->d >= 1 && m->prior_w > 0.f && m->prior_b > 0.f && m->inv_obs > 0.f))
+        return fail(D3P_E_INVALID_ARG, "%s: bad model (d >= 1, prior scales > 0 and inv_obs > 0 are required)", what);
+    if (m->guide_transform != D3P_GUIDE_SOFTPLUS && m->guide_transform != D3P_GUIDE_EXP)
+        return fail(D3P_E_INVALID_ARG, "%s: unknown guide transform %d", what, m->guide_transform);
+    if (m->family == D3P_FAMILY_LOGREG) {
+        if (!y_dev) return fail(D3P_E_INVALID_ARG, "%s: null label pointer", what);
+    } else if (m->family == D3P_FAMILY_GAUSS_MEAN) {
+        if (m->intercept) return fail(D3P_E_INVALID_ARG, "%s: the Gaussian-mean family has no intercept", what);
+        if (!(m->lik_sigma > 0.f)) return fail(D3P_E_INVALID_ARG, "%s: lik_sigma must be > 0", what);
+    } else {
+        return fail(D3P_E_INVALID_ARG, "%s: unknown likelihood family %d", what, m->family);
+    }
+    return D3P_OK;
+}
+
 inline unsigned cdiv(unsigned long long a, unsigned long long b) { return (unsigned)((a + b - 1) / b); }
 
 }  // namespace d3p

@@ -17,10 +17,22 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // derived per-column parameters ("pack"): loc, s = softplus(u), sg = sigmoid(u),
 // q = inv_obs * sg / s, lc = log(prior_std) - log(s)
 // ------------------------------------------------------------------------------------------
+// scale s(u) of the guide and ds/du: softplus (AutoDiagonalNormal) or exp (hand-written example guides)
+__device__ __forceinline__ void guide_scale(int gexp, float u, float& s, float& ds)
+{
+    if (gexp) {
+        s = ds = __expf(u);
+    } else {
+        s = softplus_f(u);
+        ds = sigmoid_f(u);
+    }
+}
+
 __device__ __forceinline__ void pack_column(const d3p_logreg_model& m, int D, int e, float loc, float u,
                                             float* __restrict__ pack)
 {
-    const float s = softplus_f(u), sg = sigmoid_f(u);
+    float s, sg;
+    guide_scale(m.guide_transform, u, s, sg);
     const float ps = (e < m.d) ? m.prior_w : m.prior_b;
     pack[e] = loc;
     pack[D + e] = s;
@@ -217,6 +229,8 @@ struct MainArgs {
     float inv_obs, lik_scale, obs_scale, clip;
     int dbg;  // developer ablation switches (0 in production)
     unsigned long long* stamps;  // nullable: per-workgroup {start, end} wall_clock64 (timing entry point)
+    int family, gexp;            // likelihood family (non-FULL kernels only), guide transform
+    float nh_inv_var, ll_const;  // Gaussian family: -0.5 / sigma^2,  D * (log sigma + log(2 pi) / 2)
     StepFuse fuse;               // MODE 2 only
 };
 
@@ -302,7 +316,8 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
         if (site == 0) {
             pk[e] = x;
         } else {
-            const float sp = softplus_f(x), sgm = sigmoid_f(x);
+            float sp, sgm;
+            guide_scale(a.gexp, x, sp, sgm);
             const float ps = (e < a.d) ? a.fuse.prior_w : a.fuse.prior_b;
             pk[D + e] = sp;
             pk[2 * D + e] = sgm;
@@ -406,6 +421,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
         if (a.fuse.flush_only) return;
     }
 
+    const bool gauss = !FULL && a.family == D3P_FAMILY_GAUSS_MEAN;
     int c0[NC], c1[NC];
     bool ok0[NC], ok1[NC];
 #pragma unroll
@@ -457,7 +473,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
                 }
             }
         }
-        L.y = a.y[row];
+        L.y = a.y ? a.y[row] : 0.f;
         if (!eps_from_mem) {
             L.k0 = a.skeys[2 * p];
             L.k1 = a.skeys[2 * p + 1];
@@ -531,13 +547,27 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
                 const float s0 = ok0[n] ? pk[D + c0[n]] : 0.f, s1 = ok1[n] ? pk[D + c1[n]] : 0.f;
                 z0[n] = __fmaf_rn(s0, e0[n], l0);
                 z1[n] = __fmaf_rn(s1, e1[n], l1);
-                tp = __fmaf_rn(cur.x0[n], z0[n], tp);
-                tp = __fmaf_rn(cur.x1[n], z1[n], tp);
+                if (gauss) {  // residuals take the place of the features: dloglik/dz = (x - z) / sigma^2
+                    cur.x0[n] = ok0[n] ? cur.x0[n] - z0[n] : 0.f;
+                    cur.x1[n] = ok1[n] ? cur.x1[n] - z1[n] : 0.f;
+                    tp = __fmaf_rn(cur.x0[n], cur.x0[n], tp);
+                    tp = __fmaf_rn(cur.x1[n], cur.x1[n], tp);
+                } else {
+                    tp = __fmaf_rn(cur.x0[n], z0[n], tp);
+                    tp = __fmaf_rn(cur.x1[n], z1[n], tp);
+                }
             }
-            const float t = wave_sum(tp);
+            const float t = wave_sum(tp);  // logit x.z, or the squared residual norm
             D3P_STAMP(4)
-            const float sp = softplus_f(t);
-            const float A = a.A_scale * (sigmoid_f(t) - cur.y);
+            // A = d(-lik_scale * inv_obs * loglik)/dt up to the per-column factor; loglik itself
+            float A, loglik;
+            if (gauss) {
+                A = 2.0f * a.A_scale * a.nh_inv_var;
+                loglik = __fmaf_rn(a.nh_inv_var, t, -a.ll_const);
+            } else {
+                A = a.A_scale * (sigmoid_f(t) - cur.y);
+                loglik = cur.y * t - softplus_f(t);
+            }
 
             // ---- per-example gradient, its squared norm and the latent part of the loss
             float g0[NC], h0[NC], g1[NC], h1[NC];
@@ -562,7 +592,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
             n2 = wave_sum(n2);
             lp = wave_sum(lp);
             // L_i = inv_obs * ((logq - logp) - lik_scale * loglik)   (svi.py:278-281)
-            const float L = a.inv_obs * (lp - a.lik_scale * (cur.y * t - sp));
+            const float L = a.inv_obs * (lp - a.lik_scale * loglik);
 
             if (MODE != 1) {
                 // clip factor 1/max(1, ||g||/C) (svi.py:121-122) folded into the running sum (svi.py:343-346)
@@ -692,7 +722,7 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g)
     g->V = vec ? 4 : 1;
     const int need = (half + 64 * g->V - 1) / (64 * g->V);
     g->NK = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 0;
-    g->full = vec && g->NK > 0 && (D == 2 * 64 * g->V * g->NK);
+    g->full = vec && g->NK > 0 && (D == 2 * 64 * g->V * g->NK) && m->family == D3P_FAMILY_LOGREG;
     if (g->NK == 0)
         return fail(D3P_E_UNSUPPORTED, "logreg kernel: latent dimension %d exceeds the supported maximum (%d)", D,
                     2 * 64 * g->V * 8);
@@ -777,6 +807,10 @@ static void fill_model_scalars(const d3p_logreg_model* m, MainArgs* a)
     a->inv_obs = m->inv_obs;
     a->lik_scale = m->lik_scale;
     a->obs_scale = 1.0f / m->inv_obs;
+    a->family = m->family;
+    a->gexp = m->guide_transform;
+    a->nh_inv_var = m->family == D3P_FAMILY_GAUSS_MEAN ? -0.5f / (m->lik_sigma * m->lik_sigma) : 0.f;
+    a->ll_const = m->family == D3P_FAMILY_GAUSS_MEAN ? (float)D * (logf(m->lik_sigma) + 0.91893853320467267f) : 0.f;
 }
 
 }  // namespace d3p

@@ -140,7 +140,8 @@ __global__ void __launch_bounds__(256) k_eval_latent(d3p_logreg_model m, const f
     float acc = 0.f;
     for (int e = threadIdx.x; e < D; e += 256) {
         const float eps = bits_to_normal(tf_iota_word(k0, k1, (uint64_t)D, (uint64_t)e));
-        const float sc = softplus_f(params[D + e]);
+        float sc, dsc;
+        guide_scale(m.guide_transform, params[D + e], sc, dsc);
         const float ps = (e < m.d) ? m.prior_w : m.prior_b;
         const float zz = __fmaf_rn(sc, eps, params[e]);
         z[e] = zz;
@@ -163,6 +164,16 @@ __global__ void k_eval_loglik(d3p_logreg_model m, const float* __restrict__ X, c
     const int lane = threadIdx.x & 63;
     if (i >= B) return;
     float tp = 0.f;
+    if (m.family == D3P_FAMILY_GAUSS_MEAN) {  // log N(x_i; z, sigma) summed over the event dimension
+        for (int c = lane; c < m.d; c += 64) {
+            const float r = X[(size_t)i * m.d + c] - z[c];
+            tp = __fmaf_rn(r, r, tp);
+        }
+        const float t = wave_sum(tp);
+        if (lane == 0)
+            ll[i] = -0.5f * t / (m.lik_sigma * m.lik_sigma) - (float)m.d * (logf(m.lik_sigma) + 0.91893853320467267f);
+        return;
+    }
     for (int c = lane; c < m.d; c += 64) tp = __fmaf_rn(X[(size_t)i * m.d + c], z[c], tp);
     float t = wave_sum(tp);
     if (m.intercept) t += z[m.d];
@@ -306,12 +317,11 @@ int d3p_logreg_px_grads(void* stream, const d3p_logreg_model* model, const float
                         const uint32_t* jax_key_dev, float* px_loss_dev, float* px_grads_dev, float* meta_dev,
                         void* workspace_dev, size_t workspace_bytes)
 {
-    D3P_REQUIRE(model && params_dev && X_dev && y_dev && px_loss_dev && px_grads_dev && meta_dev && workspace_dev,
+    D3P_REQUIRE(model && params_dev && X_dev && px_loss_dev && px_grads_dev && meta_dev && workspace_dev,
                 "d3p_logreg_px_grads: null pointer");
+    if (int rc = validate_model(model, y_dev, "d3p_logreg_px_grads")) return rc;
     D3P_REQUIRE(eps_dev || jax_key_dev, "d3p_logreg_px_grads: either eps_dev or jax_key_dev must be given");
     D3P_REQUIRE(B >= 1, "d3p_logreg_px_grads: B must be >= 1");
-    D3P_REQUIRE(model->d >= 1 && model->prior_w > 0.f && model->prior_b > 0.f && model->inv_obs > 0.f,
-                "d3p_logreg_px_grads: bad model");
     if (workspace_bytes < px_ws_bytes(model, B))
         return fail(D3P_E_WORKSPACE, "d3p_logreg_px_grads: workspace too small (%zu < %zu)", workspace_bytes,
                     px_ws_bytes(model, B));
@@ -440,9 +450,10 @@ int d3p_logreg_evaluate(void* stream, const d3p_logreg_model* model, const float
                         const float* y_dev, uint32_t B, const uint32_t* jax_key_dev, float* loss_dev, void* workspace_dev,
                         size_t workspace_bytes)
 {
-    D3P_REQUIRE(model && params_dev && X_dev && y_dev && jax_key_dev && loss_dev && workspace_dev,
+    D3P_REQUIRE(model && params_dev && X_dev && jax_key_dev && loss_dev && workspace_dev,
                 "d3p_logreg_evaluate: null pointer");
-    D3P_REQUIRE(B >= 1 && model->d >= 1 && model->prior_w > 0.f && model->prior_b > 0.f, "d3p_logreg_evaluate: bad arguments");
+    D3P_REQUIRE(B >= 1, "d3p_logreg_evaluate: B must be >= 1");
+    if (int rc = validate_model(model, y_dev, "d3p_logreg_evaluate")) return rc;
     if (workspace_bytes < d3p_logreg_evaluate_workspace(model, B))
         return fail(D3P_E_WORKSPACE, "d3p_logreg_evaluate: workspace too small");
     const size_t D = (size_t)model->d + (model->intercept ? 1 : 0);

@@ -6,8 +6,10 @@ reference's model + ``numpyro.infer.autoguide.AutoDiagonalNormal`` yields:
 
     params = {'auto_loc': (D,), 'auto_scale': (D,)}     D = number of latent scalars
 
-Reference workloads covered: README.md:89-99 (logistic regression, no intercept, prior N(0, 4))
-and examples/logistic_regression.py:49-66 (with intercept, prior N(0, 1)).
+Reference workloads covered: README.md:89-99 (logistic regression, no intercept, prior N(0, 4)),
+examples/logistic_regression.py:49-66 (with intercept, prior N(0, 1)) and
+examples/simple_gaussian_posterior.py:51-81 (Gaussian observations with a latent mean, hand-written
+guide with an exp-transformed scale; BASELINE config 1).
 """
 import math
 
@@ -20,6 +22,8 @@ class LogisticRegression:
 
     Call signature of the reference models: ``model(xs, ys, N)`` / ``model(batch_X, batch_y,
     num_obs_total=)``; the total count is taken from the keyword ``N`` or ``num_obs_total``."""
+
+    has_labels = True
 
     def __init__(self, d=None, prior_scale=1.0, intercept=False, intercept_prior_scale=1.0):
         self.d = d
@@ -41,6 +45,65 @@ class LogisticRegression:
         if len(args) >= 3 and args[2] is not None:
             return float(args[2])
         return None
+
+
+class GaussianMean:
+    """mu ~ Normal(0, prior_scale)^d;  obs ~ Normal(mu, obs_scale).to_event(1) inside
+    ``plate('batch', num_obs_total, batch_size)`` (examples/simple_gaussian_posterior.py:51-65; the example
+    passes its ``x_var = .1`` as the *scale* of the Normal, so ``obs_scale`` is a standard deviation).
+
+    Call signature of the reference model: ``model(obs, num_obs_total=)``; there are no labels."""
+
+    has_labels = False
+
+    def __init__(self, d=None, prior_scale=1.0, obs_scale=0.1):
+        self.d = d
+        self.prior_scale = float(prior_scale)
+        self.obs_scale = float(obs_scale)
+        self.intercept = False
+        self.intercept_prior_scale = float(prior_scale)
+
+    def latent_dim(self, d):
+        return d
+
+    def site_names(self):
+        return ("mu",)
+
+    @staticmethod
+    def num_obs_total(args, kwargs):
+        for k in ("N", "num_obs_total"):
+            if kwargs.get(k) is not None:
+                return float(kwargs[k])
+        if len(args) >= 2 and args[1] is not None and not hasattr(args[1], "shape"):
+            return float(args[1])
+        return None
+
+    @staticmethod
+    def analytical_solution(obs, prior_scale=1.0, obs_scale=0.1):
+        """Exact posterior of mu: (loc (d,), std scalar).  Conjugate normal-normal update; the reference's
+        helper (examples/simple_gaussian_posterior.py:84-92) is the same formula with its x_var read as a
+        variance."""
+        N = obs.shape[0]
+        var = 1.0 / (N / obs_scale ** 2 + 1.0 / prior_scale ** 2)
+        return var * obs.sum(0) / obs_scale ** 2, math.sqrt(var)
+
+
+class DiagonalNormalGuide:
+    """The hand-written mean-field guides of the reference's examples: one sample site
+    ``Normal(<site>_loc, exp(<site>_std_log))`` over the model's latent vector
+    (examples/simple_gaussian_posterior.py:67-82, 'mu_loc' / 'mu_std_log' initialised to zeros).
+    The parameter dict sorts as [<site>_loc, <site>_std_log], the same flat order as AutoDiagonalNormal."""
+
+    transform = "exp"
+
+    def __init__(self, model, site=None, init_loc=0.0, init_std_log=0.0):
+        self.model = model
+        self.site = site if site is not None else model.site_names()[0]
+        self.init_loc = init_loc
+        self.init_std_log = float(init_std_log)
+
+    def param_names(self):
+        return (self.site + "_loc", self.site + "_std_log")
 
 
 class init_to_uniform:
@@ -66,6 +129,11 @@ class AutoDiagonalNormal:
         self.model = model
         self.init_loc_fn = init_loc_fn if init_loc_fn is not None else init_to_uniform()
         self.init_scale = float(init_scale)
+
+    transform = "softplus"
+
+    def param_names(self):
+        return ("auto_loc", "auto_scale")
 
     def unconstrained_init_scale(self):
         # softplus^-1(init_scale)

@@ -16,7 +16,8 @@ import torch
 from . import _lib
 from . import random as strong_rng
 from ._lib import BatchSource, DpsviHyper, DpsviState, LogregModel, check, ptr, stream_ptr
-from .models import (SGD, Adam, AutoDiagonalNormal, LogisticRegression, init_to_uniform, init_to_value)
+from .models import (SGD, Adam, AutoDiagonalNormal, DiagonalNormalGuide, GaussianMean, LogisticRegression,
+                     init_to_uniform, init_to_value)
 from .util import example_count
 
 PRNGState = Any
@@ -175,19 +176,30 @@ class DPSVI:
 
     # ---------------------------------------------------------------- model plumbing
     def _require_logreg(self):
-        if not isinstance(self.model, LogisticRegression) or not isinstance(self.guide, AutoDiagonalNormal):
-            raise _lib.D3PError("DPSVI: model must be d3p_amd.models.LogisticRegression with an "
-                                "AutoDiagonalNormal guide (the model families built so far)")
+        if (not isinstance(self.model, (LogisticRegression, GaussianMean))
+                or not isinstance(self.guide, (AutoDiagonalNormal, DiagonalNormalGuide))):
+            raise _lib.D3PError("DPSVI: model must be d3p_amd.models.LogisticRegression or GaussianMean with an "
+                                "AutoDiagonalNormal or DiagonalNormalGuide guide (the model families built so far)")
+
+    def _labels(self, args):
+        """The label vector of the batch, or None for families without labels (GaussianMean)."""
+        if not self.model.has_labels:
+            return None
+        return args[1].contiguous().to(torch.float32)
 
     def _model_struct(self, d, kwargs, observation_scale):
         kw = dict(self.static_kwargs)
         kw.update(kwargs)
-        n_total = LogisticRegression.num_obs_total((), kw)
+        n_total = self.model.num_obs_total((), kw)
         # a per-example batch has size 1, so plate(N, 1) scales the likelihood by N (svi.py:277)
         lik_scale = 1.0 if n_total is None else n_total
         m = self.model
+        gauss = isinstance(m, GaussianMean)
         return LogregModel(int(d), int(m.intercept), m.prior_scale, m.intercept_prior_scale,
-                           float(lik_scale), 1.0 / float(observation_scale))
+                           float(lik_scale), 1.0 / float(observation_scale),
+                           _lib.D3P_FAMILY_GAUSS_MEAN if gauss else _lib.D3P_FAMILY_LOGREG,
+                           _lib.D3P_GUIDE_EXP if self.guide.transform == "exp" else _lib.D3P_GUIDE_SOFTPLUS,
+                           m.obs_scale if gauss else 0.0)
 
     def _hyper(self):
         o = self.optim
@@ -211,14 +223,19 @@ class DPSVI:
         d = int(X.shape[1])
         D = self.model.latent_dim(d)
         jax_rng_key = self._rng_suite.convert_to_jax_rng_key(rng_key)
-        fn = self.guide.init_loc_fn
-        if isinstance(fn, init_to_uniform):
-            loc = _dbg_uniform(jax_rng_key, D, -fn.radius, fn.radius)
-        elif isinstance(fn, init_to_value):
-            loc = _as_device_f32(fn.values, X.device).reshape(D).clone()
+        if isinstance(self.guide, DiagonalNormalGuide):
+            # param(<site>_loc, zeros(d)), param(<site>_std_log, zeros(d)) (simple_gaussian_posterior.py:77-79)
+            loc = torch.zeros(D, dtype=torch.float32, device=X.device) + _as_device_f32(self.guide.init_loc, X.device)
+            unc = torch.full((D,), self.guide.init_std_log, dtype=torch.float32, device=X.device)
         else:
-            raise ValueError("unsupported init_loc_fn")
-        unc = torch.full((D,), self.guide.unconstrained_init_scale(), dtype=torch.float32, device=X.device)
+            fn = self.guide.init_loc_fn
+            if isinstance(fn, init_to_uniform):
+                loc = _dbg_uniform(jax_rng_key, D, -fn.radius, fn.radius)
+            elif isinstance(fn, init_to_value):
+                loc = _as_device_f32(fn.values, X.device).reshape(D).clone()
+            else:
+                raise ValueError("unsupported init_loc_fn")
+            unc = torch.full((D,), self.guide.unconstrained_init_scale(), dtype=torch.float32, device=X.device)
         params = torch.cat([loc, unc]).contiguous()
         optim_state = self.optim.init(params)
 
@@ -226,16 +243,20 @@ class DPSVI:
         if self._clip_unscaled_observations:
             kw = dict(self.static_kwargs)
             kw.update(kwargs)
-            n_total = LogisticRegression.num_obs_total(args, kw)
+            n_total = self.model.num_obs_total(args, kw)
             # get_observations_scale on a one-element batch: plate(N, subsample_size=1) -> N (svi.py:225-234)
             observation_scale = 1.0 if n_total is None else n_total
         return DPSVIState(optim_state, rng_key, observation_scale)
 
     def get_params(self, svi_state):
-        """Constrained parameters (numpyro SVI.get_params): auto_scale = softplus(unconstrained)."""
+        """Constrained parameters (numpyro SVI.get_params): auto_scale = softplus(unconstrained) for
+        AutoDiagonalNormal; the hand-written guides keep their ``*_std_log`` unconstrained."""
         p = self.optim.get_params(svi_state.optim_state)
         D = p.numel() // 2
-        return {"auto_loc": p[:D].clone(), "auto_scale": torch.nn.functional.softplus(p[D:])}
+        n_loc, n_scale = self.guide.param_names()
+        if isinstance(self.guide, DiagonalNormalGuide):
+            return {n_loc: p[:D].clone(), n_scale: p[D:].clone()}
+        return {n_loc: p[:D].clone(), n_scale: torch.nn.functional.softplus(p[D:])}
 
     # ---------------------------------------------------------------- stage 1 (svi.py:238-308)
     def _compute_per_example_gradients(self, dp_svi_state, step_rng_key, *args, mask=True, **kwargs):
@@ -243,7 +264,7 @@ class DPSVI:
         _lib.require_device()
         lib = _lib.load()
         X = args[0].contiguous()
-        y = args[1].contiguous().to(torch.float32)
+        y = self._labels(args)
         B, d = X.shape
         D = self.model.latent_dim(d)
         jax_rng_key = self._rng_suite.convert_to_jax_rng_key(step_rng_key).contiguous()
@@ -262,7 +283,8 @@ class DPSVI:
         check(lib.d3p_logreg_px_grads(stream_ptr(), C.byref(model), ptr(params), ptr(X), ptr(y), ptr(mask_t), B,
                                       ptr(eps), ptr(jax_rng_key), ptr(px_loss), ptr(px_grads), ptr(meta),
                                       ptr(ws), ws.numel()))
-        grads = {"auto_loc": px_grads[:, :D], "auto_scale": px_grads[:, D:]}
+        n_loc, n_scale = self.guide.param_names()
+        grads = {n_loc: px_grads[:, :D], n_scale: px_grads[:, D:]}
         return dp_svi_state, px_loss, grads, meta[0], meta[1]
 
     # ---------------------------------------------------------------- stage 2 (svi.py:310-325)
@@ -373,7 +395,8 @@ class DPSVI:
 
     # ---------------------------------------------------------------- update (svi.py:395-434)
     def _fusable(self):
-        return (isinstance(self.model, LogisticRegression) and isinstance(self.guide, AutoDiagonalNormal)
+        return (isinstance(self.model, (LogisticRegression, GaussianMean))
+                and isinstance(self.guide, (AutoDiagonalNormal, DiagonalNormalGuide))
                 and isinstance(self.optim, Adam) and self._rng_suite is strong_rng)
 
     def update(self, svi_state, *args, mask=True, **kwargs):
@@ -404,7 +427,7 @@ class DPSVI:
         _lib.require_device()
         lib = _lib.load()
         X = args[0].contiguous()
-        y = args[1].contiguous().to(torch.float32)
+        y = self._labels(args)
         B, d = X.shape
         D = self.model.latent_dim(d)
         dev = X.device
@@ -440,14 +463,16 @@ class DPSVI:
         ``subsample_batchify_data`` (without replacement) or ``poisson_batchify_data``.
         Returns ``(new_state, losses[num_steps])``."""
         if not self._fusable():
-            raise _lib.D3PError("run_steps needs LogisticRegression + AutoDiagonalNormal + Adam + d3p_amd.random")
+            raise _lib.D3PError("run_steps needs a built model family + diagonal-normal guide + Adam + d3p_amd.random")
         info = getattr(get_batch, "source", None)
         if info is None or info.rng_suite is not strong_rng:
             raise _lib.D3PError("run_steps: get_batch must come from d3p_amd.minibatch with rng_suite=d3p_amd.random")
         _lib.require_device()
         lib = _lib.load()
-        X, y = info.dataset[0], info.dataset[1]
-        if not (X.is_contiguous() and y.is_contiguous() and X.dtype == torch.float32 and y.dtype == torch.float32):
+        X = info.dataset[0]
+        y = info.dataset[1] if self.model.has_labels else None
+        if not (X.is_contiguous() and X.dtype == torch.float32
+                and (y is None or (y.is_contiguous() and y.dtype == torch.float32))):
             raise _lib.D3PError("run_steps: dataset arrays must be contiguous float32 CUDA tensors")
         N, d = X.shape
         dev = X.device
@@ -475,7 +500,7 @@ class DPSVI:
         _lib.require_device()
         lib = _lib.load()
         X = args[0].contiguous()
-        y = args[1].contiguous().to(torch.float32)
+        y = self._labels(args)
         B, d = X.shape
         # we split to have the same seed as `update` given an svi_state (svi.py:446-447)
         jax_rng_key = self._rng_suite.convert_to_jax_rng_key(self._rng_suite.split(svi_state.rng_key, 1)[0]).contiguous()

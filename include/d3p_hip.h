@@ -34,7 +34,7 @@ extern "C" {
 #define D3P_E_UNSUPPORTED (-3)
 #define D3P_E_WORKSPACE (-4)
 
-#define D3P_ABI_VERSION 1
+#define D3P_ABI_VERSION 2
 
 int d3p_abi_version(void);
 const char* d3p_last_error(void);
@@ -133,7 +133,20 @@ typedef struct {
     float prior_b;     /* prior std of the intercept (examples/logistic_regression.py:62) */
     float lik_scale;   /* plate scale = num_obs_total (examples/logistic_regression.py:65) */
     float inv_obs;     /* 1 / observation_scale (svi.py:278) */
+    /* ABI 2: likelihood family and guide transform.  Zero-initialised tails give the ABI-1 meaning. */
+    int32_t family;          /* D3P_FAMILY_LOGREG: ys ~ Bernoulli(logits = xs.w + b)   (README.md:89-99)
+                              * D3P_FAMILY_GAUSS_MEAN: obs ~ Normal(mu, lik_sigma).to_event(1), mu ~ Normal(0, prior_w)
+                              *   (examples/simple_gaussian_posterior.py:51-65; y_dev unused, intercept must be 0) */
+    int32_t guide_transform; /* D3P_GUIDE_SOFTPLUS: scale = softplus(u) (AutoDiagonalNormal);
+                              * D3P_GUIDE_EXP: scale = exp(u) (the hand-written guides of the examples,
+                              *   examples/simple_gaussian_posterior.py:77-81: mu_loc, mu_std_log) */
+    float lik_sigma;         /* observation std of D3P_FAMILY_GAUSS_MEAN */
 } d3p_logreg_model;
+
+#define D3P_FAMILY_LOGREG 0
+#define D3P_FAMILY_GAUSS_MEAN 1
+#define D3P_GUIDE_SOFTPLUS 0
+#define D3P_GUIDE_EXP 1
 
 /* _compute_per_example_gradients for the logistic-regression + AutoDiagonalNormal workload
  * (svi.py:238-308).  params_dev = [auto_loc (D) | auto_scale unconstrained (D)].

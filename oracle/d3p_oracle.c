@@ -420,12 +420,26 @@ typedef struct {
     float prior_b;      /* prior std of the intercept */
     float lik_scale;    /* plate scale N (num_obs_total) */
     float inv_obs;      /* 1 / observation_scale (svi.py:278) */
+    int32_t family;     /* 0: Bernoulli-logit regression; 1: obs ~ Normal(mu, lik_sigma).to_event(1), mu ~ N(0, prior_w)
+                         * (examples/simple_gaussian_posterior.py:51-65; labels unused) */
+    int32_t guide_exp;  /* 0: scale = softplus(u) (AutoDiagonalNormal); 1: scale = exp(u)
+                         * (examples/simple_gaussian_posterior.py:77-81, params mu_loc / mu_std_log) */
+    float lik_sigma;    /* observation std of family 1 */
 } d3po_logreg_spec;
+
+/* scale of the guide and its derivative wrt the unconstrained parameter */
+static inline void guide_scale(const d3po_logreg_spec* sp, float u, float* s, float* ds);
 
 static inline float softplus_f(float t) { return fmaxf(t, 0.0f) + log1pf(expf(-fabsf(t))); }
 static inline float sigmoid_f(float t) { return 1.0f / (1.0f + expf(-t)); }
 
 #define HALF_LOG_2PI 0.918938533204672742f
+
+static inline void guide_scale(const d3po_logreg_spec* sp, float u, float* s, float* ds)
+{
+    if (sp->guide_exp) { *s = *ds = expf(u); }
+    else { *s = softplus_f(u); *ds = sigmoid_f(u); }
+}
 
 /* One example: loss and gradient wrt (auto_loc, auto_scale_unc); grad has 2*D entries
  * [d/dloc (D) | d/dunc (D)] = tree_flatten order of {auto_loc, auto_scale} (svi.py:490). */
@@ -434,28 +448,37 @@ D3P_API float d3po_logreg_px_loss_grad(const d3po_logreg_spec* sp, const float* 
                                        float* grad /* 2*D or NULL */)
 {
     const int d = sp->d, D = sp->d + (sp->intercept ? 1 : 0);
+    const int gauss = sp->family == 1;
+    const double inv_var = gauss ? 1.0 / ((double)sp->lik_sigma * (double)sp->lik_sigma) : 0.0;
     double t = 0.0, lq = 0.0, lp = 0.0; /* accumulate in double: the oracle is the accurate side */
     for (int j = 0; j < D; ++j) {
-        float s = softplus_f(unc[j]);
+        float s, sg;
+        guide_scale(sp, unc[j], &s, &sg);
         float z = fmaf(s, eps[j], loc[j]);
         float ps = (j < d) ? sp->prior_w : sp->prior_b;
         float xv = (j < d) ? x[j] : 1.0f;
-        t += (double)xv * (double)z;
+        if (gauss) { double r = (double)xv - (double)z; t += r * r; } /* squared residual norm */
+        else t += (double)xv * (double)z;                             /* logit */
         lq += -0.5 * (double)eps[j] * (double)eps[j] - log((double)s) - (double)HALF_LOG_2PI;
         lp += -0.5 * ((double)z / ps) * ((double)z / ps) - log((double)ps) - (double)HALF_LOG_2PI;
     }
     float tf = (float)t;
-    double loglik = (double)y * t - (double)softplus_f(tf);
+    double loglik = gauss ? -0.5 * t * inv_var - D * (log((double)sp->lik_sigma) + (double)HALF_LOG_2PI)
+                          : (double)y * t - (double)softplus_f(tf);
     double L = (double)sp->inv_obs * ((lq - lp) - (double)sp->lik_scale * loglik) * mask;
     if (grad) {
-        float A = sp->inv_obs * sp->lik_scale * (sigmoid_f(tf) - y);
+        /* dL/dz_j = inv_obs * z_j / ps^2 + A * xa_j, with (A, xa) = (inv_obs N (sigmoid(t) - y), x) for the
+         * Bernoulli family and (-inv_obs N / sigma^2, x - z) for the Gaussian one */
+        float A = gauss ? (float)(-(double)sp->inv_obs * sp->lik_scale * inv_var)
+                        : sp->inv_obs * sp->lik_scale * (sigmoid_f(tf) - y);
         for (int j = 0; j < D; ++j) {
-            float s = softplus_f(unc[j]);
-            float sg = sigmoid_f(unc[j]);
+            float s, sg;
+            guide_scale(sp, unc[j], &s, &sg);
             float z = fmaf(s, eps[j], loc[j]);
             float ps = (j < d) ? sp->prior_w : sp->prior_b;
             float xv = (j < d) ? x[j] : 1.0f;
-            float g = sp->inv_obs * z / (ps * ps) + A * xv;
+            float xa = gauss ? xv - z : xv;
+            float g = sp->inv_obs * z / (ps * ps) + A * xa;
             float h = (g * eps[j] - sp->inv_obs / s) * sg;
             grad[j] = g * mask;
             grad[D + j] = h * mask;
@@ -481,7 +504,7 @@ D3P_API int d3po_logreg_px_grads(const d3po_logreg_spec* sp, const float* loc, c
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < B; ++i) {
         float m = mask ? mask[i] : 1.0f;
-        float L = d3po_logreg_px_loss_grad(sp, loc, unc, Xb + (size_t)i * sp->d, yb[i],
+        float L = d3po_logreg_px_loss_grad(sp, loc, unc, Xb + (size_t)i * sp->d, yb ? yb[i] : 0.0f,
                                            eps + (size_t)i * D, m, px_grads + (size_t)i * 2 * D);
         px_loss[i] = L * obs * f;
     }
@@ -637,7 +660,8 @@ D3P_API float d3po_logreg_evaluate(const d3po_logreg_spec* sp, const float* loc,
     d3po_tf_normal(k, (uint64_t)D, eps);
     double lq = 0.0, lp = 0.0;
     for (int j = 0; j < D; ++j) {
-        float sc = softplus_f(unc[j]);
+        float sc, dsc;
+        guide_scale(sp, unc[j], &sc, &dsc);
         float ps = (j < d) ? sp->prior_w : sp->prior_b;
         z[j] = fmaf(sc, eps[j], loc[j]);
         lq += -0.5 * (double)eps[j] * eps[j] - log((double)sc) - (double)HALF_LOG_2PI;
@@ -645,6 +669,12 @@ D3P_API float d3po_logreg_evaluate(const d3po_logreg_spec* sp, const float* loc,
     }
     double ll = 0.0;
     for (int i = 0; i < B; ++i) {
+        if (sp->family == 1) {
+            double t = 0.0;
+            for (int j = 0; j < d; ++j) { double r = (double)Xb[(size_t)i * d + j] - (double)z[j]; t += r * r; }
+            ll += -0.5 * t / ((double)sp->lik_sigma * sp->lik_sigma) - d * (log((double)sp->lik_sigma) + (double)HALF_LOG_2PI);
+            continue;
+        }
         double t = sp->intercept ? (double)z[d] : 0.0;
         for (int j = 0; j < d; ++j) t += (double)Xb[(size_t)i * d + j] * (double)z[j];
         ll += (double)yb[i] * t - (double)softplus_f((float)t);

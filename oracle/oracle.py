@@ -27,7 +27,8 @@ _lib = None
 
 class LogregSpec(C.Structure):
     _fields_ = [("d", C.c_int32), ("intercept", C.c_int32), ("prior_w", C.c_float),
-                ("prior_b", C.c_float), ("lik_scale", C.c_float), ("inv_obs", C.c_float)]
+                ("prior_b", C.c_float), ("lik_scale", C.c_float), ("inv_obs", C.c_float),
+                ("family", C.c_int32), ("guide_exp", C.c_int32), ("lik_sigma", C.c_float)]
 
 
 class Hyper(C.Structure):
@@ -219,14 +220,20 @@ def poisson_select(key, q, N, cutoff, suppress=False):
 
 
 # ------------------------------------------------------------------ DP-VI stages (logistic regression)
-def logreg_spec(d, intercept=False, prior_w=1.0, prior_b=1.0, lik_scale=1.0, obs_scale=1.0):
-    return LogregSpec(d, int(intercept), prior_w, prior_b, lik_scale, 1.0 / obs_scale)
+def logreg_spec(d, intercept=False, prior_w=1.0, prior_b=1.0, lik_scale=1.0, obs_scale=1.0, guide_exp=False):
+    return LogregSpec(d, int(intercept), prior_w, prior_b, lik_scale, 1.0 / obs_scale, 0, int(guide_exp), 0.0)
+
+
+def gauss_mean_spec(d, prior=1.0, lik_sigma=0.1, lik_scale=1.0, obs_scale=1.0, guide_exp=True):
+    """examples/simple_gaussian_posterior.py:51-81 (family 1); labels are unused (pass None)."""
+    return LogregSpec(d, 0, prior, prior, lik_scale, 1.0 / obs_scale, 1, int(guide_exp), lik_sigma)
 
 
 def logreg_px_grads(spec, loc, unc, Xb, yb, eps, mask=None):
     B = Xb.shape[0]
     D = spec.d + spec.intercept
-    Xb, yb, eps, loc, unc = _f32(Xb), _f32(yb), _f32(eps), _f32(loc), _f32(unc)
+    Xb, eps, loc, unc = _f32(Xb), _f32(eps), _f32(loc), _f32(unc)
+    yb = np.zeros(B, np.float32) if yb is None else _f32(yb)   # labels are unused by the Gaussian family
     m = None if mask is None else _f32(mask)
     px_loss = np.empty(B, np.float32)
     px_grads = np.empty((B, 2 * D), np.float32)
@@ -310,7 +317,8 @@ def logreg_update(spec, hyper, st, Xb, yb, mask=None, eps=None):
     """One DPSVI.update (svi.py:395-434); returns (loss, perturbed_grads)."""
     B = Xb.shape[0]
     D = spec.d + spec.intercept
-    Xb, yb = _f32(Xb), _f32(yb)
+    Xb = _f32(Xb)
+    yb = np.zeros(B, np.float32) if yb is None else _f32(yb)
     m = None if mask is None else _f32(mask)
     e = None if eps is None else _f32(eps)
     scratch = np.empty(B * 2 * D + B + B * D + 4 * D, np.float32)
@@ -324,7 +332,8 @@ def logreg_update(spec, hyper, st, Xb, yb, mask=None, eps=None):
 
 def logreg_evaluate(spec, loc, unc, Xb, yb, jax_key):
     """DPSVI.evaluate (svi.py:436-449): -ELBO of a batch with one guide draw; jax_key = convert(split(key, 1)[0])."""
-    Xb, yb, loc, unc = _f32(Xb), _f32(yb), _f32(loc), _f32(unc)
+    Xb, loc, unc = _f32(Xb), _f32(loc), _f32(unc)
+    yb = np.zeros(Xb.shape[0], np.float32) if yb is None else _f32(yb)
     return float(lib().d3po_logreg_evaluate(C.byref(spec), _p(loc), _p(unc), _p(Xb), _p(yb), C.c_int(Xb.shape[0]),
                                             _p(_u32(jax_key))))
 

@@ -20,3 +20,16 @@ def test_logistic_regression_example_learns(gpu):
     # learns: held-out accuracy well above chance (the labels are noisy: ~0.77 is what the true weights reach)
     # and the training loss falls
     assert accs[-1] > 0.7 and train_losses[-1] < 0.8 * train_losses[0]
+
+
+def test_simple_gaussian_posterior_example_recovers_the_mean(gpu):
+    """BASELINE configs[0] with the example's own defaults (N = 1000, d = 4, batch 10 -> q = 0.01, sigma = 1, C = 1)."""
+    spec = importlib.util.spec_from_file_location("ex_gauss", os.path.join(ROOT, "examples", "simple_gaussian_posterior.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    args = argparse.Namespace(sigma=1.0, num_epochs=30, learning_rate=1e-2, batch_size=10, dimensions=4,
+                              num_samples=1000, clip_threshold=1.0)
+    mu_loc, mu_std, a_loc, a_std = mod.main(args)
+    # 3000 noisy, clipped steps from mu_loc = 0: the mean has moved most of the way to 1 and the scale shrank
+    assert float((mu_loc - a_loc).abs().max()) < 0.35
+    assert float(mu_std.max()) < 1.0

@@ -24,13 +24,13 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/d3p_hip.h but not exported"
     assert declared == set(L.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
-    assert lib.d3p_abi_version() == 1
+    assert lib.d3p_abi_version() == 2
     assert isinstance(lib.d3p_device_count(), int)
 
 
 def test_struct_layouts_match_the_header():
     import d3p_amd._lib as L
-    assert ctypes.sizeof(L.LogregModel) == 24
+    assert ctypes.sizeof(L.LogregModel) == 36 and L.LogregModel.family.offset == 24
     assert ctypes.sizeof(L.DpsviHyper) == 24
     assert ctypes.sizeof(L.DpsviState) == 48 and L.DpsviState.params.offset == 16
     assert ctypes.sizeof(L.BatchSource) == 64 and L.BatchSource.batch_key.offset == 16

@@ -282,3 +282,50 @@ def test_config1_simple_posterior_plumbing(O):
     loc = st.params[:d]
     cos = float(loc @ w / (np.linalg.norm(loc) * np.linalg.norm(w)))
     assert cos > 0.9
+
+
+@pytest.mark.parametrize("guide_exp", [False, True])
+def test_gauss_mean_gradient_vs_finite_differences(O, guide_exp):
+    """Gaussian-mean family (examples/simple_gaussian_posterior.py:51-81) and the exp-transformed hand-written
+    guide: the oracle's analytic per-example gradient against central differences of the loss in float64."""
+    d, N = 6, 50.0
+    r = np.random.default_rng(3)
+    spec = O.gauss_mean_spec(d, prior=1.3, lik_sigma=0.7, lik_scale=N, obs_scale=2.0, guide_exp=guide_exp)
+    loc = r.normal(size=d).astype(np.float32)
+    unc = (r.normal(size=d) * 0.3).astype(np.float32)
+    X = r.normal(size=(1, d)).astype(np.float32)
+    eps = r.normal(size=(1, d)).astype(np.float32)
+    loss, g, n, f = O.logreg_px_grads(spec, loc, unc, X, None, eps)
+
+    def L(p):
+        s = np.exp(p[d:]) if guide_exp else np.log1p(np.exp(p[d:]))
+        z = p[:d] + s * eps[0]
+        lq = np.sum(-0.5 * eps[0] ** 2 - np.log(s) - 0.5 * np.log(2 * np.pi))
+        lp = np.sum(-0.5 * (z / 1.3) ** 2 - np.log(1.3) - 0.5 * np.log(2 * np.pi))
+        ll = np.sum(-0.5 * ((X[0] - z) / 0.7) ** 2 - np.log(0.7) - 0.5 * np.log(2 * np.pi))
+        return 0.5 * ((lq - lp) - N * ll)      # inv_obs = 1 / 2
+
+    p = np.concatenate([loc, unc]).astype(np.float64)
+    fd = np.array([(L(p + 1e-6 * e) - L(p - 1e-6 * e)) / 2e-6 for e in np.eye(2 * d)])
+    assert n == 1 and f == 1.0
+    assert abs(loss[0] - 2.0 * L(p)) < 1e-5 * abs(2.0 * L(p))      # px_loss is rescaled by obs_scale (svi.py:306)
+    np.testing.assert_allclose(g[0], fd, rtol=1e-4, atol=1e-4)
+
+
+def test_config1_gauss_mean_converges_to_the_analytical_posterior(O):
+    """BASELINE configs[0] (examples/simple_gaussian_posterior.py: N = 1000 toy rows around mu = 1, hand-written
+    guide initialised at the prior): non-private-ish DP-VI on the CPU restatement reaches the conjugate posterior."""
+    N, d, B = 1000, 4, 100
+    r = np.random.default_rng(1234)
+    X = (1.0 + 0.1 * r.normal(size=(N, d))).astype(np.float32)
+    spec = O.gauss_mean_spec(d, prior=1.0, lik_sigma=0.1, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(20.0, 0.01, 2e-2, 0.9, 0.999, 1e-8)
+    st = O.LogregState(O.PRNGKey(0), d, np.zeros(d, np.float32), np.zeros(d, np.float32))
+    bkey = O.PRNGKey(1)
+    for i in range(1500):
+        idx = O.feistel_sample(O.fold_in(bkey, i), N, B)
+        O.logreg_update(spec, hy, st, X[idx], None)
+    var = 1.0 / (N / 0.1 ** 2 + 1.0)
+    loc_exact, std_exact = var * X.sum(0) / 0.1 ** 2, np.sqrt(var)
+    assert np.abs(st.params[:d] - loc_exact).max() < 0.02
+    assert np.all(np.exp(st.params[d:]) < 0.05)          # started at 1.0, exact value is 0.0032
