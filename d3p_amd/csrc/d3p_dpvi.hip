@@ -39,6 +39,7 @@ struct Workspace {
     float* eps;       // B x D: guide noise of the NEXT step, staged by k_carrier
     long long* acc;   // 3 x D3P_ACC_R x (P + 2) fixed-point accumulators of the one-launch step
     float* scratch_state;  // 3P + 4 floats: stand-in state for the timing entry point
+    float* pp_state;       // 3P floats: second buffer of the ping-ponged optimiser state (one-launch-per-step path)
     float* partials;  // max_blocks x (P + 2)
     unsigned long long* stamps;  // 2 x max_blocks
     void* poisson_ws;
@@ -62,6 +63,7 @@ static size_t carve(const d3p_logreg_model* m, const d3p_batch_source* src, char
     p = take(B * D * sizeof(float)); if (ws) ws->eps = (float*)p;
     p = take(3 * (size_t)D3P_ACC_R * (P + 2) * sizeof(long long)); if (ws) ws->acc = (long long*)p;
     p = take((3 * P + 4) * sizeof(float)); if (ws) ws->scratch_state = (float*)p;
+    p = take(3 * P * sizeof(float)); if (ws) ws->pp_state = (float*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * (P + 2) * sizeof(float)); if (ws) ws->partials = (float*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * 2 * sizeof(unsigned long long)); if (ws) ws->stamps = (unsigned long long*)p;
     size_t pb = 0;
@@ -956,9 +958,6 @@ static void fill_fuse_common(const Ctx& c, StepFuse* f, int g)
     f->acc_cur = c.ws.acc + (size_t)(g % 3) * D3P_ACC_R * PA;
     f->acc_next = c.ws.acc + (size_t)((g + 1) % 3) * D3P_ACC_R * PA;
     f->R = D3P_ACC_R;
-    f->params = c.st->params;
-    f->adam_m = c.st->adam_m;
-    f->adam_v = c.st->adam_v;
     f->adam_step = c.st->step;
     f->batch_index = c.src->kind == D3P_BATCH_EXPLICIT ? nullptr : c.src->batch_index;
     f->dp_scale = c.h->dp_scale;
@@ -1007,6 +1006,21 @@ static int enqueue_fused_step(const Ctx& c, int g, int t, const StepSlot* prev_s
     a.stamps = stamps ? c.ws.stamps : nullptr;
     if (const char* e = getenv("D3P_DBG")) a.dbg = atoi(e);
     fill_fuse_common(c, &a.fuse, g);
+    {
+        // Launch g applies the update of step g - 1: it reads state buffer (g - 1) & 1 and publishes to buffer g & 1
+        // (buffer 0 = the caller's arrays, buffer 1 = workspace).  The flush launch (one workgroup) always
+        // publishes to the caller's arrays; the first launch has nothing to apply and only reads them.
+        const size_t P = (size_t)c.P;
+        float* const bufs[2][3] = {{c.st->params, c.st->adam_m, c.st->adam_v},
+                                   {c.ws.pp_state, c.ws.pp_state + P, c.ws.pp_state + 2 * P}};
+        const int in = g > 0 ? ((g - 1) & 1) : 0, out = flush_only ? 0 : (g & 1);
+        a.fuse.params_in = bufs[in][0];
+        a.fuse.m_in = bufs[in][1];
+        a.fuse.v_in = bufs[in][2];
+        a.fuse.params_out = bufs[out][0];
+        a.fuse.m_out = bufs[out][1];
+        a.fuse.v_out = bufs[out][2];
+    }
     a.fuse.apply_prev = prev_slot != nullptr;
     a.fuse.prev_noise = prev_noise;
     a.fuse.prev_meta = prev_slot ? reinterpret_cast<const StepMeta*>(&prev_slot->adam_i) : nullptr;

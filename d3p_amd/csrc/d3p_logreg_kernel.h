@@ -157,9 +157,15 @@ struct StepFuse {
     int R;
     int apply_prev;
     int flush_only;       // apply the pending sums and return (after the last step of a run)
-    float* params;
-    float* adam_m;
-    float* adam_v;
+    // optimiser state, ping-ponged between two buffers: every workgroup reads the `_in` arrays and workgroup 0
+    // publishes the updated values to the `_out` arrays, so a workgroup that starts late never sees a
+    // half-published state (in == out only in the single-workgroup flush launch)
+    const float* params_in;
+    const float* m_in;
+    const float* v_in;
+    float* params_out;
+    float* m_out;
+    float* v_out;
     int32_t* adam_step;
     uint32_t* batch_index;       // nullable
     const float* prev_noise;     // P standard normals of the previous step
@@ -186,7 +192,7 @@ __device__ __forceinline__ float apply_pending_column(const StepFuse& f, const d
     long long r8[D3P_ACC_R];
 #pragma unroll
     for (int r = 0; r < D3P_ACC_R; ++r) r8[r] = f.acc_prev[(size_t)r * PA + col];
-    float x = f.params[col], m = f.adam_m[col], v = f.adam_v[col];
+    float x = f.params_in[col], m = f.m_in[col], v = f.v_in[col];
     const float z = f.prev_noise[col];
     long long s = 0;
 #pragma unroll
@@ -302,9 +308,9 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
                 const int col = threadIdx.x;
 #pragma unroll
                 for (int r = 0; r < D3P_ACC_R; ++r) pend_r8[r] = f.acc_prev[(size_t)r * PA + col];
-                pend_x = f.params[col];
-                pend_m = f.adam_m[col];
-                pend_v = f.adam_v[col];
+                pend_x = f.params_in[col];
+                pend_m = f.m_in[col];
+                pend_v = f.v_in[col];
                 pend_z = f.prev_noise[col];
             }
         }
@@ -332,7 +338,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
         const StepFuse& f = a.fuse;
         const int PA = P + 2;
         if (!f.apply_prev) {  // no pending update: derive the columns from the parameters as they are
-            for (int col = threadIdx.x; col < P; col += blockDim.x) pack_column(col, f.params[col]);
+            for (int col = threadIdx.x; col < P; col += blockDim.x) pack_column(col, f.params_in[col]);
             return;
         }
         long long nll = 0;
@@ -355,9 +361,9 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
                 v = (1.0f - f.b2) * g * g + f.b2 * v;
                 x = x - f.lr * (m / pend_bc1) / (sqrtf(v / pend_bc2) + f.adam_eps);
                 if (blockIdx.x == 0) {  // one workgroup publishes the state
-                    f.params[col] = x;
-                    f.adam_m[col] = m;
-                    f.adam_v[col] = v;
+                    f.params_out[col] = x;
+                    f.m_out[col] = m;
+                    f.v_out[col] = v;
                 }
                 pack_column(col, x);
             }
@@ -378,9 +384,9 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
                         const int cc = col < P ? col : 0;
 #pragma unroll
                         for (int r = 0; r < D3P_ACC_R; ++r) r8[j][r] = f.acc_prev[(size_t)r * PA + cc];
-                        x[j] = f.params[cc];
-                        m[j] = f.adam_m[cc];
-                        v[j] = f.adam_v[cc];
+                        x[j] = f.params_in[cc];
+                        m[j] = f.m_in[cc];
+                        v[j] = f.v_in[cc];
                         z[j] = f.prev_noise[cc];
                     }
 #pragma unroll
@@ -396,9 +402,9 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
                             const float vv = (1.0f - f.b2) * g * g + f.b2 * v[j];
                             const float xx = x[j] - f.lr * (mm / pend_bc1) / (sqrtf(vv / pend_bc2) + f.adam_eps);
                             if (blockIdx.x == 0) {  // one workgroup publishes the state
-                                f.params[col] = xx;
-                                f.adam_m[col] = mm;
-                                f.adam_v[col] = vv;
+                                f.params_out[col] = xx;
+                                f.m_out[col] = mm;
+                                f.v_out[col] = vv;
                             }
                             pack_column(col, xx);
                         }

@@ -440,3 +440,31 @@ def test_evaluate_vs_oracle(rng, O, B, d, icpt):
     t = X.astype(np.float64) @ z[:d] + (z[d] if icpt else 0.0)
     ll = np.sum(y * t - np.logaddexp(0, t))
     assert abs(exp - (-(logp + N / B * ll - logq))) <= 1e-5 * abs(exp)
+
+
+@pytest.mark.parametrize("B,d", [(16384, 64), (4096, 512)])
+def test_run_steps_with_more_workgroups_than_cus_matches_stepwise_updates(rng, B, d):
+    """The device-resident loop applies every update exactly once in every workgroup, also when a launch has more
+    workgroups than the chip has CUs (late workgroups start after the first ones have published the new
+    parameters): run_steps and the one-step-at-a-time update() walk the same trajectory, and run_steps is
+    bitwise reproducible."""
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, steps = 10**5, 7
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(N, d, generator=g).cuda()
+    y = (torch.rand(N, generator=g) < 0.5).float().cuda()
+    svi = make_svi(d, False, N, C=1.0, sigma=0.3, lr=5e-2)
+    st = state_with(svi, rng.PRNGKey(11), np.zeros(d, np.float32), np.full(d, -1.0, np.float32))
+    init, get_batch = subsample_batchify_data((X, y), B)
+    _, bstate = init(rng.PRNGKey(12))
+    runs = [svi.run_steps(st, get_batch, bstate, 0, steps) for _ in range(3)]
+    for s2, l2 in runs[1:]:
+        assert torch.equal(s2.optim_state[1], runs[0][0].optim_state[1]) and torch.equal(l2, runs[0][1])
+    ref = st
+    ref_losses = []
+    for t in range(steps):
+        ref, l = svi.update(ref, *get_batch(t, bstate))
+        ref_losses.append(float(l))
+    np.testing.assert_allclose(np_(runs[0][1]), ref_losses, rtol=2e-5)
+    np.testing.assert_allclose(np_(runs[0][0].optim_state[1]), np_(ref.optim_state[1]), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(np_(runs[0][0].optim_state[2]), np_(ref.optim_state[2]), rtol=2e-4, atol=1e-9)
