@@ -97,6 +97,8 @@ SIGNATURES = {
     "d3p_perturb": (C.c_int, [_V, _V, _V, C.POINTER(C.c_int32), C.c_int, _F, _F, _V, _F, _V, _V]),
     "d3p_adam_step": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _F, _F, _F, _F]),
     "d3p_sgd_step": (C.c_int, [_V, _V, _V, _V, _U32, _F]),
+    "d3p_adadp_workspace": (C.c_size_t, []),
+    "d3p_adadp_step": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _U32, _F, C.c_int, _V, C.c_size_t]),
     "d3p_dpvi_logreg_workspace": (_SZ, [_PM, _PB]),
     "d3p_dpvi_logreg_local_sums": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _V, _V, _V, _SZ]),
     "d3p_dpvi_logreg_finalize": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _V, _V, _SZ]),

@@ -118,6 +118,72 @@ __global__ void k_adam(float* __restrict__ x, float* __restrict__ m, float* __re
     v[j] = vv;
 }
 
+// ---- ADADP (d3p/optimizers.py:29-112).  Odd steps need err = ||(x_stepped - new_x) / max(1, x_stepped)||_2 over
+// the whole vector before any element can be accepted or rejected: k_adadp_err leaves one partial sum of squares per
+// workgroup (fixed grid -> fixed summation order), k_adadp_apply re-reduces them in every workgroup.
+#define D3P_ADADP_BLOCKS 64
+
+__global__ void __launch_bounds__(256) k_adadp_err(const float* __restrict__ x, const float* __restrict__ lr,
+                                                   const float* __restrict__ x_stepped, const int32_t* __restrict__ step,
+                                                   const float* __restrict__ g, uint32_t P, float* __restrict__ partials)
+{
+    __shared__ float red[256];
+    if ((*step & 1) == 0) return;  // even steps take no error estimate (optimizers.py:62-69)
+    const float half_lr = 0.5f * *lr;
+    float s = 0.f;
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < P; j += D3P_ADADP_BLOCKS * 256) {
+        const float nx = x[j] - half_lr * g[j];
+        const float xs = x_stepped[j];
+        const float e = (xs - nx) / fmaxf(1.0f, xs);  // max(1, x), as the reference (no absolute value)
+        s = __fmaf_rn(e, e, s);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(256) k_adadp_apply(float* __restrict__ x, const float* __restrict__ lr,
+                                                     float* __restrict__ x_stepped, float* __restrict__ x_prev,
+                                                     const int32_t* __restrict__ step, const float* __restrict__ g, uint32_t P,
+                                                     float tol, int stability_check, const float* __restrict__ partials,
+                                                     float* __restrict__ lr_next)
+{
+    const float l = *lr;
+    const bool odd = (*step & 1) != 0;
+    bool reject = false;
+    if (odd) {
+        float ss = 0.f;
+        for (int b = 0; b < D3P_ADADP_BLOCKS; ++b) ss += partials[b];
+        const float err = sqrtf(ss);
+        reject = stability_check && err > tol;
+        // the literals 0.9 / 1.1 are the reference's (optimizers.py:89-91 ignores alpha_min / alpha_max)
+        if (blockIdx.x == 0 && threadIdx.x == 0) *lr_next = l * fminf(fmaxf(sqrtf(tol / err), 0.9f), 1.1f);
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *lr_next = l;
+    }
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < P; j += gridDim.x * 256) {
+        const float xx = x[j], gg = g[j];
+        const float nx = xx - (0.5f * l) * gg;
+        if (odd) {
+            x[j] = reject ? x_prev[j] : nx;
+        } else {
+            x_prev[j] = xx;
+            x_stepped[j] = xx - l * gg;
+            x[j] = nx;
+        }
+    }
+}
+
+__global__ void k_adadp_commit(float* lr, const float* lr_next, int32_t* step)
+{
+    *lr = *lr_next;
+    *step += 1;
+}
+
 // ---- DPSVI.evaluate (svi.py:436-449): -ELBO of a batch with ONE guide draw
 // k_eval_latent: key plumbing, eps, z = loc + softplus(u) * eps, latent[D] = logq - logp summed -> lat[0]
 __global__ void __launch_bounds__(256) k_eval_latent(d3p_logreg_model m, const float* __restrict__ params,
@@ -437,6 +503,27 @@ int d3p_sgd_step(void* stream, float* params_dev, int32_t* step_dev, const float
         hipLaunchKernelGGL(k_sgd, dim3(cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, params_dev, grads_dev, P, lr);
     hipLaunchKernelGGL(k_incr_i32, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
     return check_launch("d3p_sgd_step");
+}
+
+size_t d3p_adadp_workspace(void) { return (D3P_ADADP_BLOCKS + 1) * sizeof(float); }
+
+int d3p_adadp_step(void* stream, float* params_dev, float* lr_dev, float* x_stepped_dev, float* x_prev_dev, int32_t* step_dev,
+                   const float* grads_dev, uint32_t P, float tol, int stability_check, void* workspace_dev,
+                   size_t workspace_bytes)
+{
+    D3P_REQUIRE(params_dev && lr_dev && x_stepped_dev && x_prev_dev && step_dev && grads_dev && workspace_dev,
+                "d3p_adadp_step: null pointer");
+    if (workspace_bytes < d3p_adadp_workspace()) return fail(D3P_E_WORKSPACE, "d3p_adadp_step: workspace too small");
+    float* partials = (float*)workspace_dev;
+    float* lr_next = partials + D3P_ADADP_BLOCKS;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_adadp_err, dim3(D3P_ADADP_BLOCKS), dim3(256), 0, s, (const float*)params_dev, (const float*)lr_dev,
+                       (const float*)x_stepped_dev, (const int32_t*)step_dev, grads_dev, P, partials);
+    const unsigned blocks = P == 0 ? 1u : (cdiv(P, 256) < 1024u ? cdiv(P, 256) : 1024u);
+    hipLaunchKernelGGL(k_adadp_apply, dim3(blocks), dim3(256), 0, s, params_dev, (const float*)lr_dev, x_stepped_dev, x_prev_dev,
+                       (const int32_t*)step_dev, grads_dev, P, tol, stability_check, (const float*)partials, lr_next);
+    hipLaunchKernelGGL(k_adadp_commit, dim3(1), dim3(1), 0, s, lr_dev, (const float*)lr_next, step_dev);
+    return check_launch("d3p_adadp_step");
 }
 
 size_t d3p_logreg_evaluate_workspace(const d3p_logreg_model* model, uint32_t B)

@@ -16,6 +16,7 @@ import torch
 from . import _lib
 from . import random as strong_rng
 from ._lib import BatchSource, DpsviHyper, DpsviState, LogregModel, check, ptr, stream_ptr
+from .optimizers import ADADP
 from .models import (SGD, Adam, AutoDiagonalNormal, DiagonalNormalGuide, GaussianMean, LogisticRegression,
                      init_to_uniform, init_to_value)
 from .util import example_count
@@ -377,6 +378,8 @@ class DPSVI:
         leaves, _ = _tree_flatten(perturbed_grads)
         g = torch.cat([_as_device_f32(l).reshape(-1) for l in leaves]).contiguous()
         st = dp_svi_state.optim_state
+        if isinstance(self.optim, ADADP):
+            return self._update_state_optim_state(dp_svi_state, self.optim.update(g, st))
         step = st[0].clone()
         params = st[1].clone()
         if isinstance(self.optim, Adam):
@@ -389,6 +392,7 @@ class DPSVI:
             check(lib.d3p_sgd_step(stream_ptr(), ptr(params), ptr(step), ptr(g), params.numel(),
                                    self.optim.step_size))
             new = (step, params)
+
         else:
             raise _lib.D3PError("unsupported optimiser")
         return self._update_state_optim_state(dp_svi_state, new)

@@ -207,6 +207,16 @@ int d3p_adam_step(void* stream, float* params_dev, float* m_dev, float* v_dev, i
 int d3p_sgd_step(void* stream, float* params_dev, int32_t* step_dev, const float* grads_dev, uint32_t P,
                  float lr);
 
+/* d3p.optimizers.ADADP step (optimizers.py:29-112; Koskela & Honkela's adaptive learning rate): even steps
+ * store x_prev / x_stepped and take half a step, odd steps take the second half step, estimate the local error
+ * err = ||(x_stepped - x) / max(1, x_stepped)||_2, rescale lr by min(max(sqrt(tol / err), 0.9), 1.1) and, with
+ * stability_check, fall back to x_prev when err > tol.  lr_dev: one float; step_dev incremented.
+ * Known answers: tests/test_adadp_optimizer.py:66-131. */
+size_t d3p_adadp_workspace(void);
+int d3p_adadp_step(void* stream, float* params_dev, float* lr_dev, float* x_stepped_dev, float* x_prev_dev,
+                   int32_t* step_dev, const float* grads_dev, uint32_t P, float tol, int stability_check,
+                   void* workspace_dev, size_t workspace_bytes);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused DPSVI.update (svi.py:395-434) -- the north-star path.
  * per-example gradient -> joint L2 clip -> sum, X read once, B x P never materialised.

@@ -573,6 +573,39 @@ D3P_API void d3po_perturb(const uint32_t key[16], const float* avg, const int32_
     free(ks);
 }
 
+/* d3p/optimizers.py:29-112 -- ADADP (Koskela & Honkela, arXiv:1809.03832) on the flat parameter vector.
+ * State: x, lr, x_stepped, x_prev; `i` is the step count before the update.
+ *   every step : new_x = x - 0.5 lr g                                             (optimizers.py:100)
+ *   even i     : x_prev = x; x_stepped = x - lr g; x = new_x                      (:62-69)
+ *   odd i      : err = sqrt(sum(((x_stepped - new_x) / max(1, x_stepped))^2))     (:75-87; max(1, x), not |x|)
+ *                lr *= min(max(sqrt(tol / err), 0.9), 1.1)                        (:89-91; the bounds are literals
+ *                                                                                  there, alpha_min/max are unused)
+ *                x = (stability_check && err > tol) ? x_prev : new_x              (:93-98)
+ * Pinned by the known answers of tests/test_adadp_optimizer.py:66-131. */
+D3P_API void d3po_adadp(float* x, float* lr, float* x_stepped, float* x_prev, const float* g, int P, int i, float tol,
+                        int stability_check)
+{
+    const float l = *lr;
+    if ((i & 1) == 0) {
+        for (int j = 0; j < P; ++j) {
+            x_prev[j] = x[j];
+            x_stepped[j] = x[j] - l * g[j];
+            x[j] = x[j] - (0.5f * l) * g[j];
+        }
+        return;
+    }
+    double ss = 0.0;
+    for (int j = 0; j < P; ++j) {
+        float nx = x[j] - (0.5f * l) * g[j];
+        float e = (x_stepped[j] - nx) / fmaxf(1.0f, x_stepped[j]);
+        ss += (double)e * (double)e;
+    }
+    const float err = (float)sqrt(ss);
+    *lr = l * fminf(fmaxf(sqrtf(tol / err), 0.9f), 1.1f);
+    const int reject = stability_check && err > tol;
+    for (int j = 0; j < P; ++j) x[j] = reject ? x_prev[j] : x[j] - (0.5f * l) * g[j];
+}
+
 /* numpyro.optim.Adam == jax.example_libraries.optimizers.adam(step, 0.9, 0.999, 1e-8)
  * (svi.py:379-393; examples/logistic_regression.py:141).  `i` is the step count before the update. */
 D3P_API void d3po_adam(float* x, float* m, float* v, const float* g, int P, int i, float lr, float b1,

@@ -298,6 +298,15 @@ def adam(x, m, v, g, i, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
     return x, m, v
 
 
+def adadp(x, lr, x_stepped, x_prev, g, i, tol=1.0, stability_check=True):
+    """One ADADP update (d3p/optimizers.py:29-112) on flat vectors; returns (x, lr, x_stepped, x_prev)."""
+    x, xs, xp, g = _f32(x).copy(), _f32(x_stepped).copy(), _f32(x_prev).copy(), _f32(g)
+    l = C.c_float(lr)
+    lib().d3po_adadp(_p(x), C.byref(l), _p(xs), _p(xp), _p(g), C.c_int(x.size), C.c_int(i), C.c_float(tol),
+                     C.c_int(int(stability_check)))
+    return x, l.value, xs, xp
+
+
 class LogregState:
     """Mutable mirror of DPSVIState for the oracle's full update (svi.py:37-40)."""
 

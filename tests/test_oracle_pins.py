@@ -329,3 +329,22 @@ def test_config1_gauss_mean_converges_to_the_analytical_posterior(O):
     loc_exact, std_exact = var * X.sum(0) / 0.1 ** 2, np.sqrt(var)
     assert np.abs(st.params[:d] - loc_exact).max() < 0.02
     assert np.all(np.exp(st.params[d:]) < 0.05)          # started at 1.0, exact value is 0.0032
+
+
+def test_adadp_known_answers_from_the_reference_tests(O):
+    """tests/test_adadp_optimizer.py:66-131 on the flat vector of the reference's template tree
+    ((7, 10), (7,), ((2, 7), (2,)) -> 93 scalars)."""
+    P = 93
+    zeros, ones = np.zeros(P, np.float32), np.ones(P, np.float32)
+    # test_update_step_1: even step from 0 with g = 1, lr = 1
+    x, lr, xs, xp = O.adadp(zeros, 1.0, zeros, zeros, ones, 0, tol=1.0)
+    assert np.all(x == -0.5) and lr == 1.0 and np.all(xs == -1.0) and np.all(xp == 0.0)
+    # test_update_step_2_no_stability_check: expected lr 1.018308251, x = -1.5
+    x, lr, xs, xp = O.adadp(-0.5 * ones, 1.0, -ones, zeros, 2 * ones, 1, tol=5.0, stability_check=False)
+    assert np.all(x == -1.5) and abs(lr - 1.018308251) < 1e-6
+    # test_update_step_2_with_stability_check: update rejected, lr 0.72005267 clipped to 0.9
+    x, lr, xs, xp = O.adadp(-0.5 * ones, 1.0, -ones, zeros, 3 * ones, 1, tol=5.0, stability_check=True)
+    assert np.all(x == 0.0) and abs(lr - 0.9) < 1e-7
+    # a zero error estimate gives sqrt(tol / 0) = inf -> factor 1.1
+    x, lr, xs, xp = O.adadp(zeros, 2.0, zeros, zeros, zeros, 1, tol=1.0)
+    assert abs(lr - 2.2) < 1e-6 and np.all(x == 0.0)
