@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libd3p_hip.so")
-_SRC = [os.path.join(_HERE, "csrc", f) for f in ("d3p_rng.hip", "d3p_dpvi.hip", "d3p_stages.hip")]
+_SRC = [os.path.join(_HERE, "csrc", f) for f in ("d3p_rng.hip", "d3p_dpvi.hip", "d3p_stages.hip", "d3p_gmm.hip")]
 _DEPS = _SRC + [os.path.join(_HERE, "csrc", f) for f in ("d3p_device.h", "d3p_host.h", "d3p_logreg_kernel.h")] + [
     os.path.join(os.path.dirname(_HERE), "include", "d3p_hip.h")]
 
@@ -27,6 +27,11 @@ class LogregModel(C.Structure):
     _fields_ = [("d", C.c_int32), ("intercept", C.c_int32), ("prior_w", C.c_float),
                 ("prior_b", C.c_float), ("lik_scale", C.c_float), ("inv_obs", C.c_float),
                 ("family", C.c_int32), ("guide_transform", C.c_int32), ("lik_sigma", C.c_float)]
+
+
+class GmmModel(C.Structure):
+    _fields_ = [("K", C.c_int32), ("d", C.c_int32), ("prior_mu_scale", C.c_float), ("lik_scale", C.c_float),
+                ("inv_obs", C.c_float)]
 
 
 class DpsviHyper(C.Structure):
@@ -97,6 +102,8 @@ SIGNATURES = {
     "d3p_perturb": (C.c_int, [_V, _V, _V, C.POINTER(C.c_int32), C.c_int, _F, _F, _V, _F, _V, _V]),
     "d3p_adam_step": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _F, _F, _F, _F]),
     "d3p_sgd_step": (C.c_int, [_V, _V, _V, _V, _U32, _F]),
+    "d3p_gmm_px_grads_workspace": (C.c_size_t, [_I32]),
+    "d3p_gmm_px_grads": (C.c_int, [_V, _V, _V, _V, _V, _U32, _V, _V, _V, _V, _V, _V, C.c_size_t]),
     "d3p_adadp_workspace": (C.c_size_t, []),
     "d3p_adadp_step": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _U32, _F, C.c_int, _V, C.c_size_t]),
     "d3p_dpvi_logreg_workspace": (_SZ, [_PM, _PB]),

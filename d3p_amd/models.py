@@ -88,6 +88,42 @@ class GaussianMean:
         return var * obs.sum(0) / obs_scale ** 2, math.sqrt(var)
 
 
+class GaussianMixtureModel:
+    """pis ~ Dirichlet(ones(k)); mus ~ Normal(0, prior_mu_scale)^(k x d); sigs ~ InverseGamma(1, 1)^(k x d);
+    obs ~ GaussianMixture(mus, sigs, pis) inside ``plate('batch', num_obs_total, batch_size)``
+    (examples/gaussian_mixture_model.py:51-68; BASELINE config 3).  Call signature of the reference model:
+    ``model(k, obs, num_obs_total=)``; ``k`` is passed to DPSVI as a static keyword like in the example."""
+
+    has_labels = False
+    family = "gmm"
+
+    def __init__(self, k=None, d=None, prior_mu_scale=10.0):
+        self.k = k
+        self.d = d
+        self.prior_mu_scale = float(prior_mu_scale)
+
+    def site_names(self):
+        return ("pis", "mus", "sigs")
+
+    @staticmethod
+    def num_obs_total(args, kwargs):
+        for key in ("N", "num_obs_total"):
+            if kwargs.get(key) is not None:
+                return float(kwargs[key])
+        return None
+
+
+class GaussianMixtureGuide:
+    """The example's guide (examples/gaussian_mixture_model.py:70-85): pis ~ Dirichlet(exp(alpha_log)),
+    mus ~ Normal(mus_loc, 1), sigs ~ InverseGamma(1, 1); params 'alpha_log' (k,) and 'mus_loc' (k, d), zeros at init."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def param_names(self):
+        return ("alpha_log", "mus_loc")
+
+
 class DiagonalNormalGuide:
     """The hand-written mean-field guides of the reference's examples: one sample site
     ``Normal(<site>_loc, exp(<site>_std_log))`` over the model's latent vector

@@ -15,9 +15,10 @@ import torch
 
 from . import _lib
 from . import random as strong_rng
-from ._lib import BatchSource, DpsviHyper, DpsviState, LogregModel, check, ptr, stream_ptr
+from ._lib import BatchSource, DpsviHyper, DpsviState, GmmModel, LogregModel, check, ptr, stream_ptr
 from .optimizers import ADADP
-from .models import (SGD, Adam, AutoDiagonalNormal, DiagonalNormalGuide, GaussianMean, LogisticRegression,
+from .models import (SGD, Adam, AutoDiagonalNormal, DiagonalNormalGuide, GaussianMean, GaussianMixtureGuide,
+                     GaussianMixtureModel, LogisticRegression,
                      init_to_uniform, init_to_value)
 from .util import example_count
 
@@ -176,6 +177,19 @@ class DPSVI:
         return DPSVI._update_state_rng(dp_svi_state, split_keys[0]), split_keys[1:]
 
     # ---------------------------------------------------------------- model plumbing
+    def _is_gmm(self):
+        return isinstance(self.model, GaussianMixtureModel) and isinstance(self.guide, GaussianMixtureGuide)
+
+    def _gmm_struct(self, d, kwargs, observation_scale):
+        kw = dict(self.static_kwargs)
+        kw.update(kwargs)
+        k = kw.get("k") or self.model.k
+        if k is None:
+            raise ValueError("GaussianMixtureModel: the number of components k must be given")
+        n_total = self.model.num_obs_total((), kw)
+        return GmmModel(int(k), int(d), self.model.prior_mu_scale, 1.0 if n_total is None else n_total,
+                        1.0 / float(observation_scale))
+
     def _require_logreg(self):
         if (not isinstance(self.model, (LogisticRegression, GaussianMean))
                 or not isinstance(self.guide, (AutoDiagonalNormal, DiagonalNormalGuide))):
@@ -218,6 +232,8 @@ class DPSVI:
 
     # ---------------------------------------------------------------- init (svi.py:213-236)
     def init(self, rng_key, *args, **kwargs):
+        if self._is_gmm():
+            return self._init_gmm(rng_key, *args, **kwargs)
         self._require_logreg()
         _lib.require_device()
         X = args[0]
@@ -249,10 +265,28 @@ class DPSVI:
             observation_scale = 1.0 if n_total is None else n_total
         return DPSVIState(optim_state, rng_key, observation_scale)
 
+    def _init_gmm(self, rng_key, *args, **kwargs):
+        _lib.require_device()
+        X = args[0]
+        gm = self._gmm_struct(int(X.shape[1]), kwargs, 1.0)
+        # param('alpha_log', zeros(k)), param('mus_loc', zeros((k, d)))  (gaussian_mixture_model.py:79-83)
+        params = torch.zeros(gm.K + gm.K * gm.d, dtype=torch.float32, device=X.device)
+        observation_scale = 1.0
+        if self._clip_unscaled_observations:
+            kw = dict(self.static_kwargs)
+            kw.update(kwargs)
+            n_total = self.model.num_obs_total(args, kw)
+            observation_scale = 1.0 if n_total is None else n_total
+        self._gmm_shape = (gm.K, gm.d)
+        return DPSVIState(self.optim.init(params), rng_key, observation_scale)
+
     def get_params(self, svi_state):
         """Constrained parameters (numpyro SVI.get_params): auto_scale = softplus(unconstrained) for
         AutoDiagonalNormal; the hand-written guides keep their ``*_std_log`` unconstrained."""
         p = self.optim.get_params(svi_state.optim_state)
+        if self._is_gmm():
+            K = int(self.static_kwargs.get("k") or self.model.k)
+            return {"alpha_log": p[:K].clone(), "mus_loc": p[K:].reshape(K, -1).clone()}
         D = p.numel() // 2
         n_loc, n_scale = self.guide.param_names()
         if isinstance(self.guide, DiagonalNormalGuide):
@@ -260,7 +294,35 @@ class DPSVI:
         return {n_loc: p[:D].clone(), n_scale: torch.nn.functional.softplus(p[D:])}
 
     # ---------------------------------------------------------------- stage 1 (svi.py:238-308)
+    def _compute_per_example_gradients_gmm(self, dp_svi_state, step_rng_key, *args, mask=True, **kwargs):
+        _lib.require_device()
+        lib = _lib.load()
+        X = args[0].contiguous()
+        B, d = X.shape
+        gm = self._gmm_struct(d, kwargs, dp_svi_state.observation_scale)
+        K, P = gm.K, gm.K + gm.K * d
+        jax_rng_key = self._rng_suite.convert_to_jax_rng_key(step_rng_key).contiguous()
+        params = self.optim.get_params(dp_svi_state.optim_state).contiguous()
+        if params.numel() != P:
+            raise ValueError("GaussianMixtureModel: parameter vector does not match k and the data dimension")
+        mask_t = None
+        if not isinstance(mask, bool):
+            mask_t = mask.to(torch.uint8).contiguous()
+        elif mask is False:
+            mask_t = torch.zeros(B, dtype=torch.uint8, device=X.device)
+        px_loss = torch.empty(B, dtype=torch.float32, device=X.device)
+        px_grads = torch.empty((B, P), dtype=torch.float32, device=X.device)
+        meta = torch.empty(2, dtype=torch.float32, device=X.device)
+        ws = self._workspace(lib.d3p_gmm_px_grads_workspace(K), X.device, "gmm")
+        lat = kwargs.get("_latents_out")
+        check(lib.d3p_gmm_px_grads(stream_ptr(), C.byref(gm), ptr(params), ptr(X), ptr(mask_t), B, ptr(jax_rng_key),
+                                   ptr(px_loss), ptr(px_grads), ptr(meta), ptr(lat), ptr(ws), ws.numel()))
+        grads = {"alpha_log": px_grads[:, :K], "mus_loc": px_grads[:, K:].reshape(B, K, d)}
+        return dp_svi_state, px_loss, grads, meta[0], meta[1]
+
     def _compute_per_example_gradients(self, dp_svi_state, step_rng_key, *args, mask=True, **kwargs):
+        if self._is_gmm():
+            return self._compute_per_example_gradients_gmm(dp_svi_state, step_rng_key, *args, mask=mask, **kwargs)
         self._require_logreg()
         _lib.require_device()
         lib = _lib.load()

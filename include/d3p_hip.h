@@ -173,6 +173,27 @@ int d3p_logreg_evaluate(void* stream, const d3p_logreg_model* model, const float
 int d3p_gmm_log_prob(void* stream, const float* x_dev, uint32_t B, int32_t d, const float* locs_dev,
                      const float* scales_dev, const float* pis_dev, int32_t K, float* out_dev);
 
+/* _compute_per_example_gradients for the Gaussian-mixture MODEL of BASELINE config 3
+ * (examples/gaussian_mixture_model.py:51-85: pis ~ Dirichlet(1), mus ~ Normal(0, prior_mu_scale), sigs ~
+ * InverseGamma(1, 1), obs ~ GaussianMixture(mus, sigs, pis); guide pis ~ Dirichlet(exp(alpha_log)),
+ * mus ~ Normal(mus_loc, 1), sigs ~ InverseGamma(1, 1); svi.py:238-308).
+ * params_dev = [alpha_log (K) | mus_loc (K x d)], P = K + K d; one guide draw per example from jax_key_dev
+ * (stream layout: oracle/d3p_oracle.c, d3po_gmm_*).  Outputs as d3p_logreg_px_grads; latents_out_dev (optional,
+ * B x (K + 2 K d)) receives every example's (gamma draws, eps of mus, sigs).  K <= 16 with d <= 256 or
+ * K <= 32 with d <= 128. */
+typedef struct {
+    int32_t K, d;
+    float prior_mu_scale; /* 10 (examples/gaussian_mixture_model.py:65) */
+    float lik_scale;      /* plate scale = num_obs_total */
+    float inv_obs;        /* 1 / observation_scale (svi.py:278) */
+} d3p_gmm_model;
+
+size_t d3p_gmm_px_grads_workspace(int32_t K);
+int d3p_gmm_px_grads(void* stream, const d3p_gmm_model* model, const float* params_dev, const float* X_dev,
+                     const uint8_t* mask_dev, uint32_t B, const uint32_t* jax_key_dev, float* px_loss_dev,
+                     float* px_grads_dev, float* meta_dev, float* latents_out_dev, void* workspace_dev,
+                     size_t workspace_bytes);
+
 /* _clip_gradients: every row scaled by 1/max(1, ||row||_2 / c) in place (svi.py:68-124, :310-325).
  * c == 0 -> D3P_E_INVALID_ARG (the reference raises ValueError, svi.py:119-120). */
 int d3p_clip_rows(void* stream, float* px_grads_dev, uint32_t B, uint32_t P, float c);

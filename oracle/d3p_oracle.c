@@ -757,6 +757,199 @@ D3P_API void d3po_gmm_log_prob(const float* x, int B, int d, const float* locs, 
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * DP-VI per-example gradient for the Gaussian-mixture MODEL of BASELINE config 3
+ * (examples/gaussian_mixture_model.py:51-85):
+ *   model: pis ~ Dirichlet(1_K); mus ~ Normal(0, 10)^(K x d); sigs ~ InverseGamma(1, 1)^(K x d);
+ *          obs_i ~ GaussianMixture(mus, sigs, pis)                      (d3p/gmm.py:71-86)
+ *   guide: pis ~ Dirichlet(exp(alpha_log)); mus ~ Normal(mus_loc, 1); sigs ~ InverseGamma(1, 1)
+ *   params (tree_flatten order): alpha_log (K), mus_loc (K x d);  P = K + K d.
+ * Per example (svi.py:271-281, one guide draw each): L = inv_obs * ((log q - log p)(latents) - N loglik(x | latents)).
+ * The InverseGamma terms of log q and log p are the same number and cancel.  Gradients are pathwise: mus = loc + eps,
+ * pis = g / sum(g) with g_k ~ Gamma(alpha_k) and dg_k/dalpha_k the implicit-reparametrisation derivative at fixed CDF
+ * value (what jax.random.gamma's JVP rule computes).
+ *
+ * PARITY UNPINNED for the sampling layout: the seed handler's key chain over the guide's three sample sites and the
+ * normal layout of `mus` follow numpyro / jax (k_pis = split(r0)[1], r1 = split(r0)[0], k_mus = split(r1)[1], ...), but
+ * jax.random.gamma's rejection sampler (per-element key splitting inside a while_loop) is NOT reproduced bit for bit:
+ * this build draws  g_k  by Marsaglia-Tsang with (normal, uniform) = threefry2x32(k_pis, (k, attempt)) and
+ * sigs = 1 / Exponential(1) with the uniforms of threefry(k_sigs, iota(K d)).  Same distributions, different streams.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t K, d;
+    float prior_mu_scale; /* 10 in the example */
+    float lik_scale;      /* plate scale N */
+    float inv_obs;        /* 1 / observation_scale */
+} d3po_gmm_spec;
+
+/* digamma for x > 0: recurrence up to x >= 10, then the asymptotic series */
+D3P_API double d3po_digamma(double x)
+{
+    double r = 0.0;
+    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+    const double f = 1.0 / (x * x);
+    return r + log(x) - 0.5 / x
+           - f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760))))));
+}
+
+/* dx/dalpha of x = F^{-1}(u; alpha) for the Gamma(alpha, 1) CDF F at fixed u:  -(dF/dalpha) / f.
+ * With P(alpha, x) = x^alpha e^-x S / Gamma(alpha + 1), S = sum_n t_n, t_n = x^n / ((alpha+1)...(alpha+n)):
+ *   dP/dalpha = P (log x - psi(alpha + 1) + S'/S),  S' = -sum_n t_n sum_{j<=n} 1/(alpha + j),  P / f = x S / alpha
+ * so  dx/dalpha = -(x / alpha) (S (log x - psi(alpha + 1)) + S').  The series is used for all x (terms up to n ~ x + 60);
+ * cancellation grows like e^x, fine for the x <~ 40 a Gamma with alpha = O(1..10) produces. */
+D3P_API double d3po_gamma_grad(double alpha, double x)
+{
+    if (!(x > 0.0)) return 0.0;
+    double t = 1.0, h = 0.0, S = 1.0, Sp = 0.0;
+    for (int n = 1; n < 2000; ++n) {
+        t *= x / (alpha + n);
+        h += 1.0 / (alpha + n);
+        S += t;
+        Sp -= t * h;
+        if (t < 1e-18 * S && n > x) break;
+    }
+    return -(x / alpha) * (S * (log(x) - d3po_digamma(alpha + 1.0)) + Sp);
+}
+
+static inline double bits_to_open_unit_d(uint32_t b) { return ((double)b + 0.5) * (1.0 / 4294967296.0); }
+
+/* Gamma(alpha, 1) draw for mixture component `comp`: Marsaglia & Tsang (2000); alpha < 1 boosted by U^(1/alpha). */
+D3P_API double d3po_gamma_sample(const uint32_t key[2], uint32_t comp, double alpha)
+{
+    const double a = alpha < 1.0 ? alpha + 1.0 : alpha;
+    const double dd = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
+    double g = 0.0;
+    for (uint32_t attempt = 0; attempt < 0x7fffffffu; ++attempt) {
+        uint32_t b[2];
+        d3po_threefry2x32(key[0], key[1], comp, attempt, b);
+        const double x = (double)bits_to_normal(b[0]);
+        const double U = bits_to_open_unit_d(b[1]);
+        const double v1 = 1.0 + c * x;
+        if (v1 <= 0.0) continue;
+        const double v = v1 * v1 * v1;
+        if (log(U) < 0.5 * x * x + dd - dd * v + dd * log(v)) { g = dd * v; break; }
+    }
+    if (alpha < 1.0) {
+        uint32_t b[2];
+        d3po_threefry2x32(key[0], key[1], comp, 0x80000000u, b);
+        g *= pow(bits_to_open_unit_d(b[0]), 1.0 / alpha);
+    }
+    return g;
+}
+
+/* Keys of the guide's three sample sites for the example at batch position p (numpyro.handlers.seed: every sample
+ * statement does key, sample_key = split(key)):  r0 = guide_seed = split(px_key)[1];  k_pis = split(r0)[1];
+ * r1 = split(r0)[0]; k_mus = split(r1)[1]; r2 = split(r1)[0]; k_sigs = split(r2)[1]. */
+D3P_API void d3po_gmm_site_keys(const uint32_t jax_key[2], uint32_t B, uint32_t p, uint32_t out[6])
+{
+    uint32_t px[2], s[4], r[2];
+    px[0] = tf_iota_word(jax_key[0], jax_key[1], 2ull * B, 2ull * p);
+    px[1] = tf_iota_word(jax_key[0], jax_key[1], 2ull * B, 2ull * p + 1);
+    d3po_tf_split(px, 2, s);
+    r[0] = s[2]; r[1] = s[3];
+    for (int site = 0; site < 3; ++site) {
+        d3po_tf_split(r, 2, s);
+        out[2 * site] = s[2]; out[2 * site + 1] = s[3];
+        r[0] = s[0]; r[1] = s[1];
+    }
+}
+
+/* Latent draws of one example: g[K] (Gamma(alpha_k)), eps[K d] (standard normals of mus), sigs[K d]. */
+D3P_API void d3po_gmm_px_latents(const d3po_gmm_spec* sp, const float* alpha_log, const uint32_t jax_key[2], uint32_t B,
+                                 uint32_t p, double* g, float* eps, float* sigs)
+{
+    const int K = sp->K, n = sp->K * sp->d;
+    uint32_t sk[6];
+    d3po_gmm_site_keys(jax_key, B, p, sk);
+    for (int k = 0; k < K; ++k) g[k] = d3po_gamma_sample(sk, (uint32_t)k, exp((double)alpha_log[k]));
+    d3po_tf_normal(sk + 2, (uint64_t)n, eps);
+    for (int j = 0; j < n; ++j) {
+        /* Exponential(1) = Gamma(1, 1) by inversion in float32: u = (m + 1/2) 2^-23 in [2^-24, 1 - 2^-24] is exact,
+         * so e = -log(u) lies in [6e-8, 16.7] and sigs = 1 / e is finite */
+        const uint32_t b = tf_iota_word(sk[4], sk[5], (uint64_t)n, (uint64_t)j);
+        const float u = ((float)(b >> 9) + 0.5f) * 1.1920928955078125e-07f;
+        sigs[j] = 1.0f / -logf(u);
+    }
+}
+
+/* Loss and gradient of one example given its latent draws; grad = [d/dalpha_log (K) | d/dmus_loc (K d)] or NULL. */
+D3P_API float d3po_gmm_px_loss_grad_given(const d3po_gmm_spec* sp, const float* alpha_log, const float* mus_loc,
+                                          const float* x, const double* g, const float* eps, const float* sigs,
+                                          float mask, float* grad)
+{
+    const int K = sp->K, d = sp->d;
+    const double ps = sp->prior_mu_scale, N = sp->lik_scale, io = sp->inv_obs;
+    double* alpha = (double*)malloc(sizeof(double) * 4 * (size_t)K);
+    double *pis = alpha + K, *a = pis + K, *r = a + K;
+    double S = 0.0, A0 = 0.0;
+    for (int k = 0; k < K; ++k) { alpha[k] = exp((double)alpha_log[k]); A0 += alpha[k]; S += g[k]; }
+    double lq = lgamma(A0) - lgamma((double)K), lmu = 0.0;
+    for (int k = 0; k < K; ++k) {
+        pis[k] = g[k] / S;
+        lq += -lgamma(alpha[k]) + (alpha[k] - 1.0) * log(pis[k]);
+    }
+    double best = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+        double ll = 0.0;
+        for (int j = 0; j < d; ++j) {
+            const size_t e = (size_t)k * d + j;
+            const float mu = mus_loc[e] + eps[e];
+            const double z = ((double)x[j] - mu) / sigs[e];
+            ll += -0.5 * z * z - log((double)sigs[e]) - (double)HALF_LOG_2PI;
+            lmu += -0.5 * (double)eps[e] * eps[e] - (-0.5 * ((double)mu / ps) * ((double)mu / ps) - log(ps));
+        }
+        a[k] = log(pis[k]) + ll;
+        if (a[k] > best) best = a[k];
+    }
+    double se = 0.0;
+    for (int k = 0; k < K; ++k) { r[k] = exp(a[k] - best); se += r[k]; }
+    const double loglik = best + log(se);
+    for (int k = 0; k < K; ++k) r[k] /= se;
+    const double L = io * ((lq + lmu) - N * loglik) * mask;
+    if (grad) {
+        const double psi0 = d3po_digamma(A0);
+        for (int k = 0; k < K; ++k) {
+            const double gp = d3po_gamma_grad(alpha[k], g[k]) / S; /* (dg_k/dalpha_k) / S */
+            const double dq = psi0 - d3po_digamma(alpha[k]) + log(pis[k]) + gp * ((alpha[k] - 1.0) / pis[k] - (A0 - K));
+            const double dl = gp * (r[k] / pis[k] - 1.0);
+            grad[k] = (float)(alpha[k] * io * (dq - N * dl) * mask);
+            for (int j = 0; j < d; ++j) {
+                const size_t e = (size_t)k * d + j;
+                const float mu = mus_loc[e] + eps[e];
+                const double w = ((double)x[j] - mu) / ((double)sigs[e] * sigs[e]);
+                grad[K + e] = (float)(io * ((double)mu / (ps * ps) - N * r[k] * w) * mask);
+            }
+        }
+    }
+    free(alpha);
+    return (float)L;
+}
+
+/* svi.py:238-308 for the mixture model: px_losses (B) and px_grads (B x P), latents drawn per example from jax_key. */
+D3P_API int d3po_gmm_px_grads(const d3po_gmm_spec* sp, const float* params, const float* Xb, const float* mask, int B,
+                              const uint32_t jax_key[2], float* px_loss, float* px_grads, float* factor)
+{
+    const int K = sp->K, d = sp->d, P = K + K * d;
+    int n = 0;
+    for (int i = 0; i < B; ++i) n += (mask ? (mask[i] != 0.0f) : 1);
+    const float f = (n == 0) ? 0.0f : (float)B / (float)n;
+    const float obs = 1.0f / sp->inv_obs;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < B; ++i) {
+        double* g = (double*)malloc(sizeof(double) * (size_t)K);
+        float* eps = (float*)malloc(sizeof(float) * 2 * (size_t)K * d);
+        float* sigs = eps + (size_t)K * d;
+        d3po_gmm_px_latents(sp, params, jax_key, (uint32_t)B, (uint32_t)i, g, eps, sigs);
+        const float m = mask ? mask[i] : 1.0f;
+        const float L = d3po_gmm_px_loss_grad_given(sp, params, params + K, Xb + (size_t)i * d, g, eps, sigs, m,
+                                                    px_grads + (size_t)i * P);
+        px_loss[i] = L * obs * f;
+        free(g); free(eps);
+    }
+    *factor = f;
+    return n;
+}
+
 /* Synthetic logistic-regression table, element (r, c) a pure function of (seed, r, c) so that any
  * shard can be regenerated (mirrors examples/logistic_regression.py:88-104 in
  * distribution): X[r][c] = normal from threefry2x32((seed, 0x58), (r, c))[0];

@@ -31,6 +31,11 @@ class LogregSpec(C.Structure):
                 ("family", C.c_int32), ("guide_exp", C.c_int32), ("lik_sigma", C.c_float)]
 
 
+class GmmSpec(C.Structure):
+    _fields_ = [("K", C.c_int32), ("d", C.c_int32), ("prior_mu_scale", C.c_float), ("lik_scale", C.c_float),
+                ("inv_obs", C.c_float)]
+
+
 class Hyper(C.Structure):
     _fields_ = [("clip", C.c_float), ("dp_scale", C.c_float), ("lr", C.c_float),
                 ("b1", C.c_float), ("b2", C.c_float), ("adam_eps", C.c_float)]
@@ -49,6 +54,12 @@ def lib():
         _lib.d3po_logreg_px_loss_grad.restype = C.c_float
         _lib.d3po_logreg_update.restype = C.c_float
         _lib.d3po_logreg_evaluate.restype = C.c_float
+        _lib.d3po_digamma.restype = C.c_double
+        _lib.d3po_digamma.argtypes = [C.c_double]
+        _lib.d3po_gamma_grad.restype = C.c_double
+        _lib.d3po_gamma_grad.argtypes = [C.c_double, C.c_double]
+        _lib.d3po_gamma_sample.restype = C.c_double
+        _lib.d3po_gmm_px_loss_grad_given.restype = C.c_float
     return _lib
 
 
@@ -373,3 +384,57 @@ def synth_wtrue(seed, d):
     w = np.empty(d + 1, np.float32)
     lib().d3po_synth_wtrue(C.c_uint32(seed), C.c_int(d), _p(w))
     return w
+
+
+# ------------------------------------------------------------------ Gaussian-mixture model step (config 3)
+def gmm_spec(K, d, prior_mu_scale=10.0, lik_scale=1.0, obs_scale=1.0):
+    return GmmSpec(K, d, prior_mu_scale, lik_scale, 1.0 / obs_scale)
+
+
+def digamma(x):
+    return lib().d3po_digamma(float(x))
+
+
+def gamma_grad(alpha, x):
+    """d/dalpha of the Gamma(alpha, 1) quantile at fixed CDF value (implicit reparametrisation)."""
+    return lib().d3po_gamma_grad(float(alpha), float(x))
+
+
+def gamma_sample(key, comp, alpha):
+    return lib().d3po_gamma_sample(_p(_u32(key)), C.c_uint32(comp), C.c_double(alpha))
+
+
+def gmm_site_keys(jax_key, B, p):
+    out = np.empty(6, np.uint32)
+    lib().d3po_gmm_site_keys(_p(_u32(jax_key)), C.c_uint32(B), C.c_uint32(p), _p(out))
+    return out.reshape(3, 2)
+
+
+def gmm_px_latents(spec, alpha_log, jax_key, B, p):
+    g = np.empty(spec.K, np.float64)
+    eps = np.empty(spec.K * spec.d, np.float32)
+    sigs = np.empty(spec.K * spec.d, np.float32)
+    lib().d3po_gmm_px_latents(C.byref(spec), _p(_f32(alpha_log)), _p(_u32(jax_key)), C.c_uint32(B), C.c_uint32(p),
+                              _p(g), _p(eps), _p(sigs))
+    return g, eps.reshape(spec.K, spec.d), sigs.reshape(spec.K, spec.d)
+
+
+def gmm_px_loss_grad_given(spec, alpha_log, mus_loc, x, g, eps, sigs, mask=1.0):
+    P = spec.K + spec.K * spec.d
+    grad = np.empty(P, np.float32)
+    g = np.ascontiguousarray(g, np.float64)
+    L = lib().d3po_gmm_px_loss_grad_given(C.byref(spec), _p(_f32(alpha_log)), _p(_f32(mus_loc)), _p(_f32(x)), _p(g),
+                                          _p(_f32(eps)), _p(_f32(sigs)), C.c_float(mask), _p(grad))
+    return float(L), grad
+
+
+def gmm_px_grads(spec, params, Xb, jax_key, mask=None):
+    B = Xb.shape[0]
+    P = spec.K + spec.K * spec.d
+    px_loss = np.empty(B, np.float32)
+    px_grads = np.empty((B, P), np.float32)
+    factor = C.c_float()
+    m = None if mask is None else _f32(mask)
+    n = lib().d3po_gmm_px_grads(C.byref(spec), _p(_f32(params)), _p(_f32(Xb)), None if m is None else _p(m), C.c_int(B),
+                                _p(_u32(jax_key)), _p(px_loss), _p(px_grads), C.byref(factor))
+    return px_loss, px_grads, n, factor.value

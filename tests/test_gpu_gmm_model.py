@@ -1,0 +1,119 @@
+"""DP-VI step for the Gaussian-mixture MODEL of BASELINE config 3 (examples/gaussian_mixture_model.py:51-85):
+HIP per-example gradients vs the CPU oracle (latent draws, losses, gradients), the stage-wise DPSVI.update vs the
+oracle's stage composition, and learning on the example's three-cluster toy data.
+
+Tolerances: latent draws -- normals exact to 1e-6 abs (same words, same transform), sigs / gamma draws 2e-6 relative
+(float log implementations differ in the last ulp); per-example gradients rtol 1e-4 + 1e-5 * max|g| (float32 sums over
+K d terms with magnitudes up to N / sig^2 on the device, float64 in the oracle)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def rng(gpu):
+    import d3p_amd.random as r
+    return r
+
+
+def make_svi(K, d, N, C=1.0, sigma=1.0, lr=1e-2, optim=None):
+    from d3p_amd.models import Adam, GaussianMixtureGuide, GaussianMixtureModel, Trace_ELBO
+    from d3p_amd.svi import DPSVI
+    model = GaussianMixtureModel()
+    return DPSVI(model, GaussianMixtureGuide(model), optim or Adam(lr), Trace_ELBO(), C, sigma, k=K, d=d, num_obs_total=N)
+
+
+def state_with(svi, key, params, N):
+    from d3p_amd.svi import DPSVIState
+    return DPSVIState(svi.optim.init(torch.tensor(params).cuda()), key, float(N))
+
+
+def problem(B, K, d, seed):
+    r = np.random.default_rng(seed)
+    X = (r.normal(size=(B, d)) * 3).astype(np.float32)
+    params = np.concatenate([r.normal(size=K) * 0.4, r.normal(size=K * d) * 2]).astype(np.float32)
+    return X, params
+
+
+@pytest.mark.parametrize("B,K,d", [(9, 4, 3), (33, 16, 64), (7, 3, 2), (12, 6, 100), (5, 32, 128), (6, 16, 256), (4, 5, 70)])
+def test_px_grads_and_latents_vs_oracle(rng, O, B, K, d):
+    N = 2000
+    X, params = problem(B, K, d, 10 * B + K)
+    mask = np.random.default_rng(1).random(B) < 0.8
+    svi = make_svi(K, d, N)
+    key = rng.PRNGKey(K * d)
+    st = state_with(svi, key, params, N)
+    lat = torch.empty((B, K + 2 * K * d), device="cuda")
+    _, px_loss, grads, n, f = svi._compute_per_example_gradients(st, key, torch.tensor(X).cuda(),
+                                                                 mask=torch.tensor(mask).cuda(), _latents_out=lat)
+    assert tuple(grads["alpha_log"].shape) == (B, K) and tuple(grads["mus_loc"].shape) == (B, K, d)
+    spec = O.gmm_spec(K, d, 10.0, lik_scale=N, obs_scale=N)
+    jax_key = O.convert_to_jax_rng_key(O.PRNGKey(K * d))
+    lat = np_(lat)
+    for p in range(B):
+        g, eps, sigs = O.gmm_px_latents(spec, params[:K], jax_key, B, p)
+        np.testing.assert_allclose(lat[p, :K], g, rtol=2e-6)
+        np.testing.assert_allclose(lat[p, K:K + K * d], eps.ravel(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(lat[p, K + K * d:], sigs.ravel(), rtol=2e-6)
+    eL, eG, en, ef = O.gmm_px_grads(spec, params, X, jax_key, mask.astype(np.float32))
+    assert float(n) == en and abs(float(f) - ef) < 1e-6
+    G = np.concatenate([np_(grads["alpha_log"]), np_(grads["mus_loc"]).reshape(B, -1)], axis=1)
+    for p in range(B):
+        np.testing.assert_allclose(G[p], eG[p], rtol=1e-4, atol=1e-5 * np.abs(eG[p]).max())
+    np.testing.assert_allclose(np_(px_loss), eL, rtol=2e-5, atol=1e-6 * np.abs(eL).max())
+    assert np.all(G[~mask] == 0) and np.all(np_(px_loss)[~mask] == 0)
+
+
+def test_staged_update_vs_oracle(rng, O):
+    """DPSVI.update for the mixture model = the reference's five stages; sites in tree_flatten order
+    (alpha_log, mus_loc) get their own perturbation keys (svi.py:491)."""
+    B, K, d, N = 40, 16, 64, 5000
+    X, params = problem(B, K, d, 3)
+    svi = make_svi(K, d, N, C=20.0, sigma=0.7, lr=1e-2)
+    st = state_with(svi, rng.PRNGKey(8), params, N)
+    new_st, loss = svi.update(st, torch.tensor(X).cuda())
+    spec = O.gmm_spec(K, d, 10.0, lik_scale=N, obs_scale=N)
+    ks = O.split(O.PRNGKey(8), 3)
+    L, G, n, f = O.gmm_px_grads(spec, params, X, O.convert_to_jax_rng_key(ks[1]))
+    eloss, avg = O.combine(O.clip_rows(G, 20.0), L)
+    g = O.perturb(ks[2], avg, [K, K * d], 0.7, 20.0, n, N, f)
+    x, m, v = O.adam(params, np.zeros_like(params), np.zeros_like(params), g, 0, lr=1e-2)
+    assert abs(float(loss) - eloss) <= 5e-5 * abs(eloss)
+    assert np.array_equal(np_(new_st.rng_key), ks[0])
+    np.testing.assert_allclose(np_(new_st.optim_state[1]), x, rtol=1e-4, atol=1e-5)
+    p = svi.get_params(new_st)
+    assert tuple(p["alpha_log"].shape) == (K,) and tuple(p["mus_loc"].shape) == (K, d)
+
+
+def test_learns_the_examples_toy_clusters(rng):
+    """examples/gaussian_mixture_model.py:87-110: three clusters at -10, 10 and -2 (the last twice as frequent), d = 2,
+    k = 3, C = 20; after training, every true centre has a learned component mean nearby."""
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, d, K, B = 4000, 2, 3, 200
+    g = torch.Generator().manual_seed(0)
+    comp = torch.multinomial(torch.tensor([0.25, 0.25, 0.5]), N, replacement=True, generator=g)
+    centres = torch.tensor([-10.0, 10.0, -2.0])
+    scales = torch.tensor([0.1, 1.0, 0.1])
+    X = (centres[comp, None] + scales[comp, None] * torch.randn(N, d, generator=g)).cuda()
+    svi = make_svi(K, d, N, C=20.0, sigma=0.1, lr=5e-2)
+    key, k_init, k_batch = rng.split(rng.PRNGKey(0), 3)
+    init, get_batch = subsample_batchify_data((X,), B)
+    nb, bstate = init(k_batch)
+    st = svi.init(k_init, *get_batch(0, bstate))
+    p0 = svi.get_params(st)
+    assert torch.all(p0["alpha_log"] == 0) and torch.all(p0["mus_loc"] == 0)
+    losses = []
+    for i in range(600):
+        st, l = svi.update(st, *get_batch(i % nb, bstate))
+        losses.append(float(l))
+    mus = svi.get_params(st)["mus_loc"].cpu()
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-50:]) < np.mean(losses[:50])
+    for c in centres.tolist():
+        assert float((mus - c).abs().max(dim=1).values.min()) < 1.5, (c, mus)

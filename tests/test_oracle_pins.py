@@ -348,3 +348,56 @@ def test_adadp_known_answers_from_the_reference_tests(O):
     # a zero error estimate gives sqrt(tol / 0) = inf -> factor 1.1
     x, lr, xs, xp = O.adadp(zeros, 2.0, zeros, zeros, zeros, 1, tol=1.0)
     assert abs(lr - 2.2) < 1e-6 and np.all(x == 0.0)
+
+
+def test_special_functions_vs_scipy(O):
+    """digamma and the implicit-reparametrisation derivative of the Gamma quantile (the JVP of jax.random.gamma)."""
+    import scipy.special as sp
+    for x in (0.01, 0.3, 1.0, 2.5, 10.0, 123.4):
+        assert abs(O.digamma(x) - sp.digamma(x)) < 1e-12 * max(1.0, abs(sp.digamma(x)))
+    for a in (0.2, 0.7, 1.0, 1.5, 3.0, 10.0, 40.0):
+        for u in (1e-6, 0.01, 0.3, 0.5, 0.9, 0.999):
+            x = sp.gammaincinv(a, u)
+            h = 1e-5 * a
+            fd = (sp.gammaincinv(a + h, u) - sp.gammaincinv(a - h, u)) / (2 * h)
+            assert abs(O.gamma_grad(a, x) - fd) < 1e-6 * abs(fd)
+
+
+def test_gamma_sampler_distribution(O):
+    import scipy.stats as st
+    for a in (0.3, 1.0, 4.2):
+        xs = np.array([O.gamma_sample(np.array([i, 77], np.uint32), 3, a) for i in range(6000)])
+        assert st.kstest(xs, "gamma", args=(a,)).pvalue > 1e-3
+        assert abs(xs.mean() - a) < 5 * np.sqrt(a / 6000)
+
+
+def test_gmm_model_gradient_vs_finite_differences(O):
+    """BASELINE config 3's model and guide (examples/gaussian_mixture_model.py:51-85): the oracle's analytic
+    per-example gradient against central differences of a float64 numpy restatement of the loss in which the
+    Dirichlet draw is re-parametrised through the inverse Gamma CDF at fixed uniforms (the same pathwise derivative)."""
+    import scipy.special as sp
+    K, d, N = 4, 3, 50.0
+    r = np.random.default_rng(5)
+    spec = O.gmm_spec(K, d, prior_mu_scale=10.0, lik_scale=N, obs_scale=2.0)
+    alpha_log = (r.normal(size=K) * 0.4).astype(np.float32)
+    mus_loc = r.normal(size=(K, d)).astype(np.float32)
+    x = r.normal(size=d).astype(np.float32)
+    g, eps, sigs = O.gmm_px_latents(spec, alpha_log, np.array([11, 22], np.uint32), 5, 2)
+    sigs = np.minimum(sigs, 50.0).astype(np.float32)      # keep the finite-difference problem well scaled
+    u = sp.gammainc(np.exp(alpha_log.astype(np.float64)), g)
+    loss, grad = O.gmm_px_loss_grad_given(spec, alpha_log, mus_loc, x, g, eps, sigs)
+
+    def L(p):
+        alpha = np.exp(p[:K])
+        gg = sp.gammaincinv(alpha, u)
+        pis = gg / gg.sum()
+        mus = p[K:].reshape(K, d) + eps
+        lq = sp.gammaln(alpha.sum()) - sp.gammaln(alpha).sum() + ((alpha - 1) * np.log(pis)).sum() + (-0.5 * eps ** 2).sum()
+        lp = sp.gammaln(K) + (-0.5 * (mus / 10.0) ** 2 - np.log(10.0)).sum()
+        comp = np.log(pis) + (-0.5 * ((x - mus) / sigs) ** 2 - np.log(sigs) - 0.5 * np.log(2 * np.pi)).sum(1)
+        return 0.5 * ((lq - lp) - N * sp.logsumexp(comp))
+
+    p = np.concatenate([alpha_log, mus_loc.ravel()]).astype(np.float64)
+    assert abs(loss - L(p)) < 1e-5 * abs(L(p))
+    fd = np.array([(L(p + 1e-5 * e) - L(p - 1e-5 * e)) / 2e-5 for e in np.eye(p.size)])
+    np.testing.assert_allclose(grad, fd, rtol=2e-4, atol=2e-4 * np.abs(fd).max())
