@@ -32,8 +32,9 @@ __device__ __forceinline__ double gamma_grad_d(double alpha, double x)
     if (!(x > 0.0)) return 0.0;
     double t = 1.0, h = 0.0, S = 1.0, Sp = 0.0;
     for (int n = 1; n < 2000; ++n) {
-        t *= x / (alpha + n);
-        h += 1.0 / (alpha + n);
+        const double rcp = 1.0 / (alpha + n);
+        t *= x * rcp;
+        h += rcp;
         S += t;
         Sp -= t * h;
         if (t < 1e-18 * S && n > x) break;
@@ -122,66 +123,116 @@ __global__ void __launch_bounds__(256) k_gmm_mask_meta(const uint8_t* __restrict
     }
 }
 
+// guide_seed -> the three site keys of example p
+__device__ __forceinline__ void gmm_site_keys(const uint32_t* jax_key, uint32_t B, uint32_t p, uint32_t& kp0, uint32_t& kp1,
+                                              uint32_t& km0, uint32_t& km1, uint32_t& ks0, uint32_t& ks1)
+{
+    const uint32_t px0 = tf_iota_word(jax_key[0], jax_key[1], 2ull * B, 2ull * p);
+    const uint32_t px1 = tf_iota_word(jax_key[0], jax_key[1], 2ull * B, 2ull * p + 1);
+    uint32_t r0, r1, t0, t1;
+    tf_split2(px0, px1, t0, t1, r0, r1);   // guide_seed = child 1
+    tf_split2(r0, r1, t0, t1, kp0, kp1);   // k_pis = child 1, next state = child 0
+    tf_split2(t0, t1, r0, r1, km0, km1);
+    tf_split2(r0, r1, t0, t1, ks0, ks1);
+}
+
+// Dirichlet part, one THREAD per (example, component): Gamma(alpha_k) draw and its derivative wrt alpha_k.
+// dir[(p K + k) * 2 + {0, 1}] = {g, dg/dalpha}
+__global__ void __launch_bounds__(256) k_gmm_dirichlet(const double* __restrict__ pack, const uint32_t* __restrict__ jax_key,
+                                                       uint32_t B, int K, double* __restrict__ dir)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)B * K) return;
+    const uint32_t p = (uint32_t)(i / K), k = (uint32_t)(i % K);
+    uint32_t kp0, kp1, km0, km1, ks0, ks1;
+    gmm_site_keys(jax_key, B, p, kp0, kp1, km0, km1, ks0, ks1);
+    const double alpha = pack[k];
+    const double g = gamma_sample_d(kp0, kp1, k, alpha);
+    dir[2 * i] = g;
+    dir[2 * i + 1] = gamma_grad_d(alpha, g);
+}
+
 struct GmmArgs {
     const float* params;
     const double* pack;
+    const double* dir;       // B x K x 2 from k_gmm_dirichlet
     const float* X;
+    const uint32_t* idx;     // nullable: row of example p is X[idx[p]] (minibatch of a resident table)
     const uint8_t* mask;
     const uint32_t* jax_key;
     const float* meta;
     float* px_loss;
     float* px_grads;
     float* latents_out;  // nullable: B x (K + 2 K d): g, eps, sigs of every example (tests)
+    float* partials;     // SUM mode: one row of P + 2 per wavefront: [sum_i c_i g_i | sum_i loss_i | n]
     uint32_t B;
     int K, d;
-    float inv_ps2, log_ps, lik_scale, inv_obs, obs_scale;
+    float inv_ps2, log_ps, lik_scale, inv_obs, obs_scale, clip;
 };
 
-template <int KH, int DS>
-__global__ void __launch_bounds__(256) k_gmm_px(GmmArgs a)
+// SUM = false: materialise px_loss / px_grads (stage API).  SUM = true: clip each example's gradient by its joint
+// L2 norm and accumulate (svi.py:310-348 fused into stage 1); every wavefront strides over the batch and leaves one
+// partial row, summed in fixed order by k_gmm_finalize.
+// The unrolled component loop holds 4 KH DS values per lane; asking for 4 (2) resident waves per SIMD keeps the
+// scheduler from interleaving all threefry chains at once (which drove the small shapes to 256 VGPRs, occupancy 1).
+template <int KH, int DS, bool SUM, bool PAIRED>
+__global__ void __launch_bounds__(256, (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1)) k_gmm_px(GmmArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
-    if (p >= a.B) return;
+    const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
+    const uint32_t total_waves = (gridDim.x * blockDim.x) >> 6;
+    float accg[2 * KH * DS], acca = 0.f, loss_acc = 0.f, n_acc = 0.f;
+    float locv[2 * KH * DS];  // this lane's entries of mus_loc, loaded once (slot layout as wv / muv below)
+    {
+        const int K = a.K, d = a.d, Kh = (K + 1) >> 1;
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk)
+#pragma unroll
+            for (int s = 0; s < DS; ++s) {
+                const int dd = lane + 64 * s;
+                const bool ok0 = kk < Kh && dd < d, ok1 = ok0 && kk + Kh < K;
+                accg[kk * DS + s] = accg[(KH + kk) * DS + s] = 0.f;
+                locv[kk * DS + s] = ok0 ? a.params[K + kk * d + dd] : 0.f;
+                locv[(KH + kk) * DS + s] = ok1 ? a.params[K + (kk + Kh) * d + dd] : 0.f;
+            }
+    }
+    for (uint32_t p = gw; p < a.B; p += total_waves) {
     // components are handled in pairs (kk, kk + Kh), Kh = ceil(K / 2); for even K the pair shares its threefry calls
     // (words j and j + K d / 2 of jax's iota layout), for odd K every entry takes its own call
     const int K = a.K, d = a.d, Kh = (K + 1) >> 1, P = K + K * d;
     const uint32_t n_lat = (uint32_t)(K * d), half = n_lat >> 1;
-    const bool paired = (K & 1) == 0;
     const float live = (a.mask ? a.mask[p] != 0 : true) ? 1.0f : 0.0f;
+    if (SUM && live == 0.0f) continue;  // masked examples contribute nothing (svi.py:281)
+    const size_t row = a.idx ? a.idx[p] : p;
 
     // ---- keys of the guide's sample sites (numpyro.handlers.seed over pis, mus, sigs)
-    uint32_t px0 = tf_iota_word(a.jax_key[0], a.jax_key[1], 2ull * a.B, 2ull * p);
-    uint32_t px1 = tf_iota_word(a.jax_key[0], a.jax_key[1], 2ull * a.B, 2ull * p + 1);
-    uint32_t r0, r1, t0, t1, kp0, kp1, km0, km1, ks0, ks1;
-    tf_split2(px0, px1, t0, t1, r0, r1);   // guide_seed = child 1
-    tf_split2(r0, r1, t0, t1, kp0, kp1);   // k_pis = child 1, next state = child 0
-    tf_split2(t0, t1, r0, r1, km0, km1);
-    tf_split2(r0, r1, t0, t1, ks0, ks1);
+    uint32_t kp0, kp1, km0, km1, ks0, ks1;
+    gmm_site_keys(a.jax_key, a.B, p, kp0, kp1, km0, km1, ks0, ks1);
 
     // ---- Dirichlet part on lanes < K (float64)
     double alpha = 1.0, g = 0.0, gp = 0.0;
     if (lane < K) {
         alpha = a.pack[lane];
-        g = gamma_sample_d(kp0, kp1, (uint32_t)lane, alpha);
-        gp = gamma_grad_d(alpha, g);
+        g = a.dir[((size_t)p * K + lane) * 2];
+        gp = a.dir[((size_t)p * K + lane) * 2 + 1];
     }
     double S = 0.0;
     for (int k = 0; k < K; ++k) S += readlane_d(g, k);
     const double pis = lane < K ? g / S : 1.0;
-    const float logpis = (float)log(pis);
+    const double logpis_d = log(pis);
+    const float logpis = (float)logpis_d;
 
     // ---- mus, sigs and the per-component log-densities (lanes <-> feature dimensions)
     float xs[DS];
 #pragma unroll
     for (int s = 0; s < DS; ++s) {
         const int dd = lane + 64 * s;
-        xs[s] = dd < d ? a.X[(size_t)p * d + dd] : 0.f;
+        xs[s] = dd < d ? a.X[(size_t)row * d + dd] : 0.f;
     }
     float wv[2 * KH * DS], muv[2 * KH * DS];
     float acomp[2 * KH];
     float lmu = 0.f;  // sum of  -eps^2/2 + (mu/ps)^2/2 + log ps  over this lane's entries
-    float* lat = a.latents_out ? a.latents_out + (size_t)p * (K + 2 * n_lat) : nullptr;
+    float* lat = (!SUM && a.latents_out) ? a.latents_out + (size_t)p * (K + 2 * n_lat) : nullptr;
 #pragma unroll
     for (int kk = 0; kk < KH; ++kk) {
         float ll0 = 0.f, ll1 = 0.f;
@@ -189,11 +240,12 @@ __global__ void __launch_bounds__(256) k_gmm_px(GmmArgs a)
             const bool has1 = kk + Kh < K;
 #pragma unroll
             for (int s = 0; s < DS; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
                 const int dd = lane + 64 * s;
                 const bool ok0 = dd < d, ok1 = ok0 && has1;
                 const uint32_t j0 = (uint32_t)(kk * d + dd), j1 = (uint32_t)((kk + Kh) * d + dd);
                 uint32_t b0, b1, u0, u1;
-                if (paired) {  // j1 == j0 + half
+                if (PAIRED) {  // K even: j1 == j0 + half
                     threefry2x32(km0, km1, ok0 ? j0 : 0u, ok0 ? j1 : 0u, b0, b1);
                     threefry2x32(ks0, ks1, ok0 ? j0 : 0u, ok0 ? j1 : 0u, u0, u1);
                 } else {
@@ -202,19 +254,19 @@ __global__ void __launch_bounds__(256) k_gmm_px(GmmArgs a)
                     b1 = tf_iota_word(km0, km1, n_lat, ok1 ? j1 : 0u);
                     u1 = tf_iota_word(ks0, ks1, n_lat, ok1 ? j1 : 0u);
                 }
-                const float e0 = bits_to_normal(b0), e1 = bits_to_normal(b1);
+                const float e0 = bits_to_normal_wu(b0), e1 = bits_to_normal_wu(b1);
                 // Exponential(1) by inversion; sigs = 1 / ex, so 1 / sig = ex and -log sig = log ex
                 const float ex0 = -logf(((float)(u0 >> 9) + 0.5f) * 1.1920928955078125e-07f);
                 const float ex1 = -logf(((float)(u1 >> 9) + 0.5f) * 1.1920928955078125e-07f);
-                const float mu0 = ok0 ? a.params[K + j0] + e0 : 0.f, mu1 = ok1 ? a.params[K + j1] + e1 : 0.f;
-                const float z0 = (xs[s] - mu0) * ex0, z1 = (xs[s] - mu1) * ex1;
                 const int i0 = kk * DS + s, i1 = (KH + kk) * DS + s;
+                const float mu0 = ok0 ? locv[i0] + e0 : 0.f, mu1 = ok1 ? locv[i1] + e1 : 0.f;
+                const float z0 = (xs[s] - mu0) * ex0, z1 = (xs[s] - mu1) * ex1;
                 wv[i0] = ok0 ? z0 * ex0 : 0.f;
                 wv[i1] = ok1 ? z1 * ex1 : 0.f;
                 muv[i0] = mu0;
                 muv[i1] = mu1;
                 if (ok0) {
-                    ll0 += __fmaf_rn(-0.5f * z0, z0, logf(ex0) - D3P_HALF_LOG_2PI);
+                    ll0 += __fmaf_rn(-0.5f * z0, z0, __logf(ex0) - D3P_HALF_LOG_2PI);
                     lmu += __fmaf_rn(-0.5f * e0, e0, __fmaf_rn(0.5f * a.inv_ps2 * mu0, mu0, a.log_ps));
                     if (lat) {
                         lat[K + j0] = e0;
@@ -222,7 +274,7 @@ __global__ void __launch_bounds__(256) k_gmm_px(GmmArgs a)
                     }
                 }
                 if (ok1) {
-                    ll1 += __fmaf_rn(-0.5f * z1, z1, logf(ex1) - D3P_HALF_LOG_2PI);
+                    ll1 += __fmaf_rn(-0.5f * z1, z1, __logf(ex1) - D3P_HALF_LOG_2PI);
                     lmu += __fmaf_rn(-0.5f * e1, e1, __fmaf_rn(0.5f * a.inv_ps2 * mu1, mu1, a.log_ps));
                     if (lat) {
                         lat[K + j1] = e1;
@@ -233,6 +285,7 @@ __global__ void __launch_bounds__(256) k_gmm_px(GmmArgs a)
         }
         acomp[kk] = wave_sum(ll0);
         acomp[KH + kk] = wave_sum(ll1);
+        __builtin_amdgcn_sched_barrier(0);  // one component pair at a time: keeps the live threefry chains (and VGPRs) bounded
     }
     lmu = wave_sum(lmu);
     if (lat && lane < K) lat[lane] = (float)g;
@@ -253,8 +306,8 @@ __global__ void __launch_bounds__(256) k_gmm_px(GmmArgs a)
 #pragma unroll
     for (int kk = 0; kk < KH; ++kk) {
         if (kk < Kh) {
-            acomp[kk] = expf(acomp[kk] - best);
-            acomp[KH + kk] = expf(acomp[KH + kk] - best);  // exp(-inf) = 0 for the missing partner of an odd K
+            acomp[kk] = __expf(acomp[kk] - best);
+            acomp[KH + kk] = __expf(acomp[KH + kk] - best);  // exp(-inf) = 0 for the missing partner of an odd K
             se += acomp[kk] + acomp[KH + kk];
         }
     }
@@ -262,8 +315,9 @@ __global__ void __launch_bounds__(256) k_gmm_px(GmmArgs a)
     const float inv_se = 1.0f / se;
 
     // ---- gradient wrt mus_loc: inv_obs * (mu / ps^2 - N r_k w)
-    float* gr = a.px_grads + (size_t)p * P;
+    float* gr = SUM ? nullptr : a.px_grads + (size_t)p * P;
     float my_r = 0.f;  // r_k of this lane's own component (lanes < K)
+    float n2 = 0.f;
 #pragma unroll
     for (int kk = 0; kk < KH; ++kk) {
         if (kk < Kh) {
@@ -277,8 +331,19 @@ __global__ void __launch_bounds__(256) k_gmm_px(GmmArgs a)
                 if (dd < d) {
                     const uint32_t j0 = (uint32_t)(kk * d + dd), j1 = (uint32_t)((kk + Kh) * d + dd);
                     const int i0 = kk * DS + s, i1 = (KH + kk) * DS + s;
-                    gr[K + j0] = a.inv_obs * __fmaf_rn(-a.lik_scale * ra, wv[i0], a.inv_ps2 * muv[i0]) * live;
-                    if (has1) gr[K + j1] = a.inv_obs * __fmaf_rn(-a.lik_scale * rb, wv[i1], a.inv_ps2 * muv[i1]) * live;
+                    const float g0 = a.inv_obs * __fmaf_rn(-a.lik_scale * ra, wv[i0], a.inv_ps2 * muv[i0]);
+                    const float g1 = has1 ? a.inv_obs * __fmaf_rn(-a.lik_scale * rb, wv[i1], a.inv_ps2 * muv[i1]) : 0.f;
+                    if (SUM) {  // keep the values for the clipped accumulation below
+                        wv[i0] = g0;
+                        wv[i1] = g1;
+                        n2 = __fmaf_rn(g0, g0, __fmaf_rn(g1, g1, n2));
+                    } else {
+                        gr[K + j0] = g0 * live;
+                        if (has1) gr[K + j1] = g1 * live;
+                    }
+                } else if (SUM) {
+                    wv[kk * DS + s] = 0.f;
+                    wv[(KH + kk) * DS + s] = 0.f;
                 }
             }
         }
@@ -287,71 +352,228 @@ __global__ void __launch_bounds__(256) k_gmm_px(GmmArgs a)
     // ---- gradient wrt alpha_log (lanes < K, float64) and the Dirichlet part of log q - log p
     const double A0 = a.pack[2 * K + 1];
     double lq_term = 0.0;
+    float ga = 0.f;
     if (lane < K) {
         const double psi0 = a.pack[2 * K], psik = a.pack[K + lane];
         const double gs = gp / S;
-        const double dq = psi0 - psik + log(pis) + gs * ((alpha - 1.0) / pis - (A0 - (double)K));
+        const double dq = psi0 - psik + logpis_d + gs * ((alpha - 1.0) / pis - (A0 - (double)K));
         const double dl = gs * ((double)my_r / pis - 1.0);
-        gr[lane] = (float)(alpha * (double)a.inv_obs * (dq - (double)a.lik_scale * dl)) * live;
-        lq_term = (alpha - 1.0) * log(pis);
+        ga = (float)(alpha * (double)a.inv_obs * (dq - (double)a.lik_scale * dl));
+        if (!SUM) gr[lane] = ga * live;
+        lq_term = (alpha - 1.0) * logpis_d;
     }
     double lq = a.pack[2 * K + 2];
     for (int k = 0; k < K; ++k) lq += readlane_d(lq_term, k);
-    if (lane == 0) {
-        const float L = a.inv_obs * (((float)lq + lmu) - a.lik_scale * loglik);
+    const float L = a.inv_obs * (((float)lq + lmu) - a.lik_scale * loglik);
+    if (SUM) {
+        n2 = wave_sum(__fmaf_rn(ga, ga, n2));
+        const float cf = 1.0f / fmaxf(1.0f, sqrtf(n2) / a.clip);  // svi.py:121-122
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) {
+            if (kk < Kh) {
+#pragma unroll
+                for (int s = 0; s < DS; ++s) {
+                    accg[kk * DS + s] = __fmaf_rn(cf, wv[kk * DS + s], accg[kk * DS + s]);
+                    accg[(KH + kk) * DS + s] = __fmaf_rn(cf, wv[(KH + kk) * DS + s], accg[(KH + kk) * DS + s]);
+                }
+            }
+        }
+        acca = __fmaf_rn(cf, ga, acca);
+        loss_acc += L;
+        n_acc += 1.0f;
+    } else if (lane == 0) {
         a.px_loss[p] = L * live * a.obs_scale * a.meta[1];  // svi.py:281, :306
+    }
+    }  // examples of this wavefront
+    if (SUM) {
+        const int K = a.K, d = a.d, Kh = (K + 1) >> 1, P = K + K * d;
+        float* out = a.partials + (size_t)gw * (P + 2);
+        if (lane < K) out[lane] = acca;
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) {
+            if (kk < Kh) {
+#pragma unroll
+                for (int s = 0; s < DS; ++s) {
+                    const int dd = lane + 64 * s;
+                    if (dd < d) {
+                        out[K + kk * d + dd] = accg[kk * DS + s];
+                        if (kk + Kh < K) out[K + (kk + Kh) * d + dd] = accg[(KH + kk) * DS + s];
+                    }
+                }
+            }
+        }
+        if (lane == 0) {
+            out[P] = loss_acc;
+            out[P + 1] = n_acc;
+        }
     }
 }
 
-}  // namespace d3p
+// Replicated tail of the step: fixed-order column sums of the per-wavefront partial rows, mean over the padded batch
+// (svi.py:343-346), Gaussian mechanism with per-site noise (svi.py:365-375, :487-491), numpyro Adam (svi.py:379-393).
+// The partial rows (<= D3P_GMM_MAX_WAVES) are summed by 8 row groups per column.
+struct GmmFinalArgs {
+    const float* partials;
+    uint32_t n_rows;     // partial rows
+    uint32_t B;
+    int P;
+    const float* noise;  // P standard normals: site alpha_log (K) then site mus_loc (K d)
+    float* params;
+    float* adam_m;
+    float* adam_v;
+    int32_t* step;
+    float* loss_out;     // nullable
+    float* grad_out;     // nullable
+    d3p_dpsvi_hyper h;
+    float obs_scale;
+};
 
-using namespace d3p;
+// First reduction level: the per-wavefront partial rows are cut into D3P_GMM_CHUNKS chunks of consecutive rows; workgroup
+// (column tile of 64, chunk) sums its rows with 4 row subgroups and leaves one row per chunk.  Fixed order throughout.
+#define D3P_GMM_CHUNKS 64u
 
-extern "C" {
-
-size_t d3p_gmm_px_grads_workspace(int32_t K)
+__global__ void __launch_bounds__(256) k_gmm_reduce(const float* __restrict__ parts, uint32_t n_rows, int width,
+                                                    float* __restrict__ reduced)
 {
-    return align_up_g((size_t)(2 * (K > 0 ? K : 0) + 3) * sizeof(double), 256);
+    __shared__ float lds[256];
+    const int c = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    const uint32_t per = (n_rows + D3P_GMM_CHUNKS - 1) / D3P_GMM_CHUNKS;
+    const uint32_t r0 = blockIdx.y * per, r1 = (r0 + per < n_rows) ? r0 + per : n_rows;
+    float s = 0.f;
+    if (col < width)
+        for (uint32_t r = r0 + sg; r < r1; r += 4) s += parts[(size_t)r * width + col];
+    lds[threadIdx.x] = s;
+    __syncthreads();
+    if (sg == 0 && col < width)
+        reduced[(size_t)blockIdx.y * width + col] = (lds[c] + lds[64 + c]) + (lds[128 + c] + lds[192 + c]);
 }
 
-int d3p_gmm_px_grads(void* stream, const d3p_gmm_model* model, const float* params_dev, const float* X_dev,
-                     const uint8_t* mask_dev, uint32_t B, const uint32_t* jax_key_dev, float* px_loss_dev, float* px_grads_dev,
-                     float* meta_dev, float* latents_out_dev, void* workspace_dev, size_t workspace_bytes)
+// fixed-order sum of one column of the partial rows by the whole workgroup; every thread returns the total
+__device__ __forceinline__ float gmm_block_column_sum(const float* __restrict__ parts, uint32_t n_rows, size_t stride, int col,
+                                                      float* lds)
 {
-    D3P_REQUIRE(model && params_dev && X_dev && jax_key_dev && px_loss_dev && px_grads_dev && meta_dev && workspace_dev,
-                "d3p_gmm_px_grads: null pointer");
-    D3P_REQUIRE(B >= 1, "d3p_gmm_px_grads: B must be >= 1");
-    D3P_REQUIRE(model->K >= 1 && model->d >= 1, "d3p_gmm_px_grads: K and d must be >= 1");
-    D3P_REQUIRE(model->prior_mu_scale > 0.f && model->inv_obs > 0.f, "d3p_gmm_px_grads: bad model");
+    float s = 0.f;
+    for (uint32_t r = threadIdx.x; r < n_rows; r += 256) s += parts[r * stride + col];
+    lds[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) lds[threadIdx.x] += lds[threadIdx.x + off];
+        __syncthreads();
+    }
+    const float tot = lds[0];
+    __syncthreads();
+    return tot;
+}
+
+// 32 columns per workgroup x 8 row groups; the row groups are combined through LDS in fixed order
+__global__ void __launch_bounds__(256) k_gmm_finalize(GmmFinalArgs a)
+{
+    __shared__ float lds[256];
+    const size_t stride = (size_t)a.P + 2;
+    const float n = gmm_block_column_sum(a.partials, a.n_rows, stride, a.P + 1, lds);
+    const float ls = gmm_block_column_sum(a.partials, a.n_rows, stride, a.P, lds);
+    const float Bf = (float)a.B;
+    const float factor = (n == 0.f) ? 0.f : Bf / n;  // svi.py:305
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
+    float s = 0.f;
+    if (col < a.P)
+        for (uint32_t r = rg; r < a.n_rows; r += 8) s += a.partials[r * stride + col];
+    lds[rg * 32 + c] = s;
+    __syncthreads();
+    if (rg == 0 && col < a.P) {
+        float tot = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) tot += lds[g * 32 + c];
+        const float g = (tot / Bf + a.noise[col] * (a.h.dp_scale * (a.h.clip / n))) * a.obs_scale * factor;
+        if (a.grad_out) a.grad_out[col] = g;
+        const int i = *a.step;
+        float x = a.params[col], m = a.adam_m[col], v = a.adam_v[col];
+        m = (1.0f - a.h.b1) * g + a.h.b1 * m;
+        v = (1.0f - a.h.b2) * g * g + a.h.b2 * v;
+        const float mhat = m / (1.0f - powf(a.h.b1, (float)(i + 1)));
+        const float vhat = v / (1.0f - powf(a.h.b2, (float)(i + 1)));
+        a.params[col] = x - a.h.lr * mhat / (sqrtf(vhat) + a.h.adam_eps);
+        a.adam_m[col] = m;
+        a.adam_v[col] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.loss_out) *a.loss_out = (ls / Bf) * a.obs_scale * factor;  // svi.py:342, :306
+}
+
+__global__ void k_gmm_incr(int32_t* step) { *step += 1; }
+
+#define D3P_GMM_MAX_WAVES 4096u
+
+struct GmmWorkspace {
+    double* pack;
+    double* dir;
+    float* partials;
+    float* reduced;   // D3P_GMM_CHUNKS x (P + 2)
+    float* noise;
+    float* meta;
+    uint32_t* keys;   // 3 x 16 (split of the state key) + 2 x 16 (site keys) + 16 (folded batch key) + jax key (2)
+    uint32_t* idx;    // B
+};
+
+static size_t gmm_carve(const d3p_gmm_model* m, uint32_t B, char* base, GmmWorkspace* ws)
+{
+    const size_t K = (size_t)m->K, P = K + K * (size_t)m->d;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up_g(bytes, 256); return base ? base + o : nullptr; };
+    char* q;
+    q = take((2 * K + 3) * sizeof(double)); if (ws) ws->pack = (double*)q;
+    q = take((size_t)B * K * 2 * sizeof(double)); if (ws) ws->dir = (double*)q;
+    q = take((size_t)D3P_GMM_MAX_WAVES * (P + 2) * sizeof(float)); if (ws) ws->partials = (float*)q;
+    q = take((size_t)D3P_GMM_CHUNKS * (P + 2) * sizeof(float)); if (ws) ws->reduced = (float*)q;
+    q = take(P * sizeof(float)); if (ws) ws->noise = (float*)q;
+    q = take(2 * sizeof(float)); if (ws) ws->meta = (float*)q;
+    q = take((6 * 16 + 2) * sizeof(uint32_t)); if (ws) ws->keys = (uint32_t*)q;
+    q = take((size_t)B * sizeof(uint32_t)); if (ws) ws->idx = (uint32_t*)q;
+    return off;
+}
+
+static int gmm_validate(const d3p_gmm_model* model, const char* what)
+{
+    if (!model) return fail(D3P_E_INVALID_ARG, "%s: null model", what);
+    if (!(model->K >= 1 && model->d >= 1 && model->prior_mu_scale > 0.f && model->inv_obs > 0.f))
+        return fail(D3P_E_INVALID_ARG, "%s: bad model (K, d >= 1, prior_mu_scale > 0, inv_obs > 0)", what);
     if (model->K > 32 || model->d > 256 || (model->K > 16 && model->d > 128))
-        return fail(D3P_E_UNSUPPORTED, "d3p_gmm_px_grads: supported shapes are K <= 16 with d <= 256 and K <= 32 with d <= 128 "
-                                       "(K = %d, d = %d)", model->K, model->d);
-    if (workspace_bytes < d3p_gmm_px_grads_workspace(model->K)) return fail(D3P_E_WORKSPACE, "d3p_gmm_px_grads: workspace too small");
-    hipStream_t s = (hipStream_t)stream;
-    double* pack = (double*)workspace_dev;
-    hipLaunchKernelGGL(k_gmm_pack, dim3(1), dim3(64), 0, s, params_dev, model->K, pack);
-    hipLaunchKernelGGL(k_gmm_mask_meta, dim3(1), dim3(256), 0, s, mask_dev, B, meta_dev);
-    GmmArgs a;
-    a.params = params_dev;
-    a.pack = pack;
-    a.X = X_dev;
-    a.mask = mask_dev;
-    a.jax_key = jax_key_dev;
-    a.meta = meta_dev;
-    a.px_loss = px_loss_dev;
-    a.px_grads = px_grads_dev;
-    a.latents_out = latents_out_dev;
-    a.B = B;
-    a.K = model->K;
-    a.d = model->d;
-    a.inv_ps2 = 1.0f / (model->prior_mu_scale * model->prior_mu_scale);
-    a.log_ps = logf(model->prior_mu_scale);
-    a.lik_scale = model->lik_scale;
-    a.inv_obs = model->inv_obs;
-    a.obs_scale = 1.0f / model->inv_obs;
-    const dim3 grid(cdiv((uint64_t)B * 64, 256)), block(256);
+        return fail(D3P_E_UNSUPPORTED, "%s: supported shapes are K <= 16 with d <= 256 and K <= 32 with d <= 128 (K = %d, d = %d)",
+                    what, model->K, model->d);
+    return D3P_OK;
+}
+
+static void gmm_fill(GmmArgs* a, const d3p_gmm_model* model, const float* params, const float* X, const uint32_t* idx,
+                     const uint8_t* mask, uint32_t B, const uint32_t* jax_key, float clip)
+{
+    memset(a, 0, sizeof(*a));
+    a->params = params;
+    a->X = X;
+    a->idx = idx;
+    a->mask = mask;
+    a->jax_key = jax_key;
+    a->B = B;
+    a->K = model->K;
+    a->d = model->d;
+    a->inv_ps2 = 1.0f / (model->prior_mu_scale * model->prior_mu_scale);
+    a->log_ps = logf(model->prior_mu_scale);
+    a->lik_scale = model->lik_scale;
+    a->inv_obs = model->inv_obs;
+    a->obs_scale = 1.0f / model->inv_obs;
+    a->clip = clip;
+}
+
+template <bool SUM>
+static int gmm_launch_px(hipStream_t s, const d3p_gmm_model* model, const GmmArgs& a, uint32_t n_waves)
+{
+    const dim3 grid(cdiv((uint64_t)n_waves * 64, 256)), block(256);
     const int KH = (model->K + 1) / 2 <= 8 ? 8 : 16, DS = (model->d + 63) / 64;
-#define D3P_GMM_LAUNCH(KH_, DS_) hipLaunchKernelGGL((k_gmm_px<KH_, DS_>), grid, block, 0, s, a)
+#define D3P_GMM_LAUNCH(KH_, DS_)                                                                 \
+    if (model->K % 2 == 0)                                                                       \
+        hipLaunchKernelGGL((k_gmm_px<KH_, DS_, SUM, true>), grid, block, 0, s, a);               \
+    else                                                                                         \
+        hipLaunchKernelGGL((k_gmm_px<KH_, DS_, SUM, false>), grid, block, 0, s, a)
     if (KH == 8) {
         switch (DS) {
         case 1: D3P_GMM_LAUNCH(8, 1); break;
@@ -365,7 +587,148 @@ int d3p_gmm_px_grads(void* stream, const d3p_gmm_model* model, const float* para
         }
     }
 #undef D3P_GMM_LAUNCH
-    return check_launch("d3p_gmm_px_grads");
+    return check_launch("k_gmm_px");
+}
+
+}  // namespace d3p
+
+using namespace d3p;
+
+extern "C" {
+
+size_t d3p_gmm_px_grads_workspace(int32_t K, uint32_t B)
+{
+    const size_t k = (size_t)(K > 0 ? K : 0);
+    return align_up_g((2 * k + 3) * sizeof(double), 256) + align_up_g((size_t)B * k * 2 * sizeof(double), 256);
+}
+
+int d3p_gmm_px_grads(void* stream, const d3p_gmm_model* model, const float* params_dev, const float* X_dev,
+                     const uint8_t* mask_dev, uint32_t B, const uint32_t* jax_key_dev, float* px_loss_dev, float* px_grads_dev,
+                     float* meta_dev, float* latents_out_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    D3P_REQUIRE(model && params_dev && X_dev && jax_key_dev && px_loss_dev && px_grads_dev && meta_dev && workspace_dev,
+                "d3p_gmm_px_grads: null pointer");
+    D3P_REQUIRE(B >= 1, "d3p_gmm_px_grads: B must be >= 1");
+    if (int rc = gmm_validate(model, "d3p_gmm_px_grads")) return rc;
+    if (workspace_bytes < d3p_gmm_px_grads_workspace(model->K, B)) return fail(D3P_E_WORKSPACE, "d3p_gmm_px_grads: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    double* pack = (double*)workspace_dev;
+    double* dir = (double*)((char*)workspace_dev + align_up_g((2 * (size_t)model->K + 3) * sizeof(double), 256));
+    hipLaunchKernelGGL(k_gmm_pack, dim3(1), dim3(64), 0, s, params_dev, model->K, pack);
+    hipLaunchKernelGGL(k_gmm_mask_meta, dim3(1), dim3(256), 0, s, mask_dev, B, meta_dev);
+    hipLaunchKernelGGL(k_gmm_dirichlet, dim3(cdiv((uint64_t)B * model->K, 256)), dim3(256), 0, s, (const double*)pack, jax_key_dev, B,
+                       model->K, dir);
+    GmmArgs a;
+    gmm_fill(&a, model, params_dev, X_dev, nullptr, mask_dev, B, jax_key_dev, 1.0f);
+    a.pack = pack;
+    a.dir = dir;
+    a.meta = meta_dev;
+    a.px_loss = px_loss_dev;
+    a.px_grads = px_grads_dev;
+    a.latents_out = latents_out_dev;
+    return gmm_launch_px<false>(s, model, a, B);
+}
+
+size_t d3p_dpvi_gmm_workspace(const d3p_gmm_model* model, uint32_t B)
+{
+    if (!model || model->K < 1 || model->d < 1) return 0;
+    return gmm_carve(model, B, nullptr, nullptr);
+}
+
+// One DPSVI.update (svi.py:395-434) for the mixture model, enqueued on `stream` without host synchronisation.
+static int gmm_enqueue_update(hipStream_t s, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                              int slot, const float* X_dev, const uint32_t* idx_dev, const uint8_t* mask_dev, uint32_t B,
+                              float* loss_dev, float* grad_out_dev, const GmmWorkspace& ws)
+{
+    int rc;
+    const int K = model->K, P = K + K * model->d;
+    uint32_t* cur_key = state->rng_key + 16 * (slot & 1);
+    uint32_t* split3 = ws.keys;             // [next | gradient | perturbation]   (svi.py:208-211, :413-414)
+    uint32_t* site_keys = ws.keys + 48;     // split(perturbation_key, 2)          (svi.py:491)
+    uint32_t* jax_key = ws.keys + 96;       // convert_to_jax_rng_key(gradient_key) (svi.py:259)
+    if ((rc = d3p_rng_split(s, cur_key, 3, split3))) return rc;
+    if ((rc = d3p_rng_random_bits(s, split3 + 16, 32, 2, jax_key))) return rc;
+    if ((rc = d3p_rng_split(s, split3 + 32, 2, site_keys))) return rc;
+    if ((rc = d3p_rng_normal(s, site_keys, (uint64_t)K, ws.noise))) return rc;
+    if ((rc = d3p_rng_normal(s, site_keys + 16, (uint64_t)(P - K), ws.noise + K))) return rc;
+    hipLaunchKernelGGL(k_gmm_pack, dim3(1), dim3(64), 0, s, (const float*)state->params, K, ws.pack);
+    hipLaunchKernelGGL(k_gmm_dirichlet, dim3(cdiv((uint64_t)B * K, 256)), dim3(256), 0, s, (const double*)ws.pack,
+                       (const uint32_t*)jax_key, B, K, ws.dir);
+    GmmArgs a;
+    gmm_fill(&a, model, state->params, X_dev, idx_dev, mask_dev, B, jax_key, hyper->clip);
+    a.pack = ws.pack;
+    a.dir = ws.dir;
+    a.partials = ws.partials;
+    const uint32_t n_waves = B < D3P_GMM_MAX_WAVES ? B : D3P_GMM_MAX_WAVES;
+    if ((rc = gmm_launch_px<true>(s, model, a, n_waves))) return rc;
+    const uint32_t rows = cdiv((uint64_t)n_waves * 64, 256) * 4;  // every launched wavefront wrote a row
+    hipLaunchKernelGGL(k_gmm_reduce, dim3(cdiv(P + 2, 64), D3P_GMM_CHUNKS), dim3(256), 0, s, (const float*)ws.partials, rows, P + 2,
+                       ws.reduced);
+    GmmFinalArgs f;
+    f.partials = ws.reduced;
+    f.n_rows = D3P_GMM_CHUNKS;
+    f.B = B;
+    f.P = P;
+    f.noise = ws.noise;
+    f.params = state->params;
+    f.adam_m = state->adam_m;
+    f.adam_v = state->adam_v;
+    f.step = state->step;
+    f.loss_out = loss_dev;
+    f.grad_out = grad_out_dev;
+    f.h = *hyper;
+    f.obs_scale = 1.0f / model->inv_obs;
+    hipLaunchKernelGGL(k_gmm_finalize, dim3(cdiv(P, 32)), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(k_gmm_incr, dim3(1), dim3(1), 0, s, state->step);
+    D3P_HIP_TRY(hipMemcpyAsync(state->rng_key + 16 * ((slot + 1) & 1), split3, 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    return check_launch("d3p_dpvi_gmm_update");
+}
+
+static int gmm_check_common(const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state, uint32_t B,
+                            void* workspace_dev, size_t workspace_bytes, const char* what)
+{
+    if (int rc = gmm_validate(model, what)) return rc;
+    D3P_REQUIRE(hyper && state && state->rng_key && state->params && state->adam_m && state->adam_v && state->step && workspace_dev,
+                "null pointer");
+    if (!(hyper->clip > 0.f) || !std::isfinite(hyper->clip))
+        return fail(D3P_E_INVALID_ARG, "%s: the clipping threshold must be finite and greater than 0", what);
+    D3P_REQUIRE(B >= 1, "B must be >= 1");
+    if (workspace_bytes < d3p_dpvi_gmm_workspace(model, B)) return fail(D3P_E_WORKSPACE, "%s: workspace too small", what);
+    return D3P_OK;
+}
+
+int d3p_dpvi_gmm_update(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                        const float* X_dev, const uint8_t* mask_dev, uint32_t B, float* loss_dev, float* grad_out_dev,
+                        void* workspace_dev, size_t workspace_bytes)
+{
+    if (int rc = gmm_check_common(model, hyper, state, B, workspace_dev, workspace_bytes, "d3p_dpvi_gmm_update")) return rc;
+    D3P_REQUIRE(X_dev, "d3p_dpvi_gmm_update: null data pointer");
+    GmmWorkspace ws;
+    gmm_carve(model, B, (char*)workspace_dev, &ws);
+    return gmm_enqueue_update((hipStream_t)stream, model, hyper, state, state->key_slot, X_dev, nullptr, mask_dev, B, loss_dev,
+                              grad_out_dev, ws);
+}
+
+int d3p_dpvi_gmm_run(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                     const uint32_t* batch_key_dev, uint32_t first_batch, const float* X_dev, uint32_t n_rows, uint32_t B,
+                     uint32_t num_steps, float* losses_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    if (int rc = gmm_check_common(model, hyper, state, B, workspace_dev, workspace_bytes, "d3p_dpvi_gmm_run")) return rc;
+    D3P_REQUIRE(X_dev && batch_key_dev, "d3p_dpvi_gmm_run: null pointer");
+    D3P_REQUIRE(B <= n_rows, "d3p_dpvi_gmm_run: batch larger than the table");
+    GmmWorkspace ws;
+    gmm_carve(model, B, (char*)workspace_dev, &ws);
+    uint32_t* folded = ws.keys + 80;
+    for (uint32_t t = 0; t < num_steps; ++t) {
+        int rc;
+        // get_batch(i, batchifier_state) of subsample_batchify_data (minibatch.py:226-237): fold_in + Feistel sample
+        if ((rc = d3p_rng_fold_in(stream, batch_key_dev, first_batch + t, folded))) return rc;
+        if ((rc = d3p_feistel_sample(stream, folded, n_rows, B, ws.idx))) return rc;
+        if ((rc = gmm_enqueue_update((hipStream_t)stream, model, hyper, state, state->key_slot + (int)t, X_dev, ws.idx, nullptr, B,
+                                     losses_dev ? losses_dev + t : nullptr, nullptr, ws)))
+            return rc;
+    }
+    return D3P_OK;
 }
 
 }  // extern "C"

@@ -313,7 +313,7 @@ class DPSVI:
         px_loss = torch.empty(B, dtype=torch.float32, device=X.device)
         px_grads = torch.empty((B, P), dtype=torch.float32, device=X.device)
         meta = torch.empty(2, dtype=torch.float32, device=X.device)
-        ws = self._workspace(lib.d3p_gmm_px_grads_workspace(K), X.device, "gmm")
+        ws = self._workspace(lib.d3p_gmm_px_grads_workspace(K, B), X.device, "gmm")
         lat = kwargs.get("_latents_out")
         check(lib.d3p_gmm_px_grads(stream_ptr(), C.byref(gm), ptr(params), ptr(X), ptr(mask_t), B, ptr(jax_rng_key),
                                    ptr(px_loss), ptr(px_grads), ptr(meta), ptr(lat), ptr(ws), ws.numel()))
@@ -465,8 +465,64 @@ class DPSVI:
                 and isinstance(self.guide, (AutoDiagonalNormal, DiagonalNormalGuide))
                 and isinstance(self.optim, Adam) and self._rng_suite is strong_rng)
 
+    def _gmm_fusable(self):
+        return self._is_gmm() and isinstance(self.optim, Adam) and self._rng_suite is strong_rng
+
+    def _update_gmm_fused(self, svi_state, *args, mask=True, _grad_out=None, **kwargs):
+        """DPSVI.update for the mixture model through ``d3p_dpvi_gmm_update`` (one C call, no B x P tensor)."""
+        _lib.require_device()
+        lib = _lib.load()
+        X = args[0].contiguous()
+        B, d = X.shape
+        dev = X.device
+        gm = self._gmm_struct(d, kwargs, svi_state.observation_scale)
+        hyper = self._hyper()
+        step, params, m, v = (t.clone() for t in svi_state.optim_state)
+        keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
+        keybuf[0].copy_(svi_state.rng_key.reshape(16))
+        mask_t = None
+        if not isinstance(mask, bool):
+            mask_t = mask.to(torch.uint8).contiguous()
+        elif mask is False:
+            mask_t = torch.zeros(B, dtype=torch.uint8, device=dev)
+        st = self._state_struct(keybuf, 0, (step, params, m, v))
+        ws = self._workspace(lib.d3p_dpvi_gmm_workspace(C.byref(gm), B), dev, "gmm_step")
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        check(lib.d3p_dpvi_gmm_update(stream_ptr(), C.byref(gm), C.byref(hyper), C.byref(st), ptr(X), ptr(mask_t), B,
+                                      ptr(loss), ptr(_grad_out), ptr(ws), ws.numel()))
+        return DPSVIState((step, params, m, v), keybuf[1].reshape(4, 4), svi_state.observation_scale), loss[0]
+
+    def _run_steps_gmm(self, svi_state, get_batch, batchifier_state, first_batch, num_steps, **kwargs):
+        info = getattr(get_batch, "source", None)
+        if info is None or info.rng_suite is not strong_rng or info.kind != _lib.D3P_BATCH_FEISTEL:
+            raise _lib.D3PError("run_steps (mixture model): get_batch must come from subsample_batchify_data "
+                                "(without replacement) with rng_suite=d3p_amd.random")
+        _lib.require_device()
+        lib = _lib.load()
+        X = info.dataset[0]
+        if not (X.is_contiguous() and X.dtype == torch.float32):
+            raise _lib.D3PError("run_steps: dataset arrays must be contiguous float32 CUDA tensors")
+        N, d = X.shape
+        dev = X.device
+        gm = self._gmm_struct(d, kwargs, svi_state.observation_scale)
+        hyper = self._hyper()
+        step, params, m, v = (t.clone() for t in svi_state.optim_state)
+        keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
+        keybuf[0].copy_(svi_state.rng_key.reshape(16))
+        bkey = batchifier_state.contiguous()
+        st = self._state_struct(keybuf, 0, (step, params, m, v))
+        B = int(info.batch_size)
+        ws = self._workspace(lib.d3p_dpvi_gmm_workspace(C.byref(gm), B), dev, "gmm_step")
+        losses = torch.empty(max(num_steps, 1), dtype=torch.float32, device=dev)
+        check(lib.d3p_dpvi_gmm_run(stream_ptr(), C.byref(gm), C.byref(hyper), C.byref(st), ptr(bkey), int(first_batch),
+                                   ptr(X), int(N), B, int(num_steps), ptr(losses), ptr(ws), ws.numel()))
+        return (DPSVIState((step, params, m, v), keybuf[num_steps & 1].reshape(4, 4), svi_state.observation_scale),
+                losses[:num_steps])
+
     def update(self, svi_state, *args, mask=True, **kwargs):
         """One DP-VI step on a batch; returns ``(new_state, loss)`` (svi.py:395-434)."""
+        if self._gmm_fusable():
+            return self._update_gmm_fused(svi_state, *args, mask=mask, **kwargs)
         if self._fusable():
             return self._update_fused(svi_state, *args, mask=mask, **kwargs)
         return self._update_staged(svi_state, *args, mask=mask, **kwargs)
@@ -528,6 +584,8 @@ class DPSVI:
         (examples/logistic_regression.py:149-160).  ``get_batch`` must come from
         ``subsample_batchify_data`` (without replacement) or ``poisson_batchify_data``.
         Returns ``(new_state, losses[num_steps])``."""
+        if self._gmm_fusable():
+            return self._run_steps_gmm(svi_state, get_batch, batchifier_state, first_batch, num_steps, **kwargs)
         if not self._fusable():
             raise _lib.D3PError("run_steps needs a built model family + diagonal-normal guide + Adam + d3p_amd.random")
         info = getattr(get_batch, "source", None)

@@ -188,7 +188,7 @@ typedef struct {
     float inv_obs;        /* 1 / observation_scale (svi.py:278) */
 } d3p_gmm_model;
 
-size_t d3p_gmm_px_grads_workspace(int32_t K);
+size_t d3p_gmm_px_grads_workspace(int32_t K, uint32_t B);
 int d3p_gmm_px_grads(void* stream, const d3p_gmm_model* model, const float* params_dev, const float* X_dev,
                      const uint8_t* mask_dev, uint32_t B, const uint32_t* jax_key_dev, float* px_loss_dev,
                      float* px_grads_dev, float* meta_dev, float* latents_out_dev, void* workspace_dev,
@@ -363,6 +363,23 @@ int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model
                                      const d3p_batch_source* src, const float* X_dev,
                                      const float* y_dev, void* workspace_dev, size_t workspace_bytes,
                                      int reps, float* avg_us, float* avg_event_us);
+
+/* DPSVI.update (svi.py:395-434) for the mixture model in one call: key split, per-example gradients clipped and
+ * summed without materialising B x P, per-site Gaussian noise, numpyro Adam, all enqueued on `stream`.  state as for
+ * the logistic-regression path (params = [alpha_log | mus_loc], P = K + K d; the new state key lands in the other
+ * key slot).  loss_dev[0]: batch loss; grad_out_dev (P, optional): the perturbed gradient. */
+size_t d3p_dpvi_gmm_workspace(const d3p_gmm_model* model, uint32_t B);
+int d3p_dpvi_gmm_update(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper,
+                        const d3p_dpsvi_state* state, const float* X_dev, const uint8_t* mask_dev, uint32_t B,
+                        float* loss_dev, float* grad_out_dev, void* workspace_dev, size_t workspace_bytes);
+
+/* num_steps x (get_batch(first_batch + t, batch_key) of subsample_batchify_data -> update) on the resident table
+ * X_dev (n_rows x d): the body of the example's jit(fori_loop(...)) epoch (examples/gaussian_mixture_model.py:219-230
+ * with the subsampling batchifier).  losses_dev[num_steps] optional. */
+int d3p_dpvi_gmm_run(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper,
+                     const d3p_dpsvi_state* state, const uint32_t* batch_key_dev, uint32_t first_batch,
+                     const float* X_dev, uint32_t n_rows, uint32_t B, uint32_t num_steps, float* losses_dev,
+                     void* workspace_dev, size_t workspace_bytes);
 
 /* Synthetic workload of SURVEY 8(d) / examples/logistic_regression.py:88-104, generated on device:
  * X[r][c] and y[r] are pure functions of (seed, global row, column). */

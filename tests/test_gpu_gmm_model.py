@@ -117,3 +117,42 @@ def test_learns_the_examples_toy_clusters(rng):
     assert np.mean(losses[-50:]) < np.mean(losses[:50])
     for c in centres.tolist():
         assert float((mus - c).abs().max(dim=1).values.min()) < 1.5, (c, mus)
+
+
+@pytest.mark.parametrize("B,K,d,masked", [(40, 16, 64, False), (70, 3, 2, True), (3000, 16, 64, True), (25, 5, 70, False)])
+def test_fused_update_matches_the_stage_composition(rng, B, K, d, masked):
+    """d3p_dpvi_gmm_update (clip + sum inside the gradient kernel, no B x P tensor) against the five stages run one by
+    one on the device (which the oracle tests pin); B = 3000 makes several examples share a wavefront."""
+    N = 10**5
+    X, params = problem(B, K, d, 5)
+    mask = torch.tensor(np.random.default_rng(2).random(B) < 0.7).cuda() if masked else True
+    svi = make_svi(K, d, N, C=20.0, sigma=0.7, lr=1e-2)
+    st = state_with(svi, rng.PRNGKey(8), params, N)
+    Xt = torch.tensor(X).cuda()
+    gout = torch.empty(K + K * d, device="cuda")
+    s_f, l_f = svi._update_gmm_fused(st, Xt, mask=mask, _grad_out=gout)
+    s_s, l_s = svi._update_staged(st, Xt, mask=mask)
+    assert abs(float(l_f) - float(l_s)) <= 2e-5 * abs(float(l_s))
+    assert torch.equal(s_f.rng_key, s_s.rng_key) and int(s_f.optim_state[0]) == 1
+    np.testing.assert_allclose(np_(s_f.optim_state[2]), np_(s_s.optim_state[2]), rtol=2e-4, atol=1e-6 * float(s_s.optim_state[2].abs().max()))
+    np.testing.assert_allclose(np_(s_f.optim_state[1]), np_(s_s.optim_state[1]), rtol=1e-5, atol=1e-6)
+    # bitwise reproducible
+    s_f2, l_f2 = svi._update_gmm_fused(st, Xt, mask=mask)
+    assert torch.equal(s_f2.optim_state[1], s_f.optim_state[1]) and float(l_f2) == float(l_f)
+
+
+def test_run_steps_walks_the_update_trajectory(rng):
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, d, K, B, steps = 5000, 64, 16, 128, 5
+    X = (torch.randn(N, d, generator=torch.Generator().manual_seed(1)) * 3).cuda()
+    svi = make_svi(K, d, N, C=20.0, sigma=0.5, lr=1e-2)
+    init, get_batch = subsample_batchify_data((X,), B)
+    nb, bstate = init(rng.PRNGKey(21))
+    st = svi.init(rng.PRNGKey(20), *get_batch(0, bstate))
+    new_st, losses = svi.run_steps(st, get_batch, bstate, 3, steps)
+    ref = st
+    for t in range(steps):
+        ref, l = svi.update(ref, *get_batch(3 + t, bstate))
+        assert abs(float(l) - float(losses[t])) <= 1e-6 * abs(float(l))
+    assert torch.equal(ref.rng_key, new_st.rng_key) and int(new_st.optim_state[0]) == steps
+    assert torch.equal(ref.optim_state[1], new_st.optim_state[1])

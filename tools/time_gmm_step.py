@@ -21,6 +21,18 @@ for _ in range(n):
     st, l = svi.update(st, X)
 torch.cuda.synchronize()
 print("staged update: %.1f us/step, loss %.4g" % ((time.time() - t0) / n * 1e6, float(l)))
+from d3p_amd.minibatch import subsample_batchify_data
+Xbig = torch.randn(10**6, d, generator=g).cuda() * 3
+init, get_batch = subsample_batchify_data((Xbig,), B)
+nb, bstate = init(rng.PRNGKey(5))
+st2 = svi.init(rng.PRNGKey(0), Xbig[:B])
+st2, losses = svi.run_steps(st2, get_batch, bstate, 0, 20)
+torch.cuda.synchronize()
+t0 = time.time()
+st2, losses = svi.run_steps(st2, get_batch, bstate, 20, 200)
+torch.cuda.synchronize()
+dt = (time.time() - t0) / 200
+print("run_steps (device loop, N=1e6 rows, Feistel batches): %.1f us/step = %.0f steps/s, %.3g per-example grads/s" % (dt * 1e6, 1 / dt, B / dt))
 key = rng.PRNGKey(1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 svi._compute_per_example_gradients(st, key, X)
