@@ -103,6 +103,8 @@ SIGNATURES = {
     "d3p_adam_step": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _F, _F, _F, _F]),
     "d3p_sgd_step": (C.c_int, [_V, _V, _V, _V, _U32, _F]),
     "d3p_gmm_px_grads_workspace": (C.c_size_t, [_I32, _U32]),
+    "d3p_gmm_evaluate_workspace": (C.c_size_t, [_V, _U32]),
+    "d3p_gmm_evaluate": (C.c_int, [_V, _V, _V, _V, _U32, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_gmm_workspace": (C.c_size_t, [_V, _U32]),
     "d3p_dpvi_gmm_update": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_gmm_run": (C.c_int, [_V, _V, _V, _V, _V, _U32, _V, _U32, _U32, _U32, _V, _V, C.c_size_t]),

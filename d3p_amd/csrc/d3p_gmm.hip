@@ -409,6 +409,74 @@ __global__ void __launch_bounds__(256, (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1
     }
 }
 
+// ---- DPSVI.evaluate for the mixture model: one guide draw for the whole batch (oracle: d3po_gmm_evaluate).
+// Writes mus / sigs (K d each) and pis (K) for d3p_gmm_log_prob, and lat[0] = (log q - log p)(latents).
+__global__ void __launch_bounds__(256) k_gmm_eval_latents(const float* __restrict__ params, const uint32_t* __restrict__ jax_key,
+                                                          int K, int d, float inv_ps2, float log_ps, float* __restrict__ mus,
+                                                          float* __restrict__ sigs, float* __restrict__ pis, float* __restrict__ lat)
+{
+    __shared__ double sh_g[64], sh_t[64];
+    __shared__ float red[256];
+    uint32_t a0, a1, r0, r1, t0, t1, kp0, kp1, km0, km1, ks0, ks1;
+    tf_split2(jax_key[0], jax_key[1], a0, a1, r0, r1);  // rng_key_eval = child 1
+    tf_split2(r0, r1, a0, a1, t0, t1);                  // guide_seed = child 1
+    tf_split2(t0, t1, a0, a1, kp0, kp1);
+    tf_split2(a0, a1, r0, r1, km0, km1);
+    tf_split2(r0, r1, a0, a1, ks0, ks1);
+    const int tid = threadIdx.x;
+    double alpha = 1.0;
+    if (tid < K) {
+        alpha = exp((double)params[tid]);
+        sh_g[tid] = gamma_sample_d(kp0, kp1, (uint32_t)tid, alpha);
+    }
+    __syncthreads();
+    double S = 0.0;
+    for (int k = 0; k < K; ++k) S += sh_g[k];
+    if (tid < K) {
+        const double p = sh_g[tid] / S;
+        pis[tid] = (float)p;
+        sh_t[tid] = -lgamma(alpha) + (alpha - 1.0) * log(p);
+        sh_g[tid] = alpha;
+    }
+    const uint32_t n = (uint32_t)(K * d);
+    float acc = 0.f;
+    for (uint32_t j = tid; j < n; j += 256) {
+        const float e = bits_to_normal(tf_iota_word(km0, km1, n, j));
+        const uint32_t b = tf_iota_word(ks0, ks1, n, j);
+        const float ex = -logf(((float)(b >> 9) + 0.5f) * 1.1920928955078125e-07f);
+        const float mu = params[K + j] + e;
+        mus[j] = mu;
+        sigs[j] = 1.0f / ex;
+        acc += __fmaf_rn(-0.5f * e, e, __fmaf_rn(0.5f * inv_ps2 * mu, mu, log_ps));
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double A0 = 0.0, t = 0.0;
+        for (int k = 0; k < K; ++k) { A0 += sh_g[k]; t += sh_t[k]; }
+        lat[0] = (float)(lgamma(A0) - lgamma((double)K) + t) + red[0];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gmm_eval_finish(const float* __restrict__ ll, uint32_t B, const float* __restrict__ lat,
+                                                         float lik_scale, float* __restrict__ loss)
+{
+    __shared__ float red[256];
+    float s = 0.f;
+    for (uint32_t i = threadIdx.x; i < B; i += 256) s += ll[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = lat[0] - (lik_scale / (float)B) * red[0];  // plate(N, B): likelihood scaled by N / B
+}
+
 // Replicated tail of the step: fixed-order column sums of the per-wavefront partial rows, mean over the padded batch
 // (svi.py:343-346), Gaussian mechanism with per-site noise (svi.py:365-375, :487-491), numpyro Adam (svi.py:379-393).
 // The partial rows (<= D3P_GMM_MAX_WAVES) are summed by 8 row groups per column.
@@ -627,6 +695,36 @@ int d3p_gmm_px_grads(void* stream, const d3p_gmm_model* model, const float* para
     a.px_grads = px_grads_dev;
     a.latents_out = latents_out_dev;
     return gmm_launch_px<false>(s, model, a, B);
+}
+
+size_t d3p_gmm_evaluate_workspace(const d3p_gmm_model* model, uint32_t B)
+{
+    if (!model || model->K < 1 || model->d < 1) return 0;
+    const size_t n = (size_t)model->K * model->d;
+    return 2 * align_up_g(n * sizeof(float), 256) + align_up_g((size_t)model->K * sizeof(float), 256) +
+           align_up_g((size_t)B * sizeof(float), 256) + 256;
+}
+
+int d3p_gmm_evaluate(void* stream, const d3p_gmm_model* model, const float* params_dev, const float* X_dev, uint32_t B,
+                     const uint32_t* jax_key_dev, float* loss_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    D3P_REQUIRE(params_dev && X_dev && jax_key_dev && loss_dev && workspace_dev, "d3p_gmm_evaluate: null pointer");
+    D3P_REQUIRE(B >= 1, "d3p_gmm_evaluate: B must be >= 1");
+    if (int rc = gmm_validate(model, "d3p_gmm_evaluate")) return rc;
+    if (workspace_bytes < d3p_gmm_evaluate_workspace(model, B)) return fail(D3P_E_WORKSPACE, "d3p_gmm_evaluate: workspace too small");
+    const size_t n = (size_t)model->K * model->d;
+    char* q = (char*)workspace_dev;
+    float* mus = (float*)q; q += align_up_g(n * sizeof(float), 256);
+    float* sigs = (float*)q; q += align_up_g(n * sizeof(float), 256);
+    float* pis = (float*)q; q += align_up_g((size_t)model->K * sizeof(float), 256);
+    float* ll = (float*)q; q += align_up_g((size_t)B * sizeof(float), 256);
+    float* lat = (float*)q;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gmm_eval_latents, dim3(1), dim3(256), 0, s, params_dev, jax_key_dev, model->K, model->d,
+                       1.0f / (model->prior_mu_scale * model->prior_mu_scale), logf(model->prior_mu_scale), mus, sigs, pis, lat);
+    if (int rc = d3p_gmm_log_prob(stream, X_dev, B, model->d, mus, sigs, pis, model->K, ll)) return rc;
+    hipLaunchKernelGGL(k_gmm_eval_finish, dim3(1), dim3(256), 0, s, (const float*)ll, B, (const float*)lat, model->lik_scale, loss_dev);
+    return check_launch("d3p_gmm_evaluate");
 }
 
 size_t d3p_dpvi_gmm_workspace(const d3p_gmm_model* model, uint32_t B)

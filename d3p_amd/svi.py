@@ -620,6 +620,19 @@ class DPSVI:
     # ---------------------------------------------------------------- evaluate / accounting
     def evaluate(self, svi_state, *args, **kwargs):
         """ELBO loss of a batch at the current parameters (d3p/svi.py:436-449 -> numpyro SVI.evaluate)."""
+        if self._is_gmm():
+            _lib.require_device()
+            lib = _lib.load()
+            X = args[0].contiguous()
+            B, d = X.shape
+            jax_rng_key = self._rng_suite.convert_to_jax_rng_key(self._rng_suite.split(svi_state.rng_key, 1)[0]).contiguous()
+            params = self.optim.get_params(svi_state.optim_state).contiguous()
+            gm = self._gmm_struct(d, kwargs, 1.0)
+            ws = self._workspace(lib.d3p_gmm_evaluate_workspace(C.byref(gm), B), X.device, "gmm_eval")
+            loss = torch.empty(1, dtype=torch.float32, device=X.device)
+            check(lib.d3p_gmm_evaluate(stream_ptr(), C.byref(gm), ptr(params), ptr(X), B, ptr(jax_rng_key), ptr(loss),
+                                       ptr(ws), ws.numel()))
+            return loss[0]
         self._require_logreg()
         _lib.require_device()
         lib = _lib.load()

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Gaussian mixture model with DP-VI on MI355X -- the workload of the reference's
+examples/gaussian_mixture_model.py (BASELINE config 3): model :51-68 (Dirichlet weights, Normal(0, 10) means,
+InverseGamma(1, 1) scales, d3p.gmm.GaussianMixture likelihood), guide :70-85 (alpha_log, mus_loc), three-cluster toy data
+:87-110, Poisson-subsampled training with clipping threshold 20 :176-232, and the final report of the learned mixture
+weights and modes plus the cluster-assignment accuracy on held-out data :112-161.
+
+Differences to the reference script, forced by the environment: model and guide are declared
+(d3p_amd.models.GaussianMixtureModel / GaussianMixtureGuide) instead of traced NumPyro functions, the toy data comes
+from torch's generator, dp_scale is given directly (the Fourier accountant behind approximate_sigma is not installed).
+"""
+import argparse
+import itertools
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+import d3p_amd._lib as L  # noqa: E402
+import d3p_amd.random as rng_suite  # noqa: E402
+from d3p_amd.minibatch import poisson_batchify_data, split_batchify_data  # noqa: E402
+from d3p_amd.models import Adam, GaussianMixtureGuide, GaussianMixtureModel, Trace_ELBO  # noqa: E402
+from d3p_amd.svi import DPSVI  # noqa: E402
+
+
+def create_toy_data(N, d, seed=1234):
+    """Imbalanced three-component data: the last component has twice as many samples (reference :87-110)."""
+    g = torch.Generator().manual_seed(seed)
+    mus = torch.tensor([-10.0, 10.0, -2.0])
+    sigs = torch.tensor([0.1, 1.0, 0.1])
+    z = torch.multinomial(torch.tensor([0.25, 0.25, 0.5]), 2 * N, replacement=True, generator=g)
+    X = mus[z, None] + sigs[z, None] * torch.randn(2 * N, d, generator=g)
+    X, z = X.cuda(), z.cuda()
+    return X[:N].contiguous(), X[N:].contiguous(), z[N:], mus.cuda()
+
+
+def assignment_accuracy(X_test, z_test, true_mus, modes):
+    """Assign every held-out point to the closest learned mode, map learned modes to true components by the best
+    permutation and compare with the generating assignment (reference :112-161, with unit scales)."""
+    k = modes.shape[0]
+    assign = torch.cdist(X_test, modes).argmin(dim=1)
+    d = X_test.shape[1]
+    centres = true_mus[:, None].expand(-1, d)
+    best = 0.0
+    for perm in itertools.permutations(range(k), centres.shape[0]):
+        # perm[j] = learned component standing for true component j
+        mapped = torch.full((k,), -1, device=X_test.device, dtype=torch.long)
+        for j, c in enumerate(perm):
+            mapped[c] = j
+        best = max(best, float((mapped[assign] == z_test).float().mean()))
+    return best
+
+
+def main(args):
+    L.require_device()
+    N, k, d = args.num_samples, args.num_components, args.dimensions
+    q = args.batch_size / N
+    X_train, X_test, z_test, true_mus = create_toy_data(N, d)
+    train_init, train_fetch = poisson_batchify_data((X_train,), q=q, max_batch_size=.99, rng_suite=rng_suite)
+    test_init, test_fetch = split_batchify_data((X_test,), batch_size=args.batch_size, rng_suite=rng_suite)
+
+    dpsvi_rng = rng_suite.PRNGKey(0)
+    dpsvi_rng, svi_init_rng, fetch_rng = rng_suite.split(dpsvi_rng, 3)
+    iters_per_epoch, batchifier_state = train_init(fetch_rng)
+
+    model = GaussianMixtureModel()
+    svi = DPSVI(model, GaussianMixtureGuide(model), Adam(args.learning_rate), Trace_ELBO(), dp_scale=args.sigma,
+                clipping_threshold=20., k=k, num_obs_total=N, rng_suite=rng_suite)
+    batch, _ = train_fetch(0, batchifier_state)
+    svi_state = svi.init(svi_init_rng, *batch)
+
+    for i in range(args.num_epochs):
+        t0 = time.time()
+        dpsvi_rng, data_fetch_rng = rng_suite.split(dpsvi_rng, 2)
+        num_batches, batchifier_state = train_init(rng_key=data_fetch_rng)
+        losses = []
+        for j in range(num_batches):
+            batch, mask = train_fetch(j, batchifier_state)
+            svi_state, batch_loss = svi.update(svi_state, *batch, mask=mask)
+            losses.append(batch_loss)
+        train_loss = float(torch.stack(losses).sum()) / (N * num_batches)
+        t1 = time.time()
+        if i % max(args.num_epochs // 5, 1) == 0:
+            dpsvi_rng, test_fetch_rng = rng_suite.split(dpsvi_rng, 2)
+            num_test_batches, test_state = test_init(rng_key=test_fetch_rng)
+            test_loss = sum(float(svi.evaluate(svi_state, *test_fetch(j, test_state)))
+                            for j in range(num_test_batches)) / (N * num_test_batches)
+            print("Epoch {}: loss = {:.4f} (on training set = {:.4f}) ({:.2f} s.)".format(i, test_loss, train_loss, t1 - t0))
+
+    params = svi.get_params(svi_state)
+    modes = params["mus_loc"]
+    alpha = torch.exp(params["alpha_log"])
+    pis = alpha / alpha.sum()                     # mean of Dirichlet(alpha)
+    print("MAP estimate of mixture weights: {}".format(pis.tolist()))
+    print("MAP estimate of mixture modes  : {}".format(modes.tolist()))
+    acc = assignment_accuracy(X_test, z_test, true_mus, modes)
+    print("assignment accuracy: {:.4f}".format(acc))
+    return acc, pis, modes
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser(description="parse args")
+    parser.add_argument('-n', '--num-epochs', default=100, type=int, help='number of training epochs')
+    parser.add_argument('-lr', '--learning-rate', default=5.0e-2, type=float, help='learning rate')
+    parser.add_argument('-batch-size', default=32, type=int, help='batch size')
+    parser.add_argument('-d', '--dimensions', default=2, type=int, help='data dimension')
+    parser.add_argument('-N', '--num-samples', default=2048, type=int, help='data samples count')
+    parser.add_argument('-k', '--num-components', default=3, type=int, help='number of components in the mixture model')
+    parser.add_argument('--sigma', default=1.0, type=float, help='dp_scale of the Gaussian mechanism')
+    main(parser.parse_args())

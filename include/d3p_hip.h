@@ -364,6 +364,12 @@ int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model
                                      const float* y_dev, void* workspace_dev, size_t workspace_bytes,
                                      int reps, float* avg_us, float* avg_event_us);
 
+/* DPSVI.evaluate (svi.py:436-449) for the mixture model: -ELBO of the batch with one guide draw;
+ * jax_key_dev = convert_to_jax_rng_key(split(state.rng_key, 1)[0]); model->lik_scale = num_obs_total. */
+size_t d3p_gmm_evaluate_workspace(const d3p_gmm_model* model, uint32_t B);
+int d3p_gmm_evaluate(void* stream, const d3p_gmm_model* model, const float* params_dev, const float* X_dev, uint32_t B,
+                     const uint32_t* jax_key_dev, float* loss_dev, void* workspace_dev, size_t workspace_bytes);
+
 /* DPSVI.update (svi.py:395-434) for the mixture model in one call: key split, per-example gradients clipped and
  * summed without materialising B x P, per-site Gaussian noise, numpyro Adam, all enqueued on `stream`.  state as for
  * the logistic-regression path (params = [alpha_log | mus_loc], P = K + K d; the new state key lands in the other

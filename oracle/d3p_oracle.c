@@ -950,6 +950,55 @@ D3P_API int d3po_gmm_px_grads(const d3po_gmm_spec* sp, const float* params, cons
     return n;
 }
 
+/* DPSVI.evaluate (svi.py:436-449) for the mixture model: -ELBO of the batch with ONE guide draw.
+ * rng_key_eval = split(jax_key)[1]; guide_seed = split(rng_key_eval)[1]; site keys as in d3po_gmm_site_keys;
+ * plate(N, B) scales the likelihood by N / B. */
+D3P_API float d3po_gmm_evaluate(const d3po_gmm_spec* sp, const float* params, const float* Xb, int B,
+                                const uint32_t jax_key[2])
+{
+    const int K = sp->K, d = sp->d, n = K * d;
+    uint32_t s[4], r[2], sk[6];
+    d3po_tf_split(jax_key, 2, s);
+    r[0] = s[2]; r[1] = s[3];
+    d3po_tf_split(r, 2, s);
+    r[0] = s[2]; r[1] = s[3];
+    for (int site = 0; site < 3; ++site) {
+        d3po_tf_split(r, 2, s);
+        sk[2 * site] = s[2]; sk[2 * site + 1] = s[3];
+        r[0] = s[0]; r[1] = s[1];
+    }
+    double* g = (double*)malloc(sizeof(double) * (size_t)K);
+    float* eps = (float*)malloc(sizeof(float) * 4 * (size_t)n + sizeof(float) * (size_t)K + sizeof(float) * (size_t)B);
+    float *sigs = eps + n, *mus = sigs + n, *pis = mus + n, *ll = pis + K;
+    double S = 0.0, A0 = 0.0, lat = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double alpha = exp((double)params[k]);
+        g[k] = d3po_gamma_sample(sk, (uint32_t)k, alpha);
+        S += g[k];
+        A0 += alpha;
+    }
+    lat = lgamma(A0) - lgamma((double)K);
+    for (int k = 0; k < K; ++k) {
+        const double alpha = exp((double)params[k]);
+        pis[k] = (float)(g[k] / S);
+        lat += -lgamma(alpha) + (alpha - 1.0) * log(g[k] / S);
+    }
+    d3po_tf_normal(sk + 2, (uint64_t)n, eps);
+    for (int j = 0; j < n; ++j) {
+        const uint32_t b = tf_iota_word(sk[4], sk[5], (uint64_t)n, (uint64_t)j);
+        const float u = ((float)(b >> 9) + 0.5f) * 1.1920928955078125e-07f;
+        sigs[j] = 1.0f / -logf(u);
+        mus[j] = params[K + j] + eps[j];
+        const double ps = sp->prior_mu_scale;
+        lat += -0.5 * (double)eps[j] * eps[j] - (-0.5 * ((double)mus[j] / ps) * ((double)mus[j] / ps) - log(ps));
+    }
+    d3po_gmm_log_prob(Xb, B, d, mus, sigs, pis, K, ll);
+    double tot = 0.0;
+    for (int i = 0; i < B; ++i) tot += (double)ll[i];
+    free(g); free(eps);
+    return (float)(lat - ((double)sp->lik_scale / B) * tot);
+}
+
 /* Synthetic logistic-regression table, element (r, c) a pure function of (seed, r, c) so that any
  * shard can be regenerated (mirrors examples/logistic_regression.py:88-104 in
  * distribution): X[r][c] = normal from threefry2x32((seed, 0x58), (r, c))[0];

@@ -60,6 +60,7 @@ def lib():
         _lib.d3po_gamma_grad.argtypes = [C.c_double, C.c_double]
         _lib.d3po_gamma_sample.restype = C.c_double
         _lib.d3po_gmm_px_loss_grad_given.restype = C.c_float
+        _lib.d3po_gmm_evaluate.restype = C.c_float
     return _lib
 
 
@@ -438,3 +439,9 @@ def gmm_px_grads(spec, params, Xb, jax_key, mask=None):
     n = lib().d3po_gmm_px_grads(C.byref(spec), _p(_f32(params)), _p(_f32(Xb)), None if m is None else _p(m), C.c_int(B),
                                 _p(_u32(jax_key)), _p(px_loss), _p(px_grads), C.byref(factor))
     return px_loss, px_grads, n, factor.value
+
+
+def gmm_evaluate(spec, params, Xb, jax_key):
+    """DPSVI.evaluate for the mixture model; jax_key = convert(split(state.rng_key, 1)[0])."""
+    Xb = _f32(Xb)
+    return float(lib().d3po_gmm_evaluate(C.byref(spec), _p(_f32(params)), _p(Xb), C.c_int(Xb.shape[0]), _p(_u32(jax_key))))

@@ -33,3 +33,15 @@ def test_simple_gaussian_posterior_example_recovers_the_mean(gpu):
     # 3000 noisy, clipped steps from mu_loc = 0: the mean has moved most of the way to 1 and the scale shrank
     assert float((mu_loc - a_loc).abs().max()) < 0.35
     assert float(mu_std.max()) < 1.0
+
+
+def test_gaussian_mixture_example_separates_the_clusters(gpu):
+    """BASELINE config 3's example end to end (Poisson batches + mask, update, evaluate, get_params)."""
+    spec = importlib.util.spec_from_file_location("ex_gmm", os.path.join(ROOT, "examples", "gaussian_mixture_model.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    args = argparse.Namespace(num_epochs=12, learning_rate=5e-2, batch_size=64, dimensions=2, num_samples=2048,
+                              num_components=3, sigma=0.3)
+    acc, pis, modes = mod.main(args)
+    assert acc > 0.9
+    assert abs(float(pis.sum()) - 1.0) < 1e-5

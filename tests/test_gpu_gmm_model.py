@@ -156,3 +156,16 @@ def test_run_steps_walks_the_update_trajectory(rng):
         assert abs(float(l) - float(losses[t])) <= 1e-6 * abs(float(l))
     assert torch.equal(ref.rng_key, new_st.rng_key) and int(new_st.optim_state[0]) == steps
     assert torch.equal(ref.optim_state[1], new_st.optim_state[1])
+
+
+@pytest.mark.parametrize("B,K,d", [(50, 16, 64), (17, 3, 2), (300, 5, 70)])
+def test_evaluate_vs_oracle(rng, O, B, K, d):
+    N = 10**4
+    X, params = problem(B, K, d, 9)
+    svi = make_svi(K, d, N)
+    st = state_with(svi, rng.PRNGKey(99), params, N)
+    got = float(svi.evaluate(st, torch.tensor(X).cuda()))
+    spec = O.gmm_spec(K, d, 10.0, lik_scale=N, obs_scale=1.0)
+    jax_key = O.convert_to_jax_rng_key(O.split(O.PRNGKey(99), 1)[0])
+    exp = O.gmm_evaluate(spec, params, X, jax_key)
+    assert abs(got - exp) <= 2e-5 * abs(exp)
