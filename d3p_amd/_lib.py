@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libd3p_hip.so")
-_SRC = [os.path.join(_HERE, "csrc", f) for f in ("d3p_rng.hip", "d3p_dpvi.hip", "d3p_stages.hip", "d3p_gmm.hip")]
+_SRC = [os.path.join(_HERE, "csrc", f) for f in ("d3p_rng.hip", "d3p_dpvi.hip", "d3p_stages.hip", "d3p_gmm.hip", "d3p_vae.hip")]
 _DEPS = _SRC + [os.path.join(_HERE, "csrc", f) for f in ("d3p_device.h", "d3p_host.h", "d3p_logreg_kernel.h")] + [
     os.path.join(os.path.dirname(_HERE), "include", "d3p_hip.h")]
 
@@ -32,6 +32,10 @@ class LogregModel(C.Structure):
 class GmmModel(C.Structure):
     _fields_ = [("K", C.c_int32), ("d", C.c_int32), ("prior_mu_scale", C.c_float), ("lik_scale", C.c_float),
                 ("inv_obs", C.c_float)]
+
+
+class VaeModel(C.Structure):
+    _fields_ = [("D", C.c_int32), ("H", C.c_int32), ("Z", C.c_int32), ("scale", C.c_float), ("inv_obs", C.c_float)]
 
 
 class DpsviHyper(C.Structure):
@@ -109,6 +113,11 @@ SIGNATURES = {
     "d3p_dpvi_gmm_update": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_gmm_run": (C.c_int, [_V, _V, _V, _V, _V, _U32, _V, _U32, _U32, _U32, _V, _V, C.c_size_t]),
     "d3p_gmm_px_grads": (C.c_int, [_V, _V, _V, _V, _V, _U32, _V, _V, _V, _V, _V, _V, C.c_size_t]),
+    "d3p_vae_num_params": (C.c_int64, [_V]),
+    "d3p_dpvi_vae_workspace": (C.c_size_t, [_V, _U32]),
+    "d3p_gemm_f32": (C.c_int, [_V, _V, C.c_int64, C.c_int64, _V, C.c_int64, C.c_int64, _V, _I32, _I32, _I32, _I32, _V, _F, _I32]),
+    "d3p_vae_step_sums": (C.c_int, [_V, _V, _V, _V, _V, _U32, _V, _V, _F, _V, _V, _V, _V, C.c_size_t]),
+    "d3p_dpvi_vae_update": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _V, _V, _V, _V, C.c_size_t]),
     "d3p_adadp_workspace": (C.c_size_t, []),
     "d3p_adadp_step": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _U32, _F, C.c_int, _V, C.c_size_t]),
     "d3p_dpvi_logreg_workspace": (_SZ, [_PM, _PB]),

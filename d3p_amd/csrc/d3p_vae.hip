@@ -1,0 +1,520 @@
+// DP-VI step for the variational auto-encoder of BASELINE config 5 (examples/vae.py:65-153): the one place on the
+// path where the model forward is a dense layer stack, so the per-example gradient work is GEMM-shaped and runs on
+// the matrix cores (fp32 MFMA, v_mfma_f32_32x32x2_f32; the reference computes in float32 throughout).
+//
+// The B x P per-example gradient tensor (P = 688 884) is never formed:
+//   * a dense layer y = a W + b has per-example gradients  dW_i = a_i d_i^T, db_i = d_i, so
+//     ||dW_i||_F^2 + ||db_i||^2 = (||a_i||^2 + 1) ||d_i||^2   -> the joint L2 norm needs only row norms;
+//   * the clipped sum  sum_i c_i a_i d_i^T = A^T (diag(c) Delta)  is one GEMM per layer.
+// Forward and backward-data passes are batched GEMMs over the B examples; activations, the reparametrised latent,
+// the Bernoulli likelihood and the clip factors are small row-wise kernels in between.
+// Formulas: oracle/d3p_oracle.c (d3po_vae_step_sums), which materialises every per-example gradient as the check.
+#include "d3p_device.h"
+#include "d3p_host.h"
+#include "d3p_logreg_kernel.h"  // px_sample_key
+
+namespace d3p {
+
+static inline size_t align_up_v(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// C[M x N] = alpha * sum_k A(m, k) B(k, n) (+ bias[n]) (+ C),  A(m, k) = A[m * a_sm + k * a_sk], B(k, n) = B[k * b_sk + n * b_sn]
+// (element strides cover NN / NT / TN), C row-major with leading dimension ldc.
+// Workgroup = 4 wavefronts (2 x 2), tile 64 x 64, K in slices of 16 staged through LDS; every wavefront owns a 32 x 32
+// accumulator = 16 VGPRs of v_mfma_f32_32x32x2_f32 (lane l: A row / B column l % 32, k = l / 32; D[i][j] with
+// j = l % 32, i = 8 (v / 4) + 4 (l / 32) + v % 4).
+// ------------------------------------------------------------------------------------------------------------------
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;  // nullable, length N
+    int M, N, K;
+    long long a_sm, a_sk, b_sk, b_sn;
+    int ldc;
+    float alpha;
+    int accumulate;
+};
+
+#define D3P_GT 64  // tile edge
+#define D3P_GK 16  // K slice
+
+__global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
+{
+    __shared__ float As[D3P_GK][D3P_GT + 4];  // [k][m]
+    __shared__ float Bs[D3P_GK][D3P_GT + 4];  // [k][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * D3P_GT, n0 = blockIdx.x * D3P_GT;
+    float16v acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    // staging maps: the unit-stride dimension of each operand runs along consecutive threads
+    const bool a_kfast = g.a_sk == 1, b_nfast = g.b_sn == 1;
+    for (int k0 = 0; k0 < g.K; k0 += D3P_GK) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + 256 * r;  // 0 .. 1023
+            int am, ak, bk, bn;
+            if (a_kfast) { ak = e & 15; am = e >> 4; } else { am = e & 63; ak = e >> 6; }
+            if (b_nfast) { bn = e & 63; bk = e >> 6; } else { bk = e & 15; bn = e >> 4; }
+            const int gm = m0 + am, gka = k0 + ak, gkb = k0 + bk, gn = n0 + bn;
+            As[ak][am] = (gm < g.M && gka < g.K) ? g.A[(long long)gm * g.a_sm + (long long)gka * g.a_sk] : 0.f;
+            Bs[bk][bn] = (gkb < g.K && gn < g.N) ? g.B[(long long)gkb * g.b_sk + (long long)gn * g.b_sn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < D3P_GK; kk += 2) {
+            const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
+            const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col < g.N) {
+        const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = m0 + wm * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+            if (row < g.M) {
+                float* c = g.C + (size_t)row * g.ldc + col;
+                float o = __fmaf_rn(g.alpha, acc[v], bv);
+                if (g.accumulate) o += *c;
+                *c = o;
+            }
+        }
+    }
+}
+
+static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, const float* B, long long b_sk, long long b_sn,
+                float* C, int ldc, int M, int N, int K, const float* bias, float alpha, int accumulate)
+{
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias;
+    g.M = M; g.N = N; g.K = K;
+    g.a_sm = a_sm; g.a_sk = a_sk; g.b_sk = b_sk; g.b_sn = b_sn;
+    g.ldc = ldc; g.alpha = alpha; g.accumulate = accumulate;
+    hipLaunchKernelGGL(k_gemm_f32, dim3(cdiv(N, D3P_GT), cdiv(M, D3P_GT)), dim3(256), 0, s, g);
+    return check_launch("k_gemm_f32");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// row-wise / element-wise stages
+// ------------------------------------------------------------------------------------------------------------------
+// pre (B x H, bias already added) -> h = softplus(pre) in place, sg = sigmoid(pre) (softplus')
+__global__ void k_vae_softplus(float* __restrict__ h, float* __restrict__ sg, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float t = h[i];
+    h[i] = fmaxf(t, 0.0f) + log1pf(expf(-fabsf(t)));
+    sg[i] = 1.0f / (1.0f + expf(-t));
+}
+
+// per-example guide noise: eps[i][j] = normal word j of the example's sample key (svi.py:289-290; single site 'z')
+__global__ void k_vae_eps(const uint32_t* __restrict__ jax_key, uint32_t B, int Z, float* __restrict__ eps)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)B * Z) return;
+    const uint32_t i = (uint32_t)(t / Z), j = (uint32_t)(t % Z);
+    uint32_t k0, k1;
+    px_sample_key(jax_key[0], jax_key[1], B, i, k0, k1);
+    eps[t] = bits_to_normal(tf_iota_word(k0, k1, (uint64_t)Z, (uint64_t)j));
+}
+
+// zl, u (B x Z), eps -> z = zl + exp(u) eps (written over zl), sd = exp(u) (written over u), lat[i] = log q - log p
+__global__ void k_vae_latent(float* __restrict__ zl, float* __restrict__ u, const float* __restrict__ eps, uint32_t B, int Z,
+                             float* __restrict__ lat)
+{
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= B) return;
+    float acc = 0.f;
+    for (int j = lane; j < Z; j += 64) {
+        const size_t e = (size_t)i * Z + j;
+        const float uu = u[e], ee = eps[e];
+        const float sd = expf(uu), z = __fmaf_rn(sd, ee, zl[e]);
+        zl[e] = z;
+        u[e] = sd;
+        acc += (-0.5f * ee * ee - uu) + 0.5f * z * z;  // the log(2 pi) / 2 terms of log q and log p cancel
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) lat[i] = acc;
+}
+
+// logits a (B x D), x -> da = sc (sigmoid(a) - x) in place; px_loss[i] = sc (lat_i - sum_j (x a - softplus(a))) mask_i
+__global__ void k_vae_out(float* __restrict__ a, const float* __restrict__ X, const uint8_t* __restrict__ mask, uint32_t B, int D,
+                          float sc, const float* __restrict__ lat, float* __restrict__ px_loss)
+{
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= B) return;
+    float ll = 0.f;
+    for (int j = lane; j < D; j += 64) {
+        const size_t e = (size_t)i * D + j;
+        const float t = a[e], x = X[e];
+        ll += x * t - (fmaxf(t, 0.0f) + log1pf(expf(-fabsf(t))));
+        a[e] = sc * (1.0f / (1.0f + expf(-t)) - x);
+    }
+    ll = wave_sum(ll);
+    if (lane == 0) px_loss[i] = (mask && mask[i] == 0) ? 0.f : sc * (lat[i] - ll);
+}
+
+// d *= sg   (delta through a softplus layer)
+__global__ void k_vae_mul(float* __restrict__ d, const float* __restrict__ sg, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] *= sg[i];
+}
+
+// dzraw (B x Z) = dpre2 V1^T  ->  dz = dzraw + sc z,  du = dz sd eps - sc
+__global__ void k_vae_dlatent(float* __restrict__ dz, float* __restrict__ du, const float* __restrict__ z,
+                              const float* __restrict__ sd, const float* __restrict__ eps, size_t n, float sc)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float t = __fmaf_rn(sc, z[i], dz[i]);
+    dz[i] = t;
+    du[i] = t * sd[i] * eps[i] - sc;
+}
+
+__device__ __forceinline__ float row_sumsq(const float* __restrict__ r, int n, int lane)
+{
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s = __fmaf_rn(r[j], r[j], s);
+    return wave_sum(s);
+}
+
+// joint L2 norm of every example's gradient by the outer-product identity, clip factor c_i (0 for masked rows)
+struct NormArgs {
+    const float *X, *h1, *z, *h2;            // layer inputs
+    const float *dpre1, *dz, *du, *dpre2, *da;  // layer deltas
+    const uint8_t* mask;
+    uint32_t B;
+    int D, H, Z;
+    float clip;
+    float* cf;
+    float* norms;  // nullable
+};
+
+__global__ void k_vae_norms(NormArgs a)
+{
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= a.B) return;
+    const float x2 = row_sumsq(a.X + (size_t)i * a.D, a.D, lane), h12 = row_sumsq(a.h1 + (size_t)i * a.H, a.H, lane);
+    const float z2 = row_sumsq(a.z + (size_t)i * a.Z, a.Z, lane), h22 = row_sumsq(a.h2 + (size_t)i * a.H, a.H, lane);
+    const float d1 = row_sumsq(a.dpre1 + (size_t)i * a.H, a.H, lane), dz = row_sumsq(a.dz + (size_t)i * a.Z, a.Z, lane);
+    const float du = row_sumsq(a.du + (size_t)i * a.Z, a.Z, lane), d2 = row_sumsq(a.dpre2 + (size_t)i * a.H, a.H, lane);
+    const float da = row_sumsq(a.da + (size_t)i * a.D, a.D, lane);
+    const float n2 = (h22 + 1.0f) * da + (z2 + 1.0f) * d2 + (h12 + 1.0f) * (dz + du) + (x2 + 1.0f) * d1;
+    const float nrm = sqrtf(n2);
+    const bool live = !(a.mask && a.mask[i] == 0);
+    if (lane == 0) {
+        a.cf[i] = live ? 1.0f / fmaxf(1.0f, nrm / a.clip) : 0.f;  // svi.py:121-122; masked rows contribute nothing
+        if (a.norms) a.norms[i] = live ? nrm : 0.f;
+    }
+}
+
+// rows of d (B x n) scaled by cf[i]
+__global__ void k_vae_scale_rows(float* __restrict__ d, const float* __restrict__ cf, uint32_t B, int n)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)B * n) return;
+    d[t] *= cf[t / n];
+}
+
+// out[j] = sum_i d[i][j]  (bias gradients), fixed order: 64 columns x 4 row groups per workgroup
+__global__ void __launch_bounds__(256) k_vae_colsum(const float* __restrict__ d, uint32_t B, int n, float* __restrict__ out)
+{
+    __shared__ float lds[256];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (col < n)
+        for (uint32_t r = rg; r < B; r += 4) s += d[(size_t)r * n + col];
+    lds[threadIdx.x] = s;
+    __syncthreads();
+    if (rg == 0 && col < n) out[col] = (lds[c] + lds[64 + c]) + (lds[128 + c] + lds[192 + c]);
+}
+
+// sums[P] = sum_i px_loss[i], sums[P + 1] = number of unmasked examples (one workgroup, fixed order)
+__global__ void __launch_bounds__(256) k_vae_loss_n(const float* __restrict__ px_loss, const uint8_t* __restrict__ mask, uint32_t B,
+                                                    float* __restrict__ out)
+{
+    __shared__ float l[256], c[256];
+    float s = 0.f, n = 0.f;
+    for (uint32_t i = threadIdx.x; i < B; i += 256) {
+        s += px_loss[i];
+        n += (mask && mask[i] == 0) ? 0.f : 1.f;
+    }
+    l[threadIdx.x] = s;
+    c[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { l[threadIdx.x] += l[threadIdx.x + off]; c[threadIdx.x] += c[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = l[0]; out[1] = c[0]; }
+}
+
+// mean, Gaussian mechanism, rescale (svi.py:343-346, :365-375), numpyro Adam (svi.py:379-393) over the P parameters
+struct VaeFinalArgs {
+    const float* sums;  // P + 2
+    const float* noise;
+    float* params;
+    float* adam_m;
+    float* adam_v;
+    const int32_t* step;
+    float* loss_out;
+    float* grad_out;
+    size_t P;
+    uint32_t B;
+    d3p_dpsvi_hyper h;
+    float obs_scale;
+};
+
+__global__ void k_vae_finalize(VaeFinalArgs a)
+{
+    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float n = a.sums[a.P + 1], Bf = (float)a.B;
+    const float factor = (n == 0.f) ? 0.f : Bf / n;
+    if (col == 0 && a.loss_out) *a.loss_out = (a.sums[a.P] / Bf) * a.obs_scale * factor;
+    if (col >= a.P) return;
+    const float g = (a.sums[col] / Bf + a.noise[col] * (a.h.dp_scale * (a.h.clip / n))) * a.obs_scale * factor;
+    if (a.grad_out) a.grad_out[col] = g;
+    const int i = *a.step;
+    float m = a.adam_m[col], v = a.adam_v[col];
+    m = (1.0f - a.h.b1) * g + a.h.b1 * m;
+    v = (1.0f - a.h.b2) * g * g + a.h.b2 * v;
+    const float mhat = m / (1.0f - powf(a.h.b1, (float)(i + 1)));
+    const float vhat = v / (1.0f - powf(a.h.b2, (float)(i + 1)));
+    a.params[col] -= a.h.lr * mhat / (sqrtf(vhat) + a.h.adam_eps);
+    a.adam_m[col] = m;
+    a.adam_v[col] = v;
+}
+
+__global__ void k_vae_incr(int32_t* step) { *step += 1; }
+
+struct VaeLayout {  // offsets of the 10 leaves in tree_flatten order
+    size_t V1, c1, V2, c2, W1, b1, Wl, bl, Ws, bs, P;
+};
+
+static VaeLayout vae_layout(const d3p_vae_model* m)
+{
+    const size_t D = (size_t)m->D, H = (size_t)m->H, Z = (size_t)m->Z;
+    VaeLayout l;
+    l.V1 = 0;
+    l.c1 = l.V1 + Z * H;
+    l.V2 = l.c1 + H;
+    l.c2 = l.V2 + H * D;
+    l.W1 = l.c2 + D;
+    l.b1 = l.W1 + D * H;
+    l.Wl = l.b1 + H;
+    l.bl = l.Wl + H * Z;
+    l.Ws = l.bl + Z;
+    l.bs = l.Ws + H * Z;
+    l.P = l.bs + Z;
+    return l;
+}
+
+struct VaeWorkspace {
+    float *h1, *sg1, *zl, *u, *eps, *h2, *sg2, *a, *dh2, *dz, *du, *dh1;
+    float *lat, *px_loss, *cf, *sums, *noise;
+    uint32_t* keys;  // 3 x 16 split + 10 x 16 site keys + jax key
+};
+
+static size_t vae_carve(const d3p_vae_model* m, uint32_t B, char* base, VaeWorkspace* ws)
+{
+    const size_t D = (size_t)m->D, H = (size_t)m->H, Z = (size_t)m->Z, P = vae_layout(m).P;
+    size_t off = 0;
+    auto take = [&](size_t n_floats) { size_t o = off; off += align_up_v(n_floats * sizeof(float), 256); return base ? (float*)(base + o) : nullptr; };
+    float* q;
+    q = take(B * H); if (ws) ws->h1 = q;
+    q = take(B * H); if (ws) ws->sg1 = q;
+    q = take(B * Z); if (ws) ws->zl = q;
+    q = take(B * Z); if (ws) ws->u = q;
+    q = take(B * Z); if (ws) ws->eps = q;
+    q = take(B * H); if (ws) ws->h2 = q;
+    q = take(B * H); if (ws) ws->sg2 = q;
+    q = take(B * D); if (ws) ws->a = q;
+    q = take(B * H); if (ws) ws->dh2 = q;
+    q = take(B * Z); if (ws) ws->dz = q;
+    q = take(B * Z); if (ws) ws->du = q;
+    q = take(B * H); if (ws) ws->dh1 = q;
+    q = take(B); if (ws) ws->lat = q;
+    q = take(B); if (ws) ws->px_loss = q;
+    q = take(B); if (ws) ws->cf = q;
+    q = take(P + 2); if (ws) ws->sums = q;
+    q = take(P); if (ws) ws->noise = q;
+    q = take(13 * 16 + 2); if (ws) ws->keys = (uint32_t*)q;
+    return off;
+}
+
+static int vae_validate(const d3p_vae_model* m, const char* what)
+{
+    if (!m) return fail(D3P_E_INVALID_ARG, "%s: null model", what);
+    if (!(m->D >= 1 && m->H >= 1 && m->Z >= 1 && m->scale > 0.f && m->inv_obs > 0.f))
+        return fail(D3P_E_INVALID_ARG, "%s: bad model (D, H, Z >= 1, scale > 0, inv_obs > 0)", what);
+    return D3P_OK;
+}
+
+// forward + backward + norms + clipped sums into ws.sums[P + 2]; eps_dev given or drawn from jax_key
+static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* params, const float* X, const uint8_t* mask,
+                            uint32_t B, const float* eps_ext, const uint32_t* jax_key, float clip, const VaeWorkspace& ws,
+                            float* norms_out)
+{
+    int rc;
+    const int D = m->D, H = m->H, Z = m->Z, Bi = (int)B;
+    const VaeLayout L = vae_layout(m);
+    const float sc = m->inv_obs * m->scale;
+    const float* eps = eps_ext;
+    if (!eps) {
+        hipLaunchKernelGGL(k_vae_eps, dim3(cdiv((uint64_t)B * Z, 256)), dim3(256), 0, s, jax_key, B, Z, ws.eps);
+        eps = ws.eps;
+    }
+    auto ew = [&](size_t n) { return dim3(cdiv(n, 256)); };
+    const dim3 rows(cdiv((uint64_t)B * 64, 256));
+    // ---- encoder (guide)
+    if ((rc = gemm(s, X, D, 1, params + L.W1, H, 1, ws.h1, H, Bi, H, D, params + L.b1, 1.f, 0))) return rc;
+    hipLaunchKernelGGL(k_vae_softplus, ew((size_t)B * H), dim3(256), 0, s, ws.h1, ws.sg1, (size_t)B * H);
+    if ((rc = gemm(s, ws.h1, H, 1, params + L.Wl, Z, 1, ws.zl, Z, Bi, Z, H, params + L.bl, 1.f, 0))) return rc;
+    if ((rc = gemm(s, ws.h1, H, 1, params + L.Ws, Z, 1, ws.u, Z, Bi, Z, H, params + L.bs, 1.f, 0))) return rc;
+    hipLaunchKernelGGL(k_vae_latent, rows, dim3(256), 0, s, ws.zl, ws.u, eps, B, Z, ws.lat);  // zl := z, u := sd
+    // ---- decoder (model)
+    if ((rc = gemm(s, ws.zl, Z, 1, params + L.V1, H, 1, ws.h2, H, Bi, H, Z, params + L.c1, 1.f, 0))) return rc;
+    hipLaunchKernelGGL(k_vae_softplus, ew((size_t)B * H), dim3(256), 0, s, ws.h2, ws.sg2, (size_t)B * H);
+    if ((rc = gemm(s, ws.h2, H, 1, params + L.V2, D, 1, ws.a, D, Bi, D, H, params + L.c2, 1.f, 0))) return rc;
+    hipLaunchKernelGGL(k_vae_out, rows, dim3(256), 0, s, ws.a, X, mask, B, D, sc, (const float*)ws.lat, ws.px_loss);  // a := da
+    // ---- backward (data)
+    if ((rc = gemm(s, ws.a, D, 1, params + L.V2, 1, D, ws.dh2, H, Bi, H, D, nullptr, 1.f, 0))) return rc;  // da V2^T
+    hipLaunchKernelGGL(k_vae_mul, ew((size_t)B * H), dim3(256), 0, s, ws.dh2, (const float*)ws.sg2, (size_t)B * H);  // dpre2
+    if ((rc = gemm(s, ws.dh2, H, 1, params + L.V1, 1, H, ws.dz, Z, Bi, Z, H, nullptr, 1.f, 0))) return rc;  // dpre2 V1^T
+    hipLaunchKernelGGL(k_vae_dlatent, ew((size_t)B * Z), dim3(256), 0, s, ws.dz, ws.du, (const float*)ws.zl, (const float*)ws.u, eps,
+                       (size_t)B * Z, sc);
+    if ((rc = gemm(s, ws.dz, Z, 1, params + L.Wl, 1, Z, ws.dh1, H, Bi, H, Z, nullptr, 1.f, 0))) return rc;  // dz Wl^T
+    if ((rc = gemm(s, ws.du, Z, 1, params + L.Ws, 1, Z, ws.dh1, H, Bi, H, Z, nullptr, 1.f, 1))) return rc;  // + du Ws^T
+    hipLaunchKernelGGL(k_vae_mul, ew((size_t)B * H), dim3(256), 0, s, ws.dh1, (const float*)ws.sg1, (size_t)B * H);  // dpre1
+    // ---- per-example norms and clip factors, rows of every delta scaled by c_i
+    NormArgs na;
+    na.X = X; na.h1 = ws.h1; na.z = ws.zl; na.h2 = ws.h2;
+    na.dpre1 = ws.dh1; na.dz = ws.dz; na.du = ws.du; na.dpre2 = ws.dh2; na.da = ws.a;
+    na.mask = mask; na.B = B; na.D = D; na.H = H; na.Z = Z; na.clip = clip; na.cf = ws.cf; na.norms = norms_out;
+    hipLaunchKernelGGL(k_vae_norms, rows, dim3(256), 0, s, na);
+    hipLaunchKernelGGL(k_vae_scale_rows, ew((size_t)B * D), dim3(256), 0, s, ws.a, (const float*)ws.cf, B, D);
+    hipLaunchKernelGGL(k_vae_scale_rows, ew((size_t)B * H), dim3(256), 0, s, ws.dh2, (const float*)ws.cf, B, H);
+    hipLaunchKernelGGL(k_vae_scale_rows, ew((size_t)B * Z), dim3(256), 0, s, ws.dz, (const float*)ws.cf, B, Z);
+    hipLaunchKernelGGL(k_vae_scale_rows, ew((size_t)B * Z), dim3(256), 0, s, ws.du, (const float*)ws.cf, B, Z);
+    hipLaunchKernelGGL(k_vae_scale_rows, ew((size_t)B * H), dim3(256), 0, s, ws.dh1, (const float*)ws.cf, B, H);
+    // ---- clipped sums: weights  A^T (diag(c) Delta)  (GEMMs over the batch), biases = column sums
+    float* S = ws.sums;
+    if ((rc = gemm(s, ws.zl, 1, Z, ws.dh2, H, 1, S + L.V1, H, Z, H, Bi, nullptr, 1.f, 0))) return rc;
+    hipLaunchKernelGGL(k_vae_colsum, dim3(cdiv(H, 64)), dim3(256), 0, s, (const float*)ws.dh2, B, H, S + L.c1);
+    if ((rc = gemm(s, ws.h2, 1, H, ws.a, D, 1, S + L.V2, D, H, D, Bi, nullptr, 1.f, 0))) return rc;
+    hipLaunchKernelGGL(k_vae_colsum, dim3(cdiv(D, 64)), dim3(256), 0, s, (const float*)ws.a, B, D, S + L.c2);
+    if ((rc = gemm(s, X, 1, D, ws.dh1, H, 1, S + L.W1, H, D, H, Bi, nullptr, 1.f, 0))) return rc;
+    hipLaunchKernelGGL(k_vae_colsum, dim3(cdiv(H, 64)), dim3(256), 0, s, (const float*)ws.dh1, B, H, S + L.b1);
+    if ((rc = gemm(s, ws.h1, 1, H, ws.dz, Z, 1, S + L.Wl, Z, H, Z, Bi, nullptr, 1.f, 0))) return rc;
+    hipLaunchKernelGGL(k_vae_colsum, dim3(cdiv(Z, 64)), dim3(256), 0, s, (const float*)ws.dz, B, Z, S + L.bl);
+    if ((rc = gemm(s, ws.h1, 1, H, ws.du, Z, 1, S + L.Ws, Z, H, Z, Bi, nullptr, 1.f, 0))) return rc;
+    hipLaunchKernelGGL(k_vae_colsum, dim3(cdiv(Z, 64)), dim3(256), 0, s, (const float*)ws.du, B, Z, S + L.bs);
+    hipLaunchKernelGGL(k_vae_loss_n, dim3(1), dim3(256), 0, s, (const float*)ws.px_loss, mask, B, S + L.P);
+    return check_launch("d3p_vae sums");
+}
+
+}  // namespace d3p
+
+using namespace d3p;
+
+extern "C" {
+
+// C = alpha op(A) op(B) (+ bias) (+ C) on the matrix cores; exported so the GEMM can be tested on its own.
+int d3p_gemm_f32(void* stream, const float* A_dev, int64_t a_sm, int64_t a_sk, const float* B_dev, int64_t b_sk, int64_t b_sn,
+                 float* C_dev, int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias_dev, float alpha, int32_t accumulate)
+{
+    D3P_REQUIRE(A_dev && B_dev && C_dev, "d3p_gemm_f32: null pointer");
+    D3P_REQUIRE(M >= 1 && N >= 1 && K >= 1 && ldc >= N, "d3p_gemm_f32: bad shape");
+    return gemm((hipStream_t)stream, A_dev, a_sm, a_sk, B_dev, b_sk, b_sn, C_dev, ldc, M, N, K, bias_dev, alpha, accumulate);
+}
+
+int64_t d3p_vae_num_params(const d3p_vae_model* model)
+{
+    if (!model || model->D < 1 || model->H < 1 || model->Z < 1) return 0;
+    return (int64_t)vae_layout(model).P;
+}
+
+size_t d3p_dpvi_vae_workspace(const d3p_vae_model* model, uint32_t B)
+{
+    if (!model || model->D < 1 || model->H < 1 || model->Z < 1) return 0;
+    return vae_carve(model, B, nullptr, nullptr);
+}
+
+int d3p_vae_step_sums(void* stream, const d3p_vae_model* model, const float* params_dev, const float* X_dev, const uint8_t* mask_dev,
+                      uint32_t B, const float* eps_dev, const uint32_t* jax_key_dev, float clip, float* sums_dev, float* norms_dev,
+                      float* px_loss_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    if (int rc = vae_validate(model, "d3p_vae_step_sums")) return rc;
+    D3P_REQUIRE(params_dev && X_dev && sums_dev && workspace_dev && (eps_dev || jax_key_dev), "d3p_vae_step_sums: null pointer");
+    D3P_REQUIRE(B >= 1 && clip > 0.f, "d3p_vae_step_sums: B >= 1 and clip > 0 required");
+    if (workspace_bytes < d3p_dpvi_vae_workspace(model, B)) return fail(D3P_E_WORKSPACE, "d3p_vae_step_sums: workspace too small");
+    VaeWorkspace ws;
+    vae_carve(model, B, (char*)workspace_dev, &ws);
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = vae_enqueue_sums(s, model, params_dev, X_dev, mask_dev, B, eps_dev, jax_key_dev, clip, ws, norms_dev)) return rc;
+    const size_t P = vae_layout(model).P;
+    D3P_HIP_TRY(hipMemcpyAsync(sums_dev, ws.sums, (P + 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (px_loss_dev) D3P_HIP_TRY(hipMemcpyAsync(px_loss_dev, ws.px_loss, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return D3P_OK;
+}
+
+int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                        const float* X_dev, const uint8_t* mask_dev, uint32_t B, const float* eps_dev, float* loss_dev,
+                        float* grad_out_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    if (int rc = vae_validate(model, "d3p_dpvi_vae_update")) return rc;
+    D3P_REQUIRE(hyper && state && state->rng_key && state->params && state->adam_m && state->adam_v && state->step && X_dev &&
+                    workspace_dev,
+                "d3p_dpvi_vae_update: null pointer");
+    if (!(hyper->clip > 0.f) || !std::isfinite(hyper->clip))
+        return fail(D3P_E_INVALID_ARG, "d3p_dpvi_vae_update: the clipping threshold must be finite and greater than 0");
+    D3P_REQUIRE(B >= 1, "d3p_dpvi_vae_update: B must be >= 1");
+    if (workspace_bytes < d3p_dpvi_vae_workspace(model, B)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_update: workspace too small");
+    VaeWorkspace ws;
+    vae_carve(model, B, (char*)workspace_dev, &ws);
+    hipStream_t s = (hipStream_t)stream;
+    const VaeLayout L = vae_layout(model);
+    const int slot = state->key_slot & 1;
+    uint32_t* split3 = ws.keys;           // [next | gradient | perturbation]  (svi.py:208-211)
+    uint32_t* site_keys = ws.keys + 48;   // split(perturbation_key, 10)        (svi.py:491)
+    uint32_t* jax_key = ws.keys + 208;    // convert_to_jax_rng_key(gradient_key)
+    int rc;
+    if ((rc = d3p_rng_split(s, state->rng_key + 16 * slot, 3, split3))) return rc;
+    if ((rc = d3p_rng_random_bits(s, split3 + 16, 32, 2, jax_key))) return rc;
+    if ((rc = d3p_rng_split(s, split3 + 32, 10, site_keys))) return rc;
+    const size_t leaf_off[11] = {L.V1, L.c1, L.V2, L.c2, L.W1, L.b1, L.Wl, L.bl, L.Ws, L.bs, L.P};
+    for (int k = 0; k < 10; ++k)  // one key per leaf, normal(site_key, leaf shape) (svi.py:487)
+        if ((rc = d3p_rng_normal(s, site_keys + 16 * k, (uint64_t)(leaf_off[k + 1] - leaf_off[k]), ws.noise + leaf_off[k]))) return rc;
+    if ((rc = vae_enqueue_sums(s, model, state->params, X_dev, mask_dev, B, eps_dev, jax_key, hyper->clip, ws, nullptr))) return rc;
+    VaeFinalArgs f;
+    f.sums = ws.sums;
+    f.noise = ws.noise;
+    f.params = state->params;
+    f.adam_m = state->adam_m;
+    f.adam_v = state->adam_v;
+    f.step = state->step;
+    f.loss_out = loss_dev;
+    f.grad_out = grad_out_dev;
+    f.P = L.P;
+    f.B = B;
+    f.h = *hyper;
+    f.obs_scale = 1.0f / model->inv_obs;
+    hipLaunchKernelGGL(k_vae_finalize, dim3(cdiv(L.P, 256)), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(k_vae_incr, dim3(1), dim3(1), 0, s, state->step);
+    D3P_HIP_TRY(hipMemcpyAsync(state->rng_key + 16 * (slot ^ 1), split3, 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    return check_launch("d3p_dpvi_vae_update");
+}
+
+}  // extern "C"

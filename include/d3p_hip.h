@@ -387,6 +387,43 @@ int d3p_dpvi_gmm_run(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_h
                      const float* X_dev, uint32_t n_rows, uint32_t B, uint32_t num_steps, float* losses_dev,
                      void* workspace_dev, size_t workspace_bytes);
 
+/* ---------------------------------------------------------------------------------------------
+ * Variational auto-encoder of BASELINE config 5 (examples/vae.py:65-153) -- the GEMM-shaped model on the path.
+ * encoder: h1 = softplus(x W1 + b1), z_loc = h1 Wl + bl, z_std = exp(h1 Ws + bs);  decoder: h2 = softplus(z V1 + c1),
+ * obs ~ Bernoulli(sigmoid(h2 V2 + c2)).  Parameter vector = leaves of {'decoder$params', 'encoder$params'} in
+ * tree_flatten order: V1 (Z x H), c1 (H), V2 (H x D), c2 (D), W1 (D x H), b1 (H), Wl (H x Z), bl (Z), Ws (H x Z), bs (Z).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t D, H, Z;  /* observation, hidden and latent dimension (784, 400, 50) */
+    float scale;      /* scale of every site: plate scale x handlers.scale (vae.py:194-195 -> 1) */
+    float inv_obs;    /* 1 / observation_scale (svi.py:278) */
+} d3p_vae_model;
+
+int64_t d3p_vae_num_params(const d3p_vae_model* model);
+size_t d3p_dpvi_vae_workspace(const d3p_vae_model* model, uint32_t B);
+
+/* fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32): C[M x N] = alpha * op(A) op(B) (+ bias[n]) (+ C) with element
+ * strides A(m, k) = A[m a_sm + k a_sk], B(k, n) = B[k b_sk + n b_sn]; C row-major, leading dimension ldc. */
+int d3p_gemm_f32(void* stream, const float* A_dev, int64_t a_sm, int64_t a_sk, const float* B_dev, int64_t b_sk,
+                 int64_t b_sn, float* C_dev, int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias_dev,
+                 float alpha, int32_t accumulate);
+
+/* Stages 1-3 of DPSVI.update fused (svi.py:238-348): sums_dev[P + 2] = [sum_i c_i g_i | sum_i loss_i | n] without ever
+ * forming a per-example gradient: norms by ||a d^T||_F = ||a|| ||d||, clipped sums as A^T (diag(c) Delta) GEMMs.
+ * eps_dev (B x Z, optional parity-mode noise) or jax_key_dev (per-example threefry keys, svi.py:289-290).
+ * norms_dev (B, optional): per-example gradient norms before clipping; px_loss_dev (B, optional). */
+int d3p_vae_step_sums(void* stream, const d3p_vae_model* model, const float* params_dev, const float* X_dev,
+                      const uint8_t* mask_dev, uint32_t B, const float* eps_dev, const uint32_t* jax_key_dev, float clip,
+                      float* sums_dev, float* norms_dev, float* px_loss_dev, void* workspace_dev,
+                      size_t workspace_bytes);
+
+/* One DPSVI.update (svi.py:395-434) for the VAE: key split, the fused sums above, one Gaussian-noise key per
+ * parameter leaf (svi.py:487-491, 10 leaves), numpyro Adam; state as for the other models (P = d3p_vae_num_params). */
+int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper,
+                        const d3p_dpsvi_state* state, const float* X_dev, const uint8_t* mask_dev, uint32_t B,
+                        const float* eps_dev, float* loss_dev, float* grad_out_dev, void* workspace_dev,
+                        size_t workspace_bytes);
+
 /* Synthetic workload of SURVEY 8(d) / examples/logistic_regression.py:88-104, generated on device:
  * X[r][c] and y[r] are pure functions of (seed, global row, column). */
 int d3p_synth_logreg(void* stream, uint32_t seed, uint64_t row0, uint64_t n_rows, int32_t d,

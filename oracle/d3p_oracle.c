@@ -999,6 +999,141 @@ D3P_API float d3po_gmm_evaluate(const d3po_gmm_spec* sp, const float* params, co
     return (float)(lat - ((double)sp->lik_scale / B) * tot);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * DP-VI step sums for the variational auto-encoder of BASELINE config 5 (examples/vae.py:65-153):
+ *   encoder (guide):  h1 = softplus(x W1 + b1);  z_loc = h1 Wl + bl;  z_std = exp(h1 Ws + bs);  z ~ Normal(z_loc, z_std)
+ *   decoder (model):  z ~ Normal(0, 1);  h2 = softplus(z V1 + c1);  obs ~ Bernoulli(sigmoid(h2 V2 + c2))
+ * Parameters in tree_flatten order of {'decoder$params', 'encoder$params'} (stax.Dense: W (in, out), b (out)):
+ *   V1 (Z x H), c1 (H), V2 (H x D), c2 (D), W1 (D x H), b1 (H), Wl (H x Z), bl (Z), Ws (H x Z), bs (Z);
+ *   D = 784, H = 400, Z = 50 -> P = 688 884.
+ * Per example (z is local to the plate, so every term carries the same site scale `scale` = plate scale x the
+ * example's handlers.scale(1 / N), vae.py:194-195):
+ *   L_i = inv_obs * scale * ( log q(z_i | x_i) - log p(z_i) - log p(x_i | z_i) ),   z_i = z_loc + z_std * eps_i
+ * with the Bernoulli log-likelihood evaluated on logits a: x a - softplus(a) (numpyro clamps the probabilities at
+ * float32 eps instead; the two agree to that eps).  This function materialises every per-example gradient (P floats)
+ * explicitly -- it is the check for the device path, which never does (norms by the outer-product identity
+ * ||a d^T||_F = ||a|| ||d||, clipped sums as GEMMs).
+ * sums[P + 2] = [sum_i c_i g_i | sum_i L_i mask_i | n];  norms[B] (optional) = ||g_i||_2 before clipping.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t D, H, Z;
+    float scale;    /* site scale (1 in the example) */
+    float inv_obs;  /* 1 / observation_scale */
+} d3po_vae_spec;
+
+D3P_API int64_t d3po_vae_num_params(const d3po_vae_spec* sp)
+{
+    const int64_t D = sp->D, H = sp->H, Z = sp->Z;
+    return Z * H + H + H * D + D + D * H + H + 2 * (H * Z + Z);
+}
+
+D3P_API void d3po_vae_step_sums(const d3po_vae_spec* sp, const float* params, const float* X, const float* mask, int B,
+                                const float* eps /* B x Z */, float clip, float* sums, float* norms, float* px_loss)
+{
+    const int D = sp->D, H = sp->H, Z = sp->Z;
+    const int64_t P = d3po_vae_num_params(sp);
+    const float* V1 = params;
+    const float* c1 = V1 + (int64_t)Z * H;
+    const float* V2 = c1 + H;
+    const float* c2 = V2 + (int64_t)H * D;
+    const float* W1 = c2 + D;
+    const float* b1 = W1 + (int64_t)D * H;
+    const float* Wl = b1 + H;
+    const float* bl = Wl + (int64_t)H * Z;
+    const float* Ws = bl + Z;
+    const float* bs = Ws + (int64_t)H * Z;
+    double* acc = (double*)calloc((size_t)P + 2, sizeof(double));
+    const double sc = (double)sp->inv_obs * sp->scale;
+#pragma omp parallel
+    {
+        double* g = (double*)malloc(sizeof(double) * (size_t)P);
+        double *pre1 = (double*)malloc(sizeof(double) * (size_t)(4 * H + 6 * Z + 2 * D)), *h1 = pre1 + H, *pre2 = h1 + H, *h2 = pre2 + H;
+        double *zl = h2 + H, *u = zl + Z, *z = u + Z, *dz = z + Z, *du = dz + Z, *sd = du + Z, *a = sd + Z, *da = a + D;
+#pragma omp for schedule(dynamic)
+        for (int i = 0; i < B; ++i) {
+            const float m = mask ? mask[i] : 1.0f;
+            const float* x = X + (size_t)i * D;
+            const float* e = eps + (size_t)i * Z;
+            for (int j = 0; j < H; ++j) {
+                double t = b1[j];
+                for (int k = 0; k < D; ++k) t += (double)x[k] * W1[(size_t)k * H + j];
+                pre1[j] = t;
+                h1[j] = fmax(t, 0.0) + log1p(exp(-fabs(t)));
+            }
+            double lq = 0.0, lp = 0.0;
+            for (int j = 0; j < Z; ++j) {
+                double tl = bl[j], tu = bs[j];
+                for (int k = 0; k < H; ++k) { tl += h1[k] * Wl[(size_t)k * Z + j]; tu += h1[k] * Ws[(size_t)k * Z + j]; }
+                zl[j] = tl; u[j] = tu; sd[j] = exp(tu);
+                z[j] = tl + sd[j] * (double)e[j];
+                lq += -0.5 * (double)e[j] * e[j] - tu - (double)HALF_LOG_2PI;
+                lp += -0.5 * z[j] * z[j] - (double)HALF_LOG_2PI;
+            }
+            for (int j = 0; j < H; ++j) {
+                double t = c1[j];
+                for (int k = 0; k < Z; ++k) t += z[k] * V1[(size_t)k * H + j];
+                pre2[j] = t;
+                h2[j] = fmax(t, 0.0) + log1p(exp(-fabs(t)));
+            }
+            double ll = 0.0;
+            for (int j = 0; j < D; ++j) {
+                double t = c2[j];
+                for (int k = 0; k < H; ++k) t += h2[k] * V2[(size_t)k * D + j];
+                a[j] = t;
+                ll += (double)x[j] * t - (fmax(t, 0.0) + log1p(exp(-fabs(t))));
+                da[j] = sc * (1.0 / (1.0 + exp(-t)) - (double)x[j]);   /* d(-ll)/da */
+            }
+            const double L = sc * (lq - lp - ll);
+            /* ---- backward, explicit per-example gradient */
+            double* gV1 = g; double* gc1 = gV1 + (int64_t)Z * H; double* gV2 = gc1 + H; double* gc2 = gV2 + (int64_t)H * D;
+            double* gW1 = gc2 + D; double* gb1 = gW1 + (int64_t)D * H; double* gWl = gb1 + H; double* gbl = gWl + (int64_t)H * Z;
+            double* gWs = gbl + Z; double* gbs = gWs + (int64_t)H * Z;
+            for (int k = 0; k < H; ++k) for (int j = 0; j < D; ++j) gV2[(size_t)k * D + j] = h2[k] * da[j];
+            for (int j = 0; j < D; ++j) gc2[j] = da[j];
+            for (int k = 0; k < H; ++k) {
+                double t = 0.0;
+                for (int j = 0; j < D; ++j) t += da[j] * V2[(size_t)k * D + j];
+                gc1[k] = t / (1.0 + exp(-pre2[k]));     /* softplus' = sigmoid */
+            }
+            for (int k = 0; k < Z; ++k) for (int j = 0; j < H; ++j) gV1[(size_t)k * H + j] = z[k] * gc1[j];
+            for (int k = 0; k < Z; ++k) {
+                double t = sc * z[k];                    /* from -log p(z) = z^2 / 2 */
+                for (int j = 0; j < H; ++j) t += gc1[j] * V1[(size_t)k * H + j];
+                dz[k] = t;
+                du[k] = t * sd[k] * (double)e[k] - sc;   /* z = zl + exp(u) eps;  log q contributes -u */
+            }
+            for (int k = 0; k < H; ++k) for (int j = 0; j < Z; ++j) {
+                gWl[(size_t)k * Z + j] = h1[k] * dz[j];
+                gWs[(size_t)k * Z + j] = h1[k] * du[j];
+            }
+            for (int j = 0; j < Z; ++j) { gbl[j] = dz[j]; gbs[j] = du[j]; }
+            for (int k = 0; k < H; ++k) {
+                double t = 0.0;
+                for (int j = 0; j < Z; ++j) t += dz[j] * Wl[(size_t)k * Z + j] + du[j] * Ws[(size_t)k * Z + j];
+                gb1[k] = t / (1.0 + exp(-pre1[k]));
+            }
+            for (int k = 0; k < D; ++k) for (int j = 0; j < H; ++j) gW1[(size_t)k * H + j] = (double)x[k] * gb1[j];
+            double ss = 0.0;
+            for (int64_t j = 0; j < P; ++j) ss += g[j] * g[j];
+            const double nrm = sqrt(ss);
+            if (norms) norms[i] = (float)(nrm * m);
+            if (px_loss) px_loss[i] = (float)(L * m);
+            if (m != 0.0f) {
+                const double cf = 1.0 / fmax(1.0, nrm / clip);
+#pragma omp critical
+                {
+                    for (int64_t j = 0; j < P; ++j) acc[j] += cf * g[j];
+                    acc[P] += L;
+                    acc[P + 1] += 1.0;
+                }
+            }
+        }
+        free(g); free(pre1);
+    }
+    for (int64_t j = 0; j < P + 2; ++j) sums[j] = (float)acc[j];
+    free(acc);
+}
+
 /* Synthetic logistic-regression table, element (r, c) a pure function of (seed, r, c) so that any
  * shard can be regenerated (mirrors examples/logistic_regression.py:88-104 in
  * distribution): X[r][c] = normal from threefry2x32((seed, 0x58), (r, c))[0];

@@ -36,6 +36,10 @@ class GmmSpec(C.Structure):
                 ("inv_obs", C.c_float)]
 
 
+class VaeSpec(C.Structure):
+    _fields_ = [("D", C.c_int32), ("H", C.c_int32), ("Z", C.c_int32), ("scale", C.c_float), ("inv_obs", C.c_float)]
+
+
 class Hyper(C.Structure):
     _fields_ = [("clip", C.c_float), ("dp_scale", C.c_float), ("lr", C.c_float),
                 ("b1", C.c_float), ("b2", C.c_float), ("adam_eps", C.c_float)]
@@ -61,6 +65,7 @@ def lib():
         _lib.d3po_gamma_sample.restype = C.c_double
         _lib.d3po_gmm_px_loss_grad_given.restype = C.c_float
         _lib.d3po_gmm_evaluate.restype = C.c_float
+        _lib.d3po_vae_num_params.restype = C.c_int64
     return _lib
 
 
@@ -445,3 +450,25 @@ def gmm_evaluate(spec, params, Xb, jax_key):
     """DPSVI.evaluate for the mixture model; jax_key = convert(split(state.rng_key, 1)[0])."""
     Xb = _f32(Xb)
     return float(lib().d3po_gmm_evaluate(C.byref(spec), _p(_f32(params)), _p(Xb), C.c_int(Xb.shape[0]), _p(_u32(jax_key))))
+
+
+# ------------------------------------------------------------------ VAE step (config 5)
+def vae_spec(D, H, Z, scale=1.0, obs_scale=1.0):
+    return VaeSpec(D, H, Z, scale, 1.0 / obs_scale)
+
+
+def vae_num_params(spec):
+    return int(lib().d3po_vae_num_params(C.byref(spec)))
+
+
+def vae_step_sums(spec, params, X, eps, clip, mask=None):
+    """(sums[P + 2], norms[B], px_loss[B]) with explicit per-example gradients (examples/vae.py:65-153)."""
+    B = X.shape[0]
+    P = vae_num_params(spec)
+    sums = np.empty(P + 2, np.float32)
+    norms = np.empty(B, np.float32)
+    px_loss = np.empty(B, np.float32)
+    m = None if mask is None else _f32(mask)
+    lib().d3po_vae_step_sums(C.byref(spec), _p(_f32(params)), _p(_f32(X)), None if m is None else _p(m), C.c_int(B),
+                             _p(_f32(eps)), C.c_float(clip), _p(sums), _p(norms), _p(px_loss))
+    return sums, norms, px_loss

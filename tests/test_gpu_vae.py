@@ -1,0 +1,91 @@
+"""VAE step (BASELINE config 5, examples/vae.py:65-153): the fp32 MFMA GEMM against torch.matmul, the fused
+norm / clipped-sum path (no per-example gradient tensor) against the oracle's explicit per-example gradients,
+and DPSVI.update against the oracle's stage composition.
+
+Tolerances: GEMM rtol 2e-5 of the row scale (fp32 accumulation order); clipped sums rtol 2e-4 + 2e-5 * max|g|
+(sums of B products of fp32 activations; the oracle works in float64); norms rtol 5e-5."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def lib(gpu):
+    import d3p_amd._lib as L
+    return L
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (5, 7, 3), (100, 130, 70), (257, 65, 1000), (4096, 400, 784)])
+@pytest.mark.parametrize("form", ["nn", "nt", "tn"])
+def test_mfma_gemm_vs_torch(lib, M, N, K, form):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    Bm = torch.randn(K, N, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    Cinit = torch.randn(M, N, generator=g).cuda()
+    if form == "nn":
+        a_t, a_sm, a_sk, b_t, b_sk, b_sn = A.contiguous(), K, 1, Bm.contiguous(), N, 1
+    elif form == "nt":      # B stored as N x K
+        a_t, a_sm, a_sk, b_t, b_sk, b_sn = A.contiguous(), K, 1, Bm.t().contiguous(), 1, K
+    else:                   # A stored as K x M
+        a_t, a_sm, a_sk, b_t, b_sk, b_sn = A.t().contiguous(), 1, M, Bm.contiguous(), N, 1
+    L = lib.load()
+    out = Cinit.clone()
+    lib.check(L.d3p_gemm_f32(lib.stream_ptr(), lib.ptr(a_t), a_sm, a_sk, lib.ptr(b_t), b_sk, b_sn, lib.ptr(out), N, M, N, K,
+                             lib.ptr(bias), 0.5, 1))
+    ref = 0.5 * (A.double() @ Bm.double()) + bias.double() + Cinit.double()
+    scale = float((A.abs().double() @ Bm.abs().double()).max())
+    assert float((out.double() - ref).abs().max()) <= 2e-5 * scale
+    out2 = torch.empty(M, N + 3, device="cuda").fill_(7.0)      # leading dimension > N, no bias, overwrite
+    lib.check(L.d3p_gemm_f32(lib.stream_ptr(), lib.ptr(a_t), a_sm, a_sk, lib.ptr(b_t), b_sk, b_sn, lib.ptr(out2), N + 3, M, N, K,
+                             None, 1.0, 0))
+    assert float((out2[:, :N].double() - A.double() @ Bm.double()).abs().max()) <= 2e-5 * scale
+    assert torch.all(out2[:, N:] == 7.0)
+
+
+def vae_problem(B, D, H, Z, seed, pscale=0.2):
+    import oracle.oracle as O
+    r = np.random.default_rng(seed)
+    spec = O.vae_spec(D, H, Z, scale=1.0, obs_scale=1.0)
+    P = O.vae_num_params(spec)
+    params = (r.normal(size=P) * pscale).astype(np.float32)
+    X = (r.random((B, D)) < 0.3).astype(np.float32)
+    eps = r.normal(size=(B, Z)).astype(np.float32)
+    return spec, P, params, X, eps
+
+
+@pytest.mark.parametrize("B,D,H,Z,pscale", [(5, 12, 7, 3, 0.3), (70, 100, 33, 9, 0.2), (48, 784, 400, 50, 0.03)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_step_sums_vs_explicit_per_example_gradients(lib, O, B, D, H, Z, pscale, masked):
+    spec, P, params, X, eps = vae_problem(B, D, H, Z, B + D, pscale)
+    mask = (np.random.default_rng(3).random(B) < 0.7) if masked else None
+    # a clip threshold in the middle of the norm distribution, so that some rows are clipped and some are not
+    _, norms0, _ = O.vae_step_sums(spec, params, X, eps, 1e30, None)
+    clip = float(np.median(norms0))
+    esums, enorms, eloss = O.vae_step_sums(spec, params, X, eps, clip, None if mask is None else mask.astype(np.float32))
+    L = lib.load()
+    model = lib.VaeModel(D, H, Z, 1.0, 1.0)
+    assert L.d3p_vae_num_params(C.byref(model)) == P
+    ws = torch.empty(int(L.d3p_dpvi_vae_workspace(C.byref(model), B)), dtype=torch.uint8, device="cuda")
+    sums = torch.empty(P + 2, device="cuda")
+    norms = torch.empty(B, device="cuda")
+    pxl = torch.empty(B, device="cuda")
+    mt = None if mask is None else torch.tensor(mask).to(torch.uint8).cuda()
+    pt, Xt, et = torch.tensor(params).cuda(), torch.tensor(X).cuda(), torch.tensor(eps).cuda()   # keep the inputs alive
+    lib.check(L.d3p_vae_step_sums(lib.stream_ptr(), C.byref(model), lib.ptr(pt), lib.ptr(Xt), lib.ptr(mt), B, lib.ptr(et), None,
+                                  clip, lib.ptr(sums), lib.ptr(norms), lib.ptr(pxl), lib.ptr(ws), ws.numel()))
+    np.testing.assert_allclose(np_(norms), enorms, rtol=5e-5)
+    np.testing.assert_allclose(np_(pxl), eloss, rtol=2e-5, atol=1e-5)
+    got = np_(sums)
+    assert got[P + 1] == esums[P + 1]
+    assert abs(got[P] - esums[P]) <= 2e-5 * abs(esums[P])
+    np.testing.assert_allclose(got[:P], esums[:P], rtol=2e-4, atol=2e-5 * np.abs(esums[:P]).max())
+    assert (enorms > clip).any() and (enorms[enorms > 0] < clip).any()
