@@ -36,6 +36,9 @@ struct GemmArgs {
     int ldc;
     float alpha;
     int accumulate;
+    int a_last_one;   // row M - 1 of op(A) is all ones (bias gradients ride along with the weight gradients)
+    int k_per;        // K range of one split (multiple of D3P_GK); gridDim.z splits
+    float* part;      // split-K partial tiles [gridDim.z][M][N] (nullable when gridDim.z == 1)
 };
 
 #define D3P_GT 64  // tile edge
@@ -48,23 +51,41 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * D3P_GT, n0 = blockIdx.x * D3P_GT;
+    const int kbeg = blockIdx.z * g.k_per, kend = (kbeg + g.k_per < g.K) ? kbeg + g.k_per : g.K;
     float16v acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
     // staging maps: the unit-stride dimension of each operand runs along consecutive threads
     const bool a_kfast = g.a_sk == 1, b_nfast = g.b_sn == 1;
-    for (int k0 = 0; k0 < g.K; k0 += D3P_GK) {
+    int am[4], ak[4], bk[4], bn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = tid + 256 * r;  // 0 .. 1023
+        if (a_kfast) { ak[r] = e & 15; am[r] = e >> 4; } else { am[r] = e & 63; ak[r] = e >> 6; }
+        if (b_nfast) { bn[r] = e & 63; bk[r] = e >> 6; } else { bk[r] = e & 15; bn[r] = e >> 4; }
+    }
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {  // global -> registers for the slice starting at k0
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int e = tid + 256 * r;  // 0 .. 1023
-            int am, ak, bk, bn;
-            if (a_kfast) { ak = e & 15; am = e >> 4; } else { am = e & 63; ak = e >> 6; }
-            if (b_nfast) { bn = e & 63; bk = e >> 6; } else { bk = e & 15; bn = e >> 4; }
-            const int gm = m0 + am, gka = k0 + ak, gkb = k0 + bk, gn = n0 + bn;
-            As[ak][am] = (gm < g.M && gka < g.K) ? g.A[(long long)gm * g.a_sm + (long long)gka * g.a_sk] : 0.f;
-            Bs[bk][bn] = (gkb < g.K && gn < g.N) ? g.B[(long long)gkb * g.b_sk + (long long)gn * g.b_sn] : 0.f;
+            const int gm = m0 + am[r], gka = k0 + ak[r], gkb = k0 + bk[r], gn = n0 + bn[r];
+            float va = 0.f, vb = 0.f;
+            if (gm < g.M && gka < kend)
+                va = (g.a_last_one && gm == g.M - 1) ? 1.0f : g.A[(long long)gm * g.a_sm + (long long)gka * g.a_sk];
+            if (gkb < kend && gn < g.N) vb = g.B[(long long)gkb * g.b_sk + (long long)gn * g.b_sn];
+            ra[r] = va;
+            rb[r] = vb;
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += D3P_GK) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            As[ak[r]][am[r]] = ra[r];
+            Bs[bk[r]][bn[r]] = rb[r];
         }
         __syncthreads();
+        if (k0 + D3P_GK < kend) fetch(k0 + D3P_GK);  // next slice in flight while this one multiplies
 #pragma unroll
         for (int kk = 0; kk < D3P_GK; kk += 2) {
             const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
@@ -74,30 +95,71 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
         __syncthreads();
     }
     const int col = n0 + wn * 32 + (lane & 31);
-    if (col < g.N) {
-        const float bv = g.bias ? g.bias[col] : 0.f;
+    if (col >= g.N) return;
+    if (g.part) {  // split-K: raw partial tile, combined in fixed order by k_gemm_reduce
+        float* out = g.part + (size_t)blockIdx.z * g.M * g.N;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int row = m0 + wm * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
-            if (row < g.M) {
-                float* c = g.C + (size_t)row * g.ldc + col;
-                float o = __fmaf_rn(g.alpha, acc[v], bv);
-                if (g.accumulate) o += *c;
-                *c = o;
-            }
+            if (row < g.M) out[(size_t)row * g.N + col] = acc[v];
+        }
+        return;
+    }
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int row = m0 + wm * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+        if (row < g.M) {
+            float* c = g.C + (size_t)row * g.ldc + col;
+            float o = __fmaf_rn(g.alpha, acc[v], bv);
+            if (g.accumulate) o += *c;
+            *c = o;
         }
     }
 }
 
+__global__ void k_gemm_reduce(GemmArgs g, int splits)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)g.M * g.N) return;
+    const int row = (int)(t / g.N), col = (int)(t % g.N);
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += g.part[(size_t)z * g.M * g.N + t];  // fixed order
+    float* c = g.C + (size_t)row * g.ldc + col;
+    float o = __fmaf_rn(g.alpha, s, g.bias ? g.bias[col] : 0.f);
+    if (g.accumulate) o += *c;
+    *c = o;
+}
+
+// part / part_floats: optional split-K scratch.  The split count is chosen so that short grids (the weight-gradient
+// GEMMs: K = batch, M x N = a weight matrix) still put a few workgroups on every CU.
 static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, const float* B, long long b_sk, long long b_sn,
-                float* C, int ldc, int M, int N, int K, const float* bias, float alpha, int accumulate)
+                float* C, int ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, int a_last_one = 0,
+                float* part = nullptr, size_t part_floats = 0)
 {
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     g.M = M; g.N = N; g.K = K;
     g.a_sm = a_sm; g.a_sk = a_sk; g.b_sk = b_sk; g.b_sn = b_sn;
     g.ldc = ldc; g.alpha = alpha; g.accumulate = accumulate;
-    hipLaunchKernelGGL(k_gemm_f32, dim3(cdiv(N, D3P_GT), cdiv(M, D3P_GT)), dim3(256), 0, s, g);
+    g.a_last_one = a_last_one;
+    const unsigned tiles = cdiv(N, D3P_GT) * cdiv(M, D3P_GT);
+    int splits = 1;
+    if (part && tiles < 512 && K >= 8 * D3P_GK) {
+        splits = (int)((1024 + tiles - 1) / tiles);
+        const int max_by_k = K / (4 * D3P_GK);
+        if (splits > max_by_k) splits = max_by_k;
+        const size_t max_by_mem = part_floats / ((size_t)M * N);
+        if ((size_t)splits > max_by_mem) splits = (int)max_by_mem;
+        if (splits < 1) splits = 1;
+    }
+    int k_per = (K + splits - 1) / splits;
+    k_per = (k_per + D3P_GK - 1) / D3P_GK * D3P_GK;
+    splits = (K + k_per - 1) / k_per;
+    g.k_per = k_per;
+    g.part = splits > 1 ? part : nullptr;
+    hipLaunchKernelGGL(k_gemm_f32, dim3(cdiv(N, D3P_GT), cdiv(M, D3P_GT), splits), dim3(256), 0, s, g);
+    if (splits > 1) hipLaunchKernelGGL(k_gemm_reduce, dim3(cdiv((uint64_t)M * N, 256)), dim3(256), 0, s, g, splits);
     return check_launch("k_gemm_f32");
 }
 
@@ -227,20 +289,6 @@ __global__ void k_vae_scale_rows(float* __restrict__ d, const float* __restrict_
     d[t] *= cf[t / n];
 }
 
-// out[j] = sum_i d[i][j]  (bias gradients), fixed order: 64 columns x 4 row groups per workgroup
-__global__ void __launch_bounds__(256) k_vae_colsum(const float* __restrict__ d, uint32_t B, int n, float* __restrict__ out)
-{
-    __shared__ float lds[256];
-    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + c;
-    float s = 0.f;
-    if (col < n)
-        for (uint32_t r = rg; r < B; r += 4) s += d[(size_t)r * n + col];
-    lds[threadIdx.x] = s;
-    __syncthreads();
-    if (rg == 0 && col < n) out[col] = (lds[c] + lds[64 + c]) + (lds[128 + c] + lds[192 + c]);
-}
-
 // sums[P] = sum_i px_loss[i], sums[P + 1] = number of unmasked examples (one workgroup, fixed order)
 __global__ void __launch_bounds__(256) k_vae_loss_n(const float* __restrict__ px_loss, const uint8_t* __restrict__ mask, uint32_t B,
                                                     float* __restrict__ out)
@@ -323,7 +371,8 @@ static VaeLayout vae_layout(const d3p_vae_model* m)
 
 struct VaeWorkspace {
     float *h1, *sg1, *zl, *u, *eps, *h2, *sg2, *a, *dh2, *dz, *du, *dh1;
-    float *lat, *px_loss, *cf, *sums, *noise;
+    float *lat, *px_loss, *cf, *sums, *noise, *part;
+    size_t part_floats;
     uint32_t* keys;  // 3 x 16 split + 10 x 16 site keys + jax key
 };
 
@@ -351,6 +400,8 @@ static size_t vae_carve(const d3p_vae_model* m, uint32_t B, char* base, VaeWorks
     q = take(P + 2); if (ws) ws->sums = q;
     q = take(P); if (ws) ws->noise = q;
     q = take(13 * 16 + 2); if (ws) ws->keys = (uint32_t*)q;
+    const size_t pf = 16 * (D + 1) * H;  // split-K partial tiles: up to 16 splits of the largest weight matrix
+    q = take(pf); if (ws) { ws->part = q; ws->part_floats = pf; }
     return off;
 }
 
@@ -410,17 +461,14 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     hipLaunchKernelGGL(k_vae_scale_rows, ew((size_t)B * Z), dim3(256), 0, s, ws.du, (const float*)ws.cf, B, Z);
     hipLaunchKernelGGL(k_vae_scale_rows, ew((size_t)B * H), dim3(256), 0, s, ws.dh1, (const float*)ws.cf, B, H);
     // ---- clipped sums: weights  A^T (diag(c) Delta)  (GEMMs over the batch), biases = column sums
+    // [W | b] of every layer is contiguous in the flat layout, so the bias gradient is row `in` of a GEMM whose A carries a
+    // virtual row of ones
     float* S = ws.sums;
-    if ((rc = gemm(s, ws.zl, 1, Z, ws.dh2, H, 1, S + L.V1, H, Z, H, Bi, nullptr, 1.f, 0))) return rc;
-    hipLaunchKernelGGL(k_vae_colsum, dim3(cdiv(H, 64)), dim3(256), 0, s, (const float*)ws.dh2, B, H, S + L.c1);
-    if ((rc = gemm(s, ws.h2, 1, H, ws.a, D, 1, S + L.V2, D, H, D, Bi, nullptr, 1.f, 0))) return rc;
-    hipLaunchKernelGGL(k_vae_colsum, dim3(cdiv(D, 64)), dim3(256), 0, s, (const float*)ws.a, B, D, S + L.c2);
-    if ((rc = gemm(s, X, 1, D, ws.dh1, H, 1, S + L.W1, H, D, H, Bi, nullptr, 1.f, 0))) return rc;
-    hipLaunchKernelGGL(k_vae_colsum, dim3(cdiv(H, 64)), dim3(256), 0, s, (const float*)ws.dh1, B, H, S + L.b1);
-    if ((rc = gemm(s, ws.h1, 1, H, ws.dz, Z, 1, S + L.Wl, Z, H, Z, Bi, nullptr, 1.f, 0))) return rc;
-    hipLaunchKernelGGL(k_vae_colsum, dim3(cdiv(Z, 64)), dim3(256), 0, s, (const float*)ws.dz, B, Z, S + L.bl);
-    if ((rc = gemm(s, ws.h1, 1, H, ws.du, Z, 1, S + L.Ws, Z, H, Z, Bi, nullptr, 1.f, 0))) return rc;
-    hipLaunchKernelGGL(k_vae_colsum, dim3(cdiv(Z, 64)), dim3(256), 0, s, (const float*)ws.du, B, Z, S + L.bs);
+    if ((rc = gemm(s, ws.zl, 1, Z, ws.dh2, H, 1, S + L.V1, H, Z + 1, H, Bi, nullptr, 1.f, 0, 1, ws.part, ws.part_floats))) return rc;
+    if ((rc = gemm(s, ws.h2, 1, H, ws.a, D, 1, S + L.V2, D, H + 1, D, Bi, nullptr, 1.f, 0, 1, ws.part, ws.part_floats))) return rc;
+    if ((rc = gemm(s, X, 1, D, ws.dh1, H, 1, S + L.W1, H, D + 1, H, Bi, nullptr, 1.f, 0, 1, ws.part, ws.part_floats))) return rc;
+    if ((rc = gemm(s, ws.h1, 1, H, ws.dz, Z, 1, S + L.Wl, Z, H + 1, Z, Bi, nullptr, 1.f, 0, 1, ws.part, ws.part_floats))) return rc;
+    if ((rc = gemm(s, ws.h1, 1, H, ws.du, Z, 1, S + L.Ws, Z, H + 1, Z, Bi, nullptr, 1.f, 0, 1, ws.part, ws.part_floats))) return rc;
     hipLaunchKernelGGL(k_vae_loss_n, dim3(1), dim3(256), 0, s, (const float*)ws.px_loss, mask, B, S + L.P);
     return check_launch("d3p_vae sums");
 }

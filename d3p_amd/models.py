@@ -124,6 +124,35 @@ class GaussianMixtureGuide:
         return ("alpha_log", "mus_loc")
 
 
+class VAEModel:
+    """The decoder side of examples/vae.py:104-135: z ~ Normal(0, I_z) inside the plate, decoder
+    z -> Dense(hidden, softplus) -> Dense(out, sigmoid), obs ~ Bernoulli.  ``scale`` is the factor of an enclosing
+    ``numpyro.handlers.scale`` (the example uses 1 / num_samples, vae.py:194-195)."""
+
+    has_labels = False
+    family = "vae"
+
+    def __init__(self, z_dim=None, hidden_dim=None, scale=1.0):
+        self.z_dim = z_dim
+        self.hidden_dim = hidden_dim
+        self.scale = float(scale)
+
+    @staticmethod
+    def num_obs_total(args, kwargs):
+        for key in ("N", "num_obs_total"):
+            if kwargs.get(key) is not None:
+                return float(kwargs[key])
+        return None
+
+
+class VAEGuide:
+    """The encoder side of examples/vae.py:138-153: x -> Dense(hidden, softplus) -> (Dense(z), exp(Dense(z))),
+    z ~ Normal(z_loc, z_std).  Parameters live in the numpyro.module trees 'decoder$params' / 'encoder$params'."""
+
+    def __init__(self, model):
+        self.model = model
+
+
 class DiagonalNormalGuide:
     """The hand-written mean-field guides of the reference's examples: one sample site
     ``Normal(<site>_loc, exp(<site>_std_log))`` over the model's latent vector

@@ -15,10 +15,10 @@ import torch
 
 from . import _lib
 from . import random as strong_rng
-from ._lib import BatchSource, DpsviHyper, DpsviState, GmmModel, LogregModel, check, ptr, stream_ptr
+from ._lib import BatchSource, DpsviHyper, DpsviState, GmmModel, LogregModel, VaeModel, check, ptr, stream_ptr
 from .optimizers import ADADP
 from .models import (SGD, Adam, AutoDiagonalNormal, DiagonalNormalGuide, GaussianMean, GaussianMixtureGuide,
-                     GaussianMixtureModel, LogisticRegression,
+                     GaussianMixtureModel, LogisticRegression, VAEGuide, VAEModel,
                      init_to_uniform, init_to_value)
 from .util import example_count
 
@@ -177,6 +177,80 @@ class DPSVI:
         return DPSVI._update_state_rng(dp_svi_state, split_keys[0]), split_keys[1:]
 
     # ---------------------------------------------------------------- model plumbing
+    # ---------------------------------------------------------------- VAE (BASELINE config 5)
+    def _is_vae(self):
+        return isinstance(self.model, VAEModel) and isinstance(self.guide, VAEGuide)
+
+    def _vae_struct(self, D, kwargs, observation_scale):
+        kw = dict(self.static_kwargs)
+        kw.update(kwargs)
+        z = kw.get("z_dim") or self.model.z_dim
+        h = kw.get("hidden_dim") or self.model.hidden_dim
+        if z is None or h is None:
+            raise ValueError("VAEModel: z_dim and hidden_dim must be given")
+        n_total = self.model.num_obs_total((), kw)
+        site_scale = (1.0 if n_total is None else n_total) * self.model.scale   # plate(N, 1) x handlers.scale
+        return VaeModel(int(D), int(h), int(z), float(site_scale), 1.0 / float(observation_scale))
+
+    @staticmethod
+    def _vae_flat(X):
+        return X.reshape(X.shape[0], -1).contiguous().to(torch.float32)
+
+    def _vae_tree(self, flat, vm):
+        """Flat parameter vector -> the numpyro.module trees of stax.serial (empty tuples for the parameter-free layers)."""
+        D, H, Z = vm.D, vm.H, vm.Z
+        shapes = [(Z, H), (H,), (H, D), (D,), (D, H), (H,), (H, Z), (Z,), (H, Z), (Z,)]
+        leaves, pos = [], 0
+        for shp in shapes:
+            n = int(np.prod(shp))
+            leaves.append(flat[pos:pos + n].reshape(shp))
+            pos += n
+        V1, c1, V2, c2, W1, b1, Wl, bl, Ws, bs = leaves
+        return {"decoder$params": [(V1, c1), (), (V2, c2), ()],
+                "encoder$params": [(W1, b1), (), (), ((Wl, bl), ((Ws, bs), ()))]}
+
+    def _init_vae(self, rng_key, *args, **kwargs):
+        _lib.require_device()
+        lib = _lib.load()
+        X = self._vae_flat(args[0])
+        vm = self._vae_struct(X.shape[1], kwargs, 1.0)
+        P = int(lib.d3p_vae_num_params(C.byref(vm)))
+        # stax.Dense(W_init=stax.randn(), b_init=normal()): every leaf ~ N(0, 0.01^2); the reference's key plumbing
+        # through numpyro.module / stax init_fun is unpinned, this build draws the flat vector from the init key
+        jax_rng_key = self._rng_suite.convert_to_jax_rng_key(rng_key).contiguous()
+        params = torch.empty(P, dtype=torch.float32, device=X.device)
+        check(lib.d3p_tf_normal(stream_ptr(), ptr(jax_rng_key), P, ptr(params)))
+        params.mul_(1e-2)
+        observation_scale = 1.0
+        if self._clip_unscaled_observations:
+            observation_scale = vm.scale        # get_observations_scale: scale of the 'obs' site (svi.py:43-65)
+        return DPSVIState(self.optim.init(params), rng_key, observation_scale)
+
+    def _update_vae(self, svi_state, *args, mask=True, _eps=None, _grad_out=None, **kwargs):
+        if not (isinstance(self.optim, Adam) and self._rng_suite is strong_rng):
+            raise _lib.D3PError("VAE step: needs numpyro-style Adam and rng_suite=d3p_amd.random")
+        _lib.require_device()
+        lib = _lib.load()
+        X = self._vae_flat(args[0])
+        B, D = X.shape
+        dev = X.device
+        vm = self._vae_struct(D, kwargs, svi_state.observation_scale)
+        hyper = self._hyper()
+        step, params, m, v = (t.clone() for t in svi_state.optim_state)
+        keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
+        keybuf[0].copy_(svi_state.rng_key.reshape(16))
+        mask_t = None
+        if not isinstance(mask, bool):
+            mask_t = mask.to(torch.uint8).contiguous()
+        elif mask is False:
+            mask_t = torch.zeros(B, dtype=torch.uint8, device=dev)
+        st = self._state_struct(keybuf, 0, (step, params, m, v))
+        ws = self._workspace(lib.d3p_dpvi_vae_workspace(C.byref(vm), B), dev, "vae_step")
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        check(lib.d3p_dpvi_vae_update(stream_ptr(), C.byref(vm), C.byref(hyper), C.byref(st), ptr(X), ptr(mask_t), B,
+                                      ptr(_eps), ptr(loss), ptr(_grad_out), ptr(ws), ws.numel()))
+        return DPSVIState((step, params, m, v), keybuf[1].reshape(4, 4), svi_state.observation_scale), loss[0]
+
     def _is_gmm(self):
         return isinstance(self.model, GaussianMixtureModel) and isinstance(self.guide, GaussianMixtureGuide)
 
@@ -234,6 +308,8 @@ class DPSVI:
     def init(self, rng_key, *args, **kwargs):
         if self._is_gmm():
             return self._init_gmm(rng_key, *args, **kwargs)
+        if self._is_vae():
+            return self._init_vae(rng_key, *args, **kwargs)
         self._require_logreg()
         _lib.require_device()
         X = args[0]
@@ -284,6 +360,11 @@ class DPSVI:
         """Constrained parameters (numpyro SVI.get_params): auto_scale = softplus(unconstrained) for
         AutoDiagonalNormal; the hand-written guides keep their ``*_std_log`` unconstrained."""
         p = self.optim.get_params(svi_state.optim_state)
+        if self._is_vae():
+            kw = self.static_kwargs
+            z, h = int(kw.get("z_dim") or self.model.z_dim), int(kw.get("hidden_dim") or self.model.hidden_dim)
+            D = (p.numel() - (z * h + h) - 2 * (h * z + z) - h) // (2 * h + 1)
+            return self._vae_tree(p.clone(), VaeModel(D, h, z, 1.0, 1.0))
         if self._is_gmm():
             K = int(self.static_kwargs.get("k") or self.model.k)
             return {"alpha_log": p[:K].clone(), "mus_loc": p[K:].reshape(K, -1).clone()}
@@ -523,6 +604,8 @@ class DPSVI:
         """One DP-VI step on a batch; returns ``(new_state, loss)`` (svi.py:395-434)."""
         if self._gmm_fusable():
             return self._update_gmm_fused(svi_state, *args, mask=mask, **kwargs)
+        if self._is_vae():
+            return self._update_vae(svi_state, *args, mask=mask, **kwargs)
         if self._fusable():
             return self._update_fused(svi_state, *args, mask=mask, **kwargs)
         return self._update_staged(svi_state, *args, mask=mask, **kwargs)

@@ -89,3 +89,66 @@ def test_step_sums_vs_explicit_per_example_gradients(lib, O, B, D, H, Z, pscale,
     assert abs(got[P] - esums[P]) <= 2e-5 * abs(esums[P])
     np.testing.assert_allclose(got[:P], esums[:P], rtol=2e-4, atol=2e-5 * np.abs(esums[:P]).max())
     assert (enorms > clip).any() and (enorms[enorms > 0] < clip).any()
+
+
+def make_svi(Z, H, N, C=10.0, sigma=1.0, lr=1e-3):
+    from d3p_amd.models import Adam, Trace_ELBO, VAEGuide, VAEModel
+    from d3p_amd.svi import DPSVI
+    model = VAEModel(scale=1.0 / N)                       # handlers.scale(model, 1 / num_samples), vae.py:194-195
+    return DPSVI(model, VAEGuide(model), Adam(lr), Trace_ELBO(), C, sigma, num_obs_total=N, z_dim=Z, hidden_dim=H)
+
+
+@pytest.mark.parametrize("B,D,H,Z,masked", [(6, 12, 7, 3, False), (40, 784, 400, 50, True)])
+def test_update_vs_oracle_stage_composition(gpu, O, B, D, H, Z, masked):
+    """DPSVI.update for the VAE: split(key, 3); per-example eps from the gradient key (svi.py:289-290); clipped sums;
+    one perturbation key per parameter leaf in tree_flatten order (svi.py:487-491); numpyro Adam."""
+    import d3p_amd.random as rng
+    from d3p_amd.svi import DPSVIState
+    N = 60000
+    spec, P, params, X, _ = vae_problem(B, D, H, Z, 11, 0.03 if D > 100 else 0.3)
+    mask = (np.random.default_rng(4).random(B) < 0.7) if masked else None
+    svi = make_svi(Z, H, N, C=3.0, sigma=0.8, lr=1e-2)
+    st = DPSVIState(svi.optim.init(torch.tensor(params).cuda()), rng.PRNGKey(77), 1.0)
+    Xt = torch.tensor(X.reshape(B, -1)).cuda()
+    gout = torch.empty(P, device="cuda")
+    new_st, loss = svi.update(st, Xt, mask=True if mask is None else torch.tensor(mask).cuda(), _grad_out=gout)
+
+    ks = O.split(O.PRNGKey(77), 3)
+    eps = O.px_eps(O.convert_to_jax_rng_key(ks[1]), B, Z)
+    sums, _, _ = O.vae_step_sums(spec, params, X, eps, 3.0, None if mask is None else mask.astype(np.float32))
+    n = sums[P + 1]
+    f = B / n
+    sizes = [Z * H, H, H * D, D, D * H, H, H * Z, Z, H * Z, Z]
+    g = O.perturb(ks[2], sums[:P] / B, sizes, 0.8, 3.0, n, 1.0, f)
+    x, m, v = O.adam(params, np.zeros(P), np.zeros(P), g, 0, lr=1e-2)
+    eloss = sums[P] / B * f
+    assert abs(float(loss) - eloss) <= 5e-5 * abs(eloss)
+    np.testing.assert_allclose(np_(gout), g, rtol=2e-4, atol=2e-5 * np.abs(g).max())
+    np.testing.assert_allclose(np_(new_st.optim_state[1]), x, rtol=1e-4, atol=2e-5)
+    assert np.array_equal(np_(new_st.rng_key), ks[0]) and int(new_st.optim_state[0]) == 1
+    tree = svi.get_params(new_st)
+    assert tuple(tree["decoder$params"][0][0].shape) == (Z, H) and tuple(tree["encoder$params"][3][1][0][0].shape) == (H, Z)
+    assert tree["decoder$params"][1] == () and tuple(tree["encoder$params"][0][0].shape) == (D, H)
+
+
+def test_training_reduces_the_loss_on_structured_binary_images(gpu):
+    """A few hundred non-private-ish steps on synthetic 'images' (two prototype patterns + flips): the ELBO improves."""
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, Z, H, B = 2048, 8, 64, 128
+    g = torch.Generator().manual_seed(0)
+    protos = (torch.rand(2, 28, 28, generator=g) < 0.3).float()
+    which = torch.randint(0, 2, (N,), generator=g)
+    flips = (torch.rand(N, 28, 28, generator=g) < 0.05).float()
+    X = ((protos[which] + flips) % 2).cuda()
+    svi = make_svi(Z, H, N, C=50.0, sigma=0.05, lr=3e-3)
+    init, get_batch = subsample_batchify_data((X,), B)
+    nb, bstate = init(rng.PRNGKey(1))
+    st = svi.init(rng.PRNGKey(0), *get_batch(0, bstate))
+    assert float(st.observation_scale) == 1.0            # plate scale N x handlers.scale(1 / N)
+    losses = []
+    for i in range(300):
+        st, l = svi.update(st, *get_batch(i % nb, bstate))
+        losses.append(float(l))
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-20:]) < 0.6 * np.mean(losses[:20])
