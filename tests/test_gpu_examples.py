@@ -45,3 +45,15 @@ def test_gaussian_mixture_example_separates_the_clusters(gpu):
     acc, pis, modes = mod.main(args)
     assert acc > 0.9
     assert abs(float(pis.sum()) - 1.0) < 1e-5
+
+
+def test_vae_example_learns_to_reconstruct(gpu):
+    """BASELINE config 5's example (784 -> 400 -> 50) end to end on synthetic binary images."""
+    spec = importlib.util.spec_from_file_location("ex_vae", os.path.join(ROOT, "examples", "vae.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    # little noise and a larger step size than the script's defaults: the test runs only 320 steps
+    args = argparse.Namespace(num_epochs=10, learning_rate=3e-3, batch_size=128, z_dim=50, hidden_dim=400, num_samples=4096,
+                              sigma=0.01)
+    errs = mod.main(args)
+    assert errs[-1] < 0.75 * errs[0]
