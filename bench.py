@@ -129,8 +129,21 @@ def main():
     else:
         engine_cls = ddist.HipEngine if os.environ.get("D3P_DIST_TWO_PHASE") else ddist.FusedHipEngine
         engine = engine_cls(svi, X, y, n_rows, lo, hi, L.D3P_BATCH_FEISTEL, Bg)
+        # Preferred: the native loop (one C call for the whole run; per step one launch + one in-place ncclAllReduce on
+        # the same stream, communicator owned by libd3p_hip.so).  If RCCL cannot be set up that way, or on request,
+        # the same steps are driven from Python through torch.distributed.all_reduce.
+        comm = None
+        if engine_cls is ddist.FusedHipEngine and not os.environ.get("D3P_DIST_TORCH_LOOP"):
+            try:
+                comm = ddist.NativeComm()
+            except Exception as e:  # noqa: BLE001 -- any failure here only selects the slower driver
+                if rank == 0:
+                    print(f"[bench] native RCCL loop unavailable ({e}); using the torch.distributed loop", file=sys.stderr)
+        dist_driver = "native" if comm is not None else "torch"
 
         def run(st, first, k):
+            if comm is not None:
+                return ddist.run_steps_native(engine, st, bkey, first, k, comm=comm, collect_losses=False)
             return ddist.run_steps(engine, st, bkey, first, k, collect_losses=False)
 
     state, _ = run(state, 0, args.warmup)
@@ -192,6 +205,8 @@ def main():
 
     if dist.is_initialized():
         dist.barrier()
+        if not (world == 1 and not args.force_dist_loop) and comm is not None:
+            comm.close()
         dist.destroy_process_group()
     if rank == 0:
         out = {
@@ -206,7 +221,7 @@ def main():
                                                           "Poisson sampling q = B/N padded to the 0.99 quantile") + ", AutoDiagonalNormal, "
                                    "C=1, sigma=1, Adam 1e-3",
                        "rows": n_rows, "dim": d, "global_batch": Bg, "parallelism": f"dp{world}",
-                       "collective": "none" if world == 1 else "1 all-reduce(sum) per step of the int64 fixed-point accumulator, 8 x (2D+2) words (RCCL)"},
+                       "collective": "none" if world == 1 else "1 all-reduce(sum) per step of the int64 fixed-point accumulator, 4 x (2D+2) words (RCCL); driver: " + dist_driver},
             "final_loss": final_loss,
             "roofline": roofline,
             "cpu_baseline": cpu,

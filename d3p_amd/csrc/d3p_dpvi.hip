@@ -22,6 +22,9 @@
 // gathers X, reads eps and does the parameter-dependent arithmetic.
 #include "d3p_logreg_kernel.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the entry points are resolved at run time from the RCCL torch has loaded
+
 #define D3P_STEP_BATCH 32
 #define D3P_RING 8        // ring of step slots used by the pipelined run loop (> look-ahead)
 #define D3P_LOOKAHEAD 4
@@ -1036,10 +1039,41 @@ static int enqueue_fused_step(const Ctx& c, int g, int t, const StepSlot* prev_s
     return launch_main<2>(c.s, g2, a, e0, e1);
 }
 
+// ---- RCCL, resolved lazily with dlopen so that libd3p_hip.so has no link-time dependency on it (single-GPU users
+// never touch it) and shares the copy torch.distributed already loaded when there is one.
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*);
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    const char* (*GetErrorString)(ncclResult_t);
+};
+
+static const RcclApi* rccl_api()
+{
+    static RcclApi api;
+    static int state = 0;  // 0 = not tried, 1 = ok, -1 = unavailable
+    if (state == 0) {
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+            api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+            api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+            api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
+            api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+        }
+        state = (h && api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString) ? 1 : -1;
+    }
+    return state == 1 ? &api : nullptr;
+}
+
 static int enqueue_sampler(const Ctx& c, int K);
 static int enqueue_chain(const Ctx& c, int K);
 
-static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_t num_steps, float* losses)
+// comm != nullptr: data-parallel run -- after every step launch the rank's fixed-point accumulator (R x (P + 2) int64) is
+// sum-all-reduced in place on the same stream (the ONE collective of the step); the next launch applies the global sums.
+static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_t num_steps, float* losses, ncclComm_t comm = nullptr)
 {
     int rc;
     const size_t acc_bytes = 3 * (size_t)D3P_ACC_R * (c.P + 2) * sizeof(long long);
@@ -1069,6 +1103,12 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
             if ((rc = enqueue_fused_step(cb[cur], g, t, prev_slot, prev_noise, X, y, (losses && g > 0) ? losses + g - 1 : nullptr,
                                          cslot, t, t == K_next - 1, false)))
                 return rc;
+            if (comm) {
+                const size_t words = (size_t)D3P_ACC_R * (c.P + 2);
+                long long* acc = c.ws.acc + (size_t)(g % 3) * words;
+                const ncclResult_t r = rccl_api()->AllReduce(acc, acc, words, ncclInt64, ncclSum, comm, c.s);
+                if (r != ncclSuccess) return fail(D3P_E_HIP, "ncclAllReduce: %s", rccl_api()->GetErrorString(r));
+            }
             prev_slot = cb[cur].ws.slots + t;
             prev_noise = cb[cur].ws.noise + (size_t)t * c.P;
         }
@@ -1291,6 +1331,61 @@ int d3p_dpvi_logreg_fused_step(void* stream, const d3p_logreg_model* model, cons
     const float* prev_noise = have_prev ? cb[prev_buf & 1].ws.noise + (size_t)prev_t * c.P : nullptr;
     return enqueue_fused_step(cur, (int)g, (int)t, prev_slot, prev_noise, X_dev, y_dev, prev_loss_dev, nullptr, 0, 0,
                               flush_only != 0);
+}
+
+int d3p_comm_unique_id(uint8_t* id_out, size_t id_bytes)
+{
+    D3P_REQUIRE(id_out && id_bytes >= sizeof(ncclUniqueId), "d3p_comm_unique_id: buffer of at least 128 bytes required");
+    const RcclApi* api = rccl_api();
+    if (!api) return fail(D3P_E_UNSUPPORTED, "d3p_comm_unique_id: librccl.so could not be loaded");
+    ncclUniqueId id;
+    const ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(D3P_E_HIP, "ncclGetUniqueId: %s", api->GetErrorString(r));
+    memcpy(id_out, &id, sizeof(id));
+    return D3P_OK;
+}
+
+int d3p_comm_init(const uint8_t* id, size_t id_bytes, int32_t nranks, int32_t rank, void** comm_out)
+{
+    D3P_REQUIRE(id && comm_out && id_bytes >= sizeof(ncclUniqueId) && nranks >= 1 && rank >= 0 && rank < nranks,
+                "d3p_comm_init: bad arguments");
+    const RcclApi* api = rccl_api();
+    if (!api) return fail(D3P_E_UNSUPPORTED, "d3p_comm_init: librccl.so could not be loaded");
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = api->CommInitRank(&comm, nranks, uid, rank);
+    if (r != ncclSuccess) return fail(D3P_E_HIP, "ncclCommInitRank: %s", api->GetErrorString(r));
+    *comm_out = (void*)comm;
+    return D3P_OK;
+}
+
+int d3p_comm_destroy(void* comm)
+{
+    if (!comm) return D3P_OK;
+    const RcclApi* api = rccl_api();
+    if (!api) return fail(D3P_E_UNSUPPORTED, "d3p_comm_destroy: librccl.so could not be loaded");
+    const ncclResult_t r = api->CommDestroy((ncclComm_t)comm);
+    if (r != ncclSuccess) return fail(D3P_E_HIP, "ncclCommDestroy: %s", api->GetErrorString(r));
+    return D3P_OK;
+}
+
+int d3p_dpvi_logreg_run_dist(void* stream, void* comm, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                             const d3p_dpsvi_state* state, const d3p_batch_source* src, const float* X_dev, const float* y_dev,
+                             uint32_t num_steps, float* losses_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    Ctx c;
+    int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    D3P_REQUIRE(X_dev || src->row_lo == src->row_hi, "null data pointer");
+    if (int rcm = validate_model(model, y_dev ? (const void*)y_dev : (src->row_lo == src->row_hi ? (const void*)model : nullptr),
+                                 "d3p_dpvi_logreg_run_dist"))
+        return rcm;
+    D3P_REQUIRE(src->kind != D3P_BATCH_EXPLICIT, "d3p_dpvi_logreg_run_dist: needs an on-device sampler (Feistel or Poisson)");
+    if (comm && !rccl_api()) return fail(D3P_E_UNSUPPORTED, "d3p_dpvi_logreg_run_dist: librccl.so could not be loaded");
+    if ((rc = enqueue_sched_init(c))) return rc;
+    if ((rc = run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev, (ncclComm_t)comm))) return rc;
+    return enqueue_sched_finish(c, (int)num_steps);
 }
 
 int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,

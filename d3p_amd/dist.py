@@ -45,6 +45,10 @@ class HipEngine:
         self.sums = torch.empty(self.P + 2, dtype=torch.float32, device=self.dev)
 
     def begin(self, state, batch_key, first_batch):
+        self._setup(state, batch_key, first_batch)
+        check(_lib.load().d3p_dpvi_logreg_begin(stream_ptr(), *self._args, ptr(self.ws), self.ws.numel()))
+
+    def _setup(self, state, batch_key, first_batch):
         self.model = self.svi._model_struct(self.d, self.model_kwargs, state.observation_scale)
         self.hyper = self.svi._hyper()
         self.step, self.params, self.m, self.v = (t.clone() for t in state.optim_state)
@@ -66,7 +70,6 @@ class HipEngine:
         self.prepared = 0     # steps the current batch holds
         self.done = 0
         self.remaining = None
-        check(lib.d3p_dpvi_logreg_begin(stream_ptr(), *self._args, ptr(self.ws), self.ws.numel()))
 
     STEP_BATCH = 32
 
@@ -162,6 +165,48 @@ class FusedHipEngine(HipEngine):
         if self.prev is not None:
             self._launch(True)  # apply the update of the last step
         return super().end()
+
+
+class NativeComm:
+    """RCCL communicator owned by libd3p_hip.so (d3p_comm_*): rank 0 draws the id, torch.distributed carries it to the
+    other ranks, every rank joins.  Used by the native data-parallel loop, which then needs no Python per step."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        _lib.require_device()
+        lib = _lib.load()
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        buf = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            check(lib.d3p_comm_unique_id(buf, 128))
+        box = [bytes(buf)]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        handle = C.c_void_p()
+        check(lib.d3p_comm_init(ident, 128, self.world, self.rank, C.byref(handle)))
+        self.handle = handle
+
+    def close(self):
+        if self.handle:
+            check(_lib.load().d3p_comm_destroy(self.handle))
+            self.handle = None
+
+
+def run_steps_native(engine, state, batch_key, first_batch, num_steps, comm=None, collect_losses=True):
+    """The whole data-parallel run in one C call (d3p_dpvi_logreg_run_dist): per step one kernel launch and one
+    in-place ncclAllReduce of the int64 accumulator on the same stream; no host work between steps.
+    `engine` is a FusedHipEngine (it supplies the shard and the model); `comm` a NativeComm or None (single rank)."""
+    from .svi import DPSVIState
+    engine._setup(state, batch_key, first_batch)
+    losses = torch.zeros(max(int(num_steps), 1), dtype=torch.float32, device=engine.dev) if collect_losses else None
+    check(_lib.load().d3p_dpvi_logreg_run_dist(stream_ptr(), comm.handle if comm is not None else None, *engine._args,
+                                               ptr(engine.X), ptr(engine.y), int(num_steps), ptr(losses), ptr(engine.ws),
+                                               engine.ws.numel()))
+    new_state = DPSVIState((engine.step, engine.params, engine.m, engine.v),
+                           engine.keybuf[int(num_steps) & 1].reshape(4, 4).clone(), engine.observation_scale)
+    return new_state, (losses[:int(num_steps)] if collect_losses else None)
 
 
 def run_steps(engine, state, batch_key, first_batch, num_steps, group=None, collect_losses=True):

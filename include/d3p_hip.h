@@ -379,6 +379,23 @@ int d3p_dpvi_gmm_update(void* stream, const d3p_gmm_model* model, const d3p_dpsv
                         const d3p_dpsvi_state* state, const float* X_dev, const uint8_t* mask_dev, uint32_t B,
                         float* loss_dev, float* grad_out_dev, void* workspace_dev, size_t workspace_bytes);
 
+/* ---------------------------------------------------------------------------------------------
+ * Data-parallel run over the GPUs of one node (the reference is single-device).  One process per GPU;
+ * every rank calls the same sequence.  The communicator is RCCL's, created from an id that rank 0 obtains and the
+ * host layer distributes (torch.distributed broadcast); librccl.so is resolved at run time.
+ * d3p_dpvi_logreg_run_dist = d3p_dpvi_logreg_run on this rank's row shard (src->row_lo / row_hi) with ONE collective
+ * per step: the in-place sum-all-reduce of the rank's fixed-point accumulator (4 x (P + 2) int64 words: exact integer
+ * sums, so every rank applies bitwise the same update under any reduction order); the Gaussian noise is added once,
+ * after the reduce, from the same key on every rank.  comm == NULL runs without the collective.
+ * ------------------------------------------------------------------------------------------- */
+int d3p_comm_unique_id(uint8_t* id_out, size_t id_bytes); /* id_bytes >= 128 */
+int d3p_comm_init(const uint8_t* id, size_t id_bytes, int32_t nranks, int32_t rank, void** comm_out);
+int d3p_comm_destroy(void* comm);
+int d3p_dpvi_logreg_run_dist(void* stream, void* comm, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                             const d3p_dpsvi_state* state, const d3p_batch_source* src, const float* X_dev,
+                             const float* y_dev, uint32_t num_steps, float* losses_dev, void* workspace_dev,
+                             size_t workspace_bytes);
+
 /* num_steps x (get_batch(first_batch + t, batch_key) of subsample_batchify_data -> update) on the resident table
  * X_dev (n_rows x d): the body of the example's jit(fori_loop(...)) epoch (examples/gaussian_mixture_model.py:219-230
  * with the subsampling batchifier).  losses_dev[num_steps] optional. */

@@ -261,3 +261,35 @@ def test_dist_run_steps_equals_svi_run_steps(gpu):
     np.testing.assert_allclose(a_losses.cpu().numpy(), b_losses.cpu().numpy(), rtol=1e-5)
     np.testing.assert_allclose(a_state.optim_state[1].cpu().numpy(), b_state.optim_state[1].cpu().numpy(),
                                rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_native_rccl_loop_on_one_rank_equals_the_single_gpu_run(gpu):
+    """d3p_dpvi_logreg_run_dist with a 1-rank RCCL communicator created through d3p_comm_* (the in-place all-reduce of
+    the int64 accumulator is then the identity): same losses, parameters and keys as DPSVI.run_steps, bit for bit."""
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    from d3p_amd.minibatch import subsample_batchify_data
+    from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
+    from d3p_amd.svi import DPSVI, DPSVIState
+    N, d, B, steps = 20000, 512, 4096, 37
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(N, d, generator=g).cuda()
+    y = (torch.rand(N, generator=g) < 0.5).float().cuda()
+    model = LogisticRegression(d)
+    svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-2), Trace_ELBO(), 1.0, 0.7, num_obs_total=N)
+    params = torch.cat([torch.zeros(d), torch.full((d,), -2.0)]).cuda()
+    st = DPSVIState(svi.optim.init(params), rng.PRNGKey(3), float(N))
+    bkey = rng.PRNGKey(4)
+    _, get_batch = subsample_batchify_data((X, y), B)
+    ref_state, ref_losses = svi.run_steps(st, get_batch, bkey, 5, steps)
+    comm = ddist.NativeComm()
+    try:
+        engine = ddist.FusedHipEngine(svi, X, y, N, 0, N, L.D3P_BATCH_FEISTEL, B)
+        new_state, losses = ddist.run_steps_native(engine, st, bkey, 5, steps, comm=comm)
+    finally:
+        comm.close()
+    assert torch.equal(losses, ref_losses)
+    assert torch.equal(new_state.optim_state[1], ref_state.optim_state[1])
+    assert torch.equal(new_state.rng_key, ref_state.rng_key) and int(new_state.optim_state[0]) == steps
