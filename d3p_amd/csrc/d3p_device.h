@@ -272,6 +272,6 @@ __device__ __forceinline__ float wave_sum(float v)
 // softplus(t) = max(t, 0) + log(1 + exp(-|t|)); exp(-|t|) is in (0, 1], so log(1 + e) via v_log_f32 has an
 // absolute error of ~1e-7 (relative to values >= ln 2 * e): inside the stated float32 tolerance.
 __device__ __forceinline__ float softplus_f(float t) { return fmaxf(t, 0.0f) + __logf(1.0f + __expf(-fabsf(t))); }
-__device__ __forceinline__ float sigmoid_f(float t) { return 1.0f / (1.0f + __expf(-t)); }
+__device__ __forceinline__ float sigmoid_f(float t) { return __builtin_amdgcn_rcpf(1.0f + __expf(-t)); }  // v_rcp_f32: 1 ulp
 
 }  // namespace d3p

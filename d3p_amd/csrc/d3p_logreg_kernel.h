@@ -602,7 +602,8 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
 
             if (MODE != 1) {
                 // clip factor 1/max(1, ||g||/C) (svi.py:121-122) folded into the running sum (svi.py:343-346)
-                const float cf = 1.0f / fmaxf(1.0f, __fsqrt_rn(n2) / a.clip);
+                // = min(1, C / ||g||) with the hardware reciprocal square root (1 ulp; ||g|| = 0 gives min(1, inf) = 1)
+                const float cf = fminf(1.0f, a.clip * __builtin_amdgcn_rsqf(n2));
 #pragma unroll
                 for (int n = 0; n < NC; ++n) {
                     accg0[n] = __fmaf_rn(cf, g0[n], accg0[n]);
