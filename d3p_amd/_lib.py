@@ -117,6 +117,7 @@ SIGNATURES = {
     "d3p_dpvi_vae_workspace": (C.c_size_t, [_V, _U32]),
     "d3p_gemm_f32": (C.c_int, [_V, _V, C.c_int64, C.c_int64, _V, C.c_int64, C.c_int64, _V, _I32, _I32, _I32, _I32, _V, _F, _I32]),
     "d3p_vae_step_sums": (C.c_int, [_V, _V, _V, _V, _V, _U32, _V, _V, _F, _V, _V, _V, _V, C.c_size_t]),
+    "d3p_vae_evaluate": (C.c_int, [_V, _V, _V, _V, _U32, _V, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_vae_update": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _V, _V, _V, _V, C.c_size_t]),
     "d3p_comm_unique_id": (C.c_int, [_V, C.c_size_t]),
     "d3p_comm_init": (C.c_int, [_V, C.c_size_t, _I32, _I32, _V]),

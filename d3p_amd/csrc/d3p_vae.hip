@@ -187,6 +187,25 @@ __global__ void k_vae_eps(const uint32_t* __restrict__ jax_key, uint32_t B, int 
     eps[t] = bits_to_normal(tf_iota_word(k0, k1, (uint64_t)Z, (uint64_t)j));
 }
 
+// DPSVI.evaluate: ONE guide draw for the whole batch -- eps = normal(k_z, (B, Z)) with
+// rng_key_eval = split(key)[1], guide_seed = split(.)[1], k_z = split(.)[1]  (numpyro SVI.evaluate / Trace_ELBO / seed handler)
+__global__ void k_vae_eval_eps(const uint32_t* __restrict__ jax_key, uint32_t B, int Z, float* __restrict__ eps)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)B * Z;
+    if (t >= n) return;
+    uint32_t k0 = jax_key[0], k1 = jax_key[1];
+#pragma unroll
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        uint32_t a, b0, b1;
+        threefry2x32(k0, k1, 0u, 2u, a, b0);
+        threefry2x32(k0, k1, 1u, 3u, a, b1);
+        k0 = b0;
+        k1 = b1;
+    }
+    eps[t] = bits_to_normal(tf_iota_word(k0, k1, (uint64_t)n, (uint64_t)t));
+}
+
 // zl, u (B x Z), eps -> z = zl + exp(u) eps (written over zl), sd = exp(u) (written over u), lat[i] = log q - log p
 __global__ void k_vae_latent(float* __restrict__ zl, float* __restrict__ u, const float* __restrict__ eps, uint32_t B, int Z,
                              float* __restrict__ lat)
@@ -413,6 +432,29 @@ static int vae_validate(const d3p_vae_model* m, const char* what)
     return D3P_OK;
 }
 
+// forward pass: activations, the reparametrised latent, da = sc (sigmoid(a) - x) and px_loss[i] = sc (log q - log p - log lik)
+static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const float* params, const float* X, const uint8_t* mask,
+                               uint32_t B, const float* eps, float sc, const VaeWorkspace& ws)
+{
+    int rc;
+    const int D = m->D, H = m->H, Z = m->Z, Bi = (int)B;
+    const VaeLayout L = vae_layout(m);
+    auto ew = [&](size_t n) { return dim3(cdiv(n, 256)); };
+    const dim3 rows(cdiv((uint64_t)B * 64, 256));
+    // ---- encoder (guide)
+    if ((rc = gemm(s, X, D, 1, params + L.W1, H, 1, ws.h1, H, Bi, H, D, params + L.b1, 1.f, 0))) return rc;
+    hipLaunchKernelGGL(k_vae_softplus, ew((size_t)B * H), dim3(256), 0, s, ws.h1, ws.sg1, (size_t)B * H);
+    if ((rc = gemm(s, ws.h1, H, 1, params + L.Wl, Z, 1, ws.zl, Z, Bi, Z, H, params + L.bl, 1.f, 0))) return rc;
+    if ((rc = gemm(s, ws.h1, H, 1, params + L.Ws, Z, 1, ws.u, Z, Bi, Z, H, params + L.bs, 1.f, 0))) return rc;
+    hipLaunchKernelGGL(k_vae_latent, rows, dim3(256), 0, s, ws.zl, ws.u, eps, B, Z, ws.lat);  // zl := z, u := sd
+    // ---- decoder (model)
+    if ((rc = gemm(s, ws.zl, Z, 1, params + L.V1, H, 1, ws.h2, H, Bi, H, Z, params + L.c1, 1.f, 0))) return rc;
+    hipLaunchKernelGGL(k_vae_softplus, ew((size_t)B * H), dim3(256), 0, s, ws.h2, ws.sg2, (size_t)B * H);
+    if ((rc = gemm(s, ws.h2, H, 1, params + L.V2, D, 1, ws.a, D, Bi, D, H, params + L.c2, 1.f, 0))) return rc;
+    hipLaunchKernelGGL(k_vae_out, rows, dim3(256), 0, s, ws.a, X, mask, B, D, sc, (const float*)ws.lat, ws.px_loss);  // a := da
+    return check_launch("d3p_vae forward");
+}
+
 // forward + backward + norms + clipped sums into ws.sums[P + 2]; eps_dev given or drawn from jax_key
 static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* params, const float* X, const uint8_t* mask,
                             uint32_t B, const float* eps_ext, const uint32_t* jax_key, float clip, const VaeWorkspace& ws,
@@ -429,17 +471,7 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     }
     auto ew = [&](size_t n) { return dim3(cdiv(n, 256)); };
     const dim3 rows(cdiv((uint64_t)B * 64, 256));
-    // ---- encoder (guide)
-    if ((rc = gemm(s, X, D, 1, params + L.W1, H, 1, ws.h1, H, Bi, H, D, params + L.b1, 1.f, 0))) return rc;
-    hipLaunchKernelGGL(k_vae_softplus, ew((size_t)B * H), dim3(256), 0, s, ws.h1, ws.sg1, (size_t)B * H);
-    if ((rc = gemm(s, ws.h1, H, 1, params + L.Wl, Z, 1, ws.zl, Z, Bi, Z, H, params + L.bl, 1.f, 0))) return rc;
-    if ((rc = gemm(s, ws.h1, H, 1, params + L.Ws, Z, 1, ws.u, Z, Bi, Z, H, params + L.bs, 1.f, 0))) return rc;
-    hipLaunchKernelGGL(k_vae_latent, rows, dim3(256), 0, s, ws.zl, ws.u, eps, B, Z, ws.lat);  // zl := z, u := sd
-    // ---- decoder (model)
-    if ((rc = gemm(s, ws.zl, Z, 1, params + L.V1, H, 1, ws.h2, H, Bi, H, Z, params + L.c1, 1.f, 0))) return rc;
-    hipLaunchKernelGGL(k_vae_softplus, ew((size_t)B * H), dim3(256), 0, s, ws.h2, ws.sg2, (size_t)B * H);
-    if ((rc = gemm(s, ws.h2, H, 1, params + L.V2, D, 1, ws.a, D, Bi, D, H, params + L.c2, 1.f, 0))) return rc;
-    hipLaunchKernelGGL(k_vae_out, rows, dim3(256), 0, s, ws.a, X, mask, B, D, sc, (const float*)ws.lat, ws.px_loss);  // a := da
+    if ((rc = vae_enqueue_forward(s, m, params, X, mask, B, eps, sc, ws))) return rc;
     // ---- backward (data)
     if ((rc = gemm(s, ws.a, D, 1, params + L.V2, 1, D, ws.dh2, H, Bi, H, D, nullptr, 1.f, 0))) return rc;  // da V2^T
     hipLaunchKernelGGL(k_vae_mul, ew((size_t)B * H), dim3(256), 0, s, ws.dh2, (const float*)ws.sg2, (size_t)B * H);  // dpre2
@@ -516,6 +548,28 @@ int d3p_vae_step_sums(void* stream, const d3p_vae_model* model, const float* par
     D3P_HIP_TRY(hipMemcpyAsync(sums_dev, ws.sums, (P + 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (px_loss_dev) D3P_HIP_TRY(hipMemcpyAsync(px_loss_dev, ws.px_loss, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
     return D3P_OK;
+}
+
+int d3p_vae_evaluate(void* stream, const d3p_vae_model* model, const float* params_dev, const float* X_dev, uint32_t B,
+                     const uint32_t* jax_key_dev, const float* eps_dev, float* loss_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    if (int rc = vae_validate(model, "d3p_vae_evaluate")) return rc;
+    D3P_REQUIRE(params_dev && X_dev && loss_dev && workspace_dev && (jax_key_dev || eps_dev), "d3p_vae_evaluate: null pointer");
+    D3P_REQUIRE(B >= 1, "d3p_vae_evaluate: B must be >= 1");
+    if (workspace_bytes < d3p_dpvi_vae_workspace(model, B)) return fail(D3P_E_WORKSPACE, "d3p_vae_evaluate: workspace too small");
+    VaeWorkspace ws;
+    vae_carve(model, B, (char*)workspace_dev, &ws);
+    hipStream_t s = (hipStream_t)stream;
+    const float* eps = eps_dev;
+    if (!eps) {
+        hipLaunchKernelGGL(k_vae_eval_eps, dim3(cdiv((uint64_t)B * model->Z, 256)), dim3(256), 0, s, jax_key_dev, B, model->Z, ws.eps);
+        eps = ws.eps;
+    }
+    if (int rc = vae_enqueue_forward(s, model, params_dev, X_dev, nullptr, B, eps, model->inv_obs * model->scale, ws)) return rc;
+    const size_t P = vae_layout(model).P;
+    hipLaunchKernelGGL(k_vae_loss_n, dim3(1), dim3(256), 0, s, (const float*)ws.px_loss, (const uint8_t*)nullptr, B, ws.sums + P);
+    D3P_HIP_TRY(hipMemcpyAsync(loss_dev, ws.sums + P, sizeof(float), hipMemcpyDeviceToDevice, s));
+    return check_launch("d3p_vae_evaluate");
 }
 
 int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,

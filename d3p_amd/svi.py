@@ -703,6 +703,20 @@ class DPSVI:
     # ---------------------------------------------------------------- evaluate / accounting
     def evaluate(self, svi_state, *args, **kwargs):
         """ELBO loss of a batch at the current parameters (d3p/svi.py:436-449 -> numpyro SVI.evaluate)."""
+        if self._is_vae():
+            _lib.require_device()
+            lib = _lib.load()
+            X = self._vae_flat(args[0])
+            B, D = X.shape
+            jax_rng_key = self._rng_suite.convert_to_jax_rng_key(self._rng_suite.split(svi_state.rng_key, 1)[0]).contiguous()
+            params = self.optim.get_params(svi_state.optim_state).contiguous()
+            vm = self._vae_struct(D, kwargs, 1.0)
+            vm.scale = vm.scale / B                  # plate(N, B) scales every site by N / B instead of N
+            ws = self._workspace(lib.d3p_dpvi_vae_workspace(C.byref(vm), B), X.device, "vae_step")
+            loss = torch.empty(1, dtype=torch.float32, device=X.device)
+            check(lib.d3p_vae_evaluate(stream_ptr(), C.byref(vm), ptr(params), ptr(X), B, ptr(jax_rng_key),
+                                       ptr(kwargs.get("_eps")), ptr(loss), ptr(ws), ws.numel()))
+            return loss[0]
         if self._is_gmm():
             _lib.require_device()
             lib = _lib.load()

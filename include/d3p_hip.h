@@ -434,6 +434,13 @@ int d3p_vae_step_sums(void* stream, const d3p_vae_model* model, const float* par
                       float* sums_dev, float* norms_dev, float* px_loss_dev, void* workspace_dev,
                       size_t workspace_bytes);
 
+/* DPSVI.evaluate (svi.py:436-449) for the VAE: -ELBO of the batch with one guide draw (eps for all B rows from one key,
+ * jax_key_dev = convert_to_jax_rng_key(split(state.rng_key, 1)[0]); eps_dev optionally overrides it);
+ * model->scale = handlers.scale x num_obs_total / B (the plate scale of the batch), model->inv_obs = 1. */
+int d3p_vae_evaluate(void* stream, const d3p_vae_model* model, const float* params_dev, const float* X_dev, uint32_t B,
+                     const uint32_t* jax_key_dev, const float* eps_dev, float* loss_dev, void* workspace_dev,
+                     size_t workspace_bytes);
+
 /* One DPSVI.update (svi.py:395-434) for the VAE: key split, the fused sums above, one Gaussian-noise key per
  * parameter leaf (svi.py:487-491, 10 leaves), numpyro Adam; state as for the other models (P = d3p_vae_num_params). */
 int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper,

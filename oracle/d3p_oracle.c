@@ -1134,6 +1134,22 @@ D3P_API void d3po_vae_step_sums(const d3po_vae_spec* sp, const float* params, co
     free(acc);
 }
 
+/* DPSVI.evaluate for the VAE: -ELBO of the batch with one guide draw; eps (B x Z) = tf_normal(k_z, B Z) with
+ * k_z = split(split(split(jax_key)[1])[1])[1]; every site is scaled by sp->scale (= handlers.scale x N / B). */
+D3P_API float d3po_vae_evaluate(const d3po_vae_spec* sp, const float* params, const float* X, int B, const uint32_t jax_key[2])
+{
+    uint32_t s[4], k[2] = {jax_key[0], jax_key[1]};
+    for (int lvl = 0; lvl < 3; ++lvl) { d3po_tf_split(k, 2, s); k[0] = s[2]; k[1] = s[3]; }
+    float* eps = (float*)malloc(sizeof(float) * (size_t)B * sp->Z);
+    d3po_tf_normal(k, (uint64_t)B * sp->Z, eps);
+    const int64_t P = d3po_vae_num_params(sp);
+    float* sums = (float*)malloc(sizeof(float) * ((size_t)P + 2));
+    d3po_vae_step_sums(sp, params, X, NULL, B, eps, 1e30f, sums, NULL, NULL);
+    const float loss = sums[P];
+    free(eps); free(sums);
+    return loss;
+}
+
 /* Synthetic logistic-regression table, element (r, c) a pure function of (seed, r, c) so that any
  * shard can be regenerated (mirrors examples/logistic_regression.py:88-104 in
  * distribution): X[r][c] = normal from threefry2x32((seed, 0x58), (r, c))[0];

@@ -66,6 +66,7 @@ def lib():
         _lib.d3po_gmm_px_loss_grad_given.restype = C.c_float
         _lib.d3po_gmm_evaluate.restype = C.c_float
         _lib.d3po_vae_num_params.restype = C.c_int64
+        _lib.d3po_vae_evaluate.restype = C.c_float
     return _lib
 
 
@@ -472,3 +473,9 @@ def vae_step_sums(spec, params, X, eps, clip, mask=None):
     lib().d3po_vae_step_sums(C.byref(spec), _p(_f32(params)), _p(_f32(X)), None if m is None else _p(m), C.c_int(B),
                              _p(_f32(eps)), C.c_float(clip), _p(sums), _p(norms), _p(px_loss))
     return sums, norms, px_loss
+
+
+def vae_evaluate(spec, params, X, jax_key):
+    """DPSVI.evaluate for the VAE; spec.scale = handlers.scale x N / B; jax_key = convert(split(state.rng_key, 1)[0])."""
+    X = _f32(X)
+    return float(lib().d3po_vae_evaluate(C.byref(spec), _p(_f32(params)), _p(X), C.c_int(X.shape[0]), _p(_u32(jax_key))))

@@ -152,3 +152,18 @@ def test_training_reduces_the_loss_on_structured_binary_images(gpu):
         losses.append(float(l))
     assert np.isfinite(losses).all()
     assert np.mean(losses[-20:]) < 0.6 * np.mean(losses[:20])
+
+
+@pytest.mark.parametrize("B,D,H,Z", [(6, 12, 7, 3), (64, 784, 400, 50)])
+def test_evaluate_vs_oracle(gpu, O, B, D, H, Z):
+    import d3p_amd.random as rng
+    from d3p_amd.svi import DPSVIState
+    N = 60000
+    _, P, params, X, _ = vae_problem(B, D, H, Z, 5, 0.03 if D > 100 else 0.3)
+    svi = make_svi(Z, H, N)
+    st = DPSVIState(svi.optim.init(torch.tensor(params).cuda()), rng.PRNGKey(31), 1.0)
+    got = float(svi.evaluate(st, torch.tensor(X).cuda()))
+    spec = O.vae_spec(D, H, Z, scale=1.0 / B, obs_scale=1.0)          # (1 / N) x (N / B)
+    jax_key = O.convert_to_jax_rng_key(O.split(O.PRNGKey(31), 1)[0])
+    exp = O.vae_evaluate(spec, params, X, jax_key)
+    assert abs(got - exp) <= 3e-5 * abs(exp)
