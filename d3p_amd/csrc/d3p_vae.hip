@@ -39,7 +39,24 @@ struct GemmArgs {
     int a_last_one;   // row M - 1 of op(A) is all ones (bias gradients ride along with the weight gradients)
     int k_per;        // K range of one split (multiple of D3P_GK); gridDim.z splits
     float* part;      // split-K partial tiles [gridDim.z][M][N] (nullable when gridDim.z == 1)
+    int epi;          // epilogue: 0 store; 1 softplus (C = softplus(o), C2 = sigmoid(o) = its derivative); 2 C = o * C2
+    float* C2;        // second operand / output of the epilogue, same shape and leading dimension as C
 };
+
+// o = alpha * acc + bias (+ C); then the epilogue
+__device__ __forceinline__ void gemm_store(const GemmArgs& g, int row, int col, float acc, float bv)
+{
+    const size_t e = (size_t)row * g.ldc + col;
+    float o = __fmaf_rn(g.alpha, acc, bv);
+    if (g.accumulate) o += g.C[e];
+    if (g.epi == 1) {
+        g.C2[e] = 1.0f / (1.0f + expf(-o));
+        o = fmaxf(o, 0.0f) + log1pf(expf(-fabsf(o)));
+    } else if (g.epi == 2) {
+        o *= g.C2[e];
+    }
+    g.C[e] = o;
+}
 
 #define D3P_GT 64  // tile edge
 #define D3P_GK 16  // K slice
@@ -109,12 +126,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int row = m0 + wm * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
-        if (row < g.M) {
-            float* c = g.C + (size_t)row * g.ldc + col;
-            float o = __fmaf_rn(g.alpha, acc[v], bv);
-            if (g.accumulate) o += *c;
-            *c = o;
-        }
+        if (row < g.M) gemm_store(g, row, col, acc[v], bv);
     }
 }
 
@@ -125,17 +137,14 @@ __global__ void k_gemm_reduce(GemmArgs g, int splits)
     const int row = (int)(t / g.N), col = (int)(t % g.N);
     float s = 0.f;
     for (int z = 0; z < splits; ++z) s += g.part[(size_t)z * g.M * g.N + t];  // fixed order
-    float* c = g.C + (size_t)row * g.ldc + col;
-    float o = __fmaf_rn(g.alpha, s, g.bias ? g.bias[col] : 0.f);
-    if (g.accumulate) o += *c;
-    *c = o;
+    gemm_store(g, row, col, s, g.bias ? g.bias[col] : 0.f);
 }
 
 // part / part_floats: optional split-K scratch.  The split count is chosen so that short grids (the weight-gradient
 // GEMMs: K = batch, M x N = a weight matrix) still put a few workgroups on every CU.
 static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, const float* B, long long b_sk, long long b_sn,
                 float* C, int ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, int a_last_one = 0,
-                float* part = nullptr, size_t part_floats = 0)
+                float* part = nullptr, size_t part_floats = 0, int epi = 0, float* C2 = nullptr)
 {
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias;
@@ -143,12 +152,15 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     g.a_sm = a_sm; g.a_sk = a_sk; g.b_sk = b_sk; g.b_sn = b_sn;
     g.ldc = ldc; g.alpha = alpha; g.accumulate = accumulate;
     g.a_last_one = a_last_one;
+    g.epi = epi;
+    g.C2 = C2;
     const unsigned tiles = cdiv(N, D3P_GT) * cdiv(M, D3P_GT);
     int splits = 1;
     if (part && tiles < 512 && K >= 8 * D3P_GK) {
         splits = (int)((1024 + tiles - 1) / tiles);
         const int max_by_k = K / (4 * D3P_GK);
         if (splits > max_by_k) splits = max_by_k;
+        if (splits > 16) splits = 16;  // the reduction adds the partial tiles serially
         const size_t max_by_mem = part_floats / ((size_t)M * N);
         if ((size_t)splits > max_by_mem) splits = (int)max_by_mem;
         if (splits < 1) splits = 1;
@@ -166,16 +178,6 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
 // ------------------------------------------------------------------------------------------------------------------
 // row-wise / element-wise stages
 // ------------------------------------------------------------------------------------------------------------------
-// pre (B x H, bias already added) -> h = softplus(pre) in place, sg = sigmoid(pre) (softplus')
-__global__ void k_vae_softplus(float* __restrict__ h, float* __restrict__ sg, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float t = h[i];
-    h[i] = fmaxf(t, 0.0f) + log1pf(expf(-fabsf(t)));
-    sg[i] = 1.0f / (1.0f + expf(-t));
-}
-
 // per-example guide noise: eps[i][j] = normal word j of the example's sample key (svi.py:289-290; single site 'z')
 __global__ void k_vae_eps(const uint32_t* __restrict__ jax_key, uint32_t B, int Z, float* __restrict__ eps)
 {
@@ -244,13 +246,6 @@ __global__ void k_vae_out(float* __restrict__ a, const float* __restrict__ X, co
     if (lane == 0) px_loss[i] = (mask && mask[i] == 0) ? 0.f : sc * (lat[i] - ll);
 }
 
-// d *= sg   (delta through a softplus layer)
-__global__ void k_vae_mul(float* __restrict__ d, const float* __restrict__ sg, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) d[i] *= sg[i];
-}
-
 // dzraw (B x Z) = dpre2 V1^T  ->  dz = dzraw + sc z,  du = dz sd eps - sc
 __global__ void k_vae_dlatent(float* __restrict__ dz, float* __restrict__ du, const float* __restrict__ z,
                               const float* __restrict__ sd, const float* __restrict__ eps, size_t n, float sc)
@@ -298,14 +293,6 @@ __global__ void k_vae_norms(NormArgs a)
         a.cf[i] = live ? 1.0f / fmaxf(1.0f, nrm / a.clip) : 0.f;  // svi.py:121-122; masked rows contribute nothing
         if (a.norms) a.norms[i] = live ? nrm : 0.f;
     }
-}
-
-// rows of d (B x n) scaled by cf[i]
-__global__ void k_vae_scale_rows(float* __restrict__ d, const float* __restrict__ cf, uint32_t B, int n)
-{
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)B * n) return;
-    d[t] *= cf[t / n];
 }
 
 // sums[P] = sum_i px_loss[i], sums[P + 1] = number of unmasked examples (one workgroup, fixed order)
@@ -362,6 +349,55 @@ __global__ void k_vae_finalize(VaeFinalArgs a)
     a.params[col] -= a.h.lr * mhat / (sqrtf(vhat) + a.h.adam_eps);
     a.adam_m[col] = m;
     a.adam_v[col] = v;
+}
+
+// Gaussian-mechanism noise for all 10 parameter leaves in one launch: leaf k draws normal(site_key_k, leaf shape)
+// (svi.py:487-491), i.e. word w of ChaCha block b of key k is element 16 b + w of that leaf.
+struct SiteNoiseArgs {
+    const uint32_t* site_keys;   // 10 x 16
+    uint32_t blk_off[11];        // prefix sums of ceil(leaf size / 16)
+    uint32_t elem_off[11];       // prefix sums of the leaf sizes
+    float* noise;
+};
+
+__global__ void __launch_bounds__(256) k_vae_site_noise(SiteNoiseArgs a)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.blk_off[10]) return;
+    int site = 0;
+#pragma unroll
+    for (int k = 1; k < 10; ++k) site += (b >= a.blk_off[k]) ? 1 : 0;
+    const uint32_t lb = b - a.blk_off[site], n_site = a.elem_off[site + 1] - a.elem_off[site];
+    uint32_t key[16], o[16];
+    load_key(a.site_keys + 16 * site, key);
+    keystream_block(key, lb, o);
+    float* dst = a.noise + a.elem_off[site];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t e = 16u * lb + w;
+        if (e < n_site) dst[e] = bits_to_normal(o[w]);
+    }
+}
+
+// rows of the five delta arrays scaled by the clip factors in one launch
+struct ScaleArgs {
+    float* d[5];
+    int n[5];
+    uint32_t off[6];  // prefix sums of B * n[k]
+    const float* cf;
+};
+
+__global__ void __launch_bounds__(256) k_vae_scale_all(ScaleArgs a)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.off[5]) return;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 5; ++j) k += (t >= a.off[j]) ? 1 : 0;
+    const uint32_t e = t - a.off[k];
+    float* d = k == 0 ? a.d[0] : k == 1 ? a.d[1] : k == 2 ? a.d[2] : k == 3 ? a.d[3] : a.d[4];
+    const int n = k == 0 ? a.n[0] : k == 1 ? a.n[1] : k == 2 ? a.n[2] : k == 3 ? a.n[3] : a.n[4];
+    d[e] *= a.cf[e / (uint32_t)n];
 }
 
 __global__ void k_vae_incr(int32_t* step) { *step += 1; }
@@ -442,14 +478,12 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
     auto ew = [&](size_t n) { return dim3(cdiv(n, 256)); };
     const dim3 rows(cdiv((uint64_t)B * 64, 256));
     // ---- encoder (guide)
-    if ((rc = gemm(s, X, D, 1, params + L.W1, H, 1, ws.h1, H, Bi, H, D, params + L.b1, 1.f, 0))) return rc;
-    hipLaunchKernelGGL(k_vae_softplus, ew((size_t)B * H), dim3(256), 0, s, ws.h1, ws.sg1, (size_t)B * H);
+    if ((rc = gemm(s, X, D, 1, params + L.W1, H, 1, ws.h1, H, Bi, H, D, params + L.b1, 1.f, 0, 0, nullptr, 0, 1, ws.sg1))) return rc;
     if ((rc = gemm(s, ws.h1, H, 1, params + L.Wl, Z, 1, ws.zl, Z, Bi, Z, H, params + L.bl, 1.f, 0))) return rc;
     if ((rc = gemm(s, ws.h1, H, 1, params + L.Ws, Z, 1, ws.u, Z, Bi, Z, H, params + L.bs, 1.f, 0))) return rc;
     hipLaunchKernelGGL(k_vae_latent, rows, dim3(256), 0, s, ws.zl, ws.u, eps, B, Z, ws.lat);  // zl := z, u := sd
     // ---- decoder (model)
-    if ((rc = gemm(s, ws.zl, Z, 1, params + L.V1, H, 1, ws.h2, H, Bi, H, Z, params + L.c1, 1.f, 0))) return rc;
-    hipLaunchKernelGGL(k_vae_softplus, ew((size_t)B * H), dim3(256), 0, s, ws.h2, ws.sg2, (size_t)B * H);
+    if ((rc = gemm(s, ws.zl, Z, 1, params + L.V1, H, 1, ws.h2, H, Bi, H, Z, params + L.c1, 1.f, 0, 0, nullptr, 0, 1, ws.sg2))) return rc;
     if ((rc = gemm(s, ws.h2, H, 1, params + L.V2, D, 1, ws.a, D, Bi, D, H, params + L.c2, 1.f, 0))) return rc;
     hipLaunchKernelGGL(k_vae_out, rows, dim3(256), 0, s, ws.a, X, mask, B, D, sc, (const float*)ws.lat, ws.px_loss);  // a := da
     return check_launch("d3p_vae forward");
@@ -473,25 +507,27 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     const dim3 rows(cdiv((uint64_t)B * 64, 256));
     if ((rc = vae_enqueue_forward(s, m, params, X, mask, B, eps, sc, ws))) return rc;
     // ---- backward (data)
-    if ((rc = gemm(s, ws.a, D, 1, params + L.V2, 1, D, ws.dh2, H, Bi, H, D, nullptr, 1.f, 0))) return rc;  // da V2^T
-    hipLaunchKernelGGL(k_vae_mul, ew((size_t)B * H), dim3(256), 0, s, ws.dh2, (const float*)ws.sg2, (size_t)B * H);  // dpre2
+    if ((rc = gemm(s, ws.a, D, 1, params + L.V2, 1, D, ws.dh2, H, Bi, H, D, nullptr, 1.f, 0, 0, nullptr, 0, 2, ws.sg2))) return rc;  // dpre2 = (da V2^T) . softplus'(pre2)
     if ((rc = gemm(s, ws.dh2, H, 1, params + L.V1, 1, H, ws.dz, Z, Bi, Z, H, nullptr, 1.f, 0))) return rc;  // dpre2 V1^T
     hipLaunchKernelGGL(k_vae_dlatent, ew((size_t)B * Z), dim3(256), 0, s, ws.dz, ws.du, (const float*)ws.zl, (const float*)ws.u, eps,
                        (size_t)B * Z, sc);
     if ((rc = gemm(s, ws.dz, Z, 1, params + L.Wl, 1, Z, ws.dh1, H, Bi, H, Z, nullptr, 1.f, 0))) return rc;  // dz Wl^T
-    if ((rc = gemm(s, ws.du, Z, 1, params + L.Ws, 1, Z, ws.dh1, H, Bi, H, Z, nullptr, 1.f, 1))) return rc;  // + du Ws^T
-    hipLaunchKernelGGL(k_vae_mul, ew((size_t)B * H), dim3(256), 0, s, ws.dh1, (const float*)ws.sg1, (size_t)B * H);  // dpre1
+    if ((rc = gemm(s, ws.du, Z, 1, params + L.Ws, 1, Z, ws.dh1, H, Bi, H, Z, nullptr, 1.f, 1, 0, nullptr, 0, 2, ws.sg1))) return rc;  // dpre1 = (dz Wl^T + du Ws^T) . softplus'(pre1)
     // ---- per-example norms and clip factors, rows of every delta scaled by c_i
     NormArgs na;
     na.X = X; na.h1 = ws.h1; na.z = ws.zl; na.h2 = ws.h2;
     na.dpre1 = ws.dh1; na.dz = ws.dz; na.du = ws.du; na.dpre2 = ws.dh2; na.da = ws.a;
     na.mask = mask; na.B = B; na.D = D; na.H = H; na.Z = Z; na.clip = clip; na.cf = ws.cf; na.norms = norms_out;
     hipLaunchKernelGGL(k_vae_norms, rows, dim3(256), 0, s, na);
-    hipLaunchKernelGGL(k_vae_scale_rows, ew((size_t)B * D), dim3(256), 0, s, ws.a, (const float*)ws.cf, B, D);
-    hipLaunchKernelGGL(k_vae_scale_rows, ew((size_t)B * H), dim3(256), 0, s, ws.dh2, (const float*)ws.cf, B, H);
-    hipLaunchKernelGGL(k_vae_scale_rows, ew((size_t)B * Z), dim3(256), 0, s, ws.dz, (const float*)ws.cf, B, Z);
-    hipLaunchKernelGGL(k_vae_scale_rows, ew((size_t)B * Z), dim3(256), 0, s, ws.du, (const float*)ws.cf, B, Z);
-    hipLaunchKernelGGL(k_vae_scale_rows, ew((size_t)B * H), dim3(256), 0, s, ws.dh1, (const float*)ws.cf, B, H);
+    {
+        ScaleArgs sa;
+        float* arrs[5] = {ws.a, ws.dh2, ws.dz, ws.du, ws.dh1};
+        const int widths[5] = {D, H, Z, Z, H};
+        sa.off[0] = 0;
+        for (int k = 0; k < 5; ++k) { sa.d[k] = arrs[k]; sa.n[k] = widths[k]; sa.off[k + 1] = sa.off[k] + B * (uint32_t)widths[k]; }
+        sa.cf = ws.cf;
+        hipLaunchKernelGGL(k_vae_scale_all, dim3(cdiv(sa.off[5], 256)), dim3(256), 0, s, sa);
+    }
     // ---- clipped sums: weights  A^T (diag(c) Delta)  (GEMMs over the batch), biases = column sums
     // [W | b] of every layer is contiguous in the flat layout, so the bias gradient is row `in` of a GEMM whose A carries a
     // virtual row of ones
@@ -596,9 +632,19 @@ int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsv
     if ((rc = d3p_rng_split(s, state->rng_key + 16 * slot, 3, split3))) return rc;
     if ((rc = d3p_rng_random_bits(s, split3 + 16, 32, 2, jax_key))) return rc;
     if ((rc = d3p_rng_split(s, split3 + 32, 10, site_keys))) return rc;
-    const size_t leaf_off[11] = {L.V1, L.c1, L.V2, L.c2, L.W1, L.b1, L.Wl, L.bl, L.Ws, L.bs, L.P};
-    for (int k = 0; k < 10; ++k)  // one key per leaf, normal(site_key, leaf shape) (svi.py:487)
-        if ((rc = d3p_rng_normal(s, site_keys + 16 * k, (uint64_t)(leaf_off[k + 1] - leaf_off[k]), ws.noise + leaf_off[k]))) return rc;
+    {
+        const size_t leaf_off[11] = {L.V1, L.c1, L.V2, L.c2, L.W1, L.b1, L.Wl, L.bl, L.Ws, L.bs, L.P};
+        SiteNoiseArgs na;  // one key per leaf, normal(site_key, leaf shape) (svi.py:487)
+        na.site_keys = site_keys;
+        na.noise = ws.noise;
+        na.blk_off[0] = 0;
+        for (int k = 0; k < 10; ++k) {
+            na.elem_off[k] = (uint32_t)leaf_off[k];
+            na.blk_off[k + 1] = na.blk_off[k] + (uint32_t)((leaf_off[k + 1] - leaf_off[k] + 15) / 16);
+        }
+        na.elem_off[10] = (uint32_t)leaf_off[10];
+        hipLaunchKernelGGL(k_vae_site_noise, dim3(cdiv(na.blk_off[10], 256)), dim3(256), 0, s, na);
+    }
     if ((rc = vae_enqueue_sums(s, model, state->params, X_dev, mask_dev, B, eps_dev, jax_key, hyper->clip, ws, nullptr))) return rc;
     VaeFinalArgs f;
     f.sums = ws.sums;
