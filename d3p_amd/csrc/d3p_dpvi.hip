@@ -14,20 +14,15 @@
 //   k_finalize    : deterministic reduction of the per-workgroup partial rows, mean, Gaussian
 //                   mechanism, rescale (svi.py:350-377), Adam (svi.py:379-393), derived columns
 //
-// Pipelined variant (default for Feistel subsampling, d3p_dpvi_logreg_run): the main kernel is bound
-// by VALU issue, 60 % of it the generation of the guide noise eps, while k_finalize keeps only 16 of
-// 256 CUs busy.  k_carrier therefore runs k_finalize's work for step u next to workgroups that do
-// the parameter-independent work of LATER steps: key chain (u+4), derived keys (u+3), sample keys +
-// Gaussian-mechanism normals (u+2), Feistel indices + eps (u+1).  The main kernel then only
-// gathers X, reads eps and does the parameter-dependent arithmetic.
+// One launch per step (default): the MODE-2 step kernel accumulates the clipped sums with 64-bit fixed-point atomics
+// and the NEXT launch's prologue applies mean / noise / Adam (d3p_logreg_kernel.h), so k_finalize disappears from the
+// per-step path; the key-chain step of the next batch rides along as one extra workgroup.
 #include "d3p_logreg_kernel.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only: the entry points are resolved at run time from the RCCL torch has loaded
 
 #define D3P_STEP_BATCH 32
-#define D3P_RING 8        // ring of step slots used by the pipelined run loop (> look-ahead)
-#define D3P_LOOKAHEAD 4
 
 namespace d3p {
 
@@ -39,7 +34,6 @@ struct Workspace {
     uint32_t* skeys;  // D3P_STEP_BATCH x 2B
     uint32_t* plist;  // D3P_STEP_BATCH x B: dense owned-position lists
     float* noise;     // D3P_STEP_BATCH x P
-    float* eps;       // B x D: guide noise of the NEXT step, staged by k_carrier
     long long* acc;   // 3 x D3P_ACC_R x (P + 2) fixed-point accumulators of the one-launch step
     float* scratch_state;  // 3P + 4 floats: stand-in state for the timing entry point
     float* pp_state;       // 3P floats: second buffer of the ping-ponged optimiser state (one-launch-per-step path)
@@ -63,7 +57,6 @@ static size_t carve(const d3p_logreg_model* m, const d3p_batch_source* src, char
     p = take(K * 2 * B * sizeof(uint32_t)); if (ws) ws->skeys = (uint32_t*)p;
     p = take(K * B * sizeof(uint32_t)); if (ws) ws->plist = (uint32_t*)p;
     p = take(K * P * sizeof(float)); if (ws) ws->noise = (float*)p;
-    p = take(B * D * sizeof(float)); if (ws) ws->eps = (float*)p;
     p = take(3 * (size_t)D3P_ACC_R * (P + 2) * sizeof(long long)); if (ws) ws->acc = (long long*)p;
     p = take((3 * P + 4) * sizeof(float)); if (ws) ws->scratch_state = (float*)p;
     p = take(3 * P * sizeof(float)); if (ws) ws->pp_state = (float*)p;
@@ -453,205 +446,6 @@ __global__ void __launch_bounds__(1024) k_finalize(FinalArgs a, uint32_t n_fin)
 }
 
 // ------------------------------------------------------------------------------------------
-// carrier kernel: finalize of step u + parameter-independent stages of later steps
-// ------------------------------------------------------------------------------------------
-struct CarrierArgs {
-    FinalArgs fin;
-    int n_fin;           // finalize workgroups (0: no finalize in this launch)
-    Sched* sched;
-    StepSlot* slots;     // ring of D3P_RING
-    const uint32_t* bkey;
-    uint32_t* skeys;     // ring x 2B
-    float* noise;        // ring x P
-    uint32_t* idx;       // B (next step)
-    float* eps;          // B x D (next step)
-    int tA, tB, tC, tD;  // step (relative to the start of the run) each stage works on, -1 = idle
-    uint32_t B;
-    int D;
-    uint32_t capacity;
-    int bits_lower, bits_upper;
-    float b1, b2;
-    int n_idx_wg, n_eps_wg, n_sk_wg;
-};
-
-// stage A: (next, gradient, perturbation) = split(chain_key, 3)   (svi.py:208-211, :413-414)
-__device__ __forceinline__ void stage_chain(Sched* sched, StepSlot* slot, int t)
-{
-    const int lane = threadIdx.x & 63;
-    uint32_t cur[16], child[16];
-    load_key(sched->key, cur);
-    const int32_t adam0 = sched->adam_i;
-    const uint32_t batch0 = sched->batch_i;
-    derive_child(cur, (uint32_t)(lane < 3 ? lane : 0), 0u, D3P_TAG_SPLIT, child);
-    uint32_t* dst = lane == 0 ? slot->next_key : (lane == 1 ? slot->grad_key : slot->pert_key);
-    if (lane < 3) {
-#pragma unroll
-        for (int w = 0; w < 16; ++w) dst[w] = child[w];
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int w = 0; w < 16; ++w) sched->key[w] = child[w];
-    } else if (lane == 3) {
-        slot->adam_i = adam0 + t;
-        slot->batch_i = batch0 + (uint32_t)t;
-    }
-}
-
-// stage B: jax key, per-site keys, batch key -- one ChaCha block each, four lanes of one wave
-__device__ __forceinline__ void stage_keys(StepSlot* slot, const uint32_t* __restrict__ bkey)
-{
-    const int lane = threadIdx.x & 63;
-    if (lane == 0) {  // convert_to_jax_rng_key(gradient_key) (svi.py:259; random/__init__.py:155)
-        uint32_t k[16], o[16];
-        load_key(slot->grad_key, k);
-        keystream_block(k, 0u, o);
-        slot->jax_key[0] = o[0];
-        slot->jax_key[1] = o[1];
-    } else if (lane == 1 || lane == 2) {  // split(perturbation_key, 2) (svi.py:491)
-        uint32_t k[16], c[16];
-        load_key(slot->pert_key, k);
-        derive_child(k, (uint32_t)(lane - 1), 0u, D3P_TAG_SPLIT, c);
-#pragma unroll
-        for (int w = 0; w < 16; ++w) slot->site_keys[lane - 1][w] = c[w];
-    } else if (lane == 3 && bkey) {  // fold_in(batchifier_state, i) (minibatch.py:230)
-        uint32_t k[16], c[16];
-        load_key(bkey, k);
-        derive_child(k, 0u, slot->batch_i, D3P_TAG_FOLD, c);
-#pragma unroll
-        for (int w = 0; w < 16; ++w) slot->batch_key[w] = c[w];
-    }
-}
-
-// stage C: Feistel round constants, Gaussian-mechanism normals, Adam bias terms, sample keys
-__device__ __forceinline__ void stage_derive(const CarrierArgs& a, StepSlot* slot, uint32_t* skeys, float* noise)
-{
-    const int tid = threadIdx.x;
-    if (tid < 2) {  // round constants (util.py:240-246)
-        uint32_t k[16], o[16];
-        load_key(slot->batch_key, k);
-        keystream_block(k, (uint32_t)tid, o);
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int g = 16 * tid + w;
-            if (g < 30) slot->rc[g] = (g % 3 == 0) ? (o[w] | 1u) : o[w];
-        }
-    } else if (tid == 63) {
-        slot->counts[0] = a.B;
-        slot->counts[1] = a.B;
-        const float ip1 = (float)(slot->adam_i + 1);
-        slot->bc1 = 1.0f - powf(a.b1, ip1);
-        slot->bc2 = 1.0f - powf(a.b2, ip1);
-    }
-    const int blocks_per_site = (a.D + 15) / 16;
-    for (int j = tid - 64; j >= 0 && j < 2 * blocks_per_site; j += (int)blockDim.x) {  // svi.py:487
-        const int site = j / blocks_per_site, b = j % blocks_per_site;
-        uint32_t k[16], o[16];
-        load_key(slot->site_keys[site], k);
-        keystream_block(k, (uint32_t)b, o);
-        float* dst = noise + (size_t)site * a.D;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int e = 16 * b + w;
-            if (e < a.D) dst[e] = bits_to_normal(o[w]);
-        }
-    }
-}
-
-// stage C (sample keys): 256 positions per workgroup on 4 of its waves -- six dependent threefry calls per
-// position, so few waves per SIMD finish soonest   (svi.py:289-290 + numpyro key plumbing)
-__device__ __forceinline__ void stage_sample_keys(const StepSlot* slot, uint32_t* __restrict__ skeys, uint32_t B,
-                                                  uint32_t wg)
-{
-    if (threadIdx.x >= 256) return;
-    const uint32_t p = wg * 256 + threadIdx.x;
-    if (p >= B) return;
-    uint32_t s0, s1;
-    px_sample_key(slot->jax_key[0], slot->jax_key[1], B, p, s0, s1);
-    skeys[2 * p] = s0;
-    skeys[2 * p + 1] = s1;
-}
-
-// stage D (eps): one wavefront per example, jax.random.normal(sample_key, (D,)) in JAX's word layout
-__device__ __forceinline__ void stage_eps(const uint32_t* __restrict__ skeys, float* __restrict__ eps, uint32_t B, int D,
-                                          uint32_t wg, uint32_t n_wg)
-{
-    const int lane = threadIdx.x & 63;
-    const uint32_t waves = blockDim.x >> 6;
-    for (uint32_t p = wg * waves + (threadIdx.x >> 6); p < B; p += n_wg * waves) {
-    const uint32_t k0 = skeys[2 * p], k1 = skeys[2 * p + 1];
-    const int half = (D + 1) >> 1;
-    float* row = eps + (size_t)p * D;
-    if ((D & 7) == 0 && (half & 255) == 0) {  // 16-byte stores: lane owns pairs 4l..4l+3 (+256k); all lanes active
-        for (int j = 4 * lane; j < half; j += 256) {
-            float v0[4], v1[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t b0, b1;
-                threefry2x32(k0, k1, (uint32_t)(j + i), (uint32_t)(j + i + half), b0, b1);
-                v0[i] = bits_to_normal_wu(b0);
-                v1[i] = bits_to_normal_wu(b1);
-            }
-            *reinterpret_cast<float4*>(row + j) = make_float4(v0[0], v0[1], v0[2], v0[3]);
-            *reinterpret_cast<float4*>(row + j + half) = make_float4(v1[0], v1[1], v1[2], v1[3]);
-        }
-    } else {
-        for (int j0 = 0; j0 < half; j0 += 64) {  // all lanes iterate together (wave-uniform erf_inv tail)
-            const int j = j0 + lane;
-            const bool ok = j < half, ok1 = ok && (j + half < D);
-            uint32_t b0, b1;
-            threefry2x32(k0, k1, (uint32_t)j, ok1 ? (uint32_t)(j + half) : 0u, b0, b1);
-            const float v0 = bits_to_normal_wu(b0), v1 = bits_to_normal_wu(b1);
-            if (ok) row[j] = v0;
-            if (ok1) row[j + half] = v1;
-        }
-    }
-    }
-}
-
-__global__ void __launch_bounds__(1024) k_carrier(CarrierArgs a)
-{
-    __shared__ float lds[D3P_FIN_W][64];
-    __shared__ uint32_t sh_rc[32];
-    uint32_t blk = blockIdx.x;
-    if (blk < (uint32_t)a.n_fin) {
-        finalize_role(a.fin, blk, lds);
-        return;
-    }
-    blk -= a.n_fin;
-    if (blk == 0) {  // stages A and B on two different waves (they work on different steps)
-        const int wave = threadIdx.x >> 6;
-        if (wave == 0 && a.tA >= 0) stage_chain(a.sched, a.slots + (a.tA % D3P_RING), a.tA);
-        if (wave == 1 && a.tB >= 0) stage_keys(a.slots + (a.tB % D3P_RING), a.bkey);
-        return;
-    }
-    if (blk == 1) {
-        if (a.tC >= 0) {
-            const int r = a.tC % D3P_RING;
-            stage_derive(a, a.slots + r, a.skeys + (size_t)r * 2 * a.B, a.noise + (size_t)r * 2 * a.D);
-        }
-        return;
-    }
-    blk -= 2;
-    if (blk < (uint32_t)a.n_sk_wg) {
-        const int r = a.tC % D3P_RING;
-        stage_sample_keys(a.slots + r, a.skeys + (size_t)r * 2 * a.B, a.B, blk);
-        return;
-    }
-    blk -= a.n_sk_wg;
-    if (a.tD < 0) return;
-    const int rD = a.tD % D3P_RING;
-    if (blk < (uint32_t)a.n_idx_wg) {  // Feistel indices of the next step (util.py:273-300)
-        if (threadIdx.x < 32) sh_rc[threadIdx.x] = a.slots[rD].rc[threadIdx.x];
-        __syncthreads();
-        const uint32_t p = blk * blockDim.x + threadIdx.x;
-        if (p < a.B) a.idx[p] = feistel_permute_dev(sh_rc, a.capacity, a.bits_lower, a.bits_upper, p);
-        return;
-    }
-    blk -= a.n_idx_wg;
-    stage_eps(a.skeys + (size_t)rD * 2 * a.B, a.eps, a.B, a.D, blk, (uint32_t)a.n_eps_wg);
-}
-
-// ------------------------------------------------------------------------------------------
 // host-side launch logic
 // ------------------------------------------------------------------------------------------
 static int validate(const d3p_logreg_model* m, const d3p_dpsvi_hyper* h, const d3p_dpsvi_state* st,
@@ -683,6 +477,13 @@ static inline int bit_length_u32(uint32_t v)
     int b = 0;
     while (v) { ++b; v >>= 1; }
     return b;
+}
+
+// D3P_DBG: developer ablation / phase-stamp switches of the step kernel (0 in production); read once per process
+static int dev_dbg_flags()
+{
+    static const int v = [] { const char* e = getenv("D3P_DBG"); return e ? atoi(e) : 0; }();
+    return v;
 }
 
 static bool need_owned_list(const d3p_batch_source* src)
@@ -789,7 +590,7 @@ static int enqueue_main(const Ctx& c, int t, const float* X, const float* y, con
     a.row_hi = c.src->row_hi;
     a.clip = c.h->clip;
     a.stamps = stamps ? c.ws.stamps : nullptr;
-    if (const char* e = getenv("D3P_DBG")) a.dbg = atoi(e);
+    a.dbg = dev_dbg_flags();
     return launch_main<0>(c.s, c.g, a, e0, e1);
 }
 
@@ -828,130 +629,13 @@ static int enqueue_sched_finish(const Ctx& c, int steps_done)
     return check_launch("k_sched_finish");
 }
 
-__global__ void k_copy_key(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst)
-{
-    if (threadIdx.x < 16) dst[threadIdx.x] = src[threadIdx.x];
-}
-
-static bool use_carrier(const Ctx& c)
-{
-    // Measured on MI355X (round 1): 21.7 us/step against 17.8 us/step for the fused-RNG path -- every extra
-    // role pays its own launch ramp / cold instruction cache, and the VALU work of eps is the same wherever it
-    // runs.  Kept as an opt-in experiment.
-    return c.src->kind == D3P_BATCH_FEISTEL && getenv("D3P_CARRIER") != nullptr;
-}
-
-// carrier launch number j of a run of n steps (j = -D3P_LOOKAHEAD .. n-1): finalize(j) if j >= 0 plus the
-// look-ahead stages that still have a step to work on
-static int enqueue_carrier(const Ctx& c, int j, int n, float* loss_out)
-{
-    CarrierArgs ca;
-    memset(&ca, 0, sizeof(ca));
-    auto in_run = [&](int t) { return (t >= 0 && t < n) ? t : -1; };
-    ca.tA = in_run(j + 4);
-    ca.tB = in_run(j + 3);
-    ca.tC = in_run(j + 2);
-    ca.tD = in_run(j + 1);
-    const bool fin = j >= 0;
-    if (!fin && ca.tA < 0 && ca.tB < 0 && ca.tC < 0 && ca.tD < 0) return D3P_OK;
-    if (fin) {
-        const int r = j % D3P_RING;
-        FinalArgs& fa = ca.fin;
-        fa.parts = c.ws.partials;
-        fa.nparts = c.g.blocks;
-        fa.slot = c.ws.slots + r;
-        fa.noise = c.ws.noise + (size_t)r * c.P;
-        fa.params = c.st->params;
-        fa.adam_m = c.st->adam_m;
-        fa.adam_v = c.st->adam_v;
-        fa.adam_step = c.st->step;
-        fa.batch_index = c.src->batch_index;
-        fa.pack = c.ws.pack;
-        fa.loss_out = loss_out;
-        fa.grad_out = nullptr;
-        fa.B = c.src->B;
-        fa.m = *c.m;
-        fa.h = *c.h;
-        ca.n_fin = (int)cdiv(c.P, 64);
-    }
-    ca.sched = c.ws.sched;
-    ca.slots = c.ws.slots;
-    ca.bkey = c.src->batch_key;
-    ca.skeys = c.ws.skeys;
-    ca.noise = c.ws.noise;
-    ca.idx = c.ws.idx;
-    ca.eps = c.ws.eps;
-    ca.B = c.src->B;
-    ca.D = c.D;
-    ca.capacity = (uint32_t)c.src->n_rows;
-    const int bits = bit_length_u32(ca.capacity - 1);
-    ca.bits_lower = bits >> 1;
-    ca.bits_upper = bits - ca.bits_lower;
-    ca.b1 = c.h->b1;
-    ca.b2 = c.h->b2;
-    ca.n_idx_wg = ca.tD >= 0 ? (int)cdiv(c.src->B, 1024) : 0;
-    ca.n_sk_wg = ca.tC >= 0 ? (int)cdiv(c.src->B, 256) : 0;
-    // one 1024-thread workgroup per CU: keep the whole launch within 256 workgroups (a second scheduling
-    // round would double its duration); the eps role grid-strides over the examples
-    ca.n_eps_wg = ca.tD >= 0 ? (int)cdiv(c.src->B, 16) : 0;
-    const int others = ca.n_fin + 2 + ca.n_sk_wg + ca.n_idx_wg;
-    if (ca.n_eps_wg > 0 && others + ca.n_eps_wg > 256) ca.n_eps_wg = (256 - others) > 16 ? (256 - others) : 16;
-    if (const char* e = getenv("D3P_CARRIER_SKIP")) {  // developer ablation (results invalid): bit0 eps, 1 sample keys, 2 idx, 3 C, 4 A/B
-        const int m = atoi(e);
-        if (m & 1) ca.n_eps_wg = 0;
-        if (m & 2) ca.n_sk_wg = 0;
-        if (m & 4) ca.n_idx_wg = 0;
-        if (m & 8) ca.tC = -1;
-        if (m & 16) ca.tA = ca.tB = -1;
-        if (m & 32) ca.n_fin = 0;
-    }
-    hipLaunchKernelGGL(k_carrier, dim3(ca.n_fin + 2 + ca.n_sk_wg + ca.n_idx_wg + ca.n_eps_wg), dim3(1024), 0, c.s, ca);
-    return check_launch("k_carrier");
-}
-
-static int enqueue_main_staged(const Ctx& c, int j, const float* X, const float* y, bool stamps,
-                               hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
-{
-    MainArgs a;
-    memset(&a, 0, sizeof(a));
-    fill_model_scalars(c.m, &a);
-    a.X = X;
-    a.y = y;
-    a.idx = c.ws.idx;
-    a.counts = c.ws.slots[j % D3P_RING].counts;
-    a.skeys = nullptr;
-    a.eps_ext = c.ws.eps;
-    a.pack = c.ws.pack;
-    a.partials = c.ws.partials;
-    a.B = c.src->B;
-    a.row_lo = c.src->row_lo;
-    a.row_hi = c.src->row_hi;
-    a.clip = c.h->clip;
-    a.stamps = stamps ? c.ws.stamps : nullptr;
-    return launch_main<0>(c.s, c.g, a, e0, e1);
-}
-
-static int run_pipelined(const Ctx& c, const float* X, const float* y, int n, float* losses)
-{
-    int rc;
-    for (int j = -D3P_LOOKAHEAD; j < n; ++j) {
-        if (j >= 0 && (rc = enqueue_main_staged(c, j, X, y, false))) return rc;
-        if ((rc = enqueue_carrier(c, j, n, (j >= 0 && losses) ? losses + j : nullptr))) return rc;
-    }
-    if (n > 0) {  // the state key after n steps is the chain key recorded by step n-1
-        hipLaunchKernelGGL(k_copy_key, dim3(1), dim3(64), 0, c.s, (const uint32_t*)c.ws.slots[(n - 1) % D3P_RING].next_key,
-                           c.st->rng_key + 16 * ((c.st->key_slot + n) & 1));
-        return check_launch("k_copy_key");
-    }
-    return D3P_OK;
-}
-
 // ------------------------------------------------------------------------------------------
 // one launch per step (MODE 2)
 // ------------------------------------------------------------------------------------------
 static bool use_fused_step(const Ctx& c)
 {
-    return getenv("D3P_NO_FUSED_STEP") == nullptr && getenv("D3P_CARRIER") == nullptr;
+    static const bool off = getenv("D3P_NO_FUSED_STEP") != nullptr;  // two-kernel steps (main + finalize), kept for comparison
+    return !off;
 }
 
 static void fill_fuse_common(const Ctx& c, StepFuse* f, int g)
@@ -1007,7 +691,7 @@ static int enqueue_fused_step(const Ctx& c, int g, int t, const StepSlot* prev_s
     a.row_hi = c.src->row_hi;
     a.clip = c.h->clip;
     a.stamps = stamps ? c.ws.stamps : nullptr;
-    if (const char* e = getenv("D3P_DBG")) a.dbg = atoi(e);
+    a.dbg = dev_dbg_flags();
     fill_fuse_common(c, &a.fuse, g);
     {
         // Launch g applies the update of step g - 1: it reads state buffer (g - 1) & 1 and publishes to buffer g & 1
@@ -1091,6 +775,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     if (num_steps == 0) return D3P_OK;
     if ((rc = enqueue_chain(cb[0], batch_len(0)))) return rc;
     if ((rc = enqueue_sampler(cb[0], batch_len(0)))) return rc;
+    static const bool no_piggy = getenv("D3P_NO_CHAIN_PIGGYBACK") != nullptr;  // developer switch, read once
     const StepSlot* prev_slot = nullptr;
     const float* prev_noise = nullptr;
     int g = 0;
@@ -1098,7 +783,6 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
         const int cur = (int)(b & 1), nxt = cur ^ 1;
         const int K = batch_len(b), K_next = (b + 1 < n_batches) ? batch_len(b + 1) : 0;
         for (int t = 0; t < K; ++t, ++g) {
-            static const bool no_piggy = getenv("D3P_NO_CHAIN_PIGGYBACK") != nullptr;
             StepSlot* cslot = (!no_piggy && t < K_next) ? cb[nxt].ws.slots + t : nullptr;
             if ((rc = enqueue_fused_step(cb[cur], g, t, prev_slot, prev_noise, X, y, (losses && g > 0) ? losses + g - 1 : nullptr,
                                          cslot, t, t == K_next - 1, false)))
@@ -1113,8 +797,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
             prev_noise = cb[cur].ws.noise + (size_t)t * c.P;
         }
         if (b + 1 < n_batches) {
-            static const bool no_piggy2 = getenv("D3P_NO_CHAIN_PIGGYBACK") != nullptr;
-            if (no_piggy2 && (rc = enqueue_chain(cb[nxt], K_next))) return rc;
+            if (no_piggy && (rc = enqueue_chain(cb[nxt], K_next))) return rc;
             if ((rc = enqueue_sampler(cb[nxt], K_next))) return rc;
         }
     }
@@ -1400,46 +1083,13 @@ int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_d
     if (int rcm = validate_model(model, y_dev, "d3p_dpvi_logreg_run")) return rcm;
     D3P_REQUIRE(src->row_lo == 0 && src->row_hi == src->n_rows, "d3p_dpvi_logreg_run is the single-GPU path");
     if ((rc = enqueue_sched_init(c))) return rc;
-    if (use_carrier(c)) return run_pipelined(c, X_dev, y_dev, (int)num_steps, losses_dev);
     if (use_fused_step(c)) {
         if ((rc = run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev))) return rc;
         return enqueue_sched_finish(c, (int)num_steps);
     }
-    // The serial ChaCha key chain of batch b+1 (one wavefront, ~1.8 us per step) runs on an auxiliary stream
-    // while the update steps of batch b run on `stream`; the two streams meet once per batch.  (Putting the
-    // sampler there too made things slower: its workgroups delay the dispatch of the main kernel.)
-    // Measured: even this costs more than it hides (19.3-20.1 vs 17.6 us/step), so it is opt-in; by default the
-    // chain step of the next batch rides in every k_finalize launch as one extra workgroup instead.
-    const bool pipelined = num_steps > D3P_STEP_BATCH && getenv("D3P_AUX_STREAM") != nullptr;
-    const bool piggyback = !pipelined && getenv("D3P_NO_CHAIN_PIGGYBACK") == nullptr;
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_init = nullptr;
-    auto cleanup = [&]() {
-        for (int i = 0; i < 2; ++i) {
-            if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]);
-            if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
-        }
-        if (ev_init) (void)hipEventDestroy(ev_init);
-        if (aux) (void)hipStreamDestroy(aux);
-    };
-#define D3P_TRY_CLEAN(expr)                                                                    \
-    do {                                                                                       \
-        hipError_t e__ = (expr);                                                               \
-        if (e__ != hipSuccess) {                                                               \
-            cleanup();                                                                         \
-            return fail(D3P_E_HIP, "%s: %s", #expr, hipGetErrorString(e__));                   \
-        }                                                                                      \
-    } while (0)
-    if (pipelined) {
-        D3P_TRY_CLEAN(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-            D3P_TRY_CLEAN(hipEventCreateWithFlags(&ev_ready[i], hipEventDisableTiming));
-            D3P_TRY_CLEAN(hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming));
-        }
-        D3P_TRY_CLEAN(hipEventCreateWithFlags(&ev_init, hipEventDisableTiming));
-        D3P_TRY_CLEAN(hipEventRecord(ev_init, c.s));
-        D3P_TRY_CLEAN(hipStreamWaitEvent(aux, ev_init, 0));
-    }
+    // Two-kernel steps (D3P_NO_FUSED_STEP): main + finalize per step; the key-chain step of the next batch rides in every
+    // k_finalize launch as one extra workgroup.  (Running the chain or the sampler on an auxiliary stream was measured
+    // slower -- 19.3-20.1 vs 17.6 us/step -- and is not kept.)
     const uint32_t n_batches = (num_steps + D3P_STEP_BATCH - 1) / D3P_STEP_BATCH;
     auto batch_len = [&](uint32_t b) {
         const uint32_t rem = num_steps - b * D3P_STEP_BATCH;
@@ -1448,48 +1098,20 @@ int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_d
     Ctx cb[2] = {c, c};  // views of the two slot buffers
     cb[1].ws = c.ws2;
     cb[1].ws.partials = c.ws.partials;
-    Ctx ca[2] = {cb[0], cb[1]};  // the same, enqueuing on the auxiliary stream
-    if (pipelined) ca[0].s = ca[1].s = aux;
-    if (num_steps > 0) {
-        if ((rc = enqueue_chain(ca[0], batch_len(0)))) { cleanup(); return rc; }
-        if (pipelined) {
-            D3P_TRY_CLEAN(hipEventRecord(ev_ready[0], aux));
-            D3P_TRY_CLEAN(hipStreamWaitEvent(c.s, ev_ready[0], 0));
-        }
-        if ((rc = enqueue_sampler(cb[0], batch_len(0)))) { cleanup(); return rc; }
-    }
+    if (num_steps > 0 && (rc = enqueue_batch_prep(cb[0], batch_len(0)))) return rc;
     for (uint32_t b = 0; b < n_batches; ++b) {
-        const bool dbuf = pipelined || piggyback;
-        const int cur = dbuf ? (int)(b & 1) : 0, nxt = dbuf ? (cur ^ 1) : 0;
-        const int K_next = (b + 1 < n_batches) ? batch_len(b + 1) : 0;
-        if (pipelined && b + 1 < n_batches) {
-            if (b >= 1) D3P_TRY_CLEAN(hipStreamWaitEvent(aux, ev_done[nxt], 0));  // buffer `nxt` consumed
-            if ((rc = enqueue_chain(ca[nxt], batch_len(b + 1)))) { cleanup(); return rc; }
-            D3P_TRY_CLEAN(hipEventRecord(ev_ready[nxt], aux));
-        }
-        const int K = batch_len(b);
+        const int cur = (int)(b & 1), nxt = cur ^ 1;
+        const int K = batch_len(b), K_next = (b + 1 < n_batches) ? batch_len(b + 1) : 0;
         for (int t = 0; t < K; ++t) {
-            if ((rc = enqueue_main(cb[cur], t, X_dev, y_dev, nullptr, false))) { cleanup(); return rc; }
-            StepSlot* cslot = (piggyback && t < K_next) ? cb[nxt].ws.slots + t : nullptr;
+            if ((rc = enqueue_main(cb[cur], t, X_dev, y_dev, nullptr, false))) return rc;
+            StepSlot* cslot = t < K_next ? cb[nxt].ws.slots + t : nullptr;
             if ((rc = enqueue_finalize(cb[cur], t, c.ws.partials, c.g.blocks,
-                                       losses_dev ? losses_dev + (size_t)b * D3P_STEP_BATCH + t : nullptr, nullptr,
-                                       cslot, t, t == K_next - 1))) {
-                cleanup();
+                                       losses_dev ? losses_dev + (size_t)b * D3P_STEP_BATCH + t : nullptr, nullptr, cslot, t,
+                                       t == K_next - 1)))
                 return rc;
-            }
         }
-        if (b + 1 < n_batches) {
-            if (pipelined) {
-                D3P_TRY_CLEAN(hipEventRecord(ev_done[cur], c.s));
-                D3P_TRY_CLEAN(hipStreamWaitEvent(c.s, ev_ready[nxt], 0));
-            } else if (!piggyback && (rc = enqueue_chain(cb[0], batch_len(b + 1)))) {
-                return rc;
-            }
-            if ((rc = enqueue_sampler(cb[nxt], batch_len(b + 1)))) { cleanup(); return rc; }
-        }
+        if (b + 1 < n_batches && (rc = enqueue_sampler(cb[nxt], K_next))) return rc;
     }
-    cleanup();  // events/streams are released once their pending work completes (HIP defers destruction)
-#undef D3P_TRY_CLEAN
     return enqueue_sched_finish(c, (int)num_steps);
 }
 
@@ -1504,14 +1126,8 @@ int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model
     D3P_REQUIRE(X_dev && avg_us && reps >= 1, "bad arguments");
     if (int rcm = validate_model(model, y_dev, "d3p_dpvi_logreg_time_main_kernel")) return rcm;
     if ((rc = enqueue_sched_init(c))) return rc;
-    const bool staged = use_carrier(c);
-    if (staged) {
-        for (int j = -D3P_LOOKAHEAD; j < 0; ++j)
-            if ((rc = enqueue_carrier(c, j, 1, nullptr))) return rc;
-    } else if ((rc = enqueue_batch_prep(c, 1))) {
-        return rc;
-    }
-    const bool fused = !staged && use_fused_step(c);
+    if ((rc = enqueue_batch_prep(c, 1))) return rc;
+    const bool fused = use_fused_step(c);
     Ctx ct = c;  // the fused step applies an update in its prologue: let it work on a scratch copy of the state
     d3p_dpsvi_state st_scratch = *c.st;
     if (fused) {
@@ -1535,8 +1151,7 @@ int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model
         if (fused)  // same launch as step 1 of a run: previous step = slot 0, key-chain workgroup piggy-backed
             return enqueue_fused_step(ct, 1, 0, c.ws.slots, c.ws.noise, X_dev, y_dev, nullptr, c.ws2.slots, 0, 0, false, stamps,
                                       a0, a1);
-        return staged ? enqueue_main_staged(c, 0, X_dev, y_dev, stamps, a0, a1)
-                      : enqueue_main(c, 0, X_dev, y_dev, nullptr, stamps, a0, a1);
+        return enqueue_main(c, 0, X_dev, y_dev, nullptr, stamps, a0, a1);
     };
     if (fused)  // prime the accumulator the timed launches read as "previous step" with real sums
         if ((rc = enqueue_fused_step(ct, 0, 0, nullptr, nullptr, X_dev, y_dev, nullptr, nullptr, 0, 0, false))) return rc;
@@ -1558,8 +1173,7 @@ int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model
         if (e == hipSuccess) e = hipStreamSynchronize(c.s);
         if (e != hipSuccess) { free(host); return fail(D3P_E_HIP, "timing: %s", hipGetErrorString(e)); }
         unsigned long long t0 = ~0ull, t1 = 0ull;
-        const char* dbg = getenv("D3P_DBG");
-        const int SS = (dbg && (atoi(dbg) & 32)) ? 8 : 2;
+        const int SS = (dev_dbg_flags() & 32) ? 8 : 2;
         for (uint32_t b = 0; b < nb && SS * b + 1 < 2 * D3P_MAIN_MAX_BLOCKS; ++b) {
             if (host[SS * b] < t0) t0 = host[SS * b];
             if (host[SS * b + 1] > t1) t1 = host[SS * b + 1];

@@ -256,7 +256,7 @@ struct ExLoad {
 
 // FULL: every lane's column pairs exist (D == 2 * 64 * V * NK, no intercept) -> no guards at all.
 // EPS: where the guide noise comes from: 0 = generated on chip (threefry + erf_inv), 1 = read from
-// a.eps_ext (parity mode, or staged by the carrier kernel one step ahead), -1 = decided at run time.
+// a.eps_ext (parity mode), -1 = decided at run time.
 // NK == 1 (d <= 512): 1024-thread workgroups (<= 128 VGPRs); wider rows keep more columns per lane in registers,
 // so those variants are built for 512-thread workgroups (<= 256 VGPRs) and launched with at most 8 waves.
 template <int V, int NK, int MODE, bool FULL, int EPS>
@@ -736,8 +736,12 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g)
     // waves per workgroup (default 16 = one 1024-thread workgroup per CU at 4 waves/SIMD), reduced until
     // pack (5D) + reduction buffer (W x P) fit 64 KiB of LDS; one example per wave per pass.
     int W = g->NK == 1 ? 16 : 8, epw = 1;
-    if (const char* e = getenv("D3P_MAIN_W")) { int v = atoi(e); if (v >= 1 && v <= (g->NK == 1 ? 16 : 8)) W = v; }
-    if (const char* e = getenv("D3P_MAIN_EPW")) { int v = atoi(e); if (v >= 1 && v <= 64) epw = v; }
+    {  // developer overrides of the geometry (tuning sweeps), read once per process
+        static const int env_w = [] { const char* e = getenv("D3P_MAIN_W"); return e ? atoi(e) : 0; }();
+        static const int env_epw = [] { const char* e = getenv("D3P_MAIN_EPW"); return e ? atoi(e) : 0; }();
+        if (env_w >= 1 && env_w <= (g->NK == 1 ? 16 : 8)) W = env_w;
+        if (env_epw >= 1 && env_epw <= 64) epw = env_epw;
+    }
     auto lds_bytes = [&](int w) { return (size_t)(((5 * D + 3) & ~3) + w * P + 2 * w) * sizeof(float); };
     while (W > 1 && lds_bytes(W) > 96 * 1024) W >>= 1;
     if (lds_bytes(W) > 160 * 1024)
