@@ -300,10 +300,10 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
             if (i < D3P_ACC_R * PA) f.acc_next[i] = 0;
         }
         if (f.apply_prev) {
-#pragma unroll
-            for (int r = 0; r < D3P_ACC_R; ++r) pend_n8[r] = f.acc_prev[(size_t)r * PA + P + 1];
-            pend_bc1 = f.prev_meta->bc1;
-            pend_bc2 = f.prev_meta->bc2;
+            if (pend_fast) {
+                pend_bc1 = f.prev_meta->bc1;
+                pend_bc2 = f.prev_meta->bc2;
+            }
             if (pend_fast && (int)threadIdx.x < P) {
                 const int col = threadIdx.x;
 #pragma unroll
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
             const float ps = (e < a.d) ? a.fuse.prior_w : a.fuse.prior_b;
             pk[D + e] = sp;
             pk[2 * D + e] = sgm;
-            pk[3 * D + e] = a.inv_obs * sgm / sp;
+            pk[3 * D + e] = a.inv_obs * sgm * __builtin_amdgcn_rcpf(sp);
             pk[4 * D + e] = __logf(ps) - __logf(sp);
         }
     };
@@ -341,16 +341,34 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
             for (int col = threadIdx.x; col < P; col += blockDim.x) pack_column(col, f.params_in[col]);
             return;
         }
-        long long nll = 0;
+        // n (the count column) is consumed only AFTER the column loads below have been issued: its load was issued
+        // at kernel entry, and summing it here first would put a second memory round trip in front of those loads
+        const float Bf = (float)a.B;
+        // the count column is loaded in the same batch as the gradient columns (one memory round trip, not two)
+        // (wave-uniform values: the compiler moves them to SGPRs with a wait right after their loads, so they are issued
+        // AFTER the per-lane column loads -- otherwise every uniform load costs its own memory round trip first)
+        auto load_n = [&]() {
 #pragma unroll
-        for (int r = 0; r < D3P_ACC_R; ++r) nll += pend_n8[r];
-        const float n = (float)nll, Bf = (float)a.B;
-        const float factor = (n == 0.0f) ? 0.0f : Bf / n;  // svi.py:305
+            for (int r = 0; r < D3P_ACC_R; ++r) pend_n8[r] = f.acc_prev[(size_t)r * PA + P + 1];
+            if (!pend_fast) {
+                pend_bc1 = f.prev_meta->bc1;
+                pend_bc2 = f.prev_meta->bc2;
+            }
+        };
+        auto count_n = [&]() {
+            long long nll = 0;
+#pragma unroll
+            for (int r = 0; r < D3P_ACC_R; ++r) nll += pend_n8[r];
+            return (float)nll;
+        };
         d3p_logreg_model_view mv;
         mv.obs_scale = a.obs_scale;
         if (pend_fast) {
             const int col = threadIdx.x;
             if (col < P) {
+                load_n();
+                const float n = count_n();
+                const float factor = (n == 0.0f) ? 0.0f : Bf / n;  // svi.py:305
                 long long sll = 0;
 #pragma unroll
                 for (int r = 0; r < D3P_ACC_R; ++r) sll += pend_r8[r];
@@ -389,6 +407,15 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
                         v[j] = f.v_in[cc];
                         z[j] = f.prev_noise[cc];
                     }
+                    __builtin_amdgcn_sched_barrier(0);  // keep the uniform loads behind the column loads
+                    load_n();
+                    const float n = count_n();
+                    const float factor = (n == 0.0f) ? 0.0f : Bf / n;  // svi.py:305
+                    // This arithmetic sits on the critical path of every step (all waves wait for the derived columns), so
+                    // the per-step constants are inverted once and the per-column divisions / square root use the 1-ulp
+                    // hardware approximations (the two-kernel path keeps IEEE division; they agree to ~1e-7 relative).
+                    const float inv_B = 1.0f / Bf, inv_bc1 = 1.0f / pend_bc1, inv_bc2 = 1.0f / pend_bc2;
+                    const float noise_scale = f.dp_scale * (a.clip / n), out_scale = a.obs_scale * factor;
 #pragma unroll
                     for (int j = 0; j < CB; ++j) {
                         const int col = col0 + j * stride;
@@ -397,10 +424,11 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
 #pragma unroll
                             for (int r = 0; r < D3P_ACC_R; ++r) sll += r8[j][r];
                             const float tot = (float)((double)sll * f.inv_sg);
-                            const float g = (tot / Bf + z[j] * (f.dp_scale * (a.clip / n))) * a.obs_scale * factor;
+                            const float g = __fmaf_rn(z[j], noise_scale, tot * inv_B) * out_scale;
                             const float mm = (1.0f - f.b1) * g + f.b1 * m[j];
                             const float vv = (1.0f - f.b2) * g * g + f.b2 * v[j];
-                            const float xx = x[j] - f.lr * (mm / pend_bc1) / (sqrtf(vv / pend_bc2) + f.adam_eps);
+                            const float xx = x[j] - f.lr * (mm * inv_bc1) *
+                                                        __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv * inv_bc2) + f.adam_eps);
                             if (blockIdx.x == 0) {  // one workgroup publishes the state
                                 f.params_out[col] = xx;
                                 f.m_out[col] = mm;
@@ -413,6 +441,9 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
             }
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
+            load_n();
+            const float n = count_n();
+            const float factor = (n == 0.0f) ? 0.0f : Bf / n;
             long long lll = 0;
 #pragma unroll
             for (int r = 0; r < D3P_ACC_R; ++r) lll += f.acc_prev[(size_t)r * PA + P];
@@ -421,6 +452,9 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
             if (f.batch_index) *f.batch_index = f.prev_meta->batch_i + 1u;
         }
     };
+    // the 4 waves (one per SIMD) that apply the pending update in finish_prologue()  (s_setprio on them was measured to
+    // change nothing: the SIMD shares its issue slots evenly whatever the priority)
+    const bool prologue_wave = MODE == 2 && !a.fuse.flush_only && a.fuse.apply_prev && wave < 4;
     if (MODE == 2 && (a.fuse.flush_only || !kLatePrologue)) {
         finish_prologue();
         D3P_STAMP(2)
@@ -512,9 +546,15 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
     ExLoad<NC> cur;
     uint32_t p = gw;  // item index
     if (p < n_items) issue(pos(p), cur);
-    // The derived columns are first needed AFTER the noise of the first example has been generated,
-    // so the staging barrier sits behind that phase (every wave passes exactly one of the two).
+    // The derived columns are first needed AFTER the noise of the first example has been generated, so for the waves that
+    // do not run the prologue the staging barrier sits behind that phase.  The prologue waves arrive at the barrier as
+    // soon as the columns are in LDS -- BEFORE generating their own noise: the other 12 waves then start their arithmetic
+    // ~1.8 us earlier and the prologue waves' noise generation overlaps with it (every wave passes exactly one barrier).
     bool staged = false;
+    if (prologue_wave && p < n_items) {
+        __syncthreads();
+        staged = true;
+    }
     if (!(p < n_items)) { finish_prologue(); __syncthreads(); staged = true; }
 
     while (p < n_items) {

@@ -16,7 +16,7 @@ params = torch.cat([torch.zeros(d, device=dev), torch.full((d,), -2.25, device=d
 m = torch.zeros_like(params); v = torch.zeros_like(params); step = torch.zeros((), dtype=torch.int32, device=dev)
 keybuf = torch.zeros((2, 16), dtype=torch.int32, device=dev); keybuf[0].copy_(rng.PRNGKey(0).reshape(16).view(torch.int32))
 bkey = rng.PRNGKey(1); bidx = torch.zeros(1, dtype=torch.int32, device=dev)
-for W, EPW, DBG in [(16, 1, 0)]:
+for W, EPW, DBG in [(16, 1, int(os.environ.get("D3P_DBG", "0")))]:
     os.environ["D3P_MAIN_W"] = str(W); os.environ["D3P_MAIN_EPW"] = str(EPW); os.environ["D3P_DBG"] = str(DBG)
     st = L.DpsviState(keybuf.data_ptr(), 0, params.data_ptr(), m.data_ptr(), v.data_ptr(), step.data_ptr())
     src = L.BatchSource(L.D3P_BATCH_FEISTEL, B, 0.0, 0, bkey.data_ptr(), bidx.data_ptr(), None, N, 0, N)
