@@ -126,6 +126,20 @@ __device__ __forceinline__ void derive_child_quad(const uint32_t* __restrict__ p
     chacha20_block_quad(a, b, c, d);
 }
 
+// the same with the lane's four parent words (rows q, 4+q, 8+q, 12+q of the parent state) already in registers
+__device__ __forceinline__ void derive_child_quad_regs(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t child,
+                                                       uint32_t tag, uint32_t data, uint32_t& a, uint32_t& b)
+{
+    const int q = threadIdx.x & 3;
+    a = p0;
+    b = p1;
+    uint32_t c = p2, d = p3;
+    if (q == 0) d += child;   // counter  (word 12)
+    if (q == 1) d ^= data;    // nonce[0] (word 13)
+    if (q == 3) d ^= tag;     // nonce[2] (word 15)
+    chacha20_block_quad(a, b, c, d);
+}
+
 // threefry2x32-20 (Random123), as used by jax.random.
 __device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t& o0,
                                              uint32_t& o1)

@@ -37,6 +37,7 @@ struct Workspace {
     long long* acc;   // 3 x D3P_ACC_R x (P + 2) fixed-point accumulators of the one-launch step
     float* scratch_state;  // 3P + 4 floats: stand-in state for the timing entry point
     float* pp_state;       // 3P floats: second buffer of the ping-ponged optimiser state (one-launch-per-step path)
+    uint32_t* chain_bar;   // chained form: (D3P_STEP_BATCH + 1) x D3P_BAR_WORDS arrival counters + 16 words (abort flag)
     float* partials;  // max_blocks x (P + 2)
     unsigned long long* stamps;  // 2 x max_blocks
     void* poisson_ws;
@@ -60,6 +61,7 @@ static size_t carve(const d3p_logreg_model* m, const d3p_batch_source* src, char
     p = take(3 * (size_t)D3P_ACC_R * (P + 2) * sizeof(long long)); if (ws) ws->acc = (long long*)p;
     p = take((3 * P + 4) * sizeof(float)); if (ws) ws->scratch_state = (float*)p;
     p = take(3 * P * sizeof(float)); if (ws) ws->pp_state = (float*)p;
+    p = take(((size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS + 16) * sizeof(uint32_t)); if (ws) ws->chain_bar = (uint32_t*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * (P + 2) * sizeof(float)); if (ws) ws->partials = (float*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * 2 * sizeof(unsigned long long)); if (ws) ws->stamps = (unsigned long long*)p;
     size_t pb = 0;
@@ -723,6 +725,56 @@ static int enqueue_fused_step(const Ctx& c, int g, int t, const StepSlot* prev_s
     return launch_main<2>(c.s, g2, a, e0, e1);
 }
 
+// Chained form (MODE 3): the K steps of the prepared batch in ONE launch of K x (nw + 1) workgroups (see ChainFuse in
+// d3p_logreg_kernel.h).  On by default for the single-GPU run loop; D3P_NO_CHAINED_STEPS=1 falls back to one launch per step.
+static bool use_chained_steps(const Ctx& c)
+{
+    static const bool off = getenv("D3P_NO_CHAINED_STEPS") != nullptr;
+    return !off && !need_owned_list(c.src) && c.src->kind != D3P_BATCH_EXPLICIT;
+}
+
+static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* prev_slot0, const float* prev_noise0, const float* X,
+                                 const float* y, float* losses, StepSlot* chain_slots, int K_next)
+{
+    MainArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_model_scalars(c.m, &a);
+    a.X = X;
+    a.y = y;
+    a.pack = c.ws.pack;
+    a.partials = c.ws.partials;
+    a.B = c.src->B;
+    a.row_lo = c.src->row_lo;
+    a.row_hi = c.src->row_hi;
+    a.clip = c.h->clip;
+    fill_fuse_common(c, &a.fuse, g0);
+    a.fuse.chain_sched = c.ws.sched;
+    ChainFuse& cf = a.chain;
+    cf.nw = (int)c.g.blocks;
+    cf.g0 = g0;
+    cf.K = K;
+    cf.slots = c.ws.slots;
+    cf.idx_base = c.ws.idx;
+    cf.skeys_base = c.ws.skeys;
+    cf.noise_base = c.ws.noise;
+    cf.prev_slot0 = prev_slot0;
+    cf.prev_noise0 = prev_noise0;
+    cf.acc_base = c.ws.acc;
+    const size_t P = (size_t)c.P;
+    cf.state[0][0] = c.st->params; cf.state[0][1] = c.st->adam_m; cf.state[0][2] = c.st->adam_v;
+    cf.state[1][0] = c.ws.pp_state; cf.state[1][1] = c.ws.pp_state + P; cf.state[1][2] = c.ws.pp_state + 2 * P;
+    cf.losses = losses;
+    cf.bar = c.ws.chain_bar;
+    cf.abort_flag = c.ws.chain_bar + (size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS;
+    cf.chain_slots = chain_slots;
+    cf.K_next = chain_slots ? K_next : 0;
+    // arrival counters of this launch (the abort flag behind them is sticky for the whole run)
+    D3P_HIP_TRY(hipMemsetAsync(c.ws.chain_bar, 0, (size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS * sizeof(uint32_t), c.s));
+    MainGeom g2 = c.g;
+    g2.blocks = (uint32_t)K * (c.g.blocks + 1u);
+    return launch_main<3>(c.s, g2, a);
+}
+
 // ---- RCCL, resolved lazily with dlopen so that libd3p_hip.so has no link-time dependency on it (single-GPU users
 // never touch it) and shares the copy torch.distributed already loaded when there is one.
 struct RcclApi {
@@ -779,10 +831,21 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     const StepSlot* prev_slot = nullptr;
     const float* prev_noise = nullptr;
     int g = 0;
+    const bool chained = !comm && use_chained_steps(c);
+    if (chained)  // the abort flag of the bounded waits: cleared once per run, read back by d3p_dpvi_logreg_chain_status
+        D3P_HIP_TRY(hipMemsetAsync(c.ws.chain_bar + (size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS, 0, 16 * sizeof(uint32_t), c.s));
     for (uint32_t b = 0; b < n_batches; ++b) {
         const int cur = (int)(b & 1), nxt = cur ^ 1;
         const int K = batch_len(b), K_next = (b + 1 < n_batches) ? batch_len(b + 1) : 0;
-        for (int t = 0; t < K; ++t, ++g) {
+        if (chained) {
+            if ((rc = enqueue_chained_batch(cb[cur], g, K, prev_slot, prev_noise, X, y, losses, no_piggy ? nullptr : cb[nxt].ws.slots,
+                                            K_next)))
+                return rc;
+            g += K;
+            prev_slot = cb[cur].ws.slots + (K - 1);
+            prev_noise = cb[cur].ws.noise + (size_t)(K - 1) * c.P;
+        }
+        for (int t = 0; !chained && t < K; ++t, ++g) {
             StepSlot* cslot = (!no_piggy && t < K_next) ? cb[nxt].ws.slots + t : nullptr;
             if ((rc = enqueue_fused_step(cb[cur], g, t, prev_slot, prev_noise, X, y, (losses && g > 0) ? losses + g - 1 : nullptr,
                                          cslot, t, t == K_next - 1, false)))
@@ -1113,6 +1176,21 @@ int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_d
         if (b + 1 < n_batches && (rc = enqueue_sampler(cb[nxt], K_next))) return rc;
     }
     return enqueue_sched_finish(c, (int)num_steps);
+}
+
+int d3p_dpvi_logreg_chain_status(void* stream, const d3p_logreg_model* model, const d3p_batch_source* src, void* workspace_dev,
+                                 size_t workspace_bytes, int32_t* aborted_out)
+{
+    D3P_REQUIRE(model && src && workspace_dev && aborted_out, "d3p_dpvi_logreg_chain_status: null pointer");
+    if (workspace_bytes < d3p_dpvi_logreg_workspace(model, src)) return fail(D3P_E_WORKSPACE, "workspace too small");
+    Workspace ws;
+    carve(model, src, (char*)workspace_dev, &ws);
+    uint32_t flag = 0;
+    D3P_HIP_TRY(hipMemcpyAsync(&flag, ws.chain_bar + (size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS, sizeof(flag), hipMemcpyDeviceToHost,
+                               (hipStream_t)stream));
+    D3P_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    *aborted_out = (int32_t)flag;
+    return D3P_OK;
 }
 
 int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,

@@ -115,28 +115,63 @@ struct Sched {
     uint32_t pad[2];
 };
 
+#define D3P_BAR_WORDS 144        // per step: word 0 = groups arrived, word 16 (1 + g) = arrivals of group g (8 groups)
+#define D3P_AGENT __HIP_MEMORY_SCOPE_AGENT
+
+template <bool CH, typename T>
+__device__ __forceinline__ T ld_x(const T* p)  // cross-workgroup load: agent-scope in the chained form
+{
+    if (CH) return __hip_atomic_load(p, __ATOMIC_RELAXED, D3P_AGENT);
+    return *p;
+}
+
+template <bool CH, typename T>
+__device__ __forceinline__ void st_x(T* p, T v)
+{
+    if (CH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, D3P_AGENT);
+    else *p = v;
+}
+
+// bounded wait until *p >= target; false (and the abort flag raised) when the bound is hit or another waiter gave up
+__device__ __forceinline__ bool chain_wait(const uint32_t* p, uint32_t target, uint32_t* abort_flag)
+{
+    for (uint32_t spins = 0;; ++spins) {
+        if (__hip_atomic_load(p, __ATOMIC_RELAXED, D3P_AGENT) >= target) return true;
+        if (spins > (1u << 21) || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, D3P_AGENT) != 0u) {
+            __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, D3P_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 // One step of the serial key chain for step `t` of the next batch: (next, gradient, perturbation) =
 // split(chain_key, 3) (svi.py:208-211, :413-414).  `last` advances the batch counters of the schedule.
+template <bool CH = false>
 __device__ __forceinline__ void chain_step(Sched* sched, StepSlot* slot, int t, int last)
 {
     // lanes 0-3 / 4-7 / 8-11 derive children 0 / 1 / 2 with the 4-lane ChaCha block (the call needs whole quads:
-    // it is made by the first 64 threads of a workgroup, lanes >= 12 compute a discarded fourth copy)
+    // it is made by the first 64 threads of a workgroup, lanes >= 12 compute a discarded fourth copy).
+    // CH: consecutive chain steps run in different workgroups of ONE launch, so the schedule goes through agent-scope
+    // accesses (the slot is only read by later launches).
     const int lane = threadIdx.x & 63, q = lane & 3, child = (lane >> 2) < 3 ? (lane >> 2) : 0;
-    const int32_t adam0 = sched->adam_i;
-    const uint32_t batch0 = sched->batch_i;
+    const int32_t adam0 = ld_x<CH>(&sched->adam_i);
+    const uint32_t batch0 = ld_x<CH>(&sched->batch_i);
+    const uint32_t p0 = ld_x<CH>(&sched->key[q]), p1 = ld_x<CH>(&sched->key[4 + q]);
+    const uint32_t p2 = ld_x<CH>(&sched->key[8 + q]), p3 = ld_x<CH>(&sched->key[12 + q]);
     uint32_t a, b;
-    derive_child_quad(sched->key, (uint32_t)child, D3P_TAG_SPLIT, 0u, a, b);
+    derive_child_quad_regs(p0, p1, p2, p3, (uint32_t)child, D3P_TAG_SPLIT, 0u, a, b);
     if (lane < 4) {          // next state key: only the key words and the (zero) counter/nonce change
-        sched->key[4 + q] = a;
-        sched->key[8 + q] = b;
-        sched->key[12 + q] = 0u;
+        st_x<CH>(&sched->key[4 + q], a);
+        st_x<CH>(&sched->key[8 + q], b);
+        st_x<CH>(&sched->key[12 + q], 0u);
         if (lane == 0 && last) {
-            sched->adam_i = adam0 + t + 1;
-            sched->batch_i = batch0 + (uint32_t)(t + 1);
+            st_x<CH>(&sched->adam_i, adam0 + t + 1);
+            st_x<CH>(&sched->batch_i, batch0 + (uint32_t)(t + 1));
         }
     } else if (lane < 12) {  // gradient key (child 1), perturbation key (child 2)
         uint32_t* dst = lane < 8 ? slot->grad_key : slot->pert_key;
-        dst[q] = sched->key[q];  // constants row
+        dst[q] = p0;  // constants row
         dst[4 + q] = a;
         dst[8 + q] = b;
         dst[12 + q] = 0u;
@@ -211,6 +246,34 @@ __device__ __forceinline__ float apply_pending_column(const StepFuse& f, const d
     return x;
 }
 
+// Arguments of the chained form (MODE 3): ONE launch covers the K steps of a prepared batch.  The grid has
+// K x (nw + 1) workgroups; workgroup i belongs to step i / (nw + 1).  Workgroups are dispatched in linear-id order, so
+// every workgroup of step t is resident before any workgroup of step t + 1 is placed: a step-(t+1) workgroup can start
+// its parameter-independent work (row loads, eps generation) the moment a CU frees up, and only its update prologue
+// waits -- on a two-level arrival counter -- until all workgroups of step t have added their sums.  That overlaps the
+// eps generation of step t + 1 with the tail of step t and removes the kernel-launch boundary between steps.
+// Everything exchanged between workgroups inside the launch (accumulators, the ping-ponged optimiser state, counters,
+// the key-chain schedule) is accessed with agent-scope relaxed atomics only (coherent at the memory side: no L2-wide
+// flush/invalidate); waits are bounded and raise `abort_flag` instead of hanging.
+struct ChainFuse {
+    int nw;                      // compute workgroups per step (the (nw + 1)-th is the key-chain workgroup)
+    int g0;                      // global index of step 0 of this launch (accumulator rotation, state ping-pong)
+    int K;                       // steps in this launch
+    StepSlot* slots;             // K slots of this batch
+    const uint32_t* idx_base;    // K x B (nullable: rows are positions)
+    const uint32_t* skeys_base;  // K x 2B
+    const float* noise_base;     // K x P
+    const StepSlot* prev_slot0;  // slot of step g0 - 1 (nullptr: nothing to apply before step 0)
+    const float* prev_noise0;
+    long long* acc_base;         // 3 x R x (P + 2)
+    float* state[2][3];          // ping-ponged {params, m, v}
+    float* losses;               // nullable; losses[g] of the run
+    uint32_t* bar;               // K x D3P_BAR_WORDS arrival counters (zeroed before the launch) + chain progress word
+    uint32_t* abort_flag;
+    StepSlot* chain_slots;       // slots of the NEXT batch (key chain), K_next of them
+    int K_next;
+};
+
 struct MainArgs {
     const float* X;
     const float* y;
@@ -237,7 +300,8 @@ struct MainArgs {
     unsigned long long* stamps;  // nullable: per-workgroup {start, end} wall_clock64 (timing entry point)
     int family, gexp;            // likelihood family (non-FULL kernels only), guide transform
     float nh_inv_var, ll_const;  // Gaussian family: -0.5 / sigma^2,  D * (log sigma + log(2 pi) / 2)
-    StepFuse fuse;               // MODE 2 only
+    StepFuse fuse;               // MODE 2 / 3
+    ChainFuse chain;             // MODE 3 only
 };
 
 // Lane l of the wave that owns an example holds, for k < NK and i < V, the column pair
@@ -260,21 +324,54 @@ struct ExLoad {
 // NK == 1 (d <= 512): 1024-thread workgroups (<= 128 VGPRs); wider rows keep more columns per lane in registers,
 // so those variants are built for 512-thread workgroups (<= 256 VGPRs) and launched with at most 8 waves.
 template <int V, int NK, int MODE, bool FULL, int EPS>
-__global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a)
+__global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a_in)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool FUSE = MODE == 2 || MODE == 3;   // update applied in the prologue, fixed-point accumulators
+    constexpr bool CHAIN = MODE == 3;               // K steps in one launch (see ChainFuse)
+    MainArgs a = a_in;
+    uint32_t bid = blockIdx.x, nblk = gridDim.x;    // workgroup index / count within the step
+    int step_t = 0;
+    if (CHAIN) {
+        const ChainFuse& cf = a_in.chain;
+        const uint32_t per = (uint32_t)cf.nw + 1u;
+        step_t = (int)(blockIdx.x / per);
+        bid = blockIdx.x % per;
+        nblk = per;
+        const int g = cf.g0 + step_t;
+        const size_t Pc = 2 * (size_t)a_in.D, words = (size_t)D3P_ACC_R * (Pc + 2);
+        a.idx = cf.idx_base ? cf.idx_base + (size_t)step_t * a_in.B : nullptr;
+        a.counts = cf.slots[step_t].counts;
+        a.skeys = cf.skeys_base + (size_t)step_t * 2 * a_in.B;
+        StepFuse& f = a.fuse;
+        f.acc_prev = cf.acc_base + (size_t)((g + 2) % 3) * words;
+        f.acc_cur = cf.acc_base + (size_t)(g % 3) * words;
+        f.acc_next = cf.acc_base + (size_t)((g + 1) % 3) * words;
+        const int in = g > 0 ? ((g - 1) & 1) : 0, out = g & 1;
+        f.params_in = cf.state[in][0]; f.m_in = cf.state[in][1]; f.v_in = cf.state[in][2];
+        f.params_out = cf.state[out][0]; f.m_out = cf.state[out][1]; f.v_out = cf.state[out][2];
+        const StepSlot* ps = step_t > 0 ? cf.slots + (step_t - 1) : cf.prev_slot0;
+        f.apply_prev = ps != nullptr;
+        f.prev_meta = ps ? reinterpret_cast<const StepMeta*>(&ps->adam_i) : nullptr;
+        f.prev_noise = step_t > 0 ? cf.noise_base + (size_t)(step_t - 1) * Pc : cf.prev_noise0;
+        f.prev_loss_out = (cf.losses && g > 0) ? cf.losses + (g - 1) : nullptr;
+        f.flush_only = 0;
+        f.chain_slot = step_t < cf.K_next ? cf.chain_slots + step_t : nullptr;
+        f.chain_t = step_t;
+        f.chain_last = step_t == cf.K_next - 1;
+    }
     const bool eps_from_mem = (EPS == 1) || (EPS < 0 && a.eps_ext != nullptr);
     const int SS = (a.dbg & 32) ? 8 : 2;  // diagnostic build: 8 phase stamps per workgroup
     const long long clk0 = (a.dbg & 32) ? clock64() : 0;
-    if (a.stamps && threadIdx.x == 0) a.stamps[SS * blockIdx.x] = wall_clock64();
-#define D3P_STAMP(k) if ((a.dbg & 32) && a.stamps && threadIdx.x == 0) a.stamps[8 * blockIdx.x + (k)] = wall_clock64();
+    if (a.stamps && threadIdx.x == 0) a.stamps[SS * bid] = wall_clock64();
+#define D3P_STAMP(k) if ((a.dbg & 32) && a.stamps && threadIdx.x == 0) a.stamps[8 * bid + (k)] = wall_clock64();
     constexpr int NC = V * NK;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = blockDim.x >> 6;
     const int D = a.D, half = a.half, P = 2 * D;
-    const uint32_t total_waves = (gridDim.x - ((MODE == 2 && a.fuse.chain_slot) ? 1u : 0u)) * W;
-    const uint32_t gw = blockIdx.x * W + wave;
+    const uint32_t total_waves = (nblk - ((CHAIN || (MODE == 2 && a.fuse.chain_slot)) ? 1u : 0u)) * W;
+    const uint32_t gw = bid * W + wave;
 
     // ---- stage the derived parameter columns in LDS once per workgroup (5 x D floats)
     float* pk = lds;                       // [loc | s | sg | q | lc]
@@ -286,17 +383,29 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
     // Measured: keeping these loads in registers across the eps generation costs 12 extra VGPRs -> 128 VGPRs +
     // scratch and a slower kernel (14.8 vs 12.5 us), so the prologue runs in order, before the row loads.
     constexpr bool kLatePrologue = false;
-    const bool pend_fast = kLatePrologue && (MODE == 2) && a.fuse.apply_prev && (P <= (int)blockDim.x);
-    if (MODE == 2) {
+    const bool pend_fast = kLatePrologue && FUSE && a.fuse.apply_prev && (P <= (int)blockDim.x);
+    if (FUSE) {
         const StepFuse& f = a.fuse;
         const int PA = P + 2;
-        if (blockIdx.x == gridDim.x - 1 && f.chain_slot) {  // piggy-backed key-chain workgroup
-            if (threadIdx.x < 64) chain_step(f.chain_sched, f.chain_slot, f.chain_t, f.chain_last);
+        if (bid == nblk - 1 && (CHAIN || f.chain_slot)) {  // piggy-backed key-chain workgroup
+            if (f.chain_slot && threadIdx.x < 64) {
+                bool go = true;
+                if (CHAIN && step_t > 0)  // the schedule is serial: wait for the chain step of the previous step
+                    go = chain_wait(a.chain.bar + (size_t)a.chain.K * D3P_BAR_WORDS, (uint32_t)step_t, a.chain.abort_flag);
+                if (go) chain_step<CHAIN>(f.chain_sched, f.chain_slot, f.chain_t, f.chain_last);
+                if (CHAIN) {
+                    __builtin_amdgcn_s_waitcnt(0);
+                    if (threadIdx.x == 0)
+                        __hip_atomic_store(a.chain.bar + (size_t)a.chain.K * D3P_BAR_WORDS, (uint32_t)step_t + 1u, __ATOMIC_RELAXED,
+                                           D3P_AGENT);
+                }
+            }
             return;
         }
-        // zero the accumulator of the NEXT launch (last read one launch ago, never touched in this one)
-        {
-            const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        // zero the accumulator of the NEXT step (last read one step ago, never touched in this one).  Chained form: the
+        // workgroups of step t - 1 may still be reading it in their prologue, so it is zeroed after the wait below.
+        if (!CHAIN) {
+            const int i = bid * blockDim.x + threadIdx.x;
             if (i < D3P_ACC_R * PA) f.acc_next[i] = 0;
         }
         if (f.apply_prev) {
@@ -333,13 +442,29 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
     };
     bool prologue_done = false;
     auto finish_prologue = [&]() {
-        if (MODE != 2 || prologue_done) return;
+        if (!FUSE || prologue_done) return;
         prologue_done = true;
         const StepFuse& f = a.fuse;
         const int PA = P + 2;
         if (!f.apply_prev) {  // no pending update: derive the columns from the parameters as they are
+            if (CHAIN)  // (first step of a run) nobody reads the next accumulator yet
+                for (int i = bid * blockDim.x + threadIdx.x; i < D3P_ACC_R * PA; i += a.chain.nw * blockDim.x)
+                    st_x<true>(f.acc_next + i, 0ll);
             for (int col = threadIdx.x; col < P; col += blockDim.x) pack_column(col, f.params_in[col]);
             return;
+        }
+        if (CHAIN) {
+            // every workgroup of the previous step must have added its sums (and published the state) before the
+            // prologue reads them; the first step of a launch follows a kernel boundary instead
+            const int PWc = W < 4 ? W : 4;
+            if (step_t > 0 && wave < PWc && lane == 0)  // target: the non-empty arrival groups
+                (void)chain_wait(a.chain.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS, a.chain.nw < 8 ? (uint32_t)a.chain.nw : 8u,
+                                 a.chain.abort_flag);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            // now nobody reads the next accumulator any more (the previous step's prologues are over): zero it
+            if (wave < PWc)
+                for (int i = bid * (64 * PWc) + (int)threadIdx.x; i < D3P_ACC_R * PA; i += a.chain.nw * 64 * PWc)
+                    st_x<true>(f.acc_next + i, 0ll);
         }
         // n (the count column) is consumed only AFTER the column loads below have been issued: its load was issued
         // at kernel entry, and summing it here first would put a second memory round trip in front of those loads
@@ -349,7 +474,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
         // AFTER the per-lane column loads -- otherwise every uniform load costs its own memory round trip first)
         auto load_n = [&]() {
 #pragma unroll
-            for (int r = 0; r < D3P_ACC_R; ++r) pend_n8[r] = f.acc_prev[(size_t)r * PA + P + 1];
+            for (int r = 0; r < D3P_ACC_R; ++r) pend_n8[r] = ld_x<CHAIN>(f.acc_prev + (size_t)r * PA + P + 1);
             if (!pend_fast) {
                 pend_bc1 = f.prev_meta->bc1;
                 pend_bc2 = f.prev_meta->bc2;
@@ -378,7 +503,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
                 m = (1.0f - f.b1) * g + f.b1 * m;
                 v = (1.0f - f.b2) * g * g + f.b2 * v;
                 x = x - f.lr * (m / pend_bc1) / (sqrtf(v / pend_bc2) + f.adam_eps);
-                if (blockIdx.x == 0) {  // one workgroup publishes the state
+                if (bid == 0) {  // one workgroup publishes the state
                     f.params_out[col] = x;
                     f.m_out[col] = m;
                     f.v_out[col] = v;
@@ -401,10 +526,10 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
                         const int col = col0 + j * stride;
                         const int cc = col < P ? col : 0;
 #pragma unroll
-                        for (int r = 0; r < D3P_ACC_R; ++r) r8[j][r] = f.acc_prev[(size_t)r * PA + cc];
-                        x[j] = f.params_in[cc];
-                        m[j] = f.m_in[cc];
-                        v[j] = f.v_in[cc];
+                        for (int r = 0; r < D3P_ACC_R; ++r) r8[j][r] = ld_x<CHAIN>(f.acc_prev + (size_t)r * PA + cc);
+                        x[j] = ld_x<CHAIN>(f.params_in + cc);
+                        m[j] = ld_x<CHAIN>(f.m_in + cc);
+                        v[j] = ld_x<CHAIN>(f.v_in + cc);
                         z[j] = f.prev_noise[cc];
                     }
                     __builtin_amdgcn_sched_barrier(0);  // keep the uniform loads behind the column loads
@@ -429,10 +554,10 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
                             const float vv = (1.0f - f.b2) * g * g + f.b2 * v[j];
                             const float xx = x[j] - f.lr * (mm * inv_bc1) *
                                                         __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv * inv_bc2) + f.adam_eps);
-                            if (blockIdx.x == 0) {  // one workgroup publishes the state
-                                f.params_out[col] = xx;
-                                f.m_out[col] = mm;
-                                f.v_out[col] = vv;
+                            if (bid == 0) {  // one workgroup publishes the state
+                                st_x<CHAIN>(f.params_out + col, xx);
+                                st_x<CHAIN>(f.m_out + col, mm);
+                                st_x<CHAIN>(f.v_out + col, vv);
                             }
                             pack_column(col, xx);
                         }
@@ -440,13 +565,13 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
                 }
             }
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (bid == 0 && threadIdx.x == 0) {
             load_n();
             const float n = count_n();
             const float factor = (n == 0.0f) ? 0.0f : Bf / n;
             long long lll = 0;
 #pragma unroll
-            for (int r = 0; r < D3P_ACC_R; ++r) lll += f.acc_prev[(size_t)r * PA + P];
+            for (int r = 0; r < D3P_ACC_R; ++r) lll += ld_x<CHAIN>(f.acc_prev + (size_t)r * PA + P);
             if (f.prev_loss_out) *f.prev_loss_out = ((float)((double)lll * f.inv_sl) / Bf) * a.obs_scale * factor;
             *f.adam_step = f.prev_meta->adam_i + 1;
             if (f.batch_index) *f.batch_index = f.prev_meta->batch_i + 1u;
@@ -454,8 +579,8 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
     };
     // the 4 waves (one per SIMD) that apply the pending update in finish_prologue()  (s_setprio on them was measured to
     // change nothing: the SIMD shares its issue slots evenly whatever the priority)
-    const bool prologue_wave = MODE == 2 && !a.fuse.flush_only && a.fuse.apply_prev && wave < 4;
-    if (MODE == 2 && (a.fuse.flush_only || !kLatePrologue)) {
+    const bool prologue_wave = FUSE && !a.fuse.flush_only && a.fuse.apply_prev && wave < 4;
+    if (FUSE && (a.fuse.flush_only || !kLatePrologue)) {
         finish_prologue();
         D3P_STAMP(2)
         if (a.fuse.flush_only) return;
@@ -682,9 +807,9 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
         if (lane == 0) { tail[2 * wave] = loss_acc; tail[2 * wave + 1] = n_acc; }
         __syncthreads();
         D3P_STAMP(6)
-        if (MODE == 2) {
+        if (FUSE) {
             // fixed-point integer atomics: exact, order-independent sum of the workgroups' fp32 partials
-            long long* out = a.fuse.acc_cur + (size_t)(blockIdx.x % D3P_ACC_R) * (P + 2);
+            long long* out = a.fuse.acc_cur + (size_t)(bid % D3P_ACC_R) * (P + 2);
             for (int c = threadIdx.x; c < P; c += blockDim.x) {
                 float s = 0.f;
                 for (int w = 0; w < W; ++w) s += red[(size_t)w * P + c];
@@ -698,8 +823,20 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
                 atomicAdd(reinterpret_cast<unsigned long long*>(out + P + threadIdx.x),
                           (unsigned long long)__double2ll_rn((double)s * sc));
             }
+            if (CHAIN) {
+                // arrive: this workgroup's atomics (and, for workgroup 0, the published state and the zeroed accumulator)
+                // are complete at the memory side before the counters move; two levels keep the contention per word low
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    uint32_t* bar = a.chain.bar + (size_t)step_t * D3P_BAR_WORDS;
+                    const uint32_t nw = (uint32_t)a.chain.nw, grp = bid & 7u, gsize = (nw + 7u - grp) / 8u;
+                    const uint32_t prev = __hip_atomic_fetch_add(bar + 16 * (1 + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
+                    if (prev + 1u == gsize) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, D3P_AGENT);
+                }
+            }
         } else {
-            float* out = a.partials + (size_t)blockIdx.x * (P + 2);
+            float* out = a.partials + (size_t)bid * (P + 2);
             for (int c = threadIdx.x; c < P; c += blockDim.x) {
                 float s = 0.f;
                 for (int w = 0; w < W; ++w) s += red[(size_t)w * P + c];
@@ -714,8 +851,8 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
     }
     if (a.stamps) {
         __syncthreads();
-        if (threadIdx.x == 0) a.stamps[SS * blockIdx.x + 1] = wall_clock64();
-        if ((a.dbg & 32) && threadIdx.x == 0) a.stamps[8 * blockIdx.x + 7] = (unsigned long long)(clock64() - clk0);
+        if (threadIdx.x == 0) a.stamps[SS * bid + 1] = wall_clock64();
+        if ((a.dbg & 32) && threadIdx.x == 0) a.stamps[8 * bid + 7] = (unsigned long long)(clock64() - clk0);
     }
 }
 

@@ -379,6 +379,12 @@ int d3p_dpvi_gmm_update(void* stream, const d3p_gmm_model* model, const d3p_dpsv
                         const d3p_dpsvi_state* state, const float* X_dev, const uint8_t* mask_dev, uint32_t B,
                         float* loss_dev, float* grad_out_dev, void* workspace_dev, size_t workspace_bytes);
 
+/* The single-GPU run loop executes the steps of a prepared batch (<= 32) as ONE launch whose workgroups wait on
+ * arrival counters for the previous step (bounded waits).  This reads back, after synchronising `stream`, whether any
+ * wait of the last run hit its bound (aborted_out != 0: the results of that run are invalid). */
+int d3p_dpvi_logreg_chain_status(void* stream, const d3p_logreg_model* model, const d3p_batch_source* src,
+                                 void* workspace_dev, size_t workspace_bytes, int32_t* aborted_out);
+
 /* ---------------------------------------------------------------------------------------------
  * Data-parallel run over the GPUs of one node (the reference is single-device).  One process per GPU;
  * every rank calls the same sequence.  The communicator is RCCL's, created from an id that rank 0 obtains and the

@@ -6,6 +6,8 @@ rtol 2e-5 (float32 dot products of length d accumulate in a different order; the
 accumulates in float64); batch-level gradients after the sum over B examples to
 rtol 1e-4 / atol 1e-6 * max|g|.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -468,3 +470,54 @@ def test_run_steps_with_more_workgroups_than_cus_matches_stepwise_updates(rng, B
     np.testing.assert_allclose(np_(runs[0][1]), ref_losses, rtol=2e-5)
     np.testing.assert_allclose(np_(runs[0][0].optim_state[1]), np_(ref.optim_state[1]), rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(np_(runs[0][0].optim_state[2]), np_(ref.optim_state[2]), rtol=2e-4, atol=1e-9)
+
+
+def test_chained_launch_matches_one_launch_per_step(rng):
+    """The default run loop executes the <= 32 steps of a prepared batch as ONE launch whose workgroups wait on arrival
+    counters (MODE 3); D3P_NO_CHAINED_STEPS=1 (read once per process, so checked in a child process) selects one launch per
+    step.  Both walk the same trajectory bit for bit -- the sums are exact integer sums in both -- and no wait hit its bound."""
+    import ctypes as C
+    import subprocess
+    import sys
+    import d3p_amd._lib as L
+    from d3p_amd.minibatch import subsample_batchify_data
+    code = r'''
+import sys, torch, numpy as np
+sys.path.insert(0, %r)
+import d3p_amd.random as rng
+from d3p_amd.minibatch import subsample_batchify_data
+from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
+from d3p_amd.svi import DPSVI, DPSVIState
+N, d, B, steps = 50000, 512, 4096, 70
+g = torch.Generator().manual_seed(0)
+X = torch.randn(N, d, generator=g).cuda(); y = (torch.rand(N, generator=g) < 0.5).float().cuda()
+model = LogisticRegression(d)
+svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-2), Trace_ELBO(), 1.0, 0.7, num_obs_total=N)
+st = DPSVIState(svi.optim.init(torch.cat([torch.zeros(d), torch.full((d,), -2.0)]).cuda()), rng.PRNGKey(3), float(N))
+_, gb = subsample_batchify_data((X, y), B)
+s2, losses = svi.run_steps(st, gb, rng.PRNGKey(4), 0, steps)
+np.save(sys.argv[1], np.concatenate([losses.cpu().numpy(), s2.optim_state[1].cpu().numpy()]))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    import tempfile
+    outs = []
+    for env_extra in ({}, {"D3P_NO_CHAINED_STEPS": "1"}):
+        with tempfile.NamedTemporaryFile(suffix=".npy") as f:
+            env = dict(os.environ, **env_extra)
+            subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env, timeout=300)
+            outs.append(np.load(f.name))
+    assert np.array_equal(outs[0], outs[1])
+    # abort flag of the bounded waits after a run in this process
+    N, d, B = 20000, 64, 1024
+    X = torch.randn(N, d).cuda()
+    y = (torch.rand(N) < 0.5).float().cuda()
+    svi = make_svi(d, False, N)
+    st = state_with(svi, rng.PRNGKey(1), np.zeros(d, np.float32), np.full(d, -2.0, np.float32))
+    _, gb = subsample_batchify_data((X, y), B)
+    svi.run_steps(st, gb, rng.PRNGKey(2), 0, 40)
+    lib = L.load()
+    model = svi._model_struct(d, {}, float(N))
+    src = L.BatchSource(L.D3P_BATCH_FEISTEL, B, 0.0, 0, None, None, None, N, 0, N)
+    ws = svi._ws["ws"]
+    flag = C.c_int32(-1)
+    L.check(lib.d3p_dpvi_logreg_chain_status(L.stream_ptr(), C.byref(model), C.byref(src), L.ptr(ws), ws.numel(), C.byref(flag)))
+    assert flag.value == 0
