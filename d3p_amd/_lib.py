@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libd3p_hip.so")
 _SRC = [os.path.join(_HERE, "csrc", f) for f in ("d3p_rng.hip", "d3p_dpvi.hip", "d3p_stages.hip", "d3p_gmm.hip", "d3p_vae.hip")]
-_DEPS = _SRC + [os.path.join(_HERE, "csrc", f) for f in ("d3p_device.h", "d3p_host.h", "d3p_logreg_kernel.h")] + [
+_DEPS = _SRC + [os.path.join(_HERE, "csrc", f) for f in ("d3p_device.h", "d3p_host.h", "d3p_logreg_kernel.h", "d3p_logreg_persist.h")] + [
     os.path.join(os.path.dirname(_HERE), "include", "d3p_hip.h")]
 
 D3P_BATCH_EXPLICIT, D3P_BATCH_FEISTEL, D3P_BATCH_POISSON = 0, 1, 2
@@ -55,12 +55,28 @@ class BatchSource(C.Structure):
 
 
 def build(force=False, verbose=False):
-    """Compile libd3p_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile libd3p_hip.so for gfx950 (hipcc cross-compiles without a GPU): one object per source under build/
+    (recompiled only when the source or a header is newer; the compiles run in parallel), then one link."""
     if not force and os.path.exists(_SO) and all(
             os.path.getmtime(_SO) >= os.path.getmtime(p) for p in _DEPS):
         return _SO
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", _SO] + _SRC
+    objdir = os.path.join(os.path.dirname(_HERE), "build", "d3p_hip")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [p for p in _DEPS if p not in _SRC]
+    newest_header = max(os.path.getmtime(p) for p in headers)
+    jobs, objs = [], []
+    for src in _SRC:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", _SO] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

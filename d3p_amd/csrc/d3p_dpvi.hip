@@ -18,6 +18,7 @@
 // and the NEXT launch's prologue applies mean / noise / Adam (d3p_logreg_kernel.h), so k_finalize disappears from the
 // per-step path; the key-chain step of the next batch rides along as one extra workgroup.
 #include "d3p_logreg_kernel.h"
+#include "d3p_logreg_persist.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only: the entry points are resolved at run time from the RCCL torch has loaded
@@ -733,6 +734,30 @@ static bool use_chained_steps(const Ctx& c)
     return !off && !need_owned_list(c.src) && c.src->kind != D3P_BATCH_EXPLICIT;
 }
 
+// Persistent form (MODE 4, d3p_logreg_persist.h): the same K steps in ONE launch of RESIDENT workgroups that loop over the
+// steps and overlap the noise generation of step t + 1 with the arrival / update latency of step t.  Used when the batch
+// geometry is the specialised one (d = 512, no intercept, softplus guide, one example per wave) and every workgroup of the
+// launch is resident at once (one 1024-thread workgroup per CU); selected with D3P_PERSISTENT_STEPS=1.
+static bool use_persistent_steps(const Ctx& c)
+{
+    static const bool off = getenv("D3P_PERSISTENT_STEPS") == nullptr;  // opt-in while it only ties the chained form
+    if (off || !c.g.full || c.g.V != 4 || c.g.NK != 1 || c.g.W != D3P_PERSIST_W || c.D != D3P_PERSIST_D) return false;
+    if (c.m->guide_transform != D3P_GUIDE_SOFTPLUS || c.m->family != D3P_FAMILY_LOGREG) return false;
+    if ((uint64_t)c.g.blocks * D3P_PERSIST_W < (uint64_t)c.src->B) return false;  // one example per wave and step
+    if (c.g.blocks != D3P_PERSIST_NW) return false;  // workgroup b owns gradient columns 4 b .. 4 b + 3
+    static int resident = -1;  // workgroups of this kernel the device holds at once (queried once per process)
+    if (resident < 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_logreg_persist<false>, 64 * D3P_PERSIST_W, persist_lds_bytes()) != hipSuccess)
+            resident = 0;
+        else
+            resident = cus * per_cu;
+        (void)hipGetLastError();
+    }
+    return (int)c.g.blocks <= resident;
+}
+
 static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* prev_slot0, const float* prev_noise0, const float* X,
                                  const float* y, float* losses, StepSlot* chain_slots, int K_next)
 {
@@ -770,6 +795,33 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
     cf.K_next = chain_slots ? K_next : 0;
     // arrival counters of this launch (the abort flag behind them is sticky for the whole run)
     D3P_HIP_TRY(hipMemsetAsync(c.ws.chain_bar, 0, (size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS * sizeof(uint32_t), c.s));
+    if (use_persistent_steps(c)) {
+        static const bool stamps = getenv("D3P_PERSIST_STAMPS") != nullptr;  // developer diagnostic, read once
+        if (stamps) {
+            a.stamps = c.ws.stamps;
+            hipLaunchKernelGGL(k_logreg_persist<true>, dim3(c.g.blocks), dim3(64 * D3P_PERSIST_W), persist_lds_bytes(), c.s, a);
+            int rc = check_launch("k_logreg_persist");
+            if (rc) return rc;
+            static unsigned long long host[4 * 32 * 16];
+            D3P_HIP_TRY(hipMemcpyAsync(host, c.ws.stamps, sizeof(host), hipMemcpyDeviceToHost, c.s));
+            D3P_HIP_TRY(hipStreamSynchronize(c.s));
+            static int printed = 0;
+            if (printed++ == 2) {  // third launch of the process: steady state
+                for (int wg = 0; wg < 4; ++wg)
+                    for (int t = 8; t < 12 && t < K; ++t) {
+                        const unsigned long long* h = host + ((size_t)wg * 32 + t) * 16;
+                        const unsigned long long z = host[((size_t)0 * 32 + t) * 16 + 2];  // wg 0, wave 0, after barrier S
+                        fprintf(stderr, "wg %3d t %2d | w0: start %.2f C %.2f R %.2f arr1 %.2f A %.2f rows-read %.2f publ %.2f seen2 %.2f | w5: start %.2f C %.2f R %.2f A %.2f\n",
+                                wg * 85, t, ((double)h[2] - z) * 0.01, ((double)h[3] - z) * 0.01, ((double)h[4] - z) * 0.01, ((double)h[5] - z) * 0.01,
+                                ((double)h[7] - z) * 0.01, ((double)h[6] - z) * 0.01, ((double)h[1] - z) * 0.01, ((double)h[12] - z) * 0.01,
+                                ((double)h[8] - z) * 0.01, ((double)h[9] - z) * 0.01, ((double)h[10] - z) * 0.01, ((double)h[11] - z) * 0.01);
+                    }
+            }
+            return D3P_OK;
+        }
+        hipLaunchKernelGGL(k_logreg_persist<false>, dim3(c.g.blocks), dim3(64 * D3P_PERSIST_W), persist_lds_bytes(), c.s, a);
+        return check_launch("k_logreg_persist");
+    }
     MainGeom g2 = c.g;
     g2.blocks = (uint32_t)K * (c.g.blocks + 1u);
     return launch_main<3>(c.s, g2, a);
@@ -832,6 +884,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     const float* prev_noise = nullptr;
     int g = 0;
     const bool chained = !comm && use_chained_steps(c);
+    const bool persist = chained && use_persistent_steps(c);
     if (chained)  // the abort flag of the bounded waits: cleared once per run, read back by d3p_dpvi_logreg_chain_status
         D3P_HIP_TRY(hipMemsetAsync(c.ws.chain_bar + (size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS, 0, 16 * sizeof(uint32_t), c.s));
     for (uint32_t b = 0; b < n_batches; ++b) {
@@ -842,8 +895,10 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
                                             K_next)))
                 return rc;
             g += K;
-            prev_slot = cb[cur].ws.slots + (K - 1);
-            prev_noise = cb[cur].ws.noise + (size_t)(K - 1) * c.P;
+            if (!persist) {  // the persistent form applies every update inside its launch: nothing is pending afterwards
+                prev_slot = cb[cur].ws.slots + (K - 1);
+                prev_noise = cb[cur].ws.noise + (size_t)(K - 1) * c.P;
+            }
         }
         for (int t = 0; !chained && t < K; ++t, ++g) {
             StepSlot* cslot = (!no_piggy && t < K_next) ? cb[nxt].ws.slots + t : nullptr;
@@ -864,6 +919,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
             if ((rc = enqueue_sampler(cb[nxt], K_next))) return rc;
         }
     }
+    if (persist) return D3P_OK;  // state, step counters and losses are already final
     // apply the update of the last step
     const int last_buf = (int)((n_batches - 1) & 1);
     if ((rc = enqueue_fused_step(cb[last_buf], g, 0, prev_slot, prev_noise, X, y, losses ? losses + g - 1 : nullptr, nullptr, 0, 0,

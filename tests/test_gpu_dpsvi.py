@@ -473,9 +473,10 @@ def test_run_steps_with_more_workgroups_than_cus_matches_stepwise_updates(rng, B
 
 
 def test_chained_launch_matches_one_launch_per_step(rng):
-    """The default run loop executes the <= 32 steps of a prepared batch as ONE launch whose workgroups wait on arrival
-    counters (MODE 3); D3P_NO_CHAINED_STEPS=1 (read once per process, so checked in a child process) selects one launch per
-    step.  Both walk the same trajectory bit for bit -- the sums are exact integer sums in both -- and no wait hit its bound."""
+    """The default run loop executes the <= 32 steps of a prepared batch as ONE launch: resident workgroups that loop over
+    the steps (MODE 4, d = 512, D3P_PERSISTENT_STEPS=1) or one workgroup set per step waiting on arrival counters (MODE 3); D3P_NO_CHAINED_STEPS=1 (switches are read once per process, so checked in child
+    processes) selects one launch per step.  All walk the same trajectory bit for bit -- the sums are exact integer sums
+    in each -- and no wait hit its bound."""
     import ctypes as C
     import subprocess
     import sys
@@ -500,14 +501,23 @@ np.save(sys.argv[1], np.concatenate([losses.cpu().numpy(), s2.optim_state[1].cpu
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     import tempfile
     outs = []
-    for env_extra in ({}, {"D3P_NO_CHAINED_STEPS": "1"}):
+    # persistent launch (MODE 4, this geometry qualifies); the chained form (MODE 3); one launch per step
+    for env_extra in ({"D3P_PERSISTENT_STEPS": "1"}, {}, {"D3P_NO_CHAINED_STEPS": "1"}):
         with tempfile.NamedTemporaryFile(suffix=".npy") as f:
             env = dict(os.environ, **env_extra)
             subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env, timeout=300)
             outs.append(np.load(f.name))
-    assert np.array_equal(outs[0], outs[1])
-    # abort flag of the bounded waits after a run in this process
-    N, d, B = 20000, 64, 1024
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.all(np.isfinite(outs[0]))
+    # abort flag of the bounded waits after a run in this process (d = 512: persistent form; d = 64: chained form)
+    for N, d, B in ((20000, 512, 4096), (20000, 64, 1024)):
+        _check_no_wait_hit_its_bound(rng, N, d, B)
+
+
+def _check_no_wait_hit_its_bound(rng, N, d, B):
+    import ctypes as C
+    import d3p_amd._lib as L
+    from d3p_amd.minibatch import subsample_batchify_data
     X = torch.randn(N, d).cuda()
     y = (torch.rand(N) < 0.5).float().cuda()
     svi = make_svi(d, False, N)

@@ -1,0 +1,168 @@
+// Probe: cost per step of the cross-workgroup exchange a PERSISTENT DP-VI step kernel needs (256 resident 1024-thread
+// workgroups, P = 1024 gradient columns), with waves 4..15 optionally busy with ~2.5 us of VALU work (the next step's noise).
+//   mode 0: barrier only (two-level arrival counter, per-wave arrivals of 4 waves)
+//   mode 1: 1024 int64 atomics per workgroup into R replicas, every workgroup in the same column order; barrier; every
+//           workgroup reads the R replicas back (the MODE 2/3 protocol)
+//   mode 2: the same with the start column rotated by workgroup (spreads simultaneous atomics over different lines)
+//   mode 3: plain partial rows: workgroup b stores its 1024 floats, barrier 1, workgroup b sums column block b (4 columns x
+//           256 rows, fixed-point integers => exact), stores the 4 results, barrier 2, everybody reads the 1024 results
+//   mode 4: mode 3 with only 64 reducer workgroups (16 columns each)
+// build: hipcc --offload-arch=gfx950 -O3 -o exchange_probe exchange_probe.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define AGENT __HIP_MEMORY_SCOPE_AGENT
+#define P 1024
+#define PW 4
+
+__device__ __forceinline__ void arrive(unsigned* bar, unsigned nwg, unsigned waves)
+{
+    const unsigned grp = blockIdx.x & 7u, gsize = (nwg + 7u - grp) / 8u;
+    const unsigned prev = __hip_atomic_fetch_add(bar + 16 * (1 + grp), 1u, __ATOMIC_RELAXED, AGENT);
+    if (prev + 1u == gsize * waves) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, AGENT);
+}
+
+__device__ __forceinline__ bool wait_all(const unsigned* bar, unsigned* abort_flag)
+{
+    for (unsigned spins = 0;; ++spins) {
+        if (__hip_atomic_load(bar, __ATOMIC_RELAXED, AGENT) >= 8u) return true;
+        if (spins > (1u << 20) || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, AGENT)) {
+            __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_probe(unsigned long long* acc, float* rows, float* newp, unsigned* bars, unsigned* abort_flag,
+                                                int iters, int mode, int R, int filler, float* out)
+{
+    __shared__ float lds[P];
+    __shared__ long long lsum[4 * 16];
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float carry = 0.f;
+    for (int t = 0; t < iters; ++t) {
+        unsigned* bar1 = bars + (size_t)(2 * t) * 144;
+        unsigned* bar2 = bars + (size_t)(2 * t + 1) * 144;
+        if (wave < PW) {
+            float v[4];
+            for (int j = 0; j < 4; ++j) v[j] = (float)((tid * 4 + j + t) & 255) * 1e-3f + carry;
+            if (mode == 1 || mode == 2) {
+                unsigned long long* a = acc + (size_t)(t % 3) * R * P + (size_t)(bid % R) * P;
+                const int rot = mode == 2 ? (int)((bid / R) * 16) % P : 0;
+                for (int j = 0; j < 4; ++j) {
+                    const int col = (4 * tid + j + rot) % P;
+                    atomicAdd(a + col, (unsigned long long)__float2ll_rn(v[j] * 1048576.0f));
+                }
+                // zero the accumulator two steps ahead (distributed)
+                unsigned long long* z = acc + (size_t)((t + 1) % 3) * R * P;
+                for (int i = bid * 256 + tid; i < R * P; i += nwg * 256) __hip_atomic_store(z + i, 0ull, __ATOMIC_RELAXED, AGENT);
+                __builtin_amdgcn_s_waitcnt(0);
+                if (lane == 0) arrive(bar1, nwg, PW);
+            } else if (mode == 3 || mode == 4) {
+                float* r = rows + ((size_t)(t & 1) * nwg + bid) * P + 4 * tid;
+                for (int j = 0; j < 4; ++j) __hip_atomic_store(r + j, v[j], __ATOMIC_RELAXED, AGENT);
+                __builtin_amdgcn_s_waitcnt(0);
+                if (lane == 0) arrive(bar1, nwg, PW);
+            } else {
+                if (lane == 0) arrive(bar1, nwg, PW);
+            }
+        } else if (filler) {
+            float x = (float)tid;
+            for (int i = 0; i < filler; ++i) x = __fmaf_rn(x, 1.0000001f, 0.5f);
+            if (x == 12345.678f) out[0] = x;
+        }
+        if (wave < PW) {
+            if (lane == 0) (void)wait_all(bar1, abort_flag);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            if (mode == 1 || mode == 2) {
+                const unsigned long long* a = acc + (size_t)(t % 3) * R * P;
+                float s4 = 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    long long s = 0;
+                    for (int r = 0; r < R; ++r) s += (long long)__hip_atomic_load(a + (size_t)r * P + tid + 256 * j, __ATOMIC_RELAXED, AGENT);
+                    lds[tid + 256 * j] = (float)s * 1e-12f;
+                    s4 += (float)s * 1e-12f;
+                }
+                carry = s4 * 1e-6f;
+            } else if (mode == 3 || mode == 4) {
+                const int nred = mode == 3 ? 256 : 64, cpr = P / nred;  // columns per reducer
+                if ((int)bid < nred) {
+                    // thread r sums row r's cpr columns of this block in fixed point; then a 256-thread LDS reduction
+                    const float* src = rows + ((size_t)(t & 1) * nwg + tid) * P + (size_t)bid * cpr;
+                    long long part[16];
+                    for (int c = 0; c < cpr; ++c)
+                        part[c] = tid < (int)nwg ? __float2ll_rn(__hip_atomic_load(src + c, __ATOMIC_RELAXED, AGENT) * 1048576.0f) : 0ll;
+                    for (int c = 0; c < cpr; ++c) {
+                        long long s = part[c];
+                        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                        if (lane == 0) lsum[wave * 16 + c] = s;
+                    }
+                    // 4 waves -> named sync via LDS spin is overkill: each wave publishes, wave 0 combines after a tiny wait
+                    __builtin_amdgcn_s_waitcnt(0);
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+        }
+        __syncthreads();
+        if (mode == 3 || mode == 4) {
+            const int nred = mode == 3 ? 256 : 64, cpr = P / nred;
+            if ((int)bid < nred && tid < cpr) {
+                const long long s = lsum[tid] + lsum[16 + tid] + lsum[32 + tid] + lsum[48 + tid];
+                __hip_atomic_store(newp + (size_t)(t & 1) * P + (size_t)bid * cpr + tid, (float)s * 1e-12f, __ATOMIC_RELAXED, AGENT);
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                if ((int)bid < nred) {
+                    const unsigned grp = bid & 7u, gsize = ((unsigned)nred + 7u - grp) / 8u;
+                    const unsigned prev = __hip_atomic_fetch_add(bar2 + 16 * (1 + grp), 1u, __ATOMIC_RELAXED, AGENT);
+                    if (prev + 1u == gsize) __hip_atomic_fetch_add(bar2, 1u, __ATOMIC_RELAXED, AGENT);
+                }
+                (void)wait_all(bar2, abort_flag);
+            }
+            __syncthreads();
+            if (tid < 256) {
+                float s4 = 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const float x = __hip_atomic_load(newp + (size_t)(t & 1) * P + tid + 256 * j, __ATOMIC_RELAXED, AGENT);
+                    lds[tid + 256 * j] = x;
+                    s4 += x;
+                }
+                carry = s4 * 1e-6f;
+            }
+            __syncthreads();
+        }
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, AGENT)) return;
+    }
+    if (bid == 0 && tid < 256) out[tid] = carry + lds[tid];
+}
+
+int main()
+{
+    hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, 0);
+    const int grid = prop.multiProcessorCount;
+    const int iters = 400;
+    unsigned long long* acc; float *rows, *newp, *out; unsigned* bars;
+    (void)hipMalloc(&acc, 3 * 16 * P * 8); (void)hipMalloc(&rows, 2 * (size_t)grid * P * 4); (void)hipMalloc(&newp, 2 * P * 4);
+    (void)hipMalloc(&out, 4096); (void)hipMalloc(&bars, (size_t)(2 * iters + 1) * 144 * 4 + 64);
+    unsigned* abort_flag = bars + (size_t)(2 * iters) * 144 + 16;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    printf("CUs %d\n", grid);
+    const int cfgs[][3] = {{0, 4, 0}, {0, 4, 600}, {1, 4, 0}, {1, 4, 600}, {1, 8, 600}, {1, 16, 600}, {2, 4, 0}, {2, 4, 600}, {2, 8, 600},
+                           {3, 4, 0}, {3, 4, 600}, {4, 4, 0}, {4, 4, 600}};
+    for (auto& c : cfgs) {
+        (void)hipMemset(acc, 0, 3 * 16 * P * 8); (void)hipMemset(bars, 0, (size_t)(2 * iters + 1) * 144 * 4 + 64);
+        (void)hipMemset(rows, 0, 2 * (size_t)grid * P * 4);
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_probe, dim3(grid), dim3(1024), 0, 0, acc, rows, newp, bars, abort_flag, iters, c[0], c[1], c[2], out);
+        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        unsigned ab = 0; (void)hipMemcpy(&ab, abort_flag, 4, hipMemcpyDeviceToHost);
+        printf("mode %d  R %2d  filler %3d : %.3f us per iteration (abort=%u)\n", c[0], c[1], c[2], ms * 1000 / iters, ab);
+    }
+    return 0;
+}

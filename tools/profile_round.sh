@@ -1,7 +1,7 @@
-set -x
+set -ex
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-O=$R/gpurun_out/r01d
+O=$R/gpurun_out/${PROFILE_TAG:-r01e}
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r01 -- python3 $R/bench.py --steps 2000 --warmup 200 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python3 $R/bench.py --steps 300 --warmup 30 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err
