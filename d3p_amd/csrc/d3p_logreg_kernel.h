@@ -115,7 +115,12 @@ struct Sched {
     uint32_t pad[2];
 };
 
-#define D3P_BAR_WORDS 144        // per step: word 0 = groups arrived, word 16 (1 + g) = arrivals of group g (8 groups)
+// Arrival counters of one step: 17 lines of 128 bytes -- line 0 = groups arrived, line 1 + g = arrivals of group g
+// (blockIdx % 8: the workgroups of one XCD), line 9 + g = release word of group g, written by the workgroup that completes
+// the last group.  Every counter has a line of its own and a waiter polls the release word of its own group: measured on
+// MI355X (tools/probes/barrier_probe.hip), counters sharing lines + every waiter polling one word cost several us more.
+#define D3P_BAR_LINE 32
+#define D3P_BAR_WORDS (17 * D3P_BAR_LINE)
 #define D3P_AGENT __HIP_MEMORY_SCOPE_AGENT
 
 template <bool CH, typename T>
@@ -137,7 +142,8 @@ __device__ __forceinline__ bool chain_wait(const uint32_t* p, uint32_t target, u
 {
     for (uint32_t spins = 0;; ++spins) {
         if (__hip_atomic_load(p, __ATOMIC_RELAXED, D3P_AGENT) >= target) return true;
-        if (spins > (1u << 21) || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, D3P_AGENT) != 0u) {
+        // (the abort flag is looked at every 64th spin only: reading it on every spin doubles the polling traffic)
+        if (spins > (1u << 21) || ((spins & 63u) == 63u && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, D3P_AGENT) != 0u)) {
             __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, D3P_AGENT);
             return false;
         }
@@ -457,8 +463,8 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
             // every workgroup of the previous step must have added its sums (and published the state) before the
             // prologue reads them; the first step of a launch follows a kernel boundary instead
             const int PWc = W < 4 ? W : 4;
-            if (step_t > 0 && wave < PWc && lane == 0)  // target: the non-empty arrival groups
-                (void)chain_wait(a.chain.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS, a.chain.nw < 8 ? (uint32_t)a.chain.nw : 8u,
+            if (step_t > 0 && wave < PWc && lane == 0)  // the release word of this workgroup's group
+                (void)chain_wait(a.chain.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (9 + (bid & 7u)), 1u,
                                  a.chain.abort_flag);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             // now nobody reads the next accumulator any more (the previous step's prologues are over): zero it
@@ -831,8 +837,13 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
                 if (threadIdx.x == 0) {
                     uint32_t* bar = a.chain.bar + (size_t)step_t * D3P_BAR_WORDS;
                     const uint32_t nw = (uint32_t)a.chain.nw, grp = bid & 7u, gsize = (nw + 7u - grp) / 8u;
-                    const uint32_t prev = __hip_atomic_fetch_add(bar + 16 * (1 + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
-                    if (prev + 1u == gsize) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, D3P_AGENT);
+                    const uint32_t prev = __hip_atomic_fetch_add(bar + D3P_BAR_LINE * (1 + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
+                    if (prev + 1u == gsize) {
+                        const uint32_t top = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, D3P_AGENT);
+                        if (top + 1u == (nw < 8u ? nw : 8u))
+                            for (uint32_t g8 = 0; g8 < 8u; ++g8)
+                                __hip_atomic_store(bar + D3P_BAR_LINE * (9 + g8), 1u, __ATOMIC_RELAXED, D3P_AGENT);
+                    }
                 }
             }
         } else {
