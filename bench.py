@@ -148,10 +148,15 @@ def main():
 
     state, _ = run(state, 0, args.warmup)
     barrier()
+    # HIP start/stop events around every step-kernel launch of the timed region, on the launch stream (roofline figure)
+    L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(1))
     t0 = time.perf_counter()
     state, losses = run(state, args.warmup, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(0))
+    kt_us, kt_launches, kt_steps = C.c_double(), C.c_uint32(), C.c_uint32()
+    L.check(lib.d3p_dpvi_logreg_kernel_timing_read(C.byref(kt_us), C.byref(kt_launches), C.byref(kt_steps)))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -159,45 +164,40 @@ def main():
     steps_per_s = args.steps / elapsed
     final_loss = float(losses[-1]) if losses is not None else None
 
-    # ---- dominant kernel (fused gradient/clip/sum), timed live with HIP events on the launch stream
+    # ---- dominant kernel: the step kernel of the timed region itself (k_logreg_main; one chained launch covers up to 32
+    # DP-VI steps on one GPU, one launch per step in the data-parallel loop), HIP events on the launch stream
     P = 2 * D
     roofline = None
-    if rank == 0:
-        st_c = L.DpsviState(torch.zeros((2, 16), dtype=torch.int32, device=dev).data_ptr(), 0,
-                            state.optim_state[1].data_ptr(), state.optim_state[2].data_ptr(),
-                            state.optim_state[3].data_ptr(), state.optim_state[0].data_ptr())
-        keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
-        keybuf[0].copy_(state.rng_key.reshape(16))
-        st_c.rng_key = keybuf.data_ptr()
-        bidx = torch.zeros(1, dtype=torch.int32, device=dev)
-        src = L.BatchSource(L.D3P_BATCH_FEISTEL, Bg, 0.0, 0, bkey.data_ptr(), bidx.data_ptr(), None, n_rows, lo, hi)
-        mdl = svi._model_struct(d, {}, float(n_rows))
-        hyp = svi._hyper()
-        ws = torch.empty(lib.d3p_dpvi_logreg_workspace(C.byref(mdl), C.byref(src)), dtype=torch.uint8, device=dev)
-        avg_us, ev_us = C.c_float(), C.c_float()
-        L.check(lib.d3p_dpvi_logreg_time_main_kernel(L.stream_ptr(), C.byref(mdl), C.byref(hyp), C.byref(st_c),
-                                                     C.byref(src), L.ptr(X), L.ptr(y), L.ptr(ws), ws.numel(), 200,
-                                                     C.byref(avg_us), C.byref(ev_us)))
-        # per launch this rank processes its share of the global batch
-        alg = algorithmic_bytes(Bg // world, d, P)
-        # HIP start/stop events around each launch: the duration that agrees with rocprofv3's kernel trace
-        achieved = alg / (ev_us.value * 1e-6) / 1e9
+    if rank == 0 and kt_launches.value > 0:
+        alg_step = algorithmic_bytes(Bg // world, d, P)   # this rank's share of the global batch, per step
+        steps_per_launch = kt_steps.value / kt_launches.value
+        avg_launch_us = kt_us.value / kt_launches.value
+        alg_launch = alg_step * steps_per_launch
+        achieved = alg_step * kt_steps.value / (kt_us.value * 1e-6) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                per_step = json.load(open(tfile)).get("hbm_bytes_per_step")
+                traffic = per_step * steps_per_launch if per_step is not None else None
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_logreg_main<MODE 2> (one launch per DP-VI step)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(ev_us.value, 3),
-                    "avg_launch_us_device_stamps": round(avg_us.value, 3),
-                    "co_bound": {"what": "VALU issue (eps generation: threefry2x32-20 + erf_inv)",
-                                 "valu_instr_per_launch": 3.2e6, "valu_floor_us": 5.5},
-                    "timing": "avg over 200 launches of the production launch (one-launch step incl. the key-chain "
-                              "workgroup) with HIP start/stop events (hipExtLaunchKernel) on the launch stream; "
-                              "device_stamps = first workgroup entry -> last compute workgroup exit (100 MHz clock)"}
+        chained = world == 1 and not args.force_dist_loop and not os.environ.get("D3P_NO_CHAINED_STEPS")
+        roofline = {"bound": "hbm",
+                    "kernel": ("k_logreg_main<MODE 3> (chained launch: the <= 32 DP-VI steps of a prepared batch per launch)" if chained
+                               else "k_logreg_main<MODE 2> (one launch per DP-VI step)"),
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(alg_launch, 1), "algorithmic_bytes_per_step": alg_step,
+                    "avg_launch_us": round(avg_launch_us, 3), "launches": kt_launches.value,
+                    "steps_per_launch": round(steps_per_launch, 3),
+                    "kernel_us_per_step": round(kt_us.value / kt_steps.value, 3),
+                    "co_bound": {"what": "VALU issue (eps generation: threefry2x32-20 + erf_inv) and, between steps, the "
+                                         "cross-workgroup exchange (arrival counters + redundant update prologue)",
+                                 "valu_instr_per_step": 3.2e6, "valu_floor_us_per_step": 5.5},
+                    "timing": "HIP start/stop events (hipExtLaunchKernel) around EVERY step-kernel launch of the timed region, "
+                              "on the launch stream (d3p_dpvi_logreg_kernel_timing_*); achieved = algorithmic bytes of the "
+                              "steps covered / summed kernel time"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

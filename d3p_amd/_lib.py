@@ -136,6 +136,8 @@ SIGNATURES = {
     "d3p_vae_evaluate": (C.c_int, [_V, _V, _V, _V, _U32, _V, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_vae_update": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _V, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_logreg_chain_status": (C.c_int, [_V, _V, _V, _V, C.c_size_t, _V]),
+    "d3p_dpvi_logreg_kernel_timing_enable": (C.c_int, [C.c_int]),
+    "d3p_dpvi_logreg_kernel_timing_read": (C.c_int, [_V, _V, _V]),
     "d3p_comm_unique_id": (C.c_int, [_V, C.c_size_t]),
     "d3p_comm_init": (C.c_int, [_V, C.c_size_t, _I32, _I32, _V]),
     "d3p_comm_destroy": (C.c_int, [_V]),

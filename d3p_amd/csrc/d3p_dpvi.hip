@@ -21,6 +21,7 @@
 #include "d3p_logreg_persist.h"
 
 #include <dlfcn.h>
+#include <vector>
 #include <rccl/rccl.h>  // types only: the entry points are resolved at run time from the RCCL torch has loaded
 
 #define D3P_STEP_BATCH 32
@@ -633,6 +634,34 @@ static int enqueue_sched_finish(const Ctx& c, int steps_done)
 }
 
 // ------------------------------------------------------------------------------------------
+// kernel timing of the run loops (d3p_dpvi_logreg_kernel_timing_*): event pairs around the step-kernel launches
+// ------------------------------------------------------------------------------------------
+struct KernelTiming {
+    bool on = false;
+    std::vector<hipEvent_t> ev;  // start, stop, start, stop, ...
+    uint32_t steps = 0;
+};
+static KernelTiming g_kt;
+
+// a fresh (start, stop) pair for a launch that covers `steps` DP-VI steps; nullptrs when timing is off
+static void timing_pair(int steps, hipEvent_t* e0, hipEvent_t* e1)
+{
+    *e0 = *e1 = nullptr;
+    if (!g_kt.on) return;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        if (a) (void)hipEventDestroy(a);
+        (void)hipGetLastError();
+        return;
+    }
+    g_kt.ev.push_back(a);
+    g_kt.ev.push_back(b);
+    g_kt.steps += (uint32_t)steps;
+    *e0 = a;
+    *e1 = b;
+}
+
+// ------------------------------------------------------------------------------------------
 // one launch per step (MODE 2)
 // ------------------------------------------------------------------------------------------
 static bool use_fused_step(const Ctx& c)
@@ -819,12 +848,20 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
             }
             return D3P_OK;
         }
-        hipLaunchKernelGGL(k_logreg_persist<false>, dim3(c.g.blocks), dim3(64 * D3P_PERSIST_W), persist_lds_bytes(), c.s, a);
+        hipEvent_t e0, e1;
+        timing_pair(K, &e0, &e1);
+        if (e0)
+            hipExtLaunchKernelGGL(k_logreg_persist<false>, dim3(c.g.blocks), dim3(64 * D3P_PERSIST_W), persist_lds_bytes(), c.s, e0, e1,
+                                  0, a);
+        else
+            hipLaunchKernelGGL(k_logreg_persist<false>, dim3(c.g.blocks), dim3(64 * D3P_PERSIST_W), persist_lds_bytes(), c.s, a);
         return check_launch("k_logreg_persist");
     }
     MainGeom g2 = c.g;
     g2.blocks = (uint32_t)K * (c.g.blocks + 1u);
-    return launch_main<3>(c.s, g2, a);
+    hipEvent_t e0, e1;
+    timing_pair(K, &e0, &e1);
+    return launch_main<3>(c.s, g2, a, e0, e1);
 }
 
 // ---- RCCL, resolved lazily with dlopen so that libd3p_hip.so has no link-time dependency on it (single-GPU users
@@ -902,8 +939,10 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
         }
         for (int t = 0; !chained && t < K; ++t, ++g) {
             StepSlot* cslot = (!no_piggy && t < K_next) ? cb[nxt].ws.slots + t : nullptr;
+            hipEvent_t e0, e1;
+            timing_pair(1, &e0, &e1);
             if ((rc = enqueue_fused_step(cb[cur], g, t, prev_slot, prev_noise, X, y, (losses && g > 0) ? losses + g - 1 : nullptr,
-                                         cslot, t, t == K_next - 1, false)))
+                                         cslot, t, t == K_next - 1, false, false, e0, e1)))
                 return rc;
             if (comm) {
                 const size_t words = (size_t)D3P_ACC_R * (c.P + 2);
@@ -1232,6 +1271,35 @@ int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_d
         if (b + 1 < n_batches && (rc = enqueue_sampler(cb[nxt], K_next))) return rc;
     }
     return enqueue_sched_finish(c, (int)num_steps);
+}
+
+int d3p_dpvi_logreg_kernel_timing_enable(int enable)
+{
+    g_kt.on = enable != 0;
+    return D3P_OK;
+}
+
+int d3p_dpvi_logreg_kernel_timing_read(double* total_us_out, uint32_t* launches_out, uint32_t* steps_out)
+{
+    D3P_REQUIRE(total_us_out && launches_out && steps_out, "d3p_dpvi_logreg_kernel_timing_read: null pointer");
+    double us = 0.0;
+    uint32_t n = 0;
+    hipError_t err = hipSuccess;
+    for (size_t i = 0; i + 1 < g_kt.ev.size(); i += 2) {
+        float ms = 0.f;
+        if (err == hipSuccess) err = hipEventSynchronize(g_kt.ev[i + 1]);
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, g_kt.ev[i], g_kt.ev[i + 1]);
+        if (err == hipSuccess) { us += 1000.0 * ms; ++n; }
+        (void)hipEventDestroy(g_kt.ev[i]);
+        (void)hipEventDestroy(g_kt.ev[i + 1]);
+    }
+    *total_us_out = us;
+    *launches_out = n;
+    *steps_out = g_kt.steps;
+    g_kt.ev.clear();
+    g_kt.steps = 0;
+    if (err != hipSuccess) return fail(D3P_E_HIP, "kernel timing: %s", hipGetErrorString(err));
+    return D3P_OK;
 }
 
 int d3p_dpvi_logreg_chain_status(void* stream, const d3p_logreg_model* model, const d3p_batch_source* src, void* workspace_dev,

@@ -385,6 +385,14 @@ int d3p_dpvi_gmm_update(void* stream, const d3p_gmm_model* model, const d3p_dpsv
 int d3p_dpvi_logreg_chain_status(void* stream, const d3p_logreg_model* model, const d3p_batch_source* src,
                                  void* workspace_dev, size_t workspace_bytes, int32_t* aborted_out);
 
+/* Measurement hook for the run loops (d3p_dpvi_logreg_run, d3p_dpvi_logreg_run_dist): while enabled, every launch of the
+ * step kernel is bracketed by HIP start/stop events on the launch stream (hipExtLaunchKernel).
+ * d3p_dpvi_logreg_kernel_timing_read synchronises the recorded events, returns the summed kernel time (microseconds), the
+ * number of launches and the number of DP-VI steps they covered since the last read, and clears the record.  Process-wide
+ * switch, not thread-safe; used by bench.py for the roofline figure of the kernel that runs in the timed region. */
+int d3p_dpvi_logreg_kernel_timing_enable(int enable);
+int d3p_dpvi_logreg_kernel_timing_read(double* total_us_out, uint32_t* launches_out, uint32_t* steps_out);
+
 /* ---------------------------------------------------------------------------------------------
  * Data-parallel run over the GPUs of one node (the reference is single-device).  One process per GPU;
  * every rank calls the same sequence.  The communicator is RCCL's, created from an id that rank 0 obtains and the

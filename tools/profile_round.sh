@@ -7,7 +7,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r01 -- pytho
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python3 $R/bench.py --steps 300 --warmup 30 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python3 $R/bench.py --steps 300 --warmup 30 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err
 cd $R
-python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > /dev/null 2> $O/pmc_traffic.err
+python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json 330 > /dev/null 2> $O/pmc_traffic.err
 cp $O/pmc_traffic.json $R/profiles/traffic_latest.json 2>/dev/null
 python3 bench.py --steps 3000 --warmup 300 > $O/bench.json 2> $O/bench.err
 ls -R $O | head -40
