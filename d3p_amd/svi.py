@@ -755,15 +755,15 @@ class DPSVI:
         return num_iter
 
     def get_epsilon(self, target_delta, q, num_epochs=None, num_iter=None):
-        """d3p/svi.py:458-462; needs the optional `fourier_accountant` package."""
+        """d3p/svi.py:458-462 (accountant: d3p_amd.accountant, the restated Fourier accountant)."""
         num_iter = self._validate_epochs_and_iter(num_epochs, num_iter, q)
-        from fourier_accountant.compute_eps import get_epsilon_R
+        from d3p_amd.accountant import get_epsilon_R
         return get_epsilon_R(target_delta, self._dp_scale, q, ncomp=num_iter)
 
     def get_delta(self, target_epsilon, q, num_epochs=None, num_iter=None):
-        """d3p/svi.py:464-468; needs the optional `fourier_accountant` package."""
+        """d3p/svi.py:464-468 (accountant: d3p_amd.accountant, the restated Fourier accountant)."""
         num_iter = self._validate_epochs_and_iter(num_epochs, num_iter, q)
-        from fourier_accountant.compute_delta import get_delta_R
+        from d3p_amd.accountant import get_delta_R
         return get_delta_R(target_epsilon, self._dp_scale, q, ncomp=num_iter)
 
 
