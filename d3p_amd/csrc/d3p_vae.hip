@@ -179,13 +179,16 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
 // row-wise / element-wise stages
 // ------------------------------------------------------------------------------------------------------------------
 // per-example guide noise: eps[i][j] = normal word j of the example's sample key (svi.py:289-290; single site 'z')
-__global__ void k_vae_eps(const uint32_t* __restrict__ jax_key, uint32_t B, int Z, float* __restrict__ eps)
+// (data-parallel: a rank holds positions pos0 .. pos0 + B - 1 of a global batch of B_total examples; the key of an example
+// is a function of its GLOBAL position, so 1 GPU and N GPUs draw the same noise)
+__global__ void k_vae_eps(const uint32_t* __restrict__ jax_key, uint32_t B, uint32_t B_total, uint32_t pos0, int Z,
+                          float* __restrict__ eps)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)B * Z) return;
     const uint32_t i = (uint32_t)(t / Z), j = (uint32_t)(t % Z);
     uint32_t k0, k1;
-    px_sample_key(jax_key[0], jax_key[1], B, i, k0, k1);
+    px_sample_key(jax_key[0], jax_key[1], B_total, pos0 + i, k0, k1);
     eps[t] = bits_to_normal(tf_iota_word(k0, k1, (uint64_t)Z, (uint64_t)j));
 }
 
@@ -492,15 +495,16 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
 // forward + backward + norms + clipped sums into ws.sums[P + 2]; eps_dev given or drawn from jax_key
 static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* params, const float* X, const uint8_t* mask,
                             uint32_t B, const float* eps_ext, const uint32_t* jax_key, float clip, const VaeWorkspace& ws,
-                            float* norms_out)
+                            float* norms_out, uint32_t B_total = 0, uint32_t pos0 = 0)
 {
+    if (B_total == 0) B_total = B;
     int rc;
     const int D = m->D, H = m->H, Z = m->Z, Bi = (int)B;
     const VaeLayout L = vae_layout(m);
     const float sc = m->inv_obs * m->scale;
     const float* eps = eps_ext;
     if (!eps) {
-        hipLaunchKernelGGL(k_vae_eps, dim3(cdiv((uint64_t)B * Z, 256)), dim3(256), 0, s, jax_key, B, Z, ws.eps);
+        hipLaunchKernelGGL(k_vae_eps, dim3(cdiv((uint64_t)B * Z, 256)), dim3(256), 0, s, jax_key, B, B_total, pos0, Z, ws.eps);
         eps = ws.eps;
     }
     auto ew = [&](size_t n) { return dim3(cdiv(n, 256)); };
@@ -608,34 +612,67 @@ int d3p_vae_evaluate(void* stream, const d3p_vae_model* model, const float* para
     return check_launch("d3p_vae_evaluate");
 }
 
-int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
-                        const float* X_dev, const uint8_t* mask_dev, uint32_t B, const float* eps_dev, float* loss_dev,
-                        float* grad_out_dev, void* workspace_dev, size_t workspace_bytes)
+static int vae_update_checks(const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                             const void* workspace_dev, const char* what)
 {
-    if (int rc = vae_validate(model, "d3p_dpvi_vae_update")) return rc;
-    D3P_REQUIRE(hyper && state && state->rng_key && state->params && state->adam_m && state->adam_v && state->step && X_dev &&
-                    workspace_dev,
-                "d3p_dpvi_vae_update: null pointer");
+    if (int rc = vae_validate(model, what)) return rc;
+    if (!(hyper && state && state->rng_key && state->params && state->adam_m && state->adam_v && state->step && workspace_dev))
+        return fail(D3P_E_INVALID_ARG, "%s: null pointer", what);
     if (!(hyper->clip > 0.f) || !std::isfinite(hyper->clip))
-        return fail(D3P_E_INVALID_ARG, "d3p_dpvi_vae_update: the clipping threshold must be finite and greater than 0");
-    D3P_REQUIRE(B >= 1, "d3p_dpvi_vae_update: B must be >= 1");
-    if (workspace_bytes < d3p_dpvi_vae_workspace(model, B)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_update: workspace too small");
+        return fail(D3P_E_INVALID_ARG, "%s: the clipping threshold must be finite and greater than 0", what);
+    return D3P_OK;
+}
+
+// keys of one update, all functions of the state key: [next | gradient | perturbation] = split(key, 3) (svi.py:208-211),
+// split(perturbation_key, 10) (svi.py:491), convert_to_jax_rng_key(gradient_key)
+static int vae_step_keys(hipStream_t s, const d3p_dpsvi_state* state, const VaeWorkspace& ws)
+{
+    const int slot = state->key_slot & 1;
+    int rc;
+    if ((rc = d3p_rng_split(s, state->rng_key + 16 * slot, 3, ws.keys))) return rc;
+    if ((rc = d3p_rng_random_bits(s, ws.keys + 16, 32, 2, ws.keys + 208))) return rc;
+    return d3p_rng_split(s, ws.keys + 32, 10, ws.keys + 48);
+}
+
+int d3p_dpvi_vae_local_sums(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                            const float* X_dev, const uint8_t* mask_dev, uint32_t B_local, uint32_t B_total, uint32_t pos0,
+                            const float* eps_dev, float* sums_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_local_sums")) return rc;
+    D3P_REQUIRE(X_dev && sums_dev, "d3p_dpvi_vae_local_sums: null pointer");
+    D3P_REQUIRE(B_local >= 1 && (uint64_t)pos0 + B_local <= B_total, "d3p_dpvi_vae_local_sums: need 1 <= B_local and pos0 + B_local <= B_total");
+    if (workspace_bytes < d3p_dpvi_vae_workspace(model, B_local)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_local_sums: workspace too small");
     VaeWorkspace ws;
-    vae_carve(model, B, (char*)workspace_dev, &ws);
+    vae_carve(model, B_local, (char*)workspace_dev, &ws);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = vae_step_keys(s, state, ws))) return rc;
+    if ((rc = vae_enqueue_sums(s, model, state->params, X_dev, mask_dev, B_local, eps_dev, ws.keys + 208, hyper->clip, ws, nullptr,
+                               B_total, pos0)))
+        return rc;
+    if (sums_dev != ws.sums)
+        D3P_HIP_TRY(hipMemcpyAsync(sums_dev, ws.sums, (vae_layout(model).P + 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return check_launch("d3p_dpvi_vae_local_sums");
+}
+
+int d3p_dpvi_vae_apply(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                       const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
+                       void* workspace_dev, size_t workspace_bytes)
+{
+    if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_apply")) return rc;
+    D3P_REQUIRE(sums_dev && B_total >= 1 && B_local >= 1, "d3p_dpvi_vae_apply: null pointer or empty batch");
+    if (workspace_bytes < d3p_dpvi_vae_workspace(model, B_local)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_apply: workspace too small");
+    VaeWorkspace ws;
+    vae_carve(model, B_local, (char*)workspace_dev, &ws);
     hipStream_t s = (hipStream_t)stream;
     const VaeLayout L = vae_layout(model);
     const int slot = state->key_slot & 1;
-    uint32_t* split3 = ws.keys;           // [next | gradient | perturbation]  (svi.py:208-211)
-    uint32_t* site_keys = ws.keys + 48;   // split(perturbation_key, 10)        (svi.py:491)
-    uint32_t* jax_key = ws.keys + 208;    // convert_to_jax_rng_key(gradient_key)
     int rc;
-    if ((rc = d3p_rng_split(s, state->rng_key + 16 * slot, 3, split3))) return rc;
-    if ((rc = d3p_rng_random_bits(s, split3 + 16, 32, 2, jax_key))) return rc;
-    if ((rc = d3p_rng_split(s, split3 + 32, 10, site_keys))) return rc;
+    if ((rc = vae_step_keys(s, state, ws))) return rc;
     {
         const size_t leaf_off[11] = {L.V1, L.c1, L.V2, L.c2, L.W1, L.b1, L.Wl, L.bl, L.Ws, L.bs, L.P};
         SiteNoiseArgs na;  // one key per leaf, normal(site_key, leaf shape) (svi.py:487)
-        na.site_keys = site_keys;
+        na.site_keys = ws.keys + 48;
         na.noise = ws.noise;
         na.blk_off[0] = 0;
         for (int k = 0; k < 10; ++k) {
@@ -645,9 +682,8 @@ int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsv
         na.elem_off[10] = (uint32_t)leaf_off[10];
         hipLaunchKernelGGL(k_vae_site_noise, dim3(cdiv(na.blk_off[10], 256)), dim3(256), 0, s, na);
     }
-    if ((rc = vae_enqueue_sums(s, model, state->params, X_dev, mask_dev, B, eps_dev, jax_key, hyper->clip, ws, nullptr))) return rc;
     VaeFinalArgs f;
-    f.sums = ws.sums;
+    f.sums = sums_dev;
     f.noise = ws.noise;
     f.params = state->params;
     f.adam_m = state->adam_m;
@@ -656,13 +692,30 @@ int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsv
     f.loss_out = loss_dev;
     f.grad_out = grad_out_dev;
     f.P = L.P;
-    f.B = B;
+    f.B = B_total;
     f.h = *hyper;
     f.obs_scale = 1.0f / model->inv_obs;
     hipLaunchKernelGGL(k_vae_finalize, dim3(cdiv(L.P, 256)), dim3(256), 0, s, f);
     hipLaunchKernelGGL(k_vae_incr, dim3(1), dim3(1), 0, s, state->step);
-    D3P_HIP_TRY(hipMemcpyAsync(state->rng_key + 16 * (slot ^ 1), split3, 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-    return check_launch("d3p_dpvi_vae_update");
+    D3P_HIP_TRY(hipMemcpyAsync(state->rng_key + 16 * (slot ^ 1), ws.keys, 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    return check_launch("d3p_dpvi_vae_apply");
+}
+
+int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                        const float* X_dev, const uint8_t* mask_dev, uint32_t B, const float* eps_dev, float* loss_dev,
+                        float* grad_out_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    // the single-device update IS the data-parallel one with one rank: local sums, (no reduce), apply
+    if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_update")) return rc;
+    D3P_REQUIRE(X_dev, "d3p_dpvi_vae_update: null pointer");
+    D3P_REQUIRE(B >= 1, "d3p_dpvi_vae_update: B must be >= 1");
+    if (workspace_bytes < d3p_dpvi_vae_workspace(model, B)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_update: workspace too small");
+    VaeWorkspace ws;
+    vae_carve(model, B, (char*)workspace_dev, &ws);
+    if (int rc = d3p_dpvi_vae_local_sums(stream, model, hyper, state, X_dev, mask_dev, B, B, 0, eps_dev, ws.sums, workspace_dev,
+                                         workspace_bytes))
+        return rc;
+    return d3p_dpvi_vae_apply(stream, model, hyper, state, ws.sums, B, B, loss_dev, grad_out_dev, workspace_dev, workspace_bytes);
 }
 
 }  // extern "C"

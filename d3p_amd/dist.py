@@ -233,3 +233,71 @@ def run_steps(engine, state, batch_key, first_batch, num_steps, group=None, coll
     if getattr(engine, "losses", None) is not None and collect_losses:
         return new_state, engine.losses[:int(num_steps)]
     return new_state, (torch.stack(losses).reshape(-1) if losses else None)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# VAE (BASELINE config 5, "1 vs 8 GPU"): the dataset (MNIST-sized) is replicated, the BATCH is sharded by position
+# ------------------------------------------------------------------------------------------------------------------
+def shard_batch(batch_size: int, rank: int, world: int):
+    """(pos0, B_local): the contiguous batch positions of `rank` (the first batch_size % world ranks hold one more)."""
+    lo, hi = shard_rows(batch_size, rank, world)
+    return lo, hi - lo
+
+
+class VaeHipEngine:
+    """local_sums / apply of one rank through libd3p_hip.so (d3p_dpvi_vae_local_sums / d3p_dpvi_vae_apply)."""
+
+    def __init__(self, svi, **model_kwargs):
+        _lib.require_device()
+        if not svi._is_vae():
+            raise _lib.D3PError("VaeHipEngine: the DPSVI object must hold a VAEModel / VAEGuide pair")
+        self.svi, self.model_kwargs = svi, model_kwargs
+
+    def begin(self, state, X_local, batch_size_total, pos0, mask=None, eps=None):
+        svi, lib = self.svi, _lib.load()
+        self.X = svi._vae_flat(X_local)
+        self.B_local, D = self.X.shape
+        self.B_total, self.pos0 = int(batch_size_total), int(pos0)
+        dev = self.X.device
+        self.vm = svi._vae_struct(D, self.model_kwargs, state.observation_scale)
+        self.hyper = svi._hyper()
+        self.step, self.params, self.m, self.v = (t.clone() for t in state.optim_state)
+        self.keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
+        self.keybuf[0].copy_(state.rng_key.reshape(16))
+        self.st = svi._state_struct(self.keybuf, 0, (self.step, self.params, self.m, self.v))
+        self.mask = None if mask is None else mask.to(torch.uint8).contiguous()
+        self.eps = eps
+        self.ws = svi._workspace(lib.d3p_dpvi_vae_workspace(C.byref(self.vm), self.B_local), dev, "vae_step")
+        P = int(lib.d3p_vae_num_params(C.byref(self.vm)))
+        self.sums = torch.empty(P + 2, dtype=torch.float32, device=dev)
+        self.loss = torch.empty(1, dtype=torch.float32, device=dev)
+        self.observation_scale = state.observation_scale
+
+    def local_sums(self):
+        check(_lib.load().d3p_dpvi_vae_local_sums(
+            stream_ptr(), C.byref(self.vm), C.byref(self.hyper), C.byref(self.st), ptr(self.X), ptr(self.mask),
+            self.B_local, self.B_total, self.pos0, ptr(self.eps), ptr(self.sums), ptr(self.ws), self.ws.numel()))
+        return self.sums
+
+    def apply(self, sums, grad_out=None):
+        from .svi import DPSVIState
+        check(_lib.load().d3p_dpvi_vae_apply(
+            stream_ptr(), C.byref(self.vm), C.byref(self.hyper), C.byref(self.st), ptr(sums), self.B_total, self.B_local,
+            ptr(self.loss), ptr(grad_out), ptr(self.ws), self.ws.numel()))
+        new_state = DPSVIState((self.step, self.params, self.m, self.v), self.keybuf[1].reshape(4, 4),
+                               self.observation_scale)
+        return new_state, self.loss[0]
+
+
+def vae_update(engine, state, X_local, batch_size_total, pos0, group=None, mask=None, _eps=None, _grad_out=None):
+    """One data-parallel DPSVI.update (svi.py:395-434) of the VAE on every rank of `group`: the rank's examples are the
+    positions pos0 .. pos0 + len(X_local) - 1 of the global batch.  local sums -> ONE all_reduce(SUM) of the P + 2 sums
+    (skipped with world size 1) -> apply (noise once, after the reduce, identical on every rank).  Returns (state, loss)."""
+    import torch.distributed as dist
+    initialised = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if initialised else 1
+    engine.begin(state, X_local, batch_size_total, pos0, mask=mask, eps=_eps)
+    sums = engine.local_sums()
+    if world > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)   # the ONLY data-path collective
+    return engine.apply(sums, _grad_out) if _grad_out is not None else engine.apply(sums)

@@ -462,6 +462,22 @@ int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsv
                         const float* eps_dev, float* loss_dev, float* grad_out_dev, void* workspace_dev,
                         size_t workspace_bytes);
 
+/* Data-parallel form of d3p_dpvi_vae_update (BASELINE config 5, "1 vs 8 GPU"): a rank holds the B_local
+ * examples at positions pos0 .. pos0 + B_local - 1 of the global batch of B_total (per-example noise keys are functions of
+ * the GLOBAL position, svi.py:289-290).  d3p_dpvi_vae_local_sums leaves sums_dev[P + 2] = [sum_i c_i g_i | sum_i loss_i | n]
+ * of the rank's examples; the caller sum-all-reduces sums_dev over the ranks (the ONE collective of the step, 2.76 MB at
+ * 784/400/50) and every rank calls d3p_dpvi_vae_apply with the reduced sums: noise once per parameter leaf from the same
+ * perturbation key on every rank (svi.py:487-491), identical Adam step, new state key in the other key slot -- replicas stay
+ * identical without a broadcast.  state is read by both calls and advanced by apply only.  The workspace is sized for
+ * B_local.  d3p_dpvi_vae_update is exactly local_sums + apply with one rank. */
+int d3p_dpvi_vae_local_sums(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper,
+                            const d3p_dpsvi_state* state, const float* X_dev, const uint8_t* mask_dev, uint32_t B_local,
+                            uint32_t B_total, uint32_t pos0, const float* eps_dev, float* sums_dev, void* workspace_dev,
+                            size_t workspace_bytes);
+int d3p_dpvi_vae_apply(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                       const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
+                       void* workspace_dev, size_t workspace_bytes);
+
 /* Synthetic workload of SURVEY 8(d) / examples/logistic_regression.py:88-104, generated on device:
  * X[r][c] and y[r] are pure functions of (seed, global row, column). */
 int d3p_synth_logreg(void* stream, uint32_t seed, uint64_t row0, uint64_t n_rows, int32_t d,

@@ -293,3 +293,117 @@ def test_native_rccl_loop_on_one_rank_equals_the_single_gpu_run(gpu):
     assert torch.equal(losses, ref_losses)
     assert torch.equal(new_state.optim_state[1], ref_state.optim_state[1])
     assert torch.equal(new_state.rng_key, ref_state.rng_key) and int(new_state.optim_state[0]) == steps
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# VAE (BASELINE config 5): batch positions sharded over the ranks, one all-reduce of the P + 2 sums per update
+# ------------------------------------------------------------------------------------------------------------------
+VB, VD, VH, VZ = 12, 10, 6, 3
+
+
+def _vae_problem(O):
+    r = np.random.default_rng(8)
+    spec = O.vae_spec(VD, VH, VZ, scale=1.0, obs_scale=1.0)
+    P = O.vae_num_params(spec)
+    params = (0.3 * r.normal(size=P)).astype(np.float32)
+    X = (r.random((VB, VD)) < 0.4).astype(np.float32)
+    return spec, P, params, X
+
+
+class OracleVaeEngine:
+    """Engine interface of d3p_amd.dist.vae_update with oracle/ as the compute (test infrastructure only)."""
+
+    def __init__(self, O, spec, params, clip):
+        self.O, self.spec, self.params, self.clip = O, spec, params, clip
+
+    def begin(self, state, X_local, batch_size_total, pos0, mask=None, eps=None):
+        self.key, self.X, self.B_total, self.pos0 = state, np.asarray(X_local), batch_size_total, pos0
+
+    def local_sums(self):
+        O = self.O
+        jax_key = O.convert_to_jax_rng_key(O.split(self.key, 3)[1])
+        eps = O.px_eps(jax_key, self.B_total, VZ)[self.pos0:self.pos0 + len(self.X)]   # keyed by GLOBAL position
+        sums, _, _ = O.vae_step_sums(self.spec, self.params, self.X, eps, self.clip)
+        return torch.from_numpy(sums)
+
+    def apply(self, sums):
+        return sums.numpy().copy(), None   # the test inspects the reduced sums every rank would apply
+
+
+def _vae_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from d3p_amd.dist import shard_batch, vae_update
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec, P, params, X = _vae_problem(O)
+    pos0, b_local = shard_batch(VB, rank, world)
+    eng = OracleVaeEngine(O, spec, params, 2.0)
+    sums, _ = vae_update(eng, O.PRNGKey(5), X[pos0:pos0 + b_local], VB, pos0)
+    out[rank] = (pos0, b_local, sums)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_vae_two_rank_gloo_reduces_to_the_single_process_sums(O):
+    """Every rank ends up with the sums of the WHOLE batch (per-example noise keyed by global position), identical on
+    both ranks: what d3p_dpvi_vae_apply is then called with."""
+    import torch.multiprocessing as mp
+    from d3p_amd.dist import shard_batch
+    assert [shard_batch(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    spec, P, params, X = _vae_problem(O)
+    eps = O.px_eps(O.convert_to_jax_rng_key(O.split(O.PRNGKey(5), 3)[1]), VB, VZ)
+    ref, _, _ = O.vae_step_sums(spec, params, X, eps, 2.0)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_vae_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0][:2] == (0, 6) and out[1][:2] == (6, 6)
+    assert np.array_equal(out[0][2], out[1][2])                    # replicas apply identical sums
+    np.testing.assert_allclose(out[0][2], ref, rtol=2e-5, atol=1e-6)
+    assert out[0][2][P + 1] == VB
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,D,H,Z,world", [(40, 784, 400, 50, 2), (30, 12, 7, 3, 4)])
+def test_vae_virtual_ranks_on_one_gpu_match_single_rank(gpu, O, B, D, H, Z, world):
+    """`world` virtual ranks on one device (batch positions sharded, partial sums added by hand, apply on every rank):
+    replicas are bitwise identical, agree with the single-rank DPSVI.update up to the float order of the sums, and the
+    partial sums of a rank equal the oracle's sums of its positions."""
+    import d3p_amd.random as rng
+    from d3p_amd.dist import VaeHipEngine, shard_batch
+    from d3p_amd.models import Adam, Trace_ELBO, VAEGuide, VAEModel
+    from d3p_amd.svi import DPSVI, DPSVIState
+    N = 60000
+    r = np.random.default_rng(21)
+    spec = O.vae_spec(D, H, Z, scale=1.0, obs_scale=1.0)
+    P = O.vae_num_params(spec)
+    params = ((0.03 if D > 100 else 0.3) * r.normal(size=P)).astype(np.float32)
+    X = (r.random((B, D)) < 0.4).astype(np.float32)
+    model = VAEModel(z_dim=Z, hidden_dim=H, scale=1.0 / N)
+    svi = DPSVI(model, VAEGuide(model), Adam(1e-2), Trace_ELBO(), 3.0, 0.8, num_obs_total=N)
+    st = DPSVIState(svi.optim.init(torch.tensor(params).cuda()), rng.PRNGKey(77), 1.0)
+    Xt = torch.tensor(X).cuda()
+    ref_state, ref_loss = svi.update(st, Xt)
+
+    engines, parts = [], []
+    eps_all = O.px_eps(O.convert_to_jax_rng_key(O.split(O.PRNGKey(77), 3)[1]), B, Z)
+    for rk in range(world):
+        pos0, b_local = shard_batch(B, rk, world)
+        e = VaeHipEngine(DPSVI(model, VAEGuide(model), Adam(1e-2), Trace_ELBO(), 3.0, 0.8, num_obs_total=N))
+        e.begin(st, Xt[pos0:pos0 + b_local], B, pos0)
+        part = e.local_sums().clone()
+        exp, _, _ = O.vae_step_sums(spec, params, X[pos0:pos0 + b_local], eps_all[pos0:pos0 + b_local], 3.0)
+        np.testing.assert_allclose(part.cpu().numpy(), exp, rtol=2e-4, atol=2e-5 * np.abs(exp).max())
+        engines.append(e)
+        parts.append(part)
+    total = torch.stack(parts).sum(dim=0)           # what the all-reduce leaves on every rank
+    outs = [e.apply(total.clone()) for e in engines]
+    for s2, l2 in outs[1:]:
+        assert torch.equal(s2.optim_state[1], outs[0][0].optim_state[1]) and torch.equal(s2.rng_key, outs[0][0].rng_key)
+        assert float(l2) == float(outs[0][1])
+    s0, l0 = outs[0]
+    assert torch.equal(s0.rng_key, ref_state.rng_key) and int(s0.optim_state[0]) == 1
+    assert abs(float(l0) - float(ref_loss)) <= 2e-5 * abs(float(ref_loss))
+    np.testing.assert_allclose(s0.optim_state[1].cpu().numpy(), ref_state.optim_state[1].cpu().numpy(), rtol=1e-4, atol=2e-5)
