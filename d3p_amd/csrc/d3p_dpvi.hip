@@ -760,7 +760,7 @@ static int enqueue_fused_step(const Ctx& c, int g, int t, const StepSlot* prev_s
 static bool use_chained_steps(const Ctx& c)
 {
     static const bool off = getenv("D3P_NO_CHAINED_STEPS") != nullptr;
-    return !off && !need_owned_list(c.src) && c.src->kind != D3P_BATCH_EXPLICIT;
+    return !off && c.src->kind != D3P_BATCH_EXPLICIT;
 }
 
 // Persistent form (MODE 4, d3p_logreg_persist.h): the same K steps in ONE launch of RESIDENT workgroups that loop over the
@@ -774,6 +774,7 @@ static bool use_persistent_steps(const Ctx& c)
     if (c.m->guide_transform != D3P_GUIDE_SOFTPLUS || c.m->family != D3P_FAMILY_LOGREG) return false;
     if ((uint64_t)c.g.blocks * D3P_PERSIST_W < (uint64_t)c.src->B) return false;  // one example per wave and step
     if (c.g.blocks != D3P_PERSIST_NW) return false;  // workgroup b owns gradient columns 4 b .. 4 b + 3
+    if (need_owned_list(c.src)) return false;        // every wave owns one fixed batch position
     static int resident = -1;  // workgroups of this kernel the device holds at once (queried once per process)
     if (resident < 0) {
         int dev = 0, cus = 0, per_cu = 0;
@@ -810,6 +811,7 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
     cf.slots = c.ws.slots;
     cf.idx_base = c.ws.idx;
     cf.skeys_base = c.ws.skeys;
+    cf.plist_base = need_owned_list(c.src) ? c.ws.plist : nullptr;
     cf.noise_base = c.ws.noise;
     cf.prev_slot0 = prev_slot0;
     cf.prev_noise0 = prev_noise0;

@@ -268,6 +268,7 @@ struct ChainFuse {
     StepSlot* slots;             // K slots of this batch
     const uint32_t* idx_base;    // K x B (nullable: rows are positions)
     const uint32_t* skeys_base;  // K x 2B
+    const uint32_t* plist_base;  // K x B dense owned-position lists (nullable: every batch position is processed)
     const float* noise_base;     // K x P
     const StepSlot* prev_slot0;  // slot of step g0 - 1 (nullptr: nothing to apply before step 0)
     const float* prev_noise0;
@@ -349,6 +350,10 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a
         a.idx = cf.idx_base ? cf.idx_base + (size_t)step_t * a_in.B : nullptr;
         a.counts = cf.slots[step_t].counts;
         a.skeys = cf.skeys_base + (size_t)step_t * 2 * a_in.B;
+        if (cf.plist_base) {  // Poisson padding / row-sharded ranks: the step's valid, owned positions
+            a.plist = cf.plist_base + (size_t)step_t * a_in.B;
+            a.n_list = &cf.slots[step_t].n_owned;
+        }
         StepFuse& f = a.fuse;
         f.acc_prev = cf.acc_base + (size_t)((g + 2) % 3) * words;
         f.acc_cur = cf.acc_base + (size_t)(g % 3) * words;

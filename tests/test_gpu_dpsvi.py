@@ -514,6 +514,37 @@ np.save(sys.argv[1], np.concatenate([losses.cpu().numpy(), s2.optim_state[1].cpu
         _check_no_wait_hit_its_bound(rng, N, d, B)
 
 
+def test_chained_launch_with_poisson_batches_matches_one_launch_per_step(rng):
+    """Poisson batches are padded to max_batch_size and processed through dense lists of the valid positions; the chained
+    launch walks those lists too and is bitwise identical to one launch per step."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, torch, numpy as np
+sys.path.insert(0, %r)
+import d3p_amd.random as rng
+from d3p_amd.minibatch import poisson_batchify_data
+from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
+from d3p_amd.svi import DPSVI, DPSVIState
+N, d, steps = 60000, 512, 70
+g = torch.Generator().manual_seed(0)
+X = torch.randn(N, d, generator=g).cuda(); y = (torch.rand(N, generator=g) < 0.5).float().cuda()
+model = LogisticRegression(d)
+svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-2), Trace_ELBO(), 1.0, 0.7, num_obs_total=N)
+st = DPSVIState(svi.optim.init(torch.cat([torch.zeros(d), torch.full((d,), -2.0)]).cuda()), rng.PRNGKey(3), float(N))
+_, gb = poisson_batchify_data((X, y), 4096 / N, 0.99)
+s2, losses = svi.run_steps(st, gb, rng.PRNGKey(4), 0, steps)
+np.save(sys.argv[1], np.concatenate([losses.cpu().numpy(), s2.optim_state[1].cpu().numpy()]))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    outs = []
+    for env_extra in ({}, {"D3P_NO_CHAINED_STEPS": "1"}):
+        with tempfile.NamedTemporaryFile(suffix=".npy") as f:
+            subprocess.run([sys.executable, "-c", code, f.name], check=True, env=dict(os.environ, **env_extra), timeout=300)
+            outs.append(np.load(f.name))
+    assert np.array_equal(outs[0], outs[1]) and np.all(np.isfinite(outs[0]))
+
+
 def _check_no_wait_hit_its_bound(rng, N, d, B):
     import ctypes as C
     import d3p_amd._lib as L
