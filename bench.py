@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-batch", action="store_true",
+                    help="skip the extra leg that times the same step kernel at batch 32768 (throughput regime)")
     ap.add_argument("--sampler", choices=["feistel", "poisson"], default="feistel",
                     help="feistel = subsample_batchify_data w/o replacement (headline); poisson = poisson_batchify_data "
                          "with q = B/N and the 0.99-quantile padding of examples/logistic_regression.py:126-127")
@@ -198,6 +200,26 @@ def main():
                     "timing": "HIP start/stop events (hipExtLaunchKernel) around EVERY step-kernel launch of the timed region, "
                               "on the launch stream (d3p_dpvi_logreg_kernel_timing_*); achieved = algorithmic bytes of the "
                               "steps covered / summed kernel time"}
+
+    # ---- the same kernel in the throughput regime (context for `frac`: at batch 4096 a step is latency-bound by the
+    # cross-workgroup exchange; at batch 32768 = 8 examples per wave it runs at its VALU ceiling)
+    if roofline is not None and world == 1 and not args.force_dist_loop and not args.no_large_batch and args.sampler == "feistel":
+        Bl = 32768
+        _, gb_l = subsample_batchify_data((X, y), Bl)
+        st_l, _ = svi.run_steps(state, gb_l, bkey, 0, 64)
+        torch.cuda.synchronize()
+        L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(1))
+        svi.run_steps(st_l, gb_l, bkey, 64, 320)
+        torch.cuda.synchronize()
+        L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(0))
+        us_l, n_l, steps_l = C.c_double(), C.c_uint32(), C.c_uint32()
+        L.check(lib.d3p_dpvi_logreg_kernel_timing_read(C.byref(us_l), C.byref(n_l), C.byref(steps_l)))
+        if steps_l.value:
+            ach = algorithmic_bytes(Bl, d, P) * steps_l.value / (us_l.value * 1e-6) / 1e9
+            roofline["large_batch"] = {"batch": Bl, "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBPS, 4),
+                                       "kernel_us_per_step": round(us_l.value / steps_l.value, 3),
+                                       "note": "same kernel and method, 320 steps at batch 32768 on one GPU (8 examples per "
+                                               "wave): the VALU-issue ceiling of the fused step with JAX-faithful noise"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

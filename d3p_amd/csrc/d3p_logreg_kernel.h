@@ -929,6 +929,23 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g)
     // waves per workgroup (default 16 = one 1024-thread workgroup per CU at 4 waves/SIMD), reduced until
     // pack (5D) + reduction buffer (W x P) fit 64 KiB of LDS; one example per wave per pass.
     int W = g->NK == 1 ? 16 : 8, epw = 1;
+    {
+        // One workgroup per CU and ceil(B / (W x CUs)) examples per wave: every workgroup pays the update prologue (48 KB
+        // of replica / state reads) and P + 2 accumulator atomics per step, so more workgroups than CUs only multiplies
+        // that (B = 32768: 2048 workgroups 80.5 us per step, 256 workgroups x 8 examples per wave 41.8 us = 1.61 TB/s of
+        // algorithmic traffic, the VALU ceiling of this kernel; B = 8192: 23.0 -> 16.9 us).
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+                n = 256;
+            (void)hipGetLastError();
+            return n;
+        }();
+        const uint64_t per_pass = (uint64_t)W * (uint64_t)cus;
+        epw = (int)(((uint64_t)B + per_pass - 1) / per_pass);
+        if (epw < 1) epw = 1;
+        if (epw > 64) epw = 64;
+    }
     {  // developer overrides of the geometry (tuning sweeps), read once per process
         static const int env_w = [] { const char* e = getenv("D3P_MAIN_W"); return e ? atoi(e) : 0; }();
         static const int env_epw = [] { const char* e = getenv("D3P_MAIN_EPW"); return e ? atoi(e) : 0; }();
