@@ -197,7 +197,8 @@ def main():
                     "co_bound": {"what": "VALU issue (eps generation: threefry2x32-20 + erf_inv) and, between steps, the "
                                          "cross-workgroup exchange (arrival counters + redundant update prologue)",
                                  "valu_instr_per_step": 3.2e6, "valu_floor_us_per_step": 5.5},
-                    "timing": "HIP start/stop events (hipExtLaunchKernel) around EVERY step-kernel launch of the timed region, "
+                    "timing": "HIP start/stop events (hipExtLaunchKernel) around " + ("every 16th" if (world > 1 or args.force_dist_loop) else "EVERY") +
+                              " step-kernel launch of the timed region, "
                               "on the launch stream (d3p_dpvi_logreg_kernel_timing_*); achieved = algorithmic bytes of the "
                               "steps covered / summed kernel time"}
 

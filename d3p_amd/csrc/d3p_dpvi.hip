@@ -941,8 +941,10 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
         }
         for (int t = 0; !chained && t < K; ++t, ++g) {
             StepSlot* cslot = (!no_piggy && t < K_next) ? cb[nxt].ws.slots + t : nullptr;
-            hipEvent_t e0, e1;
-            timing_pair(1, &e0, &e1);
+            // (data-parallel loop: only every 16th launch is bracketed, so that event creation does not sit on the host's
+            // enqueue path of every step)
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (!comm || (g & 15) == 0) timing_pair(1, &e0, &e1);
             if ((rc = enqueue_fused_step(cb[cur], g, t, prev_slot, prev_noise, X, y, (losses && g > 0) ? losses + g - 1 : nullptr,
                                          cslot, t, t == K_next - 1, false, false, e0, e1)))
                 return rc;
