@@ -7,6 +7,8 @@
 //   mode 3: plain partial rows: workgroup b stores its 1024 floats, barrier 1, workgroup b sums column block b (4 columns x
 //           256 rows, fixed-point integers => exact), stores the 4 results, barrier 2, everybody reads the 1024 results
 //   mode 4: mode 3 with only 64 reducer workgroups (16 columns each)
+//   mode 5: mode 1, but the replicas are read back with PLAIN loads behind an agent-scope acquire fence (buffer_inv sc1):
+//           do the 32 workgroups of an XCD then share the lines through their L2 instead of each going to the memory side?
 // build: hipcc --offload-arch=gfx950 -O3 -o exchange_probe exchange_probe.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -49,7 +51,7 @@ __global__ void __launch_bounds__(1024) k_probe(unsigned long long* acc, float* 
         if (wave < PW) {
             float v[4];
             for (int j = 0; j < 4; ++j) v[j] = (float)((tid * 4 + j + t) & 255) * 1e-3f + carry;
-            if (mode == 1 || mode == 2) {
+            if (mode == 1 || mode == 2 || mode == 5) {
                 unsigned long long* a = acc + (size_t)(t % 3) * R * P + (size_t)(bid % R) * P;
                 const int rot = mode == 2 ? (int)((bid / R) * 16) % P : 0;
                 for (int j = 0; j < 4; ++j) {
@@ -77,7 +79,18 @@ __global__ void __launch_bounds__(1024) k_probe(unsigned long long* acc, float* 
         if (wave < PW) {
             if (lane == 0) (void)wait_all(bar1, abort_flag);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            if (mode == 1 || mode == 2) {
+            if (mode == 5) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const unsigned long long* a = acc + (size_t)(t % 3) * R * P;
+                float s4 = 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    long long s = 0;
+                    for (int r = 0; r < R; ++r) s += (long long)a[(size_t)r * P + tid + 256 * j];
+                    lds[tid + 256 * j] = (float)s * 1e-12f;
+                    s4 += (float)s * 1e-12f;
+                }
+                carry = s4 * 1e-6f;
+            } else if (mode == 1 || mode == 2) {
                 const unsigned long long* a = acc + (size_t)(t % 3) * R * P;
                 float s4 = 0.f;
                 for (int j = 0; j < 4; ++j) {
@@ -151,8 +164,7 @@ int main()
     unsigned* abort_flag = bars + (size_t)(2 * iters) * 144 + 16;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     printf("CUs %d\n", grid);
-    const int cfgs[][3] = {{0, 4, 0}, {0, 4, 600}, {1, 4, 0}, {1, 4, 600}, {1, 8, 600}, {1, 16, 600}, {2, 4, 0}, {2, 4, 600}, {2, 8, 600},
-                           {3, 4, 0}, {3, 4, 600}, {4, 4, 0}, {4, 4, 600}};
+    const int cfgs[][3] = {{0, 4, 0}, {1, 4, 0}, {1, 8, 0}, {1, 16, 0}, {5, 4, 0}, {5, 8, 0}, {5, 16, 0}, {3, 4, 0}};
     for (auto& c : cfgs) {
         (void)hipMemset(acc, 0, 3 * 16 * P * 8); (void)hipMemset(bars, 0, (size_t)(2 * iters + 1) * 144 * 4 + 64);
         (void)hipMemset(rows, 0, 2 * (size_t)grid * P * 4);
