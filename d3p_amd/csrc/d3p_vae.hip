@@ -634,6 +634,10 @@ static int vae_step_keys(hipStream_t s, const d3p_dpsvi_state* state, const VaeW
     return d3p_rng_split(s, ws.keys + 32, 10, ws.keys + 48);
 }
 
+static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                          const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
+                          void* workspace_dev, size_t workspace_bytes, bool derive_keys);
+
 int d3p_dpvi_vae_local_sums(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                             const float* X_dev, const uint8_t* mask_dev, uint32_t B_local, uint32_t B_total, uint32_t pos0,
                             const float* eps_dev, float* sums_dev, void* workspace_dev, size_t workspace_bytes)
@@ -659,6 +663,16 @@ int d3p_dpvi_vae_apply(void* stream, const d3p_vae_model* model, const d3p_dpsvi
                        const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
                        void* workspace_dev, size_t workspace_bytes)
 {
+    return vae_apply_impl(stream, model, hyper, state, sums_dev, B_total, B_local, loss_dev, grad_out_dev, workspace_dev,
+                          workspace_bytes, true);
+}
+
+// derive_keys = false: the keys of this update are already in the workspace (left there by d3p_dpvi_vae_local_sums on the same
+// workspace and state, as in the single-device update)
+static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                          const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
+                          void* workspace_dev, size_t workspace_bytes, bool derive_keys)
+{
     if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_apply")) return rc;
     D3P_REQUIRE(sums_dev && B_total >= 1 && B_local >= 1, "d3p_dpvi_vae_apply: null pointer or empty batch");
     if (workspace_bytes < d3p_dpvi_vae_workspace(model, B_local)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_apply: workspace too small");
@@ -668,7 +682,7 @@ int d3p_dpvi_vae_apply(void* stream, const d3p_vae_model* model, const d3p_dpsvi
     const VaeLayout L = vae_layout(model);
     const int slot = state->key_slot & 1;
     int rc;
-    if ((rc = vae_step_keys(s, state, ws))) return rc;
+    if (derive_keys && (rc = vae_step_keys(s, state, ws))) return rc;
     {
         const size_t leaf_off[11] = {L.V1, L.c1, L.V2, L.c2, L.W1, L.b1, L.Wl, L.bl, L.Ws, L.bs, L.P};
         SiteNoiseArgs na;  // one key per leaf, normal(site_key, leaf shape) (svi.py:487)
@@ -715,7 +729,7 @@ int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsv
     if (int rc = d3p_dpvi_vae_local_sums(stream, model, hyper, state, X_dev, mask_dev, B, B, 0, eps_dev, ws.sums, workspace_dev,
                                          workspace_bytes))
         return rc;
-    return d3p_dpvi_vae_apply(stream, model, hyper, state, ws.sums, B, B, loss_dev, grad_out_dev, workspace_dev, workspace_bytes);
+    return vae_apply_impl(stream, model, hyper, state, ws.sums, B, B, loss_dev, grad_out_dev, workspace_dev, workspace_bytes, false);
 }
 
 }  // extern "C"
