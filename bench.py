@@ -148,7 +148,20 @@ def main():
                 return ddist.run_steps_native(engine, st, bkey, first, k, comm=comm, collect_losses=False)
             return ddist.run_steps(engine, st, bkey, first, k, collect_losses=False)
 
-    state, _ = run(state, 0, args.warmup)
+    try:
+        state, _ = run(state, 0, args.warmup)
+    except Exception as e:  # noqa: BLE001
+        # the native RCCL loop has only been rehearsed on one rank: if it fails at run time, drive the same steps through
+        # torch.distributed instead of losing the measurement (all ranks take the same branch: the failure is collective)
+        if world == 1 and not args.force_dist_loop:
+            raise
+        if comm is None:
+            raise
+        if rank == 0:
+            print(f"[bench] native RCCL loop failed in warm-up ({e}); falling back to the torch.distributed loop", file=sys.stderr)
+        comm = None
+        dist_driver = "torch"
+        state, _ = run(state, 0, args.warmup)
     barrier()
     # HIP start/stop events around every step-kernel launch of the timed region, on the launch stream (roofline figure)
     L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(1))

@@ -7,6 +7,7 @@
 //   mode 3: plain partial rows: workgroup b stores its 1024 floats, barrier 1, workgroup b sums column block b (4 columns x
 //           256 rows, fixed-point integers => exact), stores the 4 results, barrier 2, everybody reads the 1024 results
 //   mode 4: mode 3 with only 64 reducer workgroups (16 columns each)
+//   mode 6: mode 3 with the partial row published by 64-bit atomic swaps (2 floats each, result dropped) instead of stores
 //   mode 5: mode 1, but the replicas are read back with PLAIN loads behind an agent-scope acquire fence (buffer_inv sc1):
 //           do the 32 workgroups of an XCD then share the lines through their L2 instead of each going to the memory side?
 // build: hipcc --offload-arch=gfx950 -O3 -o exchange_probe exchange_probe.hip
@@ -63,6 +64,12 @@ __global__ void __launch_bounds__(1024) k_probe(unsigned long long* acc, float* 
                 for (int i = bid * 256 + tid; i < R * P; i += nwg * 256) __hip_atomic_store(z + i, 0ull, __ATOMIC_RELAXED, AGENT);
                 __builtin_amdgcn_s_waitcnt(0);
                 if (lane == 0) arrive(bar1, nwg, PW);
+            } else if (mode == 6) {
+                unsigned long long* r = reinterpret_cast<unsigned long long*>(rows + ((size_t)(t & 1) * nwg + bid) * P + 4 * tid);
+                (void)__hip_atomic_exchange(r, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]), __ATOMIC_RELAXED, AGENT);
+                (void)__hip_atomic_exchange(r + 1, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]), __ATOMIC_RELAXED, AGENT);
+                __builtin_amdgcn_s_waitcnt(0);
+                if (lane == 0) arrive(bar1, nwg, PW);
             } else if (mode == 3 || mode == 4) {
                 float* r = rows + ((size_t)(t & 1) * nwg + bid) * P + 4 * tid;
                 for (int j = 0; j < 4; ++j) __hip_atomic_store(r + j, v[j], __ATOMIC_RELAXED, AGENT);
@@ -100,8 +107,8 @@ __global__ void __launch_bounds__(1024) k_probe(unsigned long long* acc, float* 
                     s4 += (float)s * 1e-12f;
                 }
                 carry = s4 * 1e-6f;
-            } else if (mode == 3 || mode == 4) {
-                const int nred = mode == 3 ? 256 : 64, cpr = P / nred;  // columns per reducer
+            } else if (mode == 3 || mode == 4 || mode == 6) {
+                const int nred = mode != 4 ? 256 : 64, cpr = P / nred;  // columns per reducer
                 if ((int)bid < nred) {
                     // thread r sums row r's cpr columns of this block in fixed point; then a 256-thread LDS reduction
                     const float* src = rows + ((size_t)(t & 1) * nwg + tid) * P + (size_t)bid * cpr;
@@ -120,8 +127,8 @@ __global__ void __launch_bounds__(1024) k_probe(unsigned long long* acc, float* 
             }
         }
         __syncthreads();
-        if (mode == 3 || mode == 4) {
-            const int nred = mode == 3 ? 256 : 64, cpr = P / nred;
+        if (mode == 3 || mode == 4 || mode == 6) {
+            const int nred = mode != 4 ? 256 : 64, cpr = P / nred;
             if ((int)bid < nred && tid < cpr) {
                 const long long s = lsum[tid] + lsum[16 + tid] + lsum[32 + tid] + lsum[48 + tid];
                 __hip_atomic_store(newp + (size_t)(t & 1) * P + (size_t)bid * cpr + tid, (float)s * 1e-12f, __ATOMIC_RELAXED, AGENT);
@@ -164,7 +171,7 @@ int main()
     unsigned* abort_flag = bars + (size_t)(2 * iters) * 144 + 16;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     printf("CUs %d\n", grid);
-    const int cfgs[][3] = {{0, 4, 0}, {1, 4, 0}, {1, 8, 0}, {1, 16, 0}, {5, 4, 0}, {5, 8, 0}, {5, 16, 0}, {3, 4, 0}};
+    const int cfgs[][3] = {{0, 4, 0}, {1, 4, 0}, {1, 8, 0}, {1, 16, 0}, {3, 4, 0}, {6, 4, 0}, {3, 4, 600}, {6, 4, 600}};
     for (auto& c : cfgs) {
         (void)hipMemset(acc, 0, 3 * 16 * P * 8); (void)hipMemset(bars, 0, (size_t)(2 * iters + 1) * 144 * 4 + 64);
         (void)hipMemset(rows, 0, 2 * (size_t)grid * P * 4);
