@@ -7,7 +7,7 @@ weights and modes plus the cluster-assignment accuracy on held-out data :112-161
 
 Differences to the reference script, forced by the environment: model and guide are declared
 (d3p_amd.models.GaussianMixtureModel / GaussianMixtureGuide) instead of traced NumPyro functions, the toy data comes
-from torch's generator, dp_scale is given directly (the Fourier accountant behind approximate_sigma is not installed).
+from torch's generator, dp_scale is calibrated for --epsilon by d3p_amd.dputil as in the reference (:193-196), or given directly with --sigma.
 """
 import argparse
 import itertools
@@ -66,8 +66,17 @@ def main(args):
     dpsvi_rng, svi_init_rng, fetch_rng = rng_suite.split(dpsvi_rng, 3)
     iters_per_epoch, batchifier_state = train_init(fetch_rng)
 
+    dp_scale = getattr(args, "sigma", None)
+    if dp_scale is None:  # examples/gaussian_mixture_model.py:193-196
+        from d3p_amd.dputil import approximate_sigma_remove_relation
+        # (maxeval 20 instead of the default 10: at epsilon = 10 the search starts next to the accountant's unstable
+        # range and needs the extra evaluations to reach the tolerance; very few iterations -- e.g. -n 3 -- put the answer
+        # inside that range and raise RuntimeError, as designed in d3p/dputil.py:69-70: pass --sigma then)
+        dp_scale, eps, _ = approximate_sigma_remove_relation(args.epsilon, 1 / N, q, num_iter=iters_per_epoch * args.num_epochs,
+                                                             maxeval=20)
+        print("noise scale {:.4f} for epsilon {:.4f}, delta {:.2e}".format(dp_scale, eps, 1 / N))
     model = GaussianMixtureModel()
-    svi = DPSVI(model, GaussianMixtureGuide(model), Adam(args.learning_rate), Trace_ELBO(), dp_scale=args.sigma,
+    svi = DPSVI(model, GaussianMixtureGuide(model), Adam(args.learning_rate), Trace_ELBO(), dp_scale=dp_scale,
                 clipping_threshold=20., k=k, num_obs_total=N, rng_suite=rng_suite)
     batch, _ = train_fetch(0, batchifier_state)
     svi_state = svi.init(svi_init_rng, *batch)
@@ -109,5 +118,6 @@ if __name__ == "__main__":
     parser.add_argument('-d', '--dimensions', default=2, type=int, help='data dimension')
     parser.add_argument('-N', '--num-samples', default=2048, type=int, help='data samples count')
     parser.add_argument('-k', '--num-components', default=3, type=int, help='number of components in the mixture model')
-    parser.add_argument('--sigma', default=1.0, type=float, help='dp_scale of the Gaussian mechanism')
+    parser.add_argument('-e', '--epsilon', default=10., type=float, help='privacy parameter epsilon (delta = 1 / N)')
+    parser.add_argument('--sigma', default=None, type=float, help='dp_scale of the Gaussian mechanism (overrides --epsilon)')
     main(parser.parse_args())

@@ -4,9 +4,9 @@ examples/logistic_regression.py (model :49-66, training loop :118-204) on the d3
 
 Differences to the reference script, all forced by the environment: the model is declared
 (d3p_amd.models.LogisticRegression) instead of traced from a NumPyro function, the guide is
-AutoDiagonalNormal (README.md:99) instead of the hand-written guide, dp_scale is given directly
-(the Fourier accountant is not installed), and an epoch is one `run_steps` call (the reference's
-jit(fori_loop(...)) at :149-160).
+AutoDiagonalNormal (README.md:99) instead of the hand-written guide, and an epoch is one `run_steps` call (the
+reference's jit(fori_loop(...)) at :149-160).  As in the reference (:135-137) dp_scale is calibrated for --epsilon, with
+d3p_amd.dputil on the restated Fourier accountant; --sigma gives it directly.
 """
 import argparse
 import os
@@ -46,8 +46,14 @@ def main(args):
     num_iter_per_epoch, batchifier_state = train_init(rng_key=data_fetch_rng)
     sample_batch, _ = train_fetch(0, batchifier_state)
 
+    dp_scale = getattr(args, "sigma", None)
+    if dp_scale is None:  # examples/logistic_regression.py:135-137: calibrate the noise for the target epsilon
+        from d3p_amd.dputil import approximate_sigma_remove_relation
+        dp_scale, eps, _ = approximate_sigma_remove_relation(args.epsilon, delta=1 / N**2, q=q,
+                                                             num_iter=num_iter_per_epoch * args.num_epochs)
+        print("noise scale {:.4f} for epsilon {:.4f}, delta {:.2e}".format(dp_scale, eps, 1 / N**2))
     model = LogisticRegression(args.dimensions, prior_scale=1.0, intercept=True)
-    svi = DPSVI(model, AutoDiagonalNormal(model), Adam(args.learning_rate), Trace_ELBO(), dp_scale=args.sigma,
+    svi = DPSVI(model, AutoDiagonalNormal(model), Adam(args.learning_rate), Trace_ELBO(), dp_scale=dp_scale,
                 clipping_threshold=1., num_obs_total=N, rng_suite=rng_suite)
     svi_state = svi.init(svi_init_rng, *sample_batch)
 
@@ -79,7 +85,8 @@ def main(args):
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser(description="parse args")
-    parser.add_argument('--sigma', default=1.0, type=float, help='dp_scale of the Gaussian mechanism')
+    parser.add_argument('-e', '--epsilon', default=.1, type=float, help='privacy epsilon (delta = 1 / N^2)')
+    parser.add_argument('--sigma', default=None, type=float, help='dp_scale of the Gaussian mechanism (overrides --epsilon)')
     parser.add_argument('-n', '--num-epochs', default=10, type=int, help='number of training epochs')
     parser.add_argument('-lr', '--learning-rate', default=1.0e-2, type=float, help='learning rate')
     parser.add_argument('-batch-size', default=200, type=int, help='batch size')

@@ -48,6 +48,12 @@ def main(args):
     _, batchifier_state = train_init(rng_key=batchifier_rng)
     svi_state = svi.init(svi_init_rng, *train_fetch(0, batchifier_state))
 
+    q = args.batch_size / N
+    delta = getattr(args, "delta", None)
+    if delta is not None:  # examples/simple_gaussian_posterior.py:136-140
+        eps = svi.get_epsilon(delta, q, num_epochs=args.num_epochs)
+        print("Privacy epsilon {} (for sigma: {}, delta: {}, C: {}, q: {})".format(eps, args.sigma, delta, args.clip_threshold, q))
+
     for i in range(args.num_epochs):
         t0 = time.time()
         dpsvi_rng, data_fetch_rng = rng_suite.split(dpsvi_rng, 2)
@@ -81,5 +87,6 @@ if __name__ == "__main__":
     parser.add_argument('-d', '--dimensions', default=4, type=int, help='data dimension')
     parser.add_argument('-N', '--num-samples', default=10000, type=int, help='data samples count')
     parser.add_argument('--sigma', default=1.0, type=float, help='privacy scale')
+    parser.add_argument('--delta', default=1e-5, type=float, help='privacy slack parameter delta')
     parser.add_argument('-C', '--clip-threshold', default=1., type=float, help='clipping threshold for gradients')
     main(parser.parse_args())

@@ -6,9 +6,9 @@ training batches :172 and held-out evaluation.
 
 Differences to the reference script, forced by the environment: MNIST cannot be downloaded (no network), so the data are
 synthetic 28 x 28 binary images (ten random prototype patterns with 5 % pixel flips); encoder and decoder are the
-declared d3p_amd.models.VAEGuide / VAEModel instead of stax modules traced by NumPyro; dp_scale is given directly
-(the Fourier accountant behind approximate_sigma is not installed); reconstructions are summarised by their pixel
-error instead of being written as image files.
+declared d3p_amd.models.VAEGuide / VAEModel instead of stax modules traced by NumPyro; reconstructions are summarised by
+their pixel error instead of being written as image files.  As in the reference (:199-207) dp_scale is calibrated for
+--epsilon by d3p_amd.dputil.approximate_sigma; --sigma gives it directly.
 """
 import argparse
 import os
@@ -50,8 +50,14 @@ def main(args):
     X_train, X_test = X[:N].contiguous(), X[N:].contiguous()
     train_init, train_fetch = subsample_batchify_data((X_train,), batch_size=args.batch_size, rng_suite=rng_suite)
 
+    dp_scale = getattr(args, "sigma", None)
+    if dp_scale is None:  # examples/vae.py:199-207 (substitution relation: batches of fixed size without replacement)
+        from d3p_amd.dputil import approximate_sigma
+        num_iter = (N // args.batch_size) * args.num_epochs
+        dp_scale, eps, _ = approximate_sigma(args.epsilon, 1 / N, args.batch_size / N, num_iter, maxeval=20)
+        print(f"using noise scale {dp_scale} for epsilon of {eps} (targeted: {args.epsilon})")
     model = VAEModel(scale=1.0 / N)
-    svi = DPSVI(model, VAEGuide(model), Adam(args.learning_rate), Trace_ELBO(), dp_scale=args.sigma,
+    svi = DPSVI(model, VAEGuide(model), Adam(args.learning_rate), Trace_ELBO(), dp_scale=dp_scale,
                 clipping_threshold=10., num_obs_total=N, z_dim=args.z_dim, hidden_dim=args.hidden_dim,
                 rng_suite=rng_suite)
     dpsvi_rng = rng_suite.PRNGKey(0)
@@ -85,5 +91,6 @@ if __name__ == "__main__":
     parser.add_argument('-z-dim', default=50, type=int, help='size of latent')
     parser.add_argument('-hidden-dim', default=400, type=int, help='size of hidden layer in encoder/decoder networks')
     parser.add_argument('-N', '--num-samples', default=8192, type=int, help='training images')
-    parser.add_argument('--sigma', default=1.0, type=float, help='dp_scale of the Gaussian mechanism')
+    parser.add_argument('--epsilon', default=1., type=float, help='targeted value for privacy parameter epsilon')
+    parser.add_argument('--sigma', default=None, type=float, help='dp_scale of the Gaussian mechanism (overrides --epsilon)')
     main(parser.parse_args())
