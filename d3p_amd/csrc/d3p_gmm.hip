@@ -485,7 +485,9 @@ struct GmmFinalArgs {
     uint32_t n_rows;     // partial rows
     uint32_t B;
     int P;
-    const float* noise;  // P standard normals: site alpha_log (K) then site mus_loc (K d)
+    const float* noise;  // P standard normals: site alpha_log (K) then site mus_loc (K d); unused when site_keys is given
+    const uint32_t* site_keys;  // nullable: split(perturbation_key, 2) -- the noise is then generated inside the kernel
+    int K;
     float* params;
     float* adam_m;
     float* adam_v;
@@ -495,6 +497,91 @@ struct GmmFinalArgs {
     d3p_dpsvi_hyper h;
     float obs_scale;
 };
+
+// Everything of one update that is a function of the state alone, in ONE launch (each of these was a launch of ~5 us: three
+// key derivations, a one-block keystream, the parameter pack, the step counter and a 64-byte copy made up a third of the
+// 140 us step):  wave 0: [next | gradient | perturbation] = split(state_key, 3) (svi.py:208-211), the next state key written
+// straight into the other key slot, jax_key = convert_to_jax_rng_key(gradient_key) (svi.py:259), site keys =
+// split(perturbation_key, 2) (svi.py:491); wave 1: the double-precision pack of the Dirichlet parameters; the optimiser step
+// index is saved for k_gmm_finalize and advanced.
+struct GmmPreArgs {
+    const uint32_t* cur_key;
+    uint32_t* next_slot;
+    uint32_t* keys;        // workspace: split3 (48) | site keys (32) | folded batch key (16) | jax key (2)
+    const float* params;
+    int K;
+    double* pack;
+    int32_t* step;
+    int32_t* step_saved;
+    const uint32_t* batch_key;  // nullable (run loop): keys[80..95] = fold_in(batch_key, batch_index), minibatch.py:226-230
+    uint32_t batch_index;
+};
+
+__global__ void __launch_bounds__(128) k_gmm_pre(GmmPreArgs a)
+{
+    __shared__ uint32_t sk[3][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        if (lane < 3) {
+            uint32_t parent[16], child[16];
+            load_key(a.cur_key, parent);
+            derive_child(parent, (uint32_t)lane, 0u, D3P_TAG_SPLIT, child);
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                a.keys[16 * lane + w] = child[w];
+                sk[lane][w] = child[w];
+                if (lane == 0) a.next_slot[w] = child[w];
+            }
+        }
+        if (lane == 3) {
+            const int32_t i = *a.step;
+            *a.step_saved = i;
+            *a.step = i + 1;
+        }
+        if (lane == 4 && a.batch_key) {
+            uint32_t parent[16], child[16];
+            load_key(a.batch_key, parent);
+            derive_child(parent, 0u, a.batch_index, D3P_TAG_FOLD, child);
+#pragma unroll
+            for (int w = 0; w < 16; ++w) a.keys[80 + w] = child[w];
+        }
+    } else {
+        // pack (doubles): [alpha_k (K) | psi(alpha_k) (K) | psi(A0), A0, lgamma(A0) - sum lgamma(alpha_k) - lgamma(K)]
+        const int k = lane, K = a.K;
+        double alpha = 0.0, lg = 0.0;
+        if (k < K) {
+            alpha = exp((double)a.params[k]);
+            lg = lgamma(alpha);
+            a.pack[k] = alpha;
+            a.pack[K + k] = digamma_d(alpha);
+        }
+        double A0 = 0.0, LG = 0.0;
+        for (int j = 0; j < K; ++j) {  // fixed order
+            A0 += readlane_d(alpha, j);
+            LG += readlane_d(lg, j);
+        }
+        if (k == 0) {
+            a.pack[2 * K] = digamma_d(A0);
+            a.pack[2 * K + 1] = A0;
+            a.pack[2 * K + 2] = lgamma(A0) - LG - lgamma((double)K);
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 3) {
+        uint32_t key[16], o[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) key[w] = sk[lane == 0 ? 1 : 2][w];
+        if (lane == 0) {  // random_bits(gradient_key, 32, (2,))
+            keystream_block(key, 0u, o);
+            a.keys[96] = o[0];
+            a.keys[97] = o[1];
+        } else {          // split(perturbation_key, 2)[lane - 1]
+            derive_child(key, (uint32_t)(lane - 1), 0u, D3P_TAG_SPLIT, o);
+#pragma unroll
+            for (int w = 0; w < 16; ++w) a.keys[48 + 16 * (lane - 1) + w] = o[w];
+        }
+    }
+}
 
 // First reduction level: the per-wavefront partial rows are cut into D3P_GMM_CHUNKS chunks of consecutive rows; workgroup
 // (column tile of 64, chunk) sums its rows with 4 row subgroups and leaves one row per chunk.  Fixed order throughout.
@@ -554,7 +641,21 @@ __global__ void __launch_bounds__(256) k_gmm_finalize(GmmFinalArgs a)
         float tot = 0.f;
 #pragma unroll
         for (int g = 0; g < 8; ++g) tot += lds[g * 32 + c];
-        const float g = (tot / Bf + a.noise[col] * (a.h.dp_scale * (a.h.clip / n))) * a.obs_scale * factor;
+        float z;
+        if (a.site_keys) {  // normal(site_key, leaf shape)[e] generated here (d3p.random.normal: word e of the key's stream)
+            const int site = col >= a.K ? 1 : 0;
+            const uint32_t e = (uint32_t)(col - (site ? a.K : 0));
+            uint32_t key[16], o[16];
+            load_key(a.site_keys + 16 * site, key);
+            keystream_block(key, e >> 4, o);
+            uint32_t word = o[0];
+#pragma unroll
+            for (int w = 1; w < 16; ++w) word = ((e & 15u) == (uint32_t)w) ? o[w] : word;
+            z = bits_to_normal(word);
+        } else {
+            z = a.noise[col];
+        }
+        const float g = (tot / Bf + z * (a.h.dp_scale * (a.h.clip / n))) * a.obs_scale * factor;
         if (a.grad_out) a.grad_out[col] = g;
         const int i = *a.step;
         float x = a.params[col], m = a.adam_m[col], v = a.adam_v[col];
@@ -569,8 +670,6 @@ __global__ void __launch_bounds__(256) k_gmm_finalize(GmmFinalArgs a)
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.loss_out) *a.loss_out = (ls / Bf) * a.obs_scale * factor;  // svi.py:342, :306
 }
 
-__global__ void k_gmm_incr(int32_t* step) { *step += 1; }
-
 #define D3P_GMM_MAX_WAVES 4096u
 
 struct GmmWorkspace {
@@ -582,6 +681,7 @@ struct GmmWorkspace {
     float* meta;
     uint32_t* keys;   // 3 x 16 (split of the state key) + 2 x 16 (site keys) + 16 (folded batch key) + jax key (2)
     uint32_t* idx;    // B
+    int32_t* step_saved;  // optimiser step index of the update in flight (k_gmm_pre -> k_gmm_finalize)
 };
 
 static size_t gmm_carve(const d3p_gmm_model* m, uint32_t B, char* base, GmmWorkspace* ws)
@@ -598,6 +698,7 @@ static size_t gmm_carve(const d3p_gmm_model* m, uint32_t B, char* base, GmmWorks
     q = take(2 * sizeof(float)); if (ws) ws->meta = (float*)q;
     q = take((6 * 16 + 2) * sizeof(uint32_t)); if (ws) ws->keys = (uint32_t*)q;
     q = take((size_t)B * sizeof(uint32_t)); if (ws) ws->idx = (uint32_t*)q;
+    q = take(sizeof(int32_t)); if (ws) ws->step_saved = (int32_t*)q;
     return off;
 }
 
@@ -734,9 +835,12 @@ size_t d3p_dpvi_gmm_workspace(const d3p_gmm_model* model, uint32_t B)
 }
 
 // One DPSVI.update (svi.py:395-434) for the mixture model, enqueued on `stream` without host synchronisation.
+// batch_key_dev != nullptr (run loop): the batch of this step is get_batch(batch_index, batch_key) of
+// subsample_batchify_data (minibatch.py:226-237) over n_rows rows -- fold_in in the pre kernel, Feistel indices into ws.idx
 static int gmm_enqueue_update(hipStream_t s, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                               int slot, const float* X_dev, const uint32_t* idx_dev, const uint8_t* mask_dev, uint32_t B,
-                              float* loss_dev, float* grad_out_dev, const GmmWorkspace& ws)
+                              float* loss_dev, float* grad_out_dev, const GmmWorkspace& ws,
+                              const uint32_t* batch_key_dev = nullptr, uint32_t batch_index = 0, uint32_t n_rows = 0)
 {
     int rc;
     const int K = model->K, P = K + K * model->d;
@@ -744,12 +848,25 @@ static int gmm_enqueue_update(hipStream_t s, const d3p_gmm_model* model, const d
     uint32_t* split3 = ws.keys;             // [next | gradient | perturbation]   (svi.py:208-211, :413-414)
     uint32_t* site_keys = ws.keys + 48;     // split(perturbation_key, 2)          (svi.py:491)
     uint32_t* jax_key = ws.keys + 96;       // convert_to_jax_rng_key(gradient_key) (svi.py:259)
-    if ((rc = d3p_rng_split(s, cur_key, 3, split3))) return rc;
-    if ((rc = d3p_rng_random_bits(s, split3 + 16, 32, 2, jax_key))) return rc;
-    if ((rc = d3p_rng_split(s, split3 + 32, 2, site_keys))) return rc;
-    if ((rc = d3p_rng_normal(s, site_keys, (uint64_t)K, ws.noise))) return rc;
-    if ((rc = d3p_rng_normal(s, site_keys + 16, (uint64_t)(P - K), ws.noise + K))) return rc;
-    hipLaunchKernelGGL(k_gmm_pack, dim3(1), dim3(64), 0, s, (const float*)state->params, K, ws.pack);
+    {
+        GmmPreArgs pa;
+        pa.cur_key = cur_key;
+        pa.next_slot = state->rng_key + 16 * ((slot + 1) & 1);
+        pa.keys = ws.keys;
+        pa.params = state->params;
+        pa.K = K;
+        pa.pack = ws.pack;
+        pa.step = state->step;
+        pa.step_saved = ws.step_saved;
+        pa.batch_key = batch_key_dev;
+        pa.batch_index = batch_index;
+        hipLaunchKernelGGL(k_gmm_pre, dim3(1), dim3(128), 0, s, pa);
+    }
+    if (batch_key_dev) {
+        if ((rc = d3p_feistel_sample(s, ws.keys + 80, n_rows, B, ws.idx))) return rc;
+        idx_dev = ws.idx;
+    }
+    (void)split3;
     hipLaunchKernelGGL(k_gmm_dirichlet, dim3(cdiv((uint64_t)B * K, 256)), dim3(256), 0, s, (const double*)ws.pack,
                        (const uint32_t*)jax_key, B, K, ws.dir);
     GmmArgs a;
@@ -767,18 +884,18 @@ static int gmm_enqueue_update(hipStream_t s, const d3p_gmm_model* model, const d
     f.n_rows = D3P_GMM_CHUNKS;
     f.B = B;
     f.P = P;
-    f.noise = ws.noise;
+    f.noise = nullptr;
+    f.site_keys = site_keys;
+    f.K = K;
     f.params = state->params;
     f.adam_m = state->adam_m;
     f.adam_v = state->adam_v;
-    f.step = state->step;
+    f.step = ws.step_saved;
     f.loss_out = loss_dev;
     f.grad_out = grad_out_dev;
     f.h = *hyper;
     f.obs_scale = 1.0f / model->inv_obs;
     hipLaunchKernelGGL(k_gmm_finalize, dim3(cdiv(P, 32)), dim3(256), 0, s, f);
-    hipLaunchKernelGGL(k_gmm_incr, dim3(1), dim3(1), 0, s, state->step);
-    D3P_HIP_TRY(hipMemcpyAsync(state->rng_key + 16 * ((slot + 1) & 1), split3, 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     return check_launch("d3p_dpvi_gmm_update");
 }
 
@@ -816,14 +933,10 @@ int d3p_dpvi_gmm_run(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_h
     D3P_REQUIRE(B <= n_rows, "d3p_dpvi_gmm_run: batch larger than the table");
     GmmWorkspace ws;
     gmm_carve(model, B, (char*)workspace_dev, &ws);
-    uint32_t* folded = ws.keys + 80;
     for (uint32_t t = 0; t < num_steps; ++t) {
         int rc;
-        // get_batch(i, batchifier_state) of subsample_batchify_data (minibatch.py:226-237): fold_in + Feistel sample
-        if ((rc = d3p_rng_fold_in(stream, batch_key_dev, first_batch + t, folded))) return rc;
-        if ((rc = d3p_feistel_sample(stream, folded, n_rows, B, ws.idx))) return rc;
-        if ((rc = gmm_enqueue_update((hipStream_t)stream, model, hyper, state, state->key_slot + (int)t, X_dev, ws.idx, nullptr, B,
-                                     losses_dev ? losses_dev + t : nullptr, nullptr, ws)))
+        if ((rc = gmm_enqueue_update((hipStream_t)stream, model, hyper, state, state->key_slot + (int)t, X_dev, nullptr, nullptr, B,
+                                     losses_dev ? losses_dev + t : nullptr, nullptr, ws, batch_key_dev, first_batch + t, n_rows)))
             return rc;
     }
     return D3P_OK;
