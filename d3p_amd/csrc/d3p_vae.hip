@@ -403,7 +403,47 @@ __global__ void __launch_bounds__(256) k_vae_scale_all(ScaleArgs a)
     d[e] *= a.cf[e / (uint32_t)n];
 }
 
-__global__ void k_vae_incr(int32_t* step) { *step += 1; }
+// All keys of one update in ONE launch (they were three launches + a step-counter launch + a 64-byte copy, ~5 us each):
+// keys[0..47] = [next | gradient | perturbation] = split(state_key, 3) (svi.py:208-211), keys[48..207] =
+// split(perturbation_key, 10) (svi.py:491), keys[208..209] = convert_to_jax_rng_key(gradient_key).  advance: also write the
+// next state key into the other key slot, save the optimiser step index in keys[210] for k_vae_finalize and advance it.
+__global__ void __launch_bounds__(64) k_vae_keys(const uint32_t* __restrict__ cur_key, uint32_t* __restrict__ keys,
+                                                 uint32_t* __restrict__ next_slot, int32_t* __restrict__ step, int advance)
+{
+    __shared__ uint32_t sk[3][16];
+    const int lane = threadIdx.x;
+    if (lane < 3) {
+        uint32_t parent[16], child[16];
+        load_key(cur_key, parent);
+        derive_child(parent, (uint32_t)lane, 0u, D3P_TAG_SPLIT, child);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            keys[16 * lane + w] = child[w];
+            sk[lane][w] = child[w];
+            if (lane == 0 && advance) next_slot[w] = child[w];
+        }
+    }
+    if (lane == 3 && advance) {
+        const int32_t i = *step;
+        keys[210] = (uint32_t)i;
+        *step = i + 1;
+    }
+    __syncthreads();
+    if (lane < 11) {
+        uint32_t key[16], o[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) key[w] = sk[lane == 0 ? 1 : 2][w];
+        if (lane == 0) {
+            keystream_block(key, 0u, o);
+            keys[208] = o[0];
+            keys[209] = o[1];
+        } else {
+            derive_child(key, (uint32_t)(lane - 1), 0u, D3P_TAG_SPLIT, o);
+#pragma unroll
+            for (int w = 0; w < 16; ++w) keys[48 + 16 * (lane - 1) + w] = o[w];
+        }
+    }
+}
 
 struct VaeLayout {  // offsets of the 10 leaves in tree_flatten order
     size_t V1, c1, V2, c2, W1, b1, Wl, bl, Ws, bs, P;
@@ -457,7 +497,7 @@ static size_t vae_carve(const d3p_vae_model* m, uint32_t B, char* base, VaeWorks
     q = take(B); if (ws) ws->cf = q;
     q = take(P + 2); if (ws) ws->sums = q;
     q = take(P); if (ws) ws->noise = q;
-    q = take(13 * 16 + 2); if (ws) ws->keys = (uint32_t*)q;
+    q = take(13 * 16 + 2 + 2); if (ws) ws->keys = (uint32_t*)q;  // + [210]: optimiser step index of the update in flight
     const size_t pf = 16 * (D + 1) * H;  // split-K partial tiles: up to 16 splits of the largest weight matrix
     q = take(pf); if (ws) { ws->part = q; ws->part_floats = pf; }
     return off;
@@ -625,22 +665,23 @@ static int vae_update_checks(const d3p_vae_model* model, const d3p_dpsvi_hyper* 
 
 // keys of one update, all functions of the state key: [next | gradient | perturbation] = split(key, 3) (svi.py:208-211),
 // split(perturbation_key, 10) (svi.py:491), convert_to_jax_rng_key(gradient_key)
-static int vae_step_keys(hipStream_t s, const d3p_dpsvi_state* state, const VaeWorkspace& ws)
+static int vae_step_keys(hipStream_t s, const d3p_dpsvi_state* state, const VaeWorkspace& ws, bool advance)
 {
     const int slot = state->key_slot & 1;
-    int rc;
-    if ((rc = d3p_rng_split(s, state->rng_key + 16 * slot, 3, ws.keys))) return rc;
-    if ((rc = d3p_rng_random_bits(s, ws.keys + 16, 32, 2, ws.keys + 208))) return rc;
-    return d3p_rng_split(s, ws.keys + 32, 10, ws.keys + 48);
+    hipLaunchKernelGGL(k_vae_keys, dim3(1), dim3(64), 0, s, (const uint32_t*)(state->rng_key + 16 * slot), ws.keys,
+                       state->rng_key + 16 * (slot ^ 1), state->step, advance ? 1 : 0);
+    return check_launch("k_vae_keys");
 }
 
 static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                           const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
                           void* workspace_dev, size_t workspace_bytes, bool derive_keys);
 
-int d3p_dpvi_vae_local_sums(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
-                            const float* X_dev, const uint8_t* mask_dev, uint32_t B_local, uint32_t B_total, uint32_t pos0,
-                            const float* eps_dev, float* sums_dev, void* workspace_dev, size_t workspace_bytes)
+// advance = true (single-device update): the key kernel also writes the next state key and advances the step counter, so that
+// vae_apply_impl(derive_keys = false) has nothing left to launch for them
+static int vae_local_sums_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                               const float* X_dev, const uint8_t* mask_dev, uint32_t B_local, uint32_t B_total, uint32_t pos0,
+                               const float* eps_dev, float* sums_dev, void* workspace_dev, size_t workspace_bytes, bool advance)
 {
     if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_local_sums")) return rc;
     D3P_REQUIRE(X_dev && sums_dev, "d3p_dpvi_vae_local_sums: null pointer");
@@ -650,13 +691,21 @@ int d3p_dpvi_vae_local_sums(void* stream, const d3p_vae_model* model, const d3p_
     vae_carve(model, B_local, (char*)workspace_dev, &ws);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if ((rc = vae_step_keys(s, state, ws))) return rc;
+    if ((rc = vae_step_keys(s, state, ws, advance))) return rc;
     if ((rc = vae_enqueue_sums(s, model, state->params, X_dev, mask_dev, B_local, eps_dev, ws.keys + 208, hyper->clip, ws, nullptr,
                                B_total, pos0)))
         return rc;
     if (sums_dev != ws.sums)
         D3P_HIP_TRY(hipMemcpyAsync(sums_dev, ws.sums, (vae_layout(model).P + 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
     return check_launch("d3p_dpvi_vae_local_sums");
+}
+
+int d3p_dpvi_vae_local_sums(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                            const float* X_dev, const uint8_t* mask_dev, uint32_t B_local, uint32_t B_total, uint32_t pos0,
+                            const float* eps_dev, float* sums_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    return vae_local_sums_impl(stream, model, hyper, state, X_dev, mask_dev, B_local, B_total, pos0, eps_dev, sums_dev, workspace_dev,
+                               workspace_bytes, false);
 }
 
 int d3p_dpvi_vae_apply(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
@@ -682,7 +731,7 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
     const VaeLayout L = vae_layout(model);
     const int slot = state->key_slot & 1;
     int rc;
-    if (derive_keys && (rc = vae_step_keys(s, state, ws))) return rc;
+    if (derive_keys && (rc = vae_step_keys(s, state, ws, true))) return rc;
     {
         const size_t leaf_off[11] = {L.V1, L.c1, L.V2, L.c2, L.W1, L.b1, L.Wl, L.bl, L.Ws, L.bs, L.P};
         SiteNoiseArgs na;  // one key per leaf, normal(site_key, leaf shape) (svi.py:487)
@@ -702,7 +751,7 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
     f.params = state->params;
     f.adam_m = state->adam_m;
     f.adam_v = state->adam_v;
-    f.step = state->step;
+    f.step = reinterpret_cast<const int32_t*>(ws.keys + 210);  // the step index k_vae_keys saved before advancing it
     f.loss_out = loss_dev;
     f.grad_out = grad_out_dev;
     f.P = L.P;
@@ -710,8 +759,6 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
     f.h = *hyper;
     f.obs_scale = 1.0f / model->inv_obs;
     hipLaunchKernelGGL(k_vae_finalize, dim3(cdiv(L.P, 256)), dim3(256), 0, s, f);
-    hipLaunchKernelGGL(k_vae_incr, dim3(1), dim3(1), 0, s, state->step);
-    D3P_HIP_TRY(hipMemcpyAsync(state->rng_key + 16 * (slot ^ 1), ws.keys, 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
     return check_launch("d3p_dpvi_vae_apply");
 }
 
@@ -726,8 +773,8 @@ int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsv
     if (workspace_bytes < d3p_dpvi_vae_workspace(model, B)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_update: workspace too small");
     VaeWorkspace ws;
     vae_carve(model, B, (char*)workspace_dev, &ws);
-    if (int rc = d3p_dpvi_vae_local_sums(stream, model, hyper, state, X_dev, mask_dev, B, B, 0, eps_dev, ws.sums, workspace_dev,
-                                         workspace_bytes))
+    if (int rc = vae_local_sums_impl(stream, model, hyper, state, X_dev, mask_dev, B, B, 0, eps_dev, ws.sums, workspace_dev,
+                                     workspace_bytes, true))
         return rc;
     return vae_apply_impl(stream, model, hyper, state, ws.sums, B, B, loss_dev, grad_out_dev, workspace_dev, workspace_bytes, false);
 }
