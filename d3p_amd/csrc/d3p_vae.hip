@@ -61,10 +61,15 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& g, int row, int col, 
 #define D3P_GT 64  // tile edge
 #define D3P_GK 16  // K slice
 
+// VA / VB: the operand is fetched with ONE 16-byte load per thread and slice along its unit-stride dimension (the host
+// checks alignment and that the other stride and the extents are multiples of 4); otherwise 4 scalar loads with per-element
+// guards.  The scalar form issues 8 loads per thread and slice, each behind 64-bit index arithmetic, and was the
+// bottleneck of these GEMMs (adding one more dependent load per element cost +13 % on the whole step).
+template <bool VA, bool VB>
 __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
 {
-    __shared__ float As[D3P_GK][D3P_GT + 4];  // [k][m]
-    __shared__ float Bs[D3P_GK][D3P_GT + 4];  // [k][n]
+    __shared__ __attribute__((aligned(16))) float As[D3P_GK][D3P_GT + 4];  // [k][m]
+    __shared__ __attribute__((aligned(16))) float Bs[D3P_GK][D3P_GT + 4];  // [k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * D3P_GT, n0 = blockIdx.x * D3P_GT;
@@ -81,26 +86,95 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
         if (a_kfast) { ak[r] = e & 15; am[r] = e >> 4; } else { am[r] = e & 63; ak[r] = e >> 6; }
         if (b_nfast) { bn[r] = e & 63; bk[r] = e >> 6; } else { bk[r] = e & 15; bn[r] = e >> 4; }
     }
+    // vector maps: 4 consecutive elements of the fast dimension per thread
+    const int vam = a_kfast ? (tid >> 2) : 4 * (tid & 15), vak = a_kfast ? 4 * (tid & 3) : (tid >> 4);
+    const int vbn = b_nfast ? 4 * (tid & 15) : (tid >> 2), vbk = b_nfast ? (tid >> 4) : 4 * (tid & 3);
+    const int m_real = g.a_last_one ? g.M - 1 : g.M;  // rows of A that exist in memory
     float ra[4], rb[4];
     auto fetch = [&](int k0) {  // global -> registers for the slice starting at k0
+        if (VA) {
+            const int gm = m0 + vam, gk = k0 + vak;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_kfast) {  // 4 k of one row
+                if (gm < m_real && gk < kend) v = *reinterpret_cast<const float4*>(g.A + (long long)gm * g.a_sm + gk);
+                else if (gm < g.M && gk < kend) v = make_float4(1.f, 1.f, 1.f, 1.f);  // the virtual row of ones
+            } else {        // 4 rows of one k
+                if (gk < kend) {
+                    if (gm + 3 < m_real) {
+                        v = *reinterpret_cast<const float4*>(g.A + (long long)gk * g.a_sk + gm);
+                    } else {
+                        float t[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gm = m0 + am[r], gka = k0 + ak[r], gkb = k0 + bk[r], gn = n0 + bn[r];
-            float va = 0.f, vb = 0.f;
-            if (gm < g.M && gka < kend)
-                va = (g.a_last_one && gm == g.M - 1) ? 1.0f : g.A[(long long)gm * g.a_sm + (long long)gka * g.a_sk];
-            if (gkb < kend && gn < g.N) vb = g.B[(long long)gkb * g.b_sk + (long long)gn * g.b_sn];
-            ra[r] = va;
-            rb[r] = vb;
+                        for (int i = 0; i < 4; ++i)
+                            t[i] = (gm + i < m_real) ? g.A[(long long)gk * g.a_sk + gm + i] : ((gm + i < g.M) ? 1.0f : 0.f);
+                        v = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+            }
+            ra[0] = v.x; ra[1] = v.y; ra[2] = v.z; ra[3] = v.w;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + am[r], gka = k0 + ak[r];
+                float va = 0.f;
+                if (gm < g.M && gka < kend)
+                    va = (g.a_last_one && gm == g.M - 1) ? 1.0f : g.A[(long long)gm * g.a_sm + (long long)gka * g.a_sk];
+                ra[r] = va;
+            }
+        }
+        if (VB) {
+            const int gn = n0 + vbn, gk = k0 + vbk;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_nfast) {  // 4 n of one k
+                if (gk < kend) {
+                    if (gn + 3 < g.N) {
+                        v = *reinterpret_cast<const float4*>(g.B + (long long)gk * g.b_sk + gn);
+                    } else {
+                        float t[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) t[i] = (gn + i < g.N) ? g.B[(long long)gk * g.b_sk + gn + i] : 0.f;
+                        v = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+            } else {        // 4 k of one column
+                if (gn < g.N && gk < kend) v = *reinterpret_cast<const float4*>(g.B + (long long)gn * g.b_sn + gk);
+            }
+            rb[0] = v.x; rb[1] = v.y; rb[2] = v.z; rb[3] = v.w;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gkb = k0 + bk[r], gn = n0 + bn[r];
+                rb[r] = (gkb < kend && gn < g.N) ? g.B[(long long)gkb * g.b_sk + (long long)gn * g.b_sn] : 0.f;
+            }
+        }
+    };
+    auto stage = [&]() {  // registers -> LDS
+        if (VA) {
+            if (a_kfast) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) As[vak + i][vam] = ra[i];
+            } else {
+                *reinterpret_cast<float4*>(&As[vak][vam]) = make_float4(ra[0], ra[1], ra[2], ra[3]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) As[ak[r]][am[r]] = ra[r];
+        }
+        if (VB) {
+            if (b_nfast) {
+                *reinterpret_cast<float4*>(&Bs[vbk][vbn]) = make_float4(rb[0], rb[1], rb[2], rb[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Bs[vbk + i][vbn] = rb[i];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Bs[bk[r]][bn[r]] = rb[r];
         }
     };
     if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += D3P_GK) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            As[ak[r]][am[r]] = ra[r];
-            Bs[bk[r]][bn[r]] = rb[r];
-        }
+        stage();
         __syncthreads();
         if (k0 + D3P_GK < kend) fetch(k0 + D3P_GK);  // next slice in flight while this one multiplies
 #pragma unroll
@@ -170,7 +244,16 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     splits = (K + k_per - 1) / k_per;
     g.k_per = k_per;
     g.part = splits > 1 ? part : nullptr;
-    hipLaunchKernelGGL(k_gemm_f32, dim3(cdiv(N, D3P_GT), cdiv(M, D3P_GT), splits), dim3(256), 0, s, g);
+    // 16-byte fetches along the unit-stride dimension when every such load is aligned: base pointer, the other stride and the
+    // K range of a split (k_per is a multiple of 16) -- the kernel guards the M / N edges itself, K must be a multiple of 4
+    auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    const bool va = aligned16(A) && K % 4 == 0 && ((a_sk == 1 && a_sm % 4 == 0) || (a_sm == 1 && a_sk % 4 == 0));
+    const bool vb = aligned16(B) && K % 4 == 0 && ((b_sn == 1 && b_sk % 4 == 0) || (b_sk == 1 && b_sn % 4 == 0));
+    const dim3 grid(cdiv(N, D3P_GT), cdiv(M, D3P_GT), splits);
+    if (va && vb) hipLaunchKernelGGL((k_gemm_f32<true, true>), grid, dim3(256), 0, s, g);
+    else if (va) hipLaunchKernelGGL((k_gemm_f32<true, false>), grid, dim3(256), 0, s, g);
+    else if (vb) hipLaunchKernelGGL((k_gemm_f32<false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_gemm_f32<false, false>), grid, dim3(256), 0, s, g);
     if (splits > 1) hipLaunchKernelGGL(k_gemm_reduce, dim3(cdiv((uint64_t)M * N, 256)), dim3(256), 0, s, g, splits);
     return check_launch("k_gemm_f32");
 }
