@@ -517,33 +517,38 @@ struct GmmPreArgs {
     uint32_t batch_index;
 };
 
+// (key derivations with the 4-lane ChaCha block of d3p_device.h: quad j of wave 0 derives one child, a third of the serial
+// instruction count of the one-lane block -- the launch is pure latency)
+__device__ __forceinline__ void gmm_store_child_quad(uint32_t* dst, const uint32_t* parent, int q, uint32_t a, uint32_t b)
+{
+    dst[q] = parent[q];  // constants row
+    dst[4 + q] = a;
+    dst[8 + q] = b;
+    dst[12 + q] = 0u;
+}
+
 __global__ void __launch_bounds__(128) k_gmm_pre(GmmPreArgs a)
 {
     __shared__ uint32_t sk[3][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int quad = lane >> 2, q = lane & 3;
     if (wave == 0) {
-        if (lane < 3) {
-            uint32_t parent[16], child[16];
-            load_key(a.cur_key, parent);
-            derive_child(parent, (uint32_t)lane, 0u, D3P_TAG_SPLIT, child);
-#pragma unroll
-            for (int w = 0; w < 16; ++w) {
-                a.keys[16 * lane + w] = child[w];
-                sk[lane][w] = child[w];
-                if (lane == 0) a.next_slot[w] = child[w];
-            }
+        // quads 0..2: split(state_key, 3)[quad]; quad 3: fold_in(batch_key, batch_index) (idle copy of the split otherwise)
+        const bool fold = quad == 3 && a.batch_key != nullptr;
+        const uint32_t* parent = fold ? a.batch_key : a.cur_key;
+        uint32_t ka, kb;
+        derive_child_quad(parent, (quad < 3) ? (uint32_t)quad : 0u, fold ? D3P_TAG_FOLD : D3P_TAG_SPLIT, fold ? a.batch_index : 0u, ka, kb);
+        if (quad < 3) {
+            gmm_store_child_quad(a.keys + 16 * quad, parent, q, ka, kb);
+            gmm_store_child_quad(sk[quad], parent, q, ka, kb);
+            if (quad == 0) gmm_store_child_quad(a.next_slot, parent, q, ka, kb);
+        } else if (fold) {
+            gmm_store_child_quad(a.keys + 80, parent, q, ka, kb);
         }
-        if (lane == 3) {
+        if (lane == 63) {
             const int32_t i = *a.step;
             *a.step_saved = i;
             *a.step = i + 1;
-        }
-        if (lane == 4 && a.batch_key) {
-            uint32_t parent[16], child[16];
-            load_key(a.batch_key, parent);
-            derive_child(parent, 0u, a.batch_index, D3P_TAG_FOLD, child);
-#pragma unroll
-            for (int w = 0; w < 16; ++w) a.keys[80 + w] = child[w];
         }
     } else {
         // pack (doubles): [alpha_k (K) | psi(alpha_k) (K) | psi(A0), A0, lgamma(A0) - sum lgamma(alpha_k) - lgamma(K)]
@@ -567,19 +572,14 @@ __global__ void __launch_bounds__(128) k_gmm_pre(GmmPreArgs a)
         }
     }
     __syncthreads();
-    if (wave == 0 && lane < 3) {
-        uint32_t key[16], o[16];
-#pragma unroll
-        for (int w = 0; w < 16; ++w) key[w] = sk[lane == 0 ? 1 : 2][w];
-        if (lane == 0) {  // random_bits(gradient_key, 32, (2,))
-            keystream_block(key, 0u, o);
-            a.keys[96] = o[0];
-            a.keys[97] = o[1];
-        } else {          // split(perturbation_key, 2)[lane - 1]
-            derive_child(key, (uint32_t)(lane - 1), 0u, D3P_TAG_SPLIT, o);
-#pragma unroll
-            for (int w = 0; w < 16; ++w) a.keys[48 + 16 * (lane - 1) + w] = o[w];
-        }
+    if (wave == 0) {
+        // quad 0: block 0 of the gradient key's stream -> jax key (random_bits(gradient_key, 32, (2,)));
+        // quads 1, 2: split(perturbation_key, 2)
+        const uint32_t* parent = quad == 0 ? sk[1] : sk[2];
+        uint32_t ka, kb;
+        derive_child_quad(parent, (quad == 1 || quad == 2) ? (uint32_t)(quad - 1) : 0u, quad == 0 ? 0u : D3P_TAG_SPLIT, 0u, ka, kb);
+        if (quad == 0 && q < 2) a.keys[96 + q] = ka;
+        if (quad == 1 || quad == 2) gmm_store_child_quad(a.keys + 48 + 16 * (quad - 1), parent, q, ka, kb);
     }
 }
 

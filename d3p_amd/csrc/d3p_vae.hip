@@ -493,38 +493,38 @@ __global__ void __launch_bounds__(256) k_vae_scale_all(ScaleArgs a)
 __global__ void __launch_bounds__(64) k_vae_keys(const uint32_t* __restrict__ cur_key, uint32_t* __restrict__ keys,
                                                  uint32_t* __restrict__ next_slot, int32_t* __restrict__ step, int advance)
 {
+    // one quad of lanes per derivation (4-lane ChaCha block, d3p_device.h): the launch is pure latency
     __shared__ uint32_t sk[3][16];
-    const int lane = threadIdx.x;
-    if (lane < 3) {
-        uint32_t parent[16], child[16];
-        load_key(cur_key, parent);
-        derive_child(parent, (uint32_t)lane, 0u, D3P_TAG_SPLIT, child);
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            keys[16 * lane + w] = child[w];
-            sk[lane][w] = child[w];
-            if (lane == 0 && advance) next_slot[w] = child[w];
+    const int lane = threadIdx.x, quad = lane >> 2, q = lane & 3;
+    auto store_child = [&](uint32_t* dst, const uint32_t* parent, uint32_t a, uint32_t b) {
+        dst[q] = parent[q];
+        dst[4 + q] = a;
+        dst[8 + q] = b;
+        dst[12 + q] = 0u;
+    };
+    {
+        uint32_t a, b;
+        derive_child_quad(cur_key, quad < 3 ? (uint32_t)quad : 0u, D3P_TAG_SPLIT, 0u, a, b);
+        if (quad < 3) {
+            store_child(keys + 16 * quad, cur_key, a, b);
+            store_child(sk[quad], cur_key, a, b);
+            if (quad == 0 && advance) store_child(next_slot, cur_key, a, b);
         }
     }
-    if (lane == 3 && advance) {
+    if (lane == 63 && advance) {
         const int32_t i = *step;
         keys[210] = (uint32_t)i;
         *step = i + 1;
     }
     __syncthreads();
-    if (lane < 11) {
-        uint32_t key[16], o[16];
-#pragma unroll
-        for (int w = 0; w < 16; ++w) key[w] = sk[lane == 0 ? 1 : 2][w];
-        if (lane == 0) {
-            keystream_block(key, 0u, o);
-            keys[208] = o[0];
-            keys[209] = o[1];
-        } else {
-            derive_child(key, (uint32_t)(lane - 1), 0u, D3P_TAG_SPLIT, o);
-#pragma unroll
-            for (int w = 0; w < 16; ++w) keys[48 + 16 * (lane - 1) + w] = o[w];
-        }
+    {
+        // quad 0: block 0 of the gradient key's stream -> jax key; quads 1..10: split(perturbation_key, 10)
+        const uint32_t* parent = quad == 0 ? sk[1] : sk[2];
+        const bool site = quad >= 1 && quad <= 10;
+        uint32_t a, b;
+        derive_child_quad(parent, site ? (uint32_t)(quad - 1) : 0u, quad == 0 ? 0u : D3P_TAG_SPLIT, 0u, a, b);
+        if (quad == 0 && q < 2) keys[208 + q] = a;
+        if (site) store_child(keys + 48 + 16 * (quad - 1), parent, a, b);
     }
 }
 
