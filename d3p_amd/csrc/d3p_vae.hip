@@ -214,7 +214,9 @@ __global__ void k_gemm_reduce(GemmArgs g, int splits)
     gemm_store(g, row, col, s, g.bias ? g.bias[col] : 0.f);
 }
 
-// part / part_floats: optional split-K scratch.  The split count is chosen so that short grids (the weight-gradient
+// part / part_floats: optional split-K scratch.  At B = 4096 the GEMMs of this model are parallelism-starved on 256 CUs (bigger
+// tiles lose), so besides the weight gradients the two N = 400 forward / backward-data GEMMs are split too.
+// The split count is chosen so that short grids (the weight-gradient
 // GEMMs: K = batch, M x N = a weight matrix) still put a few workgroups on every CU.
 static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, const float* B, long long b_sk, long long b_sn,
                 float* C, int ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, int a_last_one = 0,
@@ -604,7 +606,7 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
     auto ew = [&](size_t n) { return dim3(cdiv(n, 256)); };
     const dim3 rows(cdiv((uint64_t)B * 64, 256));
     // ---- encoder (guide)
-    if ((rc = gemm(s, X, D, 1, params + L.W1, H, 1, ws.h1, H, Bi, H, D, params + L.b1, 1.f, 0, 0, nullptr, 0, 1, ws.sg1))) return rc;
+    if ((rc = gemm(s, X, D, 1, params + L.W1, H, 1, ws.h1, H, Bi, H, D, params + L.b1, 1.f, 0, 0, ws.part, ws.part_floats, 1, ws.sg1))) return rc;
     if ((rc = gemm(s, ws.h1, H, 1, params + L.Wl, Z, 1, ws.zl, Z, Bi, Z, H, params + L.bl, 1.f, 0))) return rc;
     if ((rc = gemm(s, ws.h1, H, 1, params + L.Ws, Z, 1, ws.u, Z, Bi, Z, H, params + L.bs, 1.f, 0))) return rc;
     hipLaunchKernelGGL(k_vae_latent, rows, dim3(256), 0, s, ws.zl, ws.u, eps, B, Z, ws.lat);  // zl := z, u := sd
@@ -634,7 +636,7 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     const dim3 rows(cdiv((uint64_t)B * 64, 256));
     if ((rc = vae_enqueue_forward(s, m, params, X, mask, B, eps, sc, ws))) return rc;
     // ---- backward (data)
-    if ((rc = gemm(s, ws.a, D, 1, params + L.V2, 1, D, ws.dh2, H, Bi, H, D, nullptr, 1.f, 0, 0, nullptr, 0, 2, ws.sg2))) return rc;  // dpre2 = (da V2^T) . softplus'(pre2)
+    if ((rc = gemm(s, ws.a, D, 1, params + L.V2, 1, D, ws.dh2, H, Bi, H, D, nullptr, 1.f, 0, 0, ws.part, ws.part_floats, 2, ws.sg2))) return rc;  // dpre2 = (da V2^T) . softplus'(pre2)
     if ((rc = gemm(s, ws.dh2, H, 1, params + L.V1, 1, H, ws.dz, Z, Bi, Z, H, nullptr, 1.f, 0))) return rc;  // dpre2 V1^T
     hipLaunchKernelGGL(k_vae_dlatent, ew((size_t)B * Z), dim3(256), 0, s, ws.dz, ws.du, (const float*)ws.zl, (const float*)ws.u, eps,
                        (size_t)B * Z, sc);
