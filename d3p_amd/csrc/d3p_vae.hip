@@ -607,8 +607,8 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
     const dim3 rows(cdiv((uint64_t)B * 64, 256));
     // ---- encoder (guide)
     if ((rc = gemm(s, X, D, 1, params + L.W1, H, 1, ws.h1, H, Bi, H, D, params + L.b1, 1.f, 0, 0, ws.part, ws.part_floats, 1, ws.sg1))) return rc;
-    if ((rc = gemm(s, ws.h1, H, 1, params + L.Wl, Z, 1, ws.zl, Z, Bi, Z, H, params + L.bl, 1.f, 0))) return rc;
-    if ((rc = gemm(s, ws.h1, H, 1, params + L.Ws, Z, 1, ws.u, Z, Bi, Z, H, params + L.bs, 1.f, 0))) return rc;
+    if ((rc = gemm(s, ws.h1, H, 1, params + L.Wl, Z, 1, ws.zl, Z, Bi, Z, H, params + L.bl, 1.f, 0, 0, ws.part, ws.part_floats))) return rc;
+    if ((rc = gemm(s, ws.h1, H, 1, params + L.Ws, Z, 1, ws.u, Z, Bi, Z, H, params + L.bs, 1.f, 0, 0, ws.part, ws.part_floats))) return rc;
     hipLaunchKernelGGL(k_vae_latent, rows, dim3(256), 0, s, ws.zl, ws.u, eps, B, Z, ws.lat);  // zl := z, u := sd
     // ---- decoder (model)
     if ((rc = gemm(s, ws.zl, Z, 1, params + L.V1, H, 1, ws.h2, H, Bi, H, Z, params + L.c1, 1.f, 0, 0, nullptr, 0, 1, ws.sg2))) return rc;
@@ -637,7 +637,7 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     if ((rc = vae_enqueue_forward(s, m, params, X, mask, B, eps, sc, ws))) return rc;
     // ---- backward (data)
     if ((rc = gemm(s, ws.a, D, 1, params + L.V2, 1, D, ws.dh2, H, Bi, H, D, nullptr, 1.f, 0, 0, ws.part, ws.part_floats, 2, ws.sg2))) return rc;  // dpre2 = (da V2^T) . softplus'(pre2)
-    if ((rc = gemm(s, ws.dh2, H, 1, params + L.V1, 1, H, ws.dz, Z, Bi, Z, H, nullptr, 1.f, 0))) return rc;  // dpre2 V1^T
+    if ((rc = gemm(s, ws.dh2, H, 1, params + L.V1, 1, H, ws.dz, Z, Bi, Z, H, nullptr, 1.f, 0, 0, ws.part, ws.part_floats))) return rc;  // dpre2 V1^T
     hipLaunchKernelGGL(k_vae_dlatent, ew((size_t)B * Z), dim3(256), 0, s, ws.dz, ws.du, (const float*)ws.zl, (const float*)ws.u, eps,
                        (size_t)B * Z, sc);
     if ((rc = gemm(s, ws.dz, Z, 1, params + L.Wl, 1, Z, ws.dh1, H, Bi, H, Z, nullptr, 1.f, 0))) return rc;  // dz Wl^T
