@@ -261,38 +261,64 @@ __global__ void __launch_bounds__(1024)
 k_owned_list(StepSlot* __restrict__ slots, const uint32_t* __restrict__ idx, uint32_t B, uint64_t row_lo, uint64_t row_hi,
              uint32_t* __restrict__ plist)
 {
-    __shared__ uint32_t part[1024];
+    // Ordered compaction of the valid, owned positions of one step (blockIdx.y).  Positions are taken in rounds of 1024
+    // consecutive ones (thread t <-> position 1024 r + t: coalesced index reads), 32 rounds per pass; a thread keeps its 32
+    // flags in a bit mask, wave ballots give the counts per (round, wave), one wave scans them, and the second half
+    // writes every owned position to base + count of owned positions before it.
+    __shared__ uint32_t cnt[32 * 16 + 1];
+    __shared__ uint32_t base_s;
     const int t = blockIdx.y;
     const uint32_t* ix = idx + (size_t)t * B;
     uint32_t* out = plist + (size_t)t * B;
     const uint32_t n_valid = slots[t].counts[1];
-    const uint32_t chunk = (B + 1023u) / 1024u;
-    const uint32_t p0 = threadIdx.x * chunk;
-    uint32_t c = 0;
-    for (uint32_t i = 0; i < chunk; ++i) {
-        const uint32_t p = p0 + i;
-        if (p < B && p < n_valid) {
-            const uint64_t r = ix[p];
-            c += (r >= row_lo && r < row_hi) ? 1u : 0u;
-        }
-    }
-    part[threadIdx.x] = c;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0u;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const uint32_t v = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t w = part[threadIdx.x] - c;
-    for (uint32_t i = 0; i < chunk; ++i) {
-        const uint32_t p = p0 + i;
-        if (p < B && p < n_valid) {
-            const uint64_t r = ix[p];
-            if (r >= row_lo && r < row_hi) out[w++] = p;
+    for (uint32_t p0 = 0; p0 < B; p0 += 32u * 1024u) {
+        uint32_t mask = 0u;
+#pragma unroll 4
+        for (int r = 0; r < 32; ++r) {
+            const uint32_t p = p0 + 1024u * (uint32_t)r + threadIdx.x;
+            bool own = false;
+            if (p < B && p < n_valid) {
+                const uint64_t row = ix[p];
+                own = row >= row_lo && row < row_hi;
+            }
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(own);
+            if (lane == 0) cnt[16 * r + wave] = (uint32_t)__popcll(bal);
+            mask |= (own ? 1u : 0u) << r;
         }
+        __syncthreads();
+        if (wave == 0) {  // exclusive scan of the 512 counts: 8 consecutive entries per lane, then a wave prefix
+            uint32_t v[8], s = 0u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[j] = cnt[8 * lane + j]; s += v[j]; }
+            uint32_t inc = s;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off);
+                if (lane >= off) inc += o;
+            }
+            uint32_t run = base_s + inc - s;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cnt[8 * lane + j] = run; run += v[j]; }
+            if (lane == 63) cnt[512] = run;  // owned positions so far, including this pass
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < 32; ++r) {
+            const bool own = (mask >> r) & 1u;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(own);
+            if (own) {
+                const uint32_t before = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                out[cnt[16 * r + wave] + before] = p0 + 1024u * (uint32_t)r + threadIdx.x;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base_s = cnt[512];
+        __syncthreads();
     }
-    if (threadIdx.x == 1023) slots[t].n_owned = part[1023];
+    if (threadIdx.x == 0) slots[t].n_owned = base_s;
 }
 
 // ------------------------------------------------------------------------------------------
