@@ -352,10 +352,12 @@ __device__ __forceinline__ float row_sumsq(const float* __restrict__ r, int n, i
     return wave_sum(s);
 }
 
-// joint L2 norm of every example's gradient by the outer-product identity, clip factor c_i (0 for masked rows)
+// joint L2 norm of every example's gradient by the outer-product identity, clip factor c_i (0 for masked rows); the rows of
+// the five delta arrays are staged in LDS while their squares are summed and written back scaled by c_i (svi.py:121-122
+// folded into the sums), so the deltas are read once and written once (a separate rescaling pass read them a second time)
 struct NormArgs {
-    const float *X, *h1, *z, *h2;            // layer inputs
-    const float *dpre1, *dz, *du, *dpre2, *da;  // layer deltas
+    const float *X, *h1, *z, *h2;         // layer inputs
+    float *dpre1, *dz, *du, *dpre2, *da;  // layer deltas, rescaled in place
     const uint8_t* mask;
     uint32_t B;
     int D, H, Z;
@@ -364,23 +366,51 @@ struct NormArgs {
     float* norms;  // nullable
 };
 
+// sum of squares of a row while copying it to `keep` (lane l owns elements l, l + 64, ...)
+__device__ __forceinline__ float row_sumsq_keep(const float* __restrict__ r, int n, int lane, float* __restrict__ keep)
+{
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) {
+        const float v = r[j];
+        keep[j] = v;
+        s = __fmaf_rn(v, v, s);
+    }
+    return wave_sum(s);
+}
+
 __global__ void k_vae_norms(NormArgs a)
 {
+    extern __shared__ float norm_stage[];  // 4 waves x (D + 2 H + 2 Z)
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (i >= a.B) return;
+    float* k_da = norm_stage + (size_t)(threadIdx.x >> 6) * (a.D + 2 * a.H + 2 * a.Z);
+    float* k_d2 = k_da + a.D;
+    float* k_d1 = k_d2 + a.H;
+    float* k_dz = k_d1 + a.H;
+    float* k_du = k_dz + a.Z;
+    float* r_da = a.da + (size_t)i * a.D;
+    float* r_d2 = a.dpre2 + (size_t)i * a.H;
+    float* r_d1 = a.dpre1 + (size_t)i * a.H;
+    float* r_dz = a.dz + (size_t)i * a.Z;
+    float* r_du = a.du + (size_t)i * a.Z;
     const float x2 = row_sumsq(a.X + (size_t)i * a.D, a.D, lane), h12 = row_sumsq(a.h1 + (size_t)i * a.H, a.H, lane);
     const float z2 = row_sumsq(a.z + (size_t)i * a.Z, a.Z, lane), h22 = row_sumsq(a.h2 + (size_t)i * a.H, a.H, lane);
-    const float d1 = row_sumsq(a.dpre1 + (size_t)i * a.H, a.H, lane), dz = row_sumsq(a.dz + (size_t)i * a.Z, a.Z, lane);
-    const float du = row_sumsq(a.du + (size_t)i * a.Z, a.Z, lane), d2 = row_sumsq(a.dpre2 + (size_t)i * a.H, a.H, lane);
-    const float da = row_sumsq(a.da + (size_t)i * a.D, a.D, lane);
+    const float d1 = row_sumsq_keep(r_d1, a.H, lane, k_d1), dz = row_sumsq_keep(r_dz, a.Z, lane, k_dz);
+    const float du = row_sumsq_keep(r_du, a.Z, lane, k_du), d2 = row_sumsq_keep(r_d2, a.H, lane, k_d2);
+    const float da = row_sumsq_keep(r_da, a.D, lane, k_da);
     const float n2 = (h22 + 1.0f) * da + (z2 + 1.0f) * d2 + (h12 + 1.0f) * (dz + du) + (x2 + 1.0f) * d1;
     const float nrm = sqrtf(n2);
     const bool live = !(a.mask && a.mask[i] == 0);
+    const float c = live ? 1.0f / fmaxf(1.0f, nrm / a.clip) : 0.f;  // svi.py:121-122; masked rows contribute nothing
     if (lane == 0) {
-        a.cf[i] = live ? 1.0f / fmaxf(1.0f, nrm / a.clip) : 0.f;  // svi.py:121-122; masked rows contribute nothing
+        a.cf[i] = c;
         if (a.norms) a.norms[i] = live ? nrm : 0.f;
     }
+    // every lane reads back exactly the LDS words it wrote: no barrier needed
+    for (int j = lane; j < a.D; j += 64) r_da[j] = k_da[j] * c;
+    for (int j = lane; j < a.H; j += 64) { r_d2[j] = k_d2[j] * c; r_d1[j] = k_d1[j] * c; }
+    for (int j = lane; j < a.Z; j += 64) { r_dz[j] = k_dz[j] * c; r_du[j] = k_du[j] * c; }
 }
 
 // sums[P] = sum_i px_loss[i], sums[P + 1] = number of unmasked examples (one workgroup, fixed order)
@@ -468,26 +498,6 @@ __global__ void __launch_bounds__(256) k_vae_site_noise(SiteNoiseArgs a)
 }
 
 // rows of the five delta arrays scaled by the clip factors in one launch
-struct ScaleArgs {
-    float* d[5];
-    int n[5];
-    uint32_t off[6];  // prefix sums of B * n[k]
-    const float* cf;
-};
-
-__global__ void __launch_bounds__(256) k_vae_scale_all(ScaleArgs a)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.off[5]) return;
-    int k = 0;
-#pragma unroll
-    for (int j = 1; j < 5; ++j) k += (t >= a.off[j]) ? 1 : 0;
-    const uint32_t e = t - a.off[k];
-    float* d = k == 0 ? a.d[0] : k == 1 ? a.d[1] : k == 2 ? a.d[2] : k == 3 ? a.d[3] : a.d[4];
-    const int n = k == 0 ? a.n[0] : k == 1 ? a.n[1] : k == 2 ? a.n[2] : k == 3 ? a.n[3] : a.n[4];
-    d[e] *= a.cf[e / (uint32_t)n];
-}
-
 // All keys of one update in ONE launch (they were three launches + a step-counter launch + a 64-byte copy, ~5 us each):
 // keys[0..47] = [next | gradient | perturbation] = split(state_key, 3) (svi.py:208-211), keys[48..207] =
 // split(perturbation_key, 10) (svi.py:491), keys[208..209] = convert_to_jax_rng_key(gradient_key).  advance: also write the
@@ -642,21 +652,12 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
                        (size_t)B * Z, sc);
     if ((rc = gemm(s, ws.dz, Z, 1, params + L.Wl, 1, Z, ws.dh1, H, Bi, H, Z, nullptr, 1.f, 0))) return rc;  // dz Wl^T
     if ((rc = gemm(s, ws.du, Z, 1, params + L.Ws, 1, Z, ws.dh1, H, Bi, H, Z, nullptr, 1.f, 1, 0, nullptr, 0, 2, ws.sg1))) return rc;  // dpre1 = (dz Wl^T + du Ws^T) . softplus'(pre1)
-    // ---- per-example norms and clip factors, rows of every delta scaled by c_i
+    // ---- per-example norms and clip factors; the rows of every delta come back scaled by c_i
     NormArgs na;
     na.X = X; na.h1 = ws.h1; na.z = ws.zl; na.h2 = ws.h2;
     na.dpre1 = ws.dh1; na.dz = ws.dz; na.du = ws.du; na.dpre2 = ws.dh2; na.da = ws.a;
     na.mask = mask; na.B = B; na.D = D; na.H = H; na.Z = Z; na.clip = clip; na.cf = ws.cf; na.norms = norms_out;
-    hipLaunchKernelGGL(k_vae_norms, rows, dim3(256), 0, s, na);
-    {
-        ScaleArgs sa;
-        float* arrs[5] = {ws.a, ws.dh2, ws.dz, ws.du, ws.dh1};
-        const int widths[5] = {D, H, Z, Z, H};
-        sa.off[0] = 0;
-        for (int k = 0; k < 5; ++k) { sa.d[k] = arrs[k]; sa.n[k] = widths[k]; sa.off[k + 1] = sa.off[k] + B * (uint32_t)widths[k]; }
-        sa.cf = ws.cf;
-        hipLaunchKernelGGL(k_vae_scale_all, dim3(cdiv(sa.off[5], 256)), dim3(256), 0, s, sa);
-    }
+    hipLaunchKernelGGL(k_vae_norms, rows, dim3(256), 4 * (size_t)(D + 2 * H + 2 * Z) * sizeof(float), s, na);
     // ---- clipped sums: weights  A^T (diag(c) Delta)  (GEMMs over the batch), biases = column sums
     // [W | b] of every layer is contiguous in the flat layout, so the bias gradient is row `in` of a GEMM whose A carries a
     // virtual row of ones
