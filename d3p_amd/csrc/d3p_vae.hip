@@ -323,12 +323,25 @@ __global__ void k_vae_out(float* __restrict__ a, const float* __restrict__ X, co
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (i >= B) return;
+    // one exponential per element: e = exp(-|t|) gives softplus(t) = max(t, 0) + log1p(e) and sigmoid(t) = 1 / (1 + e) for
+    // t >= 0, e / (1 + e) otherwise
+    auto elem = [&](float t, float x, float& ll) {
+        const float e = expf(-fabsf(t)), r = 1.0f / (1.0f + e);
+        ll += x * t - (fmaxf(t, 0.0f) + log1pf(e));
+        return sc * ((t >= 0.0f ? r : e * r) - x);
+    };
     float ll = 0.f;
-    for (int j = lane; j < D; j += 64) {
-        const size_t e = (size_t)i * D + j;
-        const float t = a[e], x = X[e];
-        ll += x * t - (fmaxf(t, 0.0f) + log1pf(expf(-fabsf(t))));
-        a[e] = sc * (1.0f / (1.0f + expf(-t)) - x);
+    float* ar = a + (size_t)i * D;
+    const float* xr = X + (size_t)i * D;
+    if ((D & 3) == 0 && ((reinterpret_cast<uintptr_t>(ar) | reinterpret_cast<uintptr_t>(xr)) & 15u) == 0) {
+        for (int j = 4 * lane; j < D; j += 256) {
+            const float4 t = *reinterpret_cast<const float4*>(ar + j), x = *reinterpret_cast<const float4*>(xr + j);
+            float4 o;
+            o.x = elem(t.x, x.x, ll); o.y = elem(t.y, x.y, ll); o.z = elem(t.z, x.z, ll); o.w = elem(t.w, x.w, ll);
+            *reinterpret_cast<float4*>(ar + j) = o;
+        }
+    } else {
+        for (int j = lane; j < D; j += 64) ar[j] = elem(ar[j], xr[j], ll);
     }
     ll = wave_sum(ll);
     if (lane == 0) px_loss[i] = (mask && mask[i] == 0) ? 0.f : sc * (lat[i] - ll);
