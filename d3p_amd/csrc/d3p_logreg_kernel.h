@@ -329,9 +329,10 @@ struct ExLoad {
 // EPS: where the guide noise comes from: 0 = generated on chip (threefry + erf_inv), 1 = read from
 // a.eps_ext (parity mode), -1 = decided at run time.
 // NK == 1 (d <= 512): 1024-thread workgroups (<= 128 VGPRs); wider rows keep more columns per lane in registers,
-// so those variants are built for 512-thread workgroups (<= 256 VGPRs) and launched with at most 8 waves.
+// so NK == 2 is built for 512-thread workgroups (<= 256 VGPRs, at most 8 waves) and NK >= 4 for 256-thread workgroups
+// (one wave per SIMD: the whole 512-entry register file, AGPRs included, instead of scratch).
 template <int V, int NK, int MODE, bool FULL, int EPS>
-__global__ void __launch_bounds__(NK == 1 ? 1024 : 512) k_logreg_main(MainArgs a_in)
+__global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg_main(MainArgs a_in)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool FUSE = MODE == 2 || MODE == 3;   // update applied in the prologue, fixed-point accumulators
@@ -928,7 +929,7 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g)
                     2 * 64 * g->V * 8);
     // waves per workgroup (default 16 = one 1024-thread workgroup per CU at 4 waves/SIMD), reduced until
     // pack (5D) + reduction buffer (W x P) fit 64 KiB of LDS; one example per wave per pass.
-    int W = g->NK == 1 ? 16 : 8, epw = 1;
+    int W = g->NK == 1 ? 16 : g->NK == 2 ? 8 : 4, epw = 1;
     {
         // One workgroup per CU and ceil(B / (W x CUs)) examples per wave: every workgroup pays the update prologue (48 KB
         // of replica / state reads) and P + 2 accumulator atomics per step, so more workgroups than CUs only multiplies
@@ -949,7 +950,7 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g)
     {  // developer overrides of the geometry (tuning sweeps), read once per process
         static const int env_w = [] { const char* e = getenv("D3P_MAIN_W"); return e ? atoi(e) : 0; }();
         static const int env_epw = [] { const char* e = getenv("D3P_MAIN_EPW"); return e ? atoi(e) : 0; }();
-        if (env_w >= 1 && env_w <= (g->NK == 1 ? 16 : 8)) W = env_w;
+        if (env_w >= 1 && env_w <= (g->NK == 1 ? 16 : g->NK == 2 ? 8 : 4)) W = env_w;
         if (env_epw >= 1 && env_epw <= 64) epw = env_epw;
     }
     auto lds_bytes = [&](int w) { return (size_t)(((5 * D + 3) & ~3) + w * P + 2 * w) * sizeof(float); };
