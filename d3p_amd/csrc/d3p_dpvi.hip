@@ -887,6 +887,31 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
     }
     MainGeom g2 = c.g;
     g2.blocks = (uint32_t)K * (c.g.blocks + 1u);
+    a.dbg = dev_dbg_flags();
+    if (a.dbg & 32) {  // developer diagnostic (D3P_DBG=32): phase stamps of the LAST step of the launch, printed to stderr
+        a.stamps = c.ws.stamps;
+        int rc = launch_main<3>(c.s, g2, a);
+        if (rc) return rc;
+        static unsigned long long host[8 * 257];
+        D3P_HIP_TRY(hipMemcpyAsync(host, c.ws.stamps, sizeof(host), hipMemcpyDeviceToHost, c.s));
+        D3P_HIP_TRY(hipStreamSynchronize(c.s));
+        static int printed = 0;
+        if (printed++ == 3 && K > 1) {
+            unsigned long long t0 = ~0ull;
+            for (uint32_t b = 0; b < c.g.blocks; ++b) t0 = host[8 * b] < t0 ? host[8 * b] : t0;
+            double sum[8] = {0}, mx[8] = {0};
+            for (uint32_t b = 0; b < c.g.blocks; ++b)
+                for (int k = 0; k < 8; ++k) {
+                    const double v = ((double)host[8 * b + k] - (double)t0) * 0.01;
+                    sum[k] += v;
+                    if (v > mx[k]) mx[k] = v;
+                }
+            const char* names[8] = {"entry", "exit(arrived)", "prologue+staged", "eps done", "dot done", "loop done", "red-sync", "release seen"};
+            for (int k : {0, 7, 2, 3, 4, 5, 6, 1})
+                fprintf(stderr, "MODE3 last step: %-16s mean %.2f  max %.2f us after the first entry\n", names[k], sum[k] / c.g.blocks, mx[k]);
+        }
+        return D3P_OK;
+    }
     hipEvent_t e0, e1;
     timing_pair(K, &e0, &e1);
     return launch_main<3>(c.s, g2, a, e0, e1);

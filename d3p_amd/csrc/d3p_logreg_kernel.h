@@ -473,6 +473,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                 (void)chain_wait(a.chain.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (9 + (bid & 7u)), 1u,
                                  a.chain.abort_flag);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            if ((a.dbg & 32) && a.stamps && threadIdx.x == 0) a.stamps[8 * bid + 7] = wall_clock64();  // release seen
             // now nobody reads the next accumulator any more (the previous step's prologues are over): zero it
             if (wave < PWc)
                 for (int i = bid * (64 * PWc) + (int)threadIdx.x; i < D3P_ACC_R * PA; i += a.chain.nw * 64 * PWc)
@@ -592,6 +593,10 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
     // the 4 waves (one per SIMD) that apply the pending update in finish_prologue()  (s_setprio on them was measured to
     // change nothing: the SIMD shares its issue slots evenly whatever the priority)
     const bool prologue_wave = FUSE && !a.fuse.flush_only && a.fuse.apply_prev && wave < 4;
+    // (Chained form, measured per workgroup with D3P_DBG=32: wait for the release 1.8 us, prologue 3.2 us, the prologue
+    // waves' own noise 2.4 us, dot / gradient / reduction 2.0 us, atomics + arrival 2.15 us.  Generating every wave's noise
+    // BEFORE the prologue does not help: the index -> row / key load chain issued at entry is hidden behind the prologue in
+    // this order and exposed in the other one: 12.2 -> 18.4 us per step.)
     if (FUSE && (a.fuse.flush_only || !kLatePrologue)) {
         finish_prologue();
         D3P_STAMP(2)
@@ -869,7 +874,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
     if (a.stamps) {
         __syncthreads();
         if (threadIdx.x == 0) a.stamps[SS * bid + 1] = wall_clock64();
-        if ((a.dbg & 32) && threadIdx.x == 0) a.stamps[8 * bid + 7] = (unsigned long long)(clock64() - clk0);
+        if ((a.dbg & 32) && !CHAIN && threadIdx.x == 0) a.stamps[8 * bid + 7] = (unsigned long long)(clock64() - clk0);
     }
 }
 
