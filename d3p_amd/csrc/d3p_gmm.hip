@@ -138,14 +138,16 @@ __device__ __forceinline__ void gmm_site_keys(const uint32_t* jax_key, uint32_t 
 
 // Dirichlet part, one THREAD per (example, component): Gamma(alpha_k) draw and its derivative wrt alpha_k.
 // dir[(p K + k) * 2 + {0, 1}] = {g, dg/dalpha}
+// (data-parallel: the B examples are positions pos0 .. pos0 + B - 1 of a global batch of B_total; the keys of an example are
+// functions of its GLOBAL position)
 __global__ void __launch_bounds__(256) k_gmm_dirichlet(const double* __restrict__ pack, const uint32_t* __restrict__ jax_key,
-                                                       uint32_t B, int K, double* __restrict__ dir)
+                                                       uint32_t B, uint32_t B_total, uint32_t pos0, int K, double* __restrict__ dir)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)B * K) return;
     const uint32_t p = (uint32_t)(i / K), k = (uint32_t)(i % K);
     uint32_t kp0, kp1, km0, km1, ks0, ks1;
-    gmm_site_keys(jax_key, B, p, kp0, kp1, km0, km1, ks0, ks1);
+    gmm_site_keys(jax_key, B_total, pos0 + p, kp0, kp1, km0, km1, ks0, ks1);
     const double alpha = pack[k];
     const double g = gamma_sample_d(kp0, kp1, k, alpha);
     dir[2 * i] = g;
@@ -166,6 +168,7 @@ struct GmmArgs {
     float* latents_out;  // nullable: B x (K + 2 K d): g, eps, sigs of every example (tests)
     float* partials;     // SUM mode: one row of P + 2 per wavefront: [sum_i c_i g_i | sum_i loss_i | n]
     uint32_t B;
+    uint32_t B_total, pos0;  // key derivation: example p is position pos0 + p of a global batch of B_total (= B, 0 on one device)
     int K, d;
     float inv_ps2, log_ps, lik_scale, inv_obs, obs_scale, clip;
 };
@@ -207,7 +210,7 @@ __global__ void __launch_bounds__(256, (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1
 
     // ---- keys of the guide's sample sites (numpyro.handlers.seed over pis, mus, sigs)
     uint32_t kp0, kp1, km0, km1, ks0, ks1;
-    gmm_site_keys(a.jax_key, a.B, p, kp0, kp1, km0, km1, ks0, ks1);
+    gmm_site_keys(a.jax_key, a.B_total, a.pos0 + p, kp0, kp1, km0, km1, ks0, ks1);
 
     // ---- Dirichlet part on lanes < K (float64)
     double alpha = 1.0, g = 0.0, gp = 0.0;
@@ -516,6 +519,7 @@ struct GmmPreArgs {
     int32_t* step_saved;
     const uint32_t* batch_key;  // nullable (run loop): keys[80..95] = fold_in(batch_key, batch_index), minibatch.py:226-230
     uint32_t batch_index;
+    int advance;                // 0: keys and pack only (the local-sums half of a data-parallel update leaves the state alone)
 };
 
 // (key derivations with the 4-lane ChaCha block of d3p_device.h: quad j of wave 0 derives one child, a third of the serial
@@ -542,11 +546,11 @@ __global__ void __launch_bounds__(128) k_gmm_pre(GmmPreArgs a)
         if (quad < 3) {
             gmm_store_child_quad(a.keys + 16 * quad, parent, q, ka, kb);
             gmm_store_child_quad(sk[quad], parent, q, ka, kb);
-            if (quad == 0) gmm_store_child_quad(a.next_slot, parent, q, ka, kb);
+            if (quad == 0 && a.advance) gmm_store_child_quad(a.next_slot, parent, q, ka, kb);
         } else if (fold) {
             gmm_store_child_quad(a.keys + 80, parent, q, ka, kb);
         }
-        if (lane == 63) {
+        if (lane == 63 && a.advance) {
             const int32_t i = *a.step;
             *a.step_saved = i;
             *a.step = i + 1;
@@ -724,6 +728,8 @@ static void gmm_fill(GmmArgs* a, const d3p_gmm_model* model, const float* params
     a->mask = mask;
     a->jax_key = jax_key;
     a->B = B;
+    a->B_total = B;
+    a->pos0 = 0;
     a->K = model->K;
     a->d = model->d;
     a->inv_ps2 = 1.0f / (model->prior_mu_scale * model->prior_mu_scale);
@@ -786,7 +792,7 @@ int d3p_gmm_px_grads(void* stream, const d3p_gmm_model* model, const float* para
     double* dir = (double*)((char*)workspace_dev + align_up_g((2 * (size_t)model->K + 3) * sizeof(double), 256));
     hipLaunchKernelGGL(k_gmm_pack, dim3(1), dim3(64), 0, s, params_dev, model->K, pack);
     hipLaunchKernelGGL(k_gmm_mask_meta, dim3(1), dim3(256), 0, s, mask_dev, B, meta_dev);
-    hipLaunchKernelGGL(k_gmm_dirichlet, dim3(cdiv((uint64_t)B * model->K, 256)), dim3(256), 0, s, (const double*)pack, jax_key_dev, B,
+    hipLaunchKernelGGL(k_gmm_dirichlet, dim3(cdiv((uint64_t)B * model->K, 256)), dim3(256), 0, s, (const double*)pack, jax_key_dev, B, B, 0u,
                        model->K, dir);
     GmmArgs a;
     gmm_fill(&a, model, params_dev, X_dev, nullptr, mask_dev, B, jax_key_dev, 1.0f);
@@ -835,13 +841,27 @@ size_t d3p_dpvi_gmm_workspace(const d3p_gmm_model* model, uint32_t B)
     return gmm_carve(model, B, nullptr, nullptr);
 }
 
+// out[c] = sum over the D3P_GMM_CHUNKS reduced rows (fixed order): the rank's [clipped sums | loss sum | n]
+__global__ void __launch_bounds__(256) k_gmm_fold(const float* __restrict__ reduced, int width, float* __restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    float s = 0.f;
+    for (uint32_t r = 0; r < D3P_GMM_CHUNKS; ++r) s += reduced[(size_t)r * width + c];
+    out[c] = s;
+}
+
 // One DPSVI.update (svi.py:395-434) for the mixture model, enqueued on `stream` without host synchronisation.
+// stage: 0 = the whole update; 1 = local sums only (keys and pack without touching the state, the rank's P + 2 sums folded
+// into sums_io); 2 = apply only (sums_io holds the reduced sums of the whole batch of B_total examples).  B_total / pos0:
+// the B examples are positions pos0 .. of a global batch of B_total (0 / 0: B is the whole batch).
 // batch_key_dev != nullptr (run loop): the batch of this step is get_batch(batch_index, batch_key) of
 // subsample_batchify_data (minibatch.py:226-237) over n_rows rows -- fold_in in the pre kernel, Feistel indices into ws.idx
 static int gmm_enqueue_update(hipStream_t s, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                               int slot, const float* X_dev, const uint32_t* idx_dev, const uint8_t* mask_dev, uint32_t B,
                               float* loss_dev, float* grad_out_dev, const GmmWorkspace& ws,
-                              const uint32_t* batch_key_dev = nullptr, uint32_t batch_index = 0, uint32_t n_rows = 0)
+                              const uint32_t* batch_key_dev = nullptr, uint32_t batch_index = 0, uint32_t n_rows = 0,
+                              int stage = 0, uint32_t B_total = 0, uint32_t pos0 = 0, float* sums_io = nullptr)
 {
     int rc;
     const int K = model->K, P = K + K * model->d;
@@ -861,17 +881,20 @@ static int gmm_enqueue_update(hipStream_t s, const d3p_gmm_model* model, const d
         pa.step_saved = ws.step_saved;
         pa.batch_key = batch_key_dev;
         pa.batch_index = batch_index;
+        pa.advance = stage == 1 ? 0 : 1;
         hipLaunchKernelGGL(k_gmm_pre, dim3(1), dim3(128), 0, s, pa);
     }
+    if (stage != 2) {
     if (batch_key_dev) {
         if ((rc = d3p_feistel_sample(s, ws.keys + 80, n_rows, B, ws.idx))) return rc;
         idx_dev = ws.idx;
     }
     (void)split3;
     hipLaunchKernelGGL(k_gmm_dirichlet, dim3(cdiv((uint64_t)B * K, 256)), dim3(256), 0, s, (const double*)ws.pack,
-                       (const uint32_t*)jax_key, B, K, ws.dir);
+                       (const uint32_t*)jax_key, B, B_total ? B_total : B, pos0, K, ws.dir);
     GmmArgs a;
     gmm_fill(&a, model, state->params, X_dev, idx_dev, mask_dev, B, jax_key, hyper->clip);
+    if (B_total) { a.B_total = B_total; a.pos0 = pos0; }
     a.pack = ws.pack;
     a.dir = ws.dir;
     a.partials = ws.partials;
@@ -880,10 +903,15 @@ static int gmm_enqueue_update(hipStream_t s, const d3p_gmm_model* model, const d
     const uint32_t rows = cdiv((uint64_t)n_waves * 64, 256) * 4;  // every launched wavefront wrote a row
     hipLaunchKernelGGL(k_gmm_reduce, dim3(cdiv(P + 2, 64), D3P_GMM_CHUNKS), dim3(256), 0, s, (const float*)ws.partials, rows, P + 2,
                        ws.reduced);
+    }
+    if (stage == 1) {
+        hipLaunchKernelGGL(k_gmm_fold, dim3(cdiv(P + 2, 256)), dim3(256), 0, s, (const float*)ws.reduced, P + 2, sums_io);
+        return check_launch("d3p_dpvi_gmm_local_sums");
+    }
     GmmFinalArgs f;
-    f.partials = ws.reduced;
-    f.n_rows = D3P_GMM_CHUNKS;
-    f.B = B;
+    f.partials = stage == 2 ? sums_io : ws.reduced;
+    f.n_rows = stage == 2 ? 1u : D3P_GMM_CHUNKS;
+    f.B = (stage == 2 && B_total) ? B_total : B;
     f.P = P;
     f.noise = nullptr;
     f.site_keys = site_keys;
@@ -923,6 +951,31 @@ int d3p_dpvi_gmm_update(void* stream, const d3p_gmm_model* model, const d3p_dpsv
     gmm_carve(model, B, (char*)workspace_dev, &ws);
     return gmm_enqueue_update((hipStream_t)stream, model, hyper, state, state->key_slot, X_dev, nullptr, mask_dev, B, loss_dev,
                               grad_out_dev, ws);
+}
+
+int d3p_dpvi_gmm_local_sums(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                            const float* X_dev, const uint8_t* mask_dev, uint32_t B_local, uint32_t B_total, uint32_t pos0,
+                            float* sums_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    if (int rc = gmm_check_common(model, hyper, state, B_local, workspace_dev, workspace_bytes, "d3p_dpvi_gmm_local_sums")) return rc;
+    D3P_REQUIRE(X_dev && sums_dev, "d3p_dpvi_gmm_local_sums: null pointer");
+    D3P_REQUIRE((uint64_t)pos0 + B_local <= B_total, "d3p_dpvi_gmm_local_sums: pos0 + B_local must not exceed B_total");
+    GmmWorkspace ws;
+    gmm_carve(model, B_local, (char*)workspace_dev, &ws);
+    return gmm_enqueue_update((hipStream_t)stream, model, hyper, state, state->key_slot, X_dev, nullptr, mask_dev, B_local, nullptr,
+                              nullptr, ws, nullptr, 0, 0, 1, B_total, pos0, sums_dev);
+}
+
+int d3p_dpvi_gmm_apply(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                       float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
+                       void* workspace_dev, size_t workspace_bytes)
+{
+    if (int rc = gmm_check_common(model, hyper, state, B_local, workspace_dev, workspace_bytes, "d3p_dpvi_gmm_apply")) return rc;
+    D3P_REQUIRE(sums_dev && B_total >= 1, "d3p_dpvi_gmm_apply: null pointer or empty batch");
+    GmmWorkspace ws;
+    gmm_carve(model, B_local, (char*)workspace_dev, &ws);
+    return gmm_enqueue_update((hipStream_t)stream, model, hyper, state, state->key_slot, nullptr, nullptr, nullptr, B_local, loss_dev,
+                              grad_out_dev, ws, nullptr, 0, 0, 2, B_total, 0, sums_dev);
 }
 
 int d3p_dpvi_gmm_run(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,

@@ -289,6 +289,57 @@ class VaeHipEngine:
         return new_state, self.loss[0]
 
 
+class GmmHipEngine:
+    """local_sums / apply of one rank for the mixture model (d3p_dpvi_gmm_local_sums / d3p_dpvi_gmm_apply)."""
+
+    def __init__(self, svi, **model_kwargs):
+        _lib.require_device()
+        if not svi._is_gmm():
+            raise _lib.D3PError("GmmHipEngine: the DPSVI object must hold a GaussianMixtureModel / GaussianMixtureGuide pair")
+        self.svi, self.model_kwargs = svi, model_kwargs
+
+    def begin(self, state, X_local, batch_size_total, pos0, mask=None, eps=None):
+        svi, lib = self.svi, _lib.load()
+        if eps is not None:
+            raise _lib.D3PError("GmmHipEngine: the mixture model has no external-noise mode")
+        self.X = X_local.contiguous()
+        self.B_local, d = self.X.shape
+        self.B_total, self.pos0 = int(batch_size_total), int(pos0)
+        dev = self.X.device
+        self.gm = svi._gmm_struct(d, self.model_kwargs, state.observation_scale)
+        self.hyper = svi._hyper()
+        self.step, self.params, self.m, self.v = (t.clone() for t in state.optim_state)
+        self.keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
+        self.keybuf[0].copy_(state.rng_key.reshape(16))
+        self.st = svi._state_struct(self.keybuf, 0, (self.step, self.params, self.m, self.v))
+        self.mask = None if mask is None else mask.to(torch.uint8).contiguous()
+        self.ws = svi._workspace(lib.d3p_dpvi_gmm_workspace(C.byref(self.gm), self.B_local), dev, "gmm_step")
+        self.sums = torch.empty(self.params.numel() + 2, dtype=torch.float32, device=dev)
+        self.loss = torch.empty(1, dtype=torch.float32, device=dev)
+        self.observation_scale = state.observation_scale
+
+    def local_sums(self):
+        check(_lib.load().d3p_dpvi_gmm_local_sums(
+            stream_ptr(), C.byref(self.gm), C.byref(self.hyper), C.byref(self.st), ptr(self.X), ptr(self.mask),
+            self.B_local, self.B_total, self.pos0, ptr(self.sums), ptr(self.ws), self.ws.numel()))
+        return self.sums
+
+    def apply(self, sums, grad_out=None):
+        from .svi import DPSVIState
+        check(_lib.load().d3p_dpvi_gmm_apply(
+            stream_ptr(), C.byref(self.gm), C.byref(self.hyper), C.byref(self.st), ptr(sums), self.B_total, self.B_local,
+            ptr(self.loss), ptr(grad_out), ptr(self.ws), self.ws.numel()))
+        new_state = DPSVIState((self.step, self.params, self.m, self.v), self.keybuf[1].reshape(4, 4),
+                               self.observation_scale)
+        return new_state, self.loss[0]
+
+
+def sharded_batch_update(engine, state, X_local, batch_size_total, pos0, group=None, mask=None, _eps=None, _grad_out=None):
+    """One data-parallel DPSVI.update (svi.py:395-434) with the BATCH sharded by position over the ranks of `group` (the VAE
+    and mixture-model engines above; the dataset is replicated or the rank holds the rows of its positions)."""
+    return vae_update(engine, state, X_local, batch_size_total, pos0, group=group, mask=mask, _eps=_eps, _grad_out=_grad_out)
+
+
 def vae_update(engine, state, X_local, batch_size_total, pos0, group=None, mask=None, _eps=None, _grad_out=None):
     """One data-parallel DPSVI.update (svi.py:395-434) of the VAE on every rank of `group`: the rank's examples are the
     positions pos0 .. pos0 + len(X_local) - 1 of the global batch.  local sums -> ONE all_reduce(SUM) of the P + 2 sums

@@ -379,6 +379,18 @@ int d3p_dpvi_gmm_update(void* stream, const d3p_gmm_model* model, const d3p_dpsv
                         const d3p_dpsvi_state* state, const float* X_dev, const uint8_t* mask_dev, uint32_t B,
                         float* loss_dev, float* grad_out_dev, void* workspace_dev, size_t workspace_bytes);
 
+/* Data-parallel form of d3p_dpvi_gmm_update, as for the VAE below: a rank holds the B_local examples at positions
+ * pos0 .. pos0 + B_local - 1 of the global batch of B_total (the per-example site keys are functions of the GLOBAL position).
+ * d3p_dpvi_gmm_local_sums leaves sums_dev[P + 2] = [sum_i c_i g_i | sum_i loss_i | n] of the rank's examples and does not
+ * touch the state; the caller sum-all-reduces sums_dev over the ranks; d3p_dpvi_gmm_apply adds the per-site noise once,
+ * applies Adam and advances the state identically on every rank.  The workspace is sized for B_local. */
+int d3p_dpvi_gmm_local_sums(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper,
+                            const d3p_dpsvi_state* state, const float* X_dev, const uint8_t* mask_dev, uint32_t B_local,
+                            uint32_t B_total, uint32_t pos0, float* sums_dev, void* workspace_dev, size_t workspace_bytes);
+int d3p_dpvi_gmm_apply(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                       float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
+                       void* workspace_dev, size_t workspace_bytes);
+
 /* The single-GPU run loop executes the steps of a prepared batch (<= 32) as ONE launch whose workgroups wait on
  * arrival counters for the previous step (bounded waits).  This reads back, after synchronising `stream`, whether any
  * wait of the last run hit its bound (aborted_out != 0: the results of that run are invalid). */

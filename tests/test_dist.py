@@ -407,3 +407,43 @@ def test_vae_virtual_ranks_on_one_gpu_match_single_rank(gpu, O, B, D, H, Z, worl
     assert torch.equal(s0.rng_key, ref_state.rng_key) and int(s0.optim_state[0]) == 1
     assert abs(float(l0) - float(ref_loss)) <= 2e-5 * abs(float(ref_loss))
     np.testing.assert_allclose(s0.optim_state[1].cpu().numpy(), ref_state.optim_state[1].cpu().numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,K,d,world", [(64, 3, 2, 2), (200, 16, 64, 4)])
+def test_gmm_virtual_ranks_on_one_gpu_match_single_rank(gpu, B, K, d, world):
+    """The mixture-model step with the batch sharded by position over `world` virtual ranks on one device: per-example site
+    keys are functions of the global position, so the added partial sums give the single-rank update (up to the float order
+    of the sums), replicas are bitwise identical and the state advances once."""
+    import d3p_amd.random as rng
+    from d3p_amd.dist import GmmHipEngine, shard_batch
+    from d3p_amd.models import Adam, GaussianMixtureGuide, GaussianMixtureModel, Trace_ELBO
+    from d3p_amd.svi import DPSVI
+    N = 5000
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(B, d, generator=g).cuda() * 2.0
+
+    def make():
+        model = GaussianMixtureModel()
+        return DPSVI(model, GaussianMixtureGuide(model), Adam(5e-2), Trace_ELBO(), 20.0, 0.5, k=K, num_obs_total=N)
+
+    svi = make()
+    st = svi.init(rng.PRNGKey(9), X)
+    ref_state, ref_loss = svi.update(st, X)
+    engines, parts = [], []
+    for rk in range(world):
+        pos0, b_local = shard_batch(B, rk, world)
+        e = GmmHipEngine(make(), k=K)
+        e.begin(st, X[pos0:pos0 + b_local], B, pos0)
+        parts.append(e.local_sums().clone())
+        engines.append(e)
+    total = torch.stack(parts).sum(dim=0)
+    assert float(total[-1]) == B
+    outs = [e.apply(total.clone()) for e in engines]
+    for s2, l2 in outs[1:]:
+        assert torch.equal(s2.optim_state[1], outs[0][0].optim_state[1]) and torch.equal(s2.rng_key, outs[0][0].rng_key)
+        assert float(l2) == float(outs[0][1])
+    s0, l0 = outs[0]
+    assert torch.equal(s0.rng_key, ref_state.rng_key) and int(s0.optim_state[0]) == int(ref_state.optim_state[0]) == 1
+    assert abs(float(l0) - float(ref_loss)) <= 2e-5 * abs(float(ref_loss))
+    np.testing.assert_allclose(s0.optim_state[1].cpu().numpy(), ref_state.optim_state[1].cpu().numpy(), rtol=1e-4, atol=2e-5)
