@@ -562,3 +562,35 @@ def _check_no_wait_hit_its_bound(rng, N, d, B):
     flag = C.c_int32(-1)
     L.check(lib.d3p_dpvi_logreg_chain_status(L.stream_ptr(), C.byref(model), C.byref(src), L.ptr(ws), ws.numel(), C.byref(flag)))
     assert flag.value == 0
+
+
+def test_kernel_timing_hook_counts_launches_and_steps(rng):
+    """d3p_dpvi_logreg_kernel_timing_*: while enabled the run loop brackets its step-kernel launches with HIP events; the read
+    returns the summed kernel time, the launches and the DP-VI steps they covered, and clears the record (bench.py's roofline
+    block is built from exactly these three numbers)."""
+    import ctypes as C
+    import d3p_amd._lib as L
+    from d3p_amd.minibatch import subsample_batchify_data
+    lib = L.load()
+    N, d, B, steps = 20000, 64, 1024, 70
+    X = torch.randn(N, d).cuda()
+    y = (torch.rand(N) < 0.5).float().cuda()
+    svi = make_svi(d, False, N)
+    st = state_with(svi, rng.PRNGKey(1), np.zeros(d, np.float32), np.full(d, -2.0, np.float32))
+    _, gb = subsample_batchify_data((X, y), B)
+    us, launches, nsteps = C.c_double(-1.0), C.c_uint32(99), C.c_uint32(99)
+    L.check(lib.d3p_dpvi_logreg_kernel_timing_read(C.byref(us), C.byref(launches), C.byref(nsteps)))  # clear
+    svi.run_steps(st, gb, rng.PRNGKey(2), 0, steps)                                                 # hook off: nothing recorded
+    L.check(lib.d3p_dpvi_logreg_kernel_timing_read(C.byref(us), C.byref(launches), C.byref(nsteps)))
+    assert (us.value, launches.value, nsteps.value) == (0.0, 0, 0)
+    L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(1))
+    try:
+        svi.run_steps(st, gb, rng.PRNGKey(2), 0, steps)
+    finally:
+        L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(0))
+    L.check(lib.d3p_dpvi_logreg_kernel_timing_read(C.byref(us), C.byref(launches), C.byref(nsteps)))
+    assert nsteps.value == steps
+    assert launches.value == 3                       # chained launches of 32 + 32 + 6 steps
+    assert 0.0 < us.value < 1e6 and us.value / steps > 1.0   # a step takes microseconds, not nanoseconds or seconds
+    L.check(lib.d3p_dpvi_logreg_kernel_timing_read(C.byref(us), C.byref(launches), C.byref(nsteps)))
+    assert (launches.value, nsteps.value) == (0, 0)
