@@ -19,6 +19,7 @@
 // per-step path; the key-chain step of the next batch rides along as one extra workgroup.
 #include "d3p_logreg_kernel.h"
 #include "d3p_logreg_persist.h"
+#include "d3p_logreg_wide.h"
 
 #include <dlfcn.h>
 #include <vector>
@@ -621,6 +622,19 @@ static int enqueue_main(const Ctx& c, int t, const float* X, const float* y, con
     a.clip = c.h->clip;
     a.stamps = stamps ? c.ws.stamps : nullptr;
     a.dbg = dev_dbg_flags();
+    if (c.g.wide) {  // wide rows: column-chunked kernel, same partial-row output
+        static const bool attr_set = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_logreg_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipGetLastError();
+            return true;
+        }();
+        (void)attr_set;
+        if (e0)
+            hipExtLaunchKernelGGL(k_logreg_wide, dim3(c.g.blocks), dim3(64 * D3P_WIDE_W), c.g.lds, c.s, e0, e1, 0, a);
+        else
+            hipLaunchKernelGGL(k_logreg_wide, dim3(c.g.blocks), dim3(64 * D3P_WIDE_W), c.g.lds, c.s, a);
+        return check_launch("k_logreg_wide");
+    }
     return launch_main<0>(c.s, c.g, a, e0, e1);
 }
 
@@ -693,7 +707,7 @@ static void timing_pair(int steps, hipEvent_t* e0, hipEvent_t* e1)
 static bool use_fused_step(const Ctx& c)
 {
     static const bool off = getenv("D3P_NO_FUSED_STEP") != nullptr;  // two-kernel steps (main + finalize), kept for comparison
-    return !off;
+    return !off && !c.g.wide;  // wide rows run as two-kernel steps with the column-chunked main kernel
 }
 
 static void fill_fuse_common(const Ctx& c, StepFuse* f, int g)

@@ -917,11 +917,14 @@ __device__ __forceinline__ float block_sum_column(const float* __restrict__ part
 struct MainGeom {
     int V, NK, W;
     bool full;
+    bool wide;  // 2048 < d <= 4096, logistic regression: the column-chunked kernel of d3p_logreg_wide.h (two-kernel steps)
     uint32_t blocks;
     size_t lds;
 };
 
-static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g)
+// allow_wide: the caller launches the clip-and-accumulate stage (MODE 0) and may be given the column-chunked geometry; the
+// materialising stage (MODE 1) always uses the register-tiled kernel
+static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g, bool allow_wide = true)
 {
     const int D = m->d + (m->intercept ? 1 : 0), half = (D + 1) / 2, P = 2 * D;
     const bool vec = !m->intercept && (m->d % 8 == 0);
@@ -929,9 +932,15 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g)
     const int need = (half + 64 * g->V - 1) / (64 * g->V);
     g->NK = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 0;
     g->full = vec && g->NK > 0 && (D == 2 * 64 * g->V * g->NK) && m->family == D3P_FAMILY_LOGREG;
-    if (g->NK == 0)
+    // rows too wide for the register-tiled kernel (NK == 0), or its spilling NK == 8 form: the column-chunked kernel of
+    // d3p_logreg_wide.h takes them when the caller runs the clip-and-accumulate stage of a logistic-regression model and its
+    // 4 accumulator rows fit the LDS
+    const bool wide_ok = allow_wide && m->family == D3P_FAMILY_LOGREG && (size_t)(4 * P + 8) * sizeof(float) <= 160 * 1024 &&
+                         getenv("D3P_NO_WIDE_KERNEL") == nullptr;
+    if (g->NK == 0 && !wide_ok)
         return fail(D3P_E_UNSUPPORTED, "logreg kernel: latent dimension %d exceeds the supported maximum (%d)", D,
                     2 * 64 * g->V * 8);
+    if (g->NK == 0 && wide_ok) g->NK = 8;  // placeholder: only the chunked kernel is launched with this geometry
     // waves per workgroup (default 16 = one 1024-thread workgroup per CU at 4 waves/SIMD), reduced until
     // pack (5D) + reduction buffer (W x P) fit 64 KiB of LDS; one example per wave per pass.
     int W = g->NK == 1 ? 16 : g->NK == 2 ? 8 : 4, epw = 1;
@@ -959,16 +968,20 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g)
         if (env_epw >= 1 && env_epw <= 64) epw = env_epw;
     }
     auto lds_bytes = [&](int w) { return (size_t)(((5 * D + 3) & ~3) + w * P + 2 * w) * sizeof(float); };
-    while (W > 1 && lds_bytes(W) > 96 * 1024) W >>= 1;
-    if (lds_bytes(W) > 160 * 1024)
-        return fail(D3P_E_UNSUPPORTED, "logreg kernel: P = %d does not fit the LDS reduction buffer", P);
+    g->wide = wide_ok && g->NK == 8;  // accumulator rows only (the derived columns are read from the global pack): 4 waves
+    if (!g->wide) {
+        while (W > 1 && lds_bytes(W) > 96 * 1024) W >>= 1;
+        if (lds_bytes(W) > 160 * 1024)
+            return fail(D3P_E_UNSUPPORTED, "logreg kernel: P = %d does not fit the LDS reduction buffer", P);
+    }
+    if (g->wide) W = 4;
     g->W = W;
     uint64_t waves = ((uint64_t)B + epw - 1) / epw;
     uint64_t blocks = (waves + W - 1) / W;
     if (blocks < 1) blocks = 1;
     if (blocks > D3P_MAIN_MAX_BLOCKS) blocks = D3P_MAIN_MAX_BLOCKS;
     g->blocks = (uint32_t)blocks;
-    g->lds = lds_bytes(W);
+    g->lds = g->wide ? (size_t)(4 * P + 8) * sizeof(float) : lds_bytes(W);
     return D3P_OK;
 }
 

@@ -242,7 +242,9 @@ def test_constructor_validation(gpu):
 
 # --------------------------------------------------------------------------- fused update vs oracle
 @pytest.mark.parametrize("B,d,icpt,masked", [(16, 8, False, False), (16, 8, True, True), (50, 512, False, True),
-                                             (256, 512, False, False), (37, 100, True, True), (8, 1024, False, False)])
+                                             (256, 512, False, False), (37, 100, True, True), (8, 1024, False, False),
+                                             # wide rows: the column-chunked kernel of d3p_logreg_wide.h (2048 < d <= 4096)
+                                             (21, 3000, True, True), (12, 4096, False, False)])
 @pytest.mark.parametrize("onchip", [False, True])
 def test_fused_update_vs_oracle(rng, O, B, d, icpt, masked, onchip):
     N = 5000
@@ -594,3 +596,25 @@ def test_kernel_timing_hook_counts_launches_and_steps(rng):
     assert 0.0 < us.value < 1e6 and us.value / steps > 1.0   # a step takes microseconds, not nanoseconds or seconds
     L.check(lib.d3p_dpvi_logreg_kernel_timing_read(C.byref(us), C.byref(launches), C.byref(nsteps)))
     assert (launches.value, nsteps.value) == (0, 0)
+
+
+def test_wide_rows_run_steps_matches_stepwise_updates(rng):
+    """d = 3000 (the column-chunked kernel, two-kernel steps): the device-resident loop and one update() per step walk the same
+    trajectory, bitwise reproducibly."""
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, d, B, steps = 3000, 3000, 512, 5
+    g = torch.Generator().manual_seed(4)
+    X = torch.randn(N, d, generator=g).cuda()
+    y = (torch.rand(N, generator=g) < 0.5).float().cuda()
+    svi = make_svi(d, False, N, C=1.0, sigma=0.4, lr=2e-2)
+    st = state_with(svi, rng.PRNGKey(21), np.zeros(d, np.float32), np.full(d, -1.5, np.float32))
+    init, get_batch = subsample_batchify_data((X, y), B)
+    _, bstate = init(rng.PRNGKey(22))
+    runs = [svi.run_steps(st, get_batch, bstate, 0, steps) for _ in range(2)]
+    assert torch.equal(runs[0][0].optim_state[1], runs[1][0].optim_state[1]) and torch.equal(runs[0][1], runs[1][1])
+    ref, ref_losses = st, []
+    for t in range(steps):
+        ref, l = svi.update(ref, *get_batch(t, bstate))
+        ref_losses.append(float(l))
+    np.testing.assert_allclose(np_(runs[0][1]), ref_losses, rtol=2e-5)
+    np.testing.assert_allclose(np_(runs[0][0].optim_state[1]), np_(ref.optim_state[1]), rtol=1e-5, atol=2e-6)
