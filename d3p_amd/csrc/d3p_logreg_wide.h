@@ -32,6 +32,9 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
     float* mine = acc + (size_t)wave * P;
     const float* pk = a.pack;         // [loc | s | sg | q | lc] x D
     const bool eps_from_mem = a.eps_ext != nullptr;
+    const bool vec_ok = !a.icpt && (d & 3) == 0 && (half & 3) == 0 && D == 2 * half &&
+                        ((reinterpret_cast<uintptr_t>(a.X) | reinterpret_cast<uintptr_t>(pk) |
+                          reinterpret_cast<uintptr_t>(a.eps_ext)) & 15u) == 0;
     const uint32_t n_valid = a.counts ? a.counts[1] : a.B;
     const uint32_t n_items = a.plist ? *a.n_list : a.B;
     const uint32_t total_waves = gridDim.x * W;
@@ -50,19 +53,50 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
         if (!eps_from_mem) { k0 = a.skeys[2 * pp]; k1 = a.skeys[2 * pp + 1]; }
         const float* er = eps_from_mem ? a.eps_ext + (size_t)pp * D : nullptr;
 
+        // 4 consecutive entries base[c .. c + 3]: one 16-byte load on the aligned fast path (d and D / 2 multiples of 4, no
+        // intercept, chunk inside the row), guarded scalar loads otherwise
+        auto ld4 = [&](const float* base, int c, int limit, bool fast, float (&v)[4]) {
+            if (fast) {
+                const float4 t = *reinterpret_cast<const float4*>(base + c);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (c + i < limit) ? base[c + i] : 0.f;
+            }
+        };
         // x, eps and z of the 4 column pairs (c, c + half), c = cb + 4 lane + i, of one chunk
         auto chunk = [&](int cb, float (&x0)[4], float (&x1)[4], float (&e0)[4], float (&e1)[4], float (&z0)[4], float (&z1)[4],
                          bool (&ok0)[4], bool (&ok1)[4]) {
+            const int cl = cb + 4 * lane;
+            const bool fast = vec_ok && cl + 3 < half;  // then c1 + 3 < D as well (D == 2 half)
+            float l0[4], l1[4], s0[4], s1[4];
+            if (fast) {
+                ld4(xrow, cl, d, true, x0);
+                ld4(xrow, cl + half, d, true, x1);
+                if (eps_from_mem) { ld4(er, cl, D, true, e0); ld4(er, cl + half, D, true, e1); }
+                ld4(pk, cl, D, true, l0);
+                ld4(pk, cl + half, D, true, l1);
+                ld4(pk + D, cl, D, true, s0);
+                ld4(pk + D, cl + half, D, true, s1);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int c0 = cb + 4 * lane + i, c1 = c0 + half;
+                const int c0 = cl + i, c1 = c0 + half;
                 ok0[i] = c0 < half;
                 ok1[i] = ok0[i] && c1 < D;
-                x0[i] = ok0[i] ? (c0 < d ? xrow[c0] : 1.0f) : 0.f;  // column d = intercept
-                x1[i] = ok1[i] ? (c1 < d ? xrow[c1] : 1.0f) : 0.f;
+                if (!fast) {
+                    x0[i] = ok0[i] ? (c0 < d ? xrow[c0] : 1.0f) : 0.f;  // column d = intercept
+                    x1[i] = ok1[i] ? (c1 < d ? xrow[c1] : 1.0f) : 0.f;
+                    l0[i] = ok0[i] ? pk[c0] : 0.f;
+                    l1[i] = ok1[i] ? pk[c1] : 0.f;
+                    s0[i] = ok0[i] ? pk[D + c0] : 0.f;
+                    s1[i] = ok1[i] ? pk[D + c1] : 0.f;
+                }
                 if (eps_from_mem) {
-                    e0[i] = ok0[i] ? er[c0] : 0.f;
-                    e1[i] = ok1[i] ? er[c1] : 0.f;
+                    if (!fast) {
+                        e0[i] = ok0[i] ? er[c0] : 0.f;
+                        e1[i] = ok1[i] ? er[c1] : 0.f;
+                    }
                 } else {
                     uint32_t b0, b1;
                     threefry2x32(k0, k1, ok0[i] ? (uint32_t)c0 : 0u, ok1[i] ? (uint32_t)c1 : 0u, b0, b1);
@@ -70,10 +104,19 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
                     e0[i] = ok0[i] ? v0 : 0.f;
                     e1[i] = ok1[i] ? v1 : 0.f;
                 }
-                const float l0 = ok0[i] ? pk[c0] : 0.f, l1 = ok1[i] ? pk[c1] : 0.f;
-                const float s0 = ok0[i] ? pk[D + c0] : 0.f, s1 = ok1[i] ? pk[D + c1] : 0.f;
-                z0[i] = __fmaf_rn(s0, e0[i], l0);
-                z1[i] = __fmaf_rn(s1, e1[i], l1);
+                z0[i] = __fmaf_rn(s0[i], e0[i], l0[i]);
+                z1[i] = __fmaf_rn(s1[i], e1[i], l1[i]);
+            }
+        };
+        // 4 consecutive entries of derived-column array `arr` (0 .. 4) for both halves of a chunk
+        auto pk4 = [&](int arr, int cb, float (&v0)[4], float (&v1)[4]) {
+            const int cl = cb + 4 * lane;
+            const bool fast = vec_ok && cl + 3 < half;
+            ld4(pk + (size_t)arr * D, cl, half, fast, v0);
+            ld4(pk + (size_t)arr * D, cl + half, D, fast, v1);
+            if (!fast) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (!(cl + i < half)) v1[i] = 0.f;
             }
         };
         auto col_c1 = [&](int c) { return (a.icpt && c == d) ? a.c1_b : a.c1_w; };
@@ -85,14 +128,15 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
             float x0[4], x1[4], e0[4], e1[4], z0[4], z1[4];
             bool ok0[4], ok1[4];
             chunk(cb, x0, x1, e0, e1, z0, z1, ok0, ok1);
+            float lc0[4], lc1[4];
+            pk4(4, cb, lc0, lc1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c0 = cb + 4 * lane + i, c1 = c0 + half;
                 tp = __fmaf_rn(x0[i], z0[i], tp);
                 tp = __fmaf_rn(x1[i], z1[i], tp);
-                const float lc0 = ok0[i] ? pk[4 * D + c0] : 0.f, lc1 = ok1[i] ? pk[4 * D + c1] : 0.f;
-                lp += __fmaf_rn(col_hz(c0) * z0[i], z0[i], __fmaf_rn(-0.5f * e0[i], e0[i], lc0));
-                lp += __fmaf_rn(col_hz(c1) * z1[i], z1[i], __fmaf_rn(-0.5f * e1[i], e1[i], lc1));
+                lp += ok0[i] ? __fmaf_rn(col_hz(c0) * z0[i], z0[i], __fmaf_rn(-0.5f * e0[i], e0[i], lc0[i])) : 0.f;
+                lp += ok1[i] ? __fmaf_rn(col_hz(c1) * z1[i], z1[i], __fmaf_rn(-0.5f * e1[i], e1[i], lc1[i])) : 0.f;
             }
         }
         const float t = wave_sum(tp);
@@ -107,11 +151,14 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
             float x0[4], x1[4], e0[4], e1[4], z0[4], z1[4];
             bool ok0[4], ok1[4];
             chunk(cb, x0, x1, e0, e1, z0, z1, ok0, ok1);
+            float sgv0[4], sgv1[4], qv0[4], qv1[4];
+            pk4(2, cb, sgv0, sgv1);
+            pk4(3, cb, qv0, qv1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c0 = cb + 4 * lane + i, c1 = c0 + half;
-                const float sg0 = ok0[i] ? pk[2 * D + c0] : 0.f, sg1 = ok1[i] ? pk[2 * D + c1] : 0.f;
-                const float q0 = ok0[i] ? pk[3 * D + c0] : 0.f, q1 = ok1[i] ? pk[3 * D + c1] : 0.f;
+                const float sg0 = ok0[i] ? sgv0[i] : 0.f, sg1 = ok1[i] ? sgv1[i] : 0.f;
+                const float q0 = ok0[i] ? qv0[i] : 0.f, q1 = ok1[i] ? qv1[i] : 0.f;
                 const float g0 = __fmaf_rn(col_c1(c0), z0[i], A * x0[i]), g1 = __fmaf_rn(col_c1(c1), z1[i], A * x1[i]);
                 const float h0 = __fmaf_rn(g0 * e0[i], sg0, -q0), h1 = __fmaf_rn(g1 * e1[i], sg1, -q1);
                 n2 = __fmaf_rn(g0, g0, n2);
@@ -128,11 +175,14 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
             float x0[4], x1[4], e0[4], e1[4], z0[4], z1[4];
             bool ok0[4], ok1[4];
             chunk(cb, x0, x1, e0, e1, z0, z1, ok0, ok1);
+            float sgv0[4], sgv1[4], qv0[4], qv1[4];
+            pk4(2, cb, sgv0, sgv1);
+            pk4(3, cb, qv0, qv1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c0 = cb + 4 * lane + i, c1 = c0 + half;
-                const float sg0 = ok0[i] ? pk[2 * D + c0] : 0.f, sg1 = ok1[i] ? pk[2 * D + c1] : 0.f;
-                const float q0 = ok0[i] ? pk[3 * D + c0] : 0.f, q1 = ok1[i] ? pk[3 * D + c1] : 0.f;
+                const float sg0 = ok0[i] ? sgv0[i] : 0.f, sg1 = ok1[i] ? sgv1[i] : 0.f;
+                const float q0 = ok0[i] ? qv0[i] : 0.f, q1 = ok1[i] ? qv1[i] : 0.f;
                 const float g0 = __fmaf_rn(col_c1(c0), z0[i], A * x0[i]), g1 = __fmaf_rn(col_c1(c1), z1[i], A * x1[i]);
                 const float h0 = __fmaf_rn(g0 * e0[i], sg0, -q0), h1 = __fmaf_rn(g1 * e1[i], sg1, -q1);
                 if (ok0[i]) { mine[c0] = __fmaf_rn(cf, g0, mine[c0]); mine[D + c0] = __fmaf_rn(cf, h0, mine[D + c0]); }
