@@ -122,6 +122,7 @@ struct Sched {
 #define D3P_BAR_LINE 32
 #define D3P_BAR_WORDS (17 * D3P_BAR_LINE)
 #define D3P_AGENT __HIP_MEMORY_SCOPE_AGENT
+typedef unsigned int d3p_u32x4 __attribute__((ext_vector_type(4)));
 
 template <bool CH, typename T>
 __device__ __forceinline__ T ld_x(const T* p)  // cross-workgroup load: agent-scope in the chained form
@@ -279,6 +280,7 @@ struct ChainFuse {
     uint32_t* abort_flag;
     StepSlot* chain_slots;       // slots of the NEXT batch (key chain), K_next of them
     int K_next;
+    int pregen;                  // pipelined geometry: noise of a wave's first two examples is generated before the release wait
 };
 
 struct MainArgs {
@@ -529,7 +531,88 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             // prologue's memory latency hides behind their VALU work.  Flush launches use every wave.
             constexpr int CB = 4;
             const int PW = f.flush_only ? W : (W < 4 ? W : 4);
-            if (wave < PW) {
+            // Chained form, P a multiple of 8 and 16-byte aligned state: a thread takes 4 ADJACENT columns and fetches them
+            // with 12 sixteen-byte agent-scope loads instead of 32 four/eight-byte ones (same bytes, fewer and larger
+            // memory-side requests), and workgroup 0 publishes the state with 16-byte stores.  Measured A/B on one box
+            // (D3P_DBG=64 selects the narrow loads): 16-wave workgroups 11.89 -> 11.59 us per step; in the pipelined form
+            // (8-wave workgroups, `pregen`) the narrow loads are the faster ones (10.93 vs 11.08), so it keeps them.
+            const bool wide16 =
+                CHAIN && !a.chain.pregen && !f.flush_only && (P & 7) == 0 && !(a.dbg & 64) &&
+                ((((uintptr_t)f.acc_prev | (uintptr_t)f.params_in | (uintptr_t)f.m_in | (uintptr_t)f.v_in | (uintptr_t)f.params_out |
+                   (uintptr_t)f.m_out | (uintptr_t)f.v_out | (uintptr_t)f.prev_noise) & 15) == 0);
+            if (wide16) {
+                if (wave < PW) {
+                    const auto r_acc = __builtin_amdgcn_make_buffer_rsrc((void*)f.acc_prev, 0, D3P_ACC_R * PA * 8, 0x00020000);
+                    const auto r_x = __builtin_amdgcn_make_buffer_rsrc((void*)f.params_in, 0, P * 4, 0x00020000);
+                    const auto r_m = __builtin_amdgcn_make_buffer_rsrc((void*)f.m_in, 0, P * 4, 0x00020000);
+                    const auto r_v = __builtin_amdgcn_make_buffer_rsrc((void*)f.v_in, 0, P * 4, 0x00020000);
+                    for (int col = 4 * (int)threadIdx.x; col < P; col += 4 * 64 * PW) {
+                        d3p_u32x4 a8[D3P_ACC_R][2];
+#pragma unroll
+                        for (int r = 0; r < D3P_ACC_R; ++r) {
+                            a8[r][0] = __builtin_amdgcn_raw_buffer_load_b128(r_acc, (r * PA + col) * 8, 0, 16);
+                            a8[r][1] = __builtin_amdgcn_raw_buffer_load_b128(r_acc, (r * PA + col) * 8 + 16, 0, 16);
+                        }
+                        const d3p_u32x4 xv = __builtin_amdgcn_raw_buffer_load_b128(r_x, col * 4, 0, 16);
+                        const d3p_u32x4 mv4 = __builtin_amdgcn_raw_buffer_load_b128(r_m, col * 4, 0, 16);
+                        const d3p_u32x4 vv4 = __builtin_amdgcn_raw_buffer_load_b128(r_v, col * 4, 0, 16);
+                        const float4 zv = *reinterpret_cast<const float4*>(f.prev_noise + col);
+                        __builtin_amdgcn_sched_barrier(0);  // keep the uniform loads behind the column loads
+                        load_n();
+                        const float n = count_n();
+                        const float factor = (n == 0.0f) ? 0.0f : Bf / n;  // svi.py:305
+                        const float inv_B = 1.0f / Bf, inv_bc1 = 1.0f / pend_bc1, inv_bc2 = 1.0f / pend_bc2;
+                        const float noise_scale = f.dp_scale * (a.clip / n), out_scale = a.obs_scale * factor;
+                        const float z[4] = {zv.x, zv.y, zv.z, zv.w};
+                        d3p_u32x4 xo, mo, vo;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            long long sll = 0;
+#pragma unroll
+                            for (int r = 0; r < D3P_ACC_R; ++r)
+                                sll += (long long)(((unsigned long long)a8[r][j >> 1][2 * (j & 1) + 1] << 32) |
+                                                   a8[r][j >> 1][2 * (j & 1)]);
+                            const float tot = (float)((double)sll * f.inv_sg);
+                            const float g = __fmaf_rn(z[j], noise_scale, tot * inv_B) * out_scale;
+                            const float mm = (1.0f - f.b1) * g + f.b1 * __uint_as_float(mv4[j]);
+                            const float vv = (1.0f - f.b2) * g * g + f.b2 * __uint_as_float(vv4[j]);
+                            const float xx = __uint_as_float(xv[j]) - f.lr * (mm * inv_bc1) *
+                                                                          __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv * inv_bc2) + f.adam_eps);
+                            xo[j] = __float_as_uint(xx);
+                            mo[j] = __float_as_uint(mm);
+                            vo[j] = __float_as_uint(vv);
+                        }
+                        {  // derived columns, 16-byte LDS writes (4 adjacent columns never straddle the two sites: D % 4 == 0)
+                            const int site = col >= D, e = col - site * D;
+                            if (site == 0) {
+                                *reinterpret_cast<float4*>(pk + e) = make_float4(__uint_as_float(xo[0]), __uint_as_float(xo[1]),
+                                                                                 __uint_as_float(xo[2]), __uint_as_float(xo[3]));
+                            } else {
+                                float sp[4], sgm[4], qq[4], lc[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    guide_scale(a.gexp, __uint_as_float(xo[j]), sp[j], sgm[j]);
+                                    const float ps = (e + j < a.d) ? a.fuse.prior_w : a.fuse.prior_b;
+                                    qq[j] = a.inv_obs * sgm[j] * __builtin_amdgcn_rcpf(sp[j]);
+                                    lc[j] = __logf(ps) - __logf(sp[j]);
+                                }
+                                *reinterpret_cast<float4*>(pk + D + e) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                                *reinterpret_cast<float4*>(pk + 2 * D + e) = make_float4(sgm[0], sgm[1], sgm[2], sgm[3]);
+                                *reinterpret_cast<float4*>(pk + 3 * D + e) = make_float4(qq[0], qq[1], qq[2], qq[3]);
+                                *reinterpret_cast<float4*>(pk + 4 * D + e) = make_float4(lc[0], lc[1], lc[2], lc[3]);
+                            }
+                        }
+                        if (bid == 0) {  // one workgroup publishes the state
+                            __builtin_amdgcn_raw_buffer_store_b128(
+                                xo, __builtin_amdgcn_make_buffer_rsrc((void*)f.params_out, 0, P * 4, 0x00020000), col * 4, 0, 16);
+                            __builtin_amdgcn_raw_buffer_store_b128(
+                                mo, __builtin_amdgcn_make_buffer_rsrc((void*)f.m_out, 0, P * 4, 0x00020000), col * 4, 0, 16);
+                            __builtin_amdgcn_raw_buffer_store_b128(
+                                vo, __builtin_amdgcn_make_buffer_rsrc((void*)f.v_out, 0, P * 4, 0x00020000), col * 4, 0, 16);
+                        }
+                    }
+                }
+            } else if (wave < PW) {
                 const int stride = 64 * PW;
                 for (int col0 = threadIdx.x; col0 < P; col0 += stride * CB) {
                     long long r8[CB][D3P_ACC_R];
@@ -597,12 +680,6 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
     // waves' own noise 2.4 us, dot / gradient / reduction 2.0 us, atomics + arrival 2.15 us.  Generating every wave's noise
     // BEFORE the prologue does not help: the index -> row / key load chain issued at entry is hidden behind the prologue in
     // this order and exposed in the other one: 12.2 -> 18.4 us per step.)
-    if (FUSE && (a.fuse.flush_only || !kLatePrologue)) {
-        finish_prologue();
-        D3P_STAMP(2)
-        if (a.fuse.flush_only) return;
-    }
-
     const bool gauss = !FULL && a.family == D3P_FAMILY_GAUSS_MEAN;
     int c0[NC], c1[NC];
     bool ok0[NC], ok1[NC];
@@ -687,13 +764,50 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
     auto pos = [&](uint32_t k) { return a.plist ? a.plist[k] : k; };
     ExLoad<NC> cur;
     uint32_t p = gw;  // item index
-    if (p < n_items) issue(pos(p), cur);
+    // The loads of the first example are issued BEFORE the update prologue also by the prologue waves: their index -> row ->
+    // features chain then completes while those waves wait for the previous step's release, instead of after the prologue.
+    if (!(FUSE && a.fuse.flush_only) && p < n_items) issue(pos(p), cur);
+    // Pipelined chained form (8-wave workgroups, two resident per CU: the workgroups of step t + 1 arrive while step t is
+    // still in its exchange).  Every wave -- the prologue waves too -- generates the noise of its first TWO examples into
+    // its own (still unused) row of the reduction buffer BEFORE waiting for the previous step's release, so between that
+    // release and this workgroup's arrival there is only the prologue, the gradient arithmetic and the exchange.
+    const bool pregen = CHAIN && FULL && V == 4 && NK == 1 && !eps_from_mem && a.chain.pregen && !a.fuse.flush_only && !(a.dbg & 1);
+    int it = 0;  // examples this wave has gone through
+    ExLoad<NC> pre;         // second example, loaded ahead of the prologue as well (its index -> row chain would otherwise sit
+    bool have_pre = false;  // between the release and the first gradient)
+    if (NC == 4 && pregen && p < n_items) {
+        float* er = red + (size_t)wave * P;
+        const uint32_t p2 = p + total_waves;
+        if (p2 < n_items) {
+            issue(pos(p2), pre);
+            have_pre = true;
+        }
+        auto gen = [&](uint32_t k0, uint32_t k1, float* dst) {
+            float v0[4], v1[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                uint32_t b0, b1;
+                threefry2x32(k0, k1, (uint32_t)c0[n], (uint32_t)c1[n], b0, b1);
+                v0[n] = bits_to_normal_wu(b0);
+                v1[n] = bits_to_normal_wu(b1);
+            }
+            *reinterpret_cast<float4*>(dst + c0[0]) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+            *reinterpret_cast<float4*>(dst + c1[0]) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+        };
+        if (cur.live) gen(cur.k0, cur.k1, er);
+        if (have_pre && pre.live) gen(pre.k0, pre.k1, er + D);
+    }
+    if (FUSE && (a.fuse.flush_only || !kLatePrologue)) {
+        finish_prologue();
+        D3P_STAMP(2)
+        if (a.fuse.flush_only) return;
+    }
     // The derived columns are first needed AFTER the noise of the first example has been generated, so for the waves that
     // do not run the prologue the staging barrier sits behind that phase.  The prologue waves arrive at the barrier as
     // soon as the columns are in LDS -- BEFORE generating their own noise: the other 12 waves then start their arithmetic
     // ~1.8 us earlier and the prologue waves' noise generation overlaps with it (every wave passes exactly one barrier).
     bool staged = false;
-    if (prologue_wave && p < n_items) {
+    if ((prologue_wave || pregen) && p < n_items) {
         __syncthreads();
         staged = true;
     }
@@ -702,7 +816,8 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
     while (p < n_items) {
         const uint32_t pn = p + total_waves;
         ExLoad<NC> nxt;
-        if (pn < n_items) issue(pos(pn), nxt);  // prefetch: in flight while the current example computes
+        if (it == 0 && have_pre) nxt = pre;
+        else if (pn < n_items) issue(pos(pn), nxt);  // prefetch: in flight while the current example computes
 
         if (cur.live || MODE == 1) {
             // ---- guide noise eps_i (svi.py:289-290): parity mode reads it, otherwise threefry on chip
@@ -714,13 +829,22 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
 #pragma unroll
                 for (int n = 0; n < NC; ++n) { e0[n] = __uint_as_float(cur.k0 & 0x3fffffffu); e1[n] = e0[n] * 0.5f; }
             } else {
+                if (pregen && it < 2) {  // generated before the update prologue (see `pregen`)
+                    const float* er = red + (size_t)wave * P + it * D;
+                    float t0[4], t1[4];
+                    *reinterpret_cast<float4*>(t0) = *reinterpret_cast<const float4*>(er + c0[0]);
+                    *reinterpret_cast<float4*>(t1) = *reinterpret_cast<const float4*>(er + c1[0]);
 #pragma unroll
-                for (int n = 0; n < NC; ++n) {
-                    uint32_t b0, b1;
-                    threefry2x32(cur.k0, cur.k1, (uint32_t)c0[n], ok1[n] ? (uint32_t)c1[n] : 0u, b0, b1);
-                    const float v0 = bits_to_normal_wu(b0), v1 = bits_to_normal_wu(b1);
-                    e0[n] = ok0[n] ? v0 : 0.f;
-                    e1[n] = ok1[n] ? v1 : 0.f;
+                    for (int n = 0; n < NC && n < 4; ++n) { e0[n] = t0[n]; e1[n] = t1[n]; }
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NC; ++n) {
+                        uint32_t b0, b1;
+                        threefry2x32(cur.k0, cur.k1, (uint32_t)c0[n], ok1[n] ? (uint32_t)c1[n] : 0u, b0, b1);
+                        const float v0 = bits_to_normal_wu(b0), v1 = bits_to_normal_wu(b1);
+                        e0[n] = ok0[n] ? v0 : 0.f;
+                        e1[n] = ok1[n] ? v1 : 0.f;
+                    }
                 }
             }
 
@@ -809,6 +933,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         if (!staged) { finish_prologue(); __syncthreads(); staged = true; }  // example skipped before reaching the barrier
         cur = nxt;
         p = pn;
+        ++it;
     }
 
     D3P_STAMP(5)

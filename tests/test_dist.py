@@ -266,7 +266,7 @@ def test_dist_run_steps_equals_svi_run_steps(gpu):
 @pytest.mark.gpu
 def test_native_rccl_loop_on_one_rank_equals_the_single_gpu_run(gpu):
     """d3p_dpvi_logreg_run_dist with a 1-rank RCCL communicator created through d3p_comm_* (the in-place all-reduce of
-    the int64 accumulator is then the identity): same losses, parameters and keys as DPSVI.run_steps, bit for bit."""
+    the int64 accumulator is then the identity): same losses, parameters and keys as DPSVI.run_steps."""
     import d3p_amd._lib as L
     import d3p_amd.random as rng
     from d3p_amd import dist as ddist
@@ -290,8 +290,10 @@ def test_native_rccl_loop_on_one_rank_equals_the_single_gpu_run(gpu):
         new_state, losses = ddist.run_steps_native(engine, st, bkey, 5, steps, comm=comm)
     finally:
         comm.close()
-    assert torch.equal(losses, ref_losses)
-    assert torch.equal(new_state.optim_state[1], ref_state.optim_state[1])
+    # (the single-GPU loop runs the pipelined chained form: 8-wave workgroups, so its fp32 workgroup partials are grouped
+    # differently from the one-launch-per-step form of the RCCL loop -- same trajectory to fp32 rounding, same keys)
+    torch.testing.assert_close(losses, ref_losses, rtol=2e-6, atol=0)
+    torch.testing.assert_close(new_state.optim_state[1], ref_state.optim_state[1], rtol=1e-4, atol=2e-6)
     assert torch.equal(new_state.rng_key, ref_state.rng_key) and int(new_state.optim_state[0]) == steps
 
 

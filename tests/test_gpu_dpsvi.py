@@ -478,7 +478,8 @@ def test_chained_launch_matches_one_launch_per_step(rng):
     """The default run loop executes the <= 32 steps of a prepared batch as ONE launch: resident workgroups that loop over
     the steps (MODE 4, d = 512, D3P_PERSISTENT_STEPS=1) or one workgroup set per step waiting on arrival counters (MODE 3); D3P_NO_CHAINED_STEPS=1 (switches are read once per process, so checked in child
     processes) selects one launch per step.  All walk the same trajectory bit for bit -- the sums are exact integer sums
-    in each -- and no wait hit its bound."""
+    in each -- when their workgroups hold the same examples; the default chained form is pipelined (8-wave workgroups, two
+    examples per wave) and agrees to fp32 rounding.  No wait hit its bound."""
     import ctypes as C
     import subprocess
     import sys
@@ -503,14 +504,21 @@ np.save(sys.argv[1], np.concatenate([losses.cpu().numpy(), s2.optim_state[1].cpu
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     import tempfile
     outs = []
-    # persistent launch (MODE 4, this geometry qualifies); the chained form (MODE 3); one launch per step
-    for env_extra in ({"D3P_PERSISTENT_STEPS": "1"}, {}, {"D3P_NO_CHAINED_STEPS": "1"}):
+    # persistent launch (MODE 4, this geometry qualifies); the chained form (MODE 3) with the workgroup shape of the
+    # other two; one launch per step; then the default chained form (pipelined: 8-wave workgroups), twice
+    for env_extra in ({"D3P_PERSISTENT_STEPS": "1"}, {"D3P_NO_PIPELINED_STEPS": "1"}, {"D3P_NO_CHAINED_STEPS": "1"}, {}, {}):
         with tempfile.NamedTemporaryFile(suffix=".npy") as f:
             env = dict(os.environ, **env_extra)
             subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env, timeout=300)
             outs.append(np.load(f.name))
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert np.all(np.isfinite(outs[0]))
+    # The pipelined form groups the examples differently into workgroups (two per wave), so its fp32 workgroup partials
+    # round differently: reproducible bit for bit run to run, and equal to the others to fp32 rounding over the 70 steps
+    assert np.array_equal(outs[3], outs[4])
+    steps = 70
+    np.testing.assert_allclose(outs[3][:steps], outs[0][:steps], rtol=2e-6)
+    np.testing.assert_allclose(outs[3][steps:], outs[0][steps:], rtol=1e-4, atol=2e-6)
     # abort flag of the bounded waits after a run in this process (d = 512: persistent form; d = 64: chained form)
     for N, d, B in ((20000, 512, 4096), (20000, 64, 1024)):
         _check_no_wait_hit_its_bound(rng, N, d, B)
@@ -518,7 +526,8 @@ np.save(sys.argv[1], np.concatenate([losses.cpu().numpy(), s2.optim_state[1].cpu
 
 def test_chained_launch_with_poisson_batches_matches_one_launch_per_step(rng):
     """Poisson batches are padded to max_batch_size and processed through dense lists of the valid positions; the chained
-    launch walks those lists too and is bitwise identical to one launch per step."""
+    launch walks those lists too and is bitwise identical to one launch per step (same workgroup shape; the pipelined
+    default agrees to fp32 rounding)."""
     import subprocess
     import sys
     import tempfile
@@ -540,11 +549,14 @@ s2, losses = svi.run_steps(st, gb, rng.PRNGKey(4), 0, steps)
 np.save(sys.argv[1], np.concatenate([losses.cpu().numpy(), s2.optim_state[1].cpu().numpy()]))
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     outs = []
-    for env_extra in ({}, {"D3P_NO_CHAINED_STEPS": "1"}):
+    for env_extra in ({"D3P_NO_PIPELINED_STEPS": "1"}, {"D3P_NO_CHAINED_STEPS": "1"}, {}):
         with tempfile.NamedTemporaryFile(suffix=".npy") as f:
             subprocess.run([sys.executable, "-c", code, f.name], check=True, env=dict(os.environ, **env_extra), timeout=300)
             outs.append(np.load(f.name))
     assert np.array_equal(outs[0], outs[1]) and np.all(np.isfinite(outs[0]))
+    # default (pipelined) chained form: other grouping of the examples into workgroups => equal to fp32 rounding
+    np.testing.assert_allclose(outs[2][:70], outs[0][:70], rtol=2e-6)
+    np.testing.assert_allclose(outs[2][70:], outs[0][70:], rtol=1e-4, atol=2e-6)
 
 
 def _check_no_wait_hit_its_bound(rng, N, d, B):
