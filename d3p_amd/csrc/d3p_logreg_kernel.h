@@ -2,6 +2,7 @@
 // threefry sample keys, the fused main kernel template (MODE 0: clip + accumulate, MODE 1:
 // materialise px_grads) and its launch geometry.
 #pragma once
+#include <type_traits>
 #include "d3p_device.h"
 #include "d3p_host.h"
 #include <hip/hip_ext.h>
@@ -82,7 +83,7 @@ __device__ __forceinline__ void px_sample_key(uint32_t j0, uint32_t j1, uint32_t
 
 struct d3p_logreg_model_view { float obs_scale; };
 
-#define D3P_ACC_R 4  // replicas of the fixed-point accumulator (measured: 8 -> 14.75, 4 -> 14.43, 2 -> 15.9 us/step)
+#define D3P_ACC_R 4  // replicas of the fixed-point accumulator (16-wave form: 8 -> 14.75, 4 -> 14.43, 2 -> 15.9 us/step; pipelined form: 8 -> 11.2, 4 -> 10.6, 2 -> 12.3)
 
 // Per-step record produced by the key chain / sampler (device memory).
 struct StepSlot {
@@ -460,6 +461,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         prologue_done = true;
         const StepFuse& f = a.fuse;
         const int PA = P + 2;
+        const bool all_waves = CHAIN && a.chain.pregen && !f.flush_only && !(a.dbg & 128);
         if (!f.apply_prev) {  // no pending update: derive the columns from the parameters as they are
             if (CHAIN)  // (first step of a run) nobody reads the next accumulator yet
                 for (int i = bid * blockDim.x + threadIdx.x; i < D3P_ACC_R * PA; i += a.chain.nw * blockDim.x)
@@ -470,10 +472,13 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         if (CHAIN) {
             // every workgroup of the previous step must have added its sums (and published the state) before the
             // prologue reads them; the first step of a launch follows a kernel boundary instead
-            const int PWc = W < 4 ? W : 4;
-            if (step_t > 0 && wave < PWc && lane == 0)  // the release word of this workgroup's group
+            // (pipelined form: every wave has prepared its examples already, so ONE lane polls and, behind a workgroup
+            // barrier, all waves share the prologue)
+            const int PWc = all_waves ? W : (W < 4 ? W : 4);
+            if (step_t > 0 && (all_waves ? threadIdx.x == 0 : (wave < PWc && lane == 0)))  // the release word of this workgroup's group
                 (void)chain_wait(a.chain.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (9 + (bid & 7u)), 1u,
                                  a.chain.abort_flag);
+            if (all_waves) __syncthreads();
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             if ((a.dbg & 32) && a.stamps && threadIdx.x == 0) a.stamps[8 * bid + 7] = wall_clock64();  // release seen
             // now nobody reads the next accumulator any more (the previous step's prologues are over): zero it
@@ -529,8 +534,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             // Only the first PW waves (one per SIMD) run the prologue, CB columns per thread with all loads in
             // flight together; the other waves go straight to their row loads and eps generation, so the
             // prologue's memory latency hides behind their VALU work.  Flush launches use every wave.
-            constexpr int CB = 4;
-            const int PW = f.flush_only ? W : (W < 4 ? W : 4);
+            const int PW = (f.flush_only || all_waves) ? W : (W < 4 ? W : 4);
             // Chained form, P a multiple of 8 and 16-byte aligned state: a thread takes 4 ADJACENT columns and fetches them
             // with 12 sixteen-byte agent-scope loads instead of 32 four/eight-byte ones (same bytes, fewer and larger
             // memory-side requests), and workgroup 0 publishes the state with 16-byte stores.  Measured A/B on one box
@@ -613,6 +617,8 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                     }
                 }
             } else if (wave < PW) {
+              auto narrow_cols = [&](auto cb_tag) {
+                constexpr int CB = decltype(cb_tag)::value;
                 const int stride = 64 * PW;
                 for (int col0 = threadIdx.x; col0 < P; col0 += stride * CB) {
                     long long r8[CB][D3P_ACC_R];
@@ -659,6 +665,9 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                         }
                     }
                 }
+              };
+              if (P <= 2 * 64 * PW) narrow_cols(std::integral_constant<int, 2>{});
+              else narrow_cols(std::integral_constant<int, 4>{});
             }
         }
         if (bid == 0 && threadIdx.x == 0) {
