@@ -81,7 +81,6 @@ __device__ __forceinline__ void px_sample_key(uint32_t j0, uint32_t j1, uint32_t
     threefry2x32(g0, g1, 1u, 3u, b, o1);
 }
 
-struct d3p_logreg_model_view { float obs_scale; };
 
 #define D3P_ACC_R 4  // replicas of the fixed-point accumulator (16-wave form: 8 -> 14.75, 4 -> 14.43, 2 -> 15.9 us/step; pipelined form: 8 -> 11.2, 4 -> 10.6, 2 -> 12.3)
 
@@ -224,36 +223,6 @@ struct StepFuse {
     int chain_t, chain_last;
 };
 
-// Applies the pending sums of the previous step for column `col`: mean, Gaussian mechanism, rescale
-// (svi.py:343-346, :365-375), Adam (svi.py:379-393).  Every workgroup computes the same values from the
-// same inputs; returns the new unconstrained parameter.
-__device__ __forceinline__ float apply_pending_column(const StepFuse& f, const d3p_logreg_model_view& mv, int PA, int col,
-                                                      float n, float Bf, float clip, float bc1, float bc2, float& m_out,
-                                                      float& v_out)
-{
-    // all loads first (8 replica words + state + noise), then the arithmetic
-    long long r8[D3P_ACC_R];
-#pragma unroll
-    for (int r = 0; r < D3P_ACC_R; ++r) r8[r] = f.acc_prev[(size_t)r * PA + col];
-    float x = f.params_in[col], m = f.m_in[col], v = f.v_in[col];
-    const float z = f.prev_noise[col];
-    long long s = 0;
-#pragma unroll
-    for (int r = 0; r < D3P_ACC_R; ++r) s += r8[r];
-    const float tot = (float)((double)s * f.inv_sg);
-    const float factor = (n == 0.0f) ? 0.0f : Bf / n;  // svi.py:305
-    const float avg = tot / Bf;
-    const float scale = f.dp_scale * (clip / n);
-    const float g = (avg + z * scale) * mv.obs_scale * factor;
-    m = (1.0f - f.b1) * g + f.b1 * m;
-    v = (1.0f - f.b2) * g * g + f.b2 * v;
-    const float mhat = m / bc1, vhat = v / bc2;
-    x = x - f.lr * mhat / (sqrtf(vhat) + f.adam_eps);
-    m_out = m;
-    v_out = v;
-    return x;
-}
-
 // Arguments of the chained form (MODE 3): ONE launch covers the K steps of a prepared batch.  The grid has
 // K x (nw + 1) workgroups; workgroup i belongs to step i / (nw + 1).  Workgroups are dispatched in linear-id order, so
 // every workgroup of step t is resident before any workgroup of step t + 1 is placed: a step-(t+1) workgroup can start
@@ -391,14 +360,11 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
     // ---- stage the derived parameter columns in LDS once per workgroup (5 x D floats)
     float* pk = lds;                       // [loc | s | sg | q | lc]
     float* red = lds + ((5 * D + 3) & ~3); // W x P reduction buffer (MODE 0) + 2W tail
-    // MODE 2 prologue, split in two so that its memory latency hides behind the eps generation:
-    // the loads are issued here, the arithmetic (and the LDS writes) happen right before the staging barrier.
-    long long pend_r8[D3P_ACC_R], pend_n8[D3P_ACC_R];
-    float pend_x = 0.f, pend_m = 0.f, pend_v = 0.f, pend_z = 0.f, pend_bc1 = 1.f, pend_bc2 = 1.f;
-    // Measured: keeping these loads in registers across the eps generation costs 12 extra VGPRs -> 128 VGPRs +
-    // scratch and a slower kernel (14.8 vs 12.5 us), so the prologue runs in order, before the row loads.
-    constexpr bool kLatePrologue = false;
-    const bool pend_fast = kLatePrologue && FUSE && a.fuse.apply_prev && (P <= (int)blockDim.x);
+    // Update prologue of MODE 2 / 3 (finish_prologue below).  Measured: issuing its loads here and keeping them in registers
+    // across the eps generation costs 12 extra VGPRs -> 128 VGPRs + scratch and a slower kernel (14.8 vs 12.5 us), so the
+    // prologue runs in one piece.
+    long long pend_n8[D3P_ACC_R];
+    float pend_bc1 = 1.f, pend_bc2 = 1.f;
     if (FUSE) {
         const StepFuse& f = a.fuse;
         const int PA = P + 2;
@@ -422,21 +388,6 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         if (!CHAIN) {
             const int i = bid * blockDim.x + threadIdx.x;
             if (i < D3P_ACC_R * PA) f.acc_next[i] = 0;
-        }
-        if (f.apply_prev) {
-            if (pend_fast) {
-                pend_bc1 = f.prev_meta->bc1;
-                pend_bc2 = f.prev_meta->bc2;
-            }
-            if (pend_fast && (int)threadIdx.x < P) {
-                const int col = threadIdx.x;
-#pragma unroll
-                for (int r = 0; r < D3P_ACC_R; ++r) pend_r8[r] = f.acc_prev[(size_t)r * PA + col];
-                pend_x = f.params_in[col];
-                pend_m = f.m_in[col];
-                pend_v = f.v_in[col];
-                pend_z = f.prev_noise[col];
-            }
         }
     } else {
         for (int i = threadIdx.x; i < 5 * D; i += blockDim.x) pk[i] = a.pack[i];
@@ -495,10 +446,8 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         auto load_n = [&]() {
 #pragma unroll
             for (int r = 0; r < D3P_ACC_R; ++r) pend_n8[r] = ld_x<CHAIN>(f.acc_prev + (size_t)r * PA + P + 1);
-            if (!pend_fast) {
-                pend_bc1 = f.prev_meta->bc1;
-                pend_bc2 = f.prev_meta->bc2;
-            }
+            pend_bc1 = f.prev_meta->bc1;
+            pend_bc2 = f.prev_meta->bc2;
         };
         auto count_n = [&]() {
             long long nll = 0;
@@ -506,31 +455,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             for (int r = 0; r < D3P_ACC_R; ++r) nll += pend_n8[r];
             return (float)nll;
         };
-        d3p_logreg_model_view mv;
-        mv.obs_scale = a.obs_scale;
-        if (pend_fast) {
-            const int col = threadIdx.x;
-            if (col < P) {
-                load_n();
-                const float n = count_n();
-                const float factor = (n == 0.0f) ? 0.0f : Bf / n;  // svi.py:305
-                long long sll = 0;
-#pragma unroll
-                for (int r = 0; r < D3P_ACC_R; ++r) sll += pend_r8[r];
-                const float tot = (float)((double)sll * f.inv_sg);
-                const float g = (tot / Bf + pend_z * (f.dp_scale * (a.clip / n))) * a.obs_scale * factor;
-                float x = pend_x, m = pend_m, v = pend_v;
-                m = (1.0f - f.b1) * g + f.b1 * m;
-                v = (1.0f - f.b2) * g * g + f.b2 * v;
-                x = x - f.lr * (m / pend_bc1) / (sqrtf(v / pend_bc2) + f.adam_eps);
-                if (bid == 0) {  // one workgroup publishes the state
-                    f.params_out[col] = x;
-                    f.m_out[col] = m;
-                    f.v_out[col] = v;
-                }
-                pack_column(col, x);
-            }
-        } else {
+        {
             // Only the first PW waves (one per SIMD) run the prologue, CB columns per thread with all loads in
             // flight together; the other waves go straight to their row loads and eps generation, so the
             // prologue's memory latency hides behind their VALU work.  Flush launches use every wave.
@@ -685,10 +610,10 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
     // the 4 waves (one per SIMD) that apply the pending update in finish_prologue()  (s_setprio on them was measured to
     // change nothing: the SIMD shares its issue slots evenly whatever the priority)
     const bool prologue_wave = FUSE && !a.fuse.flush_only && a.fuse.apply_prev && wave < 4;
-    // (Chained form, measured per workgroup with D3P_DBG=32: wait for the release 1.8 us, prologue 3.2 us, the prologue
-    // waves' own noise 2.4 us, dot / gradient / reduction 2.0 us, atomics + arrival 2.15 us.  Generating every wave's noise
-    // BEFORE the prologue does not help: the index -> row / key load chain issued at entry is hidden behind the prologue in
-    // this order and exposed in the other one: 12.2 -> 18.4 us per step.)
+    // (16-wave chained form, D3P_DBG=32 stamps: release seen 1.8 us after entry, prologue 3.2 us, staging barrier passed
+    // 2.4-3.5 us later -- it waits for the 12 other waves, whose noise generation starts behind their index -> key load chain --
+    // then dot / gradient / reduction 2.0 us, atomics + arrival 2.15 us.  Generating every wave's noise BEFORE the prologue
+    // inside ONE workgroup does not help (12.2 -> 18.4 us per step); starting it a whole step earlier does: `pregen` below.)
     const bool gauss = !FULL && a.family == D3P_FAMILY_GAUSS_MEAN;
     int c0[NC], c1[NC];
     bool ok0[NC], ok1[NC];
@@ -806,7 +731,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         if (cur.live) gen(cur.k0, cur.k1, er);
         if (have_pre && pre.live) gen(pre.k0, pre.k1, er + D);
     }
-    if (FUSE && (a.fuse.flush_only || !kLatePrologue)) {
+    if (FUSE) {
         finish_prologue();
         D3P_STAMP(2)
         if (a.fuse.flush_only) return;
