@@ -624,15 +624,15 @@ static int enqueue_main(const Ctx& c, int t, const float* X, const float* y, con
     a.dbg = dev_dbg_flags();
     if (c.g.wide) {  // wide rows: column-chunked kernel, same partial-row output
         static const bool attr_set = [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_logreg_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_logreg_wide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipGetLastError();
             return true;
         }();
         (void)attr_set;
         if (e0)
-            hipExtLaunchKernelGGL(k_logreg_wide, dim3(c.g.blocks), dim3(64 * D3P_WIDE_W), c.g.lds, c.s, e0, e1, 0, a);
+            hipExtLaunchKernelGGL(k_logreg_wide<false>, dim3(c.g.blocks), dim3(64 * D3P_WIDE_W), c.g.lds, c.s, e0, e1, 0, a);
         else
-            hipLaunchKernelGGL(k_logreg_wide, dim3(c.g.blocks), dim3(64 * D3P_WIDE_W), c.g.lds, c.s, a);
+            hipLaunchKernelGGL(k_logreg_wide<false>, dim3(c.g.blocks), dim3(64 * D3P_WIDE_W), c.g.lds, c.s, a);
         return check_launch("k_logreg_wide");
     }
     return launch_main<0>(c.s, c.g, a, e0, e1);

@@ -986,6 +986,10 @@ struct MainGeom {
 static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g, bool allow_wide = true)
 {
     const int D = m->d + (m->intercept ? 1 : 0), half = (D + 1) / 2, P = 2 * D;
+    // V = 4: a lane owns 4 adjacent columns of each half and fetches them with 16-byte loads -- needs both halves of a row
+    // 16-byte aligned.  (Measured: extending it to rows whose second half is not -- odd halves, the intercept column -- with
+    // scalar second-half loads gains little there (d = 512 + intercept 32 -> 29 us/step) and costs the aligned shapes 2 us
+    // of extra spills (d = 256: 14.0 -> 16.1), so those shapes stay on the scalar-load form.)
     const bool vec = !m->intercept && (m->d % 8 == 0);
     g->V = vec ? 4 : 1;
     const int need = (half + 64 * g->V - 1) / (64 * g->V);
@@ -999,7 +1003,8 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g, boo
     if (g->NK == 0 && !wide_ok)
         return fail(D3P_E_UNSUPPORTED, "logreg kernel: latent dimension %d exceeds the supported maximum (%d)", D,
                     2 * 64 * g->V * 8);
-    if (g->NK == 0 && wide_ok) g->NK = 8;  // placeholder: only the chunked kernel is launched with this geometry
+    const bool too_wide = g->NK == 0;
+    if (too_wide && wide_ok) g->NK = 8;  // placeholder: only the chunked kernel is launched with this geometry
     // waves per workgroup (default 16 = one 1024-thread workgroup per CU at 4 waves/SIMD), reduced until
     // pack (5D) + reduction buffer (W x P) fit 64 KiB of LDS; one example per wave per pass.
     int W = g->NK == 1 ? 16 : g->NK == 2 ? 8 : 4, epw = 1;
@@ -1027,7 +1032,8 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g, boo
         if (env_epw >= 1 && env_epw <= 64) epw = env_epw;
     }
     auto lds_bytes = [&](int w) { return (size_t)(((5 * D + 3) & ~3) + w * P + 2 * w) * sizeof(float); };
-    g->wide = wide_ok && g->NK == 8;  // accumulator rows only (the derived columns are read from the global pack): 4 waves
+    // (the scalar-load V = 1, NK = 8 form does not spill and beats the chunked kernel: d = 512 + intercept 32 vs 94 us/step)
+    g->wide = wide_ok && (too_wide || (g->V == 4 && g->NK == 8));  // accumulator rows only (derived columns come from the global pack): 4 waves
     if (!g->wide) {
         while (W > 1 && lds_bytes(W) > 96 * 1024) W >>= 1;
         if (lds_bytes(W) > 160 * 1024)

@@ -18,6 +18,9 @@ namespace d3p {
 
 static inline size_t wide_lds_bytes(int P) { return (size_t)(D3P_WIDE_W * P + 2 * D3P_WIDE_W) * sizeof(float); }
 
+// PXG: the materialising stage instead (MODE 1 of k_logreg_main, d3p_logreg_px_grads): pass 1, then one pass that writes
+// the example's unclipped gradient row and loss (zeros for masked-out positions); no accumulator rows, no partial rows.
+template <bool PXG>
 __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -27,8 +30,10 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
     const int D = a.D, half = a.half, P = 2 * D, d = a.d;
     float* acc = lds;                 // W x P
     float* tail = lds + (size_t)W * P;
-    for (int i = threadIdx.x; i < W * P; i += blockDim.x) acc[i] = 0.f;
-    __syncthreads();
+    if (!PXG) {
+        for (int i = threadIdx.x; i < W * P; i += blockDim.x) acc[i] = 0.f;
+        __syncthreads();
+    }
     float* mine = acc + (size_t)wave * P;
     const float* pk = a.pack;         // [loc | s | sg | q | lc] x D
     const bool eps_from_mem = a.eps_ext != nullptr;
@@ -45,7 +50,14 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
         const uint32_t row_g = a.idx ? a.idx[pp] : pp;
         const bool valid = (pp < n_valid) && (a.mask ? a.mask[pp] != 0 : true);
         const bool own = (uint64_t)row_g >= a.row_lo && (uint64_t)row_g < a.row_hi;
-        if (!(valid && own)) continue;  // wave-uniform
+        if (!(valid && own)) {  // wave-uniform
+            if (PXG) {  // loss * mask => zero loss and gradient (svi.py:281)
+                float* gr = a.px_grads + (size_t)pp * P;
+                for (int c = lane; c < P; c += 64) gr[c] = 0.f;
+                if (lane == 0) a.px_loss[pp] = 0.f;
+            }
+            continue;
+        }
         const size_t row = (size_t)((uint64_t)row_g - a.row_lo);
         const float* xrow = a.X + row * (size_t)d;
         const float yv = a.y ? a.y[row] : 0.f;
@@ -145,6 +157,31 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
         const float loglik = yv * t - softplus_f(t);
         const float L = a.inv_obs * (lp - a.lik_scale * loglik);  // svi.py:278-281
 
+        if (PXG) {
+            // ---- the example's gradient row as it is (svi.py:291-306; clipping is a later stage)
+            float* gr = a.px_grads + (size_t)pp * P;
+            for (int cb = 0; cb < half; cb += 256) {
+                float x0[4], x1[4], e0[4], e1[4], z0[4], z1[4];
+                bool ok0[4], ok1[4];
+                chunk(cb, x0, x1, e0, e1, z0, z1, ok0, ok1);
+                float sgv0[4], sgv1[4], qv0[4], qv1[4];
+                pk4(2, cb, sgv0, sgv1);
+                pk4(3, cb, qv0, qv1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c0 = cb + 4 * lane + i, c1 = c0 + half;
+                    const float sg0 = ok0[i] ? sgv0[i] : 0.f, sg1 = ok1[i] ? sgv1[i] : 0.f;
+                    const float q0 = ok0[i] ? qv0[i] : 0.f, q1 = ok1[i] ? qv1[i] : 0.f;
+                    const float g0 = __fmaf_rn(col_c1(c0), z0[i], A * x0[i]), g1 = __fmaf_rn(col_c1(c1), z1[i], A * x1[i]);
+                    const float h0 = __fmaf_rn(g0 * e0[i], sg0, -q0), h1 = __fmaf_rn(g1 * e1[i], sg1, -q1);
+                    if (ok0[i]) { gr[c0] = g0; gr[D + c0] = h0; }
+                    if (ok1[i]) { gr[c1] = g1; gr[D + c1] = h1; }
+                }
+            }
+            if (lane == 0) a.px_loss[pp] = L * a.obs_scale * a.meta[1];  // svi.py:306
+            continue;
+        }
+
         // ---- pass 2: squared joint norm of the example's gradient
         float n2 = 0.f;
         for (int cb = 0; cb < half; cb += 256) {
@@ -193,6 +230,7 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
         n_acc += 1.0f;
     }
 
+    if (PXG) return;
     if (lane == 0) { tail[2 * wave] = loss_acc; tail[2 * wave + 1] = n_acc; }
     __syncthreads();
     float* out = a.partials + (size_t)blockIdx.x * (P + 2);

@@ -1,6 +1,7 @@
 // Stage-level DP-VI API on materialised tensors (the five stages the reference's tests call
 // directly), optimiser steps and the synthetic-table generator.
 #include "d3p_logreg_kernel.h"
+#include "d3p_logreg_wide.h"
 
 namespace d3p {
 
@@ -396,7 +397,7 @@ int d3p_logreg_px_grads(void* stream, const d3p_logreg_model* model, const float
     float* pack = (float*)workspace_dev;
     uint32_t* skeys = (uint32_t*)((char*)workspace_dev + align_up(5 * (size_t)D * sizeof(float), 256));
     MainGeom g;
-    int rc = main_geometry(model, B, &g, false);
+    int rc = main_geometry(model, B, &g);  // (rows too wide for the register-tiled kernel: the column-chunked one)
     if (rc) return rc;
     hipLaunchKernelGGL(k_pack, dim3(cdiv(D, 256)), dim3(256), 0, s, *model, params_dev, pack);
     hipLaunchKernelGGL(k_mask_meta, dim3(1), dim3(256), 0, s, mask_dev, B, meta_dev);
@@ -417,6 +418,10 @@ int d3p_logreg_px_grads(void* stream, const d3p_logreg_model* model, const float
     a.row_lo = 0;
     a.row_hi = B;
     a.clip = 1.0f;
+    if (g.wide) {
+        hipLaunchKernelGGL(k_logreg_wide<true>, dim3(g.blocks), dim3(64 * D3P_WIDE_W), 0, s, a);
+        return check_launch("k_logreg_wide");
+    }
     return launch_main<1>(s, g, a);
 }
 

@@ -64,7 +64,14 @@ def state_with(svi, key, loc, unc):
 
 # --------------------------------------------------------------------------- stage 1 vs oracle
 @pytest.mark.parametrize("B,d,icpt", [(7, 8, False), (13, 5, True), (64, 512, False), (33, 520, False),
-                                      (9, 130, True), (5, 1024, False), (3, 1, False), (4, 1, True), (6, 2048, False)])
+                                      (9, 130, True), (5, 1024, False), (3, 1, False), (4, 1, True), (6, 2048, False),
+                                      # rows whose second half is not 16-byte aligned (odd half / intercept column):
+                                      # the scalar-load form with up to 8 column pairs per lane; (20, 512, True) is
+                                      # examples/logistic_regression.py's shape
+                                      (20, 512, True), (11, 128, True), (10, 300, False), (9, 132, False),
+                                      # rows too wide for the register-tiled kernel: the column-chunked kernel's
+                                      # materialising form
+                                      (6, 1024, True), (5, 3000, True), (4, 4096, False)])
 @pytest.mark.parametrize("onchip", [False, True])
 def test_px_grads_vs_oracle(rng, O, B, d, icpt, onchip):
     N = 1000
@@ -243,6 +250,7 @@ def test_constructor_validation(gpu):
 # --------------------------------------------------------------------------- fused update vs oracle
 @pytest.mark.parametrize("B,d,icpt,masked", [(16, 8, False, False), (16, 8, True, True), (50, 512, False, True),
                                              (256, 512, False, False), (37, 100, True, True), (8, 1024, False, False),
+                                             (70, 512, True, True), (40, 300, False, False), (33, 128, True, False),
                                              # wide rows: the column-chunked kernel of d3p_logreg_wide.h (2048 < d <= 4096)
                                              (21, 3000, True, True), (12, 4096, False, False)])
 @pytest.mark.parametrize("onchip", [False, True])
