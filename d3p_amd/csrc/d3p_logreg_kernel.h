@@ -293,6 +293,7 @@ struct ExLoad {
     float x0[NC], x1[NC];
     float e0[NC], e1[NC];  // guide noise when it is read from memory (issued with the row loads)
     float y;
+    float xt, et;     // TAIL: feature / stored noise of the tail column (see k_logreg_main)
     uint32_t k0, k1;  // threefry sample key
     bool live;        // valid && held by this rank
 };
@@ -303,7 +304,12 @@ struct ExLoad {
 // NK == 1 (d <= 512): 1024-thread workgroups (<= 128 VGPRs); wider rows keep more columns per lane in registers,
 // so NK == 2 is built for 512-thread workgroups (<= 256 VGPRs, at most 8 waves) and NK >= 4 for 256-thread workgroups
 // (one wave per SIMD: the whole 512-entry register file, AGPRs included, instead of scratch).
-template <int V, int NK, int MODE, bool FULL, int EPS>
+// TAIL (with FULL): a full tile of features PLUS the intercept column, D = 2 * 64 * V * NK + 1 -- the shape of
+// examples/logistic_regression.py.  half = 64 * V * NK + 1 is odd: lane pairs (c, c + half), c < half - 1, cover columns
+// 0 .. half - 2 and half .. D - 1 (the last one is the intercept); the second-half features are not 16-byte aligned and
+// come through scalar loads.  The left-over pair (half - 1, -) is the "tail column": every lane computes it redundantly
+// (one more threefry call per example) and lane 0 owns its accumulators.
+template <int V, int NK, int MODE, bool FULL, int EPS, bool TAIL = false>
 __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg_main(MainArgs a_in)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -632,6 +638,8 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
 #pragma unroll
     for (int n = 0; n < NC; ++n) accg0[n] = acch0[n] = accg1[n] = acch1[n] = 0.f;
     float loss_acc = 0.f, n_acc = 0.f;
+    float acc_gt = 0.f, acc_ht = 0.f;  // TAIL: the tail column's two accumulators (identical in every lane)
+    const int ct = half - 1;           // TAIL: the tail column
     const uint32_t n_valid = a.counts ? a.counts[1] : a.B;
 
     // issue every global load of example p (index -> row -> features, label, sample key)
@@ -642,6 +650,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         L.live = valid && mine;
         L.k0 = L.k1 = 0u;
         L.y = 0.f;
+        L.xt = L.et = 0.f;
 #pragma unroll
         for (int n = 0; n < NC; ++n) L.x0[n] = L.x1[n] = L.e0[n] = L.e1[n] = 0.f;
         if (!L.live && MODE != 1) return;
@@ -654,9 +663,14 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                 const int n = k * 4;
                 float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
                 if (ok0[n]) v0 = *reinterpret_cast<const float4*>(xrow + c0[n]);
-                if (ok1[n]) v1 = *reinterpret_cast<const float4*>(xrow + c1[n]);
                 L.x0[n] = v0.x; L.x0[n + 1] = v0.y; L.x0[n + 2] = v0.z; L.x0[n + 3] = v0.w;
-                L.x1[n] = v1.x; L.x1[n + 1] = v1.y; L.x1[n + 2] = v1.z; L.x1[n + 3] = v1.w;
+                if (TAIL) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) L.x1[n + i] = c1[n + i] < a.d ? xrow[c1[n + i]] : 1.0f;  // column d = intercept
+                } else {
+                    if (ok1[n]) v1 = *reinterpret_cast<const float4*>(xrow + c1[n]);
+                    L.x1[n] = v1.x; L.x1[n + 1] = v1.y; L.x1[n + 2] = v1.z; L.x1[n + 3] = v1.w;
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
@@ -667,14 +681,16 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             }
         }
         L.y = a.y ? a.y[row] : 0.f;
+        if (TAIL) L.xt = xrow[half - 1];
         if (!eps_from_mem) {
             L.k0 = a.skeys[2 * p];
             L.k1 = a.skeys[2 * p + 1];
         } else {
             const float* er = a.eps_ext + (size_t)p * D;
+            if (TAIL) L.et = er[half - 1];
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
-                if (V == 4) {
+                if (V == 4 && !TAIL) {  // (TAIL: rows of D = odd floats are not 16-byte aligned)
                     const int n = k * 4;
                     float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
                     if (ok0[n]) v0 = *reinterpret_cast<const float4*>(er + c0[n]);
@@ -705,7 +721,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
     // still in its exchange).  Every wave -- the prologue waves too -- generates the noise of its first TWO examples into
     // its own (still unused) row of the reduction buffer BEFORE waiting for the previous step's release, so between that
     // release and this workgroup's arrival there is only the prologue, the gradient arithmetic and the exchange.
-    const bool pregen = CHAIN && FULL && V == 4 && NK == 1 && !eps_from_mem && a.chain.pregen && !a.fuse.flush_only && !(a.dbg & 1);
+    const bool pregen = CHAIN && FULL && !TAIL && V == 4 && NK == 1 && !eps_from_mem && a.chain.pregen && !a.fuse.flush_only && !(a.dbg & 1);
     int it = 0;  // examples this wave has gone through
     ExLoad<NC> pre;         // second example, loaded ahead of the prologue as well (its index -> row chain would otherwise sit
     bool have_pre = false;  // between the release and the first gradient)
@@ -782,6 +798,16 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                 }
             }
 
+            float et = 0.f;
+            if (TAIL) {
+                if (eps_from_mem) {
+                    et = cur.et;
+                } else {
+                    uint32_t b0, b1;
+                    threefry2x32(cur.k0, cur.k1, (uint32_t)ct, 0u, b0, b1);
+                    et = bits_to_normal_wu(b0);
+                }
+            }
             D3P_STAMP(3)
             if (!staged) { finish_prologue(); __syncthreads(); staged = true; }
             // ---- z = loc + s * eps, logit t = x . z   (derived columns come from LDS)
@@ -803,7 +829,12 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                     tp = __fmaf_rn(cur.x1[n], z1[n], tp);
                 }
             }
-            const float t = wave_sum(tp);  // logit x.z, or the squared residual norm
+            float t = wave_sum(tp);  // logit x.z, or the squared residual norm
+            float zt = 0.f;
+            if (TAIL) {
+                zt = __fmaf_rn(pk[D + ct], et, pk[ct]);
+                t = __fmaf_rn(cur.xt, zt, t);
+            }
             D3P_STAMP(4)
             // A = d(-lik_scale * inv_obs * loglik)/dt up to the per-column factor; loglik itself
             float A, loglik;
@@ -820,7 +851,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             float n2 = 0.f, lp = 0.f;
 #pragma unroll
             for (int n = 0; n < NC; ++n) {
-                const bool ic0 = !FULL && a.icpt && (c0[n] == a.d), ic1 = !FULL && a.icpt && (c1[n] == a.d);
+                const bool ic0 = !FULL && a.icpt && (c0[n] == a.d), ic1 = (!FULL || TAIL) && a.icpt && (c1[n] == a.d);
                 const float sg0 = ok0[n] ? pk[2 * D + c0[n]] : 0.f, sg1 = ok1[n] ? pk[2 * D + c1[n]] : 0.f;
                 const float q0 = ok0[n] ? pk[3 * D + c0[n]] : 0.f, q1 = ok1[n] ? pk[3 * D + c1[n]] : 0.f;
                 const float lc0 = ok0[n] ? pk[4 * D + c0[n]] : 0.f, lc1 = ok1[n] ? pk[4 * D + c1[n]] : 0.f;
@@ -837,6 +868,13 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             }
             n2 = wave_sum(n2);
             lp = wave_sum(lp);
+            float gt = 0.f, ht = 0.f;
+            if (TAIL) {  // the tail column is a feature column (prior of the weights)
+                gt = __fmaf_rn(a.c1_w, zt, A * cur.xt);
+                ht = __fmaf_rn(gt * et, pk[2 * D + ct], -pk[3 * D + ct]);
+                n2 = __fmaf_rn(gt, gt, __fmaf_rn(ht, ht, n2));
+                lp += __fmaf_rn(a.hz_w * zt, zt, __fmaf_rn(-0.5f * et, et, pk[4 * D + ct]));
+            }
             // L_i = inv_obs * ((logq - logp) - lik_scale * loglik)   (svi.py:278-281)
             const float L = a.inv_obs * (lp - a.lik_scale * loglik);
 
@@ -850,6 +888,10 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                     acch0[n] = __fmaf_rn(cf, h0[n], acch0[n]);
                     accg1[n] = __fmaf_rn(cf, g1[n], accg1[n]);
                     acch1[n] = __fmaf_rn(cf, h1[n], acch1[n]);
+                }
+                if (TAIL) {
+                    acc_gt = __fmaf_rn(cf, gt, acc_gt);
+                    acc_ht = __fmaf_rn(cf, ht, acc_ht);
                 }
                 loss_acc += L;
                 n_acc += 1.0f;
@@ -879,6 +921,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             if (ok0[n]) { mine[c0[n]] = accg0[n]; mine[D + c0[n]] = acch0[n]; }
             if (ok1[n]) { mine[c1[n]] = accg1[n]; mine[D + c1[n]] = acch1[n]; }
         }
+        if (TAIL && lane == 0) { mine[ct] = acc_gt; mine[D + ct] = acc_ht; }
         float* tail = red + (size_t)W * P;
         if (lane == 0) { tail[2 * wave] = loss_acc; tail[2 * wave + 1] = n_acc; }
         __syncthreads();
@@ -976,6 +1019,7 @@ __device__ __forceinline__ float block_sum_column(const float* __restrict__ part
 struct MainGeom {
     int V, NK, W;
     bool full;
+    bool tail;  // full tile of features + the intercept column (k_logreg_main's TAIL form)
     bool wide;  // 2048 < d <= 4096, logistic regression: the column-chunked kernel of d3p_logreg_wide.h (two-kernel steps)
     uint32_t blocks;
     size_t lds;
@@ -983,7 +1027,8 @@ struct MainGeom {
 
 // allow_wide: the caller launches the clip-and-accumulate stage (MODE 0) and may be given the column-chunked geometry; the
 // materialising stage (MODE 1) always uses the register-tiled kernel
-static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g, bool allow_wide = true)
+// allow_tail: the caller launches a stage that has the TAIL form (MODE 0 / 2 / 3; the materialising stage has not)
+static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g, bool allow_wide = true, bool allow_tail = true)
 {
     const int D = m->d + (m->intercept ? 1 : 0), half = (D + 1) / 2, P = 2 * D;
     // V = 4: a lane owns 4 adjacent columns of each half and fetches them with 16-byte loads -- needs both halves of a row
@@ -995,6 +1040,14 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g, boo
     const int need = (half + 64 * g->V - 1) / (64 * g->V);
     g->NK = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 0;
     g->full = vec && g->NK > 0 && (D == 2 * 64 * g->V * g->NK) && m->family == D3P_FAMILY_LOGREG;
+    // full tile of features + intercept column (d = 512 or 1024 with an intercept: examples/logistic_regression.py)
+    static const bool no_tail = getenv("D3P_NO_TAIL_TILE") != nullptr;  // developer switch: the scalar-load form instead
+    g->tail = allow_tail && !no_tail && m->intercept && (m->d == 512 || m->d == 1024) && m->family == D3P_FAMILY_LOGREG;
+    if (g->tail) {
+        g->V = 4;
+        g->NK = m->d / 512;
+        g->full = true;
+    }
     // rows too wide for the register-tiled kernel (NK == 0), or its spilling NK == 8 form: the column-chunked kernel of
     // d3p_logreg_wide.h takes them when the caller runs the clip-and-accumulate stage of a logistic-regression model and its
     // 4 accumulator rows fit the LDS
@@ -1063,6 +1116,23 @@ static int launch_main(hipStream_t s, const MainGeom& g, const MainArgs& a, hipE
         hipLaunchKernelGGL((k_logreg_main<V_, NK_, MODE, F_, E_>), dim3(g.blocks), dim3(64 * g.W), g.lds, s, a);          \
     return check_launch("k_logreg_main")
 #define D3P_LAUNCH(V_, NK_) D3P_LAUNCH_F(V_, NK_, false, -1)
+#define D3P_LAUNCH_T(NK_, E_)                                                                                               \
+    if (e0)                                                                                                               \
+        hipExtLaunchKernelGGL((k_logreg_main<4, NK_, MODE, true, E_, true>), dim3(g.blocks), dim3(64 * g.W), g.lds, s, e0,  \
+                              e1, 0, a);                                                                                  \
+    else                                                                                                                  \
+        hipLaunchKernelGGL((k_logreg_main<4, NK_, MODE, true, E_, true>), dim3(g.blocks), dim3(64 * g.W), g.lds, s, a);     \
+    return check_launch("k_logreg_main")
+    if (g.tail) {
+        if (MODE == 1) return fail(D3P_E_UNSUPPORTED, "logreg kernel: the materialising stage has no tail-column form");
+        if (MODE != 1) {
+            if (a.eps_ext) {
+                if (g.NK == 1) { D3P_LAUNCH_T(1, 1); } else { D3P_LAUNCH_T(2, 1); }
+            } else {
+                if (g.NK == 1) { D3P_LAUNCH_T(1, 0); } else { D3P_LAUNCH_T(2, 0); }
+            }
+        }
+    }
     if (g.V == 4 && g.full && MODE != 1) {
         if (a.eps_ext) {
             switch (g.NK) {
@@ -1094,6 +1164,7 @@ static int launch_main(hipStream_t s, const MainGeom& g, const MainArgs& a, hipE
         }
     }
 #undef D3P_LAUNCH_F
+#undef D3P_LAUNCH_T
 #undef D3P_LAUNCH
 }
 

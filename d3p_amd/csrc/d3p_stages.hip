@@ -397,7 +397,7 @@ int d3p_logreg_px_grads(void* stream, const d3p_logreg_model* model, const float
     float* pack = (float*)workspace_dev;
     uint32_t* skeys = (uint32_t*)((char*)workspace_dev + align_up(5 * (size_t)D * sizeof(float), 256));
     MainGeom g;
-    int rc = main_geometry(model, B, &g);  // (rows too wide for the register-tiled kernel: the column-chunked one)
+    int rc = main_geometry(model, B, &g, true, false);  // (rows too wide for the register-tiled kernel: the column-chunked one)
     if (rc) return rc;
     hipLaunchKernelGGL(k_pack, dim3(cdiv(D, 256)), dim3(256), 0, s, *model, params_dev, pack);
     hipLaunchKernelGGL(k_mask_meta, dim3(1), dim3(256), 0, s, mask_dev, B, meta_dev);

@@ -638,3 +638,54 @@ def test_wide_rows_run_steps_matches_stepwise_updates(rng):
         ref_losses.append(float(l))
     np.testing.assert_allclose(np_(runs[0][1]), ref_losses, rtol=2e-5)
     np.testing.assert_allclose(np_(runs[0][0].optim_state[1]), np_(ref.optim_state[1]), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("d", [512, 1024])
+def test_intercept_tile_run_steps_matches_stepwise_updates_and_scalar_form(rng, d):
+    """d = 512 / 1024 WITH an intercept (examples/logistic_regression.py:49-66): k_logreg_main's TAIL form -- a full tile of
+    features, the intercept as the last second-half column, the left-over middle column computed by every lane.  The chained
+    device-resident loop (40 steps: two launches) and one update() per step walk the same trajectory, reproducibly; a child
+    process with D3P_NO_TAIL_TILE=1 (the scalar-load form, other summation order) agrees to fp32 rounding."""
+    import subprocess
+    import sys
+    import tempfile
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, B, steps = 6000, 700, 40
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(N, d, generator=g).cuda()
+    y = (torch.rand(N, generator=g) < 0.5).float().cuda()
+    svi = make_svi(d, True, N, C=1.0, sigma=0.4, lr=2e-2)
+    st = state_with(svi, rng.PRNGKey(31), np.zeros(d + 1, np.float32), np.full(d + 1, -1.5, np.float32))
+    init, get_batch = subsample_batchify_data((X, y), B)
+    _, bstate = init(rng.PRNGKey(32))
+    runs = [svi.run_steps(st, get_batch, bstate, 0, steps) for _ in range(2)]
+    assert torch.equal(runs[0][0].optim_state[1], runs[1][0].optim_state[1]) and torch.equal(runs[0][1], runs[1][1])
+    ref, ref_losses = st, []
+    for t in range(steps):
+        ref, l = svi.update(ref, *get_batch(t, bstate))
+        ref_losses.append(float(l))
+    np.testing.assert_allclose(np_(runs[0][1]), ref_losses, rtol=2e-5)
+    np.testing.assert_allclose(np_(runs[0][0].optim_state[1]), np_(ref.optim_state[1]), rtol=1e-5, atol=2e-6)
+    code = r'''
+import sys, torch, numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import d3p_amd.random as rng
+from d3p_amd.minibatch import subsample_batchify_data
+from test_gpu_dpsvi import make_svi, state_with
+d = int(sys.argv[2]); N, B, steps = 6000, 700, 40
+g = torch.Generator().manual_seed(5)
+X = torch.randn(N, d, generator=g).cuda(); y = (torch.rand(N, generator=g) < 0.5).float().cuda()
+svi = make_svi(d, True, N, C=1.0, sigma=0.4, lr=2e-2)
+st = state_with(svi, rng.PRNGKey(31), np.zeros(d + 1, np.float32), np.full(d + 1, -1.5, np.float32))
+init, get_batch = subsample_batchify_data((X, y), B)
+_, bstate = init(rng.PRNGKey(32))
+s2, losses = svi.run_steps(st, get_batch, bstate, 0, steps)
+np.save(sys.argv[1], np.concatenate([losses.cpu().numpy(), s2.optim_state[1].cpu().numpy()]))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.NamedTemporaryFile(suffix=".npy") as f:
+        subprocess.run([sys.executable, "-c", code, f.name, str(d)], check=True, env=dict(os.environ, D3P_NO_TAIL_TILE="1"),
+                       timeout=300)
+        other = np.load(f.name)
+    np.testing.assert_allclose(other[:steps], np_(runs[0][1]), rtol=2e-5)
+    np.testing.assert_allclose(other[steps:], np_(runs[0][0].optim_state[1]), rtol=1e-4, atol=5e-6)
