@@ -1004,8 +1004,9 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     int g = 0;
     const bool chained = !comm && use_chained_steps(c);
     const bool persist = chained && use_persistent_steps(c);
-    if (chained)  // the abort flag of the bounded waits: cleared once per run, read back by d3p_dpvi_logreg_chain_status
-        D3P_HIP_TRY(hipMemsetAsync(c.ws.chain_bar + (size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS, 0, 16 * sizeof(uint32_t), c.s));
+    // the abort flag of the bounded waits: cleared once per run (whatever form the steps take), read back by
+    // d3p_dpvi_logreg_chain_status
+    D3P_HIP_TRY(hipMemsetAsync(c.ws.chain_bar + (size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS, 0, 16 * sizeof(uint32_t), c.s));
     for (uint32_t b = 0; b < n_batches; ++b) {
         const int cur = (int)(b & 1), nxt = cur ^ 1;
         const int K = batch_len(b), K_next = (b + 1 < n_batches) ? batch_len(b + 1) : 0;
