@@ -199,7 +199,7 @@ def main():
                 traffic = None
         chained = world == 1 and not args.force_dist_loop and not os.environ.get("D3P_NO_CHAINED_STEPS")
         roofline = {"bound": "hbm",
-                    "kernel": ("k_logreg_main<MODE 3> (chained launch: the <= 32 DP-VI steps of a prepared batch per launch)" if chained
+                    "kernel": ("k_logreg_main<MODE 3> (chained launch: the <= 128 DP-VI steps of a prepared batch per launch)" if chained
                                else "k_logreg_main<MODE 2> (one launch per DP-VI step)"),
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,

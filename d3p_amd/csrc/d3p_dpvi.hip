@@ -25,7 +25,9 @@
 #include <vector>
 #include <rccl/rccl.h>  // types only: the entry points are resolved at run time from the RCCL torch has loaded
 
-#define D3P_STEP_BATCH 32
+// steps prepared (key chain, sampler, noise) and chained into one launch at a time: measured 32 / 64 / 128 ->
+// 87.4 / 89.4 / 91.5 k steps/s on the headline config (fewer launch boundaries and sampler launches per step)
+#define D3P_STEP_BATCH 128
 
 namespace d3p {
 
@@ -873,7 +875,7 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
             hipLaunchKernelGGL(k_logreg_persist<true>, dim3(c.g.blocks), dim3(64 * D3P_PERSIST_W), persist_lds_bytes(), c.s, a);
             int rc = check_launch("k_logreg_persist");
             if (rc) return rc;
-            static unsigned long long host[4 * 32 * 16];
+            static unsigned long long host[4 * 32 * 16];  // (the kernel stamps the first 32 steps of a launch)
             D3P_HIP_TRY(hipMemcpyAsync(host, c.ws.stamps, sizeof(host), hipMemcpyDeviceToHost, c.s));
             D3P_HIP_TRY(hipStreamSynchronize(c.s));
             static int printed = 0;
@@ -1145,7 +1147,7 @@ int d3p_dpvi_logreg_prepare(void* stream, const d3p_logreg_model* model, const d
     Ctx c;
     int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
     if (rc) return rc;
-    D3P_REQUIRE(num_steps >= 1 && num_steps <= D3P_STEP_BATCH, "d3p_dpvi_logreg_prepare: 1 <= num_steps <= 32");
+    D3P_REQUIRE(num_steps >= 1 && num_steps <= D3P_STEP_BATCH, "d3p_dpvi_logreg_prepare: 1 <= num_steps <= 128");
     return enqueue_batch_prep(c, (int)num_steps);
 }
 
@@ -1159,7 +1161,7 @@ int d3p_dpvi_logreg_step_sums(void* stream, const d3p_logreg_model* model, const
     if (rc) return rc;
     D3P_REQUIRE(X_dev && sums_dev, "null data pointer");
     if (int rcm = validate_model(model, y_dev, "d3p_dpvi_logreg")) return rcm;
-    D3P_REQUIRE(t < D3P_STEP_BATCH, "d3p_dpvi_logreg_step_sums: t must be < 32");
+    D3P_REQUIRE(t < D3P_STEP_BATCH, "d3p_dpvi_logreg_step_sums: t must be < 128");
     if ((rc = enqueue_main(c, (int)t, X_dev, y_dev, eps_dev, false))) return rc;
     hipLaunchKernelGGL(k_reduce_partials, dim3(cdiv(c.P + 2, 64)), dim3(64 * D3P_FIN_W), 0, c.s,
                        (const float*)c.ws.partials, c.g.blocks, (uint32_t)(c.P + 2), sums_dev);
@@ -1175,7 +1177,7 @@ int d3p_dpvi_logreg_step_finalize(void* stream, const d3p_logreg_model* model, c
     int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
     if (rc) return rc;
     D3P_REQUIRE(sums_dev, "null sums pointer");
-    D3P_REQUIRE(t < D3P_STEP_BATCH, "d3p_dpvi_logreg_step_finalize: t must be < 32");
+    D3P_REQUIRE(t < D3P_STEP_BATCH, "d3p_dpvi_logreg_step_finalize: t must be < 128");
     return enqueue_finalize(c, (int)t, sums_dev, 1u, loss_dev, grad_out_dev);
 }
 
@@ -1198,7 +1200,7 @@ int d3p_dpvi_logreg_prepare_buf(void* stream, const d3p_logreg_model* model, con
     Ctx c;
     int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
     if (rc) return rc;
-    D3P_REQUIRE(num_steps >= 1 && num_steps <= D3P_STEP_BATCH, "d3p_dpvi_logreg_prepare_buf: 1 <= num_steps <= 32");
+    D3P_REQUIRE(num_steps >= 1 && num_steps <= D3P_STEP_BATCH, "d3p_dpvi_logreg_prepare_buf: 1 <= num_steps <= 128");
     D3P_REQUIRE(buf == 0 || buf == 1, "d3p_dpvi_logreg_prepare_buf: buf must be 0 or 1");
     Ctx cb = c;
     if (buf) {
@@ -1246,7 +1248,7 @@ int d3p_dpvi_logreg_fused_step(void* stream, const d3p_logreg_model* model, cons
     D3P_REQUIRE(flush_only || X_dev, "null data pointer");
     if (!flush_only)
         if (int rcm = validate_model(model, y_dev, "d3p_dpvi_logreg_fused_step")) return rcm;
-    D3P_REQUIRE(t < D3P_STEP_BATCH && prev_t < D3P_STEP_BATCH, "slot index must be < 32");
+    D3P_REQUIRE(t < D3P_STEP_BATCH && prev_t < D3P_STEP_BATCH, "slot index must be < 128");
     Ctx cb[2] = {c, c};
     cb[1].ws = c.ws2;
     cb[1].ws.partials = c.ws.partials;

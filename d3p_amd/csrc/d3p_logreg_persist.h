@@ -1,4 +1,4 @@
-// Persistent form of the logistic-regression DP-VI step (MODE 4): the K <= 32 steps of a prepared batch run in ONE launch
+// Persistent form of the logistic-regression DP-VI step (MODE 4): the K <= 128 steps of a prepared batch run in ONE launch
 // of 256 RESIDENT workgroups (one per CU) that loop over the steps.  Wave w of workgroup b owns batch position 16 b + w in
 // every step.  The step of DPSVI.update (svi.py:395-434) has two kinds of work:
 //
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(64 * D3P_PERSIST_W) k_logreg_persist(MainArgs 
     float* const adam_v = cf.state[0][2];
     const bool st_on = STAMPS && a.stamps && (bid % 85u == 0u) && (bid / 85u < 4u) && lane == 0 && (wave == 0 || wave == 5);
     int st_t = 0;
-#define D3P_PST(k) if (STAMPS && st_on) a.stamps[((size_t)(bid / 85u) * 32 + st_t) * 16 + (wave == 0 ? 0 : 8) + (k)] = wall_clock64();
+#define D3P_PST(k) if (STAMPS && st_on && st_t < 32) a.stamps[((size_t)(bid / 85u) * 32 + st_t) * 16 + (wave == 0 ? 0 : 8) + (k)] = wall_clock64();
 
     // ---- parameter-independent part of a step for this wave's example.  Index, validity and threefry key are fetched ONE
     // STEP AHEAD (PersistPre), so the row gather can be issued at once and the noise generation never waits on memory:

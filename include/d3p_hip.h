@@ -107,7 +107,7 @@ int d3p_poisson_select_rng(void* stream, int rng_kind, const uint32_t* key_dev, 
                            uint32_t cutoff, int suppress, uint32_t* out_idx_dev,
                            uint32_t* out_counts_dev, void* workspace_dev, size_t workspace_bytes);
 
-/* The same for `num_steps` independent draws in one set of launches (the fused run loop prepares 32 steps at
+/* The same for `num_steps` independent draws in one set of launches (the fused run loop prepares 128 steps at
  * once): step t uses the key at keys_dev + t * key_stride_words and writes out_idx_dev + t * idx_stride_words,
  * out_counts_dev + t * counts_stride_words; the workspace is num_steps x d3p_poisson_select_workspace(N). */
 int d3p_poisson_select_batch(void* stream, int rng_kind, const uint32_t* keys_dev, size_t key_stride_words,
@@ -297,7 +297,7 @@ int d3p_dpvi_logreg_finalize(void* stream, const d3p_logreg_model* model,
                              float* grad_out_dev, void* workspace_dev, size_t workspace_bytes);
 
 /* Stepwise form of the two phases for the data-parallel loop (d3p_amd/dist.py): the key schedule and
- * the sampler are evaluated for up to 32 steps at once (`prepare`), so that each step only launches
+ * the sampler are evaluated for up to 128 steps at once (`prepare`), so that each step only launches
  * the fused kernel + partial reduction (`step_sums`), and -- after the caller's sum-all-reduce of
  * sums_dev -- `step_finalize`.  `t` is the step index inside the prepared batch.
  *   begin -> { prepare(K) -> K x [ step_sums(t) -> all-reduce -> step_finalize(t) ] }* -> end(total steps)
@@ -391,7 +391,7 @@ int d3p_dpvi_gmm_apply(void* stream, const d3p_gmm_model* model, const d3p_dpsvi
                        float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
                        void* workspace_dev, size_t workspace_bytes);
 
-/* The single-GPU run loop executes the steps of a prepared batch (<= 32) as ONE launch whose workgroups wait on
+/* The single-GPU run loop executes the steps of a prepared batch (<= 128) as ONE launch whose workgroups wait on
  * arrival counters for the previous step (bounded waits).  This reads back, after synchronising `stream`, whether any
  * wait of the last run hit its bound (aborted_out != 0: the results of that run are invalid). */
 int d3p_dpvi_logreg_chain_status(void* stream, const d3p_logreg_model* model, const d3p_batch_source* src,

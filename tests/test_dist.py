@@ -243,7 +243,7 @@ def test_dist_run_steps_equals_svi_run_steps(gpu):
     from d3p_amd.minibatch import subsample_batchify_data
     from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
     from d3p_amd.svi import DPSVI, DPSVIState
-    n, d, Bg, steps = 4000, 512, 256, 40
+    n, d, Bg, steps = 4000, 512, 256, 140
     r = np.random.default_rng(2)
     X = torch.tensor(r.normal(size=(n, d)).astype(np.float32)).cuda()
     y = torch.tensor((r.random(n) < 0.5).astype(np.float32)).cuda()
@@ -253,7 +253,7 @@ def test_dist_run_steps_equals_svi_run_steps(gpu):
     st0 = DPSVIState(svi.optim.init(params), rng.PRNGKey(1), float(n))
     bkey = rng.PRNGKey(2)
     _, get_batch = subsample_batchify_data((X, y), Bg)
-    a_state, a_losses = svi.run_steps(st0, get_batch, bkey, 0, steps)       # batched key chain (32 + 8 steps)
+    a_state, a_losses = svi.run_steps(st0, get_batch, bkey, 0, steps)       # batched key chain (128 + 12 steps)
     eng = ddist.HipEngine(svi, X, y, n, 0, n, L.D3P_BATCH_FEISTEL, Bg)
     b_state, b_losses = ddist.run_steps(eng, st0, bkey, 0, steps)           # one step per call
     assert torch.equal(a_state.rng_key, b_state.rng_key)
@@ -273,7 +273,7 @@ def test_native_rccl_loop_on_one_rank_equals_the_single_gpu_run(gpu):
     from d3p_amd.minibatch import subsample_batchify_data
     from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
     from d3p_amd.svi import DPSVI, DPSVIState
-    N, d, B, steps = 20000, 512, 4096, 37
+    N, d, B, steps = 20000, 512, 4096, 137
     g = torch.Generator().manual_seed(0)
     X = torch.randn(N, d, generator=g).cuda()
     y = (torch.rand(N, generator=g) < 0.5).float().cuda()

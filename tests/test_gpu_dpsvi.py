@@ -483,7 +483,7 @@ def test_run_steps_with_more_workgroups_than_cus_matches_stepwise_updates(rng, B
 
 
 def test_chained_launch_matches_one_launch_per_step(rng):
-    """The default run loop executes the <= 32 steps of a prepared batch as ONE launch: resident workgroups that loop over
+    """The default run loop executes the <= 128 steps of a prepared batch as ONE launch: resident workgroups that loop over
     the steps (MODE 4, d = 512, D3P_PERSISTENT_STEPS=1) or one workgroup set per step waiting on arrival counters (MODE 3); D3P_NO_CHAINED_STEPS=1 (switches are read once per process, so checked in child
     processes) selects one launch per step.  All walk the same trajectory bit for bit -- the sums are exact integer sums
     in each -- when their workgroups hold the same examples; the default chained form is pipelined (8-wave workgroups, two
@@ -500,7 +500,7 @@ import d3p_amd.random as rng
 from d3p_amd.minibatch import subsample_batchify_data
 from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
 from d3p_amd.svi import DPSVI, DPSVIState
-N, d, B, steps = 50000, 512, 4096, 70
+N, d, B, steps = 50000, 512, 4096, 150
 g = torch.Generator().manual_seed(0)
 X = torch.randn(N, d, generator=g).cuda(); y = (torch.rand(N, generator=g) < 0.5).float().cuda()
 model = LogisticRegression(d)
@@ -522,9 +522,9 @@ np.save(sys.argv[1], np.concatenate([losses.cpu().numpy(), s2.optim_state[1].cpu
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert np.all(np.isfinite(outs[0]))
     # The pipelined form groups the examples differently into workgroups (two per wave), so its fp32 workgroup partials
-    # round differently: reproducible bit for bit run to run, and equal to the others to fp32 rounding over the 70 steps
+    # round differently: reproducible bit for bit run to run, and equal to the others to fp32 rounding over the 150 steps (two launches: 128 + 22)
     assert np.array_equal(outs[3], outs[4])
-    steps = 70
+    steps = 150
     np.testing.assert_allclose(outs[3][:steps], outs[0][:steps], rtol=2e-6)
     np.testing.assert_allclose(outs[3][steps:], outs[0][steps:], rtol=1e-4, atol=2e-6)
     # abort flag of the bounded waits after a run in this process (d = 512: persistent form; d = 64: chained form)
@@ -546,7 +546,7 @@ import d3p_amd.random as rng
 from d3p_amd.minibatch import poisson_batchify_data
 from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
 from d3p_amd.svi import DPSVI, DPSVIState
-N, d, steps = 60000, 512, 70
+N, d, steps = 60000, 512, 150
 g = torch.Generator().manual_seed(0)
 X = torch.randn(N, d, generator=g).cuda(); y = (torch.rand(N, generator=g) < 0.5).float().cuda()
 model = LogisticRegression(d)
@@ -563,8 +563,8 @@ np.save(sys.argv[1], np.concatenate([losses.cpu().numpy(), s2.optim_state[1].cpu
             outs.append(np.load(f.name))
     assert np.array_equal(outs[0], outs[1]) and np.all(np.isfinite(outs[0]))
     # default (pipelined) chained form: other grouping of the examples into workgroups => equal to fp32 rounding
-    np.testing.assert_allclose(outs[2][:70], outs[0][:70], rtol=2e-6)
-    np.testing.assert_allclose(outs[2][70:], outs[0][70:], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(outs[2][:150], outs[0][:150], rtol=2e-6)
+    np.testing.assert_allclose(outs[2][150:], outs[0][150:], rtol=1e-4, atol=2e-6)
 
 
 def _check_no_wait_hit_its_bound(rng, N, d, B):
@@ -594,7 +594,7 @@ def test_kernel_timing_hook_counts_launches_and_steps(rng):
     import d3p_amd._lib as L
     from d3p_amd.minibatch import subsample_batchify_data
     lib = L.load()
-    N, d, B, steps = 20000, 64, 1024, 70
+    N, d, B, steps = 20000, 64, 1024, 300
     X = torch.randn(N, d).cuda()
     y = (torch.rand(N) < 0.5).float().cuda()
     svi = make_svi(d, False, N)
@@ -612,7 +612,7 @@ def test_kernel_timing_hook_counts_launches_and_steps(rng):
         L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(0))
     L.check(lib.d3p_dpvi_logreg_kernel_timing_read(C.byref(us), C.byref(launches), C.byref(nsteps)))
     assert nsteps.value == steps
-    assert launches.value == 3                       # chained launches of 32 + 32 + 6 steps
+    assert launches.value == 3                       # chained launches of 128 + 128 + 44 steps
     assert 0.0 < us.value < 1e6 and us.value / steps > 1.0   # a step takes microseconds, not nanoseconds or seconds
     L.check(lib.d3p_dpvi_logreg_kernel_timing_read(C.byref(us), C.byref(launches), C.byref(nsteps)))
     assert (launches.value, nsteps.value) == (0, 0)
@@ -644,13 +644,13 @@ def test_wide_rows_run_steps_matches_stepwise_updates(rng):
 def test_intercept_tile_run_steps_matches_stepwise_updates_and_scalar_form(rng, d):
     """d = 512 / 1024 WITH an intercept (examples/logistic_regression.py:49-66): k_logreg_main's TAIL form -- a full tile of
     features, the intercept as the last second-half column, the left-over middle column computed by every lane.  The chained
-    device-resident loop (40 steps: two launches) and one update() per step walk the same trajectory, reproducibly; a child
+    device-resident loop (140 steps: two launches) and one update() per step walk the same trajectory, reproducibly; a child
     process with D3P_NO_TAIL_TILE=1 (the scalar-load form, other summation order) agrees to fp32 rounding."""
     import subprocess
     import sys
     import tempfile
     from d3p_amd.minibatch import subsample_batchify_data
-    N, B, steps = 6000, 700, 40
+    N, B, steps = 6000, 700, 140
     g = torch.Generator().manual_seed(5)
     X = torch.randn(N, d, generator=g).cuda()
     y = (torch.rand(N, generator=g) < 0.5).float().cuda()
@@ -673,7 +673,7 @@ sys.path.insert(0, %r)
 import d3p_amd.random as rng
 from d3p_amd.minibatch import subsample_batchify_data
 from test_gpu_dpsvi import make_svi, state_with
-d = int(sys.argv[2]); N, B, steps = 6000, 700, 40
+d = int(sys.argv[2]); N, B, steps = 6000, 700, 140
 g = torch.Generator().manual_seed(5)
 X = torch.randn(N, d, generator=g).cuda(); y = (torch.rand(N, generator=g) < 0.5).float().cuda()
 svi = make_svi(d, True, N, C=1.0, sigma=0.4, lr=2e-2)
