@@ -115,10 +115,12 @@ struct Sched {
     uint32_t pad[2];
 };
 
-// Arrival counters of one step: 17 lines of 128 bytes -- line 0 = groups arrived, line 1 + g = arrivals of group g
-// (blockIdx % 8: the workgroups of one XCD), line 9 + g = release word of group g, written by the workgroup that completes
-// the last group.  Every counter has a line of its own and a waiter polls the release word of its own group: measured on
-// MI355X (tools/probes/barrier_probe.hip), counters sharing lines + every waiter polling one word cost several us more.
+// Arrival counters of one step: 17 lines of 128 bytes -- line 1 + g = arrivals of group g (blockIdx % 8: the workgroups of
+// one XCD), line 9 + g = flag of group g, set by the workgroup whose arrival completes that group; a waiter polls the 8 flags
+// with ONE load instruction (lane g <-> flag g).  Counters are only ever added to, flags only ever polled, every word has a
+// line of its own: measured on MI355X (tools/probes/barrier_probe.hip), counters sharing lines or waiters polling a word that
+// takes atomics cost several us more.  (D3P_DBG=512: the earlier two-level form -- the last arriver of a group adds to a top
+// counter on line 0, the last of those sets all 8 flags, a waiter polls its own group's flag: 10.49 vs 10.41 us per step.)
 #define D3P_BAR_LINE 32
 #define D3P_BAR_WORDS (17 * D3P_BAR_LINE)
 #define D3P_AGENT __HIP_MEMORY_SCOPE_AGENT
@@ -146,6 +148,24 @@ __device__ __forceinline__ bool chain_wait(const uint32_t* p, uint32_t target, u
         // (the abort flag is looked at every 64th spin only: reading it on every spin doubles the polling traffic)
         if (spins > (1u << 21) || ((spins & 63u) == 63u && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, D3P_AGENT) != 0u)) {
             __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, D3P_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// bounded wait, made by a whole wavefront, until the `ngroups` group flags (one per 128-byte line) are all set: lane g polls
+// the flag of group g -- one load instruction per round
+__device__ __forceinline__ bool chain_wait_groups(const uint32_t* flags, uint32_t ngroups, uint32_t* abort_flag)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t spins = 0;; ++spins) {
+        const uint32_t v = lane < ngroups ? __hip_atomic_load(flags + D3P_BAR_LINE * lane, __ATOMIC_RELAXED, D3P_AGENT) : 1u;
+        if (__ballot(v == 0u) == 0ull) return true;
+        const bool give_up = spins > (1u << 21) ||
+                             ((spins & 63u) == 63u && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, D3P_AGENT) != 0u);
+        if (give_up) {
+            if (lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, D3P_AGENT);
             return false;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -432,7 +452,12 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             // (pipelined form: every wave has prepared its examples already, so ONE lane polls and, behind a workgroup
             // barrier, all waves share the prologue)
             const int PWc = all_waves ? W : (W < 4 ? W : 4);
-            if (step_t > 0 && (all_waves ? threadIdx.x == 0 : (wave < PWc && lane == 0)))  // the release word of this workgroup's group
+            const bool flat = !(a.dbg & 512);  // the last arriver of each group sets that group's flag; waiters poll all of them
+            if (flat) {
+                if (step_t > 0 && (all_waves ? wave == 0 : wave < PWc))
+                    (void)chain_wait_groups(a.chain.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * 9,
+                                            a.chain.nw < 8 ? (uint32_t)a.chain.nw : 8u, a.chain.abort_flag);
+            } else if (step_t > 0 && (all_waves ? threadIdx.x == 0 : (wave < PWc && lane == 0)))  // the release word of this workgroup's group
                 (void)chain_wait(a.chain.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (9 + (bid & 7u)), 1u,
                                  a.chain.abort_flag);
             if (all_waves) __syncthreads();
@@ -952,10 +977,14 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                     const uint32_t nw = (uint32_t)a.chain.nw, grp = bid & 7u, gsize = (nw + 7u - grp) / 8u;
                     const uint32_t prev = __hip_atomic_fetch_add(bar + D3P_BAR_LINE * (1 + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
                     if (prev + 1u == gsize) {
-                        const uint32_t top = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, D3P_AGENT);
-                        if (top + 1u == (nw < 8u ? nw : 8u))
-                            for (uint32_t g8 = 0; g8 < 8u; ++g8)
-                                __hip_atomic_store(bar + D3P_BAR_LINE * (9 + g8), 1u, __ATOMIC_RELAXED, D3P_AGENT);
+                        if (!(a.dbg & 512)) {  // flat: this group's flag; the waiters poll the flags of all groups
+                            __hip_atomic_store(bar + D3P_BAR_LINE * (9 + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
+                        } else {
+                            const uint32_t top = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, D3P_AGENT);
+                            if (top + 1u == (nw < 8u ? nw : 8u))
+                                for (uint32_t g8 = 0; g8 < 8u; ++g8)
+                                    __hip_atomic_store(bar + D3P_BAR_LINE * (9 + g8), 1u, __ATOMIC_RELAXED, D3P_AGENT);
+                        }
                     }
                 }
             }
