@@ -122,7 +122,8 @@ struct Sched {
 // takes atomics cost several us more.  (D3P_DBG=512: the earlier two-level form -- the last arriver of a group adds to a top
 // counter on line 0, the last of those sets all 8 flags, a waiter polls its own group's flag: 10.49 vs 10.41 us per step.)
 #define D3P_BAR_LINE 32
-#define D3P_BAR_WORDS (17 * D3P_BAR_LINE)
+#define D3P_BAR_GROUPS 8u  // arrival groups per step (blockIdx % 8: the workgroups of one XCD; 16 and 32 groups measured the same: 10.39 / 10.43-10.49 vs 10.41 us per step)
+#define D3P_BAR_WORDS ((1 + 2 * D3P_BAR_GROUPS) * D3P_BAR_LINE)
 #define D3P_AGENT __HIP_MEMORY_SCOPE_AGENT
 typedef unsigned int d3p_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -455,10 +456,11 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             const bool flat = !(a.dbg & 512);  // the last arriver of each group sets that group's flag; waiters poll all of them
             if (flat) {
                 if (step_t > 0 && (all_waves ? wave == 0 : wave < PWc))
-                    (void)chain_wait_groups(a.chain.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * 9,
-                                            a.chain.nw < 8 ? (uint32_t)a.chain.nw : 8u, a.chain.abort_flag);
+                    (void)chain_wait_groups(a.chain.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS),
+                                            (uint32_t)a.chain.nw < D3P_BAR_GROUPS ? (uint32_t)a.chain.nw : D3P_BAR_GROUPS,
+                                            a.chain.abort_flag);
             } else if (step_t > 0 && (all_waves ? threadIdx.x == 0 : (wave < PWc && lane == 0)))  // the release word of this workgroup's group
-                (void)chain_wait(a.chain.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (9 + (bid & 7u)), 1u,
+                (void)chain_wait(a.chain.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS + (bid % D3P_BAR_GROUPS)), 1u,
                                  a.chain.abort_flag);
             if (all_waves) __syncthreads();
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
@@ -974,16 +976,16 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                 __syncthreads();
                 if (threadIdx.x == 0) {
                     uint32_t* bar = a.chain.bar + (size_t)step_t * D3P_BAR_WORDS;
-                    const uint32_t nw = (uint32_t)a.chain.nw, grp = bid & 7u, gsize = (nw + 7u - grp) / 8u;
+                    const uint32_t nw = (uint32_t)a.chain.nw, grp = bid % D3P_BAR_GROUPS, gsize = (nw + D3P_BAR_GROUPS - 1u - grp) / D3P_BAR_GROUPS;
                     const uint32_t prev = __hip_atomic_fetch_add(bar + D3P_BAR_LINE * (1 + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
                     if (prev + 1u == gsize) {
                         if (!(a.dbg & 512)) {  // flat: this group's flag; the waiters poll the flags of all groups
-                            __hip_atomic_store(bar + D3P_BAR_LINE * (9 + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
+                            __hip_atomic_store(bar + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
                         } else {
                             const uint32_t top = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, D3P_AGENT);
-                            if (top + 1u == (nw < 8u ? nw : 8u))
-                                for (uint32_t g8 = 0; g8 < 8u; ++g8)
-                                    __hip_atomic_store(bar + D3P_BAR_LINE * (9 + g8), 1u, __ATOMIC_RELAXED, D3P_AGENT);
+                            if (top + 1u == (nw < D3P_BAR_GROUPS ? nw : D3P_BAR_GROUPS))
+                                for (uint32_t g8 = 0; g8 < D3P_BAR_GROUPS; ++g8)
+                                    __hip_atomic_store(bar + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS + g8), 1u, __ATOMIC_RELAXED, D3P_AGENT);
                         }
                     }
                 }
