@@ -911,7 +911,7 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
         // the next step just halves the occupancy of the working one (B = 32768: 44 -> 55 us per step).  The 12 % slack
         // admits Poisson batches padded to a quantile above 16 x workgroups (a few waves then take a third example and
         // generate its noise in the loop): 63.2 -> 68.6 k steps/s at q = 4096 / 1e6.
-        if (!off && c.g.full && !c.g.tail && c.g.V == 4 && c.g.NK == 1 && c.g.W == 16 && (uint64_t)c.src->B <= 18ull * c.g.blocks) {
+        if (!off && c.g.full && c.g.V == 4 && c.g.NK == 1 && c.g.W == 16 && (uint64_t)c.src->B <= 18ull * c.g.blocks) {
             g2.W = 8;
             g2.lds = (size_t)(((5 * c.D + 3) & ~3) + g2.W * c.P + 2 * g2.W) * sizeof(float);
             cf.pregen = 1;

@@ -748,7 +748,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
     // still in its exchange).  Every wave -- the prologue waves too -- generates the noise of its first TWO examples into
     // its own (still unused) row of the reduction buffer BEFORE waiting for the previous step's release, so between that
     // release and this workgroup's arrival there is only the prologue, the gradient arithmetic and the exchange.
-    const bool pregen = CHAIN && FULL && !TAIL && V == 4 && NK == 1 && !eps_from_mem && a.chain.pregen && !a.fuse.flush_only && !(a.dbg & 1);
+    const bool pregen = CHAIN && FULL && V == 4 && NK == 1 && !eps_from_mem && a.chain.pregen && !a.fuse.flush_only && !(a.dbg & 1);
     int it = 0;  // examples this wave has gone through
     ExLoad<NC> pre;         // second example, loaded ahead of the prologue as well (its index -> row chain would otherwise sit
     bool have_pre = false;  // between the release and the first gradient)
@@ -769,7 +769,15 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                 v1[n] = bits_to_normal_wu(b1);
             }
             *reinterpret_cast<float4*>(dst + c0[0]) = make_float4(v0[0], v0[1], v0[2], v0[3]);
-            *reinterpret_cast<float4*>(dst + c1[0]) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+            if (TAIL) {  // odd half: the second-half columns are not 16-byte aligned; + the tail column (every lane, same value)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) dst[c1[n]] = v1[n];
+                uint32_t b0, b1;
+                threefry2x32(k0, k1, (uint32_t)ct, 0u, b0, b1);
+                if (lane == 0) dst[ct] = bits_to_normal_wu(b0);
+            } else {
+                *reinterpret_cast<float4*>(dst + c1[0]) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+            }
         };
         if (cur.live) gen(cur.k0, cur.k1, er);
         if (have_pre && pre.live) gen(pre.k0, pre.k1, er + D);
@@ -810,7 +818,12 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                     const float* er = red + (size_t)wave * P + it * D;
                     float t0[4], t1[4];
                     *reinterpret_cast<float4*>(t0) = *reinterpret_cast<const float4*>(er + c0[0]);
-                    *reinterpret_cast<float4*>(t1) = *reinterpret_cast<const float4*>(er + c1[0]);
+                    if (TAIL) {
+#pragma unroll
+                        for (int n = 0; n < NC && n < 4; ++n) t1[n] = er[c1[n]];
+                    } else {
+                        *reinterpret_cast<float4*>(t1) = *reinterpret_cast<const float4*>(er + c1[0]);
+                    }
 #pragma unroll
                     for (int n = 0; n < NC && n < 4; ++n) { e0[n] = t0[n]; e1[n] = t1[n]; }
                 } else {
@@ -829,6 +842,8 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             if (TAIL) {
                 if (eps_from_mem) {
                     et = cur.et;
+                } else if (pregen && it < 2) {
+                    et = red[(size_t)wave * P + it * D + ct];
                 } else {
                     uint32_t b0, b1;
                     threefry2x32(cur.k0, cur.k1, (uint32_t)ct, 0u, b0, b1);
