@@ -25,6 +25,18 @@ from .util import example_count
 PRNGState = Any
 
 
+def _fresh_optim_state(optim_state):
+    """Copies of (step, params, m, v) for a functional update (svi.py:395-434 returns a new state): the three float
+    vectors are copied by ONE kernel into one buffer (views of it are returned) -- per-call host time matters for
+    step-by-step loops."""
+    step, params, m, v = optim_state
+    n = params.numel()
+    if m.numel() == n and v.numel() == n and params.dtype == m.dtype == v.dtype:
+        flat = torch.cat((params.reshape(-1), m.reshape(-1), v.reshape(-1)))
+        return step.clone(), flat[:n].view_as(params), flat[n:2 * n].view_as(m), flat[2 * n:].view_as(v)
+    return step.clone(), params.clone(), m.clone(), v.clone()
+
+
 class DPSVIState(NamedTuple):
     """d3p/svi.py:37-40."""
     optim_state: Any
@@ -236,7 +248,7 @@ class DPSVI:
         dev = X.device
         vm = self._vae_struct(D, kwargs, svi_state.observation_scale)
         hyper = self._hyper()
-        step, params, m, v = (t.clone() for t in svi_state.optim_state)
+        step, params, m, v = _fresh_optim_state(svi_state.optim_state)
         keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
         keybuf[0].copy_(svi_state.rng_key.reshape(16))
         mask_t = None
@@ -558,7 +570,7 @@ class DPSVI:
         dev = X.device
         gm = self._gmm_struct(d, kwargs, svi_state.observation_scale)
         hyper = self._hyper()
-        step, params, m, v = (t.clone() for t in svi_state.optim_state)
+        step, params, m, v = _fresh_optim_state(svi_state.optim_state)
         keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
         keybuf[0].copy_(svi_state.rng_key.reshape(16))
         mask_t = None
@@ -587,7 +599,7 @@ class DPSVI:
         dev = X.device
         gm = self._gmm_struct(d, kwargs, svi_state.observation_scale)
         hyper = self._hyper()
-        step, params, m, v = (t.clone() for t in svi_state.optim_state)
+        step, params, m, v = _fresh_optim_state(svi_state.optim_state)
         keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
         keybuf[0].copy_(svi_state.rng_key.reshape(16))
         bkey = batchifier_state.contiguous()
@@ -638,7 +650,7 @@ class DPSVI:
         dev = X.device
         model = self._model_struct(d, kwargs, svi_state.observation_scale)
         hyper = self._hyper()
-        step, params, m, v = (t.clone() for t in svi_state.optim_state)
+        step, params, m, v = _fresh_optim_state(svi_state.optim_state)
         keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
         keybuf[0].copy_(svi_state.rng_key.reshape(16))
         mask_t = None
@@ -685,7 +697,7 @@ class DPSVI:
         dev = X.device
         model = self._model_struct(d, kwargs, svi_state.observation_scale)
         hyper = self._hyper()
-        step, params, m, v = (t.clone() for t in svi_state.optim_state)
+        step, params, m, v = _fresh_optim_state(svi_state.optim_state)
         keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
         keybuf[0].copy_(svi_state.rng_key.reshape(16))
         bkey = batchifier_state.contiguous()
