@@ -103,13 +103,18 @@ __global__ void k_sched_finish(const Sched* __restrict__ sched, uint32_t* __rest
 }
 
 // One wavefront; lanes 0..2 each derive one child of split(cur, 3), lane 0's child is the next key.
-__global__ void __launch_bounds__(64) k_chain(Sched* __restrict__ sched, StepSlot* __restrict__ slots, int K)
+// state_key != nullptr: the schedule starts from the state (what k_sched_init would have stored) -- one launch less on the
+// path of a single update() call.
+__global__ void __launch_bounds__(64) k_chain(Sched* __restrict__ sched, StepSlot* __restrict__ slots, int K,
+                                              const uint32_t* __restrict__ state_key = nullptr,
+                                              const int32_t* __restrict__ adam_step = nullptr,
+                                              const uint32_t* __restrict__ batch_index = nullptr)
 {
     const int lane = threadIdx.x;
     uint32_t cur[16], child[16];
-    load_key(sched->key, cur);
-    const int32_t adam0 = sched->adam_i;
-    const uint32_t batch0 = sched->batch_i;
+    load_key(state_key ? state_key : sched->key, cur);
+    const int32_t adam0 = state_key ? *adam_step : sched->adam_i;
+    const uint32_t batch0 = state_key ? (batch_index ? *batch_index : 0u) : sched->batch_i;
     for (int t = 0; t < K; ++t) {
         derive_child(cur, (uint32_t)(lane < 3 ? lane : 0), 0u, D3P_TAG_SPLIT, child);
         if (lane == 1) {
@@ -548,7 +553,19 @@ static int enqueue_sched_init(const Ctx& c)
 
 static int enqueue_chain(const Ctx& c, int K)
 {
-    hipLaunchKernelGGL(k_chain, dim3(1), dim3(64), 0, c.s, c.ws.sched, c.ws.slots, K);
+    hipLaunchKernelGGL(k_chain, dim3(1), dim3(64), 0, c.s, c.ws.sched, c.ws.slots, K, (const uint32_t*)nullptr,
+                       (const int32_t*)nullptr, (const uint32_t*)nullptr);
+    return check_launch("k_chain");
+}
+
+// enqueue_sched_init + enqueue_chain in two launches instead of three (the schedule is initialised inside k_chain)
+static int enqueue_sched_init_chain(const Ctx& c, int K)
+{
+    const bool sampled = c.src->kind != D3P_BATCH_EXPLICIT;
+    hipLaunchKernelGGL(k_pack, dim3(cdiv(c.D, 256)), dim3(256), 0, c.s, *c.m, (const float*)c.st->params, c.ws.pack);
+    hipLaunchKernelGGL(k_chain, dim3(1), dim3(64), 0, c.s, c.ws.sched, c.ws.slots, K,
+                       (const uint32_t*)(c.st->rng_key + 16 * (c.st->key_slot & 1)), (const int32_t*)c.st->step,
+                       sampled ? (const uint32_t*)c.src->batch_index : nullptr);
     return check_launch("k_chain");
 }
 
@@ -1108,8 +1125,8 @@ int d3p_dpvi_logreg_local_sums(void* stream, const d3p_logreg_model* model, cons
     if (rc) return rc;
     D3P_REQUIRE(X_dev && sums_dev, "null data pointer");
     if (int rcm = validate_model(model, y_dev, "d3p_dpvi_logreg")) return rcm;
-    if ((rc = enqueue_sched_init(c))) return rc;
-    if ((rc = enqueue_batch_prep(c, 1))) return rc;
+    if ((rc = enqueue_sched_init_chain(c, 1))) return rc;
+    if ((rc = enqueue_sampler(c, 1))) return rc;
     if ((rc = enqueue_main(c, 0, X_dev, y_dev, eps_dev, false))) return rc;
     hipLaunchKernelGGL(k_reduce_partials, dim3(cdiv(c.P + 2, 64)), dim3(64 * D3P_FIN_W), 0, c.s,
                        (const float*)c.ws.partials, c.g.blocks, (uint32_t)(c.P + 2), sums_dev);
