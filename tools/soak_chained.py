@@ -27,7 +27,24 @@ for name, (init, gb) in (("feistel", subsample_batchify_data((X, y), B)), ("pois
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         outs.append((s2.optim_state[1].clone(), losses.clone()))
         print(f"{name} run {rep}: {steps} steps in {dt:.2f} s = {dt / steps * 1e6:.2f} us/step, last loss {float(losses[-1]):.3f}", flush=True)
-    same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # third run under UNEVEN load: matrix products of changing size on a second stream compete for the CUs while the chained
+    # launches run; a hand-off that depended on timing would show up as a different result
+    side = torch.cuda.Stream()
+    mats = [torch.randn(n, n, device="cuda") for n in (512, 1024, 3072)]
+    done = torch.cuda.Event()
+    s3, losses3 = svi.run_steps(st, gb, rng.PRNGKey(4), 0, steps)
+    done.record()
+    k = 0
+    with torch.cuda.stream(side):
+        while not done.query():
+            a = mats[k % 3]
+            (a @ a).sum()
+            k += 1
+    torch.cuda.synchronize()
+    print(f"{name}: disturbed run with {k} concurrent matrix products", flush=True)
+    outs.append((s3.optim_state[1].clone(), losses3.clone()))
+    same = (torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and
+            torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1]))
     finite = bool(torch.isfinite(outs[0][0]).all()) and bool(torch.isfinite(outs[0][1]).all())
     print(f"{name}: bitwise identical runs: {same}; finite: {finite}", flush=True)
     assert same and finite
