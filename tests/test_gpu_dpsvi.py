@@ -689,3 +689,35 @@ np.save(sys.argv[1], np.concatenate([losses.cpu().numpy(), s2.optim_state[1].cpu
         other = np.load(f.name)
     np.testing.assert_allclose(other[:steps], np_(runs[0][1]), rtol=2e-5)
     np.testing.assert_allclose(other[steps:], np_(runs[0][0].optim_state[1]), rtol=1e-4, atol=5e-6)
+
+
+def test_chained_launch_is_reproducible_under_uneven_load(rng):
+    """The cross-workgroup hand-offs of the chained launch (arrival counters, group flags, agent-scope accumulator reads) must
+    not depend on timing: a run made while matrix products of changing size on a second stream compete for the CUs ends bit
+    for bit like the undisturbed one, and no bounded wait hits its bound (tools/soak_chained.py is the long form)."""
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, d, B, steps = 60000, 512, 4096, 3000
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(N, d, generator=g).cuda()
+    y = (torch.rand(N, generator=g) < 0.5).float().cuda()
+    svi = make_svi(d, False, N)
+    st = state_with(svi, rng.PRNGKey(41), np.zeros(d, np.float32), np.full(d, -2.0, np.float32))
+    _, gb = subsample_batchify_data((X, y), B)
+    quiet_state, quiet_losses = svi.run_steps(st, gb, rng.PRNGKey(42), 0, steps)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    mats = [torch.randn(n, n, device="cuda") for n in (512, 1024, 3072)]
+    done = torch.cuda.Event()
+    loud_state, loud_losses = svi.run_steps(st, gb, rng.PRNGKey(42), 0, steps)
+    done.record()
+    k = 0
+    with torch.cuda.stream(side):
+        while not done.query():
+            a = mats[k % 3]
+            (a @ a).sum()
+            k += 1
+    torch.cuda.synchronize()
+    assert k > 0
+    assert torch.equal(loud_losses, quiet_losses) and torch.equal(loud_state.optim_state[1], quiet_state.optim_state[1])
+    assert bool(torch.isfinite(quiet_losses).all())
+    _check_no_wait_hit_its_bound(rng, 20000, 512, 4096)
