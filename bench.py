@@ -55,8 +55,8 @@ def cpu_baseline(d, B, seconds, rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=2048)   # whole prepared batches of 128 steps
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--rows-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--batch-per-gpu", type=int, default=4096)
     ap.add_argument("--dim", type=int, default=512)
