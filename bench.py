@@ -3,16 +3,23 @@
 regression (d=512, batch 4096 per GPU, AutoDiagonalNormal) on MI355X -- BASELINE.json's metric.
 
     python bench.py --gpus N --steps K --warmup W
-(N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+N > 1 either under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment) or as plain `python bench.py --gpus N`: the parent then starts N rank
+processes itself -- fresh interpreters, before anything in the parent has touched a GPU -- and rank 0 prints the line.
 
 A step = one DPSVI.update on one freshly sampled minibatch: key schedule -> Feistel subsampling
 -> fused per-example gradient / clip / sum -> Gaussian mechanism (ChaCha20) -> Adam.  Inputs
-(the synthetic table) are resident in HBM before the timed region.  Prints ONE JSON line.
+(the synthetic table) are resident in HBM before the timed region.  Prints ONE JSON line:
+`value` is tied to --steps; `steady_state` (a fixed 4096-step leg) and `north_star_N1e7` (the same workload over a
+10^7-row table) are measured in the same run whatever --steps is.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,28 +35,90 @@ def algorithmic_bytes(B, d, P):
 
 
 def cpu_baseline(d, B, seconds, rows):
-    """The oracle's stage-by-stage update (materialised B x P like jax.vmap) on the host cores."""
+    """The oracle's C loop over DPSVI.update (reference dataflow: gather, per-example gradients materialised B x P like
+    jax.vmap, clip pass, mean, perturb, Adam; Feistel sampling and the gather in C) on the host cores: a 1-thread figure
+    and the best of a few thread counts, each on a bounded sample."""
     import numpy as np
     from oracle import oracle as O
     O.build()
     cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
     X, y = O.synth_logreg(123, 0, rows, d)
     spec = O.logreg_spec(d, False, 1.0, 1.0, lik_scale=rows, obs_scale=rows)
     hy = O.Hyper(1.0, 1.0, 1e-3, 0.9, 0.999, 1e-8)
-    st = O.LogregState(O.PRNGKey(0), d, np.zeros(d, np.float32), np.full(d, -2.25, np.float32))
     bkey = O.PRNGKey(1)
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        idx = O.feistel_sample(O.fold_in(bkey, steps), rows, B)
-        O.logreg_update(spec, hy, st, X[idx], y[idx])
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= seconds and steps >= 3:
-            break
-    return {"value": B * steps / el, "unit": "examples/s", "steps_per_sec": steps / el, "cores": cores,
-            "kind": "port",
-            "sample": f"{steps} update steps (B={B}, d={d}) over a {rows}-row synthetic table in {el:.1f} s; "
-                      "oracle/ C restatement of the reference dataflow (B x P materialised), OpenMP over examples"}
+
+    def timed(threads, budget):
+        st = O.LogregState(O.PRNGKey(0), d, np.zeros(d, np.float32), np.full(d, -2.25, np.float32))
+        O.logreg_run_feistel(spec, hy, st, X, y, bkey, 0, B, 1, threads)          # warm-up step (page-in, thread start)
+        done, chunk, t0 = 0, 1, time.perf_counter()
+        while True:
+            O.logreg_run_feistel(spec, hy, st, X, y, bkey, 1 + done, B, chunk, threads)
+            done += chunk
+            el = time.perf_counter() - t0
+            if el >= budget:
+                return done / el, done, el
+            chunk = max(1, min(64, int(done / el * (budget - el)) // 2 or 1))
+
+    one, n1, e1 = timed(1, min(3.0, seconds / 4))
+    best = (one, 1, n1, e1)
+    cands = sorted({t for t in (8, 16, 32, 64, 128, cores) if 1 < t <= cores})
+    per = max(1.0, (seconds - e1) / max(1, len(cands)))
+    tried = {1: round(one, 2)}
+    for t in cands:
+        sps, n, el = timed(t, per)
+        tried[t] = round(sps, 2)
+        if sps > best[0]:
+            best = (sps, t, n, el)
+    sps, threads, n, el = best
+    return {"value": B * sps, "unit": "examples/s", "steps_per_sec": round(sps, 3), "cores": threads, "kind": "port",
+            "host_cores": cores, "one_thread_steps_per_sec": round(one, 3), "one_thread_value": round(B * one, 1),
+            "steps_per_sec_by_threads": tried,
+            "sample": f"{n} update steps (B={B}, d={d}) in {el:.1f} s on {threads} OpenMP threads (best of {sorted(tried)}; "
+                      f"1 thread: {n1} steps in {e1:.1f} s) over a {rows}-row synthetic table; oracle/ C loop "
+                      "d3po_logreg_run_feistel = the reference dataflow (Feistel sampling, gather, B x P per-example "
+                      "gradients materialised like jax.vmap, clip pass, mean, ChaCha20 perturbation, Adam), float32"}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes here.  The parent never initialises a
+    GPU (counting devices does not), the ranks are fresh interpreters; rank 0 prints the JSON line to the shared stdout."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"[bench] --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:          # one rank failed: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
@@ -64,6 +133,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-batch", action="store_true",
                     help="skip the extra leg that times the same step kernel at batch 32768 (throughput regime)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the steady_state and north_star_N1e7 legs (profiling runs)")
+    ap.add_argument("--steady-steps", type=int, default=4096)
     ap.add_argument("--sampler", choices=["feistel", "poisson"], default="feistel",
                     help="feistel = subsample_batchify_data w/o replacement (headline); poisson = poisson_batchify_data "
                          "with q = B/N and the 0.99-quantile padding of examples/logistic_regression.py:126-127")
@@ -73,6 +145,9 @@ def main():
     ap.add_argument("--force-dist-loop", action="store_true",
                     help="developer switch: use the stepwise data-parallel loop (d3p_amd.dist) even with one rank")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -87,7 +162,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or (args.force_dist_loop and "RANK" in os.environ):
@@ -97,22 +172,13 @@ def main():
     lib = L.load()
 
     emu = args.emulate_world if args.emulate_world > 1 else 0
-    d, Bg = args.dim, args.batch_per_gpu * (emu or world)
-    n_rows = args.rows_per_gpu * (emu or world)
-    lo, hi = ddist.shard_rows(n_rows, rank, emu or world)
+    ranks = emu or world
+    d, Bg = args.dim, args.batch_per_gpu * ranks
+    D = d
+    P = 2 * D
+    single = world == 1 and not args.force_dist_loop and not emu
     if emu:
         args.force_dist_loop = True
-    X = torch.empty((hi - lo, d), dtype=torch.float32, device=dev)
-    y = torch.empty(hi - lo, dtype=torch.float32, device=dev)
-    L.check(lib.d3p_synth_logreg(L.stream_ptr(), 123, lo, hi - lo, d, L.ptr(X), L.ptr(y)))
-
-    model = LogisticRegression(d, prior_scale=1.0)
-    svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-3), Trace_ELBO(), clipping_threshold=1.0, dp_scale=1.0,
-                num_obs_total=n_rows)
-    D = d
-    params = torch.cat([torch.zeros(D, device=dev), torch.full((D,), svi.guide.unconstrained_init_scale(), device=dev)])
-    state = DPSVIState(svi.optim.init(params), rng.PRNGKey(0), float(n_rows))
-    bkey = rng.PRNGKey(1)
 
     def barrier():
         torch.cuda.synchronize()
@@ -120,149 +186,251 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1 and not args.force_dist_loop:
-        if args.sampler == "poisson":
-            _, get_batch = poisson_batchify_data((X, y), Bg / n_rows, 0.99)
-        else:
-            _, get_batch = subsample_batchify_data((X, y), Bg)
+    def read_kernel_timing():
+        us, launches, steps = C.c_double(), C.c_uint32(), C.c_uint32()
+        L.check(lib.d3p_dpvi_logreg_kernel_timing_read(C.byref(us), C.byref(launches), C.byref(steps)))
+        return us.value, launches.value, steps.value
 
-        def run(st, first, k):
-            return svi.run_steps(st, get_batch, bkey, first, k)
-    else:
-        engine_cls = ddist.HipEngine if os.environ.get("D3P_DIST_TWO_PHASE") else ddist.FusedHipEngine
-        engine = engine_cls(svi, X, y, n_rows, lo, hi, L.D3P_BATCH_FEISTEL, Bg)
-        # Preferred: the native loop (one C call for the whole run; per step one launch + one in-place ncclAllReduce on
-        # the same stream, communicator owned by libd3p_hip.so).  If RCCL cannot be set up that way, or on request,
-        # the same steps are driven from Python through torch.distributed.all_reduce.
-        comm = None
-        if engine_cls is ddist.FusedHipEngine and not os.environ.get("D3P_DIST_TORCH_LOOP"):
-            try:
-                comm = ddist.NativeComm()
-            except Exception as e:  # noqa: BLE001 -- any failure here only selects the slower driver
-                if rank == 0:
-                    print(f"[bench] native RCCL loop unavailable ({e}); using the torch.distributed loop", file=sys.stderr)
+    comm = None
+    dist_driver = "none"
+    if not single and not os.environ.get("D3P_DIST_TWO_PHASE") and not os.environ.get("D3P_DIST_TORCH_LOOP"):
+        # Preferred data-parallel driver: the native loop (one C call for the whole run; per step one launch and the
+        # rank's accumulator exchange on the same stream, communicator owned by libd3p_hip.so).  Every rank must take the
+        # same decision, so success is agreed on with an all-reduce of a flag.
+        ok = 1
+        try:
+            comm = ddist.NativeComm()
+        except Exception as e:  # noqa: BLE001 -- a failure here only selects the slower driver
+            ok = 0
+            print(f"[bench] rank {rank}: native communicator unavailable ({e})", file=sys.stderr)
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag[0])
+        if not ok and comm is not None:
+            comm.close()
+            comm = None
+    if not single:
         dist_driver = "native" if comm is not None else "torch"
 
-        def run(st, first, k):
-            if comm is not None:
-                return ddist.run_steps_native(engine, st, bkey, first, k, comm=comm, collect_losses=False)
-            return ddist.run_steps(engine, st, bkey, first, k, collect_losses=False)
+    def make_workload(n_rows_total, native=True):
+        """Table shard + model + state + a `run(state, first, k)` closure for a table of n_rows_total rows.
+        native (data-parallel runs only): the one-C-call loop of libd3p_hip.so, else the Python-driven loop."""
+        lo, hi = ddist.shard_rows(n_rows_total, rank, ranks)
+        X = torch.empty((hi - lo, d), dtype=torch.float32, device=dev)
+        y = torch.empty(hi - lo, dtype=torch.float32, device=dev)
+        L.check(lib.d3p_synth_logreg(L.stream_ptr(), 123, lo, hi - lo, d, L.ptr(X), L.ptr(y)))
+        model = LogisticRegression(d, prior_scale=1.0)
+        svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-3), Trace_ELBO(), clipping_threshold=1.0, dp_scale=1.0,
+                    num_obs_total=n_rows_total)
+        params = torch.cat([torch.zeros(D, device=dev), torch.full((D,), svi.guide.unconstrained_init_scale(), device=dev)])
+        state = DPSVIState(svi.optim.init(params), rng.PRNGKey(0), float(n_rows_total))
+        bkey = rng.PRNGKey(1)
+        if single:
+            if args.sampler == "poisson":
+                _, get_batch = poisson_batchify_data((X, y), Bg / n_rows_total, 0.99)
+            else:
+                _, get_batch = subsample_batchify_data((X, y), Bg)
 
-    try:
-        state, _ = run(state, 0, args.warmup)
-    except Exception as e:  # noqa: BLE001
-        # the native RCCL loop has only been rehearsed on one rank: if it fails at run time, drive the same steps through
-        # torch.distributed instead of losing the measurement (all ranks take the same branch: the failure is collective)
-        if world == 1 and not args.force_dist_loop:
-            raise
-        if comm is None:
-            raise
-        if rank == 0:
-            print(f"[bench] native RCCL loop failed in warm-up ({e}); falling back to the torch.distributed loop", file=sys.stderr)
-        comm = None
-        dist_driver = "torch"
-        state, _ = run(state, 0, args.warmup)
-    barrier()
-    # HIP start/stop events around every step-kernel launch of the timed region, on the launch stream (roofline figure)
-    L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(1))
-    t0 = time.perf_counter()
-    state, losses = run(state, args.warmup, args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(0))
-    kt_us, kt_launches, kt_steps = C.c_double(), C.c_uint32(), C.c_uint32()
-    L.check(lib.d3p_dpvi_logreg_kernel_timing_read(C.byref(kt_us), C.byref(kt_launches), C.byref(kt_steps)))
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    steps_per_s = args.steps / elapsed
-    final_loss = float(losses[-1]) if losses is not None else None
+            def run(st, first, k):
+                return svi.run_steps(st, get_batch, bkey, first, k)   # (raises if the chained launch was aborted)
+        else:
+            engine_cls = ddist.HipEngine if os.environ.get("D3P_DIST_TWO_PHASE") else ddist.FusedHipEngine
+            engine = engine_cls(svi, X, y, n_rows_total, lo, hi, L.D3P_BATCH_FEISTEL, Bg)
 
-    # ---- dominant kernel: the step kernel of the timed region itself (k_logreg_main; one chained launch covers up to 32
-    # DP-VI steps on one GPU, one launch per step in the data-parallel loop), HIP events on the launch stream
-    P = 2 * D
-    roofline = None
-    if rank == 0 and kt_launches.value > 0:
-        alg_step = algorithmic_bytes(Bg // world, d, P)   # this rank's share of the global batch, per step
-        steps_per_launch = kt_steps.value / kt_launches.value
-        avg_launch_us = kt_us.value / kt_launches.value
-        alg_launch = alg_step * steps_per_launch
-        achieved = alg_step * kt_steps.value / (kt_us.value * 1e-6) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tfile):
-            try:
-                per_step = json.load(open(tfile)).get("hbm_bytes_per_step")
-                traffic = per_step * steps_per_launch if per_step is not None else None
-            except Exception:
-                traffic = None
-        chained = world == 1 and not args.force_dist_loop and not os.environ.get("D3P_NO_CHAINED_STEPS")
-        roofline = {"bound": "hbm",
-                    "kernel": ("k_logreg_main<MODE 3> (chained launch: the <= 128 DP-VI steps of a prepared batch per launch)" if chained
-                               else "k_logreg_main<MODE 2> (one launch per DP-VI step)"),
-                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": round(alg_launch, 1), "algorithmic_bytes_per_step": alg_step,
-                    "avg_launch_us": round(avg_launch_us, 3), "launches": kt_launches.value,
-                    "steps_per_launch": round(steps_per_launch, 3),
-                    "kernel_us_per_step": round(kt_us.value / kt_steps.value, 3),
-                    "co_bound": {"what": "VALU issue (eps generation: threefry2x32-20 + erf_inv) and, between steps, the "
-                                         "cross-workgroup exchange (arrival counters + redundant update prologue)",
-                                 "valu_instr_per_step": 3.2e6, "valu_floor_us_per_step": 5.5},
-                    "timing": "HIP start/stop events (hipExtLaunchKernel) around " + ("every 16th" if (world > 1 or args.force_dist_loop) else "EVERY") +
-                              " step-kernel launch of the timed region, "
-                              "on the launch stream (d3p_dpvi_logreg_kernel_timing_*); achieved = algorithmic bytes of the "
-                              "steps covered / summed kernel time"}
+            def run(st, first, k):
+                if comm is not None and native:
+                    return ddist.run_steps_native(engine, st, bkey, first, k, comm=comm, collect_losses=False)
+                return ddist.run_steps(engine, st, bkey, first, k, collect_losses=False)
+        return svi, state, run, (X, y), bkey
 
-    # ---- the same kernel in the throughput regime (context for `frac`: at batch 4096 a step is latency-bound by the
-    # cross-workgroup exchange; at batch 32768 = 8 examples per wave it runs at its VALU ceiling)
-    if roofline is not None and world == 1 and not args.force_dist_loop and not args.no_large_batch and args.sampler == "feistel":
-        Bl = 32768
-        _, gb_l = subsample_batchify_data((X, y), Bl)
-        st_l, _ = svi.run_steps(state, gb_l, bkey, 0, 64)
-        torch.cuda.synchronize()
+    def timed_leg(run, state, first, warm, steps):
+        """warm-up, barrier, `steps` timed steps bracketed by barriers (max over ranks), HIP-event kernel timing."""
+        state, _ = run(state, first, warm)
+        barrier()
         L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(1))
-        svi.run_steps(st_l, gb_l, bkey, 64, 320)
-        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        state, losses = run(state, first + warm, steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
         L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(0))
-        us_l, n_l, steps_l = C.c_double(), C.c_uint32(), C.c_uint32()
-        L.check(lib.d3p_dpvi_logreg_kernel_timing_read(C.byref(us_l), C.byref(n_l), C.byref(steps_l)))
-        if steps_l.value:
-            ach = algorithmic_bytes(Bl, d, P) * steps_l.value / (us_l.value * 1e-6) / 1e9
-            roofline["large_batch"] = {"batch": Bl, "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBPS, 4),
-                                       "kernel_us_per_step": round(us_l.value / steps_l.value, 3),
-                                       "note": "same kernel and method, 320 steps at batch 32768 on one GPU (8 examples per "
-                                               "wave): the VALU-issue ceiling of the fused step with JAX-faithful noise"}
+        kt = read_kernel_timing()
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
+        return state, losses, elapsed, kt
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(d, args.batch_per_gpu, args.cpu_seconds, rows=100_000)
+    def kernel_record(kt, B_rank):
+        us, launches, ksteps = kt
+        if not launches or not ksteps:
+            return None
+        alg_step = algorithmic_bytes(B_rank, d, P)
+        ach = alg_step * ksteps / (us * 1e-6) / 1e9
+        return {"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBPS, 4), "kernel_us_per_step": round(us / ksteps, 3),
+                "avg_launch_us": round(us / launches, 3), "launches": launches, "steps_per_launch": round(ksteps / launches, 3),
+                "algorithmic_bytes_per_step": alg_step}
 
-    if dist.is_initialized():
-        dist.barrier()
-        if not (world == 1 and not args.force_dist_loop) and comm is not None:
-            comm.close()
-        dist.destroy_process_group()
-    if rank == 0:
+    def measure(native, extra_legs):
+        """All GPU legs with one driver; returns the fields of the JSON line (rank 0) or None."""
+        # ---------------------------------------------------------------- headline leg (value is tied to --steps)
+        n_rows = args.rows_per_gpu * ranks
+        svi, state, run, table, bkey = make_workload(n_rows, native)
+        state, losses, elapsed, kt = timed_leg(run, state, 0, args.warmup, args.steps)
+        steps_per_s = args.steps / elapsed
+        final_loss = float(losses[-1]) if losses is not None else None
+
+        # ---- dominant kernel: the step kernel of the timed region itself, HIP events on the launch stream
+        roofline = None
+        krec = kernel_record(kt, Bg // ranks) if rank == 0 else None
+        if krec is not None:
+            chained = single and not os.environ.get("D3P_NO_CHAINED_STEPS")
+            traffic, traffic_src = None, None
+            tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if chained and os.path.exists(tfile):
+                # NOT measured in this run: PMC counters need rocprofv3's own passes (tools/profile_round.sh); the figure is the
+                # committed profile's bytes per step x this run's steps per launch, with its provenance beside it
+                try:
+                    rec = json.load(open(tfile))
+                    per_step = rec.get("hbm_bytes_per_step")
+                    traffic = per_step * krec["steps_per_launch"] if per_step is not None else None
+                    traffic_src = {"file": "profiles/" + str(rec.get("source", "traffic_latest.json")), "commit": rec.get("commit"),
+                                   "profiled_steps": rec.get("steps"), "hbm_bytes_per_step": per_step,
+                                   "ratio_to_algorithmic": (round(per_step / krec["algorithmic_bytes_per_step"], 3)
+                                                            if per_step is not None else None),
+                                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at the named commit "
+                                           "(FETCH doubled per the gfx950 correction); not re-measured in this run"}
+                except Exception:  # noqa: BLE001
+                    traffic, traffic_src = None, None
+            roofline = {"bound": "hbm",
+                        "kernel": ("k_logreg_main<MODE 3> (chained launch: the <= 128 DP-VI steps of a prepared batch per launch)" if chained
+                                   else "k_logreg_main<MODE 2> (one launch per DP-VI step)"),
+                        "achieved": krec["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": krec["frac"],
+                        "traffic": traffic, "traffic_source": traffic_src,
+                        "algorithmic_bytes_per_launch": round(krec["algorithmic_bytes_per_step"] * krec["steps_per_launch"], 1),
+                        "algorithmic_bytes_per_step": krec["algorithmic_bytes_per_step"],
+                        "avg_launch_us": krec["avg_launch_us"], "launches": krec["launches"],
+                        "steps_per_launch": krec["steps_per_launch"], "kernel_us_per_step": krec["kernel_us_per_step"],
+                        "co_bound": "between steps the cross-workgroup exchange (accumulator atomics -> arrival -> release -> "
+                                    "update prologue); inside a step VALU issue (eps generation: threefry2x32-20 + erf_inv); "
+                                    "DESIGN.md section 6",
+                        "timing": "HIP start/stop events (hipExtLaunchKernel) around " + ("EVERY" if single else "every 16th") +
+                                  " step-kernel launch of the timed region, on the launch stream "
+                                  "(d3p_dpvi_logreg_kernel_timing_*); achieved = algorithmic bytes of the steps covered / "
+                                  "summed kernel time"}
+
+        # ---------------------------------------------------------------- steady state: a fixed leg, whatever --steps is
+        steady = None
+        if extra_legs:
+            state, _, el_s, kt_s = timed_leg(run, state, args.warmup + args.steps, 256, args.steady_steps)
+            if rank == 0:
+                sps = args.steady_steps / el_s
+                steady = {"steps": args.steady_steps, "warmup": 256, "steps_per_sec": round(sps, 2), "value": round(Bg * sps, 1),
+                          "ms_per_step": round(1000.0 * el_s / args.steady_steps, 6), "kernel": kernel_record(kt_s, Bg // ranks)}
+        del table, run, state, svi
+        torch.cuda.empty_cache()
+
+        # ---------------------------------------------------------------- north_star: the same workload over N = 10^7 rows
+        north = None
+        if extra_legs and args.sampler == "feistel":
+            n7 = 10_000_000
+            svi7, st7, run7, table7, _ = make_workload(n7, native)
+            st7, _, el7, kt7 = timed_leg(run7, st7, 0, 256, 2048)
+            if rank == 0:
+                sps = 2048 / el7
+                north = {"rows": n7, "table_GB": round(n7 * (d + 1) * 4 / 1e9, 2), "steps": 2048, "warmup": 256,
+                         "steps_per_sec": round(sps, 2), "value": round(Bg * sps, 1), "ms_per_step": round(1000.0 * el7 / 2048, 6),
+                         "kernel": kernel_record(kt7, Bg // ranks),
+                         "note": "north_star's table size (N = 10M rows, row-sharded over the ranks); same batch per GPU"}
+            del table7, run7, st7, svi7
+            torch.cuda.empty_cache()
+
+        # ---------------------------------------------------------------- the same kernel in the throughput regime
+        # (context for `frac`: at batch 4096 a step is latency-bound by the cross-workgroup exchange; at batch 32768 = 8
+        # examples per wave the kernel is bound by its own instruction issue)
+        if roofline is not None and single and not args.no_large_batch and args.sampler == "feistel":
+            Bl = 32768
+            svi_l, st_l, _, (Xl, yl), bkey_l = make_workload(args.rows_per_gpu)
+            _, gb_l = subsample_batchify_data((Xl, yl), Bl)
+            st_l, _ = svi_l.run_steps(st_l, gb_l, bkey_l, 0, 64)
+            torch.cuda.synchronize()
+            L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(1))
+            svi_l.run_steps(st_l, gb_l, bkey_l, 64, 320)
+            torch.cuda.synchronize()
+            L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(0))
+            us_l, n_l, steps_l = read_kernel_timing()
+            if steps_l:
+                ach = algorithmic_bytes(Bl, d, P) * steps_l / (us_l * 1e-6) / 1e9
+                roofline["large_batch"] = {"batch": Bl, "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBPS, 4),
+                                           "kernel_us_per_step": round(us_l / steps_l, 3),
+                                           "note": "same kernel and method, 320 steps at batch 32768 on one GPU (8 examples per "
+                                                   "wave): the instruction-issue regime of the fused step with JAX-faithful noise"}
+            del Xl, yl, gb_l, st_l, svi_l
+        if rank != 0:
+            return None
+        return {"value": round(Bg * steps_per_s, 1), "steps_per_sec": round(steps_per_s, 2),
+                "ms_per_step": round(1000.0 * elapsed / args.steps, 6), "final_loss": final_loss, "steady_state": steady,
+                "north_star_N1e7": north, "roofline": roofline, "rows": n_rows,
+                "driver": "single-GPU chained launch" if single else ("native" if (native and comm is not None) else "torch")}
+
+    def line(m, cpu=None, extra=None):
         out = {
             "metric": "DP-VI per-example grads/sec (logreg d=512 B=4096/GPU, AutoDiagonalNormal); steps/sec in steps_per_sec",
-            "value": round(Bg * steps_per_s, 1), "unit": "examples/s",
-            "steps_per_sec": round(steps_per_s, 2),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1000.0 * elapsed / args.steps, 6),
+            "value": m["value"], "unit": "examples/s", "steps_per_sec": m["steps_per_sec"],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: logistic regression d=512, 1e6 rows per GPU (fp32, HBM-resident), "
                                    "batch 4096 per GPU by " + ("Feistel subsampling w/o replacement" if args.sampler == "feistel" else
                                                           "Poisson sampling q = B/N padded to the 0.99 quantile") + ", AutoDiagonalNormal, "
                                    "C=1, sigma=1, Adam 1e-3",
-                       "rows": n_rows, "dim": d, "global_batch": Bg, "parallelism": f"dp{world}",
-                       "collective": "none" if world == 1 else "1 all-reduce(sum) per step of the int64 fixed-point accumulator, 4 x (2D+2) words (RCCL); driver: " + dist_driver},
-            "final_loss": final_loss,
-            "roofline": roofline,
-            "cpu_baseline": cpu,
+                       "rows": m["rows"], "dim": d, "global_batch": Bg, "parallelism": f"dp{world}",
+                       "collective": "none" if world == 1 else "1 sum-exchange per step of the rank's int64 fixed-point accumulator "
+                                                               "(d3p_amd.dist); driver: " + m["driver"]},
+            "final_loss": m["final_loss"], "steady_state": m["steady_state"], "north_star_N1e7": m["north_star_N1e7"],
+            "roofline": m["roofline"], "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        if extra:
+            out.update(extra)
+        return json.dumps(out)
+
+    extra = None
+    if single or comm is None:
+        m = measure(False, not args.no_extra_legs)
+    else:
+        # Data-parallel run with the native loop available.  The Python-driven loop (torch.distributed's own RCCL) is
+        # measured FIRST and kept as the fallback line: should the native loop stall on some rank, a watchdog prints that
+        # line and ends the process instead of leaving the driver without a number.
+        fb = measure(False, False)
+        import threading
+
+        def give_up():
+            if rank == 0:
+                print(line(fb, extra={"note": "native data-parallel loop did not finish within the watchdog limit; this is "
+                                              "the Python-driven torch.distributed loop"}), flush=True)
+            os._exit(0)
+        dog = threading.Timer(float(os.environ.get("D3P_BENCH_WATCHDOG_S", "240")), give_up)
+        dog.daemon = True
+        dog.start()
+        m = measure(True, not args.no_extra_legs)
+        barrier()
+        dog.cancel()
+        if rank == 0:
+            extra = {"torch_loop": {"steps_per_sec": fb["steps_per_sec"], "value": fb["value"],
+                                    "note": "same steps driven from Python through torch.distributed.all_reduce"}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(d, args.batch_per_gpu, args.cpu_seconds, rows=200_000)
+
+    if dist.is_initialized():
+        dist.barrier()
+        if comm is not None:
+            comm.close()
+        dist.destroy_process_group()
+    elif comm is not None:
+        comm.close()
+    if rank == 0:
+        print(line(m, cpu, extra), flush=True)
 
 
 if __name__ == "__main__":

@@ -140,6 +140,7 @@ SIGNATURES = {
     "d3p_dpvi_vae_local_sums": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _U32, _U32, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_vae_apply": (C.c_int, [_V, _V, _V, _V, _V, _U32, _U32, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_logreg_chain_status": (C.c_int, [_V, _V, _V, _V, C.c_size_t, _V]),
+    "d3p_dpvi_logreg_run_status": (C.c_int, [_V, _V, _V, _V, C.c_size_t, _V, _V]),
     "d3p_dpvi_logreg_kernel_timing_enable": (C.c_int, [C.c_int]),
     "d3p_dpvi_logreg_kernel_timing_read": (C.c_int, [_V, _V, _V]),
     "d3p_comm_unique_id": (C.c_int, [_V, C.c_size_t]),
@@ -186,7 +187,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.d3p_abi_version() != 2:
+        if lib.d3p_abi_version() != 3:
             raise D3PError("libd3p_hip.so ABI version mismatch")
         _lib = lib
     return _lib

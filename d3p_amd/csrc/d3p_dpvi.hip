@@ -493,8 +493,11 @@ static int validate(const d3p_logreg_model* m, const d3p_dpsvi_hyper* h, const d
     D3P_REQUIRE(m->d >= 1, "model.d must be >= 1");
     D3P_REQUIRE(m->prior_w > 0.f && m->prior_b > 0.f, "prior scales must be positive");
     D3P_REQUIRE(m->inv_obs > 0.f, "inv_obs must be positive");
-    D3P_REQUIRE(h->clip != 0.f, "The clipping threshold must be greater than 0.");  // svi.py:119-120
+    // svi.py:119-120 rejects C == 0; a negative C would turn 1 / max(1, norm / C) into "no clipping at all" there and
+    // flip every clipped gradient here, so C <= 0 is refused altogether (as the mixture-model and VAE entry points do)
+    D3P_REQUIRE(h->clip > 0.f || std::isnan(h->clip), "The clipping threshold must be greater than 0.");
     D3P_REQUIRE(std::isfinite(h->clip), "clipping_threshold must be finite!");       // svi.py:187-188
+    D3P_REQUIRE(std::isfinite(h->dp_scale) && h->dp_scale >= 0.f, "dp_scale must be finite and >= 0");
     D3P_REQUIRE(st->rng_key && st->params && st->adam_m && st->adam_v && st->step, "null state pointer");
     D3P_REQUIRE(src->B >= 1, "batch size must be >= 1");
     D3P_REQUIRE(src->kind == D3P_BATCH_EXPLICIT || src->kind == D3P_BATCH_FEISTEL || src->kind == D3P_BATCH_POISSON,
@@ -516,6 +519,9 @@ static inline int bit_length_u32(uint32_t v)
     while (v) { ++b; v >>= 1; }
     return b;
 }
+
+// the run's sticky status words (StepFuse::status): behind the arrival counters of the chained launch
+static inline uint32_t* run_status_words(const Workspace& ws) { return ws.chain_bar + (size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS; }
 
 // D3P_DBG: developer ablation / phase-stamp switches of the step kernel (0 in production); read once per process
 static int dev_dbg_flags()
@@ -745,6 +751,7 @@ static void fill_fuse_common(const Ctx& c, StepFuse* f, int g)
     f->adam_eps = c.h->adam_eps;
     f->prior_w = c.m->prior_w;
     f->prior_b = c.m->prior_b;
+    f->status = run_status_words(c.ws);
     // gradient columns: every workgroup partial is bounded by 16 * C per step, sums by B * C -> 2^40 / C keeps
     // B up to 2^22 inside int64 with a resolution of C * 2^-40
     f->sg = 1099511627776.0 / (double)fabsf(c.h->clip);
@@ -880,7 +887,7 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
     cf.state[1][0] = c.ws.pp_state; cf.state[1][1] = c.ws.pp_state + P; cf.state[1][2] = c.ws.pp_state + 2 * P;
     cf.losses = losses;
     cf.bar = c.ws.chain_bar;
-    cf.abort_flag = c.ws.chain_bar + (size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS;
+    cf.abort_flag = run_status_words(c.ws);
     cf.chain_slots = chain_slots;
     cf.K_next = chain_slots ? K_next : 0;
     // arrival counters of this launch (the abort flag behind them is sticky for the whole run)
@@ -930,7 +937,7 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
         // generate its noise in the loop): 63.2 -> 68.6 k steps/s at q = 4096 / 1e6.
         if (!off && c.g.full && c.g.V == 4 && c.g.NK == 1 && c.g.W == 16 && (uint64_t)c.src->B <= 18ull * c.g.blocks) {
             g2.W = 8;
-            g2.lds = (size_t)(((5 * c.D + 3) & ~3) + g2.W * c.P + 2 * g2.W) * sizeof(float);
+            g2.lds = main_lds_bytes(c.D, g2.W);
             cf.pregen = 1;
         }
     }
@@ -1025,7 +1032,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     const bool persist = chained && use_persistent_steps(c);
     // the abort flag of the bounded waits: cleared once per run (whatever form the steps take), read back by
     // d3p_dpvi_logreg_chain_status
-    D3P_HIP_TRY(hipMemsetAsync(c.ws.chain_bar + (size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS, 0, 16 * sizeof(uint32_t), c.s));
+    D3P_HIP_TRY(hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s));
     for (uint32_t b = 0; b < n_batches; ++b) {
         const int cur = (int)(b & 1), nxt = cur ^ 1;
         const int K = batch_len(b), K_next = (b + 1 < n_batches) ? batch_len(b + 1) : 0;
@@ -1248,6 +1255,7 @@ int d3p_dpvi_logreg_acc_reset(void* stream, const d3p_logreg_model* model, const
     int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
     if (rc) return rc;
     D3P_HIP_TRY(hipMemsetAsync(c.ws.acc, 0, 3 * (size_t)D3P_ACC_R * (c.P + 2) * sizeof(long long), c.s));
+    D3P_HIP_TRY(hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s));
     return D3P_OK;
 }
 
@@ -1421,6 +1429,21 @@ int d3p_dpvi_logreg_chain_status(void* stream, const d3p_logreg_model* model, co
     return D3P_OK;
 }
 
+int d3p_dpvi_logreg_run_status(void* stream, const d3p_logreg_model* model, const d3p_batch_source* src, void* workspace_dev,
+                               size_t workspace_bytes, int32_t* aborted_out, int32_t* nonfinite_out)
+{
+    D3P_REQUIRE(model && src && workspace_dev && aborted_out && nonfinite_out, "d3p_dpvi_logreg_run_status: null pointer");
+    if (workspace_bytes < d3p_dpvi_logreg_workspace(model, src)) return fail(D3P_E_WORKSPACE, "workspace too small");
+    Workspace ws;
+    carve(model, src, (char*)workspace_dev, &ws);
+    uint32_t words[2] = {0u, 0u};
+    D3P_HIP_TRY(hipMemcpyAsync(words, run_status_words(ws), sizeof(words), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    D3P_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    *aborted_out = (int32_t)words[0];
+    *nonfinite_out = (int32_t)words[1];
+    return D3P_OK;
+}
+
 int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
                                      const d3p_dpsvi_state* state, const d3p_batch_source* src, const float* X_dev,
                                      const float* y_dev, void* workspace_dev, size_t workspace_bytes, int reps,
@@ -1442,6 +1465,7 @@ int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model
         D3P_HIP_TRY(hipMemcpyAsync(c.ws.scratch_state + P, c.st->adam_m, P * sizeof(float), hipMemcpyDeviceToDevice, c.s));
         D3P_HIP_TRY(hipMemcpyAsync(c.ws.scratch_state + 2 * P, c.st->adam_v, P * sizeof(float), hipMemcpyDeviceToDevice, c.s));
         D3P_HIP_TRY(hipMemsetAsync(c.ws.acc, 0, 3 * (size_t)D3P_ACC_R * (P + 2) * sizeof(long long), c.s));
+        D3P_HIP_TRY(hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s));
         st_scratch.params = c.ws.scratch_state;
         st_scratch.adam_m = c.ws.scratch_state + P;
         st_scratch.adam_v = c.ws.scratch_state + 2 * P;

@@ -12,6 +12,9 @@ namespace d3p {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// LDS of k_logreg_main: derived columns (5 x D) | W x P reduction rows | 2W loss/count tail | 4 status words
+static inline size_t main_lds_bytes(int D, int W) { return (size_t)(((5 * D + 3) & ~3) + W * 2 * D + 2 * W + 4) * sizeof(float); }
+
 #define D3P_MAIN_MAX_BLOCKS 2048u
 
 // ------------------------------------------------------------------------------------------
@@ -156,16 +159,21 @@ __device__ __forceinline__ bool chain_wait(const uint32_t* p, uint32_t target, u
 }
 
 // bounded wait, made by a whole wavefront, until the `ngroups` group flags (one per 128-byte line) are all set: lane g polls
-// the flag of group g -- one load instruction per round
+// the flag of group g and lane `ngroups` the run's abort flag -- one load instruction per round.  false when the bound is hit
+// or the abort flag is (or becomes) set: the caller must then leave without applying or publishing anything.
+// flags == nullptr: nothing to wait for (first step of a launch), only the abort flag is looked at.
 __device__ __forceinline__ bool chain_wait_groups(const uint32_t* flags, uint32_t ngroups, uint32_t* abort_flag)
 {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t spins = 0;; ++spins) {
-        const uint32_t v = lane < ngroups ? __hip_atomic_load(flags + D3P_BAR_LINE * lane, __ATOMIC_RELAXED, D3P_AGENT) : 1u;
-        if (__ballot(v == 0u) == 0ull) return true;
-        const bool give_up = spins > (1u << 21) ||
-                             ((spins & 63u) == 63u && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, D3P_AGENT) != 0u);
-        if (give_up) {
+        uint32_t v = 1u;
+        if (lane < ngroups && flags) v = __hip_atomic_load(flags + D3P_BAR_LINE * lane, __ATOMIC_RELAXED, D3P_AGENT);
+        else if (lane == ngroups) v = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, D3P_AGENT);
+        const unsigned long long zero = __ballot(v == 0u);
+        const bool aborted = ((zero >> ngroups) & 1ull) == 0ull;  // lane `ngroups` read a non-zero abort flag
+        if (aborted) return false;
+        if ((zero & ((1ull << ngroups) - 1ull)) == 0ull) return true;
+        if (spins > (1u << 21)) {
             if (lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, D3P_AGENT);
             return false;
         }
@@ -238,6 +246,11 @@ struct StepFuse {
     float prior_w, prior_b;
     double sg, inv_sg;           // fixed-point scale of the gradient columns (2^40 / C) and its inverse
     double sl, inv_sl;           // fixed-point scale of the loss column
+    // run status (sticky, cleared once per run, read back by d3p_dpvi_logreg_run_status): [0] a bounded wait of the chained
+    // launch ran out (the run stops advancing: no workgroup applies or publishes anything any more), [1] a workgroup
+    // partial was not finite or left the fixed-point range (the next update turns the parameters and the loss into NaN, as
+    // the reference's float arithmetic would)
+    uint32_t* status;
     // piggy-backed key-chain step of the next batch (extra workgroup), nullable
     Sched* chain_sched;
     StepSlot* chain_slot;
@@ -367,6 +380,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         f.prev_noise = step_t > 0 ? cf.noise_base + (size_t)(step_t - 1) * Pc : cf.prev_noise0;
         f.prev_loss_out = (cf.losses && g > 0) ? cf.losses + (g - 1) : nullptr;
         f.flush_only = 0;
+        f.status = cf.abort_flag;
         f.chain_slot = step_t < cf.K_next ? cf.chain_slots + step_t : nullptr;
         f.chain_t = step_t;
         f.chain_last = step_t == cf.K_next - 1;
@@ -392,6 +406,8 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
     // prologue runs in one piece.
     long long pend_n8[D3P_ACC_R];
     float pend_bc1 = 1.f, pend_bc2 = 1.f;
+    // per-polling-wave verdicts of the chained launch's wait (see finish_prologue): 4 words behind the loss / count tail
+    auto okw = [&]() { return reinterpret_cast<uint32_t*>(red + (size_t)W * P + 2 * W); };
     if (FUSE) {
         const StepFuse& f = a.fuse;
         const int PA = P + 2;
@@ -412,9 +428,11 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         }
         // zero the accumulator of the NEXT step (last read one step ago, never touched in this one).  Chained form: the
         // workgroups of step t - 1 may still be reading it in their prologue, so it is zeroed after the wait below.
+        // (grid-stride over the COMPUTE workgroups: a small grid -- few examples per rank, wide rows -- has fewer threads than
+        // accumulator words, and words left uncleared would keep the sums of step g - 3, the count column included)
         if (!CHAIN) {
-            const int i = bid * blockDim.x + threadIdx.x;
-            if (i < D3P_ACC_R * PA) f.acc_next[i] = 0;
+            const int ncomp = (int)nblk - (f.chain_slot ? 1 : 0);
+            for (int i = bid * blockDim.x + threadIdx.x; i < D3P_ACC_R * PA; i += ncomp * (int)blockDim.x) f.acc_next[i] = 0;
         }
     } else {
         for (int i = threadIdx.x; i < 5 * D; i += blockDim.x) pk[i] = a.pack[i];
@@ -434,38 +452,50 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         }
     };
     bool prologue_done = false;
-    auto finish_prologue = [&]() {
-        if (!FUSE || prologue_done) return;
+    // returns true when the run was aborted and this WHOLE workgroup knows it (pipelined form); the 16-wave form learns it
+    // behind the staging barrier (stage_aborted)
+    auto finish_prologue = [&]() -> bool {
+        if (!FUSE || prologue_done) return false;
         prologue_done = true;
         const StepFuse& f = a.fuse;
         const int PA = P + 2;
         const bool all_waves = CHAIN && a.chain.pregen && !f.flush_only && !(a.dbg & 128);
+        // ---- run status first: an aborted run (a bounded wait ran out somewhere) must not advance any further
+        if (CHAIN) {
+            // every workgroup of the previous step must have added its sums (and published the state) before the
+            // prologue reads them; the first step of a launch follows a kernel boundary instead (then only the abort flag
+            // is looked at).  Pipelined form: every wave has prepared its examples already, so ONE wave polls and, behind a
+            // workgroup barrier, all waves share the prologue; 16-wave form: each of the (up to 4) prologue waves polls for
+            // itself.  The last arriver of each group sets that group's flag; a waiter polls all of them at once.
+            const int PWc = all_waves ? W : (W < 4 ? W : 4);
+            if (all_waves ? wave == 0 : wave < PWc) {
+                const bool ok = chain_wait_groups(
+                    step_t > 0 ? a.chain.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS) : nullptr,
+                    (uint32_t)a.chain.nw < D3P_BAR_GROUPS ? (uint32_t)a.chain.nw : D3P_BAR_GROUPS, a.chain.abort_flag);
+                if (lane == 0) okw()[wave] = ok ? 0u : 1u;
+                if (!ok && !all_waves) return false;  // (the other waves learn it behind the staging barrier, see stage_aborted)
+            }
+            if (all_waves) {
+                __syncthreads();
+                if (okw()[0] != 0u) return true;
+            }
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            if ((a.dbg & 32) && a.stamps && threadIdx.x == 0) a.stamps[8 * bid + 7] = wall_clock64();  // release seen
+        } else if (f.status && __hip_atomic_load(f.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) {
+            // (flush launch behind an aborted chained launch: the pending sums are incomplete)
+            if (bid == 0 && threadIdx.x == 0 && f.prev_loss_out) *f.prev_loss_out = __builtin_nanf("");
+            return true;
+        }
         if (!f.apply_prev) {  // no pending update: derive the columns from the parameters as they are
             if (CHAIN)  // (first step of a run) nobody reads the next accumulator yet
                 for (int i = bid * blockDim.x + threadIdx.x; i < D3P_ACC_R * PA; i += a.chain.nw * blockDim.x)
                     st_x<true>(f.acc_next + i, 0ll);
             for (int col = threadIdx.x; col < P; col += blockDim.x) pack_column(col, f.params_in[col]);
-            return;
+            return false;
         }
         if (CHAIN) {
-            // every workgroup of the previous step must have added its sums (and published the state) before the
-            // prologue reads them; the first step of a launch follows a kernel boundary instead
-            // (pipelined form: every wave has prepared its examples already, so ONE lane polls and, behind a workgroup
-            // barrier, all waves share the prologue)
-            const int PWc = all_waves ? W : (W < 4 ? W : 4);
-            const bool flat = !(a.dbg & 512);  // the last arriver of each group sets that group's flag; waiters poll all of them
-            if (flat) {
-                if (step_t > 0 && (all_waves ? wave == 0 : wave < PWc))
-                    (void)chain_wait_groups(a.chain.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS),
-                                            (uint32_t)a.chain.nw < D3P_BAR_GROUPS ? (uint32_t)a.chain.nw : D3P_BAR_GROUPS,
-                                            a.chain.abort_flag);
-            } else if (step_t > 0 && (all_waves ? threadIdx.x == 0 : (wave < PWc && lane == 0)))  // the release word of this workgroup's group
-                (void)chain_wait(a.chain.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS + (bid % D3P_BAR_GROUPS)), 1u,
-                                 a.chain.abort_flag);
-            if (all_waves) __syncthreads();
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            if ((a.dbg & 32) && a.stamps && threadIdx.x == 0) a.stamps[8 * bid + 7] = wall_clock64();  // release seen
             // now nobody reads the next accumulator any more (the previous step's prologues are over): zero it
+            const int PWc = all_waves ? W : (W < 4 ? W : 4);
             if (wave < PWc)
                 for (int i = bid * (64 * PWc) + (int)threadIdx.x; i < D3P_ACC_R * PA; i += a.chain.nw * 64 * PWc)
                     st_x<true>(f.acc_next + i, 0ll);
@@ -486,7 +516,9 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             long long nll = 0;
 #pragma unroll
             for (int r = 0; r < D3P_ACC_R; ++r) nll += pend_n8[r];
-            return (float)nll;
+            // a workgroup that saw a non-finite partial also added 2^44 to the count column: NaN count -> NaN gradient,
+            // parameters and loss (what the reference's float sums give), never finite garbage
+            return nll >= (1ll << 40) ? __builtin_nanf("") : (float)nll;
         };
         {
             // Only the first PW waves (one per SIMD) run the prologue, CB columns per thread with all loads in
@@ -639,6 +671,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             *f.adam_step = f.prev_meta->adam_i + 1;
             if (f.batch_index) *f.batch_index = f.prev_meta->batch_i + 1u;
         }
+        return false;
     };
     // the 4 waves (one per SIMD) that apply the pending update in finish_prologue()  (s_setprio on them was measured to
     // change nothing: the SIMD shares its issue slots evenly whatever the priority)
@@ -782,21 +815,33 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         if (cur.live) gen(cur.k0, cur.k1, er);
         if (have_pre && pre.live) gen(pre.k0, pre.k1, er + D);
     }
+    // After a staging barrier every wave looks at the verdicts of the polling waves: an aborted run leaves here, as a whole
+    // workgroup, before it adds or arrives anywhere.
+    const bool all_waves_k = CHAIN && a.chain.pregen && !a.fuse.flush_only && !(a.dbg & 128);
+    auto stage_aborted = [&]() {
+        uint32_t bad = okw()[0];
+        if (!all_waves_k)
+            for (int w = 1; w < (W < 4 ? W : 4); ++w) bad |= okw()[w];
+        return bad != 0u;
+    };
+#define D3P_STAGE_SYNC()                          \
+    do {                                          \
+        __syncthreads();                          \
+        staged = true;                            \
+        if (CHAIN && stage_aborted()) return;     \
+    } while (0)
     if (FUSE) {
-        finish_prologue();
+        const bool aborted = finish_prologue();
         D3P_STAMP(2)
-        if (a.fuse.flush_only) return;
+        if (a.fuse.flush_only || aborted) return;  // (aborted: uniform, decided behind the workgroup barrier of the poll)
     }
     // The derived columns are first needed AFTER the noise of the first example has been generated, so for the waves that
     // do not run the prologue the staging barrier sits behind that phase.  The prologue waves arrive at the barrier as
     // soon as the columns are in LDS -- BEFORE generating their own noise: the other 12 waves then start their arithmetic
     // ~1.8 us earlier and the prologue waves' noise generation overlaps with it (every wave passes exactly one barrier).
     bool staged = false;
-    if ((prologue_wave || pregen) && p < n_items) {
-        __syncthreads();
-        staged = true;
-    }
-    if (!(p < n_items)) { finish_prologue(); __syncthreads(); staged = true; }
+    if ((prologue_wave || pregen) && p < n_items) D3P_STAGE_SYNC();
+    if (!(p < n_items)) { finish_prologue(); D3P_STAGE_SYNC(); }
 
     while (p < n_items) {
         const uint32_t pn = p + total_waves;
@@ -851,7 +896,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                 }
             }
             D3P_STAMP(3)
-            if (!staged) { finish_prologue(); __syncthreads(); staged = true; }
+            if (!staged) { finish_prologue(); D3P_STAGE_SYNC(); }
             // ---- z = loc + s * eps, logit t = x . z   (derived columns come from LDS)
             float z0[NC], z1[NC];
             float tp = 0.f;
@@ -948,7 +993,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                 if (lane == 0) a.px_loss[p] = L * m * a.obs_scale * a.meta[1];  // svi.py:306
             }
         }
-        if (!staged) { finish_prologue(); __syncthreads(); staged = true; }  // example skipped before reaching the barrier
+        if (!staged) { finish_prologue(); D3P_STAGE_SYNC(); }  // example skipped before reaching the barrier
         cur = nxt;
         p = pn;
         ++it;
@@ -970,19 +1015,27 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         D3P_STAMP(6)
         if (FUSE) {
             // fixed-point integer atomics: exact, order-independent sum of the workgroups' fp32 partials
+            // (a partial that is not finite, or whose fixed-point image leaves +-2^52 -- 2048 of those still fit int64 --,
+            // raises status[1]: the next prologue then yields NaN like the reference's float sums, instead of finite garbage)
             long long* out = a.fuse.acc_cur + (size_t)(bid % D3P_ACC_R) * (P + 2);
+            bool bad = false;
             for (int c = threadIdx.x; c < P; c += blockDim.x) {
                 float s = 0.f;
                 for (int w = 0; w < W; ++w) s += red[(size_t)w * P + c];
-                atomicAdd(reinterpret_cast<unsigned long long*>(out + c),
-                          (unsigned long long)__double2ll_rn((double)s * a.fuse.sg));
+                const double sd = (double)s * a.fuse.sg;
+                bad |= !(fabs(sd) < 4503599627370496.0);
+                atomicAdd(reinterpret_cast<unsigned long long*>(out + c), (unsigned long long)__double2ll_rn(sd));
             }
             if (threadIdx.x < 2) {
                 float s = 0.f;
                 for (int w = 0; w < W; ++w) s += tail[2 * w + threadIdx.x];
-                const double sc = threadIdx.x == 0 ? a.fuse.sl : 1.0;
-                atomicAdd(reinterpret_cast<unsigned long long*>(out + P + threadIdx.x),
-                          (unsigned long long)__double2ll_rn((double)s * sc));
+                const double sd = (double)s * (threadIdx.x == 0 ? a.fuse.sl : 1.0);
+                bad |= !(fabs(sd) < 4503599627370496.0);
+                atomicAdd(reinterpret_cast<unsigned long long*>(out + P + threadIdx.x), (unsigned long long)__double2ll_rn(sd));
+            }
+            if (bad) {  // (rare path) poison the count column, see count_n; at most 2^18 of these per step -> still inside int64
+                atomicAdd(reinterpret_cast<unsigned long long*>(out + P + 1), 1ull << 44);
+                if (a.fuse.status) __hip_atomic_store(a.fuse.status + 1, 1u, __ATOMIC_RELAXED, D3P_AGENT);
             }
             if (CHAIN) {
                 // arrive: this workgroup's atomics (and, for workgroup 0, the published state and the zeroed accumulator)
@@ -993,16 +1046,8 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                     uint32_t* bar = a.chain.bar + (size_t)step_t * D3P_BAR_WORDS;
                     const uint32_t nw = (uint32_t)a.chain.nw, grp = bid % D3P_BAR_GROUPS, gsize = (nw + D3P_BAR_GROUPS - 1u - grp) / D3P_BAR_GROUPS;
                     const uint32_t prev = __hip_atomic_fetch_add(bar + D3P_BAR_LINE * (1 + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
-                    if (prev + 1u == gsize) {
-                        if (!(a.dbg & 512)) {  // flat: this group's flag; the waiters poll the flags of all groups
-                            __hip_atomic_store(bar + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
-                        } else {
-                            const uint32_t top = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, D3P_AGENT);
-                            if (top + 1u == (nw < D3P_BAR_GROUPS ? nw : D3P_BAR_GROUPS))
-                                for (uint32_t g8 = 0; g8 < D3P_BAR_GROUPS; ++g8)
-                                    __hip_atomic_store(bar + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS + g8), 1u, __ATOMIC_RELAXED, D3P_AGENT);
-                        }
-                    }
+                    if (prev + 1u == gsize)  // this group's flag; the waiters poll the flags of all groups
+                        __hip_atomic_store(bar + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
                 }
             }
         } else {
@@ -1026,6 +1071,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
     }
 }
 
+#undef D3P_STAGE_SYNC
 #define D3P_FIN_COLS 32
 #define D3P_FIN_ROWG 8
 
@@ -1130,7 +1176,7 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g, boo
         if (env_w >= 1 && env_w <= (g->NK == 1 ? 16 : g->NK == 2 ? 8 : 4)) W = env_w;
         if (env_epw >= 1 && env_epw <= 64) epw = env_epw;
     }
-    auto lds_bytes = [&](int w) { return (size_t)(((5 * D + 3) & ~3) + w * P + 2 * w) * sizeof(float); };
+    auto lds_bytes = [&](int w) { return main_lds_bytes(D, w); };
     // (the scalar-load V = 1, NK = 8 form does not spill and beats the chunked kernel: d = 512 + intercept 32 vs 94 us/step)
     g->wide = wide_ok && (too_wide || (g->V == 4 && g->NK == 8));  // accumulator rows only (derived columns come from the global pack): 4 waves
     if (!g->wide) {

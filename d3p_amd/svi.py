@@ -168,6 +168,12 @@ class DPSVI:
         self._clip_unscaled_observations = clip_unscaled_observations
         if not np.isfinite(clipping_threshold):
             raise ValueError("clipping_threshold must be finite!")
+        # (the reference only rejects C == 0, at the first clip_gradient call, svi.py:119-120; a negative C would disable
+        # clipping there -- this build refuses C <= 0 and a negative / non-finite noise scale up front)
+        if clipping_threshold < 0:
+            raise ValueError("The clipping threshold must be greater than 0.")
+        if not (np.isfinite(dp_scale) and dp_scale >= 0):
+            raise ValueError("dp_scale must be finite and >= 0")
         self.model = model
         self.guide = guide
         self.optim = optim
@@ -673,12 +679,17 @@ class DPSVI:
         return new_state, loss[0]
 
     # ---------------------------------------------------------------- fused multi-step loop
-    def run_steps(self, svi_state, get_batch, batchifier_state, first_batch, num_steps, **kwargs):
+    def run_steps(self, svi_state, get_batch, batchifier_state, first_batch, num_steps, check_status=True, **kwargs):
         """``num_steps`` x (get_batch(i, batchifier_state) -> update) for i = first_batch..., enqueued
         back to back on the device: the body of the reference's ``jit(lax.fori_loop(...))`` epoch
         (examples/logistic_regression.py:149-160).  ``get_batch`` must come from
         ``subsample_batchify_data`` (without replacement) or ``poisson_batchify_data``.
-        Returns ``(new_state, losses[num_steps])``."""
+        Returns ``(new_state, losses[num_steps])``.
+
+        ``check_status`` (default): synchronise the stream once after the run and read the run's status words
+        (``d3p_dpvi_logreg_run_status``); a run whose chained launch was aborted by a bounded wait raises ``D3PError``
+        instead of returning a silently truncated trajectory.  ``check_status=False`` keeps the call asynchronous; the
+        caller then checks with ``DPSVI.last_run_status()`` before trusting the result."""
         if self._gmm_fusable():
             return self._run_steps_gmm(svi_state, get_batch, batchifier_state, first_batch, num_steps, **kwargs)
         if not self._fusable():
@@ -709,8 +720,27 @@ class DPSVI:
         losses = torch.empty(max(num_steps, 1), dtype=torch.float32, device=dev)
         check(lib.d3p_dpvi_logreg_run(stream_ptr(), C.byref(model), C.byref(hyper), C.byref(st), C.byref(src),
                                       ptr(X), ptr(y), int(num_steps), ptr(losses), ptr(ws), ws.numel()))
+        self._last_run = (model, src, ws, (bkey, bidx))   # what last_run_status() needs (keeps the buffers alive)
+        if check_status:
+            aborted, _ = self.last_run_status()
+            if aborted:
+                raise _lib.D3PError("run_steps: a bounded wait of the chained launch ran out (the step kernel's workgroups "
+                                    "did not make progress); the run was stopped and its state and losses are invalid")
         new_key = keybuf[num_steps & 1].reshape(4, 4)
         return DPSVIState((step, params, m, v), new_key, svi_state.observation_scale), losses[:num_steps]
+
+    def last_run_status(self):
+        """(aborted, nonfinite) of the last ``run_steps`` call, after synchronising the stream: ``aborted`` -- a bounded
+        wait of the chained launch ran out and the run stopped advancing; ``nonfinite`` -- a partial sum was NaN / Inf, so
+        parameters and losses turned NaN from that step on (the reference's float sums do the same)."""
+        last = getattr(self, "_last_run", None)
+        if last is None:
+            return False, False
+        model, src, ws, _ = last
+        aborted, nonfinite = C.c_int32(0), C.c_int32(0)
+        check(_lib.load().d3p_dpvi_logreg_run_status(stream_ptr(), C.byref(model), C.byref(src), ptr(ws), ws.numel(),
+                                                     C.byref(aborted), C.byref(nonfinite)))
+        return bool(aborted.value), bool(nonfinite.value)
 
     # ---------------------------------------------------------------- evaluate / accounting
     def evaluate(self, svi_state, *args, **kwargs):

@@ -34,7 +34,7 @@ extern "C" {
 #define D3P_E_UNSUPPORTED (-3)
 #define D3P_E_WORKSPACE (-4)
 
-#define D3P_ABI_VERSION 2
+#define D3P_ABI_VERSION 3
 
 int d3p_abi_version(void);
 const char* d3p_last_error(void);
@@ -396,6 +396,16 @@ int d3p_dpvi_gmm_apply(void* stream, const d3p_gmm_model* model, const d3p_dpsvi
  * wait of the last run hit its bound (aborted_out != 0: the results of that run are invalid). */
 int d3p_dpvi_logreg_chain_status(void* stream, const d3p_logreg_model* model, const d3p_batch_source* src,
                                  void* workspace_dev, size_t workspace_bytes, int32_t* aborted_out);
+
+/* ABI 3: both sticky status words of the last run, after synchronising `stream`.
+ *   aborted_out   != 0: a bounded wait of the chained launch ran out; from then on no workgroup applied, published or
+ *                       arrived anywhere, i.e. the run stopped advancing -- state and losses of that run are invalid
+ *                       (d3p_amd.svi.DPSVI.run_steps raises D3PError).
+ *   nonfinite_out != 0: a workgroup partial was NaN / Inf or left the fixed-point range of the accumulator; the update that
+ *                       followed turned the parameters and the loss into NaN, which is what the reference's float sums
+ *                       (svi.py:342-346) give for a diverged model -- never finite garbage. */
+int d3p_dpvi_logreg_run_status(void* stream, const d3p_logreg_model* model, const d3p_batch_source* src,
+                               void* workspace_dev, size_t workspace_bytes, int32_t* aborted_out, int32_t* nonfinite_out);
 
 /* Measurement hook for the run loops (d3p_dpvi_logreg_run, d3p_dpvi_logreg_run_dist): while enabled, every launch of the
  * step kernel is bracketed by HIP start/stop events on the launch stream (hipExtLaunchKernel).

@@ -674,6 +674,116 @@ D3P_API float d3po_logreg_update(const d3po_logreg_spec* sp, const d3po_dpsvi_hy
     return loss;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * bench.py's cpu_baseline ("port"): `steps` consecutive DPSVI.update calls (svi.py:395-434) on Feistel minibatches
+ * (minibatch.py:217-237: fold_in, sample_from_array, take) drawn from a RESIDENT table, entirely in C -- no numpy gather,
+ * no Python between steps -- on `threads` OpenMP threads (1 = the single-thread figure SURVEY 8(d) asks for).
+ * The dataflow is the reference's, stage by stage: gather the batch (`jnp.take`: B x d copied), per-example noise from
+ * the threefry keys (:289-290), per-example gradients MATERIALISED as a B x P tensor (what jax.vmap yields, :299), a
+ * clipping pass over its rows (:321), the mean over the batch axis (:343), perturbation (:470-498), Adam (:379-393).
+ * Arithmetic is float32 like the reference's; the per-column guide terms softplus(u), sigmoid(u), log s are computed once
+ * per step (XLA hoists them out of the vmapped body), unlike d3po_logreg_px_loss_grad above, which is the accurate
+ * float64 checker and recomputes them per example.  Logistic regression without intercept, softplus guide.
+ * tests/test_oracle_pins.py checks this loop against the step-by-step composition of the checker functions.
+ * scratch: B*d + B + B*2D + B + B*D + 8*D floats, idx: B words.  Returns the loss of the last step. */
+D3P_API float d3po_logreg_run_feistel(const d3po_logreg_spec* sp, const d3po_dpsvi_hyper* hy, uint32_t state_key[16],
+                                      float* params, float* adam_m, float* adam_v, int32_t* adam_step, const float* X,
+                                      const float* y, uint32_t n_rows, const uint32_t batch_key[16], uint32_t first_batch,
+                                      int B, int steps, int threads, float* scratch, uint32_t* idx)
+{
+    const int d = sp->d, D = d, P = 2 * D;
+    if (threads < 1) threads = 1;
+    float* Xb = scratch;
+    float* yb = Xb + (size_t)B * d;
+    float* px_grads = yb + B;
+    float* px_loss = px_grads + (size_t)B * P;
+    float* eps = px_loss + B;
+    float* col = eps + (size_t)B * D; /* s | sg | q | lc  (4D) */
+    float* avg = col + 4 * (size_t)D;
+    float* pert = avg + P;
+    const float inv_obs = sp->inv_obs, obs = 1.0f / sp->inv_obs;
+    const float c1 = inv_obs / (sp->prior_w * sp->prior_w), hz = 0.5f / (sp->prior_w * sp->prior_w);
+    const float A_scale = inv_obs * sp->lik_scale;
+    float loss = 0.0f;
+    for (int t = 0; t < steps; ++t) {
+        uint32_t ks[48], jaxkey[2], bk[16], rc[30];
+        d3po_split(state_key, 3, ks);
+        d3po_random_words(ks + 16, 0, 2, jaxkey);
+        d3po_fold_in(batch_key, first_batch + (uint32_t)t, bk);
+        d3po_feistel_constants(bk, rc);
+        const float* loc = params;
+        for (int j = 0; j < D; ++j) {
+            float s, sg;
+            guide_scale(sp, params[D + j], &s, &sg);
+            col[j] = s;
+            col[D + j] = sg;
+            col[2 * D + j] = inv_obs * sg / s;
+            col[3 * D + j] = logf(sp->prior_w) - logf(s);
+        }
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (int i = 0; i < B; ++i) {
+            /* minibatch.py:231-233: Feistel index, take */
+            const uint32_t r = d3po_feistel_permute(rc, n_rows, (uint32_t)i);
+            idx[i] = r;
+            memcpy(Xb + (size_t)i * d, X + (size_t)r * d, (size_t)d * sizeof(float));
+            yb[i] = y[r];
+        }
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (int i = 0; i < B; ++i) {
+            uint32_t sk[2];
+            d3po_px_sample_key(jaxkey, (uint32_t)B, (uint32_t)i, sk);
+            float* e = eps + (size_t)i * D;
+            d3po_tf_normal(sk, (uint64_t)D, e);
+            const float* x = Xb + (size_t)i * d;
+            float* g = px_grads + (size_t)i * P;
+            float tl = 0.0f, lp = 0.0f;
+            for (int j = 0; j < D; ++j) {
+                const float z = fmaf(col[j], e[j], loc[j]);
+                g[j] = z; /* z kept in the gradient row until the logit is known */
+                tl = fmaf(x[j], z, tl);
+                lp += fmaf(hz * z, z, fmaf(-0.5f * e[j], e[j], col[3 * D + j]));
+            }
+            const float A = A_scale * (sigmoid_f(tl) - yb[i]);
+            for (int j = 0; j < D; ++j) {
+                const float gz = fmaf(c1, g[j], A * x[j]);
+                g[j] = gz;
+                g[D + j] = fmaf(gz * e[j], col[D + j], -col[2 * D + j]);
+            }
+            const float loglik = yb[i] * tl - softplus_f(tl);
+            px_loss[i] = inv_obs * (lp - sp->lik_scale * loglik) * obs; /* factor = 1: no padding (svi.py:305-306) */
+        }
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (int i = 0; i < B; ++i) { /* svi.py:321: clip_gradient per row */
+            float* g = px_grads + (size_t)i * P;
+            float ss = 0.0f;
+            for (int j = 0; j < P; ++j) ss = fmaf(g[j], g[j], ss);
+            const float scale = 1.0f / fmaxf(1.0f, sqrtf(ss) / hy->clip);
+            for (int j = 0; j < P; ++j) g[j] *= scale;
+        }
+        /* svi.py:343-346: mean over the batch axis (threads own column blocks, rows streamed) */
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (int jb = 0; jb < P; jb += 64) {
+            float acc[64];
+            const int w = (P - jb) < 64 ? (P - jb) : 64;
+            for (int j = 0; j < w; ++j) acc[j] = 0.0f;
+            for (int i = 0; i < B; ++i) {
+                const float* g = px_grads + (size_t)i * P + jb;
+                for (int j = 0; j < w; ++j) acc[j] += g[j];
+            }
+            for (int j = 0; j < w; ++j) avg[jb + j] = acc[j] / (float)B;
+        }
+        double l = 0.0;
+        for (int i = 0; i < B; ++i) l += (double)px_loss[i];
+        loss = (float)(l / B);
+        int32_t sites[2] = {D, D};
+        d3po_perturb(ks + 32, avg, sites, 2, hy->dp_scale, hy->clip, (float)B, obs, 1.0f, pert);
+        d3po_adam(params, adam_m, adam_v, pert, P, *adam_step, hy->lr, hy->b1, hy->b2, hy->adam_eps);
+        *adam_step += 1;
+        memcpy(state_key, ks, 16 * sizeof(uint32_t));
+    }
+    return loss;
+}
+
 /* DPSVI.evaluate (svi.py:436-449) -> numpyro SVI.evaluate: `_, key = split(rng_key)`; -Trace_ELBO on the whole
  * batch with ONE guide draw: model_seed, guide_seed = split(key); sample key = split(guide_seed)[1]
  * (numpyro.handlers.seed); plate(N, B) scales the likelihood by N / B.  (numpyro plumbing UNPINNED.) */

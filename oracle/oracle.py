@@ -58,6 +58,7 @@ def lib():
         _lib.d3po_logreg_px_loss_grad.restype = C.c_float
         _lib.d3po_logreg_update.restype = C.c_float
         _lib.d3po_logreg_evaluate.restype = C.c_float
+        _lib.d3po_logreg_run_feistel.restype = C.c_float
         _lib.d3po_digamma.restype = C.c_double
         _lib.d3po_digamma.argtypes = [C.c_double]
         _lib.d3po_gamma_grad.restype = C.c_double
@@ -355,6 +356,19 @@ def logreg_update(spec, hyper, st, Xb, yb, mask=None, eps=None):
                                     None if m is None else _p(m), C.c_int(B),
                                     None if e is None else _p(e), _p(scratch), _p(grad))
     return float(loss), grad
+
+
+def logreg_run_feistel(spec, hyper, st, X, y, batch_key, first_batch, B, steps, threads=1):
+    """`steps` DPSVI.update calls on Feistel minibatches of the resident table (X, y), all inside one C call on `threads`
+    OpenMP threads (bench.py's cpu_baseline).  Advances `st` in place; returns the last loss."""
+    X, y = _f32(X), _f32(y)
+    d = spec.d
+    scratch = np.empty(B * d + B + B * 2 * d + B + B * d + 8 * d, np.float32)
+    idx = np.empty(B, np.uint32)
+    return float(lib().d3po_logreg_run_feistel(C.byref(spec), C.byref(hyper), _p(st.key), _p(st.params), _p(st.m), _p(st.v),
+                                               C.byref(st.step), _p(X), _p(y), C.c_uint32(X.shape[0]),
+                                               _p(_u32(batch_key).reshape(16)), C.c_uint32(first_batch), C.c_int(B),
+                                               C.c_int(steps), C.c_int(threads), _p(scratch), _p(idx)))
 
 
 def logreg_evaluate(spec, loc, unc, Xb, yb, jax_key):

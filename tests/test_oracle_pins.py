@@ -401,3 +401,24 @@ def test_gmm_model_gradient_vs_finite_differences(O):
     assert abs(loss - L(p)) < 1e-5 * abs(L(p))
     fd = np.array([(L(p + 1e-5 * e) - L(p - 1e-5 * e)) / 2e-5 for e in np.eye(p.size)])
     np.testing.assert_allclose(grad, fd, rtol=2e-4, atol=2e-4 * np.abs(fd).max())
+
+
+def test_cpu_baseline_loop_walks_the_checker_trajectory(O):
+    """bench.py's cpu_baseline times d3po_logreg_run_feistel (Feistel sampling + gather + the reference's staged dataflow
+    in one C loop, float32, per-column guide terms hoisted).  It must walk the same trajectory as the step-by-step
+    composition of the checker functions (float64 accumulation inside): same keys, same indices, parameters to 1e-5."""
+    d, B, rows, steps = 64, 96, 5000, 5
+    X, y = O.synth_logreg(123, 0, rows, d)
+    spec = O.logreg_spec(d, False, 1.0, 1.0, lik_scale=rows, obs_scale=rows)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    bkey = O.PRNGKey(1)
+    ref = O.LogregState(O.PRNGKey(0), d, np.zeros(d, np.float32), np.full(d, -2.0, np.float32))
+    for t in range(steps):
+        idx = O.feistel_sample(O.fold_in(bkey, 3 + t), rows, B)
+        ref_loss, _ = O.logreg_update(spec, hy, ref, X[idx], y[idx])
+    for threads in (1, 3):
+        st = O.LogregState(O.PRNGKey(0), d, np.zeros(d, np.float32), np.full(d, -2.0, np.float32))
+        loss = O.logreg_run_feistel(spec, hy, st, X, y, bkey, 3, B, steps, threads)
+        assert np.array_equal(st.key, ref.key) and st.step.value == steps
+        assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss)
+        np.testing.assert_allclose(st.params, ref.params, rtol=1e-5, atol=1e-6)

@@ -6,7 +6,7 @@ the dominant step kernel, following /opt/skills/guides/MI355X_MICROARCH.md secti
     reads -> doubled; WRITE_SIZE is exact for 16-B stores.
 The dominant kernel is the k_logreg_main instantiation with the largest summed FETCH_SIZE (the chained launch covers up to
 32 steps, so the figures are normalised by the number of steps the profiled command ran: warmup + steps).
-usage: pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <out.json> <total_steps>"""
+usage: pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <out.json> <total_steps> [<committed file name> <commit>]"""
 import collections
 import csv
 import glob
@@ -30,7 +30,8 @@ fetch_kib, write_kib = sum(fetch[kernel]), sum(write.get(kernel, [0.0]))
 n1, n2 = len(fetch[kernel]), len(write.get(kernel, []))
 fetch_bytes = 2.0 * fetch_kib * 1024.0
 write_bytes = write_kib * 1024.0
-out = {"kernel": kernel, "launches": [n1, n2], "steps": steps,
+out = {"source": sys.argv[5] if len(sys.argv) > 5 else None, "commit": sys.argv[6] if len(sys.argv) > 6 else None,
+       "kernel": kernel, "launches": [n1, n2], "steps": steps,
        "FETCH_SIZE_KiB_raw_sum": fetch_kib, "WRITE_SIZE_KiB_raw_sum": write_kib,
        "fetch_bytes_corrected_x2_per_step": fetch_bytes / steps, "write_bytes_per_step": write_bytes / steps,
        "hbm_bytes_per_step": (fetch_bytes + write_bytes) / steps,
