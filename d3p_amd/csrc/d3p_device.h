@@ -141,20 +141,31 @@ __device__ __forceinline__ void derive_child_quad_regs(uint32_t p0, uint32_t p1,
 }
 
 // threefry2x32-20 (Random123), as used by jax.random.
+// D3P_TF_PIN: x0 only ever grows by additions (x0 += x1 in every round, + a key word every fourth), and LLVM's
+// reassociation pass likes to keep it as "sum of the x1's" + "sum of the key words and counters" and to rebuild x0 with two
+// v_add3_u32 in EVERY round for the xor -- 5 VALU instructions per round instead of 3 (measured on gfx950, ROCm 7.2: 109
+// instead of 75 integer instructions per call; integer VALU instructions issue at 4 cycles per wave64).  An empty asm that
+// "modifies" x0 after each key injection makes it one opaque value again; it emits no instruction.
+#define D3P_TF_PIN(x) asm volatile("" : "+v"(x), "+v"(x1))
 __device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t& o0,
                                              uint32_t& o1)
 {
     const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
     uint32_t x0 = c0 + k0, x1 = c1 + k1;
+    D3P_TF_PIN(x0);
 #define D3P_TF_R(r) x0 += x1; x1 = d3p::rotl32(x1, r); x1 ^= x0;
     D3P_TF_R(13) D3P_TF_R(15) D3P_TF_R(26) D3P_TF_R(6)
     x0 += k1; x1 += k2 + 1u;
+    D3P_TF_PIN(x0);
     D3P_TF_R(17) D3P_TF_R(29) D3P_TF_R(16) D3P_TF_R(24)
     x0 += k2; x1 += k0 + 2u;
+    D3P_TF_PIN(x0);
     D3P_TF_R(13) D3P_TF_R(15) D3P_TF_R(26) D3P_TF_R(6)
     x0 += k0; x1 += k1 + 3u;
+    D3P_TF_PIN(x0);
     D3P_TF_R(17) D3P_TF_R(29) D3P_TF_R(16) D3P_TF_R(24)
     x0 += k1; x1 += k2 + 4u;
+    D3P_TF_PIN(x0);
     D3P_TF_R(13) D3P_TF_R(15) D3P_TF_R(26) D3P_TF_R(6)
     x0 += k2; x1 += k0 + 5u;
 #undef D3P_TF_R

@@ -19,6 +19,7 @@
 // per-step path; the key-chain step of the next batch rides along as one extra workgroup.
 #include "d3p_logreg_kernel.h"
 #include "d3p_logreg_persist.h"
+#include "d3p_logreg_chain.h"
 #include "d3p_logreg_wide.h"
 
 #include <dlfcn.h>
@@ -63,12 +64,12 @@ static size_t carve(const d3p_logreg_model* m, const d3p_batch_source* src, char
     p = take(K * 2 * B * sizeof(uint32_t)); if (ws) ws->skeys = (uint32_t*)p;
     p = take(K * B * sizeof(uint32_t)); if (ws) ws->plist = (uint32_t*)p;
     p = take(K * P * sizeof(float)); if (ws) ws->noise = (float*)p;
-    p = take(3 * (size_t)D3P_ACC_R * (P + 2) * sizeof(long long)); if (ws) ws->acc = (long long*)p;
+    p = take(3 * (size_t)D3P_ACC_R * D3P_ACC_COLS(P) * sizeof(long long)); if (ws) ws->acc = (long long*)p;
     p = take((3 * P + 4) * sizeof(float)); if (ws) ws->scratch_state = (float*)p;
     p = take(3 * P * sizeof(float)); if (ws) ws->pp_state = (float*)p;
     p = take(((size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS + 16) * sizeof(uint32_t)); if (ws) ws->chain_bar = (uint32_t*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * (P + 2) * sizeof(float)); if (ws) ws->partials = (float*)p;
-    p = take((size_t)D3P_MAIN_MAX_BLOCKS * 2 * sizeof(unsigned long long)); if (ws) ws->stamps = (unsigned long long*)p;
+    p = take((size_t)D3P_MAIN_MAX_BLOCKS * 4 * sizeof(unsigned long long)); if (ws) ws->stamps = (unsigned long long*)p;  // >= 2 x 256 x 16 phase stamps
     size_t pb = 0;
     if (src->kind == D3P_BATCH_POISSON) pb = K * d3p_poisson_select_workspace((uint32_t)src->n_rows);
     p = take(pb); if (ws) { ws->poisson_ws = p; ws->poisson_bytes = pb; }
@@ -737,7 +738,7 @@ static bool use_fused_step(const Ctx& c)
 
 static void fill_fuse_common(const Ctx& c, StepFuse* f, int g)
 {
-    const size_t PA = (size_t)c.P + 2;
+    const size_t PA = (size_t)D3P_ACC_COLS(c.P);
     f->acc_prev = c.ws.acc + (size_t)((g + 2) % 3) * D3P_ACC_R * PA;
     f->acc_cur = c.ws.acc + (size_t)(g % 3) * D3P_ACC_R * PA;
     f->acc_next = c.ws.acc + (size_t)((g + 1) % 3) * D3P_ACC_R * PA;
@@ -756,12 +757,7 @@ static void fill_fuse_common(const Ctx& c, StepFuse* f, int g)
     // B up to 2^22 inside int64 with a resolution of C * 2^-40
     f->sg = 1099511627776.0 / (double)fabsf(c.h->clip);
     f->inv_sg = 1.0 / f->sg;
-    // loss column: bound per example by inv_obs * (50 D + 1e3 * lik_scale); keep 2^61 of headroom
-    const double bound = (double)c.m->inv_obs * (50.0 * c.D + 1.0e3 * (double)c.m->lik_scale) * (double)c.src->B + 1.0;
-    int e = 0;
-    (void)frexp(bound, &e);
-    f->sl = ldexp(1.0, 61 - e);
-    f->inv_sl = 1.0 / f->sl;
+    // (the loss takes two columns, coarse and fine, at fixed scales: D3P_ACC_COLS in d3p_logreg_kernel.h)
 }
 
 // step `g` of the run (slot `t` of buffer `cur`); prev = slot of step g-1 (nullable for g == 0)
@@ -854,6 +850,49 @@ static bool use_persistent_steps(const Ctx& c)
     return (int)c.g.blocks <= resident;
 }
 
+// D3P_DBG=32: reads the phase stamps the stamped chained kernels left for the last two steps of a launch and prints the
+// anatomy of the last step (fourth launch of the process = steady state) to stderr.
+static int print_chain_anatomy(const Ctx& c)
+{
+    static unsigned long long host[2 * 256 * 16];
+    D3P_HIP_TRY(hipMemcpyAsync(host, c.ws.stamps, sizeof(host), hipMemcpyDeviceToHost, c.s));
+    D3P_HIP_TRY(hipStreamSynchronize(c.s));
+    static int printed = 0;
+    if (printed++ == 3) {  // fourth launch of the process: steady state
+        const uint32_t nb = c.g.blocks < 256u ? c.g.blocks : 256u;
+        auto at = [&](int rec, uint32_t b, int k) { return (double)host[((size_t)rec * 256 + b) * 16 + k] * 0.01; };
+        // what a step waits for: the LAST arrival of the previous step
+        double last_arr = 0.0, last_acked = 0.0;
+        for (uint32_t b = 0; b < nb; ++b) {
+            last_arr = at(0, b, 12) > last_arr ? at(0, b, 12) : last_arr;
+            last_acked = at(0, b, 10) > last_acked ? at(0, b, 10) : last_acked;
+        }
+        const char* names[13] = {"entry", "-", "prologue done", "-", "-", "examples done", "reduction barrier", "release seen",
+                                 "param-independent work done", "atomics issued", "atomics acknowledged", "arrival barrier",
+                                 "arrival returned"};
+        fprintf(stderr, "chained step anatomy (us, relative to the last arrival of the previous step; mean / min / max over %u workgroups)\n", nb);
+        for (int k : {0, 8, 7, 2, 5, 6, 9, 10, 11, 12}) {
+            double sum = 0.0, mn = 1e30, mx = -1e30;
+            for (uint32_t b = 0; b < nb; ++b) {
+                const double v = at(1, b, k) - last_arr;
+                sum += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+            }
+            fprintf(stderr, "  %-30s %7.2f %7.2f %7.2f\n", names[k], sum / nb, mn, mx);
+        }
+        fprintf(stderr, "  previous step: last acknowledgement %.2f us before its last arrival\n", last_arr - last_acked);
+        const int order[9][2] = {{7, 2}, {2, 5}, {5, 6}, {6, 9}, {9, 10}, {10, 11}, {11, 12}, {8, 7}, {0, 8}};
+        for (auto& o : order) {
+            double sum = 0.0, mx = -1e30;
+            for (uint32_t b = 0; b < nb; ++b) {
+                const double v = at(1, b, o[1]) - at(1, b, o[0]);
+                sum += v; mx = v > mx ? v : mx;
+            }
+            fprintf(stderr, "  phase %-28s -> %-28s mean %6.2f max %6.2f\n", names[o[0]], names[o[1]], sum / nb, mx);
+        }
+    }
+    return D3P_OK;
+}
+
 static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* prev_slot0, const float* prev_noise0, const float* X,
                                  const float* y, float* losses, StepSlot* chain_slots, int K_next)
 {
@@ -925,6 +964,68 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
             hipLaunchKernelGGL(k_logreg_persist<false>, dim3(c.g.blocks), dim3(64 * D3P_PERSIST_W), persist_lds_bytes(), c.s, a);
         return check_launch("k_logreg_persist");
     }
+    {
+        // The headline shape (d = 512, no intercept, logistic regression; at most ~two examples per wave of an 8-wave
+        // workgroup) runs the kernel written for it (d3p_logreg_chain.h); D3P_NO_LEAN_CHAIN=1 keeps the generic template.
+        static const bool off = getenv("D3P_NO_LEAN_CHAIN") != nullptr || getenv("D3P_NO_PIPELINED_STEPS") != nullptr ||
+                                getenv("D3P_MAIN_W") != nullptr;
+        if (!off && c.g.full && !c.g.tail && c.g.V == 4 && c.g.NK == 1 && c.g.W == 16 && c.D == D3P_CHAIN_D &&
+            c.m->family == D3P_FAMILY_LOGREG && (uint64_t)c.src->B <= 18ull * c.g.blocks) {
+            ChainArgs ca;
+            memset(&ca, 0, sizeof(ca));
+            ca.X = X;
+            ca.y = y;
+            ca.idx_base = c.ws.idx;
+            ca.skeys_base = c.ws.skeys;
+            ca.plist_base = need_owned_list(c.src) ? c.ws.plist : nullptr;
+            ca.noise_base = c.ws.noise;
+            ca.slots = c.ws.slots;
+            ca.prev_slot0 = prev_slot0;
+            ca.prev_noise0 = prev_noise0;
+            ca.acc_base = c.ws.acc;
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 3; ++j) ca.state[i][j] = cf.state[i][j];
+            ca.losses = losses;
+            ca.bar = cf.bar;
+            ca.status = cf.abort_flag;
+            ca.chain_sched = c.ws.sched;
+            ca.chain_slots = cf.chain_slots;
+            ca.adam_step = a.fuse.adam_step;
+            ca.batch_index = a.fuse.batch_index;
+            ca.row_lo = c.src->row_lo;
+            ca.sg = a.fuse.sg; ca.inv_sg = a.fuse.inv_sg;
+            ca.B = c.src->B;
+            ca.nw = (int)c.g.blocks;
+            ca.g0 = g0;
+            ca.K = K;
+            ca.K_next = cf.K_next;
+            ca.A_scale = a.A_scale; ca.c1 = a.c1_w; ca.hz = a.hz_w; ca.inv_obs = a.inv_obs; ca.lik_scale = a.lik_scale;
+            ca.obs_scale = a.obs_scale; ca.clip = a.clip; ca.dp_scale = a.fuse.dp_scale; ca.lr = a.fuse.lr; ca.b1 = a.fuse.b1;
+            ca.b2 = a.fuse.b2; ca.adam_eps = a.fuse.adam_eps; ca.log_prior = logf(c.m->prior_w);
+            ca.gexp = a.gexp;
+            ca.dbg = dev_dbg_flags();
+            const dim3 grid((uint32_t)K * (c.g.blocks + 1u)), block(64 * D3P_CHAIN_W);
+            const bool plist = ca.plist_base != nullptr;
+            if ((ca.dbg & 32) && K >= 2) {  // D3P_DBG=32: the stamped instantiation + the phase anatomy on stderr
+                ca.stamps = c.ws.stamps;
+                if (plist) hipLaunchKernelGGL((k_logreg_chain<true, true>), grid, block, chain_lds_bytes(), c.s, ca);
+                else hipLaunchKernelGGL((k_logreg_chain<false, true>), grid, block, chain_lds_bytes(), c.s, ca);
+                int rc = check_launch("k_logreg_chain");
+                if (rc) return rc;
+                return print_chain_anatomy(c);
+            }
+            hipEvent_t e0, e1;
+            timing_pair(K, &e0, &e1);
+            if (e0) {
+                if (plist) hipExtLaunchKernelGGL((k_logreg_chain<true, false>), grid, block, chain_lds_bytes(), c.s, e0, e1, 0, ca);
+                else hipExtLaunchKernelGGL((k_logreg_chain<false, false>), grid, block, chain_lds_bytes(), c.s, e0, e1, 0, ca);
+            } else {
+                if (plist) hipLaunchKernelGGL((k_logreg_chain<true, false>), grid, block, chain_lds_bytes(), c.s, ca);
+                else hipLaunchKernelGGL((k_logreg_chain<false, false>), grid, block, chain_lds_bytes(), c.s, ca);
+            }
+            return check_launch("k_logreg_chain");
+        }
+    }
     MainGeom g2 = c.g;
     {
         // Pipelined geometry (D3P_NO_PIPELINED_STEPS=1 keeps one 16-wave workgroup per CU): the same number of workgroups
@@ -943,29 +1044,11 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
     }
     g2.blocks = (uint32_t)K * (c.g.blocks + 1u);
     a.dbg = dev_dbg_flags();
-    if (a.dbg & 32) {  // developer diagnostic (D3P_DBG=32): phase stamps of the LAST step of the launch, printed to stderr
+    if ((a.dbg & 32) && K >= 2) {  // developer diagnostic (D3P_DBG=32): phase stamps of the last two steps, printed to stderr
         a.stamps = c.ws.stamps;
         int rc = launch_main<3>(c.s, g2, a);
         if (rc) return rc;
-        static unsigned long long host[8 * 257];
-        D3P_HIP_TRY(hipMemcpyAsync(host, c.ws.stamps, sizeof(host), hipMemcpyDeviceToHost, c.s));
-        D3P_HIP_TRY(hipStreamSynchronize(c.s));
-        static int printed = 0;
-        if (printed++ == 3 && K > 1) {
-            unsigned long long t0 = ~0ull;
-            for (uint32_t b = 0; b < c.g.blocks; ++b) t0 = host[8 * b] < t0 ? host[8 * b] : t0;
-            double sum[8] = {0}, mx[8] = {0};
-            for (uint32_t b = 0; b < c.g.blocks; ++b)
-                for (int k = 0; k < 8; ++k) {
-                    const double v = ((double)host[8 * b + k] - (double)t0) * 0.01;
-                    sum[k] += v;
-                    if (v > mx[k]) mx[k] = v;
-                }
-            const char* names[8] = {"entry", "exit(arrived)", "prologue+staged", "eps done", "dot done", "loop done", "red-sync", "release seen"};
-            for (int k : {0, 7, 2, 3, 4, 5, 6, 1})
-                fprintf(stderr, "MODE3 last step: %-16s mean %.2f  max %.2f us after the first entry\n", names[k], sum[k] / c.g.blocks, mx[k]);
-        }
-        return D3P_OK;
+        return print_chain_anatomy(c);
     }
     hipEvent_t e0, e1;
     timing_pair(K, &e0, &e1);
@@ -1009,7 +1092,7 @@ static int enqueue_chain(const Ctx& c, int K);
 static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_t num_steps, float* losses, ncclComm_t comm = nullptr)
 {
     int rc;
-    const size_t acc_bytes = 3 * (size_t)D3P_ACC_R * (c.P + 2) * sizeof(long long);
+    const size_t acc_bytes = 3 * (size_t)D3P_ACC_R * D3P_ACC_COLS(c.P) * sizeof(long long);
     D3P_HIP_TRY(hipMemsetAsync(c.ws.acc, 0, acc_bytes, c.s));
     const uint32_t n_batches = (num_steps + D3P_STEP_BATCH - 1) / D3P_STEP_BATCH;
     auto batch_len = [&](uint32_t b) {
@@ -1056,7 +1139,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
                                          cslot, t, t == K_next - 1, false, false, e0, e1)))
                 return rc;
             if (comm) {
-                const size_t words = (size_t)D3P_ACC_R * (c.P + 2);
+                const size_t words = (size_t)D3P_ACC_R * D3P_ACC_COLS(c.P);
                 long long* acc = c.ws.acc + (size_t)(g % 3) * words;
                 const ncclResult_t r = rccl_api()->AllReduce(acc, acc, words, ncclInt64, ncclSum, comm, c.s);
                 if (r != ncclSuccess) return fail(D3P_E_HIP, "ncclAllReduce: %s", rccl_api()->GetErrorString(r));
@@ -1243,7 +1326,7 @@ int d3p_dpvi_logreg_acc_layout(const d3p_logreg_model* model, const d3p_batch_so
     Workspace ws;
     carve(model, src, (char*)nullptr + 256, &ws);  // offsets relative to a fake base
     *offset_bytes = (size_t)((char*)ws.acc - ((char*)nullptr + 256));
-    *words_per_buffer = (size_t)D3P_ACC_R * (2 * ((size_t)model->d + (model->intercept ? 1 : 0)) + 2);
+    *words_per_buffer = (size_t)D3P_ACC_R * D3P_ACC_COLS(2 * ((size_t)model->d + (model->intercept ? 1 : 0)));
     return D3P_OK;
 }
 
@@ -1254,7 +1337,7 @@ int d3p_dpvi_logreg_acc_reset(void* stream, const d3p_logreg_model* model, const
     Ctx c;
     int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
     if (rc) return rc;
-    D3P_HIP_TRY(hipMemsetAsync(c.ws.acc, 0, 3 * (size_t)D3P_ACC_R * (c.P + 2) * sizeof(long long), c.s));
+    D3P_HIP_TRY(hipMemsetAsync(c.ws.acc, 0, 3 * (size_t)D3P_ACC_R * D3P_ACC_COLS(c.P) * sizeof(long long), c.s));
     D3P_HIP_TRY(hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s));
     return D3P_OK;
 }
@@ -1357,6 +1440,7 @@ int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_d
         if ((rc = run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev))) return rc;
         return enqueue_sched_finish(c, (int)num_steps);
     }
+    D3P_HIP_TRY(hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s));  // (no waits, no fixed-point sums: stays 0)
     // Two-kernel steps (D3P_NO_FUSED_STEP): main + finalize per step; the key-chain step of the next batch rides in every
     // k_finalize launch as one extra workgroup.  (Running the chain or the sampler on an auxiliary stream was measured
     // slower -- 19.3-20.1 vs 17.6 us/step -- and is not kept.)
@@ -1464,7 +1548,7 @@ int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model
         D3P_HIP_TRY(hipMemcpyAsync(c.ws.scratch_state, c.st->params, P * sizeof(float), hipMemcpyDeviceToDevice, c.s));
         D3P_HIP_TRY(hipMemcpyAsync(c.ws.scratch_state + P, c.st->adam_m, P * sizeof(float), hipMemcpyDeviceToDevice, c.s));
         D3P_HIP_TRY(hipMemcpyAsync(c.ws.scratch_state + 2 * P, c.st->adam_v, P * sizeof(float), hipMemcpyDeviceToDevice, c.s));
-        D3P_HIP_TRY(hipMemsetAsync(c.ws.acc, 0, 3 * (size_t)D3P_ACC_R * (P + 2) * sizeof(long long), c.s));
+        D3P_HIP_TRY(hipMemsetAsync(c.ws.acc, 0, 3 * (size_t)D3P_ACC_R * D3P_ACC_COLS(P) * sizeof(long long), c.s));
         D3P_HIP_TRY(hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s));
         st_scratch.params = c.ws.scratch_state;
         st_scratch.adam_m = c.ws.scratch_state + P;

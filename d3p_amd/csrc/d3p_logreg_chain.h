@@ -1,0 +1,392 @@
+// The headline kernel: the chained DP-VI launch for Bayesian logistic regression with d = 512 features, no intercept
+// (D = 512 latents, P = 1024 parameters) -- BASELINE configs[1] / the north_star workload -- written for nothing else.
+//
+// k_logreg_main<.., MODE 3, ..> (d3p_logreg_kernel.h) is one template for every shape, likelihood family, noise source and
+// launch form; its chained instantiation carries ~20 derived pointers and two argument structs through the whole kernel:
+// 106 SGPRs with ~390 v_readlane / v_writelane spill moves and 56 kernel-argument reloads (s_load + s_waitcnt lgkmcnt(0))
+// scattered over 37 KB of code, many of them between the release of the previous step and this workgroup's arrival -- the
+// serial chain that bounds the step (phase stamps, profiles/r02_chain_anatomy.txt: 3.4 us for the gradients of two examples
+// and 1.2 us for an 8-row LDS reduction, each ~5 x their instruction count).  This kernel does the same step with the same
+// protocol (fixed-point accumulator replicas, group arrival counters + flags, bounded waits, status words) and the same
+// arithmetic, but keeps only what the step needs live:
+//
+//   phase 0  parameter-independent, BEFORE the release of step t - 1: index -> row -> features of the wave's two examples,
+//            their threefry sample keys, their guide noise (svi.py:289-290) into the wave's own LDS row, the Gaussian-mechanism
+//            normals and bias corrections of the pending update;
+//   phase 1  wave 0 polls the 8 group flags of step t - 1 (+ the abort flag) with one load per round; workgroup barrier;
+//   phase 2  update prologue, redundantly per workgroup: thread e owns latent e -- columns e (auto_loc) and D + e (auto_scale) --
+//            sums the 4 replicas, mean, noise, rescale (svi.py:343-375), Adam (svi.py:379-393), derived columns into LDS;
+//            workgroup 0 publishes the state;
+//   phase 3  per example: z, logit (DPP wave sum), gradient, joint norm, clip factor, accumulate (svi.py:238-346);
+//   phase 4  LDS reduction of the 8 waves, 2 fixed-point int64 atomics per thread, arrival.
+//
+// Geometry: 8-wave workgroups, two resident per CU (<= 128 VGPRs), every wave takes at most two items:
+// item k -> wave (k / 8) % nw ... i.e. k1 = 8 bid + wave, k2 = k1 + 8 nw; the host picks nw >= ceil(items / 16).
+// PLIST: the items are the entries of the step's dense owned-position list (Poisson padding, row-sharded ranks).
+#pragma once
+#include "d3p_logreg_kernel.h"
+
+namespace d3p {
+
+#define D3P_CHAIN_D 512
+#define D3P_CHAIN_W 8
+
+struct ChainArgs {
+    const float* X;
+    const float* y;
+    const uint32_t* idx_base;    // K x B
+    const uint32_t* skeys_base;  // K x 2B
+    const uint32_t* plist_base;  // K x B (PLIST)
+    const float* noise_base;     // K x P
+    StepSlot* slots;             // K slots of this batch
+    const StepSlot* prev_slot0;  // slot of step g0 - 1 (nullptr: nothing to apply before step 0)
+    const float* prev_noise0;
+    long long* acc_base;         // 3 x R x D3P_ACC_COLS(P)
+    float* state[2][3];          // ping-ponged {params, m, v}
+    float* losses;               // nullable
+    uint32_t* bar;               // K x D3P_BAR_WORDS arrival counters + chain progress word
+    uint32_t* status;            // [0] abort, [1] non-finite
+    Sched* chain_sched;
+    StepSlot* chain_slots;       // slots of the NEXT batch (key chain), K_next of them
+    int32_t* adam_step;
+    uint32_t* batch_index;
+    unsigned long long* stamps;  // STAMPS
+    uint64_t row_lo;
+    double sg, inv_sg;
+    uint32_t B;
+    int nw, g0, K, K_next;
+    float A_scale, c1, hz, inv_obs, lik_scale, obs_scale, clip, dp_scale, lr, b1, b2, adam_eps, log_prior;
+    int gexp;
+    int dbg;  // developer switches (D3P_DBG): 2 = raised wave priority on the critical path, 4 = no gradient atomics (STAMPS only)
+};
+
+static inline size_t chain_lds_bytes()
+{
+    return (size_t)(5 * D3P_CHAIN_D + D3P_CHAIN_W * 2 * D3P_CHAIN_D + 2 * D3P_CHAIN_W + 4 + 32) * sizeof(float);
+}
+
+template <bool PLIST, bool STAMPS>
+__global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int D = D3P_CHAIN_D, P = 2 * D, PA = D3P_ACC_COLS(P), W = D3P_CHAIN_W, R = D3P_ACC_R;
+    float* pk = lds;                    // [loc | s | sg | q | lc] x D
+    float* red = lds + 5 * D;           // W rows of P floats: the waves' noise, later their partial sums
+    float* tail = red + W * P;          // 2 W: loss / count per wave
+    uint32_t* okw = reinterpret_cast<uint32_t*>(tail + 2 * W);             // verdict of the polling wave
+    unsigned long long* stamp = reinterpret_cast<unsigned long long*>(okw + 4);
+#define D3P_CSTAMP(k) if (STAMPS && threadIdx.x == 0) stamp[k] = wall_clock64();
+    D3P_CSTAMP(0)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t per = (uint32_t)a.nw + 1u;
+    const int step_t = (int)(blockIdx.x / per);
+    const uint32_t bid = blockIdx.x % per;
+
+    if (bid == (uint32_t)a.nw) {  // key-chain workgroup: split(state_key, 3) of step `step_t` of the NEXT batch
+        if (step_t < a.K_next && tid < 64) {
+            uint32_t* progress = a.bar + (size_t)a.K * D3P_BAR_WORDS;
+            bool go = true;
+            if (step_t > 0) go = chain_wait(progress, (uint32_t)step_t, a.status);
+            if (go) chain_step<true>(a.chain_sched, a.chain_slots + step_t, step_t, step_t == a.K_next - 1);
+            __builtin_amdgcn_s_waitcnt(0);
+            if (tid == 0) __hip_atomic_store(progress, (uint32_t)step_t + 1u, __ATOMIC_RELAXED, D3P_AGENT);
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------ phase 0: parameter-independent
+    const StepSlot* slot = a.slots + step_t;
+    const uint32_t n_items = PLIST ? slot->n_owned : a.B;
+    const uint32_t k1 = bid * W + (uint32_t)wave, k2 = k1 + (uint32_t)a.nw * W;
+    const bool live1 = k1 < n_items, live2 = k2 < n_items;
+    const uint32_t* idx = a.idx_base + (size_t)step_t * a.B;
+    const uint32_t* skeys = a.skeys_base + (size_t)step_t * 2 * a.B;
+    float4 xa0 = make_float4(0.f, 0.f, 0.f, 0.f), xa1 = xa0, xb0 = xa0, xb1 = xa0;
+    float ya = 0.f, yb = 0.f;
+    uint32_t ka0 = 0, ka1 = 0, kb0 = 0, kb1 = 0;
+    if (live1) {
+        const uint32_t p = PLIST ? (a.plist_base + (size_t)step_t * a.B)[k1] : k1;
+        const size_t row = (size_t)((uint64_t)idx[p] - a.row_lo);
+        const float* xr = a.X + row * D;
+        xa0 = *reinterpret_cast<const float4*>(xr + 4 * lane);
+        xa1 = *reinterpret_cast<const float4*>(xr + D / 2 + 4 * lane);
+        ya = a.y[row];
+        ka0 = skeys[2 * p];
+        ka1 = skeys[2 * p + 1];
+    }
+    if (live2) {
+        const uint32_t p = PLIST ? (a.plist_base + (size_t)step_t * a.B)[k2] : k2;
+        const size_t row = (size_t)((uint64_t)idx[p] - a.row_lo);
+        const float* xr = a.X + row * D;
+        xb0 = *reinterpret_cast<const float4*>(xr + 4 * lane);
+        xb1 = *reinterpret_cast<const float4*>(xr + D / 2 + 4 * lane);
+        yb = a.y[row];
+        kb0 = skeys[2 * p];
+        kb1 = skeys[2 * p + 1];
+    }
+    // the pending update of step g - 1: which state buffers, which slot / noise row (all known before the release)
+    const int g = a.g0 + step_t;
+    const StepSlot* ps = step_t > 0 ? a.slots + (step_t - 1) : a.prev_slot0;
+    const bool apply_prev = ps != nullptr;
+    const float* prev_noise = step_t > 0 ? a.noise_base + (size_t)(step_t - 1) * P : a.prev_noise0;
+    float zL = 0.f, zS = 0.f, bc1 = 1.f, bc2 = 1.f;
+    if (apply_prev) {  // Gaussian-mechanism normals of this thread's two columns and the bias corrections
+        zL = prev_noise[tid];
+        zS = prev_noise[D + tid];
+        bc1 = ps->bc1;
+        bc2 = ps->bc2;
+    }
+    // guide noise of both examples into the wave's own row: lane owns columns 4 lane .. + 3 and D/2 + the same, i.e. the
+    // pairs (c, c + D/2) of jax's iota layout come out of ONE threefry2x32 call
+    float* er = red + (size_t)wave * P;
+    auto gen = [&](uint32_t k0, uint32_t k1_, float* dst) {
+        const uint32_t s0 = __builtin_amdgcn_readfirstlane(k0), s1 = __builtin_amdgcn_readfirstlane(k1_);  // wave-uniform keys
+        float v0[4], v1[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            uint32_t b0, b1;
+            threefry2x32(s0, s1, (uint32_t)(4 * lane + n), (uint32_t)(4 * lane + n + D / 2), b0, b1);
+            v0[n] = bits_to_normal_wu(b0);
+            v1[n] = bits_to_normal_wu(b1);
+        }
+        *reinterpret_cast<float4*>(dst + 4 * lane) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+        *reinterpret_cast<float4*>(dst + D / 2 + 4 * lane) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+    };
+    if (live1) gen(ka0, ka1, er);
+    if (live2) gen(kb0, kb1, er + D);
+    D3P_CSTAMP(8)
+    // From here on the workgroup is on the critical path of the step (D3P_DBG=2: raised wave priority against the co-resident
+    // workgroup of the next step, which is generating its noise on the same SIMDs).
+    if (a.dbg & 2) __builtin_amdgcn_s_setprio(3);
+
+    // ------------------------------------------------------------------ phase 1: release of step t - 1
+    const size_t words = (size_t)R * PA;
+    long long* acc_prev = a.acc_base + (size_t)((g + 2) % 3) * words;
+    long long* acc_cur = a.acc_base + (size_t)(g % 3) * words;
+    long long* acc_next = a.acc_base + (size_t)((g + 1) % 3) * words;
+    if (wave == 0) {
+        const uint32_t ng = (uint32_t)a.nw < D3P_BAR_GROUPS ? (uint32_t)a.nw : D3P_BAR_GROUPS;
+        const bool ok = chain_wait_groups(
+            step_t > 0 ? a.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS) : nullptr, ng, a.status);
+        if (lane == 0) okw[0] = ok ? 0u : 1u;
+    }
+    __syncthreads();
+    if (okw[0] != 0u) return;  // the run was aborted: no update, no publication, no arrival
+    D3P_CSTAMP(7)
+
+    // ------------------------------------------------------------------ phase 2: update prologue (thread e <-> latent e)
+    const int in = g > 0 ? ((g - 1) & 1) : 0, out = g & 1;
+    {
+        float xL, xS;
+        if (apply_prev) {
+            long long aL[R], aS[R], n8[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                aL[r] = __hip_atomic_load(acc_prev + (size_t)r * PA + tid, __ATOMIC_RELAXED, D3P_AGENT);
+                aS[r] = __hip_atomic_load(acc_prev + (size_t)r * PA + D + tid, __ATOMIC_RELAXED, D3P_AGENT);
+            }
+            xL = __hip_atomic_load(a.state[in][0] + tid, __ATOMIC_RELAXED, D3P_AGENT);
+            xS = __hip_atomic_load(a.state[in][0] + D + tid, __ATOMIC_RELAXED, D3P_AGENT);
+            float mL = __hip_atomic_load(a.state[in][1] + tid, __ATOMIC_RELAXED, D3P_AGENT);
+            float mS = __hip_atomic_load(a.state[in][1] + D + tid, __ATOMIC_RELAXED, D3P_AGENT);
+            float vL = __hip_atomic_load(a.state[in][2] + tid, __ATOMIC_RELAXED, D3P_AGENT);
+            float vS = __hip_atomic_load(a.state[in][2] + D + tid, __ATOMIC_RELAXED, D3P_AGENT);
+#pragma unroll
+            for (int r = 0; r < R; ++r) n8[r] = __hip_atomic_load(acc_prev + (size_t)r * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT);
+            // nobody reads the next accumulator any more (the previous step's prologues are over): zero it
+            for (int i = (int)bid * (64 * W) + tid; i < R * PA; i += a.nw * 64 * W)
+                __hip_atomic_store(acc_next + i, 0ll, __ATOMIC_RELAXED, D3P_AGENT);
+            long long nll = 0, sL = 0, sS = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { nll += n8[r]; sL += aL[r]; sS += aS[r]; }
+            // (a workgroup that saw a non-finite partial added 2^44 to the count column: NaN from here on, like float sums)
+            const float n = nll >= (1ll << 40) ? __builtin_nanf("") : (float)nll;
+            const float Bf = (float)a.B;
+            const float factor = (n == 0.0f) ? 0.0f : Bf / n;  // svi.py:305
+            const float inv_B = 1.0f / Bf, inv_bc1 = 1.0f / bc1, inv_bc2 = 1.0f / bc2;
+            const float noise_scale = a.dp_scale * (a.clip / n), out_scale = a.obs_scale * factor;  // svi.py:365-375
+            auto adam = [&](long long s, float z, float& x, float& m, float& v) {
+                const float tot = (float)((double)s * a.inv_sg);
+                const float gr = __fmaf_rn(z, noise_scale, tot * inv_B) * out_scale;
+                m = (1.0f - a.b1) * gr + a.b1 * m;
+                v = (1.0f - a.b2) * gr * gr + a.b2 * v;
+                x = x - a.lr * (m * inv_bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * inv_bc2) + a.adam_eps);
+            };
+            adam(sL, zL, xL, mL, vL);
+            adam(sS, zS, xS, mS, vS);
+            if (bid == 0) {  // one workgroup publishes the state
+                __hip_atomic_store(a.state[out][0] + tid, xL, __ATOMIC_RELAXED, D3P_AGENT);
+                __hip_atomic_store(a.state[out][0] + D + tid, xS, __ATOMIC_RELAXED, D3P_AGENT);
+                __hip_atomic_store(a.state[out][1] + tid, mL, __ATOMIC_RELAXED, D3P_AGENT);
+                __hip_atomic_store(a.state[out][1] + D + tid, mS, __ATOMIC_RELAXED, D3P_AGENT);
+                __hip_atomic_store(a.state[out][2] + tid, vL, __ATOMIC_RELAXED, D3P_AGENT);
+                __hip_atomic_store(a.state[out][2] + D + tid, vS, __ATOMIC_RELAXED, D3P_AGENT);
+                if (tid == 0) {
+                    long long lll = 0, lhh = 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        lll += __hip_atomic_load(acc_prev + (size_t)r * PA + P, __ATOMIC_RELAXED, D3P_AGENT);
+                        lhh += __hip_atomic_load(acc_prev + (size_t)r * PA + P + 2, __ATOMIC_RELAXED, D3P_AGENT);
+                    }
+                    if (a.losses && g > 0) a.losses[g - 1] = ((float)loss_join(lhh, lll) / Bf) * a.obs_scale * factor;
+                    *a.adam_step = ps->adam_i + 1;
+                    if (a.batch_index) *a.batch_index = ps->batch_i + 1u;
+                }
+            }
+        } else {  // first step of a run: nothing pending, nobody reads the next accumulator yet
+            xL = a.state[in][0][tid];
+            xS = a.state[in][0][D + tid];
+            for (int i = (int)bid * (64 * W) + tid; i < R * PA; i += a.nw * 64 * W)
+                __hip_atomic_store(acc_next + i, 0ll, __ATOMIC_RELAXED, D3P_AGENT);
+        }
+        float sp, sgm;
+        guide_scale(a.gexp, xS, sp, sgm);
+        pk[tid] = xL;
+        pk[D + tid] = sp;
+        pk[2 * D + tid] = sgm;
+        pk[3 * D + tid] = a.inv_obs * sgm * __builtin_amdgcn_rcpf(sp);
+        pk[4 * D + tid] = a.log_prior - __logf(sp);
+    }
+    D3P_CSTAMP(2)
+    __syncthreads();
+    D3P_CSTAMP(1)
+
+    // ------------------------------------------------------------------ phase 3: the wave's (up to) two examples
+    float accg0[4] = {0.f, 0.f, 0.f, 0.f}, acch0[4] = {0.f, 0.f, 0.f, 0.f}, accg1[4] = {0.f, 0.f, 0.f, 0.f}, acch1[4] = {0.f, 0.f, 0.f, 0.f};
+    float loss_acc = 0.f, n_acc = 0.f;
+    const int c0 = 4 * lane, c1 = D / 2 + 4 * lane;
+    auto example = [&](const float4& x0v, const float4& x1v, float yv, const float* e) {
+        float x0[4] = {x0v.x, x0v.y, x0v.z, x0v.w}, x1[4] = {x1v.x, x1v.y, x1v.z, x1v.w};
+        float e0[4], e1[4], l0[4], l1[4], s0[4], s1[4];
+        *reinterpret_cast<float4*>(e0) = *reinterpret_cast<const float4*>(e + c0);
+        *reinterpret_cast<float4*>(e1) = *reinterpret_cast<const float4*>(e + c1);
+        *reinterpret_cast<float4*>(l0) = *reinterpret_cast<const float4*>(pk + c0);
+        *reinterpret_cast<float4*>(l1) = *reinterpret_cast<const float4*>(pk + c1);
+        *reinterpret_cast<float4*>(s0) = *reinterpret_cast<const float4*>(pk + D + c0);
+        *reinterpret_cast<float4*>(s1) = *reinterpret_cast<const float4*>(pk + D + c1);
+        float z0[4], z1[4], tp = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            z0[n] = __fmaf_rn(s0[n], e0[n], l0[n]);
+            z1[n] = __fmaf_rn(s1[n], e1[n], l1[n]);
+            tp = __fmaf_rn(x0[n], z0[n], tp);
+            tp = __fmaf_rn(x1[n], z1[n], tp);
+        }
+        float sg0[4], sg1[4], q0[4], q1[4], lc0[4], lc1[4];  // (requested before the wave sum needs its result)
+        *reinterpret_cast<float4*>(sg0) = *reinterpret_cast<const float4*>(pk + 2 * D + c0);
+        *reinterpret_cast<float4*>(sg1) = *reinterpret_cast<const float4*>(pk + 2 * D + c1);
+        *reinterpret_cast<float4*>(q0) = *reinterpret_cast<const float4*>(pk + 3 * D + c0);
+        *reinterpret_cast<float4*>(q1) = *reinterpret_cast<const float4*>(pk + 3 * D + c1);
+        *reinterpret_cast<float4*>(lc0) = *reinterpret_cast<const float4*>(pk + 4 * D + c0);
+        *reinterpret_cast<float4*>(lc1) = *reinterpret_cast<const float4*>(pk + 4 * D + c1);
+        const float t = wave_sum(tp);                      // logit x . z
+        const float A = a.A_scale * (sigmoid_f(t) - yv);   // d(-lik_scale inv_obs loglik)/dt
+        const float loglik = yv * t - softplus_f(t);
+        float g0[4], g1[4], h0[4], h1[4], n2 = 0.f, lp = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            g0[n] = __fmaf_rn(a.c1, z0[n], A * x0[n]);
+            g1[n] = __fmaf_rn(a.c1, z1[n], A * x1[n]);
+            h0[n] = __fmaf_rn(g0[n] * e0[n], sg0[n], -q0[n]);
+            h1[n] = __fmaf_rn(g1[n] * e1[n], sg1[n], -q1[n]);
+            n2 = __fmaf_rn(g0[n], g0[n], n2);
+            n2 = __fmaf_rn(h0[n], h0[n], n2);
+            n2 = __fmaf_rn(g1[n], g1[n], n2);
+            n2 = __fmaf_rn(h1[n], h1[n], n2);
+            lp += __fmaf_rn(a.hz * z0[n], z0[n], __fmaf_rn(-0.5f * e0[n], e0[n], lc0[n]));
+            lp += __fmaf_rn(a.hz * z1[n], z1[n], __fmaf_rn(-0.5f * e1[n], e1[n], lc1[n]));
+        }
+        n2 = wave_sum(n2);
+        lp = wave_sum(lp);
+        // clip factor 1 / max(1, ||g|| / C) (svi.py:121-122) folded into the running sum (svi.py:343-346)
+        const float cf = fminf(1.0f, a.clip * __builtin_amdgcn_rsqf(n2));
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            accg0[n] = __fmaf_rn(cf, g0[n], accg0[n]);
+            acch0[n] = __fmaf_rn(cf, h0[n], acch0[n]);
+            accg1[n] = __fmaf_rn(cf, g1[n], accg1[n]);
+            acch1[n] = __fmaf_rn(cf, h1[n], acch1[n]);
+        }
+        loss_acc += a.inv_obs * (lp - a.lik_scale * loglik);  // svi.py:278-281
+        n_acc += 1.0f;
+    };
+    if (live1) example(xa0, xa1, ya, er);
+    if (live2) example(xb0, xb1, yb, er + D);
+    // further items of this wave (only when the grid was sized for fewer items than the step has: an unlucky shard of a
+    // row-sharded batch): loaded, their noise generated and consumed one at a time
+    for (uint32_t k = k2 + (uint32_t)a.nw * W; k < n_items; k += (uint32_t)a.nw * W) {
+        const uint32_t p = PLIST ? (a.plist_base + (size_t)step_t * a.B)[k] : k;
+        const size_t row = (size_t)((uint64_t)idx[p] - a.row_lo);
+        const float* xr = a.X + row * D;
+        const float4 x0 = *reinterpret_cast<const float4*>(xr + 4 * lane), x1 = *reinterpret_cast<const float4*>(xr + D / 2 + 4 * lane);
+        const float yv = a.y[row];
+        gen(skeys[2 * p], skeys[2 * p + 1], er);
+        example(x0, x1, yv, er);
+    }
+    D3P_CSTAMP(5)
+
+    // ------------------------------------------------------------------ phase 4: workgroup reduction, atomics, arrival
+    // (the wave's row held its noise; both examples are consumed, the row now takes its partial sums)
+    *reinterpret_cast<float4*>(er + c0) = make_float4(accg0[0], accg0[1], accg0[2], accg0[3]);
+    *reinterpret_cast<float4*>(er + c1) = make_float4(accg1[0], accg1[1], accg1[2], accg1[3]);
+    *reinterpret_cast<float4*>(er + D + c0) = make_float4(acch0[0], acch0[1], acch0[2], acch0[3]);
+    *reinterpret_cast<float4*>(er + D + c1) = make_float4(acch1[0], acch1[1], acch1[2], acch1[3]);
+    if (lane == 0) { tail[2 * wave] = loss_acc; tail[2 * wave + 1] = n_acc; }
+    __syncthreads();
+    D3P_CSTAMP(6)
+    {
+        // fixed-point integer atomics: the exact, order-independent sum of the workgroups' fp32 partials
+        long long* outp = acc_cur + (size_t)(bid % R) * PA;
+        float sL = 0.f, sS = 0.f;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            sL += red[(size_t)w * P + tid];
+            sS += red[(size_t)w * P + D + tid];
+        }
+        const double dL = (double)sL * a.sg, dS = (double)sS * a.sg;
+        bool bad = !(fabs(dL) < 4503599627370496.0) | !(fabs(dS) < 4503599627370496.0);
+        if (!(STAMPS && (a.dbg & 4))) {  // (diagnostic instantiation only: D3P_DBG=4 switches the gradient atomics off)
+            atomicAdd(reinterpret_cast<unsigned long long*>(outp + tid), (unsigned long long)__double2ll_rn(dL));
+            atomicAdd(reinterpret_cast<unsigned long long*>(outp + D + tid), (unsigned long long)__double2ll_rn(dS));
+        }
+        if (tid < 3) {  // thread 0: loss, fine part; 1: example count; 2: loss, coarse part
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < W; ++w) s += tail[2 * w + (tid & 1)];
+            long long hi, lo;
+            const bool ok = loss_split(s, hi, lo);
+            if (tid != 1) bad |= !ok;
+            const long long v = tid == 0 ? lo : tid == 1 ? (long long)s : hi;
+            atomicAdd(reinterpret_cast<unsigned long long*>(outp + P + tid), (unsigned long long)v);
+        }
+        if (bad) {  // (rare) poison the count column: the next prologue yields NaN like the reference's float sums
+            atomicAdd(reinterpret_cast<unsigned long long*>(outp + P + 1), 1ull << 44);
+            __hip_atomic_store(a.status + 1, 1u, __ATOMIC_RELAXED, D3P_AGENT);
+        }
+    }
+    D3P_CSTAMP(9)
+    // arrive: this workgroup's atomics (and, for workgroup 0, the published state; the zeroed accumulator) are complete
+    // at the memory side before the counters move
+    __builtin_amdgcn_s_waitcnt(0);
+    D3P_CSTAMP(10)
+    __syncthreads();
+    D3P_CSTAMP(11)
+    if (tid == 0) {
+        uint32_t* bar = a.bar + (size_t)step_t * D3P_BAR_WORDS;
+        const uint32_t nw = (uint32_t)a.nw, grp = bid % D3P_BAR_GROUPS, gsize = (nw + D3P_BAR_GROUPS - 1u - grp) / D3P_BAR_GROUPS;
+        const uint32_t prev = __hip_atomic_fetch_add(bar + D3P_BAR_LINE * (1 + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
+        if (prev + 1u == gsize)  // this group's flag; the waiters poll the flags of all groups
+            __hip_atomic_store(bar + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
+        if (STAMPS && a.stamps) {
+            stamp[12] = wall_clock64();
+            stamp[13] = (unsigned long long)prev;
+            const int rec = step_t - (a.K - 2);
+            if (rec >= 0 && bid < 256u)
+                for (int k = 0; k < 16; ++k) a.stamps[((size_t)rec * 256 + bid) * 16 + k] = stamp[k];
+        }
+    }
+#undef D3P_CSTAMP
+}
+
+}  // namespace d3p

@@ -13,7 +13,8 @@ namespace d3p {
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // LDS of k_logreg_main: derived columns (5 x D) | W x P reduction rows | 2W loss/count tail | 4 status words
-static inline size_t main_lds_bytes(int D, int W) { return (size_t)(((5 * D + 3) & ~3) + W * 2 * D + 2 * W + 4) * sizeof(float); }
+// (+ 16 phase stamps of 8 bytes for the D3P_DBG=32 diagnostic of the chained launch)
+static inline size_t main_lds_bytes(int D, int W) { return (size_t)(((5 * D + 3) & ~3) + W * 2 * D + 2 * W + 4 + 32) * sizeof(float); }
 
 #define D3P_MAIN_MAX_BLOCKS 2048u
 
@@ -84,6 +85,30 @@ __device__ __forceinline__ void px_sample_key(uint32_t j0, uint32_t j1, uint32_t
     threefry2x32(g0, g1, 1u, 3u, b, o1);
 }
 
+
+
+// Row layout of a fixed-point accumulator replica: P gradient columns (scale 2^40 / C) | loss, fine part | example count |
+// loss, coarse part | spare.  The loss partial s of a workgroup (any magnitude a float can hold up to 2^78) is split exactly
+// as s = hi 2^27 + lo with hi = rint(s 2^-27) and the remainder lo kept at a resolution of 2^-24: both parts are integers that
+// sum exactly and order-independently like the gradient columns, and no model-dependent bound has to be guessed.
+#define D3P_ACC_COLS(P) ((P) + 4)
+#define D3P_LOSS_HI_UNIT 134217728.0   // 2^27
+#define D3P_LOSS_LO_SCALE 16777216.0   // 2^24
+
+// the two integer parts of a workgroup's loss partial; false when it is not finite or beyond 2^78
+__device__ __forceinline__ bool loss_split(float s, long long& hi, long long& lo)
+{
+    const double sd = (double)s;
+    const double h = rint(sd * (1.0 / D3P_LOSS_HI_UNIT));
+    hi = __double2ll_rn(h);
+    lo = __double2ll_rn((sd - h * D3P_LOSS_HI_UNIT) * D3P_LOSS_LO_SCALE);
+    return fabs(sd) < 3.0e23;
+}
+
+__device__ __forceinline__ double loss_join(long long hi, long long lo)
+{
+    return (double)hi * D3P_LOSS_HI_UNIT + (double)lo * (1.0 / D3P_LOSS_LO_SCALE);
+}
 
 #define D3P_ACC_R 4  // replicas of the fixed-point accumulator (16-wave form: 8 -> 14.75, 4 -> 14.43, 2 -> 15.9 us/step; pipelined form: 8 -> 11.2, 4 -> 10.6, 2 -> 12.3)
 
@@ -222,9 +247,9 @@ __device__ __forceinline__ void chain_step(Sched* sched, StepSlot* slot, int t, 
 // associative, so the result is the exact sum of the fp32 workgroup partials and bitwise reproducible,
 // unlike float atomics); the NEXT launch's prologue turns the pending sums into the parameter update.
 struct StepFuse {
-    long long* acc_prev;  // R x (P + 2): sums of the previous step (read in the prologue if apply_prev)
-    long long* acc_cur;   // R x (P + 2): this step's sums (zeroed by the previous launch)
-    long long* acc_next;  // R x (P + 2): zeroed here for the next launch
+    long long* acc_prev;  // R x D3P_ACC_COLS(P): sums of the previous step (read in the prologue if apply_prev)
+    long long* acc_cur;   // R x D3P_ACC_COLS(P): this step's sums (zeroed by the previous launch)
+    long long* acc_next;  // R x D3P_ACC_COLS(P): zeroed here for the next launch
     int R;
     int apply_prev;
     int flush_only;       // apply the pending sums and return (after the last step of a run)
@@ -245,7 +270,6 @@ struct StepFuse {
     float dp_scale, lr, b1, b2, adam_eps;
     float prior_w, prior_b;
     double sg, inv_sg;           // fixed-point scale of the gradient columns (2^40 / C) and its inverse
-    double sl, inv_sl;           // fixed-point scale of the loss column
     // run status (sticky, cleared once per run, read back by d3p_dpvi_logreg_run_status): [0] a bounded wait of the chained
     // launch ran out (the run stops advancing: no workgroup applies or publishes anything any more), [1] a workgroup
     // partial was not finite or left the fixed-point range (the next update turns the parameters and the loss into NaN, as
@@ -277,7 +301,7 @@ struct ChainFuse {
     const float* noise_base;     // K x P
     const StepSlot* prev_slot0;  // slot of step g0 - 1 (nullptr: nothing to apply before step 0)
     const float* prev_noise0;
-    long long* acc_base;         // 3 x R x (P + 2)
+    long long* acc_base;         // 3 x R x D3P_ACC_COLS(P)
     float* state[2][3];          // ping-ponged {params, m, v}
     float* losses;               // nullable; losses[g] of the run
     uint32_t* bar;               // K x D3P_BAR_WORDS arrival counters (zeroed before the launch) + chain progress word
@@ -343,7 +367,8 @@ struct ExLoad {
 // 0 .. half - 2 and half .. D - 1 (the last one is the intercept); the second-half features are not 16-byte aligned and
 // come through scalar loads.  The left-over pair (half - 1, -) is the "tail column": every lane computes it redundantly
 // (one more threefry call per example) and lane 0 owns its accumulators.
-template <int V, int NK, int MODE, bool FULL, int EPS, bool TAIL = false>
+// STAMPS: diagnostic instantiation of the chained form with phase stamps (D3P_DBG=32); production kernels carry none.
+template <int V, int NK, int MODE, bool FULL, int EPS, bool TAIL = false, bool STAMPS = false>
 __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg_main(MainArgs a_in)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -359,7 +384,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         bid = blockIdx.x % per;
         nblk = per;
         const int g = cf.g0 + step_t;
-        const size_t Pc = 2 * (size_t)a_in.D, words = (size_t)D3P_ACC_R * (Pc + 2);
+        const size_t Pc = 2 * (size_t)a_in.D, words = (size_t)D3P_ACC_R * D3P_ACC_COLS(Pc);
         a.idx = cf.idx_base ? cf.idx_base + (size_t)step_t * a_in.B : nullptr;
         a.counts = cf.slots[step_t].counts;
         a.skeys = cf.skeys_base + (size_t)step_t * 2 * a_in.B;
@@ -388,8 +413,16 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
     const bool eps_from_mem = (EPS == 1) || (EPS < 0 && a.eps_ext != nullptr);
     const int SS = (a.dbg & 32) ? 8 : 2;  // diagnostic build: 8 phase stamps per workgroup
     const long long clk0 = (a.dbg & 32) ? clock64() : 0;
-    if (a.stamps && threadIdx.x == 0) a.stamps[SS * bid] = wall_clock64();
-#define D3P_STAMP(k) if ((a.dbg & 32) && a.stamps && threadIdx.x == 0) a.stamps[8 * bid + (k)] = wall_clock64();
+    if (!CHAIN && a.stamps && threadIdx.x == 0) a.stamps[SS * bid] = wall_clock64();
+    // D3P_DBG=32 phase stamps (100 MHz wall clock).  Chained launch: thread 0 keeps 16 stamps in LDS -- no global stores
+    // between the phases, whose acknowledgements the in-order vmcnt would charge to the next phase -- and copies them out
+    // when the workgroup is done; the last two steps of the launch are recorded.  Other modes: straight to memory.
+#define D3P_STAMP(k)                                                                                                     \
+    if (CHAIN) {                                                                                                         \
+        if (STAMPS && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(lds)[stamp_off + (k)] = wall_clock64();    \
+    } else if ((k) < 8 && (a.dbg & 32) && a.stamps && threadIdx.x == 0) {                                                \
+        a.stamps[8 * bid + (k)] = wall_clock64();                                                                        \
+    }
     constexpr int NC = V * NK;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -401,6 +434,8 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
     // ---- stage the derived parameter columns in LDS once per workgroup (5 x D floats)
     float* pk = lds;                       // [loc | s | sg | q | lc]
     float* red = lds + ((5 * D + 3) & ~3); // W x P reduction buffer (MODE 0) + 2W tail
+    const int stamp_off = (((5 * D + 3) & ~3) + W * P + 2 * W + 4) / 2;  // in 8-byte units, behind the 4 status words
+    D3P_STAMP(0)
     // Update prologue of MODE 2 / 3 (finish_prologue below).  Measured: issuing its loads here and keeping them in registers
     // across the eps generation costs 12 extra VGPRs -> 128 VGPRs + scratch and a slower kernel (14.8 vs 12.5 us), so the
     // prologue runs in one piece.
@@ -410,7 +445,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
     auto okw = [&]() { return reinterpret_cast<uint32_t*>(red + (size_t)W * P + 2 * W); };
     if (FUSE) {
         const StepFuse& f = a.fuse;
-        const int PA = P + 2;
+        const int PA = D3P_ACC_COLS(P);
         if (bid == nblk - 1 && (CHAIN || f.chain_slot)) {  // piggy-backed key-chain workgroup
             if (f.chain_slot && threadIdx.x < 64) {
                 bool go = true;
@@ -458,7 +493,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         if (!FUSE || prologue_done) return false;
         prologue_done = true;
         const StepFuse& f = a.fuse;
-        const int PA = P + 2;
+        const int PA = D3P_ACC_COLS(P);
         const bool all_waves = CHAIN && a.chain.pregen && !f.flush_only && !(a.dbg & 128);
         // ---- run status first: an aborted run (a bounded wait ran out somewhere) must not advance any further
         if (CHAIN) {
@@ -480,7 +515,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
                 if (okw()[0] != 0u) return true;
             }
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            if ((a.dbg & 32) && a.stamps && threadIdx.x == 0) a.stamps[8 * bid + 7] = wall_clock64();  // release seen
+            D3P_STAMP(7)  // release seen
         } else if (f.status && __hip_atomic_load(f.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) {
             // (flush launch behind an aborted chained launch: the pending sums are incomplete)
             if (bid == 0 && threadIdx.x == 0 && f.prev_loss_out) *f.prev_loss_out = __builtin_nanf("");
@@ -664,10 +699,13 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             load_n();
             const float n = count_n();
             const float factor = (n == 0.0f) ? 0.0f : Bf / n;
-            long long lll = 0;
+            long long lll = 0, lhh = 0;
 #pragma unroll
-            for (int r = 0; r < D3P_ACC_R; ++r) lll += ld_x<CHAIN>(f.acc_prev + (size_t)r * PA + P);
-            if (f.prev_loss_out) *f.prev_loss_out = ((float)((double)lll * f.inv_sl) / Bf) * a.obs_scale * factor;
+            for (int r = 0; r < D3P_ACC_R; ++r) {
+                lll += ld_x<CHAIN>(f.acc_prev + (size_t)r * PA + P);
+                lhh += ld_x<CHAIN>(f.acc_prev + (size_t)r * PA + P + 2);
+            }
+            if (f.prev_loss_out) *f.prev_loss_out = ((float)loss_join(lhh, lll) / Bf) * a.obs_scale * factor;
             *f.adam_step = f.prev_meta->adam_i + 1;
             if (f.batch_index) *f.batch_index = f.prev_meta->batch_i + 1u;
         }
@@ -830,6 +868,11 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
         staged = true;                            \
         if (CHAIN && stage_aborted()) return;     \
     } while (0)
+    D3P_STAMP(8)  // parameter-independent work done (rows loaded, noise of the first two examples generated)
+    // Pipelined form: from here on this workgroup is on the critical path of the step (wait for the release, update, gradients,
+    // exchange), while the co-resident workgroup of the NEXT step generates its noise on the same SIMDs -- integer VALU work
+    // that issues at 4 cycles per wave64 instruction.  Raising the wave priority lets the critical instructions go first.
+    if (CHAIN && (a.dbg & 2)) __builtin_amdgcn_s_setprio(3);
     if (FUSE) {
         const bool aborted = finish_prologue();
         D3P_STAMP(2)
@@ -1017,21 +1060,24 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             // fixed-point integer atomics: exact, order-independent sum of the workgroups' fp32 partials
             // (a partial that is not finite, or whose fixed-point image leaves +-2^52 -- 2048 of those still fit int64 --,
             // raises status[1]: the next prologue then yields NaN like the reference's float sums, instead of finite garbage)
-            long long* out = a.fuse.acc_cur + (size_t)(bid % D3P_ACC_R) * (P + 2);
+            long long* out = a.fuse.acc_cur + (size_t)(bid % D3P_ACC_R) * D3P_ACC_COLS(P);
             bool bad = false;
             for (int c = threadIdx.x; c < P; c += blockDim.x) {
                 float s = 0.f;
                 for (int w = 0; w < W; ++w) s += red[(size_t)w * P + c];
                 const double sd = (double)s * a.fuse.sg;
                 bad |= !(fabs(sd) < 4503599627370496.0);
+                if (STAMPS && (a.dbg & 4)) continue;  // ablation (diagnostic instantiation only): no gradient atomics
                 atomicAdd(reinterpret_cast<unsigned long long*>(out + c), (unsigned long long)__double2ll_rn(sd));
             }
-            if (threadIdx.x < 2) {
+            if (threadIdx.x < 3) {  // thread 0: loss, fine part; 1: example count; 2: loss, coarse part
                 float s = 0.f;
-                for (int w = 0; w < W; ++w) s += tail[2 * w + threadIdx.x];
-                const double sd = (double)s * (threadIdx.x == 0 ? a.fuse.sl : 1.0);
-                bad |= !(fabs(sd) < 4503599627370496.0);
-                atomicAdd(reinterpret_cast<unsigned long long*>(out + P + threadIdx.x), (unsigned long long)__double2ll_rn(sd));
+                for (int w = 0; w < W; ++w) s += tail[2 * w + (threadIdx.x & 1)];
+                long long hi, lo;
+                const bool ok = loss_split(s, hi, lo);
+                if (threadIdx.x != 1) bad |= !ok;
+                const long long v = threadIdx.x == 0 ? lo : threadIdx.x == 1 ? (long long)s : hi;
+                atomicAdd(reinterpret_cast<unsigned long long*>(out + P + threadIdx.x), (unsigned long long)v);
             }
             if (bad) {  // (rare path) poison the count column, see count_n; at most 2^18 of these per step -> still inside int64
                 atomicAdd(reinterpret_cast<unsigned long long*>(out + P + 1), 1ull << 44);
@@ -1039,15 +1085,26 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             }
             if (CHAIN) {
                 // arrive: this workgroup's atomics (and, for workgroup 0, the published state and the zeroed accumulator)
-                // are complete at the memory side before the counters move; two levels keep the contention per word low
+                // are complete at the memory side before the counters move; one counter per group keeps the contention low
+                D3P_STAMP(9)   // atomics issued
                 __builtin_amdgcn_s_waitcnt(0);
+                D3P_STAMP(10)  // ... and acknowledged (wave 0)
                 __syncthreads();
+                D3P_STAMP(11)
                 if (threadIdx.x == 0) {
                     uint32_t* bar = a.chain.bar + (size_t)step_t * D3P_BAR_WORDS;
                     const uint32_t nw = (uint32_t)a.chain.nw, grp = bid % D3P_BAR_GROUPS, gsize = (nw + D3P_BAR_GROUPS - 1u - grp) / D3P_BAR_GROUPS;
                     const uint32_t prev = __hip_atomic_fetch_add(bar + D3P_BAR_LINE * (1 + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
                     if (prev + 1u == gsize)  // this group's flag; the waiters poll the flags of all groups
                         __hip_atomic_store(bar + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
+                    if (STAMPS && a.stamps) {  // arrival returned; copy the stamps of the last two steps out
+                        unsigned long long* st = reinterpret_cast<unsigned long long*>(lds) + stamp_off;
+                        st[12] = wall_clock64();
+                        st[13] = (unsigned long long)prev;
+                        const int rec = step_t - (a.chain.K - 2);
+                        if (rec >= 0 && bid < 256u)
+                            for (int k = 0; k < 16; ++k) a.stamps[((size_t)rec * 256 + bid) * 16 + k] = st[k];
+                    }
                 }
             }
         } else {
@@ -1064,7 +1121,7 @@ __global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg
             }
         }
     }
-    if (a.stamps) {
+    if (!CHAIN && a.stamps) {
         __syncthreads();
         if (threadIdx.x == 0) a.stamps[SS * bid + 1] = wall_clock64();
         if ((a.dbg & 32) && !CHAIN && threadIdx.x == 0) a.stamps[8 * bid + 7] = (unsigned long long)(clock64() - clk0);
@@ -1215,6 +1272,12 @@ static int launch_main(hipStream_t s, const MainGeom& g, const MainArgs& a, hipE
     else                                                                                                                  \
         hipLaunchKernelGGL((k_logreg_main<4, NK_, MODE, true, E_, true>), dim3(g.blocks), dim3(64 * g.W), g.lds, s, a);     \
     return check_launch("k_logreg_main")
+    if constexpr (MODE == 3) {  // D3P_DBG=32: the stamped instantiation of the headline tile
+        if ((a.dbg & 32) && a.stamps && g.V == 4 && g.full && !g.tail && g.NK == 1 && !a.eps_ext) {
+            hipLaunchKernelGGL((k_logreg_main<4, 1, 3, true, 0, false, true>), dim3(g.blocks), dim3(64 * g.W), g.lds, s, a);
+            return check_launch("k_logreg_main");
+        }
+    }
     if (g.tail) {
         if (MODE == 1) return fail(D3P_E_UNSUPPORTED, "logreg kernel: the materialising stage has no tail-column form");
         if (MODE != 1) {

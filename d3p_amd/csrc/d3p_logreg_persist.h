@@ -355,7 +355,8 @@ __global__ void __launch_bounds__(64 * D3P_PERSIST_W) k_logreg_persist(MainArgs 
             long long s2 = wave_sum_i64(__double2ll_rn((double)__uint_as_float((uint32_t)w23) * f.sg));
             long long s3 = wave_sum_i64(__double2ll_rn((double)__uint_as_float((uint32_t)(w23 >> 32)) * f.sg));
             long long sn = wave_sum_i64(__double2ll_rn((double)rc));
-            long long sl = bid == 0 ? wave_sum_i64(__double2ll_rn((double)rl * f.sl)) : 0ll;
+            // (loss: fixed point at 2^-24 within this one workgroup -- exact and order independent for |row loss| < 2^30)
+            long long sl = bid == 0 ? wave_sum_i64(__double2ll_rn((double)rl * D3P_LOSS_LO_SCALE)) : 0ll;
             if (wave > 0) {
                 if (lane == 0) {
                     long long* mp = lpart + 6 * wave;
@@ -387,7 +388,7 @@ __global__ void __launch_bounds__(64 * D3P_PERSIST_W) k_logreg_persist(MainArgs 
                     adam_v[own_col] = vv;
                 }
                 if (bid == 0 && lane == 0) {
-                    if (cf.losses) cf.losses[g] = ((float)((double)sl * f.inv_sl) / Bf) * a.obs_scale * factor;
+                    if (cf.losses) cf.losses[g] = ((float)((double)sl * (1.0 / D3P_LOSS_LO_SCALE)) / Bf) * a.obs_scale * factor;
                     *f.adam_step = pm->adam_i + 1;
                     if (f.batch_index) *f.batch_index = pm->batch_i + 1u;
                 }

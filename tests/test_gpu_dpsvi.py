@@ -708,7 +708,7 @@ def test_chained_launch_is_reproducible_under_uneven_load(rng):
     side = torch.cuda.Stream()
     mats = [torch.randn(n, n, device="cuda") for n in (512, 1024, 3072)]
     done = torch.cuda.Event()
-    loud_state, loud_losses = svi.run_steps(st, gb, rng.PRNGKey(42), 0, steps)
+    loud_state, loud_losses = svi.run_steps(st, gb, rng.PRNGKey(42), 0, steps, check_status=False)   # stays asynchronous
     done.record()
     k = 0
     with torch.cuda.stream(side):
@@ -718,6 +718,7 @@ def test_chained_launch_is_reproducible_under_uneven_load(rng):
             k += 1
     torch.cuda.synchronize()
     assert k > 0
+    assert svi.last_run_status() == (False, False)
     assert torch.equal(loud_losses, quiet_losses) and torch.equal(loud_state.optim_state[1], quiet_state.optim_state[1])
     assert bool(torch.isfinite(quiet_losses).all())
     _check_no_wait_hit_its_bound(rng, 20000, 512, 4096)
