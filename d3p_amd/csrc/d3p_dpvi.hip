@@ -867,11 +867,11 @@ static int print_chain_anatomy(const Ctx& c)
             last_arr = at(0, b, 12) > last_arr ? at(0, b, 12) : last_arr;
             last_acked = at(0, b, 10) > last_acked ? at(0, b, 10) : last_acked;
         }
-        const char* names[13] = {"entry", "-", "prologue done", "-", "-", "examples done", "reduction barrier", "release seen",
+        const char* names[13] = {"entry", "staging barrier (lean kernel)", "prologue done", "-", "-", "examples done", "reduction barrier", "release seen",
                                  "param-independent work done", "atomics issued", "atomics acknowledged", "arrival barrier",
                                  "arrival returned"};
         fprintf(stderr, "chained step anatomy (us, relative to the last arrival of the previous step; mean / min / max over %u workgroups)\n", nb);
-        for (int k : {0, 8, 7, 2, 5, 6, 9, 10, 11, 12}) {
+        for (int k : {0, 8, 7, 2, 1, 5, 6, 9, 10, 11, 12}) {
             double sum = 0.0, mn = 1e30, mx = -1e30;
             for (uint32_t b = 0; b < nb; ++b) {
                 const double v = at(1, b, k) - last_arr;

@@ -256,63 +256,94 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     float accg0[4] = {0.f, 0.f, 0.f, 0.f}, acch0[4] = {0.f, 0.f, 0.f, 0.f}, accg1[4] = {0.f, 0.f, 0.f, 0.f}, acch1[4] = {0.f, 0.f, 0.f, 0.f};
     float loss_acc = 0.f, n_acc = 0.f;
     const int c0 = 4 * lane, c1 = D / 2 + 4 * lane;
-    auto example = [&](const float4& x0v, const float4& x1v, float yv, const float* e) {
-        float x0[4] = {x0v.x, x0v.y, x0v.z, x0v.w}, x1[4] = {x1v.x, x1v.y, x1v.z, x1v.w};
-        float e0[4], e1[4], l0[4], l1[4], s0[4], s1[4];
-        *reinterpret_cast<float4*>(e0) = *reinterpret_cast<const float4*>(e + c0);
-        *reinterpret_cast<float4*>(e1) = *reinterpret_cast<const float4*>(e + c1);
+    // NE examples in lockstep: their dependency chains (LDS reads -> dot product -> DPP wave sum -> sigmoid -> gradient ->
+    // two more wave sums -> clip factor) are independent, so the instructions of one fill the latency gaps of the other; the
+    // derived parameter columns are read from LDS once for all of them.
+    auto examples = [&](auto ne_tag, const float4* x0v, const float4* x1v, const float* yv, const float* const* ev) {
+        constexpr int NE = decltype(ne_tag)::value;
+        float x0[NE][4], x1[NE][4], e0[NE][4], e1[NE][4], z0[NE][4], z1[NE][4], tp[NE];
+        float l0[4], l1[4], s0[4], s1[4];
         *reinterpret_cast<float4*>(l0) = *reinterpret_cast<const float4*>(pk + c0);
         *reinterpret_cast<float4*>(l1) = *reinterpret_cast<const float4*>(pk + c1);
         *reinterpret_cast<float4*>(s0) = *reinterpret_cast<const float4*>(pk + D + c0);
         *reinterpret_cast<float4*>(s1) = *reinterpret_cast<const float4*>(pk + D + c1);
-        float z0[4], z1[4], tp = 0.f;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            z0[n] = __fmaf_rn(s0[n], e0[n], l0[n]);
-            z1[n] = __fmaf_rn(s1[n], e1[n], l1[n]);
-            tp = __fmaf_rn(x0[n], z0[n], tp);
-            tp = __fmaf_rn(x1[n], z1[n], tp);
+        for (int j = 0; j < NE; ++j) {
+            *reinterpret_cast<float4*>(e0[j]) = *reinterpret_cast<const float4*>(ev[j] + c0);
+            *reinterpret_cast<float4*>(e1[j]) = *reinterpret_cast<const float4*>(ev[j] + c1);
+            x0[j][0] = x0v[j].x; x0[j][1] = x0v[j].y; x0[j][2] = x0v[j].z; x0[j][3] = x0v[j].w;
+            x1[j][0] = x1v[j].x; x1[j][1] = x1v[j].y; x1[j][2] = x1v[j].z; x1[j][3] = x1v[j].w;
+            tp[j] = 0.f;
         }
-        float sg0[4], sg1[4], q0[4], q1[4], lc0[4], lc1[4];  // (requested before the wave sum needs its result)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                z0[j][n] = __fmaf_rn(s0[n], e0[j][n], l0[n]);
+                z1[j][n] = __fmaf_rn(s1[n], e1[j][n], l1[n]);
+                tp[j] = __fmaf_rn(x0[j][n], z0[j][n], tp[j]);
+                tp[j] = __fmaf_rn(x1[j][n], z1[j][n], tp[j]);
+            }
+        float sg0[4], sg1[4], q0[4], q1[4], lc0[4], lc1[4];  // (requested before the wave sums need their results)
         *reinterpret_cast<float4*>(sg0) = *reinterpret_cast<const float4*>(pk + 2 * D + c0);
         *reinterpret_cast<float4*>(sg1) = *reinterpret_cast<const float4*>(pk + 2 * D + c1);
         *reinterpret_cast<float4*>(q0) = *reinterpret_cast<const float4*>(pk + 3 * D + c0);
         *reinterpret_cast<float4*>(q1) = *reinterpret_cast<const float4*>(pk + 3 * D + c1);
         *reinterpret_cast<float4*>(lc0) = *reinterpret_cast<const float4*>(pk + 4 * D + c0);
         *reinterpret_cast<float4*>(lc1) = *reinterpret_cast<const float4*>(pk + 4 * D + c1);
-        const float t = wave_sum(tp);                      // logit x . z
-        const float A = a.A_scale * (sigmoid_f(t) - yv);   // d(-lik_scale inv_obs loglik)/dt
-        const float loglik = yv * t - softplus_f(t);
-        float g0[4], g1[4], h0[4], h1[4], n2 = 0.f, lp = 0.f;
+        float t[NE], A[NE], loglik[NE], n2[NE], lp[NE];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            g0[n] = __fmaf_rn(a.c1, z0[n], A * x0[n]);
-            g1[n] = __fmaf_rn(a.c1, z1[n], A * x1[n]);
-            h0[n] = __fmaf_rn(g0[n] * e0[n], sg0[n], -q0[n]);
-            h1[n] = __fmaf_rn(g1[n] * e1[n], sg1[n], -q1[n]);
-            n2 = __fmaf_rn(g0[n], g0[n], n2);
-            n2 = __fmaf_rn(h0[n], h0[n], n2);
-            n2 = __fmaf_rn(g1[n], g1[n], n2);
-            n2 = __fmaf_rn(h1[n], h1[n], n2);
-            lp += __fmaf_rn(a.hz * z0[n], z0[n], __fmaf_rn(-0.5f * e0[n], e0[n], lc0[n]));
-            lp += __fmaf_rn(a.hz * z1[n], z1[n], __fmaf_rn(-0.5f * e1[n], e1[n], lc1[n]));
-        }
-        n2 = wave_sum(n2);
-        lp = wave_sum(lp);
-        // clip factor 1 / max(1, ||g|| / C) (svi.py:121-122) folded into the running sum (svi.py:343-346)
-        const float cf = fminf(1.0f, a.clip * __builtin_amdgcn_rsqf(n2));
+        for (int j = 0; j < NE; ++j) t[j] = wave_sum(tp[j]);                 // logit x . z
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            accg0[n] = __fmaf_rn(cf, g0[n], accg0[n]);
-            acch0[n] = __fmaf_rn(cf, h0[n], acch0[n]);
-            accg1[n] = __fmaf_rn(cf, g1[n], accg1[n]);
-            acch1[n] = __fmaf_rn(cf, h1[n], acch1[n]);
+        for (int j = 0; j < NE; ++j) {
+            A[j] = a.A_scale * (sigmoid_f(t[j]) - yv[j]);                    // d(-lik_scale inv_obs loglik)/dt
+            loglik[j] = yv[j] * t[j] - softplus_f(t[j]);
+            n2[j] = lp[j] = 0.f;
         }
-        loss_acc += a.inv_obs * (lp - a.lik_scale * loglik);  // svi.py:278-281
-        n_acc += 1.0f;
+        float g0[NE][4], g1[NE][4], h0[NE][4], h1[NE][4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                g0[j][n] = __fmaf_rn(a.c1, z0[j][n], A[j] * x0[j][n]);
+                g1[j][n] = __fmaf_rn(a.c1, z1[j][n], A[j] * x1[j][n]);
+                h0[j][n] = __fmaf_rn(g0[j][n] * e0[j][n], sg0[n], -q0[n]);
+                h1[j][n] = __fmaf_rn(g1[j][n] * e1[j][n], sg1[n], -q1[n]);
+                n2[j] = __fmaf_rn(g0[j][n], g0[j][n], n2[j]);
+                n2[j] = __fmaf_rn(h0[j][n], h0[j][n], n2[j]);
+                n2[j] = __fmaf_rn(g1[j][n], g1[j][n], n2[j]);
+                n2[j] = __fmaf_rn(h1[j][n], h1[j][n], n2[j]);
+                lp[j] += __fmaf_rn(a.hz * z0[j][n], z0[j][n], __fmaf_rn(-0.5f * e0[j][n], e0[j][n], lc0[n]));
+                lp[j] += __fmaf_rn(a.hz * z1[j][n], z1[j][n], __fmaf_rn(-0.5f * e1[j][n], e1[j][n], lc1[n]));
+            }
+#pragma unroll
+        for (int j = 0; j < NE; ++j) n2[j] = wave_sum(n2[j]);
+#pragma unroll
+        for (int j = 0; j < NE; ++j) lp[j] = wave_sum(lp[j]);
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            // clip factor 1 / max(1, ||g|| / C) (svi.py:121-122) folded into the running sum (svi.py:343-346)
+            const float cf = fminf(1.0f, a.clip * __builtin_amdgcn_rsqf(n2[j]));
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                accg0[n] = __fmaf_rn(cf, g0[j][n], accg0[n]);
+                acch0[n] = __fmaf_rn(cf, h0[j][n], acch0[n]);
+                accg1[n] = __fmaf_rn(cf, g1[j][n], accg1[n]);
+                acch1[n] = __fmaf_rn(cf, h1[j][n], acch1[n]);
+            }
+            loss_acc += a.inv_obs * (lp[j] - a.lik_scale * loglik[j]);  // svi.py:278-281
+            n_acc += 1.0f;
+        }
     };
-    if (live1) example(xa0, xa1, ya, er);
-    if (live2) example(xb0, xb1, yb, er + D);
+    if (live2) {  // (live2 implies live1) the common case: both in lockstep
+        const float4 xs0[2] = {xa0, xb0}, xs1[2] = {xa1, xb1};
+        const float ys[2] = {ya, yb};
+        const float* es[2] = {er, er + D};
+        examples(std::integral_constant<int, 2>{}, xs0, xs1, ys, es);
+    } else if (live1) {
+        const float* es[1] = {er};
+        examples(std::integral_constant<int, 1>{}, &xa0, &xa1, &ya, es);
+    }
     // further items of this wave (only when the grid was sized for fewer items than the step has: an unlucky shard of a
     // row-sharded batch): loaded, their noise generated and consumed one at a time
     for (uint32_t k = k2 + (uint32_t)a.nw * W; k < n_items; k += (uint32_t)a.nw * W) {
@@ -322,7 +353,8 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         const float4 x0 = *reinterpret_cast<const float4*>(xr + 4 * lane), x1 = *reinterpret_cast<const float4*>(xr + D / 2 + 4 * lane);
         const float yv = a.y[row];
         gen(skeys[2 * p], skeys[2 * p + 1], er);
-        example(x0, x1, yv, er);
+        const float* es[1] = {er};
+        examples(std::integral_constant<int, 1>{}, &x0, &x1, &yv, es);
     }
     D3P_CSTAMP(5)
 

@@ -4,8 +4,8 @@ the dominant step kernel, following /opt/skills/guides/MI355X_MICROARCH.md secti
   * counters come from separate passes (TCC slots), values are in KiB;
   * on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of wide (16 B/lane) coalesced streaming
     reads -> doubled; WRITE_SIZE is exact for 16-B stores.
-The dominant kernel is the k_logreg_main instantiation with the largest summed FETCH_SIZE (the chained launch covers up to
-32 steps, so the figures are normalised by the number of steps the profiled command ran: warmup + steps).
+The dominant kernel is the k_logreg_* kernel with the largest summed FETCH_SIZE (a chained launch covers up to 128 steps,
+so the figures are normalised by the number of steps the profiled command ran: warmup + steps).
 usage: pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <out.json> <total_steps> [<committed file name> <commit>]"""
 import collections
 import csv
@@ -18,7 +18,7 @@ def per_kernel(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "k_logreg_main" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if "k_logreg" in r["Kernel_Name"] and r["Counter_Name"] == counter:
             acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return acc
 
