@@ -140,21 +140,26 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     // guide noise of both examples into the wave's own row: lane owns columns 4 lane .. + 3 and D/2 + the same, i.e. the
     // pairs (c, c + D/2) of jax's iota layout come out of ONE threefry2x32 call
     float* er = red + (size_t)wave * P;
+    // returns the lane's share of -0.5 |eps|^2 (the log q term of the loss: parameter-independent, so summed here)
     auto gen = [&](uint32_t k0, uint32_t k1_, float* dst) {
         const uint32_t s0 = __builtin_amdgcn_readfirstlane(k0), s1 = __builtin_amdgcn_readfirstlane(k1_);  // wave-uniform keys
-        float v0[4], v1[4];
+        float v0[4], v1[4], e2 = 0.f;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             uint32_t b0, b1;
             threefry2x32(s0, s1, (uint32_t)(4 * lane + n), (uint32_t)(4 * lane + n + D / 2), b0, b1);
             v0[n] = bits_to_normal_wu(b0);
             v1[n] = bits_to_normal_wu(b1);
+            e2 = __fmaf_rn(v0[n], v0[n], e2);
+            e2 = __fmaf_rn(v1[n], v1[n], e2);
         }
         *reinterpret_cast<float4*>(dst + 4 * lane) = make_float4(v0[0], v0[1], v0[2], v0[3]);
         *reinterpret_cast<float4*>(dst + D / 2 + 4 * lane) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+        return -0.5f * e2;
     };
-    if (live1) gen(ka0, ka1, er);
-    if (live2) gen(kb0, kb1, er + D);
+    float ea = 0.f, eb = 0.f;
+    if (live1) ea = gen(ka0, ka1, er);
+    if (live2) eb = gen(kb0, kb1, er + D);
     D3P_CSTAMP(8)
     // From here on the workgroup is on the critical path of the step (D3P_DBG=2: raised wave priority against the co-resident
     // workgroup of the next step, which is generating its noise on the same SIMDs).
@@ -259,7 +264,10 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     // NE examples in lockstep: their dependency chains (LDS reads -> dot product -> DPP wave sum -> sigmoid -> gradient ->
     // two more wave sums -> clip factor) are independent, so the instructions of one fill the latency gaps of the other; the
     // derived parameter columns are read from LDS once for all of them.
-    auto examples = [&](auto ne_tag, const float4* x0v, const float4* x1v, const float* yv, const float* const* ev) {
+    // The latent part of the loss of an example, sum_j [ hz z_j^2 - eps_j^2 / 2 + lc_j ] (log p(z) - log q(z) up to constants),
+    // is split into the parameter-independent -|eps|^2 / 2 (from phase 0, `e2v`), the example-independent sum of the lc
+    // column (one pass per call) and hz |z|^2, which alone stays in the per-element loop.
+    auto examples = [&](auto ne_tag, const float4* x0v, const float4* x1v, const float* yv, const float* const* ev, const float* e2v) {
         constexpr int NE = decltype(ne_tag)::value;
         float x0[NE][4], x1[NE][4], e0[NE][4], e1[NE][4], z0[NE][4], z1[NE][4], tp[NE];
         float l0[4], l1[4], s0[4], s1[4];
@@ -313,9 +321,12 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
                 n2[j] = __fmaf_rn(h0[j][n], h0[j][n], n2[j]);
                 n2[j] = __fmaf_rn(g1[j][n], g1[j][n], n2[j]);
                 n2[j] = __fmaf_rn(h1[j][n], h1[j][n], n2[j]);
-                lp[j] += __fmaf_rn(a.hz * z0[j][n], z0[j][n], __fmaf_rn(-0.5f * e0[j][n], e0[j][n], lc0[n]));
-                lp[j] += __fmaf_rn(a.hz * z1[j][n], z1[j][n], __fmaf_rn(-0.5f * e1[j][n], e1[j][n], lc1[n]));
+                lp[j] = __fmaf_rn(z0[j][n], z0[j][n], lp[j]);
+                lp[j] = __fmaf_rn(z1[j][n], z1[j][n], lp[j]);
             }
+        const float lcs = ((lc0[0] + lc0[1]) + (lc0[2] + lc0[3])) + ((lc1[0] + lc1[1]) + (lc1[2] + lc1[3]));
+#pragma unroll
+        for (int j = 0; j < NE; ++j) lp[j] = __fmaf_rn(a.hz, lp[j], lcs + e2v[j]);
 #pragma unroll
         for (int j = 0; j < NE; ++j) n2[j] = wave_sum(n2[j]);
 #pragma unroll
@@ -339,10 +350,11 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         const float4 xs0[2] = {xa0, xb0}, xs1[2] = {xa1, xb1};
         const float ys[2] = {ya, yb};
         const float* es[2] = {er, er + D};
-        examples(std::integral_constant<int, 2>{}, xs0, xs1, ys, es);
+        const float e2s[2] = {ea, eb};
+        examples(std::integral_constant<int, 2>{}, xs0, xs1, ys, es, e2s);
     } else if (live1) {
         const float* es[1] = {er};
-        examples(std::integral_constant<int, 1>{}, &xa0, &xa1, &ya, es);
+        examples(std::integral_constant<int, 1>{}, &xa0, &xa1, &ya, es, &ea);
     }
     // further items of this wave (only when the grid was sized for fewer items than the step has: an unlucky shard of a
     // row-sharded batch): loaded, their noise generated and consumed one at a time
@@ -352,9 +364,9 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         const float* xr = a.X + row * D;
         const float4 x0 = *reinterpret_cast<const float4*>(xr + 4 * lane), x1 = *reinterpret_cast<const float4*>(xr + D / 2 + 4 * lane);
         const float yv = a.y[row];
-        gen(skeys[2 * p], skeys[2 * p + 1], er);
+        const float e2 = gen(skeys[2 * p], skeys[2 * p + 1], er);
         const float* es[1] = {er};
-        examples(std::integral_constant<int, 1>{}, &x0, &x1, &yv, es);
+        examples(std::integral_constant<int, 1>{}, &x0, &x1, &yv, es, &e2);
     }
     D3P_CSTAMP(5)
 
