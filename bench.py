@@ -286,15 +286,17 @@ def main():
         if krec is not None:
             chained = single and not os.environ.get("D3P_NO_CHAINED_STEPS")
             traffic, traffic_src = None, None
-            tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if chained and os.path.exists(tfile):
+            import glob
+            tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+            tfile = tfiles[-1] if tfiles else ""
+            if chained and tfile:
                 # NOT measured in this run: PMC counters need rocprofv3's own passes (tools/profile_round.sh); the figure is the
                 # committed profile's bytes per step x this run's steps per launch, with its provenance beside it
                 try:
                     rec = json.load(open(tfile))
                     per_step = rec.get("hbm_bytes_per_step")
                     traffic = per_step * krec["steps_per_launch"] if per_step is not None else None
-                    traffic_src = {"file": "profiles/" + str(rec.get("source", "traffic_latest.json")), "commit": rec.get("commit"),
+                    traffic_src = {"file": "profiles/" + os.path.basename(tfile), "commit": rec.get("commit"), "kernel": rec.get("kernel"),
                                    "profiled_steps": rec.get("steps"), "hbm_bytes_per_step": per_step,
                                    "ratio_to_algorithmic": (round(per_step / krec["algorithmic_bytes_per_step"], 3)
                                                             if per_step is not None else None),
@@ -303,7 +305,8 @@ def main():
                 except Exception:  # noqa: BLE001
                     traffic, traffic_src = None, None
             roofline = {"bound": "hbm",
-                        "kernel": ("k_logreg_main<MODE 3> (chained launch: the <= 128 DP-VI steps of a prepared batch per launch)" if chained
+                        "kernel": ("k_logreg_chain (chained launch: the <= 128 DP-VI steps of a prepared batch per launch; "
+                                   "k_logreg_main<MODE 3> for shapes other than d = 512 without intercept)" if chained
                                    else "k_logreg_main<MODE 2> (one launch per DP-VI step)"),
                         "achieved": krec["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": krec["frac"],
                         "traffic": traffic, "traffic_source": traffic_src,
