@@ -97,6 +97,7 @@ SIGNATURES = {
     "d3p_rng_uniform": (C.c_int, [_V, _V, _U64, _F, _F, _V]),
     "d3p_rng_normal": (C.c_int, [_V, _V, _U64, _V]),
     "d3p_rng_randint": (C.c_int, [_V, _V, _U64, _I32, _I32, _V]),
+    "d3p_rng_randint_bits": (C.c_int, [_V, _V, _U64, C.c_int, C.c_int64, C.c_int64, _V]),
     "d3p_tf_split": (C.c_int, [_V, _V, C.c_int, _V]),
     "d3p_tf_fold_in": (C.c_int, [_V, _V, _U32, _V]),
     "d3p_tf_random_bits": (C.c_int, [_V, _V, _U64, _V]),

@@ -77,6 +77,38 @@ __global__ void k_rng_randint(const uint32_t* __restrict__ key, uint64_t n, uint
     out[j] = (int32_t)u + minval;
 }
 
+// The same for the 8-, 16-, 32- and 64-bit integer dtypes (d3p/random/__init__.py:115-123): element j of
+// random_bits(round_key, nbits, shape) is the little-endian nbits-wide view of the keystream at byte j * nbits / 8.
+template <typename U, typename V>
+__global__ void k_rng_randint_bits(const uint32_t* __restrict__ key, uint64_t n, U delta, U bitmask, V minval, V* __restrict__ out)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    constexpr int NB = (int)sizeof(U);
+    const uint64_t byte0 = j * NB;
+    const uint32_t blk = (uint32_t)(byte0 >> 6), w0 = (uint32_t)(byte0 & 63) >> 2, sh = (uint32_t)(byte0 & 3) * 8u;
+    uint32_t cur[16], nxt[16], rk[16], o[16];
+    load_key(key, cur);
+    U u = 0;
+    for (int round = 0; round < 4096; ++round) {
+        derive_child(cur, 0u, 0u, D3P_TAG_SPLIT, nxt);
+        derive_child(cur, 1u, 0u, D3P_TAG_SPLIT, rk);
+        keystream_block(rk, blk, o);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            lo = (w0 == (uint32_t)t) ? o[t] : lo;
+            hi = (w0 + 1u == (uint32_t)t) ? o[t] : hi;
+        }
+        const unsigned long long raw = NB == 8 ? (((unsigned long long)hi << 32) | lo) : (unsigned long long)(lo >> sh);
+        u = (U)raw & bitmask;
+        if (u <= delta) break;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) cur[t] = nxt[t];
+    }
+    out[j] = (V)((V)u + minval);  // vdtype(uvals) + minval, wrapping in the value dtype
+}
+
 // ------------------------------------------------------------------------------------------
 // threefry (jax.random layouts)
 // ------------------------------------------------------------------------------------------
@@ -326,6 +358,20 @@ __global__ void k_take_rows(const char* __restrict__ table, uint32_t row_bytes, 
 
 using namespace d3p;
 
+// delta, log2 in float32 and the power-of-two mask exactly as d3p/random/__init__.py:124-128, in the unsigned dtype
+template <typename U>
+static void randint_mask(int64_t minval, int64_t maxval, U* delta, U* bitmask)
+{
+    constexpr int nbits = 8 * (int)sizeof(U);
+    *delta = (U)(unsigned long long)(maxval - 1 - minval);
+    const float l2 = log2f((float)*delta) + 1.0f;
+    int lg;
+    if (!(l2 > 0.0f)) lg = 0;                  // udtype(-inf): 0
+    else if (l2 >= (float)nbits) lg = nbits;   // jnp.minimum(..., nbits)
+    else lg = (int)l2;
+    *bitmask = lg >= nbits ? (U)~(U)0 : (U)(((U)1 << lg) - (U)1);
+}
+
 extern "C" {
 
 int d3p_abi_version(void) { return D3P_ABI_VERSION; }
@@ -407,6 +453,36 @@ int d3p_rng_randint(void* stream, const uint32_t* key_dev, uint64_t n, int32_t m
     hipLaunchKernelGGL(k_rng_randint, dim3(cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, key_dev, n, delta,
                        bitmask, minval, out_dev);
     return check_launch("d3p_rng_randint");
+}
+
+int d3p_rng_randint_bits(void* stream, const uint32_t* key_dev, uint64_t n, int bit_width, int64_t minval, int64_t maxval,
+                         void* out_dev)
+{
+    D3P_REQUIRE(key_dev && out_dev, "d3p_rng_randint_bits: null pointer");
+    D3P_REQUIRE(bit_width == 8 || bit_width == 16 || bit_width == 32 || bit_width == 64, "d3p_rng_randint_bits: bit_width must be 8, 16, 32 or 64");
+    D3P_REQUIRE((n * (uint64_t)(bit_width / 8) + 63) / 64 <= 0xFFFFFFFFull, "d3p_rng_randint_bits: too many elements");
+    if (n == 0) return D3P_OK;
+    const dim3 grid(cdiv(n, 128)), block(128);
+    hipStream_t s = (hipStream_t)stream;
+    if (bit_width == 8) {
+        uint8_t d, m;
+        randint_mask<uint8_t>(minval, maxval, &d, &m);
+        hipLaunchKernelGGL((k_rng_randint_bits<uint8_t, int8_t>), grid, block, 0, s, key_dev, n, d, m, (int8_t)minval, (int8_t*)out_dev);
+    } else if (bit_width == 16) {
+        uint16_t d, m;
+        randint_mask<uint16_t>(minval, maxval, &d, &m);
+        hipLaunchKernelGGL((k_rng_randint_bits<uint16_t, int16_t>), grid, block, 0, s, key_dev, n, d, m, (int16_t)minval, (int16_t*)out_dev);
+    } else if (bit_width == 32) {
+        uint32_t d, m;
+        randint_mask<uint32_t>(minval, maxval, &d, &m);
+        hipLaunchKernelGGL((k_rng_randint_bits<uint32_t, int32_t>), grid, block, 0, s, key_dev, n, d, m, (int32_t)minval, (int32_t*)out_dev);
+    } else {
+        unsigned long long d, m;
+        randint_mask<unsigned long long>(minval, maxval, &d, &m);
+        hipLaunchKernelGGL((k_rng_randint_bits<unsigned long long, long long>), grid, block, 0, s, key_dev, n, d, m, (long long)minval,
+                           (long long*)out_dev);
+    }
+    return check_launch("d3p_rng_randint_bits");
 }
 
 int d3p_tf_split(void* stream, const uint32_t* key_dev, int num, uint32_t* out_keys_dev)

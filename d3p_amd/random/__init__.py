@@ -135,17 +135,34 @@ def normal(key: PRNGState, shape: Sequence[int] = (), dtype=torch.float32) -> to
     return out[:n].reshape(shape)
 
 
-def randint(key: PRNGState, shape: Sequence[int], minval: int, maxval: int, dtype=torch.int32):
-    """d3p/random/__init__.py:84-146 (int32 on the device path)."""
-    if dtype in _FLOATS or dtype is float:
+_INT_BITS = {torch.int8: 8, torch.int16: 16, torch.int32: 32, torch.int64: 64}
+
+
+def _int_dtype(dtype):
+    """torch / numpy / python integer dtypes -> torch dtype (d3p/random/__init__.py:101-103: anything else is a TypeError)."""
+    if dtype is int:
+        return torch.int32                     # jax.dtypes.canonicalize_dtype without x64
+    if isinstance(dtype, torch.dtype):
+        t = dtype
+    else:
+        import numpy as np
+        try:
+            t = {"int8": torch.int8, "int16": torch.int16, "int32": torch.int32, "int64": torch.int64}.get(np.dtype(dtype).name)
+        except TypeError:
+            t = None
+    if t not in _INT_BITS:
         raise TypeError(f"dtype argument to `randint` must be an integer dtype, got {dtype}")
-    if dtype not in (torch.int32, int):
-        raise _lib.D3PError("`randint`: only int32 is implemented on the device path")
+    return t
+
+
+def randint(key: PRNGState, shape: Sequence[int], minval: int, maxval: int, dtype=torch.int32):
+    """d3p/random/__init__.py:84-146: masked rejection sampling in the 8-, 16-, 32- or 64-bit integer dtype."""
+    t = _int_dtype(dtype)
     key = _key(key)
     shape = tuple(shape)
     n = _numel(shape)
-    out = torch.empty(max(n, 1), dtype=torch.int32, device=key.device)
-    check(_lib.load().d3p_rng_randint(stream_ptr(), ptr(key), n, int(minval), int(maxval), ptr(out)))
+    out = torch.empty(max(n, 1), dtype=t, device=key.device)
+    check(_lib.load().d3p_rng_randint_bits(stream_ptr(), ptr(key), n, _INT_BITS[t], int(minval), int(maxval), ptr(out)))
     return out[:n].reshape(shape)
 
 

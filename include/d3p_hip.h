@@ -69,6 +69,13 @@ int d3p_rng_randint(void* stream, const uint32_t* key_dev, uint64_t n, int32_t m
  * debug rng_suite: threefry2x32 in jax.random's array layout -- replaces d3p/random/debug.py:34-80.
  * The same generator produces the per-example guide noise (svi.py:259, :289-290).
  * ------------------------------------------------------------------------------------------- */
+/* ABI 3: randint for the 8-, 16-, 32- and 64-bit integer dtypes (d3p/random/__init__.py:108-146, the dtype table at
+ * :115-123; tests/test_random.py:74-135 draw int8 over the full range and int16 up to 2^15): delta and the power-of-two
+ * mask are formed in the unsigned dtype of that width (float32 log2, :124-128), element j of random_bits(round_key, bit_width,
+ * shape) is the little-endian bit_width-wide view of the keystream, the result wraps in the signed dtype.  out_dev holds n
+ * elements of bit_width bits. */
+int d3p_rng_randint_bits(void* stream, const uint32_t* key_dev, uint64_t n, int bit_width, int64_t minval, int64_t maxval,
+                         void* out_dev);
 int d3p_tf_split(void* stream, const uint32_t* key_dev, int num, uint32_t* out_keys_dev);
 int d3p_tf_fold_in(void* stream, const uint32_t* key_dev, uint32_t data, uint32_t* out_key_dev);
 int d3p_tf_random_bits(void* stream, const uint32_t* key_dev, uint64_t n_words, uint32_t* out_dev);

@@ -263,6 +263,54 @@ D3P_API int d3po_randint32(const uint32_t key_in[16], uint64_t n, int32_t minval
     return 0;
 }
 
+/* The same for every integer dtype of d3p/random/__init__.py:115-123 (8, 16, 32, 64 bits): delta and the mask live in the
+ * unsigned dtype of that width (wrapping), element j of random_bits(round_key, nbits, shape) is the little-endian view of
+ * the keystream bytes, the result wraps in the signed dtype.  `out` holds n elements of nbits bits. */
+D3P_API int d3po_randint_bits(const uint32_t key_in[16], uint64_t n, int nbits, int64_t minval, int64_t maxval, void* out)
+{
+    if (nbits != 8 && nbits != 16 && nbits != 32 && nbits != 64) return -1;
+    const uint64_t full = nbits == 64 ? ~0ull : ((1ull << nbits) - 1ull);
+    const uint64_t delta = (uint64_t)(maxval - 1 - minval) & full;      /* udtype(maxval - 1 - minval) */
+    float l2 = log2f((float)delta) + 1.0f;                              /* jnp.log2(jnp.float32(delta)) + 1 */
+    int lg;
+    if (!(l2 > 0.0f)) lg = 0;
+    else if (l2 >= (float)nbits) lg = nbits;
+    else lg = (int)l2;
+    const uint64_t bitmask = lg >= nbits ? full : ((1ull << lg) - 1ull);
+    const int nb = nbits / 8;
+    const uint64_t nwords = (n * (uint64_t)nb + 3) / 4 + 1;
+    uint32_t* w = (uint32_t*)malloc(nwords * sizeof(uint32_t));
+    uint64_t* u = (uint64_t*)malloc((n ? n : 1) * sizeof(uint64_t));
+    uint8_t* done = (uint8_t*)calloc(n ? n : 1, 1);
+    if (!w || !u || !done) { free(w); free(u); free(done); return -2; }
+    uint32_t key[16], ks[32];
+    memcpy(key, key_in, sizeof(key));
+    for (int round = 0; round < 4096; ++round) {
+        int any = 0;
+        if (round > 0) {
+            for (uint64_t j = 0; j < n; ++j) any |= !done[j];
+            if (!any) break;
+        }
+        d3po_split(key, 2, ks);
+        memcpy(key, ks, sizeof(key));
+        d3po_random_words(ks + 16, 0, nwords, w);
+        const uint8_t* bytes = (const uint8_t*)w;   /* little-endian host, as the reference's */
+        for (uint64_t j = 0; j < n; ++j) {
+            if (done[j]) continue;
+            uint64_t raw = 0;
+            memcpy(&raw, bytes + j * (uint64_t)nb, (size_t)nb);
+            u[j] = raw & bitmask;
+            done[j] = u[j] <= delta;
+        }
+    }
+    for (uint64_t j = 0; j < n; ++j) {
+        const uint64_t v = (u[j] + (uint64_t)minval) & full;            /* vdtype(uvals) + minval, wrapping */
+        memcpy((uint8_t*)out + j * (uint64_t)nb, &v, (size_t)nb);
+    }
+    free(w); free(u); free(done);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * threefry2x32-20 and the jax.random (<= 0.4.10, non-partitionable) array layouts.
  * Used for (i) d3p.random.debug (d3p/random/debug.py:34-80), (ii) the per-example guide noise

@@ -151,7 +151,21 @@ def normal(key, shape=()):
     return out[:n].reshape(shape)
 
 
-def randint(key, shape, minval, maxval):
+def randint(key, shape, minval, maxval, dtype=np.int32):
+    """d3p/random/__init__.py:84-146 for int8 / int16 / int32 / int64."""
+    dt = np.dtype(dtype)
+    if dt.kind != "i":
+        raise TypeError(f"dtype argument to `randint` must be an integer dtype, got {dtype}")
+    n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
+    out = np.empty(max(n, 1), dt)
+    rc = lib().d3po_randint_bits(_p(_u32(key).reshape(16)), C.c_uint64(n), C.c_int(8 * dt.itemsize), C.c_int64(int(minval)),
+                                 C.c_int64(int(maxval)), _p(out))
+    assert rc == 0
+    return out[:n].reshape(shape)
+
+
+def randint32_legacy(key, shape, minval, maxval):
+    """The int32-only restatement (d3po_randint32), kept to pin the generic one against."""
     n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
     out = np.empty(max(n, 1), np.int32)
     lib().d3po_randint32(_p(_u32(key).reshape(16)), C.c_uint64(n), C.c_int32(minval),

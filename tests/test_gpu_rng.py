@@ -150,6 +150,22 @@ def test_debug_suite_matches_jax_layout(gpu, O):
     assert dbg.convert_to_jax_rng_key(key) is key
 
 
+@pytest.mark.parametrize("dtype,lo,hi", [(torch.int8, -2**7, 2**7), (torch.int16, 0, 2**15), (torch.int16, -300, 77),
+                                         (torch.int32, 8, 8 + 2**10 + 1), (torch.int64, -(2**40), 2**40 + 3),
+                                         (torch.int8, 5, 6)])
+def test_randint_integer_dtypes_bit_exact_vs_oracle(rng, O, dtype, lo, hi):
+    """d3p/random/__init__.py:115-123: int8 / int16 / int32 / int64 (tests/test_random.py:74-135 use int8 over its full range
+    and int16 up to 2^15).  Integer streams are compared bit for bit."""
+    npdt = {torch.int8: np.int8, torch.int16: np.int16, torch.int32: np.int32, torch.int64: np.int64}[dtype]
+    for seed, shape in [(802511, (1000, 8, 9)), (3, (1,)), (4, (65,))]:
+        got = rng.randint(rng.PRNGKey(seed), shape, lo, hi, dtype)
+        assert got.dtype == dtype and tuple(got.shape) == shape
+        exp = O.randint(O.PRNGKey(seed), shape, lo, hi, npdt)
+        assert np.array_equal(np_(got), exp)
+        assert int(got.min()) >= lo and int(got.max()) < hi
+    assert rng.randint(rng.PRNGKey(1), (4,), 0, 5, np.int16).dtype == torch.int16     # numpy dtypes are accepted too
+
+
 def test_debug_randint(gpu, O):
     import warnings
     with warnings.catch_warnings():

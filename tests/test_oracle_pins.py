@@ -422,3 +422,27 @@ def test_cpu_baseline_loop_walks_the_checker_trajectory(O):
         assert np.array_equal(st.key, ref.key) and st.step.value == steps
         assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss)
         np.testing.assert_allclose(st.params, ref.params, rtol=1e-5, atol=1e-6)
+
+
+def test_randint_integer_dtypes_like_the_reference_tests(O):
+    """d3p/random/__init__.py:108-146 for every dtype of its table (:115-123); the cases are the reference's own
+    (tests/test_random.py:74-146): int32 with 2^10 + 1 values hits both bounds and is uniform, int8 over its FULL range
+    (delta = 255 wraps in uint8, the mask is all ones), int16 up to 2^15, a single-value support gives that value."""
+    import scipy.stats
+    n = 72000
+    x = O.randint(O.PRNGKey(8025111), (1000, 8, 9), 8, 8 + 2**10 + 1, np.int32)
+    assert x.dtype == np.int32 and x.shape == (1000, 8, 9) and x.max() == 8 + 2**10 and x.min() == 8
+    assert scipy.stats.chisquare(np.bincount(x.ravel() - 8, minlength=2**10 + 1)).pvalue >= 0.01
+    assert np.array_equal(x, O.randint32_legacy(O.PRNGKey(8025111), (1000, 8, 9), 8, 8 + 2**10 + 1))   # the 32-bit restatement
+    x = O.randint(O.PRNGKey(802511), (n,), -2**7, 2**7, np.int8)
+    assert x.dtype == np.int8 and x.min() == -128 and x.max() == 127
+    assert scipy.stats.chisquare(np.bincount(x.astype(np.int64) + 128, minlength=256)).pvalue >= 0.01
+    x = O.randint(O.PRNGKey(8025111), (n,), 0, 2**15, np.int16)
+    assert x.dtype == np.int16 and x.min() >= 0 and 2**15 - 64 <= x.max() < 2**15
+    assert scipy.stats.chisquare(np.bincount(x.astype(np.int64) // 128, minlength=256)).pvalue >= 0.01
+    x = O.randint(O.PRNGKey(5), (n,), -(2**40), 2**40 + 3, np.int64)
+    assert x.dtype == np.int64 and x.min() >= -(2**40) and x.max() < 2**40 + 3 and (np.abs(x) > 2**33).any()
+    for dt in (np.int8, np.int16, np.int32, np.int64):
+        assert np.all(O.randint(O.PRNGKey(8025111), (100,), -4, -3, dt) == -4)
+    with pytest.raises(TypeError):
+        O.randint(O.PRNGKey(1), (3,), 0, 5, np.float32)
