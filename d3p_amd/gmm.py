@@ -1,7 +1,8 @@
 """Gaussian mixture density: mirror of ``d3p.gmm.GaussianMixture`` (reference d3p/gmm.py:26-107) for the part
-that is on the DP-VI path, ``log_prob``.  Sampling (``sample`` / ``sample_with_intermediates``) and the
-per-example-gradient kernel for the mixture model of examples/gaussian_mixture_model.py are not built yet
-(DESIGN.md section 9)."""
+that is on the DP-VI path, ``log_prob`` (``d3p_gmm_log_prob``).  The DP-VI step of the mixture MODEL of
+examples/gaussian_mixture_model.py (BASELINE config 3) lives in ``d3p_amd/csrc/d3p_gmm.hip`` behind
+``d3p_amd.models.GaussianMixtureModel`` / ``DPSVI``; ancestral sampling (``sample`` /
+``sample_with_intermediates``, d3p/gmm.py:88-95) is off the update path and not built."""
 import torch
 
 from . import _lib

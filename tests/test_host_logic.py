@@ -160,3 +160,42 @@ def test_shard_rows_partition():
         assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
         sizes = [hi - lo for lo, hi in parts]
         assert max(sizes) - min(sizes) <= 1
+
+
+# ---------------------------------------------------------------------------------------------- numpyro adapter
+def _site(name, dist, shape, observed=False, plate=None, **params):
+    return {"name": name, "dist": dist, "shape": tuple(shape), "event_dim": 1 if len(shape) else 0, "is_observed": observed,
+            "scale": None, "plate_sizes": [("batch", plate)] if plate else [], "params": params}
+
+
+def test_numpyro_adapter_maps_trace_records_to_the_built_families():
+    """spec_from_sites is the pure-Python half of the adapter (trace_model, the numpyro-facing half, cannot run here):
+    site records written the way numpyro's trace writes them -> model spec + flat layout.  AutoDiagonalNormal packs the
+    latent sites in SORTED name order (ravel_pytree of a dict), so the example's 'intercept' precedes 'w' in numpyro's flat
+    vector while this build keeps the intercept as the last column: the layout carries the permutation."""
+    from d3p_amd._lib import D3PError
+    from d3p_amd.models import GaussianMean, GaussianMixtureModel, LogisticRegression
+    from d3p_amd.numpyro_adapter import spec_from_sites
+    # examples/logistic_regression.py:49-66
+    spec, lay, n = spec_from_sites([_site("w", "Normal", (5,), loc=0.0, scale=4.0), _site("intercept", "Normal", (), loc=0.0, scale=4.0),
+                                    _site("ys", "Bernoulli", (7,), observed=True, plate=1000)])
+    assert isinstance(spec, LogisticRegression) and spec.d == 5 and spec.intercept and spec.prior_scale == 4.0 and n == 1000
+    assert [s for s, _ in lay.sites] == ["intercept", "w"] and lay.build_order == ["w", "intercept"] and lay.D == 6
+    numpyro_flat = [100, 0, 1, 2, 3, 4]                       # [intercept | w0..w4]
+    cols = lay.to_build_order(numpyro_flat)
+    assert cols == [0, 1, 2, 3, 4, 100] and lay.from_build_order(cols) == numpyro_flat
+    # README.md:89-99 (no intercept)
+    spec, lay, n = spec_from_sites([_site("w", "Normal", (3,), loc=0.0, scale=1.0), _site("obs", "Bernoulli", (4,), observed=True, plate=50)])
+    assert isinstance(spec, LogisticRegression) and not spec.intercept and lay.to_build == [0, 1, 2] and n == 50
+    # examples/simple_gaussian_posterior.py:51-65
+    spec, lay, _ = spec_from_sites([_site("mu", "Normal", (4,), loc=0.0, scale=1.0), _site("obs", "Normal", (10, 4), observed=True, plate=1000, scale=0.1)])
+    assert isinstance(spec, GaussianMean) and spec.d == 4 and spec.obs_scale == 0.1
+    # examples/gaussian_mixture_model.py:51-68
+    spec, lay, _ = spec_from_sites([_site("pis", "Dirichlet", (3,)), _site("mus", "Normal", (3, 2), loc=0.0, scale=10.0),
+                                    _site("sigs", "InverseGamma", (3, 2)), _site("obs", "GaussianMixture", (9, 2), observed=True, plate=100)])
+    assert isinstance(spec, GaussianMixtureModel) and (spec.k, spec.d) == (3, 2) and [s for s, _ in lay.sites] == ["mus", "pis", "sigs"]
+    with pytest.raises(D3PError):                             # anything else is refused, naming the sites
+        spec_from_sites([_site("a", "Gamma", (2,)), _site("obs", "Poisson", (3,), observed=True, plate=10)])
+    with pytest.raises(D3PError):                             # and tracing itself needs numpyro
+        from d3p_amd.numpyro_adapter import trace_model
+        trace_model(lambda: None)
