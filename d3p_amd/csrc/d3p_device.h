@@ -60,18 +60,31 @@ __device__ __forceinline__ void keystream_block(const uint32_t (&key)[16], uint3
     chacha20_block(in, out);
 }
 
+// ============================ KEY LAYOUT (this build's own -- PARITY UNPINNED, DESIGN.md sections 2-3) ============================
+// jax-chacha-prng defines how split / fold_in derive a child key; it is not vendored and no reference test pins it.  What
+// THIS build does is stated in exactly two functions -- layout_child_tweak (which words of the parent state are changed
+// before the block function) and the "child = constants | block words 0..7 | zero counter and nonce" rule in derive_child /
+// the quad forms below -- plus keystream_block above (random_bits: counter + block index, nonce untouched).  oracle/d3p_oracle.c
+// has the same three places (derive_child, d3po_key_from_bytes, d3po_random_words).  Once tests/golden/capture_from_reference.py
+// has been run against the real package, adopting its layout means editing these and nothing else.
+__device__ __forceinline__ void layout_child_tweak(uint32_t& w12, uint32_t& w13, uint32_t& w15, uint32_t ctr_add, uint32_t data,
+                                                   uint32_t tag)
+{
+    w12 += ctr_add;  // counter:  split child index
+    w13 ^= data;     // nonce[0]: fold_in data
+    w15 ^= tag;      // nonce[2]: D3P_TAG_SPLIT / D3P_TAG_FOLD -- keeps bits, split and fold_in in disjoint domains
+}
+
 // Child key derivation shared by split (tag 1, ctr_add = i) and fold_in (tag 2, data): the child
 // key is words 0..7 of the parent's block at (counter + ctr_add, nonce ^ (data, 0, tag)); child
-// counter/nonce are zero.  Layout is this build's own (parity unpinned).
+// counter/nonce are zero.
 __device__ __forceinline__ void derive_child(const uint32_t (&parent)[16], uint32_t ctr_add, uint32_t data,
                                              uint32_t tag, uint32_t (&child)[16])
 {
     uint32_t in[16], blk[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) in[i] = parent[i];
-    in[12] += ctr_add;
-    in[13] ^= data;
-    in[15] ^= tag;
+    layout_child_tweak(in[12], in[13], in[15], ctr_add, data, tag);
     chacha20_block(in, blk);
 #pragma unroll
     for (int i = 0; i < 4; ++i) child[i] = parent[i];
@@ -120,9 +133,11 @@ __device__ __forceinline__ void derive_child_quad(const uint32_t* __restrict__ p
     a = parent[q];
     b = parent[4 + q];
     uint32_t c = parent[8 + q], d = parent[12 + q];
-    if (q == 0) d += child;   // counter  (word 12)
-    if (q == 1) d ^= data;    // nonce[0] (word 13)
-    if (q == 3) d ^= tag;     // nonce[2] (word 15)
+    {  // lane q holds word 12 + q of the state: apply the layout rule to the word this lane owns
+        uint32_t w12 = d, w13 = d, w15 = d;
+        layout_child_tweak(w12, w13, w15, child, data, tag);
+        d = q == 0 ? w12 : q == 1 ? w13 : q == 3 ? w15 : d;
+    }
     chacha20_block_quad(a, b, c, d);
 }
 
@@ -134,9 +149,11 @@ __device__ __forceinline__ void derive_child_quad_regs(uint32_t p0, uint32_t p1,
     a = p0;
     b = p1;
     uint32_t c = p2, d = p3;
-    if (q == 0) d += child;   // counter  (word 12)
-    if (q == 1) d ^= data;    // nonce[0] (word 13)
-    if (q == 3) d ^= tag;     // nonce[2] (word 15)
+    {
+        uint32_t w12 = d, w13 = d, w15 = d;
+        layout_child_tweak(w12, w13, w15, child, data, tag);
+        d = q == 0 ? w12 : q == 1 ? w13 : q == 3 ? w15 : d;
+    }
     chacha20_block_quad(a, b, c, d);
 }
 

@@ -1084,12 +1084,113 @@ static const RcclApi* rccl_api()
     return state == 1 ? &api : nullptr;
 }
 
+
+// ---- One-shot full-mesh exchange of the step message: xGMI is point to point (7 links per GPU), so for
+// a message of 8 KB the latency-optimal all-reduce is not a ring (2 (n - 1) dependent hops) but ONE hop: every rank folds its
+// 4 accumulator replicas, writes the folded vector straight into an inbox slot on each of its peers (and its own), raises a
+// flag there, waits for the n flags of its own inbox and adds the n vectors locally.  int64 sums are exact and commutative, so
+// every rank obtains bitwise the same totals -- the property the RCCL path has too (it stays as the checker and fallback).
+// Inboxes are allocated uncached (fine-grained) and shared between the processes with hipIpc handles; all cross-device
+// accesses are system-scope.  Slots and flags are double-buffered by the parity of the step count: a rank can only start
+// exchange e + 1 after every peer has finished READING in exchange e (it needs their flag of e + 1, sent after their
+// exchange e), so slot parity e is free again when exchange e + 2 writes it.  Waits are bounded and raise status[0].
+#define D3P_XCHG_MAX_WORLD 16
+#define D3P_XCHG_FLAG_STRIDE 16  // uint64 words: one 128-byte line per flag
+
+struct Xchg {
+    int world, rank;
+    uint32_t words;                    // int64 words per message (one folded accumulator row)
+    unsigned long long epoch;          // exchanges done (host-side count; the device sees it as an argument)
+    char* inbox;                       // this rank's inbox: data[2][world][words] | flags[2][world][FLAG_STRIDE]
+    size_t inbox_bytes;
+    char* peer[D3P_XCHG_MAX_WORLD];    // the peers' inboxes mapped into this process (peer[rank] == inbox)
+    bool opened[D3P_XCHG_MAX_WORLD];
+};
+
+static inline size_t xchg_data_bytes(int world, uint32_t words) { return align_up((size_t)2 * world * words * sizeof(long long), 256); }
+
+struct XchgArgs {
+    long long* acc;  // R x words: this rank's replicas of the step's accumulator; on return row 0 holds the global totals, rows 1.. zeros
+    int R;
+    uint32_t words;
+    int world, rank;
+    unsigned long long epoch;  // 1-based count of this exchange
+    char* peer[D3P_XCHG_MAX_WORLD];
+    size_t data_bytes;
+    uint32_t* status;  // nullable: [0] raised when a wait runs out
+};
+
+__global__ void __launch_bounds__(1024) k_xchg(XchgArgs a)
+{
+    __shared__ uint32_t bad;
+    const int tid = threadIdx.x;
+    const unsigned parity = (unsigned)(a.epoch & 1ull);
+    if (tid == 0) bad = 0u;
+    // fold the replicas and deliver the folded row to every inbox (slot [parity][my rank])
+    for (uint32_t c = tid; c < a.words; c += blockDim.x) {
+        long long v = 0;
+        for (int r = 0; r < a.R; ++r) v += a.acc[(size_t)r * a.words + c];
+        for (int p = 0; p < a.world; ++p) {
+            long long* slot = reinterpret_cast<long long*>(a.peer[p]) + ((size_t)parity * a.world + a.rank) * a.words;
+            __hip_atomic_store(slot + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __threadfence_system();  // the rows are performed at their destinations before any flag moves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < a.world) {
+        unsigned long long* f = reinterpret_cast<unsigned long long*>(a.peer[tid] + a.data_bytes) +
+                                ((size_t)parity * a.world + a.rank) * D3P_XCHG_FLAG_STRIDE;
+        __hip_atomic_store(f, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // ... and wait for the row of rank `tid` in this rank's own inbox
+        const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(a.peer[a.rank] + a.data_bytes) +
+                                         ((size_t)parity * a.world + tid) * D3P_XCHG_FLAG_STRIDE;
+        bool ok = false;
+        for (uint32_t spins = 0; spins < (1u << 24); ++spins) {
+            if (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= a.epoch) { ok = true; break; }
+            if ((spins & 255u) == 255u && a.status && __hip_atomic_load(a.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (!ok) {
+            bad = 1u;
+            if (a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, D3P_AGENT);
+        }
+    }
+    __syncthreads();
+    if (bad) return;  // aborted: leave the accumulator as it is, the run is over (status[0])
+    const long long* inbox = reinterpret_cast<const long long*>(a.peer[a.rank]) + (size_t)parity * a.world * a.words;
+    for (uint32_t c = tid; c < a.words; c += blockDim.x) {
+        long long tot = 0;
+        for (int p = 0; p < a.world; ++p) tot += __hip_atomic_load(inbox + (size_t)p * a.words + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        a.acc[c] = tot;
+        for (int r = 1; r < a.R; ++r) a.acc[(size_t)r * a.words + c] = 0;
+    }
+}
+
+static int enqueue_xchg(hipStream_t s, Xchg* x, long long* acc, int R, uint32_t* status)
+{
+    XchgArgs a;
+    memset(&a, 0, sizeof(a));
+    a.acc = acc;
+    a.R = R;
+    a.words = x->words;
+    a.world = x->world;
+    a.rank = x->rank;
+    a.epoch = ++x->epoch;
+    for (int p = 0; p < x->world; ++p) a.peer[p] = x->peer[p];
+    a.data_bytes = xchg_data_bytes(x->world, x->words);
+    a.status = status;
+    hipLaunchKernelGGL(k_xchg, dim3(1), dim3(1024), 0, s, a);
+    return check_launch("k_xchg");
+}
+
 static int enqueue_sampler(const Ctx& c, int K);
 static int enqueue_chain(const Ctx& c, int K);
 
 // comm != nullptr: data-parallel run -- after every step launch the rank's fixed-point accumulator (R x (P + 2) int64) is
 // sum-all-reduced in place on the same stream (the ONE collective of the step); the next launch applies the global sums.
-static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_t num_steps, float* losses, ncclComm_t comm = nullptr)
+static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_t num_steps, float* losses, ncclComm_t comm = nullptr,
+                           Xchg* xchg = nullptr)
 {
     int rc;
     const size_t acc_bytes = 3 * (size_t)D3P_ACC_R * D3P_ACC_COLS(c.P) * sizeof(long long);
@@ -1111,7 +1212,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     const StepSlot* prev_slot = nullptr;
     const float* prev_noise = nullptr;
     int g = 0;
-    const bool chained = !comm && use_chained_steps(c);
+    const bool chained = !comm && !xchg && use_chained_steps(c);
     const bool persist = chained && use_persistent_steps(c);
     // the abort flag of the bounded waits: cleared once per run (whatever form the steps take), read back by
     // d3p_dpvi_logreg_chain_status
@@ -1134,7 +1235,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
             // (data-parallel loop: only every 16th launch is bracketed, so that event creation does not sit on the host's
             // enqueue path of every step)
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (!comm || (g & 15) == 0) timing_pair(1, &e0, &e1);
+            if (!(comm || xchg) || (g & 15) == 0) timing_pair(1, &e0, &e1);
             if ((rc = enqueue_fused_step(cb[cur], g, t, prev_slot, prev_noise, X, y, (losses && g > 0) ? losses + g - 1 : nullptr,
                                          cslot, t, t == K_next - 1, false, false, e0, e1)))
                 return rc;
@@ -1143,6 +1244,9 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
                 long long* acc = c.ws.acc + (size_t)(g % 3) * words;
                 const ncclResult_t r = rccl_api()->AllReduce(acc, acc, words, ncclInt64, ncclSum, comm, c.s);
                 if (r != ncclSuccess) return fail(D3P_E_HIP, "ncclAllReduce: %s", rccl_api()->GetErrorString(r));
+            } else if (xchg) {  // one-shot full-mesh exchange of the folded accumulator (8 KB per peer)
+                long long* acc = c.ws.acc + (size_t)(g % 3) * D3P_ACC_R * D3P_ACC_COLS(c.P);
+                if ((rc = enqueue_xchg(c.s, xchg, acc, D3P_ACC_R, run_status_words(c.ws)))) return rc;
             }
             prev_slot = cb[cur].ws.slots + t;
             prev_noise = cb[cur].ws.noise + (size_t)t * c.P;
@@ -1404,6 +1508,98 @@ int d3p_comm_destroy(void* comm)
     const ncclResult_t r = api->CommDestroy((ncclComm_t)comm);
     if (r != ncclSuccess) return fail(D3P_E_HIP, "ncclCommDestroy: %s", api->GetErrorString(r));
     return D3P_OK;
+}
+
+int d3p_xchg_create(int32_t world, int32_t rank, uint32_t words, void** xchg_out, uint8_t* handle_out, size_t handle_bytes)
+{
+    D3P_REQUIRE(xchg_out && handle_out && handle_bytes >= sizeof(hipIpcMemHandle_t), "d3p_xchg_create: null pointer or handle buffer < 64 bytes");
+    D3P_REQUIRE(world >= 1 && world <= D3P_XCHG_MAX_WORLD && rank >= 0 && rank < world && words >= 1, "d3p_xchg_create: bad arguments");
+    Xchg* x = new Xchg();
+    x->world = world;
+    x->rank = rank;
+    x->words = words;
+    x->epoch = 0;
+    x->inbox_bytes = xchg_data_bytes(world, words) + (size_t)2 * world * D3P_XCHG_FLAG_STRIDE * sizeof(unsigned long long);
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, x->inbox_bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { delete x; return fail(D3P_E_HIP, "d3p_xchg_create: hipExtMallocWithFlags: %s", hipGetErrorString(e)); }
+    x->inbox = (char*)p;
+    e = hipMemset(p, 0, x->inbox_bytes);
+    hipIpcMemHandle_t h;
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) { (void)hipFree(p); delete x; return fail(D3P_E_HIP, "d3p_xchg_create: %s", hipGetErrorString(e)); }
+    memcpy(handle_out, &h, sizeof(h));
+    for (int i = 0; i < D3P_XCHG_MAX_WORLD; ++i) { x->peer[i] = nullptr; x->opened[i] = false; }
+    x->peer[rank] = x->inbox;
+    *xchg_out = x;
+    return D3P_OK;
+}
+
+int d3p_xchg_connect(void* xchg, const uint8_t* handles, size_t handle_stride)
+{
+    D3P_REQUIRE(xchg && handles && handle_stride >= sizeof(hipIpcMemHandle_t), "d3p_xchg_connect: bad arguments");
+    Xchg* x = (Xchg*)xchg;
+    for (int p = 0; p < x->world; ++p) {
+        if (p == x->rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)p * handle_stride, sizeof(h));
+        void* q = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return fail(D3P_E_HIP, "d3p_xchg_connect: hipIpcOpenMemHandle(rank %d): %s", p, hipGetErrorString(e));
+        x->peer[p] = (char*)q;
+        x->opened[p] = true;
+    }
+    return D3P_OK;
+}
+
+int d3p_xchg_connect_local(void* xchg, void* const* peers, int32_t world)
+{
+    D3P_REQUIRE(xchg && peers, "d3p_xchg_connect_local: null pointer");
+    Xchg* x = (Xchg*)xchg;
+    D3P_REQUIRE(world == x->world, "d3p_xchg_connect_local: group size differs from the one the exchange was created for");
+    for (int p = 0; p < world; ++p) {
+        const Xchg* q = (const Xchg*)peers[p];
+        D3P_REQUIRE(q && q->rank == p && q->words == x->words && q->world == world, "d3p_xchg_connect_local: peers must be the group's exchanges in rank order");
+        x->peer[p] = q->inbox;
+    }
+    return D3P_OK;
+}
+
+int d3p_xchg_destroy(void* xchg)
+{
+    if (!xchg) return D3P_OK;
+    Xchg* x = (Xchg*)xchg;
+    for (int p = 0; p < x->world; ++p)
+        if (x->opened[p]) (void)hipIpcCloseMemHandle(x->peer[p]);
+    (void)hipFree(x->inbox);
+    (void)hipGetLastError();
+    delete x;
+    return D3P_OK;
+}
+
+int d3p_xchg_allreduce(void* stream, void* xchg, long long* acc_dev, int32_t replicas)
+{
+    D3P_REQUIRE(xchg && acc_dev && replicas >= 1, "d3p_xchg_allreduce: bad arguments");
+    return enqueue_xchg((hipStream_t)stream, (Xchg*)xchg, acc_dev, replicas, nullptr);
+}
+
+int d3p_dpvi_logreg_run_xchg(void* stream, void* xchg, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                             const d3p_dpsvi_state* state, const d3p_batch_source* src, const float* X_dev, const float* y_dev,
+                             uint32_t num_steps, float* losses_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    Ctx c;
+    int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    D3P_REQUIRE(xchg, "d3p_dpvi_logreg_run_xchg: null exchange");
+    D3P_REQUIRE(X_dev || src->row_lo == src->row_hi, "null data pointer");
+    if (int rcm = validate_model(model, y_dev ? (const void*)y_dev : (src->row_lo == src->row_hi ? (const void*)model : nullptr),
+                                 "d3p_dpvi_logreg_run_xchg"))
+        return rcm;
+    D3P_REQUIRE(src->kind != D3P_BATCH_EXPLICIT, "d3p_dpvi_logreg_run_xchg: needs an on-device sampler (Feistel or Poisson)");
+    D3P_REQUIRE(((Xchg*)xchg)->words == (uint32_t)D3P_ACC_COLS(c.P), "d3p_dpvi_logreg_run_xchg: the exchange was created for another message size");
+    if ((rc = enqueue_sched_init(c))) return rc;
+    if ((rc = run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev, nullptr, (Xchg*)xchg))) return rc;
+    return enqueue_sched_finish(c, (int)num_steps);
 }
 
 int d3p_dpvi_logreg_run_dist(void* stream, void* comm, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,

@@ -194,16 +194,75 @@ class NativeComm:
             self.handle = None
 
 
+class XchgComm:
+    """One-shot full-mesh exchange owned by libd3p_hip.so (d3p_xchg_*): every rank's inbox is mapped into its peers with
+    hipIpc handles (gathered here through torch.distributed, any backend), and the step's collective becomes ONE kernel
+    that writes the rank's folded 8 KB accumulator row into the 7 peers over xGMI and adds the 8 rows locally -- one hop
+    instead of a ring's 14.  `words` = int64 words of the message: 2 D + 4 for a model with D latents."""
+
+    def __init__(self, words, group=None, _local=None):
+        import torch.distributed as dist
+        _lib.require_device()
+        lib = _lib.load()
+        if _local is not None:                      # (rank, world) of a single-process group: see local_group
+            self.rank, self.world = _local
+        else:
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.words = int(words)
+        handle, buf = C.c_void_p(), (C.c_uint8 * 64)()
+        check(lib.d3p_xchg_create(self.world, self.rank, self.words, C.byref(handle), buf, 64))
+        self.handle = handle
+        if _local is not None:
+            return
+        mine = bytes(buf)
+        if self.world > 1:
+            box = [None] * self.world
+            dist.all_gather_object(box, mine, group=group)
+        else:
+            box = [mine]
+        allh = (C.c_uint8 * (64 * self.world)).from_buffer_copy(b"".join(box))
+        check(lib.d3p_xchg_connect(self.handle, allh, 64))
+        if self.world > 1:
+            dist.barrier(group=group)      # nobody writes into an inbox that its owner has not finished setting up
+
+    @classmethod
+    def local_group(cls, world, words):
+        """`world` ranks inside ONE process (each drives its own stream): the inboxes are wired to each other directly
+        (d3p_xchg_connect_local) instead of through hipIpc handles; kernels and protocol are those of the multi-process
+        path.  For tests on a single GPU and for single-process multi-stream use."""
+        comms = [cls(words, _local=(r, world)) for r in range(world)]
+        arr = (C.c_void_p * world)(*[c.handle for c in comms])
+        for c in comms:
+            check(_lib.load().d3p_xchg_connect_local(c.handle, arr, world))
+        return comms
+
+    def allreduce(self, acc, replicas):
+        """acc: int64 tensor [replicas, words] (this rank's accumulator replicas) -> row 0 = global sums, other rows 0."""
+        check(_lib.load().d3p_xchg_allreduce(stream_ptr(), self.handle, ptr(acc), int(replicas)))
+
+    def close(self):
+        if self.handle:
+            torch.cuda.synchronize()
+            check(_lib.load().d3p_xchg_destroy(self.handle))
+            self.handle = None
+
+
 def run_steps_native(engine, state, batch_key, first_batch, num_steps, comm=None, collect_losses=True):
-    """The whole data-parallel run in one C call (d3p_dpvi_logreg_run_dist): per step one kernel launch and one
-    in-place ncclAllReduce of the int64 accumulator on the same stream; no host work between steps.
-    `engine` is a FusedHipEngine (it supplies the shard and the model); `comm` a NativeComm or None (single rank)."""
+    """The whole data-parallel run in one C call: per step one kernel launch and ONE collective of the int64 accumulator
+    on the same stream, no host work between steps.  `comm`: a NativeComm (RCCL ring all-reduce, d3p_dpvi_logreg_run_dist),
+    an XchgComm (one-shot full-mesh exchange, d3p_dpvi_logreg_run_xchg) or None (single rank).
+    `engine` is a FusedHipEngine (it supplies the shard and the model)."""
     from .svi import DPSVIState
     engine._setup(state, batch_key, first_batch)
     losses = torch.zeros(max(int(num_steps), 1), dtype=torch.float32, device=engine.dev) if collect_losses else None
-    check(_lib.load().d3p_dpvi_logreg_run_dist(stream_ptr(), comm.handle if comm is not None else None, *engine._args,
-                                               ptr(engine.X), ptr(engine.y), int(num_steps), ptr(losses), ptr(engine.ws),
-                                               engine.ws.numel()))
+    if isinstance(comm, XchgComm):
+        check(_lib.load().d3p_dpvi_logreg_run_xchg(stream_ptr(), comm.handle, *engine._args, ptr(engine.X), ptr(engine.y),
+                                                   int(num_steps), ptr(losses), ptr(engine.ws), engine.ws.numel()))
+    else:
+        check(_lib.load().d3p_dpvi_logreg_run_dist(stream_ptr(), comm.handle if comm is not None else None, *engine._args,
+                                                   ptr(engine.X), ptr(engine.y), int(num_steps), ptr(losses), ptr(engine.ws),
+                                                   engine.ws.numel()))
     new_state = DPSVIState((engine.step, engine.params, engine.m, engine.v),
                            engine.keybuf[int(num_steps) & 1].reshape(4, 4).clone(), engine.observation_scale)
     return new_state, (losses[:int(num_steps)] if collect_losses else None)

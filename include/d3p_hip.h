@@ -431,6 +431,28 @@ int d3p_dpvi_logreg_kernel_timing_read(double* total_us_out, uint32_t* launches_
  * sums, so every rank applies bitwise the same update under any reduction order); the Gaussian noise is added once,
  * after the reduce, from the same key on every rank.  comm == NULL runs without the collective.
  * ------------------------------------------------------------------------------------------- */
+/* One-shot full-mesh exchange over xGMI (ABI 3; SURVEY 5 / 8e: for a message of 8 KB one hop beats a ring's 2 (n - 1)).
+ * Every rank owns an inbox (uncached device memory, double-buffered slots + flags) that its peers map with hipIpc:
+ *   d3p_xchg_create   allocates the inbox for messages of `words` int64 words and returns its 64-byte IPC handle;
+ *   d3p_xchg_connect  takes the handles of ALL ranks (world x handle_stride bytes, the host layer gathers them, e.g. with
+ *                     torch.distributed.all_gather_object) and maps the peers' inboxes;
+ *   d3p_xchg_allreduce  enqueues ONE kernel: fold acc_dev[replicas][words] -> write the folded row into slot [rank] of every
+ *                     inbox -> system-scope fence -> flags -> wait for the n flags of the own inbox -> acc_dev row 0 = the sum
+ *                     of the n rows (int64: exact, identical on every rank), rows 1.. = 0.  Every rank must call it the same
+ *                     number of times.  Bounded waits.
+ *   d3p_dpvi_logreg_run_xchg = d3p_dpvi_logreg_run_dist with this exchange as the step's one collective (`words` must be
+ *                     the accumulator row of the model: 2 D + 4). */
+int d3p_xchg_create(int32_t world, int32_t rank, uint32_t words, void** xchg_out, uint8_t* handle_out, size_t handle_bytes);
+int d3p_xchg_connect(void* xchg, const uint8_t* handles, size_t handle_stride);
+ /* d3p_xchg_connect_local: the same for ranks that live in ONE process (one stream each): `peers` = the `world` exchange
+  * objects of the group, in rank order; their inboxes are wired directly. */
+int d3p_xchg_connect_local(void* xchg, void* const* peers, int32_t world);
+int d3p_xchg_destroy(void* xchg);
+int d3p_xchg_allreduce(void* stream, void* xchg, long long* acc_dev, int32_t replicas);
+int d3p_dpvi_logreg_run_xchg(void* stream, void* xchg, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                             const d3p_dpsvi_state* state, const d3p_batch_source* src, const float* X_dev, const float* y_dev,
+                             uint32_t num_steps, float* losses_dev, void* workspace_dev, size_t workspace_bytes);
+
 int d3p_comm_unique_id(uint8_t* id_out, size_t id_bytes); /* id_bytes >= 128 */
 int d3p_comm_init(const uint8_t* id, size_t id_bytes, int32_t nranks, int32_t rank, void** comm_out);
 int d3p_comm_destroy(void* comm);
