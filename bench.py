@@ -197,21 +197,36 @@ def main():
         # Preferred data-parallel driver: the native loop (one C call for the whole run; per step one launch and the
         # rank's accumulator exchange on the same stream, communicator owned by libd3p_hip.so).  Every rank must take the
         # same decision, so success is agreed on with an all-reduce of a flag.
-        ok = 1
-        try:
-            comm = ddist.NativeComm()
-        except Exception as e:  # noqa: BLE001 -- a failure here only selects the slower driver
-            ok = 0
-            print(f"[bench] rank {rank}: native communicator unavailable ({e})", file=sys.stderr)
-        if world > 1:
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag[0])
-        if not ok and comm is not None:
-            comm.close()
-            comm = None
+        # First choice: the one-shot full-mesh exchange (d3p_xchg_*: one kernel per step writes the folded 8 KB row into the
+        # peers over xGMI); second: the RCCL ring all-reduce inside the same native loop.
+        def agreed(make):
+            ok, c = 1, None
+            try:
+                c = make()
+            except Exception as e:  # noqa: BLE001 -- a failure here only selects the next driver
+                ok = 0
+                print(f"[bench] rank {rank}: {make.__name__} unavailable ({e})", file=sys.stderr)
+            if world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag[0])
+            if not ok and c is not None:
+                c.close()
+                c = None
+            return c
+
+        def xchg_comm():
+            return ddist.XchgComm(2 * D + 4)
+
+        def rccl_comm():
+            return ddist.NativeComm()
+        if not os.environ.get("D3P_DIST_RCCL"):
+            comm = agreed(xchg_comm)
+        if comm is None:
+            comm = agreed(rccl_comm)
     if not single:
-        dist_driver = "native" if comm is not None else "torch"
+        dist_driver = ("native loop, one-shot full-mesh exchange (d3p_xchg)" if isinstance(comm, ddist.XchgComm) else
+                       "native loop, RCCL all-reduce" if comm is not None else "torch")
 
     def make_workload(n_rows_total, native=True):
         """Table shard + model + state + a `run(state, first, k)` closure for a table of n_rows_total rows.
@@ -374,7 +389,7 @@ def main():
         return {"value": round(Bg * steps_per_s, 1), "steps_per_sec": round(steps_per_s, 2),
                 "ms_per_step": round(1000.0 * elapsed / args.steps, 6), "final_loss": final_loss, "steady_state": steady,
                 "north_star_N1e7": north, "roofline": roofline, "rows": n_rows,
-                "driver": "single-GPU chained launch" if single else ("native" if (native and comm is not None) else "torch")}
+                "driver": "single-GPU chained launch" if single else (dist_driver if (native and comm is not None) else "torch")}
 
     def line(m, cpu=None, extra=None):
         out = {

@@ -474,7 +474,7 @@ def _xchg_svi(n, d):
 
 @pytest.mark.gpu
 def test_xchg_on_one_rank_is_the_fold(gpu):
-    """world = 1: the exchange folds the replicas into row 0; the run equals the run without a collective bit for bit."""
+    """world = 1: the exchange folds the replicas into row 0; the run walks the trajectory of the run without a collective."""
     import d3p_amd._lib as L
     import d3p_amd.random as rng
     from d3p_amd import dist as ddist
@@ -493,8 +493,11 @@ def test_xchg_on_one_rank_is_the_fold(gpu):
         torch.cuda.synchronize()
     finally:
         comm.close()
-    assert torch.equal(a_state.optim_state[1], b_state.optim_state[1]) and torch.equal(a_losses, b_losses)
-    assert torch.equal(a_state.rng_key, b_state.rng_key)
+    # (without a collective the run takes the chained launch, with one the one-launch-per-step kernel: other workgroup
+    # partials, same trajectory to fp32 rounding, same keys)
+    torch.testing.assert_close(b_losses, a_losses, rtol=2e-6, atol=0)
+    torch.testing.assert_close(b_state.optim_state[1], a_state.optim_state[1], rtol=1e-4, atol=2e-6)
+    assert torch.equal(a_state.rng_key, b_state.rng_key) and int(b_state.optim_state[0]) == 33
 
 
 @pytest.mark.gpu
