@@ -969,7 +969,8 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
         // workgroup) runs the kernel written for it (d3p_logreg_chain.h); D3P_NO_LEAN_CHAIN=1 keeps the generic template.
         static const bool off = getenv("D3P_NO_LEAN_CHAIN") != nullptr || getenv("D3P_NO_PIPELINED_STEPS") != nullptr ||
                                 getenv("D3P_MAIN_W") != nullptr;
-        if (!off && c.g.full && !c.g.tail && c.g.V == 4 && c.g.NK == 1 && c.g.W == 16 && c.D == D3P_CHAIN_D &&
+        const bool icpt = c.g.tail;  // 512 features + intercept (D = 513): the ICPT instantiations
+        if (!off && c.g.full && c.g.V == 4 && c.g.NK == 1 && c.g.W == 16 && c.m->d == D3P_CHAIN_D &&
             c.m->family == D3P_FAMILY_LOGREG && (uint64_t)c.src->B <= 18ull * c.g.blocks) {
             ChainArgs ca;
             memset(&ca, 0, sizeof(ca));
@@ -1002,28 +1003,32 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
             ca.A_scale = a.A_scale; ca.c1 = a.c1_w; ca.hz = a.hz_w; ca.inv_obs = a.inv_obs; ca.lik_scale = a.lik_scale;
             ca.obs_scale = a.obs_scale; ca.clip = a.clip; ca.dp_scale = a.fuse.dp_scale; ca.lr = a.fuse.lr; ca.b1 = a.fuse.b1;
             ca.b2 = a.fuse.b2; ca.adam_eps = a.fuse.adam_eps; ca.log_prior = logf(c.m->prior_w);
+            ca.c1_b = a.c1_b; ca.hz_b = a.hz_b; ca.log_prior_b = logf(c.m->prior_b);
             ca.gexp = a.gexp;
             ca.dbg = dev_dbg_flags();
             const dim3 grid((uint32_t)K * (c.g.blocks + 1u)), block(64 * D3P_CHAIN_W);
             const bool plist = ca.plist_base != nullptr;
-            if ((ca.dbg & 32) && K >= 2) {  // D3P_DBG=32: the stamped instantiation + the phase anatomy on stderr
-                ca.stamps = c.ws.stamps;
-                if (plist) hipLaunchKernelGGL((k_logreg_chain<true, true>), grid, block, chain_lds_bytes(), c.s, ca);
-                else hipLaunchKernelGGL((k_logreg_chain<false, true>), grid, block, chain_lds_bytes(), c.s, ca);
-                int rc = check_launch("k_logreg_chain");
-                if (rc) return rc;
-                return print_chain_anatomy(c);
-            }
-            hipEvent_t e0, e1;
-            timing_pair(K, &e0, &e1);
-            if (e0) {
-                if (plist) hipExtLaunchKernelGGL((k_logreg_chain<true, false>), grid, block, chain_lds_bytes(), c.s, e0, e1, 0, ca);
-                else hipExtLaunchKernelGGL((k_logreg_chain<false, false>), grid, block, chain_lds_bytes(), c.s, e0, e1, 0, ca);
+            const size_t lds = chain_lds_bytes(icpt);
+            const bool stamped = (ca.dbg & 32) && K >= 2;  // D3P_DBG=32: the stamped instantiation + the phase anatomy on stderr
+            if (stamped) ca.stamps = c.ws.stamps;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (!stamped) timing_pair(K, &e0, &e1);
+#define D3P_CHAIN_LAUNCH(PL_, ST_, IC_)                                                                      \
+    do {                                                                                                     \
+        if (e0) hipExtLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_>), grid, block, lds, c.s, e0, e1, 0, ca); \
+        else hipLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_>), grid, block, lds, c.s, ca);                  \
+    } while (0)
+            if (stamped) {
+                if (icpt) { if (plist) D3P_CHAIN_LAUNCH(true, true, true); else D3P_CHAIN_LAUNCH(false, true, true); }
+                else { if (plist) D3P_CHAIN_LAUNCH(true, true, false); else D3P_CHAIN_LAUNCH(false, true, false); }
             } else {
-                if (plist) hipLaunchKernelGGL((k_logreg_chain<true, false>), grid, block, chain_lds_bytes(), c.s, ca);
-                else hipLaunchKernelGGL((k_logreg_chain<false, false>), grid, block, chain_lds_bytes(), c.s, ca);
+                if (icpt) { if (plist) D3P_CHAIN_LAUNCH(true, false, true); else D3P_CHAIN_LAUNCH(false, false, true); }
+                else { if (plist) D3P_CHAIN_LAUNCH(true, false, false); else D3P_CHAIN_LAUNCH(false, false, false); }
             }
-            return check_launch("k_logreg_chain");
+#undef D3P_CHAIN_LAUNCH
+            int rc = check_launch("k_logreg_chain");
+            if (rc || !stamped) return rc;
+            return print_chain_anatomy(c);
         }
     }
     MainGeom g2 = c.g;

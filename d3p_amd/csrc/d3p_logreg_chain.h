@@ -56,23 +56,37 @@ struct ChainArgs {
     uint32_t B;
     int nw, g0, K, K_next;
     float A_scale, c1, hz, inv_obs, lik_scale, obs_scale, clip, dp_scale, lr, b1, b2, adam_eps, log_prior;
+    float c1_b, hz_b, log_prior_b;  // ICPT: the intercept's prior
     int gexp;
     int dbg;  // developer switches (D3P_DBG): 2 = raised wave priority on the critical path, 4 = no gradient atomics (STAMPS only)
 };
 
-static inline size_t chain_lds_bytes()
+// ICPT: the same 512 features plus the intercept (examples/logistic_regression.py:49-66): D = 513 latents.  jax's iota
+// layout for an odd D pads the counter array, so the pairs of one threefry call are (c, c + 257), c < 256, and (256, pad):
+// lanes own latents 4 l .. 4 l + 3 and 257 + 4 l .. 260 + 4 l (the very last one, 512, is the intercept: x = 1, its own
+// prior), and latent 256 -- the "tail" -- is a feature column every lane carries redundantly (one more threefry call per
+// example, added once after the wave sums).  In LDS the second half is stored from index 260 on, so that its 16-byte
+// reads stay aligned: latent j lives at j (j <= 256) or j + 3 (j >= 257), arrays are 520 long.
+#define D3P_CHAIN_DL(ICPT) ((ICPT) ? 520 : 512)
+static inline size_t chain_lds_bytes(bool icpt)
 {
-    return (size_t)(5 * D3P_CHAIN_D + D3P_CHAIN_W * 2 * D3P_CHAIN_D + 2 * D3P_CHAIN_W + 4 + 32) * sizeof(float);
+    return (size_t)(5 * D3P_CHAIN_DL(icpt) + D3P_CHAIN_W * 2 * D3P_CHAIN_DL(icpt) + 2 * D3P_CHAIN_W + 4 + 32) * sizeof(float);
 }
 
-template <bool PLIST, bool STAMPS>
+template <bool PLIST, bool STAMPS, bool ICPT = false>
 __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int D = D3P_CHAIN_D, P = 2 * D, PA = D3P_ACC_COLS(P), W = D3P_CHAIN_W, R = D3P_ACC_R;
-    float* pk = lds;                    // [loc | s | sg | q | lc] x D
-    float* red = lds + 5 * D;           // W rows of P floats: the waves' noise, later their partial sums
-    float* tail = red + W * P;          // 2 W: loss / count per wave
+    constexpr int DF = D3P_CHAIN_D;                 // feature columns of a table row
+    constexpr int D = DF + (ICPT ? 1 : 0), P = 2 * D, PA = D3P_ACC_COLS(P), W = D3P_CHAIN_W, R = D3P_ACC_R;
+    constexpr int HALF = ICPT ? 257 : 256;          // second index of a threefry pair = first + HALF
+    constexpr int DL = D3P_CHAIN_DL(ICPT);          // LDS array length per quantity
+    constexpr int C1 = ICPT ? 260 : 256;            // LDS index of the lane-0 element of the second half
+    constexpr int TL = 256;                         // ICPT: latent / LDS index of the tail column
+    auto lix = [](int j) { return (!ICPT || j <= 256) ? j : j + 3; };  // latent -> LDS index
+    float* pk = lds;                    // [loc | s | sg | q | lc] x DL
+    float* red = lds + 5 * DL;          // W rows of 2 DL floats: the waves' noise, later their partial sums
+    float* tail = red + W * 2 * DL;     // 2 W: loss / count per wave
     uint32_t* okw = reinterpret_cast<uint32_t*>(tail + 2 * W);             // verdict of the polling wave
     unsigned long long* stamp = reinterpret_cast<unsigned long long*>(okw + 4);
 #define D3P_CSTAMP(k) if (STAMPS && threadIdx.x == 0) stamp[k] = wall_clock64();
@@ -103,14 +117,24 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     const uint32_t* idx = a.idx_base + (size_t)step_t * a.B;
     const uint32_t* skeys = a.skeys_base + (size_t)step_t * 2 * a.B;
     float4 xa0 = make_float4(0.f, 0.f, 0.f, 0.f), xa1 = xa0, xb0 = xa0, xb1 = xa0;
-    float ya = 0.f, yb = 0.f;
+    float ya = 0.f, yb = 0.f, xta = 0.f, xtb = 0.f;  // xt*: ICPT, the tail feature
     uint32_t ka0 = 0, ka1 = 0, kb0 = 0, kb1 = 0;
+    // features of one table row for this lane: first half 16-byte aligned; ICPT: the second half starts one float off
+    // (scalar loads), its last element is the intercept's constant 1
+    auto load_x = [&](const float* xr, float4& x0, float4& x1, float& xt) {
+        x0 = *reinterpret_cast<const float4*>(xr + 4 * lane);
+        if (ICPT) {
+            const int f = HALF + 4 * lane;
+            x1 = make_float4(xr[f], xr[f + 1], xr[f + 2], f + 3 < DF ? xr[f + 3] : 1.0f);
+            xt = xr[TL];
+        } else {
+            x1 = *reinterpret_cast<const float4*>(xr + HALF + 4 * lane);
+        }
+    };
     if (live1) {
         const uint32_t p = PLIST ? (a.plist_base + (size_t)step_t * a.B)[k1] : k1;
         const size_t row = (size_t)((uint64_t)idx[p] - a.row_lo);
-        const float* xr = a.X + row * D;
-        xa0 = *reinterpret_cast<const float4*>(xr + 4 * lane);
-        xa1 = *reinterpret_cast<const float4*>(xr + D / 2 + 4 * lane);
+        load_x(a.X + row * DF, xa0, xa1, xta);
         ya = a.y[row];
         ka0 = skeys[2 * p];
         ka1 = skeys[2 * p + 1];
@@ -118,9 +142,7 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     if (live2) {
         const uint32_t p = PLIST ? (a.plist_base + (size_t)step_t * a.B)[k2] : k2;
         const size_t row = (size_t)((uint64_t)idx[p] - a.row_lo);
-        const float* xr = a.X + row * D;
-        xb0 = *reinterpret_cast<const float4*>(xr + 4 * lane);
-        xb1 = *reinterpret_cast<const float4*>(xr + D / 2 + 4 * lane);
+        load_x(a.X + row * DF, xb0, xb1, xtb);
         yb = a.y[row];
         kb0 = skeys[2 * p];
         kb1 = skeys[2 * p + 1];
@@ -139,7 +161,7 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     }
     // guide noise of both examples into the wave's own row: lane owns columns 4 lane .. + 3 and D/2 + the same, i.e. the
     // pairs (c, c + D/2) of jax's iota layout come out of ONE threefry2x32 call
-    float* er = red + (size_t)wave * P;
+    float* er = red + (size_t)wave * 2 * DL;
     // returns the lane's share of -0.5 |eps|^2 (the log q term of the loss: parameter-independent, so summed here)
     auto gen = [&](uint32_t k0, uint32_t k1_, float* dst) {
         const uint32_t s0 = __builtin_amdgcn_readfirstlane(k0), s1 = __builtin_amdgcn_readfirstlane(k1_);  // wave-uniform keys
@@ -147,19 +169,24 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             uint32_t b0, b1;
-            threefry2x32(s0, s1, (uint32_t)(4 * lane + n), (uint32_t)(4 * lane + n + D / 2), b0, b1);
+            threefry2x32(s0, s1, (uint32_t)(4 * lane + n), (uint32_t)(4 * lane + n + HALF), b0, b1);
             v0[n] = bits_to_normal_wu(b0);
             v1[n] = bits_to_normal_wu(b1);
             e2 = __fmaf_rn(v0[n], v0[n], e2);
             e2 = __fmaf_rn(v1[n], v1[n], e2);
         }
         *reinterpret_cast<float4*>(dst + 4 * lane) = make_float4(v0[0], v0[1], v0[2], v0[3]);
-        *reinterpret_cast<float4*>(dst + D / 2 + 4 * lane) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+        *reinterpret_cast<float4*>(dst + C1 + 4 * lane) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+        if (ICPT) {  // the tail latent: word 256 pairs with the padding of the odd counter array (jax pads with a zero)
+            uint32_t b0, b1;
+            threefry2x32(s0, s1, (uint32_t)TL, 0u, b0, b1);
+            if (lane == 0) dst[TL] = bits_to_normal_wu(b0);
+        }
         return -0.5f * e2;
     };
     float ea = 0.f, eb = 0.f;
     if (live1) ea = gen(ka0, ka1, er);
-    if (live2) eb = gen(kb0, kb1, er + D);
+    if (live2) eb = gen(kb0, kb1, er + DL);
     D3P_CSTAMP(8)
     // From here on the workgroup is on the critical path of the step (D3P_DBG=2: raised wave priority against the co-resident
     // workgroup of the next step, which is generating its noise on the same SIMDs).
@@ -183,75 +210,85 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     // ------------------------------------------------------------------ phase 2: update prologue (thread e <-> latent e)
     const int in = g > 0 ? ((g - 1) & 1) : 0, out = g & 1;
     {
-        float xL, xS;
+        float n = 0.f, factor = 0.f;
         if (apply_prev) {
-            long long aL[R], aS[R], n8[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                aL[r] = __hip_atomic_load(acc_prev + (size_t)r * PA + tid, __ATOMIC_RELAXED, D3P_AGENT);
-                aS[r] = __hip_atomic_load(acc_prev + (size_t)r * PA + D + tid, __ATOMIC_RELAXED, D3P_AGENT);
-            }
-            xL = __hip_atomic_load(a.state[in][0] + tid, __ATOMIC_RELAXED, D3P_AGENT);
-            xS = __hip_atomic_load(a.state[in][0] + D + tid, __ATOMIC_RELAXED, D3P_AGENT);
-            float mL = __hip_atomic_load(a.state[in][1] + tid, __ATOMIC_RELAXED, D3P_AGENT);
-            float mS = __hip_atomic_load(a.state[in][1] + D + tid, __ATOMIC_RELAXED, D3P_AGENT);
-            float vL = __hip_atomic_load(a.state[in][2] + tid, __ATOMIC_RELAXED, D3P_AGENT);
-            float vS = __hip_atomic_load(a.state[in][2] + D + tid, __ATOMIC_RELAXED, D3P_AGENT);
-#pragma unroll
-            for (int r = 0; r < R; ++r) n8[r] = __hip_atomic_load(acc_prev + (size_t)r * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT);
             // nobody reads the next accumulator any more (the previous step's prologues are over): zero it
             for (int i = (int)bid * (64 * W) + tid; i < R * PA; i += a.nw * 64 * W)
                 __hip_atomic_store(acc_next + i, 0ll, __ATOMIC_RELAXED, D3P_AGENT);
-            long long nll = 0, sL = 0, sS = 0;
-#pragma unroll
-            for (int r = 0; r < R; ++r) { nll += n8[r]; sL += aL[r]; sS += aS[r]; }
-            // (a workgroup that saw a non-finite partial added 2^44 to the count column: NaN from here on, like float sums)
-            const float n = nll >= (1ll << 40) ? __builtin_nanf("") : (float)nll;
-            const float Bf = (float)a.B;
-            const float factor = (n == 0.0f) ? 0.0f : Bf / n;  // svi.py:305
-            const float inv_B = 1.0f / Bf, inv_bc1 = 1.0f / bc1, inv_bc2 = 1.0f / bc2;
-            const float noise_scale = a.dp_scale * (a.clip / n), out_scale = a.obs_scale * factor;  // svi.py:365-375
-            auto adam = [&](long long s, float z, float& x, float& m, float& v) {
-                const float tot = (float)((double)s * a.inv_sg);
-                const float gr = __fmaf_rn(z, noise_scale, tot * inv_B) * out_scale;
-                m = (1.0f - a.b1) * gr + a.b1 * m;
-                v = (1.0f - a.b2) * gr * gr + a.b2 * v;
-                x = x - a.lr * (m * inv_bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * inv_bc2) + a.adam_eps);
-            };
-            adam(sL, zL, xL, mL, vL);
-            adam(sS, zS, xS, mS, vS);
-            if (bid == 0) {  // one workgroup publishes the state
-                __hip_atomic_store(a.state[out][0] + tid, xL, __ATOMIC_RELAXED, D3P_AGENT);
-                __hip_atomic_store(a.state[out][0] + D + tid, xS, __ATOMIC_RELAXED, D3P_AGENT);
-                __hip_atomic_store(a.state[out][1] + tid, mL, __ATOMIC_RELAXED, D3P_AGENT);
-                __hip_atomic_store(a.state[out][1] + D + tid, mS, __ATOMIC_RELAXED, D3P_AGENT);
-                __hip_atomic_store(a.state[out][2] + tid, vL, __ATOMIC_RELAXED, D3P_AGENT);
-                __hip_atomic_store(a.state[out][2] + D + tid, vS, __ATOMIC_RELAXED, D3P_AGENT);
-                if (tid == 0) {
-                    long long lll = 0, lhh = 0;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        lll += __hip_atomic_load(acc_prev + (size_t)r * PA + P, __ATOMIC_RELAXED, D3P_AGENT);
-                        lhh += __hip_atomic_load(acc_prev + (size_t)r * PA + P + 2, __ATOMIC_RELAXED, D3P_AGENT);
-                    }
-                    if (a.losses && g > 0) a.losses[g - 1] = ((float)loss_join(lhh, lll) / Bf) * a.obs_scale * factor;
-                    *a.adam_step = ps->adam_i + 1;
-                    if (a.batch_index) *a.batch_index = ps->batch_i + 1u;
-                }
-            }
         } else {  // first step of a run: nothing pending, nobody reads the next accumulator yet
-            xL = a.state[in][0][tid];
-            xS = a.state[in][0][D + tid];
             for (int i = (int)bid * (64 * W) + tid; i < R * PA; i += a.nw * 64 * W)
                 __hip_atomic_store(acc_next + i, 0ll, __ATOMIC_RELAXED, D3P_AGENT);
         }
-        float sp, sgm;
-        guide_scale(a.gexp, xS, sp, sgm);
-        pk[tid] = xL;
-        pk[D + tid] = sp;
-        pk[2 * D + tid] = sgm;
-        pk[3 * D + tid] = a.inv_obs * sgm * __builtin_amdgcn_rcpf(sp);
-        pk[4 * D + tid] = a.log_prior - __logf(sp);
+        // one latent: pending update of its two columns (e: auto_loc, D + e: auto_scale) and its derived LDS entries
+        auto latent = [&](int e, float zl, float zs) {
+            float xL, xS;
+            if (apply_prev) {
+                long long aL[R], aS[R], n8[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    aL[r] = __hip_atomic_load(acc_prev + (size_t)r * PA + e, __ATOMIC_RELAXED, D3P_AGENT);
+                    aS[r] = __hip_atomic_load(acc_prev + (size_t)r * PA + D + e, __ATOMIC_RELAXED, D3P_AGENT);
+                }
+                xL = __hip_atomic_load(a.state[in][0] + e, __ATOMIC_RELAXED, D3P_AGENT);
+                xS = __hip_atomic_load(a.state[in][0] + D + e, __ATOMIC_RELAXED, D3P_AGENT);
+                float mL = __hip_atomic_load(a.state[in][1] + e, __ATOMIC_RELAXED, D3P_AGENT);
+                float mS = __hip_atomic_load(a.state[in][1] + D + e, __ATOMIC_RELAXED, D3P_AGENT);
+                float vL = __hip_atomic_load(a.state[in][2] + e, __ATOMIC_RELAXED, D3P_AGENT);
+                float vS = __hip_atomic_load(a.state[in][2] + D + e, __ATOMIC_RELAXED, D3P_AGENT);
+#pragma unroll
+                for (int r = 0; r < R; ++r) n8[r] = __hip_atomic_load(acc_prev + (size_t)r * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT);
+                long long nll = 0, sL = 0, sS = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) { nll += n8[r]; sL += aL[r]; sS += aS[r]; }
+                // (a workgroup that saw a non-finite partial added 2^44 to the count column: NaN from here on, like float sums)
+                n = nll >= (1ll << 40) ? __builtin_nanf("") : (float)nll;
+                const float Bf = (float)a.B;
+                factor = (n == 0.0f) ? 0.0f : Bf / n;  // svi.py:305
+                const float inv_B = 1.0f / Bf, inv_bc1 = 1.0f / bc1, inv_bc2 = 1.0f / bc2;
+                const float noise_scale = a.dp_scale * (a.clip / n), out_scale = a.obs_scale * factor;  // svi.py:365-375
+                auto adam = [&](long long sm, float z, float& x, float& m, float& v) {
+                    const float tot = (float)((double)sm * a.inv_sg);
+                    const float gr = __fmaf_rn(z, noise_scale, tot * inv_B) * out_scale;
+                    m = (1.0f - a.b1) * gr + a.b1 * m;
+                    v = (1.0f - a.b2) * gr * gr + a.b2 * v;
+                    x = x - a.lr * (m * inv_bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * inv_bc2) + a.adam_eps);
+                };
+                adam(sL, zl, xL, mL, vL);
+                adam(sS, zs, xS, mS, vS);
+                if (bid == 0) {  // one workgroup publishes the state
+                    __hip_atomic_store(a.state[out][0] + e, xL, __ATOMIC_RELAXED, D3P_AGENT);
+                    __hip_atomic_store(a.state[out][0] + D + e, xS, __ATOMIC_RELAXED, D3P_AGENT);
+                    __hip_atomic_store(a.state[out][1] + e, mL, __ATOMIC_RELAXED, D3P_AGENT);
+                    __hip_atomic_store(a.state[out][1] + D + e, mS, __ATOMIC_RELAXED, D3P_AGENT);
+                    __hip_atomic_store(a.state[out][2] + e, vL, __ATOMIC_RELAXED, D3P_AGENT);
+                    __hip_atomic_store(a.state[out][2] + D + e, vS, __ATOMIC_RELAXED, D3P_AGENT);
+                }
+            } else {
+                xL = a.state[in][0][e];
+                xS = a.state[in][0][D + e];
+            }
+            float sp, sgm;
+            guide_scale(a.gexp, xS, sp, sgm);
+            const int li = lix(e);
+            pk[li] = xL;
+            pk[DL + li] = sp;
+            pk[2 * DL + li] = sgm;
+            pk[3 * DL + li] = a.inv_obs * sgm * __builtin_amdgcn_rcpf(sp);
+            pk[4 * DL + li] = ((ICPT && e == D - 1) ? a.log_prior_b : a.log_prior) - __logf(sp);
+        };
+        latent(tid, zL, zS);
+        if (ICPT && tid == 1) latent(D - 1, apply_prev ? prev_noise[D - 1] : 0.f, apply_prev ? prev_noise[2 * D - 1] : 0.f);  // the intercept
+        if (apply_prev && bid == 0 && tid == 0) {
+            long long lll = 0, lhh = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                lll += __hip_atomic_load(acc_prev + (size_t)r * PA + P, __ATOMIC_RELAXED, D3P_AGENT);
+                lhh += __hip_atomic_load(acc_prev + (size_t)r * PA + P + 2, __ATOMIC_RELAXED, D3P_AGENT);
+            }
+            if (a.losses && g > 0) a.losses[g - 1] = ((float)loss_join(lhh, lll) / (float)a.B) * a.obs_scale * factor;
+            *a.adam_step = ps->adam_i + 1;
+            if (a.batch_index) *a.batch_index = ps->batch_i + 1u;
+        }
     }
     D3P_CSTAMP(2)
     __syncthreads();
@@ -259,22 +296,26 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
 
     // ------------------------------------------------------------------ phase 3: the wave's (up to) two examples
     float accg0[4] = {0.f, 0.f, 0.f, 0.f}, acch0[4] = {0.f, 0.f, 0.f, 0.f}, accg1[4] = {0.f, 0.f, 0.f, 0.f}, acch1[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc_gt = 0.f, acc_ht = 0.f;  // ICPT: the tail latent's two sums (identical in every lane, lane 0 stores them)
     float loss_acc = 0.f, n_acc = 0.f;
-    const int c0 = 4 * lane, c1 = D / 2 + 4 * lane;
+    const int c0 = 4 * lane, c1 = C1 + 4 * lane;
+    const bool icpt_lane = ICPT && lane == 63;  // its last second-half element is the intercept (own prior scale)
     // NE examples in lockstep: their dependency chains (LDS reads -> dot product -> DPP wave sum -> sigmoid -> gradient ->
     // two more wave sums -> clip factor) are independent, so the instructions of one fill the latency gaps of the other; the
     // derived parameter columns are read from LDS once for all of them.
     // The latent part of the loss of an example, sum_j [ hz z_j^2 - eps_j^2 / 2 + lc_j ] (log p(z) - log q(z) up to constants),
     // is split into the parameter-independent -|eps|^2 / 2 (from phase 0, `e2v`), the example-independent sum of the lc
     // column (one pass per call) and hz |z|^2, which alone stays in the per-element loop.
-    auto examples = [&](auto ne_tag, const float4* x0v, const float4* x1v, const float* yv, const float* const* ev, const float* e2v) {
+    auto examples = [&](auto ne_tag, const float4* x0v, const float4* x1v, const float* xtv, const float* yv, const float* const* ev,
+                        const float* e2v) {
         constexpr int NE = decltype(ne_tag)::value;
         float x0[NE][4], x1[NE][4], e0[NE][4], e1[NE][4], z0[NE][4], z1[NE][4], tp[NE];
         float l0[4], l1[4], s0[4], s1[4];
         *reinterpret_cast<float4*>(l0) = *reinterpret_cast<const float4*>(pk + c0);
         *reinterpret_cast<float4*>(l1) = *reinterpret_cast<const float4*>(pk + c1);
-        *reinterpret_cast<float4*>(s0) = *reinterpret_cast<const float4*>(pk + D + c0);
-        *reinterpret_cast<float4*>(s1) = *reinterpret_cast<const float4*>(pk + D + c1);
+        *reinterpret_cast<float4*>(s0) = *reinterpret_cast<const float4*>(pk + DL + c0);
+        *reinterpret_cast<float4*>(s1) = *reinterpret_cast<const float4*>(pk + DL + c1);
+        float et[NE], zt[NE];  // ICPT: noise and latent value of the tail column
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             *reinterpret_cast<float4*>(e0[j]) = *reinterpret_cast<const float4*>(ev[j] + c0);
@@ -282,6 +323,8 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
             x0[j][0] = x0v[j].x; x0[j][1] = x0v[j].y; x0[j][2] = x0v[j].z; x0[j][3] = x0v[j].w;
             x1[j][0] = x1v[j].x; x1[j][1] = x1v[j].y; x1[j][2] = x1v[j].z; x1[j][3] = x1v[j].w;
             tp[j] = 0.f;
+            et[j] = ICPT ? ev[j][TL] : 0.f;
+            zt[j] = ICPT ? __fmaf_rn(pk[DL + TL], et[j], pk[TL]) : 0.f;
         }
 #pragma unroll
         for (int n = 0; n < 4; ++n)
@@ -293,15 +336,18 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
                 tp[j] = __fmaf_rn(x1[j][n], z1[j][n], tp[j]);
             }
         float sg0[4], sg1[4], q0[4], q1[4], lc0[4], lc1[4];  // (requested before the wave sums need their results)
-        *reinterpret_cast<float4*>(sg0) = *reinterpret_cast<const float4*>(pk + 2 * D + c0);
-        *reinterpret_cast<float4*>(sg1) = *reinterpret_cast<const float4*>(pk + 2 * D + c1);
-        *reinterpret_cast<float4*>(q0) = *reinterpret_cast<const float4*>(pk + 3 * D + c0);
-        *reinterpret_cast<float4*>(q1) = *reinterpret_cast<const float4*>(pk + 3 * D + c1);
-        *reinterpret_cast<float4*>(lc0) = *reinterpret_cast<const float4*>(pk + 4 * D + c0);
-        *reinterpret_cast<float4*>(lc1) = *reinterpret_cast<const float4*>(pk + 4 * D + c1);
+        *reinterpret_cast<float4*>(sg0) = *reinterpret_cast<const float4*>(pk + 2 * DL + c0);
+        *reinterpret_cast<float4*>(sg1) = *reinterpret_cast<const float4*>(pk + 2 * DL + c1);
+        *reinterpret_cast<float4*>(q0) = *reinterpret_cast<const float4*>(pk + 3 * DL + c0);
+        *reinterpret_cast<float4*>(q1) = *reinterpret_cast<const float4*>(pk + 3 * DL + c1);
+        *reinterpret_cast<float4*>(lc0) = *reinterpret_cast<const float4*>(pk + 4 * DL + c0);
+        *reinterpret_cast<float4*>(lc1) = *reinterpret_cast<const float4*>(pk + 4 * DL + c1);
         float t[NE], A[NE], loglik[NE], n2[NE], lp[NE];
 #pragma unroll
-        for (int j = 0; j < NE; ++j) t[j] = wave_sum(tp[j]);                 // logit x . z
+        for (int j = 0; j < NE; ++j) {
+            t[j] = wave_sum(tp[j]);                                          // logit x . z
+            if (ICPT) t[j] = __fmaf_rn(xtv[j], zt[j], t[j]);                 // + the tail feature, once
+        }
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             A[j] = a.A_scale * (sigmoid_f(t[j]) - yv[j]);                    // d(-lik_scale inv_obs loglik)/dt
@@ -313,8 +359,9 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
+                const bool isb = n == 3 && icpt_lane;                        // the intercept's own prior
                 g0[j][n] = __fmaf_rn(a.c1, z0[j][n], A[j] * x0[j][n]);
-                g1[j][n] = __fmaf_rn(a.c1, z1[j][n], A[j] * x1[j][n]);
+                g1[j][n] = __fmaf_rn(isb ? a.c1_b : a.c1, z1[j][n], A[j] * x1[j][n]);
                 h0[j][n] = __fmaf_rn(g0[j][n] * e0[j][n], sg0[n], -q0[n]);
                 h1[j][n] = __fmaf_rn(g1[j][n] * e1[j][n], sg1[n], -q1[n]);
                 n2[j] = __fmaf_rn(g0[j][n], g0[j][n], n2[j]);
@@ -322,17 +369,28 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
                 n2[j] = __fmaf_rn(g1[j][n], g1[j][n], n2[j]);
                 n2[j] = __fmaf_rn(h1[j][n], h1[j][n], n2[j]);
                 lp[j] = __fmaf_rn(z0[j][n], z0[j][n], lp[j]);
-                lp[j] = __fmaf_rn(z1[j][n], z1[j][n], lp[j]);
+                if (!(ICPT && n == 3)) lp[j] = __fmaf_rn(z1[j][n], z1[j][n], lp[j]);
             }
         const float lcs = ((lc0[0] + lc0[1]) + (lc0[2] + lc0[3])) + ((lc1[0] + lc1[1]) + (lc1[2] + lc1[3]));
 #pragma unroll
-        for (int j = 0; j < NE; ++j) lp[j] = __fmaf_rn(a.hz, lp[j], lcs + e2v[j]);
+        for (int j = 0; j < NE; ++j) {
+            lp[j] = __fmaf_rn(a.hz, lp[j], lcs + e2v[j]);
+            if (ICPT) lp[j] = __fmaf_rn((icpt_lane ? a.hz_b : a.hz) * z1[j][3], z1[j][3], lp[j]);
+        }
+        float gt[NE], ht[NE];
 #pragma unroll
         for (int j = 0; j < NE; ++j) n2[j] = wave_sum(n2[j]);
 #pragma unroll
         for (int j = 0; j < NE; ++j) lp[j] = wave_sum(lp[j]);
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
+            gt[j] = ht[j] = 0.f;
+            if (ICPT) {  // the tail latent is a feature column (prior of the weights); its terms enter every sum once
+                gt[j] = __fmaf_rn(a.c1, zt[j], A[j] * xtv[j]);
+                ht[j] = __fmaf_rn(gt[j] * et[j], pk[2 * DL + TL], -pk[3 * DL + TL]);
+                n2[j] = __fmaf_rn(gt[j], gt[j], __fmaf_rn(ht[j], ht[j], n2[j]));
+                lp[j] += __fmaf_rn(a.hz * zt[j], zt[j], __fmaf_rn(-0.5f * et[j], et[j], pk[4 * DL + TL]));
+            }
             // clip factor 1 / max(1, ||g|| / C) (svi.py:121-122) folded into the running sum (svi.py:343-346)
             const float cf = fminf(1.0f, a.clip * __builtin_amdgcn_rsqf(n2[j]));
 #pragma unroll
@@ -342,58 +400,71 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
                 accg1[n] = __fmaf_rn(cf, g1[j][n], accg1[n]);
                 acch1[n] = __fmaf_rn(cf, h1[j][n], acch1[n]);
             }
+            if (ICPT) {
+                acc_gt = __fmaf_rn(cf, gt[j], acc_gt);
+                acc_ht = __fmaf_rn(cf, ht[j], acc_ht);
+            }
             loss_acc += a.inv_obs * (lp[j] - a.lik_scale * loglik[j]);  // svi.py:278-281
             n_acc += 1.0f;
         }
     };
     if (live2) {  // (live2 implies live1) the common case: both in lockstep
         const float4 xs0[2] = {xa0, xb0}, xs1[2] = {xa1, xb1};
-        const float ys[2] = {ya, yb};
-        const float* es[2] = {er, er + D};
+        const float xts[2] = {xta, xtb}, ys[2] = {ya, yb};
+        const float* es[2] = {er, er + DL};
         const float e2s[2] = {ea, eb};
-        examples(std::integral_constant<int, 2>{}, xs0, xs1, ys, es, e2s);
+        examples(std::integral_constant<int, 2>{}, xs0, xs1, xts, ys, es, e2s);
     } else if (live1) {
         const float* es[1] = {er};
-        examples(std::integral_constant<int, 1>{}, &xa0, &xa1, &ya, es, &ea);
+        examples(std::integral_constant<int, 1>{}, &xa0, &xa1, &xta, &ya, es, &ea);
     }
     // further items of this wave (only when the grid was sized for fewer items than the step has: an unlucky shard of a
     // row-sharded batch): loaded, their noise generated and consumed one at a time
     for (uint32_t k = k2 + (uint32_t)a.nw * W; k < n_items; k += (uint32_t)a.nw * W) {
         const uint32_t p = PLIST ? (a.plist_base + (size_t)step_t * a.B)[k] : k;
         const size_t row = (size_t)((uint64_t)idx[p] - a.row_lo);
-        const float* xr = a.X + row * D;
-        const float4 x0 = *reinterpret_cast<const float4*>(xr + 4 * lane), x1 = *reinterpret_cast<const float4*>(xr + D / 2 + 4 * lane);
+        float4 x0, x1;
+        float xt = 0.f;
+        load_x(a.X + row * DF, x0, x1, xt);
         const float yv = a.y[row];
         const float e2 = gen(skeys[2 * p], skeys[2 * p + 1], er);
         const float* es[1] = {er};
-        examples(std::integral_constant<int, 1>{}, &x0, &x1, &yv, es, &e2);
+        examples(std::integral_constant<int, 1>{}, &x0, &x1, &xt, &yv, es, &e2);
     }
     D3P_CSTAMP(5)
 
     // ------------------------------------------------------------------ phase 4: workgroup reduction, atomics, arrival
-    // (the wave's row held its noise; both examples are consumed, the row now takes its partial sums)
+    // (the wave's row held its noise; both examples are consumed, the row now takes its partial sums: [loc-gradient | scale-
+    // gradient] x DL, indexed like the LDS columns)
     *reinterpret_cast<float4*>(er + c0) = make_float4(accg0[0], accg0[1], accg0[2], accg0[3]);
     *reinterpret_cast<float4*>(er + c1) = make_float4(accg1[0], accg1[1], accg1[2], accg1[3]);
-    *reinterpret_cast<float4*>(er + D + c0) = make_float4(acch0[0], acch0[1], acch0[2], acch0[3]);
-    *reinterpret_cast<float4*>(er + D + c1) = make_float4(acch1[0], acch1[1], acch1[2], acch1[3]);
+    *reinterpret_cast<float4*>(er + DL + c0) = make_float4(acch0[0], acch0[1], acch0[2], acch0[3]);
+    *reinterpret_cast<float4*>(er + DL + c1) = make_float4(acch1[0], acch1[1], acch1[2], acch1[3]);
+    if (ICPT && lane == 0) { er[TL] = acc_gt; er[DL + TL] = acc_ht; }
     if (lane == 0) { tail[2 * wave] = loss_acc; tail[2 * wave + 1] = n_acc; }
     __syncthreads();
     D3P_CSTAMP(6)
     {
         // fixed-point integer atomics: the exact, order-independent sum of the workgroups' fp32 partials
         long long* outp = acc_cur + (size_t)(bid % R) * PA;
-        float sL = 0.f, sS = 0.f;
+        bool bad = false;
+        auto column_pair = [&](int e) {  // latent e: columns e (auto_loc) and D + e (auto_scale)
+            const int li = lix(e);
+            float sL = 0.f, sS = 0.f;
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
-            sL += red[(size_t)w * P + tid];
-            sS += red[(size_t)w * P + D + tid];
-        }
-        const double dL = (double)sL * a.sg, dS = (double)sS * a.sg;
-        bool bad = !(fabs(dL) < 4503599627370496.0) | !(fabs(dS) < 4503599627370496.0);
-        if (!(STAMPS && (a.dbg & 4))) {  // (diagnostic instantiation only: D3P_DBG=4 switches the gradient atomics off)
-            atomicAdd(reinterpret_cast<unsigned long long*>(outp + tid), (unsigned long long)__double2ll_rn(dL));
-            atomicAdd(reinterpret_cast<unsigned long long*>(outp + D + tid), (unsigned long long)__double2ll_rn(dS));
-        }
+            for (int w = 0; w < W; ++w) {
+                sL += red[(size_t)w * 2 * DL + li];
+                sS += red[(size_t)w * 2 * DL + DL + li];
+            }
+            const double dL = (double)sL * a.sg, dS = (double)sS * a.sg;
+            bad |= !(fabs(dL) < 4503599627370496.0) | !(fabs(dS) < 4503599627370496.0);
+            if (!(STAMPS && (a.dbg & 4))) {  // (diagnostic instantiation only: D3P_DBG=4 switches the gradient atomics off)
+                atomicAdd(reinterpret_cast<unsigned long long*>(outp + e), (unsigned long long)__double2ll_rn(dL));
+                atomicAdd(reinterpret_cast<unsigned long long*>(outp + D + e), (unsigned long long)__double2ll_rn(dS));
+            }
+        };
+        column_pair(tid);
+        if (ICPT && tid == 64) column_pair(D - 1);  // the intercept
         if (tid < 3) {  // thread 0: loss, fine part; 1: example count; 2: loss, coarse part
             float s = 0.f;
 #pragma unroll
