@@ -143,6 +143,141 @@ __global__ void __launch_bounds__(64) k_chain(Sched* __restrict__ sched, StepSlo
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Start and end of a device-resident run in ONE launch each (a run of a few steps is dominated by launch latencies: a
+// 20-step run spent ~180 of its 350 us outside the step kernel).
+// k_run_init (1 workgroup): wave 0 walks the serial key chain of the first batch -- split(key, 3) per step with the 4-lane
+//   ChaCha block, three children in three quads (0.7 us per step instead of 1.9 for the one-lane form of k_chain) -- starting
+//   from the state's key and counters; the other waves zero the fixed-point accumulators and the run's status words.
+//   Replaces k_sched_init + k_chain + two memsets (and k_pack, which only the two-kernel path reads).
+// k_flush (1 workgroup): applies the update that is still pending after the last step (the arithmetic of the step kernels'
+//   prologue), leaves the state in the caller's arrays, stores the final key of the schedule into the state's other key slot
+//   and copies the run's status words to pinned host memory.  Replaces the flush launch of the step kernel + k_sched_finish
+//   + the device-to-host copy of d3p_dpvi_logreg_run_status.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_run_init(const uint32_t* __restrict__ state_key, const int32_t* __restrict__ adam_step,
+                                                  const uint32_t* __restrict__ batch_index, Sched* __restrict__ sched,
+                                                  StepSlot* __restrict__ slots, int K, long long* __restrict__ acc, uint32_t acc_words,
+                                                  uint32_t* __restrict__ status)
+{
+    const int tid = threadIdx.x;
+    if (tid >= 64) {  // waves 1..3: zero the accumulators (3 x R x cols int64) and the status words
+        for (uint32_t i = tid - 64; i < acc_words; i += 192) acc[i] = 0;
+        if (tid < 64 + 16) status[tid - 64] = 0u;
+        return;
+    }
+    const int lane = tid, q = lane & 3, child = (lane >> 2) < 3 ? (lane >> 2) : 0;
+    const int32_t adam0 = *adam_step;
+    const uint32_t batch0 = batch_index ? *batch_index : 0u;
+    const uint32_t p0 = state_key[q];
+    uint32_t p1 = state_key[4 + q], p2 = state_key[8 + q], p3 = state_key[12 + q];
+    for (int t = 0; t < K; ++t) {
+        uint32_t a, b;
+        derive_child_quad_regs(p0, p1, p2, p3, (uint32_t)child, D3P_TAG_SPLIT, 0u, a, b);
+        if (lane >= 4 && lane < 12) {  // gradient key (child 1), perturbation key (child 2)
+            uint32_t* dst = lane < 8 ? slots[t].grad_key : slots[t].pert_key;
+            dst[q] = p0;
+            dst[4 + q] = a;
+            dst[8 + q] = b;
+            dst[12 + q] = 0u;
+        } else if (lane == 12) {
+            slots[t].adam_i = adam0 + t;
+            slots[t].batch_i = batch0 + (uint32_t)t;
+        }
+        // the next state key is child 0 (lanes 0..3): every quad continues from it
+        p1 = __shfl(a, q);
+        p2 = __shfl(b, q);
+        p3 = 0u;
+    }
+    if (lane < 4) {
+        sched->key[q] = p0;
+        sched->key[4 + q] = p1;
+        sched->key[8 + q] = p2;
+        sched->key[12 + q] = p3;
+    }
+    if (lane == 0) {
+        sched->adam_i = adam0 + K;
+        sched->batch_i = batch0 + (uint32_t)K;
+    }
+}
+
+struct FlushArgs {
+    const long long* acc_prev;  // R x cols
+    const float* noise;         // P normals of the last step
+    const StepSlot* slot;       // its slot
+    const float* state_in[3];
+    float* state_out[3];        // the caller's arrays
+    float* loss_out;            // nullable
+    int32_t* adam_step;
+    uint32_t* batch_index;      // nullable
+    const Sched* sched;
+    uint32_t* key_out;          // the state's key slot after the run
+    const uint32_t* status;
+    unsigned long long* host_status;  // nullable: pinned host record {abort, nonfinite, tag}
+    unsigned long long host_tag;
+    int P, B;
+    float dp_scale, clip, obs_scale, lr, b1, b2, adam_eps;
+    double inv_sg;
+};
+
+__global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
+{
+    const int tid = threadIdx.x, PA = D3P_ACC_COLS(a.P);
+    if (tid < 16) a.key_out[tid] = a.sched->key[tid];
+    const uint32_t aborted = a.status[0];
+    if (tid == 0 && a.host_status) {
+        a.host_status[0] = aborted;
+        a.host_status[1] = a.status[1];
+        a.host_status[2] = a.host_tag;
+    }
+    if (aborted) {  // the pending sums are incomplete: leave the state where the run stopped
+        if (tid == 0 && a.loss_out) *a.loss_out = __builtin_nanf("");
+        return;
+    }
+    long long nll = 0;
+    for (int r = 0; r < D3P_ACC_R; ++r) nll += a.acc_prev[(size_t)r * PA + a.P + 1];
+    const float n = nll >= (1ll << 40) ? __builtin_nanf("") : (float)nll;
+    const float Bf = (float)a.B;
+    const float factor = (n == 0.0f) ? 0.0f : Bf / n;
+    const float inv_B = 1.0f / Bf, inv_bc1 = 1.0f / a.slot->bc1, inv_bc2 = 1.0f / a.slot->bc2;
+    const float noise_scale = a.dp_scale * (a.clip / n), out_scale = a.obs_scale * factor;
+    for (int col = tid; col < a.P; col += blockDim.x) {
+        long long sll = 0;
+        for (int r = 0; r < D3P_ACC_R; ++r) sll += a.acc_prev[(size_t)r * PA + col];
+        const float tot = (float)((double)sll * a.inv_sg);
+        const float g = __fmaf_rn(a.noise[col], noise_scale, tot * inv_B) * out_scale;
+        const float mm = (1.0f - a.b1) * g + a.b1 * a.state_in[1][col];
+        const float vv = (1.0f - a.b2) * g * g + a.b2 * a.state_in[2][col];
+        const float xx = a.state_in[0][col] - a.lr * (mm * inv_bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv * inv_bc2) + a.adam_eps);
+        a.state_out[0][col] = xx;
+        a.state_out[1][col] = mm;
+        a.state_out[2][col] = vv;
+    }
+    if (tid == 0) {
+        long long lll = 0, lhh = 0;
+        for (int r = 0; r < D3P_ACC_R; ++r) {
+            lll += a.acc_prev[(size_t)r * PA + a.P];
+            lhh += a.acc_prev[(size_t)r * PA + a.P + 2];
+        }
+        if (a.loss_out) *a.loss_out = ((float)loss_join(lhh, lll) / Bf) * a.obs_scale * factor;
+        *a.adam_step = a.slot->adam_i + 1;
+        if (a.batch_index) *a.batch_index = a.slot->batch_i + 1u;
+    }
+}
+
+// pinned host record of the last run's status words (written by k_flush): spares d3p_dpvi_logreg_run_status its copy
+static unsigned long long* host_status_record()
+{
+    static unsigned long long* p = [] {
+        void* q = nullptr;
+        if (hipHostMalloc(&q, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return (unsigned long long*)nullptr; }
+        memset(q, 0, 64);
+        return (unsigned long long*)q;
+    }();
+    return p;
+}
+
 // ------------------------------------------------------------------------------------------
 // sampler: grid (ceil(B/256) + 1, K); blockIdx.y = step within the batch; the extra x-block of every
 // step produces the Gaussian-mechanism normals and the slot scalars.
@@ -1194,12 +1329,15 @@ static int enqueue_chain(const Ctx& c, int K);
 
 // comm != nullptr: data-parallel run -- after every step launch the rank's fixed-point accumulator (R x (P + 2) int64) is
 // sum-all-reduced in place on the same stream (the ONE collective of the step); the next launch applies the global sums.
+// The whole run: k_run_init (schedule from the state, key chain of the first batch, zeroed accumulators and status) ->
+// per batch the sampler and the step launches -> k_flush (last pending update, final key, status to the host record).
 static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_t num_steps, float* losses, ncclComm_t comm = nullptr,
                            Xchg* xchg = nullptr)
 {
     int rc;
-    const size_t acc_bytes = 3 * (size_t)D3P_ACC_R * D3P_ACC_COLS(c.P) * sizeof(long long);
-    D3P_HIP_TRY(hipMemsetAsync(c.ws.acc, 0, acc_bytes, c.s));
+    const uint32_t acc_words = 3u * D3P_ACC_R * (uint32_t)D3P_ACC_COLS(c.P);
+    const bool sampled = c.src->kind != D3P_BATCH_EXPLICIT;
+    uint32_t* key_out = c.st->rng_key + 16 * ((c.st->key_slot + (int)num_steps) & 1);
     const uint32_t n_batches = (num_steps + D3P_STEP_BATCH - 1) / D3P_STEP_BATCH;
     auto batch_len = [&](uint32_t b) {
         const uint32_t rem = num_steps - b * D3P_STEP_BATCH;
@@ -1210,8 +1348,15 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     cb[1].ws.partials = c.ws.partials;
     cb[1].ws.acc = c.ws.acc;
     cb[1].ws.stamps = c.ws.stamps;
-    if (num_steps == 0) return D3P_OK;
-    if ((rc = enqueue_chain(cb[0], batch_len(0)))) return rc;
+    if (num_steps == 0) {  // nothing to run: the key and the status words are still defined afterwards
+        D3P_HIP_TRY(hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s));
+        D3P_HIP_TRY(hipMemcpyAsync(key_out, c.st->rng_key + 16 * (c.st->key_slot & 1), 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice, c.s));
+        return D3P_OK;
+    }
+    hipLaunchKernelGGL(k_run_init, dim3(1), dim3(256), 0, c.s, (const uint32_t*)(c.st->rng_key + 16 * (c.st->key_slot & 1)),
+                       (const int32_t*)c.st->step, sampled ? (const uint32_t*)c.src->batch_index : nullptr, c.ws.sched, cb[0].ws.slots,
+                       batch_len(0), c.ws.acc, acc_words, run_status_words(c.ws));
+    if ((rc = check_launch("k_run_init"))) return rc;
     if ((rc = enqueue_sampler(cb[0], batch_len(0)))) return rc;
     static const bool no_piggy = getenv("D3P_NO_CHAIN_PIGGYBACK") != nullptr;  // developer switch, read once
     const StepSlot* prev_slot = nullptr;
@@ -1219,9 +1364,6 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     int g = 0;
     const bool chained = !comm && !xchg && use_chained_steps(c);
     const bool persist = chained && use_persistent_steps(c);
-    // the abort flag of the bounded waits: cleared once per run (whatever form the steps take), read back by
-    // d3p_dpvi_logreg_chain_status
-    D3P_HIP_TRY(hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s));
     for (uint32_t b = 0; b < n_batches; ++b) {
         const int cur = (int)(b & 1), nxt = cur ^ 1;
         const int K = batch_len(b), K_next = (b + 1 < n_batches) ? batch_len(b + 1) : 0;
@@ -1261,13 +1403,38 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
             if ((rc = enqueue_sampler(cb[nxt], K_next))) return rc;
         }
     }
-    if (persist) return D3P_OK;  // state, step counters and losses are already final
-    // apply the update of the last step
-    const int last_buf = (int)((n_batches - 1) & 1);
-    if ((rc = enqueue_fused_step(cb[last_buf], g, 0, prev_slot, prev_noise, X, y, losses ? losses + g - 1 : nullptr, nullptr, 0, 0,
-                                 true)))
-        return rc;
-    return D3P_OK;
+    if (persist) {  // state, step counters and losses are already final: only the key is left
+        hipLaunchKernelGGL(k_sched_finish, dim3(1), dim3(64), 0, c.s, (const Sched*)c.ws.sched, key_out);
+        return check_launch("k_sched_finish");
+    }
+    // apply the update of the last step, store the final key, report the status
+    FlushArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    const size_t words = (size_t)D3P_ACC_R * D3P_ACC_COLS(c.P);
+    fa.acc_prev = c.ws.acc + (size_t)((g + 2) % 3) * words;
+    fa.noise = prev_noise;
+    fa.slot = prev_slot;
+    {
+        const size_t P = (size_t)c.P;
+        float* const bufs[2][3] = {{c.st->params, c.st->adam_m, c.st->adam_v}, {c.ws.pp_state, c.ws.pp_state + P, c.ws.pp_state + 2 * P}};
+        const int in = g > 0 ? ((g - 1) & 1) : 0;  // launch g - 1 published to buffer (g - 1) & 1
+        for (int j = 0; j < 3; ++j) { fa.state_in[j] = bufs[in][j]; fa.state_out[j] = bufs[0][j]; }
+    }
+    fa.loss_out = losses ? losses + g - 1 : nullptr;
+    fa.adam_step = c.st->step;
+    fa.batch_index = sampled ? c.src->batch_index : nullptr;
+    fa.sched = c.ws.sched;
+    fa.key_out = key_out;
+    fa.status = run_status_words(c.ws);
+    fa.host_status = host_status_record();
+    fa.host_tag = (unsigned long long)(uintptr_t)run_status_words(c.ws);
+    fa.P = c.P;
+    fa.B = (int)c.src->B;
+    fa.dp_scale = c.h->dp_scale; fa.clip = c.h->clip; fa.obs_scale = 1.0f / c.m->inv_obs;
+    fa.lr = c.h->lr; fa.b1 = c.h->b1; fa.b2 = c.h->b2; fa.adam_eps = c.h->adam_eps;
+    fa.inv_sg = 1.0 / (1099511627776.0 / (double)fabsf(c.h->clip));
+    hipLaunchKernelGGL(k_flush, dim3(1), dim3(1024), 0, c.s, fa);
+    return check_launch("k_flush");
 }
 
 static int make_ctx(Ctx* c, void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
@@ -1602,9 +1769,7 @@ int d3p_dpvi_logreg_run_xchg(void* stream, void* xchg, const d3p_logreg_model* m
         return rcm;
     D3P_REQUIRE(src->kind != D3P_BATCH_EXPLICIT, "d3p_dpvi_logreg_run_xchg: needs an on-device sampler (Feistel or Poisson)");
     D3P_REQUIRE(((Xchg*)xchg)->words == (uint32_t)D3P_ACC_COLS(c.P), "d3p_dpvi_logreg_run_xchg: the exchange was created for another message size");
-    if ((rc = enqueue_sched_init(c))) return rc;
-    if ((rc = run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev, nullptr, (Xchg*)xchg))) return rc;
-    return enqueue_sched_finish(c, (int)num_steps);
+    return run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev, nullptr, (Xchg*)xchg);
 }
 
 int d3p_dpvi_logreg_run_dist(void* stream, void* comm, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
@@ -1620,9 +1785,7 @@ int d3p_dpvi_logreg_run_dist(void* stream, void* comm, const d3p_logreg_model* m
         return rcm;
     D3P_REQUIRE(src->kind != D3P_BATCH_EXPLICIT, "d3p_dpvi_logreg_run_dist: needs an on-device sampler (Feistel or Poisson)");
     if (comm && !rccl_api()) return fail(D3P_E_UNSUPPORTED, "d3p_dpvi_logreg_run_dist: librccl.so could not be loaded");
-    if ((rc = enqueue_sched_init(c))) return rc;
-    if ((rc = run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev, (ncclComm_t)comm))) return rc;
-    return enqueue_sched_finish(c, (int)num_steps);
+    return run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev, (ncclComm_t)comm);
 }
 
 int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
@@ -1636,11 +1799,8 @@ int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_d
     D3P_REQUIRE(X_dev, "null data pointer");
     if (int rcm = validate_model(model, y_dev, "d3p_dpvi_logreg_run")) return rcm;
     D3P_REQUIRE(src->row_lo == 0 && src->row_hi == src->n_rows, "d3p_dpvi_logreg_run is the single-GPU path");
+    if (use_fused_step(c)) return run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev);
     if ((rc = enqueue_sched_init(c))) return rc;
-    if (use_fused_step(c)) {
-        if ((rc = run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev))) return rc;
-        return enqueue_sched_finish(c, (int)num_steps);
-    }
     D3P_HIP_TRY(hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s));  // (no waits, no fixed-point sums: stays 0)
     // Two-kernel steps (D3P_NO_FUSED_STEP): main + finalize per step; the key-chain step of the next batch rides in every
     // k_finalize launch as one extra workgroup.  (Running the chain or the sampler on an auxiliary stream was measured
@@ -1721,9 +1881,16 @@ int d3p_dpvi_logreg_run_status(void* stream, const d3p_logreg_model* model, cons
     if (workspace_bytes < d3p_dpvi_logreg_workspace(model, src)) return fail(D3P_E_WORKSPACE, "workspace too small");
     Workspace ws;
     carve(model, src, (char*)workspace_dev, &ws);
-    uint32_t words[2] = {0u, 0u};
-    D3P_HIP_TRY(hipMemcpyAsync(words, run_status_words(ws), sizeof(words), hipMemcpyDeviceToHost, (hipStream_t)stream));
     D3P_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    // the run's last launch (k_flush) left the words in a pinned host record, tagged with this workspace's status address
+    const volatile unsigned long long* rec = host_status_record();
+    if (rec && rec[2] == (unsigned long long)(uintptr_t)run_status_words(ws)) {
+        *aborted_out = (int32_t)rec[0];
+        *nonfinite_out = (int32_t)rec[1];
+        return D3P_OK;
+    }
+    uint32_t words[2] = {0u, 0u};
+    D3P_HIP_TRY(hipMemcpy(words, run_status_words(ws), sizeof(words), hipMemcpyDeviceToHost));
     *aborted_out = (int32_t)words[0];
     *nonfinite_out = (int32_t)words[1];
     return D3P_OK;

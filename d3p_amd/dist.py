@@ -55,7 +55,7 @@ class HipEngine:
         self.keybuf = torch.empty((2, 16), dtype=torch.uint32, device=self.dev)
         self.keybuf[0].copy_(state.rng_key.reshape(16))
         self.bkey = batch_key.contiguous()
-        self.bidx = torch.tensor([int(first_batch)], dtype=torch.int32, device=self.dev)
+        self.bidx = torch.full((1,), int(first_batch), dtype=torch.int32, device=self.dev)
         self.src = BatchSource(self.kind, self.B, self.q, int(self.suppress), self.bkey.data_ptr(),
                                self.bidx.data_ptr(), None, self.n, self.lo, self.hi)
         lib = _lib.load()

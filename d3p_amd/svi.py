@@ -712,7 +712,7 @@ class DPSVI:
         keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
         keybuf[0].copy_(svi_state.rng_key.reshape(16))
         bkey = batchifier_state.contiguous()
-        bidx = torch.tensor([int(first_batch)], dtype=torch.int32, device=dev)
+        bidx = torch.full((1,), int(first_batch), dtype=torch.int32, device=dev)   # (a fill kernel: no host-to-device copy + sync)
         src = BatchSource(info.kind, info.batch_size, float(info.q), int(info.suppress), bkey.data_ptr(),
                           bidx.data_ptr(), None, N, 0, N)
         st = self._state_struct(keybuf, 0, (step, params, m, v))

@@ -519,7 +519,13 @@ np.save(sys.argv[1], np.concatenate([losses.cpu().numpy(), s2.optim_state[1].cpu
             env = dict(os.environ, **env_extra)
             subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env, timeout=300)
             outs.append(np.load(f.name))
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    steps = 150
+    # losses (every one the exact integer sum of the same fp32 partials) and the trajectory they imply: bit for bit.  The very
+    # last update is applied by k_flush for the chained / one-launch forms and inside the launch by the persistent form:
+    # the same formula compiled in two kernels (fma contraction may differ), so the final parameters agree to 1 ulp-ish.
+    assert np.array_equal(outs[1], outs[2])
+    assert np.array_equal(outs[0][:steps], outs[1][:steps])
+    np.testing.assert_allclose(outs[0][steps:], outs[1][steps:], rtol=1e-6, atol=1e-7)
     assert np.all(np.isfinite(outs[0]))
     # The pipelined form groups the examples differently into workgroups (two per wave), so its fp32 workgroup partials
     # round differently: reproducible bit for bit run to run, and equal to the others to fp32 rounding over the 150 steps (two launches: 128 + 22)
