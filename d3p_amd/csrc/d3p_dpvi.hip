@@ -44,6 +44,7 @@ struct Workspace {
     float* scratch_state;  // 3P + 4 floats: stand-in state for the timing entry point
     float* pp_state;       // 3P floats: second buffer of the ping-ponged optimiser state (one-launch-per-step path)
     uint32_t* chain_bar;   // chained form: (D3P_STEP_BATCH + 1) x D3P_BAR_WORDS arrival counters + 16 words (abort flag)
+    uint32_t* xflags;      // in-launch exchange of a data-parallel run: D3P_STEP_BATCH flags, 128 bytes apart
     float* partials;  // max_blocks x (P + 2)
     unsigned long long* stamps;  // 2 x max_blocks
     void* poisson_ws;
@@ -68,6 +69,7 @@ static size_t carve(const d3p_logreg_model* m, const d3p_batch_source* src, char
     p = take((3 * P + 4) * sizeof(float)); if (ws) ws->scratch_state = (float*)p;
     p = take(3 * P * sizeof(float)); if (ws) ws->pp_state = (float*)p;
     p = take(((size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS + 16) * sizeof(uint32_t)); if (ws) ws->chain_bar = (uint32_t*)p;
+    p = take((size_t)D3P_STEP_BATCH * 32 * sizeof(uint32_t)); if (ws) ws->xflags = (uint32_t*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * (P + 2) * sizeof(float)); if (ws) ws->partials = (float*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * 4 * sizeof(unsigned long long)); if (ws) ws->stamps = (unsigned long long*)p;  // >= 2 x 256 x 16 phase stamps
     size_t pb = 0;
@@ -681,6 +683,7 @@ struct Ctx {
     Workspace ws;
     MainGeom g;
     int D, P;
+    uint64_t items_expected;  // batch positions this rank expects to process per step (B, or its share of a row-sharded batch)
     Workspace ws2;  // second slot buffer (slots / idx / skeys / noise) for the pipelined run loop
 };
 
@@ -1028,8 +1031,20 @@ static int print_chain_anatomy(const Ctx& c)
     return D3P_OK;
 }
 
+struct Xchg;
+static void xchg_fill_dev(Xchg* x, XchgDev* d, int K);  // (defined with the exchange, below) takes K epochs of the exchange
+
+// can this run's chained launch be the kernel of d3p_logreg_chain.h?
+static bool lean_chain_ok(const Ctx& c)
+{
+    static const bool off = getenv("D3P_NO_LEAN_CHAIN") != nullptr || getenv("D3P_NO_PIPELINED_STEPS") != nullptr ||
+                            getenv("D3P_MAIN_W") != nullptr;
+    return !off && c.g.full && c.g.V == 4 && c.g.NK == 1 && c.g.W == 16 && c.m->d == D3P_CHAIN_D &&
+           c.m->family == D3P_FAMILY_LOGREG && c.items_expected <= 18ull * c.g.blocks;
+}
+
 static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* prev_slot0, const float* prev_noise0, const float* X,
-                                 const float* y, float* losses, StepSlot* chain_slots, int K_next)
+                                 const float* y, float* losses, StepSlot* chain_slots, int K_next, Xchg* xchg = nullptr)
 {
     MainArgs a;
     memset(&a, 0, sizeof(a));
@@ -1102,11 +1117,8 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
     {
         // The headline shape (d = 512, no intercept, logistic regression; at most ~two examples per wave of an 8-wave
         // workgroup) runs the kernel written for it (d3p_logreg_chain.h); D3P_NO_LEAN_CHAIN=1 keeps the generic template.
-        static const bool off = getenv("D3P_NO_LEAN_CHAIN") != nullptr || getenv("D3P_NO_PIPELINED_STEPS") != nullptr ||
-                                getenv("D3P_MAIN_W") != nullptr;
         const bool icpt = c.g.tail;  // 512 features + intercept (D = 513): the ICPT instantiations
-        if (!off && c.g.full && c.g.V == 4 && c.g.NK == 1 && c.g.W == 16 && c.m->d == D3P_CHAIN_D &&
-            c.m->family == D3P_FAMILY_LOGREG && (uint64_t)c.src->B <= 18ull * c.g.blocks) {
+        if (lean_chain_ok(c)) {
             ChainArgs ca;
             memset(&ca, 0, sizeof(ca));
             ca.X = X;
@@ -1141,7 +1153,12 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
             ca.c1_b = a.c1_b; ca.hz_b = a.hz_b; ca.log_prior_b = logf(c.m->prior_b);
             ca.gexp = a.gexp;
             ca.dbg = dev_dbg_flags();
-            const dim3 grid((uint32_t)K * (c.g.blocks + 1u)), block(64 * D3P_CHAIN_W);
+            if (xchg) {  // data-parallel run: the step's exchange rides in the launch (one more workgroup per step)
+                xchg_fill_dev(xchg, &ca.x, K);
+                ca.x.xflag = c.ws.xflags;
+                D3P_HIP_TRY(hipMemsetAsync(c.ws.xflags, 0, (size_t)D3P_STEP_BATCH * 32 * sizeof(uint32_t), c.s));
+            }
+            const dim3 grid((uint32_t)K * (c.g.blocks + 1u + (xchg ? 1u : 0u))), block(64 * D3P_CHAIN_W);
             const bool plist = ca.plist_base != nullptr;
             const size_t lds = chain_lds_bytes(icpt);
             const bool stamped = (ca.dbg & 32) && K >= 2;  // D3P_DBG=32: the stamped instantiation + the phase anatomy on stderr
@@ -1234,9 +1251,6 @@ static const RcclApi* rccl_api()
 // accesses are system-scope.  Slots and flags are double-buffered by the parity of the step count: a rank can only start
 // exchange e + 1 after every peer has finished READING in exchange e (it needs their flag of e + 1, sent after their
 // exchange e), so slot parity e is free again when exchange e + 2 writes it.  Waits are bounded and raise status[0].
-#define D3P_XCHG_MAX_WORLD 16
-#define D3P_XCHG_FLAG_STRIDE 16  // uint64 words: one 128-byte line per flag
-
 struct Xchg {
     int world, rank;
     uint32_t words;                    // int64 words per message (one folded accumulator row)
@@ -1307,6 +1321,16 @@ __global__ void __launch_bounds__(1024) k_xchg(XchgArgs a)
     }
 }
 
+static void xchg_fill_dev(Xchg* x, XchgDev* d, int K)
+{
+    d->world = x->world;
+    d->rank = x->rank;
+    for (int p = 0; p < x->world; ++p) d->peer[p] = x->peer[p];
+    d->data_bytes = xchg_data_bytes(x->world, x->words);
+    d->epoch0 = x->epoch;
+    x->epoch += (unsigned long long)K;
+}
+
 static int enqueue_xchg(hipStream_t s, Xchg* x, long long* acc, int R, uint32_t* status)
 {
     XchgArgs a;
@@ -1362,14 +1386,17 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     const StepSlot* prev_slot = nullptr;
     const float* prev_noise = nullptr;
     int g = 0;
-    const bool chained = !comm && !xchg && use_chained_steps(c);
+    // (data-parallel with the one-shot exchange: chained too when the shape has the dedicated kernel -- the exchange then rides
+    // in the launch; D3P_XCHG_PER_STEP=1 keeps one step launch + one exchange launch per step)
+    static const bool xchg_per_step = getenv("D3P_XCHG_PER_STEP") != nullptr;
+    const bool chained = !comm && use_chained_steps(c) && (!xchg || (lean_chain_ok(c) && !xchg_per_step));
     const bool persist = chained && use_persistent_steps(c);
     for (uint32_t b = 0; b < n_batches; ++b) {
         const int cur = (int)(b & 1), nxt = cur ^ 1;
         const int K = batch_len(b), K_next = (b + 1 < n_batches) ? batch_len(b + 1) : 0;
         if (chained) {
             if ((rc = enqueue_chained_batch(cb[cur], g, K, prev_slot, prev_noise, X, y, losses, no_piggy ? nullptr : cb[nxt].ws.slots,
-                                            K_next)))
+                                            K_next, xchg)))
                 return rc;
             g += K;
             if (!persist) {  // the persistent form applies every update inside its launch: nothing is pending afterwards
@@ -1458,6 +1485,9 @@ static int make_ctx(Ctx* c, void* stream, const d3p_logreg_model* model, const d
         if (blocks > 256u) blocks = 256u;
         if (blocks < 1u) blocks = 1u;
         c->g.blocks = blocks;
+        c->items_expected = expected;
+    } else {
+        c->items_expected = src->B;
     }
     c->s = (hipStream_t)stream;
     c->m = model;

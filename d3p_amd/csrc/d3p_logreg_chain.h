@@ -31,6 +31,21 @@ namespace d3p {
 #define D3P_CHAIN_D 512
 #define D3P_CHAIN_W 8
 
+// In-launch exchange of a data-parallel run (world > 0): one more workgroup per step waits for the step's arrivals, folds the
+// rank's accumulator replicas, writes the folded row into every rank's inbox (d3p_xchg_*: system-scope stores over xGMI),
+// waits for the world's rows, leaves their sum in replica 0 of the step's accumulator (replicas 1.. zeroed) and raises the
+// step's exchange flag -- which is what the NEXT step's workgroups then wait for instead of the arrival flags.  The next
+// step's parameter-independent work (row gathers, noise) overlaps the exchange; there is no launch boundary per step.
+#define D3P_XCHG_MAX_WORLD 16
+#define D3P_XCHG_FLAG_STRIDE 16  // uint64 words: one 128-byte line per flag
+struct XchgDev {
+    int world, rank;                   // world == 0: no exchange
+    char* peer[D3P_XCHG_MAX_WORLD];    // inboxes: data[2][world][words] | flags[2][world][FLAG_STRIDE]
+    size_t data_bytes;
+    unsigned long long epoch0;         // exchanges done before this launch; step t of the launch is exchange epoch0 + t + 1
+    uint32_t* xflag;                   // K flags, 32 words apart, zeroed before the launch
+};
+
 struct ChainArgs {
     const float* X;
     const float* y;
@@ -58,6 +73,7 @@ struct ChainArgs {
     float A_scale, c1, hz, inv_obs, lik_scale, obs_scale, clip, dp_scale, lr, b1, b2, adam_eps, log_prior;
     float c1_b, hz_b, log_prior_b;  // ICPT: the intercept's prior
     int gexp;
+    XchgDev x;
     int dbg;  // developer switches (D3P_DBG): 2 = raised wave priority on the critical path, 4 = no gradient atomics (STAMPS only)
 };
 
@@ -93,9 +109,65 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     D3P_CSTAMP(0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t per = (uint32_t)a.nw + 1u;
+    const uint32_t per = (uint32_t)a.nw + 1u + (a.x.world > 0 ? 1u : 0u);
     const int step_t = (int)(blockIdx.x / per);
     const uint32_t bid = blockIdx.x % per;
+
+    if (a.x.world > 0 && bid == (uint32_t)a.nw + 1u) {  // ---- the exchange workgroup of step `step_t`
+        const size_t words = (size_t)R * PA;
+        long long* acc = a.acc_base + (size_t)((a.g0 + step_t) % 3) * words;
+        if (tid == 64) okw[1] = 0u;
+        if (wave == 0) {  // every compute workgroup of the step has added its sums
+            const uint32_t ng = (uint32_t)a.nw < D3P_BAR_GROUPS ? (uint32_t)a.nw : D3P_BAR_GROUPS;
+            const bool ok = chain_wait_groups(a.bar + (size_t)step_t * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS), ng, a.status);
+            if (lane == 0) okw[0] = ok ? 0u : 1u;
+        }
+        __syncthreads();
+        if (okw[0] != 0u) return;
+        const unsigned long long epoch = a.x.epoch0 + (unsigned long long)step_t + 1ull;
+        const unsigned parity = (unsigned)(epoch & 1ull);
+        for (int c = tid; c < PA; c += 64 * W) {  // fold the replicas, deliver the row to every inbox
+            long long v = 0;
+            for (int r = 0; r < R; ++r) v += __hip_atomic_load(acc + (size_t)r * PA + c, __ATOMIC_RELAXED, D3P_AGENT);
+            for (int p = 0; p < a.x.world; ++p) {
+                long long* slot = reinterpret_cast<long long*>(a.x.peer[p]) + ((size_t)parity * a.x.world + a.x.rank) * PA;
+                __hip_atomic_store(slot + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        __threadfence_system();  // the rows are performed at their destinations before any flag moves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid < a.x.world) {
+            unsigned long long* f = reinterpret_cast<unsigned long long*>(a.x.peer[tid] + a.x.data_bytes) +
+                                    ((size_t)parity * a.x.world + a.x.rank) * D3P_XCHG_FLAG_STRIDE;
+            __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(a.x.peer[a.x.rank] + a.x.data_bytes) +
+                                             ((size_t)parity * a.x.world + tid) * D3P_XCHG_FLAG_STRIDE;
+            bool ok = false;
+            for (uint32_t spins = 0; spins < (1u << 24); ++spins) {
+                if (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= epoch) { ok = true; break; }
+                if ((spins & 255u) == 255u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok) {
+                okw[1] = 1u;
+                __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, D3P_AGENT);
+            }
+        }
+        __syncthreads();
+        if (okw[1] != 0u) return;  // aborted: the run stops here (status[0])
+        const long long* inbox = reinterpret_cast<const long long*>(a.x.peer[a.x.rank]) + (size_t)parity * a.x.world * PA;
+        for (int c = tid; c < PA; c += 64 * W) {
+            long long tot = 0;
+            for (int p = 0; p < a.x.world; ++p) tot += __hip_atomic_load(inbox + (size_t)p * PA + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(acc + c, tot, __ATOMIC_RELAXED, D3P_AGENT);
+            for (int r = 1; r < R; ++r) __hip_atomic_store(acc + (size_t)r * PA + c, 0ll, __ATOMIC_RELAXED, D3P_AGENT);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.x.xflag + (size_t)step_t * 32, 1u, __ATOMIC_RELAXED, D3P_AGENT);
+        return;
+    }
 
     if (bid == (uint32_t)a.nw) {  // key-chain workgroup: split(state_key, 3) of step `step_t` of the NEXT batch
         if (step_t < a.K_next && tid < 64) {
@@ -199,8 +271,12 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     long long* acc_next = a.acc_base + (size_t)((g + 1) % 3) * words;
     if (wave == 0) {
         const uint32_t ng = (uint32_t)a.nw < D3P_BAR_GROUPS ? (uint32_t)a.nw : D3P_BAR_GROUPS;
-        const bool ok = chain_wait_groups(
-            step_t > 0 ? a.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS) : nullptr, ng, a.status);
+        bool ok;
+        if (a.x.world > 0)  // data-parallel: the previous step's exchange flag (global sums in place) instead of its arrival flags
+            ok = chain_wait_groups(step_t > 0 ? a.x.xflag + (size_t)(step_t - 1) * 32 : nullptr, 1u, a.status);
+        else
+            ok = chain_wait_groups(
+                step_t > 0 ? a.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS) : nullptr, ng, a.status);
         if (lane == 0) okw[0] = ok ? 0u : 1u;
     }
     __syncthreads();
