@@ -45,6 +45,7 @@ struct Workspace {
     float* pp_state;       // 3P floats: second buffer of the ping-ponged optimiser state (one-launch-per-step path)
     uint32_t* chain_bar;   // chained form: (D3P_STEP_BATCH + 1) x D3P_BAR_WORDS arrival counters + 16 words (abort flag)
     uint32_t* xflags;      // in-launch exchange of a data-parallel run: D3P_STEP_BATCH flags, 128 bytes apart
+    long long* xsum;       // ... and the world's sums of step g in row g % 3 (3 x cols)
     float* partials;  // max_blocks x (P + 2)
     unsigned long long* stamps;  // 2 x max_blocks
     void* poisson_ws;
@@ -70,6 +71,7 @@ static size_t carve(const d3p_logreg_model* m, const d3p_batch_source* src, char
     p = take(3 * P * sizeof(float)); if (ws) ws->pp_state = (float*)p;
     p = take(((size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS + 16) * sizeof(uint32_t)); if (ws) ws->chain_bar = (uint32_t*)p;
     p = take((size_t)D3P_STEP_BATCH * 32 * sizeof(uint32_t)); if (ws) ws->xflags = (uint32_t*)p;
+    p = take(3 * (size_t)D3P_ACC_COLS(P) * sizeof(long long)); if (ws) ws->xsum = (long long*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * (P + 2) * sizeof(float)); if (ws) ws->partials = (float*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * 4 * sizeof(unsigned long long)); if (ws) ws->stamps = (unsigned long long*)p;  // >= 2 x 256 x 16 phase stamps
     size_t pb = 0;
@@ -205,7 +207,8 @@ __global__ void __launch_bounds__(256) k_run_init(const uint32_t* __restrict__ s
 }
 
 struct FlushArgs {
-    const long long* acc_prev;  // R x cols
+    const long long* acc_prev;  // nrep x cols: the local replicas, or the one row of world sums of a data-parallel chained run
+    int nrep;
     const float* noise;         // P normals of the last step
     const StepSlot* slot;       // its slot
     const float* state_in[3];
@@ -238,7 +241,7 @@ __global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
         return;
     }
     long long nll = 0;
-    for (int r = 0; r < D3P_ACC_R; ++r) nll += a.acc_prev[(size_t)r * PA + a.P + 1];
+    for (int r = 0; r < a.nrep; ++r) nll += a.acc_prev[(size_t)r * PA + a.P + 1];
     const float n = nll >= (1ll << 40) ? __builtin_nanf("") : (float)nll;
     const float Bf = (float)a.B;
     const float factor = (n == 0.0f) ? 0.0f : Bf / n;
@@ -246,7 +249,7 @@ __global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
     const float noise_scale = a.dp_scale * (a.clip / n), out_scale = a.obs_scale * factor;
     for (int col = tid; col < a.P; col += blockDim.x) {
         long long sll = 0;
-        for (int r = 0; r < D3P_ACC_R; ++r) sll += a.acc_prev[(size_t)r * PA + col];
+        for (int r = 0; r < a.nrep; ++r) sll += a.acc_prev[(size_t)r * PA + col];
         const float tot = (float)((double)sll * a.inv_sg);
         const float g = __fmaf_rn(a.noise[col], noise_scale, tot * inv_B) * out_scale;
         const float mm = (1.0f - a.b1) * g + a.b1 * a.state_in[1][col];
@@ -258,7 +261,7 @@ __global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
     }
     if (tid == 0) {
         long long lll = 0, lhh = 0;
-        for (int r = 0; r < D3P_ACC_R; ++r) {
+        for (int r = 0; r < a.nrep; ++r) {
             lll += a.acc_prev[(size_t)r * PA + a.P];
             lhh += a.acc_prev[(size_t)r * PA + a.P + 2];
         }
@@ -1156,6 +1159,7 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
             if (xchg) {  // data-parallel run: the step's exchange rides in the launch (one more workgroup per step)
                 xchg_fill_dev(xchg, &ca.x, K);
                 ca.x.xflag = c.ws.xflags;
+                ca.x.xsum = c.ws.xsum;
                 D3P_HIP_TRY(hipMemsetAsync(c.ws.xflags, 0, (size_t)D3P_STEP_BATCH * 32 * sizeof(uint32_t), c.s));
             }
             const dim3 grid((uint32_t)K * (c.g.blocks + 1u + (xchg ? 1u : 0u))), block(64 * D3P_CHAIN_W);
@@ -1289,7 +1293,7 @@ __global__ void __launch_bounds__(1024) k_xchg(XchgArgs a)
             __hip_atomic_store(slot + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    __threadfence_system();  // the rows are performed at their destinations before any flag moves
+    // system-scope stores are write-through: acknowledged (vmcnt) = performed at their destinations; only then the flags move
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid < a.world) {
@@ -1439,6 +1443,11 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     memset(&fa, 0, sizeof(fa));
     const size_t words = (size_t)D3P_ACC_R * D3P_ACC_COLS(c.P);
     fa.acc_prev = c.ws.acc + (size_t)((g + 2) % 3) * words;
+    fa.nrep = D3P_ACC_R;
+    if (chained && xchg) {  // the exchange workgroups left the world's sums in one row per step
+        fa.acc_prev = c.ws.xsum + (size_t)((g + 2) % 3) * D3P_ACC_COLS(c.P);
+        fa.nrep = 1;
+    }
     fa.noise = prev_noise;
     fa.slot = prev_slot;
     {

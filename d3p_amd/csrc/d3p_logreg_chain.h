@@ -44,6 +44,8 @@ struct XchgDev {
     size_t data_bytes;
     unsigned long long epoch0;         // exchanges done before this launch; step t of the launch is exchange epoch0 + t + 1
     uint32_t* xflag;                   // K flags, 32 words apart, zeroed before the launch
+    long long* xsum;                   // 3 x cols: the world's sums of step g in row g % 3 -- ONE row, which is all the next
+                                       // step's prologues read in a data-parallel run (not the 4 local replicas)
 };
 
 struct ChainArgs {
@@ -126,15 +128,30 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         if (okw[0] != 0u) return;
         const unsigned long long epoch = a.x.epoch0 + (unsigned long long)step_t + 1ull;
         const unsigned parity = (unsigned)(epoch & 1ull);
-        for (int c = tid; c < PA; c += 64 * W) {  // fold the replicas, deliver the row to every inbox
-            long long v = 0;
-            for (int r = 0; r < R; ++r) v += __hip_atomic_load(acc + (size_t)r * PA + c, __ATOMIC_RELAXED, D3P_AGENT);
-            for (int p = 0; p < a.x.world; ++p) {
-                long long* slot = reinterpret_cast<long long*>(a.x.peer[p]) + ((size_t)parity * a.x.world + a.x.rank) * PA;
-                __hip_atomic_store(slot + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        {  // fold the replicas (all loads of a thread in flight together), deliver the row to every inbox
+            constexpr int NC = (PA + 64 * W - 1) / (64 * W);
+            long long v[NC][R];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const int c = tid + i * 64 * W;
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[i][r] = c < PA ? __hip_atomic_load(acc + (size_t)r * PA + c, __ATOMIC_RELAXED, D3P_AGENT) : 0ll;
+            }
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const int c = tid + i * 64 * W;
+                long long s = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) s += v[i][r];
+                if (c < PA)
+                    for (int p = 0; p < a.x.world; ++p) {
+                        long long* slot = reinterpret_cast<long long*>(a.x.peer[p]) + ((size_t)parity * a.x.world + a.x.rank) * PA;
+                        __hip_atomic_store(slot + c, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
             }
         }
-        __threadfence_system();  // the rows are performed at their destinations before any flag moves
+        // system-scope stores are write-through: once they are acknowledged (vmcnt) the rows are at their destinations, and
+        // only then the flags move -- no cache write-back fence is needed, there is nothing dirty to write back
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid < a.x.world) {
@@ -157,11 +174,11 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         __syncthreads();
         if (okw[1] != 0u) return;  // aborted: the run stops here (status[0])
         const long long* inbox = reinterpret_cast<const long long*>(a.x.peer[a.x.rank]) + (size_t)parity * a.x.world * PA;
+        long long* xrow = a.x.xsum + (size_t)((a.g0 + step_t) % 3) * PA;
         for (int c = tid; c < PA; c += 64 * W) {
             long long tot = 0;
             for (int p = 0; p < a.x.world; ++p) tot += __hip_atomic_load(inbox + (size_t)p * PA + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(acc + c, tot, __ATOMIC_RELAXED, D3P_AGENT);
-            for (int r = 1; r < R; ++r) __hip_atomic_store(acc + (size_t)r * PA + c, 0ll, __ATOMIC_RELAXED, D3P_AGENT);
+            __hip_atomic_store(xrow + c, tot, __ATOMIC_RELAXED, D3P_AGENT);
         }
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
@@ -296,14 +313,17 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
                 __hip_atomic_store(acc_next + i, 0ll, __ATOMIC_RELAXED, D3P_AGENT);
         }
         // one latent: pending update of its two columns (e: auto_loc, D + e: auto_scale) and its derived LDS entries
+        // the sums of the previous step: the 4 local replicas, or (data-parallel) the ONE row the exchange workgroup left
+        const long long* sums = a.x.world > 0 ? a.x.xsum + (size_t)((g + 2) % 3) * PA : acc_prev;
+        const int nrep = a.x.world > 0 ? 1 : R;
         auto latent = [&](int e, float zl, float zs) {
             float xL, xS;
             if (apply_prev) {
                 long long aL[R], aS[R], n8[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    aL[r] = __hip_atomic_load(acc_prev + (size_t)r * PA + e, __ATOMIC_RELAXED, D3P_AGENT);
-                    aS[r] = __hip_atomic_load(acc_prev + (size_t)r * PA + D + e, __ATOMIC_RELAXED, D3P_AGENT);
+                    aL[r] = r < nrep ? __hip_atomic_load(sums + (size_t)r * PA + e, __ATOMIC_RELAXED, D3P_AGENT) : 0ll;
+                    aS[r] = r < nrep ? __hip_atomic_load(sums + (size_t)r * PA + D + e, __ATOMIC_RELAXED, D3P_AGENT) : 0ll;
                 }
                 xL = __hip_atomic_load(a.state[in][0] + e, __ATOMIC_RELAXED, D3P_AGENT);
                 xS = __hip_atomic_load(a.state[in][0] + D + e, __ATOMIC_RELAXED, D3P_AGENT);
@@ -312,7 +332,7 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
                 float vL = __hip_atomic_load(a.state[in][2] + e, __ATOMIC_RELAXED, D3P_AGENT);
                 float vS = __hip_atomic_load(a.state[in][2] + D + e, __ATOMIC_RELAXED, D3P_AGENT);
 #pragma unroll
-                for (int r = 0; r < R; ++r) n8[r] = __hip_atomic_load(acc_prev + (size_t)r * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT);
+                for (int r = 0; r < R; ++r) n8[r] = r < nrep ? __hip_atomic_load(sums + (size_t)r * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT) : 0ll;
                 long long nll = 0, sL = 0, sS = 0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) { nll += n8[r]; sL += aL[r]; sS += aS[r]; }
@@ -357,9 +377,9 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         if (apply_prev && bid == 0 && tid == 0) {
             long long lll = 0, lhh = 0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                lll += __hip_atomic_load(acc_prev + (size_t)r * PA + P, __ATOMIC_RELAXED, D3P_AGENT);
-                lhh += __hip_atomic_load(acc_prev + (size_t)r * PA + P + 2, __ATOMIC_RELAXED, D3P_AGENT);
+            for (int r = 0; r < nrep; ++r) {
+                lll += __hip_atomic_load(sums + (size_t)r * PA + P, __ATOMIC_RELAXED, D3P_AGENT);
+                lhh += __hip_atomic_load(sums + (size_t)r * PA + P + 2, __ATOMIC_RELAXED, D3P_AGENT);
             }
             if (a.losses && g > 0) a.losses[g - 1] = ((float)loss_join(lhh, lll) / (float)a.B) * a.obs_scale * factor;
             *a.adam_step = ps->adam_i + 1;
