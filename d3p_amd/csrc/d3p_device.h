@@ -316,4 +316,47 @@ __device__ __forceinline__ float wave_sum(float v)
 __device__ __forceinline__ float softplus_f(float t) { return fmaxf(t, 0.0f) + __logf(1.0f + __expf(-fabsf(t))); }
 __device__ __forceinline__ float sigmoid_f(float t) { return __builtin_amdgcn_rcpf(1.0f + __expf(-t)); }  // v_rcp_f32: 1 ulp
 
+// Row layout of a fixed-point accumulator replica: P gradient columns (scale 2^40 / C) | loss, fine part | example count |
+// loss, coarse part | spare.  The loss partial s of a workgroup (any magnitude a float can hold up to 2^78) is split exactly
+// as s = hi 2^27 + lo with hi = rint(s 2^-27) and the remainder lo kept at a resolution of 2^-24: both parts are integers that
+// sum exactly and order-independently like the gradient columns, and no model-dependent bound has to be guessed.
+#define D3P_ACC_COLS(P) ((P) + 4)
+#define D3P_LOSS_HI_UNIT 134217728.0   // 2^27
+#define D3P_LOSS_LO_SCALE 16777216.0   // 2^24
+
+// the two integer parts of a workgroup's loss partial; false when it is not finite or beyond 2^78
+__device__ __forceinline__ bool loss_split(float s, long long& hi, long long& lo)
+{
+    const double sd = (double)s;
+    const double h = rint(sd * (1.0 / D3P_LOSS_HI_UNIT));
+    hi = __double2ll_rn(h);
+    lo = __double2ll_rn((sd - h * D3P_LOSS_HI_UNIT) * D3P_LOSS_LO_SCALE);
+    return fabs(sd) < 3.0e23;
+}
+
+__device__ __forceinline__ double loss_join(long long hi, long long lo)
+{
+    return (double)hi * D3P_LOSS_HI_UNIT + (double)lo * (1.0 / D3P_LOSS_LO_SCALE);
+}
+
+// Position -> row of the Feistel permutation sampler (util.py:248-301): ten rounds over the (upper, lower) halves of the position,
+// cycle-walking until the value falls below the capacity.  rc: the 30 round constants (column 0 already forced odd).
+__device__ __forceinline__ uint32_t feistel_permute_dev(const uint32_t* rc, uint32_t capacity, int bits_lower,
+                                                        int bits_upper, uint32_t position)
+{
+    const uint32_t mask_lower = (1u << bits_lower) - 1u, mask_upper = (1u << bits_upper) - 1u;
+    uint32_t x = position;
+    do {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const uint32_t k0 = rc[3 * j], k1 = rc[3 * j + 1], k2 = rc[3 * j + 2];
+            const uint32_t xu = x >> bits_lower, xl = x & mask_lower;
+            const uint32_t yu = xl ^ ((((xu * k1) >> bits_upper) ^ k2) & mask_lower);
+            const uint32_t yl = (xu * k0) & mask_upper;
+            x = (yu << bits_upper) | yl;
+        }
+    } while (x >= capacity);
+    return x;
+}
+
 }  // namespace d3p

@@ -15,6 +15,8 @@
 
 namespace d3p {
 
+#define D3P_GMM_ACC_R 4  // replicas of the fixed-point accumulator (workgroup b adds to replica b % R)
+
 static inline size_t align_up_g(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 __device__ __forceinline__ double digamma_d(double x)
@@ -166,7 +168,9 @@ struct GmmArgs {
     float* px_loss;
     float* px_grads;
     float* latents_out;  // nullable: B x (K + 2 K d): g, eps, sigs of every example (tests)
-    float* partials;     // SUM mode: one row of P + 2 per wavefront: [sum_i c_i g_i | sum_i loss_i | n]
+    const uint32_t* skeys;  // nullable: B x 6 words [k_pis | k_mus | k_sigs] of every example, prepared once per batch of steps
+    long long* acc;      // SUM mode: D3P_GMM_ACC_R x D3P_ACC_COLS(P) fixed-point sums [sum_i c_i g_i | loss lo | n | loss hi | -]
+    double sg;           // fixed-point scale of the gradient columns (2^40 / clip)
     uint32_t B;
     uint32_t B_total, pos0;  // key derivation: example p is position pos0 + p of a global batch of B_total (= B, 0 on one device)
     int K, d;
@@ -174,15 +178,17 @@ struct GmmArgs {
 };
 
 // SUM = false: materialise px_loss / px_grads (stage API).  SUM = true: clip each example's gradient by its joint
-// L2 norm and accumulate (svi.py:310-348 fused into stage 1); every wavefront strides over the batch and leaves one
-// partial row, summed in fixed order by k_gmm_finalize.
+// L2 norm and accumulate (svi.py:310-348 fused into stage 1); every wavefront strides over the batch, the four wavefronts of
+// a workgroup are summed through LDS in fixed order and the workgroup adds its P + 3 partials to one of D3P_GMM_ACC_R
+// replicas of a 64-bit fixed-point accumulator (exact, hence independent of the order the workgroups arrive in).
+// The example index is wave-uniform (readfirstlane), so the key loads / derivations run on the scalar unit.
 // The unrolled component loop holds 4 KH DS values per lane; asking for 4 (2) resident waves per SIMD keeps the
 // scheduler from interleaving all threefry chains at once (which drove the small shapes to 256 VGPRs, occupancy 1).
-template <int KH, int DS, bool SUM, bool PAIRED>
-__global__ void __launch_bounds__(256, (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1)) k_gmm_px(GmmArgs a)
+template <int KH, int DS, bool SUM, bool PAIRED, int OCC = (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1)>
+__global__ void __launch_bounds__(256, OCC) k_gmm_px(GmmArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
+    const uint32_t gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const uint32_t total_waves = (gridDim.x * blockDim.x) >> 6;
     float accg[2 * KH * DS], acca = 0.f, loss_acc = 0.f, n_acc = 0.f;
     float locv[2 * KH * DS];  // this lane's entries of mus_loc, loaded once (slot layout as wv / muv below)
@@ -210,7 +216,12 @@ __global__ void __launch_bounds__(256, (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1
 
     // ---- keys of the guide's sample sites (numpyro.handlers.seed over pis, mus, sigs)
     uint32_t kp0, kp1, km0, km1, ks0, ks1;
-    gmm_site_keys(a.jax_key, a.B_total, a.pos0 + p, kp0, kp1, km0, km1, ks0, ks1);
+    if (a.skeys) {
+        const uint32_t* sk = a.skeys + (size_t)p * 6;
+        km0 = sk[2]; km1 = sk[3]; ks0 = sk[4]; ks1 = sk[5];
+    } else {
+        gmm_site_keys(a.jax_key, a.B_total, a.pos0 + p, kp0, kp1, km0, km1, ks0, ks1);
+    }
 
     // ---- Dirichlet part on lanes < K (float64)
     double alpha = 1.0, g = 0.0, gp = 0.0;
@@ -390,26 +401,50 @@ __global__ void __launch_bounds__(256, (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1
     }
     }  // examples of this wavefront
     if (SUM) {
+        extern __shared__ float red[];  // P + 2 floats: [gradient columns | loss | n], the workgroup's four wavefronts in turn
         const int K = a.K, d = a.d, Kh = (K + 1) >> 1, P = K + K * d;
-        float* out = a.partials + (size_t)gw * (P + 2);
-        if (lane < K) out[lane] = acca;
+        const int wave = threadIdx.x >> 6;
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+                if (lane < K) red[lane] = (w ? red[lane] : 0.f) + acca;
 #pragma unroll
-        for (int kk = 0; kk < KH; ++kk) {
-            if (kk < Kh) {
+                for (int kk = 0; kk < KH; ++kk) {
+                    if (kk < Kh) {
 #pragma unroll
-                for (int s = 0; s < DS; ++s) {
-                    const int dd = lane + 64 * s;
-                    if (dd < d) {
-                        out[K + kk * d + dd] = accg[kk * DS + s];
-                        if (kk + Kh < K) out[K + (kk + Kh) * d + dd] = accg[(KH + kk) * DS + s];
+                        for (int s = 0; s < DS; ++s) {
+                            const int dd = lane + 64 * s;
+                            if (dd < d) {
+                                const int c0 = K + kk * d + dd, c1 = K + (kk + Kh) * d + dd;
+                                red[c0] = (w ? red[c0] : 0.f) + accg[kk * DS + s];
+                                if (kk + Kh < K) red[c1] = (w ? red[c1] : 0.f) + accg[(KH + kk) * DS + s];
+                            }
+                        }
                     }
                 }
+                if (lane == 0) {
+                    red[P] = (w ? red[P] : 0.f) + loss_acc;
+                    red[P + 1] = (w ? red[P + 1] : 0.f) + n_acc;
+                }
             }
+            __syncthreads();
         }
-        if (lane == 0) {
-            out[P] = loss_acc;
-            out[P + 1] = n_acc;
+        long long* out = a.acc + (size_t)(blockIdx.x % D3P_GMM_ACC_R) * D3P_ACC_COLS(P);
+        const int tid = threadIdx.x;
+        bool bad = false;
+        for (int c = tid; c < P; c += 256) {
+            const float v = red[c];
+            bad |= !(fabsf(v) <= 3.0e38f);
+            if (v != 0.f) atomicAdd(reinterpret_cast<unsigned long long*>(out + c), (unsigned long long)__double2ll_rn((double)v * a.sg));
         }
+        if (tid < 3) {  // thread 0: loss, fine part; 1: example count; 2: loss, coarse part
+            long long hi, lo;
+            const bool ok = loss_split(red[P], hi, lo);
+            if (tid != 1) bad |= !ok;
+            const long long v = tid == 0 ? lo : tid == 1 ? (long long)red[P + 1] : hi;
+            if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(out + P + tid), (unsigned long long)v);
+        }
+        // a non-finite partial poisons the count column: the update that reads it yields NaN like the reference's float sums
+        if (bad) atomicAdd(reinterpret_cast<unsigned long long*>(out + P + 1), 1ull << 44);
     }
 }
 
@@ -481,86 +516,276 @@ __global__ void __launch_bounds__(256) k_gmm_eval_finish(const float* __restrict
     if (threadIdx.x == 0) *loss = lat[0] - (lik_scale / (float)B) * red[0];  // plate(N, B): likelihood scaled by N / B
 }
 
-// Replicated tail of the step: fixed-order column sums of the per-wavefront partial rows, mean over the padded batch
-// (svi.py:343-346), Gaussian mechanism with per-site noise (svi.py:365-375, :487-491), numpyro Adam (svi.py:379-393).
-// The partial rows (<= D3P_GMM_MAX_WAVES) are summed by 8 row groups per column.
-struct GmmFinalArgs {
-    const float* partials;
-    uint32_t n_rows;     // partial rows
-    uint32_t B;
-    int P;
-    const float* noise;  // P standard normals: site alpha_log (K) then site mus_loc (K d); unused when site_keys is given
-    const uint32_t* site_keys;  // nullable: split(perturbation_key, 2) -- the noise is then generated inside the kernel
-    int K;
-    float* params;
-    float* adam_m;
-    float* adam_v;
-    int32_t* step;
-    float* loss_out;     // nullable
-    float* grad_out;     // nullable
-    d3p_dpsvi_hyper h;
-    float obs_scale;
+// ------------------------------------------------------------------------------------------
+// The update loop of the mixture model (DPSVI.update, svi.py:395-434) as launches:
+//   per batch of <= gmm_step_batch(B) steps (nothing here depends on the parameters):
+//     k_gmm_prep_chain : the serial key chain -- (next, gradient, perturbation) = split(state_key, 3) per step
+//                        (svi.py:208-211, :413-414), 4-lane ChaCha block, one workgroup
+//     k_gmm_prep_steps : per step, in parallel: jax key of the gradient key (svi.py:259), the batchifier's fold_in and Feistel
+//                        rows (minibatch.py:226-237), the three site keys of every example (numpyro seed handler over pis,
+//                        mus, sigs -- one thread per example instead of once per lane of the example's wavefront), the
+//                        per-site keys split(perturbation_key, 2) and their P normals (svi.py:487-491), Adam's bias terms
+//   per step, two launches:
+//     k_gmm_head : applies the PREVIOUS step's update (mean, Gaussian mechanism, Adam; svi.py:343-393) from the fixed-point
+//                  sums -- every workgroup for the K Dirichlet columns it needs, the first ones for all columns into the other
+//                  state buffer --, zeroes this step's accumulator, packs the Dirichlet constants and draws the Gamma variates
+//                  with their implicit-reparametrisation derivatives, one thread per (example, component)
+//     k_gmm_px   : per-example gradients, clip, sum into the accumulator (above)
+//   k_gmm_flush : the update still pending after the last step, into the caller's arrays.
+// The optimiser state ping-pongs between the caller's arrays (even steps of a run) and a workspace copy (odd steps), so no
+// kernel reads a column another workgroup of the same launch writes.
+// ------------------------------------------------------------------------------------------
+struct GmmSlot {
+    uint32_t grad_key[16];
+    uint32_t pert_key[16];
+    int32_t adam_i;
+    uint32_t batch_i;
+    float bc1, bc2;  // 1 - b1^(i+1), 1 - b2^(i+1)
+    uint32_t pad[12];
 };
 
-// Everything of one update that is a function of the state alone, in ONE launch (each of these was a launch of ~5 us: three
-// key derivations, a one-block keystream, the parameter pack, the step counter and a 64-byte copy made up a third of the
-// 140 us step):  wave 0: [next | gradient | perturbation] = split(state_key, 3) (svi.py:208-211), the next state key written
-// straight into the other key slot, jax_key = convert_to_jax_rng_key(gradient_key) (svi.py:259), site keys =
-// split(perturbation_key, 2) (svi.py:491); wave 1: the double-precision pack of the Dirichlet parameters; the optimiser step
-// index is saved for k_gmm_finalize and advanced.
-struct GmmPreArgs {
-    const uint32_t* cur_key;
-    uint32_t* next_slot;
-    uint32_t* keys;        // workspace: split3 (48) | site keys (32) | folded batch key (16) | jax key (2)
-    const float* params;
-    int K;
-    double* pack;
-    int32_t* step;
-    int32_t* step_saved;
-    const uint32_t* batch_key;  // nullable (run loop): keys[80..95] = fold_in(batch_key, batch_index), minibatch.py:226-230
-    uint32_t batch_index;
-    int advance;                // 0: keys and pack only (the local-sums half of a data-parallel update leaves the state alone)
-};
-
-// (key derivations with the 4-lane ChaCha block of d3p_device.h: quad j of wave 0 derives one child, a third of the serial
-// instruction count of the one-lane block -- the launch is pure latency)
-__device__ __forceinline__ void gmm_store_child_quad(uint32_t* dst, const uint32_t* parent, int q, uint32_t a, uint32_t b)
+// steps prepared per launch pair: bounded so that the prepared rows / site keys (28 bytes per example and step) stay small
+static inline uint32_t gmm_step_batch(uint32_t B)
 {
-    dst[q] = parent[q];  // constants row
-    dst[4 + q] = a;
-    dst[8 + q] = b;
-    dst[12 + q] = 0u;
+    const uint32_t n = (1u << 20) / (B ? B : 1u);
+    return n < 1u ? 1u : n > 64u ? 64u : n;
 }
 
-__global__ void __launch_bounds__(128) k_gmm_pre(GmmPreArgs a)
+struct GmmChainArgs {
+    const uint32_t* in_key;
+    uint32_t* out_key;      // nullable: the key after the K steps
+    const int32_t* step;    // optimiser step counter of the state (not advanced here)
+    int32_t step_add;       // steps of this run already prepared
+    uint32_t batch0;        // batch index of the first step
+    GmmSlot* slots;
+    int K;
+};
+
+__global__ void __launch_bounds__(64) k_gmm_prep_chain(GmmChainArgs a)
 {
-    __shared__ uint32_t sk[3][16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int quad = lane >> 2, q = lane & 3;
-    if (wave == 0) {
-        // quads 0..2: split(state_key, 3)[quad]; quad 3: fold_in(batch_key, batch_index) (idle copy of the split otherwise)
-        const bool fold = quad == 3 && a.batch_key != nullptr;
-        const uint32_t* parent = fold ? a.batch_key : a.cur_key;
+    const int lane = threadIdx.x, q = lane & 3, child = (lane >> 2) < 3 ? (lane >> 2) : 0;
+    const int32_t adam0 = *a.step + a.step_add;
+    const uint32_t p0 = a.in_key[q];
+    uint32_t p1 = a.in_key[4 + q], p2 = a.in_key[8 + q], p3 = a.in_key[12 + q];
+    for (int t = 0; t < a.K; ++t) {
         uint32_t ka, kb;
-        derive_child_quad(parent, (quad < 3) ? (uint32_t)quad : 0u, fold ? D3P_TAG_FOLD : D3P_TAG_SPLIT, fold ? a.batch_index : 0u, ka, kb);
-        if (quad < 3) {
-            gmm_store_child_quad(a.keys + 16 * quad, parent, q, ka, kb);
-            gmm_store_child_quad(sk[quad], parent, q, ka, kb);
-            if (quad == 0 && a.advance) gmm_store_child_quad(a.next_slot, parent, q, ka, kb);
-        } else if (fold) {
-            gmm_store_child_quad(a.keys + 80, parent, q, ka, kb);
+        derive_child_quad_regs(p0, p1, p2, p3, (uint32_t)child, D3P_TAG_SPLIT, 0u, ka, kb);
+        if (lane >= 4 && lane < 12) {  // gradient key (child 1), perturbation key (child 2)
+            uint32_t* dst = lane < 8 ? a.slots[t].grad_key : a.slots[t].pert_key;
+            dst[q] = p0;
+            dst[4 + q] = ka;
+            dst[8 + q] = kb;
+            dst[12 + q] = 0u;
+        } else if (lane == 12) {
+            a.slots[t].adam_i = adam0 + t;
+            a.slots[t].batch_i = a.batch0 + (uint32_t)t;
         }
-        if (lane == 63 && a.advance) {
-            const int32_t i = *a.step;
-            *a.step_saved = i;
-            *a.step = i + 1;
+        p1 = __shfl(ka, q);  // the next state key is child 0 (lanes 0..3): every quad continues from it
+        p2 = __shfl(kb, q);
+        p3 = 0u;
+    }
+    if (lane < 4 && a.out_key) {
+        a.out_key[q] = p0;
+        a.out_key[4 + q] = p1;
+        a.out_key[8 + q] = p2;
+        a.out_key[12 + q] = p3;
+    }
+}
+
+struct GmmPrepArgs {
+    GmmSlot* slots;
+    const uint32_t* batch_key;  // nullable: the step's examples are the rows the caller passes
+    uint32_t* idx;              // K x B rows of the Feistel batches
+    uint32_t* skeys;            // K x B x 6
+    float* noise;               // K x P
+    uint32_t B, B_total, pos0;  // example p of this rank is position pos0 + p of a batch of B_total
+    uint32_t capacity;
+    int bits_lower, bits_upper;
+    int Kc, P;
+    float b1, b2;
+};
+
+// grid (ceil(B / 256) + 1, K): blockIdx.y = step of the batch; the last x-block of a step produces the step's noise and scalars
+__global__ void __launch_bounds__(256) k_gmm_prep_steps(GmmPrepArgs a)
+{
+    __shared__ uint32_t sh_key[2][16], sh_jax[2], sh_rc[32];
+    const int tid = threadIdx.x, t = blockIdx.y;
+    GmmSlot* slot = a.slots + t;
+    if (blockIdx.x + 1 < gridDim.x) {
+        if (tid == 0) {  // convert_to_jax_rng_key(gradient_key) (svi.py:259; random/__init__.py:155)
+            uint32_t k[16], o[16];
+            load_key(slot->grad_key, k);
+            keystream_block(k, 0u, o);
+            sh_jax[0] = o[0];
+            sh_jax[1] = o[1];
+        } else if (tid == 64 && a.batch_key) {  // fold_in(batchifier_state, i) (minibatch.py:230)
+            uint32_t k[16], c[16];
+            load_key(a.batch_key, k);
+            derive_child(k, 0u, slot->batch_i, D3P_TAG_FOLD, c);
+#pragma unroll
+            for (int w = 0; w < 16; ++w) sh_key[0][w] = c[w];
         }
+        __syncthreads();
+        if ((tid == 64 || tid == 128) && a.batch_key) {  // round constants (util.py:240-246)
+            const uint32_t b = tid == 64 ? 0u : 1u;
+            uint32_t k[16], o[16];
+#pragma unroll
+            for (int w = 0; w < 16; ++w) k[w] = sh_key[0][w];
+            keystream_block(k, b, o);
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                const int g = 16 * (int)b + w;
+                if (g < 30) sh_rc[g] = (g % 3 == 0) ? (o[w] | 1u) : o[w];
+            }
+        }
+        __syncthreads();
+        const uint32_t p = blockIdx.x * 256u + (uint32_t)tid;
+        if (p < a.B) {
+            if (a.batch_key) a.idx[(size_t)t * a.B + p] = feistel_permute_dev(sh_rc, a.capacity, a.bits_lower, a.bits_upper, p);
+            uint32_t* sk = a.skeys + ((size_t)t * a.B + p) * 6;
+            gmm_site_keys(sh_jax, a.B_total, a.pos0 + p, sk[0], sk[1], sk[2], sk[3], sk[4], sk[5]);
+        }
+        return;
+    }
+    // ---- per-site keys split(perturbation_key, 2) (svi.py:491), then normal(site_key, leaf shape) (d3p.random.normal: word e
+    // of the key's stream); site 0 = alpha_log (K), site 1 = mus_loc (K d)
+    if (tid < 2) {
+        uint32_t k[16], c[16];
+        load_key(slot->pert_key, k);
+        derive_child(k, (uint32_t)tid, 0u, D3P_TAG_SPLIT, c);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) sh_key[tid][w] = c[w];
+    } else if (tid == 64) {
+        const float i1 = (float)(slot->adam_i + 1);
+        slot->bc1 = 1.0f - powf(a.b1, i1);
+        slot->bc2 = 1.0f - powf(a.b2, i1);
+    }
+    __syncthreads();
+    const int n0 = a.Kc, n1 = a.P - a.Kc, nb0 = (n0 + 15) >> 4, nb1 = (n1 + 15) >> 4;
+    float* noise = a.noise + (size_t)t * a.P;
+    for (int blk = tid; blk < nb0 + nb1; blk += 256) {
+        const int site = blk >= nb0 ? 1 : 0, b = blk - (site ? nb0 : 0);
+        uint32_t key[16], o[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) key[w] = sh_key[site][w];
+        keystream_block(key, (uint32_t)b, o);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int e = 16 * b + w;
+            if (e < (site ? n1 : n0)) noise[(site ? n0 : 0) + e] = bits_to_normal(o[w]);
+        }
+    }
+}
+
+// The pending update of one step: the sums come from the fixed-point accumulator (this device's examples are the whole batch)
+// or as P + 2 floats (data-parallel apply: the all-reduced [clipped sums | loss | n] of d3p_dpvi_gmm_local_sums).
+struct GmmPending {
+    const long long* acc;   // D3P_GMM_ACC_R x D3P_ACC_COLS(P), or nullptr
+    const float* fsums;     // P + 2, or nullptr
+    const float* noise;     // P normals of that step
+    const GmmSlot* slot;
+    const float* in[3];     // params, adam_m, adam_v before the update
+    float* out[3];          // ... after (may alias `in` only in k_gmm_flush, where every column has one reader)
+    float* loss_out;        // nullable
+    float* grad_out;        // nullable
+    int P;
+    float Bf, dp_scale, clip, obs_scale, lr, b1, b2, adam_eps;
+    double inv_sg;
+};
+
+__device__ __forceinline__ float gmm_pending_count(const GmmPending& u)
+{
+    if (u.fsums) return u.fsums[u.P + 1];
+    long long n = 0;
+    for (int r = 0; r < D3P_GMM_ACC_R; ++r) n += u.acc[(size_t)r * D3P_ACC_COLS(u.P) + u.P + 1];
+    return n >= (1ll << 40) ? __builtin_nanf("") : (float)n;
+}
+
+__device__ __forceinline__ float gmm_pending_loss(const GmmPending& u, float factor)
+{
+    float ls;
+    if (u.fsums) {
+        ls = u.fsums[u.P];
     } else {
+        long long lo = 0, hi = 0;
+        for (int r = 0; r < D3P_GMM_ACC_R; ++r) {
+            lo += u.acc[(size_t)r * D3P_ACC_COLS(u.P) + u.P];
+            hi += u.acc[(size_t)r * D3P_ACC_COLS(u.P) + u.P + 2];
+        }
+        ls = (float)loss_join(hi, lo);
+    }
+    return __fmul_rn(__fmul_rn(__fdiv_rn(ls, u.Bf), u.obs_scale), factor);  // svi.py:342, :306
+}
+
+// mean over the padded batch (svi.py:343-346), Gaussian mechanism (svi.py:365-375), rescale (svi.py:377), numpyro Adam
+// (svi.py:379-393) for column c.  Every rounding is explicit (no fused multiply-add left to the compiler): the head kernel,
+// the flush kernel and every workgroup that recomputes a Dirichlet column must agree bit for bit.
+__device__ __forceinline__ float gmm_apply_column(const GmmPending& u, int c, float n, float factor, float& m, float& v, float& g)
+{
+    float tot;
+    if (u.fsums) {
+        tot = u.fsums[c];
+    } else {
+        long long s = 0;
+        for (int r = 0; r < D3P_GMM_ACC_R; ++r) s += u.acc[(size_t)r * D3P_ACC_COLS(u.P) + c];
+        tot = (float)((double)s * u.inv_sg);
+    }
+    const float noise_scale = __fmul_rn(u.dp_scale, __fdiv_rn(u.clip, n));
+    g = __fmul_rn(__fmul_rn(__fadd_rn(__fdiv_rn(tot, u.Bf), __fmul_rn(u.noise[c], noise_scale)), u.obs_scale), factor);
+    m = __fadd_rn(__fmul_rn(1.0f - u.b1, g), __fmul_rn(u.b1, u.in[1][c]));
+    v = __fadd_rn(__fmul_rn(__fmul_rn(1.0f - u.b2, g), g), __fmul_rn(u.b2, u.in[2][c]));
+    const float mhat = __fdiv_rn(m, u.slot->bc1), vhat = __fdiv_rn(v, u.slot->bc2);
+    return __fsub_rn(u.in[0][c], __fdiv_rn(__fmul_rn(u.lr, mhat), __fadd_rn(__fsqrt_rn(vhat), u.adam_eps)));
+}
+
+struct GmmHeadArgs {
+    GmmPending prev;          // valid when apply_prev
+    int apply_prev;
+    const float* params;      // parameters of THIS step when there is no pending update (= prev.out[0] otherwise)
+    long long* acc_zero;      // this step's accumulator
+    uint32_t acc_words;
+    double* pack;
+    double* dir;
+    const uint32_t* skeys;    // B x 6
+    const uint8_t* mask;      // nullable
+    uint32_t B;
+    int K;
+};
+
+__global__ void __launch_bounds__(256) k_gmm_head(GmmHeadArgs a)
+{
+    __shared__ double sh_alpha[32];
+    const int tid = threadIdx.x, K = a.K;
+    const uint32_t gtid = blockIdx.x * 256u + (uint32_t)tid, gsize = gridDim.x * 256u;
+    float n = 0.f, factor = 0.f;
+    if (a.apply_prev) {
+        n = gmm_pending_count(a.prev);
+        factor = (n == 0.f) ? 0.f : __fdiv_rn(a.prev.Bf, n);  // svi.py:305
+    }
+    if (tid < K) {
+        float x, m, v, g;
+        if (a.apply_prev) x = gmm_apply_column(a.prev, tid, n, factor, m, v, g);
+        else x = a.params[tid];
+        sh_alpha[tid] = exp((double)x);
+    }
+    if (a.apply_prev) {
+        for (uint32_t c = gtid; c < (uint32_t)a.prev.P; c += gsize) {
+            float m, v, g;
+            const float x = gmm_apply_column(a.prev, (int)c, n, factor, m, v, g);
+            a.prev.out[0][c] = x;
+            a.prev.out[1][c] = m;
+            a.prev.out[2][c] = v;
+        }
+        if (gtid == 0 && a.prev.loss_out) *a.prev.loss_out = gmm_pending_loss(a.prev, factor);
+    }
+    for (uint32_t i = gtid; i < a.acc_words; i += gsize) a.acc_zero[i] = 0;
+    __syncthreads();
+    if (blockIdx.x == 0 && tid >= 64 && tid < 128) {
         // pack (doubles): [alpha_k (K) | psi(alpha_k) (K) | psi(A0), A0, lgamma(A0) - sum lgamma(alpha_k) - lgamma(K)]
-        const int k = lane, K = a.K;
+        const int k = tid - 64;
         double alpha = 0.0, lg = 0.0;
         if (k < K) {
-            alpha = exp((double)a.params[k]);
+            alpha = sh_alpha[k];
             lg = lgamma(alpha);
             a.pack[k] = alpha;
             a.pack[K + k] = digamma_d(alpha);
@@ -576,134 +801,91 @@ __global__ void __launch_bounds__(128) k_gmm_pre(GmmPreArgs a)
             a.pack[2 * K + 2] = lgamma(A0) - LG - lgamma((double)K);
         }
     }
-    __syncthreads();
-    if (wave == 0) {
-        // quad 0: block 0 of the gradient key's stream -> jax key (random_bits(gradient_key, 32, (2,)));
-        // quads 1, 2: split(perturbation_key, 2)
-        const uint32_t* parent = quad == 0 ? sk[1] : sk[2];
-        uint32_t ka, kb;
-        derive_child_quad(parent, (quad == 1 || quad == 2) ? (uint32_t)(quad - 1) : 0u, quad == 0 ? 0u : D3P_TAG_SPLIT, 0u, ka, kb);
-        if (quad == 0 && q < 2) a.keys[96 + q] = ka;
-        if (quad == 1 || quad == 2) gmm_store_child_quad(a.keys + 48 + 16 * (quad - 1), parent, q, ka, kb);
+    // Dirichlet part, one thread per (example, component): dir[(p K + k) * 2 + {0, 1}] = {g, dg/dalpha}
+    const uint64_t total = (uint64_t)a.B * K;
+    for (uint64_t i = gtid; i < total; i += gsize) {
+        const uint32_t p = (uint32_t)(i / K), k = (uint32_t)(i % K);
+        if (a.mask && a.mask[p] == 0) continue;  // masked examples are skipped by k_gmm_px
+        const uint32_t* sk = a.skeys + (size_t)p * 6;
+        const double alpha = sh_alpha[k];
+        const double g = gamma_sample_d(sk[0], sk[1], k, alpha);
+        a.dir[2 * i] = g;
+        a.dir[2 * i + 1] = gamma_grad_d(alpha, g);
     }
 }
 
-// First reduction level: the per-wavefront partial rows are cut into D3P_GMM_CHUNKS chunks of consecutive rows; workgroup
-// (column tile of 64, chunk) sums its rows with 4 row subgroups and leaves one row per chunk.  Fixed order throughout.
-#define D3P_GMM_CHUNKS 64u
+struct GmmFlushArgs {
+    GmmPending prev;
+    int32_t* step;  // nullable: the state's optimiser step counter, set to the applied step's index + 1
+};
 
-__global__ void __launch_bounds__(256) k_gmm_reduce(const float* __restrict__ parts, uint32_t n_rows, int width,
-                                                    float* __restrict__ reduced)
+__global__ void __launch_bounds__(256) k_gmm_flush(GmmFlushArgs a)
 {
-    __shared__ float lds[256];
-    const int c = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + c;
-    const uint32_t per = (n_rows + D3P_GMM_CHUNKS - 1) / D3P_GMM_CHUNKS;
-    const uint32_t r0 = blockIdx.y * per, r1 = (r0 + per < n_rows) ? r0 + per : n_rows;
-    float s = 0.f;
-    if (col < width)
-        for (uint32_t r = r0 + sg; r < r1; r += 4) s += parts[(size_t)r * width + col];
-    lds[threadIdx.x] = s;
-    __syncthreads();
-    if (sg == 0 && col < width)
-        reduced[(size_t)blockIdx.y * width + col] = (lds[c] + lds[64 + c]) + (lds[128 + c] + lds[192 + c]);
-}
-
-// fixed-order sum of one column of the partial rows by the whole workgroup; every thread returns the total
-__device__ __forceinline__ float gmm_block_column_sum(const float* __restrict__ parts, uint32_t n_rows, size_t stride, int col,
-                                                      float* lds)
-{
-    float s = 0.f;
-    for (uint32_t r = threadIdx.x; r < n_rows; r += 256) s += parts[r * stride + col];
-    lds[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) lds[threadIdx.x] += lds[threadIdx.x + off];
-        __syncthreads();
+    const uint32_t gtid = blockIdx.x * 256u + threadIdx.x, gsize = gridDim.x * 256u;
+    const float n = gmm_pending_count(a.prev);
+    const float factor = (n == 0.f) ? 0.f : __fdiv_rn(a.prev.Bf, n);
+    for (uint32_t c = gtid; c < (uint32_t)a.prev.P; c += gsize) {
+        float m, v, g;
+        const float x = gmm_apply_column(a.prev, (int)c, n, factor, m, v, g);
+        a.prev.out[0][c] = x;
+        a.prev.out[1][c] = m;
+        a.prev.out[2][c] = v;
+        if (a.prev.grad_out) a.prev.grad_out[c] = g;
     }
-    const float tot = lds[0];
-    __syncthreads();
-    return tot;
-}
-
-// 32 columns per workgroup x 8 row groups; the row groups are combined through LDS in fixed order
-__global__ void __launch_bounds__(256) k_gmm_finalize(GmmFinalArgs a)
-{
-    __shared__ float lds[256];
-    const size_t stride = (size_t)a.P + 2;
-    const float n = gmm_block_column_sum(a.partials, a.n_rows, stride, a.P + 1, lds);
-    const float ls = gmm_block_column_sum(a.partials, a.n_rows, stride, a.P, lds);
-    const float Bf = (float)a.B;
-    const float factor = (n == 0.f) ? 0.f : Bf / n;  // svi.py:305
-    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int col = blockIdx.x * 32 + c;
-    float s = 0.f;
-    if (col < a.P)
-        for (uint32_t r = rg; r < a.n_rows; r += 8) s += a.partials[r * stride + col];
-    lds[rg * 32 + c] = s;
-    __syncthreads();
-    if (rg == 0 && col < a.P) {
-        float tot = 0.f;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) tot += lds[g * 32 + c];
-        float z;
-        if (a.site_keys) {  // normal(site_key, leaf shape)[e] generated here (d3p.random.normal: word e of the key's stream)
-            const int site = col >= a.K ? 1 : 0;
-            const uint32_t e = (uint32_t)(col - (site ? a.K : 0));
-            uint32_t key[16], o[16];
-            load_key(a.site_keys + 16 * site, key);
-            keystream_block(key, e >> 4, o);
-            uint32_t word = o[0];
-#pragma unroll
-            for (int w = 1; w < 16; ++w) word = ((e & 15u) == (uint32_t)w) ? o[w] : word;
-            z = bits_to_normal(word);
-        } else {
-            z = a.noise[col];
-        }
-        const float g = (tot / Bf + z * (a.h.dp_scale * (a.h.clip / n))) * a.obs_scale * factor;
-        if (a.grad_out) a.grad_out[col] = g;
-        const int i = *a.step;
-        float x = a.params[col], m = a.adam_m[col], v = a.adam_v[col];
-        m = (1.0f - a.h.b1) * g + a.h.b1 * m;
-        v = (1.0f - a.h.b2) * g * g + a.h.b2 * v;
-        const float mhat = m / (1.0f - powf(a.h.b1, (float)(i + 1)));
-        const float vhat = v / (1.0f - powf(a.h.b2, (float)(i + 1)));
-        a.params[col] = x - a.h.lr * mhat / (sqrtf(vhat) + a.h.adam_eps);
-        a.adam_m[col] = m;
-        a.adam_v[col] = v;
+    if (gtid == 0) {
+        if (a.prev.loss_out) *a.prev.loss_out = gmm_pending_loss(a.prev, factor);
+        if (a.step) *a.step = a.prev.slot->adam_i + 1;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.loss_out) *a.loss_out = (ls / Bf) * a.obs_scale * factor;  // svi.py:342, :306
 }
 
-#define D3P_GMM_MAX_WAVES 4096u
+// out[c] = this rank's [clipped sums | loss sum | n] as floats (d3p_dpvi_gmm_local_sums)
+__global__ void __launch_bounds__(256) k_gmm_fold(const long long* __restrict__ acc, int P, double inv_sg, float* __restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P + 2) return;
+    const size_t PA = D3P_ACC_COLS(P);
+    if (c < P) {
+        long long s = 0;
+        for (int r = 0; r < D3P_GMM_ACC_R; ++r) s += acc[r * PA + c];
+        out[c] = (float)((double)s * inv_sg);
+    } else if (c == P) {
+        long long lo = 0, hi = 0;
+        for (int r = 0; r < D3P_GMM_ACC_R; ++r) { lo += acc[r * PA + P]; hi += acc[r * PA + P + 2]; }
+        out[c] = (float)loss_join(hi, lo);
+    } else {
+        long long n = 0;
+        for (int r = 0; r < D3P_GMM_ACC_R; ++r) n += acc[r * PA + P + 1];
+        out[c] = n >= (1ll << 40) ? __builtin_nanf("") : (float)n;
+    }
+}
 
 struct GmmWorkspace {
     double* pack;
     double* dir;
-    float* partials;
-    float* reduced;   // D3P_GMM_CHUNKS x (P + 2)
-    float* noise;
-    float* meta;
-    uint32_t* keys;   // 3 x 16 (split of the state key) + 2 x 16 (site keys) + 16 (folded batch key) + jax key (2)
-    uint32_t* idx;    // B
-    int32_t* step_saved;  // optimiser step index of the update in flight (k_gmm_pre -> k_gmm_finalize)
+    long long* acc;       // 2 x D3P_GMM_ACC_R x D3P_ACC_COLS(P): steps alternate
+    float* pp[3];         // second buffer of the ping-ponged optimiser state
+    GmmSlot* slots[2];    // gmm_step_batch(B) slots, alternating by prepared batch (the head of a batch's first step still
+    float* noise[2];      // ... reads the last slot / noise row of the batch before)
+    uint32_t* idx;        // step_batch x B
+    uint32_t* skeys;      // step_batch x B x 6
+    uint32_t* chain_key;  // 16: key chain between prepared batches
 };
 
 static size_t gmm_carve(const d3p_gmm_model* m, uint32_t B, char* base, GmmWorkspace* ws)
 {
-    const size_t K = (size_t)m->K, P = K + K * (size_t)m->d;
+    const size_t K = (size_t)m->K, P = K + K * (size_t)m->d, SB = gmm_step_batch(B);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up_g(bytes, 256); return base ? base + o : nullptr; };
     char* q;
     q = take((2 * K + 3) * sizeof(double)); if (ws) ws->pack = (double*)q;
     q = take((size_t)B * K * 2 * sizeof(double)); if (ws) ws->dir = (double*)q;
-    q = take((size_t)D3P_GMM_MAX_WAVES * (P + 2) * sizeof(float)); if (ws) ws->partials = (float*)q;
-    q = take((size_t)D3P_GMM_CHUNKS * (P + 2) * sizeof(float)); if (ws) ws->reduced = (float*)q;
-    q = take(P * sizeof(float)); if (ws) ws->noise = (float*)q;
-    q = take(2 * sizeof(float)); if (ws) ws->meta = (float*)q;
-    q = take((6 * 16 + 2) * sizeof(uint32_t)); if (ws) ws->keys = (uint32_t*)q;
-    q = take((size_t)B * sizeof(uint32_t)); if (ws) ws->idx = (uint32_t*)q;
-    q = take(sizeof(int32_t)); if (ws) ws->step_saved = (int32_t*)q;
+    q = take(2 * (size_t)D3P_GMM_ACC_R * D3P_ACC_COLS(P) * sizeof(long long)); if (ws) ws->acc = (long long*)q;
+    for (int i = 0; i < 3; ++i) { q = take(P * sizeof(float)); if (ws) ws->pp[i] = (float*)q; }
+    for (int i = 0; i < 2; ++i) { q = take(SB * sizeof(GmmSlot)); if (ws) ws->slots[i] = (GmmSlot*)q; }
+    for (int i = 0; i < 2; ++i) { q = take(SB * P * sizeof(float)); if (ws) ws->noise[i] = (float*)q; }
+    q = take(SB * B * sizeof(uint32_t)); if (ws) ws->idx = (uint32_t*)q;
+    q = take(SB * B * 6 * sizeof(uint32_t)); if (ws) ws->skeys = (uint32_t*)q;
+    q = take(16 * sizeof(uint32_t)); if (ws) ws->chain_key = (uint32_t*)q;
     return off;
 }
 
@@ -740,17 +922,28 @@ static void gmm_fill(GmmArgs* a, const d3p_gmm_model* model, const float* params
     a->clip = clip;
 }
 
+// SUM: a resident grid (OCC workgroups per CU on 256 CUs, or fewer when the batch is small) strides over the examples
 template <bool SUM>
-static int gmm_launch_px(hipStream_t s, const d3p_gmm_model* model, const GmmArgs& a, uint32_t n_waves)
+static int gmm_launch_px(hipStream_t s, const d3p_gmm_model* model, const GmmArgs& a)
 {
-    const dim3 grid(cdiv((uint64_t)n_waves * 64, 256)), block(256);
     const int KH = (model->K + 1) / 2 <= 8 ? 8 : 16, DS = (model->d + 63) / 64;
+    int occ = KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1;
+    static const int occ_env = [] { const char* e = getenv("D3P_GMM_OCC"); return e ? atoi(e) : 0; }();  // developer switch
+    const bool tune = SUM && KH == 8 && DS == 1 && model->K % 2 == 0 && (occ_env == 2 || occ_env == 4);
+    if (tune) occ = occ_env;
+    const uint32_t P = (uint32_t)(model->K + model->K * model->d);
+    const uint32_t wgs_all = (uint32_t)cdiv((uint64_t)a.B, 4), wgs_res = 256u * (uint32_t)occ;
+    const dim3 grid(SUM ? (wgs_all < wgs_res ? wgs_all : wgs_res) : wgs_all), block(256);
+    const size_t lds = SUM ? (size_t)(P + 2) * sizeof(float) : 0;
 #define D3P_GMM_LAUNCH(KH_, DS_)                                                                 \
     if (model->K % 2 == 0)                                                                       \
-        hipLaunchKernelGGL((k_gmm_px<KH_, DS_, SUM, true>), grid, block, 0, s, a);               \
+        hipLaunchKernelGGL((k_gmm_px<KH_, DS_, SUM, true>), grid, block, lds, s, a);             \
     else                                                                                         \
-        hipLaunchKernelGGL((k_gmm_px<KH_, DS_, SUM, false>), grid, block, 0, s, a)
-    if (KH == 8) {
+        hipLaunchKernelGGL((k_gmm_px<KH_, DS_, SUM, false>), grid, block, lds, s, a)
+    if (tune) {
+        if (occ == 2) hipLaunchKernelGGL((k_gmm_px<8, 1, SUM, true, 2>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_gmm_px<8, 1, SUM, true, 4>), grid, block, lds, s, a);
+    } else if (KH == 8) {
         switch (DS) {
         case 1: D3P_GMM_LAUNCH(8, 1); break;
         case 2: D3P_GMM_LAUNCH(8, 2); break;
@@ -802,7 +995,7 @@ int d3p_gmm_px_grads(void* stream, const d3p_gmm_model* model, const float* para
     a.px_loss = px_loss_dev;
     a.px_grads = px_grads_dev;
     a.latents_out = latents_out_dev;
-    return gmm_launch_px<false>(s, model, a, B);
+    return gmm_launch_px<false>(s, model, a);
 }
 
 size_t d3p_gmm_evaluate_workspace(const d3p_gmm_model* model, uint32_t B)
@@ -841,90 +1034,126 @@ size_t d3p_dpvi_gmm_workspace(const d3p_gmm_model* model, uint32_t B)
     return gmm_carve(model, B, nullptr, nullptr);
 }
 
-// out[c] = sum over the D3P_GMM_CHUNKS reduced rows (fixed order): the rank's [clipped sums | loss sum | n]
-__global__ void __launch_bounds__(256) k_gmm_fold(const float* __restrict__ reduced, int width, float* __restrict__ out)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= width) return;
-    float s = 0.f;
-    for (uint32_t r = 0; r < D3P_GMM_CHUNKS; ++r) s += reduced[(size_t)r * width + c];
-    out[c] = s;
-}
-
-// One DPSVI.update (svi.py:395-434) for the mixture model, enqueued on `stream` without host synchronisation.
-// stage: 0 = the whole update; 1 = local sums only (keys and pack without touching the state, the rank's P + 2 sums folded
-// into sums_io); 2 = apply only (sums_io holds the reduced sums of the whole batch of B_total examples).  B_total / pos0:
-// the B examples are positions pos0 .. of a global batch of B_total (0 / 0: B is the whole batch).
-// batch_key_dev != nullptr (run loop): the batch of this step is get_batch(batch_index, batch_key) of
-// subsample_batchify_data (minibatch.py:226-237) over n_rows rows -- fold_in in the pre kernel, Feistel indices into ws.idx
-static int gmm_enqueue_update(hipStream_t s, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
-                              int slot, const float* X_dev, const uint32_t* idx_dev, const uint8_t* mask_dev, uint32_t B,
-                              float* loss_dev, float* grad_out_dev, const GmmWorkspace& ws,
-                              const uint32_t* batch_key_dev = nullptr, uint32_t batch_index = 0, uint32_t n_rows = 0,
-                              int stage = 0, uint32_t B_total = 0, uint32_t pos0 = 0, float* sums_io = nullptr)
+// num_steps consecutive DPSVI.update calls (svi.py:395-434) for the mixture model, enqueued on `stream` without host
+// synchronisation (launch structure: the block comment above k_gmm_prep_chain).
+// stage: 0 = whole updates; 1 = local sums of ONE step only (keys without touching the state, the rank's P + 2 sums folded
+// into sums_io); 2 = apply ONE step only (sums_io holds the reduced sums of the whole batch of B_total examples).
+// B_total / pos0: the B examples are positions pos0 .. of a global batch of B_total (0 / 0: B is the whole batch).
+// batch_key_dev != nullptr (run loop): the batch of step t is get_batch(first_batch + t, batch_key) of
+// subsample_batchify_data (minibatch.py:226-237) over n_rows rows; otherwise the B rows of X_dev are the batch.
+static int gmm_enqueue_steps(hipStream_t s, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                             const float* X_dev, const uint8_t* mask_dev, uint32_t B, uint32_t num_steps, float* losses_dev,
+                             float* grad_out_dev, const GmmWorkspace& ws, const uint32_t* batch_key_dev = nullptr,
+                             uint32_t first_batch = 0, uint32_t n_rows = 0, int stage = 0, uint32_t B_total = 0, uint32_t pos0 = 0,
+                             float* sums_io = nullptr)
 {
     int rc;
     const int K = model->K, P = K + K * model->d;
-    uint32_t* cur_key = state->rng_key + 16 * (slot & 1);
-    uint32_t* split3 = ws.keys;             // [next | gradient | perturbation]   (svi.py:208-211, :413-414)
-    uint32_t* site_keys = ws.keys + 48;     // split(perturbation_key, 2)          (svi.py:491)
-    uint32_t* jax_key = ws.keys + 96;       // convert_to_jax_rng_key(gradient_key) (svi.py:259)
-    {
-        GmmPreArgs pa;
-        pa.cur_key = cur_key;
-        pa.next_slot = state->rng_key + 16 * ((slot + 1) & 1);
-        pa.keys = ws.keys;
-        pa.params = state->params;
-        pa.K = K;
-        pa.pack = ws.pack;
-        pa.step = state->step;
-        pa.step_saved = ws.step_saved;
-        pa.batch_key = batch_key_dev;
-        pa.batch_index = batch_index;
-        pa.advance = stage == 1 ? 0 : 1;
-        hipLaunchKernelGGL(k_gmm_pre, dim3(1), dim3(128), 0, s, pa);
-    }
-    if (stage != 2) {
+    const uint32_t SB = gmm_step_batch(B);
+    const size_t acc_words = (size_t)D3P_GMM_ACC_R * D3P_ACC_COLS(P);
+    const double sg = 1099511627776.0 / (double)hyper->clip;  // 2^40 / C: |sum of clipped gradients| <= B C < 2^63 / sg
+    float* const caller[3] = {state->params, state->adam_m, state->adam_v};
+    auto buf = [&](uint32_t t, int i) { return (t & 1u) ? ws.pp[i] : caller[i]; };
+    auto pending = [&](uint32_t t, GmmPending* u) {  // the update of step t of this run
+        memset(u, 0, sizeof(*u));
+        u->acc = ws.acc + (size_t)(t & 1u) * acc_words;
+        u->noise = ws.noise[(t / SB) & 1u] + (size_t)(t % SB) * P;
+        u->slot = ws.slots[(t / SB) & 1u] + (t % SB);
+        for (int i = 0; i < 3; ++i) { u->in[i] = buf(t, i); u->out[i] = buf(t + 1, i); }
+        u->loss_out = losses_dev ? losses_dev + t : nullptr;
+        u->P = P;
+        u->Bf = (float)B;
+        u->dp_scale = hyper->dp_scale;
+        u->clip = hyper->clip;
+        u->obs_scale = 1.0f / model->inv_obs;
+        u->lr = hyper->lr;
+        u->b1 = hyper->b1;
+        u->b2 = hyper->b2;
+        u->adam_eps = hyper->adam_eps;
+        u->inv_sg = 1.0 / sg;
+    };
+    int bits_lower = 0, bits_upper = 0;
     if (batch_key_dev) {
-        if ((rc = d3p_feistel_sample(s, ws.keys + 80, n_rows, B, ws.idx))) return rc;
-        idx_dev = ws.idx;
+        uint32_t v = n_rows - 1, bits = 0;
+        while (v) { ++bits; v >>= 1; }  // util.py:230
+        bits_lower = (int)bits >> 1;
+        bits_upper = (int)bits - bits_lower;
     }
-    (void)split3;
-    hipLaunchKernelGGL(k_gmm_dirichlet, dim3(cdiv((uint64_t)B * K, 256)), dim3(256), 0, s, (const double*)ws.pack,
-                       (const uint32_t*)jax_key, B, B_total ? B_total : B, pos0, K, ws.dir);
-    GmmArgs a;
-    gmm_fill(&a, model, state->params, X_dev, idx_dev, mask_dev, B, jax_key, hyper->clip);
-    if (B_total) { a.B_total = B_total; a.pos0 = pos0; }
-    a.pack = ws.pack;
-    a.dir = ws.dir;
-    a.partials = ws.partials;
-    const uint32_t n_waves = B < D3P_GMM_MAX_WAVES ? B : D3P_GMM_MAX_WAVES;
-    if ((rc = gmm_launch_px<true>(s, model, a, n_waves))) return rc;
-    const uint32_t rows = cdiv((uint64_t)n_waves * 64, 256) * 4;  // every launched wavefront wrote a row
-    hipLaunchKernelGGL(k_gmm_reduce, dim3(cdiv(P + 2, 64), D3P_GMM_CHUNKS), dim3(256), 0, s, (const float*)ws.partials, rows, P + 2,
-                       ws.reduced);
+    const uint32_t* cur_key = state->rng_key + 16 * (state->key_slot & 1);
+    uint32_t* final_key = state->rng_key + 16 * ((state->key_slot + (int)num_steps) & 1);
+    for (uint32_t t0 = 0; t0 < num_steps; t0 += SB) {
+        const uint32_t Kb = num_steps - t0 < SB ? num_steps - t0 : SB, par = (t0 / SB) & 1u;
+        const bool last = t0 + Kb == num_steps;
+        GmmChainArgs ca;
+        ca.in_key = t0 == 0 ? cur_key : ws.chain_key;
+        ca.out_key = last ? (stage == 1 ? nullptr : final_key) : ws.chain_key;
+        ca.step = state->step;
+        ca.step_add = (int32_t)t0;
+        ca.batch0 = first_batch + t0;
+        ca.slots = ws.slots[par];
+        ca.K = (int)Kb;
+        hipLaunchKernelGGL(k_gmm_prep_chain, dim3(1), dim3(64), 0, s, ca);
+        GmmPrepArgs pa;
+        pa.slots = ws.slots[par];
+        pa.batch_key = batch_key_dev;
+        pa.idx = ws.idx;
+        pa.skeys = ws.skeys;
+        pa.noise = ws.noise[par];
+        pa.B = stage == 2 ? 0u : B;
+        pa.B_total = B_total ? B_total : B;
+        pa.pos0 = pos0;
+        pa.capacity = n_rows;
+        pa.bits_lower = bits_lower;
+        pa.bits_upper = bits_upper;
+        pa.Kc = K;
+        pa.P = P;
+        pa.b1 = hyper->b1;
+        pa.b2 = hyper->b2;
+        hipLaunchKernelGGL(k_gmm_prep_steps, dim3(cdiv(pa.B, 256) + 1, Kb), dim3(256), 0, s, pa);
+        if ((rc = check_launch("k_gmm_prep"))) return rc;
+        if (stage == 2) break;
+        for (uint32_t t = t0; t < t0 + Kb; ++t) {
+            const uint32_t* skeys = ws.skeys + (size_t)(t - t0) * B * 6;
+            GmmHeadArgs ha;
+            memset(&ha, 0, sizeof(ha));
+            ha.apply_prev = t > 0 ? 1 : 0;
+            if (t > 0) pending(t - 1, &ha.prev);
+            ha.params = buf(t, 0);
+            ha.acc_zero = ws.acc + (size_t)(t & 1u) * acc_words;
+            ha.acc_words = (uint32_t)acc_words;
+            ha.pack = ws.pack;
+            ha.dir = ws.dir;
+            ha.skeys = skeys;
+            ha.mask = mask_dev;
+            ha.B = B;
+            ha.K = K;
+            hipLaunchKernelGGL(k_gmm_head, dim3(cdiv((uint64_t)B * K, 256)), dim3(256), 0, s, ha);
+            GmmArgs a;
+            gmm_fill(&a, model, buf(t, 0), X_dev, batch_key_dev ? ws.idx + (size_t)(t - t0) * B : nullptr, mask_dev, B, nullptr,
+                     hyper->clip);
+            a.skeys = skeys;
+            a.pack = ws.pack;
+            a.dir = ws.dir;
+            a.acc = ha.acc_zero;
+            a.sg = sg;
+            if ((rc = gmm_launch_px<true>(s, model, a))) return rc;
+        }
     }
     if (stage == 1) {
-        hipLaunchKernelGGL(k_gmm_fold, dim3(cdiv(P + 2, 256)), dim3(256), 0, s, (const float*)ws.reduced, P + 2, sums_io);
+        hipLaunchKernelGGL(k_gmm_fold, dim3(cdiv(P + 2, 256)), dim3(256), 0, s, (const long long*)ws.acc, P, 1.0 / sg, sums_io);
         return check_launch("d3p_dpvi_gmm_local_sums");
     }
-    GmmFinalArgs f;
-    f.partials = stage == 2 ? sums_io : ws.reduced;
-    f.n_rows = stage == 2 ? 1u : D3P_GMM_CHUNKS;
-    f.B = (stage == 2 && B_total) ? B_total : B;
-    f.P = P;
-    f.noise = nullptr;
-    f.site_keys = site_keys;
-    f.K = K;
-    f.params = state->params;
-    f.adam_m = state->adam_m;
-    f.adam_v = state->adam_v;
-    f.step = ws.step_saved;
-    f.loss_out = loss_dev;
-    f.grad_out = grad_out_dev;
-    f.h = *hyper;
-    f.obs_scale = 1.0f / model->inv_obs;
-    hipLaunchKernelGGL(k_gmm_finalize, dim3(cdiv(P, 32)), dim3(256), 0, s, f);
+    GmmFlushArgs fa;
+    pending(num_steps - 1, &fa.prev);
+    for (int i = 0; i < 3; ++i) fa.prev.out[i] = caller[i];
+    fa.prev.grad_out = grad_out_dev;
+    if (stage == 2) {
+        fa.prev.acc = nullptr;
+        fa.prev.fsums = sums_io;
+        fa.prev.Bf = (float)(B_total ? B_total : B);
+    }
+    fa.step = state->step;
+    hipLaunchKernelGGL(k_gmm_flush, dim3(cdiv(P, 256)), dim3(256), 0, s, fa);
     return check_launch("d3p_dpvi_gmm_update");
 }
 
@@ -949,8 +1178,7 @@ int d3p_dpvi_gmm_update(void* stream, const d3p_gmm_model* model, const d3p_dpsv
     D3P_REQUIRE(X_dev, "d3p_dpvi_gmm_update: null data pointer");
     GmmWorkspace ws;
     gmm_carve(model, B, (char*)workspace_dev, &ws);
-    return gmm_enqueue_update((hipStream_t)stream, model, hyper, state, state->key_slot, X_dev, nullptr, mask_dev, B, loss_dev,
-                              grad_out_dev, ws);
+    return gmm_enqueue_steps((hipStream_t)stream, model, hyper, state, X_dev, mask_dev, B, 1, loss_dev, grad_out_dev, ws);
 }
 
 int d3p_dpvi_gmm_local_sums(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
@@ -962,8 +1190,8 @@ int d3p_dpvi_gmm_local_sums(void* stream, const d3p_gmm_model* model, const d3p_
     D3P_REQUIRE((uint64_t)pos0 + B_local <= B_total, "d3p_dpvi_gmm_local_sums: pos0 + B_local must not exceed B_total");
     GmmWorkspace ws;
     gmm_carve(model, B_local, (char*)workspace_dev, &ws);
-    return gmm_enqueue_update((hipStream_t)stream, model, hyper, state, state->key_slot, X_dev, nullptr, mask_dev, B_local, nullptr,
-                              nullptr, ws, nullptr, 0, 0, 1, B_total, pos0, sums_dev);
+    return gmm_enqueue_steps((hipStream_t)stream, model, hyper, state, X_dev, mask_dev, B_local, 1, nullptr, nullptr, ws, nullptr, 0, 0,
+                             1, B_total, pos0, sums_dev);
 }
 
 int d3p_dpvi_gmm_apply(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
@@ -974,8 +1202,8 @@ int d3p_dpvi_gmm_apply(void* stream, const d3p_gmm_model* model, const d3p_dpsvi
     D3P_REQUIRE(sums_dev && B_total >= 1, "d3p_dpvi_gmm_apply: null pointer or empty batch");
     GmmWorkspace ws;
     gmm_carve(model, B_local, (char*)workspace_dev, &ws);
-    return gmm_enqueue_update((hipStream_t)stream, model, hyper, state, state->key_slot, nullptr, nullptr, nullptr, B_local, loss_dev,
-                              grad_out_dev, ws, nullptr, 0, 0, 2, B_total, 0, sums_dev);
+    return gmm_enqueue_steps((hipStream_t)stream, model, hyper, state, nullptr, nullptr, B_local, 1, loss_dev, grad_out_dev, ws, nullptr, 0,
+                             0, 2, B_total, 0, sums_dev);
 }
 
 int d3p_dpvi_gmm_run(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
@@ -985,15 +1213,11 @@ int d3p_dpvi_gmm_run(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_h
     if (int rc = gmm_check_common(model, hyper, state, B, workspace_dev, workspace_bytes, "d3p_dpvi_gmm_run")) return rc;
     D3P_REQUIRE(X_dev && batch_key_dev, "d3p_dpvi_gmm_run: null pointer");
     D3P_REQUIRE(B <= n_rows, "d3p_dpvi_gmm_run: batch larger than the table");
+    if (num_steps == 0) return D3P_OK;
     GmmWorkspace ws;
     gmm_carve(model, B, (char*)workspace_dev, &ws);
-    for (uint32_t t = 0; t < num_steps; ++t) {
-        int rc;
-        if ((rc = gmm_enqueue_update((hipStream_t)stream, model, hyper, state, state->key_slot + (int)t, X_dev, nullptr, nullptr, B,
-                                     losses_dev ? losses_dev + t : nullptr, nullptr, ws, batch_key_dev, first_batch + t, n_rows)))
-            return rc;
-    }
-    return D3P_OK;
+    return gmm_enqueue_steps((hipStream_t)stream, model, hyper, state, X_dev, nullptr, B, num_steps, losses_dev, nullptr, ws, batch_key_dev,
+                             first_batch, n_rows);
 }
 
 }  // extern "C"
