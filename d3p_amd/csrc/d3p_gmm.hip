@@ -19,29 +19,39 @@ namespace d3p {
 
 static inline size_t align_up_g(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// 1 / x for finite positive normal x: v_rcp_f64 (about 2^-24) and two Newton steps, to within an ulp or two of the division --
+// a third of its instructions.  Used where a reciprocal sits inside a serial double-precision chain (the series below).
+__device__ __forceinline__ double rcp_d(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
 __device__ __forceinline__ double digamma_d(double x)
 {
     double r = 0.0;
-    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
-    const double f = 1.0 / (x * x);
+    while (x < 10.0) { r -= rcp_d(x); x += 1.0; }
+    const double f = rcp_d(x * x);
     return r + log(x) - 0.5 / x
            - f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760))))));
 }
 
-// d/dalpha of the Gamma(alpha, 1) quantile at fixed CDF value (see d3po_gamma_grad)
-__device__ __forceinline__ double gamma_grad_d(double alpha, double x)
+// d/dalpha of the Gamma(alpha, 1) quantile at fixed CDF value (see d3po_gamma_grad); psi1 = digamma(alpha + 1).
+// The series is cut where its terms fall below 1e-16 of the sum (the oracle goes on to 1e-18; the result is used in float32).
+__device__ __forceinline__ double gamma_grad_d(double alpha, double x, double psi1)
 {
     if (!(x > 0.0)) return 0.0;
     double t = 1.0, h = 0.0, S = 1.0, Sp = 0.0;
     for (int n = 1; n < 2000; ++n) {
-        const double rcp = 1.0 / (alpha + n);
+        const double rcp = rcp_d(alpha + n);
         t *= x * rcp;
         h += rcp;
         S += t;
         Sp -= t * h;
-        if (t < 1e-18 * S && n > x) break;
+        if (t < 1e-16 * S && n > x) break;
     }
-    return -(x / alpha) * (S * (log(x) - digamma_d(alpha + 1.0)) + Sp);
+    return -(x * rcp_d(alpha)) * (S * (log(x) - psi1) + Sp);
 }
 
 __device__ __forceinline__ double open_unit_d(uint32_t b) { return ((double)b + 0.5) * (1.0 / 4294967296.0); }
@@ -138,28 +148,73 @@ __device__ __forceinline__ void gmm_site_keys(const uint32_t* jax_key, uint32_t 
     tf_split2(r0, r1, t0, t1, ks0, ks1);
 }
 
-// Dirichlet part, one THREAD per (example, component): Gamma(alpha_k) draw and its derivative wrt alpha_k.
-// dir[(p K + k) * 2 + {0, 1}] = {g, dg/dalpha}
-// (data-parallel: the B examples are positions pos0 .. pos0 + B - 1 of a global batch of B_total; the keys of an example are
-// functions of its GLOBAL position)
-__global__ void __launch_bounds__(256) k_gmm_dirichlet(const double* __restrict__ pack, const uint32_t* __restrict__ jax_key,
-                                                       uint32_t B, uint32_t B_total, uint32_t pos0, int K, double* __restrict__ dir)
+// Dirichlet part of a step, one THREAD per (example, component), whole examples per workgroup (256 / K of them): the
+// Gamma(alpha_k) draw g_k (Marsaglia-Tsang), its derivative wrt alpha_k at fixed CDF value, and -- after normalising over the
+// example's components through LDS -- everything of the example's gradient that depends on the Dirichlet site alone:
+//   dir[(p K + k) * 4 + {0, 1, 2, 3}] = { log pis_k, gs_k = g'_k / S, (alpha_k - 1) / pis_k, 1 / pis_k },   S = sum_k g_k
+//   lqs[p] = sum_k (alpha_k - 1) log pis_k        gdraw[p K + k] = g_k (float; nullable, for latents_out)
+// k_gmm_px finishes d/d alpha_log_k from these and the responsibilities with a dozen double operations on K lanes.
+// sh: 2 x 256 doubles of LDS.  All 256 threads of the workgroup call it (p_ok: this thread has an example).
+#define D3P_GMM_DIR_ROW 4
+__device__ __forceinline__ void gmm_dirichlet_thread(bool p_ok, uint32_t p, uint32_t k, int K, uint32_t kp0, uint32_t kp1, double alpha,
+                                                     double psi1, double* sh, double* __restrict__ dir, double* __restrict__ lqs,
+                                                     float* __restrict__ gdraw)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)B * K) return;
-    const uint32_t p = (uint32_t)(i / K), k = (uint32_t)(i % K);
-    uint32_t kp0, kp1, km0, km1, ks0, ks1;
-    gmm_site_keys(jax_key, B_total, pos0 + p, kp0, kp1, km0, km1, ks0, ks1);
-    const double alpha = pack[k];
-    const double g = gamma_sample_d(kp0, kp1, k, alpha);
-    dir[2 * i] = g;
-    dir[2 * i + 1] = gamma_grad_d(alpha, g);
+    const int tid = threadIdx.x, e0 = tid - (int)k;  // first thread of this example
+    double g = 1.0, gp = 0.0;
+    if (p_ok) {
+        g = gamma_sample_d(kp0, kp1, k, alpha);
+        gp = gamma_grad_d(alpha, g, psi1);
+    }
+    sh[tid] = g;
+    __syncthreads();
+    double S = 0.0;
+    if (p_ok)
+        for (int j = 0; j < K; ++j) S += sh[e0 + j];  // fixed order
+    const double rS = p_ok ? 1.0 / S : 1.0;
+    const double pis = g * rS, logpis = log(pis), rp = 1.0 / pis;
+    sh[256 + tid] = (alpha - 1.0) * logpis;
+    __syncthreads();
+    if (!p_ok) return;
+    double* row = dir + ((size_t)p * K + k) * D3P_GMM_DIR_ROW;
+    row[0] = logpis;
+    row[1] = gp * rS;
+    row[2] = (alpha - 1.0) * rp;
+    row[3] = rp;
+    if (gdraw) gdraw[(size_t)p * K + k] = (float)g;
+    if (k == 0) {
+        double q = 0.0;
+        for (int j = 0; j < K; ++j) q += sh[256 + e0 + j];
+        lqs[p] = q;
+    }
+}
+
+// stage API (d3p_gmm_px_grads): keys derived here; data-parallel: the B examples are positions pos0 .. pos0 + B - 1 of a global
+// batch of B_total, the keys of an example are functions of its GLOBAL position
+__global__ void __launch_bounds__(256) k_gmm_dirichlet(const double* __restrict__ pack, const uint32_t* __restrict__ jax_key,
+                                                       uint32_t B, uint32_t B_total, uint32_t pos0, int K, double* __restrict__ dir,
+                                                       double* __restrict__ lqs, float* __restrict__ gdraw)
+{
+    __shared__ double sh[512];
+    const uint32_t epw = 256u / (uint32_t)K, pl = threadIdx.x / (uint32_t)K, k = threadIdx.x % (uint32_t)K;
+    const uint32_t p = blockIdx.x * epw + pl;
+    const bool p_ok = pl < epw && p < B;
+    uint32_t kp0 = 0, kp1 = 0, km0, km1, ks0, ks1;
+    double alpha = 1.0, psi1 = 0.0;
+    if (p_ok) {
+        gmm_site_keys(jax_key, B_total, pos0 + p, kp0, kp1, km0, km1, ks0, ks1);
+        alpha = pack[k];
+        psi1 = pack[K + k] + 1.0 / alpha;  // psi(alpha + 1) = psi(alpha) + 1 / alpha
+    }
+    gmm_dirichlet_thread(p_ok, p, k, K, kp0, kp1, alpha, psi1, sh, dir, lqs, gdraw);
 }
 
 struct GmmArgs {
     const float* params;
     const double* pack;
-    const double* dir;       // B x K x 2 from k_gmm_dirichlet
+    const double* dir;       // B x K x D3P_GMM_DIR_ROW and
+    const double* lqs;       // B from gmm_dirichlet_thread
+    const float* gdraw;      // B x K Gamma draws (latents_out only)
     const float* X;
     const uint32_t* idx;     // nullable: row of example p is X[idx[p]] (minibatch of a resident table)
     const uint8_t* mask;
@@ -184,32 +239,38 @@ struct GmmArgs {
 // The example index is wave-uniform (readfirstlane), so the key loads / derivations run on the scalar unit.
 // The unrolled component loop holds 4 KH DS values per lane; asking for 4 (2) resident waves per SIMD keeps the
 // scheduler from interleaving all threefry chains at once (which drove the small shapes to 256 VGPRs, occupancy 1).
-template <int KH, int DS, bool SUM, bool PAIRED, int OCC = (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1)>
+// FULLT: K == 2 KH and d == 64 DS exactly (BASELINE config 3: K = 16, d = 64) -- every lane / slot predicate is true and folds
+// away (about a tenth of the instructions of the component loop).
+template <int KH, int DS, bool SUM, bool PAIRED, bool FULLT = false, int OCC = (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1)>
 __global__ void __launch_bounds__(256, OCC) k_gmm_px(GmmArgs a)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const uint32_t total_waves = (gridDim.x * blockDim.x) >> 6;
+    const int K = FULLT ? 2 * KH : a.K, d = FULLT ? 64 * DS : a.d, Kh = FULLT ? KH : (K + 1) >> 1, P = K + K * d;
     float accg[2 * KH * DS], acca = 0.f, loss_acc = 0.f, n_acc = 0.f;
     float locv[2 * KH * DS];  // this lane's entries of mus_loc, loaded once (slot layout as wv / muv below)
-    {
-        const int K = a.K, d = a.d, Kh = (K + 1) >> 1;
 #pragma unroll
-        for (int kk = 0; kk < KH; ++kk)
+    for (int kk = 0; kk < KH; ++kk)
 #pragma unroll
-            for (int s = 0; s < DS; ++s) {
-                const int dd = lane + 64 * s;
-                const bool ok0 = kk < Kh && dd < d, ok1 = ok0 && kk + Kh < K;
-                accg[kk * DS + s] = accg[(KH + kk) * DS + s] = 0.f;
-                locv[kk * DS + s] = ok0 ? a.params[K + kk * d + dd] : 0.f;
-                locv[(KH + kk) * DS + s] = ok1 ? a.params[K + (kk + Kh) * d + dd] : 0.f;
-            }
+        for (int s = 0; s < DS; ++s) {
+            const int dd = lane + 64 * s;
+            const bool ok0 = FULLT || (kk < Kh && dd < d), ok1 = FULLT || (ok0 && kk + Kh < K);
+            accg[kk * DS + s] = accg[(KH + kk) * DS + s] = 0.f;
+            locv[kk * DS + s] = ok0 ? a.params[K + kk * d + dd] : 0.f;
+            locv[(KH + kk) * DS + s] = ok1 ? a.params[K + (kk + Kh) * d + dd] : 0.f;
+        }
+    // Dirichlet constants of this lane's component (lanes < K)
+    double alpha = 1.0, psi_d = 0.0;  // psi(A0) - psi(alpha_k)
+    if (lane < K) {
+        alpha = a.pack[lane];
+        psi_d = a.pack[2 * K] - a.pack[K + lane];
     }
+    const double A0mK = a.pack[2 * K + 1] - (double)K, lq0 = a.pack[2 * K + 2];
     for (uint32_t p = gw; p < a.B; p += total_waves) {
     // components are handled in pairs (kk, kk + Kh), Kh = ceil(K / 2); for even K the pair shares its threefry calls
     // (words j and j + K d / 2 of jax's iota layout), for odd K every entry takes its own call
-    const int K = a.K, d = a.d, Kh = (K + 1) >> 1, P = K + K * d;
-    const uint32_t n_lat = (uint32_t)(K * d), half = n_lat >> 1;
+    const uint32_t n_lat = (uint32_t)(K * d);
     const float live = (a.mask ? a.mask[p] != 0 : true) ? 1.0f : 0.0f;
     if (SUM && live == 0.0f) continue;  // masked examples contribute nothing (svi.py:281)
     const size_t row = a.idx ? a.idx[p] : p;
@@ -223,17 +284,15 @@ __global__ void __launch_bounds__(256, OCC) k_gmm_px(GmmArgs a)
         gmm_site_keys(a.jax_key, a.B_total, a.pos0 + p, kp0, kp1, km0, km1, ks0, ks1);
     }
 
-    // ---- Dirichlet part on lanes < K (float64)
-    double alpha = 1.0, g = 0.0, gp = 0.0;
+    // ---- Dirichlet part (lanes < K, float64): finished per (example, component) by gmm_dirichlet_thread
+    double logpis_d = 0.0, gs = 0.0, apm = 0.0, rp = 1.0;
     if (lane < K) {
-        alpha = a.pack[lane];
-        g = a.dir[((size_t)p * K + lane) * 2];
-        gp = a.dir[((size_t)p * K + lane) * 2 + 1];
+        const double* drow = a.dir + ((size_t)p * K + lane) * D3P_GMM_DIR_ROW;
+        logpis_d = drow[0];
+        gs = drow[1];
+        apm = drow[2];
+        rp = drow[3];
     }
-    double S = 0.0;
-    for (int k = 0; k < K; ++k) S += readlane_d(g, k);
-    const double pis = lane < K ? g / S : 1.0;
-    const double logpis_d = log(pis);
     const float logpis = (float)logpis_d;
 
     // ---- mus, sigs and the per-component log-densities (lanes <-> feature dimensions)
@@ -241,7 +300,7 @@ __global__ void __launch_bounds__(256, OCC) k_gmm_px(GmmArgs a)
 #pragma unroll
     for (int s = 0; s < DS; ++s) {
         const int dd = lane + 64 * s;
-        xs[s] = dd < d ? a.X[(size_t)row * d + dd] : 0.f;
+        xs[s] = (FULLT || dd < d) ? a.X[(size_t)row * d + dd] : 0.f;
     }
     float wv[2 * KH * DS], muv[2 * KH * DS];
     float acomp[2 * KH];
@@ -250,13 +309,13 @@ __global__ void __launch_bounds__(256, OCC) k_gmm_px(GmmArgs a)
 #pragma unroll
     for (int kk = 0; kk < KH; ++kk) {
         float ll0 = 0.f, ll1 = 0.f;
-        if (kk < Kh) {
-            const bool has1 = kk + Kh < K;
+        if (FULLT || kk < Kh) {
+            const bool has1 = FULLT || kk + Kh < K;
 #pragma unroll
             for (int s = 0; s < DS; ++s) {
                 __builtin_amdgcn_sched_barrier(0);
                 const int dd = lane + 64 * s;
-                const bool ok0 = dd < d, ok1 = ok0 && has1;
+                const bool ok0 = FULLT || dd < d, ok1 = ok0 && has1;
                 const uint32_t j0 = (uint32_t)(kk * d + dd), j1 = (uint32_t)((kk + Kh) * d + dd);
                 uint32_t b0, b1, u0, u1;
                 if (PAIRED) {  // K even: j1 == j0 + half
@@ -303,14 +362,14 @@ __global__ void __launch_bounds__(256, OCC) k_gmm_px(GmmArgs a)
         __builtin_amdgcn_sched_barrier(0);  // one component pair at a time: keeps the live threefry chains (and VGPRs) bounded
     }
     lmu = wave_sum(lmu);
-    if (lat && lane < K) lat[lane] = (float)g;
+    if (lat && lane < K) lat[lane] = a.gdraw[(size_t)p * K + lane];
 
     // ---- mixture: a_k = log pis_k + ll_k, responsibilities r_k, loglik = logsumexp_k a_k  (gmm.py:71-86)
     float best = -INFINITY;
 #pragma unroll
     for (int kk = 0; kk < KH; ++kk) {
-        if (kk < Kh) {
-            const bool has1 = kk + Kh < K;
+        if (FULLT || kk < Kh) {
+            const bool has1 = FULLT || kk + Kh < K;
             acomp[kk] += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(logpis), kk));
             acomp[KH + kk] = has1 ? acomp[KH + kk] + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(logpis), has1 ? kk + Kh : 0))
                                   : -INFINITY;
@@ -320,7 +379,7 @@ __global__ void __launch_bounds__(256, OCC) k_gmm_px(GmmArgs a)
     float se = 0.f;
 #pragma unroll
     for (int kk = 0; kk < KH; ++kk) {
-        if (kk < Kh) {
+        if (FULLT || kk < Kh) {
             acomp[kk] = __expf(acomp[kk] - best);
             acomp[KH + kk] = __expf(acomp[KH + kk] - best);  // exp(-inf) = 0 for the missing partner of an odd K
             se += acomp[kk] + acomp[KH + kk];
@@ -335,15 +394,15 @@ __global__ void __launch_bounds__(256, OCC) k_gmm_px(GmmArgs a)
     float n2 = 0.f;
 #pragma unroll
     for (int kk = 0; kk < KH; ++kk) {
-        if (kk < Kh) {
-            const bool has1 = kk + Kh < K;
+        if (FULLT || kk < Kh) {
+            const bool has1 = FULLT || kk + Kh < K;
             const float ra = acomp[kk] * inv_se, rb = acomp[KH + kk] * inv_se;
             if (lane == kk) my_r = ra;
             if (lane == kk + Kh) my_r = rb;
 #pragma unroll
             for (int s = 0; s < DS; ++s) {
                 const int dd = lane + 64 * s;
-                if (dd < d) {
+                if (FULLT || dd < d) {
                     const uint32_t j0 = (uint32_t)(kk * d + dd), j1 = (uint32_t)((kk + Kh) * d + dd);
                     const int i0 = kk * DS + s, i1 = (KH + kk) * DS + s;
                     const float g0 = a.inv_obs * __fmaf_rn(-a.lik_scale * ra, wv[i0], a.inv_ps2 * muv[i0]);
@@ -365,27 +424,21 @@ __global__ void __launch_bounds__(256, OCC) k_gmm_px(GmmArgs a)
     }
 
     // ---- gradient wrt alpha_log (lanes < K, float64) and the Dirichlet part of log q - log p
-    const double A0 = a.pack[2 * K + 1];
-    double lq_term = 0.0;
     float ga = 0.f;
     if (lane < K) {
-        const double psi0 = a.pack[2 * K], psik = a.pack[K + lane];
-        const double gs = gp / S;
-        const double dq = psi0 - psik + logpis_d + gs * ((alpha - 1.0) / pis - (A0 - (double)K));
-        const double dl = gs * ((double)my_r / pis - 1.0);
+        const double dq = psi_d + logpis_d + gs * (apm - A0mK);
+        const double dl = gs * ((double)my_r * rp - 1.0);
         ga = (float)(alpha * (double)a.inv_obs * (dq - (double)a.lik_scale * dl));
         if (!SUM) gr[lane] = ga * live;
-        lq_term = (alpha - 1.0) * logpis_d;
     }
-    double lq = a.pack[2 * K + 2];
-    for (int k = 0; k < K; ++k) lq += readlane_d(lq_term, k);
+    const double lq = lq0 + a.lqs[p];
     const float L = a.inv_obs * (((float)lq + lmu) - a.lik_scale * loglik);
     if (SUM) {
         n2 = wave_sum(__fmaf_rn(ga, ga, n2));
         const float cf = 1.0f / fmaxf(1.0f, sqrtf(n2) / a.clip);  // svi.py:121-122
 #pragma unroll
         for (int kk = 0; kk < KH; ++kk) {
-            if (kk < Kh) {
+            if (FULLT || kk < Kh) {
 #pragma unroll
                 for (int s = 0; s < DS; ++s) {
                     accg[kk * DS + s] = __fmaf_rn(cf, wv[kk * DS + s], accg[kk * DS + s]);
@@ -402,21 +455,20 @@ __global__ void __launch_bounds__(256, OCC) k_gmm_px(GmmArgs a)
     }  // examples of this wavefront
     if (SUM) {
         extern __shared__ float red[];  // P + 2 floats: [gradient columns | loss | n], the workgroup's four wavefronts in turn
-        const int K = a.K, d = a.d, Kh = (K + 1) >> 1, P = K + K * d;
         const int wave = threadIdx.x >> 6;
         for (int w = 0; w < 4; ++w) {
             if (wave == w) {
                 if (lane < K) red[lane] = (w ? red[lane] : 0.f) + acca;
 #pragma unroll
                 for (int kk = 0; kk < KH; ++kk) {
-                    if (kk < Kh) {
+                    if (FULLT || kk < Kh) {
 #pragma unroll
                         for (int s = 0; s < DS; ++s) {
                             const int dd = lane + 64 * s;
-                            if (dd < d) {
+                            if (FULLT || dd < d) {
                                 const int c0 = K + kk * d + dd, c1 = K + (kk + Kh) * d + dd;
                                 red[c0] = (w ? red[c0] : 0.f) + accg[kk * DS + s];
-                                if (kk + Kh < K) red[c1] = (w ? red[c1] : 0.f) + accg[(KH + kk) * DS + s];
+                                if (FULLT || kk + Kh < K) red[c1] = (w ? red[c1] : 0.f) + accg[(KH + kk) * DS + s];
                             }
                         }
                     }
@@ -746,6 +798,7 @@ struct GmmHeadArgs {
     uint32_t acc_words;
     double* pack;
     double* dir;
+    double* lqs;
     const uint32_t* skeys;    // B x 6
     const uint8_t* mask;      // nullable
     uint32_t B;
@@ -754,7 +807,7 @@ struct GmmHeadArgs {
 
 __global__ void __launch_bounds__(256) k_gmm_head(GmmHeadArgs a)
 {
-    __shared__ double sh_alpha[32];
+    __shared__ double sh_alpha[32], sh_psi1[32], sh_dir[512];
     const int tid = threadIdx.x, K = a.K;
     const uint32_t gtid = blockIdx.x * 256u + (uint32_t)tid, gsize = gridDim.x * 256u;
     float n = 0.f, factor = 0.f;
@@ -801,16 +854,19 @@ __global__ void __launch_bounds__(256) k_gmm_head(GmmHeadArgs a)
             a.pack[2 * K + 2] = lgamma(A0) - LG - lgamma((double)K);
         }
     }
-    // Dirichlet part, one thread per (example, component): dir[(p K + k) * 2 + {0, 1}] = {g, dg/dalpha}
-    const uint64_t total = (uint64_t)a.B * K;
-    for (uint64_t i = gtid; i < total; i += gsize) {
-        const uint32_t p = (uint32_t)(i / K), k = (uint32_t)(i % K);
-        if (a.mask && a.mask[p] == 0) continue;  // masked examples are skipped by k_gmm_px
-        const uint32_t* sk = a.skeys + (size_t)p * 6;
-        const double alpha = sh_alpha[k];
-        const double g = gamma_sample_d(sk[0], sk[1], k, alpha);
-        a.dir[2 * i] = g;
-        a.dir[2 * i + 1] = gamma_grad_d(alpha, g);
+    // Dirichlet part: whole examples per workgroup (gmm_dirichlet_thread)
+    if (tid < K) sh_psi1[tid] = digamma_d(sh_alpha[tid] + 1.0);
+    __syncthreads();
+    const uint32_t epw = 256u / (uint32_t)K, pl = (uint32_t)tid / (uint32_t)K, k = (uint32_t)tid % (uint32_t)K;
+    for (uint32_t p0 = blockIdx.x * epw; p0 < a.B; p0 += gridDim.x * epw) {  // (one pass: the grid covers the batch)
+        const uint32_t p = p0 + pl;
+        const bool p_ok = pl < epw && p < a.B && !(a.mask && a.mask[p] == 0);  // masked examples are skipped by k_gmm_px
+        uint32_t kp0 = 0, kp1 = 0;
+        if (p_ok) {
+            kp0 = a.skeys[(size_t)p * 6];
+            kp1 = a.skeys[(size_t)p * 6 + 1];
+        }
+        gmm_dirichlet_thread(p_ok, p, k, K, kp0, kp1, sh_alpha[k], sh_psi1[k], sh_dir, a.dir, a.lqs, nullptr);
     }
 }
 
@@ -861,7 +917,8 @@ __global__ void __launch_bounds__(256) k_gmm_fold(const long long* __restrict__ 
 
 struct GmmWorkspace {
     double* pack;
-    double* dir;
+    double* dir;          // B x K x D3P_GMM_DIR_ROW
+    double* lqs;          // B
     long long* acc;       // 2 x D3P_GMM_ACC_R x D3P_ACC_COLS(P): steps alternate
     float* pp[3];         // second buffer of the ping-ponged optimiser state
     GmmSlot* slots[2];    // gmm_step_batch(B) slots, alternating by prepared batch (the head of a batch's first step still
@@ -878,7 +935,8 @@ static size_t gmm_carve(const d3p_gmm_model* m, uint32_t B, char* base, GmmWorks
     auto take = [&](size_t bytes) { size_t o = off; off += align_up_g(bytes, 256); return base ? base + o : nullptr; };
     char* q;
     q = take((2 * K + 3) * sizeof(double)); if (ws) ws->pack = (double*)q;
-    q = take((size_t)B * K * 2 * sizeof(double)); if (ws) ws->dir = (double*)q;
+    q = take((size_t)B * K * D3P_GMM_DIR_ROW * sizeof(double)); if (ws) ws->dir = (double*)q;
+    q = take((size_t)B * sizeof(double)); if (ws) ws->lqs = (double*)q;
     q = take(2 * (size_t)D3P_GMM_ACC_R * D3P_ACC_COLS(P) * sizeof(long long)); if (ws) ws->acc = (long long*)q;
     for (int i = 0; i < 3; ++i) { q = take(P * sizeof(float)); if (ws) ws->pp[i] = (float*)q; }
     for (int i = 0; i < 2; ++i) { q = take(SB * sizeof(GmmSlot)); if (ws) ws->slots[i] = (GmmSlot*)q; }
@@ -929,20 +987,23 @@ static int gmm_launch_px(hipStream_t s, const d3p_gmm_model* model, const GmmArg
     const int KH = (model->K + 1) / 2 <= 8 ? 8 : 16, DS = (model->d + 63) / 64;
     int occ = KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1;
     static const int occ_env = [] { const char* e = getenv("D3P_GMM_OCC"); return e ? atoi(e) : 0; }();  // developer switch
-    const bool tune = SUM && KH == 8 && DS == 1 && model->K % 2 == 0 && (occ_env == 2 || occ_env == 4);
+    const bool tune = SUM && KH == 8 && DS == 1 && model->K == 16 && model->d == 64 && (occ_env == 2 || occ_env == 4);
     if (tune) occ = occ_env;
     const uint32_t P = (uint32_t)(model->K + model->K * model->d);
     const uint32_t wgs_all = (uint32_t)cdiv((uint64_t)a.B, 4), wgs_res = 256u * (uint32_t)occ;
     const dim3 grid(SUM ? (wgs_all < wgs_res ? wgs_all : wgs_res) : wgs_all), block(256);
     const size_t lds = SUM ? (size_t)(P + 2) * sizeof(float) : 0;
+    const bool full = SUM && model->K == 2 * KH && model->d == 64 * DS;
 #define D3P_GMM_LAUNCH(KH_, DS_)                                                                 \
-    if (model->K % 2 == 0)                                                                       \
+    if (full)                                                                                    \
+        hipLaunchKernelGGL((k_gmm_px<KH_, DS_, SUM, true, SUM>), grid, block, lds, s, a);        \
+    else if (model->K % 2 == 0)                                                                  \
         hipLaunchKernelGGL((k_gmm_px<KH_, DS_, SUM, true>), grid, block, lds, s, a);             \
     else                                                                                         \
         hipLaunchKernelGGL((k_gmm_px<KH_, DS_, SUM, false>), grid, block, lds, s, a)
     if (tune) {
-        if (occ == 2) hipLaunchKernelGGL((k_gmm_px<8, 1, SUM, true, 2>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((k_gmm_px<8, 1, SUM, true, 4>), grid, block, lds, s, a);
+        if (occ == 2) hipLaunchKernelGGL((k_gmm_px<8, 1, SUM, true, SUM, 2>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_gmm_px<8, 1, SUM, true, SUM, 4>), grid, block, lds, s, a);
     } else if (KH == 8) {
         switch (DS) {
         case 1: D3P_GMM_LAUNCH(8, 1); break;
@@ -968,7 +1029,8 @@ extern "C" {
 size_t d3p_gmm_px_grads_workspace(int32_t K, uint32_t B)
 {
     const size_t k = (size_t)(K > 0 ? K : 0);
-    return align_up_g((2 * k + 3) * sizeof(double), 256) + align_up_g((size_t)B * k * 2 * sizeof(double), 256);
+    return align_up_g((2 * k + 3) * sizeof(double), 256) + align_up_g((size_t)B * k * D3P_GMM_DIR_ROW * sizeof(double), 256) +
+           align_up_g((size_t)B * sizeof(double), 256) + align_up_g((size_t)B * k * sizeof(float), 256);
 }
 
 int d3p_gmm_px_grads(void* stream, const d3p_gmm_model* model, const float* params_dev, const float* X_dev,
@@ -981,16 +1043,22 @@ int d3p_gmm_px_grads(void* stream, const d3p_gmm_model* model, const float* para
     if (int rc = gmm_validate(model, "d3p_gmm_px_grads")) return rc;
     if (workspace_bytes < d3p_gmm_px_grads_workspace(model->K, B)) return fail(D3P_E_WORKSPACE, "d3p_gmm_px_grads: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    double* pack = (double*)workspace_dev;
-    double* dir = (double*)((char*)workspace_dev + align_up_g((2 * (size_t)model->K + 3) * sizeof(double), 256));
+    const size_t k = (size_t)model->K;
+    char* q = (char*)workspace_dev;
+    double* pack = (double*)q; q += align_up_g((2 * k + 3) * sizeof(double), 256);
+    double* dir = (double*)q; q += align_up_g((size_t)B * k * D3P_GMM_DIR_ROW * sizeof(double), 256);
+    double* lqs = (double*)q; q += align_up_g((size_t)B * sizeof(double), 256);
+    float* gdraw = (float*)q;
     hipLaunchKernelGGL(k_gmm_pack, dim3(1), dim3(64), 0, s, params_dev, model->K, pack);
     hipLaunchKernelGGL(k_gmm_mask_meta, dim3(1), dim3(256), 0, s, mask_dev, B, meta_dev);
-    hipLaunchKernelGGL(k_gmm_dirichlet, dim3(cdiv((uint64_t)B * model->K, 256)), dim3(256), 0, s, (const double*)pack, jax_key_dev, B, B, 0u,
-                       model->K, dir);
+    hipLaunchKernelGGL(k_gmm_dirichlet, dim3(cdiv(B, 256u / (uint32_t)model->K)), dim3(256), 0, s, (const double*)pack, jax_key_dev, B, B, 0u,
+                       model->K, dir, lqs, gdraw);
     GmmArgs a;
     gmm_fill(&a, model, params_dev, X_dev, nullptr, mask_dev, B, jax_key_dev, 1.0f);
     a.pack = pack;
     a.dir = dir;
+    a.lqs = lqs;
+    a.gdraw = gdraw;
     a.meta = meta_dev;
     a.px_loss = px_loss_dev;
     a.px_grads = px_grads_dev;
@@ -1123,17 +1191,19 @@ static int gmm_enqueue_steps(hipStream_t s, const d3p_gmm_model* model, const d3
             ha.acc_words = (uint32_t)acc_words;
             ha.pack = ws.pack;
             ha.dir = ws.dir;
+            ha.lqs = ws.lqs;
             ha.skeys = skeys;
             ha.mask = mask_dev;
             ha.B = B;
             ha.K = K;
-            hipLaunchKernelGGL(k_gmm_head, dim3(cdiv((uint64_t)B * K, 256)), dim3(256), 0, s, ha);
+            hipLaunchKernelGGL(k_gmm_head, dim3(cdiv(B, 256u / (uint32_t)K)), dim3(256), 0, s, ha);
             GmmArgs a;
             gmm_fill(&a, model, buf(t, 0), X_dev, batch_key_dev ? ws.idx + (size_t)(t - t0) * B : nullptr, mask_dev, B, nullptr,
                      hyper->clip);
             a.skeys = skeys;
             a.pack = ws.pack;
             a.dir = ws.dir;
+            a.lqs = ws.lqs;
             a.acc = ha.acc_zero;
             a.sg = sg;
             if ((rc = gmm_launch_px<true>(s, model, a))) return rc;
