@@ -241,8 +241,8 @@ struct GmmArgs {
 // scheduler from interleaving all threefry chains at once (which drove the small shapes to 256 VGPRs, occupancy 1).
 // FULLT: K == 2 KH and d == 64 DS exactly (BASELINE config 3: K = 16, d = 64) -- every lane / slot predicate is true and folds
 // away (about a tenth of the instructions of the component loop).
-template <int KH, int DS, bool SUM, bool PAIRED, bool FULLT = false, int OCC = (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1)>
-__global__ void __launch_bounds__(256, OCC) k_gmm_px(GmmArgs a)
+template <int KH, int DS, bool SUM, bool PAIRED, bool FULLT = false>
+__global__ void __launch_bounds__(256, (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1)) k_gmm_px(GmmArgs a)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -980,15 +980,15 @@ static void gmm_fill(GmmArgs* a, const d3p_gmm_model* model, const float* params
     a->clip = clip;
 }
 
-// SUM: a resident grid (OCC workgroups per CU on 256 CUs, or fewer when the batch is small) strides over the examples
+// SUM: a resident grid (as many workgroups per CU as the launch bound allows, on 256 CUs; fewer when the batch is small) strides
+// over the examples
 template <bool SUM>
 static int gmm_launch_px(hipStream_t s, const d3p_gmm_model* model, const GmmArgs& a)
 {
     const int KH = (model->K + 1) / 2 <= 8 ? 8 : 16, DS = (model->d + 63) / 64;
-    int occ = KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1;
-    static const int occ_env = [] { const char* e = getenv("D3P_GMM_OCC"); return e ? atoi(e) : 0; }();  // developer switch
-    const bool tune = SUM && KH == 8 && DS == 1 && model->K == 16 && model->d == 64 && (occ_env == 2 || occ_env == 4);
-    if (tune) occ = occ_env;
+    // workgroups per CU = the kernel's launch bound (measured at K = 16, d = 64, B = 8192: 3 -> 57.4, 4 (128 VGPRs, 68 bytes of
+    // scratch) -> 61.2, 2 -> 77.7 us per step)
+    const int occ = KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1;
     const uint32_t P = (uint32_t)(model->K + model->K * model->d);
     const uint32_t wgs_all = (uint32_t)cdiv((uint64_t)a.B, 4), wgs_res = 256u * (uint32_t)occ;
     const dim3 grid(SUM ? (wgs_all < wgs_res ? wgs_all : wgs_res) : wgs_all), block(256);
@@ -1001,10 +1001,7 @@ static int gmm_launch_px(hipStream_t s, const d3p_gmm_model* model, const GmmArg
         hipLaunchKernelGGL((k_gmm_px<KH_, DS_, SUM, true>), grid, block, lds, s, a);             \
     else                                                                                         \
         hipLaunchKernelGGL((k_gmm_px<KH_, DS_, SUM, false>), grid, block, lds, s, a)
-    if (tune) {
-        if (occ == 2) hipLaunchKernelGGL((k_gmm_px<8, 1, SUM, true, SUM, 2>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((k_gmm_px<8, 1, SUM, true, SUM, 4>), grid, block, lds, s, a);
-    } else if (KH == 8) {
+    if (KH == 8) {
         switch (DS) {
         case 1: D3P_GMM_LAUNCH(8, 1); break;
         case 2: D3P_GMM_LAUNCH(8, 2); break;
