@@ -9,6 +9,7 @@
 // Forward and backward-data passes are batched GEMMs over the B examples; activations, the reparametrised latent,
 // the Bernoulli likelihood and the clip factors are small row-wise kernels in between.
 // Formulas: oracle/d3p_oracle.c (d3po_vae_step_sums), which materialises every per-example gradient as the check.
+#include <type_traits>
 #include "d3p_device.h"
 #include "d3p_host.h"
 #include "d3p_logreg_kernel.h"  // px_sample_key
@@ -204,6 +205,218 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// GEMM for the large products (operands 16-byte loadable): tile 128 (M) x 64 (N), K slices of 32, EIGHT wavefronts, each
+// owning one 32 x 32 block of the tile (wavefront w: rows 32 (w & 3), columns 32 (w >> 2)).
+//
+// What bounds an fp32 GEMM on this chip (measured: tools/probes/mfma_probe.hip, mfma_valu_probe.hip, profiles/r02_mfma_*):
+//   * v_mfma_f32_32x32x2_f32 sustains 155 TFLOP/s (27.1 ns per instruction and SIMD) from one wavefront per SIMD and one
+//     accumulator chain;
+//   * while an fp32 MFMA runs NOTHING else issues on its SIMD -- not a later instruction of the same wavefront, not a sibling
+//     wavefront's VALU, LDS or memory instruction, whatever its priority.  The efficiency of a GEMM is therefore
+//     MFMA cycles / (MFMA cycles + issue cycles of every other instruction on the SIMD + stalls nobody covers).
+// Hence: (a) few instructions per MFMA -- fragments are read with ds_read_b128 (4 MFMA steps per read), operands are fetched
+// with 16-byte loads whose addresses are a per-thread base + slice offset, edges are applied arithmetically at staging time;
+// (b) two wavefronts per SIMD even when the tile count gives one workgroup per CU (224 tiles for 4096 x 400), so that one's
+// waits (LDS round trip after the barrier, the barrier itself) are covered by the other's MFMAs; (c) one barrier per slice,
+// placed in the MIDDLE of the slice's MFMAs: 8 MFMAs | stage slice i + 1, fetch slice i + 3 | barrier | read the fragments
+// of slice i + 1 | 8 MFMAs -- the fragment reads land during the second half.
+// (Tried and measured slower: 4 wavefronts of 32 x 64 with one workgroup per CU, 40-57 TFLOP/s; a ping-pong of two wavefront
+// groups alternating between MFMA and memory phases, 35-44: the memory phase cannot run beside the MFMA phase.)
+//
+// LDS layout [row][k], k fastest, row stride 36 floats.  The MFMA step t of a slice multiplies columns {t, 16 + t} (any pairing
+// of the 32 k's gives the same sum), so lane (r, h) needs k = 16 h .. 16 h + 15 of its row: four ds_read_b128 per operand.
+// An operand that is k-fast in memory is stored as loaded (b128).  A row-fast one (float4 = 4 rows at one k) is transposed in
+// registers where the thread holds two k's (A: 4 x b64 stores) and by four b32 stores otherwise (B).
+// Loads are straight-line from CLAMPED addresses, the edges are applied arithmetically at staging time (guarded loads -- also
+// "valid ? load : fill", which LLVM turns back into a branch -- make the compiler wait with vmcnt(0): no prefetch):
+//   * k beyond the split's range: A is multiplied by 0 there (B may hold anything finite);
+//   * rows of A beyond m_real: multiplied by 0, plus 1 for the virtual row of ones; rows >= M / columns >= N only feed
+//     accumulator entries that are never stored.
+// The host guarantees m_real % 4 == 0 for an m-fast A and N % 4 == 0 for an n-fast B (a float4 is inside or outside whole).
+// AK: A is k-fast (a_sk == 1), otherwise m-fast (a_sm == 1); BN: B is n-fast (b_sn == 1), otherwise k-fast (b_sk == 1).
+// ------------------------------------------------------------------------------------------------------------------
+#define D3P_GTM 128
+#define D3P_GKB 32
+#define D3P_GLD (D3P_GKB + 4)
+template <bool AK, bool BN>
+__global__ void __launch_bounds__(512) k_gemm_f32_w8(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) float As[2][D3P_GTM][D3P_GLD];  // [m][k]
+    __shared__ __attribute__((aligned(16))) float Bs[2][D3P_GT][D3P_GLD];   // [n][k]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2, wr = wave & 3;
+    const int m0 = blockIdx.y * D3P_GTM, n0 = blockIdx.x * D3P_GT;
+    const int kbeg = blockIdx.z * g.k_per, kend = (kbeg + g.k_per < g.K) ? kbeg + g.k_per : g.K;
+    const int m_real = g.a_last_one ? g.M - 1 : g.M;  // rows of A that exist in memory
+    float16v acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+
+    // ---- this thread's share of a slice: two float4 of A, one of B (row / k offsets inside the tile and slice)
+    int a_m[2], a_k[2], b_n, b_k;
+    if (AK) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { const int f = tid + 512 * r; a_m[r] = f >> 3; a_k[r] = 4 * (f & 7); }
+    } else {  // rows 4 mg .. 4 mg + 3 at k = 2 kp, 2 kp + 1
+        const int mg = (tid & 7) + 8 * (tid >> 7), kp = (tid >> 3) & 15;
+        a_m[0] = a_m[1] = 4 * mg;
+        a_k[0] = 2 * kp;
+        a_k[1] = 2 * kp + 1;
+    }
+    if (BN) { b_n = 4 * ((tid & 7) + 8 * (tid >> 8)); b_k = (tid >> 3) & 31; } else { b_n = tid >> 3; b_k = 4 * (tid & 7); }
+    // Source addresses: per-thread 32-bit element offsets inside (tile rows, slice) -- rows clamped into the matrix -- on top of a
+    // wavefront-uniform slice base that the scalar unit advances.  The two uniform conditions below select the cheap paths: a
+    // slice that lies inside [0, K) whole is fetched from base + offset (no per-thread arithmetic; the few slices that straddle
+    // K or lie beyond it -- the tail and the prefetches past the end -- clamp k per thread), and a tile that touches neither the
+    // last rows of A nor the end of the split's K range is staged as loaded.
+    const int ka_last = g.K - (AK ? 4 : 1), kb_last = g.K - (BN ? 1 : 4);
+    const int m_last = m_real - (AK ? 1 : 4), n_last = g.N - (BN ? 4 : 1);
+    const long long a_kstride = AK ? 1 : g.a_sk, b_kstride = BN ? g.b_sk : 1;
+    long long a_row[2];  // element offset of this thread's (clamped) row(s), k = 0
+    unsigned a_off[2];   // ... + its k offset inside a slice, relative to the slice base
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int gm = m0 + a_m[r], cm = gm < m_last ? gm : m_last;
+        a_row[r] = AK ? (long long)cm * g.a_sm : (long long)cm;
+        a_off[r] = (unsigned)(a_row[r] - (AK ? (long long)m0 * g.a_sm : (long long)m0) + (long long)a_k[r] * a_kstride);
+    }
+    const float* a_tile = g.A + (AK ? (long long)m0 * g.a_sm : (long long)m0);  // uniform; rows clamp downwards only: offsets stay >= 0
+    const int gn_c = (n0 + b_n) < n_last ? (n0 + b_n) : n_last;
+    const long long b_row = BN ? (long long)gn_c : (long long)gn_c * g.b_sn;
+    // (a clamped column can lie left of the tile's first column only when the tile starts within 3 of N: then the base is moved)
+    const int n_base = n0 < n_last ? n0 : n_last;
+    const float* b_tile = g.B + (BN ? (long long)n_base : (long long)n_base * g.b_sn);
+    const unsigned b_off = (unsigned)(b_row - (BN ? (long long)n_base : (long long)n_base * g.b_sn) + (long long)b_k * b_kstride);
+    const bool m_edge = m0 + D3P_GTM > m_real;  // uniform: some rows of the tile are virtual (ones row) or absent
+    float keep_m[2], one_m[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int gm = m0 + a_m[r];
+        keep_m[r] = gm < m_real ? 1.f : 0.f;
+        // the ones row: row m_real when a_last_one.  m-fast: m_real % 4 == 0, so it is the FIRST of the thread's four rows
+        one_m[r] = (g.a_last_one && gm == m_real) ? 1.f : 0.f;
+    }
+
+    // (separate variables, not arrays: an array of float4 written on two paths was promoted to LDS by the compiler)
+    float4 ra00, ra01, rb0, ra10, ra11, rb1;
+    auto fetch = [&](auto S, int k0) {  // slice starting at k0 -> register set S; exactly three loads on either path
+        constexpr int s = decltype(S)::value;
+        float4 &a0 = s ? ra10 : ra00, &a1 = s ? ra11 : ra01, &bb = s ? rb1 : rb0;
+        if (k0 + D3P_GKB <= g.K) {
+            const float* as = a_tile + (long long)k0 * a_kstride;
+            const float* bs = b_tile + (long long)k0 * b_kstride;
+            a0 = *reinterpret_cast<const float4*>(as + a_off[0]);
+            a1 = *reinterpret_cast<const float4*>(as + a_off[1]);
+            bb = *reinterpret_cast<const float4*>(bs + b_off);
+        } else {
+            const int gk0 = k0 + a_k[0], gk1 = k0 + a_k[1], gkb = k0 + b_k;
+            a0 = *reinterpret_cast<const float4*>(g.A + a_row[0] + (long long)(gk0 < ka_last ? gk0 : ka_last) * a_kstride);
+            a1 = *reinterpret_cast<const float4*>(g.A + a_row[1] + (long long)(gk1 < ka_last ? gk1 : ka_last) * a_kstride);
+            bb = *reinterpret_cast<const float4*>(g.B + b_row + (long long)(gkb < kb_last ? gkb : kb_last) * b_kstride);
+        }
+    };
+    auto stage = [&](auto S, int buf, int k0) {  // register set S (slice starting at k0) -> LDS buffer, edges applied
+        constexpr int s = decltype(S)::value;
+        const float4 bb = s ? rb1 : rb0;
+        float4 o[2] = {s ? ra10 : ra00, s ? ra11 : ra01};
+        if (m_edge || k0 + D3P_GKB > kend) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float in_k = (k0 + a_k[r] < kend) ? 1.f : 0.f, keep = keep_m[r] * in_k, one = one_m[r] * in_k;
+                const float4 v = o[r];
+                o[r] = make_float4(__fmaf_rn(v.x, keep, one), __fmaf_rn(v.y, keep, AK ? one : 0.f), __fmaf_rn(v.z, keep, AK ? one : 0.f),
+                                   __fmaf_rn(v.w, keep, AK ? one : 0.f));
+            }
+        }
+        if (AK) {
+            *reinterpret_cast<float4*>(&As[buf][a_m[0]][a_k[0]]) = o[0];
+            *reinterpret_cast<float4*>(&As[buf][a_m[1]][a_k[1]]) = o[1];
+        } else {  // 2 k x 4 rows, transposed in registers
+            *reinterpret_cast<float2*>(&As[buf][a_m[0] + 0][a_k[0]]) = make_float2(o[0].x, o[1].x);
+            *reinterpret_cast<float2*>(&As[buf][a_m[0] + 1][a_k[0]]) = make_float2(o[0].y, o[1].y);
+            *reinterpret_cast<float2*>(&As[buf][a_m[0] + 2][a_k[0]]) = make_float2(o[0].z, o[1].z);
+            *reinterpret_cast<float2*>(&As[buf][a_m[0] + 3][a_k[0]]) = make_float2(o[0].w, o[1].w);
+        }
+        if (BN) {
+            Bs[buf][b_n + 0][b_k] = bb.x;
+            Bs[buf][b_n + 1][b_k] = bb.y;
+            Bs[buf][b_n + 2][b_k] = bb.z;
+            Bs[buf][b_n + 3][b_k] = bb.w;
+        } else {
+            *reinterpret_cast<float4*>(&Bs[buf][b_n][b_k]) = bb;
+        }
+    };
+    struct Frag { float4 a[4], b[4]; };
+    const int fr = lane & 31, fh = lane >> 5;
+    auto read_frags = [&](int buf, Frag& f) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f.a[q] = *reinterpret_cast<const float4*>(&As[buf][32 * wr + fr][16 * fh + 4 * q]);
+            f.b[q] = *reinterpret_cast<const float4*>(&Bs[buf][32 * grp + fr][16 * fh + 4 * q]);
+        }
+    };
+    auto mma_half = [&](const Frag& f, int half) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 a = f.a[2 * half + q], b = f.b[2 * half + q];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int KB = D3P_GKB;
+    // Slice i lives in LDS buffer i & 1; at the top of iteration i the register set (i + 1) & 1 holds slice i + 1 and the set i & 1
+    // slice i + 2 (both possibly still in flight) and f0 the fragments of slice i.  A buffer is rewritten one barrier after its last
+    // reader issued (and completed) its reads, and read after the barrier that follows its writes.
+    // (the slice count is rounded up to even: the register-set indices stay compile-time constants; empty slices multiply zeros)
+    Frag f0, f1;
+    fetch(S0{}, kbeg);
+    fetch(S1{}, kbeg + KB);
+    stage(S0{}, 0, kbeg);
+    fetch(S0{}, kbeg + 2 * KB);
+    __syncthreads();
+    read_frags(0, f0);
+    const int ns = (kend - kbeg + KB - 1) / KB;
+    for (int i = 0; i < ns; i += 2) {
+        const int k_i = kbeg + i * KB;
+        mma_half(f0, 0);
+        stage(S1{}, 1, k_i + KB);
+        fetch(S1{}, k_i + 3 * KB);
+        __syncthreads();
+        read_frags(1, f1);
+        mma_half(f0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(f1, 0);
+        stage(S0{}, 0, k_i + 2 * KB);
+        fetch(S0{}, k_i + 4 * KB);
+        __syncthreads();
+        read_frags(0, f0);
+        mma_half(f1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int col = n0 + 32 * grp + (lane & 31);
+    if (col >= g.N) return;
+    if (g.part) {  // split-K: raw partial tile, combined in fixed order by the consumer
+        float* out = g.part + (size_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = m0 + wr * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+            if (row < g.M) out[(size_t)row * g.N + col] = acc[v];
+        }
+        return;
+    }
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int row = m0 + wr * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+        if (row < g.M) gemm_store(g, row, col, acc[v], bv);
+    }
+}
+
 __global__ void k_gemm_reduce(GemmArgs g, int splits)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -230,10 +443,18 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     g.a_last_one = a_last_one;
     g.epi = epi;
     g.C2 = C2;
-    const unsigned tiles = cdiv(N, D3P_GT) * cdiv(M, D3P_GT);
+    // 16-byte fetches along the unit-stride dimension when every such load is aligned: base pointer, the other stride and the
+    // K range of a split (k_per is a multiple of 16) -- the kernels guard the M / N edges themselves, K must be a multiple of 4
+    auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    const bool va = aligned16(A) && K % 4 == 0 && ((a_sk == 1 && a_sm % 4 == 0) || (a_sm == 1 && a_sk % 4 == 0));
+    const bool vb = aligned16(B) && K % 4 == 0 && ((b_sn == 1 && b_sk % 4 == 0) || (b_sk == 1 && b_sn % 4 == 0));
+    // 128 x 64 tiles (k_gemm_f32_w8): whole float4s only (see its header)
+    const bool big = va && vb && M > 96 && (a_sk == 1 || (a_last_one ? M - 1 : M) % 4 == 0) && (b_sn != 1 || N % 4 == 0);
+    const int tm = big ? D3P_GTM : D3P_GT;
+    const unsigned tiles = cdiv(N, D3P_GT) * cdiv(M, tm);
     int splits = 1;
-    if (part && tiles < 512 && K >= 8 * D3P_GK) {
-        splits = (int)((1024 + tiles - 1) / tiles);
+    if (part && tiles < (big ? 160u : 512u) && K >= 8 * D3P_GK) {
+        splits = big ? (int)(512 / tiles) : (int)((1024 + tiles - 1) / tiles);  // big: two 8-wave workgroups per CU, one round
         const int max_by_k = K / (4 * D3P_GK);
         if (splits > max_by_k) splits = max_by_k;
         if (splits > 16) splits = 16;  // the reduction adds the partial tiles serially
@@ -241,18 +462,20 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
         if ((size_t)splits > max_by_mem) splits = (int)max_by_mem;
         if (splits < 1) splits = 1;
     }
+    const int kq = big ? D3P_GKB : D3P_GK;  // K slice of the kernel: a split starts on a slice boundary
     int k_per = (K + splits - 1) / splits;
-    k_per = (k_per + D3P_GK - 1) / D3P_GK * D3P_GK;
+    k_per = (k_per + kq - 1) / kq * kq;
     splits = (K + k_per - 1) / k_per;
     g.k_per = k_per;
     g.part = splits > 1 ? part : nullptr;
-    // 16-byte fetches along the unit-stride dimension when every such load is aligned: base pointer, the other stride and the
-    // K range of a split (k_per is a multiple of 16) -- the kernel guards the M / N edges itself, K must be a multiple of 4
-    auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    const bool va = aligned16(A) && K % 4 == 0 && ((a_sk == 1 && a_sm % 4 == 0) || (a_sm == 1 && a_sk % 4 == 0));
-    const bool vb = aligned16(B) && K % 4 == 0 && ((b_sn == 1 && b_sk % 4 == 0) || (b_sk == 1 && b_sn % 4 == 0));
-    const dim3 grid(cdiv(N, D3P_GT), cdiv(M, D3P_GT), splits);
-    if (va && vb) hipLaunchKernelGGL((k_gemm_f32<true, true>), grid, dim3(256), 0, s, g);
+    const dim3 grid(cdiv(N, D3P_GT), cdiv(M, tm), splits);
+    if (big) {
+        const bool ak = a_sk == 1, bn = b_sn == 1;
+        if (ak && bn) hipLaunchKernelGGL((k_gemm_f32_w8<true, true>), grid, dim3(512), 0, s, g);
+        else if (ak) hipLaunchKernelGGL((k_gemm_f32_w8<true, false>), grid, dim3(512), 0, s, g);
+        else if (bn) hipLaunchKernelGGL((k_gemm_f32_w8<false, true>), grid, dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((k_gemm_f32_w8<false, false>), grid, dim3(512), 0, s, g);
+    } else if (va && vb) hipLaunchKernelGGL((k_gemm_f32<true, true>), grid, dim3(256), 0, s, g);
     else if (va) hipLaunchKernelGGL((k_gemm_f32<true, false>), grid, dim3(256), 0, s, g);
     else if (vb) hipLaunchKernelGGL((k_gemm_f32<false, true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_f32<false, false>), grid, dim3(256), 0, s, g);
