@@ -50,9 +50,10 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& g, int row, int col, 
     const size_t e = (size_t)row * g.ldc + col;
     float o = __fmaf_rn(g.alpha, acc, bv);
     if (g.accumulate) o += g.C[e];
-    if (g.epi == 1) {
-        g.C2[e] = 1.0f / (1.0f + expf(-o));
-        o = fmaxf(o, 0.0f) + log1pf(expf(-fabsf(o)));
+    if (g.epi == 1) {  // one exponential: en = exp(-|o|); sigmoid = 1 / (1 + en) or en / (1 + en); softplus = max(o, 0) + log(1 + en)
+        const float en = __expf(-fabsf(o)), r = __builtin_amdgcn_rcpf(1.0f + en);
+        g.C2[e] = o >= 0.0f ? r : en * r;
+        o = fmaxf(o, 0.0f) + __logf(1.0f + en);
     } else if (g.epi == 2) {
         o *= g.C2[e];
     }
@@ -433,8 +434,10 @@ __global__ void k_gemm_reduce(GemmArgs g, int splits)
 // GEMMs: K = batch, M x N = a weight matrix) still put a few workgroups on every CU.
 static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, const float* B, long long b_sk, long long b_sn,
                 float* C, int ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, int a_last_one = 0,
-                float* part = nullptr, size_t part_floats = 0, int epi = 0, float* C2 = nullptr)
+                float* part = nullptr, size_t part_floats = 0, int epi = 0, float* C2 = nullptr, int* splits_left = nullptr)
 {
+    // splits_left != nullptr: a split-K product is NOT reduced here -- the partial tiles stay in `part` ([splits][M][N]) and
+    // *splits_left says how many (0: the product went to C as usual); the consumer sums them in fixed order (k_vae_finalize)
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     g.M = M; g.N = N; g.K = K;
@@ -479,7 +482,8 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     else if (va) hipLaunchKernelGGL((k_gemm_f32<true, false>), grid, dim3(256), 0, s, g);
     else if (vb) hipLaunchKernelGGL((k_gemm_f32<false, true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((k_gemm_f32<false, false>), grid, dim3(256), 0, s, g);
-    if (splits > 1) hipLaunchKernelGGL(k_gemm_reduce, dim3(cdiv((uint64_t)M * N, 256)), dim3(256), 0, s, g, splits);
+    if (splits_left) *splits_left = splits > 1 ? splits : 0;
+    if (splits > 1 && !splits_left) hipLaunchKernelGGL(k_gemm_reduce, dim3(cdiv((uint64_t)M * N, 256)), dim3(256), 0, s, g, splits);
     return check_launch("k_gemm_f32");
 }
 
@@ -549,8 +553,9 @@ __global__ void k_vae_out(float* __restrict__ a, const float* __restrict__ X, co
     // one exponential per element: e = exp(-|t|) gives softplus(t) = max(t, 0) + log1p(e) and sigmoid(t) = 1 / (1 + e) for
     // t >= 0, e / (1 + e) otherwise
     auto elem = [&](float t, float x, float& ll) {
-        const float e = expf(-fabsf(t)), r = 1.0f / (1.0f + e);
-        ll += x * t - (fmaxf(t, 0.0f) + log1pf(e));
+        // (hardware exp2 / log2 / rcp paths: 1 + e is in (1, 2], so log(1 + e) has an absolute error of ~1e-7 against terms >= ln 2 e)
+        const float e = __expf(-fabsf(t)), r = __builtin_amdgcn_rcpf(1.0f + e);
+        ll += x * t - (fmaxf(t, 0.0f) + __logf(1.0f + e));
         return sc * ((t >= 0.0f ? r : e * r) - x);
     };
     float ll = 0.f;
@@ -670,8 +675,15 @@ __global__ void __launch_bounds__(256) k_vae_loss_n(const float* __restrict__ px
 }
 
 // mean, Gaussian mechanism, rescale (svi.py:343-346, :365-375), numpyro Adam (svi.py:379-393) over the P parameters
+#define D3P_WPART_SPLITS 16  // most split-K partial tiles a product leaves
+
 struct VaeFinalArgs {
     const float* sums;  // P + 2
+    // weight-gradient blocks whose split-K partial tiles were left unreduced (single-device update): block b = columns
+    // [w_off[b], w_off[b] + w_mn[b]) of the flat layout, w_splits[b] tiles of w_mn[b] floats at wpart + D3P_WPART_SPLITS * w_off[b]
+    const float* wpart;
+    uint32_t w_off[6], w_mn[5];
+    int w_splits[5];
     const float* noise;
     float* params;
     float* adam_m;
@@ -687,19 +699,32 @@ struct VaeFinalArgs {
 
 __global__ void k_vae_finalize(VaeFinalArgs a)
 {
+    __shared__ float bc[2];  // Adam's bias corrections 1 - b^(i + 1): two powf per workgroup instead of per column
+    if (threadIdx.x < 2) bc[threadIdx.x] = 1.0f - powf(threadIdx.x ? a.h.b2 : a.h.b1, (float)(*a.step + 1));
+    __syncthreads();
     const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const float n = a.sums[a.P + 1], Bf = (float)a.B;
     const float factor = (n == 0.f) ? 0.f : Bf / n;
     if (col == 0 && a.loss_out) *a.loss_out = (a.sums[a.P] / Bf) * a.obs_scale * factor;
     if (col >= a.P) return;
-    const float g = (a.sums[col] / Bf + a.noise[col] * (a.h.dp_scale * (a.h.clip / n))) * a.obs_scale * factor;
+    float tot = a.sums[col];
+    if (a.wpart) {
+        int b = 0;
+#pragma unroll
+        for (int k = 1; k < 5; ++k) b += (col >= a.w_off[k]) ? 1 : 0;
+        if (a.w_splits[b] > 0) {
+            const float* t = a.wpart + (size_t)D3P_WPART_SPLITS * a.w_off[b] + (col - a.w_off[b]);
+            tot = 0.f;
+            for (int z = 0; z < a.w_splits[b]; ++z) tot += t[(size_t)z * a.w_mn[b]];  // fixed order
+        }
+    }
+    const float g = (tot / Bf + a.noise[col] * (a.h.dp_scale * (a.h.clip / n))) * a.obs_scale * factor;
     if (a.grad_out) a.grad_out[col] = g;
-    const int i = *a.step;
     float m = a.adam_m[col], v = a.adam_v[col];
     m = (1.0f - a.h.b1) * g + a.h.b1 * m;
     v = (1.0f - a.h.b2) * g * g + a.h.b2 * v;
-    const float mhat = m / (1.0f - powf(a.h.b1, (float)(i + 1)));
-    const float vhat = v / (1.0f - powf(a.h.b2, (float)(i + 1)));
+    const float mhat = m / bc[0];
+    const float vhat = v / bc[1];
     a.params[col] -= a.h.lr * mhat / (sqrtf(vhat) + a.h.adam_eps);
     a.adam_m[col] = m;
     a.adam_v[col] = v;
@@ -800,7 +825,7 @@ static VaeLayout vae_layout(const d3p_vae_model* m)
 
 struct VaeWorkspace {
     float *h1, *sg1, *zl, *u, *eps, *h2, *sg2, *a, *dh2, *dz, *du, *dh1;
-    float *lat, *px_loss, *cf, *sums, *noise, *part;
+    float *lat, *px_loss, *cf, *sums, *noise, *part, *wpart;
     size_t part_floats;
     uint32_t* keys;  // 3 x 16 split + 10 x 16 site keys + jax key
 };
@@ -831,6 +856,7 @@ static size_t vae_carve(const d3p_vae_model* m, uint32_t B, char* base, VaeWorks
     q = take(13 * 16 + 2 + 2); if (ws) ws->keys = (uint32_t*)q;  // + [210]: optimiser step index of the update in flight
     const size_t pf = 16 * (D + 1) * H;  // split-K partial tiles: up to 16 splits of the largest weight matrix
     q = take(pf); if (ws) { ws->part = q; ws->part_floats = pf; }
+    q = take((size_t)D3P_WPART_SPLITS * P); if (ws) ws->wpart = q;  // unreduced weight-gradient tiles
     return off;
 }
 
@@ -866,8 +892,10 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
 // forward + backward + norms + clipped sums into ws.sums[P + 2]; eps_dev given or drawn from jax_key
 static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* params, const float* X, const uint8_t* mask,
                             uint32_t B, const float* eps_ext, const uint32_t* jax_key, float clip, const VaeWorkspace& ws,
-                            float* norms_out, uint32_t B_total = 0, uint32_t pos0 = 0)
+                            float* norms_out, uint32_t B_total = 0, uint32_t pos0 = 0, int* w_splits = nullptr)
 {
+    // w_splits != nullptr (single-device update): the split-K partial tiles of the five weight-gradient products stay in ws.wpart
+    // and w_splits[0..4] says how many each (k_vae_finalize sums them); otherwise ws.sums holds the reduced sums
     if (B_total == 0) B_total = B;
     int rc;
     const int D = m->D, H = m->H, Z = m->Z, Bi = (int)B;
@@ -898,11 +926,16 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     // [W | b] of every layer is contiguous in the flat layout, so the bias gradient is row `in` of a GEMM whose A carries a
     // virtual row of ones
     float* S = ws.sums;
-    if ((rc = gemm(s, ws.zl, 1, Z, ws.dh2, H, 1, S + L.V1, H, Z + 1, H, Bi, nullptr, 1.f, 0, 1, ws.part, ws.part_floats))) return rc;
-    if ((rc = gemm(s, ws.h2, 1, H, ws.a, D, 1, S + L.V2, D, H + 1, D, Bi, nullptr, 1.f, 0, 1, ws.part, ws.part_floats))) return rc;
-    if ((rc = gemm(s, X, 1, D, ws.dh1, H, 1, S + L.W1, H, D + 1, H, Bi, nullptr, 1.f, 0, 1, ws.part, ws.part_floats))) return rc;
-    if ((rc = gemm(s, ws.h1, 1, H, ws.dz, Z, 1, S + L.Wl, Z, H + 1, Z, Bi, nullptr, 1.f, 0, 1, ws.part, ws.part_floats))) return rc;
-    if ((rc = gemm(s, ws.h1, 1, H, ws.du, Z, 1, S + L.Ws, Z, H + 1, Z, Bi, nullptr, 1.f, 0, 1, ws.part, ws.part_floats))) return rc;
+    struct WG { const float* A; int in; const float* Bm; int out; size_t off; };
+    const WG wg[5] = {{ws.zl, Z, ws.dh2, H, L.V1}, {ws.h2, H, ws.a, D, L.V2}, {X, D, ws.dh1, H, L.W1}, {ws.h1, H, ws.dz, Z, L.Wl},
+                      {ws.h1, H, ws.du, Z, L.Ws}};
+    for (int b = 0; b < 5; ++b) {
+        float* part = w_splits ? ws.wpart + (size_t)D3P_WPART_SPLITS * wg[b].off : ws.part;
+        const size_t part_floats = w_splits ? (size_t)D3P_WPART_SPLITS * (wg[b].in + 1) * wg[b].out : ws.part_floats;
+        if ((rc = gemm(s, wg[b].A, 1, wg[b].in, wg[b].Bm, wg[b].out, 1, S + wg[b].off, wg[b].out, wg[b].in + 1, wg[b].out, Bi, nullptr, 1.f, 0, 1,
+                       part, part_floats, 0, nullptr, w_splits ? w_splits + b : nullptr)))
+            return rc;
+    }
     hipLaunchKernelGGL(k_vae_loss_n, dim3(1), dim3(256), 0, s, (const float*)ws.px_loss, mask, B, S + L.P);
     return check_launch("d3p_vae sums");
 }
@@ -997,13 +1030,14 @@ static int vae_step_keys(hipStream_t s, const d3p_dpsvi_state* state, const VaeW
 
 static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                           const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
-                          void* workspace_dev, size_t workspace_bytes, bool derive_keys);
+                          void* workspace_dev, size_t workspace_bytes, bool derive_keys, const int* w_splits = nullptr);
 
 // advance = true (single-device update): the key kernel also writes the next state key and advances the step counter, so that
 // vae_apply_impl(derive_keys = false) has nothing left to launch for them
 static int vae_local_sums_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                                const float* X_dev, const uint8_t* mask_dev, uint32_t B_local, uint32_t B_total, uint32_t pos0,
-                               const float* eps_dev, float* sums_dev, void* workspace_dev, size_t workspace_bytes, bool advance)
+                               const float* eps_dev, float* sums_dev, void* workspace_dev, size_t workspace_bytes, bool advance,
+                               int* w_splits = nullptr)
 {
     if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_local_sums")) return rc;
     D3P_REQUIRE(X_dev && sums_dev, "d3p_dpvi_vae_local_sums: null pointer");
@@ -1015,7 +1049,7 @@ static int vae_local_sums_impl(void* stream, const d3p_vae_model* model, const d
     int rc;
     if ((rc = vae_step_keys(s, state, ws, advance))) return rc;
     if ((rc = vae_enqueue_sums(s, model, state->params, X_dev, mask_dev, B_local, eps_dev, ws.keys + 208, hyper->clip, ws, nullptr,
-                               B_total, pos0)))
+                               B_total, pos0, w_splits)))
         return rc;
     if (sums_dev != ws.sums)
         D3P_HIP_TRY(hipMemcpyAsync(sums_dev, ws.sums, (vae_layout(model).P + 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1042,7 +1076,7 @@ int d3p_dpvi_vae_apply(void* stream, const d3p_vae_model* model, const d3p_dpsvi
 // workspace and state, as in the single-device update)
 static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                           const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
-                          void* workspace_dev, size_t workspace_bytes, bool derive_keys)
+                          void* workspace_dev, size_t workspace_bytes, bool derive_keys, const int* w_splits)
 {
     if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_apply")) return rc;
     D3P_REQUIRE(sums_dev && B_total >= 1 && B_local >= 1, "d3p_dpvi_vae_apply: null pointer or empty batch");
@@ -1069,6 +1103,16 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
     }
     VaeFinalArgs f;
     f.sums = sums_dev;
+    f.wpart = w_splits ? ws.wpart : nullptr;
+    {
+        const size_t blk[6] = {L.V1, L.V2, L.W1, L.Wl, L.Ws, L.P};  // [W | b] blocks of the flat layout
+        for (int b = 0; b < 5; ++b) {
+            f.w_off[b] = (uint32_t)blk[b];
+            f.w_mn[b] = (uint32_t)(blk[b + 1] - blk[b]);
+            f.w_splits[b] = w_splits ? w_splits[b] : 0;
+        }
+        f.w_off[5] = (uint32_t)L.P;
+    }
     f.noise = ws.noise;
     f.params = state->params;
     f.adam_m = state->adam_m;
@@ -1095,10 +1139,12 @@ int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsv
     if (workspace_bytes < d3p_dpvi_vae_workspace(model, B)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_update: workspace too small");
     VaeWorkspace ws;
     vae_carve(model, B, (char*)workspace_dev, &ws);
+    int w_splits[5];  // split-K partial tiles of the weight gradients are summed by k_vae_finalize, not by reduction launches
     if (int rc = vae_local_sums_impl(stream, model, hyper, state, X_dev, mask_dev, B, B, 0, eps_dev, ws.sums, workspace_dev,
-                                     workspace_bytes, true))
+                                     workspace_bytes, true, w_splits))
         return rc;
-    return vae_apply_impl(stream, model, hyper, state, ws.sums, B, B, loss_dev, grad_out_dev, workspace_dev, workspace_bytes, false);
+    return vae_apply_impl(stream, model, hyper, state, ws.sums, B, B, loss_dev, grad_out_dev, workspace_dev, workspace_bytes, false,
+                          w_splits);
 }
 
 }  // extern "C"
