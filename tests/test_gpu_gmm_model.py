@@ -158,6 +158,28 @@ def test_run_steps_walks_the_update_trajectory(rng):
     assert torch.equal(ref.optim_state[1], new_st.optim_state[1])
 
 
+def test_run_steps_across_prepared_batches(rng):
+    """A run longer than one prepared batch of steps (64: keys, Feistel rows, site keys and noise are prepared per batch and
+    the slot / noise arrays alternate between batches) ends where the step-by-step loop ends, bit for bit, also when the run
+    starts from an odd step count."""
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, d, K, B, steps = 3000, 2, 3, 64, 131
+    X = (torch.randn(N, d, generator=torch.Generator().manual_seed(3)) * 3).cuda()
+    svi = make_svi(K, d, N, C=20.0, sigma=0.5, lr=1e-2)
+    init, get_batch = subsample_batchify_data((X,), B)
+    nb, bstate = init(rng.PRNGKey(31))
+    st = svi.init(rng.PRNGKey(30), *get_batch(0, bstate))
+    st, _ = svi.update(st, *get_batch(0, bstate))          # odd starting step
+    new_st, losses = svi.run_steps(st, get_batch, bstate, 1, steps)
+    ref = st
+    for t in range(steps):
+        ref, l = svi.update(ref, *get_batch(1 + t, bstate))
+        assert float(l) == float(losses[t]), t
+    assert torch.equal(ref.rng_key, new_st.rng_key) and int(new_st.optim_state[0]) == steps + 1
+    for a, b in zip(ref.optim_state[1:], new_st.optim_state[1:]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,K,d", [(50, 16, 64), (17, 3, 2), (300, 5, 70)])
 def test_evaluate_vs_oracle(rng, O, B, K, d):
     N = 10**4
