@@ -27,6 +27,11 @@ static inline size_t align_up_v(size_t v, size_t a) { return (v + a - 1) / a * a
 // ------------------------------------------------------------------------------------------------------------------
 typedef float float16v __attribute__((ext_vector_type(16)));
 
+struct GemmJumps {  // see GemmArgs::n_seg
+    int n_seg, k_seg;
+    long long b_njump, b_kjump, bias_njump, c_njump;
+};
+
 struct GemmArgs {
     const float* A;
     const float* B;
@@ -41,13 +46,18 @@ struct GemmArgs {
     int k_per;        // K range of one split (multiple of D3P_GK); gridDim.z splits
     float* part;      // split-K partial tiles [gridDim.z][M][N] (nullable when gridDim.z == 1)
     int epi;          // epilogue: 0 store; 1 softplus (C = softplus(o), C2 = sigmoid(o) = its derivative); 2 C = o * C2
+    // Two operands side by side that are not adjacent in memory (the pairs (Wl, Ws) / (bl, bs) of the flat parameter layout lie
+    // H Z apart): columns n >= n_seg of B, of the bias and of C, and rows k >= k_seg of B, are displaced by a constant.  0 / 0 /
+    // INT_MAX segments = plain GEMM.  Honoured by the scalar B fetch and by every store path.
+    int n_seg, k_seg;
+    long long b_njump, b_kjump, bias_njump, c_njump;
     float* C2;        // second operand / output of the epilogue, same shape and leading dimension as C
 };
 
 // o = alpha * acc + bias (+ C); then the epilogue
 __device__ __forceinline__ void gemm_store(const GemmArgs& g, int row, int col, float acc, float bv)
 {
-    const size_t e = (size_t)row * g.ldc + col;
+    const size_t e = (size_t)row * g.ldc + col + (col >= g.n_seg ? g.c_njump : 0ll);
     float o = __fmaf_rn(g.alpha, acc, bv);
     if (g.accumulate) o += g.C[e];
     if (g.epi == 1) {  // one exponential: en = exp(-|o|); sigmoid = 1 / (1 + en) or en / (1 + en); softplus = max(o, 0) + log(1 + en)
@@ -146,7 +156,9 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gkb = k0 + bk[r], gn = n0 + bn[r];
-                rb[r] = (gkb < kend && gn < g.N) ? g.B[(long long)gkb * g.b_sk + (long long)gn * g.b_sn] : 0.f;
+                rb[r] = (gkb < kend && gn < g.N)
+                            ? g.B[(long long)gkb * g.b_sk + (long long)gn * g.b_sn + (gn >= g.n_seg ? g.b_njump : 0ll) + (gkb >= g.k_seg ? g.b_kjump : 0ll)]
+                            : 0.f;
             }
         }
     };
@@ -198,7 +210,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
         }
         return;
     }
-    const float bv = g.bias ? g.bias[col] : 0.f;
+    const float bv = g.bias ? g.bias[col + (col >= g.n_seg ? g.bias_njump : 0ll)] : 0.f;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int row = m0 + wm * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
@@ -410,7 +422,7 @@ __global__ void __launch_bounds__(512) k_gemm_f32_w8(GemmArgs g)
         }
         return;
     }
-    const float bv = g.bias ? g.bias[col] : 0.f;
+    const float bv = g.bias ? g.bias[col + (col >= g.n_seg ? g.bias_njump : 0ll)] : 0.f;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int row = m0 + wr * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
@@ -425,7 +437,7 @@ __global__ void k_gemm_reduce(GemmArgs g, int splits)
     const int row = (int)(t / g.N), col = (int)(t % g.N);
     float s = 0.f;
     for (int z = 0; z < splits; ++z) s += g.part[(size_t)z * g.M * g.N + t];  // fixed order
-    gemm_store(g, row, col, s, g.bias ? g.bias[col] : 0.f);
+    gemm_store(g, row, col, s, g.bias ? g.bias[col + (col >= g.n_seg ? g.bias_njump : 0ll)] : 0.f);
 }
 
 // part / part_floats: optional split-K scratch.  At B = 4096 the GEMMs of this model are parallelism-starved on 256 CUs (bigger
@@ -434,7 +446,8 @@ __global__ void k_gemm_reduce(GemmArgs g, int splits)
 // GEMMs: K = batch, M x N = a weight matrix) still put a few workgroups on every CU.
 static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, const float* B, long long b_sk, long long b_sn,
                 float* C, int ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, int a_last_one = 0,
-                float* part = nullptr, size_t part_floats = 0, int epi = 0, float* C2 = nullptr, int* splits_left = nullptr)
+                float* part = nullptr, size_t part_floats = 0, int epi = 0, float* C2 = nullptr, int* splits_left = nullptr,
+                const GemmJumps* jumps = nullptr)
 {
     // splits_left != nullptr: a split-K product is NOT reduced here -- the partial tiles stay in `part` ([splits][M][N]) and
     // *splits_left says how many (0: the product went to C as usual); the consumer sums them in fixed order (k_vae_finalize)
@@ -446,11 +459,18 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     g.a_last_one = a_last_one;
     g.epi = epi;
     g.C2 = C2;
+    g.n_seg = jumps ? jumps->n_seg : 0x7fffffff;
+    g.k_seg = jumps ? jumps->k_seg : 0x7fffffff;
+    g.b_njump = jumps ? jumps->b_njump : 0;
+    g.b_kjump = jumps ? jumps->b_kjump : 0;
+    g.bias_njump = jumps ? jumps->bias_njump : 0;
+    g.c_njump = jumps ? jumps->c_njump : 0;
     // 16-byte fetches along the unit-stride dimension when every such load is aligned: base pointer, the other stride and the
     // K range of a split (k_per is a multiple of 16) -- the kernels guard the M / N edges themselves, K must be a multiple of 4
     auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool va = aligned16(A) && K % 4 == 0 && ((a_sk == 1 && a_sm % 4 == 0) || (a_sm == 1 && a_sk % 4 == 0));
-    const bool vb = aligned16(B) && K % 4 == 0 && ((b_sn == 1 && b_sk % 4 == 0) || (b_sk == 1 && b_sn % 4 == 0));
+    const bool vb = aligned16(B) && K % 4 == 0 && ((b_sn == 1 && b_sk % 4 == 0) || (b_sk == 1 && b_sn % 4 == 0)) &&
+                    !(jumps && (jumps->b_njump || jumps->b_kjump));  // displaced B segments: scalar fetch only
     // 128 x 64 tiles (k_gemm_f32_w8): whole float4s only (see its header)
     const bool big = va && vb && M > 96 && (a_sk == 1 || (a_last_one ? M - 1 : M) % 4 == 0) && (b_sn != 1 || N % 4 == 0);
     const int tm = big ? D3P_GTM : D3P_GT;
@@ -524,7 +544,8 @@ __global__ void k_vae_eval_eps(const uint32_t* __restrict__ jax_key, uint32_t B,
 }
 
 // zl, u (B x Z), eps -> z = zl + exp(u) eps (written over zl), sd = exp(u) (written over u), lat[i] = log q - log p
-__global__ void k_vae_latent(float* __restrict__ zl, float* __restrict__ u, const float* __restrict__ eps, uint32_t B, int Z,
+// (zl / u, like dz / du below, are the two halves of one B x 2 Z array: row stride ld)
+__global__ void k_vae_latent(float* __restrict__ zl, float* __restrict__ u, const float* __restrict__ eps, uint32_t B, int Z, int ld,
                              float* __restrict__ lat)
 {
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -532,8 +553,8 @@ __global__ void k_vae_latent(float* __restrict__ zl, float* __restrict__ u, cons
     if (i >= B) return;
     float acc = 0.f;
     for (int j = lane; j < Z; j += 64) {
-        const size_t e = (size_t)i * Z + j;
-        const float uu = u[e], ee = eps[e];
+        const size_t e = (size_t)i * ld + j;
+        const float uu = u[e], ee = eps[(size_t)i * Z + j];
         const float sd = expf(uu), z = __fmaf_rn(sd, ee, zl[e]);
         zl[e] = z;
         u[e] = sd;
@@ -577,13 +598,14 @@ __global__ void k_vae_out(float* __restrict__ a, const float* __restrict__ X, co
 
 // dzraw (B x Z) = dpre2 V1^T  ->  dz = dzraw + sc z,  du = dz sd eps - sc
 __global__ void k_vae_dlatent(float* __restrict__ dz, float* __restrict__ du, const float* __restrict__ z,
-                              const float* __restrict__ sd, const float* __restrict__ eps, size_t n, float sc)
+                              const float* __restrict__ sd, const float* __restrict__ eps, size_t n, int Z, int ld, float sc)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float t = __fmaf_rn(sc, z[i], dz[i]);
-    dz[i] = t;
-    du[i] = t * sd[i] * eps[i] - sc;
+    const size_t e = i / Z * ld + i % Z;
+    const float t = __fmaf_rn(sc, z[e], dz[e]);
+    dz[e] = t;
+    du[e] = t * sd[e] * eps[i] - sc;
 }
 
 __device__ __forceinline__ float row_sumsq(const float* __restrict__ r, int n, int lane)
@@ -601,7 +623,7 @@ struct NormArgs {
     float *dpre1, *dz, *du, *dpre2, *da;  // layer deltas, rescaled in place
     const uint8_t* mask;
     uint32_t B;
-    int D, H, Z;
+    int D, H, Z, ldz;  // ldz: row stride of z, dz, du
     float clip;
     float* cf;
     float* norms;  // nullable
@@ -633,10 +655,10 @@ __global__ void k_vae_norms(NormArgs a)
     float* r_da = a.da + (size_t)i * a.D;
     float* r_d2 = a.dpre2 + (size_t)i * a.H;
     float* r_d1 = a.dpre1 + (size_t)i * a.H;
-    float* r_dz = a.dz + (size_t)i * a.Z;
-    float* r_du = a.du + (size_t)i * a.Z;
+    float* r_dz = a.dz + (size_t)i * a.ldz;
+    float* r_du = a.du + (size_t)i * a.ldz;
     const float x2 = row_sumsq(a.X + (size_t)i * a.D, a.D, lane), h12 = row_sumsq(a.h1 + (size_t)i * a.H, a.H, lane);
-    const float z2 = row_sumsq(a.z + (size_t)i * a.Z, a.Z, lane), h22 = row_sumsq(a.h2 + (size_t)i * a.H, a.H, lane);
+    const float z2 = row_sumsq(a.z + (size_t)i * a.ldz, a.Z, lane), h22 = row_sumsq(a.h2 + (size_t)i * a.H, a.H, lane);
     const float d1 = row_sumsq_keep(r_d1, a.H, lane, k_d1), dz = row_sumsq_keep(r_dz, a.Z, lane, k_dz);
     const float du = row_sumsq_keep(r_du, a.Z, lane, k_du), d2 = row_sumsq_keep(r_d2, a.H, lane, k_d2);
     const float da = row_sumsq_keep(r_da, a.D, lane, k_da);
@@ -682,8 +704,9 @@ struct VaeFinalArgs {
     // weight-gradient blocks whose split-K partial tiles were left unreduced (single-device update): block b = columns
     // [w_off[b], w_off[b] + w_mn[b]) of the flat layout, w_splits[b] tiles of w_mn[b] floats at wpart + D3P_WPART_SPLITS * w_off[b]
     const float* wpart;
-    uint32_t w_off[6], w_mn[5];
-    int w_splits[5];
+    uint32_t w_off[6];                                          // first column of block b (w_off[5] = P)
+    uint32_t w_base[5], w_tile[5], w_ld[5], w_coff[5], w_out[5];  // its tiles: wpart + w_base, w_tile apart, element (r, c) of the
+    int w_splits[5];                                            // block at r * w_ld + w_coff + c, c < w_out
     const float* noise;
     float* params;
     float* adam_m;
@@ -713,9 +736,10 @@ __global__ void k_vae_finalize(VaeFinalArgs a)
 #pragma unroll
         for (int k = 1; k < 5; ++k) b += (col >= a.w_off[k]) ? 1 : 0;
         if (a.w_splits[b] > 0) {
-            const float* t = a.wpart + (size_t)D3P_WPART_SPLITS * a.w_off[b] + (col - a.w_off[b]);
+            const uint32_t e = (uint32_t)col - a.w_off[b];
+            const float* t = a.wpart + a.w_base[b] + (size_t)(e / a.w_out[b]) * a.w_ld[b] + a.w_coff[b] + e % a.w_out[b];
             tot = 0.f;
-            for (int z = 0; z < a.w_splits[b]; ++z) tot += t[(size_t)z * a.w_mn[b]];  // fixed order
+            for (int z = 0; z < a.w_splits[b]; ++z) tot += t[(size_t)z * a.w_tile[b]];  // fixed order
         }
     }
     const float g = (tot / Bf + a.noise[col] * (a.h.dp_scale * (a.h.clip / n))) * a.obs_scale * factor;
@@ -838,15 +862,13 @@ static size_t vae_carve(const d3p_vae_model* m, uint32_t B, char* base, VaeWorks
     float* q;
     q = take(B * H); if (ws) ws->h1 = q;
     q = take(B * H); if (ws) ws->sg1 = q;
-    q = take(B * Z); if (ws) ws->zl = q;
-    q = take(B * Z); if (ws) ws->u = q;
+    q = take(B * 2 * Z); if (ws) { ws->zl = q; ws->u = q + Z; }    // [z_loc -> z | log z_std -> z_std]: B x 2 Z, row stride 2 Z
     q = take(B * Z); if (ws) ws->eps = q;
     q = take(B * H); if (ws) ws->h2 = q;
     q = take(B * H); if (ws) ws->sg2 = q;
     q = take(B * D); if (ws) ws->a = q;
     q = take(B * H); if (ws) ws->dh2 = q;
-    q = take(B * Z); if (ws) ws->dz = q;
-    q = take(B * Z); if (ws) ws->du = q;
+    q = take(B * 2 * Z); if (ws) { ws->dz = q; ws->du = q + Z; }  // [dz | du], likewise
     q = take(B * H); if (ws) ws->dh1 = q;
     q = take(B); if (ws) ws->lat = q;
     q = take(B); if (ws) ws->px_loss = q;
@@ -879,11 +901,16 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
     const dim3 rows(cdiv((uint64_t)B * 64, 256));
     // ---- encoder (guide)
     if ((rc = gemm(s, X, D, 1, params + L.W1, H, 1, ws.h1, H, Bi, H, D, params + L.b1, 1.f, 0, 0, ws.part, ws.part_floats, 1, ws.sg1))) return rc;
-    if ((rc = gemm(s, ws.h1, H, 1, params + L.Wl, Z, 1, ws.zl, Z, Bi, Z, H, params + L.bl, 1.f, 0, 0, ws.part, ws.part_floats))) return rc;
-    if ((rc = gemm(s, ws.h1, H, 1, params + L.Ws, Z, 1, ws.u, Z, Bi, Z, H, params + L.bs, 1.f, 0, 0, ws.part, ws.part_floats))) return rc;
-    hipLaunchKernelGGL(k_vae_latent, rows, dim3(256), 0, s, ws.zl, ws.u, eps, B, Z, ws.lat);  // zl := z, u := sd
+    // [z_loc | log z_std] = h1 [Wl | Ws] + [bl | bs] in ONE product of N = 2 Z: Ws lies H Z behind where Wl's columns Z .. 2 Z - 1
+    // would be, and bs likewise behind bl (flat layout: Wl, bl, Ws, bs)
+    const int ldz = 2 * Z;
+    const GemmJumps enc = {Z, 0x7fffffff, (long long)H * Z, 0, (long long)H * Z, 0};
+    if ((rc = gemm(s, ws.h1, H, 1, params + L.Wl, Z, 1, ws.zl, ldz, Bi, 2 * Z, H, params + L.bl, 1.f, 0, 0, ws.part, ws.part_floats, 0, nullptr,
+                   nullptr, &enc)))
+        return rc;
+    hipLaunchKernelGGL(k_vae_latent, rows, dim3(256), 0, s, ws.zl, ws.u, eps, B, Z, ldz, ws.lat);  // zl := z, u := sd
     // ---- decoder (model)
-    if ((rc = gemm(s, ws.zl, Z, 1, params + L.V1, H, 1, ws.h2, H, Bi, H, Z, params + L.c1, 1.f, 0, 0, nullptr, 0, 1, ws.sg2))) return rc;
+    if ((rc = gemm(s, ws.zl, ldz, 1, params + L.V1, H, 1, ws.h2, H, Bi, H, Z, params + L.c1, 1.f, 0, 0, nullptr, 0, 1, ws.sg2))) return rc;
     if ((rc = gemm(s, ws.h2, H, 1, params + L.V2, D, 1, ws.a, D, Bi, D, H, params + L.c2, 1.f, 0))) return rc;
     hipLaunchKernelGGL(k_vae_out, rows, dim3(256), 0, s, ws.a, X, mask, B, D, sc, (const float*)ws.lat, ws.px_loss);  // a := da
     return check_launch("d3p_vae forward");
@@ -911,30 +938,42 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     if ((rc = vae_enqueue_forward(s, m, params, X, mask, B, eps, sc, ws))) return rc;
     // ---- backward (data)
     if ((rc = gemm(s, ws.a, D, 1, params + L.V2, 1, D, ws.dh2, H, Bi, H, D, nullptr, 1.f, 0, 0, ws.part, ws.part_floats, 2, ws.sg2))) return rc;  // dpre2 = (da V2^T) . softplus'(pre2)
-    if ((rc = gemm(s, ws.dh2, H, 1, params + L.V1, 1, H, ws.dz, Z, Bi, Z, H, nullptr, 1.f, 0, 0, ws.part, ws.part_floats))) return rc;  // dpre2 V1^T
+    const int ldz = 2 * Z;
+    if ((rc = gemm(s, ws.dh2, H, 1, params + L.V1, 1, H, ws.dz, ldz, Bi, Z, H, nullptr, 1.f, 0, 0, ws.part, ws.part_floats))) return rc;  // dpre2 V1^T
     hipLaunchKernelGGL(k_vae_dlatent, ew((size_t)B * Z), dim3(256), 0, s, ws.dz, ws.du, (const float*)ws.zl, (const float*)ws.u, eps,
-                       (size_t)B * Z, sc);
-    if ((rc = gemm(s, ws.dz, Z, 1, params + L.Wl, 1, Z, ws.dh1, H, Bi, H, Z, nullptr, 1.f, 0))) return rc;  // dz Wl^T
-    if ((rc = gemm(s, ws.du, Z, 1, params + L.Ws, 1, Z, ws.dh1, H, Bi, H, Z, nullptr, 1.f, 1, 0, nullptr, 0, 2, ws.sg1))) return rc;  // dpre1 = (dz Wl^T + du Ws^T) . softplus'(pre1)
+                       (size_t)B * Z, Z, ldz, sc);
+    // dpre1 = ([dz | du] [Wl^T ; Ws^T]) . softplus'(pre1): ONE product of K = 2 Z (rows Z .. 2 Z - 1 of the stacked B are Ws^T,
+    // H Z behind where Wl^T's would be)
+    const GemmJumps dec = {0x7fffffff, Z, 0, (long long)H * Z, 0, 0};
+    if ((rc = gemm(s, ws.dz, ldz, 1, params + L.Wl, 1, Z, ws.dh1, H, Bi, H, 2 * Z, nullptr, 1.f, 0, 0, nullptr, 0, 2, ws.sg1, nullptr, &dec)))
+        return rc;
     // ---- per-example norms and clip factors; the rows of every delta come back scaled by c_i
     NormArgs na;
     na.X = X; na.h1 = ws.h1; na.z = ws.zl; na.h2 = ws.h2;
     na.dpre1 = ws.dh1; na.dz = ws.dz; na.du = ws.du; na.dpre2 = ws.dh2; na.da = ws.a;
-    na.mask = mask; na.B = B; na.D = D; na.H = H; na.Z = Z; na.clip = clip; na.cf = ws.cf; na.norms = norms_out;
+    na.mask = mask; na.B = B; na.D = D; na.H = H; na.Z = Z; na.ldz = ldz; na.clip = clip; na.cf = ws.cf; na.norms = norms_out;
     hipLaunchKernelGGL(k_vae_norms, rows, dim3(256), 4 * (size_t)(D + 2 * H + 2 * Z) * sizeof(float), s, na);
     // ---- clipped sums: weights  A^T (diag(c) Delta)  (GEMMs over the batch), biases = column sums
     // [W | b] of every layer is contiguous in the flat layout, so the bias gradient is row `in` of a GEMM whose A carries a
     // virtual row of ones
     float* S = ws.sums;
-    struct WG { const float* A; int in; const float* Bm; int out; size_t off; };
-    const WG wg[5] = {{ws.zl, Z, ws.dh2, H, L.V1}, {ws.h2, H, ws.a, D, L.V2}, {X, D, ws.dh1, H, L.W1}, {ws.h1, H, ws.dz, Z, L.Wl},
-                      {ws.h1, H, ws.du, Z, L.Ws}};
-    for (int b = 0; b < 5; ++b) {
+    // four products: V1, V2, W1 and [Wl | Ws] (B operand [dz | du], N = 2 Z; the Ws block of the sums lies H Z behind where
+    // columns Z .. 2 Z - 1 of a Z-wide C would be)
+    struct WG { const float* A; long long a_sk; int in; const float* Bm; int ldb; int out; int ldc; size_t off; const GemmJumps* j; int blk; };
+    const GemmJumps wls = {Z, 0x7fffffff, 0, 0, 0, (long long)H * Z};
+    const WG wg[4] = {{ws.zl, ldz, Z, ws.dh2, H, H, H, L.V1, nullptr, 0}, {ws.h2, H, H, ws.a, D, D, D, L.V2, nullptr, 1},
+                      {X, D, D, ws.dh1, H, H, H, L.W1, nullptr, 2}, {ws.h1, H, H, ws.dz, ldz, 2 * Z, Z, L.Wl, &wls, 3}};
+    for (int b = 0; b < 4; ++b) {
         float* part = w_splits ? ws.wpart + (size_t)D3P_WPART_SPLITS * wg[b].off : ws.part;
         const size_t part_floats = w_splits ? (size_t)D3P_WPART_SPLITS * (wg[b].in + 1) * wg[b].out : ws.part_floats;
-        if ((rc = gemm(s, wg[b].A, 1, wg[b].in, wg[b].Bm, wg[b].out, 1, S + wg[b].off, wg[b].out, wg[b].in + 1, wg[b].out, Bi, nullptr, 1.f, 0, 1,
-                       part, part_floats, 0, nullptr, w_splits ? w_splits + b : nullptr)))
+        int left = 0;
+        if ((rc = gemm(s, wg[b].A, 1, wg[b].a_sk, wg[b].Bm, wg[b].ldb, 1, S + wg[b].off, wg[b].ldc, wg[b].in + 1, wg[b].out, Bi, nullptr, 1.f, 0, 1,
+                       part, part_floats, 0, nullptr, w_splits ? &left : nullptr, wg[b].j)))
             return rc;
+        if (w_splits) {
+            w_splits[wg[b].blk] = left;
+            if (b == 3) w_splits[4] = left;
+        }
     }
     hipLaunchKernelGGL(k_vae_loss_n, dim3(1), dim3(256), 0, s, (const float*)ws.px_loss, mask, B, S + L.P);
     return check_launch("d3p_vae sums");
@@ -1106,11 +1145,20 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
     f.wpart = w_splits ? ws.wpart : nullptr;
     {
         const size_t blk[6] = {L.V1, L.V2, L.W1, L.Wl, L.Ws, L.P};  // [W | b] blocks of the flat layout
+        const int outs[5] = {model->H, model->D, model->H, model->Z, model->Z};
         for (int b = 0; b < 5; ++b) {
             f.w_off[b] = (uint32_t)blk[b];
-            f.w_mn[b] = (uint32_t)(blk[b + 1] - blk[b]);
+            f.w_base[b] = (uint32_t)(D3P_WPART_SPLITS * blk[b]);
+            f.w_tile[b] = (uint32_t)(blk[b + 1] - blk[b]);
+            f.w_ld[b] = f.w_out[b] = (uint32_t)outs[b];
+            f.w_coff[b] = 0;
             f.w_splits[b] = w_splits ? w_splits[b] : 0;
         }
+        // blocks 3, 4 (Wl, Ws) come from ONE product with N = 2 Z: shared tiles of (H + 1) x 2 Z in the region of block 3
+        f.w_tile[3] = f.w_tile[4] = f.w_tile[3] + f.w_tile[4];
+        f.w_ld[3] = f.w_ld[4] = 2u * (uint32_t)model->Z;
+        f.w_base[4] = f.w_base[3];
+        f.w_coff[4] = (uint32_t)model->Z;
         f.w_off[5] = (uint32_t)L.P;
     }
     f.noise = ws.noise;
