@@ -170,6 +170,7 @@ SIGNATURES = {
     "d3p_dpvi_logreg_fused_step": (C.c_int, [_V, _PM, _PH, _PS, _PB, _U32, _U32, C.c_int, C.c_int, _U32, C.c_int, _V, _V,
                                              _V, C.c_int, _V, _SZ]),
     "d3p_dpvi_logreg_run": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _U32, _V, _V, _SZ]),
+    "d3p_dpvi_logreg_run_from": (C.c_int, [_V, _PM, _PH, _PS, _PS, _PB, _U32, _V, _V, _U32, _V, _V, _SZ]),
     "d3p_dpvi_logreg_time_main_kernel": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _V, _SZ, C.c_int,
                                                    C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "d3p_synth_logreg": (C.c_int, [_V, _U32, _U64, _U64, _I32, _V, _V]),
@@ -194,7 +195,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.d3p_abi_version() != 3:
+        if lib.d3p_abi_version() != 4:
             raise D3PError("libd3p_hip.so ABI version mismatch")
         _lib = lib
     return _lib

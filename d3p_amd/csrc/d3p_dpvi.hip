@@ -160,20 +160,41 @@ __global__ void __launch_bounds__(64) k_chain(Sched* __restrict__ sched, StepSlo
 //   and copies the run's status words to pinned host memory.  Replaces the flush launch of the step kernel + k_sched_finish
 //   + the device-to-host copy of d3p_dpvi_logreg_run_status.
 // ------------------------------------------------------------------------------------------
+struct RunInitCopy {  // d3p_dpvi_logreg_run_from: the optimiser state is copied from `src` into the run's arrays here
+    const float* src[3];
+    float* dst[3];
+    int32_t* step_dst;
+    uint32_t* batch_index_dst;  // the run's batch-index word (by-value start)
+    uint32_t batch0;
+    int n, by_value;
+    uint32_t* bar;       // arrival counters of the first chained launch, zeroed here (nullable)
+    uint32_t bar_words;
+};
+
 __global__ void __launch_bounds__(256) k_run_init(const uint32_t* __restrict__ state_key, const int32_t* __restrict__ adam_step,
                                                   const uint32_t* __restrict__ batch_index, Sched* __restrict__ sched,
                                                   StepSlot* __restrict__ slots, int K, long long* __restrict__ acc, uint32_t acc_words,
-                                                  uint32_t* __restrict__ status)
+                                                  uint32_t* __restrict__ status, RunInitCopy cp)
 {
     const int tid = threadIdx.x;
-    if (tid >= 64) {  // waves 1..3: zero the accumulators (3 x R x cols int64) and the status words
+    if (tid >= 64) {  // waves 1..3: zero the accumulators (3 x R x cols int64) and the status words; copy the state if asked to
         for (uint32_t i = tid - 64; i < acc_words; i += 192) acc[i] = 0;
         if (tid < 64 + 16) status[tid - 64] = 0u;
+        if (cp.bar)
+            for (uint32_t i = tid - 64; i < cp.bar_words; i += 192) cp.bar[i] = 0u;
+        if (cp.dst[0]) {
+            for (int j = 0; j < 3; ++j)
+                for (int i = tid - 64; i < cp.n; i += 192) cp.dst[j][i] = cp.src[j][i];
+            if (tid == 64) {
+                *cp.step_dst = *adam_step;
+                if (cp.by_value) *cp.batch_index_dst = cp.batch0;
+            }
+        }
         return;
     }
     const int lane = tid, q = lane & 3, child = (lane >> 2) < 3 ? (lane >> 2) : 0;
     const int32_t adam0 = *adam_step;
-    const uint32_t batch0 = batch_index ? *batch_index : 0u;
+    const uint32_t batch0 = cp.by_value ? cp.batch0 : (batch_index ? *batch_index : 0u);
     const uint32_t p0 = state_key[q];
     uint32_t p1 = state_key[4 + q], p2 = state_key[8 + q], p3 = state_key[12 + q];
     for (int t = 0; t < K; ++t) {
@@ -205,6 +226,7 @@ __global__ void __launch_bounds__(256) k_run_init(const uint32_t* __restrict__ s
         sched->batch_i = batch0 + (uint32_t)K;
     }
 }
+
 
 struct FlushArgs {
     const long long* acc_prev;  // nrep x cols: the local replicas, or the one row of world sums of a data-parallel chained run
@@ -302,13 +324,14 @@ struct SamplerArgs {
     uint64_t row_lo, row_hi;  // rows held by this rank: sample keys are only needed for those
 };
 
-__global__ void __launch_bounds__(256) k_sampler(SamplerArgs a)
+// The sampler work of x-block bx (of gx) for step t of the batch.
+__device__ __forceinline__ void sampler_block(const SamplerArgs& a, int bx, int gx, int t)
 {
     __shared__ uint32_t sh_key[2][16], sh_jax[2], sh_rc[32];
     const int tid = threadIdx.x;
-    const int t = blockIdx.y;
     StepSlot* slot = a.slots + t;
-    const bool aux = blockIdx.x == gridDim.x - 1;
+    const bool aux = bx == gx - 1;
+    const uint32_t slot_batch_i = slot->batch_i;
     if (!aux) {
         if (tid == 0) {  // convert_to_jax_rng_key(gradient_key) (svi.py:259; random/__init__.py:155)
             uint32_t k[16], o[16];
@@ -319,7 +342,7 @@ __global__ void __launch_bounds__(256) k_sampler(SamplerArgs a)
         } else if (tid == 64 && a.kind == D3P_BATCH_FEISTEL) {  // fold_in(batchifier_state, i) (minibatch.py:230)
             uint32_t k[16], c[16];
             load_key(a.batch_key, k);
-            derive_child(k, 0u, slot->batch_i, D3P_TAG_FOLD, c);
+            derive_child(k, 0u, slot_batch_i, D3P_TAG_FOLD, c);
 #pragma unroll
             for (int w = 0; w < 16; ++w) sh_key[0][w] = c[w];
         }
@@ -337,7 +360,7 @@ __global__ void __launch_bounds__(256) k_sampler(SamplerArgs a)
             }
         }
         __syncthreads();
-        const uint32_t p = blockIdx.x * blockDim.x + tid;
+        const uint32_t p = (uint32_t)bx * blockDim.x + tid;
         if (p < a.B) {
             bool owned = true;
             if (a.kind == D3P_BATCH_FEISTEL) {
@@ -371,7 +394,7 @@ __global__ void __launch_bounds__(256) k_sampler(SamplerArgs a)
         if (a.batch_key) {
             uint32_t k[16], c[16];
             load_key(a.batch_key, k);
-            derive_child(k, 0u, slot->batch_i, D3P_TAG_FOLD, c);
+            derive_child(k, 0u, slot_batch_i, D3P_TAG_FOLD, c);
 #pragma unroll
             for (int w = 0; w < 16; ++w) slot->batch_key[w] = c[w];
         }
@@ -400,6 +423,8 @@ __global__ void __launch_bounds__(256) k_sampler(SamplerArgs a)
         }
     }
 }
+
+__global__ void __launch_bounds__(256) k_sampler(SamplerArgs a) { sampler_block(a, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y); }
 
 // ------------------------------------------------------------------------------------------
 // dense list of the batch positions a rank processes: valid (p < counts[1]) and row in [row_lo, row_hi).
@@ -687,6 +712,9 @@ struct Ctx {
     MainGeom g;
     int D, P;
     uint64_t items_expected;  // batch positions this rank expects to process per step (B, or its share of a row-sharded batch)
+    const d3p_dpsvi_state* from = nullptr;  // d3p_dpvi_logreg_run_from: the run starts from THIS state (read only), st receives the result
+    bool batch0_by_value = false;           // ... and from batch index batch0 instead of *src->batch_index
+    uint32_t batch0 = 0;
     Workspace ws2;  // second slot buffer (slots / idx / skeys / noise) for the pipelined run loop
 };
 
@@ -727,9 +755,9 @@ static int enqueue_batch_prep(const Ctx& c, int K)
     return enqueue_sampler(c, K);
 }
 
-static int enqueue_sampler(const Ctx& c, int K)
+static void fill_sampler_args(const Ctx& c, SamplerArgs* out)
 {
-    SamplerArgs sa;
+    SamplerArgs& sa = *out;
     sa.slots = c.ws.slots;
     sa.batch_key = c.src->kind == D3P_BATCH_EXPLICIT ? nullptr : c.src->batch_key;
     sa.idx = c.ws.idx;
@@ -746,6 +774,12 @@ static int enqueue_sampler(const Ctx& c, int K)
     sa.b2 = c.h->b2;
     sa.row_lo = c.src->kind == D3P_BATCH_EXPLICIT ? 0 : c.src->row_lo;
     sa.row_hi = c.src->kind == D3P_BATCH_EXPLICIT ? ~0ull : c.src->row_hi;
+}
+
+static int enqueue_sampler(const Ctx& c, int K)
+{
+    SamplerArgs sa;
+    fill_sampler_args(c, &sa);
     hipLaunchKernelGGL(k_sampler, dim3(cdiv(c.src->B, 256) + 1, K), dim3(256), 0, c.s, sa);
     int rc = check_launch("k_sampler");
     if (rc) return rc;
@@ -1082,8 +1116,9 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
     cf.abort_flag = run_status_words(c.ws);
     cf.chain_slots = chain_slots;
     cf.K_next = chain_slots ? K_next : 0;
-    // arrival counters of this launch (the abort flag behind them is sticky for the whole run)
-    D3P_HIP_TRY(hipMemsetAsync(c.ws.chain_bar, 0, (size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS * sizeof(uint32_t), c.s));
+    // arrival counters of this launch (the abort flag behind them is sticky for the whole run); the first launch of a run finds
+    // them zeroed by k_run_init
+    if (g0 > 0) D3P_HIP_TRY(hipMemsetAsync(c.ws.chain_bar, 0, (size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS * sizeof(uint32_t), c.s));
     if (use_persistent_steps(c)) {
         static const bool stamps = getenv("D3P_PERSIST_STAMPS") != nullptr;  // developer diagnostic, read once
         if (stamps) {
@@ -1352,7 +1387,6 @@ static int enqueue_xchg(hipStream_t s, Xchg* x, long long* acc, int R, uint32_t*
     return check_launch("k_xchg");
 }
 
-static int enqueue_sampler(const Ctx& c, int K);
 static int enqueue_chain(const Ctx& c, int K);
 
 // comm != nullptr: data-parallel run -- after every step launch the rank's fixed-point accumulator (R x (P + 2) int64) is
@@ -1378,12 +1412,39 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     cb[1].ws.stamps = c.ws.stamps;
     if (num_steps == 0) {  // nothing to run: the key and the status words are still defined afterwards
         D3P_HIP_TRY(hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s));
-        D3P_HIP_TRY(hipMemcpyAsync(key_out, c.st->rng_key + 16 * (c.st->key_slot & 1), 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice, c.s));
+        const d3p_dpsvi_state* st0 = c.from ? c.from : c.st;
+        D3P_HIP_TRY(hipMemcpyAsync(key_out, st0->rng_key + 16 * (st0->key_slot & 1), 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice, c.s));
+        if (c.from) {
+            D3P_HIP_TRY(hipMemcpyAsync(c.st->params, c.from->params, c.P * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+            D3P_HIP_TRY(hipMemcpyAsync(c.st->adam_m, c.from->adam_m, c.P * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+            D3P_HIP_TRY(hipMemcpyAsync(c.st->adam_v, c.from->adam_v, c.P * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+            D3P_HIP_TRY(hipMemcpyAsync(c.st->step, c.from->step, sizeof(int32_t), hipMemcpyDeviceToDevice, c.s));
+        }
         return D3P_OK;
     }
-    hipLaunchKernelGGL(k_run_init, dim3(1), dim3(256), 0, c.s, (const uint32_t*)(c.st->rng_key + 16 * (c.st->key_slot & 1)),
-                       (const int32_t*)c.st->step, sampled ? (const uint32_t*)c.src->batch_index : nullptr, c.ws.sched, cb[0].ws.slots,
-                       batch_len(0), c.ws.acc, acc_words, run_status_words(c.ws));
+    RunInitCopy cp;
+    memset(&cp, 0, sizeof(cp));
+    const d3p_dpsvi_state* st0 = c.from ? c.from : c.st;  // where the run starts from
+    if (c.from) {
+        cp.src[0] = c.from->params; cp.src[1] = c.from->adam_m; cp.src[2] = c.from->adam_v;
+        cp.dst[0] = c.st->params; cp.dst[1] = c.st->adam_m; cp.dst[2] = c.st->adam_v;
+        cp.step_dst = c.st->step;
+        cp.n = c.P;
+        cp.by_value = c.batch0_by_value ? 1 : 0;
+        cp.batch0 = c.batch0;
+        cp.batch_index_dst = c.src->batch_index;
+    }
+    const bool init_zeroes_bar = !comm && use_chained_steps(c);  // the first chained launch's arrival counters: no memset launch
+    if (init_zeroes_bar) {
+        cp.bar = c.ws.chain_bar;
+        cp.bar_words = (uint32_t)((batch_len(0) + 1) * D3P_BAR_WORDS);
+    }
+    // (Measured and not kept: the sampler's workgroups inside this launch, each waiting for the key chain to pass its step -- the
+    // launch then takes 36 us for 20 steps, exactly the 18 + 17 us of the two launches: the sampler's ~15 us are LATENCY of the
+    // last step's blocks (serial ChaCha derivations, Feistel walk, six dependent threefry calls), not throughput.)
+    hipLaunchKernelGGL(k_run_init, dim3(1), dim3(256), 0, c.s, (const uint32_t*)(st0->rng_key + 16 * (st0->key_slot & 1)),
+                       (const int32_t*)st0->step, sampled ? (const uint32_t*)c.src->batch_index : nullptr, c.ws.sched, cb[0].ws.slots,
+                       batch_len(0), c.ws.acc, acc_words, run_status_words(c.ws), cp);
     if ((rc = check_launch("k_run_init"))) return rc;
     if ((rc = enqueue_sampler(cb[0], batch_len(0)))) return rc;
     static const bool no_piggy = getenv("D3P_NO_CHAIN_PIGGYBACK") != nullptr;  // developer switch, read once
@@ -1825,6 +1886,47 @@ int d3p_dpvi_logreg_run_dist(void* stream, void* comm, const d3p_logreg_model* m
     D3P_REQUIRE(src->kind != D3P_BATCH_EXPLICIT, "d3p_dpvi_logreg_run_dist: needs an on-device sampler (Feistel or Poisson)");
     if (comm && !rccl_api()) return fail(D3P_E_UNSUPPORTED, "d3p_dpvi_logreg_run_dist: librccl.so could not be loaded");
     return run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev, (ncclComm_t)comm);
+}
+
+// d3p_dpvi_logreg_run as a function of an immutable state (DPSVI.update / the fori_loop body return a NEW state,
+// svi.py:395-434): the run starts from `from` (key slot from->key_slot, optimiser state, step counter: read only) and from
+// batch index first_batch (by value), and leaves its result in `state` (key in slot num_steps & 1 of state->rng_key; its
+// key_slot is taken as 0) -- the copies and the batch-index word that the caller would otherwise prepare with four small
+// launches happen inside the run's first kernel.  Fused-step configurations only (the default).
+int d3p_dpvi_logreg_run_from(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                             const d3p_dpsvi_state* state, const d3p_dpsvi_state* from, const d3p_batch_source* src,
+                             uint32_t first_batch, const float* X_dev, const float* y_dev, uint32_t num_steps, float* losses_dev,
+                             void* workspace_dev, size_t workspace_bytes)
+{
+    D3P_REQUIRE(from && from->rng_key && from->params && from->adam_m && from->adam_v && from->step, "d3p_dpvi_logreg_run_from: null source state");
+    D3P_REQUIRE(src && workspace_dev, "d3p_dpvi_logreg_run_from: null pointer");
+    d3p_batch_source s2 = *src;
+    if (s2.kind != D3P_BATCH_EXPLICIT && !s2.batch_index) s2.batch_index = reinterpret_cast<uint32_t*>(workspace_dev);  // placeholder for validate(); set below
+    Ctx c;
+    int rc = make_ctx(&c, stream, model, hyper, state, &s2, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    D3P_REQUIRE(X_dev, "null data pointer");
+    if (int rcm = validate_model(model, y_dev, "d3p_dpvi_logreg_run_from")) return rcm;
+    D3P_REQUIRE(src->row_lo == 0 && src->row_hi == src->n_rows, "d3p_dpvi_logreg_run_from is the single-GPU path");
+    D3P_REQUIRE(state->key_slot == 0, "d3p_dpvi_logreg_run_from: state->key_slot must be 0");
+    // the run's own batch-index word: a spare word of the workspace (k_run_init stores first_batch there, k_flush advances it)
+    s2.batch_index = reinterpret_cast<uint32_t*>(c.ws.scratch_state + 3 * c.P + 2);
+    if (!use_fused_step(c)) {  // two-kernel steps (wide rows, D3P_NO_FUSED_STEP): copy here, then the in-place run
+        hipStream_t hs = (hipStream_t)stream;
+        const size_t pb = (size_t)c.P * sizeof(float);
+        D3P_HIP_TRY(hipMemcpyAsync(state->params, from->params, pb, hipMemcpyDeviceToDevice, hs));
+        D3P_HIP_TRY(hipMemcpyAsync(state->adam_m, from->adam_m, pb, hipMemcpyDeviceToDevice, hs));
+        D3P_HIP_TRY(hipMemcpyAsync(state->adam_v, from->adam_v, pb, hipMemcpyDeviceToDevice, hs));
+        D3P_HIP_TRY(hipMemcpyAsync(state->step, from->step, sizeof(int32_t), hipMemcpyDeviceToDevice, hs));
+        D3P_HIP_TRY(hipMemcpyAsync(state->rng_key, from->rng_key + 16 * (from->key_slot & 1), 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice, hs));
+        D3P_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)s2.batch_index, (int)first_batch, 1, hs));
+        return d3p_dpvi_logreg_run(stream, model, hyper, state, &s2, X_dev, y_dev, num_steps, losses_dev, workspace_dev, workspace_bytes);
+    }
+    c.src = &s2;
+    c.from = from;
+    c.batch0_by_value = true;
+    c.batch0 = first_batch;
+    return run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev);
 }
 
 int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,

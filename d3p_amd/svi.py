@@ -708,18 +708,37 @@ class DPSVI:
         dev = X.device
         model = self._model_struct(d, kwargs, svi_state.observation_scale)
         hyper = self._hyper()
-        step, params, m, v = _fresh_optim_state(svi_state.optim_state)
-        keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
-        keybuf[0].copy_(svi_state.rng_key.reshape(16))
         bkey = batchifier_state.contiguous()
-        bidx = torch.full((1,), int(first_batch), dtype=torch.int32, device=dev)   # (a fill kernel: no host-to-device copy + sync)
-        src = BatchSource(info.kind, info.batch_size, float(info.q), int(info.suppress), bkey.data_ptr(),
-                          bidx.data_ptr(), None, N, 0, N)
-        st = self._state_struct(keybuf, 0, (step, params, m, v))
-        ws = self._workspace(lib.d3p_dpvi_logreg_workspace(C.byref(model), C.byref(src)), dev)
         losses = torch.empty(max(num_steps, 1), dtype=torch.float32, device=dev)
-        check(lib.d3p_dpvi_logreg_run(stream_ptr(), C.byref(model), C.byref(hyper), C.byref(st), C.byref(src),
-                                      ptr(X), ptr(y), int(num_steps), ptr(losses), ptr(ws), ws.numel()))
+        step0, params0, m0, v0 = svi_state.optim_state
+        key0 = svi_state.rng_key.reshape(16)
+        n = params0.numel()
+        if (params0.dtype == m0.dtype == v0.dtype == torch.float32 and m0.numel() == n
+                and v0.numel() == n and params0.is_contiguous() and m0.is_contiguous() and v0.is_contiguous()
+                and key0.is_contiguous() and key0.dtype == torch.uint32 and step0.dtype == torch.int32):
+            # the new state is written by the run itself (d3p_dpvi_logreg_run_from copies the old one inside its first kernel):
+            # no copy / fill launches on the host's enqueue path -- they were ~80 us of a 20-step run
+            flat = torch.empty(3 * n, dtype=torch.float32, device=dev)
+            step, params, m, v = torch.empty_like(step0), flat[:n].view_as(params0), flat[n:2 * n].view_as(m0), flat[2 * n:].view_as(v0)
+            keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
+            bidx = None
+            src = BatchSource(info.kind, info.batch_size, float(info.q), int(info.suppress), bkey.data_ptr(), None, None, N, 0, N)
+            st = self._state_struct(keybuf, 0, (step, params, m, v))
+            frm = self._state_struct(key0, 0, (step0, params0, m0, v0))
+            ws = self._workspace(lib.d3p_dpvi_logreg_workspace(C.byref(model), C.byref(src)), dev)
+            check(lib.d3p_dpvi_logreg_run_from(stream_ptr(), C.byref(model), C.byref(hyper), C.byref(st), C.byref(frm), C.byref(src),
+                                               int(first_batch), ptr(X), ptr(y), int(num_steps), ptr(losses), ptr(ws), ws.numel()))
+        else:
+            step, params, m, v = _fresh_optim_state(svi_state.optim_state)
+            keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
+            keybuf[0].copy_(key0)
+            bidx = torch.full((1,), int(first_batch), dtype=torch.int32, device=dev)   # (a fill kernel: no host-to-device copy + sync)
+            src = BatchSource(info.kind, info.batch_size, float(info.q), int(info.suppress), bkey.data_ptr(),
+                              bidx.data_ptr(), None, N, 0, N)
+            st = self._state_struct(keybuf, 0, (step, params, m, v))
+            ws = self._workspace(lib.d3p_dpvi_logreg_workspace(C.byref(model), C.byref(src)), dev)
+            check(lib.d3p_dpvi_logreg_run(stream_ptr(), C.byref(model), C.byref(hyper), C.byref(st), C.byref(src),
+                                          ptr(X), ptr(y), int(num_steps), ptr(losses), ptr(ws), ws.numel()))
         self._last_run = (model, src, ws, (bkey, bidx))   # what last_run_status() needs (keeps the buffers alive)
         if check_status:
             aborted, _ = self.last_run_status()

@@ -34,7 +34,7 @@ extern "C" {
 #define D3P_E_UNSUPPORTED (-3)
 #define D3P_E_WORKSPACE (-4)
 
-#define D3P_ABI_VERSION 3
+#define D3P_ABI_VERSION 4
 
 int d3p_abi_version(void);
 const char* d3p_last_error(void);
@@ -357,6 +357,17 @@ int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_d
                         const d3p_dpsvi_state* state, const d3p_batch_source* src,
                         const float* X_dev, const float* y_dev, uint32_t num_steps,
                         float* losses_dev, void* workspace_dev, size_t workspace_bytes);
+
+/* The same run as a function of an immutable state (DPSVI.update returns a NEW state, svi.py:395-434; the epoch body of
+ * examples/logistic_regression.py:149-160 threads it through fori_loop): it starts from `from` (rng key in slot
+ * from->key_slot, optimiser state and step counter; read only) and from batch index `first_batch` (by value;
+ * src->batch_index may be NULL) and leaves the result in `state` (state->key_slot must be 0; the final key is in slot
+ * num_steps & 1 of state->rng_key).  The state copy and the batch-index word are written by the run's first kernel, so a
+ * caller with functional semantics needs no launches of its own around the call.  ABI 4. */
+int d3p_dpvi_logreg_run_from(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                             const d3p_dpsvi_state* state, const d3p_dpsvi_state* from, const d3p_batch_source* src,
+                             uint32_t first_batch, const float* X_dev, const float* y_dev, uint32_t num_steps,
+                             float* losses_dev, void* workspace_dev, size_t workspace_bytes);
 
 /* Times only the dominant kernel (fused gradient/clip/sum) of one step over `reps` launches on
  * `stream` (host out-pointers):
