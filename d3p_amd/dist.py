@@ -51,7 +51,8 @@ class HipEngine:
     def _setup(self, state, batch_key, first_batch):
         self.model = self.svi._model_struct(self.d, self.model_kwargs, state.observation_scale)
         self.hyper = self.svi._hyper()
-        self.step, self.params, self.m, self.v = (t.clone() for t in state.optim_state)
+        from .svi import _fresh_optim_state
+        self.step, self.params, self.m, self.v = _fresh_optim_state(state.optim_state)   # (one copy kernel for params, m, v)
         self.keybuf = torch.empty((2, 16), dtype=torch.uint32, device=self.dev)
         self.keybuf[0].copy_(state.rng_key.reshape(16))
         self.bkey = batch_key.contiguous()
@@ -60,7 +61,8 @@ class HipEngine:
                                self.bidx.data_ptr(), None, self.n, self.lo, self.hi)
         lib = _lib.load()
         nbytes = lib.d3p_dpvi_logreg_workspace(C.byref(self.model), C.byref(self.src))
-        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        if getattr(self, "ws", None) is None or self.ws.numel() < nbytes:   # kept across runs: per-run host time matters for short runs
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
         self.loss = torch.empty(1, dtype=torch.float32, device=self.dev)
         self.observation_scale = state.observation_scale
 
@@ -264,7 +266,7 @@ def run_steps_native(engine, state, batch_key, first_batch, num_steps, comm=None
                                                    ptr(engine.X), ptr(engine.y), int(num_steps), ptr(losses), ptr(engine.ws),
                                                    engine.ws.numel()))
     new_state = DPSVIState((engine.step, engine.params, engine.m, engine.v),
-                           engine.keybuf[int(num_steps) & 1].reshape(4, 4).clone(), engine.observation_scale)
+                           engine.keybuf[int(num_steps) & 1].reshape(4, 4), engine.observation_scale)   # (keybuf is this run's own)
     return new_state, (losses[:int(num_steps)] if collect_losses else None)
 
 
