@@ -141,6 +141,19 @@ __device__ __forceinline__ void derive_child_quad(const uint32_t* __restrict__ p
     chacha20_block_quad(a, b, c, d);
 }
 
+// Block `blk` of the keystream of `key` in quad form (keystream_block above): on return lane q of the quad holds words
+// q, 4 + q, 8 + q, 12 + q of the block in (a, b, c, d).  `key` may live in global memory or LDS.
+__device__ __forceinline__ void keystream_block_quad(const uint32_t* __restrict__ key, uint32_t blk, uint32_t& a, uint32_t& b, uint32_t& c,
+                                                     uint32_t& d)
+{
+    const int q = threadIdx.x & 3;
+    a = key[q];
+    b = key[4 + q];
+    c = key[8 + q];
+    d = key[12 + q] + (q == 0 ? blk : 0u);
+    chacha20_block_quad(a, b, c, d);
+}
+
 // the same with the lane's four parent words (rows q, 4+q, 8+q, 12+q of the parent state) already in registers
 __device__ __forceinline__ void derive_child_quad_regs(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t child,
                                                        uint32_t tag, uint32_t data, uint32_t& a, uint32_t& b)

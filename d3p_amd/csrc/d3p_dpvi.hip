@@ -325,38 +325,41 @@ struct SamplerArgs {
 };
 
 // The sampler work of x-block bx (of gx) for step t of the batch.
+// (every ChaCha block of the sampler runs on a quad of lanes -- chacha20_block_quad, ~310 instructions instead of ~970 for the
+// one-lane form: the sampler is a chain of three dependent derivations per block, i.e. latency, and sits on the start-up path
+// of every run)
 __device__ __forceinline__ void sampler_block(const SamplerArgs& a, int bx, int gx, int t)
 {
     __shared__ uint32_t sh_key[2][16], sh_jax[2], sh_rc[32];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, quad = tid >> 2, q = tid & 3;
     StepSlot* slot = a.slots + t;
     const bool aux = bx == gx - 1;
     const uint32_t slot_batch_i = slot->batch_i;
+    auto store_child = [&](uint32_t* dst, const uint32_t* parent, uint32_t ka, uint32_t kb) {  // child key = constants | block words 0..7 | 0
+        dst[q] = parent[q];
+        dst[4 + q] = ka;
+        dst[8 + q] = kb;
+        dst[12 + q] = 0u;
+    };
     if (!aux) {
-        if (tid == 0) {  // convert_to_jax_rng_key(gradient_key) (svi.py:259; random/__init__.py:155)
-            uint32_t k[16], o[16];
-            load_key(slot->grad_key, k);
-            keystream_block(k, 0u, o);
-            sh_jax[0] = o[0];
-            sh_jax[1] = o[1];
-        } else if (tid == 64 && a.kind == D3P_BATCH_FEISTEL) {  // fold_in(batchifier_state, i) (minibatch.py:230)
-            uint32_t k[16], c[16];
-            load_key(a.batch_key, k);
-            derive_child(k, 0u, slot_batch_i, D3P_TAG_FOLD, c);
-#pragma unroll
-            for (int w = 0; w < 16; ++w) sh_key[0][w] = c[w];
+        if (quad == 0) {  // convert_to_jax_rng_key(gradient_key) (svi.py:259; random/__init__.py:155): words 0, 1 of block 0
+            uint32_t ka, kb, kc, kd;
+            keystream_block_quad(slot->grad_key, 0u, ka, kb, kc, kd);
+            if (q < 2) sh_jax[q] = ka;
+        } else if (quad == 16 && a.kind == D3P_BATCH_FEISTEL) {  // fold_in(batchifier_state, i) (minibatch.py:230)
+            uint32_t ka, kb;
+            derive_child_quad(a.batch_key, 0u, D3P_TAG_FOLD, slot_batch_i, ka, kb);
+            store_child(sh_key[0], a.batch_key, ka, kb);
         }
         __syncthreads();
-        if ((tid == 64 || tid == 128) && a.kind == D3P_BATCH_FEISTEL) {  // round constants (util.py:240-246)
-            const uint32_t b = tid == 64 ? 0u : 1u;
-            uint32_t k[16], o[16];
+        if ((quad == 16 || quad == 32) && a.kind == D3P_BATCH_FEISTEL) {  // round constants: keystream blocks 0, 1 (util.py:240-246)
+            const uint32_t b = quad == 16 ? 0u : 1u;
+            uint32_t w[4];
+            keystream_block_quad(sh_key[0], b, w[0], w[1], w[2], w[3]);
 #pragma unroll
-            for (int w = 0; w < 16; ++w) k[w] = sh_key[0][w];
-            keystream_block(k, b, o);
-#pragma unroll
-            for (int w = 0; w < 16; ++w) {
-                const int g = 16 * (int)b + w;
-                if (g < 30) sh_rc[g] = (g % 3 == 0) ? (o[w] | 1u) : o[w];
+            for (int i = 0; i < 4; ++i) {
+                const int g = 16 * (int)b + 4 * i + q;
+                if (g < 30) sh_rc[g] = (g % 3 == 0) ? (w[i] | 1u) : w[i];
             }
         }
         __syncthreads();
@@ -378,48 +381,42 @@ __device__ __forceinline__ void sampler_block(const SamplerArgs& a, int bx, int 
         return;
     }
     // ---- aux block: per-site keys split(perturbation_key, 2) (svi.py:491), then the normals
-    if (tid < 2) {
-        uint32_t k[16], c[16];
-        load_key(slot->pert_key, k);
-        derive_child(k, (uint32_t)tid, 0u, D3P_TAG_SPLIT, c);
-#pragma unroll
-        for (int w = 0; w < 16; ++w) sh_key[tid][w] = c[w];
-    } else if (tid == 64) {
-        uint32_t k[16], o[16];
-        load_key(slot->grad_key, k);
-        keystream_block(k, 0u, o);
-        slot->jax_key[0] = o[0];
-        slot->jax_key[1] = o[1];
-    } else if (tid == 128) {
+    if (quad < 2) {
+        uint32_t ka, kb;
+        derive_child_quad(slot->pert_key, (uint32_t)quad, D3P_TAG_SPLIT, 0u, ka, kb);
+        store_child(sh_key[quad], slot->pert_key, ka, kb);
+    } else if (quad == 16) {
+        uint32_t ka, kb, kc, kd;
+        keystream_block_quad(slot->grad_key, 0u, ka, kb, kc, kd);
+        if (q < 2) slot->jax_key[q] = ka;
+    } else if (quad == 32) {
         if (a.batch_key) {
-            uint32_t k[16], c[16];
-            load_key(a.batch_key, k);
-            derive_child(k, 0u, slot_batch_i, D3P_TAG_FOLD, c);
-#pragma unroll
-            for (int w = 0; w < 16; ++w) slot->batch_key[w] = c[w];
+            uint32_t ka, kb;
+            derive_child_quad(a.batch_key, 0u, D3P_TAG_FOLD, slot_batch_i, ka, kb);
+            store_child(slot->batch_key, a.batch_key, ka, kb);
         }
-        if (a.kind != D3P_BATCH_POISSON) {  // POISSON: written by the select kernels
-            slot->counts[0] = a.B;
-            slot->counts[1] = a.B;
+        if (q == 0) {
+            if (a.kind != D3P_BATCH_POISSON) {  // POISSON: written by the select kernels
+                slot->counts[0] = a.B;
+                slot->counts[1] = a.B;
+            }
+            const float ip1 = (float)(slot->adam_i + 1);
+            slot->bc1 = 1.0f - powf(a.b1, ip1);
+            slot->bc2 = 1.0f - powf(a.b2, ip1);
         }
-        const float ip1 = (float)(slot->adam_i + 1);
-        slot->bc1 = 1.0f - powf(a.b1, ip1);
-        slot->bc2 = 1.0f - powf(a.b2, ip1);
     }
     __syncthreads();
-    // noise[site * D + e] = normal(site_key[site])[e]  (svi.py:487): ChaCha block e/16, word e%16
+    // noise[site * D + e] = normal(site_key[site])[e]  (svi.py:487): ChaCha block e/16, word e%16; one quad per block
     const int blocks_per_site = (a.D + 15) / 16;
-    for (int j = tid; j < 2 * blocks_per_site; j += blockDim.x) {
+    for (int j = quad; j < 2 * blocks_per_site; j += (int)blockDim.x / 4) {
         const int site = j / blocks_per_site, b = j % blocks_per_site;
-        uint32_t k[16], o[16];
-#pragma unroll
-        for (int w = 0; w < 16; ++w) k[w] = sh_key[site][w];
-        keystream_block(k, (uint32_t)b, o);
+        uint32_t w[4];
+        keystream_block_quad(sh_key[site], (uint32_t)b, w[0], w[1], w[2], w[3]);
         float* dst = a.noise + (size_t)t * 2 * a.D + (size_t)site * a.D;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int e = 16 * b + w;
-            if (e < a.D) dst[e] = bits_to_normal(o[w]);
+        for (int i = 0; i < 4; ++i) {
+            const int e = 16 * b + 4 * i + q;
+            if (e < a.D) dst[e] = bits_to_normal(w[i]);
         }
     }
 }
