@@ -402,6 +402,34 @@ def test_run_steps_vs_oracle(rng, O, sampler):
     np.testing.assert_allclose(np_(st2.optim_state[1]), np_(new_st.optim_state[1]), rtol=1e-5, atol=1e-6)
 
 
+def test_run_steps_is_a_function_of_its_input_state(rng):
+    """DPSVI.update / the epoch body return a NEW state (svi.py:395-434): the state handed to run_steps is bit for bit what it
+    was afterwards (the native run copies it inside its first kernel, d3p_dpvi_logreg_run_from), running from it twice gives
+    the same result, and zero steps return an equal state."""
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, d, B = 2000, 64, 32
+    r = np.random.default_rng(5)
+    Xt = torch.tensor(r.normal(size=(N, d)).astype(np.float32)).cuda()
+    yt = torch.tensor((r.random(N) < 0.5).astype(np.float32)).cuda()
+    svi = make_svi(d, False, N, C=1.0, sigma=0.5, lr=1e-2)
+    st = state_with(svi, rng.PRNGKey(7), np.zeros(d, np.float32), np.full(d, -2.0, np.float32))
+    init, get_batch = subsample_batchify_data((Xt, yt), B)
+    nb, bstate = init(rng.PRNGKey(8))
+    st, _ = svi.run_steps(st, get_batch, bstate, 0, 3)
+    before = [t.clone() for t in st.optim_state] + [st.rng_key.clone()]
+    a, la = svi.run_steps(st, get_batch, bstate, 3, 9)
+    b, lb = svi.run_steps(st, get_batch, bstate, 3, 9)
+    for x, y0 in zip(list(st.optim_state) + [st.rng_key], before):
+        assert torch.equal(x, y0)
+    assert torch.equal(la, lb) and torch.equal(a.rng_key, b.rng_key) and int(a.optim_state[0]) == 12
+    for x, y0 in zip(a.optim_state, b.optim_state):
+        assert torch.equal(x, y0)
+    z, lz = svi.run_steps(st, get_batch, bstate, 3, 0)
+    assert lz.numel() == 0 and torch.equal(z.rng_key, st.rng_key)
+    for x, y0 in zip(z.optim_state, st.optim_state):
+        assert torch.equal(x, y0)
+
+
 def test_staged_update_with_debug_rng_suite(gpu, O):
     """rng_suite=d3p_amd.random.debug routes DPSVI through the threefry suite (d3p/random/debug.py)."""
     import warnings
