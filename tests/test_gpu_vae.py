@@ -23,8 +23,10 @@ def lib(gpu):
     return L
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (5, 7, 3), (100, 130, 70), (257, 65, 1000), (4096, 400, 784)])
-@pytest.mark.parametrize("form", ["nn", "nt", "tn"])
+# (260, 132, 200) and (388, 68, 96): 16-byte loadable in every form, i.e. the 128 x 64 eight-wave kernel with ragged M / N tiles, a
+# partial last K slice (200 = 6.25 slices of 32) and an odd number of slices (96 = 3: one padded)
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (5, 7, 3), (100, 130, 70), (257, 65, 1000), (260, 132, 200), (388, 68, 96), (4096, 400, 784)])
+@pytest.mark.parametrize("form", ["nn", "nt", "tn", "tt"])
 def test_mfma_gemm_vs_torch(lib, M, N, K, form):
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).cuda()
@@ -35,8 +37,10 @@ def test_mfma_gemm_vs_torch(lib, M, N, K, form):
         a_t, a_sm, a_sk, b_t, b_sk, b_sn = A.contiguous(), K, 1, Bm.contiguous(), N, 1
     elif form == "nt":      # B stored as N x K
         a_t, a_sm, a_sk, b_t, b_sk, b_sn = A.contiguous(), K, 1, Bm.t().contiguous(), 1, K
-    else:                   # A stored as K x M
+    elif form == "tn":      # A stored as K x M
         a_t, a_sm, a_sk, b_t, b_sk, b_sn = A.t().contiguous(), 1, M, Bm.contiguous(), N, 1
+    else:                   # both transposed
+        a_t, a_sm, a_sk, b_t, b_sk, b_sn = A.t().contiguous(), 1, M, Bm.t().contiguous(), 1, K
     L = lib.load()
     out = Cinit.clone()
     lib.check(L.d3p_gemm_f32(lib.stream_ptr(), lib.ptr(a_t), a_sm, a_sk, lib.ptr(b_t), b_sk, b_sn, lib.ptr(out), N, M, N, K,
