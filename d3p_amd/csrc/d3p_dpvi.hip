@@ -1883,6 +1883,39 @@ int d3p_dpvi_logreg_run_from(void* stream, const d3p_logreg_model* model, const 
     return run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev);
 }
 
+// The data-parallel runs (d3p_dpvi_logreg_run_dist / _run_xchg) likewise as functions of an immutable state: `comm` (RCCL) or
+// `xchg` (one-shot exchange) or neither; the rank's shard is src->row_lo .. row_hi.
+int d3p_dpvi_logreg_run_dist_from(void* stream, void* comm, void* xchg, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                                  const d3p_dpsvi_state* state, const d3p_dpsvi_state* from, const d3p_batch_source* src,
+                                  uint32_t first_batch, const float* X_dev, const float* y_dev, uint32_t num_steps, float* losses_dev,
+                                  void* workspace_dev, size_t workspace_bytes)
+{
+    D3P_REQUIRE(from && from->rng_key && from->params && from->adam_m && from->adam_v && from->step, "d3p_dpvi_logreg_run_dist_from: null source state");
+    D3P_REQUIRE(src && workspace_dev, "d3p_dpvi_logreg_run_dist_from: null pointer");
+    D3P_REQUIRE(!(comm && xchg), "d3p_dpvi_logreg_run_dist_from: give one of comm / xchg");
+    d3p_batch_source s2 = *src;
+    if (s2.kind != D3P_BATCH_EXPLICIT && !s2.batch_index) s2.batch_index = reinterpret_cast<uint32_t*>(workspace_dev);  // placeholder for validate(); set below
+    Ctx c;
+    int rc = make_ctx(&c, stream, model, hyper, state, &s2, workspace_dev, workspace_bytes);
+    if (rc) return rc;
+    D3P_REQUIRE(X_dev || src->row_lo == src->row_hi, "null data pointer");
+    if (int rcm = validate_model(model, y_dev ? (const void*)y_dev : (src->row_lo == src->row_hi ? (const void*)model : nullptr),
+                                 "d3p_dpvi_logreg_run_dist_from"))
+        return rcm;
+    D3P_REQUIRE(src->kind != D3P_BATCH_EXPLICIT, "d3p_dpvi_logreg_run_dist_from: needs an on-device sampler (Feistel or Poisson)");
+    D3P_REQUIRE(state->key_slot == 0, "d3p_dpvi_logreg_run_dist_from: state->key_slot must be 0");
+    if (comm && !rccl_api()) return fail(D3P_E_UNSUPPORTED, "d3p_dpvi_logreg_run_dist_from: librccl.so could not be loaded");
+    if (xchg)
+        D3P_REQUIRE(((Xchg*)xchg)->words == (uint32_t)D3P_ACC_COLS(c.P), "d3p_dpvi_logreg_run_dist_from: the exchange was created for another message size");
+    if (!use_fused_step(c)) return fail(D3P_E_UNSUPPORTED, "d3p_dpvi_logreg_run_dist_from: the data-parallel run needs the fused step");
+    s2.batch_index = reinterpret_cast<uint32_t*>(c.ws.scratch_state + 3 * c.P + 2);
+    c.src = &s2;
+    c.from = from;
+    c.batch0_by_value = true;
+    c.batch0 = first_batch;
+    return run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev, (ncclComm_t)comm, (Xchg*)xchg);
+}
+
 int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
                         const d3p_dpsvi_state* state, const d3p_batch_source* src, const float* X_dev,
                         const float* y_dev, uint32_t num_steps, float* losses_dev, void* workspace_dev,

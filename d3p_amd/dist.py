@@ -48,17 +48,33 @@ class HipEngine:
         self._setup(state, batch_key, first_batch)
         check(_lib.load().d3p_dpvi_logreg_begin(stream_ptr(), *self._args, ptr(self.ws), self.ws.numel()))
 
-    def _setup(self, state, batch_key, first_batch):
+    def _setup(self, state, batch_key, first_batch, copy=True):
+        """copy=False (run_steps_native): the new state's arrays are left EMPTY -- the native run copies the old state inside
+        its first kernel (d3p_dpvi_logreg_run_dist_from) and takes the batch index by value: no launches here."""
         self.model = self.svi._model_struct(self.d, self.model_kwargs, state.observation_scale)
         self.hyper = self.svi._hyper()
         from .svi import _fresh_optim_state
-        self.step, self.params, self.m, self.v = _fresh_optim_state(state.optim_state)   # (one copy kernel for params, m, v)
+        step0, params0, m0, v0 = state.optim_state
+        key0 = state.rng_key.reshape(16)
+        n = params0.numel()
         self.keybuf = torch.empty((2, 16), dtype=torch.uint32, device=self.dev)
-        self.keybuf[0].copy_(state.rng_key.reshape(16))
         self.bkey = batch_key.contiguous()
-        self.bidx = torch.full((1,), int(first_batch), dtype=torch.int32, device=self.dev)
+        self.frm = None
+        if (not copy and params0.dtype == m0.dtype == v0.dtype == torch.float32 and m0.numel() == n and v0.numel() == n
+                and params0.is_contiguous() and m0.is_contiguous() and v0.is_contiguous() and key0.is_contiguous()
+                and key0.dtype == torch.uint32 and step0.dtype == torch.int32):
+            flat = torch.empty(3 * n, dtype=torch.float32, device=self.dev)
+            self.step, self.params, self.m, self.v = (torch.empty_like(step0), flat[:n].view_as(params0), flat[n:2 * n].view_as(m0),
+                                                      flat[2 * n:].view_as(v0))
+            self._from_keep = (step0, params0, m0, v0, key0)
+            self.frm = self.svi._state_struct(key0, 0, (step0, params0, m0, v0))
+            self.bidx = None
+        else:
+            self.step, self.params, self.m, self.v = _fresh_optim_state(state.optim_state)   # (one copy kernel for params, m, v)
+            self.keybuf[0].copy_(key0)
+            self.bidx = torch.full((1,), int(first_batch), dtype=torch.int32, device=self.dev)
         self.src = BatchSource(self.kind, self.B, self.q, int(self.suppress), self.bkey.data_ptr(),
-                               self.bidx.data_ptr(), None, self.n, self.lo, self.hi)
+                               self.bidx.data_ptr() if self.bidx is not None else None, None, self.n, self.lo, self.hi)
         lib = _lib.load()
         nbytes = lib.d3p_dpvi_logreg_workspace(C.byref(self.model), C.byref(self.src))
         if getattr(self, "ws", None) is None or self.ws.numel() < nbytes:   # kept across runs: per-run host time matters for short runs
@@ -256,9 +272,15 @@ def run_steps_native(engine, state, batch_key, first_batch, num_steps, comm=None
     an XchgComm (one-shot full-mesh exchange, d3p_dpvi_logreg_run_xchg) or None (single rank).
     `engine` is a FusedHipEngine (it supplies the shard and the model)."""
     from .svi import DPSVIState
-    engine._setup(state, batch_key, first_batch)
+    engine._setup(state, batch_key, first_batch, copy=False)
     losses = torch.zeros(max(int(num_steps), 1), dtype=torch.float32, device=engine.dev) if collect_losses else None
-    if isinstance(comm, XchgComm):
+    if engine.frm is not None:
+        is_x = isinstance(comm, XchgComm)
+        check(_lib.load().d3p_dpvi_logreg_run_dist_from(
+            stream_ptr(), comm.handle if (comm is not None and not is_x) else None, comm.handle if is_x else None,
+            engine._args[0], engine._args[1], engine._args[2], C.byref(engine.frm), engine._args[3], int(first_batch),
+            ptr(engine.X), ptr(engine.y), int(num_steps), ptr(losses), ptr(engine.ws), engine.ws.numel()))
+    elif isinstance(comm, XchgComm):
         check(_lib.load().d3p_dpvi_logreg_run_xchg(stream_ptr(), comm.handle, *engine._args, ptr(engine.X), ptr(engine.y),
                                                    int(num_steps), ptr(losses), ptr(engine.ws), engine.ws.numel()))
     else:

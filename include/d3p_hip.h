@@ -368,6 +368,12 @@ int d3p_dpvi_logreg_run_from(void* stream, const d3p_logreg_model* model, const 
                              const d3p_dpsvi_state* state, const d3p_dpsvi_state* from, const d3p_batch_source* src,
                              uint32_t first_batch, const float* X_dev, const float* y_dev, uint32_t num_steps,
                              float* losses_dev, void* workspace_dev, size_t workspace_bytes);
+/* ... and the data-parallel runs d3p_dpvi_logreg_run_dist / d3p_dpvi_logreg_run_xchg (declared below) in the same form:
+ * comm (d3p_comm_*: RCCL) or xchg (d3p_xchg_*: one-shot exchange) or neither; the rank's shard is src->row_lo .. row_hi. */
+int d3p_dpvi_logreg_run_dist_from(void* stream, void* comm, void* xchg, const d3p_logreg_model* model,
+                                  const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state, const d3p_dpsvi_state* from,
+                                  const d3p_batch_source* src, uint32_t first_batch, const float* X_dev, const float* y_dev,
+                                  uint32_t num_steps, float* losses_dev, void* workspace_dev, size_t workspace_bytes);
 
 /* Times only the dominant kernel (fused gradient/clip/sum) of one step over `reps` launches on
  * `stream` (host out-pointers):
