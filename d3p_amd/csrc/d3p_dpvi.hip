@@ -228,8 +228,70 @@ __global__ void __launch_bounds__(256) k_run_init(const uint32_t* __restrict__ s
 }
 
 
-// (FlushArgs / flush_body: d3p_logreg_kernel.h -- the chained launch of d3p_logreg_chain.h runs the same code as its last workgroup)
-__global__ void __launch_bounds__(1024) k_flush(FlushArgs a) { flush_body<false>(a, (int)threadIdx.x, (int)blockDim.x); }
+struct FlushArgs {
+    const long long* acc_prev;  // nrep x cols: the local replicas, or the one row of world sums of a data-parallel chained run
+    int nrep;
+    const float* noise;         // P normals of the last step
+    const StepSlot* slot;       // its slot
+    const float* state_in[3];
+    float* state_out[3];        // the caller's arrays
+    float* loss_out;            // nullable
+    int32_t* adam_step;
+    uint32_t* batch_index;      // nullable
+    const Sched* sched;
+    uint32_t* key_out;          // the state's key slot after the run
+    const uint32_t* status;
+    unsigned long long* host_status;  // nullable: pinned host record {abort, nonfinite, tag}
+    unsigned long long host_tag;
+    int P, B;
+    float dp_scale, clip, obs_scale, lr, b1, b2, adam_eps;
+    double inv_sg;
+};
+
+__global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
+{
+    const int tid = threadIdx.x, PA = D3P_ACC_COLS(a.P);
+    if (tid < 16) a.key_out[tid] = a.sched->key[tid];
+    const uint32_t aborted = a.status[0];
+    if (tid == 0 && a.host_status) {
+        a.host_status[0] = aborted;
+        a.host_status[1] = a.status[1];
+        a.host_status[2] = a.host_tag;
+    }
+    if (aborted) {  // the pending sums are incomplete: leave the state where the run stopped
+        if (tid == 0 && a.loss_out) *a.loss_out = __builtin_nanf("");
+        return;
+    }
+    long long nll = 0;
+    for (int r = 0; r < a.nrep; ++r) nll += a.acc_prev[(size_t)r * PA + a.P + 1];
+    const float n = nll >= (1ll << 40) ? __builtin_nanf("") : (float)nll;
+    const float Bf = (float)a.B;
+    const float factor = (n == 0.0f) ? 0.0f : Bf / n;
+    const float inv_B = 1.0f / Bf, inv_bc1 = 1.0f / a.slot->bc1, inv_bc2 = 1.0f / a.slot->bc2;
+    const float noise_scale = a.dp_scale * (a.clip / n), out_scale = a.obs_scale * factor;
+    for (int col = tid; col < a.P; col += blockDim.x) {
+        long long sll = 0;
+        for (int r = 0; r < a.nrep; ++r) sll += a.acc_prev[(size_t)r * PA + col];
+        const float tot = (float)((double)sll * a.inv_sg);
+        const float g = __fmaf_rn(a.noise[col], noise_scale, tot * inv_B) * out_scale;
+        const float mm = (1.0f - a.b1) * g + a.b1 * a.state_in[1][col];
+        const float vv = (1.0f - a.b2) * g * g + a.b2 * a.state_in[2][col];
+        const float xx = a.state_in[0][col] - a.lr * (mm * inv_bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv * inv_bc2) + a.adam_eps);
+        a.state_out[0][col] = xx;
+        a.state_out[1][col] = mm;
+        a.state_out[2][col] = vv;
+    }
+    if (tid == 0) {
+        long long lll = 0, lhh = 0;
+        for (int r = 0; r < a.nrep; ++r) {
+            lll += a.acc_prev[(size_t)r * PA + a.P];
+            lhh += a.acc_prev[(size_t)r * PA + a.P + 2];
+        }
+        if (a.loss_out) *a.loss_out = ((float)loss_join(lhh, lll) / Bf) * a.obs_scale * factor;
+        *a.adam_step = a.slot->adam_i + 1;
+        if (a.batch_index) *a.batch_index = a.slot->batch_i + 1u;
+    }
+}
 
 // pinned host record of the last run's status words (written by k_flush): spares d3p_dpvi_logreg_run_status its copy
 static unsigned long long* host_status_record()
@@ -1015,11 +1077,8 @@ static bool lean_chain_ok(const Ctx& c)
            c.m->family == D3P_FAMILY_LOGREG && c.items_expected <= 18ull * c.g.blocks;
 }
 
-// flush != nullptr (last batch of a run, single device): if this launch is k_logreg_chain, k_flush's work rides in it as one more
-// workgroup and *flushed is set
 static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* prev_slot0, const float* prev_noise0, const float* X,
-                                 const float* y, float* losses, StepSlot* chain_slots, int K_next, Xchg* xchg = nullptr,
-                                 const FlushArgs* flush = nullptr, bool* flushed = nullptr)
+                                 const float* y, float* losses, StepSlot* chain_slots, int K_next, Xchg* xchg = nullptr)
 {
     MainArgs a;
     memset(&a, 0, sizeof(a));
@@ -1135,14 +1194,7 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
                 ca.x.xsum = c.ws.xsum;
                 D3P_HIP_TRY(hipMemsetAsync(c.ws.xflags, 0, (size_t)D3P_STEP_BATCH * 32 * sizeof(uint32_t), c.s));
             }
-            static const bool no_inl_flush = getenv("D3P_NO_INLAUNCH_FLUSH") != nullptr;  // developer switch, read once
-            const bool do_flush = flush && !xchg && !no_inl_flush;
-            if (do_flush) {
-                ca.flush = *flush;
-                ca.do_flush = 1;
-                if (flushed) *flushed = true;
-            }
-            const dim3 grid((uint32_t)K * (c.g.blocks + 1u + (xchg ? 1u : 0u)) + (do_flush ? 1u : 0u)), block(64 * D3P_CHAIN_W);
+            const dim3 grid((uint32_t)K * (c.g.blocks + 1u + (xchg ? 1u : 0u))), block(64 * D3P_CHAIN_W);
             const bool plist = ca.plist_base != nullptr;
             const size_t lds = chain_lds_bytes(icpt);
             const bool stamped = (ca.dbg & 32) && K >= 2;  // D3P_DBG=32: the stamped instantiation + the phase anatomy on stderr
@@ -1401,50 +1453,12 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     static const bool xchg_per_step = getenv("D3P_XCHG_PER_STEP") != nullptr;
     const bool chained = !comm && use_chained_steps(c) && (!xchg || (lean_chain_ok(c) && !xchg_per_step));
     const bool persist = chained && use_persistent_steps(c);
-    // the run's last action -- apply the update of the last step, store the final key, report the status -- as arguments
-    auto make_flush = [&](int g_final, const StepSlot* last_slot, const float* last_noise, bool world_sums) {
-        FlushArgs fa;
-        memset(&fa, 0, sizeof(fa));
-        const size_t words = (size_t)D3P_ACC_R * D3P_ACC_COLS(c.P);
-        fa.acc_prev = c.ws.acc + (size_t)((g_final + 2) % 3) * words;
-        fa.nrep = D3P_ACC_R;
-        if (world_sums) {  // the exchange workgroups left the world's sums in one row per step
-            fa.acc_prev = c.ws.xsum + (size_t)((g_final + 2) % 3) * D3P_ACC_COLS(c.P);
-            fa.nrep = 1;
-        }
-        fa.noise = last_noise;
-        fa.slot = last_slot;
-        {
-            const size_t P = (size_t)c.P;
-            float* const bufs[2][3] = {{c.st->params, c.st->adam_m, c.st->adam_v}, {c.ws.pp_state, c.ws.pp_state + P, c.ws.pp_state + 2 * P}};
-            const int in = g_final > 0 ? ((g_final - 1) & 1) : 0;  // launch g - 1 published to buffer (g - 1) & 1
-            for (int j = 0; j < 3; ++j) { fa.state_in[j] = bufs[in][j]; fa.state_out[j] = bufs[0][j]; }
-        }
-        fa.loss_out = losses ? losses + g_final - 1 : nullptr;
-        fa.adam_step = c.st->step;
-        fa.batch_index = sampled ? c.src->batch_index : nullptr;
-        fa.sched = c.ws.sched;
-        fa.key_out = key_out;
-        fa.status = run_status_words(c.ws);
-        fa.host_status = host_status_record();
-        fa.host_tag = (unsigned long long)(uintptr_t)run_status_words(c.ws);
-        fa.P = c.P;
-        fa.B = (int)c.src->B;
-        fa.dp_scale = c.h->dp_scale; fa.clip = c.h->clip; fa.obs_scale = 1.0f / c.m->inv_obs;
-        fa.lr = c.h->lr; fa.b1 = c.h->b1; fa.b2 = c.h->b2; fa.adam_eps = c.h->adam_eps;
-        fa.inv_sg = 1.0 / (1099511627776.0 / (double)fabsf(c.h->clip));
-        return fa;
-    };
-    bool flushed_in_launch = false;
     for (uint32_t b = 0; b < n_batches; ++b) {
         const int cur = (int)(b & 1), nxt = cur ^ 1;
         const int K = batch_len(b), K_next = (b + 1 < n_batches) ? batch_len(b + 1) : 0;
         if (chained) {
-            FlushArgs fl;
-            const bool last = b + 1 == n_batches && !persist;
-            if (last) fl = make_flush(g + K, cb[cur].ws.slots + (K - 1), cb[cur].ws.noise + (size_t)(K - 1) * c.P, false);
             if ((rc = enqueue_chained_batch(cb[cur], g, K, prev_slot, prev_noise, X, y, losses, no_piggy ? nullptr : cb[nxt].ws.slots,
-                                            K_next, xchg, last ? &fl : nullptr, &flushed_in_launch)))
+                                            K_next, xchg)))
                 return rc;
             g += K;
             if (!persist) {  // the persistent form applies every update inside its launch: nothing is pending afterwards
@@ -1482,8 +1496,37 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
         hipLaunchKernelGGL(k_sched_finish, dim3(1), dim3(64), 0, c.s, (const Sched*)c.ws.sched, key_out);
         return check_launch("k_sched_finish");
     }
-    if (flushed_in_launch) return D3P_OK;  // the last chained launch did it
-    const FlushArgs fa = make_flush(g, prev_slot, prev_noise, chained && xchg);
+    // apply the update of the last step, store the final key, report the status
+    FlushArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    const size_t words = (size_t)D3P_ACC_R * D3P_ACC_COLS(c.P);
+    fa.acc_prev = c.ws.acc + (size_t)((g + 2) % 3) * words;
+    fa.nrep = D3P_ACC_R;
+    if (chained && xchg) {  // the exchange workgroups left the world's sums in one row per step
+        fa.acc_prev = c.ws.xsum + (size_t)((g + 2) % 3) * D3P_ACC_COLS(c.P);
+        fa.nrep = 1;
+    }
+    fa.noise = prev_noise;
+    fa.slot = prev_slot;
+    {
+        const size_t P = (size_t)c.P;
+        float* const bufs[2][3] = {{c.st->params, c.st->adam_m, c.st->adam_v}, {c.ws.pp_state, c.ws.pp_state + P, c.ws.pp_state + 2 * P}};
+        const int in = g > 0 ? ((g - 1) & 1) : 0;  // launch g - 1 published to buffer (g - 1) & 1
+        for (int j = 0; j < 3; ++j) { fa.state_in[j] = bufs[in][j]; fa.state_out[j] = bufs[0][j]; }
+    }
+    fa.loss_out = losses ? losses + g - 1 : nullptr;
+    fa.adam_step = c.st->step;
+    fa.batch_index = sampled ? c.src->batch_index : nullptr;
+    fa.sched = c.ws.sched;
+    fa.key_out = key_out;
+    fa.status = run_status_words(c.ws);
+    fa.host_status = host_status_record();
+    fa.host_tag = (unsigned long long)(uintptr_t)run_status_words(c.ws);
+    fa.P = c.P;
+    fa.B = (int)c.src->B;
+    fa.dp_scale = c.h->dp_scale; fa.clip = c.h->clip; fa.obs_scale = 1.0f / c.m->inv_obs;
+    fa.lr = c.h->lr; fa.b1 = c.h->b1; fa.b2 = c.h->b2; fa.adam_eps = c.h->adam_eps;
+    fa.inv_sg = 1.0 / (1099511627776.0 / (double)fabsf(c.h->clip));
     hipLaunchKernelGGL(k_flush, dim3(1), dim3(1024), 0, c.s, fa);
     return check_launch("k_flush");
 }

@@ -76,8 +76,6 @@ struct ChainArgs {
     float c1_b, hz_b, log_prior_b;  // ICPT: the intercept's prior
     int gexp;
     XchgDev x;
-    FlushArgs flush;  // do_flush: the launch has ONE more workgroup, which waits for the last step and does k_flush's work
-    int do_flush;
     int dbg;  // developer switches (D3P_DBG): 2 = raised wave priority on the critical path, 4 = no gradient atomics (STAMPS only)
 };
 
@@ -116,17 +114,6 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     const uint32_t per = (uint32_t)a.nw + 1u + (a.x.world > 0 ? 1u : 0u);
     const int step_t = (int)(blockIdx.x / per);
     const uint32_t bid = blockIdx.x % per;
-
-    if (step_t == a.K) {  // ---- the flush workgroup (last launch of a run): update of the launch's last step, key, status
-        if (tid == 64) okw[1] = 0u;
-        if (wave == 0) {  // every compute workgroup of the last step has added its sums (and workgroup 0 published the state)
-            const uint32_t ng = (uint32_t)a.nw < D3P_BAR_GROUPS ? (uint32_t)a.nw : D3P_BAR_GROUPS;
-            (void)chain_wait_groups(a.bar + (size_t)(a.K - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS), ng, a.status);
-        }
-        __syncthreads();  // (a wait that ran out has raised the abort flag: flush_body reports it and leaves the state alone)
-        flush_body<true>(a.flush, tid, 64 * W);
-        return;
-    }
 
     if (a.x.world > 0 && bid == (uint32_t)a.nw + 1u) {  // ---- the exchange workgroup of step `step_t`
         const size_t words = (size_t)R * PA;

@@ -166,76 +166,6 @@ __device__ __forceinline__ bool chain_wait_groups(const uint32_t* flags, uint32_
     }
 }
 
-struct FlushArgs {
-    const long long* acc_prev;  // nrep x cols: the local replicas, or the one row of world sums of a data-parallel chained run
-    int nrep;
-    const float* noise;         // P normals of the last step
-    const StepSlot* slot;       // its slot
-    const float* state_in[3];
-    float* state_out[3];        // the caller's arrays
-    float* loss_out;            // nullable
-    int32_t* adam_step;
-    uint32_t* batch_index;      // nullable
-    const Sched* sched;
-    uint32_t* key_out;          // the state's key slot after the run
-    const uint32_t* status;
-    unsigned long long* host_status;  // nullable: pinned host record {abort, nonfinite, tag}
-    unsigned long long host_tag;
-    int P, B;
-    float dp_scale, clip, obs_scale, lr, b1, b2, adam_eps;
-    double inv_sg;
-};
-
-// The update still pending after a run's last step (the arithmetic of the step kernels' prologue), the caller's state arrays,
-// the final key, the run's status for the host.  XW: called by the LAST workgroup of a chained launch, after the arrival flags
-// of the launch's last step -- sums, the state published by that step and the status words then come from other workgroups of
-// the same launch and are read with agent-scope loads; otherwise (k_flush, its own launch) plain loads do.
-template <bool XW>
-__device__ __forceinline__ void flush_body(const FlushArgs& a, int tid, int nthreads)
-{
-    const int PA = D3P_ACC_COLS(a.P);
-    if (tid < 16) a.key_out[tid] = a.sched->key[tid];
-    const uint32_t aborted = ld_x<XW>(a.status);
-    if (tid == 0 && a.host_status) {
-        a.host_status[0] = aborted;
-        a.host_status[1] = ld_x<XW>(a.status + 1);
-        a.host_status[2] = a.host_tag;
-    }
-    if (aborted) {  // the pending sums are incomplete: leave the state where the run stopped
-        if (tid == 0 && a.loss_out) *a.loss_out = __builtin_nanf("");
-        return;
-    }
-    long long nll = 0;
-    for (int r = 0; r < a.nrep; ++r) nll += ld_x<XW>(a.acc_prev + (size_t)r * PA + a.P + 1);
-    const float n = nll >= (1ll << 40) ? __builtin_nanf("") : (float)nll;
-    const float Bf = (float)a.B;
-    const float factor = (n == 0.0f) ? 0.0f : Bf / n;
-    const float inv_B = 1.0f / Bf, inv_bc1 = 1.0f / a.slot->bc1, inv_bc2 = 1.0f / a.slot->bc2;
-    const float noise_scale = a.dp_scale * (a.clip / n), out_scale = a.obs_scale * factor;
-    for (int col = tid; col < a.P; col += nthreads) {
-        long long sll = 0;
-        for (int r = 0; r < a.nrep; ++r) sll += ld_x<XW>(a.acc_prev + (size_t)r * PA + col);
-        const float tot = (float)((double)sll * a.inv_sg);
-        const float g = __fmaf_rn(a.noise[col], noise_scale, tot * inv_B) * out_scale;
-        const float mm = (1.0f - a.b1) * g + a.b1 * ld_x<XW>(a.state_in[1] + col);
-        const float vv = (1.0f - a.b2) * g * g + a.b2 * ld_x<XW>(a.state_in[2] + col);
-        const float xx = ld_x<XW>(a.state_in[0] + col) - a.lr * (mm * inv_bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv * inv_bc2) + a.adam_eps);
-        a.state_out[0][col] = xx;
-        a.state_out[1][col] = mm;
-        a.state_out[2][col] = vv;
-    }
-    if (tid == 0) {
-        long long lll = 0, lhh = 0;
-        for (int r = 0; r < a.nrep; ++r) {
-            lll += ld_x<XW>(a.acc_prev + (size_t)r * PA + a.P);
-            lhh += ld_x<XW>(a.acc_prev + (size_t)r * PA + a.P + 2);
-        }
-        if (a.loss_out) *a.loss_out = ((float)loss_join(lhh, lll) / Bf) * a.obs_scale * factor;
-        *a.adam_step = a.slot->adam_i + 1;
-        if (a.batch_index) *a.batch_index = a.slot->batch_i + 1u;
-    }
-}
-
 // One step of the serial key chain for step `t` of the next batch: (next, gradient, perturbation) =
 // split(chain_key, 3) (svi.py:208-211, :413-414).  `last` advances the batch counters of the schedule.
 template <bool CH = false>
