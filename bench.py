@@ -299,10 +299,10 @@ def main():
         # shows the cold figure).  Every leg does its own warm-up steps and is bracketed by barriers.
         steady = None
         if extra_legs:
-            _, _, el_s, kt_s = timed_leg(run, state0, args.warmup + args.steps, 256, args.steady_steps)
+            _, _, el_s, kt_s = timed_leg(run, state0, args.warmup + args.steps, 2048, args.steady_steps)
             if rank == 0:
                 sps = args.steady_steps / el_s
-                steady = {"steps": args.steady_steps, "warmup": 256, "steps_per_sec": round(sps, 2), "value": round(Bg * sps, 1),
+                steady = {"steps": args.steady_steps, "warmup": 2048, "steps_per_sec": round(sps, 2), "value": round(Bg * sps, 1),
                           "ms_per_step": round(1000.0 * el_s / args.steady_steps, 6), "kernel": kernel_record(kt_s, Bg // ranks)}
         # ---------------------------------------------------------------- headline leg (value is tied to --steps)
         state, losses, elapsed, kt = timed_leg(run, state0, 0, args.warmup, args.steps)
