@@ -136,6 +136,7 @@ SIGNATURES = {
     "d3p_vae_step_sums": (C.c_int, [_V, _V, _V, _V, _V, _U32, _V, _V, _F, _V, _V, _V, _V, C.c_size_t]),
     "d3p_vae_evaluate": (C.c_int, [_V, _V, _V, _V, _U32, _V, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_vae_update": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _V, _V, _V, _V, C.c_size_t]),
+    "d3p_dpvi_vae_update_from": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _U32, _V, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_gmm_local_sums": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _U32, _U32, _V, _V, C.c_size_t]),
     "d3p_dpvi_gmm_apply": (C.c_int, [_V, _V, _V, _V, _V, _U32, _U32, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_vae_local_sums": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _U32, _U32, _V, _V, _V, C.c_size_t]),

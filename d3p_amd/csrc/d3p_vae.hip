@@ -708,6 +708,9 @@ struct VaeFinalArgs {
     uint32_t w_base[5], w_tile[5], w_ld[5], w_coff[5], w_out[5];  // its tiles: wpart + w_base, w_tile apart, element (r, c) of the
     int w_splits[5];                                            // block at r * w_ld + w_coff + c, c < w_out
     const float* noise;
+    const float* in_params;  // state before the update (== params / adam_m / adam_v, or the old state's arrays when the update
+    const float* in_m;       // is out of place: DPSVI.update returns a NEW state, svi.py:395-434)
+    const float* in_v;
     float* params;
     float* adam_m;
     float* adam_v;
@@ -744,12 +747,12 @@ __global__ void k_vae_finalize(VaeFinalArgs a)
     }
     const float g = (tot / Bf + a.noise[col] * (a.h.dp_scale * (a.h.clip / n))) * a.obs_scale * factor;
     if (a.grad_out) a.grad_out[col] = g;
-    float m = a.adam_m[col], v = a.adam_v[col];
+    float m = a.in_m[col], v = a.in_v[col];
     m = (1.0f - a.h.b1) * g + a.h.b1 * m;
     v = (1.0f - a.h.b2) * g * g + a.h.b2 * v;
     const float mhat = m / bc[0];
     const float vhat = v / bc[1];
-    a.params[col] -= a.h.lr * mhat / (sqrtf(vhat) + a.h.adam_eps);
+    a.params[col] = a.in_params[col] - a.h.lr * mhat / (sqrtf(vhat) + a.h.adam_eps);
     a.adam_m[col] = m;
     a.adam_v[col] = v;
 }
@@ -788,7 +791,8 @@ __global__ void __launch_bounds__(256) k_vae_site_noise(SiteNoiseArgs a)
 // split(perturbation_key, 10) (svi.py:491), keys[208..209] = convert_to_jax_rng_key(gradient_key).  advance: also write the
 // next state key into the other key slot, save the optimiser step index in keys[210] for k_vae_finalize and advance it.
 __global__ void __launch_bounds__(64) k_vae_keys(const uint32_t* __restrict__ cur_key, uint32_t* __restrict__ keys,
-                                                 uint32_t* __restrict__ next_slot, int32_t* __restrict__ step, int advance)
+                                                 uint32_t* __restrict__ next_slot, const int32_t* __restrict__ step,
+                                                 int32_t* __restrict__ step_out, int advance)
 {
     // one quad of lanes per derivation (4-lane ChaCha block, d3p_device.h): the launch is pure latency
     __shared__ uint32_t sk[3][16];
@@ -811,7 +815,7 @@ __global__ void __launch_bounds__(64) k_vae_keys(const uint32_t* __restrict__ cu
     if (lane == 63 && advance) {
         const int32_t i = *step;
         keys[210] = (uint32_t)i;
-        *step = i + 1;
+        *step_out = i + 1;  // (step_out == step, or the new state's counter when the update is out of place)
     }
     __syncthreads();
     {
@@ -1059,24 +1063,32 @@ static int vae_update_checks(const d3p_vae_model* model, const d3p_dpsvi_hyper* 
 
 // keys of one update, all functions of the state key: [next | gradient | perturbation] = split(key, 3) (svi.py:208-211),
 // split(perturbation_key, 10) (svi.py:491), convert_to_jax_rng_key(gradient_key)
-static int vae_step_keys(hipStream_t s, const d3p_dpsvi_state* state, const VaeWorkspace& ws, bool advance)
+// from != nullptr: the update reads the key and the step counter of `from` and writes the next key / counter into `state`
+// (slot 1 of its key buffer; state->key_slot is taken as 0)
+static int vae_step_keys(hipStream_t s, const d3p_dpsvi_state* state, const VaeWorkspace& ws, bool advance,
+                         const d3p_dpsvi_state* from = nullptr)
 {
     const int slot = state->key_slot & 1;
+    if (from)
+        hipLaunchKernelGGL(k_vae_keys, dim3(1), dim3(64), 0, s, (const uint32_t*)(from->rng_key + 16 * (from->key_slot & 1)), ws.keys,
+                           state->rng_key + 16, (const int32_t*)from->step, state->step, advance ? 1 : 0);
+    else
     hipLaunchKernelGGL(k_vae_keys, dim3(1), dim3(64), 0, s, (const uint32_t*)(state->rng_key + 16 * slot), ws.keys,
-                       state->rng_key + 16 * (slot ^ 1), state->step, advance ? 1 : 0);
+                       state->rng_key + 16 * (slot ^ 1), (const int32_t*)state->step, state->step, advance ? 1 : 0);
     return check_launch("k_vae_keys");
 }
 
 static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                           const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
-                          void* workspace_dev, size_t workspace_bytes, bool derive_keys, const int* w_splits = nullptr);
+                          void* workspace_dev, size_t workspace_bytes, bool derive_keys, const int* w_splits = nullptr,
+                          const d3p_dpsvi_state* from = nullptr);
 
 // advance = true (single-device update): the key kernel also writes the next state key and advances the step counter, so that
 // vae_apply_impl(derive_keys = false) has nothing left to launch for them
 static int vae_local_sums_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                                const float* X_dev, const uint8_t* mask_dev, uint32_t B_local, uint32_t B_total, uint32_t pos0,
                                const float* eps_dev, float* sums_dev, void* workspace_dev, size_t workspace_bytes, bool advance,
-                               int* w_splits = nullptr)
+                               int* w_splits = nullptr, const d3p_dpsvi_state* from = nullptr)
 {
     if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_local_sums")) return rc;
     D3P_REQUIRE(X_dev && sums_dev, "d3p_dpvi_vae_local_sums: null pointer");
@@ -1086,8 +1098,8 @@ static int vae_local_sums_impl(void* stream, const d3p_vae_model* model, const d
     vae_carve(model, B_local, (char*)workspace_dev, &ws);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if ((rc = vae_step_keys(s, state, ws, advance))) return rc;
-    if ((rc = vae_enqueue_sums(s, model, state->params, X_dev, mask_dev, B_local, eps_dev, ws.keys + 208, hyper->clip, ws, nullptr,
+    if ((rc = vae_step_keys(s, state, ws, advance, from))) return rc;
+    if ((rc = vae_enqueue_sums(s, model, from ? from->params : state->params, X_dev, mask_dev, B_local, eps_dev, ws.keys + 208, hyper->clip, ws, nullptr,
                                B_total, pos0, w_splits)))
         return rc;
     if (sums_dev != ws.sums)
@@ -1115,7 +1127,7 @@ int d3p_dpvi_vae_apply(void* stream, const d3p_vae_model* model, const d3p_dpsvi
 // workspace and state, as in the single-device update)
 static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                           const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
-                          void* workspace_dev, size_t workspace_bytes, bool derive_keys, const int* w_splits)
+                          void* workspace_dev, size_t workspace_bytes, bool derive_keys, const int* w_splits, const d3p_dpsvi_state* from)
 {
     if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_apply")) return rc;
     D3P_REQUIRE(sums_dev && B_total >= 1 && B_local >= 1, "d3p_dpvi_vae_apply: null pointer or empty batch");
@@ -1162,6 +1174,9 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
         f.w_off[5] = (uint32_t)L.P;
     }
     f.noise = ws.noise;
+    f.in_params = from ? from->params : state->params;
+    f.in_m = from ? from->adam_m : state->adam_m;
+    f.in_v = from ? from->adam_v : state->adam_v;
     f.params = state->params;
     f.adam_m = state->adam_m;
     f.adam_v = state->adam_v;
@@ -1174,6 +1189,29 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
     f.obs_scale = 1.0f / model->inv_obs;
     hipLaunchKernelGGL(k_vae_finalize, dim3(cdiv(L.P, 256)), dim3(256), 0, s, f);
     return check_launch("d3p_dpvi_vae_apply");
+}
+
+// d3p_dpvi_vae_update as a function of an immutable state: reads `from` (key slot from->key_slot, parameters, Adam moments, step
+// counter), writes the new state into `state` (its arrays may be uninitialised; the next key goes to slot 1 of state->rng_key)
+// -- no copy of the 3 x 689 k floats of state per update.
+int d3p_dpvi_vae_update_from(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                             const d3p_dpsvi_state* from, const float* X_dev, const uint8_t* mask_dev, uint32_t B, const float* eps_dev,
+                             float* loss_dev, float* grad_out_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_update_from")) return rc;
+    D3P_REQUIRE(from && from->rng_key && from->params && from->adam_m && from->adam_v && from->step, "d3p_dpvi_vae_update_from: null source state");
+    D3P_REQUIRE(X_dev, "d3p_dpvi_vae_update_from: null pointer");
+    D3P_REQUIRE(B >= 1, "d3p_dpvi_vae_update_from: B must be >= 1");
+    D3P_REQUIRE(state->key_slot == 0, "d3p_dpvi_vae_update_from: state->key_slot must be 0");
+    if (workspace_bytes < d3p_dpvi_vae_workspace(model, B)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_update_from: workspace too small");
+    VaeWorkspace ws;
+    vae_carve(model, B, (char*)workspace_dev, &ws);
+    int w_splits[5];
+    if (int rc = vae_local_sums_impl(stream, model, hyper, state, X_dev, mask_dev, B, B, 0, eps_dev, ws.sums, workspace_dev,
+                                     workspace_bytes, true, w_splits, from))
+        return rc;
+    return vae_apply_impl(stream, model, hyper, state, ws.sums, B, B, loss_dev, grad_out_dev, workspace_dev, workspace_bytes, false,
+                          w_splits, from);
 }
 
 int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,

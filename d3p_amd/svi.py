@@ -254,19 +254,33 @@ class DPSVI:
         dev = X.device
         vm = self._vae_struct(D, kwargs, svi_state.observation_scale)
         hyper = self._hyper()
-        step, params, m, v = _fresh_optim_state(svi_state.optim_state)
-        keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
-        keybuf[0].copy_(svi_state.rng_key.reshape(16))
         mask_t = None
         if not isinstance(mask, bool):
             mask_t = mask.to(torch.uint8).contiguous()
         elif mask is False:
             mask_t = torch.zeros(B, dtype=torch.uint8, device=dev)
-        st = self._state_struct(keybuf, 0, (step, params, m, v))
         ws = self._workspace(lib.d3p_dpvi_vae_workspace(C.byref(vm), B), dev, "vae_step")
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        check(lib.d3p_dpvi_vae_update(stream_ptr(), C.byref(vm), C.byref(hyper), C.byref(st), ptr(X), ptr(mask_t), B,
-                                      ptr(_eps), ptr(loss), ptr(_grad_out), ptr(ws), ws.numel()))
+        keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
+        step0, params0, m0, v0 = svi_state.optim_state
+        key0 = svi_state.rng_key.reshape(16)
+        n = params0.numel()
+        if (params0.dtype == m0.dtype == v0.dtype == torch.float32 and m0.numel() == n and v0.numel() == n
+                and params0.is_contiguous() and m0.is_contiguous() and v0.is_contiguous() and key0.is_contiguous()
+                and key0.dtype == torch.uint32 and step0.dtype == torch.int32):
+            # out of place: the kernels read the old state and write the new one (no copy of the 3 x P floats)
+            flat = torch.empty(3 * n, dtype=torch.float32, device=dev)
+            step, params, m, v = torch.empty_like(step0), flat[:n].view_as(params0), flat[n:2 * n].view_as(m0), flat[2 * n:].view_as(v0)
+            st = self._state_struct(keybuf, 0, (step, params, m, v))
+            frm = self._state_struct(key0, 0, (step0, params0, m0, v0))
+            check(lib.d3p_dpvi_vae_update_from(stream_ptr(), C.byref(vm), C.byref(hyper), C.byref(st), C.byref(frm), ptr(X),
+                                               ptr(mask_t), B, ptr(_eps), ptr(loss), ptr(_grad_out), ptr(ws), ws.numel()))
+        else:
+            step, params, m, v = _fresh_optim_state(svi_state.optim_state)
+            keybuf[0].copy_(key0)
+            st = self._state_struct(keybuf, 0, (step, params, m, v))
+            check(lib.d3p_dpvi_vae_update(stream_ptr(), C.byref(vm), C.byref(hyper), C.byref(st), ptr(X), ptr(mask_t), B,
+                                          ptr(_eps), ptr(loss), ptr(_grad_out), ptr(ws), ws.numel()))
         return DPSVIState((step, params, m, v), keybuf[1].reshape(4, 4), svi_state.observation_scale), loss[0]
 
     def _is_gmm(self):

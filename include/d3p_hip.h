@@ -529,6 +529,12 @@ int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsv
                         const d3p_dpsvi_state* state, const float* X_dev, const uint8_t* mask_dev, uint32_t B,
                         const float* eps_dev, float* loss_dev, float* grad_out_dev, void* workspace_dev,
                         size_t workspace_bytes);
+/* The same as a function of an immutable state (as d3p_dpvi_logreg_run_from): reads `from`, writes the new state into
+ * `state` (key_slot 0; the next key goes to slot 1 of state->rng_key) -- no 3 x P-float state copy per update.  ABI 4. */
+int d3p_dpvi_vae_update_from(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper,
+                             const d3p_dpsvi_state* state, const d3p_dpsvi_state* from, const float* X_dev,
+                             const uint8_t* mask_dev, uint32_t B, const float* eps_dev, float* loss_dev, float* grad_out_dev,
+                             void* workspace_dev, size_t workspace_bytes);
 
 /* Data-parallel form of d3p_dpvi_vae_update (BASELINE config 5, "1 vs 8 GPU"): a rank holds the B_local
  * examples at positions pos0 .. pos0 + B_local - 1 of the global batch of B_total (per-example noise keys are functions of
