@@ -45,7 +45,13 @@ struct GemmArgs {
     int a_last_one;   // row M - 1 of op(A) is all ones (bias gradients ride along with the weight gradients)
     int k_per;        // K range of one split (multiple of D3P_GK); gridDim.z splits
     float* part;      // split-K partial tiles [gridDim.z][M][N] (nullable when gridDim.z == 1)
-    int epi;          // epilogue: 0 store; 1 softplus (C = softplus(o), C2 = sigmoid(o) = its derivative); 2 C = o * C2
+    int epi;          // epilogue: 0 store; 1 softplus (C = softplus(o), C2 = sigmoid(o) = its derivative); 2 C = o * C2;
+                      // 3 (the dz product, C = [dz | du] of row stride 2 Z): dz = o + sc z, du = dz sd eps - sc with [z | sd] = ex_zu (same
+                      // layout as C), eps dense B x Z (the backward pass through the reparametrised latent, svi.py:289-290 draw)
+    const float* ex_zu;
+    const float* ex_eps;
+    int ex_Z;
+    float ex_sc;
     // Two operands side by side that are not adjacent in memory (the pairs (Wl, Ws) / (bl, bs) of the flat parameter layout lie
     // H Z apart): columns n >= n_seg of B, of the bias and of C, and rows k >= k_seg of B, are displaced by a constant.  0 / 0 /
     // INT_MAX segments = plain GEMM.  Honoured by the scalar B fetch and by every store path.
@@ -66,6 +72,9 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& g, int row, int col, 
         o = fmaxf(o, 0.0f) + __logf(1.0f + en);
     } else if (g.epi == 2) {
         o *= g.C2[e];
+    } else if (g.epi == 3) {
+        o = __fmaf_rn(g.ex_sc, g.ex_zu[e], o);
+        g.C[e + g.ex_Z] = o * g.ex_zu[e + g.ex_Z] * g.ex_eps[(size_t)row * g.ex_Z + col] - g.ex_sc;
     }
     g.C[e] = o;
 }
@@ -447,7 +456,7 @@ __global__ void k_gemm_reduce(GemmArgs g, int splits)
 static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, const float* B, long long b_sk, long long b_sn,
                 float* C, int ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, int a_last_one = 0,
                 float* part = nullptr, size_t part_floats = 0, int epi = 0, float* C2 = nullptr, int* splits_left = nullptr,
-                const GemmJumps* jumps = nullptr)
+                const GemmJumps* jumps = nullptr, const float* ex_zu = nullptr, const float* ex_eps = nullptr, int ex_Z = 0, float ex_sc = 0.f)
 {
     // splits_left != nullptr: a split-K product is NOT reduced here -- the partial tiles stay in `part` ([splits][M][N]) and
     // *splits_left says how many (0: the product went to C as usual); the consumer sums them in fixed order (k_vae_finalize)
@@ -459,6 +468,7 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     g.a_last_one = a_last_one;
     g.epi = epi;
     g.C2 = C2;
+    g.ex_zu = ex_zu; g.ex_eps = ex_eps; g.ex_Z = ex_Z; g.ex_sc = ex_sc;
     g.n_seg = jumps ? jumps->n_seg : 0x7fffffff;
     g.k_seg = jumps ? jumps->k_seg : 0x7fffffff;
     g.b_njump = jumps ? jumps->b_njump : 0;
@@ -510,20 +520,6 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
 // ------------------------------------------------------------------------------------------------------------------
 // row-wise / element-wise stages
 // ------------------------------------------------------------------------------------------------------------------
-// per-example guide noise: eps[i][j] = normal word j of the example's sample key (svi.py:289-290; single site 'z')
-// (data-parallel: a rank holds positions pos0 .. pos0 + B - 1 of a global batch of B_total examples; the key of an example
-// is a function of its GLOBAL position, so 1 GPU and N GPUs draw the same noise)
-__global__ void k_vae_eps(const uint32_t* __restrict__ jax_key, uint32_t B, uint32_t B_total, uint32_t pos0, int Z,
-                          float* __restrict__ eps)
-{
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)B * Z) return;
-    const uint32_t i = (uint32_t)(t / Z), j = (uint32_t)(t % Z);
-    uint32_t k0, k1;
-    px_sample_key(jax_key[0], jax_key[1], B_total, pos0 + i, k0, k1);
-    eps[t] = bits_to_normal(tf_iota_word(k0, k1, (uint64_t)Z, (uint64_t)j));
-}
-
 // DPSVI.evaluate: ONE guide draw for the whole batch -- eps = normal(k_z, (B, Z)) with
 // rng_key_eval = split(key)[1], guide_seed = split(.)[1], k_z = split(.)[1]  (numpyro SVI.evaluate / Trace_ELBO / seed handler)
 __global__ void k_vae_eval_eps(const uint32_t* __restrict__ jax_key, uint32_t B, int Z, float* __restrict__ eps)
@@ -545,16 +541,28 @@ __global__ void k_vae_eval_eps(const uint32_t* __restrict__ jax_key, uint32_t B,
 
 // zl, u (B x Z), eps -> z = zl + exp(u) eps (written over zl), sd = exp(u) (written over u), lat[i] = log q - log p
 // (zl / u, like dz / du below, are the two halves of one B x 2 Z array: row stride ld)
-__global__ void k_vae_latent(float* __restrict__ zl, float* __restrict__ u, const float* __restrict__ eps, uint32_t B, int Z, int ld,
-                             float* __restrict__ lat)
+// jax_key != nullptr: the guide noise is drawn here -- eps[i][j] = normal word j of example i's sample key (svi.py:289-290;
+// single site 'z'; the key of an example is a function of its GLOBAL position pos0 + i in a batch of B_total, so 1 GPU and N
+// GPUs draw the same noise) -- and written to eps_out for the backward pass; otherwise eps_in is used (tests, evaluate).
+__global__ void k_vae_latent(float* __restrict__ zl, float* __restrict__ u, const float* __restrict__ eps_in, const uint32_t* __restrict__ jax_key,
+                             uint32_t B_total, uint32_t pos0, float* __restrict__ eps_out, uint32_t B, int Z, int ld, float* __restrict__ lat)
 {
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (i >= B) return;
+    uint32_t k0 = 0, k1 = 0;
+    if (jax_key) px_sample_key(jax_key[0], jax_key[1], B_total, pos0 + i, k0, k1);
     float acc = 0.f;
     for (int j = lane; j < Z; j += 64) {
         const size_t e = (size_t)i * ld + j;
-        const float uu = u[e], ee = eps[(size_t)i * Z + j];
+        float ee;
+        if (jax_key) {
+            ee = bits_to_normal(tf_iota_word(k0, k1, (uint64_t)Z, (uint64_t)j));
+            eps_out[(size_t)i * Z + j] = ee;
+        } else {
+            ee = eps_in[(size_t)i * Z + j];
+        }
+        const float uu = u[e];
         const float sd = expf(uu), z = __fmaf_rn(sd, ee, zl[e]);
         zl[e] = z;
         u[e] = sd;
@@ -565,15 +573,18 @@ __global__ void k_vae_latent(float* __restrict__ zl, float* __restrict__ u, cons
 }
 
 // logits a (B x D), x -> da = sc (sigmoid(a) - x) in place; px_loss[i] = sc (lat_i - sum_j (x a - softplus(a))) mask_i
+// (also leaves x2[i] = |x_i|^2 for the norm kernel, which then need not read X again)
 __global__ void k_vae_out(float* __restrict__ a, const float* __restrict__ X, const uint8_t* __restrict__ mask, uint32_t B, int D,
-                          float sc, const float* __restrict__ lat, float* __restrict__ px_loss)
+                          float sc, const float* __restrict__ lat, float* __restrict__ px_loss, float* __restrict__ x2)
 {
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (i >= B) return;
     // one exponential per element: e = exp(-|t|) gives softplus(t) = max(t, 0) + log1p(e) and sigmoid(t) = 1 / (1 + e) for
     // t >= 0, e / (1 + e) otherwise
+    float xx = 0.f;
     auto elem = [&](float t, float x, float& ll) {
+        xx = __fmaf_rn(x, x, xx);
         // (hardware exp2 / log2 / rcp paths: 1 + e is in (1, 2], so log(1 + e) has an absolute error of ~1e-7 against terms >= ln 2 e)
         const float e = __expf(-fabsf(t)), r = __builtin_amdgcn_rcpf(1.0f + e);
         ll += x * t - (fmaxf(t, 0.0f) + __logf(1.0f + e));
@@ -593,19 +604,11 @@ __global__ void k_vae_out(float* __restrict__ a, const float* __restrict__ X, co
         for (int j = lane; j < D; j += 64) ar[j] = elem(ar[j], xr[j], ll);
     }
     ll = wave_sum(ll);
-    if (lane == 0) px_loss[i] = (mask && mask[i] == 0) ? 0.f : sc * (lat[i] - ll);
-}
-
-// dzraw (B x Z) = dpre2 V1^T  ->  dz = dzraw + sc z,  du = dz sd eps - sc
-__global__ void k_vae_dlatent(float* __restrict__ dz, float* __restrict__ du, const float* __restrict__ z,
-                              const float* __restrict__ sd, const float* __restrict__ eps, size_t n, int Z, int ld, float sc)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const size_t e = i / Z * ld + i % Z;
-    const float t = __fmaf_rn(sc, z[e], dz[e]);
-    dz[e] = t;
-    du[e] = t * sd[e] * eps[i] - sc;
+    xx = wave_sum(xx);
+    if (lane == 0) {
+        px_loss[i] = (mask && mask[i] == 0) ? 0.f : sc * (lat[i] - ll);
+        x2[i] = xx;
+    }
 }
 
 __device__ __forceinline__ float row_sumsq(const float* __restrict__ r, int n, int lane)
@@ -619,7 +622,7 @@ __device__ __forceinline__ float row_sumsq(const float* __restrict__ r, int n, i
 // the five delta arrays are staged in LDS while their squares are summed and written back scaled by c_i (svi.py:121-122
 // folded into the sums), so the deltas are read once and written once (a separate rescaling pass read them a second time)
 struct NormArgs {
-    const float *X, *h1, *z, *h2;         // layer inputs
+    const float *x2, *h1, *z, *h2;        // layer inputs (x2: |x_i|^2 from k_vae_out)
     float *dpre1, *dz, *du, *dpre2, *da;  // layer deltas, rescaled in place
     const uint8_t* mask;
     uint32_t B;
@@ -657,7 +660,7 @@ __global__ void k_vae_norms(NormArgs a)
     float* r_d1 = a.dpre1 + (size_t)i * a.H;
     float* r_dz = a.dz + (size_t)i * a.ldz;
     float* r_du = a.du + (size_t)i * a.ldz;
-    const float x2 = row_sumsq(a.X + (size_t)i * a.D, a.D, lane), h12 = row_sumsq(a.h1 + (size_t)i * a.H, a.H, lane);
+    const float x2 = a.x2[i], h12 = row_sumsq(a.h1 + (size_t)i * a.H, a.H, lane);
     const float z2 = row_sumsq(a.z + (size_t)i * a.ldz, a.Z, lane), h22 = row_sumsq(a.h2 + (size_t)i * a.H, a.H, lane);
     const float d1 = row_sumsq_keep(r_d1, a.H, lane, k_d1), dz = row_sumsq_keep(r_dz, a.Z, lane, k_dz);
     const float du = row_sumsq_keep(r_du, a.Z, lane, k_du), d2 = row_sumsq_keep(r_d2, a.H, lane, k_d2);
@@ -853,7 +856,7 @@ static VaeLayout vae_layout(const d3p_vae_model* m)
 
 struct VaeWorkspace {
     float *h1, *sg1, *zl, *u, *eps, *h2, *sg2, *a, *dh2, *dz, *du, *dh1;
-    float *lat, *px_loss, *cf, *sums, *noise, *part, *wpart;
+    float *lat, *px_loss, *x2, *cf, *sums, *noise, *part, *wpart;
     size_t part_floats;
     uint32_t* keys;  // 3 x 16 split + 10 x 16 site keys + jax key
 };
@@ -876,6 +879,7 @@ static size_t vae_carve(const d3p_vae_model* m, uint32_t B, char* base, VaeWorks
     q = take(B * H); if (ws) ws->dh1 = q;
     q = take(B); if (ws) ws->lat = q;
     q = take(B); if (ws) ws->px_loss = q;
+    q = take(B); if (ws) ws->x2 = q;
     q = take(B); if (ws) ws->cf = q;
     q = take(P + 2); if (ws) ws->sums = q;
     q = take(P); if (ws) ws->noise = q;
@@ -895,8 +899,10 @@ static int vae_validate(const d3p_vae_model* m, const char* what)
 }
 
 // forward pass: activations, the reparametrised latent, da = sc (sigmoid(a) - x) and px_loss[i] = sc (log q - log p - log lik)
+// eps != nullptr: given noise; otherwise drawn from jax_key inside k_vae_latent into ws.eps
 static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const float* params, const float* X, const uint8_t* mask,
-                               uint32_t B, const float* eps, float sc, const VaeWorkspace& ws)
+                               uint32_t B, const float* eps, float sc, const VaeWorkspace& ws, const uint32_t* jax_key = nullptr,
+                               uint32_t B_total = 0, uint32_t pos0 = 0)
 {
     int rc;
     const int D = m->D, H = m->H, Z = m->Z, Bi = (int)B;
@@ -912,11 +918,12 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
     if ((rc = gemm(s, ws.h1, H, 1, params + L.Wl, Z, 1, ws.zl, ldz, Bi, 2 * Z, H, params + L.bl, 1.f, 0, 0, ws.part, ws.part_floats, 0, nullptr,
                    nullptr, &enc)))
         return rc;
-    hipLaunchKernelGGL(k_vae_latent, rows, dim3(256), 0, s, ws.zl, ws.u, eps, B, Z, ldz, ws.lat);  // zl := z, u := sd
+    hipLaunchKernelGGL(k_vae_latent, rows, dim3(256), 0, s, ws.zl, ws.u, eps, eps ? (const uint32_t*)nullptr : jax_key, B_total ? B_total : B, pos0,
+                       ws.eps, B, Z, ldz, ws.lat);  // zl := z, u := sd
     // ---- decoder (model)
     if ((rc = gemm(s, ws.zl, ldz, 1, params + L.V1, H, 1, ws.h2, H, Bi, H, Z, params + L.c1, 1.f, 0, 0, nullptr, 0, 1, ws.sg2))) return rc;
     if ((rc = gemm(s, ws.h2, H, 1, params + L.V2, D, 1, ws.a, D, Bi, D, H, params + L.c2, 1.f, 0))) return rc;
-    hipLaunchKernelGGL(k_vae_out, rows, dim3(256), 0, s, ws.a, X, mask, B, D, sc, (const float*)ws.lat, ws.px_loss);  // a := da
+    hipLaunchKernelGGL(k_vae_out, rows, dim3(256), 0, s, ws.a, X, mask, B, D, sc, (const float*)ws.lat, ws.px_loss, ws.x2);  // a := da
     return check_launch("d3p_vae forward");
 }
 
@@ -932,20 +939,17 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     const int D = m->D, H = m->H, Z = m->Z, Bi = (int)B;
     const VaeLayout L = vae_layout(m);
     const float sc = m->inv_obs * m->scale;
-    const float* eps = eps_ext;
-    if (!eps) {
-        hipLaunchKernelGGL(k_vae_eps, dim3(cdiv((uint64_t)B * Z, 256)), dim3(256), 0, s, jax_key, B, B_total, pos0, Z, ws.eps);
-        eps = ws.eps;
-    }
+    const float* eps = eps_ext ? eps_ext : ws.eps;  // (drawn inside k_vae_latent when not given)
     auto ew = [&](size_t n) { return dim3(cdiv(n, 256)); };
     const dim3 rows(cdiv((uint64_t)B * 64, 256));
-    if ((rc = vae_enqueue_forward(s, m, params, X, mask, B, eps, sc, ws))) return rc;
+    if ((rc = vae_enqueue_forward(s, m, params, X, mask, B, eps_ext, sc, ws, jax_key, B_total, pos0))) return rc;
     // ---- backward (data)
     if ((rc = gemm(s, ws.a, D, 1, params + L.V2, 1, D, ws.dh2, H, Bi, H, D, nullptr, 1.f, 0, 0, ws.part, ws.part_floats, 2, ws.sg2))) return rc;  // dpre2 = (da V2^T) . softplus'(pre2)
     const int ldz = 2 * Z;
-    if ((rc = gemm(s, ws.dh2, H, 1, params + L.V1, 1, H, ws.dz, ldz, Bi, Z, H, nullptr, 1.f, 0, 0, ws.part, ws.part_floats))) return rc;  // dpre2 V1^T
-    hipLaunchKernelGGL(k_vae_dlatent, ew((size_t)B * Z), dim3(256), 0, s, ws.dz, ws.du, (const float*)ws.zl, (const float*)ws.u, eps,
-                       (size_t)B * Z, Z, ldz, sc);
+    // dz = dpre2 V1^T + sc z and du = dz sd eps - sc in the product's epilogue (epi 3; was the k_vae_dlatent launch)
+    if ((rc = gemm(s, ws.dh2, H, 1, params + L.V1, 1, H, ws.dz, ldz, Bi, Z, H, nullptr, 1.f, 0, 0, ws.part, ws.part_floats, 3, nullptr, nullptr,
+                   nullptr, ws.zl, eps, Z, sc)))
+        return rc;
     // dpre1 = ([dz | du] [Wl^T ; Ws^T]) . softplus'(pre1): ONE product of K = 2 Z (rows Z .. 2 Z - 1 of the stacked B are Ws^T,
     // H Z behind where Wl^T's would be)
     const GemmJumps dec = {0x7fffffff, Z, 0, (long long)H * Z, 0, 0};
@@ -953,7 +957,7 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
         return rc;
     // ---- per-example norms and clip factors; the rows of every delta come back scaled by c_i
     NormArgs na;
-    na.X = X; na.h1 = ws.h1; na.z = ws.zl; na.h2 = ws.h2;
+    na.x2 = ws.x2; na.h1 = ws.h1; na.z = ws.zl; na.h2 = ws.h2;
     na.dpre1 = ws.dh1; na.dz = ws.dz; na.du = ws.du; na.dpre2 = ws.dh2; na.da = ws.a;
     na.mask = mask; na.B = B; na.D = D; na.H = H; na.Z = Z; na.ldz = ldz; na.clip = clip; na.cf = ws.cf; na.norms = norms_out;
     hipLaunchKernelGGL(k_vae_norms, rows, dim3(256), 4 * (size_t)(D + 2 * H + 2 * Z) * sizeof(float), s, na);
