@@ -630,6 +630,8 @@ struct NormArgs {
     float clip;
     float* cf;
     float* norms;  // nullable
+    const float* px_loss;  // the LAST workgroup of the launch sums px_loss and counts the unmasked examples into loss_n[0..1]
+    float* loss_n;         // (fixed order; was a launch of its own)
 };
 
 // sum of squares of a row while copying it to `keep` (lane l owns elements l, l + 64, ...)
@@ -647,6 +649,24 @@ __device__ __forceinline__ float row_sumsq_keep(const float* __restrict__ r, int
 __global__ void k_vae_norms(NormArgs a)
 {
     extern __shared__ float norm_stage[];  // 4 waves x (D + 2 H + 2 Z)
+    if (blockIdx.x == gridDim.x - 1) {  // sums[P] = sum_i px_loss[i], sums[P + 1] = number of unmasked examples
+        float* l = norm_stage;
+        float* c = norm_stage + 256;
+        float s = 0.f, n = 0.f;
+        for (uint32_t i = threadIdx.x; i < a.B; i += 256) {
+            s += a.px_loss[i];
+            n += (a.mask && a.mask[i] == 0) ? 0.f : 1.f;
+        }
+        l[threadIdx.x] = s;
+        c[threadIdx.x] = n;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) { l[threadIdx.x] += l[threadIdx.x + off]; c[threadIdx.x] += c[threadIdx.x + off]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { a.loss_n[0] = l[0]; a.loss_n[1] = c[0]; }
+        return;
+    }
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (i >= a.B) return;
@@ -960,7 +980,12 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     na.x2 = ws.x2; na.h1 = ws.h1; na.z = ws.zl; na.h2 = ws.h2;
     na.dpre1 = ws.dh1; na.dz = ws.dz; na.du = ws.du; na.dpre2 = ws.dh2; na.da = ws.a;
     na.mask = mask; na.B = B; na.D = D; na.H = H; na.Z = Z; na.ldz = ldz; na.clip = clip; na.cf = ws.cf; na.norms = norms_out;
-    hipLaunchKernelGGL(k_vae_norms, rows, dim3(256), 4 * (size_t)(D + 2 * H + 2 * Z) * sizeof(float), s, na);
+    na.px_loss = ws.px_loss; na.loss_n = ws.sums + L.P;
+    {
+        size_t stage_floats = 4 * (size_t)(D + 2 * H + 2 * Z);
+        if (stage_floats < 512) stage_floats = 512;  // the last workgroup's loss / count reduction uses 2 x 256 floats
+        hipLaunchKernelGGL(k_vae_norms, dim3(rows.x + 1), dim3(256), stage_floats * sizeof(float), s, na);
+    }
     // ---- clipped sums: weights  A^T (diag(c) Delta)  (GEMMs over the batch), biases = column sums
     // [W | b] of every layer is contiguous in the flat layout, so the bias gradient is row `in` of a GEMM whose A carries a
     // virtual row of ones
@@ -983,7 +1008,6 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
             if (b == 3) w_splits[4] = left;
         }
     }
-    hipLaunchKernelGGL(k_vae_loss_n, dim3(1), dim3(256), 0, s, (const float*)ws.px_loss, mask, B, S + L.P);
     return check_launch("d3p_vae sums");
 }
 
