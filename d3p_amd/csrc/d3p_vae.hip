@@ -322,21 +322,30 @@ __global__ void __launch_bounds__(512) k_gemm_f32_w8(GemmArgs g)
 
     // (separate variables, not arrays: an array of float4 written on two paths was promoted to LDS by the compiler)
     float4 ra00, ra01, rb0, ra10, ra11, rb1;
-    auto fetch = [&](auto S, int k0) {  // slice starting at k0 -> register set S; exactly three loads on either path
+    // Register set S fetches the slices S, S + 2, S + 4, ... of the split: its slice base pointers and k advance by two slices per
+    // use (two scalar adds each -- a 64-bit k0 * stride product per fetch cost a dozen scalar instructions, and on this chip
+    // they too wait for the MFMA in flight).
+    const long long a_step2 = 2ll * D3P_GKB * a_kstride, b_step2 = 2ll * D3P_GKB * b_kstride;
+    int fk[2] = {kbeg, kbeg + D3P_GKB};
+    const float* fa[2] = {a_tile + (long long)kbeg * a_kstride, a_tile + (long long)(kbeg + D3P_GKB) * a_kstride};
+    const float* fb[2] = {b_tile + (long long)kbeg * b_kstride, b_tile + (long long)(kbeg + D3P_GKB) * b_kstride};
+    auto fetch = [&](auto S) {  // the set's next slice -> register set S; exactly three loads on either path
         constexpr int s = decltype(S)::value;
         float4 &a0 = s ? ra10 : ra00, &a1 = s ? ra11 : ra01, &bb = s ? rb1 : rb0;
+        const int k0 = fk[s];
         if (k0 + D3P_GKB <= g.K) {
-            const float* as = a_tile + (long long)k0 * a_kstride;
-            const float* bs = b_tile + (long long)k0 * b_kstride;
-            a0 = *reinterpret_cast<const float4*>(as + a_off[0]);
-            a1 = *reinterpret_cast<const float4*>(as + a_off[1]);
-            bb = *reinterpret_cast<const float4*>(bs + b_off);
+            a0 = *reinterpret_cast<const float4*>(fa[s] + a_off[0]);
+            a1 = *reinterpret_cast<const float4*>(fa[s] + a_off[1]);
+            bb = *reinterpret_cast<const float4*>(fb[s] + b_off);
         } else {
             const int gk0 = k0 + a_k[0], gk1 = k0 + a_k[1], gkb = k0 + b_k;
             a0 = *reinterpret_cast<const float4*>(g.A + a_row[0] + (long long)(gk0 < ka_last ? gk0 : ka_last) * a_kstride);
             a1 = *reinterpret_cast<const float4*>(g.A + a_row[1] + (long long)(gk1 < ka_last ? gk1 : ka_last) * a_kstride);
             bb = *reinterpret_cast<const float4*>(g.B + b_row + (long long)(gkb < kb_last ? gkb : kb_last) * b_kstride);
         }
+        fk[s] = k0 + 2 * D3P_GKB;
+        fa[s] += a_step2;
+        fb[s] += b_step2;
     };
     auto stage = [&](auto S, int buf, int k0) {  // register set S (slice starting at k0) -> LDS buffer, edges applied
         constexpr int s = decltype(S)::value;
@@ -396,10 +405,10 @@ __global__ void __launch_bounds__(512) k_gemm_f32_w8(GemmArgs g)
     // reader issued (and completed) its reads, and read after the barrier that follows its writes.
     // (the slice count is rounded up to even: the register-set indices stay compile-time constants; empty slices multiply zeros)
     Frag f0, f1;
-    fetch(S0{}, kbeg);
-    fetch(S1{}, kbeg + KB);
+    fetch(S0{});
+    fetch(S1{});
     stage(S0{}, 0, kbeg);
-    fetch(S0{}, kbeg + 2 * KB);
+    fetch(S0{});
     __syncthreads();
     read_frags(0, f0);
     const int ns = (kend - kbeg + KB - 1) / KB;
@@ -407,14 +416,14 @@ __global__ void __launch_bounds__(512) k_gemm_f32_w8(GemmArgs g)
         const int k_i = kbeg + i * KB;
         mma_half(f0, 0);
         stage(S1{}, 1, k_i + KB);
-        fetch(S1{}, k_i + 3 * KB);
+        fetch(S1{});
         __syncthreads();
         read_frags(1, f1);
         mma_half(f0, 1);
         __builtin_amdgcn_sched_barrier(0);
         mma_half(f1, 0);
         stage(S0{}, 0, k_i + 2 * KB);
-        fetch(S0{}, k_i + 4 * KB);
+        fetch(S0{});
         __syncthreads();
         read_frags(0, f0);
         mma_half(f1, 1);
