@@ -255,7 +255,8 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
 //   * k beyond the split's range: A is multiplied by 0 there (B may hold anything finite);
 //   * rows of A beyond m_real: multiplied by 0, plus 1 for the virtual row of ones; rows >= M / columns >= N only feed
 //     accumulator entries that are never stored.
-// The host guarantees m_real % 4 == 0 for an m-fast A and N % 4 == 0 for an n-fast B (a float4 is inside or outside whole).
+// The host guarantees N % 4 == 0 for an n-fast B (a float4 is inside or outside whole) and, for an m-fast A, a row stride of at
+// least roundup4(m_real) (the last float4 may hold up to three rows past m_real, masked one by one).
 // AK: A is k-fast (a_sk == 1), otherwise m-fast (a_sm == 1); BN: B is n-fast (b_sn == 1), otherwise k-fast (b_sk == 1).
 // ------------------------------------------------------------------------------------------------------------------
 #define D3P_GTM 128
@@ -293,7 +294,9 @@ __global__ void __launch_bounds__(512) k_gemm_f32_w8(GemmArgs g)
     // K or lie beyond it -- the tail and the prefetches past the end -- clamp k per thread), and a tile that touches neither the
     // last rows of A nor the end of the split's K range is staged as loaded.
     const int ka_last = g.K - (AK ? 4 : 1), kb_last = g.K - (BN ? 1 : 4);
-    const int m_last = m_real - (AK ? 1 : 4), n_last = g.N - (BN ? 4 : 1);
+    // (m-fast A: the last float4 that holds real rows starts at roundup4(m_real) - 4; it may run up to 3 rows past m_real inside the
+    // row stride -- the host checks a_sk >= roundup4(m_real) -- and those rows are masked one by one)
+    const int m_last = AK ? m_real - 1 : ((m_real + 3) & ~3) - 4, n_last = g.N - (BN ? 4 : 1);
     const long long a_kstride = AK ? 1 : g.a_sk, b_kstride = BN ? g.b_sk : 1;
     long long a_row[2];  // element offset of this thread's (clamped) row(s), k = 0
     unsigned a_off[2];   // ... + its k offset inside a slice, relative to the slice base
@@ -311,14 +314,14 @@ __global__ void __launch_bounds__(512) k_gemm_f32_w8(GemmArgs g)
     const float* b_tile = g.B + (BN ? (long long)n_base : (long long)n_base * g.b_sn);
     const unsigned b_off = (unsigned)(b_row - (BN ? (long long)n_base : (long long)n_base * g.b_sn) + (long long)b_k * b_kstride);
     const bool m_edge = m0 + D3P_GTM > m_real;  // uniform: some rows of the tile are virtual (ones row) or absent
-    float keep_m[2], one_m[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int gm = m0 + a_m[r];
-        keep_m[r] = gm < m_real ? 1.f : 0.f;
-        // the ones row: row m_real when a_last_one.  m-fast: m_real % 4 == 0, so it is the FIRST of the thread's four rows
-        one_m[r] = (g.a_last_one && gm == m_real) ? 1.f : 0.f;
-    }
+    // edge factors (constant over the slices): keep = 1 for a row that exists in memory, one = 1 for the virtual row of ones (row
+    // m_real when a_last_one).  k-fast A: a float4 is one row (two rows per thread); m-fast A: four rows gm .. gm + 3, the same for
+    // both of the thread's float4s.
+    const int gm_a0 = m0 + a_m[0], gm_a1 = m0 + a_m[1];
+    auto keep_of = [&](int row) { return row < m_real ? 1.f : 0.f; };
+    auto one_of = [&](int row) { return (g.a_last_one && row == m_real) ? 1.f : 0.f; };
+    const float kp0 = keep_of(gm_a0), kp1 = AK ? keep_of(gm_a1) : keep_of(gm_a0 + 1), kp2 = keep_of(gm_a0 + 2), kp3 = keep_of(gm_a0 + 3);
+    const float on0 = one_of(gm_a0), on1 = AK ? one_of(gm_a1) : one_of(gm_a0 + 1), on2 = one_of(gm_a0 + 2), on3 = one_of(gm_a0 + 3);
 
     // (separate variables, not arrays: an array of float4 written on two paths was promoted to LDS by the compiler)
     float4 ra00, ra01, rb0, ra10, ra11, rb1;
@@ -354,10 +357,15 @@ __global__ void __launch_bounds__(512) k_gemm_f32_w8(GemmArgs g)
         if (m_edge || k0 + D3P_GKB > kend) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const float in_k = (k0 + a_k[r] < kend) ? 1.f : 0.f, keep = keep_m[r] * in_k, one = one_m[r] * in_k;
+                const float in_k = (k0 + a_k[r] < kend) ? 1.f : 0.f;
                 const float4 v = o[r];
-                o[r] = make_float4(__fmaf_rn(v.x, keep, one), __fmaf_rn(v.y, keep, AK ? one : 0.f), __fmaf_rn(v.z, keep, AK ? one : 0.f),
-                                   __fmaf_rn(v.w, keep, AK ? one : 0.f));
+                if (AK) {  // one row per float4: thread rows gm_a0 (r = 0), gm_a1 (r = 1)
+                    const float keep = (r ? kp1 : kp0) * in_k, one = (r ? on1 : on0) * in_k;
+                    o[r] = make_float4(__fmaf_rn(v.x, keep, one), __fmaf_rn(v.y, keep, one), __fmaf_rn(v.z, keep, one), __fmaf_rn(v.w, keep, one));
+                } else {   // four rows per float4
+                    o[r] = make_float4(__fmaf_rn(v.x, kp0 * in_k, on0 * in_k), __fmaf_rn(v.y, kp1 * in_k, on1 * in_k),
+                                       __fmaf_rn(v.z, kp2 * in_k, on2 * in_k), __fmaf_rn(v.w, kp3 * in_k, on3 * in_k));
+                }
             }
         }
         if (AK) {
@@ -491,7 +499,10 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     const bool vb = aligned16(B) && K % 4 == 0 && ((b_sn == 1 && b_sk % 4 == 0) || (b_sk == 1 && b_sn % 4 == 0)) &&
                     !(jumps && (jumps->b_njump || jumps->b_kjump));  // displaced B segments: scalar fetch only
     // 128 x 64 tiles (k_gemm_f32_w8): whole float4s only (see its header)
-    const bool big = va && vb && M > 96 && (a_sk == 1 || (a_last_one ? M - 1 : M) % 4 == 0) && (b_sn != 1 || N % 4 == 0);
+    // (also for a short, very deep product -- the V1 weight gradient, 51 x 400 x 4096: its workgroups run alone on their CUs, where
+    // the 64 x 64 kernel's one-slice pipeline leaves every load latency exposed: 21.7 us)
+    const int m_real_h = a_last_one ? M - 1 : M;
+    const bool big = va && vb && (M > 96 || (M > 32 && K >= 2048)) && (a_sk == 1 || a_sk >= ((m_real_h + 3) & ~3)) && (b_sn != 1 || N % 4 == 0);
     const int tm = big ? D3P_GTM : D3P_GT;
     const unsigned tiles = cdiv(N, D3P_GT) * cdiv(M, tm);
     int splits = 1;

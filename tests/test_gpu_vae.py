@@ -55,6 +55,21 @@ def test_mfma_gemm_vs_torch(lib, M, N, K, form):
     assert torch.all(out2[:, N:] == 7.0)
 
 
+def test_mfma_gemm_short_deep_product_with_padded_row_stride(lib):
+    """A^T B with A stored K x ld, ld > M and M % 4 != 0 (the V1 weight gradient's shape: the [z | z_std] array is B x 100, 50
+    columns are z): the eight-wave kernel's last float4 of rows runs past M inside the row stride and is masked row by row."""
+    M, N, K, ld = 51, 132, 2048, 100
+    g = torch.Generator().manual_seed(7)
+    At = torch.randn(K, ld, generator=g).cuda()          # columns >= M are junk that must not leak into the product
+    Bm = torch.randn(K, N, generator=g).cuda()
+    out = torch.empty(M, N, device="cuda")
+    L = lib.load()
+    lib.check(L.d3p_gemm_f32(lib.stream_ptr(), lib.ptr(At), 1, ld, lib.ptr(Bm), N, 1, lib.ptr(out), N, M, N, K, None, 1.0, 0))
+    ref = At[:, :M].double().t() @ Bm.double()
+    scale = float((At[:, :M].abs().double().t() @ Bm.abs().double()).max())
+    assert float((out.double() - ref).abs().max()) <= 2e-5 * scale
+
+
 def vae_problem(B, D, H, Z, seed, pscale=0.2):
     import oracle.oracle as O
     r = np.random.default_rng(seed)
