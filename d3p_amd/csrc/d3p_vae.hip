@@ -293,7 +293,10 @@ __global__ void __launch_bounds__(512) k_gemm_f32_w8(GemmArgs g)
     // slice that lies inside [0, K) whole is fetched from base + offset (no per-thread arithmetic; the few slices that straddle
     // K or lie beyond it -- the tail and the prefetches past the end -- clamp k per thread), and a tile that touches neither the
     // last rows of A nor the end of the split's K range is staged as loaded.
-    const int ka_last = g.K - (AK ? 4 : 1), kb_last = g.K - (BN ? 1 : 4);
+    // (K need not be a multiple of 4: the last float4 of a k-fast operand then runs past K inside its row -- the host checks the row
+    // stride -- and A is masked element by element there; what B holds beyond K multiplies zeros)
+    const int K4 = (g.K + 3) & ~3;
+    const int ka_last = AK ? K4 - 4 : g.K - 1, kb_last = BN ? g.K - 1 : K4 - 4;
     // (m-fast A: the last float4 that holds real rows starts at roundup4(m_real) - 4; it may run up to 3 rows past m_real inside the
     // row stride -- the host checks a_sk >= roundup4(m_real) -- and those rows are masked one by one)
     const int m_last = AK ? m_real - 1 : ((m_real + 3) & ~3) - 4, n_last = g.N - (BN ? 4 : 1);
@@ -359,9 +362,12 @@ __global__ void __launch_bounds__(512) k_gemm_f32_w8(GemmArgs g)
             for (int r = 0; r < 2; ++r) {
                 const float in_k = (k0 + a_k[r] < kend) ? 1.f : 0.f;
                 const float4 v = o[r];
-                if (AK) {  // one row per float4: thread rows gm_a0 (r = 0), gm_a1 (r = 1)
-                    const float keep = (r ? kp1 : kp0) * in_k, one = (r ? on1 : on0) * in_k;
-                    o[r] = make_float4(__fmaf_rn(v.x, keep, one), __fmaf_rn(v.y, keep, one), __fmaf_rn(v.z, keep, one), __fmaf_rn(v.w, keep, one));
+                if (AK) {  // one row, four k's per float4: thread rows gm_a0 (r = 0), gm_a1 (r = 1)
+                    const float keep = r ? kp1 : kp0, one = r ? on1 : on0;
+                    const int kq = k0 + a_k[r];
+                    const float i0 = kq + 0 < kend ? 1.f : 0.f, i1 = kq + 1 < kend ? 1.f : 0.f, i2 = kq + 2 < kend ? 1.f : 0.f, i3 = kq + 3 < kend ? 1.f : 0.f;
+                    o[r] = make_float4(__fmaf_rn(v.x, keep * i0, one * i0), __fmaf_rn(v.y, keep * i1, one * i1), __fmaf_rn(v.z, keep * i2, one * i2),
+                                       __fmaf_rn(v.w, keep * i3, one * i3));
                 } else {   // four rows per float4
                     o[r] = make_float4(__fmaf_rn(v.x, kp0 * in_k, on0 * in_k), __fmaf_rn(v.y, kp1 * in_k, on1 * in_k),
                                        __fmaf_rn(v.z, kp2 * in_k, on2 * in_k), __fmaf_rn(v.w, kp3 * in_k, on3 * in_k));
@@ -501,8 +507,12 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     // 128 x 64 tiles (k_gemm_f32_w8): whole float4s only (see its header)
     // (also for a short, very deep product -- the V1 weight gradient, 51 x 400 x 4096: its workgroups run alone on their CUs, where
     // the 64 x 64 kernel's one-slice pipeline leaves every load latency exposed: 21.7 us)
-    const int m_real_h = a_last_one ? M - 1 : M;
-    const bool big = va && vb && (M > 96 || (M > 32 && K >= 2048)) && (a_sk == 1 || a_sk >= ((m_real_h + 3) & ~3)) && (b_sn != 1 || N % 4 == 0);
+    const int m_real_h = a_last_one ? M - 1 : M, K4 = (K + 3) & ~3;
+    // (the eight-wave kernel takes any K: a k-fast operand needs a row stride of at least roundup4(K))
+    const bool va8 = aligned16(A) && ((a_sk == 1 && a_sm % 4 == 0 && a_sm >= K4) || (a_sm == 1 && a_sk % 4 == 0 && a_sk >= ((m_real_h + 3) & ~3)));
+    const bool vb8 = aligned16(B) && ((b_sn == 1 && b_sk % 4 == 0 && N % 4 == 0) || (b_sk == 1 && b_sn % 4 == 0 && b_sn >= K4)) &&
+                     !(jumps && (jumps->b_njump || jumps->b_kjump));
+    const bool big = va8 && vb8 && (M > 96 || (M > 32 && K >= 2048));
     const int tm = big ? D3P_GTM : D3P_GT;
     const unsigned tiles = cdiv(N, D3P_GT) * cdiv(M, tm);
     int splits = 1;

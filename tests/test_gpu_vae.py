@@ -70,6 +70,21 @@ def test_mfma_gemm_short_deep_product_with_padded_row_stride(lib):
     assert float((out.double() - ref).abs().max()) <= 2e-5 * scale
 
 
+def test_mfma_gemm_k_not_a_multiple_of_four_with_padded_rows(lib):
+    """A B with A stored M x ld, ld > K and K % 4 != 0 (h2 = z V1: z is the first 50 columns of a B x 100 array): the eight-wave
+    kernel's last float4 along k runs past K inside the row and is masked element by element."""
+    M, N, K, ld = 300, 132, 50, 100
+    g = torch.Generator().manual_seed(9)
+    A = torch.randn(M, ld, generator=g).cuda()           # columns >= K are junk that must not leak into the product
+    Bm = torch.randn(K + 3, N, generator=g).cuda()       # (rows >= K exist in memory, as the next parameter leaf does, and are junk too)
+    out = torch.empty(M, N, device="cuda")
+    L = lib.load()
+    lib.check(L.d3p_gemm_f32(lib.stream_ptr(), lib.ptr(A), ld, 1, lib.ptr(Bm), N, 1, lib.ptr(out), N, M, N, K, None, 1.0, 0))
+    ref = A[:, :K].double() @ Bm[:K].double()
+    scale = float((A[:, :K].abs().double() @ Bm[:K].abs().double()).max())
+    assert float((out.double() - ref).abs().max()) <= 2e-5 * scale
+
+
 def vae_problem(B, D, H, Z, seed, pscale=0.2):
     import oracle.oracle as O
     r = np.random.default_rng(seed)
