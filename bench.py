@@ -90,6 +90,8 @@ def spawn_ranks(n):
     GPU (counting devices does not), the ranks are fresh interpreters; rank 0 prints the JSON line to the shared stdout."""
     import torch
     have = torch.cuda.device_count()
+    if os.environ.get("D3P_BENCH_SHARE_GPU"):  # developer rehearsal of the N > 1 flow on a one-GPU box: every rank on cuda:0
+        have = n
     if have < n:
         print(f"[bench] --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
@@ -165,11 +167,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    share_gpu = bool(os.environ.get("D3P_BENCH_SHARE_GPU"))  # rehearsal: all ranks on cuda:0, gloo instead of RCCL (which refuses
+    if share_gpu:                                               # two ranks on one device); the one-shot exchange works as usual
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or (args.force_dist_loop and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     L.require_device()
     lib = L.load()
 
