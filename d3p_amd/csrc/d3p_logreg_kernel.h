@@ -70,7 +70,11 @@ __device__ __forceinline__ void px_sample_key(uint32_t j0, uint32_t j1, uint32_t
 
 
 // (row layout of a fixed-point accumulator replica, loss_split / loss_join: d3p_device.h)
-#define D3P_ACC_R 4  // replicas of the fixed-point accumulator (16-wave form: 8 -> 14.75, 4 -> 14.43, 2 -> 15.9 us/step; pipelined form: 8 -> 11.2, 4 -> 10.6, 2 -> 12.3)
+// replicas of the fixed-point accumulator (workgroup b adds to replica b % R).  Measured, us per step: 16-wave form 8 -> 14.75,
+// 4 -> 14.43, 2 -> 15.9; pipelined form 8 -> 11.2, 4 -> 10.6, 2 -> 12.3; k_logreg_chain (round 2) 8 -> 8.04, 4 -> 8.12, 2 -> 8.67
+#ifndef D3P_ACC_R
+#define D3P_ACC_R 4
+#endif
 
 // Per-step record produced by the key chain / sampler (device memory).
 struct StepSlot {
