@@ -165,6 +165,28 @@ def test_update_vs_oracle_stage_composition(gpu, O, B, D, H, Z, masked):
     assert tree["decoder$params"][1] == () and tuple(tree["encoder$params"][0][0].shape) == (D, H)
 
 
+def test_update_leaves_the_input_state_alone(gpu):
+    """The VAE update is out of place (d3p_dpvi_vae_update_from): the state passed in is bit for bit unchanged, and updating
+    from it twice gives identical results (DPSVI.update returns a NEW state, svi.py:395-434)."""
+    import d3p_amd.random as rng
+    from d3p_amd.svi import DPSVIState
+    B, D, H, Z, N = 24, 12, 7, 3, 500
+    spec, P, params, X, _ = vae_problem(B, D, H, Z, 5, 0.3)
+    svi = make_svi(Z, H, N, C=3.0, sigma=0.8, lr=1e-2)
+    Xt = torch.tensor(X.reshape(B, -1)).cuda()
+    st = DPSVIState(svi.optim.init(torch.tensor(params).cuda()), rng.PRNGKey(3), 1.0)
+    st, _ = svi.update(st, Xt)                           # (a state with non-trivial Adam moments)
+    before = [t.clone() for t in st.optim_state] + [st.rng_key.clone()]
+    a, la = svi.update(st, Xt)
+    b, lb = svi.update(st, Xt)
+    for x, y0 in zip(list(st.optim_state) + [st.rng_key], before):
+        assert torch.equal(x, y0)
+    assert float(la) == float(lb) and torch.equal(a.rng_key, b.rng_key) and int(a.optim_state[0]) == 2
+    for x, y0 in zip(a.optim_state, b.optim_state):
+        assert torch.equal(x, y0)
+    assert not torch.equal(a.optim_state[1], st.optim_state[1])
+
+
 def test_training_reduces_the_loss_on_structured_binary_images(gpu):
     """A few hundred non-private-ish steps on synthetic 'images' (two prototype patterns + flips): the ELBO improves."""
     import d3p_amd.random as rng
