@@ -1,11 +1,17 @@
-"""Mirror of the hot-path helpers of d3p.util (reference d3p/util.py:68-77, :216-301)."""
+"""Mirror of d3p.util: the hot-path helpers (reference d3p/util.py:68-77, :216-301) and, host-side only, its shape / type
+predicates (d3p/util.py:29-65, :80-213) over torch tensors, numpy arrays and Python scalars."""
+import numbers
+
+import numpy as np
 import torch
 
 from . import _lib
 from . import random as strong_rng
 from ._lib import check, ptr, stream_ptr
 
-__all__ = ["example_count", "sample_from_array", "take_rows"]
+__all__ = ["example_count", "sample_from_array", "take_rows", "map_over_secondary_dims", "has_shape", "is_array", "is_scalar",
+           "is_integer", "is_int_scalar", "normalize", "unvectorize_shape", "unvectorize_shape_1d", "unvectorize_shape_2d",
+           "unvectorize_shape_3d"]
 
 
 def example_count(a):
@@ -63,3 +69,87 @@ def sample_from_array(rng_key, x: torch.Tensor, n: int, axis: int = 0, rng_suite
         return take_rows(x, idx)
     moved = x.movedim(axis, 0).contiguous()
     return take_rows(moved, idx).movedim(0, axis)
+
+
+# ---- shape / type predicates (not on the hot path; kept so that code written against d3p.util imports unchanged)
+
+def _shape_of(a):
+    return tuple(a.shape) if hasattr(a, "shape") else tuple(np.shape(a))
+
+
+def map_over_secondary_dims(f):
+    """For T of shape (a, b_1 .. b_k): the array of f(T[:, i_1 .. i_k]), shape (b_1 .. b_k) (d3p/util.py:29-65)."""
+    def mapped(T):
+        T = torch.as_tensor(T)
+        if T.dim() < 1:
+            raise ValueError("map_over_secondary_dims: the input needs at least one dimension")
+        columns = T.reshape(T.shape[0], -1)
+        values = [torch.as_tensor(f(columns[:, j])) for j in range(columns.shape[1])]
+        out = torch.stack(values) if values else torch.empty(0, dtype=T.dtype, device=T.device)
+        return out.reshape(T.shape[1:])
+    mapped.__name__ = getattr(f, "__name__", "mapped")
+    mapped.__doc__ = getattr(f, "__doc__", None)
+    return mapped
+
+
+def has_shape(a):
+    """True for anything with a ``shape`` attribute (d3p/util.py:80-90)."""
+    return hasattr(a, "shape")
+
+
+def is_array(a):
+    """True for an array type with at least one dimension (d3p/util.py:93-101)."""
+    return has_shape(a) and len(_shape_of(a)) > 0
+
+
+def is_scalar(x):
+    """True for a scalar and for an array of exactly one element, whatever its rank (d3p/util.py:104-117)."""
+    if isinstance(x, (numbers.Number, np.generic)):
+        return True
+    if not has_shape(x):
+        return False
+    count = 1
+    for extent in _shape_of(x):
+        count *= int(extent)
+    return count == 1
+
+
+def is_integer(x):
+    """True for integer-typed scalars and arrays (d3p/util.py:120-127)."""
+    if isinstance(x, torch.Tensor):
+        return not (x.dtype.is_floating_point or x.dtype.is_complex or x.dtype == torch.bool)
+    if has_shape(x) and hasattr(x, "dtype"):
+        return np.issubdtype(x.dtype, np.integer)
+    return isinstance(x, numbers.Integral) and not isinstance(x, bool)
+
+
+def is_int_scalar(x):
+    """d3p/util.py:130-137."""
+    return is_scalar(x) and is_integer(x)
+
+
+def normalize(x):
+    """x / ||x||_2 (d3p/util.py:140-146)."""
+    if isinstance(x, torch.Tensor):
+        xf = x if x.dtype.is_floating_point else x.to(torch.float32)
+        return xf / torch.linalg.vector_norm(xf)
+    xa = np.asarray(x, dtype=np.result_type(np.asarray(x).dtype, np.float32))
+    return xa / np.linalg.norm(xa)
+
+
+def unvectorize_shape(a, d):
+    """Shape of `a`, padded FROM THE FRONT with ones up to `d` dimensions (d3p/util.py:149-171)."""
+    shape = _shape_of(a)
+    return (1,) * max(d - len(shape), 0) + shape
+
+
+def unvectorize_shape_1d(a):
+    return unvectorize_shape(a, 1)
+
+
+def unvectorize_shape_2d(a):
+    return unvectorize_shape(a, 2)
+
+
+def unvectorize_shape_3d(a):
+    return unvectorize_shape(a, 3)

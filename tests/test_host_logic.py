@@ -199,3 +199,49 @@ def test_numpyro_adapter_maps_trace_records_to_the_built_families():
     with pytest.raises(D3PError):                             # and tracing itself needs numpyro
         from d3p_amd.numpyro_adapter import trace_model
         trace_model(lambda: None)
+
+
+# ---- d3p.util shape / type predicates (known answers of the reference's tests/test_util.py:30-327)
+
+def test_util_map_over_secondary_dims_with_sum():
+    from d3p_amd import util
+    x = torch.tensor([[[.3, .4], [2., 1.], [6., 1.5]], [[1., 2.], [2.4, -1], [3.2, 1.]]])
+    expected = torch.tensor([[1.3, 2.4], [4.4, 0], [9.2, 2.5]])
+    assert torch.allclose(util.map_over_secondary_dims(torch.sum)(x), expected)
+
+
+def test_util_predicates():
+    from d3p_amd import util
+    one = torch.ones(1, 1, 1)
+    many = torch.ones(3, 2)
+    for arr in (one, many, np.ones((1,)), np.ones((2, 2))):
+        assert util.has_shape(arr) and util.is_array(arr)
+    for not_arr in (3., 3, None, (1, 2)):
+        assert not util.is_array(not_arr)
+    assert not util.has_shape(None) and not util.has_shape((1, 2)) and not util.has_shape(2.)
+    assert util.is_scalar(one) and util.is_scalar(np.ones((1, 1))) and util.is_scalar(5.) and util.is_scalar(torch.tensor(2))
+    assert not util.is_scalar(many) and not util.is_scalar((1, 2)) and not util.is_scalar(None)
+    assert util.is_integer(3) and util.is_integer(torch.arange(4)) and util.is_integer(np.arange(4)) and util.is_integer(np.int32(2))
+    assert not util.is_integer(3.) and not util.is_integer(torch.ones(3)) and not util.is_integer(np.ones(3))
+    assert util.is_int_scalar(3) and util.is_int_scalar(torch.tensor([[4]])) and util.is_int_scalar(np.array([7]))
+    assert not util.is_int_scalar(3.) and not util.is_int_scalar(torch.tensor([4.])) and not util.is_int_scalar(torch.arange(3))
+
+
+def test_util_normalize():
+    from d3p_amd import util
+    assert abs(float(torch.linalg.vector_norm(util.normalize(torch.arange(7)))) - 1.) < 1e-6
+    assert abs(float(util.normalize(8.)) - 1.) < 1e-7
+    assert abs(float(np.linalg.norm(util.normalize(np.arange(7)))) - 1.) < 1e-6
+
+
+def test_util_unvectorize_shape():
+    from d3p_amd import util
+    a = torch.tensor([[3, 4], [5, 6], [7, 8]])
+    assert util.unvectorize_shape(a, 2) == (3, 2)
+    assert util.unvectorize_shape(a, 1) == (3, 2)
+    assert util.unvectorize_shape(a, 3) == (1, 3, 2)
+    assert util.unvectorize_shape(a, 4) == (1, 1, 3, 2)
+    assert util.unvectorize_shape(3, 1) == (1,)
+    assert util.unvectorize_shape(3, 2) == (1, 1)
+    assert util.unvectorize_shape_1d(3) == (1,) and util.unvectorize_shape_2d(a) == (3, 2) and util.unvectorize_shape_3d(a) == (1, 3, 2)
+    assert util.example_count(a) == 3 and util.example_count(torch.tensor([1])) == 1 and util.example_count(3.) == 1
