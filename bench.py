@@ -168,8 +168,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     share_gpu = bool(os.environ.get("D3P_BENCH_SHARE_GPU"))  # rehearsal: all ranks on cuda:0, gloo instead of RCCL (which refuses
-    if share_gpu:                                               # two ranks on one device); the one-shot exchange works as usual
-        local_rank = 0
+    if share_gpu:                                               # two ranks on one device); the one-shot exchange works as usual,
+        local_rank = 0                                          # as one launch per step: the in-launch form needs each rank's
+        os.environ.setdefault("D3P_XCHG_PER_STEP", "1")         # launch resident beside the others', which one GPU cannot give
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or (args.force_dist_loop and "RANK" in os.environ):
@@ -267,6 +268,7 @@ def main():
                 if comm is not None and native:
                     return ddist.run_steps_native(engine, st, bkey, first, k, comm=comm, collect_losses=False)
                 return ddist.run_steps(engine, st, bkey, first, k, collect_losses=False)
+            run.native_engine = engine if (comm is not None and native) else None
         return svi, state, run, (X, y), bkey
 
     def timed_leg(run, state, first, warm, steps):
@@ -280,6 +282,12 @@ def main():
         elapsed = time.perf_counter() - t0
         L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(0))
         kt = read_kernel_timing()
+        eng = getattr(run, "native_engine", None)
+        if eng is not None:  # (the single-rank run_steps raises by itself) a stopped run must not become a number
+            code, _ = ddist.native_run_status(eng)
+            if code:
+                raise SystemExit(f"[bench] rank {rank}: the data-parallel run was stopped by a bounded wait -- "
+                                 f"{L.describe_abort(code)}")
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -243,3 +243,18 @@ def ptr(t):
     if t is None:
         return C.c_void_p(0)
     return C.c_void_p(t.data_ptr())
+
+
+_ABORT_KINDS = {1: "a bounded wait", 2: "exchange workgroup: the step's compute workgroups did not all arrive",
+                3: "exchange workgroup: the row of a rank did not come (detail = that rank)",
+                4: "compute workgroup: the previous step was not released (detail 1: by the exchange)",
+                5: "key-chain workgroup: the previous link did not come", 6: "exchange kernel: the row of a rank did not come"}
+
+
+def describe_abort(code: int) -> str:
+    """Text of a run's abort code (d3p_logreg_kernel.h: kind | step << 8 | detail << 20); '' for 0."""
+    code = int(code) & 0xffffffff
+    if code == 0:
+        return ""
+    kind, step, detail = code & 0xff, (code >> 8) & 0xfff, (code >> 20) & 0xfff
+    return f"{_ABORT_KINDS.get(kind, 'unknown wait')} [kind {kind}, step {step} of its launch, detail {detail}]"

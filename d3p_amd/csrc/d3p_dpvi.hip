@@ -44,7 +44,7 @@ struct Workspace {
     float* scratch_state;  // 3P + 4 floats: stand-in state for the timing entry point
     float* pp_state;       // 3P floats: second buffer of the ping-ponged optimiser state (one-launch-per-step path)
     uint32_t* chain_bar;   // chained form: (D3P_STEP_BATCH + 1) x D3P_BAR_WORDS arrival counters + 16 words (abort flag)
-    uint32_t* xflags;      // in-launch exchange of a data-parallel run: D3P_STEP_BATCH flags, 128 bytes apart
+    uint32_t* xflags;      // in-launch exchange of a data-parallel run: D3P_STEP_BATCH x D3P_XCHG_WGS flags, 128 bytes apart
     long long* xsum;       // ... and the world's sums of step g in row g % 3 (3 x cols)
     float* partials;  // max_blocks x (P + 2)
     unsigned long long* stamps;  // 2 x max_blocks
@@ -70,7 +70,7 @@ static size_t carve(const d3p_logreg_model* m, const d3p_batch_source* src, char
     p = take((3 * P + 4) * sizeof(float)); if (ws) ws->scratch_state = (float*)p;
     p = take(3 * P * sizeof(float)); if (ws) ws->pp_state = (float*)p;
     p = take(((size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS + 16) * sizeof(uint32_t)); if (ws) ws->chain_bar = (uint32_t*)p;
-    p = take((size_t)D3P_STEP_BATCH * 32 * sizeof(uint32_t)); if (ws) ws->xflags = (uint32_t*)p;
+    p = take((size_t)D3P_STEP_BATCH * D3P_XCHG_WGS * 32 * sizeof(uint32_t)); if (ws) ws->xflags = (uint32_t*)p;
     p = take(3 * (size_t)D3P_ACC_COLS(P) * sizeof(long long)); if (ws) ws->xsum = (long long*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * (P + 2) * sizeof(float)); if (ws) ws->partials = (float*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * 4 * sizeof(unsigned long long)); if (ws) ws->stamps = (unsigned long long*)p;  // >= 2 x 256 x 16 phase stamps
@@ -243,6 +243,7 @@ struct FlushArgs {
     const uint32_t* status;
     unsigned long long* host_status;  // nullable: pinned host record {abort, nonfinite, tag}
     unsigned long long host_tag;
+    int dbg_print;
     int P, B;
     float dp_scale, clip, obs_scale, lr, b1, b2, adam_eps;
     double inv_sg;
@@ -253,6 +254,12 @@ __global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
     const int tid = threadIdx.x, PA = D3P_ACC_COLS(a.P);
     if (tid < 16) a.key_out[tid] = a.sched->key[tid];
     const uint32_t aborted = a.status[0];
+    if (tid == 0 && aborted && a.dbg_print) {  // D3P_DBG=64: where the waits of the stopped launch stood
+        printf("[d3p] run stopped, code %#x; earliest step a wait ran out at, by kind:", aborted);
+        for (int k = 1; k < 8; ++k)
+            if (a.status[8 + k]) printf(" kind %d: step %u;", k, 0x1000u - a.status[8 + k]);
+        printf("\n");
+    }
     if (tid == 0 && a.host_status) {
         a.host_status[0] = aborted;
         a.host_status[1] = a.status[1];
@@ -1192,26 +1199,29 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
                 xchg_fill_dev(xchg, &ca.x, K);
                 ca.x.xflag = c.ws.xflags;
                 ca.x.xsum = c.ws.xsum;
-                D3P_HIP_TRY(hipMemsetAsync(c.ws.xflags, 0, (size_t)D3P_STEP_BATCH * 32 * sizeof(uint32_t), c.s));
+                D3P_HIP_TRY(hipMemsetAsync(c.ws.xflags, 0, (size_t)D3P_STEP_BATCH * D3P_XCHG_WGS * 32 * sizeof(uint32_t), c.s));
             }
-            const dim3 grid((uint32_t)K * (c.g.blocks + 1u + (xchg ? 1u : 0u))), block(64 * D3P_CHAIN_W);
+            const dim3 grid((uint32_t)K * (c.g.blocks + 1u + (xchg ? (uint32_t)D3P_XCHG_WGS : 0u))), block(64 * D3P_CHAIN_W);
             const bool plist = ca.plist_base != nullptr;
             const size_t lds = chain_lds_bytes(icpt);
-            const bool stamped = (ca.dbg & 32) && K >= 2;  // D3P_DBG=32: the stamped instantiation + the phase anatomy on stderr
+            const bool stamped = (ca.dbg & 32) && K >= 2 && !xchg;  // D3P_DBG=32: the stamped instantiation + the phase anatomy on stderr
             if (stamped) ca.stamps = c.ws.stamps;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (!stamped) timing_pair(K, &e0, &e1);
-#define D3P_CHAIN_LAUNCH(PL_, ST_, IC_)                                                                      \
-    do {                                                                                                     \
-        if (e0) hipExtLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_>), grid, block, lds, c.s, e0, e1, 0, ca); \
-        else hipLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_>), grid, block, lds, c.s, ca);                  \
+#define D3P_CHAIN_LAUNCH(PL_, ST_, IC_, XC_)                                                                       \
+    do {                                                                                                           \
+        if (e0) hipExtLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, XC_>), grid, block, lds, c.s, e0, e1, 0, ca); \
+        else hipLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, XC_>), grid, block, lds, c.s, ca);                  \
     } while (0)
-            if (stamped) {
-                if (icpt) { if (plist) D3P_CHAIN_LAUNCH(true, true, true); else D3P_CHAIN_LAUNCH(false, true, true); }
-                else { if (plist) D3P_CHAIN_LAUNCH(true, true, false); else D3P_CHAIN_LAUNCH(false, true, false); }
+            if (xchg) {  // (no stamped form of the data-parallel kernel)
+                if (icpt) { if (plist) D3P_CHAIN_LAUNCH(true, false, true, true); else D3P_CHAIN_LAUNCH(false, false, true, true); }
+                else { if (plist) D3P_CHAIN_LAUNCH(true, false, false, true); else D3P_CHAIN_LAUNCH(false, false, false, true); }
+            } else if (stamped) {
+                if (icpt) { if (plist) D3P_CHAIN_LAUNCH(true, true, true, false); else D3P_CHAIN_LAUNCH(false, true, true, false); }
+                else { if (plist) D3P_CHAIN_LAUNCH(true, true, false, false); else D3P_CHAIN_LAUNCH(false, true, false, false); }
             } else {
-                if (icpt) { if (plist) D3P_CHAIN_LAUNCH(true, false, true); else D3P_CHAIN_LAUNCH(false, false, true); }
-                else { if (plist) D3P_CHAIN_LAUNCH(true, false, false); else D3P_CHAIN_LAUNCH(false, false, false); }
+                if (icpt) { if (plist) D3P_CHAIN_LAUNCH(true, false, true, false); else D3P_CHAIN_LAUNCH(false, false, true, false); }
+                else { if (plist) D3P_CHAIN_LAUNCH(true, false, false, false); else D3P_CHAIN_LAUNCH(false, false, false, false); }
             }
 #undef D3P_CHAIN_LAUNCH
             int rc = check_launch("k_logreg_chain");
@@ -1284,20 +1294,22 @@ static const RcclApi* rccl_api()
 // flag there, waits for the n flags of its own inbox and adds the n vectors locally.  int64 sums are exact and commutative, so
 // every rank obtains bitwise the same totals -- the property the RCCL path has too (it stays as the checker and fallback).
 // Inboxes are allocated uncached (fine-grained) and shared between the processes with hipIpc handles; all cross-device
-// accesses are system-scope.  Slots and flags are double-buffered by the parity of the step count: a rank can only start
-// exchange e + 1 after every peer has finished READING in exchange e (it needs their flag of e + 1, sent after their
-// exchange e), so slot parity e is free again when exchange e + 2 writes it.  Waits are bounded and raise status[0].
+// accesses are system-scope.  A row carries its own arrival signal (xchg_ll_store in d3p_logreg_chain.h: every 8-byte word
+// holds 32 data bits and the epoch's tag), so a sender neither waits for write acknowledgements nor sends a flag behind the
+// data.  Slots are double-buffered by the parity of the step count: a rank can only start exchange e + 1 after every peer
+// has finished READING in exchange e (it needs their row of e + 1, sent after their exchange e), so slot parity e is free
+// again when exchange e + 2 writes it.  Waits are bounded and raise status[0].
 struct Xchg {
     int world, rank;
     uint32_t words;                    // int64 words per message (one folded accumulator row)
     unsigned long long epoch;          // exchanges done (host-side count; the device sees it as an argument)
-    char* inbox;                       // this rank's inbox: data[2][world][words] | flags[2][world][FLAG_STRIDE]
+    char* inbox;                       // this rank's inbox: ll[2][world][words] of 16 bytes
     size_t inbox_bytes;
     char* peer[D3P_XCHG_MAX_WORLD];    // the peers' inboxes mapped into this process (peer[rank] == inbox)
     bool opened[D3P_XCHG_MAX_WORLD];
 };
 
-static inline size_t xchg_data_bytes(int world, uint32_t words) { return align_up((size_t)2 * world * words * sizeof(long long), 256); }
+static inline size_t xchg_inbox_bytes(int world, uint32_t words) { return align_up((size_t)2 * world * words * 16, 256); }
 
 struct XchgArgs {
     long long* acc;  // R x words: this rank's replicas of the step's accumulator; on return row 0 holds the global totals, rows 1.. zeros
@@ -1306,54 +1318,57 @@ struct XchgArgs {
     int world, rank;
     unsigned long long epoch;  // 1-based count of this exchange
     char* peer[D3P_XCHG_MAX_WORLD];
-    size_t data_bytes;
     uint32_t* status;  // nullable: [0] raised when a wait runs out
 };
 
 __global__ void __launch_bounds__(1024) k_xchg(XchgArgs a)
 {
-    __shared__ uint32_t bad;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned parity = (unsigned)(a.epoch & 1ull);
-    if (tid == 0) bad = 0u;
-    // fold the replicas and deliver the folded row to every inbox (slot [parity][my rank])
+    const uint32_t tag = (uint32_t)a.epoch;
+    // fold the replicas, deliver the folded row to every inbox (slot [parity][my rank]) and clear the replicas: row 0 is where
+    // the world's sums are added up below
     for (uint32_t c = tid; c < a.words; c += blockDim.x) {
         long long v = 0;
-        for (int r = 0; r < a.R; ++r) v += a.acc[(size_t)r * a.words + c];
-        for (int p = 0; p < a.world; ++p) {
-            long long* slot = reinterpret_cast<long long*>(a.peer[p]) + ((size_t)parity * a.world + a.rank) * a.words;
-            __hip_atomic_store(slot + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int r = 0; r < a.R; ++r) {
+            v += a.acc[(size_t)r * a.words + c];
+            a.acc[(size_t)r * a.words + c] = 0;
         }
+        for (int p = 0; p < a.world; ++p) xchg_ll_store(a.peer[p], ((size_t)parity * a.world + a.rank) * a.words + c, v, tag);
     }
-    // system-scope stores are write-through: acknowledged (vmcnt) = performed at their destinations; only then the flags move
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __threadfence();
     __syncthreads();
-    if (tid < a.world) {
-        unsigned long long* f = reinterpret_cast<unsigned long long*>(a.peer[tid] + a.data_bytes) +
-                                ((size_t)parity * a.world + a.rank) * D3P_XCHG_FLAG_STRIDE;
-        __hip_atomic_store(f, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        // ... and wait for the row of rank `tid` in this rank's own inbox
-        const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(a.peer[a.rank] + a.data_bytes) +
-                                         ((size_t)parity * a.world + tid) * D3P_XCHG_FLAG_STRIDE;
-        bool ok = false;
-        for (uint32_t spins = 0; spins < (1u << 24); ++spins) {
-            if (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= a.epoch) { ok = true; break; }
-            if ((spins & 255u) == 255u && a.status && __hip_atomic_load(a.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) break;
-            __builtin_amdgcn_s_sleep(4);
+    // wave w takes the row of rank w in this rank's own inbox, four columns per lane in flight, asking again until every word
+    // carries this epoch's tag
+    if (wave < a.world) {
+        const size_t row = ((size_t)parity * a.world + wave) * a.words;
+        unsigned long long* tot = reinterpret_cast<unsigned long long*>(a.acc);
+        for (uint32_t c0 = 0; c0 < a.words; c0 += 256) {
+            unsigned long long w0[4], w1[4];
+            bool ok = false;
+            for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t c = c0 + 64u * i + lane;
+                    xchg_ll_fetch(a.peer[a.rank], row + (c < a.words ? c : a.words - 1u), &w0[i], &w1[i]);
+                }
+                bool all = true;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) all = all && xchg_ll_valid(w0[i], w1[i], tag);
+                if (all) { ok = true; break; }
+                if ((spins & 63u) == 63u && a.status && __hip_atomic_load(a.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (!ok) {  // aborted: the run is over (status[0]); the accumulator is left cleared
+                if (a.status) chain_raise(a.status, abort_code(D3P_ABORT_XCHG_KERNEL, 0, (uint32_t)wave));
+                break;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t c = c0 + 64u * i + lane;
+                if (c < a.words) atomicAdd(tot + c, (unsigned long long)xchg_ll_value(w0[i], w1[i]));
+            }
         }
-        if (!ok) {
-            bad = 1u;
-            if (a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, D3P_AGENT);
-        }
-    }
-    __syncthreads();
-    if (bad) return;  // aborted: leave the accumulator as it is, the run is over (status[0])
-    const long long* inbox = reinterpret_cast<const long long*>(a.peer[a.rank]) + (size_t)parity * a.world * a.words;
-    for (uint32_t c = tid; c < a.words; c += blockDim.x) {
-        long long tot = 0;
-        for (int p = 0; p < a.world; ++p) tot += __hip_atomic_load(inbox + (size_t)p * a.words + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        a.acc[c] = tot;
-        for (int r = 1; r < a.R; ++r) a.acc[(size_t)r * a.words + c] = 0;
     }
 }
 
@@ -1362,7 +1377,6 @@ static void xchg_fill_dev(Xchg* x, XchgDev* d, int K)
     d->world = x->world;
     d->rank = x->rank;
     for (int p = 0; p < x->world; ++p) d->peer[p] = x->peer[p];
-    d->data_bytes = xchg_data_bytes(x->world, x->words);
     d->epoch0 = x->epoch;
     x->epoch += (unsigned long long)K;
 }
@@ -1378,7 +1392,6 @@ static int enqueue_xchg(hipStream_t s, Xchg* x, long long* acc, int R, uint32_t*
     a.rank = x->rank;
     a.epoch = ++x->epoch;
     for (int p = 0; p < x->world; ++p) a.peer[p] = x->peer[p];
-    a.data_bytes = xchg_data_bytes(x->world, x->words);
     a.status = status;
     hipLaunchKernelGGL(k_xchg, dim3(1), dim3(1024), 0, s, a);
     return check_launch("k_xchg");
@@ -1520,6 +1533,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     fa.sched = c.ws.sched;
     fa.key_out = key_out;
     fa.status = run_status_words(c.ws);
+    fa.dbg_print = (dev_dbg_flags() & 64) ? 1 : 0;
     fa.host_status = host_status_record();
     fa.host_tag = (unsigned long long)(uintptr_t)run_status_words(c.ws);
     fa.P = c.P;
@@ -1788,7 +1802,7 @@ int d3p_xchg_create(int32_t world, int32_t rank, uint32_t words, void** xchg_out
     x->rank = rank;
     x->words = words;
     x->epoch = 0;
-    x->inbox_bytes = xchg_data_bytes(world, words) + (size_t)2 * world * D3P_XCHG_FLAG_STRIDE * sizeof(unsigned long long);
+    x->inbox_bytes = xchg_inbox_bytes(world, words);
     void* p = nullptr;
     hipError_t e = hipExtMallocWithFlags(&p, x->inbox_bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) { delete x; return fail(D3P_E_HIP, "d3p_xchg_create: hipExtMallocWithFlags: %s", hipGetErrorString(e)); }

@@ -37,16 +37,47 @@ namespace d3p {
 // step's exchange flag -- which is what the NEXT step's workgroups then wait for instead of the arrival flags.  The next
 // step's parameter-independent work (row gathers, noise) overlaps the exchange; there is no launch boundary per step.
 #define D3P_XCHG_MAX_WORLD 16
-#define D3P_XCHG_FLAG_STRIDE 16  // uint64 words: one 128-byte line per flag
+#define D3P_XCHG_WGS 2  // exchange workgroups per step, each with its share of the columns: a lane keeps its share of a rank's
+                        // row in flight while it waits (four registers per value), and ONE workgroup's share of 17 values per
+                        // lane took the kernel from 77 to 143 VGPRs -- past the 128 that two resident workgroups per CU allow
 struct XchgDev {
     int world, rank;                   // world == 0: no exchange
-    char* peer[D3P_XCHG_MAX_WORLD];    // inboxes: data[2][world][words] | flags[2][world][FLAG_STRIDE]
-    size_t data_bytes;
+    char* peer[D3P_XCHG_MAX_WORLD];    // inboxes: ll[2][world][words] of 16 bytes (see xchg_ll_store)
     unsigned long long epoch0;         // exchanges done before this launch; step t of the launch is exchange epoch0 + t + 1
-    uint32_t* xflag;                   // K flags, 32 words apart, zeroed before the launch
+    uint32_t* xflag;                   // K x D3P_XCHG_WGS flags, 32 words apart, zeroed before the launch
     long long* xsum;                   // 3 x cols: the world's sums of step g in row g % 3 -- ONE row, which is all the next
                                        // step's prologues read in a data-parallel run (not the 4 local replicas)
 };
+
+// One int64 of an exchange message travels as two 8-byte words {32 data bits | 32-bit tag}, tag = the low word of the
+// exchange's epoch.  An aligned 8-byte store is performed as a whole, so a receiver that finds the epoch's tag in both words
+// has the value: no flag behind the data, hence no wait for the write acknowledgement between the two and no second trip over
+// the link (the low-latency protocol of RCCL's small messages).  The slot last held the tag of epoch - 2, or 0 at the start
+// (epochs count from 1), never the one waited for.
+__device__ __forceinline__ void xchg_ll_store(char* inbox, size_t value_index, long long v, uint32_t tag)
+{
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(inbox) + 2 * value_index;
+    const unsigned long long t = (unsigned long long)tag << 32;
+    __hip_atomic_store(w, t | (unsigned long long)(uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(w + 1, t | ((unsigned long long)v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__device__ __forceinline__ void xchg_ll_fetch(const char* inbox, size_t value_index, unsigned long long* w0, unsigned long long* w1)
+{
+    const unsigned long long* w = reinterpret_cast<const unsigned long long*>(inbox) + 2 * value_index;
+    *w0 = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    *w1 = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__device__ __forceinline__ bool xchg_ll_valid(unsigned long long w0, unsigned long long w1, uint32_t tag)
+{
+    return (uint32_t)(w0 >> 32) == tag && (uint32_t)(w1 >> 32) == tag;
+}
+
+__device__ __forceinline__ long long xchg_ll_value(unsigned long long w0, unsigned long long w1)
+{
+    return (long long)((w1 << 32) | (w0 & 0xffffffffull));
+}
 
 struct ChainArgs {
     const float* X;
@@ -91,7 +122,9 @@ static inline size_t chain_lds_bytes(bool icpt)
     return (size_t)(5 * D3P_CHAIN_DL(icpt) + D3P_CHAIN_W * 2 * D3P_CHAIN_DL(icpt) + 2 * D3P_CHAIN_W + 4 + 32) * sizeof(float);
 }
 
-template <bool PLIST, bool STAMPS, bool ICPT = false>
+// XCHG: the data-parallel form (a.x.world > 0) -- its own instantiation, so that the single-rank kernel does not carry the
+// exchange workgroup's registers (61 SGPRs / 77 VGPRs alone, 82 / 80 with it: 2-3 % of the single-rank step)
+template <bool PLIST, bool STAMPS, bool ICPT = false, bool XCHG = false>
 __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -111,31 +144,38 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     D3P_CSTAMP(0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t per = (uint32_t)a.nw + 1u + (a.x.world > 0 ? 1u : 0u);
+    const uint32_t per = (uint32_t)a.nw + 1u + (XCHG ? (uint32_t)D3P_XCHG_WGS : 0u);
     const int step_t = (int)(blockIdx.x / per);
     const uint32_t bid = blockIdx.x % per;
 
-    if (a.x.world > 0 && bid == (uint32_t)a.nw + 1u) {  // ---- the exchange workgroup of step `step_t`
+    if (XCHG && bid > (uint32_t)a.nw) {  // ---- exchange workgroup `xj` of step `step_t`: columns c_lo .. c_lo + CH - 1
+        constexpr int CH = (PA + D3P_XCHG_WGS - 1) / D3P_XCHG_WGS;
+        const int xj = (int)(bid - (uint32_t)a.nw - 1u), c_lo = xj * CH, cn = (PA - c_lo < CH ? PA - c_lo : CH);
         const size_t words = (size_t)R * PA;
         long long* acc = a.acc_base + (size_t)((a.g0 + step_t) % 3) * words;
         if (tid == 64) okw[1] = 0u;
         if (wave == 0) {  // every compute workgroup of the step has added its sums
             const uint32_t ng = (uint32_t)a.nw < D3P_BAR_GROUPS ? (uint32_t)a.nw : D3P_BAR_GROUPS;
-            const bool ok = chain_wait_groups(a.bar + (size_t)step_t * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS), ng, a.status);
+            const bool ok = chain_wait_groups(a.bar + (size_t)step_t * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS), ng, a.status,
+                                              abort_code(D3P_ABORT_XCHG_ARRIVALS, step_t, (uint32_t)xj));
             if (lane == 0) okw[0] = ok ? 0u : 1u;
         }
         __syncthreads();
         if (okw[0] != 0u) return;
         const unsigned long long epoch = a.x.epoch0 + (unsigned long long)step_t + 1ull;
         const unsigned parity = (unsigned)(epoch & 1ull);
+        const uint32_t tag = (uint32_t)epoch;
+        unsigned long long* tot = reinterpret_cast<unsigned long long*>(red);  // CH int64: the world's sums, built in LDS
+        for (int c = tid; c < CH; c += 64 * W) tot[c] = 0ull;
         {  // fold the replicas (all loads of a thread in flight together), deliver the row to every inbox
-            constexpr int NC = (PA + 64 * W - 1) / (64 * W);
+            constexpr int NC = (CH + 64 * W - 1) / (64 * W);
             long long v[NC][R];
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
                 const int c = tid + i * 64 * W;
 #pragma unroll
-                for (int r = 0; r < R; ++r) v[i][r] = c < PA ? __hip_atomic_load(acc + (size_t)r * PA + c, __ATOMIC_RELAXED, D3P_AGENT) : 0ll;
+                for (int r = 0; r < R; ++r)
+                    v[i][r] = c < cn ? __hip_atomic_load(acc + (size_t)r * PA + c_lo + c, __ATOMIC_RELAXED, D3P_AGENT) : 0ll;
             }
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
@@ -143,46 +183,51 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
                 long long s = 0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) s += v[i][r];
-                if (c < PA)
-                    for (int p = 0; p < a.x.world; ++p) {
-                        long long* slot = reinterpret_cast<long long*>(a.x.peer[p]) + ((size_t)parity * a.x.world + a.x.rank) * PA;
-                        __hip_atomic_store(slot + c, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
+                if (c < cn)
+                    for (int p = 0; p < a.x.world; ++p)
+                        xchg_ll_store(a.x.peer[p], ((size_t)parity * a.x.world + a.x.rank) * PA + c_lo + c, s, tag);
             }
         }
-        // system-scope stores are write-through: once they are acknowledged (vmcnt) the rows are at their destinations, and
-        // only then the flags move -- no cache write-back fence is needed, there is nothing dirty to write back
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid < a.x.world) {
-            unsigned long long* f = reinterpret_cast<unsigned long long*>(a.x.peer[tid] + a.x.data_bytes) +
-                                    ((size_t)parity * a.x.world + a.x.rank) * D3P_XCHG_FLAG_STRIDE;
-            __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(a.x.peer[a.x.rank] + a.x.data_bytes) +
-                                             ((size_t)parity * a.x.world + tid) * D3P_XCHG_FLAG_STRIDE;
+        __syncthreads();  // (tot zeroed)
+        // the world's rows: wave w takes ranks w, w + W; a lane keeps all of its columns of one row in flight and asks again
+        // until every word carries this epoch's tag
+        for (int p = wave; p < a.x.world; p += W) {
+            constexpr int NL = (CH + 63) / 64;
+            const size_t row = ((size_t)parity * a.x.world + p) * PA + c_lo;
+            unsigned long long w0[NL], w1[NL];
             bool ok = false;
-            for (uint32_t spins = 0; spins < (1u << 24); ++spins) {
-                if (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= epoch) { ok = true; break; }
-                if ((spins & 255u) == 255u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) break;
+            for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    const int c = lane + 64 * i;
+                    xchg_ll_fetch(a.x.peer[a.x.rank], row + (c < cn ? c : cn - 1), &w0[i], &w1[i]);
+                }
+                bool all = true;
+#pragma unroll
+                for (int i = 0; i < NL; ++i) all = all && xchg_ll_valid(w0[i], w1[i], tag);
+                if (all) { ok = true; break; }
+                if ((spins & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) break;
                 __builtin_amdgcn_s_sleep(2);
             }
             if (!ok) {
                 okw[1] = 1u;
-                __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, D3P_AGENT);
+                chain_raise(a.status, abort_code(D3P_ABORT_XCHG_ROW, step_t, (uint32_t)p));
+            } else {
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    const int c = lane + 64 * i;
+                    if (c < cn) atomicAdd(tot + c, (unsigned long long)xchg_ll_value(w0[i], w1[i]));
+                }
             }
         }
         __syncthreads();
         if (okw[1] != 0u) return;  // aborted: the run stops here (status[0])
-        const long long* inbox = reinterpret_cast<const long long*>(a.x.peer[a.x.rank]) + (size_t)parity * a.x.world * PA;
-        long long* xrow = a.x.xsum + (size_t)((a.g0 + step_t) % 3) * PA;
-        for (int c = tid; c < PA; c += 64 * W) {
-            long long tot = 0;
-            for (int p = 0; p < a.x.world; ++p) tot += __hip_atomic_load(inbox + (size_t)p * PA + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(xrow + c, tot, __ATOMIC_RELAXED, D3P_AGENT);
-        }
+        long long* xrow = a.x.xsum + (size_t)((a.g0 + step_t) % 3) * PA + c_lo;
+        for (int c = tid; c < cn; c += 64 * W) __hip_atomic_store(xrow + c, (long long)tot[c], __ATOMIC_RELAXED, D3P_AGENT);
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(a.x.xflag + (size_t)step_t * 32, 1u, __ATOMIC_RELAXED, D3P_AGENT);
+        if (tid == 0)
+            __hip_atomic_store(a.x.xflag + ((size_t)step_t * D3P_XCHG_WGS + xj) * D3P_BAR_LINE, 1u, __ATOMIC_RELAXED, D3P_AGENT);
         return;
     }
 
@@ -190,7 +235,7 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         if (step_t < a.K_next && tid < 64) {
             uint32_t* progress = a.bar + (size_t)a.K * D3P_BAR_WORDS;
             bool go = true;
-            if (step_t > 0) go = chain_wait(progress, (uint32_t)step_t, a.status);
+            if (step_t > 0) go = chain_wait(progress, (uint32_t)step_t, a.status, abort_code(D3P_ABORT_KEY_CHAIN, step_t));
             if (go) chain_step<true>(a.chain_sched, a.chain_slots + step_t, step_t, step_t == a.K_next - 1);
             __builtin_amdgcn_s_waitcnt(0);
             if (tid == 0) __hip_atomic_store(progress, (uint32_t)step_t + 1u, __ATOMIC_RELAXED, D3P_AGENT);
@@ -289,11 +334,13 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     if (wave == 0) {
         const uint32_t ng = (uint32_t)a.nw < D3P_BAR_GROUPS ? (uint32_t)a.nw : D3P_BAR_GROUPS;
         bool ok;
-        if (a.x.world > 0)  // data-parallel: the previous step's exchange flag (global sums in place) instead of its arrival flags
-            ok = chain_wait_groups(step_t > 0 ? a.x.xflag + (size_t)(step_t - 1) * 32 : nullptr, 1u, a.status);
+        if (XCHG)  // data-parallel: the previous step's exchange flag (global sums in place) instead of its arrival flags
+            ok = chain_wait_groups(step_t > 0 ? a.x.xflag + (size_t)(step_t - 1) * D3P_XCHG_WGS * D3P_BAR_LINE : nullptr, D3P_XCHG_WGS, a.status,
+                                   abort_code(D3P_ABORT_RELEASE, step_t, 1u));
         else
             ok = chain_wait_groups(
-                step_t > 0 ? a.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS) : nullptr, ng, a.status);
+                step_t > 0 ? a.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS) : nullptr, ng, a.status,
+                abort_code(D3P_ABORT_RELEASE, step_t));
         if (lane == 0) okw[0] = ok ? 0u : 1u;
     }
     __syncthreads();
@@ -314,8 +361,8 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         }
         // one latent: pending update of its two columns (e: auto_loc, D + e: auto_scale) and its derived LDS entries
         // the sums of the previous step: the 4 local replicas, or (data-parallel) the ONE row the exchange workgroup left
-        const long long* sums = a.x.world > 0 ? a.x.xsum + (size_t)((g + 2) % 3) * PA : acc_prev;
-        const int nrep = a.x.world > 0 ? 1 : R;
+        const long long* sums = XCHG ? a.x.xsum + (size_t)((g + 2) % 3) * PA : acc_prev;
+        constexpr int nrep = XCHG ? 1 : R;
         auto latent = [&](int e, float zl, float zs) {
             float xL, xS;
             if (apply_prev) {

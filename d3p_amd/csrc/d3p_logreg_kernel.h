@@ -133,14 +133,36 @@ __device__ __forceinline__ void st_x(T* p, T v)
     else *p = v;
 }
 
+// The abort flag of a run holds 0 or the code of the FIRST bounded wait that ran out: kind | step << 8 | detail << 20
+// (d3p_dpvi_logreg_run_status hands it out as `aborted`).
+#define D3P_ABORT_WAIT 1u          // a wait not told apart below
+#define D3P_ABORT_XCHG_ARRIVALS 2u // exchange workgroup: the step's compute workgroups did not all arrive
+#define D3P_ABORT_XCHG_ROW 3u      // exchange workgroup: the row of rank `detail` did not come
+#define D3P_ABORT_RELEASE 4u       // compute workgroup: the previous step was not released (arrival flags / exchange flags)
+#define D3P_ABORT_KEY_CHAIN 5u     // key-chain workgroup: the previous link did not come
+#define D3P_ABORT_XCHG_KERNEL 6u   // k_xchg: the row of rank `detail` did not come
+__device__ __forceinline__ uint32_t abort_code(uint32_t kind, int step, uint32_t detail = 0u)
+{
+    return kind | ((uint32_t)step & 0xfffu) << 8 | (detail & 0xfffu) << 20;
+}
+__device__ __forceinline__ void chain_raise(uint32_t* abort_flag, uint32_t code)
+{
+    uint32_t expected = 0u;  // (the first code stays)
+    (void)__hip_atomic_compare_exchange_strong(abort_flag, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, D3P_AGENT);
+    // words 8 .. 15 of the status block: per kind of wait, 0x1000 - the EARLIEST step of the launch at which one ran out (all
+    // waits of a launch start when it does and run out together, so the first code alone does not say where the run stood)
+    const uint32_t kind = code & 7u, step = (code >> 8) & 0xfffu;
+    (void)__hip_atomic_fetch_max(abort_flag + 8 + kind, 0x1000u - step, __ATOMIC_RELAXED, D3P_AGENT);
+}
+
 // bounded wait until *p >= target; false (and the abort flag raised) when the bound is hit or another waiter gave up
-__device__ __forceinline__ bool chain_wait(const uint32_t* p, uint32_t target, uint32_t* abort_flag)
+__device__ __forceinline__ bool chain_wait(const uint32_t* p, uint32_t target, uint32_t* abort_flag, uint32_t code = D3P_ABORT_WAIT)
 {
     for (uint32_t spins = 0;; ++spins) {
         if (__hip_atomic_load(p, __ATOMIC_RELAXED, D3P_AGENT) >= target) return true;
         // (the abort flag is looked at every 64th spin only: reading it on every spin doubles the polling traffic)
         if (spins > (1u << 21) || ((spins & 63u) == 63u && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, D3P_AGENT) != 0u)) {
-            __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, D3P_AGENT);
+            chain_raise(abort_flag, code);
             return false;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -151,7 +173,8 @@ __device__ __forceinline__ bool chain_wait(const uint32_t* p, uint32_t target, u
 // the flag of group g and lane `ngroups` the run's abort flag -- one load instruction per round.  false when the bound is hit
 // or the abort flag is (or becomes) set: the caller must then leave without applying or publishing anything.
 // flags == nullptr: nothing to wait for (first step of a launch), only the abort flag is looked at.
-__device__ __forceinline__ bool chain_wait_groups(const uint32_t* flags, uint32_t ngroups, uint32_t* abort_flag)
+__device__ __forceinline__ bool chain_wait_groups(const uint32_t* flags, uint32_t ngroups, uint32_t* abort_flag,
+                                                  uint32_t code = D3P_ABORT_WAIT)
 {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t spins = 0;; ++spins) {
@@ -163,7 +186,7 @@ __device__ __forceinline__ bool chain_wait_groups(const uint32_t* flags, uint32_
         if (aborted) return false;
         if ((zero & ((1ull << ngroups) - 1ull)) == 0ull) return true;
         if (spins > (1u << 21)) {
-            if (lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, D3P_AGENT);
+            if (lane == 0) chain_raise(abort_flag, code);
             return false;
         }
         __builtin_amdgcn_s_sleep(2);

@@ -292,6 +292,15 @@ def run_steps_native(engine, state, batch_key, first_batch, num_steps, comm=None
     return new_state, (losses[:int(num_steps)] if collect_losses else None)
 
 
+def native_run_status(engine):
+    """(abort code, nonfinite) of the engine's last ``run_steps_native`` after synchronising the stream; the code is 0 or names
+    the bounded wait that stopped the run (``_lib.describe_abort``)."""
+    aborted, nonfinite = C.c_int32(0), C.c_int32(0)
+    check(_lib.load().d3p_dpvi_logreg_run_status(stream_ptr(), engine._args[0], engine._args[3], ptr(engine.ws), engine.ws.numel(),
+                                                 C.byref(aborted), C.byref(nonfinite)))
+    return int(aborted.value) & 0xffffffff, bool(nonfinite.value)
+
+
 def run_steps(engine, state, batch_key, first_batch, num_steps, group=None, collect_losses=True):
     """num_steps x [local_sums -> all_reduce(SUM) -> finalize] on every rank of `group`.
 

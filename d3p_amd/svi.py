@@ -758,7 +758,8 @@ class DPSVI:
             aborted, _ = self.last_run_status()
             if aborted:
                 raise _lib.D3PError("run_steps: a bounded wait of the chained launch ran out (the step kernel's workgroups "
-                                    "did not make progress); the run was stopped and its state and losses are invalid")
+                                    "did not make progress); the run was stopped and its state and losses are invalid -- "
+                                    + self.last_abort_code())
         new_key = keybuf[num_steps & 1].reshape(4, 4)
         return DPSVIState((step, params, m, v), new_key, svi_state.observation_scale), losses[:num_steps]
 
@@ -773,7 +774,13 @@ class DPSVI:
         aborted, nonfinite = C.c_int32(0), C.c_int32(0)
         check(_lib.load().d3p_dpvi_logreg_run_status(stream_ptr(), C.byref(model), C.byref(src), ptr(ws), ws.numel(),
                                                      C.byref(aborted), C.byref(nonfinite)))
+        self._last_abort_code = int(aborted.value) & 0xffffffff
         return bool(aborted.value), bool(nonfinite.value)
+
+    def last_abort_code(self):
+        """The code of the bounded wait that stopped the last run (0: none), as text: which wait, at which step of its
+        launch (d3p_logreg_kernel.h, D3P_ABORT_*).  Valid after ``last_run_status()``."""
+        return _lib.describe_abort(getattr(self, "_last_abort_code", 0))
 
     # ---------------------------------------------------------------- evaluate / accounting
     def evaluate(self, svi_state, *args, **kwargs):

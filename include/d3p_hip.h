@@ -424,7 +424,14 @@ int d3p_dpvi_logreg_chain_status(void* stream, const d3p_logreg_model* model, co
 /* ABI 3: both sticky status words of the last run, after synchronising `stream`.
  *   aborted_out   != 0: a bounded wait of the chained launch ran out; from then on no workgroup applied, published or
  *                       arrived anywhere, i.e. the run stopped advancing -- state and losses of that run are invalid
- *                       (d3p_amd.svi.DPSVI.run_steps raises D3PError).
+ *                       (d3p_amd.svi.DPSVI.run_steps raises D3PError).  The value is the code of the FIRST wait that ran
+ *                       out: kind | step of its launch << 8 | detail << 20, kinds 1 a wait not told apart, 2 exchange
+ *                       workgroup waiting for the step's arrivals, 3 exchange workgroup waiting for the row of rank
+ *                       `detail`, 4 compute workgroup waiting for the previous step's release, 5 key-chain link, 6 k_xchg
+ *                       waiting for the row of rank `detail` (D3P_ABORT_* in csrc/d3p_logreg_kernel.h;
+ *                       d3p_amd._lib.describe_abort turns it into text).  All waits of a launch start with it and run out
+ *                       together, so the step names a waiter, not necessarily the place the run stood at; D3P_DBG=64 prints
+ *                       the earliest step per kind.
  *   nonfinite_out != 0: a workgroup partial was NaN / Inf or left the fixed-point range of the accumulator; the update that
  *                       followed turned the parameters and the loss into NaN, which is what the reference's float sums
  *                       (svi.py:342-346) give for a diverged model -- never finite garbage. */
@@ -449,14 +456,16 @@ int d3p_dpvi_logreg_kernel_timing_read(double* total_us_out, uint32_t* launches_
  * after the reduce, from the same key on every rank.  comm == NULL runs without the collective.
  * ------------------------------------------------------------------------------------------- */
 /* One-shot full-mesh exchange over xGMI (ABI 3; SURVEY 5 / 8e: for a message of 8 KB one hop beats a ring's 2 (n - 1)).
- * Every rank owns an inbox (uncached device memory, double-buffered slots + flags) that its peers map with hipIpc:
+ * Every rank owns an inbox (uncached device memory, double-buffered slots of self-validating words: 32 data bits + the
+ * 32-bit tag of the exchange's epoch per 8-byte word, so that a row is its own arrival signal) that its peers map with hipIpc:
  *   d3p_xchg_create   allocates the inbox for messages of `words` int64 words and returns its 64-byte IPC handle;
  *   d3p_xchg_connect  takes the handles of ALL ranks (world x handle_stride bytes, the host layer gathers them, e.g. with
  *                     torch.distributed.all_gather_object) and maps the peers' inboxes;
  *   d3p_xchg_allreduce  enqueues ONE kernel: fold acc_dev[replicas][words] -> write the folded row into slot [rank] of every
- *                     inbox -> system-scope fence -> flags -> wait for the n flags of the own inbox -> acc_dev row 0 = the sum
- *                     of the n rows (int64: exact, identical on every rank), rows 1.. = 0.  Every rank must call it the same
- *                     number of times.  Bounded waits.
+ *                     inbox -> poll the n rows of the own inbox until every word carries the epoch's tag -> acc_dev row 0 =
+ *                     the sum of the n rows (int64: exact, identical on every rank), rows 1.. = 0.  Every rank must call it
+ *                     the same number of times.  Bounded waits (a run stopped by one reports which: D3P_ABORT_* in
+ *                     d3p_logreg_kernel.h, handed out as `aborted` by d3p_dpvi_logreg_run_status).
  *   d3p_dpvi_logreg_run_xchg = d3p_dpvi_logreg_run_dist with this exchange as the step's one collective (`words` must be
  *                     the accumulator row of the model: 2 D + 4). */
 int d3p_xchg_create(int32_t world, int32_t rank, uint32_t words, void** xchg_out, uint8_t* handle_out, size_t handle_bytes);

@@ -503,19 +503,23 @@ def test_xchg_on_one_rank_is_the_fold(gpu):
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2])
 def test_xchg_virtual_ranks_on_streams_match_the_single_rank_run(gpu, world):
-    """The exchange kernel and its protocol (folded rows into every inbox, system-scope fence, per-rank flags, slot parity by
-    epoch, bounded waits) with `world` ranks living in ONE process on separate streams: their inboxes are wired directly
-    (XchgComm.local_group) instead of through hipIpc handles, everything else is the multi-process path.  Each rank's whole
-    run is enqueued on its own stream; for this shape (d = 512) the exchange rides INSIDE the chained launch (one more
-    workgroup per step), so the ranks' launches must be co-resident on the one GPU: two ranks with 16 workgroups per step
-    are (more streams than hardware queues would serialise the launches and trip the bounded waits; real ranks own a GPU
-    each).  The bare collective sums exactly; the row-sharded run walks the single-rank trajectory with bitwise identical
-    replicas.  tools/xchg_two_rank_check.py is the same with two processes and hipIpc, in both exchange forms."""
+    """The exchange kernel and its protocol (folded rows into every inbox as self-validating words -- 32 data bits + the
+    epoch's tag --, slot parity by epoch, bounded waits) with `world` ranks living in ONE process on separate streams: their
+    inboxes are wired directly (XchgComm.local_group) instead of through hipIpc handles, everything else is the multi-process
+    path.  Each rank's whole run is enqueued on its own stream; for this shape (d = 512) the exchange rides INSIDE the chained
+    launch (two more workgroups per step), so the ranks' launches must be co-resident on the one GPU.  That bounds the run
+    length here: the launch of the rank enqueued first is resident whole (steps x 19 workgroups of the 768 the GPU holds,
+    nothing leaves before the other rank's rows arrive), and the second rank's preparation kernels and launch need room
+    beside it -- 24 steps leave 312 places; at 40 steps (760) the second rank never starts and the bounded waits stop both
+    runs (measured: 39 steps pass, 40 do not).  Real ranks own a GPU each; nor can one process use more streams than the
+    hardware has queues for this (4 by default): the launches would serialise.  The bare collective sums exactly; the
+    row-sharded run walks the single-rank trajectory with bitwise identical replicas.  tools/xchg_two_rank_check.py is the
+    same with two processes and hipIpc, in both exchange forms."""
     import d3p_amd._lib as L
     import d3p_amd.random as rng
     from d3p_amd import dist as ddist
     n, d, B, X, y = _xchg_problem()
-    steps = 40                                                   # crosses a prepared-batch boundary
+    steps = 24                                                   # (see above: bounded by co-residency on the one GPU)
     svi, st0 = _xchg_svi(n, d)
     Xc, yc = X.cuda(), y.cuda()
     single = ddist.FusedHipEngine(svi, Xc, yc, n, 0, n, L.D3P_BATCH_FEISTEL, B)
@@ -551,7 +555,9 @@ def test_xchg_virtual_ranks_on_streams_match_the_single_rank_run(gpu, world):
     finally:
         for c in comms:
             c.close()
-    for st, losses in results:
+    for r, (st, losses) in enumerate(results):
+        code, _ = ddist.native_run_status(engines[r])
+        assert code == 0, f"rank {r}: {L.describe_abort(code)}"
         assert torch.equal(st.rng_key, ref_state.rng_key) and int(st.optim_state[0]) == steps
         assert torch.equal(st.optim_state[1], results[0][0].optim_state[1]) and torch.equal(losses, results[0][1])
     np.testing.assert_allclose(results[0][1].cpu().numpy(), ref_losses.cpu().numpy(), rtol=2e-5)
