@@ -125,6 +125,10 @@ def spawn_ranks(n):
     return rc
 
 
+class RunStopped(RuntimeError):
+    """A data-parallel run that a bounded wait stopped (d3p_dpvi_logreg_run_status): its numbers are not measurements."""
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,6 +277,7 @@ def main():
 
     def timed_leg(run, state, first, warm, steps):
         """warm-up, barrier, `steps` timed steps bracketed by barriers (max over ranks), HIP-event kernel timing."""
+        barrier()   # (the ranks enter the warm-up together: its exchanges wait for every peer, with a bound)
         state, _ = run(state, first, warm)
         barrier()
         L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(1))
@@ -286,8 +291,7 @@ def main():
         if eng is not None:  # (the single-rank run_steps raises by itself) a stopped run must not become a number
             code, _ = ddist.native_run_status(eng)
             if code:
-                raise SystemExit(f"[bench] rank {rank}: the data-parallel run was stopped by a bounded wait -- "
-                                 f"{L.describe_abort(code)}")
+                raise RunStopped(f"rank {rank}: the data-parallel run was stopped by a bounded wait -- {L.describe_abort(code)}")
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -453,7 +457,14 @@ def main():
         dog = threading.Timer(float(os.environ.get("D3P_BENCH_WATCHDOG_S", "240")), give_up)
         dog.daemon = True
         dog.start()
-        m = measure(True, not args.no_extra_legs)
+        try:
+            m = measure(True, not args.no_extra_legs)
+        except RunStopped as e:   # every rank ends up here (a stopped rank sends no rows: its peers' waits run out too)
+            print(f"[bench] {e}", file=sys.stderr, flush=True)
+            if rank == 0:
+                print(line(fb, extra={"note": f"native data-parallel loop stopped ({e}); this is the Python-driven "
+                                              "torch.distributed loop"}), flush=True)
+            os._exit(0)
         barrier()
         dog.cancel()
         if rank == 0:

@@ -1346,7 +1346,7 @@ __global__ void __launch_bounds__(1024) k_xchg(XchgArgs a)
         for (uint32_t c0 = 0; c0 < a.words; c0 += 256) {
             unsigned long long w0[4], w1[4];
             bool ok = false;
-            for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+            for (uint32_t spins = 0; spins < 2u * D3P_WAIT_ROUNDS_PEERS; ++spins) {  // (a round here is ~ 0.1 us: 13 s)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const uint32_t c = c0 + 64u * i + lane;

@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         if (wave == 0) {  // every compute workgroup of the step has added its sums
             const uint32_t ng = (uint32_t)a.nw < D3P_BAR_GROUPS ? (uint32_t)a.nw : D3P_BAR_GROUPS;
             const bool ok = chain_wait_groups(a.bar + (size_t)step_t * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS), ng, a.status,
-                                              abort_code(D3P_ABORT_XCHG_ARRIVALS, step_t, (uint32_t)xj));
+                                              abort_code(D3P_ABORT_XCHG_ARRIVALS, step_t, (uint32_t)xj), D3P_WAIT_ROUNDS_PEERS);
             if (lane == 0) okw[0] = ok ? 0u : 1u;
         }
         __syncthreads();
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
             const size_t row = ((size_t)parity * a.x.world + p) * PA + c_lo;
             unsigned long long w0[NL], w1[NL];
             bool ok = false;
-            for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+            for (uint32_t spins = 0; spins < 2u * D3P_WAIT_ROUNDS_PEERS; ++spins) {  // (a round here is ~ 0.1 us)
 #pragma unroll
                 for (int i = 0; i < NL; ++i) {
                     const int c = lane + 64 * i;
@@ -235,7 +235,9 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         if (step_t < a.K_next && tid < 64) {
             uint32_t* progress = a.bar + (size_t)a.K * D3P_BAR_WORDS;
             bool go = true;
-            if (step_t > 0) go = chain_wait(progress, (uint32_t)step_t, a.status, abort_code(D3P_ABORT_KEY_CHAIN, step_t));
+            if (step_t > 0)
+                go = chain_wait(progress, (uint32_t)step_t, a.status, abort_code(D3P_ABORT_KEY_CHAIN, step_t),
+                                XCHG ? D3P_WAIT_ROUNDS_PEERS : D3P_WAIT_ROUNDS);
             if (go) chain_step<true>(a.chain_sched, a.chain_slots + step_t, step_t, step_t == a.K_next - 1);
             __builtin_amdgcn_s_waitcnt(0);
             if (tid == 0) __hip_atomic_store(progress, (uint32_t)step_t + 1u, __ATOMIC_RELAXED, D3P_AGENT);
@@ -336,7 +338,7 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         bool ok;
         if (XCHG)  // data-parallel: the previous step's exchange flag (global sums in place) instead of its arrival flags
             ok = chain_wait_groups(step_t > 0 ? a.x.xflag + (size_t)(step_t - 1) * D3P_XCHG_WGS * D3P_BAR_LINE : nullptr, D3P_XCHG_WGS, a.status,
-                                   abort_code(D3P_ABORT_RELEASE, step_t, 1u));
+                                   abort_code(D3P_ABORT_RELEASE, step_t, 1u), D3P_WAIT_ROUNDS_PEERS);
         else
             ok = chain_wait_groups(
                 step_t > 0 ? a.bar + (size_t)(step_t - 1) * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS) : nullptr, ng, a.status,

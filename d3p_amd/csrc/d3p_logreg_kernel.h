@@ -156,12 +156,19 @@ __device__ __forceinline__ void chain_raise(uint32_t* abort_flag, uint32_t code)
 }
 
 // bounded wait until *p >= target; false (and the abort flag raised) when the bound is hit or another waiter gave up
-__device__ __forceinline__ bool chain_wait(const uint32_t* p, uint32_t target, uint32_t* abort_flag, uint32_t code = D3P_ABORT_WAIT)
+// Bounds of the waits, in polling rounds (0.2 - 0.4 us each).  Inside one GPU nothing takes longer than a few steps: 2^21
+// rounds (0.4 - 0.9 s) mean the launch is stuck.  A data-parallel run also waits for its PEERS, transitively in every wait of
+// the launch, and those may start late (another process, its first launch, a slower host): 2^26 rounds (13 - 27 s).
+#define D3P_WAIT_ROUNDS (1u << 21)
+#define D3P_WAIT_ROUNDS_PEERS (1u << 26)
+
+__device__ __forceinline__ bool chain_wait(const uint32_t* p, uint32_t target, uint32_t* abort_flag, uint32_t code = D3P_ABORT_WAIT,
+                                           uint32_t rounds = D3P_WAIT_ROUNDS)
 {
     for (uint32_t spins = 0;; ++spins) {
         if (__hip_atomic_load(p, __ATOMIC_RELAXED, D3P_AGENT) >= target) return true;
         // (the abort flag is looked at every 64th spin only: reading it on every spin doubles the polling traffic)
-        if (spins > (1u << 21) || ((spins & 63u) == 63u && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, D3P_AGENT) != 0u)) {
+        if (spins > rounds || ((spins & 63u) == 63u && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, D3P_AGENT) != 0u)) {
             chain_raise(abort_flag, code);
             return false;
         }
@@ -174,7 +181,7 @@ __device__ __forceinline__ bool chain_wait(const uint32_t* p, uint32_t target, u
 // or the abort flag is (or becomes) set: the caller must then leave without applying or publishing anything.
 // flags == nullptr: nothing to wait for (first step of a launch), only the abort flag is looked at.
 __device__ __forceinline__ bool chain_wait_groups(const uint32_t* flags, uint32_t ngroups, uint32_t* abort_flag,
-                                                  uint32_t code = D3P_ABORT_WAIT)
+                                                  uint32_t code = D3P_ABORT_WAIT, uint32_t rounds = D3P_WAIT_ROUNDS)
 {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t spins = 0;; ++spins) {
@@ -185,7 +192,7 @@ __device__ __forceinline__ bool chain_wait_groups(const uint32_t* flags, uint32_
         const bool aborted = ((zero >> ngroups) & 1ull) == 0ull;  // lane `ngroups` read a non-zero abort flag
         if (aborted) return false;
         if ((zero & ((1ull << ngroups) - 1ull)) == 0ull) return true;
-        if (spins > (1u << 21)) {
+        if (spins > rounds) {
             if (lane == 0) chain_raise(abort_flag, code);
             return false;
         }
