@@ -119,6 +119,7 @@ SIGNATURES = {
     "d3p_logreg_px_grads": (C.c_int, [_V, _PM, _V, _V, _V, _V, _U32, _V, _V, _V, _V, _V, _V, _SZ]),
     "d3p_clip_rows": (C.c_int, [_V, _V, _U32, _U32, _F]),
     "d3p_full_norm": (C.c_int, [_V, _V, _U64, _V, _V, _SZ]),
+    "d3p_full_norm_ord": (C.c_int, [_V, _V, _U64, C.c_double, _V]),
     "d3p_combine": (C.c_int, [_V, _V, _V, _U32, _U32, _V, _V]),
     "d3p_perturb": (C.c_int, [_V, _V, _V, C.POINTER(C.c_int32), C.c_int, _F, _F, _V, _F, _V, _V]),
     "d3p_adam_step": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _F, _F, _F, _F]),
@@ -197,7 +198,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.d3p_abi_version() != 4:
+        if lib.d3p_abi_version() != 5:
             raise D3PError("libd3p_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -78,6 +78,32 @@ __global__ void k_full_norm(const float* __restrict__ v, uint64_t n, float* __re
     if (threadIdx.x == 0) *out = __fsqrt_rn(lds[0]);
 }
 
+// numpy.linalg.norm(v, ord) of a vector for the orders other than 2 (d3p/svi.py:68-87 hands `ord` through): kind 0: the
+// number of non-zero entries; 1: sum |x|; 2: (sum |x|^p)^(1/p); 3: max |x|; 4: min |x|
+__global__ void k_full_norm_ord(const float* __restrict__ v, uint64_t n, int kind, float p, float* __restrict__ out)
+{
+    __shared__ float lds[256];
+    float acc = kind == 4 ? __builtin_inff() : 0.f;
+    for (uint64_t j = threadIdx.x; j < n; j += 256) {
+        const float a = fabsf(v[j]);
+        if (kind == 0) acc += (v[j] != 0.f) ? 1.f : 0.f;
+        else if (kind == 1) acc += a;
+        else if (kind == 2) acc += powf(a, p);
+        else if (kind == 3) acc = (a > acc || a != a) ? a : acc;   // (a NaN entry makes the norm NaN, as numpy's max does)
+        else acc = (a < acc || a != a) ? a : acc;
+    }
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const float x = lds[threadIdx.x], y = lds[threadIdx.x + off];
+            lds[threadIdx.x] = kind <= 2 ? x + y : kind == 3 ? ((y > x || y != y) ? y : x) : ((y < x || y != y) ? y : x);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = kind == 2 ? powf(lds[0], 1.f / p) : lds[0];
+}
+
 __global__ void k_perturb_site(const uint32_t* __restrict__ site_key, const float* __restrict__ avg, uint32_t n_site,
                                float dp_scale, float c, const float* __restrict__ meta, float obs_scale,
                                float* __restrict__ out)
@@ -443,6 +469,16 @@ int d3p_full_norm(void* stream, const float* v_dev, uint64_t n, float* out_dev, 
     D3P_REQUIRE(out_dev && (v_dev || n == 0), "d3p_full_norm: null pointer");
     hipLaunchKernelGGL(k_full_norm, dim3(1), dim3(256), 0, (hipStream_t)stream, v_dev, n, out_dev);
     return check_launch("d3p_full_norm");
+}
+
+int d3p_full_norm_ord(void* stream, const float* v_dev, uint64_t n, double ord, float* out_dev)
+{
+    D3P_REQUIRE(out_dev && v_dev && n >= 1, "d3p_full_norm_ord: null pointer or empty vector");
+    D3P_REQUIRE(ord == ord, "d3p_full_norm_ord: ord is NaN");
+    if (ord == 2.0) return d3p_full_norm(stream, v_dev, n, out_dev, nullptr, 0);
+    const int kind = ord == 0.0 ? 0 : ord == 1.0 ? 1 : std::isinf(ord) ? (ord > 0 ? 3 : 4) : 2;
+    hipLaunchKernelGGL(k_full_norm_ord, dim3(1), dim3(256), 0, (hipStream_t)stream, v_dev, n, kind, (float)ord, out_dev);
+    return check_launch("d3p_full_norm_ord");
 }
 
 int d3p_combine(void* stream, const float* px_grads_dev, const float* px_loss_dev, uint32_t B, uint32_t P,

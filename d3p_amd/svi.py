@@ -97,17 +97,25 @@ def _as_device_f32(x, device=None):
 
 # ------------------------------------------------------------------ module-level gradient manipulators
 def full_norm(vector_parts, ord=2):
-    """d3p/svi.py:68-87: norm over all leaves of a tree treated as one vector (0. if empty)."""
-    if ord != 2:
-        raise NotImplementedError("only the 2-norm is implemented on the device path")
+    """d3p/svi.py:68-87: norm over all leaves of a tree treated as one vector (0. if empty); `ord` as for
+    numpy.linalg.norm of a vector (None = 2, 0, 1, +-inf, any other p)."""
+    if ord is None:
+        ord = 2
+    if isinstance(ord, str):
+        raise ValueError(f"Invalid order '{ord}' for vector norm.")   # ('fro' / 'nuc' are matrix norms; numpy raises too)
     leaves, _ = _tree_flatten(vector_parts)
     if len(leaves) == 0:
         return 0.0
     _lib.require_device()
     flat = [_as_device_f32(g).reshape(-1) for g in leaves]
     v = torch.cat(flat) if len(flat) > 1 else flat[0].contiguous()
+    if v.numel() == 0:
+        return 0.0
     out = torch.empty(1, dtype=torch.float32, device=v.device)
-    check(_lib.load().d3p_full_norm(stream_ptr(), ptr(v), v.numel(), ptr(out), None, 0))
+    if ord == 2:
+        check(_lib.load().d3p_full_norm(stream_ptr(), ptr(v), v.numel(), ptr(out), None, 0))
+    else:
+        check(_lib.load().d3p_full_norm_ord(stream_ptr(), ptr(v), v.numel(), float(ord), ptr(out)))
     return out[0]
 
 

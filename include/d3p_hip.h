@@ -34,7 +34,7 @@ extern "C" {
 #define D3P_E_UNSUPPORTED (-3)
 #define D3P_E_WORKSPACE (-4)
 
-#define D3P_ABI_VERSION 4
+#define D3P_ABI_VERSION 5
 
 int d3p_abi_version(void);
 const char* d3p_last_error(void);
@@ -208,6 +208,10 @@ int d3p_clip_rows(void* stream, float* px_grads_dev, uint32_t B, uint32_t P, flo
 /* full_norm of a flat vector (svi.py:68-87) -> out_dev[0]. n == 0 gives 0. */
 int d3p_full_norm(void* stream, const float* v_dev, uint64_t n, float* out_dev, void* workspace_dev,
                   size_t workspace_bytes);
+/* ABI 5: numpy.linalg.norm(v, ord) of the same vector for any order (`ord` of full_norm / normalize_gradient,
+ * d3p/svi.py:68-103): 0 = number of non-zero entries, 1, 2 (= d3p_full_norm), +-inf = largest / smallest magnitude, any
+ * other p: (sum |x|^p)^(1/p).  n >= 1. */
+int d3p_full_norm_ord(void* stream, const float* v_dev, uint64_t n, double ord, float* out_dev);
 
 /* _combine_gradients: column means over the padded batch and mean loss (svi.py:327-348). */
 int d3p_combine(void* stream, const float* px_grads_dev, const float* px_loss_dev, uint32_t B,

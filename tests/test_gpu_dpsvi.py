@@ -237,6 +237,26 @@ def test_gradient_manipulators(gpu):
     assert abs(float(full_norm(normalize_gradient(tree))) - 1.0) < 1e-6              # :105-109
 
 
+@pytest.mark.parametrize("order", [0, 1, 2, 3, 0.5, -1.5, float("inf"), float("-inf"), None])
+def test_full_norm_takes_any_order_of_numpy_linalg_norm(gpu, order):
+    """`ord` of full_norm / normalize_gradient (d3p/svi.py:68-103: "any value possible for numpy.linalg.norm") on the
+    concatenation of a ragged tree; the float64 numpy norm of the same float32 values is the reference, rtol 1e-5 (fp32 sums of 176 powers)."""
+    from d3p_amd.svi import full_norm, normalize_gradient
+    g = np.random.default_rng(11)
+    parts = [g.standard_normal(s).astype(np.float32) for s in ((7, 3), (1,), (130,), (2, 2, 5))]
+    parts[2][::9] = 0.0                                        # (order 0 counts the non-zero entries)
+    tree = (torch.tensor(parts[0]).cuda(), {"b": torch.tensor(parts[1]).cuda(), "c": (torch.tensor(parts[2]).cuda(),)},
+            [torch.tensor(parts[3]).cuda()])
+    flat = np.concatenate([p.reshape(-1) for p in parts]).astype(np.float64)
+    want = np.linalg.norm(flat, ord=order)
+    got = float(full_norm(tree, ord=order))
+    assert abs(got - want) <= 1e-5 * abs(want), (order, got, want)
+    if order != 0 and want > 0:
+        assert abs(float(full_norm(normalize_gradient(tree, ord=order), ord=order)) - 1.0) < 1e-5
+    with pytest.raises(ValueError):
+        full_norm(tree, ord="fro")
+
+
 def test_constructor_validation(gpu):
     from d3p_amd.models import SGD
     from d3p_amd.svi import DPSVI
