@@ -35,7 +35,8 @@ class GmmModel(C.Structure):
 
 
 class VaeModel(C.Structure):
-    _fields_ = [("D", C.c_int32), ("H", C.c_int32), ("Z", C.c_int32), ("scale", C.c_float), ("inv_obs", C.c_float)]
+    _fields_ = [("D", C.c_int32), ("H", C.c_int32), ("Z", C.c_int32), ("scale", C.c_float), ("inv_obs", C.c_float),
+                ("H2", C.c_int32)]   # H2 > 0: a second hidden layer on each side (BASELINE config 5's [400, 200] variant)
 
 
 class DpsviHyper(C.Structure):

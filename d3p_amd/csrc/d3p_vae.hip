@@ -649,14 +649,24 @@ __device__ __forceinline__ float row_sumsq(const float* __restrict__ r, int n, i
 }
 
 // joint L2 norm of every example's gradient by the outer-product identity, clip factor c_i (0 for masked rows); the rows of
-// the five delta arrays are staged in LDS while their squares are summed and written back scaled by c_i (svi.py:121-122
-// folded into the sums), so the deltas are read once and written once (a separate rescaling pass read them a second time)
+// the delta arrays are staged in LDS while their squares are summed and written back scaled by c_i (svi.py:121-122
+// folded into the sums), so the deltas are read once and written once (a separate rescaling pass read them a second time).
+// One term per dense layer, in the order decoder output layer .. decoder first layer, latent heads, encoder last .. first:
+// ||grad||^2 = sum_t (|input_t|^2 + 1) (|delta_t|^2 [+ |delta'_t|^2])  (the + 1 is the bias; the heads share their input)
+#define D3P_VAE_MAX_TERMS 6
+struct NormTerm {
+    const float* in;  // B x in_n, row stride in_ld; nullptr: |x_i|^2 comes from x2 (left by k_vae_out)
+    float* d0;        // B x d_n, row stride d_ld: the layer's delta, rescaled in place
+    float* d1;        // the second head's delta (same shape), or nullptr
+    int in_ld, in_n, d_ld, d_n;
+};
 struct NormArgs {
-    const float *x2, *h1, *z, *h2;        // layer inputs (x2: |x_i|^2 from k_vae_out)
-    float *dpre1, *dz, *du, *dpre2, *da;  // layer deltas, rescaled in place
+    NormTerm t[D3P_VAE_MAX_TERMS];
+    int n_terms;
+    int stage;  // floats of LDS per wave = sum of the delta widths
+    const float* x2;
     const uint8_t* mask;
     uint32_t B;
-    int D, H, Z, ldz;  // ldz: row stride of z, dz, du
     float clip;
     float* cf;
     float* norms;  // nullable
@@ -678,7 +688,7 @@ __device__ __forceinline__ float row_sumsq_keep(const float* __restrict__ r, int
 
 __global__ void k_vae_norms(NormArgs a)
 {
-    extern __shared__ float norm_stage[];  // 4 waves x (D + 2 H + 2 Z)
+    extern __shared__ float norm_stage[];  // 4 waves x a.stage
     if (blockIdx.x == gridDim.x - 1) {  // sums[P] = sum_i px_loss[i], sums[P + 1] = number of unmasked examples
         float* l = norm_stage;
         float* c = norm_stage + 256;
@@ -700,22 +710,22 @@ __global__ void k_vae_norms(NormArgs a)
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (i >= a.B) return;
-    float* k_da = norm_stage + (size_t)(threadIdx.x >> 6) * (a.D + 2 * a.H + 2 * a.Z);
-    float* k_d2 = k_da + a.D;
-    float* k_d1 = k_d2 + a.H;
-    float* k_dz = k_d1 + a.H;
-    float* k_du = k_dz + a.Z;
-    float* r_da = a.da + (size_t)i * a.D;
-    float* r_d2 = a.dpre2 + (size_t)i * a.H;
-    float* r_d1 = a.dpre1 + (size_t)i * a.H;
-    float* r_dz = a.dz + (size_t)i * a.ldz;
-    float* r_du = a.du + (size_t)i * a.ldz;
-    const float x2 = a.x2[i], h12 = row_sumsq(a.h1 + (size_t)i * a.H, a.H, lane);
-    const float z2 = row_sumsq(a.z + (size_t)i * a.ldz, a.Z, lane), h22 = row_sumsq(a.h2 + (size_t)i * a.H, a.H, lane);
-    const float d1 = row_sumsq_keep(r_d1, a.H, lane, k_d1), dz = row_sumsq_keep(r_dz, a.Z, lane, k_dz);
-    const float du = row_sumsq_keep(r_du, a.Z, lane, k_du), d2 = row_sumsq_keep(r_d2, a.H, lane, k_d2);
-    const float da = row_sumsq_keep(r_da, a.D, lane, k_da);
-    const float n2 = (h22 + 1.0f) * da + (z2 + 1.0f) * d2 + (h12 + 1.0f) * (dz + du) + (x2 + 1.0f) * d1;
+    float* keep = norm_stage + (size_t)(threadIdx.x >> 6) * a.stage;
+    float n2 = 0.f;
+    {
+        float* k = keep;
+        for (int t = 0; t < a.n_terms; ++t) {
+            const NormTerm& q = a.t[t];
+            const float in2 = q.in ? row_sumsq(q.in + (size_t)i * q.in_ld, q.in_n, lane) : a.x2[i];
+            float d = row_sumsq_keep(q.d0 + (size_t)i * q.d_ld, q.d_n, lane, k);
+            k += q.d_n;
+            if (q.d1) {
+                d += row_sumsq_keep(q.d1 + (size_t)i * q.d_ld, q.d_n, lane, k);
+                k += q.d_n;
+            }
+            n2 += (in2 + 1.0f) * d;
+        }
+    }
     const float nrm = sqrtf(n2);
     const bool live = !(a.mask && a.mask[i] == 0);
     const float c = live ? 1.0f / fmaxf(1.0f, nrm / a.clip) : 0.f;  // svi.py:121-122; masked rows contribute nothing
@@ -724,9 +734,18 @@ __global__ void k_vae_norms(NormArgs a)
         if (a.norms) a.norms[i] = live ? nrm : 0.f;
     }
     // every lane reads back exactly the LDS words it wrote: no barrier needed
-    for (int j = lane; j < a.D; j += 64) r_da[j] = k_da[j] * c;
-    for (int j = lane; j < a.H; j += 64) { r_d2[j] = k_d2[j] * c; r_d1[j] = k_d1[j] * c; }
-    for (int j = lane; j < a.Z; j += 64) { r_dz[j] = k_dz[j] * c; r_du[j] = k_du[j] * c; }
+    float* k = keep;
+    for (int t = 0; t < a.n_terms; ++t) {
+        const NormTerm& q = a.t[t];
+        float* r0 = q.d0 + (size_t)i * q.d_ld;
+        for (int j = lane; j < q.d_n; j += 64) r0[j] = k[j] * c;
+        k += q.d_n;
+        if (q.d1) {
+            float* r1 = q.d1 + (size_t)i * q.d_ld;
+            for (int j = lane; j < q.d_n; j += 64) r1[j] = k[j] * c;
+            k += q.d_n;
+        }
+    }
 }
 
 // sums[P] = sum_i px_loss[i], sums[P + 1] = number of unmasked examples (one workgroup, fixed order)
@@ -751,15 +770,18 @@ __global__ void __launch_bounds__(256) k_vae_loss_n(const float* __restrict__ px
 
 // mean, Gaussian mechanism, rescale (svi.py:343-346, :365-375), numpyro Adam (svi.py:379-393) over the P parameters
 #define D3P_WPART_SPLITS 16  // most split-K partial tiles a product leaves
+#define D3P_VAE_MAX_BLOCKS 7  // [W | b] blocks of the flat layout: 2 nh + 3 with nh <= 2 hidden layers
+#define D3P_VAE_MAX_LEAVES 14 // parameter leaves: 2 (2 nh + 1) + 4
 
 struct VaeFinalArgs {
     const float* sums;  // P + 2
     // weight-gradient blocks whose split-K partial tiles were left unreduced (single-device update): block b = columns
     // [w_off[b], w_off[b] + w_mn[b]) of the flat layout, w_splits[b] tiles of w_mn[b] floats at wpart + D3P_WPART_SPLITS * w_off[b]
     const float* wpart;
-    uint32_t w_off[6];                                          // first column of block b (w_off[5] = P)
-    uint32_t w_base[5], w_tile[5], w_ld[5], w_coff[5], w_out[5];  // its tiles: wpart + w_base, w_tile apart, element (r, c) of the
-    int w_splits[5];                                            // block at r * w_ld + w_coff + c, c < w_out
+    uint32_t w_off[D3P_VAE_MAX_BLOCKS + 1];                     // first column of block b (unused entries = P)
+    uint32_t w_base[D3P_VAE_MAX_BLOCKS], w_tile[D3P_VAE_MAX_BLOCKS], w_ld[D3P_VAE_MAX_BLOCKS], w_coff[D3P_VAE_MAX_BLOCKS],
+        w_out[D3P_VAE_MAX_BLOCKS];                              // its tiles: wpart + w_base, w_tile apart, element (r, c) of the
+    int w_splits[D3P_VAE_MAX_BLOCKS];                           // block at r * w_ld + w_coff + c, c < w_out
     const float* noise;
     const float* in_params;  // state before the update (== params / adam_m / adam_v, or the old state's arrays when the update
     const float* in_m;       // is out of place: DPSVI.update returns a NEW state, svi.py:395-434)
@@ -790,7 +812,7 @@ __global__ void k_vae_finalize(VaeFinalArgs a)
     if (a.wpart) {
         int b = 0;
 #pragma unroll
-        for (int k = 1; k < 5; ++k) b += (col >= a.w_off[k]) ? 1 : 0;
+        for (int k = 1; k < D3P_VAE_MAX_BLOCKS; ++k) b += (col >= a.w_off[k]) ? 1 : 0;
         if (a.w_splits[b] > 0) {
             const uint32_t e = (uint32_t)col - a.w_off[b];
             const float* t = a.wpart + a.w_base[b] + (size_t)(e / a.w_out[b]) * a.w_ld[b] + a.w_coff[b] + e % a.w_out[b];
@@ -810,22 +832,22 @@ __global__ void k_vae_finalize(VaeFinalArgs a)
     a.adam_v[col] = v;
 }
 
-// Gaussian-mechanism noise for all 10 parameter leaves in one launch: leaf k draws normal(site_key_k, leaf shape)
-// (svi.py:487-491), i.e. word w of ChaCha block b of key k is element 16 b + w of that leaf.
+// Gaussian-mechanism noise for all parameter leaves (10, or 14 with two hidden layers) in one launch: leaf k draws
+// normal(site_key_k, leaf shape) (svi.py:487-491), i.e. word w of ChaCha block b of key k is element 16 b + w of that leaf.
 struct SiteNoiseArgs {
-    const uint32_t* site_keys;   // 10 x 16
-    uint32_t blk_off[11];        // prefix sums of ceil(leaf size / 16)
-    uint32_t elem_off[11];       // prefix sums of the leaf sizes
+    const uint32_t* site_keys;                    // n_leaves x 16
+    uint32_t blk_off[D3P_VAE_MAX_LEAVES + 1];     // prefix sums of ceil(leaf size / 16) (unused entries = the total)
+    uint32_t elem_off[D3P_VAE_MAX_LEAVES + 1];    // prefix sums of the leaf sizes
     float* noise;
 };
 
 __global__ void __launch_bounds__(256) k_vae_site_noise(SiteNoiseArgs a)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.blk_off[10]) return;
+    if (b >= a.blk_off[D3P_VAE_MAX_LEAVES]) return;
     int site = 0;
 #pragma unroll
-    for (int k = 1; k < 10; ++k) site += (b >= a.blk_off[k]) ? 1 : 0;
+    for (int k = 1; k < D3P_VAE_MAX_LEAVES; ++k) site += (b >= a.blk_off[k]) ? 1 : 0;
     const uint32_t lb = b - a.blk_off[site], n_site = a.elem_off[site + 1] - a.elem_off[site];
     uint32_t key[16], o[16];
     load_key(a.site_keys + 16 * site, key);
@@ -840,12 +862,16 @@ __global__ void __launch_bounds__(256) k_vae_site_noise(SiteNoiseArgs a)
 
 // rows of the five delta arrays scaled by the clip factors in one launch
 // All keys of one update in ONE launch (they were three launches + a step-counter launch + a 64-byte copy, ~5 us each):
-// keys[0..47] = [next | gradient | perturbation] = split(state_key, 3) (svi.py:208-211), keys[48..207] =
-// split(perturbation_key, 10) (svi.py:491), keys[208..209] = convert_to_jax_rng_key(gradient_key).  advance: also write the
-// next state key into the other key slot, save the optimiser step index in keys[210] for k_vae_finalize and advance it.
+// keys[0..47] = [next | gradient | perturbation] = split(state_key, 3) (svi.py:208-211), keys[48 ..] =
+// split(perturbation_key, n_sites) (svi.py:491; n_sites = 10 or 14 leaves), keys[D3P_VAE_KEY_JAX ..+1] =
+// convert_to_jax_rng_key(gradient_key).  advance: also write the next state key into the other key slot, save the optimiser
+// step index in keys[D3P_VAE_KEY_STEP] for k_vae_finalize and advance it.
+#define D3P_VAE_KEY_JAX (48 + 16 * D3P_VAE_MAX_LEAVES)
+#define D3P_VAE_KEY_STEP (D3P_VAE_KEY_JAX + 2)
+#define D3P_VAE_KEY_WORDS (D3P_VAE_KEY_JAX + 4)
 __global__ void __launch_bounds__(64) k_vae_keys(const uint32_t* __restrict__ cur_key, uint32_t* __restrict__ keys,
                                                  uint32_t* __restrict__ next_slot, const int32_t* __restrict__ step,
-                                                 int32_t* __restrict__ step_out, int advance)
+                                                 int32_t* __restrict__ step_out, int advance, int n_sites)
 {
     // one quad of lanes per derivation (4-lane ChaCha block, d3p_device.h): the launch is pure latency
     __shared__ uint32_t sk[3][16];
@@ -867,74 +893,103 @@ __global__ void __launch_bounds__(64) k_vae_keys(const uint32_t* __restrict__ cu
     }
     if (lane == 63 && advance) {
         const int32_t i = *step;
-        keys[210] = (uint32_t)i;
+        keys[D3P_VAE_KEY_STEP] = (uint32_t)i;
         *step_out = i + 1;  // (step_out == step, or the new state's counter when the update is out of place)
     }
     __syncthreads();
     {
-        // quad 0: block 0 of the gradient key's stream -> jax key; quads 1..10: split(perturbation_key, 10)
+        // quad 0: block 0 of the gradient key's stream -> jax key; quads 1..n_sites (<= 15): split(perturbation_key, n_sites)
         const uint32_t* parent = quad == 0 ? sk[1] : sk[2];
-        const bool site = quad >= 1 && quad <= 10;
+        const bool site = quad >= 1 && quad <= n_sites;
         uint32_t a, b;
         derive_child_quad(parent, site ? (uint32_t)(quad - 1) : 0u, quad == 0 ? 0u : D3P_TAG_SPLIT, 0u, a, b);
-        if (quad == 0 && q < 2) keys[208 + q] = a;
+        if (quad == 0 && q < 2) keys[D3P_VAE_KEY_JAX + q] = a;
         if (site) store_child(keys + 48 + 16 * (quad - 1), parent, a, b);
     }
 }
 
-struct VaeLayout {  // offsets of the 10 leaves in tree_flatten order
-    size_t V1, c1, V2, c2, W1, b1, Wl, bl, Ws, bs, P;
+// The network as lists of dense layers.  Hidden widths hs[0 .. nh - 1]: [H] (the reference, examples/vae.py:80-85) or
+// [H, H2] (BASELINE config 5's 784 -> [400, 200] variant, model->H2 > 0):
+//   encoder (guide)  x -> hs[0] -> .. -> hs[nh - 1] : dense layers enc[0 .. nh - 1] (softplus), then the heads (Wl, bl), (Ws, bs)
+//   decoder (model)  z -> hs[nh - 1] -> .. -> hs[0] -> D : dense layers dec[0 .. nh] (softplus after all but the last)
+// Flat layout = tree_flatten order of {'decoder$params', 'encoder$params'}: decoder layers, encoder layers, Wl, bl, Ws, bs; a
+// layer is [W (in x out) | b (out)] (stax.Dense).  nh = 1: V1, c1, V2, c2, W1, b1, Wl, bl, Ws, bs -- 10 leaves, 5 blocks.
+struct VaeDense { size_t W, b; int in, out; };
+struct VaeNet {
+    int nh, D, Z, HE;  // HE = hs[nh - 1]: width of the encoder's last hidden layer = input of the heads
+    VaeDense dec[3], enc[2];
+    size_t Wl, bl, Ws, bs, P;
+    int n_leaves() const { return 2 * (2 * nh + 1) + 4; }
+    int n_blocks() const { return 2 * nh + 3; }
+    // [W | b] block b of the flat layout: decoder layers, encoder layers, Wl, Ws
+    const VaeDense* block_layer(int blk) const { return blk <= nh ? &dec[blk] : blk <= 2 * nh ? &enc[blk - nh - 1] : nullptr; }
 };
 
-static VaeLayout vae_layout(const d3p_vae_model* m)
+static VaeNet vae_net(const d3p_vae_model* m)
 {
-    const size_t D = (size_t)m->D, H = (size_t)m->H, Z = (size_t)m->Z;
-    VaeLayout l;
-    l.V1 = 0;
-    l.c1 = l.V1 + Z * H;
-    l.V2 = l.c1 + H;
-    l.c2 = l.V2 + H * D;
-    l.W1 = l.c2 + D;
-    l.b1 = l.W1 + D * H;
-    l.Wl = l.b1 + H;
-    l.bl = l.Wl + H * Z;
-    l.Ws = l.bl + Z;
-    l.bs = l.Ws + H * Z;
-    l.P = l.bs + Z;
-    return l;
+    VaeNet n;
+    memset(&n, 0, sizeof(n));
+    n.nh = m->H2 > 0 ? 2 : 1;
+    n.D = m->D;
+    n.Z = m->Z;
+    const int hs[2] = {m->H, m->H2};
+    n.HE = hs[n.nh - 1];
+    size_t off = 0;
+    auto dense = [&](VaeDense* l, int in, int out) {
+        l->in = in; l->out = out;
+        l->W = off; off += (size_t)in * out;
+        l->b = off; off += (size_t)out;
+    };
+    for (int l = 0; l <= n.nh; ++l) dense(&n.dec[l], l == 0 ? n.Z : hs[n.nh - l], l == n.nh ? n.D : hs[n.nh - l - 1]);
+    for (int l = 0; l < n.nh; ++l) dense(&n.enc[l], l == 0 ? n.D : hs[l - 1], hs[l]);
+    n.Wl = off; off += (size_t)n.HE * n.Z;
+    n.bl = off; off += (size_t)n.Z;
+    n.Ws = off; off += (size_t)n.HE * n.Z;
+    n.bs = off; off += (size_t)n.Z;
+    n.P = off;
+    return n;
 }
 
 struct VaeWorkspace {
-    float *h1, *sg1, *zl, *u, *eps, *h2, *sg2, *a, *dh2, *dz, *du, *dh1;
+    float *he[2], *sge[2];   // encoder hidden activations and sigmoid(pre-activation) = softplus'
+    float *hd[2], *sgd[2];   // decoder hidden, likewise (hd[l] = output of dec[l])
+    float *dd[2], *de[2];    // deltas at the pre-activations of dec[l] / enc[l]
+    float *zl, *u, *eps, *a, *dz, *du;
     float *lat, *px_loss, *x2, *cf, *sums, *noise, *part, *wpart;
     size_t part_floats;
-    uint32_t* keys;  // 3 x 16 split + 10 x 16 site keys + jax key
+    uint32_t* keys;  // 3 x 16 split + up to 14 x 16 site keys + jax key + step index (D3P_VAE_KEY_*)
 };
 
 static size_t vae_carve(const d3p_vae_model* m, uint32_t B, char* base, VaeWorkspace* ws)
 {
-    const size_t D = (size_t)m->D, H = (size_t)m->H, Z = (size_t)m->Z, P = vae_layout(m).P;
+    const VaeNet N = vae_net(m);
+    const size_t D = (size_t)N.D, Z = (size_t)N.Z, P = N.P;
     size_t off = 0;
     auto take = [&](size_t n_floats) { size_t o = off; off += align_up_v(n_floats * sizeof(float), 256); return base ? (float*)(base + o) : nullptr; };
     float* q;
-    q = take(B * H); if (ws) ws->h1 = q;
-    q = take(B * H); if (ws) ws->sg1 = q;
+    if (ws) memset(ws, 0, sizeof(*ws));
+    for (int l = 0; l < N.nh; ++l) {
+        q = take(B * (size_t)N.enc[l].out); if (ws) ws->he[l] = q;
+        q = take(B * (size_t)N.enc[l].out); if (ws) ws->sge[l] = q;
+    }
     q = take(B * 2 * Z); if (ws) { ws->zl = q; ws->u = q + Z; }    // [z_loc -> z | log z_std -> z_std]: B x 2 Z, row stride 2 Z
     q = take(B * Z); if (ws) ws->eps = q;
-    q = take(B * H); if (ws) ws->h2 = q;
-    q = take(B * H); if (ws) ws->sg2 = q;
+    for (int l = 0; l < N.nh; ++l) {
+        q = take(B * (size_t)N.dec[l].out); if (ws) ws->hd[l] = q;
+        q = take(B * (size_t)N.dec[l].out); if (ws) ws->sgd[l] = q;
+    }
     q = take(B * D); if (ws) ws->a = q;
-    q = take(B * H); if (ws) ws->dh2 = q;
+    for (int l = 0; l < N.nh; ++l) { q = take(B * (size_t)N.dec[l].out); if (ws) ws->dd[l] = q; }
     q = take(B * 2 * Z); if (ws) { ws->dz = q; ws->du = q + Z; }  // [dz | du], likewise
-    q = take(B * H); if (ws) ws->dh1 = q;
+    for (int l = 0; l < N.nh; ++l) { q = take(B * (size_t)N.enc[l].out); if (ws) ws->de[l] = q; }
     q = take(B); if (ws) ws->lat = q;
     q = take(B); if (ws) ws->px_loss = q;
     q = take(B); if (ws) ws->x2 = q;
     q = take(B); if (ws) ws->cf = q;
     q = take(P + 2); if (ws) ws->sums = q;
     q = take(P); if (ws) ws->noise = q;
-    q = take(13 * 16 + 2 + 2); if (ws) ws->keys = (uint32_t*)q;  // + [210]: optimiser step index of the update in flight
-    const size_t pf = 16 * (D + 1) * H;  // split-K partial tiles: up to 16 splits of the largest weight matrix
+    q = take(D3P_VAE_KEY_WORDS); if (ws) ws->keys = (uint32_t*)q;
+    const size_t pf = 16 * (D + 1) * (size_t)m->H;  // split-K partial tiles: up to 16 splits of the largest weight matrix
     q = take(pf); if (ws) { ws->part = q; ws->part_floats = pf; }
     q = take((size_t)D3P_WPART_SPLITS * P); if (ws) ws->wpart = q;  // unreduced weight-gradient tiles
     return off;
@@ -943,8 +998,8 @@ static size_t vae_carve(const d3p_vae_model* m, uint32_t B, char* base, VaeWorks
 static int vae_validate(const d3p_vae_model* m, const char* what)
 {
     if (!m) return fail(D3P_E_INVALID_ARG, "%s: null model", what);
-    if (!(m->D >= 1 && m->H >= 1 && m->Z >= 1 && m->scale > 0.f && m->inv_obs > 0.f))
-        return fail(D3P_E_INVALID_ARG, "%s: bad model (D, H, Z >= 1, scale > 0, inv_obs > 0)", what);
+    if (!(m->D >= 1 && m->H >= 1 && m->Z >= 1 && m->H2 >= 0 && m->scale > 0.f && m->inv_obs > 0.f))
+        return fail(D3P_E_INVALID_ARG, "%s: bad model (D, H, Z >= 1, H2 >= 0, scale > 0, inv_obs > 0)", what);
     return D3P_OK;
 }
 
@@ -955,24 +1010,45 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
                                uint32_t B_total = 0, uint32_t pos0 = 0)
 {
     int rc;
-    const int D = m->D, H = m->H, Z = m->Z, Bi = (int)B;
-    const VaeLayout L = vae_layout(m);
-    auto ew = [&](size_t n) { return dim3(cdiv(n, 256)); };
+    const VaeNet N = vae_net(m);
+    const int D = N.D, Z = N.Z, HE = N.HE, nh = N.nh, Bi = (int)B;
     const dim3 rows(cdiv((uint64_t)B * 64, 256));
     // ---- encoder (guide)
-    if ((rc = gemm(s, X, D, 1, params + L.W1, H, 1, ws.h1, H, Bi, H, D, params + L.b1, 1.f, 0, 0, ws.part, ws.part_floats, 1, ws.sg1))) return rc;
-    // [z_loc | log z_std] = h1 [Wl | Ws] + [bl | bs] in ONE product of N = 2 Z: Ws lies H Z behind where Wl's columns Z .. 2 Z - 1
+    {
+        const float* in = X;
+        for (int l = 0; l < nh; ++l) {
+            const VaeDense& e = N.enc[l];
+            if ((rc = gemm(s, in, e.in, 1, params + e.W, e.out, 1, ws.he[l], e.out, Bi, e.out, e.in, params + e.b, 1.f, 0, 0, ws.part, ws.part_floats, 1,
+                           ws.sge[l])))
+                return rc;
+            in = ws.he[l];
+        }
+    }
+    // [z_loc | log z_std] = h [Wl | Ws] + [bl | bs] in ONE product of N = 2 Z: Ws lies HE Z behind where Wl's columns Z .. 2 Z - 1
     // would be, and bs likewise behind bl (flat layout: Wl, bl, Ws, bs)
     const int ldz = 2 * Z;
-    const GemmJumps enc = {Z, 0x7fffffff, (long long)H * Z, 0, (long long)H * Z, 0};
-    if ((rc = gemm(s, ws.h1, H, 1, params + L.Wl, Z, 1, ws.zl, ldz, Bi, 2 * Z, H, params + L.bl, 1.f, 0, 0, ws.part, ws.part_floats, 0, nullptr,
+    const GemmJumps enc = {Z, 0x7fffffff, (long long)HE * Z, 0, (long long)HE * Z, 0};
+    if ((rc = gemm(s, ws.he[nh - 1], HE, 1, params + N.Wl, Z, 1, ws.zl, ldz, Bi, 2 * Z, HE, params + N.bl, 1.f, 0, 0, ws.part, ws.part_floats, 0, nullptr,
                    nullptr, &enc)))
         return rc;
     hipLaunchKernelGGL(k_vae_latent, rows, dim3(256), 0, s, ws.zl, ws.u, eps, eps ? (const uint32_t*)nullptr : jax_key, B_total ? B_total : B, pos0,
                        ws.eps, B, Z, ldz, ws.lat);  // zl := z, u := sd
     // ---- decoder (model)
-    if ((rc = gemm(s, ws.zl, ldz, 1, params + L.V1, H, 1, ws.h2, H, Bi, H, Z, params + L.c1, 1.f, 0, 0, nullptr, 0, 1, ws.sg2))) return rc;
-    if ((rc = gemm(s, ws.h2, H, 1, params + L.V2, D, 1, ws.a, D, Bi, D, H, params + L.c2, 1.f, 0))) return rc;
+    {
+        const float* in = ws.zl;
+        int ld_in = ldz;
+        for (int l = 0; l < nh; ++l) {
+            const VaeDense& d = N.dec[l];
+            // (the first product has K = Z: no split)
+            if ((rc = gemm(s, in, ld_in, 1, params + d.W, d.out, 1, ws.hd[l], d.out, Bi, d.out, d.in, params + d.b, 1.f, 0, 0, l ? ws.part : nullptr,
+                           l ? ws.part_floats : 0, 1, ws.sgd[l])))
+                return rc;
+            in = ws.hd[l];
+            ld_in = d.out;
+        }
+        const VaeDense& o = N.dec[nh];
+        if ((rc = gemm(s, in, ld_in, 1, params + o.W, D, 1, ws.a, D, Bi, D, o.in, params + o.b, 1.f, 0))) return rc;
+    }
     hipLaunchKernelGGL(k_vae_out, rows, dim3(256), 0, s, ws.a, X, mask, B, D, sc, (const float*)ws.lat, ws.px_loss, ws.x2);  // a := da
     return check_launch("d3p_vae forward");
 }
@@ -982,37 +1058,67 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
                             uint32_t B, const float* eps_ext, const uint32_t* jax_key, float clip, const VaeWorkspace& ws,
                             float* norms_out, uint32_t B_total = 0, uint32_t pos0 = 0, int* w_splits = nullptr)
 {
-    // w_splits != nullptr (single-device update): the split-K partial tiles of the five weight-gradient products stay in ws.wpart
-    // and w_splits[0..4] says how many each (k_vae_finalize sums them); otherwise ws.sums holds the reduced sums
+    // w_splits != nullptr (single-device update): the split-K partial tiles of the weight-gradient products stay in ws.wpart
+    // and w_splits[0 .. n_blocks - 1] says how many each (k_vae_finalize sums them); otherwise ws.sums holds the reduced sums
     if (B_total == 0) B_total = B;
     int rc;
-    const int D = m->D, H = m->H, Z = m->Z, Bi = (int)B;
-    const VaeLayout L = vae_layout(m);
+    const VaeNet N = vae_net(m);
+    const int D = N.D, Z = N.Z, HE = N.HE, nh = N.nh, Bi = (int)B;
     const float sc = m->inv_obs * m->scale;
     const float* eps = eps_ext ? eps_ext : ws.eps;  // (drawn inside k_vae_latent when not given)
-    auto ew = [&](size_t n) { return dim3(cdiv(n, 256)); };
     const dim3 rows(cdiv((uint64_t)B * 64, 256));
     if ((rc = vae_enqueue_forward(s, m, params, X, mask, B, eps_ext, sc, ws, jax_key, B_total, pos0))) return rc;
-    // ---- backward (data)
-    if ((rc = gemm(s, ws.a, D, 1, params + L.V2, 1, D, ws.dh2, H, Bi, H, D, nullptr, 1.f, 0, 0, ws.part, ws.part_floats, 2, ws.sg2))) return rc;  // dpre2 = (da V2^T) . softplus'(pre2)
+    // ---- backward (data): delta_in = (delta_out W^T) . softplus'(pre) down the decoder
+    {
+        const float* delta = ws.a;
+        for (int l = nh - 1; l >= 0; --l) {
+            const VaeDense& d = N.dec[l + 1];
+            if ((rc = gemm(s, delta, d.out, 1, params + d.W, 1, d.out, ws.dd[l], d.in, Bi, d.in, d.out, nullptr, 1.f, 0, 0, ws.part, ws.part_floats, 2,
+                           ws.sgd[l])))
+                return rc;
+            delta = ws.dd[l];
+        }
+    }
     const int ldz = 2 * Z;
-    // dz = dpre2 V1^T + sc z and du = dz sd eps - sc in the product's epilogue (epi 3; was the k_vae_dlatent launch)
-    if ((rc = gemm(s, ws.dh2, H, 1, params + L.V1, 1, H, ws.dz, ldz, Bi, Z, H, nullptr, 1.f, 0, 0, ws.part, ws.part_floats, 3, nullptr, nullptr,
-                   nullptr, ws.zl, eps, Z, sc)))
+    // dz = dpre V1^T + sc z and du = dz sd eps - sc in the product's epilogue (epi 3; was the k_vae_dlatent launch)
+    if ((rc = gemm(s, ws.dd[0], N.dec[0].out, 1, params + N.dec[0].W, 1, N.dec[0].out, ws.dz, ldz, Bi, Z, N.dec[0].out, nullptr, 1.f, 0, 0, ws.part,
+                   ws.part_floats, 3, nullptr, nullptr, nullptr, ws.zl, eps, Z, sc)))
         return rc;
-    // dpre1 = ([dz | du] [Wl^T ; Ws^T]) . softplus'(pre1): ONE product of K = 2 Z (rows Z .. 2 Z - 1 of the stacked B are Ws^T,
-    // H Z behind where Wl^T's would be)
-    const GemmJumps dec = {0x7fffffff, Z, 0, (long long)H * Z, 0, 0};
-    if ((rc = gemm(s, ws.dz, ldz, 1, params + L.Wl, 1, Z, ws.dh1, H, Bi, H, 2 * Z, nullptr, 1.f, 0, 0, nullptr, 0, 2, ws.sg1, nullptr, &dec)))
+    // dpre = ([dz | du] [Wl^T ; Ws^T]) . softplus'(pre): ONE product of K = 2 Z (rows Z .. 2 Z - 1 of the stacked B are Ws^T,
+    // HE Z behind where Wl^T's would be)
+    const GemmJumps dec = {0x7fffffff, Z, 0, (long long)HE * Z, 0, 0};
+    if ((rc = gemm(s, ws.dz, ldz, 1, params + N.Wl, 1, Z, ws.de[nh - 1], HE, Bi, HE, 2 * Z, nullptr, 1.f, 0, 0, nullptr, 0, 2, ws.sge[nh - 1], nullptr,
+                   &dec)))
         return rc;
+    for (int l = nh - 2; l >= 0; --l) {
+        const VaeDense& e = N.enc[l + 1];
+        if ((rc = gemm(s, ws.de[l + 1], e.out, 1, params + e.W, 1, e.out, ws.de[l], e.in, Bi, e.in, e.out, nullptr, 1.f, 0, 0, ws.part, ws.part_floats, 2,
+                       ws.sge[l])))
+            return rc;
+    }
     // ---- per-example norms and clip factors; the rows of every delta come back scaled by c_i
     NormArgs na;
-    na.x2 = ws.x2; na.h1 = ws.h1; na.z = ws.zl; na.h2 = ws.h2;
-    na.dpre1 = ws.dh1; na.dz = ws.dz; na.du = ws.du; na.dpre2 = ws.dh2; na.da = ws.a;
-    na.mask = mask; na.B = B; na.D = D; na.H = H; na.Z = Z; na.ldz = ldz; na.clip = clip; na.cf = ws.cf; na.norms = norms_out;
-    na.px_loss = ws.px_loss; na.loss_n = ws.sums + L.P;
+    memset(&na, 0, sizeof(na));
     {
-        size_t stage_floats = 4 * (size_t)(D + 2 * H + 2 * Z);
+        int t = 0;
+        auto term = [&](const float* in, int in_ld, int in_n, float* d0, float* d1, int d_ld, int d_n) {
+            NormTerm& q = na.t[t++];
+            q.in = in; q.in_ld = in_ld; q.in_n = in_n; q.d0 = d0; q.d1 = d1; q.d_ld = d_ld; q.d_n = d_n;
+            na.stage += d_n * (d1 ? 2 : 1);
+        };
+        term(ws.hd[nh - 1], N.dec[nh].in, N.dec[nh].in, ws.a, nullptr, D, D);
+        for (int l = nh - 1; l >= 1; --l) term(ws.hd[l - 1], N.dec[l].in, N.dec[l].in, ws.dd[l], nullptr, N.dec[l].out, N.dec[l].out);
+        term(ws.zl, ldz, Z, ws.dd[0], nullptr, N.dec[0].out, N.dec[0].out);
+        term(ws.he[nh - 1], HE, HE, ws.dz, ws.du, ldz, Z);
+        for (int l = nh - 1; l >= 1; --l) term(ws.he[l - 1], N.enc[l].in, N.enc[l].in, ws.de[l], nullptr, N.enc[l].out, N.enc[l].out);
+        term(nullptr, 0, 0, ws.de[0], nullptr, N.enc[0].out, N.enc[0].out);
+        na.n_terms = t;
+    }
+    na.x2 = ws.x2;
+    na.mask = mask; na.B = B; na.clip = clip; na.cf = ws.cf; na.norms = norms_out;
+    na.px_loss = ws.px_loss; na.loss_n = ws.sums + N.P;
+    {
+        size_t stage_floats = 4 * (size_t)na.stage;
         if (stage_floats < 512) stage_floats = 512;  // the last workgroup's loss / count reduction uses 2 x 256 floats
         hipLaunchKernelGGL(k_vae_norms, dim3(rows.x + 1), dim3(256), stage_floats * sizeof(float), s, na);
     }
@@ -1020,13 +1126,22 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     // [W | b] of every layer is contiguous in the flat layout, so the bias gradient is row `in` of a GEMM whose A carries a
     // virtual row of ones
     float* S = ws.sums;
-    // four products: V1, V2, W1 and [Wl | Ws] (B operand [dz | du], N = 2 Z; the Ws block of the sums lies H Z behind where
-    // columns Z .. 2 Z - 1 of a Z-wide C would be)
+    // one product per dense layer (decoder, then encoder), then ONE for [Wl | Ws] (B operand [dz | du], N = 2 Z; the Ws block of
+    // the sums lies HE Z behind where columns Z .. 2 Z - 1 of a Z-wide C would be)
     struct WG { const float* A; long long a_sk; int in; const float* Bm; int ldb; int out; int ldc; size_t off; const GemmJumps* j; int blk; };
-    const GemmJumps wls = {Z, 0x7fffffff, 0, 0, 0, (long long)H * Z};
-    const WG wg[4] = {{ws.zl, ldz, Z, ws.dh2, H, H, H, L.V1, nullptr, 0}, {ws.h2, H, H, ws.a, D, D, D, L.V2, nullptr, 1},
-                      {X, D, D, ws.dh1, H, H, H, L.W1, nullptr, 2}, {ws.h1, H, H, ws.dz, ldz, 2 * Z, Z, L.Wl, &wls, 3}};
-    for (int b = 0; b < 4; ++b) {
+    const GemmJumps wls = {Z, 0x7fffffff, 0, 0, 0, (long long)HE * Z};
+    WG wg[6];
+    int n_wg = 0;
+    for (int l = 0; l <= nh; ++l) {
+        const VaeDense& d = N.dec[l];
+        wg[n_wg++] = {l == 0 ? ws.zl : ws.hd[l - 1], l == 0 ? ldz : d.in, d.in, l == nh ? ws.a : ws.dd[l], d.out, d.out, d.out, d.W, nullptr, l};
+    }
+    for (int l = 0; l < nh; ++l) {
+        const VaeDense& e = N.enc[l];
+        wg[n_wg++] = {l == 0 ? X : ws.he[l - 1], e.in, e.in, ws.de[l], e.out, e.out, e.out, e.W, nullptr, nh + 1 + l};
+    }
+    wg[n_wg++] = {ws.he[nh - 1], HE, HE, ws.dz, ldz, 2 * Z, Z, N.Wl, &wls, 2 * nh + 1};
+    for (int b = 0; b < n_wg; ++b) {
         float* part = w_splits ? ws.wpart + (size_t)D3P_WPART_SPLITS * wg[b].off : ws.part;
         const size_t part_floats = w_splits ? (size_t)D3P_WPART_SPLITS * (wg[b].in + 1) * wg[b].out : ws.part_floats;
         int left = 0;
@@ -1035,7 +1150,7 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
             return rc;
         if (w_splits) {
             w_splits[wg[b].blk] = left;
-            if (b == 3) w_splits[4] = left;
+            if (b == n_wg - 1) w_splits[wg[b].blk + 1] = left;
         }
     }
     return check_launch("d3p_vae sums");
@@ -1058,13 +1173,13 @@ int d3p_gemm_f32(void* stream, const float* A_dev, int64_t a_sm, int64_t a_sk, c
 
 int64_t d3p_vae_num_params(const d3p_vae_model* model)
 {
-    if (!model || model->D < 1 || model->H < 1 || model->Z < 1) return 0;
-    return (int64_t)vae_layout(model).P;
+    if (!model || model->D < 1 || model->H < 1 || model->Z < 1 || model->H2 < 0) return 0;
+    return (int64_t)vae_net(model).P;
 }
 
 size_t d3p_dpvi_vae_workspace(const d3p_vae_model* model, uint32_t B)
 {
-    if (!model || model->D < 1 || model->H < 1 || model->Z < 1) return 0;
+    if (!model || model->D < 1 || model->H < 1 || model->Z < 1 || model->H2 < 0) return 0;
     return vae_carve(model, B, nullptr, nullptr);
 }
 
@@ -1080,7 +1195,7 @@ int d3p_vae_step_sums(void* stream, const d3p_vae_model* model, const float* par
     vae_carve(model, B, (char*)workspace_dev, &ws);
     hipStream_t s = (hipStream_t)stream;
     if (int rc = vae_enqueue_sums(s, model, params_dev, X_dev, mask_dev, B, eps_dev, jax_key_dev, clip, ws, norms_dev)) return rc;
-    const size_t P = vae_layout(model).P;
+    const size_t P = vae_net(model).P;
     D3P_HIP_TRY(hipMemcpyAsync(sums_dev, ws.sums, (P + 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (px_loss_dev) D3P_HIP_TRY(hipMemcpyAsync(px_loss_dev, ws.px_loss, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
     return D3P_OK;
@@ -1102,7 +1217,7 @@ int d3p_vae_evaluate(void* stream, const d3p_vae_model* model, const float* para
         eps = ws.eps;
     }
     if (int rc = vae_enqueue_forward(s, model, params_dev, X_dev, nullptr, B, eps, model->inv_obs * model->scale, ws)) return rc;
-    const size_t P = vae_layout(model).P;
+    const size_t P = vae_net(model).P;
     hipLaunchKernelGGL(k_vae_loss_n, dim3(1), dim3(256), 0, s, (const float*)ws.px_loss, (const uint8_t*)nullptr, B, ws.sums + P);
     D3P_HIP_TRY(hipMemcpyAsync(loss_dev, ws.sums + P, sizeof(float), hipMemcpyDeviceToDevice, s));
     return check_launch("d3p_vae_evaluate");
@@ -1123,16 +1238,16 @@ static int vae_update_checks(const d3p_vae_model* model, const d3p_dpsvi_hyper* 
 // split(perturbation_key, 10) (svi.py:491), convert_to_jax_rng_key(gradient_key)
 // from != nullptr: the update reads the key and the step counter of `from` and writes the next key / counter into `state`
 // (slot 1 of its key buffer; state->key_slot is taken as 0)
-static int vae_step_keys(hipStream_t s, const d3p_dpsvi_state* state, const VaeWorkspace& ws, bool advance,
+static int vae_step_keys(hipStream_t s, const d3p_vae_model* model, const d3p_dpsvi_state* state, const VaeWorkspace& ws, bool advance,
                          const d3p_dpsvi_state* from = nullptr)
 {
-    const int slot = state->key_slot & 1;
+    const int slot = state->key_slot & 1, n_sites = vae_net(model).n_leaves();
     if (from)
         hipLaunchKernelGGL(k_vae_keys, dim3(1), dim3(64), 0, s, (const uint32_t*)(from->rng_key + 16 * (from->key_slot & 1)), ws.keys,
-                           state->rng_key + 16, (const int32_t*)from->step, state->step, advance ? 1 : 0);
+                           state->rng_key + 16, (const int32_t*)from->step, state->step, advance ? 1 : 0, n_sites);
     else
-    hipLaunchKernelGGL(k_vae_keys, dim3(1), dim3(64), 0, s, (const uint32_t*)(state->rng_key + 16 * slot), ws.keys,
-                       state->rng_key + 16 * (slot ^ 1), (const int32_t*)state->step, state->step, advance ? 1 : 0);
+        hipLaunchKernelGGL(k_vae_keys, dim3(1), dim3(64), 0, s, (const uint32_t*)(state->rng_key + 16 * slot), ws.keys,
+                           state->rng_key + 16 * (slot ^ 1), (const int32_t*)state->step, state->step, advance ? 1 : 0, n_sites);
     return check_launch("k_vae_keys");
 }
 
@@ -1156,12 +1271,12 @@ static int vae_local_sums_impl(void* stream, const d3p_vae_model* model, const d
     vae_carve(model, B_local, (char*)workspace_dev, &ws);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if ((rc = vae_step_keys(s, state, ws, advance, from))) return rc;
-    if ((rc = vae_enqueue_sums(s, model, from ? from->params : state->params, X_dev, mask_dev, B_local, eps_dev, ws.keys + 208, hyper->clip, ws, nullptr,
+    if ((rc = vae_step_keys(s, model, state, ws, advance, from))) return rc;
+    if ((rc = vae_enqueue_sums(s, model, from ? from->params : state->params, X_dev, mask_dev, B_local, eps_dev, ws.keys + D3P_VAE_KEY_JAX, hyper->clip, ws, nullptr,
                                B_total, pos0, w_splits)))
         return rc;
     if (sums_dev != ws.sums)
-        D3P_HIP_TRY(hipMemcpyAsync(sums_dev, ws.sums, (vae_layout(model).P + 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
+        D3P_HIP_TRY(hipMemcpyAsync(sums_dev, ws.sums, (vae_net(model).P + 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
     return check_launch("d3p_dpvi_vae_local_sums");
 }
 
@@ -1193,43 +1308,53 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
     VaeWorkspace ws;
     vae_carve(model, B_local, (char*)workspace_dev, &ws);
     hipStream_t s = (hipStream_t)stream;
-    const VaeLayout L = vae_layout(model);
-    const int slot = state->key_slot & 1;
+    const VaeNet N = vae_net(model);
+    const int nh = N.nh, n_leaves = N.n_leaves(), n_blocks = N.n_blocks();
     int rc;
-    if (derive_keys && (rc = vae_step_keys(s, state, ws, true))) return rc;
+    if (derive_keys && (rc = vae_step_keys(s, model, state, ws, true))) return rc;
     {
-        const size_t leaf_off[11] = {L.V1, L.c1, L.V2, L.c2, L.W1, L.b1, L.Wl, L.bl, L.Ws, L.bs, L.P};
+        size_t leaf_off[D3P_VAE_MAX_LEAVES + 1];
+        int k = 0;
+        for (int l = 0; l <= nh; ++l) { leaf_off[k++] = N.dec[l].W; leaf_off[k++] = N.dec[l].b; }
+        for (int l = 0; l < nh; ++l) { leaf_off[k++] = N.enc[l].W; leaf_off[k++] = N.enc[l].b; }
+        leaf_off[k++] = N.Wl; leaf_off[k++] = N.bl; leaf_off[k++] = N.Ws; leaf_off[k++] = N.bs;
+        for (; k <= D3P_VAE_MAX_LEAVES; ++k) leaf_off[k] = N.P;
         SiteNoiseArgs na;  // one key per leaf, normal(site_key, leaf shape) (svi.py:487)
         na.site_keys = ws.keys + 48;
         na.noise = ws.noise;
         na.blk_off[0] = 0;
-        for (int k = 0; k < 10; ++k) {
+        for (k = 0; k < D3P_VAE_MAX_LEAVES; ++k) {
             na.elem_off[k] = (uint32_t)leaf_off[k];
             na.blk_off[k + 1] = na.blk_off[k] + (uint32_t)((leaf_off[k + 1] - leaf_off[k] + 15) / 16);
         }
-        na.elem_off[10] = (uint32_t)leaf_off[10];
-        hipLaunchKernelGGL(k_vae_site_noise, dim3(cdiv(na.blk_off[10], 256)), dim3(256), 0, s, na);
+        na.elem_off[D3P_VAE_MAX_LEAVES] = (uint32_t)leaf_off[D3P_VAE_MAX_LEAVES];
+        (void)n_leaves;
+        hipLaunchKernelGGL(k_vae_site_noise, dim3(cdiv(na.blk_off[D3P_VAE_MAX_LEAVES], 256)), dim3(256), 0, s, na);
     }
     VaeFinalArgs f;
+    memset(&f, 0, sizeof(f));
     f.sums = sums_dev;
     f.wpart = w_splits ? ws.wpart : nullptr;
     {
-        const size_t blk[6] = {L.V1, L.V2, L.W1, L.Wl, L.Ws, L.P};  // [W | b] blocks of the flat layout
-        const int outs[5] = {model->H, model->D, model->H, model->Z, model->Z};
-        for (int b = 0; b < 5; ++b) {
-            f.w_off[b] = (uint32_t)blk[b];
-            f.w_base[b] = (uint32_t)(D3P_WPART_SPLITS * blk[b]);
-            f.w_tile[b] = (uint32_t)(blk[b + 1] - blk[b]);
-            f.w_ld[b] = f.w_out[b] = (uint32_t)outs[b];
+        // [W | b] blocks of the flat layout: the dense layers, then Wl and Ws -- which come from ONE product with N = 2 Z:
+        // shared tiles of (HE + 1) x 2 Z in the region of the Wl block
+        for (int b = 0; b < n_blocks; ++b) {
+            const VaeDense* lay = N.block_layer(b);
+            const size_t first = lay ? lay->W : (b == 2 * nh + 1 ? N.Wl : N.Ws);
+            const size_t next = b + 1 < n_blocks ? (N.block_layer(b + 1) ? N.block_layer(b + 1)->W : (b + 1 == 2 * nh + 1 ? N.Wl : N.Ws)) : N.P;
+            f.w_off[b] = (uint32_t)first;
+            f.w_base[b] = (uint32_t)(D3P_WPART_SPLITS * first);
+            f.w_tile[b] = (uint32_t)(next - first);
+            f.w_ld[b] = f.w_out[b] = (uint32_t)(lay ? lay->out : N.Z);
             f.w_coff[b] = 0;
             f.w_splits[b] = w_splits ? w_splits[b] : 0;
         }
-        // blocks 3, 4 (Wl, Ws) come from ONE product with N = 2 Z: shared tiles of (H + 1) x 2 Z in the region of block 3
-        f.w_tile[3] = f.w_tile[4] = f.w_tile[3] + f.w_tile[4];
-        f.w_ld[3] = f.w_ld[4] = 2u * (uint32_t)model->Z;
-        f.w_base[4] = f.w_base[3];
-        f.w_coff[4] = (uint32_t)model->Z;
-        f.w_off[5] = (uint32_t)L.P;
+        const int bl = 2 * nh + 1, bs = 2 * nh + 2;
+        f.w_tile[bl] = f.w_tile[bs] = f.w_tile[bl] + f.w_tile[bs];
+        f.w_ld[bl] = f.w_ld[bs] = 2u * (uint32_t)N.Z;
+        f.w_base[bs] = f.w_base[bl];
+        f.w_coff[bs] = (uint32_t)N.Z;
+        for (int b = n_blocks; b <= D3P_VAE_MAX_BLOCKS; ++b) f.w_off[b] = (uint32_t)N.P;
     }
     f.noise = ws.noise;
     f.in_params = from ? from->params : state->params;
@@ -1238,14 +1363,14 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
     f.params = state->params;
     f.adam_m = state->adam_m;
     f.adam_v = state->adam_v;
-    f.step = reinterpret_cast<const int32_t*>(ws.keys + 210);  // the step index k_vae_keys saved before advancing it
+    f.step = reinterpret_cast<const int32_t*>(ws.keys + D3P_VAE_KEY_STEP);  // the step index k_vae_keys saved before advancing it
     f.loss_out = loss_dev;
     f.grad_out = grad_out_dev;
-    f.P = L.P;
+    f.P = N.P;
     f.B = B_total;
     f.h = *hyper;
     f.obs_scale = 1.0f / model->inv_obs;
-    hipLaunchKernelGGL(k_vae_finalize, dim3(cdiv(L.P, 256)), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(k_vae_finalize, dim3(cdiv(N.P, 256)), dim3(256), 0, s, f);
     return check_launch("d3p_dpvi_vae_apply");
 }
 
@@ -1264,7 +1389,7 @@ int d3p_dpvi_vae_update_from(void* stream, const d3p_vae_model* model, const d3p
     if (workspace_bytes < d3p_dpvi_vae_workspace(model, B)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_update_from: workspace too small");
     VaeWorkspace ws;
     vae_carve(model, B, (char*)workspace_dev, &ws);
-    int w_splits[5];
+    int w_splits[D3P_VAE_MAX_BLOCKS];
     if (int rc = vae_local_sums_impl(stream, model, hyper, state, X_dev, mask_dev, B, B, 0, eps_dev, ws.sums, workspace_dev,
                                      workspace_bytes, true, w_splits, from))
         return rc;
@@ -1283,7 +1408,7 @@ int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsv
     if (workspace_bytes < d3p_dpvi_vae_workspace(model, B)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_update: workspace too small");
     VaeWorkspace ws;
     vae_carve(model, B, (char*)workspace_dev, &ws);
-    int w_splits[5];  // split-K partial tiles of the weight gradients are summed by k_vae_finalize, not by reduction launches
+    int w_splits[D3P_VAE_MAX_BLOCKS];  // split-K partial tiles of the weight gradients are summed by k_vae_finalize, not by reduction launches
     if (int rc = vae_local_sums_impl(stream, model, hyper, state, X_dev, mask_dev, B, B, 0, eps_dev, ws.sums, workspace_dev,
                                      workspace_bytes, true, w_splits))
         return rc;

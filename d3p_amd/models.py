@@ -132,9 +132,17 @@ class VAEModel:
     has_labels = False
     family = "vae"
 
-    def __init__(self, z_dim=None, hidden_dim=None, scale=1.0):
+    def __init__(self, z_dim=None, hidden_dim=None, scale=1.0, hidden_dim2=None):
+        """``hidden_dim2``: width of a second hidden layer on each side (encoder x -> hidden -> hidden2 -> heads, decoder
+        z -> hidden2 -> hidden -> out): BASELINE config 5's 784 -> [400, 200] -> 50 variant.  ``hidden_dim`` may also be a
+        pair ``(400, 200)``.  The reference's network has one hidden layer (examples/vae.py:80-85)."""
+        if isinstance(hidden_dim, (tuple, list)):
+            if len(hidden_dim) not in (1, 2):
+                raise ValueError("VAEModel: one or two hidden layers")
+            hidden_dim, hidden_dim2 = hidden_dim[0], (hidden_dim[1] if len(hidden_dim) == 2 else hidden_dim2)
         self.z_dim = z_dim
         self.hidden_dim = hidden_dim
+        self.hidden_dim2 = int(hidden_dim2) if hidden_dim2 else 0
         self.scale = float(scale)
 
     @staticmethod

@@ -210,13 +210,21 @@ class DPSVI:
     def _vae_struct(self, D, kwargs, observation_scale):
         kw = dict(self.static_kwargs)
         kw.update(kwargs)
-        z = kw.get("z_dim") or self.model.z_dim
-        h = kw.get("hidden_dim") or self.model.hidden_dim
-        if z is None or h is None:
-            raise ValueError("VAEModel: z_dim and hidden_dim must be given")
+        z, h, h2 = self._vae_dims(kw)
         n_total = self.model.num_obs_total((), kw)
         site_scale = (1.0 if n_total is None else n_total) * self.model.scale   # plate(N, 1) x handlers.scale
-        return VaeModel(int(D), int(h), int(z), float(site_scale), 1.0 / float(observation_scale))
+        return VaeModel(int(D), int(h), int(z), float(site_scale), 1.0 / float(observation_scale), int(h2))
+
+    def _vae_dims(self, kw):
+        """(z, hidden, hidden2) from the call's keyword arguments or the model; hidden2 = 0: one hidden layer."""
+        z = kw.get("z_dim") or self.model.z_dim
+        h = kw.get("hidden_dim") or self.model.hidden_dim
+        h2 = kw.get("hidden_dim2") or getattr(self.model, "hidden_dim2", 0) or 0
+        if isinstance(h, (tuple, list)):
+            h, h2 = h[0], (h[1] if len(h) > 1 else h2)
+        if z is None or h is None:
+            raise ValueError("VAEModel: z_dim and hidden_dim must be given")
+        return int(z), int(h), int(h2)
 
     @staticmethod
     def _vae_flat(X):
@@ -224,16 +232,30 @@ class DPSVI:
 
     def _vae_tree(self, flat, vm):
         """Flat parameter vector -> the numpyro.module trees of stax.serial (empty tuples for the parameter-free layers)."""
-        D, H, Z = vm.D, vm.H, vm.Z
-        shapes = [(Z, H), (H,), (H, D), (D,), (D, H), (H,), (H, Z), (Z,), (H, Z), (Z,)]
+        D, H, Z, H2 = vm.D, vm.H, vm.Z, vm.H2
+        hs = [H] + ([H2] if H2 else [])
+        dec_dims, enc_dims = [Z] + hs[::-1] + [D], [D] + hs
+        shapes = []
+        for i, o in zip(dec_dims[:-1], dec_dims[1:]):
+            shapes += [(i, o), (o,)]
+        for i, o in zip(enc_dims[:-1], enc_dims[1:]):
+            shapes += [(i, o), (o,)]
+        shapes += [(hs[-1], Z), (Z,), (hs[-1], Z), (Z,)]
         leaves, pos = [], 0
         for shp in shapes:
             n = int(np.prod(shp))
             leaves.append(flat[pos:pos + n].reshape(shp))
             pos += n
-        V1, c1, V2, c2, W1, b1, Wl, bl, Ws, bs = leaves
-        return {"decoder$params": [(V1, c1), (), (V2, c2), ()],
-                "encoder$params": [(W1, b1), (), (), ((Wl, bl), ((Ws, bs), ()))]}
+        n_dec, n_enc = len(dec_dims) - 1, len(enc_dims) - 1
+        dense = [(leaves[2 * k], leaves[2 * k + 1]) for k in range(n_dec + n_enc)]
+        (Wl, bl, Ws, bs) = leaves[-4:]
+        decoder, encoder = [], []
+        for lay in dense[:n_dec]:
+            decoder += [lay, ()]            # stax.serial(Dense, Softplus, .., Dense, Sigmoid): parameter-free layers are ()
+        for lay in dense[n_dec:]:
+            encoder += [lay, ()]
+        encoder += [(), ((Wl, bl), ((Ws, bs), ()))]   # FanOut(2), parallel(Dense, serial(Dense, Exp))
+        return {"decoder$params": decoder, "encoder$params": encoder}
 
     def _init_vae(self, rng_key, *args, **kwargs):
         _lib.require_device()
@@ -401,10 +423,12 @@ class DPSVI:
         AutoDiagonalNormal; the hand-written guides keep their ``*_std_log`` unconstrained."""
         p = self.optim.get_params(svi_state.optim_state)
         if self._is_vae():
-            kw = self.static_kwargs
-            z, h = int(kw.get("z_dim") or self.model.z_dim), int(kw.get("hidden_dim") or self.model.hidden_dim)
-            D = (p.numel() - (z * h + h) - 2 * (h * z + z) - h) // (2 * h + 1)
-            return self._vae_tree(p.clone(), VaeModel(D, h, z, 1.0, 1.0))
+            z, h, h2 = self._vae_dims(dict(self.static_kwargs))
+            he = h2 if h2 else h
+            # P = (z he + he) + [h2 h + h] + (h D + D) + (D h + h) + [h h2 + h2] + 2 (he z + z): solve for D
+            rest = (z * he + he) + 2 * (he * z + z) + h + (2 * h * h2 + h + h2 if h2 else 0)
+            D = (p.numel() - rest) // (2 * h + 1)
+            return self._vae_tree(p.clone(), VaeModel(D, h, z, 1.0, 1.0, h2))
         if self._is_gmm():
             K = int(self.static_kwargs.get("k") or self.model.k)
             return {"alpha_log": p[:K].clone(), "mus_loc": p[K:].reshape(K, -1).clone()}

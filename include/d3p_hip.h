@@ -504,11 +504,16 @@ int d3p_dpvi_gmm_run(void* stream, const d3p_gmm_model* model, const d3p_dpsvi_h
  * encoder: h1 = softplus(x W1 + b1), z_loc = h1 Wl + bl, z_std = exp(h1 Ws + bs);  decoder: h2 = softplus(z V1 + c1),
  * obs ~ Bernoulli(sigmoid(h2 V2 + c2)).  Parameter vector = leaves of {'decoder$params', 'encoder$params'} in
  * tree_flatten order: V1 (Z x H), c1 (H), V2 (H x D), c2 (D), W1 (D x H), b1 (H), Wl (H x Z), bl (Z), Ws (H x Z), bs (Z).
+ * H2 > 0 (ABI 5): BASELINE config 5's literal 784 -> [400, 200] -> 50 variant, one more dense softplus layer on each side
+ * (the reference itself has one hidden layer): encoder x -> H -> H2 -> heads, decoder z -> H2 -> H -> D; leaves
+ * V1 (Z x H2), c1, V2 (H2 x H), c2, V3 (H x D), c3, W1 (D x H), b1, W2 (H x H2), b2, Wl (H2 x Z), bl, Ws (H2 x Z), bs
+ * (P = 819 284 at 784 / [400, 200] / 50).
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
     int32_t D, H, Z;  /* observation, hidden and latent dimension (784, 400, 50) */
     float scale;      /* scale of every site: plate scale x handlers.scale (vae.py:194-195 -> 1) */
     float inv_obs;    /* 1 / observation_scale (svi.py:278) */
+    int32_t H2;       /* width of the second hidden layer; 0 = the reference's one-hidden-layer network */
 } d3p_vae_model;
 
 int64_t d3p_vae_num_params(const d3p_vae_model* model);
@@ -537,7 +542,7 @@ int d3p_vae_evaluate(void* stream, const d3p_vae_model* model, const float* para
                      size_t workspace_bytes);
 
 /* One DPSVI.update (svi.py:395-434) for the VAE: key split, the fused sums above, one Gaussian-noise key per
- * parameter leaf (svi.py:487-491, 10 leaves), numpyro Adam; state as for the other models (P = d3p_vae_num_params). */
+ * parameter leaf (svi.py:487-491; 10 leaves, 14 with model->H2 > 0), numpyro Adam; state as for the other models (P = d3p_vae_num_params). */
 int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper,
                         const d3p_dpsvi_state* state, const float* X_dev, const uint8_t* mask_dev, uint32_t B,
                         const float* eps_dev, float* loss_dev, float* grad_out_dev, void* workspace_dev,

@@ -1177,116 +1177,208 @@ typedef struct {
     int32_t D, H, Z;
     float scale;    /* site scale (1 in the example) */
     float inv_obs;  /* 1 / observation_scale */
+    int32_t H2;     /* > 0: a second hidden layer on each side (BASELINE config 5's 784 -> [400, 200] -> 50 variant; the
+                     * reference has one): encoder x -> H -> H2 -> heads, decoder z -> H2 -> H -> D; leaves
+                     * V1 (Z x H2), c1, V2 (H2 x H), c2, V3 (H x D), c3, W1 (D x H), b1, W2 (H x H2), b2, Wl (H2 x Z), bl, Ws, bs */
 } d3po_vae_spec;
+
+/* the dense layers of the network in tree_flatten order: decoder dec[0 .. nh], encoder enc[0 .. nh - 1], then the heads */
+typedef struct { int64_t W, b; int in, out; } d3po_dense;
+typedef struct { int nh, HE; d3po_dense dec[3], enc[2]; int64_t Wl, bl, Ws, bs, P; } d3po_vae_net;
+
+static d3po_vae_net d3po_vae_layers(const d3po_vae_spec* sp)
+{
+    d3po_vae_net n;
+    memset(&n, 0, sizeof(n));
+    n.nh = sp->H2 > 0 ? 2 : 1;
+    const int hs[2] = {sp->H, sp->H2};
+    n.HE = hs[n.nh - 1];
+    int64_t off = 0;
+    for (int l = 0; l <= n.nh; ++l) {
+        d3po_dense* d = &n.dec[l];
+        d->in = l == 0 ? sp->Z : hs[n.nh - l];
+        d->out = l == n.nh ? sp->D : hs[n.nh - l - 1];
+        d->W = off; off += (int64_t)d->in * d->out;
+        d->b = off; off += d->out;
+    }
+    for (int l = 0; l < n.nh; ++l) {
+        d3po_dense* e = &n.enc[l];
+        e->in = l == 0 ? sp->D : hs[l - 1];
+        e->out = hs[l];
+        e->W = off; off += (int64_t)e->in * e->out;
+        e->b = off; off += e->out;
+    }
+    n.Wl = off; off += (int64_t)n.HE * sp->Z;
+    n.bl = off; off += sp->Z;
+    n.Ws = off; off += (int64_t)n.HE * sp->Z;
+    n.bs = off; off += sp->Z;
+    n.P = off;
+    return n;
+}
 
 D3P_API int64_t d3po_vae_num_params(const d3po_vae_spec* sp)
 {
-    const int64_t D = sp->D, H = sp->H, Z = sp->Z;
-    return Z * H + H + H * D + D + D * H + H + 2 * (H * Z + Z);
+    return d3po_vae_layers(sp).P;
 }
+
+static double d3po_softplus(double t) { return fmax(t, 0.0) + log1p(exp(-fabs(t))); }
+static double d3po_sigmoid(double t) { return 1.0 / (1.0 + exp(-t)); }
 
 D3P_API void d3po_vae_step_sums(const d3po_vae_spec* sp, const float* params, const float* X, const float* mask, int B,
                                 const float* eps /* B x Z */, float clip, float* sums, float* norms, float* px_loss)
 {
-    const int D = sp->D, H = sp->H, Z = sp->Z;
-    const int64_t P = d3po_vae_num_params(sp);
-    const float* V1 = params;
-    const float* c1 = V1 + (int64_t)Z * H;
-    const float* V2 = c1 + H;
-    const float* c2 = V2 + (int64_t)H * D;
-    const float* W1 = c2 + D;
-    const float* b1 = W1 + (int64_t)D * H;
-    const float* Wl = b1 + H;
-    const float* bl = Wl + (int64_t)H * Z;
-    const float* Ws = bl + Z;
-    const float* bs = Ws + (int64_t)H * Z;
+    const int D = sp->D, Z = sp->Z;
+    const d3po_vae_net N = d3po_vae_layers(sp);
+    const int nh = N.nh, HE = N.HE;
+    const int64_t P = N.P;
+    int wmax = D > Z ? D : Z;
+    if (sp->H > wmax) wmax = sp->H;
+    if (sp->H2 > wmax) wmax = sp->H2;
     double* acc = (double*)calloc((size_t)P + 2, sizeof(double));
     const double sc = (double)sp->inv_obs * sp->scale;
 #pragma omp parallel
     {
         double* g = (double*)malloc(sizeof(double) * (size_t)P);
-        double *pre1 = (double*)malloc(sizeof(double) * (size_t)(4 * H + 6 * Z + 2 * D)), *h1 = pre1 + H, *pre2 = h1 + H, *h2 = pre2 + H;
-        double *zl = h2 + H, *u = zl + Z, *z = u + Z, *dz = z + Z, *du = dz + Z, *sd = du + Z, *a = sd + Z, *da = a + D;
+        /* per layer: pre-activation, activation, delta (encoder and decoder), plus the latent vectors and the logits */
+        double* buf = (double*)malloc(sizeof(double) * (size_t)(12 * wmax + 6 * Z + 2 * D));
+        double *pre_e[2], *h_e[2], *d_e[2], *pre_d[2], *h_d[2], *d_d[2];
+        {
+            double* q = buf;
+            for (int l = 0; l < 2; ++l) {
+                pre_e[l] = q; q += wmax; h_e[l] = q; q += wmax; d_e[l] = q; q += wmax;
+                pre_d[l] = q; q += wmax; h_d[l] = q; q += wmax; d_d[l] = q; q += wmax;
+            }
+        }
+        double *zl = buf + 12 * wmax, *u = zl + Z, *z = u + Z, *dz = z + Z, *du = dz + Z, *sd = du + Z, *a = sd + Z, *da = a + D;
+        double* xin = (double*)malloc(sizeof(double) * (size_t)D);
 #pragma omp for schedule(dynamic)
         for (int i = 0; i < B; ++i) {
             const float m = mask ? mask[i] : 1.0f;
             const float* x = X + (size_t)i * D;
             const float* e = eps + (size_t)i * Z;
-            for (int j = 0; j < H; ++j) {
-                double t = b1[j];
-                for (int k = 0; k < D; ++k) t += (double)x[k] * W1[(size_t)k * H + j];
-                pre1[j] = t;
-                h1[j] = fmax(t, 0.0) + log1p(exp(-fabs(t)));
+            for (int k = 0; k < D; ++k) xin[k] = (double)x[k];
+            /* ---- encoder */
+            {
+                const double* in = xin;
+                for (int l = 0; l < nh; ++l) {
+                    const d3po_dense* L = &N.enc[l];
+                    const float *W = params + L->W, *bv = params + L->b;
+                    for (int j = 0; j < L->out; ++j) {
+                        double t = bv[j];
+                        for (int k = 0; k < L->in; ++k) t += in[k] * W[(size_t)k * L->out + j];
+                        pre_e[l][j] = t;
+                        h_e[l][j] = d3po_softplus(t);
+                    }
+                    in = h_e[l];
+                }
             }
+            const double* hlast = h_e[nh - 1];
+            const float *Wl = params + N.Wl, *bl = params + N.bl, *Ws = params + N.Ws, *bs = params + N.bs;
             double lq = 0.0, lp = 0.0;
             for (int j = 0; j < Z; ++j) {
                 double tl = bl[j], tu = bs[j];
-                for (int k = 0; k < H; ++k) { tl += h1[k] * Wl[(size_t)k * Z + j]; tu += h1[k] * Ws[(size_t)k * Z + j]; }
+                for (int k = 0; k < HE; ++k) { tl += hlast[k] * Wl[(size_t)k * Z + j]; tu += hlast[k] * Ws[(size_t)k * Z + j]; }
                 zl[j] = tl; u[j] = tu; sd[j] = exp(tu);
                 z[j] = tl + sd[j] * (double)e[j];
                 lq += -0.5 * (double)e[j] * e[j] - tu - (double)HALF_LOG_2PI;
                 lp += -0.5 * z[j] * z[j] - (double)HALF_LOG_2PI;
             }
-            for (int j = 0; j < H; ++j) {
-                double t = c1[j];
-                for (int k = 0; k < Z; ++k) t += z[k] * V1[(size_t)k * H + j];
-                pre2[j] = t;
-                h2[j] = fmax(t, 0.0) + log1p(exp(-fabs(t)));
+            /* ---- decoder */
+            {
+                const double* in = z;
+                for (int l = 0; l < nh; ++l) {
+                    const d3po_dense* L = &N.dec[l];
+                    const float *W = params + L->W, *bv = params + L->b;
+                    for (int j = 0; j < L->out; ++j) {
+                        double t = bv[j];
+                        for (int k = 0; k < L->in; ++k) t += in[k] * W[(size_t)k * L->out + j];
+                        pre_d[l][j] = t;
+                        h_d[l][j] = d3po_softplus(t);
+                    }
+                    in = h_d[l];
+                }
             }
             double ll = 0.0;
-            for (int j = 0; j < D; ++j) {
-                double t = c2[j];
-                for (int k = 0; k < H; ++k) t += h2[k] * V2[(size_t)k * D + j];
-                a[j] = t;
-                ll += (double)x[j] * t - (fmax(t, 0.0) + log1p(exp(-fabs(t))));
-                da[j] = sc * (1.0 / (1.0 + exp(-t)) - (double)x[j]);   /* d(-ll)/da */
+            {
+                const d3po_dense* L = &N.dec[nh];
+                const float *W = params + L->W, *bv = params + L->b;
+                const double* in = h_d[nh - 1];
+                for (int j = 0; j < D; ++j) {
+                    double t = bv[j];
+                    for (int k = 0; k < L->in; ++k) t += in[k] * W[(size_t)k * D + j];
+                    a[j] = t;
+                    ll += (double)x[j] * t - d3po_softplus(t);
+                    da[j] = sc * (d3po_sigmoid(t) - (double)x[j]);   /* d(-ll)/da */
+                }
             }
-            const double L = sc * (lq - lp - ll);
-            /* ---- backward, explicit per-example gradient */
-            double* gV1 = g; double* gc1 = gV1 + (int64_t)Z * H; double* gV2 = gc1 + H; double* gc2 = gV2 + (int64_t)H * D;
-            double* gW1 = gc2 + D; double* gb1 = gW1 + (int64_t)D * H; double* gWl = gb1 + H; double* gbl = gWl + (int64_t)H * Z;
-            double* gWs = gbl + Z; double* gbs = gWs + (int64_t)H * Z;
-            for (int k = 0; k < H; ++k) for (int j = 0; j < D; ++j) gV2[(size_t)k * D + j] = h2[k] * da[j];
-            for (int j = 0; j < D; ++j) gc2[j] = da[j];
-            for (int k = 0; k < H; ++k) {
-                double t = 0.0;
-                for (int j = 0; j < D; ++j) t += da[j] * V2[(size_t)k * D + j];
-                gc1[k] = t / (1.0 + exp(-pre2[k]));     /* softplus' = sigmoid */
+            const double L_i = sc * (lq - lp - ll);
+            /* ---- backward, explicit per-example gradient: for a dense layer with input v and output delta d,
+             * grad W = v d^T, grad b = d, delta of the input's pre-activation = (W d) . softplus' */
+            {
+                const double* delta = da;
+                for (int l = nh; l >= 0; --l) {
+                    const d3po_dense* L = &N.dec[l];
+                    const float* W = params + L->W;
+                    const double* in = l == 0 ? z : h_d[l - 1];
+                    for (int k = 0; k < L->in; ++k) for (int j = 0; j < L->out; ++j) g[L->W + (int64_t)k * L->out + j] = in[k] * delta[j];
+                    for (int j = 0; j < L->out; ++j) g[L->b + j] = delta[j];
+                    if (l > 0) {
+                        for (int k = 0; k < L->in; ++k) {
+                            double t = 0.0;
+                            for (int j = 0; j < L->out; ++j) t += delta[j] * W[(size_t)k * L->out + j];
+                            d_d[l - 1][k] = t * d3po_sigmoid(pre_d[l - 1][k]);     /* softplus' = sigmoid */
+                        }
+                        delta = d_d[l - 1];
+                    } else {
+                        for (int k = 0; k < Z; ++k) {
+                            double t = sc * z[k];                    /* from -log p(z) = z^2 / 2 */
+                            for (int j = 0; j < L->out; ++j) t += delta[j] * W[(size_t)k * L->out + j];
+                            dz[k] = t;
+                            du[k] = t * sd[k] * (double)e[k] - sc;   /* z = zl + exp(u) eps;  log q contributes -u */
+                        }
+                    }
+                }
             }
-            for (int k = 0; k < Z; ++k) for (int j = 0; j < H; ++j) gV1[(size_t)k * H + j] = z[k] * gc1[j];
-            for (int k = 0; k < Z; ++k) {
-                double t = sc * z[k];                    /* from -log p(z) = z^2 / 2 */
-                for (int j = 0; j < H; ++j) t += gc1[j] * V1[(size_t)k * H + j];
-                dz[k] = t;
-                du[k] = t * sd[k] * (double)e[k] - sc;   /* z = zl + exp(u) eps;  log q contributes -u */
+            for (int k = 0; k < HE; ++k) for (int j = 0; j < Z; ++j) {
+                g[N.Wl + (int64_t)k * Z + j] = hlast[k] * dz[j];
+                g[N.Ws + (int64_t)k * Z + j] = hlast[k] * du[j];
             }
-            for (int k = 0; k < H; ++k) for (int j = 0; j < Z; ++j) {
-                gWl[(size_t)k * Z + j] = h1[k] * dz[j];
-                gWs[(size_t)k * Z + j] = h1[k] * du[j];
-            }
-            for (int j = 0; j < Z; ++j) { gbl[j] = dz[j]; gbs[j] = du[j]; }
-            for (int k = 0; k < H; ++k) {
+            for (int j = 0; j < Z; ++j) { g[N.bl + j] = dz[j]; g[N.bs + j] = du[j]; }
+            for (int k = 0; k < HE; ++k) {
                 double t = 0.0;
                 for (int j = 0; j < Z; ++j) t += dz[j] * Wl[(size_t)k * Z + j] + du[j] * Ws[(size_t)k * Z + j];
-                gb1[k] = t / (1.0 + exp(-pre1[k]));
+                d_e[nh - 1][k] = t * d3po_sigmoid(pre_e[nh - 1][k]);
             }
-            for (int k = 0; k < D; ++k) for (int j = 0; j < H; ++j) gW1[(size_t)k * H + j] = (double)x[k] * gb1[j];
+            for (int l = nh - 1; l >= 0; --l) {
+                const d3po_dense* L = &N.enc[l];
+                const float* W = params + L->W;
+                const double* in = l == 0 ? xin : h_e[l - 1];
+                const double* delta = d_e[l];
+                for (int k = 0; k < L->in; ++k) for (int j = 0; j < L->out; ++j) g[L->W + (int64_t)k * L->out + j] = in[k] * delta[j];
+                for (int j = 0; j < L->out; ++j) g[L->b + j] = delta[j];
+                if (l > 0)
+                    for (int k = 0; k < L->in; ++k) {
+                        double t = 0.0;
+                        for (int j = 0; j < L->out; ++j) t += delta[j] * W[(size_t)k * L->out + j];
+                        d_e[l - 1][k] = t * d3po_sigmoid(pre_e[l - 1][k]);
+                    }
+            }
             double ss = 0.0;
             for (int64_t j = 0; j < P; ++j) ss += g[j] * g[j];
             const double nrm = sqrt(ss);
             if (norms) norms[i] = (float)(nrm * m);
-            if (px_loss) px_loss[i] = (float)(L * m);
+            if (px_loss) px_loss[i] = (float)(L_i * m);
             if (m != 0.0f) {
                 const double cf = 1.0 / fmax(1.0, nrm / clip);
 #pragma omp critical
                 {
                     for (int64_t j = 0; j < P; ++j) acc[j] += cf * g[j];
-                    acc[P] += L;
+                    acc[P] += L_i;
                     acc[P + 1] += 1.0;
                 }
             }
         }
-        free(g); free(pre1);
+        free(g); free(buf); free(xin);
     }
     for (int64_t j = 0; j < P + 2; ++j) sums[j] = (float)acc[j];
     free(acc);

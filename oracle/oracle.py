@@ -37,7 +37,8 @@ class GmmSpec(C.Structure):
 
 
 class VaeSpec(C.Structure):
-    _fields_ = [("D", C.c_int32), ("H", C.c_int32), ("Z", C.c_int32), ("scale", C.c_float), ("inv_obs", C.c_float)]
+    _fields_ = [("D", C.c_int32), ("H", C.c_int32), ("Z", C.c_int32), ("scale", C.c_float), ("inv_obs", C.c_float),
+                ("H2", C.c_int32)]
 
 
 class Hyper(C.Structure):
@@ -482,8 +483,22 @@ def gmm_evaluate(spec, params, Xb, jax_key):
 
 
 # ------------------------------------------------------------------ VAE step (config 5)
-def vae_spec(D, H, Z, scale=1.0, obs_scale=1.0):
-    return VaeSpec(D, H, Z, scale, 1.0 / obs_scale)
+def vae_spec(D, H, Z, scale=1.0, obs_scale=1.0, H2=0):
+    """H2 > 0: a second hidden layer on each side (BASELINE config 5's 784 -> [400, 200] -> 50 variant)."""
+    return VaeSpec(D, H, Z, scale, 1.0 / obs_scale, H2)
+
+
+def vae_leaf_sizes(D, H, Z, H2=0):
+    """Sizes of the parameter leaves in tree_flatten order (decoder layers, encoder layers, Wl, bl, Ws, bs)."""
+    hs = [H] + ([H2] if H2 else [])
+    dims = [Z] + hs[::-1] + [D]
+    sizes = []
+    for i, o in zip(dims[:-1], dims[1:]):          # decoder z -> .. -> D
+        sizes += [i * o, o]
+    dims = [D] + hs
+    for i, o in zip(dims[:-1], dims[1:]):          # encoder x -> .. -> last hidden
+        sizes += [i * o, o]
+    return sizes + [hs[-1] * Z, Z, hs[-1] * Z, Z]
 
 
 def vae_num_params(spec):

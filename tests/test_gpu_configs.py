@@ -201,17 +201,20 @@ def test_config2_gmm_k16_d64_batch_8192(gpu, O):
 
 
 # ------------------------------------------------------------------------------------------------ configs[4]
-def test_config4_vae_784_400_50_batch_4096(gpu, O):
-    """BASELINE configs[4] (the reference's shape, examples/vae.py:80-103) at B = 4096: norms and losses of a 64-example
+@pytest.mark.parametrize("H2", [0, 200])
+def test_config4_vae_784_400_50_batch_4096(gpu, O, H2):
+    """BASELINE configs[4] at B = 4096, in the reference's shape (one hidden layer of 400, examples/vae.py:80-103; H2 = 0) and
+    in the literal 784 -> [400, 200] -> 50 shape BASELINE.json names (H2 = 200, P = 819 284): norms and losses of a 64-example
     slice against the oracle's explicit per-example gradients; the clipped sums of that slice (selected by the mask, the
     other 4032 rows still go through every GEMM) against the oracle's; linearity of the sums over a split of the batch;
     ||clipped mean|| <= C; bitwise reproducible."""
     import d3p_amd._lib as lib
     from tests.test_gpu_vae import vae_problem
     B, D, H, Z = 4096, 784, 400, 50
-    spec, P, params, X, eps = vae_problem(B, D, H, Z, 21, 0.03)
+    spec, P, params, X, eps = vae_problem(B, D, H, Z, 21, 0.03, H2)
+    assert P == (819284 if H2 else 688884)
     L = lib.load()
-    model = lib.VaeModel(D, H, Z, 1.0, 1.0)
+    model = lib.VaeModel(D, H, Z, 1.0, 1.0, H2)
     ws = torch.empty(int(L.d3p_dpvi_vae_workspace(C.byref(model), B)), dtype=torch.uint8, device="cuda")
     pt, Xt, et = torch.tensor(params).cuda(), torch.tensor(X).cuda(), torch.tensor(eps).cuda()
 

@@ -85,10 +85,10 @@ def test_mfma_gemm_k_not_a_multiple_of_four_with_padded_rows(lib):
     assert float((out.double() - ref).abs().max()) <= 2e-5 * scale
 
 
-def vae_problem(B, D, H, Z, seed, pscale=0.2):
+def vae_problem(B, D, H, Z, seed, pscale=0.2, H2=0):
     import oracle.oracle as O
     r = np.random.default_rng(seed)
-    spec = O.vae_spec(D, H, Z, scale=1.0, obs_scale=1.0)
+    spec = O.vae_spec(D, H, Z, scale=1.0, obs_scale=1.0, H2=H2)
     P = O.vae_num_params(spec)
     params = (r.normal(size=P) * pscale).astype(np.float32)
     X = (r.random((B, D)) < 0.3).astype(np.float32)
@@ -96,18 +96,20 @@ def vae_problem(B, D, H, Z, seed, pscale=0.2):
     return spec, P, params, X, eps
 
 
-@pytest.mark.parametrize("B,D,H,Z,pscale", [(5, 12, 7, 3, 0.3), (70, 100, 33, 9, 0.2), (48, 784, 400, 50, 0.03)])
+# (H2 > 0: the two-hidden-layer variant of BASELINE config 5, 784 -> [400, 200] -> 50; the reference has one hidden layer)
+@pytest.mark.parametrize("B,D,H,Z,pscale,H2", [(5, 12, 7, 3, 0.3, 0), (70, 100, 33, 9, 0.2, 0), (48, 784, 400, 50, 0.03, 0),
+                                               (5, 12, 7, 3, 0.3, 5), (70, 100, 33, 9, 0.2, 21), (48, 784, 400, 50, 0.03, 200)])
 @pytest.mark.parametrize("masked", [False, True])
-def test_step_sums_vs_explicit_per_example_gradients(lib, O, B, D, H, Z, pscale, masked):
-    spec, P, params, X, eps = vae_problem(B, D, H, Z, B + D, pscale)
+def test_step_sums_vs_explicit_per_example_gradients(lib, O, B, D, H, Z, pscale, H2, masked):
+    spec, P, params, X, eps = vae_problem(B, D, H, Z, B + D, pscale, H2)
     mask = (np.random.default_rng(3).random(B) < 0.7) if masked else None
     # a clip threshold in the middle of the norm distribution, so that some rows are clipped and some are not
     _, norms0, _ = O.vae_step_sums(spec, params, X, eps, 1e30, None)
     clip = float(np.median(norms0))
     esums, enorms, eloss = O.vae_step_sums(spec, params, X, eps, clip, None if mask is None else mask.astype(np.float32))
     L = lib.load()
-    model = lib.VaeModel(D, H, Z, 1.0, 1.0)
-    assert L.d3p_vae_num_params(C.byref(model)) == P
+    model = lib.VaeModel(D, H, Z, 1.0, 1.0, H2)
+    assert L.d3p_vae_num_params(C.byref(model)) == P == sum(O.vae_leaf_sizes(D, H, Z, H2))
     ws = torch.empty(int(L.d3p_dpvi_vae_workspace(C.byref(model), B)), dtype=torch.uint8, device="cuda")
     sums = torch.empty(P + 2, device="cuda")
     norms = torch.empty(B, device="cuda")
@@ -125,23 +127,25 @@ def test_step_sums_vs_explicit_per_example_gradients(lib, O, B, D, H, Z, pscale,
     assert (enorms > clip).any() and (enorms[enorms > 0] < clip).any()
 
 
-def make_svi(Z, H, N, C=10.0, sigma=1.0, lr=1e-3):
+def make_svi(Z, H, N, C=10.0, sigma=1.0, lr=1e-3, H2=0):
     from d3p_amd.models import Adam, Trace_ELBO, VAEGuide, VAEModel
     from d3p_amd.svi import DPSVI
     model = VAEModel(scale=1.0 / N)                       # handlers.scale(model, 1 / num_samples), vae.py:194-195
-    return DPSVI(model, VAEGuide(model), Adam(lr), Trace_ELBO(), C, sigma, num_obs_total=N, z_dim=Z, hidden_dim=H)
+    return DPSVI(model, VAEGuide(model), Adam(lr), Trace_ELBO(), C, sigma, num_obs_total=N, z_dim=Z,
+                 hidden_dim=(H, H2) if H2 else H)
 
 
-@pytest.mark.parametrize("B,D,H,Z,masked", [(6, 12, 7, 3, False), (40, 784, 400, 50, True)])
-def test_update_vs_oracle_stage_composition(gpu, O, B, D, H, Z, masked):
+@pytest.mark.parametrize("B,D,H,Z,masked,H2", [(6, 12, 7, 3, False, 0), (40, 784, 400, 50, True, 0), (6, 12, 7, 3, True, 5),
+                                               (40, 784, 400, 50, False, 200)])
+def test_update_vs_oracle_stage_composition(gpu, O, B, D, H, Z, masked, H2):
     """DPSVI.update for the VAE: split(key, 3); per-example eps from the gradient key (svi.py:289-290); clipped sums;
     one perturbation key per parameter leaf in tree_flatten order (svi.py:487-491); numpyro Adam."""
     import d3p_amd.random as rng
     from d3p_amd.svi import DPSVIState
     N = 60000
-    spec, P, params, X, _ = vae_problem(B, D, H, Z, 11, 0.03 if D > 100 else 0.3)
+    spec, P, params, X, _ = vae_problem(B, D, H, Z, 11, 0.03 if D > 100 else 0.3, H2)
     mask = (np.random.default_rng(4).random(B) < 0.7) if masked else None
-    svi = make_svi(Z, H, N, C=3.0, sigma=0.8, lr=1e-2)
+    svi = make_svi(Z, H, N, C=3.0, sigma=0.8, lr=1e-2, H2=H2)
     st = DPSVIState(svi.optim.init(torch.tensor(params).cuda()), rng.PRNGKey(77), 1.0)
     Xt = torch.tensor(X.reshape(B, -1)).cuda()
     gout = torch.empty(P, device="cuda")
@@ -152,7 +156,8 @@ def test_update_vs_oracle_stage_composition(gpu, O, B, D, H, Z, masked):
     sums, _, _ = O.vae_step_sums(spec, params, X, eps, 3.0, None if mask is None else mask.astype(np.float32))
     n = sums[P + 1]
     f = B / n
-    sizes = [Z * H, H, H * D, D, D * H, H, H * Z, Z, H * Z, Z]
+    sizes = O.vae_leaf_sizes(D, H, Z, H2)                  # 10 leaves, or 14 with the second hidden layer
+    assert sizes == [Z * H, H, H * D, D, D * H, H, H * Z, Z, H * Z, Z] or H2
     g = O.perturb(ks[2], sums[:P] / B, sizes, 0.8, 3.0, n, 1.0, f)
     x, m, v = O.adam(params, np.zeros(P), np.zeros(P), g, 0, lr=1e-2)
     eloss = sums[P] / B * f
@@ -161,8 +166,14 @@ def test_update_vs_oracle_stage_composition(gpu, O, B, D, H, Z, masked):
     np.testing.assert_allclose(np_(new_st.optim_state[1]), x, rtol=1e-4, atol=2e-5)
     assert np.array_equal(np_(new_st.rng_key), ks[0]) and int(new_st.optim_state[0]) == 1
     tree = svi.get_params(new_st)
-    assert tuple(tree["decoder$params"][0][0].shape) == (Z, H) and tuple(tree["encoder$params"][3][1][0][0].shape) == (H, Z)
+    HE = H2 if H2 else H
+    assert tuple(tree["decoder$params"][0][0].shape) == (Z, HE) and tuple(tree["encoder$params"][-1][1][0][0].shape) == (HE, Z)
     assert tree["decoder$params"][1] == () and tuple(tree["encoder$params"][0][0].shape) == (D, H)
+    if H2:
+        assert tuple(tree["decoder$params"][2][0].shape) == (H2, H) and tuple(tree["decoder$params"][4][0].shape) == (H, D)
+        assert tuple(tree["encoder$params"][2][0].shape) == (H, H2) and len(tree["decoder$params"]) == 6
+    else:
+        assert tuple(tree["encoder$params"][3][1][0][0].shape) == (H, Z)
 
 
 def test_update_leaves_the_input_state_alone(gpu):
@@ -210,16 +221,16 @@ def test_training_reduces_the_loss_on_structured_binary_images(gpu):
     assert np.mean(losses[-20:]) < 0.6 * np.mean(losses[:20])
 
 
-@pytest.mark.parametrize("B,D,H,Z", [(6, 12, 7, 3), (64, 784, 400, 50)])
-def test_evaluate_vs_oracle(gpu, O, B, D, H, Z):
+@pytest.mark.parametrize("B,D,H,Z,H2", [(6, 12, 7, 3, 0), (64, 784, 400, 50, 0), (6, 12, 7, 3, 4), (64, 784, 400, 50, 200)])
+def test_evaluate_vs_oracle(gpu, O, B, D, H, Z, H2):
     import d3p_amd.random as rng
     from d3p_amd.svi import DPSVIState
     N = 60000
-    _, P, params, X, _ = vae_problem(B, D, H, Z, 5, 0.03 if D > 100 else 0.3)
-    svi = make_svi(Z, H, N)
+    _, P, params, X, _ = vae_problem(B, D, H, Z, 5, 0.03 if D > 100 else 0.3, H2)
+    svi = make_svi(Z, H, N, H2=H2)
     st = DPSVIState(svi.optim.init(torch.tensor(params).cuda()), rng.PRNGKey(31), 1.0)
     got = float(svi.evaluate(st, torch.tensor(X).cuda()))
-    spec = O.vae_spec(D, H, Z, scale=1.0 / B, obs_scale=1.0)          # (1 / N) x (N / B)
+    spec = O.vae_spec(D, H, Z, scale=1.0 / B, obs_scale=1.0, H2=H2)   # (1 / N) x (N / B)
     jax_key = O.convert_to_jax_rng_key(O.split(O.PRNGKey(31), 1)[0])
     exp = O.vae_evaluate(spec, params, X, jax_key)
     assert abs(got - exp) <= 3e-5 * abs(exp)

@@ -446,3 +446,72 @@ def test_randint_integer_dtypes_like_the_reference_tests(O):
         assert np.all(O.randint(O.PRNGKey(8025111), (100,), -4, -3, dt) == -4)
     with pytest.raises(TypeError):
         O.randint(O.PRNGKey(1), (3,), 0, 5, np.float32)
+
+
+# ---- the oracle's VAE restatement (one and two hidden layers) against torch autograd on an ELBO written with torch.distributions
+@pytest.mark.parametrize("H2", [0, 5])
+def test_vae_per_example_gradients_vs_torch_autograd(O, H2):
+    """oracle d3po_vae_step_sums materialises every per-example gradient by hand-written backpropagation; here the same
+    per-example loss  inv_obs * scale * (log q(z|x) - log p(z) - log p(x|z))  is written with torch.distributions on
+    float64 tensors (stax.Dense layers, softplus, Normal / Bernoulli(logits), examples/vae.py:65-153) and differentiated
+    by autograd.  Norms, losses and the clipped sums must agree to float32 rounding -- for the reference's one-hidden-layer
+    network and for the 784 -> [400, 200] -> 50 style variant (H2 > 0), which has no counterpart in the reference."""
+    import torch
+    B, D, H, Z = 7, 11, 6, 3
+    r = np.random.default_rng(5)
+    spec = O.vae_spec(D, H, Z, scale=0.7, obs_scale=2.0, H2=H2)
+    sizes = O.vae_leaf_sizes(D, H, Z, H2)
+    P = O.vae_num_params(spec)
+    assert P == sum(sizes) and len(sizes) == (14 if H2 else 10)
+    params = (r.normal(size=P) * 0.4).astype(np.float32)
+    X = (r.random((B, D)) < 0.4).astype(np.float32)
+    eps = r.normal(size=(B, Z)).astype(np.float32)
+    _, norms0, _ = O.vae_step_sums(spec, params, X, eps, 1e30)
+    clip = float(np.median(norms0))
+    sums, norms, px_loss = O.vae_step_sums(spec, params, X, eps, clip)
+
+    hs = [H] + ([H2] if H2 else [])
+    dec_dims, enc_dims = [Z] + hs[::-1] + [D], [D] + hs
+    shapes = []
+    for i, o in zip(dec_dims[:-1], dec_dims[1:]):
+        shapes += [(i, o), (o,)]
+    for i, o in zip(enc_dims[:-1], enc_dims[1:]):
+        shapes += [(i, o), (o,)]
+    shapes += [(hs[-1], Z), (Z,), (hs[-1], Z), (Z,)]
+    flat = torch.tensor(params, dtype=torch.float64, requires_grad=True)
+
+    def loss_of(i):
+        leaves, pos = [], 0
+        for shp in shapes:
+            n = int(np.prod(shp))
+            leaves.append(flat[pos:pos + n].reshape(shp))
+            pos += n
+        n_dec = len(dec_dims) - 1
+        dec, enc, heads = leaves[:2 * n_dec], leaves[2 * n_dec:-4], leaves[-4:]
+        x = torch.tensor(X[i], dtype=torch.float64)
+        h = x
+        for k in range(0, len(enc), 2):
+            h = torch.nn.functional.softplus(h @ enc[k] + enc[k + 1])
+        z_loc, z_std = h @ heads[0] + heads[1], torch.exp(h @ heads[2] + heads[3])
+        z = z_loc + z_std * torch.tensor(eps[i], dtype=torch.float64)
+        log_q = torch.distributions.Normal(z_loc, z_std).log_prob(z).sum()
+        log_p = torch.distributions.Normal(0.0, 1.0).log_prob(z).sum()
+        h = z
+        for k in range(0, len(dec) - 2, 2):
+            h = torch.nn.functional.softplus(h @ dec[k] + dec[k + 1])
+        logits = h @ dec[-2] + dec[-1]
+        log_lik = torch.distributions.Bernoulli(logits=logits).log_prob(x).sum()
+        return (1.0 / 2.0) * 0.7 * (log_q - log_p - log_lik)
+
+    acc = np.zeros(P)
+    for i in range(B):
+        li = loss_of(i)
+        (g,) = torch.autograd.grad(li, flat)
+        g = g.numpy()
+        nrm = np.linalg.norm(g)
+        assert abs(li.item() - px_loss[i]) <= 2e-6 * abs(li.item()) + 1e-6
+        assert abs(nrm - norms[i]) <= 2e-6 * nrm
+        acc += g / max(1.0, nrm / clip)
+    np.testing.assert_allclose(sums[:P], acc, rtol=2e-5, atol=2e-6 * np.abs(acc).max())
+    assert sums[P + 1] == B and abs(sums[P] - px_loss.sum()) <= 1e-5 * abs(px_loss.sum())
+    assert (norms > clip).any() and (norms < clip).any()
