@@ -1309,7 +1309,7 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
     vae_carve(model, B_local, (char*)workspace_dev, &ws);
     hipStream_t s = (hipStream_t)stream;
     const VaeNet N = vae_net(model);
-    const int nh = N.nh, n_leaves = N.n_leaves(), n_blocks = N.n_blocks();
+    const int nh = N.nh, n_blocks = N.n_blocks();
     int rc;
     if (derive_keys && (rc = vae_step_keys(s, model, state, ws, true))) return rc;
     {
@@ -1328,7 +1328,6 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
             na.blk_off[k + 1] = na.blk_off[k] + (uint32_t)((leaf_off[k + 1] - leaf_off[k] + 15) / 16);
         }
         na.elem_off[D3P_VAE_MAX_LEAVES] = (uint32_t)leaf_off[D3P_VAE_MAX_LEAVES];
-        (void)n_leaves;
         hipLaunchKernelGGL(k_vae_site_noise, dim3(cdiv(na.blk_off[D3P_VAE_MAX_LEAVES], 256)), dim3(256), 0, s, na);
     }
     VaeFinalArgs f;
