@@ -368,8 +368,8 @@ def test_vae_two_rank_gloo_reduces_to_the_single_process_sums(O):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,D,H,Z,world", [(40, 784, 400, 50, 2), (30, 12, 7, 3, 4)])
-def test_vae_virtual_ranks_on_one_gpu_match_single_rank(gpu, O, B, D, H, Z, world):
+@pytest.mark.parametrize("B,D,H,Z,world,H2", [(40, 784, 400, 50, 2, 0), (30, 12, 7, 3, 4, 0), (40, 784, 400, 50, 2, 200), (30, 12, 7, 3, 4, 5)])
+def test_vae_virtual_ranks_on_one_gpu_match_single_rank(gpu, O, B, D, H, Z, world, H2):
     """`world` virtual ranks on one device (batch positions sharded, partial sums added by hand, apply on every rank):
     replicas are bitwise identical, agree with the single-rank DPSVI.update up to the float order of the sums, and the
     partial sums of a rank equal the oracle's sums of its positions."""
@@ -379,11 +379,11 @@ def test_vae_virtual_ranks_on_one_gpu_match_single_rank(gpu, O, B, D, H, Z, worl
     from d3p_amd.svi import DPSVI, DPSVIState
     N = 60000
     r = np.random.default_rng(21)
-    spec = O.vae_spec(D, H, Z, scale=1.0, obs_scale=1.0)
+    spec = O.vae_spec(D, H, Z, scale=1.0, obs_scale=1.0, H2=H2)   # (H2 > 0: the two-hidden-layer variant, 14 parameter leaves)
     P = O.vae_num_params(spec)
     params = ((0.03 if D > 100 else 0.3) * r.normal(size=P)).astype(np.float32)
     X = (r.random((B, D)) < 0.4).astype(np.float32)
-    model = VAEModel(z_dim=Z, hidden_dim=H, scale=1.0 / N)
+    model = VAEModel(z_dim=Z, hidden_dim=(H, H2) if H2 else H, scale=1.0 / N)
     svi = DPSVI(model, VAEGuide(model), Adam(1e-2), Trace_ELBO(), 3.0, 0.8, num_obs_total=N)
     st = DPSVIState(svi.optim.init(torch.tensor(params).cuda()), rng.PRNGKey(77), 1.0)
     Xt = torch.tensor(X).cuda()
