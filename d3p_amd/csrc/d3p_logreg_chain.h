@@ -353,14 +353,10 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     const int in = g > 0 ? ((g - 1) & 1) : 0, out = g & 1;
     {
         float n = 0.f, factor = 0.f;
-        if (apply_prev) {
-            // nobody reads the next accumulator any more (the previous step's prologues are over): zero it
-            for (int i = (int)bid * (64 * W) + tid; i < R * PA; i += a.nw * 64 * W)
-                __hip_atomic_store(acc_next + i, 0ll, __ATOMIC_RELAXED, D3P_AGENT);
-        } else {  // first step of a run: nothing pending, nobody reads the next accumulator yet
-            for (int i = (int)bid * (64 * W) + tid; i < R * PA; i += a.nw * 64 * W)
-                __hip_atomic_store(acc_next + i, 0ll, __ATOMIC_RELAXED, D3P_AGENT);
-        }
+        // nobody reads the next accumulator any more (the previous step's prologues are over; at the first step of a run
+        // nobody has read it yet): zero it
+        for (int i = (int)bid * (64 * W) + tid; i < R * PA; i += a.nw * 64 * W)
+            __hip_atomic_store(acc_next + i, 0ll, __ATOMIC_RELAXED, D3P_AGENT);
         // one latent: pending update of its two columns (e: auto_loc, D + e: auto_scale) and its derived LDS entries
         // the sums of the previous step: the 4 local replicas, or (data-parallel) the ONE row the exchange workgroup left
         const long long* sums = XCHG ? a.x.xsum + (size_t)((g + 2) % 3) * PA : acc_prev;

@@ -1,0 +1,263 @@
+"""The kernels the benchmark times, DIRECTLY against the CPU oracle at their production shape.
+
+`k_logreg_chain` only exists for d = 512 (with or without the intercept column); the small-shape tests in
+test_gpu_dpsvi.py therefore exercise the generic template.  Here `DPSVI.run_steps` runs BASELINE config 2's shape
+(d = 512, B = 4096, N >= 1e5) for >= 140 steps -- i.e. across the 128-step boundary between two chained launches -- and
+every loss, the final key and the final parameters are compared with the oracle's restatement of
+`d3p/svi.py:395-434` driven by `examples/logistic_regression.py:149-160`'s loop:
+
+  (i)   plain                       k_logreg_chain<PLIST=0, ICPT=0, XCHG=0>   vs  O.logreg_run_feistel
+  (ii)  intercept                   k_logreg_chain<ICPT=1>                     vs  per-step O.logreg_update
+  (iii) Poisson batches             k_logreg_chain<PLIST=1>                    vs  per-step O.logreg_update (masked)
+  (iv)  data-parallel exchange      k_logreg_chain<XCHG=1> (world 1: exchange with itself, 140 steps; two virtual ranks on two
+                                    streams in a child process, launches of 2 steps)   vs  the single-process oracle trajectory
+  (v)   B = 32768 x 5 steps         the throughput-regime kernel                vs  O.logreg_run_feistel
+
+Tolerances (fp32 path, stated once): losses rtol 5e-5, final key bit-exact, parameters rtol 2e-4 (atol 2e-5: Adam steps of
+1e-2 on parameters that cross zero).
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOSS_RTOL, PARAM_RTOL, PARAM_ATOL = 5e-5, 2e-4, 2e-5
+THREADS = max(1, min(16, os.cpu_count() or 1))
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def _table(N, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(N, d, generator=g)
+    y = (torch.rand(N, generator=g) < 0.5).float()
+    return X, y
+
+
+def _svi(d, icpt, N, sigma=0.7, lr=1e-2):
+    from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
+    from d3p_amd.svi import DPSVI
+    model = LogisticRegression(d, prior_scale=1.0, intercept=icpt, intercept_prior_scale=2.0)
+    return DPSVI(model, AutoDiagonalNormal(model), Adam(lr), Trace_ELBO(), 1.0, sigma, N=N)
+
+
+def _state(svi, key, D, N):
+    from d3p_amd.svi import DPSVIState
+    p = torch.cat([torch.zeros(D), torch.full((D,), -2.0)]).cuda()
+    return DPSVIState(svi.optim.init(p), key, float(N))
+
+
+def _oracle_state(O, seed, D):
+    return O.LogregState(O.PRNGKey(seed), D, np.zeros(D, np.float32), np.full(D, -2.0, np.float32))
+
+
+def _compare(new_st, losses, ost, elosses, steps):
+    assert bool(torch.isfinite(losses).all())
+    np.testing.assert_allclose(np_(losses), np.asarray(elosses, np.float32), rtol=LOSS_RTOL)
+    assert np.array_equal(np_(new_st.rng_key).ravel(), ost.key)
+    assert int(new_st.optim_state[0]) == steps
+    np.testing.assert_allclose(np_(new_st.optim_state[1]), ost.params, rtol=PARAM_RTOL, atol=PARAM_ATOL)
+
+
+def _oracle_losses_feistel(O, spec, hy, ost, X, y, bkey, first, B, steps):
+    """Every step's loss from the oracle's C run loop (one call per step, so each loss is seen)."""
+    out = []
+    for t in range(steps):
+        out.append(O.logreg_run_feistel(spec, hy, ost, X, y, bkey, first + t, B, 1, threads=THREADS))
+    return out
+
+
+def test_chain_kernel_plain_vs_oracle_across_a_launch_boundary(gpu, O):
+    """(i) d = 512, B = 4096, N = 1e5, 150 steps = launches of 128 + 22 steps."""
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, d, B, steps, first = 100_000, 512, 4096, 150, 3
+    X, y = _table(N, d, 11)
+    svi = _svi(d, False, N)
+    st = _state(svi, rng.PRNGKey(3), d, N)
+    _, gb = subsample_batchify_data((X.cuda(), y.cuda()), B)
+    new_st, losses = svi.run_steps(st, gb, rng.PRNGKey(4), first, steps)
+    assert svi.last_run_status() == (False, False)
+
+    spec = O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    ost = _oracle_state(O, 3, d)
+    el = _oracle_losses_feistel(O, spec, hy, ost, X.numpy(), y.numpy(), O.PRNGKey(4), first, B, steps)
+    _compare(new_st, losses, ost, el, steps)
+
+
+def test_chain_kernel_intercept_vs_oracle_across_a_launch_boundary(gpu, O):
+    """(ii) examples/logistic_regression.py:49-66's shape: d = 512 + intercept (D = 513), B = 4096, 140 steps."""
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, d, B, steps, first = 100_000, 512, 4096, 140, 0
+    X, y = _table(N, d, 12)
+    svi = _svi(d, True, N)
+    st = _state(svi, rng.PRNGKey(5), d + 1, N)
+    _, gb = subsample_batchify_data((X.cuda(), y.cuda()), B)
+    new_st, losses = svi.run_steps(st, gb, rng.PRNGKey(6), first, steps)
+    assert svi.last_run_status() == (False, False)
+
+    Xn, yn = X.numpy(), y.numpy()
+    spec = O.logreg_spec(d, True, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    ost = _oracle_state(O, 5, d + 1)
+    el = []
+    for t in range(steps):
+        idx = O.feistel_sample(O.fold_in(O.PRNGKey(6), first + t), N, B)
+        el.append(O.logreg_update(spec, hy, ost, Xn[idx], yn[idx])[0])
+    _compare(new_st, losses, ost, el, steps)
+
+
+def test_chain_kernel_poisson_batches_vs_oracle_across_a_launch_boundary(gpu, O):
+    """(iii) Poisson batches (q = 4096 / N, max_batch_size = the 0.99 quantile; d3p/minibatch.py:42-133) through the dense
+    position lists of the PLIST instantiation, 140 steps."""
+    import scipy.stats
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import poisson_batchify_data
+    N, d, steps, first = 100_000, 512, 140, 1
+    q = 4096 / N
+    maxB = int(scipy.stats.poisson(N * q).ppf(0.99))
+    X, y = _table(N, d, 13)
+    svi = _svi(d, False, N)
+    st = _state(svi, rng.PRNGKey(7), d, N)
+    _, gb = poisson_batchify_data((X.cuda(), y.cuda()), q, 0.99)
+    new_st, losses = svi.run_steps(st, gb, rng.PRNGKey(8), first, steps)
+    assert svi.last_run_status() == (False, False)
+
+    Xn, yn = X.numpy(), y.numpy()
+    spec = O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    ost = _oracle_state(O, 7, d)
+    el, counts = [], []
+    for t in range(steps):
+        idx, nsel, nvalid = O.poisson_select(O.fold_in(O.PRNGKey(8), first + t), np.float32(q), N, maxB)
+        counts.append(nvalid)
+        mask = (np.arange(maxB) < nvalid).astype(np.float32)
+        el.append(O.logreg_update(spec, hy, ost, Xn[idx], yn[idx], mask)[0])
+    assert min(counts) < maxB            # the masks are not all-true: the lists really are ragged
+    _compare(new_st, losses, ost, el, steps)
+
+
+def test_chain_kernel_exchange_on_one_rank_vs_oracle_across_a_launch_boundary(gpu, O):
+    """(iv, first half) the XCHG instantiation (two exchange workgroups per step inside the chained launch) with a world of one
+    rank -- the exchange is with the rank's own inbox, every protocol step runs -- 140 steps at B = 4096."""
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    N, d, B, steps, first = 100_000, 512, 4096, 140, 2
+    X, y = _table(N, d, 14)
+    svi = _svi(d, False, N)
+    st = _state(svi, rng.PRNGKey(9), d, N)
+    eng = ddist.FusedHipEngine(svi, X.cuda(), y.cuda(), N, 0, N, L.D3P_BATCH_FEISTEL, B)
+    comm = ddist.XchgComm(2 * d + 4)
+    try:
+        new_st, losses = ddist.run_steps_native(eng, st, rng.PRNGKey(10), first, steps, comm=comm)
+        torch.cuda.synchronize()
+        code, _ = ddist.native_run_status(eng)
+    finally:
+        comm.close()
+    assert code == 0, L.describe_abort(code)
+
+    spec = O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    ost = _oracle_state(O, 9, d)
+    el = _oracle_losses_feistel(O, spec, hy, ost, X.numpy(), y.numpy(), O.PRNGKey(10), first, B, steps)
+    _compare(new_st, losses, ost, el, steps)
+
+
+_TWO_RANK_CODE = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import d3p_amd._lib as L
+import d3p_amd.random as rng
+from d3p_amd import dist as ddist
+from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
+from d3p_amd.svi import DPSVI, DPSVIState
+N, d, B, steps, first, world = 100_000, 512, 4096, 12, 2, 2
+g = torch.Generator().manual_seed(15)
+X = torch.randn(N, d, generator=g).cuda(); y = (torch.rand(N, generator=g) < 0.5).float().cuda()
+model = LogisticRegression(d)
+svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-2), Trace_ELBO(), 1.0, 0.7, N=N)
+st0 = DPSVIState(svi.optim.init(torch.cat([torch.zeros(d), torch.full((d,), -2.0)]).cuda()), rng.PRNGKey(21), float(N))
+comms = ddist.XchgComm.local_group(world, 2 * d + 4)
+streams = [torch.cuda.Stream() for _ in range(world)]
+engines, results = [], []
+for r in range(world):
+    lo, hi = ddist.shard_rows(N, r, world)
+    engines.append(ddist.FusedHipEngine(svi, X[lo:hi], y[lo:hi], N, lo, hi, L.D3P_BATCH_FEISTEL, B))
+torch.cuda.synchronize()
+# 6 launches of 2 steps per rank, every one enqueued without a host synchronisation: call k of a rank continues from the state
+# call k - 1 of the same rank returned (same stream => ordered); the ranks only meet inside the exchange
+states = [st0] * world
+losses = [[] for _ in range(world)]
+for k in range(steps // 2):
+    for r in range(world):
+        with torch.cuda.stream(streams[r]):
+            states[r], l = ddist.run_steps_native(engines[r], states[r], rng.PRNGKey(22), first + 2 * k, 2, comm=comms[r])
+            losses[r].append(l)
+torch.cuda.synchronize()
+results = [(states[r], torch.cat(losses[r])) for r in range(world)]
+codes = [ddist.native_run_status(e)[0] for e in engines]
+for c in comms:
+    c.close()
+assert codes == [0] * world, [L.describe_abort(c) for c in codes]
+for st, losses in results[1:]:
+    assert torch.equal(st.optim_state[1], results[0][0].optim_state[1]) and torch.equal(losses, results[0][1])
+    assert torch.equal(st.rng_key, results[0][0].rng_key)
+st, losses = results[0]
+np.savez(sys.argv[1], losses=losses.cpu().numpy(), params=st.optim_state[1].cpu().numpy(),
+         key=st.rng_key.cpu().numpy().ravel(), step=int(st.optim_state[0]))
+''' % (ROOT,)
+
+
+def test_chain_kernel_exchange_between_two_virtual_ranks_vs_oracle(gpu, O):
+    """(iv, second half) two row-sharded ranks on two streams of ONE GPU, exchange inside the chained launch, at B = 4096
+    (about 2048 positions per rank): the ranks' launches must be co-resident on the one GPU (tests/test_dist.py explains), so
+    the child process runs 6 launches of 2 steps per rank, all enqueued without a host synchronisation -- the same kernel
+    instantiation as a production rank's 128-step launches.  Replicas bitwise identical; trajectory = the oracle's single-process one (per-example
+    noise is keyed by the GLOBAL batch position, the noise is added once after the exchange)."""
+    N, d, B, steps, first = 100_000, 512, 4096, 12, 2
+    with tempfile.NamedTemporaryFile(suffix=".npz") as f:
+        r = subprocess.run([sys.executable, "-c", _TWO_RANK_CODE, f.name], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        got = np.load(f.name)
+        losses, params, key, step = got["losses"], got["params"], got["key"], int(got["step"])
+    g = torch.Generator().manual_seed(15)
+    X = torch.randn(N, d, generator=g).numpy()
+    y = (torch.rand(N, generator=g) < 0.5).float().numpy()
+    spec = O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    ost = _oracle_state(O, 21, d)
+    el = _oracle_losses_feistel(O, spec, hy, ost, X, y, O.PRNGKey(22), first, B, steps)
+    np.testing.assert_allclose(losses, np.asarray(el, np.float32), rtol=LOSS_RTOL)
+    assert np.array_equal(key, ost.key) and step == steps
+    np.testing.assert_allclose(params, ost.params, rtol=PARAM_RTOL, atol=PARAM_ATOL)
+
+
+def test_throughput_regime_kernel_vs_oracle(gpu, O):
+    """(v) B = 32768 (the per-GPU batch of `roofline.large_batch`; BASELINE configs[3]'s global batch), d = 512, 5 steps."""
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, d, B, steps, first = 100_000, 512, 32768, 5, 0
+    X, y = _table(N, d, 16)
+    svi = _svi(d, False, N)
+    st = _state(svi, rng.PRNGKey(31), d, N)
+    _, gb = subsample_batchify_data((X.cuda(), y.cuda()), B)
+    new_st, losses = svi.run_steps(st, gb, rng.PRNGKey(32), first, steps)
+    assert svi.last_run_status() == (False, False)
+
+    spec = O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    ost = _oracle_state(O, 31, d)
+    el = _oracle_losses_feistel(O, spec, hy, ost, X.numpy(), y.numpy(), O.PRNGKey(32), first, B, steps)
+    _compare(new_st, losses, ost, el, steps)
