@@ -316,12 +316,15 @@ __device__ __forceinline__ float wave_sum(float v)
     v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
     v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
     v += dpp_mov<0x141>(v);  // row_half_mirror
-    v += dpp_mov<0x140>(v);  // row_mirror
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return (r0 + r1) + (r2 + r3);
+    v += dpp_mov<0x140>(v);  // row_mirror: every lane of a row of 16 holds the row's sum r0 .. r3
+    // across the rows with the two broadcast steps of the GFX9 DPP encoding: row 1 += lane 15 (r0), row 3 += lane 47 (r2), then
+    // rows 2, 3 += lane 31 (r0 + r1): lane 63 holds (r0 + r1) + (r2 + r3) -- the same value, bit for bit, as reading the four
+    // row sums through SGPRs and adding them (round 2: 4 v_readlane + 3 v_add), in 2 + 1 instructions.  (A masked-off row keeps
+    // its value, which `old` of __builtin_amdgcn_update_dpp cannot express for an add; the s_nop are the VALU -> DPP hazard.)
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+        : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // softplus(t) = max(t, 0) + log(1 + exp(-|t|)); exp(-|t|) is in (0, 1], so log(1 + e) via v_log_f32 has an
@@ -336,6 +339,17 @@ __device__ __forceinline__ float sigmoid_f(float t) { return __builtin_amdgcn_rc
 #define D3P_ACC_COLS(P) ((P) + 4)
 #define D3P_LOSS_HI_UNIT 134217728.0   // 2^27
 #define D3P_LOSS_LO_SCALE 16777216.0   // 2^24
+
+// round(v * sg) as a 64-bit integer for |v * sg| < 2^51: ONE fused multiply-add in double onto 1.5 * 2^52 leaves the rounded
+// (to nearest, ties to even) integer in the low mantissa bits, a 64-bit subtraction of the constant's bit pattern extracts it --
+// 1 conversion + 1 v_fma_f64 + 2 integer instructions where __double2ll_rn expands to ~15.  (One rounding instead of the two of
+// "multiply, then round": may differ from it in the last fixed-point digit, 2^-40 C; every form of the sum stays exact.)
+__device__ __forceinline__ long long fixed_point_rn(float v, double sg, bool& in_range)
+{
+    const double t = fma((double)v, sg, 6755399441055744.0);
+    in_range = fabs((double)v * sg) < 2251799813685248.0;  // 2^51 (NaN / Inf fail the comparison)
+    return (long long)(__double_as_longlong(t) - 0x4338000000000000ll);
+}
 
 // the two integer parts of a workgroup's loss partial; false when it is not finite or beyond 2^78
 __device__ __forceinline__ bool loss_split(float s, long long& hi, long long& lo)

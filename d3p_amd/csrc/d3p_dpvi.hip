@@ -1031,14 +1031,27 @@ static bool use_persistent_steps(const Ctx& c)
 
 // D3P_DBG=32: reads the phase stamps the stamped chained kernels left for the last two steps of a launch and prints the
 // anatomy of the last step (fourth launch of the process = steady state) to stderr.
-static int print_chain_anatomy(const Ctx& c)
+static int print_chain_anatomy(const Ctx& c, uint32_t blocks = 0)
 {
     static unsigned long long host[2 * 256 * 16];
     D3P_HIP_TRY(hipMemcpyAsync(host, c.ws.stamps, sizeof(host), hipMemcpyDeviceToHost, c.s));
     D3P_HIP_TRY(hipStreamSynchronize(c.s));
     static int printed = 0;
+    if ((dev_dbg_flags() & 256) && printed == 3) {  // per-WAVE "examples done" times of the last step (16-wave form), us after the workgroup's first wave
+        ++printed;
+        if (!blocks) blocks = c.g.blocks;
+        for (uint32_t b = 0; b < (blocks < 128u ? blocks : 128u); b += 9) {
+            unsigned long long mn = ~0ull;
+            for (int w = 0; w < 16; ++w) mn = host[((size_t)256 + b) * 16 + w] < mn ? host[((size_t)256 + b) * 16 + w] : mn;
+            fprintf(stderr, "  wg %3u waves:", b);
+            for (int w = 0; w < 16; ++w) fprintf(stderr, " %5.2f", (double)(host[((size_t)256 + b) * 16 + w] - mn) * 0.01);
+            fprintf(stderr, "\n");
+        }
+        return D3P_OK;
+    }
     if (printed++ == 3) {  // fourth launch of the process: steady state
-        const uint32_t nb = c.g.blocks < 256u ? c.g.blocks : 256u;
+        if (!blocks) blocks = c.g.blocks;
+        const uint32_t nb = blocks < 256u ? blocks : 256u;
         auto at = [&](int rec, uint32_t b, int k) { return (double)host[((size_t)rec * 256 + b) * 16 + k] * 0.01; };
         // what a step waits for: the LAST arrival of the previous step
         double last_arr = 0.0, last_acked = 0.0;
@@ -1052,11 +1065,18 @@ static int print_chain_anatomy(const Ctx& c)
         fprintf(stderr, "chained step anatomy (us, relative to the last arrival of the previous step; mean / min / max over %u workgroups)\n", nb);
         for (int k : {0, 8, 7, 2, 1, 5, 6, 9, 10, 11, 12}) {
             double sum = 0.0, mn = 1e30, mx = -1e30;
+            uint32_t who = 0;
             for (uint32_t b = 0; b < nb; ++b) {
                 const double v = at(1, b, k) - last_arr;
-                sum += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+                sum += v; mn = v < mn ? v : mn;
+                if (v > mx) { mx = v; who = b; }
             }
-            fprintf(stderr, "  %-30s %7.2f %7.2f %7.2f\n", names[k], sum / nb, mn, mx);
+            fprintf(stderr, "  %-30s %7.2f %7.2f %7.2f  (latest: workgroup %u)\n", names[k], sum / nb, mn, mx, who);
+        }
+        if (getenv("D3P_ANATOMY_ROWS")) {  // one line per workgroup: release seen, prologue done, examples done, reduction barrier, arrival
+            for (uint32_t b = 0; b < nb; ++b)
+                fprintf(stderr, "  wg %3u: %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f\n", b, at(1, b, 7) - last_arr, at(1, b, 2) - last_arr,
+                        at(1, b, 1) - last_arr, at(1, b, 5) - last_arr, at(1, b, 6) - last_arr, at(1, b, 12) - last_arr);
         }
         fprintf(stderr, "  previous step: last acknowledgement %.2f us before its last arrival\n", last_arr - last_acked);
         const int order[9][2] = {{7, 2}, {2, 5}, {5, 6}, {6, 9}, {9, 10}, {10, 11}, {11, 12}, {8, 7}, {0, 8}};
@@ -1076,12 +1096,41 @@ struct Xchg;
 static void xchg_fill_dev(Xchg* x, XchgDev* d, int K);  // (defined with the exchange, below) takes K epochs of the exchange
 
 // can this run's chained launch be the kernel of d3p_logreg_chain.h?
-static bool lean_chain_ok(const Ctx& c)
+// w16: the 16-wave form (single-rank runs; any batch size: waves take further items in pairs); else the 8-wave form, which
+// prepares at most two items per wave ahead (data-parallel runs, and D3P_CHAIN_W8=1 for A/B measurements)
+static bool chain_w16_enabled()
+{
+    static const bool off = getenv("D3P_CHAIN_W8") != nullptr;
+    return !off;
+}
+static bool lean_chain_ok(const Ctx& c, bool w16)
 {
     static const bool off = getenv("D3P_NO_LEAN_CHAIN") != nullptr || getenv("D3P_NO_PIPELINED_STEPS") != nullptr ||
                             getenv("D3P_MAIN_W") != nullptr;
     return !off && c.g.full && c.g.V == 4 && c.g.NK == 1 && c.g.W == 16 && c.m->d == D3P_CHAIN_D &&
-           c.m->family == D3P_FAMILY_LOGREG && c.items_expected <= 18ull * c.g.blocks;
+           c.m->family == D3P_FAMILY_LOGREG && (w16 || c.items_expected <= 18ull * c.g.blocks);
+}
+// workgroups per step of the 16-wave form: two items per wave; up to 12 % more items than 2 x 16 x 128 (a Poisson batch padded
+// to its 0.99 quantile) still run on 128 workgroups -- two steps side by side on 256 CUs matter more than a few waves taking a
+// third item; larger batches take the whole chip per step.  D3P_CHAIN_NW overrides (sweeps).
+static uint32_t chain16_blocks(uint64_t items)
+{
+    static const int env_nw = [] { const char* e = getenv("D3P_CHAIN_NW"); return e ? atoi(e) : 0; }();
+    if (env_nw >= 1 && env_nw <= 1024) return (uint32_t)env_nw;
+    static const uint32_t cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 2)
+            n = 256;
+        (void)hipGetLastError();
+        return (uint32_t)n;
+    }();
+    const uint64_t per_wg = 2ull * 16ull;
+    uint64_t nw = (items + per_wg - 1) / per_wg;
+    if (nw < 1) nw = 1;
+    const uint64_t half = cus / 2;
+    if (nw > half && items <= 36ull * half) nw = half;  // (up to 36 instead of 32 items per workgroup)
+    if (nw > cus) nw = cus;
+    return (uint32_t)nw;
 }
 
 static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* prev_slot0, const float* prev_noise0, const float* X,
@@ -1160,7 +1209,9 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
         // The headline shape (d = 512, no intercept, logistic regression; at most ~two examples per wave of an 8-wave
         // workgroup) runs the kernel written for it (d3p_logreg_chain.h); D3P_NO_LEAN_CHAIN=1 keeps the generic template.
         const bool icpt = c.g.tail;  // 512 features + intercept (D = 513): the ICPT instantiations
-        if (lean_chain_ok(c)) {
+        const bool w16 = !xchg && chain_w16_enabled();
+        if (lean_chain_ok(c, w16)) {
+            const uint32_t nw = w16 ? chain16_blocks(c.items_expected) : c.g.blocks;
             ChainArgs ca;
             memset(&ca, 0, sizeof(ca));
             ca.X = X;
@@ -1185,7 +1236,7 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
             ca.row_lo = c.src->row_lo;
             ca.sg = a.fuse.sg; ca.inv_sg = a.fuse.inv_sg;
             ca.B = c.src->B;
-            ca.nw = (int)c.g.blocks;
+            ca.nw = (int)nw;
             ca.g0 = g0;
             ca.K = K;
             ca.K_next = cf.K_next;
@@ -1201,9 +1252,10 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
                 ca.x.xsum = c.ws.xsum;
                 D3P_HIP_TRY(hipMemsetAsync(c.ws.xflags, 0, (size_t)D3P_STEP_BATCH * D3P_XCHG_WGS * 32 * sizeof(uint32_t), c.s));
             }
-            const dim3 grid((uint32_t)K * (c.g.blocks + 1u + (xchg ? (uint32_t)D3P_XCHG_WGS : 0u))), block(64 * D3P_CHAIN_W);
+            const int W = w16 ? 16 : D3P_CHAIN_W;
+            const dim3 grid((uint32_t)K * (nw + (w16 ? 0u : 1u) + (xchg ? (uint32_t)D3P_XCHG_WGS : 0u))), block(64 * W);
             const bool plist = ca.plist_base != nullptr;
-            const size_t lds = chain_lds_bytes(icpt);
+            const size_t lds = chain_lds_bytes(icpt, W);
             const bool stamped = (ca.dbg & 32) && K >= 2 && !xchg;  // D3P_DBG=32: the stamped instantiation + the phase anatomy on stderr
             if (stamped) ca.stamps = c.ws.stamps;
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1213,7 +1265,23 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
         if (e0) hipExtLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, XC_>), grid, block, lds, c.s, e0, e1, 0, ca); \
         else hipLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, XC_>), grid, block, lds, c.s, ca);                  \
     } while (0)
-            if (xchg) {  // (no stamped form of the data-parallel kernel)
+#define D3P_CHAIN16_LAUNCH(PL_, ST_, IC_)                                                                                     \
+    do {                                                                                                                      \
+        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logreg_chain<PL_, ST_, IC_, false, 16>), \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;   \
+        (void)lds_ok;                                                                                                         \
+        if (e0) hipExtLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, false, 16>), grid, block, lds, c.s, e0, e1, 0, ca);        \
+        else hipLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, false, 16>), grid, block, lds, c.s, ca);                         \
+    } while (0)
+            if (w16) {
+                if (stamped) {
+                    if (icpt) { if (plist) D3P_CHAIN16_LAUNCH(true, true, true); else D3P_CHAIN16_LAUNCH(false, true, true); }
+                    else { if (plist) D3P_CHAIN16_LAUNCH(true, true, false); else D3P_CHAIN16_LAUNCH(false, true, false); }
+                } else {
+                    if (icpt) { if (plist) D3P_CHAIN16_LAUNCH(true, false, true); else D3P_CHAIN16_LAUNCH(false, false, true); }
+                    else { if (plist) D3P_CHAIN16_LAUNCH(true, false, false); else D3P_CHAIN16_LAUNCH(false, false, false); }
+                }
+            } else if (xchg) {  // (no stamped form of the data-parallel kernel)
                 if (icpt) { if (plist) D3P_CHAIN_LAUNCH(true, false, true, true); else D3P_CHAIN_LAUNCH(false, false, true, true); }
                 else { if (plist) D3P_CHAIN_LAUNCH(true, false, false, true); else D3P_CHAIN_LAUNCH(false, false, false, true); }
             } else if (stamped) {
@@ -1224,9 +1292,10 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
                 else { if (plist) D3P_CHAIN_LAUNCH(true, false, false, false); else D3P_CHAIN_LAUNCH(false, false, false, false); }
             }
 #undef D3P_CHAIN_LAUNCH
+#undef D3P_CHAIN16_LAUNCH
             int rc = check_launch("k_logreg_chain");
             if (rc || !stamped) return rc;
-            return print_chain_anatomy(c);
+            return print_chain_anatomy(c, nw);
         }
     }
     MainGeom g2 = c.g;
@@ -1464,7 +1533,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     // (data-parallel with the one-shot exchange: chained too when the shape has the dedicated kernel -- the exchange then rides
     // in the launch; D3P_XCHG_PER_STEP=1 keeps one step launch + one exchange launch per step)
     static const bool xchg_per_step = getenv("D3P_XCHG_PER_STEP") != nullptr;
-    const bool chained = !comm && use_chained_steps(c) && (!xchg || (lean_chain_ok(c) && !xchg_per_step));
+    const bool chained = !comm && use_chained_steps(c) && (!xchg || (lean_chain_ok(c, false) && !xchg_per_step));
     const bool persist = chained && use_persistent_steps(c);
     for (uint32_t b = 0; b < n_batches; ++b) {
         const int cur = (int)(b & 1), nxt = cur ^ 1;

@@ -20,8 +20,17 @@
 //   phase 3  per example: z, logit (DPP wave sum), gradient, joint norm, clip factor, accumulate (svi.py:238-346);
 //   phase 4  LDS reduction of the 8 waves, 2 fixed-point int64 atomics per thread, arrival.
 //
-// Geometry: 8-wave workgroups, two resident per CU (<= 128 VGPRs), every wave takes at most two items:
-// item k -> wave (k / 8) % nw ... i.e. k1 = 8 bid + wave, k2 = k1 + 8 nw; the host picks nw >= ceil(items / 16).
+// Geometry, two forms (template parameter W_):
+//   W = 8  (round 2; still the data-parallel XCHG form): 8-wave workgroups, two resident per CU (<= 128 VGPRs), every wave takes
+//          at most two items: k1 = 8 bid + wave, k2 = k1 + 8 nw; the host picks nw >= ceil(items / 16); one more workgroup per
+//          step runs the key chain (and two more the exchange).
+//   W = 16 (round 3, the single-rank default): 16-wave workgroups, ONE per CU, nw = ceil(items / 32) -- 128 workgroups per step
+//          at B = 4096, so two consecutive steps are resident side by side on the two halves of the chip (the pipelining moves
+//          from "two workgroups per CU" to "two steps per chip"): half the accumulator atomics (131 k instead of 262 k per
+//          step) and half the redundant prologue reads, the cost that scales with the workgroup count; a CU never holds a
+//          noise-generating workgroup beside one on the step's critical path; a thread owns ONE parameter column (prologue and
+//          reduction); the key-chain step rides at the tail of workgroup 0 (no extra workgroup: 2 x 128 = the chip's 256 CUs).
+//          Waves with more than two items (B = 32768: eight) take the further ones in pairs, noise generated in the loop.
 // PLIST: the items are the entries of the step's dense owned-position list (Poisson padding, row-sharded ranks).
 #pragma once
 #include "d3p_logreg_kernel.h"
@@ -79,6 +88,24 @@ __device__ __forceinline__ long long xchg_ll_value(unsigned long long w0, unsign
     return (long long)((w1 << 32) | (w0 & 0xffffffffull));
 }
 
+// The per-element arithmetic of an example runs on PAIRS of adjacent elements: a lane's 4 + 4 elements of every operand come out
+// of 16-byte loads (table row, LDS columns) or are produced in element order (noise), so elements (0, 1) and (2, 3) already sit in
+// adjacent registers and v_pk_fma_f32 / v_pk_mul_f32 process two of them per issue slot without a single move.  Component-wise
+// IEEE: bit for bit the scalar formulation, element by element; only the order of the per-lane partial sums changes.
+typedef float d3p_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ d3p_v2f pk_fma(d3p_v2f a_, d3p_v2f b_, d3p_v2f c_) { return __builtin_elementwise_fma(a_, b_, c_); }
+__device__ __forceinline__ d3p_v2f pk_splat(float x) { return d3p_v2f{x, x}; }
+struct Quad { d3p_v2f lo, hi; };   // four adjacent elements
+__device__ __forceinline__ Quad quad_of(const float4& f) { return Quad{d3p_v2f{f.x, f.y}, d3p_v2f{f.z, f.w}}; }
+__device__ __forceinline__ Quad quad_lds(const float* p_) { return quad_of(*reinterpret_cast<const float4*>(p_)); }
+// sigmoid and log(1 + exp(-|t|)) on the hardware's exp2 / log2 / rcp: 1 + exp(-|t|) is in (1, 2], a normal number, so the raw
+// v_log_f32 needs none of the denormal handling __logf carries (ten instructions on the step's critical path)
+__device__ __forceinline__ float chain_sigmoid(float t) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * t)); }
+__device__ __forceinline__ float chain_softplus(float t)
+{
+    return fmaxf(t, 0.0f) + 0.693147180559945309f * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * fabsf(t)));
+}
+
 struct ChainArgs {
     const float* X;
     const float* y;
@@ -117,34 +144,39 @@ struct ChainArgs {
 // example, added once after the wave sums).  In LDS the second half is stored from index 260 on, so that its 16-byte
 // reads stay aligned: latent j lives at j (j <= 256) or j + 3 (j >= 257), arrays are 520 long.
 #define D3P_CHAIN_DL(ICPT) ((ICPT) ? 520 : 512)
-static inline size_t chain_lds_bytes(bool icpt)
+static inline size_t chain_lds_bytes(bool icpt, int W = D3P_CHAIN_W)
 {
-    return (size_t)(5 * D3P_CHAIN_DL(icpt) + D3P_CHAIN_W * 2 * D3P_CHAIN_DL(icpt) + 2 * D3P_CHAIN_W + 4 + 32) * sizeof(float);
+    return (size_t)(5 * D3P_CHAIN_DL(icpt) + W * 2 * D3P_CHAIN_DL(icpt) + 2 * W + 4 + 32) * sizeof(float);
 }
 
 // XCHG: the data-parallel form (a.x.world > 0) -- its own instantiation, so that the single-rank kernel does not carry the
 // exchange workgroup's registers (61 SGPRs / 77 VGPRs alone, 82 / 80 with it: 2-3 % of the single-rank step)
-template <bool PLIST, bool STAMPS, bool ICPT = false, bool XCHG = false>
-__global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
+// W_: waves per workgroup (8 or 16, see the header); RU: accumulator replicas in use (<= D3P_ACC_R; the others stay zero)
+template <bool PLIST, bool STAMPS, bool ICPT = false, bool XCHG = false, int W_ = D3P_CHAIN_W, int RU = D3P_ACC_R>
+__global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
 {
+    static_assert(W_ == 8 || W_ == 16, "8- or 16-wave workgroups");
+    static_assert(!(XCHG && W_ == 16), "the data-parallel form keeps the 8-wave geometry");
+    static_assert(RU >= 1 && RU <= D3P_ACC_R, "replicas in use");
+    constexpr bool W16 = W_ == 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int DF = D3P_CHAIN_D;                 // feature columns of a table row
-    constexpr int D = DF + (ICPT ? 1 : 0), P = 2 * D, PA = D3P_ACC_COLS(P), W = D3P_CHAIN_W, R = D3P_ACC_R;
+    constexpr int D = DF + (ICPT ? 1 : 0), P = 2 * D, PA = D3P_ACC_COLS(P), W = W_, R = D3P_ACC_R;
     constexpr int HALF = ICPT ? 257 : 256;          // second index of a threefry pair = first + HALF
     constexpr int DL = D3P_CHAIN_DL(ICPT);          // LDS array length per quantity
     constexpr int C1 = ICPT ? 260 : 256;            // LDS index of the lane-0 element of the second half
     constexpr int TL = 256;                         // ICPT: latent / LDS index of the tail column
     auto lix = [](int j) { return (!ICPT || j <= 256) ? j : j + 3; };  // latent -> LDS index
-    float* pk = lds;                    // [loc | s | sg | q | lc] x DL
+    float* pk = lds;                    // [loc | s | sg | q] x DL, then the waves' shares of sum_j lc_j (W floats)
     float* red = lds + 5 * DL;          // W rows of 2 DL floats: the waves' noise, later their partial sums
     float* tail = red + W * 2 * DL;     // 2 W: loss / count per wave
     uint32_t* okw = reinterpret_cast<uint32_t*>(tail + 2 * W);             // verdict of the polling wave
     unsigned long long* stamp = reinterpret_cast<unsigned long long*>(okw + 4);
-#define D3P_CSTAMP(k) if (STAMPS && threadIdx.x == 0) stamp[k] = wall_clock64();
+#define D3P_CSTAMP(k) if (STAMPS && threadIdx.x == 0 && !((a.dbg & 256) && (k) != 5 && (k) >= 5)) stamp[k] = wall_clock64();
     D3P_CSTAMP(0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t per = (uint32_t)a.nw + 1u + (XCHG ? (uint32_t)D3P_XCHG_WGS : 0u);
+    const uint32_t per = (uint32_t)a.nw + (W16 ? 0u : 1u) + (XCHG ? (uint32_t)D3P_XCHG_WGS : 0u);  // (W = 16: no key-chain workgroup)
     const int step_t = (int)(blockIdx.x / per);
     const uint32_t bid = blockIdx.x % per;
 
@@ -231,7 +263,7 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         return;
     }
 
-    if (bid == (uint32_t)a.nw) {  // key-chain workgroup: split(state_key, 3) of step `step_t` of the NEXT batch
+    if (!W16 && bid == (uint32_t)a.nw) {  // key-chain workgroup: split(state_key, 3) of step `step_t` of the NEXT batch
         if (step_t < a.K_next && tid < 64) {
             uint32_t* progress = a.bar + (size_t)a.K * D3P_BAR_WORDS;
             bool go = true;
@@ -288,41 +320,64 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     const StepSlot* ps = step_t > 0 ? a.slots + (step_t - 1) : a.prev_slot0;
     const bool apply_prev = ps != nullptr;
     const float* prev_noise = step_t > 0 ? a.noise_base + (size_t)(step_t - 1) * P : a.prev_noise0;
+    // W = 16: thread tid owns ONE parameter column -- auto_loc of latent tid (tid < 512) or auto_scale of latent tid - 512
+    // (ICPT: the intercept's two columns D - 1 and 2 D - 1 are second columns of threads 64 and 576)
+    const int mycol = W16 ? (tid < DF ? tid : D + (tid - DF)) : tid;
     float zL = 0.f, zS = 0.f, bc1 = 1.f, bc2 = 1.f;
-    if (apply_prev) {  // Gaussian-mechanism normals of this thread's two columns and the bias corrections
-        zL = prev_noise[tid];
-        zS = prev_noise[D + tid];
+    // W = 16: everything of the pending update that does not depend on the sums is computed HERE, before the release: the valid
+    // example count of the pending step is a function of the keys (the sampler left it in the step's slot; the count column of
+    // the accumulator is only looked at for the non-finite marker), so svi.py:305's factor, the noise scale of svi.py:365 and
+    // Adam's bias corrections -- five divisions -- leave the step's critical path.
+    float pre_n = 0.f, pre_factor = 0.f, pre_noise_scale = 0.f, pre_out_scale = 0.f, pre_inv_B = 0.f, pre_inv_bc1 = 1.f, pre_inv_bc2 = 1.f;
+    if (apply_prev) {  // Gaussian-mechanism normals of this thread's column(s) and the bias corrections
+        zL = prev_noise[mycol];
+        if (!W16) zS = prev_noise[D + tid];
         bc1 = ps->bc1;
         bc2 = ps->bc2;
+        if (W16) {
+            pre_n = (float)ps->counts[1];
+            const float Bf = (float)a.B;
+            pre_factor = (pre_n == 0.0f) ? 0.0f : Bf / pre_n;  // svi.py:305
+            pre_inv_B = 1.0f / Bf;
+            pre_inv_bc1 = 1.0f / bc1;
+            pre_inv_bc2 = 1.0f / bc2;
+            pre_noise_scale = a.dp_scale * (a.clip / pre_n);   // svi.py:365-375
+            pre_out_scale = a.obs_scale * pre_factor;
+        }
     }
-    // guide noise of both examples into the wave's own row: lane owns columns 4 lane .. + 3 and D/2 + the same, i.e. the
-    // pairs (c, c + D/2) of jax's iota layout come out of ONE threefry2x32 call
-    float* er = red + (size_t)wave * 2 * DL;
-    // returns the lane's share of -0.5 |eps|^2 (the log q term of the loss: parameter-independent, so summed here)
-    auto gen = [&](uint32_t k0, uint32_t k1_, float* dst) {
+    // guide noise of both examples, kept in registers (round 3; round 2 parked it in the wave's row of the reduction buffer: 4 KB
+    // of LDS reads per wave on the step's critical path, where all 16 waves of a CU read at once): lane owns columns
+    // 4 lane .. + 3 and D/2 + the same, i.e. the pairs (c, c + D/2) of jax's iota layout come out of ONE threefry2x32 call
+    float* er = red + (size_t)wave * 2 * DL;   // the wave's row of the reduction buffer (partial sums, phase 4)
+    struct Eps { Quad v0, v1; float vt, e2; };  // v0 / v1: the lane's 4 + 4 elements; vt: ICPT, the tail latent's noise; e2: the lane's share of -0.5 |eps|^2
+    // (e2: the log q term of the loss is parameter-independent, so it is summed here)
+    auto gen = [&](uint32_t k0, uint32_t k1_) {
         const uint32_t s0 = __builtin_amdgcn_readfirstlane(k0), s1 = __builtin_amdgcn_readfirstlane(k1_);  // wave-uniform keys
-        float v0[4], v1[4], e2 = 0.f;
+        Eps o;
+        float e2 = 0.f, w0[4], w1[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             uint32_t b0, b1;
             threefry2x32(s0, s1, (uint32_t)(4 * lane + n), (uint32_t)(4 * lane + n + HALF), b0, b1);
-            v0[n] = bits_to_normal_wu(b0);
-            v1[n] = bits_to_normal_wu(b1);
-            e2 = __fmaf_rn(v0[n], v0[n], e2);
-            e2 = __fmaf_rn(v1[n], v1[n], e2);
+            w0[n] = bits_to_normal_wu(b0);
+            w1[n] = bits_to_normal_wu(b1);
+            e2 = __fmaf_rn(w0[n], w0[n], e2);
+            e2 = __fmaf_rn(w1[n], w1[n], e2);
         }
-        *reinterpret_cast<float4*>(dst + 4 * lane) = make_float4(v0[0], v0[1], v0[2], v0[3]);
-        *reinterpret_cast<float4*>(dst + C1 + 4 * lane) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+        o.v0 = Quad{d3p_v2f{w0[0], w0[1]}, d3p_v2f{w0[2], w0[3]}};
+        o.v1 = Quad{d3p_v2f{w1[0], w1[1]}, d3p_v2f{w1[2], w1[3]}};
+        o.vt = 0.f;
         if (ICPT) {  // the tail latent: word 256 pairs with the padding of the odd counter array (jax pads with a zero)
             uint32_t b0, b1;
             threefry2x32(s0, s1, (uint32_t)TL, 0u, b0, b1);
-            if (lane == 0) dst[TL] = bits_to_normal_wu(b0);
+            o.vt = bits_to_normal_wu(b0);
         }
-        return -0.5f * e2;
+        o.e2 = -0.5f * e2;
+        return o;
     };
-    float ea = 0.f, eb = 0.f;
-    if (live1) ea = gen(ka0, ka1, er);
-    if (live2) eb = gen(kb0, kb1, er + DL);
+    Eps epa = {}, epb = {};
+    if (live1) epa = gen(ka0, ka1);
+    if (live2) epb = gen(kb0, kb1);
     D3P_CSTAMP(8)
     // From here on the workgroup is on the critical path of the step (D3P_DBG=2: raised wave priority against the co-resident
     // workgroup of the next step, which is generating its noise on the same SIMDs).
@@ -351,6 +406,7 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
 
     // ------------------------------------------------------------------ phase 2: update prologue (thread e <-> latent e)
     const int in = g > 0 ? ((g - 1) & 1) : 0, out = g & 1;
+    float lc_mine = 0.f;  // this thread's share of sum_j lc_j = sum_j [log prior scale - log s_j] (example-independent loss term)
     {
         float n = 0.f, factor = 0.f;
         // nobody reads the next accumulator any more (the previous step's prologues are over; at the first step of a run
@@ -358,17 +414,76 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         for (int i = (int)bid * (64 * W) + tid; i < R * PA; i += a.nw * 64 * W)
             __hip_atomic_store(acc_next + i, 0ll, __ATOMIC_RELAXED, D3P_AGENT);
         // one latent: pending update of its two columns (e: auto_loc, D + e: auto_scale) and its derived LDS entries
-        // the sums of the previous step: the 4 local replicas, or (data-parallel) the ONE row the exchange workgroup left
+        // the sums of the previous step: the local replicas, or (data-parallel) the ONE row the exchange workgroup left
         const long long* sums = XCHG ? a.x.xsum + (size_t)((g + 2) % 3) * PA : acc_prev;
-        constexpr int nrep = XCHG ? 1 : R;
+        constexpr int nrep = XCHG ? 1 : RU;
+        // W = 16: one parameter column c (c < D: auto_loc of latent c, else auto_scale of latent c - D): its pending update
+        // and its derived LDS entries.  Same arithmetic per column as the two-column form below.
+        long long nll_main = 0;  // example count of the pending step (summed in the thread's main column call, all lanes active)
+        auto column = [&](int c, float z, bool main_call) {
+            const bool is_scale = c >= D;
+            const int e = is_scale ? c - D : c;
+            float x;
+            if (apply_prev) {
+                long long s8[RU];
+#pragma unroll
+                for (int r = 0; r < RU; ++r) s8[r] = __hip_atomic_load(sums + (size_t)r * PA + c, __ATOMIC_RELAXED, D3P_AGENT);
+                x = __hip_atomic_load(a.state[in][0] + c, __ATOMIC_RELAXED, D3P_AGENT);
+                float m = __hip_atomic_load(a.state[in][1] + c, __ATOMIC_RELAXED, D3P_AGENT);
+                float v = __hip_atomic_load(a.state[in][2] + c, __ATOMIC_RELAXED, D3P_AGENT);
+                // the example count: ONE load instruction per wave (lane r < RU reads replica r's count column), summed over the lanes
+                long long nr = 0;
+                if (main_call) nr = __hip_atomic_load(sums + (size_t)(lane < RU ? lane : 0) * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT);
+                long long sm = 0;
+#pragma unroll
+                for (int r = 0; r < RU; ++r) sm += s8[r];
+                if (main_call) {
+#pragma unroll
+                    for (int r = 0; r < RU; ++r)
+                        nll_main += ((long long)__builtin_amdgcn_readlane((int)(nr >> 32), r) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)nr, r);
+                }
+                // (a workgroup that saw a non-finite partial added 2^44 to the count column: NaN from here on, like float sums)
+                const float poison = nll_main >= (1ll << 40) ? __builtin_nanf("") : 0.0f;
+                n = pre_n + poison;
+                factor = pre_factor + poison;
+                const float inv_B = pre_inv_B, inv_bc1 = pre_inv_bc1, inv_bc2 = pre_inv_bc2;
+                const float noise_scale = pre_noise_scale, out_scale = pre_out_scale + poison;
+                // |sm| < 2^51: the int64 -> double conversion as one integer add onto the bit pattern of 1.5 * 2^52 and one
+                // double subtraction (exact), instead of the ~12 instructions of the generic conversion
+                const double smd = __longlong_as_double(sm + 0x4338000000000000ll) - 6755399441055744.0;
+                const float tot = (float)(smd * a.inv_sg);
+                const float gr = __fmaf_rn(z, noise_scale, tot * inv_B) * out_scale;
+                m = (1.0f - a.b1) * gr + a.b1 * m;
+                v = (1.0f - a.b2) * gr * gr + a.b2 * v;
+                x = x - a.lr * (m * inv_bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * inv_bc2) + a.adam_eps);
+                if (bid == 0) {  // one workgroup publishes the state
+                    __hip_atomic_store(a.state[out][0] + c, x, __ATOMIC_RELAXED, D3P_AGENT);
+                    __hip_atomic_store(a.state[out][1] + c, m, __ATOMIC_RELAXED, D3P_AGENT);
+                    __hip_atomic_store(a.state[out][2] + c, v, __ATOMIC_RELAXED, D3P_AGENT);
+                }
+            } else {
+                x = a.state[in][0][c];
+            }
+            const int li = lix(e);
+            if (!is_scale) {
+                pk[li] = x;
+            } else {
+                float sp, sgm;
+                guide_scale(a.gexp, x, sp, sgm);
+                pk[DL + li] = sp;
+                pk[2 * DL + li] = sgm;
+                pk[3 * DL + li] = a.inv_obs * sgm * __builtin_amdgcn_rcpf(sp);
+                lc_mine += ((ICPT && e == D - 1) ? a.log_prior_b : a.log_prior) - __logf(sp);
+            }
+        };
         auto latent = [&](int e, float zl, float zs) {
             float xL, xS;
             if (apply_prev) {
-                long long aL[R], aS[R], n8[R];
+                long long aL[nrep], aS[nrep], n8[nrep];
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    aL[r] = r < nrep ? __hip_atomic_load(sums + (size_t)r * PA + e, __ATOMIC_RELAXED, D3P_AGENT) : 0ll;
-                    aS[r] = r < nrep ? __hip_atomic_load(sums + (size_t)r * PA + D + e, __ATOMIC_RELAXED, D3P_AGENT) : 0ll;
+                for (int r = 0; r < nrep; ++r) {
+                    aL[r] = __hip_atomic_load(sums + (size_t)r * PA + e, __ATOMIC_RELAXED, D3P_AGENT);
+                    aS[r] = __hip_atomic_load(sums + (size_t)r * PA + D + e, __ATOMIC_RELAXED, D3P_AGENT);
                 }
                 xL = __hip_atomic_load(a.state[in][0] + e, __ATOMIC_RELAXED, D3P_AGENT);
                 xS = __hip_atomic_load(a.state[in][0] + D + e, __ATOMIC_RELAXED, D3P_AGENT);
@@ -377,10 +492,10 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
                 float vL = __hip_atomic_load(a.state[in][2] + e, __ATOMIC_RELAXED, D3P_AGENT);
                 float vS = __hip_atomic_load(a.state[in][2] + D + e, __ATOMIC_RELAXED, D3P_AGENT);
 #pragma unroll
-                for (int r = 0; r < R; ++r) n8[r] = r < nrep ? __hip_atomic_load(sums + (size_t)r * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT) : 0ll;
+                for (int r = 0; r < nrep; ++r) n8[r] = __hip_atomic_load(sums + (size_t)r * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT);
                 long long nll = 0, sL = 0, sS = 0;
 #pragma unroll
-                for (int r = 0; r < R; ++r) { nll += n8[r]; sL += aL[r]; sS += aS[r]; }
+                for (int r = 0; r < nrep; ++r) { nll += n8[r]; sL += aL[r]; sS += aS[r]; }
                 // (a workgroup that saw a non-finite partial added 2^44 to the count column: NaN from here on, like float sums)
                 n = nll >= (1ll << 40) ? __builtin_nanf("") : (float)nll;
                 const float Bf = (float)a.B;
@@ -415,10 +530,16 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
             pk[DL + li] = sp;
             pk[2 * DL + li] = sgm;
             pk[3 * DL + li] = a.inv_obs * sgm * __builtin_amdgcn_rcpf(sp);
-            pk[4 * DL + li] = ((ICPT && e == D - 1) ? a.log_prior_b : a.log_prior) - __logf(sp);
+            lc_mine += ((ICPT && e == D - 1) ? a.log_prior_b : a.log_prior) - __logf(sp);
         };
-        latent(tid, zL, zS);
-        if (ICPT && tid == 1) latent(D - 1, apply_prev ? prev_noise[D - 1] : 0.f, apply_prev ? prev_noise[2 * D - 1] : 0.f);  // the intercept
+        if (W16) {
+            column(mycol, zL, true);
+            if (ICPT && tid == 64) column(D - 1, apply_prev ? prev_noise[D - 1] : 0.f, false);           // the intercept's auto_loc
+            if (ICPT && tid == 576) column(2 * D - 1, apply_prev ? prev_noise[2 * D - 1] : 0.f, false);  // ... and auto_scale
+        } else {
+            latent(tid, zL, zS);
+            if (ICPT && tid == 1) latent(D - 1, apply_prev ? prev_noise[D - 1] : 0.f, apply_prev ? prev_noise[2 * D - 1] : 0.f);  // the intercept
+        }
         if (apply_prev && bid == 0 && tid == 0) {
             long long lll = 0, lhh = 0;
 #pragma unroll
@@ -431,14 +552,22 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
             if (a.batch_index) *a.batch_index = ps->batch_i + 1u;
         }
     }
+    {
+        const float lcw = wave_sum(lc_mine);   // (all lanes active again)
+        if (lane == 0) pk[4 * DL + wave] = lcw;
+    }
     D3P_CSTAMP(2)
     __syncthreads();
     D3P_CSTAMP(1)
+    float lcsum = 0.f;   // fixed order over the waves' slots: identical in every thread
+#pragma unroll
+    for (int w = 0; w < W; ++w) lcsum += pk[4 * DL + w];
 
     // ------------------------------------------------------------------ phase 3: the wave's (up to) two examples
-    float accg0[4] = {0.f, 0.f, 0.f, 0.f}, acch0[4] = {0.f, 0.f, 0.f, 0.f}, accg1[4] = {0.f, 0.f, 0.f, 0.f}, acch1[4] = {0.f, 0.f, 0.f, 0.f};
+    const d3p_v2f zero2 = pk_splat(0.f);
+    Quad accg0 = {zero2, zero2}, acch0 = accg0, accg1 = accg0, acch1 = accg0;   // clipped sums of the lane's 4 + 4 columns (loc-, scale-gradient)
     float acc_gt = 0.f, acc_ht = 0.f;  // ICPT: the tail latent's two sums (identical in every lane, lane 0 stores them)
-    float loss_acc = 0.f, n_acc = 0.f;
+    float loss_lane = 0.f, loss_uni = 0.f, n_acc = 0.f;  // loss: per-lane shares / wave-uniform terms (see `examples`)
     const int c0 = 4 * lane, c1 = C1 + 4 * lane;
     const bool icpt_lane = ICPT && lane == 63;  // its last second-half element is the intercept (own prior scale)
     // NE examples in lockstep: their dependency chains (LDS reads -> dot product -> DPP wave sum -> sigmoid -> gradient ->
@@ -447,148 +576,165 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
     // The latent part of the loss of an example, sum_j [ hz z_j^2 - eps_j^2 / 2 + lc_j ] (log p(z) - log q(z) up to constants),
     // is split into the parameter-independent -|eps|^2 / 2 (from phase 0, `e2v`), the example-independent sum of the lc
     // column (one pass per call) and hz |z|^2, which alone stays in the per-element loop.
-    auto examples = [&](auto ne_tag, const float4* x0v, const float4* x1v, const float* xtv, const float* yv, const float* const* ev,
-                        const float* e2v) {
-        constexpr int NE = decltype(ne_tag)::value;
-        float x0[NE][4], x1[NE][4], e0[NE][4], e1[NE][4], z0[NE][4], z1[NE][4], tp[NE];
-        float l0[4], l1[4], s0[4], s1[4];
-        *reinterpret_cast<float4*>(l0) = *reinterpret_cast<const float4*>(pk + c0);
-        *reinterpret_cast<float4*>(l1) = *reinterpret_cast<const float4*>(pk + c1);
-        *reinterpret_cast<float4*>(s0) = *reinterpret_cast<const float4*>(pk + DL + c0);
-        *reinterpret_cast<float4*>(s1) = *reinterpret_cast<const float4*>(pk + DL + c1);
+    auto examples = [&](auto ne_tag, const float4* x0v, const float4* x1v, const float* xtv, const float* yv, const Eps* ev) {
+        constexpr int NE = decltype(ne_tag)::value;   // examples in lockstep: independent instruction streams the SIMD interleaves
+        const Quad l0 = quad_lds(pk + c0), l1 = quad_lds(pk + c1), s0 = quad_lds(pk + DL + c0), s1 = quad_lds(pk + DL + c1);
+        Quad x0[NE], x1[NE], z0[NE], z1[NE];
         float et[NE], zt[NE];  // ICPT: noise and latent value of the tail column
+        d3p_v2f tp[NE], tq[NE];
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
-            *reinterpret_cast<float4*>(e0[j]) = *reinterpret_cast<const float4*>(ev[j] + c0);
-            *reinterpret_cast<float4*>(e1[j]) = *reinterpret_cast<const float4*>(ev[j] + c1);
-            x0[j][0] = x0v[j].x; x0[j][1] = x0v[j].y; x0[j][2] = x0v[j].z; x0[j][3] = x0v[j].w;
-            x1[j][0] = x1v[j].x; x1[j][1] = x1v[j].y; x1[j][2] = x1v[j].z; x1[j][3] = x1v[j].w;
-            tp[j] = 0.f;
-            et[j] = ICPT ? ev[j][TL] : 0.f;
+            x0[j] = quad_of(x0v[j]);
+            x1[j] = quad_of(x1v[j]);
+            et[j] = ICPT ? ev[j].vt : 0.f;
             zt[j] = ICPT ? __fmaf_rn(pk[DL + TL], et[j], pk[TL]) : 0.f;
+            z0[j].lo = pk_fma(s0.lo, ev[j].v0.lo, l0.lo);
+            z0[j].hi = pk_fma(s0.hi, ev[j].v0.hi, l0.hi);
+            z1[j].lo = pk_fma(s1.lo, ev[j].v1.lo, l1.lo);
+            z1[j].hi = pk_fma(s1.hi, ev[j].v1.hi, l1.hi);
+            tp[j] = pk_fma(x0[j].hi, z0[j].hi, x0[j].lo * z0[j].lo);
+            tq[j] = pk_fma(x1[j].hi, z1[j].hi, x1[j].lo * z1[j].lo);
         }
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int j = 0; j < NE; ++j) {
-                z0[j][n] = __fmaf_rn(s0[n], e0[j][n], l0[n]);
-                z1[j][n] = __fmaf_rn(s1[n], e1[j][n], l1[n]);
-                tp[j] = __fmaf_rn(x0[j][n], z0[j][n], tp[j]);
-                tp[j] = __fmaf_rn(x1[j][n], z1[j][n], tp[j]);
-            }
-        float sg0[4], sg1[4], q0[4], q1[4], lc0[4], lc1[4];  // (requested before the wave sums need their results)
-        *reinterpret_cast<float4*>(sg0) = *reinterpret_cast<const float4*>(pk + 2 * DL + c0);
-        *reinterpret_cast<float4*>(sg1) = *reinterpret_cast<const float4*>(pk + 2 * DL + c1);
-        *reinterpret_cast<float4*>(q0) = *reinterpret_cast<const float4*>(pk + 3 * DL + c0);
-        *reinterpret_cast<float4*>(q1) = *reinterpret_cast<const float4*>(pk + 3 * DL + c1);
-        *reinterpret_cast<float4*>(lc0) = *reinterpret_cast<const float4*>(pk + 4 * DL + c0);
-        *reinterpret_cast<float4*>(lc1) = *reinterpret_cast<const float4*>(pk + 4 * DL + c1);
-        float t[NE], A[NE], loglik[NE], n2[NE], lp[NE];
+        if (STAMPS && (a.dbg & 0x700) == 0x500 && lane == 0) { asm volatile("" :: "v"(tp[0].x), "v"(tq[0].x)); stamp[wave & 15] = wall_clock64(); }
+        const Quad sg0 = quad_lds(pk + 2 * DL + c0), sg1 = quad_lds(pk + 2 * DL + c1);   // (requested before the wave sums need them)
+        const Quad q0 = quad_lds(pk + 3 * DL + c0), q1 = quad_lds(pk + 3 * DL + c1);
+        float t[NE], A[NE], loglik[NE];
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
-            t[j] = wave_sum(tp[j]);                                          // logit x . z
+            const d3p_v2f tpq = tp[j] + tq[j];
+            t[j] = wave_sum(tpq.x + tpq.y);                                  // logit x . z
             if (ICPT) t[j] = __fmaf_rn(xtv[j], zt[j], t[j]);                 // + the tail feature, once
         }
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
-            A[j] = a.A_scale * (sigmoid_f(t[j]) - yv[j]);                    // d(-lik_scale inv_obs loglik)/dt
-            loglik[j] = yv[j] * t[j] - softplus_f(t[j]);
-            n2[j] = lp[j] = 0.f;
+            A[j] = a.A_scale * (chain_sigmoid(t[j]) - yv[j]);                // d(-lik_scale inv_obs loglik)/dt
+            loglik[j] = yv[j] * t[j] - chain_softplus(t[j]);
         }
-        float g0[NE][4], g1[NE][4], h0[NE][4], h1[NE][4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int j = 0; j < NE; ++j) {
-                const bool isb = n == 3 && icpt_lane;                        // the intercept's own prior
-                g0[j][n] = __fmaf_rn(a.c1, z0[j][n], A[j] * x0[j][n]);
-                g1[j][n] = __fmaf_rn(isb ? a.c1_b : a.c1, z1[j][n], A[j] * x1[j][n]);
-                h0[j][n] = __fmaf_rn(g0[j][n] * e0[j][n], sg0[n], -q0[n]);
-                h1[j][n] = __fmaf_rn(g1[j][n] * e1[j][n], sg1[n], -q1[n]);
-                n2[j] = __fmaf_rn(g0[j][n], g0[j][n], n2[j]);
-                n2[j] = __fmaf_rn(h0[j][n], h0[j][n], n2[j]);
-                n2[j] = __fmaf_rn(g1[j][n], g1[j][n], n2[j]);
-                n2[j] = __fmaf_rn(h1[j][n], h1[j][n], n2[j]);
-                lp[j] = __fmaf_rn(z0[j][n], z0[j][n], lp[j]);
-                if (!(ICPT && n == 3)) lp[j] = __fmaf_rn(z1[j][n], z1[j][n], lp[j]);
-            }
-        const float lcs = ((lc0[0] + lc0[1]) + (lc0[2] + lc0[3])) + ((lc1[0] + lc1[1]) + (lc1[2] + lc1[3]));
+        if (STAMPS && (a.dbg & 0x700) == 0x300 && lane == 0) { asm volatile("" :: "v"(A[0])); stamp[wave & 15] = wall_clock64(); }
+        Quad g0[NE], g1[NE], h0[NE], h1[NE];
+        float n2s[NE], gt[NE], ht[NE];
+        const d3p_v2f c1p = pk_splat(a.c1);
+        const d3p_v2f c1q = ICPT ? d3p_v2f{a.c1, icpt_lane ? a.c1_b : a.c1} : c1p;   // the intercept's own prior (last element of lane 63)
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
-            lp[j] = __fmaf_rn(a.hz, lp[j], lcs + e2v[j]);
-            if (ICPT) lp[j] = __fmaf_rn((icpt_lane ? a.hz_b : a.hz) * z1[j][3], z1[j][3], lp[j]);
+            const d3p_v2f Ap = pk_splat(A[j]);
+            g0[j].lo = pk_fma(c1p, z0[j].lo, Ap * x0[j].lo);
+            g0[j].hi = pk_fma(c1p, z0[j].hi, Ap * x0[j].hi);
+            g1[j].lo = pk_fma(c1p, z1[j].lo, Ap * x1[j].lo);
+            g1[j].hi = pk_fma(c1q, z1[j].hi, Ap * x1[j].hi);
+            h0[j].lo = pk_fma(g0[j].lo * ev[j].v0.lo, sg0.lo, -q0.lo);
+            h0[j].hi = pk_fma(g0[j].hi * ev[j].v0.hi, sg0.hi, -q0.hi);
+            h1[j].lo = pk_fma(g1[j].lo * ev[j].v1.lo, sg1.lo, -q1.lo);
+            h1[j].hi = pk_fma(g1[j].hi * ev[j].v1.hi, sg1.hi, -q1.hi);
+            // squared norm of the example's gradient: four chains of two
+            const d3p_v2f na = pk_fma(g0[j].hi, g0[j].hi, g0[j].lo * g0[j].lo), nb = pk_fma(h0[j].hi, h0[j].hi, h0[j].lo * h0[j].lo);
+            const d3p_v2f nc = pk_fma(g1[j].hi, g1[j].hi, g1[j].lo * g1[j].lo), nd = pk_fma(h1[j].hi, h1[j].hi, h1[j].lo * h1[j].lo);
+            const d3p_v2f nn = (na + nb) + (nc + nd);
+            n2s[j] = nn.x + nn.y;
+            // The latent part of the loss, sum_j [hz z_j^2 - eps_j^2 / 2 + lc_j]: its per-lane share is only ever summed -- over
+            // the lanes, the examples, the waves and the workgroups -- so it is NOT wave-summed per example (round 2 did): it goes
+            // into a per-lane accumulator that the wave sums once in phase 4; the wave-uniform terms (lc sum, tail latent,
+            // likelihood) into a scalar one.
+            const d3p_v2f zz = pk_fma(z0[j].hi, z0[j].hi, z0[j].lo * z0[j].lo) + pk_fma(z1[j].hi, z1[j].hi, z1[j].lo * z1[j].lo);
+            float lpl = __fmaf_rn(a.hz, zz.x + zz.y, ev[j].e2);
+            if (ICPT) lpl = __fmaf_rn((icpt_lane ? a.hz_b - a.hz : 0.0f) * z1[j].hi.y, z1[j].hi.y, lpl);  // (the intercept's own prior)
+            loss_lane += lpl;
         }
-        float gt[NE], ht[NE];
 #pragma unroll
-        for (int j = 0; j < NE; ++j) n2[j] = wave_sum(n2[j]);
-#pragma unroll
-        for (int j = 0; j < NE; ++j) lp[j] = wave_sum(lp[j]);
+        for (int j = 0; j < NE; ++j) n2s[j] = wave_sum(n2s[j]);
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             gt[j] = ht[j] = 0.f;
+            float lpu = lcsum;
             if (ICPT) {  // the tail latent is a feature column (prior of the weights); its terms enter every sum once
                 gt[j] = __fmaf_rn(a.c1, zt[j], A[j] * xtv[j]);
                 ht[j] = __fmaf_rn(gt[j] * et[j], pk[2 * DL + TL], -pk[3 * DL + TL]);
-                n2[j] = __fmaf_rn(gt[j], gt[j], __fmaf_rn(ht[j], ht[j], n2[j]));
-                lp[j] += __fmaf_rn(a.hz * zt[j], zt[j], __fmaf_rn(-0.5f * et[j], et[j], pk[4 * DL + TL]));
+                n2s[j] = __fmaf_rn(gt[j], gt[j], __fmaf_rn(ht[j], ht[j], n2s[j]));
+                lpu += __fmaf_rn(a.hz * zt[j], zt[j], -0.5f * et[j] * et[j]);
             }
             // clip factor 1 / max(1, ||g|| / C) (svi.py:121-122) folded into the running sum (svi.py:343-346)
-            const float cf = fminf(1.0f, a.clip * __builtin_amdgcn_rsqf(n2[j]));
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                accg0[n] = __fmaf_rn(cf, g0[j][n], accg0[n]);
-                acch0[n] = __fmaf_rn(cf, h0[j][n], acch0[n]);
-                accg1[n] = __fmaf_rn(cf, g1[j][n], accg1[n]);
-                acch1[n] = __fmaf_rn(cf, h1[j][n], acch1[n]);
-            }
+            const d3p_v2f cf = pk_splat(fminf(1.0f, a.clip * __builtin_amdgcn_rsqf(n2s[j])));
+            accg0.lo = pk_fma(cf, g0[j].lo, accg0.lo); accg0.hi = pk_fma(cf, g0[j].hi, accg0.hi);
+            acch0.lo = pk_fma(cf, h0[j].lo, acch0.lo); acch0.hi = pk_fma(cf, h0[j].hi, acch0.hi);
+            accg1.lo = pk_fma(cf, g1[j].lo, accg1.lo); accg1.hi = pk_fma(cf, g1[j].hi, accg1.hi);
+            acch1.lo = pk_fma(cf, h1[j].lo, acch1.lo); acch1.hi = pk_fma(cf, h1[j].hi, acch1.hi);
             if (ICPT) {
-                acc_gt = __fmaf_rn(cf, gt[j], acc_gt);
-                acc_ht = __fmaf_rn(cf, ht[j], acc_ht);
+                acc_gt = __fmaf_rn(cf.x, gt[j], acc_gt);
+                acc_ht = __fmaf_rn(cf.x, ht[j], acc_ht);
             }
-            loss_acc += a.inv_obs * (lp[j] - a.lik_scale * loglik[j]);  // svi.py:278-281
+            loss_uni += lpu - a.lik_scale * loglik[j];  // svi.py:278-281 (times inv_obs in phase 4)
             n_acc += 1.0f;
         }
     };
     if (live2) {  // (live2 implies live1) the common case: both in lockstep
         const float4 xs0[2] = {xa0, xb0}, xs1[2] = {xa1, xb1};
         const float xts[2] = {xta, xtb}, ys[2] = {ya, yb};
-        const float* es[2] = {er, er + DL};
-        const float e2s[2] = {ea, eb};
-        examples(std::integral_constant<int, 2>{}, xs0, xs1, xts, ys, es, e2s);
+        const Eps es[2] = {epa, epb};
+        examples(std::integral_constant<int, 2>{}, xs0, xs1, xts, ys, es);
     } else if (live1) {
-        const float* es[1] = {er};
-        examples(std::integral_constant<int, 1>{}, &xa0, &xa1, &xta, &ya, es, &ea);
+        examples(std::integral_constant<int, 1>{}, &xa0, &xa1, &xta, &ya, &epa);
     }
     // further items of this wave (only when the grid was sized for fewer items than the step has: an unlucky shard of a
     // row-sharded batch): loaded, their noise generated and consumed one at a time
-    for (uint32_t k = k2 + (uint32_t)a.nw * W; k < n_items; k += (uint32_t)a.nw * W) {
+    // W = 16: in pairs (B = 32768 on 256 workgroups: eight items per wave, i.e. three more pairs).
+    const uint32_t stride = (uint32_t)a.nw * W;
+    for (uint32_t k = k2 + stride; k < n_items; k += (W16 ? 2u : 1u) * stride) {
+        const uint32_t kb = k + stride;
+        const bool two = W16 && kb < n_items;  // (wave-uniform)
         const uint32_t p = PLIST ? (a.plist_base + (size_t)step_t * a.B)[k] : k;
-        const size_t row = (size_t)((uint64_t)idx[p] - a.row_lo);
-        float4 x0, x1;
-        float xt = 0.f;
-        load_x(a.X + row * DF, x0, x1, xt);
-        const float yv = a.y[row];
-        const float e2 = gen(skeys[2 * p], skeys[2 * p + 1], er);
-        const float* es[1] = {er};
-        examples(std::integral_constant<int, 1>{}, &x0, &x1, &xt, &yv, es, &e2);
+        const uint32_t pb = two ? (PLIST ? (a.plist_base + (size_t)step_t * a.B)[kb] : kb) : p;
+        const size_t row = (size_t)((uint64_t)idx[p] - a.row_lo), rowb = (size_t)((uint64_t)idx[pb] - a.row_lo);
+        float4 xs0[2], xs1[2];
+        float xts[2] = {0.f, 0.f}, ys[2];
+        Eps es[2];
+        load_x(a.X + row * DF, xs0[0], xs1[0], xts[0]);
+        ys[0] = a.y[row];
+        const uint32_t q0 = skeys[2 * p], q1 = skeys[2 * p + 1];
+        if (two) {
+            load_x(a.X + rowb * DF, xs0[1], xs1[1], xts[1]);
+            ys[1] = a.y[rowb];
+            const uint32_t r0 = skeys[2 * pb], r1 = skeys[2 * pb + 1];
+            es[0] = gen(q0, q1);
+            es[1] = gen(r0, r1);
+            examples(std::integral_constant<int, 2>{}, xs0, xs1, xts, ys, es);
+        } else {
+            es[0] = gen(q0, q1);
+            examples(std::integral_constant<int, 1>{}, xs0, xs1, xts, ys, es);
+        }
     }
     D3P_CSTAMP(5)
+    if (STAMPS && (a.dbg & 0x700) == 0x100 && lane == 0) stamp[wave & 15] = wall_clock64();  // diagnostic: when each WAVE finished its examples
+    // (D3P_DBG = 32 + 256: examples done; + 512: after the logit / sigmoid instead; + 1024: after the z / dot-product loop instead)
 
     // ------------------------------------------------------------------ phase 4: workgroup reduction, atomics, arrival
     // (the wave's row held its noise; both examples are consumed, the row now takes its partial sums: [loc-gradient | scale-
     // gradient] x DL, indexed like the LDS columns)
-    *reinterpret_cast<float4*>(er + c0) = make_float4(accg0[0], accg0[1], accg0[2], accg0[3]);
-    *reinterpret_cast<float4*>(er + c1) = make_float4(accg1[0], accg1[1], accg1[2], accg1[3]);
-    *reinterpret_cast<float4*>(er + DL + c0) = make_float4(acch0[0], acch0[1], acch0[2], acch0[3]);
-    *reinterpret_cast<float4*>(er + DL + c1) = make_float4(acch1[0], acch1[1], acch1[2], acch1[3]);
+    *reinterpret_cast<float4*>(er + c0) = make_float4(accg0.lo.x, accg0.lo.y, accg0.hi.x, accg0.hi.y);
+    *reinterpret_cast<float4*>(er + c1) = make_float4(accg1.lo.x, accg1.lo.y, accg1.hi.x, accg1.hi.y);
+    *reinterpret_cast<float4*>(er + DL + c0) = make_float4(acch0.lo.x, acch0.lo.y, acch0.hi.x, acch0.hi.y);
+    *reinterpret_cast<float4*>(er + DL + c1) = make_float4(acch1.lo.x, acch1.lo.y, acch1.hi.x, acch1.hi.y);
     if (ICPT && lane == 0) { er[TL] = acc_gt; er[DL + TL] = acc_ht; }
-    if (lane == 0) { tail[2 * wave] = loss_acc; tail[2 * wave + 1] = n_acc; }
+    {
+        const float lw = a.inv_obs * (wave_sum(loss_lane) + loss_uni);
+        if (lane == 0) { tail[2 * wave] = lw; tail[2 * wave + 1] = n_acc; }
+    }
     __syncthreads();
     D3P_CSTAMP(6)
     {
         // fixed-point integer atomics: the exact, order-independent sum of the workgroups' fp32 partials
-        long long* outp = acc_cur + (size_t)(bid % R) * PA;
+        long long* outp = acc_cur + (size_t)(bid % RU) * PA;
         bool bad = false;
+        auto column_sum = [&](int c) {   // W = 16: one parameter column per thread
+            const bool is_scale = c >= D;
+            const int li = lix(is_scale ? c - D : c) + (is_scale ? DL : 0);
+            float sc = 0.f;
+#pragma unroll
+            for (int w = 0; w < W; ++w) sc += red[(size_t)w * 2 * DL + li];
+            bool ok;
+            const long long fx = fixed_point_rn(sc, a.sg, ok);
+            bad |= !ok;
+            if (!(STAMPS && (a.dbg & 4))) atomicAdd(reinterpret_cast<unsigned long long*>(outp + c), (unsigned long long)fx);
+        };
         auto column_pair = [&](int e) {  // latent e: columns e (auto_loc) and D + e (auto_scale)
             const int li = lix(e);
             float sL = 0.f, sS = 0.f;
@@ -604,8 +750,14 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
                 atomicAdd(reinterpret_cast<unsigned long long*>(outp + D + e), (unsigned long long)__double2ll_rn(dS));
             }
         };
-        column_pair(tid);
-        if (ICPT && tid == 64) column_pair(D - 1);  // the intercept
+        if (W16) {
+            column_sum(mycol);
+            if (ICPT && tid == 64) column_sum(D - 1);        // the intercept's two columns
+            if (ICPT && tid == 576) column_sum(2 * D - 1);
+        } else {
+            column_pair(tid);
+            if (ICPT && tid == 64) column_pair(D - 1);  // the intercept
+        }
         if (tid < 3) {  // thread 0: loss, fine part; 1: example count; 2: loss, coarse part
             float s = 0.f;
 #pragma unroll
@@ -635,12 +787,24 @@ __global__ void __launch_bounds__(64 * D3P_CHAIN_W) k_logreg_chain(ChainArgs a)
         if (prev + 1u == gsize)  // this group's flag; the waiters poll the flags of all groups
             __hip_atomic_store(bar + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
         if (STAMPS && a.stamps) {
-            stamp[12] = wall_clock64();
-            stamp[13] = (unsigned long long)prev;
+            if (!(a.dbg & 256)) {
+                stamp[12] = wall_clock64();
+                stamp[13] = (unsigned long long)prev;
+            }
             const int rec = step_t - (a.K - 2);
             if (rec >= 0 && bid < 256u)
                 for (int k = 0; k < 16; ++k) a.stamps[((size_t)rec * 256 + bid) * 16 + k] = stamp[k];
         }
+    }
+    // W = 16: the key-chain link of step `step_t` of the NEXT batch, behind the arrival of workgroup 0 (off the step's critical
+    // path; the previous link was made by workgroup 0 of the previous step, behind ITS arrival)
+    if (W16 && bid == 0 && step_t < a.K_next && tid < 64) {
+        uint32_t* progress = a.bar + (size_t)a.K * D3P_BAR_WORDS;
+        bool go = true;
+        if (step_t > 0) go = chain_wait(progress, (uint32_t)step_t, a.status, abort_code(D3P_ABORT_KEY_CHAIN, step_t));
+        if (go) chain_step<true>(a.chain_sched, a.chain_slots + step_t, step_t, step_t == a.K_next - 1);
+        __builtin_amdgcn_s_waitcnt(0);
+        if (tid == 0) __hip_atomic_store(progress, (uint32_t)step_t + 1u, __ATOMIC_RELAXED, D3P_AGENT);
     }
 #undef D3P_CSTAMP
 }
