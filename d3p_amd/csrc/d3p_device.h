@@ -329,7 +329,12 @@ __device__ __forceinline__ float wave_sum(float v)
 
 // softplus(t) = max(t, 0) + log(1 + exp(-|t|)); exp(-|t|) is in (0, 1], so log(1 + e) via v_log_f32 has an
 // absolute error of ~1e-7 (relative to values >= ln 2 * e): inside the stated float32 tolerance.
-__device__ __forceinline__ float softplus_f(float t) { return fmaxf(t, 0.0f) + __logf(1.0f + __expf(-fabsf(t))); }
+// (1 + exp(-|t|) lies in (1, 2]: a normal number, so the raw v_log_f32 (log2) needs none of the denormal scaling and fix-up
+// code __logf carries -- ten instructions, on the critical path of the step kernel's update prologue and of every example)
+__device__ __forceinline__ float softplus_f(float t)
+{
+    return fmaxf(t, 0.0f) + 0.693147180559945309f * __builtin_amdgcn_logf(1.0f + __expf(-fabsf(t)));
+}
 __device__ __forceinline__ float sigmoid_f(float t) { return __builtin_amdgcn_rcpf(1.0f + __expf(-t)); }  // v_rcp_f32: 1 ulp
 
 // Row layout of a fixed-point accumulator replica: P gradient columns (scale 2^40 / C) | loss, fine part | example count |
@@ -354,10 +359,14 @@ __device__ __forceinline__ long long fixed_point_rn(float v, double sg, bool& in
 // the two integer parts of a workgroup's loss partial; false when it is not finite or beyond 2^78
 __device__ __forceinline__ bool loss_split(float s, long long& hi, long long& lo)
 {
+    // (the same two integers as rint / llrint give, through the 1.5 * 2^52 trick of fixed_point_rn: |s 2^-27| < 2^51 and the
+    // remainder times 2^24 is below 2^51 in magnitude, so both roundings are exact integer extractions)
     const double sd = (double)s;
-    const double h = rint(sd * (1.0 / D3P_LOSS_HI_UNIT));
-    hi = __double2ll_rn(h);
-    lo = __double2ll_rn((sd - h * D3P_LOSS_HI_UNIT) * D3P_LOSS_LO_SCALE);
+    const double th = fma(sd, 1.0 / D3P_LOSS_HI_UNIT, 6755399441055744.0);
+    const double h = th - 6755399441055744.0;   // rint(sd 2^-27), ties to even
+    hi = (long long)(__double_as_longlong(th) - 0x4338000000000000ll);
+    const double tl = fma(fma(-h, D3P_LOSS_HI_UNIT, sd), D3P_LOSS_LO_SCALE, 6755399441055744.0);
+    lo = (long long)(__double_as_longlong(tl) - 0x4338000000000000ll);
     return fabs(sd) < 3.0e23;
 }
 

@@ -1116,7 +1116,7 @@ static bool lean_chain_ok(const Ctx& c, bool w16)
 static uint32_t chain16_blocks(uint64_t items)
 {
     static const int env_nw = [] { const char* e = getenv("D3P_CHAIN_NW"); return e ? atoi(e) : 0; }();
-    if (env_nw >= 1 && env_nw <= 1024) return (uint32_t)env_nw;
+    if (env_nw >= 1 && env_nw <= 480) return (uint32_t)env_nw;  // (the slot row of a step holds 512 arrival slots)
     static const uint32_t cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 2)
