@@ -29,6 +29,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, the fp32 matrix (= vector) peak
+SIMDS, SHADER_GHZ = 1024, 2.4   # 256 CUs x 4 SIMD-32; peak shader clock
+# wave64 VALU issue: MI355X_MICROARCH.md gives 2 cycles per plain fp32 instruction per SIMD; profiles/r03_valu_opcodes.json
+# measures 1.66 (VOP2 add / xor / fmac), 2.06 (v_fma_f32), 2.66 (VOP3 integer, DPP), 4.67 (transcendental) at 4 waves per SIMD
+VALU_PEAK_GINSTR = SIMDS * SHADER_GHZ / 2.0
 
 
 def algorithmic_bytes(B, d, P):
@@ -125,6 +130,135 @@ def spawn_ranks(n):
     return rc
 
 
+def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
+    """The other BASELINE workloads, each a short leg (<= ~3 s) with its own roofline, so that the driver's line witnesses them:
+    config 3 (mixture model K=16 d=64 B=8192 N=1e7), config 5 (VAE 784-400-50 and the literal [400, 200] variant, B=4096) and
+    the north_star's Poisson sampler at N=1e7.  `table7`: the resident (X, y) of the 1e7-row logistic-regression table."""
+    import torch
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import poisson_batchify_data, subsample_batchify_data
+    from d3p_amd.models import (Adam, AutoDiagonalNormal, GaussianMixtureGuide, GaussianMixtureModel, LogisticRegression, Trace_ELBO,
+                                VAEGuide, VAEModel)
+    from d3p_amd.svi import DPSVI, DPSVIState
+    out = {}
+
+    def timed(fn, warm, steps):
+        """`fn(first, k)` enqueues k steps; wall time between two device synchronisations + HIP events on the launch stream."""
+        fn(0, warm)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        fn(warm, steps)
+        e1.record()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, e0.elapsed_time(e1) * 1e-3
+
+    if "gmm" in want:
+        K, d, B, N = 16, 64, 8192, 10_000_000
+        g = torch.Generator(device=dev).manual_seed(7)
+        comp = torch.randint(0, 3, (N, 1), generator=g, device=dev).float()            # examples/gaussian_mixture_model.py:91-93,
+        X = torch.randn(N, d, generator=g, device=dev) + 4.0 * (comp - 1.0)          # three well-separated components
+        del comp
+        model = GaussianMixtureModel()
+        svi = DPSVI(model, GaussianMixtureGuide(model), Adam(1e-3), Trace_ELBO(), 20.0, 1.0, k=K, d=d, num_obs_total=N)
+        _, gb = subsample_batchify_data((X,), B)
+        bkey = rng.PRNGKey(5)
+        st = [svi.init(rng.PRNGKey(0), X[:B])]
+
+        def run(first, k):
+            st[0], losses = svi.run_steps(st[0], gb, bkey, first, k)
+            run.loss = losses[-1]
+        steps = 256
+        wall, ev = timed(run, 64, steps)
+        P = K + K * d
+        alg = B * (4 * d + 4) + 3 * 4 * P                          # SURVEY 8(d): 2 175 168 B per step
+        # wave64 VALU instructions per step, measured with SQ_INSTS_VALU (profiles/r02_gmm_pmc.json: k_gmm_px 22.5 M, k_gmm_head 3.2 M)
+        valu = 25.7e6
+        out["gmm_config3"] = {
+            "workload": "BASELINE configs[2]: mixture model K=16 d=64, N=1e7 rows resident, batch 8192 (Feistel), C=20, sigma=1, Adam 1e-3",
+            "steps": steps, "warmup": 64, "steps_per_sec": round(steps / wall, 2), "value": round(B * steps / wall, 1),
+            "unit": "examples/s", "us_per_step": round(1e6 * ev / steps, 3), "final_loss": float(run.loss),
+            "roofline": {"bound": "valu", "achieved": round(valu * steps / ev / 1e9, 2), "peak": VALU_PEAK_GINSTR, "unit": "Ginstr/s (wave64)",
+                         "frac": round(valu * steps / ev / 1e9 / VALU_PEAK_GINSTR, 4),
+                         "valu_instructions_per_step": valu, "instruction_count_source": "profiles/r02_gmm_pmc.json (SQ_INSTS_VALU of "
+                         "k_gmm_px + k_gmm_head); not re-counted in this run",
+                         "hbm": {"algorithmic_bytes_per_step": alg, "achieved_GBps": round(alg * steps / ev / 1e9, 2),
+                                 "frac": round(alg * steps / ev / 1e9 / HBM_PEAK_GBPS, 5)},
+                         "timing": "HIP events on the launch stream around the whole 256-step device-resident run (2 launches per "
+                                   "step + the per-64-step preparation)"}}
+        del X, gb, svi, st
+        torch.cuda.empty_cache()
+
+    for tag, H2 in (("vae", 0), ("vae2", 200)):
+        if tag not in want:
+            continue
+        N, B, D, H, Z = 60000, 4096, 784, 400, 50
+        X = (torch.rand(B, 28, 28, generator=torch.Generator().manual_seed(0)) < 0.3).float().to(dev)
+        model = VAEModel(scale=1.0 / N)
+        svi = DPSVI(model, VAEGuide(model), Adam(1e-3), Trace_ELBO(), 10.0, 1.0, num_obs_total=N, z_dim=Z,
+                    hidden_dim=(H, H2) if H2 else H)
+        st = [svi.init(rng.PRNGKey(0), X)]
+
+        def run(first, k):
+            for _ in range(k):
+                st[0], run.loss = svi.update(st[0], X)
+        steps = 40
+        wall, ev = timed(run, 8, steps)
+        hs = [H] + ([H2] if H2 else [])
+        dec, enc = [Z] + hs[::-1] + [D], [D] + hs
+        layers = list(zip(dec[:-1], dec[1:])) + list(zip(enc[:-1], enc[1:])) + [(hs[-1], 2 * Z)]
+        # every dense layer: forward, backward-data, weight-gradient product of 2 B in out flops; the first encoder layer has no
+        # backward-data product
+        flops = 2 * B * (3 * sum(i * o for i, o in layers) - D * H)
+        Pn = int(st[0].optim_state[1].numel())
+        out["vae_config5" + ("_400_200" if H2 else "")] = {
+            "workload": "BASELINE configs[4]: VAE 784 -> %s -> 50 (P = %d), batch 4096, C=10, sigma=1, Adam 1e-3; one DPSVI.update "
+                        "(~30 launches) per step" % (hs, Pn),
+            "steps": steps, "warmup": 8, "steps_per_sec": round(steps / wall, 2), "value": round(B * steps / wall, 1),
+            "unit": "examples/s", "us_per_step": round(1e6 * ev / steps, 2), "final_loss": float(run.loss),
+            "roofline": {"bound": "mfma", "achieved": round(flops * steps / ev / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(flops * steps / ev / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "gemm_flop_per_step": flops,
+                         "dtype": "f32 (v_mfma_f32_32x32x2_f32: the reference computes in float32)",
+                         "timing": "HIP events on the launch stream around 40 consecutive updates (all kernels of a step, not only "
+                                   "the matrix products)"}}
+        del X, svi, st
+        torch.cuda.empty_cache()
+
+    if "poisson" in want and table7 is not None:
+        X7, y7 = table7
+        N, d = X7.shape
+        B = 4096
+        model = LogisticRegression(d, prior_scale=1.0)
+        svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-3), Trace_ELBO(), 1.0, 1.0, num_obs_total=N)
+        params = torch.cat([torch.zeros(d, device=dev), torch.full((d,), svi.guide.unconstrained_init_scale(), device=dev)])
+        st = [DPSVIState(svi.optim.init(params), rng.PRNGKey(0), float(N))]
+        _, gb = poisson_batchify_data((X7, y7), B / N, 0.99)                 # examples/logistic_regression.py:126-127
+        bkey = rng.PRNGKey(1)
+
+        def run(first, k):
+            st[0], losses = svi.run_steps(st[0], gb, bkey, first, k)
+            run.loss = losses[-1]
+        steps = 256
+        wall, ev = timed(run, 128, steps)
+        blocks = (N + 15) // 16
+        lane_ops = blocks * 980.0            # SURVEY 8(d): ~980 32-bit integer operations per 64-byte ChaCha20 block
+        peak = SIMDS * 64 * SHADER_GHZ * 1e9 / 2.0   # lane-operations per second at 2 cycles per wave64 integer instruction
+        out["poisson_N1e7"] = {
+            "workload": "north_star sampler: logistic regression d=512 over N=1e7 resident rows, Poisson batches q = 4096 / N padded "
+                        "to the 0.99 quantile (N / 16 ChaCha20 blocks + an ordered compaction over N per step, fused: the keystream "
+                        "never reaches HBM)",
+            "steps": steps, "warmup": 128, "steps_per_sec": round(steps / wall, 2), "value": round(B * steps / wall, 1),
+            "unit": "examples/s (expected batch 4096)", "us_per_step": round(1e6 * ev / steps, 3), "final_loss": float(run.loss),
+            "roofline": {"bound": "valu", "achieved": round(lane_ops * steps / ev / 1e12, 3), "peak": round(peak / 1e12, 2),
+                         "unit": "T integer lane-operations/s (ChaCha20 keystream of the Bernoulli mask)",
+                         "frac": round(lane_ops * steps / ev / peak, 4), "chacha_blocks_per_step": blocks,
+                         "keystream_bytes_per_step": 4 * N,
+                         "note": "whole step (mask + compaction + the DP-VI step) over the mask's integer work alone",
+                         "timing": "HIP events on the launch stream around the 256-step device-resident run"}}
+    return out
+
+
 class RunStopped(RuntimeError):
     """A data-parallel run that a bounded wait stopped (d3p_dpvi_logreg_run_status): its numbers are not measurements."""
 
@@ -143,6 +277,8 @@ def main():
                     help="skip the extra leg that times the same step kernel at batch 32768 (throughput regime)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the steady_state and north_star_N1e7 legs (profiling runs)")
+    ap.add_argument("--no-aux-workloads", action="store_true",
+                    help="skip the legs for the other BASELINE workloads (mixture model, VAE, Poisson sampler at N = 1e7)")
     ap.add_argument("--steady-steps", type=int, default=4096)
     ap.add_argument("--sampler", choices=["feistel", "poisson"], default="feistel",
                     help="feistel = subsample_batchify_data w/o replacement (headline); poisson = poisson_batchify_data "
@@ -308,6 +444,8 @@ def main():
                 "avg_launch_us": round(us / launches, 3), "launches": launches, "steps_per_launch": round(ksteps / launches, 3),
                 "algorithmic_bytes_per_step": alg_step}
 
+    aux = {}   # the other BASELINE workloads (single-GPU runs): filled by measure()
+
     def measure(native, extra_legs):
         """All GPU legs with one driver; returns the fields of the JSON line (rank 0) or None."""
         n_rows = args.rows_per_gpu * ranks
@@ -353,10 +491,18 @@ def main():
                                            "(FETCH doubled per the gfx950 correction); not re-measured in this run"}
                 except Exception:  # noqa: BLE001
                     traffic, traffic_src = None, None
+            if chained:
+                kname = ("k_logreg_chain<PLIST, STAMPS=0, ICPT=0, XCHG=0, W=16> (chained launch: the <= 128 DP-VI steps of a prepared batch "
+                         "per launch, 128 sixteen-wave workgroups per step; k_logreg_main<MODE 3> for shapes other than d = 512)")
+            elif isinstance(comm, ddist.XchgComm) and native and not os.environ.get("D3P_XCHG_PER_STEP"):
+                kname = ("k_logreg_chain<PLIST=1, STAMPS=0, ICPT=0, XCHG=1, W=8> (data-parallel chained launch: per step 256 compute "
+                         "workgroups + 1 key-chain + 2 exchange workgroups that carry the one-shot full-mesh sum-exchange over xGMI)")
+            elif comm is not None and native:
+                kname = "k_logreg_main<MODE 2> (one launch per DP-VI step) + the step's collective (k_xchg or ncclAllReduce) on the same stream"
+            else:
+                kname = "k_logreg_main<MODE 2> (one launch per DP-VI step; torch.distributed.all_reduce between the launches)"
             roofline = {"bound": "hbm",
-                        "kernel": ("k_logreg_chain (chained launch: the <= 128 DP-VI steps of a prepared batch per launch; "
-                                   "k_logreg_main<MODE 3> for shapes other than d = 512 without intercept)" if chained
-                                   else "k_logreg_main<MODE 2> (one launch per DP-VI step)"),
+                        "kernel": kname,
                         "achieved": krec["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": krec["frac"],
                         "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": round(krec["algorithmic_bytes_per_step"] * krec["steps_per_launch"], 1),
@@ -386,6 +532,8 @@ def main():
                          "steps_per_sec": round(sps, 2), "value": round(Bg * sps, 1), "ms_per_step": round(1000.0 * el7 / 2048, 6),
                          "kernel": kernel_record(kt7, Bg // ranks),
                          "note": "north_star's table size (N = 10M rows, row-sharded over the ranks); same batch per GPU"}
+            if single and rank == 0 and not args.no_aux_workloads:
+                aux.update(aux_workloads(dev, table7, want=("poisson",)))
             del table7, run7, st7, svi7
             torch.cuda.empty_cache()
 
@@ -410,12 +558,16 @@ def main():
                                            "note": "same kernel and method, 320 steps at batch 32768 on one GPU (8 examples per "
                                                    "wave): the instruction-issue regime of the fused step with JAX-faithful noise"}
             del Xl, yl, gb_l, st_l, svi_l
+        if single and rank == 0 and extra_legs and not args.no_aux_workloads:
+            aux.update(aux_workloads(dev, None, want=("gmm", "vae", "vae2")))
         if rank != 0:
             return None
-        return {"value": round(Bg * steps_per_s, 1), "steps_per_sec": round(steps_per_s, 2),
+        B_done = Bg // emu if emu else Bg   # (--emulate-world runs ONE rank's share: the examples this GPU processed, not the job's)
+        return {"value": round(B_done * steps_per_s, 1), "steps_per_sec": round(steps_per_s, 2),
                 "ms_per_step": round(1000.0 * elapsed / args.steps, 6), "final_loss": final_loss, "steady_state": steady,
                 "north_star_N1e7": north, "roofline": roofline, "rows": n_rows,
-                "leg_order": ("steady_state, headline, north_star_N1e7, large_batch" if extra_legs else "headline only (cold GPU)"),
+                "leg_order": ("steady_state, headline, north_star_N1e7 (+ poisson_N1e7 on the same table), large_batch, gmm_config3, "
+                              "vae_config5, vae_config5_400_200" if extra_legs else "headline only (cold GPU)"),
                 "driver": "single-GPU chained launch" if single else (dist_driver if (native and comm is not None) else "torch")}
 
     def line(m, cpu=None, extra=None):
@@ -434,7 +586,11 @@ def main():
             "final_loss": m["final_loss"], "steady_state": m["steady_state"], "north_star_N1e7": m["north_star_N1e7"],
             "leg_order": m.get("leg_order"),
             "roofline": m["roofline"], "cpu_baseline": cpu,
+            "workloads": aux or None,
         }
+        if emu:
+            out["note_emulate_world"] = (f"developer run: rank 0's share of an emulated {emu}-rank weak-scaling job on ONE GPU (exchange with "
+                                         "itself); `value` counts the examples this GPU processed")
         if extra:
             out.update(extra)
         return json.dumps(out)
@@ -471,10 +627,6 @@ def main():
             extra = {"torch_loop": {"steps_per_sec": fb["steps_per_sec"], "value": fb["value"],
                                     "note": "same steps driven from Python through torch.distributed.all_reduce"}}
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(d, args.batch_per_gpu, args.cpu_seconds, rows=200_000)
-
     if dist.is_initialized():
         dist.barrier()
         if comm is not None:
@@ -482,6 +634,11 @@ def main():
         dist.destroy_process_group()
     elif comm is not None:
         comm.close()
+    # the CPU baseline: rank 0 only, after every GPU leg and after the ranks have left the process group (the other ranks are
+    # gone or idle: the host cores are rank 0's); the same bounded sample at every N -- per-GPU work is fixed (weak scaling)
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(d, args.batch_per_gpu, args.cpu_seconds, rows=200_000)
     if rank == 0:
         print(line(m, cpu, extra), flush=True)
 

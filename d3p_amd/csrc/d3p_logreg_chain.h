@@ -323,7 +323,8 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     // W = 16: thread tid owns ONE parameter column -- auto_loc of latent tid (tid < 512) or auto_scale of latent tid - 512
     // (ICPT: the intercept's two columns D - 1 and 2 D - 1 are second columns of threads 64 and 576)
     const int mycol = W16 ? (tid < DF ? tid : D + (tid - DF)) : tid;
-    float zL = 0.f, zS = 0.f, bc1 = 1.f, bc2 = 1.f;
+    const int xcol = (W16 && ICPT) ? (tid == 64 ? D - 1 : tid == 576 ? 2 * D - 1 : -1) : -1;   // a second column of this thread
+    float zL = 0.f, zS = 0.f, zX = 0.f, bc1 = 1.f, bc2 = 1.f;
     // W = 16: everything of the pending update that does not depend on the sums is computed HERE, before the release: the valid
     // example count of the pending step is a function of the keys (the sampler left it in the step's slot; the count column of
     // the accumulator is only looked at for the non-finite marker), so svi.py:305's factor, the noise scale of svi.py:365 and
@@ -332,6 +333,7 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     if (apply_prev) {  // Gaussian-mechanism normals of this thread's column(s) and the bias corrections
         zL = prev_noise[mycol];
         if (!W16) zS = prev_noise[D + tid];
+        if (xcol >= 0) zX = prev_noise[xcol];
         bc1 = ps->bc1;
         bc2 = ps->bc2;
         if (W16) {
@@ -420,28 +422,34 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
         // W = 16: one parameter column c (c < D: auto_loc of latent c, else auto_scale of latent c - D): its pending update
         // and its derived LDS entries.  Same arithmetic per column as the two-column form below.
         long long nll_main = 0;  // example count of the pending step (summed in the thread's main column call, all lanes active)
-        auto column = [&](int c, float z, bool main_call) {
+        // (loads and arithmetic are separate steps so that a thread with two columns -- ICPT: the intercept's -- has the loads of
+        // both in flight together: one memory round trip, not two, between the release and the staging barrier)
+        struct ColData { long long s8[RU]; float x, m, v; };
+        auto col_load = [&](int c) {
+            ColData d;
+            if (apply_prev) {
+#pragma unroll
+                for (int r = 0; r < RU; ++r) d.s8[r] = __hip_atomic_load(sums + (size_t)r * PA + c, __ATOMIC_RELAXED, D3P_AGENT);
+                d.x = __hip_atomic_load(a.state[in][0] + c, __ATOMIC_RELAXED, D3P_AGENT);
+                d.m = __hip_atomic_load(a.state[in][1] + c, __ATOMIC_RELAXED, D3P_AGENT);
+                d.v = __hip_atomic_load(a.state[in][2] + c, __ATOMIC_RELAXED, D3P_AGENT);
+            } else {
+#pragma unroll
+                for (int r = 0; r < RU; ++r) d.s8[r] = 0;
+                d.x = a.state[in][0][c];
+                d.m = d.v = 0.f;
+            }
+            return d;
+        };
+        auto col_apply = [&](int c, const ColData& d, float z) {
             const bool is_scale = c >= D;
             const int e = is_scale ? c - D : c;
-            float x;
+            float x = d.x;
             if (apply_prev) {
-                long long s8[RU];
-#pragma unroll
-                for (int r = 0; r < RU; ++r) s8[r] = __hip_atomic_load(sums + (size_t)r * PA + c, __ATOMIC_RELAXED, D3P_AGENT);
-                x = __hip_atomic_load(a.state[in][0] + c, __ATOMIC_RELAXED, D3P_AGENT);
-                float m = __hip_atomic_load(a.state[in][1] + c, __ATOMIC_RELAXED, D3P_AGENT);
-                float v = __hip_atomic_load(a.state[in][2] + c, __ATOMIC_RELAXED, D3P_AGENT);
-                // the example count: ONE load instruction per wave (lane r < RU reads replica r's count column), summed over the lanes
-                long long nr = 0;
-                if (main_call) nr = __hip_atomic_load(sums + (size_t)(lane < RU ? lane : 0) * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT);
+                float m = d.m, v = d.v;
                 long long sm = 0;
 #pragma unroll
-                for (int r = 0; r < RU; ++r) sm += s8[r];
-                if (main_call) {
-#pragma unroll
-                    for (int r = 0; r < RU; ++r)
-                        nll_main += ((long long)__builtin_amdgcn_readlane((int)(nr >> 32), r) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)nr, r);
-                }
+                for (int r = 0; r < RU; ++r) sm += d.s8[r];
                 // (a workgroup that saw a non-finite partial added 2^44 to the count column: NaN from here on, like float sums)
                 const float poison = nll_main >= (1ll << 40) ? __builtin_nanf("") : 0.0f;
                 n = pre_n + poison;
@@ -461,8 +469,6 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
                     __hip_atomic_store(a.state[out][1] + c, m, __ATOMIC_RELAXED, D3P_AGENT);
                     __hip_atomic_store(a.state[out][2] + c, v, __ATOMIC_RELAXED, D3P_AGENT);
                 }
-            } else {
-                x = a.state[in][0][c];
             }
             const int li = lix(e);
             if (!is_scale) {
@@ -533,9 +539,18 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             lc_mine += ((ICPT && e == D - 1) ? a.log_prior_b : a.log_prior) - __logf(sp);
         };
         if (W16) {
-            column(mycol, zL, true);
-            if (ICPT && tid == 64) column(D - 1, apply_prev ? prev_noise[D - 1] : 0.f, false);           // the intercept's auto_loc
-            if (ICPT && tid == 576) column(2 * D - 1, apply_prev ? prev_noise[2 * D - 1] : 0.f, false);  // ... and auto_scale
+            const ColData d1 = col_load(mycol);
+            ColData d2 = {};
+            if (xcol >= 0) d2 = col_load(xcol);
+            if (apply_prev) {
+                // the example count: ONE load instruction per wave (lane r < RU reads replica r's count column), summed over the lanes
+                const long long nr = __hip_atomic_load(sums + (size_t)(lane < RU ? lane : 0) * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT);
+#pragma unroll
+                for (int r = 0; r < RU; ++r)
+                    nll_main += ((long long)__builtin_amdgcn_readlane((int)(nr >> 32), r) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)nr, r);
+            }
+            col_apply(mycol, d1, zL);
+            if (xcol >= 0) col_apply(xcol, d2, zX);   // ICPT: the intercept's auto_loc (thread 64) / auto_scale (thread 576)
         } else {
             latent(tid, zL, zS);
             if (ICPT && tid == 1) latent(D - 1, apply_prev ? prev_noise[D - 1] : 0.f, apply_prev ? prev_noise[2 * D - 1] : 0.f);  // the intercept
