@@ -565,12 +565,20 @@ def test_xchg_virtual_ranks_on_streams_match_the_single_rank_run(gpu, world):
 
 
 @pytest.mark.gpu
-def test_xchg_two_processes_over_hipipc(gpu):
-    """The real thing -- one process per GPU, inboxes mapped through hipIpc handles (tools/xchg_two_rank_check.py spawns the
-    ranks itself and compares with the single-rank run).  Needs two GPUs; the build's boxes have one, where the same script
-    was run by hand with both ranks on cuda:0."""
+@pytest.mark.parametrize("form", ["in_launch", "per_step"])
+def test_xchg_two_processes_over_hipipc(gpu, form):
+    """The real thing -- one PROCESS per rank, inboxes mapped through hipIpc handles, system-scope rows across the process
+    boundary (tools/xchg_two_rank_check.py spawns the two ranks itself, compares their replicas bit for bit after every run and
+    rank 0's result with the single-rank run).  One process per GPU where two GPUs exist; on a one-GPU box both ranks share
+    cuda:0 -- every protocol step is the same, only the link is not xGMI.  `in_launch`: the exchange rides inside the chained
+    launch (two more workgroups per step), so the ranks' launches must be co-resident: 12 steps x 19 workgroups per launch
+    leave two thirds of the GPU to the other rank, three consecutive runs on one exchange (both slot
+    parities, tags of earlier runs in the slots); `per_step`: one exchange launch behind every step launch."""
     import subprocess
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs 2 GPUs (one process per GPU over xGMI)")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "xchg_two_rank_check.py")], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, D3P_XCHG_CHECK_STEPS="12", D3P_XCHG_CHECK_REPEAT="3")
+    if form == "per_step":
+        env["D3P_XCHG_PER_STEP"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "xchg_two_rank_check.py")], capture_output=True, text=True,
+                       timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '"xchg_two_rank_check": "ok"' in r.stdout, r.stdout[-2000:]

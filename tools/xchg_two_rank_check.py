@@ -29,7 +29,7 @@ def rank_main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(rank if torch.cuda.device_count() >= world else 0)
-    n, d, B, steps = 6000, 512, 512, 24   # (both ranks may share ONE GPU here: 24 x 19 workgroups per launch leave room for the
+    n, d, B, steps = 6000, 512, 512, int(os.environ.get("D3P_XCHG_CHECK_STEPS", "24"))   # (both ranks may share ONE GPU here: 24 x 19 workgroups per launch leave room for the
     #  other rank's launch beside the first one's; at 40 steps the first launch fills the GPU, see tests/test_dist.py)
     g = torch.Generator().manual_seed(5)
     X = torch.randn(n, d, generator=g)
@@ -82,9 +82,10 @@ def rank_main():
             ref, ref_l = ddist.run_steps_native(single, st0, rng.PRNGKey(4), 2, steps * repeats, comm=None)
             ref_l = ref_l[-steps:]
             ok &= np.array_equal(ref.rng_key.cpu().numpy(), res[0][2])
-            if repeats == 1:   # (over many runs the two summation orders drift apart by more than rounding; the replicas may not)
-                ok &= np.allclose(ref_l.cpu().numpy(), res[0][1], rtol=2e-5, atol=0)
-                ok &= np.allclose(ref.optim_state[1].cpu().numpy(), res[0][0], rtol=2e-5, atol=2e-6)
+            if repeats <= 4:   # (over many runs the two summation orders drift apart by more than rounding; the replicas may not)
+                tol = 2e-5 * repeats
+                ok &= np.allclose(ref_l.cpu().numpy(), res[0][1], rtol=tol, atol=0)
+                ok &= np.allclose(ref.optim_state[1].cpu().numpy(), res[0][0], rtol=tol, atol=2e-6 * repeats)
             print(json.dumps({"xchg_two_rank_check": "ok" if ok else "MISMATCH", "devices": torch.cuda.device_count(),
                               "final_loss": float(res[0][1][-1])}), flush=True)
         dist.barrier()
