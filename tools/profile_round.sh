@@ -1,9 +1,9 @@
 # Round profile of the headline bench (run on the GPU box through gpurun): rocprofv3 kernel stats, then the two PMC
 # passes for HBM traffic (separate passes, MI355X_MICROARCH.md section HBM), then the unprofiled bench line.
-# usage: PROFILE_TAG=r02 bash tools/profile_round.sh    (outputs under gpurun_out/$PROFILE_TAG; copy what is judged to profiles/)
+# usage: PROFILE_TAG=r03 bash tools/profile_round.sh    (outputs under gpurun_out/$PROFILE_TAG; copy what is judged to profiles/)
 set -ex
 R=$(cd "$(dirname "$0")/.." && pwd)
-T=${PROFILE_TAG:-r02}
+T=${PROFILE_TAG:-r03}
 O=$R/gpurun_out/$T
 COMMIT=${PROFILE_COMMIT:-unknown}
 rm -rf $O; mkdir -p $O
@@ -11,7 +11,19 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $T -- python3 $R/bench.py --steps 2048 --warmup 256 --no-cpu-baseline --no-large-batch --no-extra-legs > $O/bench_under_rocprof.json 2> $O/stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python3 $R/bench.py --steps 384 --warmup 128 --no-cpu-baseline --no-large-batch --no-extra-legs > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python3 $R/bench.py --steps 384 --warmup 128 --no-cpu-baseline --no-large-batch --no-extra-legs > /dev/null 2> $O/pmc_write.err
+# every leg of the driver's command (headline, steady state, N = 1e7, Poisson sampler, batch 32768, mixture model, both VAE shapes)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_all -o ${T}_all -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_all_legs_under_rocprof.json 2> $O/stats_all.err
 cd $R
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json 512 ${T}_pmc_traffic.json $COMMIT > /dev/null 2> $O/pmc_traffic.err
 python3 bench.py > $O/bench.json 2> $O/bench.err
-ls -R $O | head -40
+# what is judged: copies under profiles/ (tracked)
+P=$R/gpurun_out/${T}_profiles; rm -rf $P; mkdir -p $P
+cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $P/${T}_kernel_stats.csv
+cp $(find $O/stats_all -name "*kernel_stats.csv" | head -1) $P/${T}_kernel_stats_all_legs.csv
+cp $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $P/${T}_pmc_FETCH_SIZE_raw.csv || true
+cp $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $P/${T}_pmc_WRITE_SIZE_raw.csv || true
+cp $O/pmc_traffic.json $P/${T}_pmc_traffic.json
+cp $O/bench_under_rocprof.json $P/${T}_bench_under_rocprof.json
+cp $O/bench_all_legs_under_rocprof.json $P/${T}_bench_all_legs_under_rocprof.json
+cp $O/bench.json $P/${T}_bench.json
+ls -la $P
