@@ -139,6 +139,7 @@ SIGNATURES = {
     "d3p_vae_evaluate": (C.c_int, [_V, _V, _V, _V, _U32, _V, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_vae_update": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _V, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_vae_update_from": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _U32, _V, _V, _V, _V, C.c_size_t]),
+    "d3p_dpvi_vae_run": (C.c_int, [_V, _V, _V, _V, _V, _U32, _V, _U32, _U32, _U32, _V, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_gmm_local_sums": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _U32, _U32, _V, _V, C.c_size_t]),
     "d3p_dpvi_gmm_apply": (C.c_int, [_V, _V, _V, _V, _V, _U32, _U32, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_vae_local_sums": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _U32, _U32, _V, _V, _V, C.c_size_t]),
@@ -199,7 +200,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.d3p_abi_version() != 5:
+        if lib.d3p_abi_version() != 6:
             raise D3PError("libd3p_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -1415,4 +1415,32 @@ int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsv
                           w_splits);
 }
 
+// num_steps x (get_batch(first_batch + t, batch_key) of subsample_batchify_data -> update) on the resident data set X_dev
+// (n_rows x D): the body of the example's jit(fori_loop(...)) epoch (examples/vae.py:227-246) -- per step fold_in, the Feistel
+// indices, the row gather into xb_dev (B x D) and the update, all enqueued back to back: no host work depends on a result.
+// `state` is advanced in place (its key_slot field says which slot of state->rng_key holds the key BEFORE the run; afterwards
+// the key is in slot (key_slot + num_steps) & 1).  idx_dev: B uint32 + 16 (the step's batch key).
+int d3p_dpvi_vae_run(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                     const uint32_t* batch_key_dev, uint32_t first_batch, const float* X_dev, uint32_t n_rows, uint32_t B,
+                     uint32_t num_steps, float* losses_dev, float* xb_dev, uint32_t* idx_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_run")) return rc;
+    D3P_REQUIRE(batch_key_dev && X_dev && xb_dev && idx_dev, "d3p_dpvi_vae_run: null pointer");
+    D3P_REQUIRE(B >= 1 && B <= n_rows, "d3p_dpvi_vae_run: need 1 <= B <= n_rows");
+    if (workspace_bytes < d3p_dpvi_vae_workspace(model, B)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_run: workspace too small");
+    d3p_dpsvi_state st = *state;
+    uint32_t* step_key = idx_dev + B;
+    for (uint32_t t = 0; t < num_steps; ++t) {
+        int rc;
+        if ((rc = d3p_rng_fold_in(stream, batch_key_dev, first_batch + t, step_key))) return rc;          // minibatch.py:230
+        if ((rc = d3p_feistel_sample(stream, step_key, n_rows, B, idx_dev))) return rc;                   // minibatch.py:231
+        if ((rc = d3p_take_rows(stream, X_dev, n_rows, (uint32_t)(model->D * sizeof(float)), idx_dev, B, nullptr, xb_dev))) return rc;
+        if ((rc = d3p_dpvi_vae_update(stream, model, hyper, &st, xb_dev, nullptr, B, nullptr, losses_dev ? losses_dev + t : nullptr,
+                                      nullptr, workspace_dev, workspace_bytes)))
+            return rc;
+        st.key_slot ^= 1;
+    }
+    return D3P_OK;
+}
+
 }  // extern "C"

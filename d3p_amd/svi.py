@@ -664,6 +664,47 @@ class DPSVI:
         return (DPSVIState((step, params, m, v), keybuf[num_steps & 1].reshape(4, 4), svi_state.observation_scale),
                 losses[:num_steps])
 
+    def _run_steps_stepwise(self, svi_state, get_batch, batchifier_state, first_batch, num_steps, **kwargs):
+        """``num_steps`` x (``get_batch`` -> ``update``) through the public calls: what ``run_steps`` does for batchifiers and
+        model / optimiser combinations that have no native loop.  Returns ``(new_state, losses[num_steps])``."""
+        losses = []
+        for t in range(int(num_steps)):
+            out = get_batch(int(first_batch) + t, batchifier_state)
+            if isinstance(out, tuple) and len(out) == 2 and isinstance(out[0], tuple):   # (batch_tuple, mask)
+                svi_state, loss = self.update(svi_state, *out[0], mask=out[1], **kwargs)
+            else:
+                svi_state, loss = self.update(svi_state, *out, **kwargs)
+            losses.append(loss.reshape(()))
+        dev = losses[0].device if losses else svi_state.optim_state[1].device
+        return svi_state, (torch.stack(losses) if losses else torch.empty(0, dtype=torch.float32, device=dev))
+
+    def _run_steps_vae(self, svi_state, info, batchifier_state, first_batch, num_steps, **kwargs):
+        """The VAE's epoch body (examples/vae.py:227-246) as ONE native call: per step fold_in, the Feistel indices, the row
+        gather and the update (~35 launches), enqueued back to back by d3p_dpvi_vae_run."""
+        _lib.require_device()
+        lib = _lib.load()
+        X = self._vae_flat(info.dataset[0])
+        if not (X.is_contiguous() and X.dtype == torch.float32):
+            raise _lib.D3PError("run_steps: dataset arrays must be contiguous float32 CUDA tensors")
+        N, D = X.shape
+        B = int(info.batch_size)
+        dev = X.device
+        vm = self._vae_struct(D, kwargs, svi_state.observation_scale)
+        hyper = self._hyper()
+        step, params, m, v = _fresh_optim_state(svi_state.optim_state)
+        keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
+        keybuf[0].copy_(svi_state.rng_key.reshape(16))
+        bkey = batchifier_state.contiguous()
+        st = self._state_struct(keybuf, 0, (step, params, m, v))
+        ws = self._workspace(lib.d3p_dpvi_vae_workspace(C.byref(vm), B), dev, "vae_step")
+        xb = torch.empty((B, D), dtype=torch.float32, device=dev)
+        idx = torch.empty(B + 16, dtype=torch.uint32, device=dev)
+        losses = torch.empty(max(int(num_steps), 1), dtype=torch.float32, device=dev)
+        check(lib.d3p_dpvi_vae_run(stream_ptr(), C.byref(vm), C.byref(hyper), C.byref(st), ptr(bkey), int(first_batch), ptr(X), int(N), B,
+                                   int(num_steps), ptr(losses), ptr(xb), ptr(idx), ptr(ws), ws.numel()))
+        return (DPSVIState((step, params, m, v), keybuf[int(num_steps) & 1].reshape(4, 4), svi_state.observation_scale),
+                losses[:int(num_steps)])
+
     def update(self, svi_state, *args, mask=True, **kwargs):
         """One DP-VI step on a batch; returns ``(new_state, loss)`` (svi.py:395-434)."""
         if self._gmm_fusable():
@@ -728,21 +769,30 @@ class DPSVI:
     def run_steps(self, svi_state, get_batch, batchifier_state, first_batch, num_steps, check_status=True, **kwargs):
         """``num_steps`` x (get_batch(i, batchifier_state) -> update) for i = first_batch..., enqueued
         back to back on the device: the body of the reference's ``jit(lax.fori_loop(...))`` epoch
-        (examples/logistic_regression.py:149-160).  ``get_batch`` must come from
-        ``subsample_batchify_data`` (without replacement) or ``poisson_batchify_data``.
-        Returns ``(new_state, losses[num_steps])``.
+        (examples/logistic_regression.py:149-160, examples/vae.py:227-246).  Batchifiers of ``subsample_batchify_data``
+        (without replacement) and ``poisson_batchify_data`` run as native device-resident loops (logistic regression /
+        Gaussian mean: chained launches; mixture model and VAE: one native call for the whole run); everything else
+        (sampling with replacement, ``split_batchify_data``, other rng suites or optimisers) runs the same steps through
+        ``get_batch`` + ``update``.  Returns ``(new_state, losses[num_steps])``.
 
         ``check_status`` (default): synchronise the stream once after the run and read the run's status words
         (``d3p_dpvi_logreg_run_status``); a run whose chained launch was aborted by a bounded wait raises ``D3PError``
         instead of returning a silently truncated trajectory.  ``check_status=False`` keeps the call asynchronous; the
         caller then checks with ``DPSVI.last_run_status()`` before trusting the result."""
-        if self._gmm_fusable():
-            return self._run_steps_gmm(svi_state, get_batch, batchifier_state, first_batch, num_steps, **kwargs)
-        if not self._fusable():
-            raise _lib.D3PError("run_steps needs a built model family + diagonal-normal guide + Adam + d3p_amd.random")
         info = getattr(get_batch, "source", None)
-        if info is None or info.rng_suite is not strong_rng:
-            raise _lib.D3PError("run_steps: get_batch must come from d3p_amd.minibatch with rng_suite=d3p_amd.random")
+        if info is None or info.rng_suite is not strong_rng or not (self._gmm_fusable() or self._is_vae() or self._fusable()):
+            # no native loop for this combination (sampling with replacement, split_batchify_data's epochs, another rng_suite,
+            # the stage-wise optimisers): the same steps through the API-parity path -- get_batch + update, one call each,
+            # still without a host synchronisation between them
+            return self._run_steps_stepwise(svi_state, get_batch, batchifier_state, first_batch, num_steps, **kwargs)
+        if self._gmm_fusable():
+            if info.kind != _lib.D3P_BATCH_FEISTEL:
+                return self._run_steps_stepwise(svi_state, get_batch, batchifier_state, first_batch, num_steps, **kwargs)
+            return self._run_steps_gmm(svi_state, get_batch, batchifier_state, first_batch, num_steps, **kwargs)
+        if self._is_vae():
+            if info.kind != _lib.D3P_BATCH_FEISTEL or not (isinstance(self.optim, Adam)):
+                return self._run_steps_stepwise(svi_state, get_batch, batchifier_state, first_batch, num_steps, **kwargs)
+            return self._run_steps_vae(svi_state, info, batchifier_state, first_batch, num_steps, **kwargs)
         _lib.require_device()
         lib = _lib.load()
         X = info.dataset[0]

@@ -34,7 +34,7 @@ extern "C" {
 #define D3P_E_UNSUPPORTED (-3)
 #define D3P_E_WORKSPACE (-4)
 
-#define D3P_ABI_VERSION 5
+#define D3P_ABI_VERSION 6
 
 int d3p_abi_version(void);
 const char* d3p_last_error(void);
@@ -553,6 +553,16 @@ int d3p_dpvi_vae_update_from(void* stream, const d3p_vae_model* model, const d3p
                              const d3p_dpsvi_state* state, const d3p_dpsvi_state* from, const float* X_dev,
                              const uint8_t* mask_dev, uint32_t B, const float* eps_dev, float* loss_dev, float* grad_out_dev,
                              void* workspace_dev, size_t workspace_bytes);
+
+/* num_steps x (get_batch(first_batch + t, batch_key) of subsample_batchify_data -> update) on the resident data set
+ * X_dev (n_rows x D): the body of the example's jit(lax.fori_loop(...)) epoch (examples/vae.py:227-246).  Per step
+ * fold_in, the Feistel indices, the row gather and the update are enqueued back to back; nothing waits for the host.
+ * state is advanced in place: its key is read from slot state->key_slot of state->rng_key (2 x 16 words) and ends up
+ * in slot (key_slot + num_steps) & 1.  xb_dev: B x D floats (the gathered batch); idx_dev: B + 16 uint32.  ABI 6. */
+int d3p_dpvi_vae_run(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                     const uint32_t* batch_key_dev, uint32_t first_batch, const float* X_dev, uint32_t n_rows, uint32_t B,
+                     uint32_t num_steps, float* losses_dev, float* xb_dev, uint32_t* idx_dev, void* workspace_dev,
+                     size_t workspace_bytes);
 
 /* Data-parallel form of d3p_dpvi_vae_update (BASELINE config 5, "1 vs 8 GPU"): a rank holds the B_local
  * examples at positions pos0 .. pos0 + B_local - 1 of the global batch of B_total (per-example noise keys are functions of

@@ -776,3 +776,29 @@ def test_chained_launch_is_reproducible_under_uneven_load(rng):
     assert torch.equal(loud_losses, quiet_losses) and torch.equal(loud_state.optim_state[1], quiet_state.optim_state[1])
     assert bool(torch.isfinite(quiet_losses).all())
     _check_no_wait_hit_its_bound(rng, 20000, 512, 4096)
+
+
+@pytest.mark.parametrize("kind", ["with_replacement", "split"])
+def test_run_steps_serves_batchifiers_without_a_native_loop(rng, kind):
+    """Sampling with replacement (minibatch.py:195-214) and split_batchify_data's epoch batches (minibatch.py:242-312) have no
+    device-resident loop: run_steps then makes the same steps through get_batch + update and returns what that loop returns."""
+    from d3p_amd.minibatch import split_batchify_data, subsample_batchify_data
+    N, d, B, steps = 1500, 24, 50, 5
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn(N, d, generator=g).cuda()
+    y = (torch.rand(N, generator=g) < 0.5).float().cuda()
+    svi = make_svi(d, False, N, C=1.0, sigma=0.5, lr=1e-2)
+    st = state_with(svi, rng.PRNGKey(51), np.zeros(d, np.float32), np.full(d, -1.0, np.float32))
+    if kind == "with_replacement":
+        init, get_batch = subsample_batchify_data((X, y), B, with_replacement=True)
+    else:
+        init, get_batch = split_batchify_data((X, y), B)
+    _, bstate = init(rng.PRNGKey(52))
+    new_st, losses = svi.run_steps(st, get_batch, bstate, 1, steps)
+    ref, ref_losses = st, []
+    for t in range(steps):
+        ref, l = svi.update(ref, *get_batch(1 + t, bstate))
+        ref_losses.append(float(l))
+    assert losses.shape == (steps,)
+    np.testing.assert_array_equal(np_(losses), np.asarray(ref_losses, np.float32))
+    assert torch.equal(new_st.optim_state[1], ref.optim_state[1]) and torch.equal(new_st.rng_key, ref.rng_key)

@@ -234,3 +234,31 @@ def test_evaluate_vs_oracle(gpu, O, B, D, H, Z, H2):
     jax_key = O.convert_to_jax_rng_key(O.split(O.PRNGKey(31), 1)[0])
     exp = O.vae_evaluate(spec, params, X, jax_key)
     assert abs(got - exp) <= 3e-5 * abs(exp)
+
+
+def test_vae_run_steps_native_loop_matches_stepwise_updates(gpu):
+    """DPSVI.run_steps for the VAE (d3p_dpvi_vae_run: the epoch body of examples/vae.py:227-246 as one native call -- per step
+    fold_in, Feistel indices, row gather, update) walks the trajectory of get_batch + update, step by step, bit for bit (the
+    same kernels on the same batches), and leaves its input state untouched."""
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import subsample_batchify_data
+    from d3p_amd.models import Adam, Trace_ELBO, VAEGuide, VAEModel
+    from d3p_amd.svi import DPSVI
+    N, B, D, H, Z, steps, first = 600, 64, 36, 20, 5, 7, 3
+    X = (torch.rand(N, D, generator=torch.Generator().manual_seed(1)) < 0.3).float().cuda()
+    model = VAEModel(scale=1.0 / N)
+    svi = DPSVI(model, VAEGuide(model), Adam(1e-2), Trace_ELBO(), 5.0, 0.8, num_obs_total=N, z_dim=Z, hidden_dim=H)
+    st0 = svi.init(rng.PRNGKey(0), X[:B])
+    before = [t.clone() for t in st0.optim_state] + [st0.rng_key.clone()]
+    init, get_batch = subsample_batchify_data((X,), B)
+    _, bstate = init(rng.PRNGKey(9))
+    new_st, losses = svi.run_steps(st0, get_batch, bstate, first, steps)
+    ref, ref_losses = st0, []
+    for t in range(steps):
+        ref, l = svi.update(ref, *get_batch(first + t, bstate))
+        ref_losses.append(l.reshape(()))
+    assert torch.equal(losses, torch.stack(ref_losses)) and bool(torch.isfinite(losses).all())
+    assert torch.equal(new_st.optim_state[1], ref.optim_state[1]) and torch.equal(new_st.rng_key, ref.rng_key)
+    assert int(new_st.optim_state[0]) == int(ref.optim_state[0]) == steps
+    for a, b in zip([*st0.optim_state, st0.rng_key], before):
+        assert torch.equal(a, b)
