@@ -236,11 +236,22 @@ k_poisson_flags(const uint32_t* __restrict__ key, size_t key_stride_words, float
                 o[w] = (e < N) ? tf_iota_word(key[0], key[1], N, e) : 0u;
             }
         }
+        // uniform(key, (N,))[e] <= q (minibatch.py:34-35) on the raw word: the uniform of a word is EXACTLY (word >> 9) 2^-23
+        // ((1.m - 1) (1 - 0) + 0, clamped at 0), and q 2^23 is an exact float product, so the float comparison is the integer
+        // comparison (word >> 9) <= floor(q 2^23) -- two integer instructions per element and no conversion, select or branch
+        // (bit for bit the same mask; the float form stays for the last, partial chunk's bounds)
+        const uint32_t thr = q >= 1.0f ? 0xffffffffu : (uint32_t)floorf(q * 8388608.0f);
+        if (16u * t + 15u < N) {
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const uint32_t e = 16u * t + w;
-            const bool sel = (e < N) && (bits_to_uniform(o[w], 0.0f, 1.0f) <= q);
-            m |= (sel ? 1u : 0u) << w;
+            for (int w = 0; w < 16; ++w) m |= (((o[w] >> 9) - thr - 1u) >> 31) << w;   // (x <= thr <=> x - thr - 1 wraps negative; x, thr < 2^31)
+            if (q >= 1.0f) m = 0xffffu;
+        } else {
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                const uint32_t e = 16u * t + w;
+                const bool sel = (e < N) && (bits_to_uniform(o[w], 0.0f, 1.0f) <= q);
+                m |= (sel ? 1u : 0u) << w;
+            }
         }
         flags[t] = (uint16_t)m;
     }
