@@ -79,6 +79,23 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& g, int row, int col, 
     g.C[e] = o;
 }
 
+// XCD-aware tile order.  The chip's 8 XCDs have an L2 each and workgroups are dealt to them round-robin by linear id, so with the
+// natural blockIdx -> tile mapping the tiles that SHARE operand data (the N-tiles of one M row block; the tiles of one split-K
+// slab) land on 8 different L2s and every XCD streams (nearly) the whole of A and B from memory: 134 MB for the 14 MB h1 product.
+// Here workgroup L (XCD L % 8, the j = L / 8-th workgroup of that XCD) takes tile R = start(XCD) + j of the reuse order
+// n-fastest, then m, then the K slab: every XCD works through ONE contiguous run of that order, so an A row block is fetched into
+// one L2 once and hit by the other N-tiles.  (Only locality depends on the round-robin assumption; the mapping is a bijection.)
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz)
+{
+    const unsigned gx = gridDim.x, gy = gridDim.y, T = gx * gy * gridDim.z;
+    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned c = L & 7u, j = L >> 3, base = T >> 3, r = T & 7u;
+    const unsigned R = c * base + (c < r ? c : r) + j;
+    bx = (int)(R % gx);
+    by = (int)((R / gx) % gy);
+    bz = (int)(R / (gx * gy));
+}
+
 #define D3P_GT 64  // tile edge
 #define D3P_GK 16  // K slice
 
@@ -93,8 +110,10 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
     __shared__ __attribute__((aligned(16))) float Bs[D3P_GK][D3P_GT + 4];  // [k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * D3P_GT, n0 = blockIdx.x * D3P_GT;
-    const int kbeg = blockIdx.z * g.k_per, kend = (kbeg + g.k_per < g.K) ? kbeg + g.k_per : g.K;
+    int tx, ty, tz;
+    xcd_tile(tx, ty, tz);
+    const int m0 = ty * D3P_GT, n0 = tx * D3P_GT;
+    const int kbeg = tz * g.k_per, kend = (kbeg + g.k_per < g.K) ? kbeg + g.k_per : g.K;
     float16v acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
@@ -211,7 +230,7 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
     const int col = n0 + wn * 32 + (lane & 31);
     if (col >= g.N) return;
     if (g.part) {  // split-K: raw partial tile, combined in fixed order by k_gemm_reduce
-        float* out = g.part + (size_t)blockIdx.z * g.M * g.N;
+        float* out = g.part + (size_t)tz * g.M * g.N;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int row = m0 + wm * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
@@ -269,8 +288,10 @@ __global__ void __launch_bounds__(512) k_gemm_f32_w8(GemmArgs g)
     __shared__ __attribute__((aligned(16))) float Bs[2][D3P_GT][D3P_GLD];   // [n][k]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2, wr = wave & 3;
-    const int m0 = blockIdx.y * D3P_GTM, n0 = blockIdx.x * D3P_GT;
-    const int kbeg = blockIdx.z * g.k_per, kend = (kbeg + g.k_per < g.K) ? kbeg + g.k_per : g.K;
+    int tx, ty, tz;
+    xcd_tile(tx, ty, tz);
+    const int m0 = ty * D3P_GTM, n0 = tx * D3P_GT;
+    const int kbeg = tz * g.k_per, kend = (kbeg + g.k_per < g.K) ? kbeg + g.k_per : g.K;
     const int m_real = g.a_last_one ? g.M - 1 : g.M;  // rows of A that exist in memory
     float16v acc;
 #pragma unroll
@@ -446,7 +467,279 @@ __global__ void __launch_bounds__(512) k_gemm_f32_w8(GemmArgs g)
     const int col = n0 + 32 * grp + (lane & 31);
     if (col >= g.N) return;
     if (g.part) {  // split-K: raw partial tile, combined in fixed order by the consumer
-        float* out = g.part + (size_t)blockIdx.z * g.M * g.N;
+        float* out = g.part + (size_t)tz * g.M * g.N;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = m0 + wr * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+            if (row < g.M) out[(size_t)row * g.N + col] = acc[v];
+        }
+        return;
+    }
+    const float bv = g.bias ? g.bias[col + (col >= g.n_seg ? g.bias_njump : 0ll)] : 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int row = m0 + wr * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+        if (row < g.M) gemm_store(g, row, col, acc[v], bv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix pipe at fp32 accuracy (round 3): every fp32 operand element is split EXACTLY into three
+// bf16 parts (x = x0 + x1 + x2: the top 8, the next 8 and the last 8 bits of its 24-bit significand -- truncations, so each
+// remainder is exact), and the product a b is accumulated in fp32 as
+//     a0 b0 + a0 b1 + a1 b0 + a0 b2 + a1 b1 + a2 b0
+// -- six v_mfma_f32_32x32x16_bf16 per 16 k's.  Every partial product is exact (8 x 8 bits), the three dropped terms are below
+// 2^-23 |a b| -- the size of ONE fp32 rounding of the product -- and the accumulation is the fp32 accumulation of the fp32 MFMA.
+// Why: v_mfma_f32_32x32x2_f32 runs on the VECTOR pipe at 1/16 of the bf16 rate and nothing issues beside it (the 41 % ceiling of
+// k_gemm_f32_w8); the bf16 matrix pipe does six of these MFMAs in 6/16 of the time AND lets the vector unit
+// (which does the splitting: 5.5 instructions per element) and the LDS run beside it.
+// Same tile (128 x 64, eight waves of 32 x 32, K slices of 32), same fetch path, edge handling and epilogue as k_gemm_f32_w8; the
+// LDS holds three bf16 planes per operand, [plane][row][k] with k fastest and a row stride of 40 bf16 (80 bytes: the b128
+// fragment reads of 16 consecutive rows fall into distinct 16-byte slots of a 256-byte bank row).
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+#define D3P_BLD 40   // row stride of a plane in bf16 elements
+// the three bf16 parts of two fp32 values, as three words {part of x1 (high half) | part of x0 (low half)}
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& w0, uint32_t& w1, uint32_t& w2)
+{
+    const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    w0 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    w1 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    w2 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+template <bool AK, bool BN>
+__global__ void __launch_bounds__(512) k_gemm_bf16x3(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short Ap[2][3][D3P_GTM][D3P_BLD];  // [buffer][plane][m][k]
+    __shared__ __attribute__((aligned(16))) unsigned short Bp[2][3][D3P_GT][D3P_BLD];   // [buffer][plane][n][k]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2, wr = wave & 3;
+    int tx, ty, tz;
+    xcd_tile(tx, ty, tz);
+    const int m0 = ty * D3P_GTM, n0 = tx * D3P_GT;
+    const int kbeg = tz * g.k_per, kend = (kbeg + g.k_per < g.K) ? kbeg + g.k_per : g.K;
+    const int m_real = g.a_last_one ? g.M - 1 : g.M;
+    float16v acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+
+    // ---- this thread's share of a slice (as in k_gemm_f32_w8): two float4 of A, one of B
+    int a_m[2], a_k[2], b_n, b_k;
+    if (AK) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { const int f = tid + 512 * r; a_m[r] = f >> 3; a_k[r] = 4 * (f & 7); }
+    } else {  // rows 4 mg .. 4 mg + 3 at k = 2 kp, 2 kp + 1
+        const int mg = (tid & 7) + 8 * (tid >> 7), kp = (tid >> 3) & 15;
+        a_m[0] = a_m[1] = 4 * mg;
+        a_k[0] = 2 * kp;
+        a_k[1] = 2 * kp + 1;
+    }
+    // n-fast B: columns 4 ng .. 4 ng + 3 at ONE k; lanes l and l ^ 8 hold k and k ^ 1 of the same columns (bit 3 of tid = bit 0 of k)
+    if (BN) { b_n = 4 * ((tid & 7) + 8 * (tid >> 8)); b_k = (tid >> 3) & 31; } else { b_n = tid >> 3; b_k = 4 * (tid & 7); }
+    const int K4 = (g.K + 3) & ~3;
+    const int ka_last = AK ? K4 - 4 : g.K - 1, kb_last = BN ? g.K - 1 : K4 - 4;
+    const int m_last = AK ? m_real - 1 : ((m_real + 3) & ~3) - 4, n_last = g.N - (BN ? 4 : 1);
+    const long long a_kstride = AK ? 1 : g.a_sk, b_kstride = BN ? g.b_sk : 1;
+    long long a_row[2];
+    unsigned a_off[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int gm = m0 + a_m[r], cm = gm < m_last ? gm : m_last;
+        a_row[r] = AK ? (long long)cm * g.a_sm : (long long)cm;
+        a_off[r] = (unsigned)(a_row[r] - (AK ? (long long)m0 * g.a_sm : (long long)m0) + (long long)a_k[r] * a_kstride);
+    }
+    const float* a_tile = g.A + (AK ? (long long)m0 * g.a_sm : (long long)m0);
+    const int gn_c = (n0 + b_n) < n_last ? (n0 + b_n) : n_last;
+    const long long b_row = BN ? (long long)gn_c : (long long)gn_c * g.b_sn;
+    const int n_base = n0 < n_last ? n0 : n_last;
+    const float* b_tile = g.B + (BN ? (long long)n_base : (long long)n_base * g.b_sn);
+    const unsigned b_off = (unsigned)(b_row - (BN ? (long long)n_base : (long long)n_base * g.b_sn) + (long long)b_k * b_kstride);
+    const bool m_edge = m0 + D3P_GTM > m_real;
+    const int gm_a0 = m0 + a_m[0], gm_a1 = m0 + a_m[1];
+    auto keep_of = [&](int row) { return row < m_real ? 1.f : 0.f; };
+    auto one_of = [&](int row) { return (g.a_last_one && row == m_real) ? 1.f : 0.f; };
+    const float kp0 = keep_of(gm_a0), kp1 = AK ? keep_of(gm_a1) : keep_of(gm_a0 + 1), kp2 = keep_of(gm_a0 + 2), kp3 = keep_of(gm_a0 + 3);
+    const float on0 = one_of(gm_a0), on1 = AK ? one_of(gm_a1) : one_of(gm_a0 + 1), on2 = one_of(gm_a0 + 2), on3 = one_of(gm_a0 + 3);
+
+    float4 ra00, ra01, rb0, ra10, ra11, rb1;
+    const long long a_step2 = 2ll * D3P_GKB * a_kstride, b_step2 = 2ll * D3P_GKB * b_kstride;
+    int fk[2] = {kbeg, kbeg + D3P_GKB};
+    const float* fa[2] = {a_tile + (long long)kbeg * a_kstride, a_tile + (long long)(kbeg + D3P_GKB) * a_kstride};
+    const float* fb[2] = {b_tile + (long long)kbeg * b_kstride, b_tile + (long long)(kbeg + D3P_GKB) * b_kstride};
+    auto fetch = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        float4 &a0 = s ? ra10 : ra00, &a1 = s ? ra11 : ra01, &bb = s ? rb1 : rb0;
+        const int k0 = fk[s];
+        if (k0 + D3P_GKB <= g.K) {
+            a0 = *reinterpret_cast<const float4*>(fa[s] + a_off[0]);
+            a1 = *reinterpret_cast<const float4*>(fa[s] + a_off[1]);
+            bb = *reinterpret_cast<const float4*>(fb[s] + b_off);
+        } else {
+            const int gk0 = k0 + a_k[0], gk1 = k0 + a_k[1], gkb = k0 + b_k;
+            a0 = *reinterpret_cast<const float4*>(g.A + a_row[0] + (long long)(gk0 < ka_last ? gk0 : ka_last) * a_kstride);
+            a1 = *reinterpret_cast<const float4*>(g.A + a_row[1] + (long long)(gk1 < ka_last ? gk1 : ka_last) * a_kstride);
+            bb = *reinterpret_cast<const float4*>(g.B + b_row + (long long)(gkb < kb_last ? gkb : kb_last) * b_kstride);
+        }
+        fk[s] = k0 + 2 * D3P_GKB;
+        fa[s] += a_step2;
+        fb[s] += b_step2;
+    };
+    // EDGE = false: the slice lies inside [kbeg, kend) and the tile inside the rows of A that exist -- no edge arithmetic, no branch
+    // (the steady state: its body is straight-line code that the scheduler interleaves with the MFMAs of the slice before)
+    auto stage = [&](auto S, int buf, int k0, auto EDGE) {  // register set S (slice starting at k0): edges applied, split, three planes -> LDS
+        constexpr int s = decltype(S)::value;
+        float4 bb = s ? rb1 : rb0;
+        float4 o[2] = {s ? ra10 : ra00, s ? ra11 : ra01};
+        if (decltype(EDGE)::value && (m_edge || k0 + D3P_GKB > kend)) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float in_k = (k0 + a_k[r] < kend) ? 1.f : 0.f;
+                const float4 v = o[r];
+                if (AK) {
+                    const float keep = r ? kp1 : kp0, one = r ? on1 : on0;
+                    const int kq = k0 + a_k[r];
+                    const float i0 = kq + 0 < kend ? 1.f : 0.f, i1 = kq + 1 < kend ? 1.f : 0.f, i2 = kq + 2 < kend ? 1.f : 0.f, i3 = kq + 3 < kend ? 1.f : 0.f;
+                    o[r] = make_float4(__fmaf_rn(v.x, keep * i0, one * i0), __fmaf_rn(v.y, keep * i1, one * i1), __fmaf_rn(v.z, keep * i2, one * i2),
+                                       __fmaf_rn(v.w, keep * i3, one * i3));
+                } else {
+                    o[r] = make_float4(__fmaf_rn(v.x, kp0 * in_k, on0 * in_k), __fmaf_rn(v.y, kp1 * in_k, on1 * in_k),
+                                       __fmaf_rn(v.z, kp2 * in_k, on2 * in_k), __fmaf_rn(v.w, kp3 * in_k, on3 * in_k));
+                }
+            }
+        }
+        uint32_t w[3];
+        if (AK) {  // one row, four consecutive k's per float4: two words per plane, one 8-byte store
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                uint32_t x[3], y[3];
+                split_pair(o[r].x, o[r].y, x[0], x[1], x[2]);
+                split_pair(o[r].z, o[r].w, y[0], y[1], y[2]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(&Ap[buf][p][a_m[r]][a_k[r]]) = make_uint2(x[p], y[p]);
+            }
+        } else {   // four rows at k = 2 kp (o[0]) and 2 kp + 1 (o[1]): one word per row and plane
+            const float lo4[4] = {o[0].x, o[0].y, o[0].z, o[0].w}, hi4[4] = {o[1].x, o[1].y, o[1].z, o[1].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                split_pair(lo4[i], hi4[i], w[0], w[1], w[2]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint32_t*>(&Ap[buf][p][a_m[0] + i][a_k[0]]) = w[p];
+            }
+        }
+        if (BN) {  // four columns at one k; the lane 8 away holds k ^ 1: the even-k lane takes columns 0, 1, the odd-k lane 2, 3
+            const bool odd = (b_k & 1) != 0;
+            const float give0 = odd ? bb.x : bb.z, give1 = odd ? bb.y : bb.w;   // what the partner needs from this lane
+            const float got0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give0), 0x128, 0xF, 0xF, false));  // row_ror:8
+            const float got1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give1), 0x128, 0xF, 0xF, false));
+            // this lane's two columns at (k even, k odd)
+            const float e0 = odd ? got0 : bb.x, o0 = odd ? bb.z : got0, e1 = odd ? got1 : bb.y, o1 = odd ? bb.w : got1;
+            const int nn = b_n + (odd ? 2 : 0), kk = b_k & ~1;
+            split_pair(e0, o0, w[0], w[1], w[2]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint32_t*>(&Bp[buf][p][nn][kk]) = w[p];
+            split_pair(e1, o1, w[0], w[1], w[2]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint32_t*>(&Bp[buf][p][nn + 1][kk]) = w[p];
+        } else {
+            uint32_t x[3], y[3];
+            split_pair(bb.x, bb.y, x[0], x[1], x[2]);
+            split_pair(bb.z, bb.w, y[0], y[1], y[2]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(&Bp[buf][p][b_n][b_k]) = make_uint2(x[p], y[p]);
+        }
+    };
+    struct Frag { bf16x8 a[2][3], b[2][3]; };   // [k step of 16][plane]
+    const int fr = lane & 31, fh = lane >> 5;
+    auto read_frags = [&](int buf, Frag& f) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                f.a[ks][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Ap[buf][p][32 * wr + fr][16 * ks + 8 * fh]));
+                f.b[ks][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Bp[buf][p][32 * grp + fr][16 * ks + 8 * fh]));
+            }
+    };
+    auto mma_half = [&](const Frag& f, int ks) {   // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][2], f.b[ks][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][1], f.b[ks][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][1], f.b[ks][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][0], acc, 0, 0, 0);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    const int KB = D3P_GKB;
+    using EdgeY = std::true_type;
+    using EdgeN = std::false_type;
+    Frag f0, f1;
+    fetch(S0{});
+    fetch(S1{});
+    stage(S0{}, 0, kbeg, EdgeY{});
+    fetch(S0{});
+    __syncthreads();
+    read_frags(0, f0);
+    const int ns = (kend - kbeg + KB - 1) / KB;
+    // one MFMA, then a share of the other work of the same half slice: the bf16 matrix pipe runs beside the vector unit and the LDS,
+    // but only what stands BETWEEN two MFMAs in a wave's instruction stream can run beside them
+#define D3P_MIX_STAGE()                                                                                     \
+    _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  /* 1 MFMA */                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0); /* 12 VALU (splitting) */                       \
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);  /* 2 LDS writes */                              \
+    }
+#define D3P_MIX_READ()                                                                                      \
+    _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  /* 2 LDS reads */                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  /* 1 MFMA */                                    \
+    }
+    for (int i = 0; i < ns; i += 2) {
+        const int k_i = kbeg + i * KB;
+        if (!m_edge && k_i + 3 * KB <= kend) {   // both slices staged in this iteration are whole: the branch-free body
+            mma_half(f0, 0);
+            stage(S1{}, 1, k_i + KB, EdgeN{});
+            D3P_MIX_STAGE()
+            fetch(S1{});
+            __syncthreads();
+            read_frags(1, f1);
+            mma_half(f0, 1);
+            D3P_MIX_READ()
+            __builtin_amdgcn_sched_barrier(0);
+            mma_half(f1, 0);
+            stage(S0{}, 0, k_i + 2 * KB, EdgeN{});
+            D3P_MIX_STAGE()
+            fetch(S0{});
+            __syncthreads();
+            read_frags(0, f0);
+            mma_half(f1, 1);
+            D3P_MIX_READ()
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            mma_half(f0, 0);
+            stage(S1{}, 1, k_i + KB, EdgeY{});
+            fetch(S1{});
+            __syncthreads();
+            read_frags(1, f1);
+            mma_half(f0, 1);
+            mma_half(f1, 0);
+            stage(S0{}, 0, k_i + 2 * KB, EdgeY{});
+            fetch(S0{});
+            __syncthreads();
+            read_frags(0, f0);
+            mma_half(f1, 1);
+        }
+    }
+#undef D3P_MIX_STAGE
+#undef D3P_MIX_READ
+    const int col = n0 + 32 * grp + (lane & 31);
+    if (col >= g.N) return;
+    if (g.part) {
+        float* out = g.part + (size_t)tz * g.M * g.N;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int row = m0 + wr * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
@@ -532,7 +825,14 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     g.k_per = k_per;
     g.part = splits > 1 ? part : nullptr;
     const dim3 grid(cdiv(N, D3P_GT), cdiv(M, tm), splits);
-    if (big) {
+    static const bool fp32_mfma = getenv("D3P_GEMM_FP32_MFMA") != nullptr;  // developer switch: the fp32-MFMA kernel for the large products
+    if (big && !fp32_mfma) {
+        const bool ak = a_sk == 1, bn = b_sn == 1;
+        if (ak && bn) hipLaunchKernelGGL((k_gemm_bf16x3<true, true>), grid, dim3(512), 0, s, g);
+        else if (ak) hipLaunchKernelGGL((k_gemm_bf16x3<true, false>), grid, dim3(512), 0, s, g);
+        else if (bn) hipLaunchKernelGGL((k_gemm_bf16x3<false, true>), grid, dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((k_gemm_bf16x3<false, false>), grid, dim3(512), 0, s, g);
+    } else if (big) {
         const bool ak = a_sk == 1, bn = b_sn == 1;
         if (ak && bn) hipLaunchKernelGGL((k_gemm_f32_w8<true, true>), grid, dim3(512), 0, s, g);
         else if (ak) hipLaunchKernelGGL((k_gemm_f32_w8<true, false>), grid, dim3(512), 0, s, g);
