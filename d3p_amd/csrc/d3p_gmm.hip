@@ -330,8 +330,10 @@ __global__ void __launch_bounds__(256, (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1
                 const float e0 = bits_to_normal_wu(b0), e1 = bits_to_normal_wu(b1);
                 // Exponential(1) by inversion; sigs = 1 / ex, so 1 / sig = ex and -log sig = log ex
                 // (the argument is a normal float in (0, 1): the hardware log2 path is 1 ulp and a sixth of the instructions)
-                const float ex0 = -__logf(((float)(u0 >> 9) + 0.5f) * 1.1920928955078125e-07f);
-                const float ex1 = -__logf(((float)(u1 >> 9) + 0.5f) * 1.1920928955078125e-07f);
+                // (both logarithms below take normal arguments -- the uniform is in [2^-24, 1), ex in [6e-8, 17] --, so the raw
+                // v_log_f32 needs none of __logf's denormal scaling and fix-up: ten instructions less per logarithm, four per entry)
+                const float ex0 = -0.693147182f * __builtin_amdgcn_logf(((float)(u0 >> 9) + 0.5f) * 1.1920928955078125e-07f);
+                const float ex1 = -0.693147182f * __builtin_amdgcn_logf(((float)(u1 >> 9) + 0.5f) * 1.1920928955078125e-07f);
                 const int i0 = kk * DS + s, i1 = (KH + kk) * DS + s;
                 const float mu0 = ok0 ? locv[i0] + e0 : 0.f, mu1 = ok1 ? locv[i1] + e1 : 0.f;
                 const float z0 = (xs[s] - mu0) * ex0, z1 = (xs[s] - mu1) * ex1;
@@ -340,7 +342,7 @@ __global__ void __launch_bounds__(256, (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1
                 muv[i0] = mu0;
                 muv[i1] = mu1;
                 if (ok0) {
-                    ll0 += __fmaf_rn(-0.5f * z0, z0, __logf(ex0) - D3P_HALF_LOG_2PI);
+                    ll0 += __fmaf_rn(-0.5f * z0, z0, __fmaf_rn(0.693147182f, __builtin_amdgcn_logf(ex0), -D3P_HALF_LOG_2PI));
                     lmu += __fmaf_rn(-0.5f * e0, e0, __fmaf_rn(0.5f * a.inv_ps2 * mu0, mu0, a.log_ps));
                     if (lat) {
                         lat[K + j0] = e0;
@@ -348,7 +350,7 @@ __global__ void __launch_bounds__(256, (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1
                     }
                 }
                 if (ok1) {
-                    ll1 += __fmaf_rn(-0.5f * z1, z1, __logf(ex1) - D3P_HALF_LOG_2PI);
+                    ll1 += __fmaf_rn(-0.5f * z1, z1, __fmaf_rn(0.693147182f, __builtin_amdgcn_logf(ex1), -D3P_HALF_LOG_2PI));
                     lmu += __fmaf_rn(-0.5f * e1, e1, __fmaf_rn(0.5f * a.inv_ps2 * mu1, mu1, a.log_ps));
                     if (lat) {
                         lat[K + j1] = e1;
