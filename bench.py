@@ -219,7 +219,9 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
             "unit": "examples/s", "us_per_step": round(1e6 * ev / steps, 2), "final_loss": float(run.loss),
             "roofline": {"bound": "mfma", "achieved": round(flops * steps / ev / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flops * steps / ev / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "gemm_flop_per_step": flops,
-                         "dtype": "f32 (v_mfma_f32_32x32x2_f32: the reference computes in float32)",
+                         "dtype": "f32-accurate: the large products as six v_mfma_f32_32x32x16_bf16 on an EXACT three-way bf16 split of both "
+                                  "fp32 operands, fp32 accumulate (dropped terms < 2^-23 relative; DESIGN.md 1c); peak quoted = the fp32 MFMA peak "
+                                  "the reference's float32 arithmetic would be priced against",
                          "timing": "HIP events on the launch stream around 40 consecutive updates (all kernels of a step, not only "
                                    "the matrix products)"}}
         del X, svi, st

@@ -85,6 +85,36 @@ def test_mfma_gemm_k_not_a_multiple_of_four_with_padded_rows(lib):
     assert float((out.double() - ref).abs().max()) <= 2e-5 * scale
 
 
+def test_split_product_is_fp32_accurate_on_hostile_operands(lib):
+    """The large products run as six bf16 MFMAs on an exact three-way bf16 split of both operands (k_gemm_bf16x3): every
+    partial product is exact and the dropped terms are below 2^-23 of |a||b|, so the result must be as close to the float64
+    product as an fp32 product is -- also where a bf16 shortcut would show: operands whose magnitudes span 2^+-20 inside one
+    row, values with all 24 significand bits set, and a sum that cancels to 2^-12 of its terms.  Bound: 4 x 2^-24 x K^(1/2)-ish
+    fp32 accumulation noise, stated as 3e-6 of sum_k |a||b| (a 16-bit product would miss it by a factor of 100)."""
+    M, N, K = 512, 256, 1024
+    g = torch.Generator().manual_seed(77)
+    A = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-20, 21, (M, K), generator=g).float())
+    Bm = torch.randn(K, N, generator=g) * torch.exp2(torch.randint(-20, 21, (K, N), generator=g).float())
+    A[:, ::7] = torch.nextafter(torch.tensor(2.0), torch.tensor(0.0))          # 0x3fffffff: every significand bit set
+    Bm[::5, :] = torch.nextafter(torch.tensor(-1.0), torch.tensor(0.0))
+    A[:, 1::2] = -A[:, 0::2] * (1.0 + 2.0 ** -12)                              # pairs that cancel to 2^-12 of their size
+    Bm[1::2, :] = Bm[0::2, :]
+    A, Bm = A.cuda(), Bm.cuda()
+    out = torch.empty(M, N, device="cuda")
+    L = lib.load()
+    lib.check(L.d3p_gemm_f32(lib.stream_ptr(), lib.ptr(A), K, 1, lib.ptr(Bm), N, 1, lib.ptr(out), N, M, N, K, None, 1.0, 0))
+    ref = A.double() @ Bm.double()
+    scale = A.abs().double() @ Bm.abs().double()
+    err = ((out.double() - ref).abs() / scale).max()
+    assert float(err) <= 3e-6, float(err)
+    assert bool(torch.isfinite(out).all())
+    # non-finite operands propagate like in an fp32 product (a part of Inf is Inf, its remainder NaN)
+    A2 = A.clone()
+    A2[3, 10] = float("inf")
+    lib.check(L.d3p_gemm_f32(lib.stream_ptr(), lib.ptr(A2), K, 1, lib.ptr(Bm), N, 1, lib.ptr(out), N, M, N, K, None, 1.0, 0))
+    assert not bool(torch.isfinite(out[3]).any()) and bool(torch.isfinite(out[4]).all())
+
+
 def vae_problem(B, D, H, Z, seed, pscale=0.2, H2=0):
     import oracle.oracle as O
     r = np.random.default_rng(seed)
