@@ -321,9 +321,12 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     const bool apply_prev = ps != nullptr;
     const float* prev_noise = step_t > 0 ? a.noise_base + (size_t)(step_t - 1) * P : a.prev_noise0;
     // W = 16: thread tid owns ONE parameter column -- auto_loc of latent tid (tid < 512) or auto_scale of latent tid - 512
-    // (ICPT: the intercept's two columns D - 1 and 2 D - 1 are second columns of threads 64 and 576)
+    // (ICPT: the intercept's two columns D - 1 and 2 D - 1 are second columns of threads 64 and 128)
     const int mycol = W16 ? (tid < DF ? tid : D + (tid - DF)) : tid;
-    const int xcol = (W16 && ICPT) ? (tid == 64 ? D - 1 : tid == 576 ? 2 * D - 1 : -1) : -1;   // a second column of this thread
+    // ICPT: the intercept's two columns are second columns of two threads of LOC waves (waves 1 and 2: their own column is the cheap
+    // kind -- no softplus / sigmoid / logarithms --, so the wave that also takes the intercept's scale column ends 25 instructions
+    // after the scale waves instead of 70: the staging barrier waits for the slowest wave)
+    const int xcol = (W16 && ICPT) ? (tid == 64 ? D - 1 : tid == 128 ? 2 * D - 1 : -1) : -1;
     float zL = 0.f, zS = 0.f, zX = 0.f, bc1 = 1.f, bc2 = 1.f;
     // W = 16: everything of the pending update that does not depend on the sums is computed HERE, before the release: the valid
     // example count of the pending step is a function of the keys (the sampler left it in the step's slot; the count column of
@@ -550,7 +553,7 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
                     nll_main += ((long long)__builtin_amdgcn_readlane((int)(nr >> 32), r) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)nr, r);
             }
             col_apply(mycol, d1, zL);
-            if (xcol >= 0) col_apply(xcol, d2, zX);   // ICPT: the intercept's auto_loc (thread 64) / auto_scale (thread 576)
+            if (xcol >= 0) col_apply(xcol, d2, zX);   // ICPT: the intercept's auto_loc (thread 64) / auto_scale (thread 128)
         } else {
             latent(tid, zL, zS);
             if (ICPT && tid == 1) latent(D - 1, apply_prev ? prev_noise[D - 1] : 0.f, apply_prev ? prev_noise[2 * D - 1] : 0.f);  // the intercept
@@ -768,7 +771,7 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
         if (W16) {
             column_sum(mycol);
             if (ICPT && tid == 64) column_sum(D - 1);        // the intercept's two columns
-            if (ICPT && tid == 576) column_sum(2 * D - 1);
+            if (ICPT && tid == 128) column_sum(2 * D - 1);
         } else {
             column_pair(tid);
             if (ICPT && tid == 64) column_pair(D - 1);  // the intercept
