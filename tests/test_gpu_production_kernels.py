@@ -261,3 +261,42 @@ def test_throughput_regime_kernel_vs_oracle(gpu, O):
     ost = _oracle_state(O, 31, d)
     el = _oracle_losses_feistel(O, spec, hy, ost, X.numpy(), y.numpy(), O.PRNGKey(32), first, B, steps)
     _compare(new_st, losses, ost, el, steps)
+
+
+@pytest.mark.parametrize("B,icpt,sampler", [(20, False, "feistel"), (100, False, "feistel"), (33, True, "feistel"),
+                                            (700, True, "poisson"), (1500, False, "poisson")])
+def test_chain_kernel_small_and_ragged_grids_vs_oracle(gpu, O, B, icpt, sampler):
+    """The 16-wave form away from its benchmark shape: one, four and a few dozen workgroups per step (fewer arrival groups than
+    8; waves without an item), the intercept's extra columns together with Poisson position lists, a padded Poisson batch whose
+    item count changes from step to step -- 12 steps each against per-step O.logreg_update."""
+    import scipy.stats
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import poisson_batchify_data, subsample_batchify_data
+    N, d, steps, first = 20_000, 512, 12, 4
+    X, y = _table(N, d, 100 + B)
+    svi = _svi(d, icpt, N)
+    D = d + int(icpt)
+    st = _state(svi, rng.PRNGKey(61), D, N)
+    if sampler == "feistel":
+        _, gb = subsample_batchify_data((X.cuda(), y.cuda()), B)
+        maxB = B
+    else:
+        q = B / N
+        maxB = int(scipy.stats.poisson(N * q).ppf(0.99))
+        _, gb = poisson_batchify_data((X.cuda(), y.cuda()), q, 0.99)
+    new_st, losses = svi.run_steps(st, gb, rng.PRNGKey(62), first, steps)
+    assert svi.last_run_status() == (False, False)
+    Xn, yn = X.numpy(), y.numpy()
+    spec = O.logreg_spec(d, icpt, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    ost = _oracle_state(O, 61, D)
+    el = []
+    for t in range(steps):
+        bk = O.fold_in(O.PRNGKey(62), first + t)
+        if sampler == "feistel":
+            idx, mask = O.feistel_sample(bk, N, B), None
+        else:
+            idx, _, nvalid = O.poisson_select(bk, np.float32(B / N), N, maxB)
+            mask = (np.arange(maxB) < nvalid).astype(np.float32)
+        el.append(O.logreg_update(spec, hy, ost, Xn[idx], yn[idx], mask)[0])
+    _compare(new_st, losses, ost, el, steps)
