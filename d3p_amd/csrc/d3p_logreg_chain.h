@@ -617,12 +617,16 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
         const Quad sg0 = quad_lds(pk + 2 * DL + c0), sg1 = quad_lds(pk + 2 * DL + c1);   // (requested before the wave sums need them)
         const Quad q0 = quad_lds(pk + 3 * DL + c0), q1 = quad_lds(pk + 3 * DL + c1);
         float t[NE], A[NE], loglik[NE];
-#pragma unroll
-        for (int j = 0; j < NE; ++j) {
-            const d3p_v2f tpq = tp[j] + tq[j];
-            t[j] = wave_sum(tpq.x + tpq.y);                                  // logit x . z
-            if (ICPT) t[j] = __fmaf_rn(xtv[j], zt[j], t[j]);                 // + the tail feature, once
+        if (NE == 2) {   // both examples' sums in one pass (wave_sum2)
+            const d3p_v2f ta = tp[0] + tq[0], tb = tp[NE - 1] + tq[NE - 1];
+            wave_sum2(ta.x + ta.y, tb.x + tb.y, t[0], t[NE - 1]);           // logits x . z
+        } else {
+            const d3p_v2f tpq = tp[0] + tq[0];
+            t[0] = wave_sum(tpq.x + tpq.y);
         }
+#pragma unroll
+        for (int j = 0; j < NE; ++j)
+            if (ICPT) t[j] = __fmaf_rn(xtv[j], zt[j], t[j]);                 // + the tail feature, once
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             A[j] = a.A_scale * (chain_sigmoid(t[j]) - yv[j]);                // d(-lik_scale inv_obs loglik)/dt
@@ -658,8 +662,8 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             if (ICPT) lpl = __fmaf_rn((icpt_lane ? a.hz_b - a.hz : 0.0f) * z1[j].hi.y, z1[j].hi.y, lpl);  // (the intercept's own prior)
             loss_lane += lpl;
         }
-#pragma unroll
-        for (int j = 0; j < NE; ++j) n2s[j] = wave_sum(n2s[j]);
+        if (NE == 2) wave_sum2(n2s[0], n2s[NE - 1], n2s[0], n2s[NE - 1]);
+        else n2s[0] = wave_sum(n2s[0]);
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             gt[j] = ht[j] = 0.f;
