@@ -173,15 +173,15 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
         wall, ev = timed(run, 64, steps)
         P = K + K * d
         alg = B * (4 * d + 4) + 3 * 4 * P                          # 2 175 168 B per step
-        # wave64 VALU instructions per step, measured with SQ_INSTS_VALU (profiles/r02_gmm_pmc.json: k_gmm_px 22.5 M, k_gmm_head 3.2 M)
-        valu = 25.7e6
+        # wave64 VALU instructions per step, measured with SQ_INSTS_VALU (profiles/r03_gmm_pmc.json: k_gmm_px 18.46 M, k_gmm_head 3.24 M)
+        valu = 21.7e6
         out["gmm_config3"] = {
             "workload": "BASELINE configs[2]: mixture model K=16 d=64, N=1e7 rows resident, batch 8192 (Feistel), C=20, sigma=1, Adam 1e-3",
             "steps": steps, "warmup": 64, "steps_per_sec": round(steps / wall, 2), "value": round(B * steps / wall, 1),
             "unit": "examples/s", "us_per_step": round(1e6 * ev / steps, 3), "final_loss": float(run.loss),
             "roofline": {"bound": "valu", "achieved": round(valu * steps / ev / 1e9, 2), "peak": VALU_PEAK_GINSTR, "unit": "Ginstr/s (wave64)",
                          "frac": round(valu * steps / ev / 1e9 / VALU_PEAK_GINSTR, 4),
-                         "valu_instructions_per_step": valu, "instruction_count_source": "profiles/r02_gmm_pmc.json (SQ_INSTS_VALU of "
+                         "valu_instructions_per_step": valu, "instruction_count_source": "profiles/r03_gmm_pmc.json (SQ_INSTS_VALU of "
                          "k_gmm_px + k_gmm_head); not re-counted in this run",
                          "hbm": {"algorithmic_bytes_per_step": alg, "achieved_GBps": round(alg * steps / ev / 1e9, 2),
                                  "frac": round(alg * steps / ev / 1e9 / HBM_PEAK_GBPS, 5)},

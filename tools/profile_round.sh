@@ -27,3 +27,11 @@ cp $O/bench_under_rocprof.json $P/${T}_bench_under_rocprof.json
 cp $O/bench_all_legs_under_rocprof.json $P/${T}_bench_all_legs_under_rocprof.json
 cp $O/bench.json $P/${T}_bench.json
 ls -la $P
+# per-kernel VALU instruction counts of the mixture-model leg (bench.py's gmm roofline uses them) and the VAE step's kernel times
+cd /tmp
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $O/gmm_pmc -o gmm -- python3 $R/tools/time_gmm_step.py > $O/gmm_pmc.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/vae_stats -o vae -- python3 $R/tools/time_vae_step.py > $O/vae_stats.log 2>&1
+cd $R
+python3 tools/pmc_kernel_means.py $P/${T}_gmm_pmc.json $O/gmm_pmc > /dev/null
+cp $(find $O/vae_stats -name "*kernel_stats.csv" | head -1) $P/${T}_vae_kernel_stats.csv
+ls -la $P
