@@ -75,7 +75,12 @@ def test_sample_from_array_reference_properties(rng):
 @pytest.mark.parametrize("N,q,cutoff,suppress", [(100, 0.1, 100, False), (105, 0.3, 39, False), (105, 0.3, 20, False),
                                                  (105, 0.3, 20, True), (4097, 0.5, 4097, False),
                                                  (10**6, 0.004096, 4245, False), (10**6, 0.004096, 4000, True),
-                                                 (1, 1.0, 1, False), (17, 0.0, 5, False), (1000, 1.0, 1000, False)])
+                                                 (1, 1.0, 1, False), (17, 0.0, 5, False), (1000, 1.0, 1000, False),
+                                                 # thresholds at and between the 2^-23 steps of the uniform (the kernel compares integers:
+                                                 # word >> 9 <= floor(q 2^23)): q = 2^-23, 3.5 x 2^-23, 2^-24, the largest float below 1, 1/3
+                                                 (2**20, 2.0**-23, 64, False), (2**20, 3.5 * 2.0**-23, 64, False), (2**20, 2.0**-24, 64, False),
+                                                 (4096, float(np.nextafter(np.float32(1.0), np.float32(0.0))), 4096, False),
+                                                 (70001, 1.0 / 3.0, 30000, False)])
 def test_poisson_select_bit_exact(rng, O, N, q, cutoff, suppress):
     import d3p_amd._lib as L
     from d3p_amd._lib import check, ptr, stream_ptr
