@@ -998,10 +998,11 @@ static int enqueue_fused_step(const Ctx& c, int g, int t, const StepSlot* prev_s
 
 // Chained form (MODE 3): the K steps of the prepared batch in ONE launch of K x (nw + 1) workgroups (see ChainFuse in
 // d3p_logreg_kernel.h).  On by default for the single-GPU run loop; D3P_NO_CHAINED_STEPS=1 falls back to one launch per step.
+static int g_run_form = 0;   // d3p_dpvi_logreg_set_run_form: 0 = automatic, 1 = one launch per step
 static bool use_chained_steps(const Ctx& c)
 {
     static const bool off = getenv("D3P_NO_CHAINED_STEPS") != nullptr;
-    return !off && c.src->kind != D3P_BATCH_EXPLICIT;
+    return !off && g_run_form != 1 && c.src->kind != D3P_BATCH_EXPLICIT;
 }
 
 // Persistent form (MODE 4, d3p_logreg_persist.h): the same K steps in ONE launch of RESIDENT workgroups that loop over the
@@ -2082,6 +2083,13 @@ int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_d
         if (b + 1 < n_batches && (rc = enqueue_sampler(cb[nxt], K_next))) return rc;
     }
     return enqueue_sched_finish(c, (int)num_steps);
+}
+
+int d3p_dpvi_logreg_set_run_form(int form)
+{
+    D3P_REQUIRE(form == 0 || form == 1, "d3p_dpvi_logreg_set_run_form: form must be 0 (automatic) or 1 (one launch per step)");
+    g_run_form = form;
+    return D3P_OK;
 }
 
 int d3p_dpvi_logreg_kernel_timing_enable(int enable)

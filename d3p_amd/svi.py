@@ -766,7 +766,8 @@ class DPSVI:
         return new_state, loss[0]
 
     # ---------------------------------------------------------------- fused multi-step loop
-    def run_steps(self, svi_state, get_batch, batchifier_state, first_batch, num_steps, check_status=True, **kwargs):
+    def run_steps(self, svi_state, get_batch, batchifier_state, first_batch, num_steps, check_status=True, _no_fallback=False,
+                  **kwargs):
         """``num_steps`` x (get_batch(i, batchifier_state) -> update) for i = first_batch..., enqueued
         back to back on the device: the body of the reference's ``jit(lax.fori_loop(...))`` epoch
         (examples/logistic_regression.py:149-160, examples/vae.py:227-246).  Batchifiers of ``subsample_batchify_data``
@@ -778,7 +779,9 @@ class DPSVI:
         ``check_status`` (default): synchronise the stream once after the run and read the run's status words
         (``d3p_dpvi_logreg_run_status``); a run whose chained launch was aborted by a bounded wait raises ``D3PError``
         instead of returning a silently truncated trajectory.  ``check_status=False`` keeps the call asynchronous; the
-        caller then checks with ``DPSVI.last_run_status()`` before trusting the result."""
+        caller then checks with ``DPSVI.last_run_status()`` before trusting the result.  A run that was stopped is run again,
+        from the same (untouched) input state, with one launch per step (``d3p_dpvi_logreg_set_run_form``) before anything is
+        raised: a stalled chained launch costs the caller time, not the result."""
         info = getattr(get_batch, "source", None)
         if info is None or info.rng_suite is not strong_rng or not (self._gmm_fusable() or self._is_vae() or self._fusable()):
             # no native loop for this combination (sampling with replacement, split_batchify_data's epochs, another rng_suite,
@@ -838,10 +841,24 @@ class DPSVI:
         self._last_run = (model, src, ws, (bkey, bidx))   # what last_run_status() needs (keeps the buffers alive)
         if check_status:
             aborted, _ = self.last_run_status()
+            if aborted and not _no_fallback:
+                # The chained launch was stopped by a bounded wait (its workgroups did not make progress together: a GPU shared
+                # with other work).  The input state is untouched (functional update), so the same steps are run again with one
+                # launch per step -- no cross-workgroup waits, about twice the time -- instead of failing the caller: the
+                # reference's jit(fori_loop) cannot stall either.
+                import warnings
+                why = self.last_abort_code()
+                warnings.warn("run_steps: the chained launch was stopped by a bounded wait (" + why + "); re-running the "
+                              f"{int(num_steps)} steps with one launch per step", RuntimeWarning)
+                check(lib.d3p_dpvi_logreg_set_run_form(1))
+                try:
+                    return self.run_steps(svi_state, get_batch, batchifier_state, first_batch, num_steps, check_status=True,
+                                          _no_fallback=True, **kwargs)
+                finally:
+                    check(lib.d3p_dpvi_logreg_set_run_form(0))
             if aborted:
-                raise _lib.D3PError("run_steps: a bounded wait of the chained launch ran out (the step kernel's workgroups "
-                                    "did not make progress); the run was stopped and its state and losses are invalid -- "
-                                    + self.last_abort_code())
+                raise _lib.D3PError("run_steps: a bounded wait ran out (the step kernel's workgroups did not make progress); the "
+                                    "run was stopped and its state and losses are invalid -- " + self.last_abort_code())
         new_key = keybuf[num_steps & 1].reshape(4, 4)
         return DPSVIState((step, params, m, v), new_key, svi_state.observation_scale), losses[:num_steps]
 

@@ -442,6 +442,13 @@ int d3p_dpvi_logreg_chain_status(void* stream, const d3p_logreg_model* model, co
 int d3p_dpvi_logreg_run_status(void* stream, const d3p_logreg_model* model, const d3p_batch_source* src,
                                void* workspace_dev, size_t workspace_bytes, int32_t* aborted_out, int32_t* nonfinite_out);
 
+/* Form of the run loops' launches: 0 (default) -- the chained launch where the shape has one: the steps of a prepared batch in
+ * ONE launch whose workgroups hand over through arrival counters, which needs the launch's workgroups to make progress
+ * together (a GPU shared with other work can starve one: the bounded waits then stop the run, d3p_dpvi_logreg_run_status);
+ * 1 -- one launch per step: no cross-workgroup waits at all, ~2 x slower.  DPSVI.run_steps re-runs a stopped run in form 1
+ * (the reference's jit(fori_loop) cannot stall; a drop-in must not either).  Process-wide switch, not thread-safe.  ABI 6. */
+int d3p_dpvi_logreg_set_run_form(int form);
+
 /* Measurement hook for the run loops (d3p_dpvi_logreg_run, d3p_dpvi_logreg_run_dist): while enabled, every launch of the
  * step kernel is bracketed by HIP start/stop events on the launch stream (hipExtLaunchKernel).
  * d3p_dpvi_logreg_kernel_timing_read synchronises the recorded events, returns the summed kernel time (microseconds), the

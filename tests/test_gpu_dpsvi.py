@@ -802,3 +802,51 @@ def test_run_steps_serves_batchifiers_without_a_native_loop(rng, kind):
     assert losses.shape == (steps,)
     np.testing.assert_array_equal(np_(losses), np.asarray(ref_losses, np.float32))
     assert torch.equal(new_st.optim_state[1], ref.optim_state[1]) and torch.equal(new_st.rng_key, ref.rng_key)
+
+
+def test_run_steps_falls_back_to_one_launch_per_step_when_the_chained_launch_is_stopped(rng, monkeypatch):
+    """A chained launch that a bounded wait stopped (its workgroups did not make progress together: a GPU shared with other
+    work) must cost the caller time, not the result: run_steps re-runs the steps from the untouched input state with one launch
+    per step (d3p_dpvi_logreg_set_run_form(1)) and warns.  The stop is simulated at the point where run_steps reads the status."""
+    import d3p_amd._lib as L
+    from d3p_amd.minibatch import subsample_batchify_data
+    from d3p_amd.svi import DPSVI
+    N, d, B, steps = 20000, 512, 4096, 9
+    g = torch.Generator().manual_seed(17)
+    X = torch.randn(N, d, generator=g).cuda()
+    y = (torch.rand(N, generator=g) < 0.5).float().cuda()
+    svi = make_svi(d, False, N, C=1.0, sigma=0.5, lr=1e-2)
+    st = state_with(svi, rng.PRNGKey(71), np.zeros(d, np.float32), np.full(d, -2.0, np.float32))
+    _, gb = subsample_batchify_data((X, y), B)
+    want_state, want_losses = svi.run_steps(st, gb, rng.PRNGKey(72), 0, steps)
+    real = DPSVI.last_run_status
+    calls = {"n": 0}
+
+    def stopped_once(self):
+        calls["n"] += 1
+        aborted, nonfinite = real(self)
+        if calls["n"] == 1:
+            self._last_abort_code = 4 | (3 << 8)      # "the previous step was not released", step 3
+            return True, nonfinite
+        return aborted, nonfinite
+    monkeypatch.setattr(DPSVI, "last_run_status", stopped_once)
+    forms = []
+    lib = L.load()
+    real_set = lib.d3p_dpvi_logreg_set_run_form
+
+    class Spy:
+        def __call__(self, form):
+            forms.append(int(form))
+            return real_set(form)
+    monkeypatch.setattr(lib, "d3p_dpvi_logreg_set_run_form", Spy(), raising=False)
+    with pytest.warns(RuntimeWarning, match="one launch per step"):
+        got_state, got_losses = svi.run_steps(st, gb, rng.PRNGKey(72), 0, steps)
+    assert forms == [1, 0] and calls["n"] == 2
+    # (the two forms group the examples differently into workgroups: equal to fp32 rounding, same keys)
+    np.testing.assert_allclose(np_(got_losses), np_(want_losses), rtol=2e-6)
+    np.testing.assert_allclose(np_(got_state.optim_state[1]), np_(want_state.optim_state[1]), rtol=1e-4, atol=2e-6)
+    assert torch.equal(got_state.rng_key, want_state.rng_key) and int(got_state.optim_state[0]) == steps
+    # and a run that is stopped in the fallback form too raises
+    monkeypatch.setattr(DPSVI, "last_run_status", lambda self: (True, False))
+    with pytest.warns(RuntimeWarning), pytest.raises(L.D3PError):
+        svi.run_steps(st, gb, rng.PRNGKey(72), 0, steps)
