@@ -31,8 +31,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, the fp32 matrix (= vector) peak
 SIMDS, SHADER_GHZ = 1024, 2.4   # 256 CUs x 4 SIMD-32; peak shader clock
-# wave64 VALU issue: MI355X_MICROARCH.md gives 2 cycles per plain fp32 instruction per SIMD; profiles/r03_valu_opcodes.json
-# measures 1.66 (VOP2 add / xor / fmac), 2.06 (v_fma_f32), 2.66 (VOP3 integer, DPP), 4.67 (transcendental) at 4 waves per SIMD
+# wave64 VALU issue: MI355X_MICROARCH.md gives 2 cycles per plain fp32 instruction per SIMD -- the nominal peak used here; no
+# opcode measured reaches it (profiles/r03_valu_opcodes.json, launch-based: VOP2 add / xor / fmac 2.4, v_fma_f32 3.0, VOP3 integer /
+# DPP / packed 4.3, transcendental 8.3 cycles), so a `frac` against this peak is conservative
 VALU_PEAK_GINSTR = SIMDS * SHADER_GHZ / 2.0
 
 
