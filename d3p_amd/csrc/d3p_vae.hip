@@ -1116,8 +1116,16 @@ __global__ void k_vae_finalize(VaeFinalArgs a)
         if (a.w_splits[b] > 0) {
             const uint32_t e = (uint32_t)col - a.w_off[b];
             const float* t = a.wpart + a.w_base[b] + (size_t)(e / a.w_out[b]) * a.w_ld[b] + a.w_coff[b] + e % a.w_out[b];
+            // (all tiles requested at once -- a loop over a run-time count is one memory round trip per tile: 16.6 -> 13.4 us --,
+            // summed in fixed order)
+            const int nz = a.w_splits[b];
+            const size_t tile = a.w_tile[b];
+            float tv[D3P_WPART_SPLITS];
+#pragma unroll
+            for (int z = 0; z < D3P_WPART_SPLITS; ++z) tv[z] = z < nz ? t[(size_t)z * tile] : 0.f;
             tot = 0.f;
-            for (int z = 0; z < a.w_splits[b]; ++z) tot += t[(size_t)z * a.w_tile[b]];  // fixed order
+#pragma unroll
+            for (int z = 0; z < D3P_WPART_SPLITS; ++z) tot += z < nz ? tv[z] : 0.f;
         }
     }
     const float g = (tot / Bf + a.noise[col] * (a.h.dp_scale * (a.h.clip / n))) * a.obs_scale * factor;
