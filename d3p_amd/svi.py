@@ -808,17 +808,21 @@ class DPSVI:
         model = self._model_struct(d, kwargs, svi_state.observation_scale)
         hyper = self._hyper()
         bkey = batchifier_state.contiguous()
-        losses = torch.empty(max(num_steps, 1), dtype=torch.float32, device=dev)
         step0, params0, m0, v0 = svi_state.optim_state
         key0 = svi_state.rng_key.reshape(16)
         n = params0.numel()
+        nl = max(num_steps, 1)
         if (params0.dtype == m0.dtype == v0.dtype == torch.float32 and m0.numel() == n
                 and v0.numel() == n and params0.is_contiguous() and m0.is_contiguous() and v0.is_contiguous()
                 and key0.is_contiguous() and key0.dtype == torch.uint32 and step0.dtype == torch.int32):
             # the new state is written by the run itself (d3p_dpvi_logreg_run_from copies the old one inside its first kernel):
-            # no copy / fill launches on the host's enqueue path -- they were ~80 us of a 20-step run
-            flat = torch.empty(3 * n, dtype=torch.float32, device=dev)
-            step, params, m, v = torch.empty_like(step0), flat[:n].view_as(params0), flat[n:2 * n].view_as(m0), flat[2 * n:].view_as(v0)
+            # no copy / fill launches on the host's enqueue path -- they were ~80 us of a 20-step run.  Losses and the three
+            # state arrays are views of ONE allocation (one allocator call and one split instead of two calls and six views:
+            # the host's 17 us in front of the first launch are part of a short run's wall time)
+            params, m, v, losses = torch.empty(3 * n + nl, dtype=torch.float32, device=dev).split((n, n, n, nl))   # (state first: its alignment is that of three separate arrays of n)
+            if params0.dim() != 1:
+                params, m, v = params.view_as(params0), m.view_as(m0), v.view_as(v0)
+            step = torch.empty_like(step0)
             keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
             bidx = None
             src = BatchSource(info.kind, info.batch_size, float(info.q), int(info.suppress), bkey.data_ptr(), None, None, N, 0, N)
@@ -828,6 +832,7 @@ class DPSVI:
             check(lib.d3p_dpvi_logreg_run_from(stream_ptr(), C.byref(model), C.byref(hyper), C.byref(st), C.byref(frm), C.byref(src),
                                                int(first_batch), ptr(X), ptr(y), int(num_steps), ptr(losses), ptr(ws), ws.numel()))
         else:
+            losses = torch.empty(nl, dtype=torch.float32, device=dev)
             step, params, m, v = _fresh_optim_state(svi_state.optim_state)
             keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
             keybuf[0].copy_(key0)
@@ -860,7 +865,7 @@ class DPSVI:
                 raise _lib.D3PError("run_steps: a bounded wait ran out (the step kernel's workgroups did not make progress); the "
                                     "run was stopped and its state and losses are invalid -- " + self.last_abort_code())
         new_key = keybuf[num_steps & 1].reshape(4, 4)
-        return DPSVIState((step, params, m, v), new_key, svi_state.observation_scale), losses[:num_steps]
+        return DPSVIState((step, params, m, v), new_key, svi_state.observation_scale), (losses if num_steps == nl else losses[:num_steps])
 
     def last_run_status(self):
         """(aborted, nonfinite) of the last ``run_steps`` call, after synchronising the stream: ``aborted`` -- a bounded
