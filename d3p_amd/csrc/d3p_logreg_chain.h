@@ -821,12 +821,9 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     // W = 16: the key-chain link of step `step_t` of the NEXT batch, behind the arrival of workgroup 0 (off the step's critical
     // path; the previous link was made by workgroup 0 of the previous step, behind ITS arrival)
     if (W16 && bid == 0 && step_t < a.K_next && tid < 64) {
-        uint32_t* progress = a.bar + (size_t)a.K * D3P_BAR_WORDS;
-        bool go = true;
-        if (step_t > 0) go = chain_wait(progress, (uint32_t)step_t, a.status, abort_code(D3P_ABORT_KEY_CHAIN, step_t));
-        if (go) chain_step<true>(a.chain_sched, a.chain_slots + step_t, step_t, step_t == a.K_next - 1);
-        __builtin_amdgcn_s_waitcnt(0);
-        if (tid == 0) __hip_atomic_store(progress, (uint32_t)step_t + 1u, __ATOMIC_RELAXED, D3P_AGENT);
+        // (the 32 bytes in front of the words hold the progress word of the 8-wave form's key-chain workgroup: unused here)
+        unsigned long long* ll = reinterpret_cast<unsigned long long*>(a.bar + (size_t)a.K * D3P_BAR_WORDS) + 4;
+        chain_step_ll(a.chain_sched, ll, a.chain_slots + step_t, step_t, step_t == a.K_next - 1, a.status, abort_code(D3P_ABORT_KEY_CHAIN, step_t));
     }
 #undef D3P_CSTAMP
 }

@@ -236,6 +236,73 @@ __device__ __forceinline__ void chain_step(Sched* sched, StepSlot* slot, int t, 
     }
 }
 
+// chain_step for the links that ride in the tail of workgroup 0 of the 16-wave chained launch, one per step (d3p_logreg_chain.h).
+// There the tail's length is the next-but-one step's problem (the workgroup that inherits the CU enters late), and the plain form
+// spends two memory round trips before it derives anything (progress word of the previous link, then the schedule) and waits for
+// its stores before it raises the progress word: measured 0.2 us per step of a long run.  Here the running key travels between
+// consecutive links as eight self-validating 8-byte words {key word | link index} (`ll`, zeroed with the launch's arrival
+// counters): ONE round trip that is its own readiness test, and the stores are not waited for.  Link 0 starts from the schedule
+// (left by an earlier launch), the last link leaves the schedule for the next one; the counters of the schedule are constant
+// during the launch (only the last link moves them).
+__device__ __forceinline__ void chain_step_ll(Sched* sched, unsigned long long* ll, StepSlot* slot, int t, int last, uint32_t* abort_flag,
+                                              uint32_t abort_code_)
+{
+    const int lane = threadIdx.x & 63, q = lane & 3, child = (lane >> 2) < 3 ? (lane >> 2) : 0;
+    const int32_t adam0 = ld_x<true>(&sched->adam_i);
+    const uint32_t batch0 = ld_x<true>(&sched->batch_i);
+    const uint32_t p0 = ld_x<true>(&sched->key[q]);   // the constants row never changes
+    uint32_t p1, p2, p3;
+    if (t == 0) {
+        p1 = ld_x<true>(&sched->key[4 + q]);
+        p2 = ld_x<true>(&sched->key[8 + q]);
+        p3 = ld_x<true>(&sched->key[12 + q]);
+    } else {  // the key after link t - 1: words 4 + q, 8 + q tagged with t (a derived key's words 12 .. 15 are zero)
+        unsigned long long w1 = 0ull, w2 = 0ull;
+        bool ok = false;
+        for (uint32_t spins = 0; spins <= D3P_WAIT_ROUNDS; ++spins) {
+            w1 = __hip_atomic_load(ll + q, __ATOMIC_RELAXED, D3P_AGENT);
+            w2 = __hip_atomic_load(ll + 4 + q, __ATOMIC_RELAXED, D3P_AGENT);
+            const bool mine = (uint32_t)(w1 >> 32) == (uint32_t)t && (uint32_t)(w2 >> 32) == (uint32_t)t;
+            if (__ballot(!mine) == 0ull) { ok = true; break; }
+            if ((spins & 63u) == 63u && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, D3P_AGENT) != 0u) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) {
+            if (lane == 0) chain_raise(abort_flag, abort_code_);
+            return;
+        }
+        p1 = (uint32_t)w1;
+        p2 = (uint32_t)w2;
+        p3 = 0u;
+    }
+    uint32_t a, b;
+    derive_child_quad_regs(p0, p1, p2, p3, (uint32_t)child, D3P_TAG_SPLIT, 0u, a, b);
+    if (lane < 4) {
+        if (!last) {
+            const unsigned long long tag = (unsigned long long)(uint32_t)(t + 1) << 32;
+            __hip_atomic_store(ll + q, tag | a, __ATOMIC_RELAXED, D3P_AGENT);
+            __hip_atomic_store(ll + 4 + q, tag | b, __ATOMIC_RELAXED, D3P_AGENT);
+        } else {  // the schedule of the next launch
+            st_x<true>(&sched->key[4 + q], a);
+            st_x<true>(&sched->key[8 + q], b);
+            st_x<true>(&sched->key[12 + q], 0u);
+            if (lane == 0) {
+                st_x<true>(&sched->adam_i, adam0 + t + 1);
+                st_x<true>(&sched->batch_i, batch0 + (uint32_t)(t + 1));
+            }
+        }
+    } else if (lane < 12) {  // gradient key (child 1), perturbation key (child 2)
+        uint32_t* dst = lane < 8 ? slot->grad_key : slot->pert_key;
+        dst[q] = p0;
+        dst[4 + q] = a;
+        dst[8 + q] = b;
+        dst[12 + q] = 0u;
+    } else if (lane == 12) {
+        slot->adam_i = adam0 + t;
+        slot->batch_i = batch0 + (uint32_t)t;
+    }
+}
+
 // Arguments of the one-launch-per-step mode (MODE 2) of k_logreg_main: the cross-workgroup sum of the
 // clipped gradients goes through 64-bit FIXED-POINT integer atomics into R replicas (integer addition is
 // associative, so the result is the exact sum of the fp32 workgroup partials and bitwise reproducible,
