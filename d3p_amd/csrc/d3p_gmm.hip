@@ -792,6 +792,39 @@ __device__ __forceinline__ float gmm_apply_column(const GmmPending& u, int c, fl
     return __fsub_rn(u.in[0][c], __fdiv_rn(__fmul_rn(u.lr, mhat), __fadd_rn(__fsqrt_rn(vhat), u.adam_eps)));
 }
 
+// One link of the key chain of the NEXT batch of steps, made by an extra workgroup of a k_gmm_head launch (consecutive launches
+// are ordered by the stream, so link i simply continues where link i - 1 left ws.chain_key): k_gmm_prep_chain's 0.9 us per step
+// -- serial, in front of every batch of 64 steps -- hides behind the head kernel's latency chain.  slot == nullptr: no link.
+struct GmmLink {
+    uint32_t* key;        // running key of the chain (16 words)
+    GmmSlot* slot;        // the slot of the step the link is for
+    const int32_t* step;  // optimiser step counter of the state (constant during the run)
+    int32_t step_add;
+    uint32_t batch_i;
+};
+
+__device__ __forceinline__ void gmm_chain_link(const GmmLink& l)
+{
+    const int lane = threadIdx.x & 63, q = lane & 3, child = (lane >> 2) < 3 ? (lane >> 2) : 0;
+    const uint32_t p0 = l.key[q], p1 = l.key[4 + q], p2 = l.key[8 + q], p3 = l.key[12 + q];
+    uint32_t ka, kb;
+    derive_child_quad_regs(p0, p1, p2, p3, (uint32_t)child, D3P_TAG_SPLIT, 0u, ka, kb);
+    if (lane < 4) {  // the next state key (child 0)
+        l.key[4 + q] = ka;
+        l.key[8 + q] = kb;
+        l.key[12 + q] = 0u;
+    } else if (lane < 12) {  // gradient key (child 1), perturbation key (child 2)
+        uint32_t* dst = lane < 8 ? l.slot->grad_key : l.slot->pert_key;
+        dst[q] = p0;
+        dst[4 + q] = ka;
+        dst[8 + q] = kb;
+        dst[12 + q] = 0u;
+    } else if (lane == 12) {
+        l.slot->adam_i = *l.step + l.step_add;
+        l.slot->batch_i = l.batch_i;
+    }
+}
+
 struct GmmHeadArgs {
     GmmPending prev;          // valid when apply_prev
     int apply_prev;
@@ -805,13 +838,19 @@ struct GmmHeadArgs {
     const uint8_t* mask;      // nullable
     uint32_t B;
     int K;
+    GmmLink link;             // link.slot != nullptr: the LAST workgroup of the grid makes this link and nothing else
 };
 
 __global__ void __launch_bounds__(256) k_gmm_head(GmmHeadArgs a)
 {
     __shared__ double sh_alpha[32], sh_psi1[32], sh_dir[512];
     const int tid = threadIdx.x, K = a.K;
-    const uint32_t gtid = blockIdx.x * 256u + (uint32_t)tid, gsize = gridDim.x * 256u;
+    const uint32_t n_blocks = gridDim.x - (a.link.slot ? 1u : 0u);
+    if (blockIdx.x == n_blocks) {  // (only when there is a link)
+        if (tid < 64) gmm_chain_link(a.link);
+        return;
+    }
+    const uint32_t gtid = blockIdx.x * 256u + (uint32_t)tid, gsize = n_blocks * 256u;
     float n = 0.f, factor = 0.f;
     if (a.apply_prev) {
         n = gmm_pending_count(a.prev);
@@ -860,7 +899,7 @@ __global__ void __launch_bounds__(256) k_gmm_head(GmmHeadArgs a)
     if (tid < K) sh_psi1[tid] = digamma_d(sh_alpha[tid] + 1.0);
     __syncthreads();
     const uint32_t epw = 256u / (uint32_t)K, pl = (uint32_t)tid / (uint32_t)K, k = (uint32_t)tid % (uint32_t)K;
-    for (uint32_t p0 = blockIdx.x * epw; p0 < a.B; p0 += gridDim.x * epw) {  // (one pass: the grid covers the batch)
+    for (uint32_t p0 = blockIdx.x * epw; p0 < a.B; p0 += n_blocks * epw) {  // (one pass: the grid covers the batch)
         const uint32_t p = p0 + pl;
         const bool p_ok = pl < epw && p < a.B && !(a.mask && a.mask[p] == 0);  // masked examples are skipped by k_gmm_px
         uint32_t kp0 = 0, kp1 = 0;
@@ -875,6 +914,8 @@ __global__ void __launch_bounds__(256) k_gmm_head(GmmHeadArgs a)
 struct GmmFlushArgs {
     GmmPending prev;
     int32_t* step;  // nullable: the state's optimiser step counter, set to the applied step's index + 1
+    const uint32_t* key_src;  // nullable: the chain's running key after the run's last link (links made in k_gmm_head launches) ...
+    uint32_t* key_dst;        // ... goes to the state's key slot
 };
 
 __global__ void __launch_bounds__(256) k_gmm_flush(GmmFlushArgs a)
@@ -894,6 +935,7 @@ __global__ void __launch_bounds__(256) k_gmm_flush(GmmFlushArgs a)
         if (a.prev.loss_out) *a.prev.loss_out = gmm_pending_loss(a.prev, factor);
         if (a.step) *a.step = a.prev.slot->adam_i + 1;
     }
+    if (a.key_src && gtid < 16u) a.key_dst[gtid] = a.key_src[gtid];
 }
 
 // out[c] = this rank's [clipped sums | loss sum | n] as floats (d3p_dpvi_gmm_local_sums)
@@ -1151,15 +1193,21 @@ static int gmm_enqueue_steps(hipStream_t s, const d3p_gmm_model* model, const d3
     for (uint32_t t0 = 0; t0 < num_steps; t0 += SB) {
         const uint32_t Kb = num_steps - t0 < SB ? num_steps - t0 : SB, par = (t0 / SB) & 1u;
         const bool last = t0 + Kb == num_steps;
-        GmmChainArgs ca;
-        ca.in_key = t0 == 0 ? cur_key : ws.chain_key;
-        ca.out_key = last ? (stage == 1 ? nullptr : final_key) : ws.chain_key;
-        ca.step = state->step;
-        ca.step_add = (int32_t)t0;
-        ca.batch0 = first_batch + t0;
-        ca.slots = ws.slots[par];
-        ca.K = (int)Kb;
-        hipLaunchKernelGGL(k_gmm_prep_chain, dim3(1), dim3(64), 0, s, ca);
+        // whole updates: the chain of every batch but the first is made, link by link, in the head launches of the batch before
+        // it (GmmLink); the staged forms (one step only) keep the chain kernel
+        const bool links = stage == 0;
+        const uint32_t Kb_next = (links && !last) ? (num_steps - (t0 + Kb) < SB ? num_steps - (t0 + Kb) : SB) : 0u;
+        if (t0 == 0 || !links) {
+            GmmChainArgs ca;
+            ca.in_key = t0 == 0 ? cur_key : ws.chain_key;
+            ca.out_key = last ? (stage == 1 ? nullptr : final_key) : ws.chain_key;
+            ca.step = state->step;
+            ca.step_add = (int32_t)t0;
+            ca.batch0 = first_batch + t0;
+            ca.slots = ws.slots[par];
+            ca.K = (int)Kb;
+            hipLaunchKernelGGL(k_gmm_prep_chain, dim3(1), dim3(64), 0, s, ca);
+        }
         GmmPrepArgs pa;
         pa.slots = ws.slots[par];
         pa.batch_key = batch_key_dev;
@@ -1195,7 +1243,14 @@ static int gmm_enqueue_steps(hipStream_t s, const d3p_gmm_model* model, const d3
             ha.mask = mask_dev;
             ha.B = B;
             ha.K = K;
-            hipLaunchKernelGGL(k_gmm_head, dim3(cdiv(B, 256u / (uint32_t)K)), dim3(256), 0, s, ha);
+            if (t - t0 < Kb_next) {  // link t - t0 of the next batch (its slots: the other buffer)
+                ha.link.key = ws.chain_key;
+                ha.link.slot = ws.slots[par ^ 1u] + (t - t0);
+                ha.link.step = state->step;
+                ha.link.step_add = (int32_t)(t0 + Kb + (t - t0));
+                ha.link.batch_i = first_batch + t0 + Kb + (t - t0);
+            }
+            hipLaunchKernelGGL(k_gmm_head, dim3(cdiv(B, 256u / (uint32_t)K) + (ha.link.slot ? 1u : 0u)), dim3(256), 0, s, ha);
             GmmArgs a;
             gmm_fill(&a, model, buf(t, 0), X_dev, batch_key_dev ? ws.idx + (size_t)(t - t0) * B : nullptr, mask_dev, B, nullptr,
                      hyper->clip);
@@ -1222,6 +1277,12 @@ static int gmm_enqueue_steps(hipStream_t s, const d3p_gmm_model* model, const d3
         fa.prev.Bf = (float)(B_total ? B_total : B);
     }
     fa.step = state->step;
+    fa.key_src = nullptr;
+    fa.key_dst = nullptr;
+    if (stage == 0 && num_steps > SB) {  // the last batch's links were made in head launches: their key is in ws.chain_key
+        fa.key_src = ws.chain_key;
+        fa.key_dst = final_key;
+    }
     hipLaunchKernelGGL(k_gmm_flush, dim3(cdiv(P, 256)), dim3(256), 0, s, fa);
     return check_launch("d3p_dpvi_gmm_update");
 }
