@@ -743,9 +743,6 @@ class DPSVI:
         dev = X.device
         model = self._model_struct(d, kwargs, svi_state.observation_scale)
         hyper = self._hyper()
-        step, params, m, v = _fresh_optim_state(svi_state.optim_state)
-        keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
-        keybuf[0].copy_(svi_state.rng_key.reshape(16))
         mask_t = None
         if not isinstance(mask, bool):
             mask_t = mask.to(torch.uint8).contiguous()
@@ -753,6 +750,29 @@ class DPSVI:
             mask_t = torch.zeros(B, dtype=torch.uint8, device=dev)
         src = BatchSource(_lib.D3P_BATCH_EXPLICIT, B, 0.0, 0, None, None,
                           None if mask_t is None else mask_t.data_ptr(), B, 0, B)
+        step0, params0, m0, v0 = svi_state.optim_state
+        key0 = svi_state.rng_key.reshape(16)
+        n = params0.numel()
+        if (_eps is None and _grad_out is None and X.dtype == torch.float32 and (y is None or y.dtype == torch.float32)
+                and params0.dtype == m0.dtype == v0.dtype == torch.float32 and m0.numel() == n and v0.numel() == n
+                and params0.is_contiguous() and m0.is_contiguous() and v0.is_contiguous() and key0.is_contiguous()
+                and key0.dtype == torch.uint32 and step0.dtype == torch.int32):
+            # One step of the device-resident run on the caller's batch: the new state is written by the run itself (no
+            # copies of the old one), four launches instead of the nine of the two-call form below -- 59 -> 40 us per call
+            params, m, v, loss = torch.empty(3 * n + 1, dtype=torch.float32, device=dev).split((n, n, n, 1))
+            if params0.dim() != 1:
+                params, m, v = params.view_as(params0), m.view_as(m0), v.view_as(v0)
+            step = torch.empty_like(step0)
+            keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
+            st = self._state_struct(keybuf, 0, (step, params, m, v))
+            frm = self._state_struct(key0, 0, (step0, params0, m0, v0))
+            ws = self._workspace(lib.d3p_dpvi_logreg_workspace(C.byref(model), C.byref(src)), dev)
+            check(lib.d3p_dpvi_logreg_run_from(stream_ptr(), C.byref(model), C.byref(hyper), C.byref(st), C.byref(frm), C.byref(src),
+                                               0, ptr(X), ptr(y), 1, ptr(loss), ptr(ws), ws.numel()))
+            return DPSVIState((step, params, m, v), keybuf[1].reshape(4, 4), svi_state.observation_scale), loss[0]
+        step, params, m, v = _fresh_optim_state(svi_state.optim_state)
+        keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
+        keybuf[0].copy_(key0)
         st = self._state_struct(keybuf, 0, (step, params, m, v))
         ws = self._workspace(lib.d3p_dpvi_logreg_workspace(C.byref(model), C.byref(src)), dev)
         sums = torch.empty(2 * D + 2, dtype=torch.float32, device=dev)
