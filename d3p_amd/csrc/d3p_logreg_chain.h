@@ -299,22 +299,29 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             x1 = *reinterpret_cast<const float4*>(xr + HALF + 4 * lane);
         }
     };
+    // The table rows are requested BEHIND the noise generation (D3P_DBG=16384: in front of it, as before): a workgroup enters
+    // when a workgroup of step t - 2 leaves, i.e. around the moment step t - 1 is released, and 128 entering workgroups asking
+    // for 8.4 MB at once put that burst on the memory system exactly while the other step's workgroups poll for their release
+    // and fetch the sums -- the part of the chain that is pure memory latency.  The rows are not needed before phase 3.
+    size_t row_a = 0, row_b = 0;
     if (live1) {
         const uint32_t p = PLIST ? (a.plist_base + (size_t)step_t * a.B)[k1] : k1;
-        const size_t row = (size_t)((uint64_t)idx[p] - a.row_lo);
-        load_x(a.X + row * DF, xa0, xa1, xta);
-        ya = a.y[row];
+        row_a = (size_t)((uint64_t)idx[p] - a.row_lo);
         ka0 = skeys[2 * p];
         ka1 = skeys[2 * p + 1];
     }
     if (live2) {
         const uint32_t p = PLIST ? (a.plist_base + (size_t)step_t * a.B)[k2] : k2;
-        const size_t row = (size_t)((uint64_t)idx[p] - a.row_lo);
-        load_x(a.X + row * DF, xb0, xb1, xtb);
-        yb = a.y[row];
+        row_b = (size_t)((uint64_t)idx[p] - a.row_lo);
         kb0 = skeys[2 * p];
         kb1 = skeys[2 * p + 1];
     }
+    const bool rows_first = (a.dbg & 16384) != 0;
+    auto fetch_rows = [&]() {
+        if (live1) { load_x(a.X + row_a * DF, xa0, xa1, xta); ya = a.y[row_a]; }
+        if (live2) { load_x(a.X + row_b * DF, xb0, xb1, xtb); yb = a.y[row_b]; }
+    };
+    if (rows_first) fetch_rows();
     // the pending update of step g - 1: which state buffers, which slot / noise row (all known before the release)
     const int g = a.g0 + step_t;
     const StepSlot* ps = step_t > 0 ? a.slots + (step_t - 1) : a.prev_slot0;
@@ -356,12 +363,13 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     float* er = red + (size_t)wave * 2 * DL;   // the wave's row of the reduction buffer (partial sums, phase 4)
     struct Eps { Quad v0, v1; float vt, e2; };  // v0 / v1: the lane's 4 + 4 elements; vt: ICPT, the tail latent's noise; e2: the lane's share of -0.5 |eps|^2
     // (e2: the log q term of the loss is parameter-independent, so it is summed here)
-    auto gen = [&](uint32_t k0, uint32_t k1_) {
+    auto gen = [&](uint32_t k0, uint32_t k1_, auto&& halfway) {   // halfway(): called in front of the last of the four pairs
         const uint32_t s0 = __builtin_amdgcn_readfirstlane(k0), s1 = __builtin_amdgcn_readfirstlane(k1_);  // wave-uniform keys
         Eps o;
         float e2 = 0.f, w0[4], w1[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
+            if (n == 3) halfway();
             uint32_t b0, b1;
             threefry2x32(s0, s1, (uint32_t)(4 * lane + n), (uint32_t)(4 * lane + n + HALF), b0, b1);
             w0[n] = bits_to_normal_wu(b0);
@@ -381,8 +389,13 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
         return o;
     };
     Eps epa = {}, epb = {};
-    if (live1) epa = gen(ka0, ka1);
-    if (live2) epb = gen(kb0, kb1);
+    // (where in phase 0 the rows are requested, same box, us per step: in front of the noise 7.00 - 7.07, between the two examples'
+    // noise 6.98, three quarters through 6.90, HERE -- in front of the last of the eight pairs -- 6.87 - 6.91, behind all of it
+    // 6.95 - 6.99: later, and the burst meets the other step's accumulator atomics instead)
+    auto nothing = [] {};
+    if (live1) epa = gen(ka0, ka1, nothing);
+    if (live2) epb = gen(kb0, kb1, [&] { if (!rows_first) fetch_rows(); });
+    else if (!rows_first) fetch_rows();
     D3P_CSTAMP(8)
     // From here on the workgroup is on the critical path of the step (D3P_DBG=2: raised wave priority against the co-resident
     // workgroup of the next step, which is generating its noise on the same SIMDs).
@@ -412,12 +425,22 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     // ------------------------------------------------------------------ phase 2: update prologue (thread e <-> latent e)
     const int in = g > 0 ? ((g - 1) & 1) : 0, out = g & 1;
     float lc_mine = 0.f;  // this thread's share of sum_j lc_j = sum_j [log prior scale - log s_j] (example-independent loss term)
+    // W = 16: thread 0 of workgroup 0 reports the pending step (its loss, the state's counters) -- in the workgroup's TAIL, behind
+    // its arrival: nothing in the chain reads what it writes, and in the prologue it made workgroup 0 the last one at every
+    // barrier of every step (two more memory round trips on wave 0: staging barrier 1.1 us after the average workgroup).  Only
+    // the loss sums are requested here, with the column's own loads (the next step zeroes that accumulator).
+    const bool reports = W16 && apply_prev && bid == 0 && tid == 0;
+    long long rep_lll = 0, rep_lhh = 0;
+    float rep_factor = 0.f;
     {
         float n = 0.f, factor = 0.f;
         // nobody reads the next accumulator any more (the previous step's prologues are over; at the first step of a run
-        // nobody has read it yet): zero it
-        for (int i = (int)bid * (64 * W) + tid; i < R * PA; i += a.nw * 64 * W)
-            __hip_atomic_store(acc_next + i, 0ll, __ATOMIC_RELAXED, D3P_AGENT);
+        // nobody has read it yet): zero it.  W = 16: behind the reduction barrier (below) -- the prologue's loads are counted
+        // behind these stores (one in-order counter for loads and stores), so the workgroups that have any (0 - 4) waited for a
+        // write acknowledgement in the step's latency chain
+        if (!W16)
+            for (int i = (int)bid * (64 * W) + tid; i < R * PA; i += a.nw * 64 * W)
+                __hip_atomic_store(acc_next + i, 0ll, __ATOMIC_RELAXED, D3P_AGENT);
         // one latent: pending update of its two columns (e: auto_loc, D + e: auto_scale) and its derived LDS entries
         // the sums of the previous step: the local replicas, or (data-parallel) the ONE row the exchange workgroup left
         const long long* sums = XCHG ? a.x.xsum + (size_t)((g + 2) % 3) * PA : acc_prev;
@@ -545,6 +568,13 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             const ColData d1 = col_load(mycol);
             ColData d2 = {};
             if (xcol >= 0) d2 = col_load(xcol);
+            if (reports) {
+#pragma unroll
+                for (int r = 0; r < nrep; ++r) {
+                    rep_lll += __hip_atomic_load(sums + (size_t)r * PA + P, __ATOMIC_RELAXED, D3P_AGENT);
+                    rep_lhh += __hip_atomic_load(sums + (size_t)r * PA + P + 2, __ATOMIC_RELAXED, D3P_AGENT);
+                }
+            }
             if (apply_prev) {
                 // the example count: ONE load instruction per wave (lane r < RU reads replica r's count column), summed over the lanes
                 const long long nr = __hip_atomic_load(sums + (size_t)(lane < RU ? lane : 0) * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT);
@@ -558,7 +588,8 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             latent(tid, zL, zS);
             if (ICPT && tid == 1) latent(D - 1, apply_prev ? prev_noise[D - 1] : 0.f, apply_prev ? prev_noise[2 * D - 1] : 0.f);  // the intercept
         }
-        if (apply_prev && bid == 0 && tid == 0) {
+        rep_factor = factor;
+        if (!W16 && apply_prev && bid == 0 && tid == 0) {
             long long lll = 0, lhh = 0;
 #pragma unroll
             for (int r = 0; r < nrep; ++r) {
@@ -716,11 +747,11 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             load_x(a.X + rowb * DF, xs0[1], xs1[1], xts[1]);
             ys[1] = a.y[rowb];
             const uint32_t r0 = skeys[2 * pb], r1 = skeys[2 * pb + 1];
-            es[0] = gen(q0, q1);
-            es[1] = gen(r0, r1);
+            es[0] = gen(q0, q1, nothing);
+            es[1] = gen(r0, r1, nothing);
             examples(std::integral_constant<int, 2>{}, xs0, xs1, xts, ys, es);
         } else {
-            es[0] = gen(q0, q1);
+            es[0] = gen(q0, q1, nothing);
             examples(std::integral_constant<int, 1>{}, xs0, xs1, xts, ys, es);
         }
     }
@@ -742,6 +773,9 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     }
     __syncthreads();
     D3P_CSTAMP(6)
+    if (W16)   // (see the prologue; same box: 6.84 - 6.88 against 6.89 - 6.92 us per step)
+        for (int i = (int)bid * (64 * W) + tid; i < R * PA; i += a.nw * 64 * W)
+            __hip_atomic_store(acc_next + i, 0ll, __ATOMIC_RELAXED, D3P_AGENT);
     {
         // fixed-point integer atomics: the exact, order-independent sum of the workgroups' fp32 partials
         long long* outp = acc_cur + (size_t)(bid % RU) * PA;
@@ -817,6 +851,11 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             if (rec >= 0 && bid < 256u)
                 for (int k = 0; k < 16; ++k) a.stamps[((size_t)rec * 256 + bid) * 16 + k] = stamp[k];
         }
+    }
+    if (reports) {  // (see the prologue)
+        if (a.losses && g > 0) a.losses[g - 1] = ((float)loss_join(rep_lhh, rep_lll) / (float)a.B) * a.obs_scale * rep_factor;
+        *a.adam_step = ps->adam_i + 1;
+        if (a.batch_index) *a.batch_index = ps->batch_i + 1u;
     }
     // W = 16: the key-chain link of step `step_t` of the NEXT batch, behind the arrival of workgroup 0 (off the step's critical
     // path; the previous link was made by workgroup 0 of the previous step, behind ITS arrival)
