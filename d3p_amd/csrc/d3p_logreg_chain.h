@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             x1 = *reinterpret_cast<const float4*>(xr + HALF + 4 * lane);
         }
     };
-    // The table rows are requested BEHIND the noise generation (D3P_DBG=16384: in front of it, as before): a workgroup enters
+    // The table rows are requested near the END of the noise generation, not in front of it: a workgroup enters
     // when a workgroup of step t - 2 leaves, i.e. around the moment step t - 1 is released, and 128 entering workgroups asking
     // for 8.4 MB at once put that burst on the memory system exactly while the other step's workgroups poll for their release
     // and fetch the sums -- the part of the chain that is pure memory latency.  The rows are not needed before phase 3.
@@ -316,12 +316,10 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
         kb0 = skeys[2 * p];
         kb1 = skeys[2 * p + 1];
     }
-    const bool rows_first = (a.dbg & 16384) != 0;
     auto fetch_rows = [&]() {
         if (live1) { load_x(a.X + row_a * DF, xa0, xa1, xta); ya = a.y[row_a]; }
         if (live2) { load_x(a.X + row_b * DF, xb0, xb1, xtb); yb = a.y[row_b]; }
     };
-    if (rows_first) fetch_rows();
     // the pending update of step g - 1: which state buffers, which slot / noise row (all known before the release)
     const int g = a.g0 + step_t;
     const StepSlot* ps = step_t > 0 ? a.slots + (step_t - 1) : a.prev_slot0;
@@ -394,8 +392,8 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     // 6.95 - 6.99: later, and the burst meets the other step's accumulator atomics instead)
     auto nothing = [] {};
     if (live1) epa = gen(ka0, ka1, nothing);
-    if (live2) epb = gen(kb0, kb1, [&] { if (!rows_first) fetch_rows(); });
-    else if (!rows_first) fetch_rows();
+    if (live2) epb = gen(kb0, kb1, [&] { fetch_rows(); });
+    else fetch_rows();
     D3P_CSTAMP(8)
     // From here on the workgroup is on the critical path of the step (D3P_DBG=2: raised wave priority against the co-resident
     // workgroup of the next step, which is generating its noise on the same SIMDs).
@@ -425,13 +423,6 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     // ------------------------------------------------------------------ phase 2: update prologue (thread e <-> latent e)
     const int in = g > 0 ? ((g - 1) & 1) : 0, out = g & 1;
     float lc_mine = 0.f;  // this thread's share of sum_j lc_j = sum_j [log prior scale - log s_j] (example-independent loss term)
-    // W = 16: thread 0 of workgroup 0 reports the pending step (its loss, the state's counters) -- in the workgroup's TAIL, behind
-    // its arrival: nothing in the chain reads what it writes, and in the prologue it made workgroup 0 the last one at every
-    // barrier of every step (two more memory round trips on wave 0: staging barrier 1.1 us after the average workgroup).  Only
-    // the loss sums are requested here, with the column's own loads (the next step zeroes that accumulator).
-    const bool reports = W16 && apply_prev && bid == 0 && tid == 0;
-    long long rep_lll = 0, rep_lhh = 0;
-    float rep_factor = 0.f;
     {
         float n = 0.f, factor = 0.f;
         // nobody reads the next accumulator any more (the previous step's prologues are over; at the first step of a run
@@ -568,13 +559,6 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             const ColData d1 = col_load(mycol);
             ColData d2 = {};
             if (xcol >= 0) d2 = col_load(xcol);
-            if (reports) {
-#pragma unroll
-                for (int r = 0; r < nrep; ++r) {
-                    rep_lll += __hip_atomic_load(sums + (size_t)r * PA + P, __ATOMIC_RELAXED, D3P_AGENT);
-                    rep_lhh += __hip_atomic_load(sums + (size_t)r * PA + P + 2, __ATOMIC_RELAXED, D3P_AGENT);
-                }
-            }
             if (apply_prev) {
                 // the example count: ONE load instruction per wave (lane r < RU reads replica r's count column), summed over the lanes
                 const long long nr = __hip_atomic_load(sums + (size_t)(lane < RU ? lane : 0) * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT);
@@ -588,8 +572,10 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             latent(tid, zL, zS);
             if (ICPT && tid == 1) latent(D - 1, apply_prev ? prev_noise[D - 1] : 0.f, apply_prev ? prev_noise[2 * D - 1] : 0.f);  // the intercept
         }
-        rep_factor = factor;
-        if (!W16 && apply_prev && bid == 0 && tid == 0) {
+        // (measured and dropped: this report in workgroup 0's TAIL instead -- it makes workgroup 0 the last at the staging barrier of
+        // every step, 1.1 us after the average, but the tail is not free either: the workgroup that inherits the CU enters late;
+        // 6.73 -> 6.88 us per step, same box)
+        if (apply_prev && bid == 0 && tid == 0) {
             long long lll = 0, lhh = 0;
 #pragma unroll
             for (int r = 0; r < nrep; ++r) {
@@ -851,11 +837,6 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             if (rec >= 0 && bid < 256u)
                 for (int k = 0; k < 16; ++k) a.stamps[((size_t)rec * 256 + bid) * 16 + k] = stamp[k];
         }
-    }
-    if (reports) {  // (see the prologue)
-        if (a.losses && g > 0) a.losses[g - 1] = ((float)loss_join(rep_lhh, rep_lll) / (float)a.B) * a.obs_scale * rep_factor;
-        *a.adam_step = ps->adam_i + 1;
-        if (a.batch_index) *a.batch_index = ps->batch_i + 1u;
     }
     // W = 16: the key-chain link of step `step_t` of the NEXT batch, behind the arrival of workgroup 0 (off the step's critical
     // path; the previous link was made by workgroup 0 of the previous step, behind ITS arrival)
