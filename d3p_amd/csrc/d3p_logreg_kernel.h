@@ -196,7 +196,8 @@ __device__ __forceinline__ bool chain_wait_groups(const uint32_t* flags, uint32_
             if (lane == 0) chain_raise(abort_flag, code);
             return false;
         }
-        __builtin_amdgcn_s_sleep(2);
+        // (no s_sleep between two polls: a poll waits for its own answer -- a memory round trip -- anyway; without the 128 idle cycles
+        // the release is seen a little earlier: 6.73 -> 6.68 us per step, same box, five pairs of builds)
     }
 }
 
