@@ -182,6 +182,9 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
             "unit": "examples/s", "us_per_step": round(1e6 * ev / steps, 3), "final_loss": float(run.loss),
             "roofline": {"bound": "valu", "achieved": round(valu * steps / ev / 1e9, 2), "peak": VALU_PEAK_GINSTR, "unit": "Ginstr/s (wave64)",
                          "frac": round(valu * steps / ev / 1e9 / VALU_PEAK_GINSTR, 4),
+                         # (what the step achieves, for comparison with the per-opcode rates of profiles/r03_valu_opcodes.json:
+                         # VOP2 2.4, VOP3 / DPP / packed 4.3, transcendental 8.3 cycles per wave64 instruction and SIMD)
+                         "cycles_per_valu_instruction_and_simd": round(ev / steps * SHADER_GHZ * 1e9 * SIMDS / valu, 2),
                          "valu_instructions_per_step": valu, "instruction_count_source": "profiles/r03_gmm_pmc.json (SQ_INSTS_VALU of "
                          "k_gmm_px + k_gmm_head); not re-counted in this run",
                          "hbm": {"algorithmic_bytes_per_step": alg, "achieved_GBps": round(alg * steps / ev / 1e9, 2),
@@ -256,6 +259,9 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
             "roofline": {"bound": "valu", "achieved": round(lane_ops * steps / ev / 1e12, 3), "peak": round(peak / 1e12, 2),
                          "unit": "T integer lane-operations/s (ChaCha20 keystream of the Bernoulli mask)",
                          "frac": round(lane_ops * steps / ev / peak, 4), "chacha_blocks_per_step": blocks,
+                         # the mix of the block function -- 1/3 VOP3 rotates at 4.3, 2/3 VOP2 add / xor at 2.4 cycles per wave64
+                         # instruction (profiles/r03_valu_opcodes.json, launch-based) -- issues at 3.03 cycles on average, not 2
+                         "frac_of_measured_issue_rate": round(lane_ops * steps / ev / peak * 3.03 / 2.0, 4),
                          "keystream_bytes_per_step": 4 * N,
                          "note": "whole step (mask + compaction + the DP-VI step) over the mask's integer work alone",
                          "timing": "HIP events on the launch stream around the 256-step device-resident run"}}
