@@ -171,14 +171,14 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
             st[0], losses = svi.run_steps(st[0], gb, bkey, first, k)
             run.loss = losses[-1]
         steps = 256
-        wall, ev = timed(run, 64, steps)
+        wall, ev = timed(run, 256, steps)   # (13 ms of warm-up: see the VAE leg)
         P = K + K * d
         alg = B * (4 * d + 4) + 3 * 4 * P                          # 2 175 168 B per step
         # wave64 VALU instructions per step, measured with SQ_INSTS_VALU (profiles/r03_gmm_pmc.json: k_gmm_px 18.46 M, k_gmm_head 3.24 M)
         valu = 21.7e6
         out["gmm_config3"] = {
             "workload": "BASELINE configs[2]: mixture model K=16 d=64, N=1e7 rows resident, batch 8192 (Feistel), C=20, sigma=1, Adam 1e-3",
-            "steps": steps, "warmup": 64, "steps_per_sec": round(steps / wall, 2), "value": round(B * steps / wall, 1),
+            "steps": steps, "warmup": 256, "steps_per_sec": round(steps / wall, 2), "value": round(B * steps / wall, 1),
             "unit": "examples/s", "us_per_step": round(1e6 * ev / steps, 3), "final_loss": float(run.loss),
             "roofline": {"bound": "valu", "achieved": round(valu * steps / ev / 1e9, 2), "peak": VALU_PEAK_GINSTR, "unit": "Ginstr/s (wave64)",
                          "frac": round(valu * steps / ev / 1e9 / VALU_PEAK_GINSTR, 4),
@@ -208,7 +208,9 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
             for _ in range(k):
                 st[0], run.loss = svi.update(st[0], X)
         steps = 40
-        wall, ev = timed(run, 8, steps)
+        # (48 warm-up updates = 15 ms: in the driver's short command this leg follows seconds of little GPU work, and with 8 warm-up
+        # updates the first VAE leg was timed while the clocks were still ramping -- 360-382 us per step instead of 313)
+        wall, ev = timed(run, 48, steps)
         hs = [H] + ([H2] if H2 else [])
         dec, enc = [Z] + hs[::-1] + [D], [D] + hs
         layers = list(zip(dec[:-1], dec[1:])) + list(zip(enc[:-1], enc[1:])) + [(hs[-1], 2 * Z)]
@@ -219,7 +221,7 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
         out["vae_config5" + ("_400_200" if H2 else "")] = {
             "workload": "BASELINE configs[4]: VAE 784 -> %s -> 50 (P = %d), batch 4096, C=10, sigma=1, Adam 1e-3; one DPSVI.update "
                         "(~30 launches) per step" % (hs, Pn),
-            "steps": steps, "warmup": 8, "steps_per_sec": round(steps / wall, 2), "value": round(B * steps / wall, 1),
+            "steps": steps, "warmup": 48, "steps_per_sec": round(steps / wall, 2), "value": round(B * steps / wall, 1),
             "unit": "examples/s", "us_per_step": round(1e6 * ev / steps, 2), "final_loss": float(run.loss),
             "roofline": {"bound": "mfma", "achieved": round(flops * steps / ev / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flops * steps / ev / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "gemm_flop_per_step": flops,
@@ -246,7 +248,7 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
             st[0], losses = svi.run_steps(st[0], gb, bkey, first, k)
             run.loss = losses[-1]
         steps = 256
-        wall, ev = timed(run, 128, steps)
+        wall, ev = timed(run, 384, steps)
         blocks = (N + 15) // 16
         lane_ops = blocks * 980.0            # ~980 32-bit integer operations per 64-byte ChaCha20 block
         peak = SIMDS * 64 * SHADER_GHZ * 1e9 / 2.0   # lane-operations per second at 2 cycles per wave64 integer instruction
@@ -254,7 +256,7 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
             "workload": "north_star sampler: logistic regression d=512 over N=1e7 resident rows, Poisson batches q = 4096 / N padded "
                         "to the 0.99 quantile (N / 16 ChaCha20 blocks + an ordered compaction over N per step, fused: the keystream "
                         "never reaches HBM)",
-            "steps": steps, "warmup": 128, "steps_per_sec": round(steps / wall, 2), "value": round(B * steps / wall, 1),
+            "steps": steps, "warmup": 384, "steps_per_sec": round(steps / wall, 2), "value": round(B * steps / wall, 1),
             "unit": "examples/s (expected batch 4096)", "us_per_step": round(1e6 * ev / steps, 3), "final_loss": float(run.loss),
             "roofline": {"bound": "valu", "achieved": round(lane_ops * steps / ev / 1e12, 3), "peak": round(peak / 1e12, 2),
                          "unit": "T integer lane-operations/s (ChaCha20 keystream of the Bernoulli mask)",
