@@ -14,7 +14,7 @@ X = (torch.rand(B, 28, 28, generator=torch.Generator().manual_seed(0)) < 0.3).fl
 model = VAEModel(scale=1.0 / N)
 svi = DPSVI(model, VAEGuide(model), Adam(1e-3), Trace_ELBO(), 10.0, 1.0, num_obs_total=N, z_dim=Z, hidden_dim=(H, H2) if H2 else H)
 st = svi.init(rng.PRNGKey(0), X)
-for _ in range(5):
+for _ in range(60):   # (18 ms: the clocks need that long to settle after an idle phase -- with 5 updates the figure reads 3 % high)
     st, l = svi.update(st, X)
 torch.cuda.synchronize()
 t0 = time.time()
