@@ -506,7 +506,10 @@ def main():
                 kname = ("k_logreg_chain<PLIST, STAMPS=0, ICPT=0, XCHG=0, W=16> (chained launch: the <= 128 DP-VI steps of a prepared batch "
                          "per launch, 128 sixteen-wave workgroups per step; k_logreg_main<MODE 3> for shapes other than d = 512)")
             elif isinstance(comm, ddist.XchgComm) and native and not os.environ.get("D3P_XCHG_PER_STEP"):
-                kname = ("k_logreg_chain<PLIST=1, STAMPS=0, ICPT=0, XCHG=1, W=8> (data-parallel chained launch: per step 256 compute "
+                kname = ("k_logreg_chain<PLIST=1, STAMPS=0, ICPT=0, XCHG=1, W=16> (data-parallel chained launch, opt-in form D3P_XCHG_W16=1: "
+                         "128 compute workgroups per step, the one-shot full-mesh sum-exchange over xGMI in the tails of workgroups 0 and 1)"
+                         if os.environ.get("D3P_XCHG_W16") else
+                         "k_logreg_chain<PLIST=1, STAMPS=0, ICPT=0, XCHG=1, W=8> (data-parallel chained launch: per step 256 compute "
                          "workgroups + 1 key-chain + 2 exchange workgroups that carry the one-shot full-mesh sum-exchange over xGMI)")
             elif comm is not None and native:
                 kname = "k_logreg_main<MODE 2> (one launch per DP-VI step) + the step's collective (k_xchg or ncclAllReduce) on the same stream"

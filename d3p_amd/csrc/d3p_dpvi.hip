@@ -1210,7 +1210,10 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
         // The headline shape (d = 512, no intercept, logistic regression; at most ~two examples per wave of an 8-wave
         // workgroup) runs the kernel written for it (d3p_logreg_chain.h); D3P_NO_LEAN_CHAIN=1 keeps the generic template.
         const bool icpt = c.g.tail;  // 512 features + intercept (D = 513): the ICPT instantiations
-        const bool w16 = !xchg && chain_w16_enabled();
+        // (data-parallel runs: the 16-wave form with the exchange in the tails of workgroups 0 and 1 is opt-in, D3P_XCHG_W16=1 --
+        // measured on one GPU only, with a rank exchanging with itself; the 8-wave form stays the default until a multi-GPU run)
+        static const bool xchg_w16 = getenv("D3P_XCHG_W16") != nullptr;
+        const bool w16 = (!xchg || (xchg_w16 && c.items_expected >= 2ull * 16ull * 2ull)) && chain_w16_enabled();
         if (lean_chain_ok(c, w16)) {
             const uint32_t nw = w16 ? chain16_blocks(c.items_expected) : c.g.blocks;
             ChainArgs ca;
@@ -1254,7 +1257,7 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
                 D3P_HIP_TRY(hipMemsetAsync(c.ws.xflags, 0, (size_t)D3P_STEP_BATCH * D3P_XCHG_WGS * 32 * sizeof(uint32_t), c.s));
             }
             const int W = w16 ? 16 : D3P_CHAIN_W;
-            const dim3 grid((uint32_t)K * (nw + (w16 ? 0u : 1u) + (xchg ? (uint32_t)D3P_XCHG_WGS : 0u))), block(64 * W);
+            const dim3 grid((uint32_t)K * (nw + (w16 ? 0u : 1u) + ((xchg && !w16) ? (uint32_t)D3P_XCHG_WGS : 0u))), block(64 * W);
             const bool plist = ca.plist_base != nullptr;
             const size_t lds = chain_lds_bytes(icpt, W);
             const bool stamped = (ca.dbg & 32) && K >= 2 && !xchg;  // D3P_DBG=32: the stamped instantiation + the phase anatomy on stderr
@@ -1274,7 +1277,18 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
         if (e0) hipExtLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, false, 16>), grid, block, lds, c.s, e0, e1, 0, ca);        \
         else hipLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, false, 16>), grid, block, lds, c.s, ca);                         \
     } while (0)
-            if (w16) {
+#define D3P_CHAIN16_XCHG_LAUNCH(PL_, IC_)                                                                                        \
+    do {                                                                                                                      \
+        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logreg_chain<PL_, false, IC_, true, 16>), \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;   \
+        (void)lds_ok;                                                                                                         \
+        if (e0) hipExtLaunchKernelGGL((k_logreg_chain<PL_, false, IC_, true, 16>), grid, block, lds, c.s, e0, e1, 0, ca);       \
+        else hipLaunchKernelGGL((k_logreg_chain<PL_, false, IC_, true, 16>), grid, block, lds, c.s, ca);                        \
+    } while (0)
+            if (w16 && xchg) {
+                if (icpt) { if (plist) D3P_CHAIN16_XCHG_LAUNCH(true, true); else D3P_CHAIN16_XCHG_LAUNCH(false, true); }
+                else { if (plist) D3P_CHAIN16_XCHG_LAUNCH(true, false); else D3P_CHAIN16_XCHG_LAUNCH(false, false); }
+            } else if (w16) {
                 if (stamped) {
                     if (icpt) { if (plist) D3P_CHAIN16_LAUNCH(true, true, true); else D3P_CHAIN16_LAUNCH(false, true, true); }
                     else { if (plist) D3P_CHAIN16_LAUNCH(true, true, false); else D3P_CHAIN16_LAUNCH(false, true, false); }
@@ -1294,6 +1308,7 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
             }
 #undef D3P_CHAIN_LAUNCH
 #undef D3P_CHAIN16_LAUNCH
+#undef D3P_CHAIN16_XCHG_LAUNCH
             int rc = check_launch("k_logreg_chain");
             if (rc || !stamped) return rc;
             return print_chain_anatomy(c, nw);

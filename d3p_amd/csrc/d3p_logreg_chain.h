@@ -156,7 +156,6 @@ template <bool PLIST, bool STAMPS, bool ICPT = false, bool XCHG = false, int W_ 
 __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
 {
     static_assert(W_ == 8 || W_ == 16, "8- or 16-wave workgroups");
-    static_assert(!(XCHG && W_ == 16), "the data-parallel form keeps the 8-wave geometry");
     static_assert(RU >= 1 && RU <= D3P_ACC_R, "replicas in use");
     constexpr bool W16 = W_ == 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -176,11 +175,12 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     D3P_CSTAMP(0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t per = (uint32_t)a.nw + (W16 ? 0u : 1u) + (XCHG ? (uint32_t)D3P_XCHG_WGS : 0u);  // (W = 16: no key-chain workgroup)
+    // (W = 16: no key-chain workgroup, and the exchange of a data-parallel run rides in the tails of workgroups 0 and 1)
+    const uint32_t per = (uint32_t)a.nw + (W16 ? 0u : 1u) + ((XCHG && !W16) ? (uint32_t)D3P_XCHG_WGS : 0u);
     const int step_t = (int)(blockIdx.x / per);
     const uint32_t bid = blockIdx.x % per;
 
-    if (XCHG && bid > (uint32_t)a.nw) {  // ---- exchange workgroup `xj` of step `step_t`: columns c_lo .. c_lo + CH - 1
+    if (XCHG && !W16 && bid > (uint32_t)a.nw) {  // ---- exchange workgroup `xj` of step `step_t`: columns c_lo .. c_lo + CH - 1
         constexpr int CH = (PA + D3P_XCHG_WGS - 1) / D3P_XCHG_WGS;
         const int xj = (int)(bid - (uint32_t)a.nw - 1u), c_lo = xj * CH, cn = (PA - c_lo < CH ? PA - c_lo : CH);
         const size_t words = (size_t)R * PA;
@@ -441,18 +441,18 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
         long long nll_main = 0;  // example count of the pending step (summed in the thread's main column call, all lanes active)
         // (loads and arithmetic are separate steps so that a thread with two columns -- ICPT: the intercept's -- has the loads of
         // both in flight together: one memory round trip, not two, between the release and the staging barrier)
-        struct ColData { long long s8[RU]; float x, m, v; };
+        struct ColData { long long s8[nrep]; float x, m, v; };
         auto col_load = [&](int c) {
             ColData d;
             if (apply_prev) {
 #pragma unroll
-                for (int r = 0; r < RU; ++r) d.s8[r] = __hip_atomic_load(sums + (size_t)r * PA + c, __ATOMIC_RELAXED, D3P_AGENT);
+                for (int r = 0; r < nrep; ++r) d.s8[r] = __hip_atomic_load(sums + (size_t)r * PA + c, __ATOMIC_RELAXED, D3P_AGENT);
                 d.x = __hip_atomic_load(a.state[in][0] + c, __ATOMIC_RELAXED, D3P_AGENT);
                 d.m = __hip_atomic_load(a.state[in][1] + c, __ATOMIC_RELAXED, D3P_AGENT);
                 d.v = __hip_atomic_load(a.state[in][2] + c, __ATOMIC_RELAXED, D3P_AGENT);
             } else {
 #pragma unroll
-                for (int r = 0; r < RU; ++r) d.s8[r] = 0;
+                for (int r = 0; r < nrep; ++r) d.s8[r] = 0;
                 d.x = a.state[in][0][c];
                 d.m = d.v = 0.f;
             }
@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
                 float m = d.m, v = d.v;
                 long long sm = 0;
 #pragma unroll
-                for (int r = 0; r < RU; ++r) sm += d.s8[r];
+                for (int r = 0; r < nrep; ++r) sm += d.s8[r];
                 // (a workgroup that saw a non-finite partial added 2^44 to the count column: NaN from here on, like float sums)
                 const float poison = nll_main >= (1ll << 40) ? __builtin_nanf("") : 0.0f;
                 n = pre_n + poison;
@@ -561,9 +561,9 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             if (xcol >= 0) d2 = col_load(xcol);
             if (apply_prev) {
                 // the example count: ONE load instruction per wave (lane r < RU reads replica r's count column), summed over the lanes
-                const long long nr = __hip_atomic_load(sums + (size_t)(lane < RU ? lane : 0) * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT);
+                const long long nr = __hip_atomic_load(sums + (size_t)(lane < nrep ? lane : 0) * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT);
 #pragma unroll
-                for (int r = 0; r < RU; ++r)
+                for (int r = 0; r < nrep; ++r)
                     nll_main += ((long long)__builtin_amdgcn_readlane((int)(nr >> 32), r) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)nr, r);
             }
             col_apply(mycol, d1, zL);
@@ -837,6 +837,66 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             if (rec >= 0 && bid < 256u)
                 for (int k = 0; k < 16; ++k) a.stamps[((size_t)rec * 256 + bid) * 16 + k] = stamp[k];
         }
+    }
+    // W = 16, data-parallel: the step's exchange in the tails of workgroups 0 and 1 (half of the columns each, ONE column per
+    // thread): wait for the step's arrivals, fold the rank's replicas, deliver the folded row to every rank's inbox, collect the
+    // world's rows from the own inbox, leave their sum in the step's row of xsum and raise the exchange flag -- what the next
+    // step's workgroups wait for.  (Same protocol as the 8-wave form's exchange workgroups above; there a wave takes ranks, here a
+    // thread takes a column, and the chip still holds two steps side by side: 2 x 128 workgroups.)
+    if (XCHG && W16 && bid < (uint32_t)D3P_XCHG_WGS) {
+        constexpr int CH = (PA + D3P_XCHG_WGS - 1) / D3P_XCHG_WGS;
+        const int xj = (int)bid, c_lo = xj * CH, cn = (PA - c_lo < CH ? PA - c_lo : CH);
+        if (tid == 64) okw[1] = 0u;
+        if (wave == 0) {  // every compute workgroup of the step has added its sums
+            const uint32_t ng = (uint32_t)a.nw < D3P_BAR_GROUPS ? (uint32_t)a.nw : D3P_BAR_GROUPS;
+            const bool ok = chain_wait_groups(a.bar + (size_t)step_t * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS), ng, a.status,
+                                              abort_code(D3P_ABORT_XCHG_ARRIVALS, step_t, (uint32_t)xj), D3P_WAIT_ROUNDS_PEERS);
+            if (lane == 0) okw[0] = ok ? 0u : 1u;
+        }
+        __syncthreads();
+        if (okw[0] != 0u) return;
+        const unsigned long long epoch = a.x.epoch0 + (unsigned long long)step_t + 1ull;
+        const unsigned parity = (unsigned)(epoch & 1ull);
+        const uint32_t tag = (uint32_t)epoch;
+        const bool mine = tid < cn;
+        const int c = mine ? tid : 0;
+        if (mine) {
+            long long sfold = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) sfold += __hip_atomic_load(acc_cur + (size_t)r * PA + c_lo + c, __ATOMIC_RELAXED, D3P_AGENT);
+            for (int p = 0; p < a.x.world; ++p)
+                xchg_ll_store(a.x.peer[p], ((size_t)parity * a.x.world + a.x.rank) * PA + c_lo + c, sfold, tag);
+        }
+        long long tot = 0;
+        bool got = true;
+        for (int p = 0; p < a.x.world && got; ++p) {
+            const size_t row = ((size_t)parity * a.x.world + p) * PA + c_lo;
+            unsigned long long w0 = 0ull, w1 = 0ull;
+            bool ok = false;
+            for (uint32_t spins = 0; spins < 2u * D3P_WAIT_ROUNDS_PEERS; ++spins) {
+                xchg_ll_fetch(a.x.peer[a.x.rank], row + c, &w0, &w1);
+                const bool valid = !mine || xchg_ll_valid(w0, w1, tag);
+                if (__ballot(!valid) == 0ull) { ok = true; break; }
+                if ((spins & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok) {
+                got = false;
+                if (lane == 0) {
+                    okw[1] = 1u;
+                    chain_raise(a.status, abort_code(D3P_ABORT_XCHG_ROW, step_t, (uint32_t)p));
+                }
+            } else if (mine) {
+                tot += xchg_ll_value(w0, w1);
+            }
+        }
+        __syncthreads();
+        if (okw[1] != 0u) return;  // aborted: the run stops here (status[0])
+        if (mine) __hip_atomic_store(a.x.xsum + (size_t)(g % 3) * PA + c_lo + c, tot, __ATOMIC_RELAXED, D3P_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(a.x.xflag + ((size_t)step_t * D3P_XCHG_WGS + xj) * D3P_BAR_LINE, 1u, __ATOMIC_RELAXED, D3P_AGENT);
     }
     // W = 16: the key-chain link of step `step_t` of the NEXT batch, behind the arrival of workgroup 0 (off the step's critical
     // path; the previous link was made by workgroup 0 of the previous step, behind ITS arrival)
