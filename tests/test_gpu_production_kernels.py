@@ -300,3 +300,25 @@ def test_chain_kernel_small_and_ragged_grids_vs_oracle(gpu, O, B, icpt, sampler)
             mask = (np.arange(maxB) < nvalid).astype(np.float32)
         el.append(O.logreg_update(spec, hy, ost, Xn[idx], yn[idx], mask)[0])
     _compare(new_st, losses, ost, el, steps)
+
+
+@pytest.mark.parametrize("steps", [129, 255, 259, 385])
+def test_key_chain_links_across_launch_boundaries(gpu, O, steps):
+    """The key chain of every batch of 128 steps but the first is made link by link in the tail of workgroup 0 of the launch
+    before it, the running key travelling as self-validating tagged words (chain_step_ll): runs whose later batches have 1, 127,
+    3 + 128 and 1 + 2 x 128 steps end with the state key of `steps` successive split(key, 3)[0] (svi.py:208-211), bit for bit,
+    and with the step counter at `steps` -- at a small batch (two workgroups per step), where a link has the least time."""
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, d, B = 5000, 512, 64
+    X, y = _table(N, d, 71)
+    svi = _svi(d, False, N)
+    st = _state(svi, rng.PRNGKey(81), d, N)
+    _, gb = subsample_batchify_data((X.cuda(), y.cuda()), B)
+    new_st, losses = svi.run_steps(st, gb, rng.PRNGKey(82), 0, steps)
+    assert svi.last_run_status() == (False, False)
+    assert bool(torch.isfinite(losses).all()) and int(new_st.optim_state[0]) == steps
+    key = O.PRNGKey(81)
+    for _ in range(steps):
+        key = O.split(key, 3)[0]
+    assert np.array_equal(np_(new_st.rng_key).ravel(), np.asarray(key).ravel())
