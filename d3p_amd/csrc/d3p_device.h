@@ -373,6 +373,13 @@ __device__ __forceinline__ long long fixed_point_rn(float v, double sg, bool& in
     return (long long)(__double_as_longlong(t) - 0x4338000000000000ll);
 }
 
+// (double)v for every int64 v, in three instructions instead of the ~12 of the generic conversion: v = hi 2^32 + lo with hi the
+// signed upper and lo the unsigned lower word, both exact in double; the fused multiply-add rounds their exact sum once.
+__device__ __forceinline__ double i64_to_f64(long long v)
+{
+    return fma((double)(int)(v >> 32), 4294967296.0, (double)(unsigned int)v);
+}
+
 // the two integer parts of a workgroup's loss partial; false when it is not finite or beyond 2^78
 __device__ __forceinline__ bool loss_split(float s, long long& hi, long long& lo)
 {

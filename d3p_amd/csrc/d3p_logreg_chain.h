@@ -473,9 +473,12 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
                 factor = pre_factor + poison;
                 const float inv_B = pre_inv_B, inv_bc1 = pre_inv_bc1, inv_bc2 = pre_inv_bc2;
                 const float noise_scale = pre_noise_scale, out_scale = pre_out_scale + poison;
-                // |sm| < 2^51: the int64 -> double conversion as one integer add onto the bit pattern of 1.5 * 2^52 and one
-                // double subtraction (exact), instead of the ~12 instructions of the generic conversion
-                const double smd = __longlong_as_double(sm + 0x4338000000000000ll) - 6755399441055744.0;
+                // the int64 -> double conversion as hi 2^32 + lo in ONE fused multiply-add (v_cvt_f64_i32, v_cvt_f64_u32, v_fma_f64):
+                // the correctly rounded value for EVERY int64 -- the column sum over all workgroups, replicas and ranks is only
+                // bounded by B 2^40 (2^55 at B = 32768), and the bit-pattern trick of fixed_point_rn (exact below 2^51 only, used
+                // here in round 3) distorted any column whose clipped gradients add up beyond 2048 C: a constant feature, the
+                // intercept -- a wrong gradient AND a sensitivity above the C / n the noise is calibrated for
+                const double smd = i64_to_f64(sm);
                 const float tot = (float)(smd * a.inv_sg);
                 const float gr = __fmaf_rn(z, noise_scale, tot * inv_B) * out_scale;
                 m = (1.0f - a.b1) * gr + a.b1 * m;

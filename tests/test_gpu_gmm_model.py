@@ -180,6 +180,27 @@ def test_run_steps_across_prepared_batches(rng):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("steps", [1, 64, 65, 129, 200])
+def test_run_steps_key_chain_vs_oracle_split(rng, O, steps):
+    """The state key after `steps` steps of the native GMM loop is `steps` successive split(key, 3)[0] (svi.py:208-211), bit for
+    bit against the ORACLE's split -- also across the prepared batches of 64 steps, whose serial key chains are made link by link by
+    the extra workgroup of the `k_gmm_head` launches of the batch before them (not only against this build's own update())."""
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, d, K, B = 3000, 2, 3, 64
+    X = (torch.randn(N, d, generator=torch.Generator().manual_seed(5)) * 3).cuda()
+    svi = make_svi(K, d, N, C=20.0, sigma=0.5, lr=1e-2)
+    init, get_batch = subsample_batchify_data((X,), B)
+    nb, bstate = init(rng.PRNGKey(41))
+    st = svi.init(rng.PRNGKey(40), *get_batch(0, bstate))
+    new_st, losses = svi.run_steps(st, get_batch, bstate, 0, steps)
+    assert bool(torch.isfinite(losses).all()) and int(new_st.optim_state[0]) == steps
+    key = O.PRNGKey(40)
+    assert np.array_equal(np_(st.rng_key).ravel(), np.asarray(key).ravel())     # init retains the key (svi.py:213-236)
+    for _ in range(steps):
+        key = O.split(key, 3)[0]
+    assert np.array_equal(np_(new_st.rng_key).ravel(), np.asarray(key).ravel())
+
+
 @pytest.mark.parametrize("B,K,d", [(50, 16, 64), (17, 3, 2), (300, 5, 70)])
 def test_evaluate_vs_oracle(rng, O, B, K, d):
     N = 10**4

@@ -80,7 +80,11 @@ def test_sample_from_array_reference_properties(rng):
                                                  # word >> 9 <= floor(q 2^23)): q = 2^-23, 3.5 x 2^-23, 2^-24, the largest float below 1, 1/3
                                                  (2**20, 2.0**-23, 64, False), (2**20, 3.5 * 2.0**-23, 64, False), (2**20, 2.0**-24, 64, False),
                                                  (4096, float(np.nextafter(np.float32(1.0), np.float32(0.0))), 4096, False),
-                                                 (70001, 1.0 / 3.0, 30000, False)])
+                                                 (70001, 1.0 / 3.0, 30000, False),
+                                                 # the size the benchmark's Poisson leg runs (north_star N = 10^7, q = 4096 / N): 625 k ChaCha blocks, 2442
+                                                 # workgroup counts through the scan -- at the 0.99 quantile of Poisson(4096) (scipy: 4245), truncating, suppressing
+                                                 (10**7, 4096 / 10**7, 4245, False), (10**7, 4096 / 10**7, 4000, False),
+                                                 (10**7, 4096 / 10**7, 4000, True), (10**7 + 13, 4096 / 10**7, 4245, False)])
 def test_poisson_select_bit_exact(rng, O, N, q, cutoff, suppress):
     import d3p_amd._lib as L
     from d3p_amd._lib import check, ptr, stream_ptr

@@ -263,6 +263,50 @@ def test_throughput_regime_kernel_vs_oracle(gpu, O):
     _compare(new_st, losses, ost, el, steps)
 
 
+@pytest.mark.parametrize("icpt,B", [(False, 32768), (True, 32768), (False, 4096)])
+def test_aligned_gradients_column_sums_beyond_2048_C_vs_oracle(gpu, O, icpt, B):
+    """A column whose clipped per-example gradients all point the same way: its sum over the batch is only bounded by B C
+    (svi.py:343-346 before the division), i.e. B 2^40 in the accumulator's fixed point -- 2^55 at B = 32768.  Round 3's 16-wave
+    prologue converted that int64 with a bit-pattern trick that is exact below 2^51 (|sum| < 2048 C) and silently distorted larger
+    sums (advisor finding, round 3).  Here: all labels 1, one constant feature of 100 (no intercept) or features of 0.01 and the
+    intercept column (the shape of examples/logistic_regression.py:49-66 on small-scale data) -- the column's sum is ~ 0.97 B C
+    in both.  Adam normalises a gradient's magnitude away (the first update is lr sign(g)), so the check is on the MOMENTS
+    the gradient leaves behind, against the oracle: m = 0.1 g, v = 0.001 g^2 after one step."""
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, d, steps = 40_000, 512, 2
+    g = torch.Generator().manual_seed(5)
+    if icpt:
+        X = 0.01 * torch.randn(N, d, generator=g)
+    else:
+        X = torch.randn(N, d, generator=g)
+        X[:, 0] = 100.0
+    y = torch.ones(N)
+    D = d + int(icpt)
+    svi = _svi(d, icpt, N, sigma=0.0)    # no Gaussian-mechanism noise: the moments are the clipped mean gradient's alone
+    st = _state(svi, rng.PRNGKey(91), D, N)
+    _, gb = subsample_batchify_data((X.cuda(), y.cuda()), B)
+    new_st, losses = svi.run_steps(st, gb, rng.PRNGKey(92), 0, steps)
+    assert svi.last_run_status() == (False, False)
+    spec = O.logreg_spec(d, icpt, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.0, 1e-2, 0.9, 0.999, 1e-8)
+    ost = _oracle_state(O, 91, D)
+    el = _oracle_losses_feistel(O, spec, hy, ost, X.numpy(), y.numpy(), O.PRNGKey(92), 0, B, steps) if not icpt else None
+    if icpt:
+        el, Xn, yn = [], X.numpy(), y.numpy()
+        for t in range(steps):
+            idx = O.feistel_sample(O.fold_in(O.PRNGKey(92), t), N, B)
+            el.append(O.logreg_update(spec, hy, ost, Xn[idx], yn[idx])[0])
+    col = D - 1 if icpt else 0
+    m_dev, v_dev = np_(new_st.optim_state[2]), np_(new_st.optim_state[3])
+    # the column this test is about: after two steps m = 0.19 g with g = obs_scale x (column sum / B), so the sum in units of C is
+    assert abs(ost.m[col]) / 0.19 / N * B > 1.5 * 2048
+    np.testing.assert_allclose(m_dev[col], ost.m[col], rtol=1e-4)
+    np.testing.assert_allclose(v_dev[col], ost.v[col], rtol=2e-4)
+    np.testing.assert_allclose(m_dev, ost.m, rtol=2e-3, atol=2e-4 * float(np.abs(ost.m).max()))
+    _compare(new_st, losses, ost, el, steps)
+
+
 @pytest.mark.parametrize("B,icpt,sampler", [(20, False, "feistel"), (100, False, "feistel"), (33, True, "feistel"),
                                             (700, True, "poisson"), (1500, False, "poisson")])
 def test_chain_kernel_small_and_ragged_grids_vs_oracle(gpu, O, B, icpt, sampler):
