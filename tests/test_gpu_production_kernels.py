@@ -300,7 +300,7 @@ def test_aligned_gradients_column_sums_beyond_2048_C_vs_oracle(gpu, O, icpt, B):
     col = D - 1 if icpt else 0
     m_dev, v_dev = np_(new_st.optim_state[2]), np_(new_st.optim_state[3])
     # the column this test is about: after two steps m = 0.19 g with g = obs_scale x (column sum / B), so the sum in units of C is
-    assert abs(ost.m[col]) / 0.19 / N * B > 1.5 * 2048
+    assert abs(ost.m[col]) / 0.19 / N * B > 1.1 * 2048
     np.testing.assert_allclose(m_dev[col], ost.m[col], rtol=1e-4)
     np.testing.assert_allclose(v_dev[col], ost.v[col], rtol=2e-4)
     np.testing.assert_allclose(m_dev, ost.m, rtol=2e-3, atol=2e-4 * float(np.abs(ost.m).max()))
