@@ -46,6 +46,7 @@ struct Workspace {
     uint32_t* chain_bar;   // chained form: (D3P_STEP_BATCH + 1) x D3P_BAR_WORDS arrival counters + 16 words (abort flag)
     uint32_t* xflags;      // in-launch exchange of a data-parallel run: D3P_STEP_BATCH x D3P_XCHG_WGS flags, 128 bytes apart
     long long* xsum;       // ... and the world's sums of step g in row g % 3 (3 x cols)
+    unsigned long long* ll_state;  // data-parallel updater form: the optimiser state as tagged words -- parameters 2 x cols, m cols, v cols
     float* partials;  // max_blocks x (P + 2)
     unsigned long long* stamps;  // 2 x max_blocks
     void* poisson_ws;
@@ -72,6 +73,7 @@ static size_t carve(const d3p_logreg_model* m, const d3p_batch_source* src, char
     p = take(((size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS + 16) * sizeof(uint32_t)); if (ws) ws->chain_bar = (uint32_t*)p;
     p = take((size_t)D3P_STEP_BATCH * D3P_XCHG_WGS * 32 * sizeof(uint32_t)); if (ws) ws->xflags = (uint32_t*)p;
     p = take(3 * (size_t)D3P_ACC_COLS(P) * sizeof(long long)); if (ws) ws->xsum = (long long*)p;
+    p = take(4 * (size_t)D3P_ACC_COLS(P) * sizeof(unsigned long long)); if (ws) ws->ll_state = (unsigned long long*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * (P + 2) * sizeof(float)); if (ws) ws->partials = (float*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * 4 * sizeof(unsigned long long)); if (ws) ws->stamps = (unsigned long long*)p;  // >= 2 x 256 x 16 phase stamps
     size_t pb = 0;
@@ -169,6 +171,12 @@ struct RunInitCopy {  // d3p_dpvi_logreg_run_from: the optimiser state is copied
     int n, by_value;
     uint32_t* bar;       // arrival counters of the first chained launch, zeroed here (nullable)
     uint32_t bar_words;
+    // data-parallel updater form (d3p_logreg_chain.h): the optimiser state the run starts from as tagged words {fp32 | ll_tag} --
+    // the parameters into row ll_tag & 1 of ll[0] (the other row is given the tag ll_tag - 1, which no step of this run waits
+    // for: whatever an earlier run left there can never be taken for a parameter), m and v into ll[1], ll[2]
+    unsigned long long* ll[3];  // nullable
+    const float* ll_src[3];
+    uint32_t ll_tag, ll_cols;   // cols = D3P_ACC_COLS(P): the row stride of ll[0]
 };
 
 __global__ void __launch_bounds__(256) k_run_init(const uint32_t* __restrict__ state_key, const int32_t* __restrict__ adam_step,
@@ -188,6 +196,16 @@ __global__ void __launch_bounds__(256) k_run_init(const uint32_t* __restrict__ s
             if (tid == 64) {
                 *cp.step_dst = *adam_step;
                 if (cp.by_value) *cp.batch_index_dst = cp.batch0;
+            }
+        }
+        if (cp.ll[0]) {
+            const unsigned long long t = (unsigned long long)cp.ll_tag << 32, told = (unsigned long long)(cp.ll_tag - 1u) << 32;
+            for (uint32_t i = tid - 64; i < cp.ll_cols; i += 192) {
+                const bool par = i < (uint32_t)cp.n;
+                cp.ll[0][(size_t)(cp.ll_tag & 1u) * cp.ll_cols + i] = t | (par ? __float_as_uint(cp.ll_src[0][i]) : 0u);
+                cp.ll[0][(size_t)((cp.ll_tag & 1u) ^ 1u) * cp.ll_cols + i] = told;
+                cp.ll[1][i] = t | (par ? __float_as_uint(cp.ll_src[1][i]) : 0u);
+                cp.ll[2][i] = t | (par ? __float_as_uint(cp.ll_src[2][i]) : 0u);
             }
         }
         return;
@@ -247,6 +265,10 @@ struct FlushArgs {
     int P, B;
     float dp_scale, clip, obs_scale, lr, b1, b2, adam_eps;
     double inv_sg;
+    // data-parallel updater form: nothing is pending (the last step's updater applied its update and reported its loss); the state
+    // is unpacked from the tagged words {fp32 | ll_tag} (parameters: row ll_tag & 1) into the caller's arrays
+    const unsigned long long* ll[3];  // nullable
+    uint32_t ll_tag;
 };
 
 __global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
@@ -267,6 +289,20 @@ __global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
     }
     if (aborted) {  // the pending sums are incomplete: leave the state where the run stopped
         if (tid == 0 && a.loss_out) *a.loss_out = __builtin_nanf("");
+        return;
+    }
+    if (a.ll[0]) {
+        bool bad = false;
+        for (int col = tid; col < a.P; col += blockDim.x) {
+            const unsigned long long wx = a.ll[0][(size_t)(a.ll_tag & 1u) * PA + col], wm = a.ll[1][col], wv = a.ll[2][col];
+            bad |= (uint32_t)(wx >> 32) != a.ll_tag || (uint32_t)(wm >> 32) != a.ll_tag || (uint32_t)(wv >> 32) != a.ll_tag;
+            a.state_out[0][col] = __uint_as_float((uint32_t)wx);
+            a.state_out[1][col] = __uint_as_float((uint32_t)wm);
+            a.state_out[2][col] = __uint_as_float((uint32_t)wv);
+        }
+        // (cannot happen once the launches are complete: every word of the final epoch was stored by the last updater.  Reported as
+        // a stopped run rather than handed on silently.)
+        if (bad && a.host_status) a.host_status[0] = abort_code(D3P_ABORT_RELEASE, 0xfff, 4u);
         return;
     }
     long long nll = 0;
@@ -1032,12 +1068,35 @@ static bool use_persistent_steps(const Ctx& c)
 
 // D3P_DBG=32: reads the phase stamps the stamped chained kernels left for the last two steps of a launch and prints the
 // anatomy of the last step (fourth launch of the process = steady state) to stderr.
-static int print_chain_anatomy(const Ctx& c, uint32_t blocks = 0)
+static int print_chain_anatomy(const Ctx& c, uint32_t blocks = 0, bool upd = false)
 {
     static unsigned long long host[2 * 256 * 16];
     D3P_HIP_TRY(hipMemcpyAsync(host, c.ws.stamps, sizeof(host), hipMemcpyDeviceToHost, c.s));
     D3P_HIP_TRY(hipStreamSynchronize(c.s));
     static int printed = 0;
+    if (upd && (dev_dbg_flags() & 0x700) == 0x700 && printed == 3) {  // updater form: publication / parameter-seen times per wave
+        ++printed;
+        if (!blocks) blocks = c.g.blocks;
+        const uint32_t nb = blocks < 256u ? blocks : 256u;
+        unsigned long long base = ~0ull;
+        for (uint32_t b = 0; b < nb; ++b) {
+            const unsigned long long v = host[((size_t)0 * 256 + b) * 16 + 8];
+            if (v != 0ull && v < base) base = v;
+        }
+        if (base == ~0ull) { fprintf(stderr, "  (no updater found in the stamped step)\n"); return D3P_OK; }
+        fprintf(stderr, "  updaters of the step before the last: publication by their waves 0, 1 (us after the first publication):");
+        for (uint32_t b = 0; b < nb; ++b)
+            if (host[((size_t)0 * 256 + b) * 16 + 8] != 0ull)
+                fprintf(stderr, " wg %u: %.2f %.2f;", b, (double)(long long)(host[((size_t)b) * 16 + 8] - base) * 0.01,
+                        (double)(long long)(host[((size_t)b) * 16 + 9] - base) * 0.01);
+        fprintf(stderr, "\n  last step, when the even waves had their parameter words (us after the first publication):\n");
+        for (uint32_t b = 0; b < nb; b += 9) {
+            fprintf(stderr, "  wg %3u:", b);
+            for (int w = 0; w < 8; ++w) fprintf(stderr, " %5.2f", (double)(long long)(host[((size_t)256 + b) * 16 + w] - base) * 0.01);
+            fprintf(stderr, "\n");
+        }
+        return D3P_OK;
+    }
     if ((dev_dbg_flags() & 256) && printed == 3) {  // per-WAVE "examples done" times of the last step (16-wave form), us after the workgroup's first wave
         ++printed;
         if (!blocks) blocks = c.g.blocks;
@@ -1080,6 +1139,13 @@ static int print_chain_anatomy(const Ctx& c, uint32_t blocks = 0)
                         at(1, b, 1) - last_arr, at(1, b, 5) - last_arr, at(1, b, 6) - last_arr, at(1, b, 12) - last_arr);
         }
         fprintf(stderr, "  previous step: last acknowledgement %.2f us before its last arrival\n", last_arr - last_acked);
+        if (upd) {  // the updater of the previous step: the workgroup whose tail stamps are set
+            for (uint32_t b = 0; b < nb; ++b)
+                if (host[((size_t)0 * 256 + b) * 16 + 15] != 0ull)
+                    fprintf(stderr, "  updater of the previous step (workgroup %u), us after its arrival returned: replicas + state loaded %.2f, rows sent %.2f, "
+                                    "world's rows collected %.2f, parameters published %.2f\n", b, at(0, b, 3) - at(0, b, 12), at(0, b, 4) - at(0, b, 12),
+                            at(0, b, 14) - at(0, b, 12), at(0, b, 15) - at(0, b, 12));
+        }
         const int order[9][2] = {{7, 2}, {2, 5}, {5, 6}, {6, 9}, {9, 10}, {10, 11}, {11, 12}, {8, 7}, {0, 8}};
         for (auto& o : order) {
             double sum = 0.0, mx = -1e30;
@@ -1110,6 +1176,13 @@ static bool lean_chain_ok(const Ctx& c, bool w16)
                             getenv("D3P_MAIN_W") != nullptr;
     return !off && c.g.full && c.g.V == 4 && c.g.NK == 1 && c.g.W == 16 && c.m->d == D3P_CHAIN_D &&
            c.m->family == D3P_FAMILY_LOGREG && (w16 || c.items_expected <= 18ull * c.g.blocks);
+}
+// Data-parallel chained runs: the 16-wave UPDATER form of d3p_logreg_chain.h (round 4; any item count) unless D3P_XCHG_W8=1 asks
+// for round 2's 8-wave form with its two exchange workgroups per step (kept for A/B measurements).
+static bool xchg_updater_form(const Ctx& c)
+{
+    static const bool w8 = getenv("D3P_XCHG_W8") != nullptr;
+    return !w8 && chain_w16_enabled() && lean_chain_ok(c, true);
 }
 // workgroups per step of the 16-wave form: two items per wave; up to 12 % more items than 2 x 16 x 128 (a Poisson batch padded
 // to its 0.99 quantile) still run on 128 workgroups -- two steps side by side on 256 CUs matter more than a few waves taking a
@@ -1210,10 +1283,8 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
         // The headline shape (d = 512, no intercept, logistic regression; at most ~two examples per wave of an 8-wave
         // workgroup) runs the kernel written for it (d3p_logreg_chain.h); D3P_NO_LEAN_CHAIN=1 keeps the generic template.
         const bool icpt = c.g.tail;  // 512 features + intercept (D = 513): the ICPT instantiations
-        // (data-parallel runs: the 16-wave form with the exchange in the tails of workgroups 0 and 1 is opt-in, D3P_XCHG_W16=1 --
-        // measured on one GPU only, with a rank exchanging with itself; the 8-wave form stays the default until a multi-GPU run)
-        static const bool xchg_w16 = getenv("D3P_XCHG_W16") != nullptr;
-        const bool w16 = (!xchg || (xchg_w16 && c.items_expected >= 2ull * 16ull * 2ull)) && chain_w16_enabled();
+        // (data-parallel runs: the 16-wave updater form; D3P_XCHG_W8=1: the 8-wave form with two exchange workgroups per step)
+        const bool w16 = (!xchg || xchg_updater_form(c)) && chain_w16_enabled();
         if (lean_chain_ok(c, w16)) {
             const uint32_t nw = w16 ? chain16_blocks(c.items_expected) : c.g.blocks;
             ChainArgs ca;
@@ -1250,17 +1321,26 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
             ca.c1_b = a.c1_b; ca.hz_b = a.hz_b; ca.log_prior_b = logf(c.m->prior_b);
             ca.gexp = a.gexp;
             ca.dbg = dev_dbg_flags();
-            if (xchg) {  // data-parallel run: the step's exchange rides in the launch (one more workgroup per step)
+            if (xchg) {  // data-parallel run: the step's exchange rides in the launch
                 xchg_fill_dev(xchg, &ca.x, K);
                 ca.x.xflag = c.ws.xflags;
                 ca.x.xsum = c.ws.xsum;
-                D3P_HIP_TRY(hipMemsetAsync(c.ws.xflags, 0, (size_t)D3P_STEP_BATCH * D3P_XCHG_WGS * 32 * sizeof(uint32_t), c.s));
+                if (w16) {  // updater form: the state travels as tagged words, no flags
+                    static const bool self_trip = getenv("D3P_XCHG_SELF_TRIP") != nullptr;   // developer switch, read once
+                    ca.x.self_trip = self_trip ? 1 : 0;
+                    const size_t PAc = (size_t)D3P_ACC_COLS(c.P);
+                    ca.ll_state[0] = c.ws.ll_state;
+                    ca.ll_state[1] = c.ws.ll_state + 2 * PAc;
+                    ca.ll_state[2] = c.ws.ll_state + 3 * PAc;
+                } else {
+                    D3P_HIP_TRY(hipMemsetAsync(c.ws.xflags, 0, (size_t)D3P_STEP_BATCH * D3P_XCHG_WGS * 32 * sizeof(uint32_t), c.s));
+                }
             }
             const int W = w16 ? 16 : D3P_CHAIN_W;
             const dim3 grid((uint32_t)K * (nw + (w16 ? 0u : 1u) + ((xchg && !w16) ? (uint32_t)D3P_XCHG_WGS : 0u))), block(64 * W);
             const bool plist = ca.plist_base != nullptr;
             const size_t lds = chain_lds_bytes(icpt, W);
-            const bool stamped = (ca.dbg & 32) && K >= 2 && !xchg;  // D3P_DBG=32: the stamped instantiation + the phase anatomy on stderr
+            const bool stamped = (ca.dbg & 32) && K >= 2 && (!xchg || (w16 && !icpt));  // D3P_DBG=32: the stamped instantiation + the phase anatomy on stderr
             if (stamped) ca.stamps = c.ws.stamps;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (!stamped) timing_pair(K, &e0, &e1);
@@ -1277,17 +1357,21 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
         if (e0) hipExtLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, false, 16>), grid, block, lds, c.s, e0, e1, 0, ca);        \
         else hipLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, false, 16>), grid, block, lds, c.s, ca);                         \
     } while (0)
-#define D3P_CHAIN16_XCHG_LAUNCH(PL_, IC_)                                                                                        \
+#define D3P_CHAIN16_XCHG_LAUNCH(PL_, ST_, IC_)                                                                                   \
     do {                                                                                                                      \
-        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logreg_chain<PL_, false, IC_, true, 16>), \
+        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logreg_chain<PL_, ST_, IC_, true, 16>), \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;   \
         (void)lds_ok;                                                                                                         \
-        if (e0) hipExtLaunchKernelGGL((k_logreg_chain<PL_, false, IC_, true, 16>), grid, block, lds, c.s, e0, e1, 0, ca);       \
-        else hipLaunchKernelGGL((k_logreg_chain<PL_, false, IC_, true, 16>), grid, block, lds, c.s, ca);                        \
+        if (e0) hipExtLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, true, 16>), grid, block, lds, c.s, e0, e1, 0, ca);         \
+        else hipLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, true, 16>), grid, block, lds, c.s, ca);                          \
     } while (0)
             if (w16 && xchg) {
-                if (icpt) { if (plist) D3P_CHAIN16_XCHG_LAUNCH(true, true); else D3P_CHAIN16_XCHG_LAUNCH(false, true); }
-                else { if (plist) D3P_CHAIN16_XCHG_LAUNCH(true, false); else D3P_CHAIN16_XCHG_LAUNCH(false, false); }
+                if (stamped) {  // (the anatomy is taken at the production shape: owned lists, no intercept)
+                    if (plist) D3P_CHAIN16_XCHG_LAUNCH(true, true, false); else D3P_CHAIN16_XCHG_LAUNCH(false, true, false);
+                } else {
+                    if (icpt) { if (plist) D3P_CHAIN16_XCHG_LAUNCH(true, false, true); else D3P_CHAIN16_XCHG_LAUNCH(false, false, true); }
+                    else { if (plist) D3P_CHAIN16_XCHG_LAUNCH(true, false, false); else D3P_CHAIN16_XCHG_LAUNCH(false, false, false); }
+                }
             } else if (w16) {
                 if (stamped) {
                     if (icpt) { if (plist) D3P_CHAIN16_LAUNCH(true, true, true); else D3P_CHAIN16_LAUNCH(false, true, true); }
@@ -1311,7 +1395,7 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
 #undef D3P_CHAIN16_XCHG_LAUNCH
             int rc = check_launch("k_logreg_chain");
             if (rc || !stamped) return rc;
-            return print_chain_anatomy(c, nw);
+            return print_chain_anatomy(c, nw, xchg != nullptr);
         }
     }
     MainGeom g2 = c.g;
@@ -1529,6 +1613,20 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
         cp.batch0 = c.batch0;
         cp.batch_index_dst = c.src->batch_index;
     }
+    // (data-parallel with the one-shot exchange: chained too when the shape has the dedicated kernel -- the exchange then rides
+    // in the launch; D3P_XCHG_PER_STEP=1 keeps one step launch + one exchange launch per step)
+    static const bool xchg_per_step = getenv("D3P_XCHG_PER_STEP") != nullptr;
+    // updater form of the data-parallel chained launch: the optimiser state travels as tagged words, nothing is pending between
+    // launches or at the end of the run
+    const bool upd = xchg && !comm && use_chained_steps(c) && !xchg_per_step && xchg_updater_form(c);
+    if (upd) {
+        const size_t PAc = (size_t)D3P_ACC_COLS(c.P);
+        cp.ll[0] = c.ws.ll_state; cp.ll[1] = c.ws.ll_state + 2 * PAc; cp.ll[2] = c.ws.ll_state + 3 * PAc;
+        cp.ll_src[0] = st0->params; cp.ll_src[1] = st0->adam_m; cp.ll_src[2] = st0->adam_v;
+        cp.ll_tag = (uint32_t)(xchg->epoch + 1ull);   // the first step of the run is exchange epoch + 1
+        cp.ll_cols = (uint32_t)PAc;
+        cp.n = c.P;
+    }
     const bool init_zeroes_bar = !comm && use_chained_steps(c);  // the first chained launch's arrival counters: no memset launch
     if (init_zeroes_bar) {
         cp.bar = c.ws.chain_bar;
@@ -1546,10 +1644,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     const StepSlot* prev_slot = nullptr;
     const float* prev_noise = nullptr;
     int g = 0;
-    // (data-parallel with the one-shot exchange: chained too when the shape has the dedicated kernel -- the exchange then rides
-    // in the launch; D3P_XCHG_PER_STEP=1 keeps one step launch + one exchange launch per step)
-    static const bool xchg_per_step = getenv("D3P_XCHG_PER_STEP") != nullptr;
-    const bool chained = !comm && use_chained_steps(c) && (!xchg || (lean_chain_ok(c, false) && !xchg_per_step));
+    const bool chained = !comm && use_chained_steps(c) && (!xchg || upd || (lean_chain_ok(c, false) && !xchg_per_step));
     const bool persist = chained && use_persistent_steps(c);
     for (uint32_t b = 0; b < n_batches; ++b) {
         const int cur = (int)(b & 1), nxt = cur ^ 1;
@@ -1559,7 +1654,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
                                             K_next, xchg)))
                 return rc;
             g += K;
-            if (!persist) {  // the persistent form applies every update inside its launch: nothing is pending afterwards
+            if (!persist && !upd) {  // the persistent / updater forms apply every update inside the launch: nothing is pending afterwards
                 prev_slot = cb[cur].ws.slots + (K - 1);
                 prev_noise = cb[cur].ws.noise + (size_t)(K - 1) * c.P;
             }
@@ -1603,6 +1698,11 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     if (chained && xchg) {  // the exchange workgroups left the world's sums in one row per step
         fa.acc_prev = c.ws.xsum + (size_t)((g + 2) % 3) * D3P_ACC_COLS(c.P);
         fa.nrep = 1;
+    }
+    if (upd) {  // nothing pending: unpack the tagged state of the epoch after the run's last
+        const size_t PAc = (size_t)D3P_ACC_COLS(c.P);
+        fa.ll[0] = c.ws.ll_state; fa.ll[1] = c.ws.ll_state + 2 * PAc; fa.ll[2] = c.ws.ll_state + 3 * PAc;
+        fa.ll_tag = (uint32_t)(xchg->epoch + 1ull);
     }
     fa.noise = prev_noise;
     fa.slot = prev_slot;

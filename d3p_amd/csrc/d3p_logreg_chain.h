@@ -32,6 +32,19 @@
 //          reduction); the key-chain step rides at the tail of workgroup 0 (no extra workgroup: 2 x 128 = the chip's 256 CUs).
 //          Waves with more than two items (B = 32768: eight) take the further ones in pairs, noise generated in the loop.
 // PLIST: the items are the entries of the step's dense owned-position list (Poisson padding, row-sharded ranks).
+//
+// Data-parallel runs (XCHG, W = 16; round 4) -- the UPDATER form.  What a data-parallel step adds to the serial chain between two
+// steps is the sum over the ranks.  Round 3 ran it as: arrival flags -> poll (workgroups 0 / 1) -> fold the replicas -> tagged
+// stores to every inbox -> poll the own inbox -> sum -> store the sums -> wait for the acknowledgement -> barrier -> flag -> poll
+// (next step) -> load the sums -> update, redundantly in every workgroup: 3.9 us on top of the single-rank step.  Now:
+//   * the workgroup whose arrival completes the step (it knows from the value its arrival atomic returns: no flag, no poll) does
+//     the exchange in its tail, one accumulator column per thread, no barrier and no LDS: fold (the replica loads, the state
+//     words and the step's normals in ONE round trip) -> tagged stores to every inbox -> tagged loads from the own inbox until
+//     the world's rows are there -> noise, rescale, Adam (svi.py:343-393) ONCE -> the new parameter as ONE tagged 8-byte word
+//     {fp32 | epoch} (ll_state), m and v likewise for the next updater -- nothing is waited for after the stores;
+//   * the next step's workgroups poll the parameter word of their own column: the poll IS the load, and the 127 other workgroups
+//     no longer repeat the update (no replica / m / v loads, no Adam arithmetic between the release and the staging barrier).
+// No update is pending across launch boundaries or at the end of a run (k_run_init writes the tagged state, k_flush unpacks it).
 #pragma once
 #include "d3p_logreg_kernel.h"
 
@@ -56,6 +69,8 @@ struct XchgDev {
     uint32_t* xflag;                   // K x D3P_XCHG_WGS flags, 32 words apart, zeroed before the launch
     long long* xsum;                   // 3 x cols: the world's sums of step g in row g % 3 -- ONE row, which is all the next
                                        // step's prologues read in a data-parallel run (not the 4 local replicas)
+    int self_trip;                     // updater form, developer switch (D3P_XCHG_SELF_TRIP=1): the rank's OWN row takes the trip through
+                                       // its inbox too, like a peer's -- on one GPU a stand-in for the link trip of a real peer's row
 };
 
 // One int64 of an exchange message travels as two 8-byte words {32 data bits | 32-bit tag}, tag = the low word of the
@@ -134,6 +149,11 @@ struct ChainArgs {
     float c1_b, hz_b, log_prior_b;  // ICPT: the intercept's prior
     int gexp;
     XchgDev x;
+    // data-parallel 16-wave form (UPD): the optimiser state as self-validating 8-byte words {fp32 bits | tag}, tag = low word of
+    // the exchange epoch of the step the value is FOR.  [0]: parameters, two rows of D3P_ACC_COLS(P) words (row = tag & 1: the
+    // updater of step e writes row (e + 1) & 1 while row e & 1 may still be read); [1], [2]: Adam's m and v, one row each,
+    // rewritten in place (only the updaters read them, one after the other)
+    unsigned long long* ll_state[3];
     int dbg;  // developer switches (D3P_DBG): 2 = raised wave priority on the critical path, 4 = no gradient atomics (STAMPS only)
 };
 
@@ -158,6 +178,7 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     static_assert(W_ == 8 || W_ == 16, "8- or 16-wave workgroups");
     static_assert(RU >= 1 && RU <= D3P_ACC_R, "replicas in use");
     constexpr bool W16 = W_ == 16;
+    constexpr bool UPD = XCHG && W16;   // data-parallel updater form (see the header)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int DF = D3P_CHAIN_D;                 // feature columns of a table row
     constexpr int D = DF + (ICPT ? 1 : 0), P = 2 * D, PA = D3P_ACC_COLS(P), W = W_, R = D3P_ACC_R;
@@ -171,7 +192,7 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     float* tail = red + W * 2 * DL;     // 2 W: loss / count per wave
     uint32_t* okw = reinterpret_cast<uint32_t*>(tail + 2 * W);             // verdict of the polling wave
     unsigned long long* stamp = reinterpret_cast<unsigned long long*>(okw + 4);
-#define D3P_CSTAMP(k) if (STAMPS && threadIdx.x == 0 && !((a.dbg & 256) && (k) != 5 && (k) >= 5)) stamp[k] = wall_clock64();
+#define D3P_CSTAMP(k) if (STAMPS && threadIdx.x == 0 && !((a.dbg & 256) && (k) != 5 && (k) >= 5) && (a.dbg & 0x700) != 0x700) stamp[k] = wall_clock64();
     D3P_CSTAMP(0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -323,7 +344,7 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     // the pending update of step g - 1: which state buffers, which slot / noise row (all known before the release)
     const int g = a.g0 + step_t;
     const StepSlot* ps = step_t > 0 ? a.slots + (step_t - 1) : a.prev_slot0;
-    const bool apply_prev = ps != nullptr;
+    const bool apply_prev = !UPD && ps != nullptr;   // (UPD: the step's updater has already applied it)
     const float* prev_noise = step_t > 0 ? a.noise_base + (size_t)(step_t - 1) * P : a.prev_noise0;
     // W = 16: thread tid owns ONE parameter column -- auto_loc of latent tid (tid < 512) or auto_scale of latent tid - 512
     // (ICPT: the intercept's two columns D - 1 and 2 D - 1 are second columns of threads 64 and 128)
@@ -394,6 +415,33 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     if (live1) epa = gen(ka0, ka1, nothing);
     if (live2) epb = gen(kb0, kb1, [&] { fetch_rows(); });
     else fetch_rows();
+    // W = 16, a step with up to THREE items per wave (an owned-position list a little longer than 2 x 16 x nw: a Poisson batch
+    // padded to its 0.99 quantile, a row-sharded rank's share of the batch -- Binomial(B, 1 / world) around 4096 +- 60, i.e. every
+    // other step of a data-parallel run): the third item is prepared HERE too -- its table row and its noise parked in the wave's
+    // own row of the reduction buffer, which is free until phase 4 -- instead of in phase 3, where index -> row -> features and
+    // 2 us of noise generation sat on the step's critical path (anatomy, round 4: the workgroups with third items arrived 3.9 us
+    // after the others).  And the third items are dealt out ACROSS the workgroups (item 2 nw W + wave nw + bid: one per workgroup
+    // before any workgroup gets a second), not to the 16 waves of workgroup 0 first.
+    const uint32_t stride = (uint32_t)a.nw * W;
+    const bool third_pre = W16 && n_items > 2u * stride && n_items <= 3u * stride;
+    const uint32_t k3 = 2u * stride + (uint32_t)wave * (uint32_t)a.nw + bid;
+    const bool live3 = third_pre && k3 < n_items;
+    float y3 = 0.f, xt3 = 0.f, e2_3 = 0.f, vt3 = 0.f;
+    if (live3) {
+        const uint32_t p3 = PLIST ? (a.plist_base + (size_t)step_t * a.B)[k3] : k3;
+        const size_t row3 = (size_t)((uint64_t)idx[p3] - a.row_lo);
+        const uint32_t q0 = skeys[2 * p3], q1 = skeys[2 * p3 + 1];
+        float4 x30, x31;
+        load_x(a.X + row3 * DF, x30, x31, xt3);
+        y3 = a.y[row3];
+        const Eps e3 = gen(q0, q1, nothing);
+        *reinterpret_cast<float4*>(er + 4 * lane) = make_float4(e3.v0.lo.x, e3.v0.lo.y, e3.v0.hi.x, e3.v0.hi.y);
+        *reinterpret_cast<float4*>(er + C1 + 4 * lane) = make_float4(e3.v1.lo.x, e3.v1.lo.y, e3.v1.hi.x, e3.v1.hi.y);
+        *reinterpret_cast<float4*>(er + DL + 4 * lane) = x30;
+        *reinterpret_cast<float4*>(er + DL + C1 + 4 * lane) = x31;
+        e2_3 = e3.e2;
+        vt3 = e3.vt;
+    }
     D3P_CSTAMP(8)
     // From here on the workgroup is on the critical path of the step (D3P_DBG=2: raised wave priority against the co-resident
     // workgroup of the next step, which is generating its noise on the same SIMDs).
@@ -404,7 +452,7 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     long long* acc_prev = a.acc_base + (size_t)((g + 2) % 3) * words;
     long long* acc_cur = a.acc_base + (size_t)(g % 3) * words;
     long long* acc_next = a.acc_base + (size_t)((g + 1) % 3) * words;
-    if (wave == 0) {
+    if (!UPD && wave == 0) {   // (UPD: no release to wait for -- every thread polls its own parameter word, phase 2)
         const uint32_t ng = (uint32_t)a.nw < D3P_BAR_GROUPS ? (uint32_t)a.nw : D3P_BAR_GROUPS;
         bool ok;
         if (XCHG)  // data-parallel: the previous step's exchange flag (global sums in place) instead of its arrival flags
@@ -416,12 +464,15 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
                 abort_code(D3P_ABORT_RELEASE, step_t));
         if (lane == 0) okw[0] = ok ? 0u : 1u;
     }
-    __syncthreads();
-    if (okw[0] != 0u) return;  // the run was aborted: no update, no publication, no arrival
-    D3P_CSTAMP(7)
+    if (!UPD) {
+        __syncthreads();
+        if (okw[0] != 0u) return;  // the run was aborted: no update, no publication, no arrival
+        D3P_CSTAMP(7)
+    }
 
     // ------------------------------------------------------------------ phase 2: update prologue (thread e <-> latent e)
     const int in = g > 0 ? ((g - 1) & 1) : 0, out = g & 1;
+    uint32_t upd_bad = 0u;  // UPD: this wave's poll ran out, or the run was stopped
     float lc_mine = 0.f;  // this thread's share of sum_j lc_j = sum_j [log prior scale - log s_j] (example-independent loss term)
     {
         float n = 0.f, factor = 0.f;
@@ -558,7 +609,47 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             pk[3 * DL + li] = a.inv_obs * sgm * __builtin_amdgcn_rcpf(sp);
             lc_mine += ((ICPT && e == D - 1) ? a.log_prior_b : a.log_prior) - __logf(sp);
         };
-        if (W16) {
+        if (UPD) {
+            // The parameters of this step: ONE tagged word per column, written by the updater of the previous step (or by
+            // k_run_init / the last updater of the previous launch).  The poll is the load.  The waves leave the loop one by one
+            // (a wave whose 64 words carry the tag goes on to its derived columns); D3P_DBG bit 0x1000: wave 0 alone polls, the
+            // others wait at a barrier and load afterwards (fewer polls in flight, one more round trip).
+            const uint32_t etag = (uint32_t)(a.x.epoch0 + (unsigned long long)step_t + 1ull);
+            const unsigned long long* xrow = a.ll_state[0] + (size_t)(etag & 1u) * PA;
+            unsigned long long w1 = 0ull, w2 = 0ull;
+            auto poll = [&]() {
+                for (uint32_t spins = 0; spins < D3P_WAIT_ROUNDS_PEERS / 2u; ++spins) {   // (a round is a memory round trip, ~ 0.7 us: 25 s)
+                    w1 = __hip_atomic_load(xrow + mycol, __ATOMIC_RELAXED, D3P_AGENT);
+                    if (xcol >= 0) w2 = __hip_atomic_load(xrow + xcol, __ATOMIC_RELAXED, D3P_AGENT);
+                    const bool valid = (uint32_t)(w1 >> 32) == etag && (xcol < 0 || (uint32_t)(w2 >> 32) == etag);
+                    if (__ballot(!valid) == 0ull) return true;
+                    if ((spins & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) return false;
+                }
+                return false;
+            };
+            bool ok = true;
+            if (a.dbg & 0x1000) {
+                if (wave == 0) ok = poll();
+                __syncthreads();
+            }
+            if (ok) ok = poll();
+            if (!ok) {
+                upd_bad = 1u;
+                if (lane == 0) chain_raise(a.status, abort_code(D3P_ABORT_RELEASE, step_t, 2u));
+            }
+            D3P_CSTAMP(7)
+            // (D3P_DBG = 32 + 0x700: when each even WAVE had its parameter words -- slots 0 .. 7; an updater's working waves leave the
+            // time of their publication in slots 8 ..)
+            if (STAMPS && (a.dbg & 0x700) == 0x700 && lane == 0 && !(wave & 1)) { stamp[wave >> 1] = wall_clock64(); stamp[8 + (wave >> 1)] = 0ull; }
+            ColData d1 = {};
+            d1.x = __uint_as_float((uint32_t)w1);
+            col_apply(mycol, d1, 0.f);
+            if (xcol >= 0) {   // ICPT: the intercept's auto_loc (thread 64) / auto_scale (thread 128)
+                ColData d2 = {};
+                d2.x = __uint_as_float((uint32_t)w2);
+                col_apply(xcol, d2, 0.f);
+            }
+        } else if (W16) {
             const ColData d1 = col_load(mycol);
             ColData d2 = {};
             if (xcol >= 0) d2 = col_load(xcol);
@@ -592,11 +683,18 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     }
     {
         const float lcw = wave_sum(lc_mine);   // (all lanes active again)
-        if (lane == 0) pk[4 * DL + wave] = lcw;
+        if (lane == 0) {
+            pk[4 * DL + wave] = lcw;
+            if (UPD) reinterpret_cast<uint32_t*>(pk)[4 * DL + W + wave] = upd_bad;   // the wave's verdict rides through the staging barrier
+        }
     }
     D3P_CSTAMP(2)
     __syncthreads();
     D3P_CSTAMP(1)
+    if (UPD) {  // a stopped run: no arrival, nothing published (one LDS word per thread: thread t looks at the verdict of wave t % 16)
+        const uint32_t vd = reinterpret_cast<const uint32_t*>(pk)[4 * DL + W + (tid & (W - 1))];
+        if (__ballot(vd != 0u) != 0ull) return;
+    }
     float lcsum = 0.f;   // fixed order over the waves' slots: identical in every thread
 #pragma unroll
     for (int w = 0; w < W; ++w) lcsum += pk[4 * DL + w];
@@ -716,11 +814,19 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     } else if (live1) {
         examples(std::integral_constant<int, 1>{}, &xa0, &xa1, &xta, &ya, &epa);
     }
-    // further items of this wave (only when the grid was sized for fewer items than the step has: an unlucky shard of a
-    // row-sharded batch): loaded, their noise generated and consumed one at a time
+    if (live3) {  // the third item, prepared in phase 0 (a lane reads back what it wrote: no barrier)
+        Eps e3;
+        e3.v0 = quad_lds(er + c0);
+        e3.v1 = quad_lds(er + c1);
+        e3.vt = vt3;
+        e3.e2 = e2_3;
+        const float4 x30 = *reinterpret_cast<const float4*>(er + DL + c0), x31 = *reinterpret_cast<const float4*>(er + DL + c1);
+        examples(std::integral_constant<int, 1>{}, &x30, &x31, &xt3, &y3, &e3);
+    }
+    // further items of this wave (the grid was sized for fewer items than the step has -- more than three per wave): loaded,
+    // their noise generated and consumed one at a time
     // W = 16: in pairs (B = 32768 on 256 workgroups: eight items per wave, i.e. three more pairs).
-    const uint32_t stride = (uint32_t)a.nw * W;
-    for (uint32_t k = k2 + stride; k < n_items; k += (W16 ? 2u : 1u) * stride) {
+    for (uint32_t k = third_pre ? n_items : k2 + stride; k < n_items; k += (W16 ? 2u : 1u) * stride) {
         const uint32_t kb = k + stride;
         const bool two = W16 && kb < n_items;  // (wave-uniform)
         const uint32_t p = PLIST ? (a.plist_base + (size_t)step_t * a.B)[k] : k;
@@ -829,77 +935,197 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
         uint32_t* bar = a.bar + (size_t)step_t * D3P_BAR_WORDS;
         const uint32_t nw = (uint32_t)a.nw, grp = bid % D3P_BAR_GROUPS, gsize = (nw + D3P_BAR_GROUPS - 1u - grp) / D3P_BAR_GROUPS;
         const uint32_t prev = __hip_atomic_fetch_add(bar + D3P_BAR_LINE * (1 + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
-        if (prev + 1u == gsize)  // this group's flag; the waiters poll the flags of all groups
+        if (UPD) {
+            // The workgroup whose arrival completes its GROUP is one of the step's (up to 8) updaters: it adds to the step's top
+            // counter on line 0 and, unless that completes the step, waits until the other groups have (a handful of waiters on a
+            // word that takes 8 atomics per step).  Its role for the tail: okw[2] = 1 + group, 0 = none / the run was stopped.
+            uint32_t role = 0u;
+            if (prev + 1u == gsize) {
+                const uint32_t ng = nw < D3P_BAR_GROUPS ? nw : D3P_BAR_GROUPS;
+                role = 1u + grp;
+                if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, D3P_AGENT) + 1u != ng) {
+                    for (uint32_t spins = 0;; ++spins) {
+                        if (__hip_atomic_load(bar, __ATOMIC_RELAXED, D3P_AGENT) >= ng) break;
+                        if (spins > D3P_WAIT_ROUNDS_PEERS || ((spins & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u)) {
+                            chain_raise(a.status, abort_code(D3P_ABORT_XCHG_ARRIVALS, step_t, grp));
+                            role = 0u;
+                            break;
+                        }
+                    }
+                }
+            }
+            okw[2] = role;
+        } else if (prev + 1u == gsize) {  // this group's flag; the waiters poll the flags of all groups
             __hip_atomic_store(bar + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
+        }
         if (STAMPS && a.stamps) {
             if (!(a.dbg & 256)) {
                 stamp[12] = wall_clock64();
                 stamp[13] = (unsigned long long)prev;
             }
+            if (UPD && !(a.dbg & 256)) stamp[3] = stamp[4] = stamp[14] = stamp[15] = 0ull;   // (an updater's tail sets them)
+            const int rec = step_t - (a.K - 2);
+            if (!UPD && rec >= 0 && bid < 256u)
+                for (int k = 0; k < 16; ++k) a.stamps[((size_t)rec * 256 + bid) * 16 + k] = stamp[k];
+        }
+    }
+    // Data-parallel, W = 16: the step's UPDATERS -- the workgroups whose arrivals completed the 8 arrival groups -- sum the step
+    // over the ranks and apply the update, each for its share of the accumulator columns (chunks of 64 columns: updater j takes
+    // chunks j, j + 8, ...: two waves of it work, one column per lane), with no barrier and no LDS between the threads:
+    //   one round trip: the column's R replicas, its state words {x, m, v | epoch}, its Gaussian-mechanism normal and the rank's
+    //   own count column;
+    //   fold -> the column as two tagged 8-byte words into slot [parity][rank] of every PEER's inbox (system scope: over xGMI);
+    //   tagged loads from the own inbox until the column of every peer carries this epoch's tag -> the world's sum (int64: exact,
+    //   the same on every rank);
+    //   mean, noise ONCE (svi.py:365-375), rescale, Adam (svi.py:379-393) -> {x | epoch + 1} for the next step's
+    //   workgroups (phase 2 above), {m, v | epoch + 1} for its updaters.  Nothing is waited for after the stores.
+    // (Several updaters, not the one workgroup whose arrival completes the step: a tail that reads 60 KB -- 480 cache lines --
+    // through ONE CU is bound by the misses a CU keeps in flight: three memory round trips, its 16 waves publishing 2 us apart
+    // (round-4 anatomy); 8 updaters on 8 CUs have 60 lines each.)
+    if (UPD) {
+        __syncthreads();
+        const uint32_t role = okw[2];
+        const uint32_t ngr = (uint32_t)a.nw < D3P_BAR_GROUPS ? (uint32_t)a.nw : D3P_BAR_GROUPS;
+        constexpr int NCH = (PA + 63) / 64;
+        if (role != 0u && (role - 1u) + ngr * (uint32_t)wave < (uint32_t)NCH) {
+            const unsigned long long epoch = a.x.epoch0 + (unsigned long long)step_t + 1ull;
+            const unsigned parity = (unsigned)(epoch & 1ull);
+            const uint32_t tag = (uint32_t)epoch, ntag = tag + 1u, itag = tag & 0x7fffffffu;
+            const StepSlot* ms = a.slots + step_t;
+            const float* znoise = a.noise_base + (size_t)step_t * P;
+            const unsigned long long* xin = a.ll_state[0] + (size_t)(tag & 1u) * PA;
+            unsigned long long* xout = a.ll_state[0] + (size_t)(ntag & 1u) * PA;
+            // svi.py:305, :365-375 and Adam's bias corrections: functions of the keys (the sampler left them in the step's slot)
+            const float n_valid = (float)ms->counts[1], Bf = (float)a.B;
+            const float factor0 = (n_valid == 0.0f) ? 0.0f : Bf / n_valid;
+            const float inv_B = 1.0f / Bf, inv_bc1 = 1.0f / ms->bc1, inv_bc2 = 1.0f / ms->bc2;
+            const float noise_scale = a.dp_scale * (a.clip / n_valid), out_scale0 = a.obs_scale * factor0;
+            const bool self_trip = a.x.self_trip != 0;
+            // The non-finite marker (a workgroup that saw a non-finite partial added 2^44 to the count column: NaN from here on,
+            // like the reference's float sums) travels as bit 31 of the tag of every word the rank sends, so a thread needs no
+            // count column of the peers; the rank's own count column is ONE load instruction per wave (lane r reads replica r).
+            const long long nr = __hip_atomic_load(acc_cur + (size_t)(lane < R ? lane : 0) * PA + P + 1, __ATOMIC_RELAXED, D3P_AGENT);
+            auto load_fold = [&](int c) {
+                long long s8[R], sf = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) s8[r] = __hip_atomic_load(acc_cur + (size_t)r * PA + c, __ATOMIC_RELAXED, D3P_AGENT);
+#pragma unroll
+                for (int r = 0; r < R; ++r) sf += s8[r];
+                return sf;
+            };
+            for (int ch = (int)(role - 1u) + (int)ngr * wave; ch < NCH; ch += (int)ngr * W) {   // (wave-uniform; one pass unless nw < 8)
+                const int craw = 64 * ch + lane;
+                const bool mine = craw < PA;
+                const int c = mine ? craw : PA - 1;
+                const bool is_par = c < P;
+                const int cp = is_par ? c : 0;
+                // everything this column needs, in one round trip
+                unsigned long long wx = __hip_atomic_load(xin + cp, __ATOMIC_RELAXED, D3P_AGENT);
+                unsigned long long wm = __hip_atomic_load(a.ll_state[1] + cp, __ATOMIC_RELAXED, D3P_AGENT);
+                unsigned long long wv = __hip_atomic_load(a.ll_state[2] + cp, __ATOMIC_RELAXED, D3P_AGENT);
+                const float z = znoise[cp];
+                const long long sf = load_fold(c);
+                long long nloc = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    nloc += ((long long)__builtin_amdgcn_readlane((int)(nr >> 32), r) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)nr, r);
+                const bool poison_loc = nloc >= (1ll << 40);
+                if (STAMPS && lane == 0 && wave == 0 && !(a.dbg & 256)) { asm volatile("" :: "v"(sf)); stamp[3] = wall_clock64(); }
+                const uint32_t stag = itag | (poison_loc ? 0x80000000u : 0u);
+                if (mine)
+                    for (int p = 0; p < a.x.world; ++p)
+                        if (p != a.x.rank || self_trip)
+                            xchg_ll_store(a.x.peer[p], ((size_t)parity * a.x.world + a.x.rank) * PA + c, sf, stag);
+                if (STAMPS && lane == 0 && wave == 0 && !(a.dbg & 256)) stamp[4] = wall_clock64();
+                bool alive = true;   // (wave-uniform: every exit of the wait below is taken by the whole wave)
+                // the world's sum of column cc (own fold `own`), and whether any rank sent the non-finite marker: the rows of up
+                // to eight peers are asked for together, again and again until every word carries this epoch's tag
+                auto collect = [&](int cc, long long own, long long& tot, bool& poisoned) {
+                    tot = self_trip ? 0ll : own;
+                    poisoned = poison_loc;
+                    for (int p0 = 0; p0 < a.x.world && alive; p0 += 8) {
+                        unsigned long long u0[8], u1[8];
+                        bool ok = false;
+                        for (uint32_t spins = 0; spins < D3P_WAIT_ROUNDS_PEERS / 2u; ++spins) {
+                            bool valid = true;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int p = p0 + j;
+                                u0[j] = u1[j] = (unsigned long long)itag << 32;
+                                if (p < a.x.world && (p != a.x.rank || self_trip))   // (uniform)
+                                    xchg_ll_fetch(a.x.peer[a.x.rank], ((size_t)parity * a.x.world + p) * PA + cc, &u0[j], &u1[j]);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                valid = valid && ((uint32_t)(u0[j] >> 32) & 0x7fffffffu) == itag && ((uint32_t)(u1[j] >> 32) & 0x7fffffffu) == itag;
+                            if (__ballot(!valid) == 0ull) { ok = true; break; }
+                            if ((spins & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) break;
+                        }
+                        if (!ok) {
+                            alive = false;
+                            chain_raise(a.status, abort_code(D3P_ABORT_XCHG_ROW, step_t, (uint32_t)p0));
+                            return;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int p = p0 + j;
+                            if (p < a.x.world && (p != a.x.rank || self_trip)) {
+                                tot += xchg_ll_value(u0[j], u1[j]);
+                                poisoned = poisoned || ((u0[j] | u1[j]) >> 63) != 0ull;
+                            }
+                        }
+                    }
+                };
+                long long tot;
+                bool poisoned;
+                collect(c, sf, tot, poisoned);
+                if (!alive) break;
+                if (STAMPS && lane == 0 && wave == 0 && !(a.dbg & 256)) { asm volatile("" :: "v"(tot)); stamp[14] = wall_clock64(); }
+                if (mine && is_par) {   // noise, rescale, Adam, publication
+                    // (the state words were written one step -- microseconds -- ago by the previous step's updater, or by k_run_init:
+                    // the tag test is a formality, but it is what makes the hand-over correct by construction)
+                    bool have = true;
+                    for (uint32_t spins = 0; (uint32_t)(wx >> 32) != tag || (uint32_t)(wm >> 32) != tag || (uint32_t)(wv >> 32) != tag; ++spins) {
+                        if (spins > D3P_WAIT_ROUNDS) { chain_raise(a.status, abort_code(D3P_ABORT_RELEASE, step_t, 3u)); have = false; break; }
+                        wx = __hip_atomic_load(xin + c, __ATOMIC_RELAXED, D3P_AGENT);
+                        wm = __hip_atomic_load(a.ll_state[1] + c, __ATOMIC_RELAXED, D3P_AGENT);
+                        wv = __hip_atomic_load(a.ll_state[2] + c, __ATOMIC_RELAXED, D3P_AGENT);
+                    }
+                    if (have) {
+                        const float out_scale = out_scale0 + (poisoned ? __builtin_nanf("") : 0.0f);
+                        float x = __uint_as_float((uint32_t)wx), m = __uint_as_float((uint32_t)wm), v = __uint_as_float((uint32_t)wv);
+                        const float totf = (float)(i64_to_f64(tot) * a.inv_sg);
+                        const float gr = __fmaf_rn(z, noise_scale, totf * inv_B) * out_scale;
+                        m = (1.0f - a.b1) * gr + a.b1 * m;
+                        v = (1.0f - a.b2) * gr * gr + a.b2 * v;
+                        x = x - a.lr * (m * inv_bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * inv_bc2) + a.adam_eps);
+                        const unsigned long long nt = (unsigned long long)ntag << 32;
+                        __hip_atomic_store(xout + c, nt | __float_as_uint(x), __ATOMIC_RELAXED, D3P_AGENT);
+                        __hip_atomic_store(a.ll_state[1] + c, nt | __float_as_uint(m), __ATOMIC_RELAXED, D3P_AGENT);
+                        __hip_atomic_store(a.ll_state[2] + c, nt | __float_as_uint(v), __ATOMIC_RELAXED, D3P_AGENT);
+                    }
+                }
+                if (STAMPS && lane == 0 && wave == 0 && !(a.dbg & 256)) stamp[15] = wall_clock64();
+                if (STAMPS && (a.dbg & 0x700) == 0x700 && lane == 0 && wave < 8) stamp[8 + wave] = wall_clock64();
+                if (mine && c == P) {   // the step's loss (fine part P: `tot`; coarse part P + 2) and the run's counters
+                    const long long hi_own = load_fold(P + 2);
+                    long long hi;
+                    bool p2;
+                    collect(P + 2, hi_own, hi, p2);
+                    if (alive) {
+                        const float factor = factor0 + (poisoned ? __builtin_nanf("") : 0.0f);
+                        if (a.losses) a.losses[g] = ((float)loss_join(hi, tot) / Bf) * a.obs_scale * factor;
+                        *a.adam_step = ms->adam_i + 1;
+                        if (a.batch_index) *a.batch_index = ms->batch_i + 1u;
+                    }
+                }
+            }
+        }
+        if (STAMPS && tid == 0 && a.stamps) {
             const int rec = step_t - (a.K - 2);
             if (rec >= 0 && bid < 256u)
                 for (int k = 0; k < 16; ++k) a.stamps[((size_t)rec * 256 + bid) * 16 + k] = stamp[k];
         }
-    }
-    // W = 16, data-parallel: the step's exchange in the tails of workgroups 0 and 1 (half of the columns each, ONE column per
-    // thread): wait for the step's arrivals, fold the rank's replicas, deliver the folded row to every rank's inbox, collect the
-    // world's rows from the own inbox, leave their sum in the step's row of xsum and raise the exchange flag -- what the next
-    // step's workgroups wait for.  (Same protocol as the 8-wave form's exchange workgroups above; there a wave takes ranks, here a
-    // thread takes a column, and the chip still holds two steps side by side: 2 x 128 workgroups.)
-    if (XCHG && W16 && bid < (uint32_t)D3P_XCHG_WGS) {
-        constexpr int CH = (PA + D3P_XCHG_WGS - 1) / D3P_XCHG_WGS;
-        const int xj = (int)bid, c_lo = xj * CH, cn = (PA - c_lo < CH ? PA - c_lo : CH);
-        if (tid == 64) okw[1] = 0u;
-        if (wave == 0) {  // every compute workgroup of the step has added its sums
-            const uint32_t ng = (uint32_t)a.nw < D3P_BAR_GROUPS ? (uint32_t)a.nw : D3P_BAR_GROUPS;
-            const bool ok = chain_wait_groups(a.bar + (size_t)step_t * D3P_BAR_WORDS + D3P_BAR_LINE * (1 + D3P_BAR_GROUPS), ng, a.status,
-                                              abort_code(D3P_ABORT_XCHG_ARRIVALS, step_t, (uint32_t)xj), D3P_WAIT_ROUNDS_PEERS);
-            if (lane == 0) okw[0] = ok ? 0u : 1u;
-        }
-        __syncthreads();
-        if (okw[0] != 0u) return;
-        const unsigned long long epoch = a.x.epoch0 + (unsigned long long)step_t + 1ull;
-        const unsigned parity = (unsigned)(epoch & 1ull);
-        const uint32_t tag = (uint32_t)epoch;
-        const bool mine = tid < cn;
-        const int c = mine ? tid : 0;
-        if (mine) {
-            long long sfold = 0;
-#pragma unroll
-            for (int r = 0; r < R; ++r) sfold += __hip_atomic_load(acc_cur + (size_t)r * PA + c_lo + c, __ATOMIC_RELAXED, D3P_AGENT);
-            for (int p = 0; p < a.x.world; ++p)
-                xchg_ll_store(a.x.peer[p], ((size_t)parity * a.x.world + a.x.rank) * PA + c_lo + c, sfold, tag);
-        }
-        long long tot = 0;
-        bool got = true;
-        for (int p = 0; p < a.x.world && got; ++p) {
-            const size_t row = ((size_t)parity * a.x.world + p) * PA + c_lo;
-            unsigned long long w0 = 0ull, w1 = 0ull;
-            bool ok = false;
-            for (uint32_t spins = 0; spins < 2u * D3P_WAIT_ROUNDS_PEERS; ++spins) {
-                xchg_ll_fetch(a.x.peer[a.x.rank], row + c, &w0, &w1);
-                const bool valid = !mine || xchg_ll_valid(w0, w1, tag);
-                if (__ballot(!valid) == 0ull) { ok = true; break; }
-                if ((spins & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (!ok) {
-                got = false;
-                if (lane == 0) {
-                    okw[1] = 1u;
-                    chain_raise(a.status, abort_code(D3P_ABORT_XCHG_ROW, step_t, (uint32_t)p));
-                }
-            } else if (mine) {
-                tot += xchg_ll_value(w0, w1);
-            }
-        }
-        __syncthreads();
-        if (okw[1] != 0u) return;  // aborted: the run stops here (status[0])
-        if (mine) __hip_atomic_store(a.x.xsum + (size_t)(g % 3) * PA + c_lo + c, tot, __ATOMIC_RELAXED, D3P_AGENT);
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(a.x.xflag + ((size_t)step_t * D3P_XCHG_WGS + xj) * D3P_BAR_LINE, 1u, __ATOMIC_RELAXED, D3P_AGENT);
     }
     // W = 16: the key-chain link of step `step_t` of the NEXT batch, behind the arrival of workgroup 0 (off the step's critical
     // path; the previous link was made by workgroup 0 of the previous step, behind ITS arrival)
