@@ -442,6 +442,31 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
         e2_3 = e3.e2;
         vt3 = e3.vt;
     }
+    // UPD: what an updater's tail needs of the step's slot -- svi.py:305, :365-375 and Adam's bias corrections, functions of the keys
+    // (the sampler left them in the slot) -- is read and computed HERE by every workgroup: in the tail these scalar loads (first touch:
+    // a memory round trip) sat between the arrival and the publication (round-4 anatomy: 1 us)
+    float u_factor0 = 0.f, u_inv_B = 0.f, u_inv_bc1 = 1.f, u_inv_bc2 = 1.f, u_noise_scale = 0.f, u_out_scale0 = 0.f;
+    if (UPD) {
+        const StepSlot* ms = a.slots + step_t;
+        const float n_valid = (float)ms->counts[1], Bf = (float)a.B;
+        u_factor0 = (n_valid == 0.0f) ? 0.0f : Bf / n_valid;
+        u_inv_B = 1.0f / Bf;
+        u_inv_bc1 = 1.0f / ms->bc1;
+        u_inv_bc2 = 1.0f / ms->bc2;
+        u_noise_scale = a.dp_scale * (a.clip / n_valid);
+        u_out_scale0 = a.obs_scale * u_factor0;
+        // ... and the step's Gaussian-mechanism normals (written by the sampler launch, cold by now) are pulled into this XCD's L2:
+        // an updater's load of its normal is then no slower than its other loads
+        const float zwarm = (a.noise_base + (size_t)step_t * P)[tid < P ? tid : 0];
+        asm volatile("" :: "v"(zwarm));
+    }
+    if (UPD) {
+        // the kernel-argument lines an updater's tail reads (the exchange block, the state words): first touched HERE, so that the tail's
+        // scalar loads hit the scalar cache instead of costing a memory round trip between the arrival and the publication
+        asm volatile("" :: "s"(a.x.world), "s"(a.x.rank), "s"(a.x.self_trip), "s"(a.x.peer[0]), "s"(a.x.peer[D3P_XCHG_MAX_WORLD / 2]),
+                     "s"(a.x.peer[D3P_XCHG_MAX_WORLD - 1]), "s"(a.ll_state[1]), "s"(a.ll_state[2]), "s"(a.inv_sg), "s"(a.b1), "s"(a.adam_eps),
+                     "s"(a.losses), "s"(a.adam_step), "s"(a.batch_index));
+    }
     D3P_CSTAMP(8)
     // From here on the workgroup is on the critical path of the step (D3P_DBG=2: raised wave priority against the co-resident
     // workgroup of the next step, which is generating its noise on the same SIMDs).
@@ -612,8 +637,8 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
         if (UPD) {
             // The parameters of this step: ONE tagged word per column, written by the updater of the previous step (or by
             // k_run_init / the last updater of the previous launch).  The poll is the load.  The waves leave the loop one by one
-            // (a wave whose 64 words carry the tag goes on to its derived columns); D3P_DBG bit 0x1000: wave 0 alone polls, the
-            // others wait at a barrier and load afterwards (fewer polls in flight, one more round trip).
+            // (a wave whose 64 words carry the tag goes on to its derived columns).  (Measured and dropped: wave 0 alone polls, the
+            // others wait at a barrier and load afterwards -- fewer polls in flight, one more round trip: 8.78 vs 8.62 us per step.)
             const uint32_t etag = (uint32_t)(a.x.epoch0 + (unsigned long long)step_t + 1ull);
             const unsigned long long* xrow = a.ll_state[0] + (size_t)(etag & 1u) * PA;
             unsigned long long w1 = 0ull, w2 = 0ull;
@@ -627,12 +652,7 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
                 }
                 return false;
             };
-            bool ok = true;
-            if (a.dbg & 0x1000) {
-                if (wave == 0) ok = poll();
-                __syncthreads();
-            }
-            if (ok) ok = poll();
+            const bool ok = poll();
             if (!ok) {
                 upd_bad = 1u;
                 if (lane == 0) chain_raise(a.status, abort_code(D3P_ABORT_RELEASE, step_t, 2u));
@@ -936,6 +956,8 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
         const uint32_t nw = (uint32_t)a.nw, grp = bid % D3P_BAR_GROUPS, gsize = (nw + D3P_BAR_GROUPS - 1u - grp) / D3P_BAR_GROUPS;
         const uint32_t prev = __hip_atomic_fetch_add(bar + D3P_BAR_LINE * (1 + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
         if (UPD) {
+            // (measured and dropped: ONE counter per step, the last 8 workgroups to arrive as updaters -- one atomic round trip less
+            // for them, 128 same-address atomics per step: 8.78 vs 8.64 us per step)
             // The workgroup whose arrival completes its GROUP is one of the step's (up to 8) updaters: it adds to the step's top
             // counter on line 0 and, unless that completes the step, waits until the other groups have (a handful of waiters on a
             // word that takes 8 atomics per step).  Its role for the tail: okw[2] = 1 + group, 0 = none / the run was stopped.
@@ -995,11 +1017,8 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
             const float* znoise = a.noise_base + (size_t)step_t * P;
             const unsigned long long* xin = a.ll_state[0] + (size_t)(tag & 1u) * PA;
             unsigned long long* xout = a.ll_state[0] + (size_t)(ntag & 1u) * PA;
-            // svi.py:305, :365-375 and Adam's bias corrections: functions of the keys (the sampler left them in the step's slot)
-            const float n_valid = (float)ms->counts[1], Bf = (float)a.B;
-            const float factor0 = (n_valid == 0.0f) ? 0.0f : Bf / n_valid;
-            const float inv_B = 1.0f / Bf, inv_bc1 = 1.0f / ms->bc1, inv_bc2 = 1.0f / ms->bc2;
-            const float noise_scale = a.dp_scale * (a.clip / n_valid), out_scale0 = a.obs_scale * factor0;
+            const float Bf = (float)a.B, factor0 = u_factor0, inv_B = u_inv_B, inv_bc1 = u_inv_bc1, inv_bc2 = u_inv_bc2;
+            const float noise_scale = u_noise_scale, out_scale0 = u_out_scale0;   // (from phase 0)
             const bool self_trip = a.x.self_trip != 0;
             // The non-finite marker (a workgroup that saw a non-finite partial added 2^44 to the count column: NaN from here on,
             // like the reference's float sums) travels as bit 31 of the tag of every word the rank sends, so a thread needs no
@@ -1038,43 +1057,53 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
                             xchg_ll_store(a.x.peer[p], ((size_t)parity * a.x.world + a.x.rank) * PA + c, sf, stag);
                 if (STAMPS && lane == 0 && wave == 0 && !(a.dbg & 256)) stamp[4] = wall_clock64();
                 bool alive = true;   // (wave-uniform: every exit of the wait below is taken by the whole wave)
-                // the world's sum of column cc (own fold `own`), and whether any rank sent the non-finite marker: the rows of up
-                // to eight peers are asked for together, again and again until every word carries this epoch's tag
+                // The world's sum of column cc (own fold `own`), and whether any rank sent the non-finite marker.  The peers' rows are
+                // asked for TOGETHER (NP rows per round: 7 = the peers of an 8-rank job in one round), again and again until every word
+                // carries this epoch's tag.  NP is a compile-time constant per call: the tail runs on one or two waves per CU, i.e. at one
+                // instruction per ~5 cycles, and the first form of this wait -- eight peers unrolled with run-time predicates, ~400
+                // instructions around zero to seven loads -- cost 1 us between the arrival and the publication (round-4 anatomy).
+                const char* inbox = a.x.peer[a.x.rank];
+                const int npeers = self_trip ? a.x.world : a.x.world - 1;
+                auto collect_n = [&](auto np_tag, int pos, int cc, long long& tot, bool& poisoned) {   // peers pos .. pos + NP - 1 of the list
+                    constexpr int NP = decltype(np_tag)::value;   // (the list: ranks rank + 1, rank + 2, ... mod world; with self_trip it starts at rank)
+                    size_t off[NP];
+                    int pr = a.x.rank + (self_trip ? 0 : 1) + pos;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        int q = pr + j;
+                        q = q >= a.x.world ? q - a.x.world : q;
+                        off[j] = ((size_t)parity * a.x.world + q) * PA + cc;
+                    }
+                    unsigned long long u0[NP], u1[NP];
+                    bool ok = false;
+                    for (uint32_t spins = 0; spins < D3P_WAIT_ROUNDS_PEERS / 2u; ++spins) {
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) xchg_ll_fetch(inbox, off[j], &u0[j], &u1[j]);
+                        bool valid = true;
+#pragma unroll
+                        for (int j = 0; j < NP; ++j)
+                            valid = valid && ((uint32_t)(u0[j] >> 32) & 0x7fffffffu) == itag && ((uint32_t)(u1[j] >> 32) & 0x7fffffffu) == itag;
+                        if (__ballot(!valid) == 0ull) { ok = true; break; }
+                        if ((spins & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) break;
+                    }
+                    if (!ok) {
+                        alive = false;
+                        chain_raise(a.status, abort_code(D3P_ABORT_XCHG_ROW, step_t, (uint32_t)pos));
+                        return;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        tot += xchg_ll_value(u0[j], u1[j]);
+                        poisoned = poisoned || ((u0[j] | u1[j]) >> 63) != 0ull;
+                    }
+                };
                 auto collect = [&](int cc, long long own, long long& tot, bool& poisoned) {
                     tot = self_trip ? 0ll : own;
                     poisoned = poison_loc;
-                    for (int p0 = 0; p0 < a.x.world && alive; p0 += 8) {
-                        unsigned long long u0[8], u1[8];
-                        bool ok = false;
-                        for (uint32_t spins = 0; spins < D3P_WAIT_ROUNDS_PEERS / 2u; ++spins) {
-                            bool valid = true;
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const int p = p0 + j;
-                                u0[j] = u1[j] = (unsigned long long)itag << 32;
-                                if (p < a.x.world && (p != a.x.rank || self_trip))   // (uniform)
-                                    xchg_ll_fetch(a.x.peer[a.x.rank], ((size_t)parity * a.x.world + p) * PA + cc, &u0[j], &u1[j]);
-                            }
-#pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                valid = valid && ((uint32_t)(u0[j] >> 32) & 0x7fffffffu) == itag && ((uint32_t)(u1[j] >> 32) & 0x7fffffffu) == itag;
-                            if (__ballot(!valid) == 0ull) { ok = true; break; }
-                            if ((spins & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) break;
-                        }
-                        if (!ok) {
-                            alive = false;
-                            chain_raise(a.status, abort_code(D3P_ABORT_XCHG_ROW, step_t, (uint32_t)p0));
-                            return;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int p = p0 + j;
-                            if (p < a.x.world && (p != a.x.rank || self_trip)) {
-                                tot += xchg_ll_value(u0[j], u1[j]);
-                                poisoned = poisoned || ((u0[j] | u1[j]) >> 63) != 0ull;
-                            }
-                        }
-                    }
+                    int pos = 0;
+                    while (alive && npeers - pos >= 7) { collect_n(std::integral_constant<int, 7>{}, pos, cc, tot, poisoned); pos += 7; }
+                    while (alive && npeers - pos >= 3) { collect_n(std::integral_constant<int, 3>{}, pos, cc, tot, poisoned); pos += 3; }
+                    while (alive && npeers - pos >= 1) { collect_n(std::integral_constant<int, 1>{}, pos, cc, tot, poisoned); pos += 1; }
                 };
                 long long tot;
                 bool poisoned;
