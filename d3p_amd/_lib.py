@@ -55,33 +55,67 @@ class BatchSource(C.Structure):
                 ("n_rows", C.c_uint64), ("row_lo", C.c_uint64), ("row_hi", C.c_uint64)]
 
 
+_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+def _digest(paths):
+    """sha256 over the compile flags and the CONTENTS of `paths` (in order)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(_FLAGS).encode())
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return ""
+
+
 def build(force=False, verbose=False):
-    """Compile libd3p_hip.so for gfx950 (hipcc cross-compiles without a GPU): one object per source under build/
-    (recompiled only when the source or a header is newer; the compiles run in parallel), then one link."""
-    if not force and os.path.exists(_SO) and all(
-            os.path.getmtime(_SO) >= os.path.getmtime(p) for p in _DEPS):
+    """Compile libd3p_hip.so for gfx950 (hipcc cross-compiles without a GPU): one object per source under build/, then one
+    link.  Staleness is decided by CONTENT, not by modification times (a snapshot pushed to another machine need not preserve
+    them): the library carries `libd3p_hip.so.srchash` = sha256 of flags + every source and header, every object a digest of
+    its source + the headers; whatever does not match is rebuilt (the compiles run in parallel)."""
+    want = _digest(_DEPS)
+    stamp = _SO + ".srchash"
+    if not force and os.path.exists(_SO) and _read(stamp) == want:
         return _SO
     objdir = os.path.join(os.path.dirname(_HERE), "build", "d3p_hip")
     os.makedirs(objdir, exist_ok=True)
     headers = [p for p in _DEPS if p not in _SRC]
-    newest_header = max(os.path.getmtime(p) for p in headers)
     jobs, objs = [], []
     for src in _SRC:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
-            cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        obj_want = _digest([src] + headers)
+        if force or not os.path.exists(obj) or _read(obj + ".srchash") != obj_want:
+            cmd = ["hipcc"] + _FLAGS + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            jobs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, proc in jobs:
+            jobs.append((cmd, subprocess.Popen(cmd), obj, obj_want))
+    for cmd, proc, obj, obj_want in jobs:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
+        with open(obj + ".srchash", "w") as f:
+            f.write(obj_want + "\n")
     cmd = ["hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", _SO] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(want + "\n")
     return _SO
+
+
+def is_stale():
+    """True when libd3p_hip.so is missing or was not built from the sources in this tree (content digest)."""
+    return not os.path.exists(_SO) or _read(_SO + ".srchash") != _digest(_DEPS)
 
 
 _V, _U64, _U32, _I32, _F, _SZ = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_float, C.c_size_t

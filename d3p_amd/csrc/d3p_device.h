@@ -321,6 +321,10 @@ __device__ __forceinline__ float wave_sum(float v)
     // rows 2, 3 += lane 31 (r0 + r1): lane 63 holds (r0 + r1) + (r2 + r3) -- the same value, bit for bit, as reading the four
     // row sums through SGPRs and adding them (round 2: 4 v_readlane + 3 v_add), in 2 + 1 instructions.  (A masked-off row keeps
     // its value, which `old` of __builtin_amdgcn_update_dpp cannot express for an add; the s_nop are the VALU -> DPP hazard.)
+    // Hazards the compiler's recognizer cannot see inside the asm: (i) VALU write of a VGPR -> DPP read of it (2 wait states): the
+    // s_nop 1 in front of each v_add_f32_dpp; (ii) VALU write of EXEC -> DPP (5 wait states): the asm is always preceded by the four
+    // compiler-emitted v_add_f32_dpp above plus the first s_nop 1 -- six issue slots -- and the compiler itself keeps an EXEC write
+    // five wait states away from THOSE, so no EXEC write can sit closer than that to the asm block.
     asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
         "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
         : "+v"(v));

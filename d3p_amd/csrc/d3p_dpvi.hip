@@ -23,6 +23,8 @@
 #include "d3p_logreg_wide.h"
 
 #include <dlfcn.h>
+#include <mutex>
+#include <utility>
 #include <vector>
 #include <rccl/rccl.h>  // types only: the entry points are resolved at run time from the RCCL torch has loaded
 
@@ -838,6 +840,27 @@ static int enqueue_sampler(const Ctx& c, int K)
     return D3P_OK;
 }
 
+// The 16-wave kernels need more dynamic LDS than the default limit: the attribute is per function AND per device, so it is set once
+// for every (kernel, current device) pair -- a process that drives a second GPU sets it there too -- and a failure is reported
+// instead of surfacing as an unexplained launch error.
+static int ensure_dynamic_lds(const void* fn, size_t bytes, const char* what)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& d : done)
+        if (d.first == fn && d.second == dev) return D3P_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(D3P_E_HIP, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize, %zu) on device %d: %s", what, bytes, dev, hipGetErrorString(e));
+    }
+    done.emplace_back(fn, dev);
+    return D3P_OK;
+}
+
 static int enqueue_main(const Ctx& c, int t, const float* X, const float* y, const float* eps, bool stamps,
                         hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
@@ -864,12 +887,7 @@ static int enqueue_main(const Ctx& c, int t, const float* X, const float* y, con
     a.stamps = stamps ? c.ws.stamps : nullptr;
     a.dbg = dev_dbg_flags();
     if (c.g.wide) {  // wide rows: column-chunked kernel, same partial-row output
-        static const bool attr_set = [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_logreg_wide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipGetLastError();
-            return true;
-        }();
-        (void)attr_set;
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(k_logreg_wide<false>), 160 * 1024, "k_logreg_wide")) return rc_;
         if (e0)
             hipExtLaunchKernelGGL(k_logreg_wide<false>, dim3(c.g.blocks), dim3(64 * D3P_WIDE_W), c.g.lds, c.s, e0, e1, 0, a);
         else
@@ -1034,7 +1052,9 @@ static int enqueue_fused_step(const Ctx& c, int g, int t, const StepSlot* prev_s
 
 // Chained form (MODE 3): the K steps of the prepared batch in ONE launch of K x (nw + 1) workgroups (see ChainFuse in
 // d3p_logreg_kernel.h).  On by default for the single-GPU run loop; D3P_NO_CHAINED_STEPS=1 falls back to one launch per step.
-static int g_run_form = 0;   // d3p_dpvi_logreg_set_run_form: 0 = automatic, 1 = one launch per step
+// d3p_dpvi_logreg_set_run_form: 0 = automatic, 1 = one launch per step.  Per THREAD (a caller that sets it around one run -- DPSVI.run_steps'
+// fallback -- cannot flip the form of a run another thread is enqueueing), and a run reads it ONCE, when it starts (run_fused_steps).
+static thread_local int g_run_form = 0;
 static bool use_chained_steps(const Ctx& c)
 {
     static const bool off = getenv("D3P_NO_CHAINED_STEPS") != nullptr;
@@ -1351,17 +1371,17 @@ static int enqueue_chained_batch(const Ctx& c, int g0, int K, const StepSlot* pr
     } while (0)
 #define D3P_CHAIN16_LAUNCH(PL_, ST_, IC_)                                                                                     \
     do {                                                                                                                      \
-        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logreg_chain<PL_, ST_, IC_, false, 16>), \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;   \
-        (void)lds_ok;                                                                                                         \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_logreg_chain<PL_, ST_, IC_, false, 16>), 96 * 1024,   \
+                                         "k_logreg_chain (16-wave form)"))                                                    \
+            return rc_;                                                                                                       \
         if (e0) hipExtLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, false, 16>), grid, block, lds, c.s, e0, e1, 0, ca);        \
         else hipLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, false, 16>), grid, block, lds, c.s, ca);                         \
     } while (0)
 #define D3P_CHAIN16_XCHG_LAUNCH(PL_, ST_, IC_)                                                                                   \
     do {                                                                                                                      \
-        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_logreg_chain<PL_, ST_, IC_, true, 16>), \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;   \
-        (void)lds_ok;                                                                                                         \
+        if (int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&k_logreg_chain<PL_, ST_, IC_, true, 16>), 96 * 1024,    \
+                                         "k_logreg_chain (data-parallel 16-wave form)"))                                      \
+            return rc_;                                                                                                       \
         if (e0) hipExtLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, true, 16>), grid, block, lds, c.s, e0, e1, 0, ca);         \
         else hipLaunchKernelGGL((k_logreg_chain<PL_, ST_, IC_, true, 16>), grid, block, lds, c.s, ca);                          \
     } while (0)
@@ -1618,7 +1638,8 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     static const bool xchg_per_step = getenv("D3P_XCHG_PER_STEP") != nullptr;
     // updater form of the data-parallel chained launch: the optimiser state travels as tagged words, nothing is pending between
     // launches or at the end of the run
-    const bool upd = xchg && !comm && use_chained_steps(c) && !xchg_per_step && xchg_updater_form(c);
+    const bool chain_ok = use_chained_steps(c);   // (the run's form is decided here, once)
+    const bool upd = xchg && !comm && chain_ok && !xchg_per_step && xchg_updater_form(c);
     if (upd) {
         const size_t PAc = (size_t)D3P_ACC_COLS(c.P);
         cp.ll[0] = c.ws.ll_state; cp.ll[1] = c.ws.ll_state + 2 * PAc; cp.ll[2] = c.ws.ll_state + 3 * PAc;
@@ -1627,7 +1648,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
         cp.ll_cols = (uint32_t)PAc;
         cp.n = c.P;
     }
-    const bool init_zeroes_bar = !comm && use_chained_steps(c);  // the first chained launch's arrival counters: no memset launch
+    const bool init_zeroes_bar = !comm && chain_ok;  // the first chained launch's arrival counters: no memset launch
     if (init_zeroes_bar) {
         cp.bar = c.ws.chain_bar;
         cp.bar_words = (uint32_t)((batch_len(0) + 1) * D3P_BAR_WORDS);
@@ -1644,7 +1665,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     const StepSlot* prev_slot = nullptr;
     const float* prev_noise = nullptr;
     int g = 0;
-    const bool chained = !comm && use_chained_steps(c) && (!xchg || upd || (lean_chain_ok(c, false) && !xchg_per_step));
+    const bool chained = !comm && chain_ok && (!xchg || upd || (lean_chain_ok(c, false) && !xchg_per_step));
     const bool persist = chained && use_persistent_steps(c);
     for (uint32_t b = 0; b < n_batches; ++b) {
         const int cur = (int)(b & 1), nxt = cur ^ 1;

@@ -446,7 +446,8 @@ int d3p_dpvi_logreg_run_status(void* stream, const d3p_logreg_model* model, cons
  * ONE launch whose workgroups hand over through arrival counters, which needs the launch's workgroups to make progress
  * together (a GPU shared with other work can starve one: the bounded waits then stop the run, d3p_dpvi_logreg_run_status);
  * 1 -- one launch per step: no cross-workgroup waits at all, ~2 x slower.  DPSVI.run_steps re-runs a stopped run in form 1
- * (the reference's jit(fori_loop) cannot stall; a drop-in must not either).  Process-wide switch, not thread-safe.  ABI 6. */
+ * (the reference's jit(fori_loop) cannot stall; a drop-in must not either).  The switch belongs to the CALLING THREAD and a run
+ * reads it once, when it is enqueued: setting it around one run cannot change the form of a run another thread is enqueueing.  ABI 6. */
 int d3p_dpvi_logreg_set_run_form(int form);
 
 /* Measurement hook for the run loops (d3p_dpvi_logreg_run, d3p_dpvi_logreg_run_dist): while enabled, every launch of the

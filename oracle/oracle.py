@@ -14,11 +14,27 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libd3p_oracle.so")
 
 
+def _src_digest():
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("d3p_oracle.c", "Makefile"):
+        with open(os.path.join(_HERE, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False):
-    src = os.path.join(_HERE, "d3p_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    """(staleness by content, like d3p_amd._lib.build: the stamp file beside the library holds the digest of its sources)"""
+    want, stamp = _src_digest(), _SO + ".srchash"
+    have = ""
+    if os.path.exists(stamp):
+        with open(stamp) as f:
+            have = f.read().strip()
+    if force or not os.path.exists(_SO) or have != want:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libd3p_oracle.so"],
                               stdout=subprocess.DEVNULL)
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
     return _SO
 
 
