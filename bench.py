@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, the fp32 matrix (= vector) peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak; an fp32-accurate product on the bf16 pipe is SIX bf16 MFMAs: / 6 = 417 TFLOP/s
 SIMDS, SHADER_GHZ = 1024, 2.4   # 256 CUs x 4 SIMD-32; peak shader clock
 # wave64 VALU issue: MI355X_MICROARCH.md gives 2 cycles per plain fp32 instruction per SIMD -- the nominal peak used here; no
 # opcode measured reaches it (profiles/r03_valu_opcodes.json, launch-based: VOP2 add / xor / fmac 2.4, v_fma_f32 3.0, VOP3 integer /
@@ -225,6 +226,7 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
             "unit": "examples/s", "us_per_step": round(1e6 * ev / steps, 2), "final_loss": float(run.loss),
             "roofline": {"bound": "mfma", "achieved": round(flops * steps / ev / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flops * steps / ev / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "gemm_flop_per_step": flops,
+                         "frac_of_bf16_peak_over_6": round(flops * steps / ev / 1e12 / (MFMA_BF16_PEAK_TFLOPS / 6.0), 4),
                          "dtype": "f32-accurate: the large products as six v_mfma_f32_32x32x16_bf16 on an EXACT three-way bf16 split of both "
                                   "fp32 operands, fp32 accumulate (dropped terms < 2^-23 relative; DESIGN.md 1c); peak quoted = the fp32 MFMA peak "
                                   "the reference's float32 arithmetic would be priced against",
@@ -267,6 +269,60 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
                          "keystream_bytes_per_step": 4 * N,
                          "note": "whole step (mask + compaction + the DP-VI step) over the mask's integer work alone",
                          "timing": "HIP events on the launch stream around the 256-step device-resident run"}}
+    return out
+
+
+def vae_dist_workload(dev, world, rank, group_barrier, share_gpu=False):
+    """BASELINE configs[4] at N > 1 ("VAE ... 1 vs 8 GPU"): the epoch body of examples/vae.py:227-246 data-parallel -- the batch
+    sharded by position (4096 examples per GPU: weak scaling like the headline), ONE all-reduce of the P + 2 fp32 sums per step
+    (2.76 MB for 784-400-50; torch.distributed = RCCL over xGMI), the noise added once after it.  Every rank returns the timing;
+    rank 0's dictionary goes under `workloads`."""
+    import torch
+    import torch.distributed as dist
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    from d3p_amd.models import Adam, Trace_ELBO, VAEGuide, VAEModel
+    from d3p_amd.svi import DPSVI
+    out = {}
+    for tag, H2 in (("vae_config5", 0), ("vae_config5_400_200", 200)):
+        N, Bl, D, H, Z = 60000, 4096, 784, 400, 50
+        Bg = Bl * world
+        pos0 = Bl * rank
+        X = (torch.rand(Bl, 28, 28, generator=torch.Generator().manual_seed(1000 + rank)) < 0.3).float().to(dev)
+        model = VAEModel(scale=1.0 / N)
+        svi = DPSVI(model, VAEGuide(model), Adam(1e-3), Trace_ELBO(), 10.0, 1.0, num_obs_total=N, z_dim=Z,
+                    hidden_dim=(H, H2) if H2 else H)
+        st = svi.init(rng.PRNGKey(0), X)          # (a function of the key and the shapes: identical on every rank)
+        engine = ddist.VaeHipEngine(svi)
+        warm, steps = (8, 10) if share_gpu else (48, 40)
+        group_barrier()
+        st, _ = ddist.vae_run_steps(engine, st, X, Bg, pos0, warm, collect_losses=False)
+        group_barrier()
+        t0 = time.perf_counter()
+        st, losses = ddist.vae_run_steps(engine, st, X, Bg, pos0, steps)
+        group_barrier()
+        wall = time.perf_counter() - t0
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t[0])
+        hs = [H] + ([H2] if H2 else [])
+        dec, enc = [Z] + hs[::-1] + [D], [D] + hs
+        layers = list(zip(dec[:-1], dec[1:])) + list(zip(enc[:-1], enc[1:])) + [(hs[-1], 2 * Z)]
+        flops = 2 * Bl * (3 * sum(i * o for i, o in layers) - D * H)   # per RANK and step
+        Pn = int(st.optim_state[1].numel())
+        out[tag + f"_dp{world}"] = {
+            "workload": "BASELINE configs[4] data-parallel: VAE 784 -> %s -> 50 (P = %d), batch 4096 per GPU (global %d, sharded by position), "
+                        "C=10, sigma=1, Adam 1e-3; per step local sums -> one all-reduce(SUM) of %d fp32 -> apply" % (hs, Pn, Bg, Pn + 2),
+            "n_gpus": world, "steps": steps, "warmup": warm, "steps_per_sec": round(steps / wall, 2), "value": round(Bg * steps / wall, 1),
+            "unit": "examples/s (whole job)", "us_per_step": round(1e6 * wall / steps, 2), "final_loss": float(losses[-1]),
+            "collective": {"bytes_per_step": 4 * (Pn + 2), "backend": "gloo (shared-GPU rehearsal)" if share_gpu else "torch.distributed nccl = RCCL"},
+            "roofline": {"bound": "mfma", "achieved": round(flops * steps / wall / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
+                         "frac": round(flops * steps / wall / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "gemm_flop_per_step_and_gpu": flops,
+                         "frac_of_bf16_peak_over_6": round(flops * steps / wall / 1e12 / (MFMA_BF16_PEAK_TFLOPS / 6.0), 4),
+                         "timing": "wall clock between barriers around the steps (max over ranks): kernels + the collective"}}
+        del X, svi, st, engine
+        torch.cuda.empty_cache()
     return out
 
 
@@ -506,11 +562,12 @@ def main():
                 kname = ("k_logreg_chain<PLIST, STAMPS=0, ICPT=0, XCHG=0, W=16> (chained launch: the <= 128 DP-VI steps of a prepared batch "
                          "per launch, 128 sixteen-wave workgroups per step; k_logreg_main<MODE 3> for shapes other than d = 512)")
             elif isinstance(comm, ddist.XchgComm) and native and not os.environ.get("D3P_XCHG_PER_STEP"):
-                kname = ("k_logreg_chain<PLIST=1, STAMPS=0, ICPT=0, XCHG=1, W=16> (data-parallel chained launch, opt-in form D3P_XCHG_W16=1: "
-                         "128 compute workgroups per step, the one-shot full-mesh sum-exchange over xGMI in the tails of workgroups 0 and 1)"
-                         if os.environ.get("D3P_XCHG_W16") else
-                         "k_logreg_chain<PLIST=1, STAMPS=0, ICPT=0, XCHG=1, W=8> (data-parallel chained launch: per step 256 compute "
-                         "workgroups + 1 key-chain + 2 exchange workgroups that carry the one-shot full-mesh sum-exchange over xGMI)")
+                kname = ("k_logreg_chain<PLIST=1, STAMPS=0, ICPT=0, XCHG=1, W=8> (data-parallel chained launch, round-2 form D3P_XCHG_W8=1: per step 256 "
+                         "compute workgroups + 1 key-chain + 2 exchange workgroups that carry the one-shot full-mesh sum-exchange over xGMI)"
+                         if os.environ.get("D3P_XCHG_W8") else
+                         "k_logreg_chain<PLIST=1, STAMPS=0, ICPT=0, XCHG=1, W=16> (data-parallel chained launch, updater form: 128 sixteen-wave "
+                         "workgroups per step; the last arrivers of the 8 arrival groups fold the rank's sums, exchange them full-mesh over xGMI as "
+                         "tagged 8-byte words, apply noise + Adam once and publish the parameters as tagged words the next step polls)")
             elif comm is not None and native:
                 kname = "k_logreg_main<MODE 2> (one launch per DP-VI step) + the step's collective (k_xchg or ncclAllReduce) on the same stream"
             else:
@@ -574,6 +631,8 @@ def main():
             del Xl, yl, gb_l, st_l, svi_l
         if single and rank == 0 and extra_legs and not args.no_aux_workloads:
             aux.update(aux_workloads(dev, None, want=("gmm", "vae", "vae2")))
+        if world > 1 and extra_legs and not args.no_aux_workloads and not aux:   # configs[4] at N > 1 (every rank takes part)
+            aux.update(vae_dist_workload(dev, world, rank, barrier, share_gpu))
         if rank != 0:
             return None
         B_done = Bg // emu if emu else Bg   # (--emulate-world runs ONE rank's share: the examples this GPU processed, not the job's)
