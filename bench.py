@@ -469,7 +469,11 @@ def main():
                 return svi.run_steps(st, get_batch, bkey, first, k)   # (raises if the chained launch was aborted)
         else:
             engine_cls = ddist.HipEngine if os.environ.get("D3P_DIST_TWO_PHASE") else ddist.FusedHipEngine
-            engine = engine_cls(svi, X, y, n_rows_total, lo, hi, L.D3P_BATCH_FEISTEL, Bg)
+            if args.sampler == "poisson":   # q = B / N, padded to the 0.99 quantile of Poisson(B) (examples/logistic_regression.py:126-127)
+                from scipy.stats import poisson as _poisson
+                engine = engine_cls(svi, X, y, n_rows_total, lo, hi, L.D3P_BATCH_POISSON, int(_poisson.ppf(0.99, Bg)), q=Bg / n_rows_total)
+            else:
+                engine = engine_cls(svi, X, y, n_rows_total, lo, hi, L.D3P_BATCH_FEISTEL, Bg)
 
             def run(st, first, k):
                 if comm is not None and native:

@@ -146,6 +146,9 @@ SIGNATURES = {
     "d3p_feistel_from_constants": (C.c_int, [_V, _V, _U32, _U32, _V]),
     "d3p_poisson_select_rng": (C.c_int, [_V, C.c_int, _V, _F, _U32, _U32, C.c_int, _V, _V, _V, _SZ]),
     "d3p_poisson_select_batch": (C.c_int, [_V, C.c_int, _V, _SZ, _F, _U32, _U32, C.c_int, _V, _SZ, _V, _SZ, _U32, _V, _SZ]),
+    "d3p_poisson_shard_flags": (C.c_int, [_V, C.c_int, _V, _SZ, _F, _U32, _U32, _U32, _U32, _V, _V, _SZ]),
+    "d3p_poisson_shard_write": (C.c_int, [_V, _U32, _U32, _U32, _U32, _V, _SZ, _V, _V, _V, _SZ, _U32, _V, _SZ]),
+    "d3p_xchg_poisson_counts": (C.c_int, [_V, _V, _V, _U32, _U32, C.c_int, _V, _SZ, _V, _V, _SZ]),
     "d3p_perturb_apply": (C.c_int, [_V, _V, _V, _U64, _F, _F, _V, _F, _V]),
     "d3p_poisson_select_workspace": (_SZ, [_U32]),
     "d3p_poisson_select": (C.c_int, [_V, _V, _F, _U32, _U32, C.c_int, _V, _V, _V, _SZ]),
@@ -235,7 +238,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.d3p_abi_version() != 6:
+        if lib.d3p_abi_version() != 7:
             raise D3PError("libd3p_hip.so ABI version mismatch")
         _lib = lib
     return _lib

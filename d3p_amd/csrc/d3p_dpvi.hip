@@ -49,6 +49,7 @@ struct Workspace {
     uint32_t* xflags;      // in-launch exchange of a data-parallel run: D3P_STEP_BATCH x D3P_XCHG_WGS flags, 128 bytes apart
     long long* xsum;       // ... and the world's sums of step g in row g % 3 (3 x cols)
     unsigned long long* ll_state;  // data-parallel updater form: the optimiser state as tagged words -- parameters 2 x cols, m cols, v cols
+    uint32_t* pshard;      // sharded Poisson selection: [D3P_STEP_BATCH] the shard's selected counts | [D3P_STEP_BATCH] selected in the shards above
     float* partials;  // max_blocks x (P + 2)
     unsigned long long* stamps;  // 2 x max_blocks
     void* poisson_ws;
@@ -76,6 +77,7 @@ static size_t carve(const d3p_logreg_model* m, const d3p_batch_source* src, char
     p = take((size_t)D3P_STEP_BATCH * D3P_XCHG_WGS * 32 * sizeof(uint32_t)); if (ws) ws->xflags = (uint32_t*)p;
     p = take(3 * (size_t)D3P_ACC_COLS(P) * sizeof(long long)); if (ws) ws->xsum = (long long*)p;
     p = take(4 * (size_t)D3P_ACC_COLS(P) * sizeof(unsigned long long)); if (ws) ws->ll_state = (unsigned long long*)p;
+    p = take(2 * (size_t)D3P_STEP_BATCH * sizeof(uint32_t)); if (ws) ws->pshard = (uint32_t*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * (P + 2) * sizeof(float)); if (ws) ws->partials = (float*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * 4 * sizeof(unsigned long long)); if (ws) ws->stamps = (unsigned long long*)p;  // >= 2 x 256 x 16 phase stamps
     size_t pb = 0;
@@ -787,7 +789,11 @@ static int enqueue_sched_init_chain(const Ctx& c, int K)
     return check_launch("k_chain");
 }
 
-static int enqueue_sampler(const Ctx& c, int K);
+struct Xchg;
+static int enqueue_sampler(const Ctx& c, int K, Xchg* xchg = nullptr);
+static int enqueue_xchg_poisson_counts(hipStream_t s, Xchg* x, const uint32_t* local, int K, uint32_t cutoff, int suppress, uint32_t* counts,
+                                       size_t counts_stride_words, uint32_t* above_out, uint32_t* n_owned, size_t n_owned_stride_words,
+                                       uint32_t* status);
 
 // key chain + sampler for the next K steps
 static int enqueue_batch_prep(const Ctx& c, int K)
@@ -818,13 +824,31 @@ static void fill_sampler_args(const Ctx& c, SamplerArgs* out)
     sa.row_hi = c.src->kind == D3P_BATCH_EXPLICIT ? ~0ull : c.src->row_hi;
 }
 
-static int enqueue_sampler(const Ctx& c, int K)
+static int enqueue_sampler(const Ctx& c, int K, Xchg* xchg)
 {
     SamplerArgs sa;
     fill_sampler_args(c, &sa);
     hipLaunchKernelGGL(k_sampler, dim3(cdiv(c.src->B, 256) + 1, K), dim3(256), 0, c.s, sa);
     int rc = check_launch("k_sampler");
     if (rc) return rc;
+    static const bool full_mask = getenv("D3P_POISSON_FULL_MASK") != nullptr;   // developer switch: every rank makes the whole mask (round 3)
+    if (c.src->kind == D3P_BATCH_POISSON && xchg && !full_mask) {
+        // Data-parallel run with the one-shot exchange: the rank makes the Bernoulli mask of ITS rows only (1 / world of the ChaCha20
+        // blocks); the shards' selected counts of the K steps travel in one tagged exchange (d3p_xchg_poisson_counts);
+        // the rank then writes its valid selected rows at their global batch positions and its dense list of owned positions.
+        // Bit for bit the rows and positions the whole mask gives (minibatch.py:29-39, :119-124).
+        const size_t stride = sizeof(StepSlot) / sizeof(uint32_t);
+        uint32_t* local = c.ws.pshard, *above = c.ws.pshard + D3P_STEP_BATCH;
+        if ((rc = d3p_poisson_shard_flags((void*)c.s, 0, c.ws.slots[0].batch_key, stride, c.src->q, (uint32_t)c.src->n_rows, (uint32_t)c.src->row_lo,
+                                          (uint32_t)c.src->row_hi, (uint32_t)K, local, c.ws.poisson_ws, c.ws.poisson_bytes)))
+            return rc;
+        if ((rc = enqueue_xchg_poisson_counts(c.s, xchg, local, K, c.src->B, c.src->suppress, c.ws.slots[0].counts, stride, above,
+                                              &c.ws.slots[0].n_owned, stride, run_status_words(c.ws))))
+            return rc;
+        return d3p_poisson_shard_write((void*)c.s, (uint32_t)c.src->n_rows, (uint32_t)c.src->row_lo, (uint32_t)c.src->row_hi, c.src->B,
+                                       c.ws.slots[0].counts, stride, above, c.ws.idx, c.ws.plist, c.src->B, (uint32_t)K, c.ws.poisson_ws,
+                                       c.ws.poisson_bytes);
+    }
     if (c.src->kind == D3P_BATCH_POISSON) {  // all K draws in one set of launches (blockIdx.y = step)
         rc = d3p_poisson_select_batch((void*)c.s, 0, c.ws.slots[0].batch_key, sizeof(StepSlot) / sizeof(uint32_t), c.src->q,
                                       (uint32_t)c.src->n_rows, c.src->B, c.src->suppress, c.ws.idx, c.src->B,
@@ -1496,9 +1520,73 @@ struct Xchg {
     size_t inbox_bytes;
     char* peer[D3P_XCHG_MAX_WORLD];    // the peers' inboxes mapped into this process (peer[rank] == inbox)
     bool opened[D3P_XCHG_MAX_WORLD];
+    // behind the rows, in the same allocation (so the peers' mappings cover it): the COUNT box of the sharded Poisson selection,
+    // ll[2][world][D3P_STEP_BATCH] words of 16 bytes, with its own epoch (one exchange per prepared batch of steps)
+    size_t cbox_off;
+    unsigned long long cepoch;
 };
 
 static inline size_t xchg_inbox_bytes(int world, uint32_t words) { return align_up((size_t)2 * world * words * 16, 256); }
+static inline size_t xchg_cbox_bytes(int world) { return align_up((size_t)2 * world * D3P_STEP_BATCH * 16, 256); }
+
+// The shards' selected counts of the K steps of a prepared batch, all-gathered through the count box (same tagged-word protocol
+// as the rows: no flag, no acknowledgement).  Thread t <-> step t: total selected, valid after truncate / suppress
+// (minibatch.py:119-124) -> counts[0], counts[1]; selected in the shards with HIGHER rows (= higher ranks: the table is sharded
+// contiguously in rank order) -> above_out[t]; the rank's owned valid positions -> n_owned.
+struct XchgCountArgs {
+    const uint32_t* local;
+    int K;
+    uint32_t cutoff;
+    int suppress;
+    uint32_t* counts;
+    size_t counts_stride;
+    uint32_t* above_out;
+    uint32_t* n_owned;
+    size_t n_owned_stride;
+    int world, rank;
+    unsigned long long epoch;
+    char* peer[D3P_XCHG_MAX_WORLD];
+    size_t cbox_off;
+    uint32_t* status;
+};
+
+__global__ void __launch_bounds__(D3P_STEP_BATCH) k_xchg_counts(XchgCountArgs a)
+{
+    const int t = threadIdx.x;
+    if (t >= a.K) return;
+    const unsigned parity = (unsigned)(a.epoch & 1ull);
+    const uint32_t tag = (uint32_t)a.epoch;
+    const uint32_t mine = a.local[t];
+    for (int p = 0; p < a.world; ++p)
+        if (p != a.rank) xchg_ll_store(a.peer[p] + a.cbox_off, ((size_t)parity * a.world + a.rank) * D3P_STEP_BATCH + t, (long long)mine, tag);
+    uint32_t total = mine, above = 0u;
+    bool ok = true;
+    for (int p = 0; p < a.world && ok; ++p) {
+        if (p == a.rank) continue;
+        unsigned long long w0 = 0ull, w1 = 0ull;
+        ok = false;
+        for (uint32_t spins = 0; spins < D3P_WAIT_ROUNDS_PEERS; ++spins) {
+            xchg_ll_fetch(a.peer[a.rank] + a.cbox_off, ((size_t)parity * a.world + p) * D3P_STEP_BATCH + t, &w0, &w1);
+            if (xchg_ll_valid(w0, w1, tag)) { ok = true; break; }
+            if ((spins & 63u) == 63u && a.status && __hip_atomic_load(a.status, __ATOMIC_RELAXED, D3P_AGENT) != 0u) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (!ok) {
+            if (a.status) chain_raise(a.status, abort_code(D3P_ABORT_XCHG_KERNEL, t, (uint32_t)p));
+            break;
+        }
+        const uint32_t v = (uint32_t)xchg_ll_value(w0, w1);
+        total += v;
+        if (p > a.rank) above += v;
+    }
+    if (!ok) { total = 0u; above = 0u; }   // (the run is stopped: nothing of this batch is used)
+    const uint32_t valid = a.suppress ? (total <= a.cutoff ? total : 0u) : (total < a.cutoff ? total : a.cutoff);
+    a.counts[(size_t)t * a.counts_stride] = total;
+    a.counts[(size_t)t * a.counts_stride + 1] = valid;
+    a.above_out[t] = above;
+    const uint32_t room = valid > above ? valid - above : 0u;
+    a.n_owned[(size_t)t * a.n_owned_stride] = room < mine ? room : mine;
+}
 
 struct XchgArgs {
     long long* acc;  // R x words: this rank's replicas of the step's accumulator; on return row 0 holds the global totals, rows 1.. zeros
@@ -1568,6 +1656,31 @@ static void xchg_fill_dev(Xchg* x, XchgDev* d, int K)
     for (int p = 0; p < x->world; ++p) d->peer[p] = x->peer[p];
     d->epoch0 = x->epoch;
     x->epoch += (unsigned long long)K;
+}
+
+static int enqueue_xchg_poisson_counts(hipStream_t s, Xchg* x, const uint32_t* local, int K, uint32_t cutoff, int suppress, uint32_t* counts,
+                                       size_t counts_stride_words, uint32_t* above_out, uint32_t* n_owned, size_t n_owned_stride_words,
+                                       uint32_t* status)
+{
+    XchgCountArgs a;
+    memset(&a, 0, sizeof(a));
+    a.local = local;
+    a.K = K;
+    a.cutoff = cutoff;
+    a.suppress = suppress;
+    a.counts = counts;
+    a.counts_stride = counts_stride_words;
+    a.above_out = above_out;
+    a.n_owned = n_owned;
+    a.n_owned_stride = n_owned_stride_words;
+    a.world = x->world;
+    a.rank = x->rank;
+    a.epoch = ++x->cepoch;
+    for (int p = 0; p < x->world; ++p) a.peer[p] = x->peer[p];
+    a.cbox_off = x->cbox_off;
+    a.status = status;
+    hipLaunchKernelGGL(k_xchg_counts, dim3(1), dim3(D3P_STEP_BATCH), 0, s, a);
+    return check_launch("k_xchg_counts");
 }
 
 static int enqueue_xchg(hipStream_t s, Xchg* x, long long* acc, int R, uint32_t* status)
@@ -1660,7 +1773,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
                        (const int32_t*)st0->step, sampled ? (const uint32_t*)c.src->batch_index : nullptr, c.ws.sched, cb[0].ws.slots,
                        batch_len(0), c.ws.acc, acc_words, run_status_words(c.ws), cp);
     if ((rc = check_launch("k_run_init"))) return rc;
-    if ((rc = enqueue_sampler(cb[0], batch_len(0)))) return rc;
+    if ((rc = enqueue_sampler(cb[0], batch_len(0), xchg))) return rc;
     static const bool no_piggy = getenv("D3P_NO_CHAIN_PIGGYBACK") != nullptr;  // developer switch, read once
     const StepSlot* prev_slot = nullptr;
     const float* prev_noise = nullptr;
@@ -1703,7 +1816,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
         }
         if (b + 1 < n_batches) {
             if (no_piggy && (rc = enqueue_chain(cb[nxt], K_next))) return rc;
-            if ((rc = enqueue_sampler(cb[nxt], K_next))) return rc;
+            if ((rc = enqueue_sampler(cb[nxt], K_next, xchg))) return rc;
         }
     }
     if (persist) {  // state, step counters and losses are already final: only the key is left
@@ -2008,7 +2121,9 @@ int d3p_xchg_create(int32_t world, int32_t rank, uint32_t words, void** xchg_out
     x->rank = rank;
     x->words = words;
     x->epoch = 0;
-    x->inbox_bytes = xchg_inbox_bytes(world, words);
+    x->cbox_off = xchg_inbox_bytes(world, words);
+    x->cepoch = 0;
+    x->inbox_bytes = x->cbox_off + xchg_cbox_bytes(world);
     void* p = nullptr;
     hipError_t e = hipExtMallocWithFlags(&p, x->inbox_bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) { delete x; return fail(D3P_E_HIP, "d3p_xchg_create: hipExtMallocWithFlags: %s", hipGetErrorString(e)); }
@@ -2064,6 +2179,17 @@ int d3p_xchg_destroy(void* xchg)
     (void)hipGetLastError();
     delete x;
     return D3P_OK;
+}
+
+int d3p_xchg_poisson_counts(void* stream, void* xchg, const uint32_t* shard_counts_dev, uint32_t num_steps, uint32_t cutoff, int suppress,
+                            uint32_t* counts_dev, size_t counts_stride_words, uint32_t* above_dev, uint32_t* n_owned_dev,
+                            size_t n_owned_stride_words)
+{
+    D3P_REQUIRE(xchg && shard_counts_dev && counts_dev && above_dev && n_owned_dev, "d3p_xchg_poisson_counts: null pointer");
+    D3P_REQUIRE(num_steps >= 1 && num_steps <= D3P_STEP_BATCH, "d3p_xchg_poisson_counts: 1 <= num_steps <= 128 (one prepared batch)");
+    D3P_REQUIRE(counts_stride_words >= 2 && n_owned_stride_words >= 1, "d3p_xchg_poisson_counts: strides too small");
+    return enqueue_xchg_poisson_counts((hipStream_t)stream, (Xchg*)xchg, shard_counts_dev, (int)num_steps, cutoff, suppress, counts_dev,
+                                       counts_stride_words, above_dev, n_owned_dev, n_owned_stride_words, nullptr);
 }
 
 int d3p_xchg_allreduce(void* stream, void* xchg, long long* acc_dev, int32_t replicas)

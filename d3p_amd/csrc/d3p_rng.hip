@@ -213,26 +213,30 @@ __global__ void k_feistel_from_rc(const uint32_t* __restrict__ rc_in, uint32_t c
 template <int RNG>  // 0: ChaCha20 keystream (d3p.random), 1: threefry iota stream (d3p.random.debug)
 __global__ void __launch_bounds__(D3P_PS_THREADS)
 k_poisson_flags(const uint32_t* __restrict__ key, size_t key_stride_words, float q, uint32_t N,
-                uint16_t* __restrict__ flags, uint32_t* __restrict__ wg_counts, size_t ws_stride_bytes)
+                uint16_t* __restrict__ flags, uint32_t* __restrict__ wg_counts, size_t ws_stride_bytes,
+                uint32_t chunk0, uint32_t n_chunks, uint32_t elo, uint32_t ehi)
 {
+    // chunk0, n_chunks, [elo, ehi): the SHARD of the mask this launch makes (the whole mask: 0, ceil(N / 16), [0, N)).  Element e's
+    // draw is keystream word e whoever generates it (block e / 16, word e % 16), so a rank of a row-sharded data-parallel run makes
+    // the blocks of its own rows only -- 1 / world of the work -- and obtains the same bits as a single GPU.
     // blockIdx.y selects the step of a batch: every per-step array is `stride` apart
     key += (size_t)blockIdx.y * key_stride_words;
     flags = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(flags) + (size_t)blockIdx.y * ws_stride_bytes);
     wg_counts = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(wg_counts) + (size_t)blockIdx.y * ws_stride_bytes);
     __shared__ uint32_t red[D3P_PS_THREADS / 64];
     const uint32_t t = blockIdx.x * D3P_PS_THREADS + threadIdx.x;
-    const uint32_t n_chunks = (N + 15u) / 16u;
+    const uint32_t ch = chunk0 + t;   // the keystream block / group of 16 elements of this thread
     uint32_t m = 0;
     if (t < n_chunks) {
         uint32_t o[16];
         if (RNG == 0) {
             uint32_t k[16];
             load_key(key, k);
-            keystream_block(k, t, o);
+            keystream_block(k, ch, o);
         } else {
 #pragma unroll
             for (int w = 0; w < 16; ++w) {
-                const uint32_t e = 16u * t + w;
+                const uint32_t e = 16u * ch + w;
                 o[w] = (e < N) ? tf_iota_word(key[0], key[1], N, e) : 0u;
             }
         }
@@ -241,15 +245,15 @@ k_poisson_flags(const uint32_t* __restrict__ key, size_t key_stride_words, float
         // comparison (word >> 9) <= floor(q 2^23) -- two integer instructions per element and no conversion, select or branch
         // (bit for bit the same mask; the float form stays for the last, partial chunk's bounds)
         const uint32_t thr = q >= 1.0f ? 0xffffffffu : (uint32_t)floorf(q * 8388608.0f);
-        if (16u * t + 15u < N) {
+        if (16u * ch >= elo && 16u * ch + 15u < ehi) {
 #pragma unroll
             for (int w = 0; w < 16; ++w) m |= (((o[w] >> 9) - thr - 1u) >> 31) << w;   // (x <= thr <=> x - thr - 1 wraps negative; x, thr < 2^31)
             if (q >= 1.0f) m = 0xffffu;
-        } else {
+        } else {   // a chunk that straddles the end of the table or of the shard
 #pragma unroll
             for (int w = 0; w < 16; ++w) {
-                const uint32_t e = 16u * t + w;
-                const bool sel = (e < N) && (bits_to_uniform(o[w], 0.0f, 1.0f) <= q);
+                const uint32_t e = 16u * ch + w;
+                const bool sel = (e >= elo) && (e < ehi) && (bits_to_uniform(o[w], 0.0f, 1.0f) <= q);
                 m |= (sel ? 1u : 0u) << w;
             }
         }
@@ -270,8 +274,10 @@ k_poisson_flags(const uint32_t* __restrict__ key, size_t key_stride_words, float
 __global__ void __launch_bounds__(1024)
 k_poisson_scan(const uint32_t* __restrict__ wg_counts, uint32_t n_wg, uint32_t cutoff, int suppress,
                uint32_t* __restrict__ wg_above, uint32_t* __restrict__ counts, size_t ws_stride_bytes,
-               size_t counts_stride_words)
+               size_t counts_stride_words, uint32_t* __restrict__ shard_counts)
 {
+    // shard_counts != nullptr: the launch scans a SHARD of the mask; the shard's selected count of step blockIdx.y goes there and
+    // `counts` is left to whoever knows the other shards' counts (d3p_xchg_poisson_counts)
     wg_counts = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(wg_counts) + (size_t)blockIdx.y * ws_stride_bytes);
     wg_above = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(wg_above) + (size_t)blockIdx.y * ws_stride_bytes);
     counts += (size_t)blockIdx.y * counts_stride_words;
@@ -303,23 +309,33 @@ k_poisson_scan(const uint32_t* __restrict__ wg_counts, uint32_t n_wg, uint32_t c
     }
     if (threadIdx.x == 1023) {
         const uint32_t nsel = part[1023];
-        counts[0] = nsel;
-        counts[1] = suppress ? (nsel <= cutoff ? nsel : 0u) : (nsel < cutoff ? nsel : cutoff);
+        if (shard_counts) {
+            shard_counts[blockIdx.y] = nsel;
+        } else {
+            counts[0] = nsel;
+            counts[1] = suppress ? (nsel <= cutoff ? nsel : 0u) : (nsel < cutoff ? nsel : cutoff);
+        }
     }
 }
 
 __global__ void __launch_bounds__(D3P_PS_THREADS)
 k_poisson_write(const uint16_t* __restrict__ flags, const uint32_t* __restrict__ wg_above,
                 const uint32_t* __restrict__ counts, uint32_t N, uint32_t cutoff, uint32_t* __restrict__ out_idx,
-                size_t ws_stride_bytes, size_t counts_stride_words, size_t idx_stride_words)
+                size_t ws_stride_bytes, size_t counts_stride_words, size_t idx_stride_words,
+                uint32_t chunk0, uint32_t n_chunks, const uint32_t* __restrict__ shard_above, uint32_t* __restrict__ plist)
 {
+    // shard_above != nullptr: the flags are those of a SHARD (chunks chunk0 ...); shard_above[step] = selected elements in the
+    // shards ABOVE this one (higher rows).  Only the shard's selected elements are written, at their GLOBAL positions -- the
+    // selected elements come first, in descending row order (minibatch.py:36-37), so the shard's positions are the contiguous range
+    // shard_above .. + its count -- and only the valid ones (position < counts[1]: truncation keeps the globally highest rows,
+    // minibatch.py:119-124); plist[j] = shard_above + j is the shard's dense list of owned positions.
     flags = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(flags) + (size_t)blockIdx.y * ws_stride_bytes);
     wg_above = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(wg_above) + (size_t)blockIdx.y * ws_stride_bytes);
     counts += (size_t)blockIdx.y * counts_stride_words;
     out_idx += (size_t)blockIdx.y * idx_stride_words;
     __shared__ uint32_t wave_cnt[D3P_PS_THREADS / 64];
+    if (plist) plist += (size_t)blockIdx.y * idx_stride_words;
     const uint32_t t = blockIdx.x * D3P_PS_THREADS + threadIdx.x;
-    const uint32_t n_chunks = (N + 15u) / 16u;
     const uint32_t m = (t < n_chunks) ? flags[t] : 0u;
     const uint32_t c = __popc(m);
     // selected elements in higher threads of this wave (suffix sum over lanes)
@@ -334,6 +350,19 @@ k_poisson_write(const uint16_t* __restrict__ flags, const uint32_t* __restrict__
     uint32_t above = wg_above[blockIdx.x] + (suf - c);
     for (int w = (threadIdx.x >> 6) + 1; w < D3P_PS_THREADS / 64; ++w) above += wave_cnt[w];
     if (t >= n_chunks) return;
+    if (shard_above) {
+        const uint32_t first = shard_above[blockIdx.y], n_valid = counts[1];
+        above += first;
+        for (int w = 15; w >= 0; --w) {
+            if (!((m >> w) & 1u)) continue;
+            if (above < n_valid) {
+                out_idx[above] = 16u * (chunk0 + t) + (uint32_t)w;
+                if (plist) plist[above - first] = above;
+            }
+            ++above;
+        }
+        return;
+    }
     const uint32_t nsel = counts[0];
     // walk this thread's 16 elements from the top
     for (int w = 15; w >= 0; --w) {
@@ -624,17 +653,85 @@ int d3p_poisson_select_batch(void* stream, int rng_kind, const uint32_t* keys_de
     const dim3 grid(n_wg, num_steps);
     if (rng_kind == 0)
         hipLaunchKernelGGL(k_poisson_flags<0>, grid, dim3(D3P_PS_THREADS), 0, s, keys_dev, key_stride_words, q, N, flags,
-                           wg_counts, per_step);
+                           wg_counts, per_step, 0u, (uint32_t)n_chunks, 0u, N);
     else
         hipLaunchKernelGGL(k_poisson_flags<1>, grid, dim3(D3P_PS_THREADS), 0, s, keys_dev, key_stride_words, q, N, flags,
-                           wg_counts, per_step);
+                           wg_counts, per_step, 0u, (uint32_t)n_chunks, 0u, N);
     hipLaunchKernelGGL(k_poisson_scan, dim3(1, num_steps), dim3(1024), 0, s, (const uint32_t*)wg_counts, n_wg, cutoff, suppress,
-                       wg_above, out_counts_dev, per_step, counts_stride_words);
+                       wg_above, out_counts_dev, per_step, counts_stride_words, (uint32_t*)nullptr);
     if (cutoff > 0)
         hipLaunchKernelGGL(k_poisson_write, grid, dim3(D3P_PS_THREADS), 0, s, (const uint16_t*)flags,
                            (const uint32_t*)wg_above, (const uint32_t*)out_counts_dev, N, cutoff, out_idx_dev, per_step,
-                           counts_stride_words, idx_stride_words);
+                           counts_stride_words, idx_stride_words, 0u, (uint32_t)n_chunks, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     return check_launch("d3p_poisson_select");
+}
+
+// The same selection made by the ranks of a row-sharded data-parallel run, each for the rows [row_lo, row_hi) it holds (SURVEY
+// 8(e)): two calls with the exchange of the shards' counts between them (d3p_xchg_poisson_counts in the run loops; any other
+// all-gather of num_steps words per rank will do).
+//   d3p_poisson_shard_flags: the shard's part of the Bernoulli mask (ceil((row_hi - row_lo) / 16) + <= 1 ChaCha20 blocks per step
+//     instead of N / 16) and its selected count per step -> shard_counts_dev[t];
+//   d3p_poisson_shard_write: given, per step, counts {selected in the whole table, valid = after truncate / suppress} (stride
+//     counts_stride_words) and above_dev[t] = selected elements in the shards with HIGHER rows: the shard's valid selected rows at
+//     their global batch positions in out_idx (the other entries of out_idx are not touched), its dense list of owned positions
+//     (plist_dev, nullable; same stride as out_idx) -- the union over the shards is bit for bit the single-GPU selection.
+int d3p_poisson_shard_flags(void* stream, int rng_kind, const uint32_t* keys_dev, size_t key_stride_words, float q, uint32_t N,
+                            uint32_t row_lo, uint32_t row_hi, uint32_t num_steps, uint32_t* shard_counts_dev, void* workspace_dev,
+                            size_t workspace_bytes)
+{
+    D3P_REQUIRE(rng_kind == 0 || rng_kind == 1, "d3p_poisson_shard_flags: rng_kind must be 0 (chacha) or 1 (threefry)");
+    D3P_REQUIRE(keys_dev && shard_counts_dev && workspace_dev, "d3p_poisson_shard_flags: null pointer");
+    D3P_REQUIRE(N >= 1 && row_lo <= row_hi && row_hi <= N, "d3p_poisson_shard_flags: need 0 <= row_lo <= row_hi <= N, N >= 1");
+    D3P_REQUIRE(num_steps >= 1 && num_steps <= 65535, "d3p_poisson_shard_flags: 1 <= num_steps <= 65535");
+    const uint32_t chunk0 = row_lo / 16u;
+    const size_t n_chunks = row_hi > row_lo ? ((size_t)row_hi + 15) / 16 - chunk0 : 0;
+    const size_t per_step = d3p_poisson_select_workspace(n_chunks ? (uint32_t)(16 * n_chunks) : 1u);
+    if (workspace_bytes < per_step * num_steps)
+        return fail(D3P_E_WORKSPACE, "d3p_poisson_shard_flags: workspace too small (%zu < %zu)", workspace_bytes, per_step * num_steps);
+    hipStream_t s = (hipStream_t)stream;
+    if (n_chunks == 0) {  // an empty shard selects nothing
+        D3P_HIP_TRY(hipMemsetAsync(shard_counts_dev, 0, (size_t)num_steps * sizeof(uint32_t), s));
+        return D3P_OK;
+    }
+    const uint32_t n_wg = (uint32_t)((n_chunks + D3P_PS_THREADS - 1) / D3P_PS_THREADS);
+    char* ws = (char*)workspace_dev;
+    uint16_t* flags = (uint16_t*)ws;
+    uint32_t* wg_counts = (uint32_t*)(ws + align_up(n_chunks * sizeof(uint16_t), 256));
+    uint32_t* wg_above = (uint32_t*)((char*)wg_counts + align_up((n_wg + 1) * sizeof(uint32_t), 256));
+    const dim3 grid(n_wg, num_steps);
+    if (rng_kind == 0)
+        hipLaunchKernelGGL(k_poisson_flags<0>, grid, dim3(D3P_PS_THREADS), 0, s, keys_dev, key_stride_words, q, N, flags, wg_counts, per_step,
+                           chunk0, (uint32_t)n_chunks, row_lo, row_hi);
+    else
+        hipLaunchKernelGGL(k_poisson_flags<1>, grid, dim3(D3P_PS_THREADS), 0, s, keys_dev, key_stride_words, q, N, flags, wg_counts, per_step,
+                           chunk0, (uint32_t)n_chunks, row_lo, row_hi);
+    hipLaunchKernelGGL(k_poisson_scan, dim3(1, num_steps), dim3(1024), 0, s, (const uint32_t*)wg_counts, n_wg, 0u, 0, wg_above,
+                       (uint32_t*)nullptr, per_step, (size_t)0, shard_counts_dev);
+    return check_launch("d3p_poisson_shard_flags");
+}
+
+int d3p_poisson_shard_write(void* stream, uint32_t N, uint32_t row_lo, uint32_t row_hi, uint32_t cutoff, const uint32_t* counts_dev,
+                            size_t counts_stride_words, const uint32_t* above_dev, uint32_t* out_idx_dev, uint32_t* plist_dev,
+                            size_t idx_stride_words, uint32_t num_steps, void* workspace_dev, size_t workspace_bytes)
+{
+    D3P_REQUIRE(counts_dev && above_dev && workspace_dev, "d3p_poisson_shard_write: null pointer");
+    D3P_REQUIRE(out_idx_dev || cutoff == 0, "d3p_poisson_shard_write: null index buffer");
+    D3P_REQUIRE(N >= 1 && row_lo <= row_hi && row_hi <= N, "d3p_poisson_shard_write: need 0 <= row_lo <= row_hi <= N, N >= 1");
+    D3P_REQUIRE(num_steps >= 1 && num_steps <= 65535, "d3p_poisson_shard_write: 1 <= num_steps <= 65535");
+    const uint32_t chunk0 = row_lo / 16u;
+    const size_t n_chunks = row_hi > row_lo ? ((size_t)row_hi + 15) / 16 - chunk0 : 0;
+    if (n_chunks == 0 || cutoff == 0) return D3P_OK;
+    const size_t per_step = d3p_poisson_select_workspace((uint32_t)(16 * n_chunks));
+    if (workspace_bytes < per_step * num_steps)
+        return fail(D3P_E_WORKSPACE, "d3p_poisson_shard_write: workspace too small (%zu < %zu)", workspace_bytes, per_step * num_steps);
+    const uint32_t n_wg = (uint32_t)((n_chunks + D3P_PS_THREADS - 1) / D3P_PS_THREADS);
+    char* ws = (char*)workspace_dev;
+    const uint16_t* flags = (const uint16_t*)ws;
+    const uint32_t* wg_counts = (const uint32_t*)(ws + align_up(n_chunks * sizeof(uint16_t), 256));
+    const uint32_t* wg_above = (const uint32_t*)((const char*)wg_counts + align_up((n_wg + 1) * sizeof(uint32_t), 256));
+    hipLaunchKernelGGL(k_poisson_write, dim3(n_wg, num_steps), dim3(D3P_PS_THREADS), 0, (hipStream_t)stream, flags, wg_above, counts_dev, N, cutoff,
+                       out_idx_dev, per_step, counts_stride_words, idx_stride_words, chunk0, (uint32_t)n_chunks, above_dev, plist_dev);
+    return check_launch("d3p_poisson_shard_write");
 }
 
 int d3p_take_rows(void* stream, const void* table_dev, uint64_t n_rows, uint32_t row_bytes, const uint32_t* idx_dev,

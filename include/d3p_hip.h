@@ -34,7 +34,7 @@ extern "C" {
 #define D3P_E_UNSUPPORTED (-3)
 #define D3P_E_WORKSPACE (-4)
 
-#define D3P_ABI_VERSION 6
+#define D3P_ABI_VERSION 7
 
 int d3p_abi_version(void);
 const char* d3p_last_error(void);
@@ -121,6 +121,23 @@ int d3p_poisson_select_batch(void* stream, int rng_kind, const uint32_t* keys_de
                              float q, uint32_t N, uint32_t cutoff, int suppress, uint32_t* out_idx_dev,
                              size_t idx_stride_words, uint32_t* out_counts_dev, size_t counts_stride_words,
                              uint32_t num_steps, void* workspace_dev, size_t workspace_bytes);
+
+/* The same selection made by the ranks of a row-sharded data-parallel run, each for the rows [row_lo, row_hi) it holds (SURVEY 8(e);
+ * d3p/minibatch.py:29-39: element e's draw is keystream word e whoever generates it, so a rank makes the ChaCha20 blocks of its own
+ * rows only -- 1 / world of the work -- and obtains the single-GPU mask bit for bit).  Two calls with an all-gather of the shards'
+ * counts between them (d3p_xchg_poisson_counts below; the run loops with the one-shot exchange do all three per prepared batch):
+ *   d3p_poisson_shard_flags: the shard's part of the mask and its selected count per step -> shard_counts_dev[t];
+ *   d3p_poisson_shard_write: given, per step, counts {selected in the whole table, valid after truncate / suppress
+ *     (minibatch.py:119-124)} at counts_dev + t * counts_stride_words and above_dev[t] = selected elements in the shards with HIGHER
+ *     rows: the shard's valid selected rows at their GLOBAL batch positions in out_idx (descending row order, :36-37; other entries
+ *     are not touched) and its dense list of owned positions (plist_dev, nullable; stride idx_stride_words like out_idx).
+ * Same workspace for both (num_steps x d3p_poisson_select_workspace(16 * chunks of the shard) <= that of the whole table).  ABI 7. */
+int d3p_poisson_shard_flags(void* stream, int rng_kind, const uint32_t* keys_dev, size_t key_stride_words, float q, uint32_t N,
+                            uint32_t row_lo, uint32_t row_hi, uint32_t num_steps, uint32_t* shard_counts_dev, void* workspace_dev,
+                            size_t workspace_bytes);
+int d3p_poisson_shard_write(void* stream, uint32_t N, uint32_t row_lo, uint32_t row_hi, uint32_t cutoff, const uint32_t* counts_dev,
+                            size_t counts_stride_words, const uint32_t* above_dev, uint32_t* out_idx_dev, uint32_t* plist_dev,
+                            size_t idx_stride_words, uint32_t num_steps, void* workspace_dev, size_t workspace_bytes);
 
 /* jnp.take(a, idx, axis=0) for a row-major table (minibatch.py:126-129, :210, :233, :306).
  * If valid_count_dev != NULL, output rows >= *valid_count_dev are zero-filled (the mask multiply
@@ -482,7 +499,16 @@ int d3p_dpvi_logreg_kernel_timing_read(double* total_us_out, uint32_t* launches_
  *                     the accumulator row of the model: 2 D + 4). */
 int d3p_xchg_create(int32_t world, int32_t rank, uint32_t words, void** xchg_out, uint8_t* handle_out, size_t handle_bytes);
 int d3p_xchg_connect(void* xchg, const uint8_t* handles, size_t handle_stride);
- /* d3p_xchg_connect_local: the same for ranks that live in ONE process (one stream each): `peers` = the `world` exchange
+ /* All-gather of the shards' selected counts of the <= 128 steps of a prepared batch through the exchange's count box (tagged words like
+ * the rows; its own epoch), for d3p_poisson_shard_write: per step t counts_dev[t * counts_stride_words + {0, 1}] = {selected in the
+ * whole table, valid after truncate (cutoff) / suppress}, above_dev[t] = selected in the shards of the HIGHER ranks (the table is
+ * sharded contiguously in rank order), n_owned_dev[t * n_owned_stride_words] = this rank's valid selected rows.  Every rank of the
+ * exchange must call it the same number of times.  ABI 7. */
+int d3p_xchg_poisson_counts(void* stream, void* xchg, const uint32_t* shard_counts_dev, uint32_t num_steps, uint32_t cutoff, int suppress,
+                            uint32_t* counts_dev, size_t counts_stride_words, uint32_t* above_dev, uint32_t* n_owned_dev,
+                            size_t n_owned_stride_words);
+
+/* d3p_xchg_connect_local: the same for ranks that live in ONE process (one stream each): `peers` = the `world` exchange
   * objects of the group, in rank order; their inboxes are wired directly. */
 int d3p_xchg_connect_local(void* xchg, void* const* peers, int32_t world);
 int d3p_xchg_destroy(void* xchg);

@@ -565,6 +565,53 @@ def test_xchg_virtual_ranks_on_streams_match_the_single_rank_run(gpu, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("suppress,maxB", [(False, 560), (False, 500), (True, 520)])
+def test_poisson_batches_sharded_over_two_virtual_ranks_match_the_single_rank_run(gpu, suppress, maxB):
+    """Data-parallel run on Poisson batches (poisson_batchify_data's sampler, minibatch.py:29-39, :103-131) with the one-shot exchange:
+    every rank makes the mask of ITS rows only, the shards' counts travel through the exchange's count box
+    (d3p_xchg_poisson_counts), truncation (maxB below the expected batch: the globally highest rows stay) and suppression act on
+    the GLOBAL count.  Two virtual ranks on two streams (inboxes wired directly) must end with bitwise identical replicas that
+    walk the single-rank trajectory (which makes the whole mask) to fp32 rounding: same keys, same losses, same parameters."""
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    n, d, B, X, y = _xchg_problem()
+    world, steps, q = 2, 16, 512.0 / n        # (expected batch 512: maxB = 500 truncates about two steps in three, 520 suppresses some)
+    svi, st0 = _xchg_svi(n, d)
+    Xc, yc = X.cuda(), y.cuda()
+    single = ddist.FusedHipEngine(svi, Xc, yc, n, 0, n, L.D3P_BATCH_POISSON, maxB, q=q, suppress=suppress)
+    ref_state, ref_losses = ddist.run_steps_native(single, st0, rng.PRNGKey(4), 2, steps, comm=None)
+    ref_losses = ref_losses.clone()
+    comms = ddist.XchgComm.local_group(world, 2 * d + 4)
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    try:
+        engines, results = [], []
+        for r in range(world):
+            lo, hi = ddist.shard_rows(n, r, world)
+            engines.append(ddist.FusedHipEngine(svi, Xc[lo:hi], yc[lo:hi], n, lo, hi, L.D3P_BATCH_POISSON, maxB, q=q, suppress=suppress))
+        torch.cuda.synchronize()
+        for r in range(world):
+            with torch.cuda.stream(streams[r]):
+                results.append(ddist.run_steps_native(engines[r], st0, rng.PRNGKey(4), 2, steps, comm=comms[r]))
+        torch.cuda.synchronize()
+    finally:
+        for c in comms:
+            c.close()
+    for r, (st, losses) in enumerate(results):
+        code, _ = ddist.native_run_status(engines[r])
+        assert code == 0, f"rank {r}: {L.describe_abort(code)}"
+        assert torch.equal(st.rng_key, ref_state.rng_key) and int(st.optim_state[0]) == steps
+        # (bit patterns: a suppressed batch turns everything NaN, and NaN != NaN)
+        assert torch.equal(st.optim_state[1].view(torch.int32), results[0][0].optim_state[1].view(torch.int32))
+        assert torch.equal(losses.view(torch.int32), results[0][1].view(torch.int32))
+    a, b = results[0][1].cpu().numpy(), ref_losses.cpu().numpy()
+    assert np.array_equal(np.isnan(a), np.isnan(b))      # (a suppressed batch: n = 0 -> NaN like the reference, SURVEY F9)
+    if not np.isnan(b).any():
+        np.testing.assert_allclose(a, b, rtol=2e-5)
+        np.testing.assert_allclose(results[0][0].optim_state[1].cpu().numpy(), ref_state.optim_state[1].cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("form", ["in_launch", "per_step"])
 def test_xchg_two_processes_over_hipipc(gpu, form):
     """The real thing -- one PROCESS per rank, inboxes mapped through hipIpc handles, system-scope rows across the process

@@ -100,6 +100,60 @@ def test_poisson_select_bit_exact(rng, O, N, q, cutoff, suppress):
     assert np.array_equal(np_(idx), eidx)
 
 
+@pytest.mark.parametrize("N,q,cutoff,suppress,world", [
+    (10**7, 4096 / 10**7, 4245, False, 8), (10**7, 4096 / 10**7, 4000, False, 8), (10**7, 4096 / 10**7, 4000, True, 8),
+    (10**7 + 13, 4096 / 10**7, 4245, False, 3),      # ragged shards, boundaries off the 16-element chunks
+    (105, 0.3, 39, False, 4), (105, 0.3, 20, False, 4), (105, 0.3, 20, True, 4), (40, 0.5, 40, False, 8),   # shards smaller than a chunk
+    (1000, 1.0, 1000, False, 8), (1000, 1.0, 300, False, 8), (17, 0.0, 5, False, 2), (5, 0.9, 5, False, 8)])   # (more ranks than rows)
+def test_poisson_selection_sharded_over_ranks_is_the_single_gpu_selection(rng, O, N, q, cutoff, suppress, world):
+    """SURVEY 8(e) / minibatch.py:29-39, :119-124: rank r of a row-sharded job makes the Bernoulli mask of ITS rows only
+    (d3p_poisson_shard_flags: the keystream blocks of its rows), learns how many rows the HIGHER shards selected (here summed on the
+    host from the shards' counts -- in a run d3p_xchg_poisson_counts does it through the exchange) and writes its valid selected
+    rows at their GLOBAL batch positions (d3p_poisson_shard_write).  The union over the `world` virtual ranks must be the oracle's
+    selection of the whole table bit for bit: rows, order (descending), truncation to the highest rows, suppression -- and every
+    rank's dense list of owned positions must be its contiguous range of positions."""
+    import ctypes as Ct
+    import d3p_amd._lib as L
+    from d3p_amd._lib import check, ptr, stream_ptr
+    from d3p_amd.dist import shard_rows
+    lib = L.load()
+    key = rng.PRNGKey(N + cutoff)
+    eidx, nsel, nvalid = O.poisson_select(O.PRNGKey(N + cutoff), q, N, cutoff, suppress)
+    shards = [shard_rows(N, r, world) for r in range(world)]
+    wss, locals_ = [], []
+    for lo, hi in shards:
+        ws = torch.empty(max(256, lib.d3p_poisson_select_workspace(max(16, 16 * ((hi + 15) // 16 - lo // 16)))), dtype=torch.uint8, device="cuda")
+        cnt = torch.full((1,), 0xFFFFFFFF, dtype=torch.uint32, device="cuda")
+        check(lib.d3p_poisson_shard_flags(stream_ptr(), 0, ptr(key), 0, q, N, lo, hi, 1, ptr(cnt), ptr(ws), ws.numel()))
+        wss.append(ws)
+        locals_.append(int(np_(cnt)[0]))
+    assert sum(locals_) == nsel
+    valid = (nsel if nsel <= cutoff else 0) if suppress else min(nsel, cutoff)
+    assert valid == nvalid
+    union = np.full(max(cutoff, 1), 0xFFFFFFFF, np.uint32)
+    seen = np.zeros(max(cutoff, 1), np.int32)
+    for r, (lo, hi) in enumerate(shards):
+        above = sum(locals_[r + 1:])
+        counts = torch.from_numpy(np.array([nsel, valid], np.uint32)).cuda()
+        ab = torch.from_numpy(np.array([above], np.uint32)).cuda()
+        mine = torch.full((max(cutoff, 1),), 0xFFFFFFFF, dtype=torch.uint32, device="cuda")
+        plist = torch.full((max(cutoff, 1),), 0xFFFFFFFF, dtype=torch.uint32, device="cuda")
+        check(lib.d3p_poisson_shard_write(stream_ptr(), N, lo, hi, cutoff, ptr(counts), 2, ptr(ab), ptr(mine), ptr(plist), cutoff, 1,
+                                          ptr(wss[r]), wss[r].numel()))
+        m = np_(mine)
+        wrote = np.nonzero(m != 0xFFFFFFFF)[0]
+        n_owned = min(max(valid - above, 0), locals_[r])
+        assert wrote.size == n_owned
+        if n_owned:
+            assert wrote[0] == above and wrote[-1] == above + n_owned - 1          # a contiguous range of positions
+            assert np.all((m[wrote] >= lo) & (m[wrote] < hi))                       # its own rows
+            assert np.array_equal(np_(plist)[:n_owned], np.arange(above, above + n_owned, dtype=np.uint32))
+        seen[wrote] += 1
+        union[wrote] = m[wrote]
+    assert np.all(seen[:valid] == 1) and not seen[valid:].any()
+    assert np.array_equal(union[:valid], eidx[:valid])
+
+
 def test_subsample_batchifier(rng):
     """reference tests/test_minibatch.py:117-225"""
     from d3p_amd.minibatch import subsample_batchify_data
