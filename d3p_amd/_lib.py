@@ -188,6 +188,7 @@ SIGNATURES = {
     "d3p_xchg_connect_local": (C.c_int, [_V, _V, _I32]),
     "d3p_xchg_destroy": (C.c_int, [_V]),
     "d3p_xchg_allreduce": (C.c_int, [_V, _V, _V, _I32]),
+    "d3p_xchg_simulate_peers": (C.c_int, [_V, _V, _U32]),
     "d3p_dpvi_logreg_run_xchg": (C.c_int, [_V, _V, _PM, _PH, _PS, _PB, _V, _V, _U32, _V, _V, _SZ]),
     "d3p_dpvi_logreg_set_run_form": (C.c_int, [C.c_int]),
     "d3p_dpvi_logreg_kernel_timing_enable": (C.c_int, [C.c_int]),

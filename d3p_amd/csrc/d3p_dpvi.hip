@@ -1649,6 +1649,41 @@ __global__ void __launch_bounds__(1024) k_xchg(XchgArgs a)
     }
 }
 
+// Test / rehearsal helper: the OTHER world - 1 ranks of an exchange played by one workgroup on this GPU.  For each of the next
+// `n` exchanges it waits until this rank's row of that epoch has arrived in the inbox of its next peer (i.e. the rank has sent)
+// and then delivers all-zero rows of every other rank, tagged with the epoch, to this rank's inbox -- a faithful protocol partner
+// (slot parity, tags, one row per peer and epoch) that contributes nothing to the sums.  With it ONE GPU runs the 8-rank code
+// paths of the data-parallel kernels (seven rows collected per round, sends to seven inboxes): tests/test_dist.py.
+struct XchgSimArgs {
+    char* peer_next;   // inbox of rank (rank + 1) % world: where this rank's rows are watched
+    char* mine;        // this rank's inbox
+    int world, rank;
+    uint32_t words;
+    unsigned long long epoch0;
+    uint32_t n;
+};
+
+__global__ void __launch_bounds__(1024) k_xchg_simulate_peers(XchgSimArgs a)
+{
+    for (uint32_t i = 0; i < a.n; ++i) {
+        const unsigned long long epoch = a.epoch0 + i + 1ull;
+        const unsigned parity = (unsigned)(epoch & 1ull);
+        const uint32_t tag = (uint32_t)epoch;
+        for (uint32_t c = threadIdx.x; c < a.words; c += blockDim.x) {
+            bool ok = false;
+            for (uint32_t spins = 0; spins < D3P_WAIT_ROUNDS_PEERS; ++spins) {
+                unsigned long long w0, w1;
+                xchg_ll_fetch(a.peer_next, ((size_t)parity * a.world + a.rank) * a.words + c, &w0, &w1);
+                if (((uint32_t)(w0 >> 32) & 0x7fffffffu) == (tag & 0x7fffffffu) && ((uint32_t)(w1 >> 32) & 0x7fffffffu) == (tag & 0x7fffffffu)) { ok = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!ok) return;   // (the run never sent: it was stopped, or never started)
+            for (int p = 0; p < a.world; ++p)
+                if (p != a.rank) xchg_ll_store(a.mine, ((size_t)parity * a.world + p) * a.words + c, 0ll, tag);
+        }
+    }
+}
+
 static void xchg_fill_dev(Xchg* x, XchgDev* d, int K)
 {
     d->world = x->world;
@@ -2190,6 +2225,27 @@ int d3p_xchg_poisson_counts(void* stream, void* xchg, const uint32_t* shard_coun
     D3P_REQUIRE(counts_stride_words >= 2 && n_owned_stride_words >= 1, "d3p_xchg_poisson_counts: strides too small");
     return enqueue_xchg_poisson_counts((hipStream_t)stream, (Xchg*)xchg, shard_counts_dev, (int)num_steps, cutoff, suppress, counts_dev,
                                        counts_stride_words, above_dev, n_owned_dev, n_owned_stride_words, nullptr);
+}
+
+int d3p_xchg_simulate_peers(void* stream, void* xchg, uint32_t num_exchanges)
+{
+    D3P_REQUIRE(xchg, "d3p_xchg_simulate_peers: null exchange");
+    Xchg* x = (Xchg*)xchg;
+    D3P_REQUIRE(x->world >= 2, "d3p_xchg_simulate_peers: needs an exchange of at least two ranks");
+    const int nxt = (x->rank + 1) % x->world;
+    D3P_REQUIRE(x->peer[nxt] && x->peer[nxt] != x->inbox, "d3p_xchg_simulate_peers: the peers' inboxes must be mapped (d3p_xchg_connect / _connect_local)");
+    if (num_exchanges == 0) return D3P_OK;
+    XchgSimArgs a;
+    memset(&a, 0, sizeof(a));
+    a.peer_next = x->peer[nxt];
+    a.mine = x->inbox;
+    a.world = x->world;
+    a.rank = x->rank;
+    a.words = x->words;
+    a.epoch0 = x->epoch;
+    a.n = num_exchanges;
+    hipLaunchKernelGGL(k_xchg_simulate_peers, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    return check_launch("k_xchg_simulate_peers");
 }
 
 int d3p_xchg_allreduce(void* stream, void* xchg, long long* acc_dev, int32_t replicas)

@@ -259,6 +259,12 @@ class XchgComm:
         """acc: int64 tensor [replicas, words] (this rank's accumulator replicas) -> row 0 = global sums, other rows 0."""
         check(_lib.load().d3p_xchg_allreduce(stream_ptr(), self.handle, ptr(acc), int(replicas)))
 
+    def simulate_peers(self, num_exchanges):
+        """Test / rehearsal helper (d3p_xchg_simulate_peers): enqueue, on the CURRENT stream, one workgroup that plays the other
+        world - 1 ranks for the next `num_exchanges` exchanges (all-zero rows, protocol-faithful).  Enqueue it on another stream
+        than the run, before the run."""
+        check(_lib.load().d3p_xchg_simulate_peers(stream_ptr(), self.handle, int(num_exchanges)))
+
     def close(self):
         if self.handle:
             torch.cuda.synchronize()

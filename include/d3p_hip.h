@@ -508,6 +508,12 @@ int d3p_xchg_poisson_counts(void* stream, void* xchg, const uint32_t* shard_coun
                             uint32_t* counts_dev, size_t counts_stride_words, uint32_t* above_dev, uint32_t* n_owned_dev,
                             size_t n_owned_stride_words);
 
+/* Test / rehearsal helper: the other world - 1 ranks of an exchange played by ONE workgroup on this GPU, enqueued on `stream` (not
+ * the stream of the run): for each of the next `num_exchanges` exchanges it waits until this rank's row has arrived in its next
+ * peer's inbox and then delivers all-zero rows of every other rank to this rank's inbox.  A run of the 8-rank code paths on one GPU
+ * (tests/test_dist.py); the result equals the rank's run with an exchange of its own.  Needs mapped peer inboxes.  ABI 7. */
+int d3p_xchg_simulate_peers(void* stream, void* xchg, uint32_t num_exchanges);
+
 /* d3p_xchg_connect_local: the same for ranks that live in ONE process (one stream each): `peers` = the `world` exchange
   * objects of the group, in rank order; their inboxes are wired directly. */
 int d3p_xchg_connect_local(void* xchg, void* const* peers, int32_t world);

@@ -565,6 +565,56 @@ def test_xchg_virtual_ranks_on_streams_match_the_single_rank_run(gpu, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,B,steps", [(8, 4096, 140), (4, 2048, 40), (3, 512, 24), (16, 4096, 20)])
+def test_xchg_updater_form_with_simulated_peers_runs_the_many_rank_paths(gpu, world, B, steps):
+    """The data-parallel chained launch as rank 1 of a `world`-rank job on ONE GPU: the other ranks are played by
+    d3p_xchg_simulate_peers (one workgroup on a second stream that answers every exchange with all-zero rows, protocol-faithful:
+    slot parity, tags, one row per peer and epoch).  This runs what two virtual ranks cannot: the updaters' sends to seven (three,
+    two, fifteen) inboxes and their wait for seven rows at once (three; one after the other; two rounds of seven + one) -- at the
+    production shape for world 8: d = 512, global batch 4096, 140 steps across the 128-step launch boundary.  The peers add
+    nothing, so the run must be BITWISE the run of the same shard with an exchange of its own (world 1)."""
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    n, d = 20000, 512
+    g = torch.Generator().manual_seed(17)
+    X = torch.randn(n, d, generator=g)
+    y = (torch.rand(n, generator=g) < 0.5).float()
+    svi, st0 = _xchg_svi(n, d)
+    rank = 1
+    lo, hi = ddist.shard_rows(n, rank, world)
+    Xs, ys = X[lo:hi].cuda(), y[lo:hi].cuda()
+    # reference: the same shard, exchanging with itself
+    solo = ddist.XchgComm(2 * d + 4)
+    try:
+        eng0 = ddist.FusedHipEngine(svi, Xs, ys, n, lo, hi, L.D3P_BATCH_FEISTEL, B)
+        ref_state, ref_losses = ddist.run_steps_native(eng0, st0, rng.PRNGKey(4), 2, steps, comm=solo)
+        ref_losses = ref_losses.clone()
+        torch.cuda.synchronize()
+        assert ddist.native_run_status(eng0)[0] == 0
+    finally:
+        solo.close()
+    comms = ddist.XchgComm.local_group(world, 2 * d + 4)
+    side = torch.cuda.Stream()
+    try:
+        eng = ddist.FusedHipEngine(svi, Xs, ys, n, lo, hi, L.D3P_BATCH_FEISTEL, B)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            comms[rank].simulate_peers(steps)
+        st, losses = ddist.run_steps_native(eng, st0, rng.PRNGKey(4), 2, steps, comm=comms[rank])
+        torch.cuda.synchronize()
+        code, _ = ddist.native_run_status(eng)
+        assert code == 0, L.describe_abort(code)
+    finally:
+        for c in comms:
+            c.close()
+    assert torch.equal(st.rng_key, ref_state.rng_key) and int(st.optim_state[0]) == steps
+    assert torch.equal(losses, ref_losses)
+    for a, b in zip(st.optim_state[1:], ref_state.optim_state[1:]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("suppress,maxB", [(False, 560), (False, 500), (True, 520)])
 def test_poisson_batches_sharded_over_two_virtual_ranks_match_the_single_rank_run(gpu, suppress, maxB):
     """Data-parallel run on Poisson batches (poisson_batchify_data's sampler, minibatch.py:29-39, :103-131) with the one-shot exchange:
