@@ -58,7 +58,23 @@ struct GemmArgs {
     int n_seg, k_seg;
     long long b_njump, b_kjump, bias_njump, c_njump;
     float* C2;        // second operand / output of the epilogue, same shape and leading dimension as C
+    // k_gemm_bf16x3 only, nullable: a device word that is non-zero when EVERY element of A is exactly a bf16 number (low 16 bits of
+    // the fp32 pattern zero) -- binarised images (examples/vae.py:157-168), one-hot rows, small integers.  The second and third
+    // plane of A are then exactly zero: the kernel stages plane 0 alone (no splitting of A) and issues the three products with a_0
+    // (of six); the sums are those of the general path (the dropped products are exact zeros, the others come in the same order).
+    const uint32_t* a_exact16;
 };
+
+// the flag of GemmArgs::a_exact16 for an array of n floats (n a multiple of 4, 16-byte aligned): 1 unless some element has low bits
+__global__ void __launch_bounds__(256) k_exact16_flag(const float* __restrict__ x, size_t n4, uint32_t* __restrict__ flag)
+{
+    uint32_t bad = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4*>(x)[i];
+        bad |= (v.x | v.y | v.z | v.w) & 0xffffu;
+    }
+    if (__ballot(bad != 0u) != 0ull && (threadIdx.x & 63) == 0) *flag = 0u;   // (every writer writes the same value)
+}
 
 // o = alpha * acc + bias (+ C); then the epilogue
 __device__ __forceinline__ void gemm_store(const GemmArgs& g, int row, int col, float acc, float bv)
@@ -591,8 +607,9 @@ __global__ void __launch_bounds__(512) k_gemm_bf16x3(GemmArgs g)
     };
     // EDGE = false: the slice lies inside [kbeg, kend) and the tile inside the rows of A that exist -- no edge arithmetic, no branch
     // (the steady state: its body is straight-line code that the scheduler interleaves with the MFMAs of the slice before)
-    auto stage = [&](auto S, int buf, int k0, auto EDGE) {  // register set S (slice starting at k0): edges applied, split, three planes -> LDS
+    auto stage = [&](auto S, int buf, int k0, auto EDGE, auto A1P) {  // register set S (slice starting at k0): edges applied, split, three planes -> LDS
         constexpr int s = decltype(S)::value;
+        constexpr bool A1 = decltype(A1P)::value;   // A is exactly bf16: plane 0 alone
         float4 bb = s ? rb1 : rb0;
         float4 o[2] = {s ? ra10 : ra00, s ? ra11 : ra01};
         if (decltype(EDGE)::value && (m_edge || k0 + D3P_GKB > kend)) {
@@ -613,22 +630,31 @@ __global__ void __launch_bounds__(512) k_gemm_bf16x3(GemmArgs g)
             }
         }
         uint32_t w[3];
+        auto top16 = [](float x0, float x1) { return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u); };
         if (AK) {  // one row, four consecutive k's per float4: two words per plane, one 8-byte store
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                uint32_t x[3], y[3];
-                split_pair(o[r].x, o[r].y, x[0], x[1], x[2]);
-                split_pair(o[r].z, o[r].w, y[0], y[1], y[2]);
+                if (A1) {
+                    *reinterpret_cast<uint2*>(&Ap[buf][0][a_m[r]][a_k[r]]) = make_uint2(top16(o[r].x, o[r].y), top16(o[r].z, o[r].w));
+                } else {
+                    uint32_t x[3], y[3];
+                    split_pair(o[r].x, o[r].y, x[0], x[1], x[2]);
+                    split_pair(o[r].z, o[r].w, y[0], y[1], y[2]);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(&Ap[buf][p][a_m[r]][a_k[r]]) = make_uint2(x[p], y[p]);
+                    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(&Ap[buf][p][a_m[r]][a_k[r]]) = make_uint2(x[p], y[p]);
+                }
             }
         } else {   // four rows at k = 2 kp (o[0]) and 2 kp + 1 (o[1]): one word per row and plane
             const float lo4[4] = {o[0].x, o[0].y, o[0].z, o[0].w}, hi4[4] = {o[1].x, o[1].y, o[1].z, o[1].w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                split_pair(lo4[i], hi4[i], w[0], w[1], w[2]);
+                if (A1) {
+                    *reinterpret_cast<uint32_t*>(&Ap[buf][0][a_m[0] + i][a_k[0]]) = top16(lo4[i], hi4[i]);
+                } else {
+                    split_pair(lo4[i], hi4[i], w[0], w[1], w[2]);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint32_t*>(&Ap[buf][p][a_m[0] + i][a_k[0]]) = w[p];
+                    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint32_t*>(&Ap[buf][p][a_m[0] + i][a_k[0]]) = w[p];
+                }
             }
         }
         if (BN) {  // four columns at one k; the lane 8 away holds k ^ 1: the even-k lane takes columns 0, 1, the odd-k lane 2, 3
@@ -655,20 +681,23 @@ __global__ void __launch_bounds__(512) k_gemm_bf16x3(GemmArgs g)
     };
     struct Frag { bf16x8 a[2][3], b[2][3]; };   // [k step of 16][plane]
     const int fr = lane & 31, fh = lane >> 5;
-    auto read_frags = [&](int buf, Frag& f) {
+    auto read_frags = [&](int buf, Frag& f, auto A1P) {
+        constexpr bool A1 = decltype(A1P)::value;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                f.a[ks][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Ap[buf][p][32 * wr + fr][16 * ks + 8 * fh]));
+                if (!A1 || p == 0)
+                    f.a[ks][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Ap[buf][p][32 * wr + fr][16 * ks + 8 * fh]));
                 f.b[ks][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Bp[buf][p][32 * grp + fr][16 * ks + 8 * fh]));
             }
     };
-    auto mma_half = [&](const Frag& f, int ks) {   // smallest terms first
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][2], f.b[ks][0], acc, 0, 0, 0);
+    auto mma_half = [&](const Frag& f, int ks, auto A1P) {   // smallest terms first
+        constexpr bool A1 = decltype(A1P)::value;
+        if (!A1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][2], f.b[ks][0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][1], f.b[ks][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][1], f.b[ks][0], acc, 0, 0, 0);
+        if (!A1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][1], f.b[ks][1], acc, 0, 0, 0);
+        if (!A1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][1], f.b[ks][0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][0], acc, 0, 0, 0);
     };
@@ -677,13 +706,15 @@ __global__ void __launch_bounds__(512) k_gemm_bf16x3(GemmArgs g)
     const int KB = D3P_GKB;
     using EdgeY = std::true_type;
     using EdgeN = std::false_type;
+    auto main_loop = [&](auto A1P) {
+    constexpr bool A1 = decltype(A1P)::value;
     Frag f0, f1;
     fetch(S0{});
     fetch(S1{});
-    stage(S0{}, 0, kbeg, EdgeY{});
+    stage(S0{}, 0, kbeg, EdgeY{}, A1P);
     fetch(S0{});
     __syncthreads();
-    read_frags(0, f0);
+    read_frags(0, f0, A1P);
     const int ns = (kend - kbeg + KB - 1) / KB;
     // one MFMA, then a share of the other work of the same half slice: the bf16 matrix pipe runs beside the vector unit and the LDS,
     // but only what stands BETWEEN two MFMAs in a wave's instruction stream can run beside them
@@ -698,42 +729,59 @@ __global__ void __launch_bounds__(512) k_gemm_bf16x3(GemmArgs g)
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  /* 2 LDS reads */                               \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  /* 1 MFMA */                                    \
     }
+#define D3P_MIX_STAGE_A1()                                                                                  \
+    _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  /* 1 MFMA */                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0); /* 10 VALU (splitting B, packing A) */          \
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);  /* 2 LDS writes */                              \
+    }
+#define D3P_MIX_READ_A1()                                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  /* 3 LDS reads */                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  /* 1 MFMA */                                    \
+    }
     for (int i = 0; i < ns; i += 2) {
         const int k_i = kbeg + i * KB;
         if (!m_edge && k_i + 3 * KB <= kend) {   // both slices staged in this iteration are whole: the branch-free body
-            mma_half(f0, 0);
-            stage(S1{}, 1, k_i + KB, EdgeN{});
-            D3P_MIX_STAGE()
+            mma_half(f0, 0, A1P);
+            stage(S1{}, 1, k_i + KB, EdgeN{}, A1P);
+            if (A1) { D3P_MIX_STAGE_A1() } else { D3P_MIX_STAGE() }
             fetch(S1{});
             __syncthreads();
-            read_frags(1, f1);
-            mma_half(f0, 1);
-            D3P_MIX_READ()
+            read_frags(1, f1, A1P);
+            mma_half(f0, 1, A1P);
+            if (A1) { D3P_MIX_READ_A1() } else { D3P_MIX_READ() }
             __builtin_amdgcn_sched_barrier(0);
-            mma_half(f1, 0);
-            stage(S0{}, 0, k_i + 2 * KB, EdgeN{});
-            D3P_MIX_STAGE()
+            mma_half(f1, 0, A1P);
+            stage(S0{}, 0, k_i + 2 * KB, EdgeN{}, A1P);
+            if (A1) { D3P_MIX_STAGE_A1() } else { D3P_MIX_STAGE() }
             fetch(S0{});
             __syncthreads();
-            read_frags(0, f0);
-            mma_half(f1, 1);
-            D3P_MIX_READ()
+            read_frags(0, f0, A1P);
+            mma_half(f1, 1, A1P);
+            if (A1) { D3P_MIX_READ_A1() } else { D3P_MIX_READ() }
             __builtin_amdgcn_sched_barrier(0);
         } else {
-            mma_half(f0, 0);
-            stage(S1{}, 1, k_i + KB, EdgeY{});
+            mma_half(f0, 0, A1P);
+            stage(S1{}, 1, k_i + KB, EdgeY{}, A1P);
             fetch(S1{});
             __syncthreads();
-            read_frags(1, f1);
-            mma_half(f0, 1);
-            mma_half(f1, 0);
-            stage(S0{}, 0, k_i + 2 * KB, EdgeY{});
+            read_frags(1, f1, A1P);
+            mma_half(f0, 1, A1P);
+            mma_half(f1, 0, A1P);
+            stage(S0{}, 0, k_i + 2 * KB, EdgeY{}, A1P);
             fetch(S0{});
             __syncthreads();
-            read_frags(0, f0);
-            mma_half(f1, 1);
+            read_frags(0, f0, A1P);
+            mma_half(f1, 1, A1P);
         }
     }
+#undef D3P_MIX_STAGE_A1
+#undef D3P_MIX_READ_A1
+    };
+    // (wave-uniform: the flag is one word for the whole product)
+    if (g.a_exact16 && __builtin_amdgcn_readfirstlane((int)*g.a_exact16) != 0) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
 #undef D3P_MIX_STAGE
 #undef D3P_MIX_READ
     const int col = n0 + 32 * grp + (lane & 31);
@@ -772,7 +820,8 @@ __global__ void k_gemm_reduce(GemmArgs g, int splits)
 static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, const float* B, long long b_sk, long long b_sn,
                 float* C, int ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, int a_last_one = 0,
                 float* part = nullptr, size_t part_floats = 0, int epi = 0, float* C2 = nullptr, int* splits_left = nullptr,
-                const GemmJumps* jumps = nullptr, const float* ex_zu = nullptr, const float* ex_eps = nullptr, int ex_Z = 0, float ex_sc = 0.f)
+                const GemmJumps* jumps = nullptr, const float* ex_zu = nullptr, const float* ex_eps = nullptr, int ex_Z = 0, float ex_sc = 0.f,
+                const uint32_t* a_exact16 = nullptr)
 {
     // splits_left != nullptr: a split-K product is NOT reduced here -- the partial tiles stay in `part` ([splits][M][N]) and
     // *splits_left says how many (0: the product went to C as usual); the consumer sums them in fixed order (k_vae_finalize)
@@ -784,6 +833,7 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     g.a_last_one = a_last_one;
     g.epi = epi;
     g.C2 = C2;
+    g.a_exact16 = a_exact16;
     g.ex_zu = ex_zu; g.ex_eps = ex_eps; g.ex_Z = ex_Z; g.ex_sc = ex_sc;
     g.n_seg = jumps ? jumps->n_seg : 0x7fffffff;
     g.k_seg = jumps ? jumps->k_seg : 0x7fffffff;
@@ -1266,6 +1316,7 @@ struct VaeWorkspace {
     float *lat, *px_loss, *x2, *cf, *sums, *noise, *part, *wpart;
     size_t part_floats;
     uint32_t* keys;  // 3 x 16 split + up to 14 x 16 site keys + jax key + step index (D3P_VAE_KEY_*)
+    uint32_t* x_exact16;  // one word: the batch X is exactly bf16 (GemmArgs::a_exact16), set per forward pass
 };
 
 static size_t vae_carve(const d3p_vae_model* m, uint32_t B, char* base, VaeWorkspace* ws)
@@ -1300,6 +1351,7 @@ static size_t vae_carve(const d3p_vae_model* m, uint32_t B, char* base, VaeWorks
     const size_t pf = 16 * (D + 1) * (size_t)m->H;  // split-K partial tiles: up to 16 splits of the largest weight matrix
     q = take(pf); if (ws) { ws->part = q; ws->part_floats = pf; }
     q = take((size_t)D3P_WPART_SPLITS * P); if (ws) ws->wpart = q;  // unreduced weight-gradient tiles
+    q = take(64); if (ws) ws->x_exact16 = (uint32_t*)q;
     return off;
 }
 
@@ -1321,13 +1373,24 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
     const VaeNet N = vae_net(m);
     const int D = N.D, Z = N.Z, HE = N.HE, nh = N.nh, Bi = (int)B;
     const dim3 rows(cdiv((uint64_t)B * 64, 256));
+    // Is the batch exactly bf16 (binarised images, examples/vae.py:157-168)?  One pass over X (13 MB) decides for the two products
+    // that take X as their A operand -- the first encoder layer and its weight gradient: they then stage one plane of A instead
+    // of splitting it into three and issue three of the six products (GemmArgs::a_exact16).  Any other batch takes the general path.
+    const uint32_t* xflag = nullptr;
+    static const bool no_exact = getenv("D3P_VAE_NO_EXACT16") != nullptr;   // developer switch (A/B), read once
+    if (!no_exact && ((size_t)B * D) % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0) {
+        D3P_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ws.x_exact16, 1, 1, s));
+        const size_t n4 = (size_t)B * D / 4;
+        hipLaunchKernelGGL(k_exact16_flag, dim3((unsigned)(n4 / 1024 < 1 ? 1 : (n4 / 1024 > 1024 ? 1024 : n4 / 1024))), dim3(256), 0, s, X, n4, ws.x_exact16);
+        xflag = ws.x_exact16;
+    }
     // ---- encoder (guide)
     {
         const float* in = X;
         for (int l = 0; l < nh; ++l) {
             const VaeDense& e = N.enc[l];
             if ((rc = gemm(s, in, e.in, 1, params + e.W, e.out, 1, ws.he[l], e.out, Bi, e.out, e.in, params + e.b, 1.f, 0, 0, ws.part, ws.part_floats, 1,
-                           ws.sge[l])))
+                           ws.sge[l], nullptr, nullptr, nullptr, nullptr, 0, 0.f, l == 0 ? xflag : nullptr)))
                 return rc;
             in = ws.he[l];
         }
@@ -1453,8 +1516,11 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
         float* part = w_splits ? ws.wpart + (size_t)D3P_WPART_SPLITS * wg[b].off : ws.part;
         const size_t part_floats = w_splits ? (size_t)D3P_WPART_SPLITS * (wg[b].in + 1) * wg[b].out : ws.part_floats;
         int left = 0;
+        // (A = X^T: the flag of the forward pass holds -- same batch; the virtual row of ones is exact too)
+        static const bool no_exact = getenv("D3P_VAE_NO_EXACT16") != nullptr;
+        const uint32_t* xflag = (wg[b].A == X && !no_exact && ((size_t)B * D) % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0) ? ws.x_exact16 : nullptr;
         if ((rc = gemm(s, wg[b].A, 1, wg[b].a_sk, wg[b].Bm, wg[b].ldb, 1, S + wg[b].off, wg[b].ldc, wg[b].in + 1, wg[b].out, Bi, nullptr, 1.f, 0, 1,
-                       part, part_floats, 0, nullptr, w_splits ? &left : nullptr, wg[b].j)))
+                       part, part_floats, 0, nullptr, w_splits ? &left : nullptr, wg[b].j, nullptr, nullptr, 0, 0.f, xflag)))
             return rc;
         if (w_splits) {
             w_splits[wg[b].blk] = left;

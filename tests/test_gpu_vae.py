@@ -157,6 +157,35 @@ def test_step_sums_vs_explicit_per_example_gradients(lib, O, B, D, H, Z, pscale,
     assert (enorms > clip).any() and (enorms[enorms > 0] < clip).any()
 
 
+@pytest.mark.parametrize("grey", [False, True])
+def test_step_sums_on_the_bf16_pipe_with_binarised_and_grey_batches(lib, O, grey):
+    """B = 136 puts the first encoder product and its weight gradient on k_gemm_bf16x3 (M > 96).  A BINARISED batch
+    (examples/vae.py:157-168) is exactly bf16: the one-plane path of those two products (k_exact16_flag -> GemmArgs::a_exact16:
+    plane 0 of A alone, three of the six bf16 products).  A GREY batch (pixel intensities in [0, 1], what the data holds before
+    binarize) is not: the flag kernel must say so and the general three-plane path runs.  Both against the oracle's explicit
+    per-example gradients, same tolerances as the small shapes."""
+    B, D, H, Z = 136, 784, 400, 50
+    spec, P, params, X, eps = vae_problem(B, D, H, Z, 99, 0.03, 0)
+    if grey:
+        X = np.random.default_rng(5).random((B, D)).astype(np.float32)
+        assert (X.view(np.uint32) & 0xffff).any()
+    _, norms0, _ = O.vae_step_sums(spec, params, X, eps, 1e30, None)
+    clip = float(np.median(norms0))
+    esums, enorms, eloss = O.vae_step_sums(spec, params, X, eps, clip, None)
+    L = lib.load()
+    model = lib.VaeModel(D, H, Z, 1.0, 1.0, 0)
+    ws = torch.empty(int(L.d3p_dpvi_vae_workspace(C.byref(model), B)), dtype=torch.uint8, device="cuda")
+    sums, norms, pxl = torch.empty(P + 2, device="cuda"), torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    pt, Xt, et = torch.tensor(params).cuda(), torch.tensor(X).cuda(), torch.tensor(eps).cuda()
+    lib.check(L.d3p_vae_step_sums(lib.stream_ptr(), C.byref(model), lib.ptr(pt), lib.ptr(Xt), None, B, lib.ptr(et), None,
+                                  clip, lib.ptr(sums), lib.ptr(norms), lib.ptr(pxl), lib.ptr(ws), ws.numel()))
+    np.testing.assert_allclose(np_(norms), enorms, rtol=5e-5)
+    np.testing.assert_allclose(np_(pxl), eloss, rtol=2e-5, atol=1e-5)
+    got = np_(sums)
+    assert got[P + 1] == esums[P + 1] and abs(got[P] - esums[P]) <= 2e-5 * abs(esums[P])
+    np.testing.assert_allclose(got[:P], esums[:P], rtol=2e-4, atol=2e-5 * np.abs(esums[:P]).max())
+
+
 def make_svi(Z, H, N, C=10.0, sigma=1.0, lr=1e-3, H2=0):
     from d3p_amd.models import Adam, Trace_ELBO, VAEGuide, VAEModel
     from d3p_amd.svi import DPSVI
