@@ -3,7 +3,7 @@
 # usage: PROFILE_TAG=r03 bash tools/profile_round.sh    (outputs under gpurun_out/$PROFILE_TAG; copy what is judged to profiles/)
 set -ex
 R=$(cd "$(dirname "$0")/.." && pwd)
-T=${PROFILE_TAG:-r03}
+T=${PROFILE_TAG:-r04}
 O=$R/gpurun_out/$T
 COMMIT=${PROFILE_COMMIT:-unknown}
 rm -rf $O; mkdir -p $O
