@@ -63,17 +63,20 @@ struct GemmArgs {
     // plane of A are then exactly zero: the kernel stages plane 0 alone (no splitting of A) and issues the three products with a_0
     // (of six); the sums are those of the general path (the dropped products are exact zeros, the others come in the same order).
     const uint32_t* a_exact16;
+    uint32_t a_exact_nonce;   // A is exact iff *a_exact16 != a_exact_nonce: the checking pass stores the nonce of ITS pass when it finds an
+                              // inexact element, so the word needs no reset between passes (whatever it held before, a stale match can
+                              // only send an exact batch down the general path)
 };
 
 // the flag of GemmArgs::a_exact16 for an array of n floats (n a multiple of 4, 16-byte aligned): 1 unless some element has low bits
-__global__ void __launch_bounds__(256) k_exact16_flag(const float* __restrict__ x, size_t n4, uint32_t* __restrict__ flag)
+__global__ void __launch_bounds__(256) k_exact16_flag(const float* __restrict__ x, size_t n4, uint32_t* __restrict__ flag, uint32_t nonce)
 {
     uint32_t bad = 0u;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const uint4 v = reinterpret_cast<const uint4*>(x)[i];
         bad |= (v.x | v.y | v.z | v.w) & 0xffffu;
     }
-    if (__ballot(bad != 0u) != 0ull && (threadIdx.x & 63) == 0) *flag = 0u;   // (every writer writes the same value)
+    if (__ballot(bad != 0u) != 0ull && (threadIdx.x & 63) == 0) *flag = nonce;   // (every writer writes the same value)
 }
 
 // o = alpha * acc + bias (+ C); then the epilogue
@@ -780,7 +783,7 @@ __global__ void __launch_bounds__(512) k_gemm_bf16x3(GemmArgs g)
 #undef D3P_MIX_READ_A1
     };
     // (wave-uniform: the flag is one word for the whole product)
-    if (g.a_exact16 && __builtin_amdgcn_readfirstlane((int)*g.a_exact16) != 0) main_loop(std::true_type{});
+    if (g.a_exact16 && (uint32_t)__builtin_amdgcn_readfirstlane((int)*g.a_exact16) != g.a_exact_nonce) main_loop(std::true_type{});
     else main_loop(std::false_type{});
 #undef D3P_MIX_STAGE
 #undef D3P_MIX_READ
@@ -821,7 +824,7 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
                 float* C, int ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, int a_last_one = 0,
                 float* part = nullptr, size_t part_floats = 0, int epi = 0, float* C2 = nullptr, int* splits_left = nullptr,
                 const GemmJumps* jumps = nullptr, const float* ex_zu = nullptr, const float* ex_eps = nullptr, int ex_Z = 0, float ex_sc = 0.f,
-                const uint32_t* a_exact16 = nullptr)
+                const uint32_t* a_exact16 = nullptr, uint32_t a_exact_nonce = 0u)
 {
     // splits_left != nullptr: a split-K product is NOT reduced here -- the partial tiles stay in `part` ([splits][M][N]) and
     // *splits_left says how many (0: the product went to C as usual); the consumer sums them in fixed order (k_vae_finalize)
@@ -834,6 +837,7 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     g.epi = epi;
     g.C2 = C2;
     g.a_exact16 = a_exact16;
+    g.a_exact_nonce = a_exact_nonce;
     g.ex_zu = ex_zu; g.ex_eps = ex_eps; g.ex_Z = ex_Z; g.ex_sc = ex_sc;
     g.n_seg = jumps ? jumps->n_seg : 0x7fffffff;
     g.k_seg = jumps ? jumps->k_seg : 0x7fffffff;
@@ -1365,6 +1369,15 @@ static int vae_validate(const d3p_vae_model* m, const char* what)
 
 // forward pass: activations, the reparametrised latent, da = sc (sigmoid(a) - x) and px_loss[i] = sc (log q - log p - log lik)
 // eps != nullptr: given noise; otherwise drawn from jax_key inside k_vae_latent into ws.eps
+// the nonce of the current exactness pass over the batch (per host thread: a forward pass and the weight-gradient products that
+// follow it are enqueued by one thread, back to back)
+static uint32_t vae_exact_nonce(bool advance)
+{
+    static thread_local uint32_t nonce = 0x5eed0000u;
+    if (advance) ++nonce;
+    return nonce;
+}
+
 static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const float* params, const float* X, const uint8_t* mask,
                                uint32_t B, const float* eps, float sc, const VaeWorkspace& ws, const uint32_t* jax_key = nullptr,
                                uint32_t B_total = 0, uint32_t pos0 = 0)
@@ -1379,9 +1392,10 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
     const uint32_t* xflag = nullptr;
     static const bool no_exact = getenv("D3P_VAE_NO_EXACT16") != nullptr;   // developer switch (A/B), read once
     if (!no_exact && ((size_t)B * D) % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0) {
-        D3P_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ws.x_exact16, 1, 1, s));
         const size_t n4 = (size_t)B * D / 4;
-        hipLaunchKernelGGL(k_exact16_flag, dim3((unsigned)(n4 / 1024 < 1 ? 1 : (n4 / 1024 > 1024 ? 1024 : n4 / 1024))), dim3(256), 0, s, X, n4, ws.x_exact16);
+        const uint32_t nonce = vae_exact_nonce(true);   // a new nonce per pass: the flag word is never reset
+        hipLaunchKernelGGL(k_exact16_flag, dim3((unsigned)(n4 / 1024 < 1 ? 1 : (n4 / 1024 > 1024 ? 1024 : n4 / 1024))), dim3(256), 0, s, X, n4, ws.x_exact16,
+                           nonce);
         xflag = ws.x_exact16;
     }
     // ---- encoder (guide)
@@ -1390,7 +1404,7 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
         for (int l = 0; l < nh; ++l) {
             const VaeDense& e = N.enc[l];
             if ((rc = gemm(s, in, e.in, 1, params + e.W, e.out, 1, ws.he[l], e.out, Bi, e.out, e.in, params + e.b, 1.f, 0, 0, ws.part, ws.part_floats, 1,
-                           ws.sge[l], nullptr, nullptr, nullptr, nullptr, 0, 0.f, l == 0 ? xflag : nullptr)))
+                           ws.sge[l], nullptr, nullptr, nullptr, nullptr, 0, 0.f, l == 0 ? xflag : nullptr, vae_exact_nonce(false))))
                 return rc;
             in = ws.he[l];
         }
@@ -1520,7 +1534,7 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
         static const bool no_exact = getenv("D3P_VAE_NO_EXACT16") != nullptr;
         const uint32_t* xflag = (wg[b].A == X && !no_exact && ((size_t)B * D) % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0) ? ws.x_exact16 : nullptr;
         if ((rc = gemm(s, wg[b].A, 1, wg[b].a_sk, wg[b].Bm, wg[b].ldb, 1, S + wg[b].off, wg[b].ldc, wg[b].in + 1, wg[b].out, Bi, nullptr, 1.f, 0, 1,
-                       part, part_floats, 0, nullptr, w_splits ? &left : nullptr, wg[b].j, nullptr, nullptr, 0, 0.f, xflag)))
+                       part, part_floats, 0, nullptr, w_splits ? &left : nullptr, wg[b].j, nullptr, nullptr, 0, 0.f, xflag, vae_exact_nonce(false))))
             return rc;
         if (w_splits) {
             w_splits[wg[b].blk] = left;
