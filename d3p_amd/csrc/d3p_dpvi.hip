@@ -961,7 +961,8 @@ static int enqueue_sched_finish(const Ctx& c, int steps_done)
 // ------------------------------------------------------------------------------------------
 struct KernelTiming {
     bool on = false;
-    std::vector<hipEvent_t> ev;  // start, stop, start, stop, ...
+    std::vector<hipEvent_t> ev;    // start, stop, start, stop, ... of the launches timed so far
+    std::vector<hipEvent_t> pool;  // created when timing is switched on: event creation stays off the enqueue path of the timed runs
     uint32_t steps = 0;
 };
 static KernelTiming g_kt;
@@ -972,7 +973,10 @@ static void timing_pair(int steps, hipEvent_t* e0, hipEvent_t* e1)
     *e0 = *e1 = nullptr;
     if (!g_kt.on) return;
     hipEvent_t a = nullptr, b = nullptr;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+    if (g_kt.pool.size() >= 2) {
+        a = g_kt.pool.back(); g_kt.pool.pop_back();
+        b = g_kt.pool.back(); g_kt.pool.pop_back();
+    } else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
         if (a) (void)hipEventDestroy(a);
         (void)hipGetLastError();
         return;
@@ -2413,6 +2417,13 @@ int d3p_dpvi_logreg_set_run_form(int form)
 int d3p_dpvi_logreg_kernel_timing_enable(int enable)
 {
     g_kt.on = enable != 0;
+    if (g_kt.on) {  // a pool of events for the launches to come (64 pairs; more are created as needed)
+        while (g_kt.pool.size() < 128) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); break; }
+            g_kt.pool.push_back(e);
+        }
+    }
     return D3P_OK;
 }
 

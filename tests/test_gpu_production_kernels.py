@@ -148,18 +148,22 @@ def test_chain_kernel_poisson_batches_vs_oracle_across_a_launch_boundary(gpu, O)
     _compare(new_st, losses, ost, el, steps)
 
 
-def test_chain_kernel_exchange_on_one_rank_vs_oracle_across_a_launch_boundary(gpu, O):
-    """(iv, first half) the XCHG instantiation (two exchange workgroups per step inside the chained launch) with a world of one
-    rank -- the exchange is with the rank's own inbox, every protocol step runs -- 140 steps at B = 4096."""
+@pytest.mark.parametrize("icpt", [False, True])
+def test_chain_kernel_exchange_on_one_rank_vs_oracle_across_a_launch_boundary(gpu, O, icpt):
+    """(iv, first half) the XCHG instantiation -- since round 4 the 16-wave UPDATER form: the last arrivers of the 8 arrival groups
+    fold the sums, run the exchange, apply noise + Adam once and publish the state as tagged words the next step polls -- with a
+    world of one rank, 140 steps at B = 4096 (across the launch boundary: nothing is pending between launches in this form), without
+    and with the intercept column (D = 513: 1030 accumulator columns, the odd latent layout)."""
     import d3p_amd._lib as L
     import d3p_amd.random as rng
     from d3p_amd import dist as ddist
     N, d, B, steps, first = 100_000, 512, 4096, 140, 2
+    D = d + int(icpt)
     X, y = _table(N, d, 14)
-    svi = _svi(d, False, N)
-    st = _state(svi, rng.PRNGKey(9), d, N)
+    svi = _svi(d, icpt, N)
+    st = _state(svi, rng.PRNGKey(9), D, N)
     eng = ddist.FusedHipEngine(svi, X.cuda(), y.cuda(), N, 0, N, L.D3P_BATCH_FEISTEL, B)
-    comm = ddist.XchgComm(2 * d + 4)
+    comm = ddist.XchgComm(2 * D + 4)
     try:
         new_st, losses = ddist.run_steps_native(eng, st, rng.PRNGKey(10), first, steps, comm=comm)
         torch.cuda.synchronize()
@@ -168,10 +172,16 @@ def test_chain_kernel_exchange_on_one_rank_vs_oracle_across_a_launch_boundary(gp
         comm.close()
     assert code == 0, L.describe_abort(code)
 
-    spec = O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    spec = O.logreg_spec(d, icpt, 1.0, 2.0, lik_scale=N, obs_scale=N)
     hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
-    ost = _oracle_state(O, 9, d)
-    el = _oracle_losses_feistel(O, spec, hy, ost, X.numpy(), y.numpy(), O.PRNGKey(10), first, B, steps)
+    ost = _oracle_state(O, 9, D)
+    if icpt:
+        el, Xn, yn = [], X.numpy(), y.numpy()
+        for t in range(steps):
+            idx = O.feistel_sample(O.fold_in(O.PRNGKey(10), first + t), N, B)
+            el.append(O.logreg_update(spec, hy, ost, Xn[idx], yn[idx])[0])
+    else:
+        el = _oracle_losses_feistel(O, spec, hy, ost, X.numpy(), y.numpy(), O.PRNGKey(10), first, B, steps)
     _compare(new_st, losses, ost, el, steps)
 
 
