@@ -636,7 +636,10 @@ def main():
         if single and rank == 0 and extra_legs and not args.no_aux_workloads:
             aux.update(aux_workloads(dev, None, want=("gmm", "vae", "vae2")))
         if world > 1 and extra_legs and not args.no_aux_workloads and not aux:   # configs[4] at N > 1 (every rank takes part)
-            aux.update(vae_dist_workload(dev, world, rank, barrier, share_gpu))
+            try:
+                aux.update(vae_dist_workload(dev, world, rank, barrier, share_gpu))
+            except Exception as e:  # noqa: BLE001 -- an auxiliary leg must not cost the headline line
+                aux["vae_config5_dp_error"] = f"{type(e).__name__}: {e}"
         if rank != 0:
             return None
         B_done = Bg // emu if emu else Bg   # (--emulate-world runs ONE rank's share: the examples this GPU processed, not the job's)
