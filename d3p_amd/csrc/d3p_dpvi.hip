@@ -49,6 +49,7 @@ struct Workspace {
     uint32_t* xflags;      // in-launch exchange of a data-parallel run: D3P_STEP_BATCH x D3P_XCHG_WGS flags, 128 bytes apart
     long long* xsum;       // ... and the world's sums of step g in row g % 3 (3 x cols)
     unsigned long long* ll_state;  // data-parallel updater form: the optimiser state as tagged words -- parameters 2 x cols, m cols, v cols
+    unsigned long long* own_mask;  // row-sharded Feistel batches: per step ceil(B / 64) ballot words "this rank holds the row of position p"
     uint32_t* pshard;      // sharded Poisson selection: [D3P_STEP_BATCH] the shard's selected counts | [D3P_STEP_BATCH] selected in the shards above
     float* partials;  // max_blocks x (P + 2)
     unsigned long long* stamps;  // 2 x max_blocks
@@ -78,6 +79,7 @@ static size_t carve(const d3p_logreg_model* m, const d3p_batch_source* src, char
     p = take(3 * (size_t)D3P_ACC_COLS(P) * sizeof(long long)); if (ws) ws->xsum = (long long*)p;
     p = take(4 * (size_t)D3P_ACC_COLS(P) * sizeof(unsigned long long)); if (ws) ws->ll_state = (unsigned long long*)p;
     p = take(2 * (size_t)D3P_STEP_BATCH * sizeof(uint32_t)); if (ws) ws->pshard = (uint32_t*)p;
+    p = take(K * ((B + 63) / 64) * sizeof(unsigned long long)); if (ws) ws->own_mask = (unsigned long long*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * (P + 2) * sizeof(float)); if (ws) ws->partials = (float*)p;
     p = take((size_t)D3P_MAIN_MAX_BLOCKS * 4 * sizeof(unsigned long long)); if (ws) ws->stamps = (unsigned long long*)p;  // >= 2 x 256 x 16 phase stamps
     size_t pb = 0;
@@ -369,6 +371,7 @@ struct SamplerArgs {
     int D;
     float b1, b2;
     uint64_t row_lo, row_hi;  // rows held by this rank: sample keys are only needed for those
+    unsigned long long* own_mask;  // nullable: per step ceil(B / 64) words, bit l of word w = "position 64 w + l is this rank's" (k_owned_pack)
 };
 
 // The sampler work of x-block bx (of gx) for step t of the batch.
@@ -423,6 +426,10 @@ __device__ __forceinline__ void sampler_block(const SamplerArgs& a, int bx, int 
                 px_sample_key(sh_jax[0], sh_jax[1], a.B, p, s0, s1);
                 a.skeys[((size_t)t * a.B + p) * 2] = s0;
                 a.skeys[((size_t)t * a.B + p) * 2 + 1] = s1;
+            }
+            if (a.own_mask) {  // (the wave's positions 64 w .. 64 w + 63: lanes beyond B are not active and read as 0)
+                const unsigned long long bal = __ballot(owned);
+                if ((tid & 63) == 0) a.own_mask[(size_t)t * ((a.B + 63) / 64) + (p >> 6)] = bal;
             }
         }
         return;
@@ -534,6 +541,48 @@ k_owned_list(StepSlot* __restrict__ slots, const uint32_t* __restrict__ idx, uin
         }
         __syncthreads();
         if (threadIdx.x == 0) base_s = cnt[512];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) slots[t].n_owned = base_s;
+}
+
+// The same list from the sampler's ballot words (row-sharded Feistel batches: every position of the padded batch is valid): thread w
+// takes word w -- an exclusive scan of the popcounts gives its offset, the set bits its positions, ascending.  One workgroup per
+// step, B / 64 threads' worth of work: 3 us where k_owned_list's 32 rounds over the B indices took 17 (a short run's start-up).
+__global__ void __launch_bounds__(1024)
+k_owned_pack(StepSlot* __restrict__ slots, const unsigned long long* __restrict__ own_mask, uint32_t B, uint32_t* __restrict__ plist)
+{
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t base_s;
+    const int t = blockIdx.y;
+    const uint32_t nwords = (B + 63u) / 64u;
+    const unsigned long long* mk = own_mask + (size_t)t * nwords;
+    uint32_t* out = plist + (size_t)t * B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0u;
+    __syncthreads();
+    for (uint32_t w0 = 0; w0 < nwords; w0 += 1024u) {
+        const uint32_t w = w0 + threadIdx.x;
+        const unsigned long long m = w < nwords ? mk[w] : 0ull;
+        const uint32_t c = (uint32_t)__popcll(m);
+        uint32_t inc = c;   // inclusive prefix over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        uint32_t before = base_s + inc - c;
+        for (int v = 0; v < wave; ++v) before += wave_tot[v];
+        unsigned long long r = m;
+        while (r) {
+            const int b = __builtin_ctzll(r);
+            out[before++] = 64u * w + (uint32_t)b;
+            r &= r - 1ull;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) base_s = before;   // (the last thread's end = everything so far)
         __syncthreads();
     }
     if (threadIdx.x == 0) slots[t].n_owned = base_s;
@@ -822,6 +871,7 @@ static void fill_sampler_args(const Ctx& c, SamplerArgs* out)
     sa.b2 = c.h->b2;
     sa.row_lo = c.src->kind == D3P_BATCH_EXPLICIT ? 0 : c.src->row_lo;
     sa.row_hi = c.src->kind == D3P_BATCH_EXPLICIT ? ~0ull : c.src->row_hi;
+    sa.own_mask = (c.src->kind == D3P_BATCH_FEISTEL && need_owned_list(c.src)) ? c.ws.own_mask : nullptr;
 }
 
 static int enqueue_sampler(const Ctx& c, int K, Xchg* xchg)
@@ -856,7 +906,10 @@ static int enqueue_sampler(const Ctx& c, int K, Xchg* xchg)
                                       c.ws.poisson_ws, c.ws.poisson_bytes);
         if (rc) return rc;
     }
-    if (need_owned_list(c.src)) {
+    if (need_owned_list(c.src) && c.src->kind == D3P_BATCH_FEISTEL) {  // from the sampler's ballot words (every padded position is valid)
+        hipLaunchKernelGGL(k_owned_pack, dim3(1, K), dim3(1024), 0, c.s, c.ws.slots, (const unsigned long long*)c.ws.own_mask, c.src->B, c.ws.plist);
+        if ((rc = check_launch("k_owned_pack"))) return rc;
+    } else if (need_owned_list(c.src)) {
         hipLaunchKernelGGL(k_owned_list, dim3(1, K), dim3(1024), 0, c.s, c.ws.slots, (const uint32_t*)c.ws.idx, c.src->B,
                            (uint64_t)c.src->row_lo, (uint64_t)c.src->row_hi, c.ws.plist);
         if ((rc = check_launch("k_owned_list"))) return rc;
