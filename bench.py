@@ -466,7 +466,10 @@ def main():
                 _, get_batch = subsample_batchify_data((X, y), Bg)
 
             def run(st, first, k):
-                return svi.run_steps(st, get_batch, bkey, first, k)   # (raises if the chained launch was aborted)
+                # (the run's status is read AFTER the timed region, like the data-parallel legs do: timed_leg; should a chained launch
+                # ever be stopped there, the leg is taken again with run_steps' own check, which re-runs a stopped run launch by launch)
+                return svi.run_steps(st, get_batch, bkey, first, k, check_status=run.safe)
+            run.svi, run.safe = svi, False
         else:
             engine_cls = ddist.HipEngine if os.environ.get("D3P_DIST_TWO_PHASE") else ddist.FusedHipEngine
             if args.sampler == "poisson":   # q = B / N, padded to the 0.99 quantile of Poisson(B) (examples/logistic_regression.py:126-127)
@@ -485,6 +488,7 @@ def main():
     def timed_leg(run, state, first, warm, steps):
         """warm-up, barrier, `steps` timed steps bracketed by barriers (max over ranks), HIP-event kernel timing."""
         barrier()   # (the ranks enter the warm-up together: its exchanges wait for every peer, with a bound)
+        state0_of_leg = state
         state, _ = run(state, first, warm)
         barrier()
         L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(1))
@@ -494,8 +498,16 @@ def main():
         elapsed = time.perf_counter() - t0
         L.check(lib.d3p_dpvi_logreg_kernel_timing_enable(0))
         kt = read_kernel_timing()
+        one = getattr(run, "svi", None)
+        if one is not None and not run.safe:   # single rank: a stopped run must not become a number
+            aborted, _ = one.last_run_status()
+            if aborted:
+                print("[bench] the chained launch was stopped by a bounded wait (" + one.last_abort_code() + "); taking the leg again "
+                      "with DPSVI.run_steps' status check and launch-by-launch fallback", file=sys.stderr, flush=True)
+                run.safe = True
+                return timed_leg(run, state0_of_leg, first, warm, steps)
         eng = getattr(run, "native_engine", None)
-        if eng is not None:  # (the single-rank run_steps raises by itself) a stopped run must not become a number
+        if eng is not None:  # a stopped run must not become a number
             code, _ = ddist.native_run_status(eng)
             if code:
                 raise RunStopped(f"rank {rank}: the data-parallel run was stopped by a bounded wait -- {L.describe_abort(code)}")

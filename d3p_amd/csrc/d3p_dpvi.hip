@@ -372,6 +372,8 @@ struct SamplerArgs {
     float b1, b2;
     uint64_t row_lo, row_hi;  // rows held by this rank: sample keys are only needed for those
     unsigned long long* own_mask;  // nullable: per step ceil(B / 64) words, bit l of word w = "position 64 w + l is this rank's" (k_owned_pack)
+    int ppt;                  // batch positions per thread (1, or 4 for the large padded batches of a row-sharded rank: the per-step prefix --
+                              // two dependent ChaCha blocks -- is then made by a quarter of the blocks)
 };
 
 // The sampler work of x-block bx (of gx) for step t of the batch.
@@ -413,7 +415,8 @@ __device__ __forceinline__ void sampler_block(const SamplerArgs& a, int bx, int 
             }
         }
         __syncthreads();
-        const uint32_t p = (uint32_t)bx * blockDim.x + tid;
+        for (int j = 0; j < a.ppt; ++j) {
+        const uint32_t p = ((uint32_t)bx * (uint32_t)a.ppt + (uint32_t)j) * blockDim.x + tid;
         if (p < a.B) {
             bool owned = true;
             if (a.kind == D3P_BATCH_FEISTEL) {
@@ -431,6 +434,7 @@ __device__ __forceinline__ void sampler_block(const SamplerArgs& a, int bx, int 
                 const unsigned long long bal = __ballot(owned);
                 if ((tid & 63) == 0) a.own_mask[(size_t)t * ((a.B + 63) / 64) + (p >> 6)] = bal;
             }
+        }
         }
         return;
     }
@@ -872,13 +876,16 @@ static void fill_sampler_args(const Ctx& c, SamplerArgs* out)
     sa.row_lo = c.src->kind == D3P_BATCH_EXPLICIT ? 0 : c.src->row_lo;
     sa.row_hi = c.src->kind == D3P_BATCH_EXPLICIT ? ~0ull : c.src->row_hi;
     sa.own_mask = (c.src->kind == D3P_BATCH_FEISTEL && need_owned_list(c.src)) ? c.ws.own_mask : nullptr;
+    // (a rank of a row-sharded job derives sample keys for its own ~ B / world positions only: four positions per thread cost little
+    // and the step's prefix is made by a quarter of the blocks -- 22 -> ~ 12 us for 20 steps at B = 32768)
+    sa.ppt = (need_owned_list(c.src) && c.src->kind == D3P_BATCH_FEISTEL && c.src->B >= 16384u) ? 4 : 1;
 }
 
 static int enqueue_sampler(const Ctx& c, int K, Xchg* xchg)
 {
     SamplerArgs sa;
     fill_sampler_args(c, &sa);
-    hipLaunchKernelGGL(k_sampler, dim3(cdiv(c.src->B, 256) + 1, K), dim3(256), 0, c.s, sa);
+    hipLaunchKernelGGL(k_sampler, dim3(cdiv(c.src->B, 256u * (uint32_t)sa.ppt) + 1, K), dim3(256), 0, c.s, sa);
     int rc = check_launch("k_sampler");
     if (rc) return rc;
     static const bool full_mask = getenv("D3P_POISSON_FULL_MASK") != nullptr;   // developer switch: every rank makes the whole mask (round 3)
