@@ -217,6 +217,7 @@ SIGNATURES = {
     "d3p_dpvi_logreg_run_dist_from": (C.c_int, [_V, _V, _V, _PM, _PH, _PS, _PS, _PB, _U32, _V, _V, _U32, _V, _V, _SZ]),
     "d3p_dpvi_logreg_time_main_kernel": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _V, _SZ, C.c_int,
                                                    C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "d3p_selftest_wave_sums": (C.c_int, [_V, _V, _U32, _V]),
     "d3p_synth_logreg": (C.c_int, [_V, _U32, _U64, _U64, _I32, _V, _V]),
 }
 

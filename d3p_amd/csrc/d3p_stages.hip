@@ -626,6 +626,43 @@ int d3p_gmm_log_prob(void* stream, const float* x_dev, uint32_t B, int32_t d, co
     return check_launch("d3p_gmm_log_prob");
 }
 
+// Self-test of the cross-lane sums every step kernel is built on (d3p_device.h: wave_sum, wave_sum2 -- DPP adds issued from inline
+// assembly, whose hazards the compiler cannot see): one wave per 64 inputs; the sums are taken directly behind a DIVERGENT
+// branch (odd lanes do extra dependent arithmetic first, then all lanes reconverge), the situation in which an EXEC write sits
+// closest in front of the DPP block.  out[3 w + {0, 1, 2}] = wave_sum(x), and the two sums of wave_sum2(x, 2 x).
+__global__ void __launch_bounds__(256) k_selftest_wave_sums(const float* __restrict__ in, uint32_t n_waves, float* __restrict__ out)
+{
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= n_waves) return;
+    float x = in[(size_t)w * 64 + lane];
+    if (lane & 1) {   // divergent: a few dependent operations on half of the lanes, then undone exactly
+        float t = x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t = t * 2.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t = t * 0.5f;
+        x = t;
+    }
+    const float s = wave_sum(x);
+    float sa, sb;
+    if (lane & 2) x = x + 0.0f;   // (a second divergent region directly in front of wave_sum2)
+    wave_sum2(x, 2.0f * x, sa, sb);
+    if (lane == 0) {
+        out[3 * (size_t)w] = s;
+        out[3 * (size_t)w + 1] = sa;
+        out[3 * (size_t)w + 2] = sb;
+    }
+}
+
+int d3p_selftest_wave_sums(void* stream, const float* in_dev, uint32_t n_waves, float* out_dev)
+{
+    D3P_REQUIRE(in_dev && out_dev, "d3p_selftest_wave_sums: null pointer");
+    if (n_waves == 0) return D3P_OK;
+    hipLaunchKernelGGL(k_selftest_wave_sums, dim3(cdiv((uint64_t)n_waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, in_dev, n_waves, out_dev);
+    return check_launch("d3p_selftest_wave_sums");
+}
+
 int d3p_synth_logreg(void* stream, uint32_t seed, uint64_t row0, uint64_t n_rows, int32_t d, float* X_dev,
                      float* y_dev)
 {

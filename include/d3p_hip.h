@@ -620,6 +620,11 @@ int d3p_dpvi_vae_apply(void* stream, const d3p_vae_model* model, const d3p_dpsvi
                        const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
                        void* workspace_dev, size_t workspace_bytes);
 
+/* Self-test of the wave-level sums the step kernels are built on (wave_sum / wave_sum2: DPP adds from inline assembly), taken
+ * directly behind divergent branches: in_dev holds 64 floats per wave, out_dev[3 w + {0, 1, 2}] = the sum of wave w's inputs by
+ * wave_sum, and the sums of x and 2 x by wave_sum2.  No reference counterpart (jnp.sum); tests/test_gpu_rng.py.  ABI 7. */
+int d3p_selftest_wave_sums(void* stream, const float* in_dev, uint32_t n_waves, float* out_dev);
+
 /* Synthetic workload of SURVEY 8(d) / examples/logistic_regression.py:88-104, generated on device:
  * X[r][c] and y[r] are pure functions of (seed, global row, column). */
 int d3p_synth_logreg(void* stream, uint32_t seed, uint64_t row0, uint64_t n_rows, int32_t d,

@@ -180,3 +180,23 @@ def test_debug_randint(gpu, O):
     assert x.min() == 0 and x.max() == 9 and scipy.stats.chisquare(np.bincount(x, minlength=10)).pvalue > 0.01
     with pytest.raises(TypeError):
         dbg.randint(key, (3,), 0, 5, dtype=torch.float32)
+
+
+def test_wave_sums_behind_divergent_branches(rng):
+    """wave_sum / wave_sum2 (d3p_device.h) issue their last DPP steps from inline assembly, where the compiler's hazard recognizer
+    does not look (advisor finding, round 3): the sums of 64 lanes taken directly behind divergent branches must still be the sums --
+    against float64, at fp32 rounding of a 64-term sum, for values of mixed sign and magnitude."""
+    import d3p_amd._lib as L
+    from d3p_amd._lib import check, ptr, stream_ptr
+    lib = L.load()
+    n = 4096
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(n, 64, generator=g) * torch.logspace(-3, 3, 64)[torch.randperm(64, generator=g)]).cuda()
+    out = torch.empty(3 * n, device="cuda")
+    check(lib.d3p_selftest_wave_sums(stream_ptr(), ptr(x), n, ptr(out)))
+    got = out.cpu().double().reshape(n, 3)
+    ref = x.cpu().double().sum(dim=1)
+    scale = x.cpu().double().abs().sum(dim=1)
+    assert float(((got[:, 0] - ref).abs() / scale).max()) < 4e-6
+    assert float(((got[:, 1] - ref).abs() / scale).max()) < 4e-6
+    assert float(((got[:, 2] - 2 * ref).abs() / (2 * scale)).max()) < 4e-6
