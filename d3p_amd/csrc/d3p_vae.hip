@@ -531,15 +531,14 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& w0, uin
     w2 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
 
+// one 128 x 64 tile (tx, ty) of K slab tz of the product g, by one 8-wave workgroup
 template <bool AK, bool BN>
-__global__ void __launch_bounds__(512) k_gemm_bf16x3(GemmArgs g)
+__device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx, const int ty, const int tz)
 {
     __shared__ __attribute__((aligned(16))) unsigned short Ap[2][3][D3P_GTM][D3P_BLD];  // [buffer][plane][m][k]
     __shared__ __attribute__((aligned(16))) unsigned short Bp[2][3][D3P_GT][D3P_BLD];   // [buffer][plane][n][k]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2, wr = wave & 3;
-    int tx, ty, tz;
-    xcd_tile(tx, ty, tz);
     const int m0 = ty * D3P_GTM, n0 = tx * D3P_GT;
     const int kbeg = tz * g.k_per, kend = (kbeg + g.k_per < g.K) ? kbeg + g.k_per : g.K;
     const int m_real = g.a_last_one ? g.M - 1 : g.M;
@@ -806,6 +805,93 @@ __global__ void __launch_bounds__(512) k_gemm_bf16x3(GemmArgs g)
     }
 }
 
+template <bool AK, bool BN>
+__global__ void __launch_bounds__(512) k_gemm_bf16x3(GemmArgs g)
+{
+    int tx, ty, tz;
+    xcd_tile(tx, ty, tz);
+    gemm_bf16x3_tile<AK, BN>(g, tx, ty, tz);
+}
+
+// Several products of one operand form in ONE launch (the weight-gradient products of a step: independent of each other, each too
+// short to fill the chip for a whole number of rounds -- 112 / 468 / 490 / 128 workgroups on 256 CUs -- and each paying its own
+// launch floor): a linear grid over the workgroups of all members, dealt to the XCDs as xcd_tile deals one product's (every XCD
+// walks one contiguous run of the order member, K slab, m, n), the host choosing ONE K range per workgroup for all members so that
+// the run is a whole number of equal rounds (gemm_group_splits).
+#define D3P_GROUP_MAX 6
+#define D3P_WPART_SPLITS 16  // most split-K partial tiles a product leaves
+struct GemmGroup {
+    GemmArgs g[D3P_GROUP_MAX];
+    // Every XCD takes one contiguous eighth of EVERY member, member after member (so the XCDs work through the members in step --
+    // one run over all members would give some XCDs only the cheap ones): slot[p] = first per-XCD slot of member p (its share is
+    // slot[p + 1] - slot[p] = ceil(cnt[p] / 8) workgroups per XCD; the up to 7 surplus workgroups of a member leave at once)
+    unsigned slot[D3P_GROUP_MAX + 1];
+    unsigned cnt[D3P_GROUP_MAX];         // workgroups of member p = gx gy splits
+    unsigned gx[D3P_GROUP_MAX], gy[D3P_GROUP_MAX];
+};
+
+template <bool AK, bool BN>
+__global__ void __launch_bounds__(512) k_gemm_bf16x3_group(GemmGroup q)
+{
+    const unsigned c = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    int p = 0;
+#pragma unroll
+    for (int k = 1; k < D3P_GROUP_MAX; ++k) p += (j >= q.slot[k]) ? 1 : 0;
+    const unsigned R = c * (q.slot[p + 1] - q.slot[p]) + (j - q.slot[p]);
+    if (R >= q.cnt[p]) return;
+    const unsigned gx = q.gx[p], gy = q.gy[p];
+    gemm_bf16x3_tile<AK, BN>(q.g[p], (int)(R % gx), (int)((R / gx) % gy), (int)(R / (gx * gy)));
+}
+
+// members collected by gemm() instead of being launched (its `group` argument), then launched together
+struct GemmGroupPlan {
+    GemmGroup q;
+    int n = 0;
+    bool ak = false, bn = false;
+};
+
+static int gemm_group_launch(hipStream_t s, GemmGroupPlan& G)
+{
+    if (G.n == 0) return D3P_OK;
+    unsigned slots = 0;
+    for (int p = 0; p < D3P_GROUP_MAX; ++p) {
+        G.q.slot[p] = slots;
+        if (p < G.n) slots += (G.q.cnt[p] + 7u) / 8u;
+        else { G.q.cnt[p] = 0; G.q.gx[p] = G.q.gy[p] = 1; G.q.g[p] = G.q.g[0]; }
+    }
+    G.q.slot[D3P_GROUP_MAX] = slots;
+    const dim3 grid(8u * slots);
+    if (G.ak && G.bn) hipLaunchKernelGGL((k_gemm_bf16x3_group<true, true>), grid, dim3(512), 0, s, G.q);
+    else if (G.ak) hipLaunchKernelGGL((k_gemm_bf16x3_group<true, false>), grid, dim3(512), 0, s, G.q);
+    else if (G.bn) hipLaunchKernelGGL((k_gemm_bf16x3_group<false, true>), grid, dim3(512), 0, s, G.q);
+    else hipLaunchKernelGGL((k_gemm_bf16x3_group<false, false>), grid, dim3(512), 0, s, G.q);
+    G.n = 0;
+    return check_launch("k_gemm_bf16x3_group");
+}
+
+// ONE split count for all members of a group (they share K = the batch): the one whose rounds of one workgroup per CU cost least,
+// a round costing its K range plus about two slices of prologue and epilogue.  tiles = 128 x 64 tiles of all members together.
+static int gemm_group_splits(unsigned tiles, int K)
+{
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, n = 0;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    int best = 1;
+    double best_cost = 1e30;
+    for (int sp = 1; sp <= D3P_WPART_SPLITS; ++sp) {
+        int kp = (K + sp - 1) / sp;
+        kp = (kp + D3P_GKB - 1) / D3P_GKB * D3P_GKB;
+        const int ns = (K + kp - 1) / kp;
+        if (ns != sp || kp < 4 * D3P_GKB) continue;
+        const double rounds = std::ceil((double)tiles * ns / n_cu);
+        const double cost = rounds * (kp + 2 * D3P_GKB);
+        if (cost < best_cost) { best_cost = cost; best = sp; }
+    }
+    return best;
+}
+
 __global__ void k_gemm_reduce(GemmArgs g, int splits)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -824,8 +910,10 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
                 float* C, int ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, int a_last_one = 0,
                 float* part = nullptr, size_t part_floats = 0, int epi = 0, float* C2 = nullptr, int* splits_left = nullptr,
                 const GemmJumps* jumps = nullptr, const float* ex_zu = nullptr, const float* ex_eps = nullptr, int ex_Z = 0, float ex_sc = 0.f,
-                const uint32_t* a_exact16 = nullptr, uint32_t a_exact_nonce = 0u)
+                const uint32_t* a_exact16 = nullptr, uint32_t a_exact_nonce = 0u, GemmGroupPlan* group = nullptr, int force_splits = 0)
 {
+    // group != nullptr (with splits_left): a product that takes the bf16 kernel is appended to the group instead of being launched
+    // (gemm_group_launch), with force_splits K slabs (gemm_group_splits) instead of a count of its own
     // splits_left != nullptr: a split-K product is NOT reduced here -- the partial tiles stay in `part` ([splits][M][N]) and
     // *splits_left says how many (0: the product went to C as usual); the consumer sums them in fixed order (k_vae_finalize)
     GemmArgs g;
@@ -872,6 +960,12 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
         if ((size_t)splits > max_by_mem) splits = (int)max_by_mem;
         if (splits < 1) splits = 1;
     }
+    if (force_splits > 0 && part && big) {
+        splits = force_splits;
+        const size_t max_by_mem = part_floats / ((size_t)M * N);
+        if ((size_t)splits > max_by_mem) splits = (int)max_by_mem;
+        if (splits < 1) splits = 1;
+    }
     const int kq = big ? D3P_GKB : D3P_GK;  // K slice of the kernel: a split starts on a slice boundary
     int k_per = (K + splits - 1) / splits;
     k_per = (k_per + kq - 1) / kq * kq;
@@ -880,6 +974,18 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     g.part = splits > 1 ? part : nullptr;
     const dim3 grid(cdiv(N, D3P_GT), cdiv(M, tm), splits);
     static const bool fp32_mfma = getenv("D3P_GEMM_FP32_MFMA") != nullptr;  // developer switch: the fp32-MFMA kernel for the large products
+    if (big && !fp32_mfma && group && splits_left && group->n < D3P_GROUP_MAX &&
+        (group->n == 0 || (group->ak == (a_sk == 1) && group->bn == (b_sn == 1)))) {
+        const int p = group->n++;
+        group->ak = a_sk == 1;
+        group->bn = b_sn == 1;
+        group->q.g[p] = g;
+        group->q.gx[p] = grid.x;
+        group->q.gy[p] = grid.y;
+        group->q.cnt[p] = grid.x * grid.y * grid.z;
+        *splits_left = splits > 1 ? splits : 0;
+        return D3P_OK;
+    }
     if (big && !fp32_mfma) {
         const bool ak = a_sk == 1, bn = b_sn == 1;
         if (ak && bn) hipLaunchKernelGGL((k_gemm_bf16x3<true, true>), grid, dim3(512), 0, s, g);
@@ -1123,7 +1229,6 @@ __global__ void __launch_bounds__(256) k_vae_loss_n(const float* __restrict__ px
 }
 
 // mean, Gaussian mechanism, rescale (svi.py:343-346, :365-375), numpyro Adam (svi.py:379-393) over the P parameters
-#define D3P_WPART_SPLITS 16  // most split-K partial tiles a product leaves
 #define D3P_VAE_MAX_BLOCKS 7  // [W | b] blocks of the flat layout: 2 nh + 3 with nh <= 2 hidden layers
 #define D3P_VAE_MAX_LEAVES 14 // parameter leaves: 2 (2 nh + 1) + 4
 
@@ -1526,6 +1631,16 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
         wg[n_wg++] = {l == 0 ? X : ws.he[l - 1], e.in, e.in, ws.de[l], e.out, e.out, e.out, e.W, nullptr, nh + 1 + l};
     }
     wg[n_wg++] = {ws.he[nh - 1], HE, HE, ws.dz, ldz, 2 * Z, Z, N.Wl, &wls, 2 * nh + 1};
+    // single-device update: the products go out as ONE grouped launch with a common K range per workgroup
+    static const bool no_group = getenv("D3P_VAE_NO_GROUP") != nullptr;   // developer switch (A/B), read once
+    GemmGroupPlan plan;
+    GemmGroupPlan* group = (w_splits && !no_group) ? &plan : nullptr;
+    int group_splits = 0;
+    if (group) {
+        unsigned tiles = 0;
+        for (int b = 0; b < n_wg; ++b) tiles += cdiv(wg[b].out, D3P_GT) * cdiv(wg[b].in + 1, D3P_GTM);
+        group_splits = gemm_group_splits(tiles, Bi);
+    }
     for (int b = 0; b < n_wg; ++b) {
         float* part = w_splits ? ws.wpart + (size_t)D3P_WPART_SPLITS * wg[b].off : ws.part;
         const size_t part_floats = w_splits ? (size_t)D3P_WPART_SPLITS * (wg[b].in + 1) * wg[b].out : ws.part_floats;
@@ -1534,13 +1649,15 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
         static const bool no_exact = getenv("D3P_VAE_NO_EXACT16") != nullptr;
         const uint32_t* xflag = (wg[b].A == X && !no_exact && ((size_t)B * D) % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0) ? ws.x_exact16 : nullptr;
         if ((rc = gemm(s, wg[b].A, 1, wg[b].a_sk, wg[b].Bm, wg[b].ldb, 1, S + wg[b].off, wg[b].ldc, wg[b].in + 1, wg[b].out, Bi, nullptr, 1.f, 0, 1,
-                       part, part_floats, 0, nullptr, w_splits ? &left : nullptr, wg[b].j, nullptr, nullptr, 0, 0.f, xflag, vae_exact_nonce(false))))
+                       part, part_floats, 0, nullptr, w_splits ? &left : nullptr, wg[b].j, nullptr, nullptr, 0, 0.f, xflag, vae_exact_nonce(false),
+                       group, group_splits)))
             return rc;
         if (w_splits) {
             w_splits[wg[b].blk] = left;
             if (b == n_wg - 1) w_splits[wg[b].blk + 1] = left;
         }
     }
+    if (group && (rc = gemm_group_launch(s, plan))) return rc;
     return check_launch("d3p_vae sums");
 }
 
