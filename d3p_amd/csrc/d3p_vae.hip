@@ -69,14 +69,20 @@ struct GemmArgs {
 };
 
 // the flag of GemmArgs::a_exact16 for an array of n floats (n a multiple of 4, 16-byte aligned): 1 unless some element has low bits
-__global__ void __launch_bounds__(256) k_exact16_flag(const float* __restrict__ x, size_t n4, uint32_t* __restrict__ flag, uint32_t nonce)
+__device__ __forceinline__ void exact16_pass(const float* __restrict__ x, size_t n4, uint32_t* __restrict__ flag, uint32_t nonce, unsigned block,
+                                             unsigned n_blocks)
 {
     uint32_t bad = 0u;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)block * blockDim.x + threadIdx.x; i < n4; i += (size_t)n_blocks * blockDim.x) {
         const uint4 v = reinterpret_cast<const uint4*>(x)[i];
         bad |= (v.x | v.y | v.z | v.w) & 0xffffu;
     }
     if (__ballot(bad != 0u) != 0ull && (threadIdx.x & 63) == 0) *flag = nonce;   // (every writer writes the same value)
+}
+
+__global__ void __launch_bounds__(256) k_exact16_flag(const float* __restrict__ x, size_t n4, uint32_t* __restrict__ flag, uint32_t nonce)
+{
+    exact16_pass(x, n4, flag, nonce, blockIdx.x, gridDim.x);
 }
 
 // o = alpha * acc + bias (+ C); then the epilogue
@@ -1029,37 +1035,101 @@ __global__ void k_vae_eval_eps(const uint32_t* __restrict__ jax_key, uint32_t B,
     eps[t] = bits_to_normal(tf_iota_word(k0, k1, (uint64_t)n, (uint64_t)t));
 }
 
+// Gaussian-mechanism noise for all parameter leaves (10, or 14 with two hidden layers) in one launch: leaf k draws
+// normal(site_key_k, leaf shape) (svi.py:487-491), i.e. word w of ChaCha block b of key k is element 16 b + w of that leaf.
+#define D3P_VAE_MAX_LEAVES 14 // parameter leaves: 2 (2 nh + 1) + 4
+struct SiteNoiseArgs {
+    const uint32_t* site_keys;                    // n_leaves x 16
+    uint32_t blk_off[D3P_VAE_MAX_LEAVES + 1];     // prefix sums of ceil(leaf size / 16) (unused entries = the total)
+    uint32_t elem_off[D3P_VAE_MAX_LEAVES + 1];    // prefix sums of the leaf sizes
+    float* noise;
+};
+
+__device__ __forceinline__ void site_noise_block(const SiteNoiseArgs& a, uint32_t b)   // b = ChaCha block over all leaves
+{
+    if (b >= a.blk_off[D3P_VAE_MAX_LEAVES]) return;
+    int site = 0;
+#pragma unroll
+    for (int k = 1; k < D3P_VAE_MAX_LEAVES; ++k) site += (b >= a.blk_off[k]) ? 1 : 0;
+    const uint32_t lb = b - a.blk_off[site], n_site = a.elem_off[site + 1] - a.elem_off[site];
+    uint32_t key[16], o[16];
+    load_key(a.site_keys + 16 * site, key);
+    keystream_block(key, lb, o);
+    float* dst = a.noise + a.elem_off[site];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t e = 16u * lb + w;
+        if (e < n_site) dst[e] = bits_to_normal(o[w]);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_vae_site_noise(SiteNoiseArgs a) { site_noise_block(a, blockIdx.x * blockDim.x + threadIdx.x); }
+
 // zl, u (B x Z), eps -> z = zl + exp(u) eps (written over zl), sd = exp(u) (written over u), lat[i] = log q - log p
 // (zl / u, like dz / du below, are the two halves of one B x 2 Z array: row stride ld)
 // jax_key != nullptr: the guide noise is drawn here -- eps[i][j] = normal word j of example i's sample key (svi.py:289-290;
 // single site 'z'; the key of an example is a function of its GLOBAL position pos0 + i in a batch of B_total, so 1 GPU and N
 // GPUs draw the same noise) -- and written to eps_out for the backward pass; otherwise eps_in is used (tests, evaluate).
-__global__ void k_vae_latent(float* __restrict__ zl, float* __restrict__ u, const float* __restrict__ eps_in, const uint32_t* __restrict__ jax_key,
-                             uint32_t B_total, uint32_t pos0, float* __restrict__ eps_out, uint32_t B, int Z, int ld, float* __restrict__ lat)
+// splits > 0: [zl | u] has not been written yet -- the product h [Wl | Ws] left `splits` split-K partial tiles in part
+// ([split][B][2 Z]); they are summed here in the order and with the bias addition of k_gemm_reduce (which this replaces).
+// noise_blocks > 0: the first noise_blocks workgroups of the launch draw the Gaussian-mechanism noise of the update instead
+// (site_noise_block: needs the step's keys only, so it rides in this short launch instead of one of its own).
+struct LatentArgs {
+    float *zl, *u;
+    const float* eps_in;
+    const uint32_t* jax_key;
+    uint32_t B_total, pos0;
+    float* eps_out;
+    uint32_t B;
+    int Z, ld;
+    float* lat;
+    const float* part;
+    int splits;
+    const float *bias_l, *bias_s;
+    unsigned noise_blocks;
+    SiteNoiseArgs noise;
+};
+
+__global__ void __launch_bounds__(256) k_vae_latent(LatentArgs a)
 {
-    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (blockIdx.x < a.noise_blocks) {
+        site_noise_block(a.noise, blockIdx.x * blockDim.x + threadIdx.x);
+        return;
+    }
+    const uint32_t i = ((blockIdx.x - a.noise_blocks) * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (i >= B) return;
+    if (i >= a.B) return;
+    const int Z = a.Z;
     uint32_t k0 = 0, k1 = 0;
-    if (jax_key) px_sample_key(jax_key[0], jax_key[1], B_total, pos0 + i, k0, k1);
+    if (a.jax_key) px_sample_key(a.jax_key[0], a.jax_key[1], a.B_total, a.pos0 + i, k0, k1);
     float acc = 0.f;
     for (int j = lane; j < Z; j += 64) {
-        const size_t e = (size_t)i * ld + j;
+        const size_t e = (size_t)i * a.ld + j;
         float ee;
-        if (jax_key) {
+        if (a.jax_key) {
             ee = bits_to_normal(tf_iota_word(k0, k1, (uint64_t)Z, (uint64_t)j));
-            eps_out[(size_t)i * Z + j] = ee;
+            a.eps_out[(size_t)i * Z + j] = ee;
         } else {
-            ee = eps_in[(size_t)i * Z + j];
+            ee = a.eps_in[(size_t)i * Z + j];
         }
-        const float uu = u[e];
-        const float sd = expf(uu), z = __fmaf_rn(sd, ee, zl[e]);
-        zl[e] = z;
-        u[e] = sd;
+        float loc, uu;
+        if (a.splits > 0) {
+            const size_t tile = (size_t)a.B * 2 * Z, t = (size_t)i * 2 * Z + j;
+            float sl = 0.f, su = 0.f;
+            for (int z = 0; z < a.splits; ++z) { sl += a.part[z * tile + t]; su += a.part[z * tile + t + Z]; }  // fixed order
+            loc = __fmaf_rn(1.0f, sl, a.bias_l[j]);
+            uu = __fmaf_rn(1.0f, su, a.bias_s[j]);
+        } else {
+            loc = a.zl[e];
+            uu = a.u[e];
+        }
+        const float sd = expf(uu), z = __fmaf_rn(sd, ee, loc);
+        a.zl[e] = z;
+        a.u[e] = sd;
         acc += (-0.5f * ee * ee - uu) + 0.5f * z * z;  // the log(2 pi) / 2 terms of log q and log p cancel
     }
     acc = wave_sum(acc);
-    if (lane == 0) lat[i] = acc;
+    if (lane == 0) a.lat[i] = acc;
 }
 
 // logits a (B x D), x -> da = sc (sigmoid(a) - x) in place; px_loss[i] = sc (lat_i - sum_j (x a - softplus(a))) mask_i
@@ -1230,7 +1300,6 @@ __global__ void __launch_bounds__(256) k_vae_loss_n(const float* __restrict__ px
 
 // mean, Gaussian mechanism, rescale (svi.py:343-346, :365-375), numpyro Adam (svi.py:379-393) over the P parameters
 #define D3P_VAE_MAX_BLOCKS 7  // [W | b] blocks of the flat layout: 2 nh + 3 with nh <= 2 hidden layers
-#define D3P_VAE_MAX_LEAVES 14 // parameter leaves: 2 (2 nh + 1) + 4
 
 struct VaeFinalArgs {
     const float* sums;  // P + 2
@@ -1299,34 +1368,6 @@ __global__ void k_vae_finalize(VaeFinalArgs a)
     a.adam_v[col] = v;
 }
 
-// Gaussian-mechanism noise for all parameter leaves (10, or 14 with two hidden layers) in one launch: leaf k draws
-// normal(site_key_k, leaf shape) (svi.py:487-491), i.e. word w of ChaCha block b of key k is element 16 b + w of that leaf.
-struct SiteNoiseArgs {
-    const uint32_t* site_keys;                    // n_leaves x 16
-    uint32_t blk_off[D3P_VAE_MAX_LEAVES + 1];     // prefix sums of ceil(leaf size / 16) (unused entries = the total)
-    uint32_t elem_off[D3P_VAE_MAX_LEAVES + 1];    // prefix sums of the leaf sizes
-    float* noise;
-};
-
-__global__ void __launch_bounds__(256) k_vae_site_noise(SiteNoiseArgs a)
-{
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.blk_off[D3P_VAE_MAX_LEAVES]) return;
-    int site = 0;
-#pragma unroll
-    for (int k = 1; k < D3P_VAE_MAX_LEAVES; ++k) site += (b >= a.blk_off[k]) ? 1 : 0;
-    const uint32_t lb = b - a.blk_off[site], n_site = a.elem_off[site + 1] - a.elem_off[site];
-    uint32_t key[16], o[16];
-    load_key(a.site_keys + 16 * site, key);
-    keystream_block(key, lb, o);
-    float* dst = a.noise + a.elem_off[site];
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        const uint32_t e = 16u * lb + w;
-        if (e < n_site) dst[e] = bits_to_normal(o[w]);
-    }
-}
-
 // rows of the five delta arrays scaled by the clip factors in one launch
 // All keys of one update in ONE launch (they were three launches + a step-counter launch + a 64-byte copy, ~5 us each):
 // keys[0..47] = [next | gradient | perturbation] = split(state_key, 3) (svi.py:208-211), keys[48 ..] =
@@ -1336,10 +1377,18 @@ __global__ void __launch_bounds__(256) k_vae_site_noise(SiteNoiseArgs a)
 #define D3P_VAE_KEY_JAX (48 + 16 * D3P_VAE_MAX_LEAVES)
 #define D3P_VAE_KEY_STEP (D3P_VAE_KEY_JAX + 2)
 #define D3P_VAE_KEY_WORDS (D3P_VAE_KEY_JAX + 4)
-__global__ void __launch_bounds__(64) k_vae_keys(const uint32_t* __restrict__ cur_key, uint32_t* __restrict__ keys,
-                                                 uint32_t* __restrict__ next_slot, const int32_t* __restrict__ step,
-                                                 int32_t* __restrict__ step_out, int advance, int n_sites)
+// Workgroups 1 .. of the launch (if any) run the exactness pass over the batch (exact16_pass: it depends on nothing, and a launch
+// of its own cost as much as this one).
+__global__ void __launch_bounds__(256) k_vae_keys(const uint32_t* __restrict__ cur_key, uint32_t* __restrict__ keys,
+                                                  uint32_t* __restrict__ next_slot, const int32_t* __restrict__ step,
+                                                  int32_t* __restrict__ step_out, int advance, int n_sites,
+                                                  const float* __restrict__ x, size_t x_n4, uint32_t* __restrict__ x_flag, uint32_t x_nonce)
 {
+    if (blockIdx.x > 0) {
+        exact16_pass(x, x_n4, x_flag, x_nonce, blockIdx.x - 1, gridDim.x - 1);
+        return;
+    }
+    if (threadIdx.x >= 64) return;   // (the barrier below is the first wave's alone: s_barrier counts the waves that have not ended)
     // one quad of lanes per derivation (4-lane ChaCha block, d3p_device.h): the launch is pure latency
     __shared__ uint32_t sk[3][16];
     const int lane = threadIdx.x, quad = lane >> 2, q = lane & 3;
@@ -1483,10 +1532,20 @@ static uint32_t vae_exact_nonce(bool advance)
     return nonce;
 }
 
+// may the batch take the one-plane path at all (k_exact16_flag reads whole 16-byte words)?
+static bool vae_exact_eligible(const float* X, uint32_t B, int D)
+{
+    static const bool no_exact = getenv("D3P_VAE_NO_EXACT16") != nullptr;   // developer switch (A/B), read once
+    return !no_exact && ((size_t)B * D) % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0;
+}
+static unsigned vae_exact_blocks(size_t n4) { return (unsigned)(n4 / 1024 < 1 ? 1 : (n4 / 1024 > 1024 ? 1024 : n4 / 1024)); }
+
 static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const float* params, const float* X, const uint8_t* mask,
                                uint32_t B, const float* eps, float sc, const VaeWorkspace& ws, const uint32_t* jax_key = nullptr,
-                               uint32_t B_total = 0, uint32_t pos0 = 0)
+                               uint32_t B_total = 0, uint32_t pos0 = 0, bool x_checked = false, const SiteNoiseArgs* noise = nullptr)
 {
+    // x_checked: the exactness pass over X of THIS forward pass has been enqueued already (inside the key launch, vae_step_keys);
+    // noise != nullptr: the Gaussian-mechanism noise of the update is drawn beside the latent kernel
     int rc;
     const VaeNet N = vae_net(m);
     const int D = N.D, Z = N.Z, HE = N.HE, nh = N.nh, Bi = (int)B;
@@ -1495,12 +1554,12 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
     // that take X as their A operand -- the first encoder layer and its weight gradient: they then stage one plane of A instead
     // of splitting it into three and issue three of the six products (GemmArgs::a_exact16).  Any other batch takes the general path.
     const uint32_t* xflag = nullptr;
-    static const bool no_exact = getenv("D3P_VAE_NO_EXACT16") != nullptr;   // developer switch (A/B), read once
-    if (!no_exact && ((size_t)B * D) % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0) {
-        const size_t n4 = (size_t)B * D / 4;
-        const uint32_t nonce = vae_exact_nonce(true);   // a new nonce per pass: the flag word is never reset
-        hipLaunchKernelGGL(k_exact16_flag, dim3((unsigned)(n4 / 1024 < 1 ? 1 : (n4 / 1024 > 1024 ? 1024 : n4 / 1024))), dim3(256), 0, s, X, n4, ws.x_exact16,
-                           nonce);
+    if (vae_exact_eligible(X, B, D)) {
+        if (!x_checked) {
+            const size_t n4 = (size_t)B * D / 4;
+            const uint32_t nonce = vae_exact_nonce(true);   // a new nonce per pass: the flag word is never reset
+            hipLaunchKernelGGL(k_exact16_flag, dim3(vae_exact_blocks(n4)), dim3(256), 0, s, X, n4, ws.x_exact16, nonce);
+        }
         xflag = ws.x_exact16;
     }
     // ---- encoder (guide)
@@ -1518,11 +1577,26 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
     // would be, and bs likewise behind bl (flat layout: Wl, bl, Ws, bs)
     const int ldz = 2 * Z;
     const GemmJumps enc = {Z, 0x7fffffff, (long long)HE * Z, 0, (long long)HE * Z, 0};
+    // (a split-K product leaves its partial tiles for k_vae_latent to sum: no reduction launch)
+    int zl_splits = 0;
     if ((rc = gemm(s, ws.he[nh - 1], HE, 1, params + N.Wl, Z, 1, ws.zl, ldz, Bi, 2 * Z, HE, params + N.bl, 1.f, 0, 0, ws.part, ws.part_floats, 0, nullptr,
-                   nullptr, &enc)))
+                   &zl_splits, &enc)))
         return rc;
-    hipLaunchKernelGGL(k_vae_latent, rows, dim3(256), 0, s, ws.zl, ws.u, eps, eps ? (const uint32_t*)nullptr : jax_key, B_total ? B_total : B, pos0,
-                       ws.eps, B, Z, ldz, ws.lat);  // zl := z, u := sd
+    {
+        LatentArgs la;
+        memset(&la, 0, sizeof(la));
+        la.zl = ws.zl; la.u = ws.u;   // zl := z, u := sd
+        la.eps_in = eps; la.jax_key = eps ? (const uint32_t*)nullptr : jax_key;
+        la.B_total = B_total ? B_total : B; la.pos0 = pos0;
+        la.eps_out = ws.eps; la.B = B; la.Z = Z; la.ld = ldz; la.lat = ws.lat;
+        la.part = ws.part; la.splits = zl_splits;
+        la.bias_l = params + N.bl; la.bias_s = params + N.bs;
+        if (noise) {
+            la.noise = *noise;
+            la.noise_blocks = cdiv(noise->blk_off[D3P_VAE_MAX_LEAVES], 256);
+        }
+        hipLaunchKernelGGL(k_vae_latent, dim3(rows.x + la.noise_blocks), dim3(256), 0, s, la);
+    }
     // ---- decoder (model)
     {
         const float* in = ws.zl;
@@ -1546,7 +1620,8 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
 // forward + backward + norms + clipped sums into ws.sums[P + 2]; eps_dev given or drawn from jax_key
 static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* params, const float* X, const uint8_t* mask,
                             uint32_t B, const float* eps_ext, const uint32_t* jax_key, float clip, const VaeWorkspace& ws,
-                            float* norms_out, uint32_t B_total = 0, uint32_t pos0 = 0, int* w_splits = nullptr)
+                            float* norms_out, uint32_t B_total = 0, uint32_t pos0 = 0, int* w_splits = nullptr, bool x_checked = false,
+                            const SiteNoiseArgs* noise = nullptr)
 {
     // w_splits != nullptr (single-device update): the split-K partial tiles of the weight-gradient products stay in ws.wpart
     // and w_splits[0 .. n_blocks - 1] says how many each (k_vae_finalize sums them); otherwise ws.sums holds the reduced sums
@@ -1557,7 +1632,7 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     const float sc = m->inv_obs * m->scale;
     const float* eps = eps_ext ? eps_ext : ws.eps;  // (drawn inside k_vae_latent when not given)
     const dim3 rows(cdiv((uint64_t)B * 64, 256));
-    if ((rc = vae_enqueue_forward(s, m, params, X, mask, B, eps_ext, sc, ws, jax_key, B_total, pos0))) return rc;
+    if ((rc = vae_enqueue_forward(s, m, params, X, mask, B, eps_ext, sc, ws, jax_key, B_total, pos0, x_checked, noise))) return rc;
     // ---- backward (data): delta_in = (delta_out W^T) . softplus'(pre) down the decoder
     {
         const float* delta = ws.a;
@@ -1646,8 +1721,7 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
         const size_t part_floats = w_splits ? (size_t)D3P_WPART_SPLITS * (wg[b].in + 1) * wg[b].out : ws.part_floats;
         int left = 0;
         // (A = X^T: the flag of the forward pass holds -- same batch; the virtual row of ones is exact too)
-        static const bool no_exact = getenv("D3P_VAE_NO_EXACT16") != nullptr;
-        const uint32_t* xflag = (wg[b].A == X && !no_exact && ((size_t)B * D) % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0) ? ws.x_exact16 : nullptr;
+        const uint32_t* xflag = (wg[b].A == X && vae_exact_eligible(X, B, D)) ? ws.x_exact16 : nullptr;
         if ((rc = gemm(s, wg[b].A, 1, wg[b].a_sk, wg[b].Bm, wg[b].ldb, 1, S + wg[b].off, wg[b].ldc, wg[b].in + 1, wg[b].out, Bi, nullptr, 1.f, 0, 1,
                        part, part_floats, 0, nullptr, w_splits ? &left : nullptr, wg[b].j, nullptr, nullptr, 0, 0.f, xflag, vae_exact_nonce(false),
                        group, group_splits)))
@@ -1743,17 +1817,50 @@ static int vae_update_checks(const d3p_vae_model* model, const d3p_dpsvi_hyper* 
 // split(perturbation_key, 10) (svi.py:491), convert_to_jax_rng_key(gradient_key)
 // from != nullptr: the update reads the key and the step counter of `from` and writes the next key / counter into `state`
 // (slot 1 of its key buffer; state->key_slot is taken as 0)
+// X != nullptr: the exactness pass over the batch the forward pass is about to take (vae_enqueue_forward's x_checked) rides in
+// this launch; *x_checked says whether it did
 static int vae_step_keys(hipStream_t s, const d3p_vae_model* model, const d3p_dpsvi_state* state, const VaeWorkspace& ws, bool advance,
-                         const d3p_dpsvi_state* from = nullptr)
+                         const d3p_dpsvi_state* from = nullptr, const float* X = nullptr, uint32_t B = 0, bool* x_checked = nullptr)
 {
     const int slot = state->key_slot & 1, n_sites = vae_net(model).n_leaves();
+    size_t n4 = 0;
+    uint32_t nonce = 0;
+    unsigned xb = 0;
+    if (X && x_checked && vae_exact_eligible(X, B, model->D)) {
+        n4 = (size_t)B * model->D / 4;
+        nonce = vae_exact_nonce(true);
+        xb = vae_exact_blocks(n4);
+        *x_checked = true;
+    }
     if (from)
-        hipLaunchKernelGGL(k_vae_keys, dim3(1), dim3(64), 0, s, (const uint32_t*)(from->rng_key + 16 * (from->key_slot & 1)), ws.keys,
-                           state->rng_key + 16, (const int32_t*)from->step, state->step, advance ? 1 : 0, n_sites);
+        hipLaunchKernelGGL(k_vae_keys, dim3(1 + xb), dim3(256), 0, s, (const uint32_t*)(from->rng_key + 16 * (from->key_slot & 1)), ws.keys,
+                           state->rng_key + 16, (const int32_t*)from->step, state->step, advance ? 1 : 0, n_sites, X, n4, ws.x_exact16, nonce);
     else
-        hipLaunchKernelGGL(k_vae_keys, dim3(1), dim3(64), 0, s, (const uint32_t*)(state->rng_key + 16 * slot), ws.keys,
-                           state->rng_key + 16 * (slot ^ 1), (const int32_t*)state->step, state->step, advance ? 1 : 0, n_sites);
+        hipLaunchKernelGGL(k_vae_keys, dim3(1 + xb), dim3(256), 0, s, (const uint32_t*)(state->rng_key + 16 * slot), ws.keys,
+                           state->rng_key + 16 * (slot ^ 1), (const int32_t*)state->step, state->step, advance ? 1 : 0, n_sites, X, n4, ws.x_exact16,
+                           nonce);
     return check_launch("k_vae_keys");
+}
+
+// the Gaussian-mechanism noise of an update: one key per leaf, normal(site_key, leaf shape) (svi.py:487)
+static SiteNoiseArgs vae_site_noise_args(const VaeNet& N, const VaeWorkspace& ws)
+{
+    size_t leaf_off[D3P_VAE_MAX_LEAVES + 1];
+    int k = 0;
+    for (int l = 0; l <= N.nh; ++l) { leaf_off[k++] = N.dec[l].W; leaf_off[k++] = N.dec[l].b; }
+    for (int l = 0; l < N.nh; ++l) { leaf_off[k++] = N.enc[l].W; leaf_off[k++] = N.enc[l].b; }
+    leaf_off[k++] = N.Wl; leaf_off[k++] = N.bl; leaf_off[k++] = N.Ws; leaf_off[k++] = N.bs;
+    for (; k <= D3P_VAE_MAX_LEAVES; ++k) leaf_off[k] = N.P;
+    SiteNoiseArgs na;
+    na.site_keys = ws.keys + 48;
+    na.noise = ws.noise;
+    na.blk_off[0] = 0;
+    for (k = 0; k < D3P_VAE_MAX_LEAVES; ++k) {
+        na.elem_off[k] = (uint32_t)leaf_off[k];
+        na.blk_off[k + 1] = na.blk_off[k] + (uint32_t)((leaf_off[k + 1] - leaf_off[k] + 15) / 16);
+    }
+    na.elem_off[D3P_VAE_MAX_LEAVES] = (uint32_t)leaf_off[D3P_VAE_MAX_LEAVES];
+    return na;
 }
 
 static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
@@ -1776,9 +1883,13 @@ static int vae_local_sums_impl(void* stream, const d3p_vae_model* model, const d
     vae_carve(model, B_local, (char*)workspace_dev, &ws);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if ((rc = vae_step_keys(s, model, state, ws, advance, from))) return rc;
+    bool x_checked = false;
+    if ((rc = vae_step_keys(s, model, state, ws, advance, from, X_dev, B_local, &x_checked))) return rc;
+    // w_splits != nullptr = the single-device update: vae_apply_impl follows on the same workspace with these keys, so its noise is
+    // drawn here, beside the latent kernel
+    const SiteNoiseArgs noise = vae_site_noise_args(vae_net(model), ws);
     if ((rc = vae_enqueue_sums(s, model, from ? from->params : state->params, X_dev, mask_dev, B_local, eps_dev, ws.keys + D3P_VAE_KEY_JAX, hyper->clip, ws, nullptr,
-                               B_total, pos0, w_splits)))
+                               B_total, pos0, w_splits, x_checked, w_splits ? &noise : nullptr)))
         return rc;
     if (sums_dev != ws.sums)
         D3P_HIP_TRY(hipMemcpyAsync(sums_dev, ws.sums, (vae_net(model).P + 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1817,22 +1928,8 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
     const int nh = N.nh, n_blocks = N.n_blocks();
     int rc;
     if (derive_keys && (rc = vae_step_keys(s, model, state, ws, true))) return rc;
-    {
-        size_t leaf_off[D3P_VAE_MAX_LEAVES + 1];
-        int k = 0;
-        for (int l = 0; l <= nh; ++l) { leaf_off[k++] = N.dec[l].W; leaf_off[k++] = N.dec[l].b; }
-        for (int l = 0; l < nh; ++l) { leaf_off[k++] = N.enc[l].W; leaf_off[k++] = N.enc[l].b; }
-        leaf_off[k++] = N.Wl; leaf_off[k++] = N.bl; leaf_off[k++] = N.Ws; leaf_off[k++] = N.bs;
-        for (; k <= D3P_VAE_MAX_LEAVES; ++k) leaf_off[k] = N.P;
-        SiteNoiseArgs na;  // one key per leaf, normal(site_key, leaf shape) (svi.py:487)
-        na.site_keys = ws.keys + 48;
-        na.noise = ws.noise;
-        na.blk_off[0] = 0;
-        for (k = 0; k < D3P_VAE_MAX_LEAVES; ++k) {
-            na.elem_off[k] = (uint32_t)leaf_off[k];
-            na.blk_off[k + 1] = na.blk_off[k] + (uint32_t)((leaf_off[k + 1] - leaf_off[k] + 15) / 16);
-        }
-        na.elem_off[D3P_VAE_MAX_LEAVES] = (uint32_t)leaf_off[D3P_VAE_MAX_LEAVES];
+    if (derive_keys || !w_splits) {  // (the single-device update drew the noise beside its latent kernel: vae_local_sums_impl)
+        const SiteNoiseArgs na = vae_site_noise_args(N, ws);
         hipLaunchKernelGGL(k_vae_site_noise, dim3(cdiv(na.blk_off[D3P_VAE_MAX_LEAVES], 256)), dim3(256), 0, s, na);
     }
     VaeFinalArgs f;
