@@ -875,8 +875,9 @@ static int gemm_group_launch(hipStream_t s, GemmGroupPlan& G)
     return check_launch("k_gemm_bf16x3_group");
 }
 
-// ONE split count for all members of a group (they share K = the batch): the one whose rounds of one workgroup per CU cost least,
-// a round costing its K range plus about two slices of prologue and epilogue.  tiles = 128 x 64 tiles of all members together.
+// Split count of a k_gemm_bf16x3 product, or ONE count for all members of a group (they share K = the batch): the one whose rounds
+// of one workgroup per CU (92 KB of LDS each) cost least, a round costing its K range plus about two slices of prologue and
+// epilogue.  tiles = 128 x 64 tiles of the product, or of all members together.
 static int gemm_group_splits(unsigned tiles, int K)
 {
     static int n_cu = 0;
@@ -890,7 +891,7 @@ static int gemm_group_splits(unsigned tiles, int K)
         int kp = (K + sp - 1) / sp;
         kp = (kp + D3P_GKB - 1) / D3P_GKB * D3P_GKB;
         const int ns = (K + kp - 1) / kp;
-        if (ns != sp || kp < 4 * D3P_GKB) continue;
+        if (ns != sp || kp < 2 * D3P_GKB) continue;
         const double rounds = std::ceil((double)tiles * ns / n_cu);
         const double cost = rounds * (kp + 2 * D3P_GKB);
         if (cost < best_cost) { best_cost = cost; best = sp; }
@@ -903,8 +904,13 @@ __global__ void k_gemm_reduce(GemmArgs g, int splits)
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)g.M * g.N) return;
     const int row = (int)(t / g.N), col = (int)(t % g.N);
+    // (all tiles requested at once, like k_vae_finalize: a loop over a run-time count is one memory round trip per tile)
+    float tv[D3P_WPART_SPLITS];
+#pragma unroll
+    for (int z = 0; z < D3P_WPART_SPLITS; ++z) tv[z] = z < splits ? g.part[(size_t)z * g.M * g.N + t] : 0.f;
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += g.part[(size_t)z * g.M * g.N + t];  // fixed order
+#pragma unroll
+    for (int z = 0; z < D3P_WPART_SPLITS; ++z) s += z < splits ? tv[z] : 0.f;  // fixed order
     gemm_store(g, row, col, s, g.bias ? g.bias[col + (col >= g.n_seg ? g.bias_njump : 0ll)] : 0.f);
 }
 
@@ -958,9 +964,11 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     const unsigned tiles = cdiv(N, D3P_GT) * cdiv(M, tm);
     int splits = 1;
     if (part && tiles < (big ? 160u : 512u) && K >= 8 * D3P_GK) {
-        splits = big ? (int)(512 / tiles) : (int)((1024 + tiles - 1) / tiles);  // big: two 8-wave workgroups per CU, one round
+        static const bool fp32_big = getenv("D3P_GEMM_FP32_MFMA") != nullptr;
+        splits = big ? (fp32_big ? (int)(512 / tiles) : gemm_group_splits(tiles, K))   // (fp32 kernel: two 8-wave workgroups per CU, one round)
+                     : (int)((1024 + tiles - 1) / tiles);
         const int max_by_k = K / (4 * D3P_GK);
-        if (splits > max_by_k) splits = max_by_k;
+        if (splits > max_by_k && !(big && !fp32_big)) splits = max_by_k;   // (gemm_group_splits keeps its K ranges at two slices or more)
         if (splits > 16) splits = 16;  // the reduction adds the partial tiles serially
         const size_t max_by_mem = part_floats / ((size_t)M * N);
         if ((size_t)splits > max_by_mem) splits = (int)max_by_mem;
@@ -1377,15 +1385,38 @@ __global__ void k_vae_finalize(VaeFinalArgs a)
 #define D3P_VAE_KEY_JAX (48 + 16 * D3P_VAE_MAX_LEAVES)
 #define D3P_VAE_KEY_STEP (D3P_VAE_KEY_JAX + 2)
 #define D3P_VAE_KEY_WORDS (D3P_VAE_KEY_JAX + 4)
-// Workgroups 1 .. of the launch (if any) run the exactness pass over the batch (exact16_pass: it depends on nothing, and a launch
-// of its own cost as much as this one).
+// Further workgroups of the launch do work of the step that depends on nothing but its inputs (a launch of their own cost as
+// much as this one): workgroups 1 .. x_blocks the exactness pass over the batch (exact16_pass); the ones behind them pack the two
+// latent heads, which lie H Z + Z apart in the flat layout with rows of Z floats (no 16-byte fetches: the head products took the
+// scalar 64 x 64 kernel), side by side into wcat (HE x 2 Z = [Wl | Ws]) and transposed into wcatT (2 Z x HE = [Wl^T ; Ws^T]).
+struct KeysExtra {
+    const float* x;
+    size_t x_n4;
+    uint32_t* x_flag;
+    uint32_t x_nonce;
+    unsigned x_blocks;
+    const float *wl, *wsd;   // the heads' weights (HE x Z each)
+    float *wcat, *wcatT;
+    int HE, Z;
+};
+
 __global__ void __launch_bounds__(256) k_vae_keys(const uint32_t* __restrict__ cur_key, uint32_t* __restrict__ keys,
                                                   uint32_t* __restrict__ next_slot, const int32_t* __restrict__ step,
-                                                  int32_t* __restrict__ step_out, int advance, int n_sites,
-                                                  const float* __restrict__ x, size_t x_n4, uint32_t* __restrict__ x_flag, uint32_t x_nonce)
+                                                  int32_t* __restrict__ step_out, int advance, int n_sites, KeysExtra ex)
 {
+    if (blockIdx.x > ex.x_blocks) {
+        const unsigned t = (blockIdx.x - ex.x_blocks - 1) * blockDim.x + threadIdx.x;
+        const unsigned Z2 = 2u * ex.Z;
+        if (t < (unsigned)ex.HE * Z2) {
+            const unsigned k = t / Z2, n = t % Z2;
+            const float v = n < (unsigned)ex.Z ? ex.wl[k * ex.Z + n] : ex.wsd[k * ex.Z + n - ex.Z];
+            ex.wcat[t] = v;
+            ex.wcatT[(size_t)n * ex.HE + k] = v;
+        }
+        return;
+    }
     if (blockIdx.x > 0) {
-        exact16_pass(x, x_n4, x_flag, x_nonce, blockIdx.x - 1, gridDim.x - 1);
+        exact16_pass(ex.x, ex.x_n4, ex.x_flag, ex.x_nonce, blockIdx.x - 1, ex.x_blocks);
         return;
     }
     if (threadIdx.x >= 64) return;   // (the barrier below is the first wave's alone: s_barrier counts the waves that have not ended)
@@ -1475,6 +1506,13 @@ struct VaeWorkspace {
     size_t part_floats;
     uint32_t* keys;  // 3 x 16 split + up to 14 x 16 site keys + jax key + step index (D3P_VAE_KEY_*)
     uint32_t* x_exact16;  // one word: the batch X is exactly bf16 (GemmArgs::a_exact16), set per forward pass
+    float *wcat, *wcatT;  // the latent heads packed for the step (k_vae_keys): [Wl | Ws] (HE x 2 Z) and its transpose
+};
+
+// what the key launch of an update has already done for the passes that follow it (vae_step_keys)
+struct VaeStepPrep {
+    bool x_checked = false;     // the exactness pass over X of THIS forward pass has been enqueued
+    bool heads_packed = false;  // ws.wcat / ws.wcatT hold the heads of the parameters the pass runs on
 };
 
 static size_t vae_carve(const d3p_vae_model* m, uint32_t B, char* base, VaeWorkspace* ws)
@@ -1510,6 +1548,8 @@ static size_t vae_carve(const d3p_vae_model* m, uint32_t B, char* base, VaeWorks
     q = take(pf); if (ws) { ws->part = q; ws->part_floats = pf; }
     q = take((size_t)D3P_WPART_SPLITS * P); if (ws) ws->wpart = q;  // unreduced weight-gradient tiles
     q = take(64); if (ws) ws->x_exact16 = (uint32_t*)q;
+    q = take((size_t)N.HE * 2 * Z); if (ws) ws->wcat = q;
+    q = take((size_t)N.HE * 2 * Z); if (ws) ws->wcatT = q;
     return off;
 }
 
@@ -1542,9 +1582,8 @@ static unsigned vae_exact_blocks(size_t n4) { return (unsigned)(n4 / 1024 < 1 ? 
 
 static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const float* params, const float* X, const uint8_t* mask,
                                uint32_t B, const float* eps, float sc, const VaeWorkspace& ws, const uint32_t* jax_key = nullptr,
-                               uint32_t B_total = 0, uint32_t pos0 = 0, bool x_checked = false, const SiteNoiseArgs* noise = nullptr)
+                               uint32_t B_total = 0, uint32_t pos0 = 0, VaeStepPrep prep = VaeStepPrep(), const SiteNoiseArgs* noise = nullptr)
 {
-    // x_checked: the exactness pass over X of THIS forward pass has been enqueued already (inside the key launch, vae_step_keys);
     // noise != nullptr: the Gaussian-mechanism noise of the update is drawn beside the latent kernel
     int rc;
     const VaeNet N = vae_net(m);
@@ -1555,7 +1594,7 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
     // of splitting it into three and issue three of the six products (GemmArgs::a_exact16).  Any other batch takes the general path.
     const uint32_t* xflag = nullptr;
     if (vae_exact_eligible(X, B, D)) {
-        if (!x_checked) {
+        if (!prep.x_checked) {
             const size_t n4 = (size_t)B * D / 4;
             const uint32_t nonce = vae_exact_nonce(true);   // a new nonce per pass: the flag word is never reset
             hipLaunchKernelGGL(k_exact16_flag, dim3(vae_exact_blocks(n4)), dim3(256), 0, s, X, n4, ws.x_exact16, nonce);
@@ -1576,11 +1615,12 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
     // [z_loc | log z_std] = h [Wl | Ws] + [bl | bs] in ONE product of N = 2 Z: Ws lies HE Z behind where Wl's columns Z .. 2 Z - 1
     // would be, and bs likewise behind bl (flat layout: Wl, bl, Ws, bs)
     const int ldz = 2 * Z;
-    const GemmJumps enc = {Z, 0x7fffffff, (long long)HE * Z, 0, (long long)HE * Z, 0};
+    // (packed heads: B = ws.wcat, a plain HE x 2 Z matrix -- only the bias keeps its displaced second half)
+    const GemmJumps enc = {Z, 0x7fffffff, prep.heads_packed ? 0ll : (long long)HE * Z, 0, (long long)HE * Z, 0};
     // (a split-K product leaves its partial tiles for k_vae_latent to sum: no reduction launch)
     int zl_splits = 0;
-    if ((rc = gemm(s, ws.he[nh - 1], HE, 1, params + N.Wl, Z, 1, ws.zl, ldz, Bi, 2 * Z, HE, params + N.bl, 1.f, 0, 0, ws.part, ws.part_floats, 0, nullptr,
-                   &zl_splits, &enc)))
+    if ((rc = gemm(s, ws.he[nh - 1], HE, 1, prep.heads_packed ? ws.wcat : params + N.Wl, prep.heads_packed ? 2 * Z : Z, 1, ws.zl, ldz, Bi, 2 * Z, HE,
+                   params + N.bl, 1.f, 0, 0, ws.part, ws.part_floats, 0, nullptr, &zl_splits, &enc)))
         return rc;
     {
         LatentArgs la;
@@ -1620,7 +1660,7 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
 // forward + backward + norms + clipped sums into ws.sums[P + 2]; eps_dev given or drawn from jax_key
 static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* params, const float* X, const uint8_t* mask,
                             uint32_t B, const float* eps_ext, const uint32_t* jax_key, float clip, const VaeWorkspace& ws,
-                            float* norms_out, uint32_t B_total = 0, uint32_t pos0 = 0, int* w_splits = nullptr, bool x_checked = false,
+                            float* norms_out, uint32_t B_total = 0, uint32_t pos0 = 0, int* w_splits = nullptr, VaeStepPrep prep = VaeStepPrep(),
                             const SiteNoiseArgs* noise = nullptr)
 {
     // w_splits != nullptr (single-device update): the split-K partial tiles of the weight-gradient products stay in ws.wpart
@@ -1632,7 +1672,7 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     const float sc = m->inv_obs * m->scale;
     const float* eps = eps_ext ? eps_ext : ws.eps;  // (drawn inside k_vae_latent when not given)
     const dim3 rows(cdiv((uint64_t)B * 64, 256));
-    if ((rc = vae_enqueue_forward(s, m, params, X, mask, B, eps_ext, sc, ws, jax_key, B_total, pos0, x_checked, noise))) return rc;
+    if ((rc = vae_enqueue_forward(s, m, params, X, mask, B, eps_ext, sc, ws, jax_key, B_total, pos0, prep, noise))) return rc;
     // ---- backward (data): delta_in = (delta_out W^T) . softplus'(pre) down the decoder
     {
         const float* delta = ws.a;
@@ -1651,10 +1691,13 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
         return rc;
     // dpre = ([dz | du] [Wl^T ; Ws^T]) . softplus'(pre): ONE product of K = 2 Z (rows Z .. 2 Z - 1 of the stacked B are Ws^T,
     // HE Z behind where Wl^T's would be)
+    // (packed heads: B = ws.wcatT, a plain 2 Z x HE matrix with 16-byte rows -- the product takes the bf16 kernel)
     const GemmJumps dec = {0x7fffffff, Z, 0, (long long)HE * Z, 0, 0};
-    if ((rc = gemm(s, ws.dz, ldz, 1, params + N.Wl, 1, Z, ws.de[nh - 1], HE, Bi, HE, 2 * Z, nullptr, 1.f, 0, 0, nullptr, 0, 2, ws.sge[nh - 1], nullptr,
-                   &dec)))
-        return rc;
+    if (prep.heads_packed)
+        rc = gemm(s, ws.dz, ldz, 1, ws.wcatT, HE, 1, ws.de[nh - 1], HE, Bi, HE, 2 * Z, nullptr, 1.f, 0, 0, nullptr, 0, 2, ws.sge[nh - 1]);
+    else
+        rc = gemm(s, ws.dz, ldz, 1, params + N.Wl, 1, Z, ws.de[nh - 1], HE, Bi, HE, 2 * Z, nullptr, 1.f, 0, 0, nullptr, 0, 2, ws.sge[nh - 1], nullptr, &dec);
+    if (rc) return rc;
     for (int l = nh - 2; l >= 0; --l) {
         const VaeDense& e = N.enc[l + 1];
         if ((rc = gemm(s, ws.de[l + 1], e.out, 1, params + e.W, 1, e.out, ws.de[l], e.in, Bi, e.in, e.out, nullptr, 1.f, 0, 0, ws.part, ws.part_floats, 2,
@@ -1817,28 +1860,40 @@ static int vae_update_checks(const d3p_vae_model* model, const d3p_dpsvi_hyper* 
 // split(perturbation_key, 10) (svi.py:491), convert_to_jax_rng_key(gradient_key)
 // from != nullptr: the update reads the key and the step counter of `from` and writes the next key / counter into `state`
 // (slot 1 of its key buffer; state->key_slot is taken as 0)
-// X != nullptr: the exactness pass over the batch the forward pass is about to take (vae_enqueue_forward's x_checked) rides in
-// this launch; *x_checked says whether it did
+// X != nullptr (with prep): the exactness pass over the batch the forward pass is about to take, and the packing of the latent
+// heads of `params` (the parameters that pass runs on), ride in this launch; *prep says which of them did
 static int vae_step_keys(hipStream_t s, const d3p_vae_model* model, const d3p_dpsvi_state* state, const VaeWorkspace& ws, bool advance,
-                         const d3p_dpsvi_state* from = nullptr, const float* X = nullptr, uint32_t B = 0, bool* x_checked = nullptr)
+                         const d3p_dpsvi_state* from = nullptr, const float* X = nullptr, uint32_t B = 0, const float* params = nullptr,
+                         VaeStepPrep* prep = nullptr)
 {
-    const int slot = state->key_slot & 1, n_sites = vae_net(model).n_leaves();
-    size_t n4 = 0;
-    uint32_t nonce = 0;
-    unsigned xb = 0;
-    if (X && x_checked && vae_exact_eligible(X, B, model->D)) {
-        n4 = (size_t)B * model->D / 4;
-        nonce = vae_exact_nonce(true);
-        xb = vae_exact_blocks(n4);
-        *x_checked = true;
+    const VaeNet N = vae_net(model);
+    const int slot = state->key_slot & 1, n_sites = N.n_leaves();
+    KeysExtra ex;
+    memset(&ex, 0, sizeof(ex));
+    unsigned pack_blocks = 0;
+    if (X && prep && vae_exact_eligible(X, B, model->D)) {
+        ex.x = X;
+        ex.x_n4 = (size_t)B * model->D / 4;
+        ex.x_flag = ws.x_exact16;
+        ex.x_nonce = vae_exact_nonce(true);
+        ex.x_blocks = vae_exact_blocks(ex.x_n4);
+        prep->x_checked = true;
     }
+    static const bool no_pack = getenv("D3P_VAE_NO_HEAD_PACK") != nullptr;   // developer switch (A/B), read once
+    if (params && prep && !no_pack && (2 * N.Z) % 4 == 0 && N.HE % 4 == 0) {
+        ex.wl = params + N.Wl; ex.wsd = params + N.Ws;
+        ex.wcat = ws.wcat; ex.wcatT = ws.wcatT;
+        ex.HE = N.HE; ex.Z = N.Z;
+        pack_blocks = cdiv((uint64_t)N.HE * 2 * N.Z, 256);
+        prep->heads_packed = true;
+    }
+    const dim3 grid(1 + ex.x_blocks + pack_blocks);
     if (from)
-        hipLaunchKernelGGL(k_vae_keys, dim3(1 + xb), dim3(256), 0, s, (const uint32_t*)(from->rng_key + 16 * (from->key_slot & 1)), ws.keys,
-                           state->rng_key + 16, (const int32_t*)from->step, state->step, advance ? 1 : 0, n_sites, X, n4, ws.x_exact16, nonce);
+        hipLaunchKernelGGL(k_vae_keys, grid, dim3(256), 0, s, (const uint32_t*)(from->rng_key + 16 * (from->key_slot & 1)), ws.keys,
+                           state->rng_key + 16, (const int32_t*)from->step, state->step, advance ? 1 : 0, n_sites, ex);
     else
-        hipLaunchKernelGGL(k_vae_keys, dim3(1 + xb), dim3(256), 0, s, (const uint32_t*)(state->rng_key + 16 * slot), ws.keys,
-                           state->rng_key + 16 * (slot ^ 1), (const int32_t*)state->step, state->step, advance ? 1 : 0, n_sites, X, n4, ws.x_exact16,
-                           nonce);
+        hipLaunchKernelGGL(k_vae_keys, grid, dim3(256), 0, s, (const uint32_t*)(state->rng_key + 16 * slot), ws.keys,
+                           state->rng_key + 16 * (slot ^ 1), (const int32_t*)state->step, state->step, advance ? 1 : 0, n_sites, ex);
     return check_launch("k_vae_keys");
 }
 
@@ -1883,13 +1938,13 @@ static int vae_local_sums_impl(void* stream, const d3p_vae_model* model, const d
     vae_carve(model, B_local, (char*)workspace_dev, &ws);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    bool x_checked = false;
-    if ((rc = vae_step_keys(s, model, state, ws, advance, from, X_dev, B_local, &x_checked))) return rc;
+    VaeStepPrep prep;
+    if ((rc = vae_step_keys(s, model, state, ws, advance, from, X_dev, B_local, from ? from->params : state->params, &prep))) return rc;
     // w_splits != nullptr = the single-device update: vae_apply_impl follows on the same workspace with these keys, so its noise is
     // drawn here, beside the latent kernel
     const SiteNoiseArgs noise = vae_site_noise_args(vae_net(model), ws);
     if ((rc = vae_enqueue_sums(s, model, from ? from->params : state->params, X_dev, mask_dev, B_local, eps_dev, ws.keys + D3P_VAE_KEY_JAX, hyper->clip, ws, nullptr,
-                               B_total, pos0, w_splits, x_checked, w_splits ? &noise : nullptr)))
+                               B_total, pos0, w_splits, prep, w_splits ? &noise : nullptr)))
         return rc;
     if (sums_dev != ws.sums)
         D3P_HIP_TRY(hipMemcpyAsync(sums_dev, ws.sums, (vae_net(model).P + 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
