@@ -63,6 +63,10 @@ struct GemmArgs {
     // plane of A are then exactly zero: the kernel stages plane 0 alone (no splitting of A) and issues the three products with a_0
     // (of six); the sums are those of the general path (the dropped products are exact zeros, the others come in the same order).
     const uint32_t* a_exact16;
+    // k_gemm_bf16x3 with an n-fast B only, nullable: row k of B is multiplied by b_row_scale[k] while it is staged (the clip factors
+    // of the weight-gradient products: B = a delta array, k = the example -- svi.py:121-122 folded into the sum; the fp32 product
+    // c_k b is rounded once, as if the scaled rows had been written to memory and read back)
+    const float* b_row_scale;
     uint32_t a_exact_nonce;   // A is exact iff *a_exact16 != a_exact_nonce: the checking pass stores the nonce of ITS pass when it finds an
                               // inexact element, so the word needs no reset between passes (whatever it held before, a stale match can
                               // only send an exact batch down the general path)
@@ -591,6 +595,8 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
     const float on0 = one_of(gm_a0), on1 = AK ? one_of(gm_a1) : one_of(gm_a0 + 1), on2 = one_of(gm_a0 + 2), on3 = one_of(gm_a0 + 3);
 
     float4 ra00, ra01, rb0, ra10, ra11, rb1;
+    float rs0 = 1.f, rs1 = 1.f;   // b_row_scale of this thread's row of B (BN), per register set
+    const bool b_scaled = BN && g.b_row_scale != nullptr;
     const long long a_step2 = 2ll * D3P_GKB * a_kstride, b_step2 = 2ll * D3P_GKB * b_kstride;
     int fk[2] = {kbeg, kbeg + D3P_GKB};
     const float* fa[2] = {a_tile + (long long)kbeg * a_kstride, a_tile + (long long)(kbeg + D3P_GKB) * a_kstride};
@@ -599,6 +605,10 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
         constexpr int s = decltype(S)::value;
         float4 &a0 = s ? ra10 : ra00, &a1 = s ? ra11 : ra01, &bb = s ? rb1 : rb0;
         const int k0 = fk[s];
+        if (b_scaled) {
+            const int gk = k0 + b_k;
+            (s ? rs1 : rs0) = g.b_row_scale[gk < g.K ? gk : g.K - 1];
+        }
         if (k0 + D3P_GKB <= g.K) {
             a0 = *reinterpret_cast<const float4*>(fa[s] + a_off[0]);
             a1 = *reinterpret_cast<const float4*>(fa[s] + a_off[1]);
@@ -619,6 +629,7 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
         constexpr int s = decltype(S)::value;
         constexpr bool A1 = decltype(A1P)::value;   // A is exactly bf16: plane 0 alone
         float4 bb = s ? rb1 : rb0;
+        if (BN) { const float c = s ? rs1 : rs0; bb = make_float4(bb.x * c, bb.y * c, bb.z * c, bb.w * c); }
         float4 o[2] = {s ? ra10 : ra00, s ? ra11 : ra01};
         if (decltype(EDGE)::value && (m_edge || k0 + D3P_GKB > kend)) {
 #pragma unroll
@@ -918,12 +929,26 @@ __global__ void k_gemm_reduce(GemmArgs g, int splits)
 // tiles lose), so besides the weight gradients the two N = 400 forward / backward-data GEMMs are split too.
 // The split count is chosen so that short grids (the weight-gradient
 // GEMMs: K = batch, M x N = a weight matrix) still put a few workgroups on every CU.
+// will gemm() send this product (no displaced B segments) to k_gemm_bf16x3 with an n-fast B?  (the conditions of `big` below)
+static bool gemm_takes_bf16_nfast(const float* A, long long a_sm, long long a_sk, const float* B, long long b_sk, long long b_sn, int M, int N, int K,
+                                  int a_last_one)
+{
+    static const bool fp32_mfma = getenv("D3P_GEMM_FP32_MFMA") != nullptr;
+    auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    const int m_real_h = a_last_one ? M - 1 : M, K4 = (K + 3) & ~3;
+    const bool va8 = aligned16(A) && ((a_sk == 1 && a_sm % 4 == 0 && a_sm >= K4) || (a_sm == 1 && a_sk % 4 == 0 && a_sk >= ((m_real_h + 3) & ~3)));
+    const bool vb8 = aligned16(B) && b_sn == 1 && b_sk % 4 == 0 && N % 4 == 0;
+    return !fp32_mfma && va8 && vb8 && (M > 96 || (M > 32 && K >= 2048));
+}
+
 static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, const float* B, long long b_sk, long long b_sn,
                 float* C, int ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, int a_last_one = 0,
                 float* part = nullptr, size_t part_floats = 0, int epi = 0, float* C2 = nullptr, int* splits_left = nullptr,
                 const GemmJumps* jumps = nullptr, const float* ex_zu = nullptr, const float* ex_eps = nullptr, int ex_Z = 0, float ex_sc = 0.f,
-                const uint32_t* a_exact16 = nullptr, uint32_t a_exact_nonce = 0u, GemmGroupPlan* group = nullptr, int force_splits = 0)
+                const uint32_t* a_exact16 = nullptr, uint32_t a_exact_nonce = 0u, GemmGroupPlan* group = nullptr, int force_splits = 0,
+                const float* b_row_scale = nullptr)
 {
+    // b_row_scale (GemmArgs): only products that take k_gemm_bf16x3 with an n-fast B honour it -- the caller asks gemm_takes_bf16 first
     // group != nullptr (with splits_left): a product that takes the bf16 kernel is appended to the group instead of being launched
     // (gemm_group_launch), with force_splits K slabs (gemm_group_splits) instead of a count of its own
     // splits_left != nullptr: a split-K product is NOT reduced here -- the partial tiles stay in `part` ([splits][M][N]) and
@@ -938,6 +963,7 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     g.C2 = C2;
     g.a_exact16 = a_exact16;
     g.a_exact_nonce = a_exact_nonce;
+    g.b_row_scale = b_row_scale;
     g.ex_zu = ex_zu; g.ex_eps = ex_eps; g.ex_Z = ex_Z; g.ex_sc = ex_sc;
     g.n_seg = jumps ? jumps->n_seg : 0x7fffffff;
     g.k_seg = jumps ? jumps->k_seg : 0x7fffffff;
@@ -960,6 +986,8 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     const bool vb8 = aligned16(B) && ((b_sn == 1 && b_sk % 4 == 0 && N % 4 == 0) || (b_sk == 1 && b_sn % 4 == 0 && b_sn >= K4)) &&
                      !(jumps && (jumps->b_njump || jumps->b_kjump));
     const bool big = va8 && vb8 && (M > 96 || (M > 32 && K >= 2048));
+    static const bool fp32_mfma = getenv("D3P_GEMM_FP32_MFMA") != nullptr;  // developer switch: the fp32-MFMA kernel for the large products
+    if (b_row_scale && !(big && !fp32_mfma && b_sn == 1)) return fail(D3P_E_INVALID_ARG, "gemm: b_row_scale on a product that does not take the bf16 kernel");
     const int tm = big ? D3P_GTM : D3P_GT;
     const unsigned tiles = cdiv(N, D3P_GT) * cdiv(M, tm);
     int splits = 1;
@@ -987,7 +1015,6 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     g.k_per = k_per;
     g.part = splits > 1 ? part : nullptr;
     const dim3 grid(cdiv(N, D3P_GT), cdiv(M, tm), splits);
-    static const bool fp32_mfma = getenv("D3P_GEMM_FP32_MFMA") != nullptr;  // developer switch: the fp32-MFMA kernel for the large products
     if (big && !fp32_mfma && group && splits_left && group->n < D3P_GROUP_MAX &&
         (group->n == 0 || (group->ak == (a_sk == 1) && group->bn == (b_sn == 1)))) {
         const int p = group->n++;
@@ -1179,13 +1206,6 @@ __global__ void k_vae_out(float* __restrict__ a, const float* __restrict__ X, co
     }
 }
 
-__device__ __forceinline__ float row_sumsq(const float* __restrict__ r, int n, int lane)
-{
-    float s = 0.f;
-    for (int j = lane; j < n; j += 64) s = __fmaf_rn(r[j], r[j], s);
-    return wave_sum(s);
-}
-
 // joint L2 norm of every example's gradient by the outer-product identity, clip factor c_i (0 for masked rows); the rows of
 // the delta arrays are staged in LDS while their squares are summed and written back scaled by c_i (svi.py:121-122
 // folded into the sums), so the deltas are read once and written once (a separate rescaling pass read them a second time).
@@ -1208,25 +1228,47 @@ struct NormArgs {
     float clip;
     float* cf;
     float* norms;  // nullable
+    int scale_back;        // 0: the deltas stay as they are -- the weight-gradient products apply cf themselves (GemmArgs::b_row_scale)
     const float* px_loss;  // the LAST workgroup of the launch sums px_loss and counts the unmasked examples into loss_n[0..1]
     float* loss_n;         // (fixed order; was a launch of its own)
 };
 
-// sum of squares of a row while copying it to `keep` (lane l owns elements l, l + 64, ...)
-__device__ __forceinline__ float row_sumsq_keep(const float* __restrict__ r, int n, int lane, float* __restrict__ keep)
+// this lane's share of a row's sum of squares (16-byte loads: elements 4 l .. 4 l + 3, + 256, ...; rows that cannot take them:
+// elements l, l + 64, ...), copying what it reads to `keep` when given -- the wave sums come later, all terms at once
+__device__ __forceinline__ bool row_vec4(const float* r, int n) { return (n & 3) == 0 && (reinterpret_cast<uintptr_t>(r) & 15u) == 0; }
+__device__ __forceinline__ float row_sumsq_lane(const float* __restrict__ r, int n, int lane, float* __restrict__ keep)
 {
     float s = 0.f;
-    for (int j = lane; j < n; j += 64) {
-        const float v = r[j];
-        keep[j] = v;
-        s = __fmaf_rn(v, v, s);
+    if (row_vec4(r, n)) {
+        for (int j = 4 * lane; j < n; j += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(r + j);
+            if (keep) *reinterpret_cast<float4*>(keep + j) = v;
+            s = __fmaf_rn(v.x, v.x, s); s = __fmaf_rn(v.y, v.y, s); s = __fmaf_rn(v.z, v.z, s); s = __fmaf_rn(v.w, v.w, s);
+        }
+    } else {
+        for (int j = lane; j < n; j += 64) {
+            const float v = r[j];
+            if (keep) keep[j] = v;
+            s = __fmaf_rn(v, v, s);
+        }
     }
-    return wave_sum(s);
+    return s;
+}
+__device__ __forceinline__ void row_scale_back(float* __restrict__ r, int n, int lane, const float* __restrict__ keep, float c)
+{
+    if (row_vec4(r, n)) {
+        for (int j = 4 * lane; j < n; j += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(keep + j);
+            *reinterpret_cast<float4*>(r + j) = make_float4(v.x * c, v.y * c, v.z * c, v.w * c);
+        }
+    } else {
+        for (int j = lane; j < n; j += 64) r[j] = keep[j] * c;
+    }
 }
 
 __global__ void k_vae_norms(NormArgs a)
 {
-    extern __shared__ float norm_stage[];  // 4 waves x a.stage
+    extern __shared__ __attribute__((aligned(16))) float norm_stage[];  // 4 waves x a.stage
     if (blockIdx.x == gridDim.x - 1) {  // sums[P] = sum_i px_loss[i], sums[P + 1] = number of unmasked examples
         float* l = norm_stage;
         float* c = norm_stage + 256;
@@ -1249,18 +1291,32 @@ __global__ void k_vae_norms(NormArgs a)
     const int lane = threadIdx.x & 63;
     if (i >= a.B) return;
     float* keep = norm_stage + (size_t)(threadIdx.x >> 6) * a.stage;
-    float n2 = 0.f;
+    // every term's loads first (per-lane partial sums: nothing waits for a wave sum between two terms), then all wave sums
+    float pin[D3P_VAE_MAX_TERMS], pd[D3P_VAE_MAX_TERMS];
     {
         float* k = keep;
-        for (int t = 0; t < a.n_terms; ++t) {
-            const NormTerm& q = a.t[t];
-            const float in2 = q.in ? row_sumsq(q.in + (size_t)i * q.in_ld, q.in_n, lane) : a.x2[i];
-            float d = row_sumsq_keep(q.d0 + (size_t)i * q.d_ld, q.d_n, lane, k);
-            k += q.d_n;
-            if (q.d1) {
-                d += row_sumsq_keep(q.d1 + (size_t)i * q.d_ld, q.d_n, lane, k);
-                k += q.d_n;
+#pragma unroll
+        for (int t = 0; t < D3P_VAE_MAX_TERMS; ++t) {
+            pin[t] = pd[t] = 0.f;
+            if (t < a.n_terms) {
+                const NormTerm& q = a.t[t];
+                if (q.in) pin[t] = row_sumsq_lane(q.in + (size_t)i * q.in_ld, q.in_n, lane, nullptr);
+                pd[t] = row_sumsq_lane(q.d0 + (size_t)i * q.d_ld, q.d_n, lane, a.scale_back ? k : nullptr);
+                k += (q.d_n + 3) & ~3;
+                if (q.d1) {
+                    pd[t] += row_sumsq_lane(q.d1 + (size_t)i * q.d_ld, q.d_n, lane, a.scale_back ? k : nullptr);
+                    k += (q.d_n + 3) & ~3;
+                }
             }
+        }
+    }
+    float n2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < D3P_VAE_MAX_TERMS; ++t) {
+        if (t < a.n_terms) {
+            float in2, d;
+            wave_sum2(pin[t], pd[t], in2, d);
+            if (!a.t[t].in) in2 = a.x2[i];
             n2 += (in2 + 1.0f) * d;
         }
     }
@@ -1271,17 +1327,16 @@ __global__ void k_vae_norms(NormArgs a)
         a.cf[i] = c;
         if (a.norms) a.norms[i] = live ? nrm : 0.f;
     }
+    if (!a.scale_back) return;
     // every lane reads back exactly the LDS words it wrote: no barrier needed
     float* k = keep;
     for (int t = 0; t < a.n_terms; ++t) {
         const NormTerm& q = a.t[t];
-        float* r0 = q.d0 + (size_t)i * q.d_ld;
-        for (int j = lane; j < q.d_n; j += 64) r0[j] = k[j] * c;
-        k += q.d_n;
+        row_scale_back(q.d0 + (size_t)i * q.d_ld, q.d_n, lane, k, c);
+        k += (q.d_n + 3) & ~3;
         if (q.d1) {
-            float* r1 = q.d1 + (size_t)i * q.d_ld;
-            for (int j = lane; j < q.d_n; j += 64) r1[j] = k[j] * c;
-            k += q.d_n;
+            row_scale_back(q.d1 + (size_t)i * q.d_ld, q.d_n, lane, k, c);
+            k += (q.d_n + 3) & ~3;
         }
     }
 }
@@ -1704,32 +1759,6 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
                        ws.sge[l])))
             return rc;
     }
-    // ---- per-example norms and clip factors; the rows of every delta come back scaled by c_i
-    NormArgs na;
-    memset(&na, 0, sizeof(na));
-    {
-        int t = 0;
-        auto term = [&](const float* in, int in_ld, int in_n, float* d0, float* d1, int d_ld, int d_n) {
-            NormTerm& q = na.t[t++];
-            q.in = in; q.in_ld = in_ld; q.in_n = in_n; q.d0 = d0; q.d1 = d1; q.d_ld = d_ld; q.d_n = d_n;
-            na.stage += d_n * (d1 ? 2 : 1);
-        };
-        term(ws.hd[nh - 1], N.dec[nh].in, N.dec[nh].in, ws.a, nullptr, D, D);
-        for (int l = nh - 1; l >= 1; --l) term(ws.hd[l - 1], N.dec[l].in, N.dec[l].in, ws.dd[l], nullptr, N.dec[l].out, N.dec[l].out);
-        term(ws.zl, ldz, Z, ws.dd[0], nullptr, N.dec[0].out, N.dec[0].out);
-        term(ws.he[nh - 1], HE, HE, ws.dz, ws.du, ldz, Z);
-        for (int l = nh - 1; l >= 1; --l) term(ws.he[l - 1], N.enc[l].in, N.enc[l].in, ws.de[l], nullptr, N.enc[l].out, N.enc[l].out);
-        term(nullptr, 0, 0, ws.de[0], nullptr, N.enc[0].out, N.enc[0].out);
-        na.n_terms = t;
-    }
-    na.x2 = ws.x2;
-    na.mask = mask; na.B = B; na.clip = clip; na.cf = ws.cf; na.norms = norms_out;
-    na.px_loss = ws.px_loss; na.loss_n = ws.sums + N.P;
-    {
-        size_t stage_floats = 4 * (size_t)na.stage;
-        if (stage_floats < 512) stage_floats = 512;  // the last workgroup's loss / count reduction uses 2 x 256 floats
-        hipLaunchKernelGGL(k_vae_norms, dim3(rows.x + 1), dim3(256), stage_floats * sizeof(float), s, na);
-    }
     // ---- clipped sums: weights  A^T (diag(c) Delta)  (GEMMs over the batch), biases = column sums
     // [W | b] of every layer is contiguous in the flat layout, so the bias gradient is row `in` of a GEMM whose A carries a
     // virtual row of ones
@@ -1749,6 +1778,39 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
         wg[n_wg++] = {l == 0 ? X : ws.he[l - 1], e.in, e.in, ws.de[l], e.out, e.out, e.out, e.W, nullptr, nh + 1 + l};
     }
     wg[n_wg++] = {ws.he[nh - 1], HE, HE, ws.dz, ldz, 2 * Z, Z, N.Wl, &wls, 2 * nh + 1};
+    // Where do the clip factors meet the deltas?  When every product takes the bf16 kernel it multiplies the rows of its B operand by
+    // c_i while staging them (GemmArgs::b_row_scale) and the norm kernel only reads; otherwise the norm kernel writes the rows back scaled.
+    static const bool scale_back_env = getenv("D3P_VAE_SCALE_BACK") != nullptr;   // developer switch (A/B), read once
+    bool scale_in_gemm = !scale_back_env;
+    for (int b = 0; b < n_wg; ++b)
+        scale_in_gemm = scale_in_gemm && gemm_takes_bf16_nfast(wg[b].A, 1, wg[b].a_sk, wg[b].Bm, wg[b].ldb, 1, wg[b].in + 1, wg[b].out, Bi, 1);
+    // ---- per-example norms and clip factors (and, unless scale_in_gemm, the rows of every delta come back scaled by c_i)
+    NormArgs na;
+    memset(&na, 0, sizeof(na));
+    na.scale_back = scale_in_gemm ? 0 : 1;
+    {
+        int t = 0;
+        auto term = [&](const float* in, int in_ld, int in_n, float* d0, float* d1, int d_ld, int d_n) {
+            NormTerm& q = na.t[t++];
+            q.in = in; q.in_ld = in_ld; q.in_n = in_n; q.d0 = d0; q.d1 = d1; q.d_ld = d_ld; q.d_n = d_n;
+            na.stage += ((d_n + 3) & ~3) * (d1 ? 2 : 1);   // (every row of the stage starts on a 16-byte boundary)
+        };
+        term(ws.hd[nh - 1], N.dec[nh].in, N.dec[nh].in, ws.a, nullptr, D, D);
+        for (int l = nh - 1; l >= 1; --l) term(ws.hd[l - 1], N.dec[l].in, N.dec[l].in, ws.dd[l], nullptr, N.dec[l].out, N.dec[l].out);
+        term(ws.zl, ldz, Z, ws.dd[0], nullptr, N.dec[0].out, N.dec[0].out);
+        term(ws.he[nh - 1], HE, HE, ws.dz, ws.du, ldz, Z);
+        for (int l = nh - 1; l >= 1; --l) term(ws.he[l - 1], N.enc[l].in, N.enc[l].in, ws.de[l], nullptr, N.enc[l].out, N.enc[l].out);
+        term(nullptr, 0, 0, ws.de[0], nullptr, N.enc[0].out, N.enc[0].out);
+        na.n_terms = t;
+    }
+    na.x2 = ws.x2;
+    na.mask = mask; na.B = B; na.clip = clip; na.cf = ws.cf; na.norms = norms_out;
+    na.px_loss = ws.px_loss; na.loss_n = ws.sums + N.P;
+    {
+        size_t stage_floats = na.scale_back ? 4 * (size_t)na.stage : 0;
+        if (stage_floats < 512) stage_floats = 512;  // the last workgroup's loss / count reduction uses 2 x 256 floats
+        hipLaunchKernelGGL(k_vae_norms, dim3(rows.x + 1), dim3(256), stage_floats * sizeof(float), s, na);
+    }
     // single-device update: the products go out as ONE grouped launch with a common K range per workgroup
     static const bool no_group = getenv("D3P_VAE_NO_GROUP") != nullptr;   // developer switch (A/B), read once
     GemmGroupPlan plan;
@@ -1767,7 +1829,7 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
         const uint32_t* xflag = (wg[b].A == X && vae_exact_eligible(X, B, D)) ? ws.x_exact16 : nullptr;
         if ((rc = gemm(s, wg[b].A, 1, wg[b].a_sk, wg[b].Bm, wg[b].ldb, 1, S + wg[b].off, wg[b].ldc, wg[b].in + 1, wg[b].out, Bi, nullptr, 1.f, 0, 1,
                        part, part_floats, 0, nullptr, w_splits ? &left : nullptr, wg[b].j, nullptr, nullptr, 0, 0.f, xflag, vae_exact_nonce(false),
-                       group, group_splits)))
+                       group, group_splits, scale_in_gemm ? ws.cf : nullptr)))
             return rc;
         if (w_splits) {
             w_splits[wg[b].blk] = left;
