@@ -1364,15 +1364,48 @@ __global__ void __launch_bounds__(256) k_vae_loss_n(const float* __restrict__ px
 // mean, Gaussian mechanism, rescale (svi.py:343-346, :365-375), numpyro Adam (svi.py:379-393) over the P parameters
 #define D3P_VAE_MAX_BLOCKS 7  // [W | b] blocks of the flat layout: 2 nh + 3 with nh <= 2 hidden layers
 
-struct VaeFinalArgs {
-    const float* sums;  // P + 2
-    // weight-gradient blocks whose split-K partial tiles were left unreduced (single-device update): block b = columns
-    // [w_off[b], w_off[b] + w_mn[b]) of the flat layout, w_splits[b] tiles of w_mn[b] floats at wpart + D3P_WPART_SPLITS * w_off[b]
-    const float* wpart;
+// weight-gradient blocks whose split-K partial tiles were left unreduced: block b = columns [w_off[b], w_off[b + 1]) of the flat
+// layout, w_splits[b] tiles (0: the product wrote its sums itself)
+struct VaeTiles {
+    const float* wpart;                                         // nullptr: no block has tiles
     uint32_t w_off[D3P_VAE_MAX_BLOCKS + 1];                     // first column of block b (unused entries = P)
     uint32_t w_base[D3P_VAE_MAX_BLOCKS], w_tile[D3P_VAE_MAX_BLOCKS], w_ld[D3P_VAE_MAX_BLOCKS], w_coff[D3P_VAE_MAX_BLOCKS],
         w_out[D3P_VAE_MAX_BLOCKS];                              // its tiles: wpart + w_base, w_tile apart, element (r, c) of the
     int w_splits[D3P_VAE_MAX_BLOCKS];                           // block at r * w_ld + w_coff + c, c < w_out
+};
+
+// column col's sum over its block's tiles, in fixed order (`direct` = what the product wrote when the block has none)
+__device__ __forceinline__ float vae_tile_sum(const VaeTiles& a, size_t col, float direct)
+{
+    if (!a.wpart) return direct;
+    int b = 0;
+#pragma unroll
+    for (int k = 1; k < D3P_VAE_MAX_BLOCKS; ++k) b += (col >= a.w_off[k]) ? 1 : 0;
+    if (a.w_splits[b] <= 0) return direct;
+    const uint32_t e = (uint32_t)col - a.w_off[b];
+    const float* t = a.wpart + a.w_base[b] + (size_t)(e / a.w_out[b]) * a.w_ld[b] + a.w_coff[b] + e % a.w_out[b];
+    // (all tiles requested at once -- a loop over a run-time count is one memory round trip per tile: 16.6 -> 13.4 us)
+    const int nz = a.w_splits[b];
+    const size_t tile = a.w_tile[b];
+    float tv[D3P_WPART_SPLITS];
+#pragma unroll
+    for (int z = 0; z < D3P_WPART_SPLITS; ++z) tv[z] = z < nz ? t[(size_t)z * tile] : 0.f;
+    float tot = 0.f;
+#pragma unroll
+    for (int z = 0; z < D3P_WPART_SPLITS; ++z) tot += z < nz ? tv[z] : 0.f;
+    return tot;
+}
+
+// sums[col] := the tile sums (stage API and data-parallel local sums: the sums leave the device function as one vector)
+__global__ void __launch_bounds__(256) k_vae_tile_sums(VaeTiles a, float* __restrict__ sums, size_t P)
+{
+    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col < P) sums[col] = vae_tile_sum(a, col, sums[col]);
+}
+
+struct VaeFinalArgs {
+    const float* sums;  // P + 2
+    VaeTiles tiles;     // (single-device update: k_vae_finalize sums the tiles itself)
     const float* noise;
     const float* in_params;  // state before the update (== params / adam_m / adam_v, or the old state's arrays when the update
     const float* in_m;       // is out of place: DPSVI.update returns a NEW state, svi.py:395-434)
@@ -1399,26 +1432,7 @@ __global__ void k_vae_finalize(VaeFinalArgs a)
     const float factor = (n == 0.f) ? 0.f : Bf / n;
     if (col == 0 && a.loss_out) *a.loss_out = (a.sums[a.P] / Bf) * a.obs_scale * factor;
     if (col >= a.P) return;
-    float tot = a.sums[col];
-    if (a.wpart) {
-        int b = 0;
-#pragma unroll
-        for (int k = 1; k < D3P_VAE_MAX_BLOCKS; ++k) b += (col >= a.w_off[k]) ? 1 : 0;
-        if (a.w_splits[b] > 0) {
-            const uint32_t e = (uint32_t)col - a.w_off[b];
-            const float* t = a.wpart + a.w_base[b] + (size_t)(e / a.w_out[b]) * a.w_ld[b] + a.w_coff[b] + e % a.w_out[b];
-            // (all tiles requested at once -- a loop over a run-time count is one memory round trip per tile: 16.6 -> 13.4 us --,
-            // summed in fixed order)
-            const int nz = a.w_splits[b];
-            const size_t tile = a.w_tile[b];
-            float tv[D3P_WPART_SPLITS];
-#pragma unroll
-            for (int z = 0; z < D3P_WPART_SPLITS; ++z) tv[z] = z < nz ? t[(size_t)z * tile] : 0.f;
-            tot = 0.f;
-#pragma unroll
-            for (int z = 0; z < D3P_WPART_SPLITS; ++z) tot += z < nz ? tv[z] : 0.f;
-        }
-    }
+    const float tot = vae_tile_sum(a.tiles, col, a.sums[col]);
     const float g = (tot / Bf + a.noise[col] * (a.h.dp_scale * (a.h.clip / n))) * a.obs_scale * factor;
     if (a.grad_out) a.grad_out[col] = g;
     float m = a.in_m[col], v = a.in_v[col];
@@ -1616,6 +1630,34 @@ static int vae_validate(const d3p_vae_model* m, const char* what)
     return D3P_OK;
 }
 
+// [W | b] blocks of the flat layout and their unreduced tiles in ws.wpart: the dense layers, then Wl and Ws -- which come from ONE
+// product with N = 2 Z: shared tiles of (HE + 1) x 2 Z in the region of the Wl block
+static VaeTiles vae_tiles(const VaeNet& N, const VaeWorkspace& ws, const int* w_splits)
+{
+    VaeTiles f;
+    memset(&f, 0, sizeof(f));
+    f.wpart = w_splits ? ws.wpart : nullptr;
+    const int nh = N.nh, n_blocks = N.n_blocks();
+    for (int b = 0; b < n_blocks; ++b) {
+        const VaeDense* lay = N.block_layer(b);
+        const size_t first = lay ? lay->W : (b == 2 * nh + 1 ? N.Wl : N.Ws);
+        const size_t next = b + 1 < n_blocks ? (N.block_layer(b + 1) ? N.block_layer(b + 1)->W : (b + 1 == 2 * nh + 1 ? N.Wl : N.Ws)) : N.P;
+        f.w_off[b] = (uint32_t)first;
+        f.w_base[b] = (uint32_t)(D3P_WPART_SPLITS * first);
+        f.w_tile[b] = (uint32_t)(next - first);
+        f.w_ld[b] = f.w_out[b] = (uint32_t)(lay ? lay->out : N.Z);
+        f.w_coff[b] = 0;
+        f.w_splits[b] = w_splits ? w_splits[b] : 0;
+    }
+    const int bl = 2 * nh + 1, bs = 2 * nh + 2;
+    f.w_tile[bl] = f.w_tile[bs] = f.w_tile[bl] + f.w_tile[bs];
+    f.w_ld[bl] = f.w_ld[bs] = 2u * (uint32_t)N.Z;
+    f.w_base[bs] = f.w_base[bl];
+    f.w_coff[bs] = (uint32_t)N.Z;
+    for (int b = n_blocks; b <= D3P_VAE_MAX_BLOCKS; ++b) f.w_off[b] = (uint32_t)N.P;
+    return f;
+}
+
 // forward pass: activations, the reparametrised latent, da = sc (sigmoid(a) - x) and px_loss[i] = sc (log q - log p - log lik)
 // eps != nullptr: given noise; otherwise drawn from jax_key inside k_vae_latent into ws.eps
 // the nonce of the current exactness pass over the batch (per host thread: a forward pass and the weight-gradient products that
@@ -1718,8 +1760,9 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
                             float* norms_out, uint32_t B_total = 0, uint32_t pos0 = 0, int* w_splits = nullptr, VaeStepPrep prep = VaeStepPrep(),
                             const SiteNoiseArgs* noise = nullptr)
 {
-    // w_splits != nullptr (single-device update): the split-K partial tiles of the weight-gradient products stay in ws.wpart
-    // and w_splits[0 .. n_blocks - 1] says how many each (k_vae_finalize sums them); otherwise ws.sums holds the reduced sums
+    // The split-K partial tiles of the weight-gradient products stay in ws.wpart.  w_splits != nullptr (single-device update):
+    // w_splits[0 .. n_blocks - 1] says how many each, and k_vae_finalize sums them; otherwise ONE launch (k_vae_tile_sums) sums
+    // them into ws.sums here.
     if (B_total == 0) B_total = B;
     int rc;
     const VaeNet N = vae_net(m);
@@ -1814,7 +1857,9 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     // single-device update: the products go out as ONE grouped launch with a common K range per workgroup
     static const bool no_group = getenv("D3P_VAE_NO_GROUP") != nullptr;   // developer switch (A/B), read once
     GemmGroupPlan plan;
-    GemmGroupPlan* group = (w_splits && !no_group) ? &plan : nullptr;
+    GemmGroupPlan* group = !no_group ? &plan : nullptr;
+    int splits_here[D3P_VAE_MAX_BLOCKS] = {0};
+    int* const tile_splits = w_splits ? w_splits : splits_here;
     int group_splits = 0;
     if (group) {
         unsigned tiles = 0;
@@ -1822,21 +1867,20 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
         group_splits = gemm_group_splits(tiles, Bi);
     }
     for (int b = 0; b < n_wg; ++b) {
-        float* part = w_splits ? ws.wpart + (size_t)D3P_WPART_SPLITS * wg[b].off : ws.part;
-        const size_t part_floats = w_splits ? (size_t)D3P_WPART_SPLITS * (wg[b].in + 1) * wg[b].out : ws.part_floats;
+        float* part = ws.wpart + (size_t)D3P_WPART_SPLITS * wg[b].off;
+        const size_t part_floats = (size_t)D3P_WPART_SPLITS * (wg[b].in + 1) * wg[b].out;
         int left = 0;
         // (A = X^T: the flag of the forward pass holds -- same batch; the virtual row of ones is exact too)
         const uint32_t* xflag = (wg[b].A == X && vae_exact_eligible(X, B, D)) ? ws.x_exact16 : nullptr;
         if ((rc = gemm(s, wg[b].A, 1, wg[b].a_sk, wg[b].Bm, wg[b].ldb, 1, S + wg[b].off, wg[b].ldc, wg[b].in + 1, wg[b].out, Bi, nullptr, 1.f, 0, 1,
-                       part, part_floats, 0, nullptr, w_splits ? &left : nullptr, wg[b].j, nullptr, nullptr, 0, 0.f, xflag, vae_exact_nonce(false),
+                       part, part_floats, 0, nullptr, &left, wg[b].j, nullptr, nullptr, 0, 0.f, xflag, vae_exact_nonce(false),
                        group, group_splits, scale_in_gemm ? ws.cf : nullptr)))
             return rc;
-        if (w_splits) {
-            w_splits[wg[b].blk] = left;
-            if (b == n_wg - 1) w_splits[wg[b].blk + 1] = left;
-        }
+        tile_splits[wg[b].blk] = left;
+        if (b == n_wg - 1) tile_splits[wg[b].blk + 1] = left;
     }
     if (group && (rc = gemm_group_launch(s, plan))) return rc;
+    if (!w_splits) hipLaunchKernelGGL(k_vae_tile_sums, dim3(cdiv(N.P, 256)), dim3(256), 0, s, vae_tiles(N, ws, tile_splits), S, N.P);
     return check_launch("d3p_vae sums");
 }
 
@@ -2042,7 +2086,6 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
     vae_carve(model, B_local, (char*)workspace_dev, &ws);
     hipStream_t s = (hipStream_t)stream;
     const VaeNet N = vae_net(model);
-    const int nh = N.nh, n_blocks = N.n_blocks();
     int rc;
     if (derive_keys && (rc = vae_step_keys(s, model, state, ws, true))) return rc;
     if (derive_keys || !w_splits) {  // (the single-device update drew the noise beside its latent kernel: vae_local_sums_impl)
@@ -2052,28 +2095,7 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
     VaeFinalArgs f;
     memset(&f, 0, sizeof(f));
     f.sums = sums_dev;
-    f.wpart = w_splits ? ws.wpart : nullptr;
-    {
-        // [W | b] blocks of the flat layout: the dense layers, then Wl and Ws -- which come from ONE product with N = 2 Z:
-        // shared tiles of (HE + 1) x 2 Z in the region of the Wl block
-        for (int b = 0; b < n_blocks; ++b) {
-            const VaeDense* lay = N.block_layer(b);
-            const size_t first = lay ? lay->W : (b == 2 * nh + 1 ? N.Wl : N.Ws);
-            const size_t next = b + 1 < n_blocks ? (N.block_layer(b + 1) ? N.block_layer(b + 1)->W : (b + 1 == 2 * nh + 1 ? N.Wl : N.Ws)) : N.P;
-            f.w_off[b] = (uint32_t)first;
-            f.w_base[b] = (uint32_t)(D3P_WPART_SPLITS * first);
-            f.w_tile[b] = (uint32_t)(next - first);
-            f.w_ld[b] = f.w_out[b] = (uint32_t)(lay ? lay->out : N.Z);
-            f.w_coff[b] = 0;
-            f.w_splits[b] = w_splits ? w_splits[b] : 0;
-        }
-        const int bl = 2 * nh + 1, bs = 2 * nh + 2;
-        f.w_tile[bl] = f.w_tile[bs] = f.w_tile[bl] + f.w_tile[bs];
-        f.w_ld[bl] = f.w_ld[bs] = 2u * (uint32_t)N.Z;
-        f.w_base[bs] = f.w_base[bl];
-        f.w_coff[bs] = (uint32_t)N.Z;
-        for (int b = n_blocks; b <= D3P_VAE_MAX_BLOCKS; ++b) f.w_off[b] = (uint32_t)N.P;
-    }
+    f.tiles = vae_tiles(N, ws, w_splits);
     f.noise = ws.noise;
     f.in_params = from ? from->params : state->params;
     f.in_m = from ? from->adam_m : state->adam_m;

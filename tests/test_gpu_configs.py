@@ -263,3 +263,52 @@ def test_config4_vae_784_400_50_batch_4096(gpu, O, H2):
     assert float((norms > clip).float().mean()) > 0.2 and float((norms < clip).float().mean()) > 0.2
     again, _, _ = run(None, clip)
     assert torch.equal(again, full)
+
+
+@pytest.mark.parametrize("H2", [0, 200])
+def test_config4_update_is_the_composition_of_its_stages_at_batch_4096(gpu, O, H2):
+    """DPSVI.update at configs[4]'s full size takes launches no small shape takes: the weight-gradient products as ONE grouped
+    launch with a common K range (k_gemm_bf16x3_group), the clip factors applied while those products stage their deltas, the
+    exactness pass and the packing of the latent heads inside the key launch, the noise beside the latent kernel.  Its gradient
+    must be what the stages give one by one: eps from the gradient key (oracle, svi.py:289-290), the clipped sums of
+    d3p_vae_step_sums on that eps (products launched and reduced one by one: the path the test above pins to the oracle),
+    the oracle's perturbation (one key per leaf, svi.py:487-491) and Adam."""
+    import d3p_amd._lib as lib
+    import d3p_amd.random as rng
+    from d3p_amd.svi import DPSVIState
+    from tests.test_gpu_vae import make_svi, vae_problem
+    B, D, H, Z, N = 4096, 784, 400, 50, 60000
+    spec, P, params, X, _ = vae_problem(B, D, H, Z, 31, 0.03, H2)
+    mask = np.random.default_rng(6).random(B) < 0.9
+    svi = make_svi(Z, H, N, C=3.0, sigma=0.8, lr=1e-2, H2=H2)
+    st = DPSVIState(svi.optim.init(torch.tensor(params).cuda()), rng.PRNGKey(78), 1.0)
+    Xt = torch.tensor(X).cuda()
+    gout = torch.empty(P, device="cuda")
+    new_st, loss = svi.update(st, Xt, mask=torch.tensor(mask).cuda(), _grad_out=gout)
+
+    ks = O.split(O.PRNGKey(78), 3)
+    eps = O.px_eps(O.convert_to_jax_rng_key(ks[1]), B, Z)
+    L = lib.load()
+    model = lib.VaeModel(D, H, Z, 1.0, 1.0, H2)   # (plate(N) x handlers.scale(1 / N) = 1; observation_scale 1)
+    ws = torch.empty(int(L.d3p_dpvi_vae_workspace(C.byref(model), B)), dtype=torch.uint8, device="cuda")
+    sums, norms, pxl = torch.empty(P + 2, device="cuda"), torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    pt, et, mt = torch.tensor(params).cuda(), torch.tensor(eps).cuda(), torch.tensor(mask).to(torch.uint8).cuda()
+    lib.check(L.d3p_vae_step_sums(lib.stream_ptr(), C.byref(model), lib.ptr(pt), lib.ptr(Xt), lib.ptr(mt), B, lib.ptr(et), None,
+                                  3.0, lib.ptr(sums), lib.ptr(norms), lib.ptr(pxl), lib.ptr(ws), ws.numel()))
+    sums = np_(sums)
+    n = sums[P + 1]
+    assert n == mask.sum() and float((norms > 3.0).float().mean()) > 0.05
+    f = B / n
+    g = O.perturb(ks[2], sums[:P] / B, O.vae_leaf_sizes(D, H, Z, H2), 0.8, 3.0, n, 1.0, f)
+    x, m, v = O.adam(params, np.zeros(P), np.zeros(P), g, 0, lr=1e-2)
+    eloss = sums[P] / B * f
+    assert abs(float(loss) - eloss) <= 5e-5 * abs(eloss)
+    np.testing.assert_allclose(np_(gout), g, rtol=2e-4, atol=2e-5 * np.abs(g).max())
+    # Adam's first step is lr g / (|g| + 1e-8): where a gradient component is ~ 0 (a handful of the 689 k) its relative error is
+    # the step's -- compare the parameters where the gradient is not negligible, and bound the step elsewhere
+    big = np.abs(g) > 1e-4 * np.abs(g).max()
+    assert big.mean() > 0.99
+    got_x = np_(new_st.optim_state[1])
+    np.testing.assert_allclose(got_x[big], x[big], rtol=1e-4, atol=2e-5)
+    assert np.all(np.abs(got_x - params) <= 1e-2 * (1 + 1e-5))
+    assert np.array_equal(np_(new_st.rng_key), ks[0]) and int(new_st.optim_state[0]) == 1

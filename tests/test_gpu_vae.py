@@ -194,8 +194,10 @@ def make_svi(Z, H, N, C=10.0, sigma=1.0, lr=1e-3, H2=0):
                  hidden_dim=(H, H2) if H2 else H)
 
 
+# (B = 136: three of the four weight-gradient products take the bf16 kernel and go out as one grouped launch, the fourth -- 51 rows --
+# by itself; the clip factors come back through the norm kernel's scaled rows)
 @pytest.mark.parametrize("B,D,H,Z,masked,H2", [(6, 12, 7, 3, False, 0), (40, 784, 400, 50, True, 0), (6, 12, 7, 3, True, 5),
-                                               (40, 784, 400, 50, False, 200)])
+                                               (40, 784, 400, 50, False, 200), (136, 784, 400, 50, True, 0)])
 def test_update_vs_oracle_stage_composition(gpu, O, B, D, H, Z, masked, H2):
     """DPSVI.update for the VAE: split(key, 3); per-example eps from the gradient key (svi.py:289-290); clipped sums;
     one perturbation key per parameter leaf in tree_flatten order (svi.py:487-491); numpyro Adam."""
@@ -222,7 +224,13 @@ def test_update_vs_oracle_stage_composition(gpu, O, B, D, H, Z, masked, H2):
     eloss = sums[P] / B * f
     assert abs(float(loss) - eloss) <= 5e-5 * abs(eloss)
     np.testing.assert_allclose(np_(gout), g, rtol=2e-4, atol=2e-5 * np.abs(g).max())
-    np.testing.assert_allclose(np_(new_st.optim_state[1]), x, rtol=1e-4, atol=2e-5)
+    # (Adam's first step is lr g / (|g| + 1e-8): where a gradient component is ~ 0 -- one in a million at P = 689 k -- the step has the
+    # relative error of that component; the parameters are compared where the gradient is not negligible, the step is bounded elsewhere)
+    big = np.abs(g) > 1e-4 * np.abs(g).max()
+    assert big.mean() > 0.99
+    got_x = np_(new_st.optim_state[1])
+    np.testing.assert_allclose(got_x[big], x[big], rtol=1e-4, atol=2e-5)
+    assert np.all(np.abs(got_x - params) <= 1e-2 * (1 + 1e-5))
     assert np.array_equal(np_(new_st.rng_key), ks[0]) and int(new_st.optim_state[0]) == 1
     tree = svi.get_params(new_st)
     HE = H2 if H2 else H
