@@ -836,21 +836,27 @@ class DPSVI:
                 and v0.numel() == n and params0.is_contiguous() and m0.is_contiguous() and v0.is_contiguous()
                 and key0.is_contiguous() and key0.dtype == torch.uint32 and step0.dtype == torch.int32):
             # the new state is written by the run itself (d3p_dpvi_logreg_run_from copies the old one inside its first kernel):
-            # no copy / fill launches on the host's enqueue path -- they were ~80 us of a 20-step run.  Losses and the three
-            # state arrays are views of ONE allocation (one allocator call and one split instead of two calls and six views:
-            # the host's 17 us in front of the first launch are part of a short run's wall time)
-            params, m, v, losses = torch.empty(3 * n + nl, dtype=torch.float32, device=dev).split((n, n, n, nl))   # (state first: its alignment is that of three separate arrays of n)
-            if params0.dim() != 1:
-                params, m, v = params.view_as(params0), m.view_as(m0), v.view_as(v0)
-            step = torch.empty_like(step0)
-            keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
+            # no copy / fill launches on the host's enqueue path -- they were ~80 us of a 20-step run.  Everything the run
+            # writes -- the three state arrays, the losses, the step counter, the two key slots -- is ONE allocation, handed
+            # to the library as raw addresses; the tensors the caller gets back are views of it made AFTER the enqueue, while
+            # the device is already running (what the host does in front of the first launch is wall time of a short run: 17 us
+            # of a 20-step run's 205 before, 9 now)
+            # layout in 4-byte words: [params n | m n | v n | losses nl | step 1 | pad to 4 | key slots 2 x 16]
+            koff = (3 * n + nl + 1 + 3) & ~3
+            buf = torch.empty(koff + 32, dtype=torch.float32, device=dev)
+            base = buf.data_ptr()
             bidx = None
             src = BatchSource(info.kind, info.batch_size, float(info.q), int(info.suppress), bkey.data_ptr(), None, None, N, 0, N)
-            st = self._state_struct(keybuf, 0, (step, params, m, v))
-            frm = self._state_struct(key0, 0, (step0, params0, m0, v0))
+            st = DpsviState(base + 4 * koff, 0, base, base + 4 * n, base + 8 * n, base + 4 * (3 * n + nl))
+            frm = DpsviState(key0.data_ptr(), 0, params0.data_ptr(), m0.data_ptr(), v0.data_ptr(), step0.data_ptr())
             ws = self._workspace(lib.d3p_dpvi_logreg_workspace(C.byref(model), C.byref(src)), dev)
             check(lib.d3p_dpvi_logreg_run_from(stream_ptr(), C.byref(model), C.byref(hyper), C.byref(st), C.byref(frm), C.byref(src),
-                                               int(first_batch), ptr(X), ptr(y), int(num_steps), ptr(losses), ptr(ws), ws.numel()))
+                                               int(first_batch), ptr(X), ptr(y), int(num_steps), base + 12 * n, ptr(ws), ws.numel()))
+            params, m, v, losses, tail = buf.split((n, n, n, nl, koff + 32 - 3 * n - nl))
+            if params0.dim() != 1:
+                params, m, v = params.view_as(params0), m.view_as(m0), v.view_as(v0)
+            step = tail[0].view(torch.int32)
+            keybuf = tail[koff - 3 * n - nl:].view(torch.uint32).view(2, 16)
         else:
             losses = torch.empty(nl, dtype=torch.float32, device=dev)
             step, params, m, v = _fresh_optim_state(svi_state.optim_state)

@@ -1,6 +1,7 @@
 # Timeline of one short run_steps call: prints the wall time of N repetitions and leaves a rocprofv3 trace when run under it.
 import sys, time, torch, numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import d3p_amd.random as rng
 from d3p_amd.svi import DPSVI, DPSVIState
 from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
