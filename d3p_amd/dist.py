@@ -89,6 +89,50 @@ class HipEngine:
         self.done = 0
         self.remaining = None
 
+    def _setup_lean(self, state, batch_key, first_batch, nl):
+        """run_steps_native's set-up for a state the native run can copy by itself (contiguous fp32 arrays): ONE allocation for
+        the new state, the losses, the step counter and the key slots -- [params n | m n | v n | losses nl | step | pad | 2 x 16
+        key words] in 4-byte words --, raw addresses in the structs, no tensor views yet (_lean_views).  False: not applicable."""
+        from ._lib import DpsviState
+        step0, params0, m0, v0 = state.optim_state
+        key0 = state.rng_key.reshape(16)
+        n = params0.numel()
+        if not (params0.dtype == m0.dtype == v0.dtype == torch.float32 and m0.numel() == n and v0.numel() == n
+                and params0.is_contiguous() and m0.is_contiguous() and v0.is_contiguous() and key0.is_contiguous()
+                and key0.dtype == torch.uint32 and step0.dtype == torch.int32):
+            return False
+        self.model = self.svi._model_struct(self.d, self.model_kwargs, state.observation_scale)
+        self.hyper = self.svi._hyper()
+        self.bkey = batch_key.contiguous()
+        koff = (3 * n + nl + 1 + 3) & ~3
+        buf = torch.empty(koff + 32, dtype=torch.float32, device=self.dev)
+        base = buf.data_ptr()
+        self._lean = (buf, n, nl, koff, params0, m0, v0)
+        self._losses_ptr = base + 12 * n
+        self._from_keep = (step0, params0, m0, v0, key0)
+        self.frm = DpsviState(key0.data_ptr(), 0, params0.data_ptr(), m0.data_ptr(), v0.data_ptr(), step0.data_ptr())
+        self.st = DpsviState(base + 4 * koff, 0, base, base + 4 * n, base + 8 * n, base + 4 * (3 * n + nl))
+        self.bidx = None
+        self.src = BatchSource(self.kind, self.B, self.q, int(self.suppress), self.bkey.data_ptr(), None, None, self.n, self.lo, self.hi)
+        nbytes = _lib.load().d3p_dpvi_logreg_workspace(C.byref(self.model), C.byref(self.src))
+        if getattr(self, "ws", None) is None or self.ws.numel() < nbytes:   # kept across runs
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        self.observation_scale = state.observation_scale
+        self._args = (C.byref(self.model), C.byref(self.hyper), C.byref(self.st), C.byref(self.src))
+        self.t = self.prepared = self.done = 0
+        self.remaining = None
+        return True
+
+    def _lean_views(self):
+        """The tensors of _setup_lean's allocation (made after the run has been enqueued); returns the losses."""
+        buf, n, nl, koff, params0, m0, v0 = self._lean
+        params, m, v, losses, tail = buf.split((n, n, n, nl, koff + 32 - 3 * n - nl))
+        self.params, self.m, self.v = params.view_as(params0), m.view_as(m0), v.view_as(v0)
+        self.step = tail[0].view(torch.int32)
+        self.keybuf = tail[koff - 3 * n - nl:].view(torch.uint32).view(2, 16)
+        self.loss = None
+        return losses
+
     STEP_BATCH = 32
 
     def plan(self, num_steps):
@@ -278,6 +322,19 @@ def run_steps_native(engine, state, batch_key, first_batch, num_steps, comm=None
     an XchgComm (one-shot full-mesh exchange, d3p_dpvi_logreg_run_xchg) or None (single rank).
     `engine` is a FusedHipEngine (it supplies the shard and the model)."""
     from .svi import DPSVIState
+    if engine._setup_lean(state, batch_key, first_batch, max(int(num_steps), 1)):
+        # (everything the run writes is one allocation handed over as raw addresses; the views are made after the enqueue,
+        # while the device is already running -- what the host does in front of the first launch is wall time of a short run)
+        is_x = isinstance(comm, XchgComm)
+        check(_lib.load().d3p_dpvi_logreg_run_dist_from(
+            stream_ptr(), comm.handle if (comm is not None and not is_x) else None, comm.handle if is_x else None,
+            engine._args[0], engine._args[1], engine._args[2], C.byref(engine.frm), engine._args[3], int(first_batch),
+            ptr(engine.X), ptr(engine.y), int(num_steps), engine._losses_ptr if collect_losses else None, ptr(engine.ws),
+            engine.ws.numel()))
+        losses = engine._lean_views()
+        new_state = DPSVIState((engine.step, engine.params, engine.m, engine.v),
+                               engine.keybuf[int(num_steps) & 1].reshape(4, 4), engine.observation_scale)
+        return new_state, (losses[:int(num_steps)] if collect_losses else None)
     engine._setup(state, batch_key, first_batch, copy=False)
     losses = torch.zeros(max(int(num_steps), 1), dtype=torch.float32, device=engine.dev) if collect_losses else None
     if engine.frm is not None:
