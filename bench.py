@@ -175,7 +175,7 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
         wall, ev = timed(run, 256, steps)   # (13 ms of warm-up: see the VAE leg)
         P = K + K * d
         alg = B * (4 * d + 4) + 3 * 4 * P                          # 2 175 168 B per step
-        # wave64 VALU instructions per step, measured with SQ_INSTS_VALU (profiles/r03_gmm_pmc.json: k_gmm_px 18.46 M, k_gmm_head 3.24 M)
+        # wave64 VALU instructions per step, measured with SQ_INSTS_VALU (profiles/r04_gmm_pmc.json: k_gmm_px 18.46 M, k_gmm_head 3.25 M; unchanged since round 3)
         valu = 21.7e6
         out["gmm_config3"] = {
             "workload": "BASELINE configs[2]: mixture model K=16 d=64, N=1e7 rows resident, batch 8192 (Feistel), C=20, sigma=1, Adam 1e-3",
@@ -186,7 +186,7 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
                          # (what the step achieves, for comparison with the per-opcode rates of profiles/r03_valu_opcodes.json:
                          # VOP2 2.4, VOP3 / DPP / packed 4.3, transcendental 8.3 cycles per wave64 instruction and SIMD)
                          "cycles_per_valu_instruction_and_simd": round(ev / steps * SHADER_GHZ * 1e9 * SIMDS / valu, 2),
-                         "valu_instructions_per_step": valu, "instruction_count_source": "profiles/r03_gmm_pmc.json (SQ_INSTS_VALU of "
+                         "valu_instructions_per_step": valu, "instruction_count_source": "profiles/r04_gmm_pmc.json (SQ_INSTS_VALU of "
                          "k_gmm_px + k_gmm_head); not re-counted in this run",
                          "hbm": {"algorithmic_bytes_per_step": alg, "achieved_GBps": round(alg * steps / ev / 1e9, 2),
                                  "frac": round(alg * steps / ev / 1e9 / HBM_PEAK_GBPS, 5)},
