@@ -532,6 +532,7 @@ def main():
                 "algorithmic_bytes_per_step": alg_step}
 
     aux = {}   # the other BASELINE workloads (single-GPU runs): filled by measure()
+    progress = {}   # rank 0: the line's fields as soon as the headline leg of a measure() call is done (the legs behind it fill in)
 
     def measure(native, extra_legs):
         """All GPU legs with one driver; returns the fields of the JSON line (rank 0) or None."""
@@ -610,7 +611,20 @@ def main():
 
         del table, run, state, state0, svi
         torch.cuda.empty_cache()
+        B_done = Bg // emu if emu else Bg   # (--emulate-world runs ONE rank's share: the examples this GPU processed, not the job's)
+        result = None
+        if rank == 0:
+            result = {"value": round(B_done * steps_per_s, 1), "steps_per_sec": round(steps_per_s, 2),
+                      "ms_per_step": round(1000.0 * elapsed / args.steps, 6), "final_loss": final_loss, "steady_state": steady,
+                      "north_star_N1e7": None, "roofline": roofline, "rows": n_rows,
+                      "leg_order": ("steady_state, headline, north_star_N1e7 (+ poisson_N1e7 on the same table), large_batch, gmm_config3, "
+                                    "vae_config5, vae_config5_400_200" if extra_legs else "headline only (cold GPU)"),
+                      "driver": "single-GPU chained launch" if single else (dist_driver if (native and comm is not None) else "torch")}
+            if native:
+                progress["m"] = result   # (what the watchdog prints should a LATER leg of the native loop stall)
 
+        if native and os.environ.get("D3P_BENCH_INJECT_STOP"):   # developer switch: rehearse the "a later leg was stopped" exit
+            raise RunStopped(f"rank {rank}: injected stop behind the headline leg")
         # ---------------------------------------------------------------- north_star: the same workload over N = 10^7 rows
         north = None
         if extra_legs and args.sampler == "feistel":
@@ -658,13 +672,8 @@ def main():
                 aux["vae_config5_dp_error"] = f"{type(e).__name__}: {e}"
         if rank != 0:
             return None
-        B_done = Bg // emu if emu else Bg   # (--emulate-world runs ONE rank's share: the examples this GPU processed, not the job's)
-        return {"value": round(B_done * steps_per_s, 1), "steps_per_sec": round(steps_per_s, 2),
-                "ms_per_step": round(1000.0 * elapsed / args.steps, 6), "final_loss": final_loss, "steady_state": steady,
-                "north_star_N1e7": north, "roofline": roofline, "rows": n_rows,
-                "leg_order": ("steady_state, headline, north_star_N1e7 (+ poisson_N1e7 on the same table), large_batch, gmm_config3, "
-                              "vae_config5, vae_config5_400_200" if extra_legs else "headline only (cold GPU)"),
-                "driver": "single-GPU chained launch" if single else (dist_driver if (native and comm is not None) else "torch")}
+        result["north_star_N1e7"] = north
+        return result
 
     def line(m, cpu=None, extra=None):
         out = {
@@ -703,8 +712,13 @@ def main():
 
         def give_up():
             if rank == 0:
-                print(line(fb, extra={"note": "native data-parallel loop did not finish within the watchdog limit; this is "
-                                              "the Python-driven torch.distributed loop"}), flush=True)
+                if progress.get("m") is not None:   # the native headline leg is done: a leg BEHIND it stalled
+                    print(line(progress["m"], extra={"note": "a leg behind the headline leg did not finish within the watchdog limit and was "
+                                                             "cut; the headline figures are the native data-parallel loop's",
+                                                     "torch_loop": {"steps_per_sec": fb["steps_per_sec"], "value": fb["value"]}}), flush=True)
+                else:
+                    print(line(fb, extra={"note": "native data-parallel loop did not finish within the watchdog limit; this is "
+                                                  "the Python-driven torch.distributed loop"}), flush=True)
             os._exit(0)
         dog = threading.Timer(float(os.environ.get("D3P_BENCH_WATCHDOG_S", "240")), give_up)
         dog.daemon = True
@@ -714,8 +728,13 @@ def main():
         except RunStopped as e:   # every rank ends up here (a stopped rank sends no rows: its peers' waits run out too)
             print(f"[bench] {e}", file=sys.stderr, flush=True)
             if rank == 0:
-                print(line(fb, extra={"note": f"native data-parallel loop stopped ({e}); this is the Python-driven "
-                                              "torch.distributed loop"}), flush=True)
+                if progress.get("m") is not None:
+                    print(line(progress["m"], extra={"note": f"a leg behind the headline leg was stopped ({e}) and cut; the headline figures "
+                                                             "are the native data-parallel loop's",
+                                                     "torch_loop": {"steps_per_sec": fb["steps_per_sec"], "value": fb["value"]}}), flush=True)
+                else:
+                    print(line(fb, extra={"note": f"native data-parallel loop stopped ({e}); this is the Python-driven "
+                                                  "torch.distributed loop"}), flush=True)
             os._exit(0)
         barrier()
         dog.cancel()
