@@ -412,6 +412,54 @@ def test_vae_virtual_ranks_on_one_gpu_match_single_rank(gpu, O, B, D, H, Z, worl
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_vae_virtual_ranks_at_config4_batch_match_single_rank(gpu, world):
+    """BASELINE configs[4]'s batch (4096) sharded by position over 2 / 8 virtual ranks: at these sizes a rank's weight-gradient
+    products go out as ONE grouped launch (all four members at 2048 rows per rank; three of the four at 512, the 51-row one by
+    itself), their tiles summed by k_vae_tile_sums, the clip factors applied inside the products.  The added partial sums give
+    the single-rank DPSVI.update (which tests/test_gpu_configs.py pins to the oracle at this size) up to the float order of the
+    sums; replicas are bitwise identical."""
+    import d3p_amd.random as rng
+    from d3p_amd.dist import VaeHipEngine, shard_batch
+    from d3p_amd.models import Adam, Trace_ELBO, VAEGuide, VAEModel
+    from d3p_amd.svi import DPSVI, DPSVIState
+    B, D, H, Z, N = 4096, 784, 400, 50, 60000
+    r = np.random.default_rng(23)
+    P = Z * H + H + H * D + D + D * H + H + 2 * (H * Z + Z)
+    params = (0.03 * r.normal(size=P)).astype(np.float32)
+    X = (r.random((B, D)) < 0.4).astype(np.float32)
+    model = VAEModel(z_dim=Z, hidden_dim=H, scale=1.0 / N)
+
+    def make():
+        return DPSVI(model, VAEGuide(model), Adam(1e-2), Trace_ELBO(), 3.0, 0.8, num_obs_total=N)
+    st = DPSVIState(make().optim.init(torch.tensor(params).cuda()), rng.PRNGKey(79), 1.0)
+    Xt = torch.tensor(X).cuda()
+    gref = torch.empty(P, device="cuda")
+    ref_state, ref_loss = make().update(st, Xt, _grad_out=gref)
+    engines, parts = [], []
+    for rk in range(world):
+        pos0, b_local = shard_batch(B, rk, world)
+        e = VaeHipEngine(make())
+        e.begin(st, Xt[pos0:pos0 + b_local], B, pos0)
+        parts.append(e.local_sums().clone())
+        engines.append(e)
+    total = torch.stack(parts).sum(dim=0)
+    assert float(total[P + 1]) == B
+    outs = [e.apply(total.clone()) for e in engines]
+    for s2, l2 in outs[1:]:
+        assert torch.equal(s2.optim_state[1], outs[0][0].optim_state[1]) and float(l2) == float(outs[0][1])
+    s0, l0 = outs[0]
+    assert torch.equal(s0.rng_key, ref_state.rng_key)
+    assert abs(float(l0) - float(ref_loss)) <= 2e-5 * abs(float(ref_loss))
+    # (Adam's first step is lr g / (|g| + 1e-8): compared where the gradient is not negligible -- tests/test_gpu_vae.py)
+    g = gref.cpu().numpy()
+    big = np.abs(g) > 1e-4 * np.abs(g).max()
+    np.testing.assert_allclose(s0.optim_state[1].cpu().numpy()[big], ref_state.optim_state[1].cpu().numpy()[big], rtol=1e-4, atol=2e-5)
+    m0, mr = s0.optim_state[2].cpu().numpy(), ref_state.optim_state[2].cpu().numpy()      # m = 0.1 g: the gradient itself
+    np.testing.assert_allclose(m0, mr, rtol=2e-4, atol=2e-5 * np.abs(mr).max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,K,d,world", [(64, 3, 2, 2), (200, 16, 64, 4)])
 def test_gmm_virtual_ranks_on_one_gpu_match_single_rank(gpu, B, K, d, world):
     """The mixture-model step with the batch sharded by position over `world` virtual ranks on one device: per-example site
