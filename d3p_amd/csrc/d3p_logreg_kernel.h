@@ -1246,7 +1246,9 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g, boo
     // 16-byte aligned.  (Measured: extending it to rows whose second half is not -- odd halves, the intercept column -- with
     // scalar second-half loads gains little there (d = 512 + intercept 32 -> 29 us/step) and costs the aligned shapes 2 us
     // of extra spills (d = 256: 14.0 -> 16.1), so those shapes stay on the scalar-load form.)
-    const bool vec = !m->intercept && (m->d % 8 == 0);
+    // (and only pays when a half is wider than a wave: for d <= 128 the scalar-load form runs one column per lane without the
+    // per-element predicates of a partly filled V = 4 tile -- d = 16 .. 128 at batch 4096: 18 - 19 us per step with V = 4, 8 - 9 with V = 1)
+    const bool vec = !m->intercept && (m->d % 8 == 0) && half > 64;
     g->V = vec ? 4 : 1;
     const int need = (half + 64 * g->V - 1) / (64 * g->V);
     g->NK = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 0;

@@ -27,6 +27,6 @@ def run(d, icpt, B, N=200000, steps=960):
     print(f"d={d} intercept={icpt} B={B}: {dt / steps * 1e6:.2f} us/step  loss {float(losses[-1]):.3f}", flush=True)
 
 if __name__ == "__main__":
-    for d, icpt, B in ((512, False, 4096), (512, True, 4096), (256, False, 4096), (256, True, 4096), (64, True, 1024),
+    for d, icpt, B in ((4, True, 4096), (4, True, 256), (16, False, 4096), (512, False, 4096), (512, True, 4096), (256, False, 4096), (256, True, 4096), (64, True, 1024),
                        (1024, False, 4096), (1024, True, 4096), (100, False, 4096), (300, False, 4096), (2048, False, 4096)):
         run(d, icpt, B)
