@@ -1246,9 +1246,11 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g, boo
     // 16-byte aligned.  (Measured: extending it to rows whose second half is not -- odd halves, the intercept column -- with
     // scalar second-half loads gains little there (d = 512 + intercept 32 -> 29 us/step) and costs the aligned shapes 2 us
     // of extra spills (d = 256: 14.0 -> 16.1), so those shapes stay on the scalar-load form.)
-    // (and only pays when a half is wider than a wave: for d <= 128 the scalar-load form runs one column per lane without the
-    // per-element predicates of a partly filled V = 4 tile -- d = 16 .. 128 at batch 4096: 18 - 19 us per step with V = 4, 8 - 9 with V = 1)
-    const bool vec = !m->intercept && (m->d % 8 == 0) && half > 64;
+    // (and only pays as a FULL tile -- D = 512 or 1024, logistic regression: every lane / slot predicate folds away.  A partly filled
+    // V = 4 tile carries per-element predicates and loses to the scalar-load form at every width measured, batch 4096: d = 16 .. 128:
+    // 18 - 19 us per step against 8.5; d = 192, 256: 20 against 10.8; d = 320 .. 448: 21 against 21; d = 640, 768: 36 - 37 against 34 - 35)
+    // Beyond D = 1024 the scalar-load form has no tile (8 x 64 columns per half): those rows keep V = 4.
+    const bool vec = !m->intercept && (m->d % 8 == 0) && ((m->family == D3P_FAMILY_LOGREG && (m->d == 512 || m->d == 1024)) || half > 512);
     g->V = vec ? 4 : 1;
     const int need = (half + 64 * g->V - 1) / (64 * g->V);
     g->NK = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 0;
