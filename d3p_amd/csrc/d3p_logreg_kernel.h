@@ -430,8 +430,11 @@ struct ExLoad {
 // come through scalar loads.  The left-over pair (half - 1, -) is the "tail column": every lane computes it redundantly
 // (one more threefry call per example) and lane 0 owns its accumulators.
 // STAMPS: diagnostic instantiation of the chained form with phase stamps (D3P_DBG=32); production kernels carry none.
+// (the scalar-load form needs fewer registers per tile slot: V = 1, NK = 2 fits 16 waves -- 114 VGPRs --, V = 1, NK = 4 eight -- 174)
+#define D3P_MAIN_MAX_THREADS(V, NK) ((NK) == 1 ? 1024 : (NK) == 2 ? ((V) == 1 ? 1024 : 512) : ((NK) == 4 && (V) == 1) ? 512 : 256)
+#define D3P_MAIN_MAX_WAVES(V, NK) (D3P_MAIN_MAX_THREADS(V, NK) / 64)
 template <int V, int NK, int MODE, bool FULL, int EPS, bool TAIL = false, bool STAMPS = false>
-__global__ void __launch_bounds__(NK == 1 ? 1024 : NK == 2 ? 512 : 256) k_logreg_main(MainArgs a_in)
+__global__ void __launch_bounds__(D3P_MAIN_MAX_THREADS(V, NK)) k_logreg_main(MainArgs a_in)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool FUSE = MODE == 2 || MODE == 3;   // update applied in the prologue, fixed-point accumulators
@@ -1275,7 +1278,8 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g, boo
     if (too_wide && wide_ok) g->NK = 8;  // placeholder: only the chunked kernel is launched with this geometry
     // waves per workgroup (default 16 = one 1024-thread workgroup per CU at 4 waves/SIMD), reduced until
     // pack (5D) + reduction buffer (W x P) fit 64 KiB of LDS; one example per wave per pass.
-    int W = g->NK == 1 ? 16 : g->NK == 2 ? 8 : 4, epw = 1;
+    const int W_max = g->NK == 1 ? 16 : g->NK == 2 ? (g->V == 1 ? 16 : 8) : (g->NK == 4 && g->V == 1) ? 8 : 4;   // D3P_MAIN_MAX_WAVES
+    int W = W_max, epw = 1;
     {
         // One workgroup per CU and ceil(B / (W x CUs)) examples per wave: every workgroup pays the update prologue (48 KB
         // of replica / state reads) and P + 2 accumulator atomics per step, so more workgroups than CUs only multiplies
@@ -1296,7 +1300,7 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g, boo
     {  // developer overrides of the geometry (tuning sweeps), read once per process
         static const int env_w = [] { const char* e = getenv("D3P_MAIN_W"); return e ? atoi(e) : 0; }();
         static const int env_epw = [] { const char* e = getenv("D3P_MAIN_EPW"); return e ? atoi(e) : 0; }();
-        if (env_w >= 1 && env_w <= (g->NK == 1 ? 16 : g->NK == 2 ? 8 : 4)) W = env_w;
+        if (env_w >= 1 && env_w <= W_max) W = env_w;
         if (env_epw >= 1 && env_epw <= 64) epw = env_epw;
     }
     auto lds_bytes = [&](int w) { return main_lds_bytes(D, w); };
