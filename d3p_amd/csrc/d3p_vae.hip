@@ -89,6 +89,22 @@ __global__ void __launch_bounds__(256) k_exact16_flag(const float* __restrict__ 
     exact16_pass(x, n4, flag, nonce, blockIdx.x, gridDim.x);
 }
 
+// The run loop's batch: rows idx[0 .. B - 1] of the resident table gathered into xb (what d3p_take_rows does) AND the exactness
+// pass over them in the same sweep (the batch is read once instead of twice).  d4 = row length in 16-byte words.
+__global__ void __launch_bounds__(256) k_vae_gather_check(const float* __restrict__ table, const uint32_t* __restrict__ idx, uint32_t B, uint32_t d4,
+                                                          float* __restrict__ xb, uint32_t* __restrict__ flag, uint32_t nonce)
+{
+    uint32_t bad = 0u;
+    const size_t n = (size_t)B * d4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t row = (uint32_t)(e / d4), c = (uint32_t)(e % d4);
+        const uint4 v = reinterpret_cast<const uint4*>(table)[(size_t)idx[row] * d4 + c];
+        reinterpret_cast<uint4*>(xb)[e] = v;
+        bad |= (v.x | v.y | v.z | v.w) & 0xffffu;
+    }
+    if (flag && __ballot(bad != 0u) != 0ull && (threadIdx.x & 63) == 0) *flag = nonce;
+}
+
 // o = alpha * acc + bias (+ C); then the epilogue
 __device__ __forceinline__ void gemm_store(const GemmArgs& g, int row, int col, float acc, float bv)
 {
@@ -1467,12 +1483,46 @@ struct KeysExtra {
     const float *wl, *wsd;   // the heads' weights (HE x Z each)
     float *wcat, *wcatT;
     int HE, Z;
+    unsigned pack_blocks;
+    // the run loop's step (d3p_dpvi_vae_run): the workgroups behind the packing ones make the step's batch indices --
+    // fold_in(batch_key, batch_i) (minibatch.py:230), its 30 round constants, the Feistel permutation of positions 0 .. n_idx - 1
+    // (util.py:248-301), every workgroup deriving the constants for itself (two dependent quad-lane ChaCha blocks) like k_sampler
+    const uint32_t* batch_key;   // nullable
+    uint32_t batch_i, capacity, n_idx;
+    int bits_lower, bits_upper;
+    uint32_t* idx;
 };
 
 __global__ void __launch_bounds__(256) k_vae_keys(const uint32_t* __restrict__ cur_key, uint32_t* __restrict__ keys,
                                                   uint32_t* __restrict__ next_slot, const int32_t* __restrict__ step,
                                                   int32_t* __restrict__ step_out, int advance, int n_sites, KeysExtra ex)
 {
+    if (blockIdx.x > ex.x_blocks + ex.pack_blocks) {
+        __shared__ uint32_t f_key[16], f_rc[32];
+        const int tid = threadIdx.x, quad = tid >> 2, q = tid & 3;
+        if (quad == 0) {
+            uint32_t ka, kb;
+            derive_child_quad(ex.batch_key, 0u, D3P_TAG_FOLD, ex.batch_i, ka, kb);
+            f_key[q] = ex.batch_key[q];
+            f_key[4 + q] = ka;
+            f_key[8 + q] = kb;
+            f_key[12 + q] = 0u;
+        }
+        __syncthreads();
+        if (quad < 2) {  // round constants: keystream blocks 0, 1 (util.py:240-246), column 0 forced odd
+            uint32_t w[4];
+            keystream_block_quad(f_key, (uint32_t)quad, w[0], w[1], w[2], w[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int g = 16 * quad + 4 * i + q;
+                if (g < 30) f_rc[g] = (g % 3 == 0) ? (w[i] | 1u) : w[i];
+            }
+        }
+        __syncthreads();
+        const uint32_t p = (blockIdx.x - ex.x_blocks - ex.pack_blocks - 1) * blockDim.x + (uint32_t)tid;
+        if (p < ex.n_idx) ex.idx[p] = feistel_permute_dev(f_rc, ex.capacity, ex.bits_lower, ex.bits_upper, p);
+        return;
+    }
     if (blockIdx.x > ex.x_blocks) {
         const unsigned t = (blockIdx.x - ex.x_blocks - 1) * blockDim.x + threadIdx.x;
         const unsigned Z2 = 2u * ex.Z;
@@ -1576,6 +1626,15 @@ struct VaeWorkspace {
     uint32_t* keys;  // 3 x 16 split + up to 14 x 16 site keys + jax key + step index (D3P_VAE_KEY_*)
     uint32_t* x_exact16;  // one word: the batch X is exactly bf16 (GemmArgs::a_exact16), set per forward pass
     float *wcat, *wcatT;  // the latent heads packed for the step (k_vae_keys): [Wl | Ws] (HE x 2 Z) and its transpose
+};
+
+// one step of the native run loop (d3p_dpvi_vae_run): the batch is rows of a resident table, chosen by the Feistel sampler
+struct VaeRunStep {
+    const uint32_t* batch_key;   // batchifier state (device)
+    uint32_t batch_i;            // fold_in data: index of the batch (minibatch.py:230)
+    const float* table;          // n_rows x D
+    uint32_t n_rows;
+    uint32_t* idx;               // B indices (written)
 };
 
 // what the key launch of an update has already done for the passes that follow it (vae_step_keys)
@@ -1970,14 +2029,23 @@ static int vae_update_checks(const d3p_vae_model* model, const d3p_dpsvi_hyper* 
 // heads of `params` (the parameters that pass runs on), ride in this launch; *prep says which of them did
 static int vae_step_keys(hipStream_t s, const d3p_vae_model* model, const d3p_dpsvi_state* state, const VaeWorkspace& ws, bool advance,
                          const d3p_dpsvi_state* from = nullptr, const float* X = nullptr, uint32_t B = 0, const float* params = nullptr,
-                         VaeStepPrep* prep = nullptr)
+                         VaeStepPrep* prep = nullptr, const VaeRunStep* rs = nullptr)
 {
+    // rs != nullptr (the run loop): X is the batch buffer the step's rows are ABOUT to be gathered into -- this launch makes the
+    // indices, the caller gathers (and checks exactness) behind it
     const VaeNet N = vae_net(model);
     const int slot = state->key_slot & 1, n_sites = N.n_leaves();
     KeysExtra ex;
     memset(&ex, 0, sizeof(ex));
-    unsigned pack_blocks = 0;
-    if (X && prep && vae_exact_eligible(X, B, model->D)) {
+    unsigned pack_blocks = 0, feistel_blocks = 0;
+    if (rs) {
+        int bits = 0;   // bit_length(n_rows - 1), util.py:230
+        for (uint32_t v = rs->n_rows - 1; v; v >>= 1) ++bits;
+        ex.batch_key = rs->batch_key; ex.batch_i = rs->batch_i; ex.capacity = rs->n_rows; ex.n_idx = B;
+        ex.bits_lower = bits >> 1; ex.bits_upper = bits - (bits >> 1);
+        ex.idx = rs->idx;
+        feistel_blocks = cdiv(B, 256);
+    } else if (X && prep && vae_exact_eligible(X, B, model->D)) {
         ex.x = X;
         ex.x_n4 = (size_t)B * model->D / 4;
         ex.x_flag = ws.x_exact16;
@@ -1993,7 +2061,8 @@ static int vae_step_keys(hipStream_t s, const d3p_vae_model* model, const d3p_dp
         pack_blocks = cdiv((uint64_t)N.HE * 2 * N.Z, 256);
         prep->heads_packed = true;
     }
-    const dim3 grid(1 + ex.x_blocks + pack_blocks);
+    ex.pack_blocks = pack_blocks;
+    const dim3 grid(1 + ex.x_blocks + pack_blocks + feistel_blocks);
     if (from)
         hipLaunchKernelGGL(k_vae_keys, grid, dim3(256), 0, s, (const uint32_t*)(from->rng_key + 16 * (from->key_slot & 1)), ws.keys,
                            state->rng_key + 16, (const int32_t*)from->step, state->step, advance ? 1 : 0, n_sites, ex);
@@ -2034,8 +2103,9 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
 static int vae_local_sums_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                                const float* X_dev, const uint8_t* mask_dev, uint32_t B_local, uint32_t B_total, uint32_t pos0,
                                const float* eps_dev, float* sums_dev, void* workspace_dev, size_t workspace_bytes, bool advance,
-                               int* w_splits = nullptr, const d3p_dpsvi_state* from = nullptr)
+                               int* w_splits = nullptr, const d3p_dpsvi_state* from = nullptr, const VaeRunStep* rs = nullptr)
 {
+    // rs != nullptr: X_dev is the batch BUFFER; the step's rows are gathered into it here (indices from the key launch)
     if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_local_sums")) return rc;
     D3P_REQUIRE(X_dev && sums_dev, "d3p_dpvi_vae_local_sums: null pointer");
     D3P_REQUIRE(B_local >= 1 && (uint64_t)pos0 + B_local <= B_total, "d3p_dpvi_vae_local_sums: need 1 <= B_local and pos0 + B_local <= B_total");
@@ -2045,7 +2115,16 @@ static int vae_local_sums_impl(void* stream, const d3p_vae_model* model, const d
     hipStream_t s = (hipStream_t)stream;
     int rc;
     VaeStepPrep prep;
-    if ((rc = vae_step_keys(s, model, state, ws, advance, from, X_dev, B_local, from ? from->params : state->params, &prep))) return rc;
+    if ((rc = vae_step_keys(s, model, state, ws, advance, from, X_dev, B_local, from ? from->params : state->params, &prep, rs))) return rc;
+    if (rs) {   // gather + exactness pass in one sweep (d3p_take_rows and k_exact16_flag's work)
+        const bool chk = vae_exact_eligible(X_dev, B_local, model->D);
+        const uint32_t d4 = (uint32_t)model->D / 4;
+        const size_t n = (size_t)B_local * d4;
+        hipLaunchKernelGGL(k_vae_gather_check, dim3((unsigned)(n / 512 < 1 ? 1 : (n / 512 > 2048 ? 2048 : n / 512))), dim3(256), 0, s, rs->table,
+                           (const uint32_t*)rs->idx, B_local, d4, const_cast<float*>(X_dev), chk ? ws.x_exact16 : (uint32_t*)nullptr,
+                           chk ? vae_exact_nonce(true) : 0u);
+        prep.x_checked = chk;
+    }
     // w_splits != nullptr = the single-device update: vae_apply_impl follows on the same workspace with these keys, so its noise is
     // drawn here, beside the latent kernel
     const SiteNoiseArgs noise = vae_site_noise_args(vae_net(model), ws);
@@ -2137,9 +2216,9 @@ int d3p_dpvi_vae_update_from(void* stream, const d3p_vae_model* model, const d3p
                           w_splits, from);
 }
 
-int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
-                        const float* X_dev, const uint8_t* mask_dev, uint32_t B, const float* eps_dev, float* loss_dev,
-                        float* grad_out_dev, void* workspace_dev, size_t workspace_bytes)
+static int vae_update_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                           const float* X_dev, const uint8_t* mask_dev, uint32_t B, const float* eps_dev, float* loss_dev,
+                           float* grad_out_dev, void* workspace_dev, size_t workspace_bytes, const VaeRunStep* rs)
 {
     // the single-device update IS the data-parallel one with one rank: local sums, (no reduce), apply
     if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_update")) return rc;
@@ -2150,10 +2229,18 @@ int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsv
     vae_carve(model, B, (char*)workspace_dev, &ws);
     int w_splits[D3P_VAE_MAX_BLOCKS];  // split-K partial tiles of the weight gradients are summed by k_vae_finalize, not by reduction launches
     if (int rc = vae_local_sums_impl(stream, model, hyper, state, X_dev, mask_dev, B, B, 0, eps_dev, ws.sums, workspace_dev,
-                                     workspace_bytes, true, w_splits))
+                                     workspace_bytes, true, w_splits, nullptr, rs))
         return rc;
     return vae_apply_impl(stream, model, hyper, state, ws.sums, B, B, loss_dev, grad_out_dev, workspace_dev, workspace_bytes, false,
                           w_splits);
+}
+
+int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                        const float* X_dev, const uint8_t* mask_dev, uint32_t B, const float* eps_dev, float* loss_dev,
+                        float* grad_out_dev, void* workspace_dev, size_t workspace_bytes)
+{
+    return vae_update_impl(stream, model, hyper, state, X_dev, mask_dev, B, eps_dev, loss_dev, grad_out_dev, workspace_dev, workspace_bytes,
+                           nullptr);
 }
 
 // num_steps x (get_batch(first_batch + t, batch_key) of subsample_batchify_data -> update) on the resident data set X_dev
@@ -2171,14 +2258,25 @@ int d3p_dpvi_vae_run(void* stream, const d3p_vae_model* model, const d3p_dpsvi_h
     if (workspace_bytes < d3p_dpvi_vae_workspace(model, B)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_run: workspace too small");
     d3p_dpsvi_state st = *state;
     uint32_t* step_key = idx_dev + B;
+    // 16-byte rows: the step's indices come out of its key launch and ONE sweep gathers the rows and checks their exactness (two
+    // launches where fold_in, the sampler, the gather and the key launch were four: 264 -> 254 us per step at B = 4096)
+    static const bool no_fuse = getenv("D3P_VAE_RUN_UNFUSED") != nullptr;   // developer switch (A/B), read once
+    const bool fused = !no_fuse && model->D % 4 == 0 && ((reinterpret_cast<uintptr_t>(X_dev) | reinterpret_cast<uintptr_t>(xb_dev)) & 15u) == 0;
     for (uint32_t t = 0; t < num_steps; ++t) {
         int rc;
-        if ((rc = d3p_rng_fold_in(stream, batch_key_dev, first_batch + t, step_key))) return rc;          // minibatch.py:230
-        if ((rc = d3p_feistel_sample(stream, step_key, n_rows, B, idx_dev))) return rc;                   // minibatch.py:231
-        if ((rc = d3p_take_rows(stream, X_dev, n_rows, (uint32_t)(model->D * sizeof(float)), idx_dev, B, nullptr, xb_dev))) return rc;
-        if ((rc = d3p_dpvi_vae_update(stream, model, hyper, &st, xb_dev, nullptr, B, nullptr, losses_dev ? losses_dev + t : nullptr,
-                                      nullptr, workspace_dev, workspace_bytes)))
-            return rc;
+        if (fused) {
+            const VaeRunStep rs = {batch_key_dev, first_batch + t, X_dev, n_rows, idx_dev};
+            if ((rc = vae_update_impl(stream, model, hyper, &st, xb_dev, nullptr, B, nullptr, losses_dev ? losses_dev + t : nullptr, nullptr,
+                                      workspace_dev, workspace_bytes, &rs)))
+                return rc;
+        } else {
+            if ((rc = d3p_rng_fold_in(stream, batch_key_dev, first_batch + t, step_key))) return rc;          // minibatch.py:230
+            if ((rc = d3p_feistel_sample(stream, step_key, n_rows, B, idx_dev))) return rc;                   // minibatch.py:231
+            if ((rc = d3p_take_rows(stream, X_dev, n_rows, (uint32_t)(model->D * sizeof(float)), idx_dev, B, nullptr, xb_dev))) return rc;
+            if ((rc = d3p_dpvi_vae_update(stream, model, hyper, &st, xb_dev, nullptr, B, nullptr, losses_dev ? losses_dev + t : nullptr,
+                                          nullptr, workspace_dev, workspace_bytes)))
+                return rc;
+        }
         st.key_slot ^= 1;
     }
     return D3P_OK;
