@@ -271,6 +271,10 @@ def test_constructor_validation(gpu):
 @pytest.mark.parametrize("B,d,icpt,masked", [(16, 8, False, False), (16, 8, True, True), (50, 512, False, True),
                                              (256, 512, False, False), (37, 100, True, True), (8, 1024, False, False),
                                              (70, 512, True, True), (40, 300, False, False), (33, 128, True, False),
+                                             # 16-byte-aligned rows that are NOT full tiles take the scalar-load form since round 4
+                                             # (two / four columns per lane and half: 16- / 8-wave workgroups)
+                                             (300, 256, False, True), (130, 192, False, False), (200, 384, False, True),
+                                             (90, 64, False, False), (150, 640, False, False),
                                              # wide rows: the column-chunked kernel of d3p_logreg_wide.h (2048 < d <= 4096)
                                              (21, 3000, True, True), (12, 4096, False, False)])
 @pytest.mark.parametrize("onchip", [False, True])

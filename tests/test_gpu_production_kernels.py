@@ -317,6 +317,34 @@ def test_aligned_gradients_column_sums_beyond_2048_C_vs_oracle(gpu, O, icpt, B):
     _compare(new_st, losses, ost, el, steps)
 
 
+@pytest.mark.parametrize("d,icpt,B", [(64, False, 3000), (192, False, 2500), (256, False, 4096), (384, False, 1800), (256, True, 2000),
+                                      (4, True, 200)])
+def test_generic_kernel_widths_chained_run_vs_oracle(gpu, O, d, icpt, B):
+    """Widths the lean kernel does not take, through the generic kernel's chained form (k_logreg_main<V = 1, NK, MODE 3>) with the
+    launch geometry of round 4 -- one / two / four columns per lane and half as 16- / 16- / 8-wave workgroups, the scalar-load form
+    for every row that is not a full 16-byte-load tile; (4, True, 200) is examples/logistic_regression.py's default shape --:
+    10 steps each against per-step O.logreg_update."""
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, steps, first = 20_000, 10, 3
+    X, y = _table(N, d, 300 + d)
+    svi = _svi(d, icpt, N)
+    D = d + int(icpt)
+    st = _state(svi, rng.PRNGKey(63), D, N)
+    _, gb = subsample_batchify_data((X.cuda(), y.cuda()), B)
+    new_st, losses = svi.run_steps(st, gb, rng.PRNGKey(64), first, steps)
+    assert svi.last_run_status() == (False, False)
+    Xn, yn = X.numpy(), y.numpy()
+    spec = O.logreg_spec(d, icpt, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    ost = _oracle_state(O, 63, D)
+    el = []
+    for t in range(steps):
+        idx = O.feistel_sample(O.fold_in(O.PRNGKey(64), first + t), N, B)
+        el.append(O.logreg_update(spec, hy, ost, Xn[idx], yn[idx], None)[0])
+    _compare(new_st, losses, ost, el, steps)
+
+
 @pytest.mark.parametrize("B,icpt,sampler", [(20, False, "feistel"), (100, False, "feistel"), (33, True, "feistel"),
                                             (700, True, "poisson"), (1500, False, "poisson")])
 def test_chain_kernel_small_and_ragged_grids_vs_oracle(gpu, O, B, icpt, sampler):
