@@ -175,8 +175,9 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
         wall, ev = timed(run, 256, steps)   # (13 ms of warm-up: see the VAE leg)
         P = K + K * d
         alg = B * (4 * d + 4) + 3 * 4 * P                          # 2 175 168 B per step
-        # wave64 VALU instructions per step, measured with SQ_INSTS_VALU (profiles/r04_gmm_pmc.json: k_gmm_px 18.46 M, k_gmm_head 3.25 M; unchanged since round 3)
-        valu = 21.7e6
+        # wave64 VALU instructions per step, measured with SQ_INSTS_VALU (profiles/r04_gmm_pmc.json: k_gmm_px 18.13 M, k_gmm_head 3.05 M;
+        # round 3: 18.46 + 3.24)
+        valu = 21.2e6
         out["gmm_config3"] = {
             "workload": "BASELINE configs[2]: mixture model K=16 d=64, N=1e7 rows resident, batch 8192 (Feistel), C=20, sigma=1, Adam 1e-3",
             "steps": steps, "warmup": 256, "steps_per_sec": round(steps / wall, 2), "value": round(B * steps / wall, 1),
