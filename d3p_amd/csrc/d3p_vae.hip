@@ -957,18 +957,41 @@ static bool gemm_takes_bf16_nfast(const float* A, long long a_sm, long long a_sk
     return !fp32_mfma && va8 && vb8 && (M > 96 || (M > 32 && K >= 2048));
 }
 
+// what a product may ask for beyond C = alpha op(A) op(B) + bias (+ C); every field optional
+struct GemmOpts {
+    int a_last_one = 0;             // GemmArgs::a_last_one
+    float* part = nullptr;          // split-K scratch ([splits][M][N]) and its size: without it the product is not split
+    size_t part_floats = 0;
+    int epi = 0;                    // GemmArgs::epi and its operands
+    float* C2 = nullptr;
+    const float* ex_zu = nullptr;
+    const float* ex_eps = nullptr;
+    int ex_Z = 0;
+    float ex_sc = 0.f;
+    int* splits_left = nullptr;     // a split-K product is NOT reduced: the partial tiles stay in `part` and *splits_left says how many
+                                    // (0: the product went to C as usual); the consumer sums them in fixed order
+    const GemmJumps* jumps = nullptr;
+    const uint32_t* a_exact16 = nullptr;   // GemmArgs::a_exact16 / a_exact_nonce
+    uint32_t a_exact_nonce = 0u;
+    GemmGroupPlan* group = nullptr; // (with splits_left) a product that takes the bf16 kernel is appended to the group instead of
+    int force_splits = 0;           // being launched (gemm_group_launch), with force_splits K slabs instead of a count of its own
+    const float* b_row_scale = nullptr;    // GemmArgs::b_row_scale: bf16 kernel with an n-fast B only (gemm_takes_bf16_nfast)
+};
+
 static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, const float* B, long long b_sk, long long b_sn,
-                float* C, int ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, int a_last_one = 0,
-                float* part = nullptr, size_t part_floats = 0, int epi = 0, float* C2 = nullptr, int* splits_left = nullptr,
-                const GemmJumps* jumps = nullptr, const float* ex_zu = nullptr, const float* ex_eps = nullptr, int ex_Z = 0, float ex_sc = 0.f,
-                const uint32_t* a_exact16 = nullptr, uint32_t a_exact_nonce = 0u, GemmGroupPlan* group = nullptr, int force_splits = 0,
-                const float* b_row_scale = nullptr)
+                float* C, int ldc, int M, int N, int K, const float* bias, float alpha, int accumulate, const GemmOpts& o = GemmOpts())
 {
-    // b_row_scale (GemmArgs): only products that take k_gemm_bf16x3 with an n-fast B honour it -- the caller asks gemm_takes_bf16 first
-    // group != nullptr (with splits_left): a product that takes the bf16 kernel is appended to the group instead of being launched
-    // (gemm_group_launch), with force_splits K slabs (gemm_group_splits) instead of a count of its own
-    // splits_left != nullptr: a split-K product is NOT reduced here -- the partial tiles stay in `part` ([splits][M][N]) and
-    // *splits_left says how many (0: the product went to C as usual); the consumer sums them in fixed order (k_vae_finalize)
+    const int a_last_one = o.a_last_one, epi = o.epi, ex_Z = o.ex_Z, force_splits = o.force_splits;
+    float* const part = o.part;
+    const size_t part_floats = o.part_floats;
+    float* const C2 = o.C2;
+    int* const splits_left = o.splits_left;
+    const GemmJumps* const jumps = o.jumps;
+    const float *const ex_zu = o.ex_zu, *const ex_eps = o.ex_eps, *const b_row_scale = o.b_row_scale;
+    const float ex_sc = o.ex_sc;
+    const uint32_t* const a_exact16 = o.a_exact16;
+    const uint32_t a_exact_nonce = o.a_exact_nonce;
+    GemmGroupPlan* const group = o.group;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     g.M = M; g.N = N; g.K = K;
@@ -1762,9 +1785,10 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
         const float* in = X;
         for (int l = 0; l < nh; ++l) {
             const VaeDense& e = N.enc[l];
-            if ((rc = gemm(s, in, e.in, 1, params + e.W, e.out, 1, ws.he[l], e.out, Bi, e.out, e.in, params + e.b, 1.f, 0, 0, ws.part, ws.part_floats, 1,
-                           ws.sge[l], nullptr, nullptr, nullptr, nullptr, 0, 0.f, l == 0 ? xflag : nullptr, vae_exact_nonce(false))))
-                return rc;
+            GemmOpts o;   // softplus epilogue (sigmoid = its derivative to sge), split-K where the grid is short, one-plane A for the batch
+            o.part = ws.part; o.part_floats = ws.part_floats; o.epi = 1; o.C2 = ws.sge[l];
+            o.a_exact16 = l == 0 ? xflag : nullptr; o.a_exact_nonce = vae_exact_nonce(false);
+            if ((rc = gemm(s, in, e.in, 1, params + e.W, e.out, 1, ws.he[l], e.out, Bi, e.out, e.in, params + e.b, 1.f, 0, o))) return rc;
             in = ws.he[l];
         }
     }
@@ -1775,9 +1799,13 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
     const GemmJumps enc = {Z, 0x7fffffff, prep.heads_packed ? 0ll : (long long)HE * Z, 0, (long long)HE * Z, 0};
     // (a split-K product leaves its partial tiles for k_vae_latent to sum: no reduction launch)
     int zl_splits = 0;
-    if ((rc = gemm(s, ws.he[nh - 1], HE, 1, prep.heads_packed ? ws.wcat : params + N.Wl, prep.heads_packed ? 2 * Z : Z, 1, ws.zl, ldz, Bi, 2 * Z, HE,
-                   params + N.bl, 1.f, 0, 0, ws.part, ws.part_floats, 0, nullptr, &zl_splits, &enc)))
-        return rc;
+    {
+        GemmOpts o;
+        o.part = ws.part; o.part_floats = ws.part_floats; o.splits_left = &zl_splits; o.jumps = &enc;
+        if ((rc = gemm(s, ws.he[nh - 1], HE, 1, prep.heads_packed ? ws.wcat : params + N.Wl, prep.heads_packed ? 2 * Z : Z, 1, ws.zl, ldz, Bi, 2 * Z, HE,
+                       params + N.bl, 1.f, 0, o)))
+            return rc;
+    }
     {
         LatentArgs la;
         memset(&la, 0, sizeof(la));
@@ -1800,9 +1828,9 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
         for (int l = 0; l < nh; ++l) {
             const VaeDense& d = N.dec[l];
             // (the first product has K = Z: no split)
-            if ((rc = gemm(s, in, ld_in, 1, params + d.W, d.out, 1, ws.hd[l], d.out, Bi, d.out, d.in, params + d.b, 1.f, 0, 0, l ? ws.part : nullptr,
-                           l ? ws.part_floats : 0, 1, ws.sgd[l])))
-                return rc;
+            GemmOpts o;
+            o.part = l ? ws.part : nullptr; o.part_floats = l ? ws.part_floats : 0; o.epi = 1; o.C2 = ws.sgd[l];
+            if ((rc = gemm(s, in, ld_in, 1, params + d.W, d.out, 1, ws.hd[l], d.out, Bi, d.out, d.in, params + d.b, 1.f, 0, o))) return rc;
             in = ws.hd[l];
             ld_in = d.out;
         }
@@ -1835,31 +1863,39 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
         const float* delta = ws.a;
         for (int l = nh - 1; l >= 0; --l) {
             const VaeDense& d = N.dec[l + 1];
-            if ((rc = gemm(s, delta, d.out, 1, params + d.W, 1, d.out, ws.dd[l], d.in, Bi, d.in, d.out, nullptr, 1.f, 0, 0, ws.part, ws.part_floats, 2,
-                           ws.sgd[l])))
-                return rc;
+            GemmOpts o;   // epilogue 2: times softplus'(pre)
+            o.part = ws.part; o.part_floats = ws.part_floats; o.epi = 2; o.C2 = ws.sgd[l];
+            if ((rc = gemm(s, delta, d.out, 1, params + d.W, 1, d.out, ws.dd[l], d.in, Bi, d.in, d.out, nullptr, 1.f, 0, o))) return rc;
             delta = ws.dd[l];
         }
     }
     const int ldz = 2 * Z;
     // dz = dpre V1^T + sc z and du = dz sd eps - sc in the product's epilogue (epi 3; was the k_vae_dlatent launch)
-    if ((rc = gemm(s, ws.dd[0], N.dec[0].out, 1, params + N.dec[0].W, 1, N.dec[0].out, ws.dz, ldz, Bi, Z, N.dec[0].out, nullptr, 1.f, 0, 0, ws.part,
-                   ws.part_floats, 3, nullptr, nullptr, nullptr, ws.zl, eps, Z, sc)))
-        return rc;
+    {
+        GemmOpts o;
+        o.part = ws.part; o.part_floats = ws.part_floats; o.epi = 3; o.ex_zu = ws.zl; o.ex_eps = eps; o.ex_Z = Z; o.ex_sc = sc;
+        if ((rc = gemm(s, ws.dd[0], N.dec[0].out, 1, params + N.dec[0].W, 1, N.dec[0].out, ws.dz, ldz, Bi, Z, N.dec[0].out, nullptr, 1.f, 0, o))) return rc;
+    }
     // dpre = ([dz | du] [Wl^T ; Ws^T]) . softplus'(pre): ONE product of K = 2 Z (rows Z .. 2 Z - 1 of the stacked B are Ws^T,
     // HE Z behind where Wl^T's would be)
     // (packed heads: B = ws.wcatT, a plain 2 Z x HE matrix with 16-byte rows -- the product takes the bf16 kernel)
     const GemmJumps dec = {0x7fffffff, Z, 0, (long long)HE * Z, 0, 0};
-    if (prep.heads_packed)
-        rc = gemm(s, ws.dz, ldz, 1, ws.wcatT, HE, 1, ws.de[nh - 1], HE, Bi, HE, 2 * Z, nullptr, 1.f, 0, 0, nullptr, 0, 2, ws.sge[nh - 1]);
-    else
-        rc = gemm(s, ws.dz, ldz, 1, params + N.Wl, 1, Z, ws.de[nh - 1], HE, Bi, HE, 2 * Z, nullptr, 1.f, 0, 0, nullptr, 0, 2, ws.sge[nh - 1], nullptr, &dec);
-    if (rc) return rc;
+    {
+        GemmOpts o;
+        o.epi = 2; o.C2 = ws.sge[nh - 1];
+        if (prep.heads_packed) {
+            rc = gemm(s, ws.dz, ldz, 1, ws.wcatT, HE, 1, ws.de[nh - 1], HE, Bi, HE, 2 * Z, nullptr, 1.f, 0, o);
+        } else {
+            o.jumps = &dec;
+            rc = gemm(s, ws.dz, ldz, 1, params + N.Wl, 1, Z, ws.de[nh - 1], HE, Bi, HE, 2 * Z, nullptr, 1.f, 0, o);
+        }
+        if (rc) return rc;
+    }
     for (int l = nh - 2; l >= 0; --l) {
         const VaeDense& e = N.enc[l + 1];
-        if ((rc = gemm(s, ws.de[l + 1], e.out, 1, params + e.W, 1, e.out, ws.de[l], e.in, Bi, e.in, e.out, nullptr, 1.f, 0, 0, ws.part, ws.part_floats, 2,
-                       ws.sge[l])))
-            return rc;
+        GemmOpts o;
+        o.part = ws.part; o.part_floats = ws.part_floats; o.epi = 2; o.C2 = ws.sge[l];
+        if ((rc = gemm(s, ws.de[l + 1], e.out, 1, params + e.W, 1, e.out, ws.de[l], e.in, Bi, e.in, e.out, nullptr, 1.f, 0, o))) return rc;
     }
     // ---- clipped sums: weights  A^T (diag(c) Delta)  (GEMMs over the batch), biases = column sums
     // [W | b] of every layer is contiguous in the flat layout, so the bias gradient is row `in` of a GEMM whose A carries a
@@ -1931,9 +1967,11 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
         int left = 0;
         // (A = X^T: the flag of the forward pass holds -- same batch; the virtual row of ones is exact too)
         const uint32_t* xflag = (wg[b].A == X && vae_exact_eligible(X, B, D)) ? ws.x_exact16 : nullptr;
-        if ((rc = gemm(s, wg[b].A, 1, wg[b].a_sk, wg[b].Bm, wg[b].ldb, 1, S + wg[b].off, wg[b].ldc, wg[b].in + 1, wg[b].out, Bi, nullptr, 1.f, 0, 1,
-                       part, part_floats, 0, nullptr, &left, wg[b].j, nullptr, nullptr, 0, 0.f, xflag, vae_exact_nonce(false),
-                       group, group_splits, scale_in_gemm ? ws.cf : nullptr)))
+        GemmOpts o;   // A carries the virtual row of ones (bias gradient); tiles left unreduced; grouped; clip factors on B's rows
+        o.a_last_one = 1; o.part = part; o.part_floats = part_floats; o.splits_left = &left; o.jumps = wg[b].j;
+        o.a_exact16 = xflag; o.a_exact_nonce = vae_exact_nonce(false);
+        o.group = group; o.force_splits = group_splits; o.b_row_scale = scale_in_gemm ? ws.cf : nullptr;
+        if ((rc = gemm(s, wg[b].A, 1, wg[b].a_sk, wg[b].Bm, wg[b].ldb, 1, S + wg[b].off, wg[b].ldc, wg[b].in + 1, wg[b].out, Bi, nullptr, 1.f, 0, o)))
             return rc;
         tile_splits[wg[b].blk] = left;
         if (b == n_wg - 1) tile_splits[wg[b].blk + 1] = left;
