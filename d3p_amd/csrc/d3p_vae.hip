@@ -907,11 +907,12 @@ static int gemm_group_launch(hipStream_t s, GemmGroupPlan& G)
 // epilogue.  tiles = 128 x 64 tiles of the product, or of all members together.
 static int gemm_group_splits(unsigned tiles, int K)
 {
-    static int n_cu = 0;
-    if (n_cu == 0) {
+    static const int n_cu = [] {   // (one process drives one device: d3p_amd.dist; initialised once, thread-safely)
         int dev = 0, n = 0;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
+        const bool ok = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0;
+        if (!ok) (void)hipGetLastError();
+        return ok ? n : 256;
+    }();
     int best = 1;
     double best_cost = 1e30;
     for (int sp = 1; sp <= D3P_WPART_SPLITS; ++sp) {
@@ -1561,17 +1562,17 @@ __global__ void __launch_bounds__(256) k_vae_keys(const uint32_t* __restrict__ c
         exact16_pass(ex.x, ex.x_n4, ex.x_flag, ex.x_nonce, blockIdx.x - 1, ex.x_blocks);
         return;
     }
-    if (threadIdx.x >= 64) return;   // (the barrier below is the first wave's alone: s_barrier counts the waves that have not ended)
-    // one quad of lanes per derivation (4-lane ChaCha block, d3p_device.h): the launch is pure latency
+    // one quad of lanes per derivation (4-lane ChaCha block, d3p_device.h), on the first wave: the launch is pure latency
     __shared__ uint32_t sk[3][16];
-    const int lane = threadIdx.x, quad = lane >> 2, q = lane & 3;
+    const bool kt = threadIdx.x < 64;
+    const int lane = threadIdx.x & 63, quad = lane >> 2, q = lane & 3;
     auto store_child = [&](uint32_t* dst, const uint32_t* parent, uint32_t a, uint32_t b) {
         dst[q] = parent[q];
         dst[4 + q] = a;
         dst[8 + q] = b;
         dst[12 + q] = 0u;
     };
-    {
+    if (kt) {
         uint32_t a, b;
         derive_child_quad(cur_key, quad < 3 ? (uint32_t)quad : 0u, D3P_TAG_SPLIT, 0u, a, b);
         if (quad < 3) {
@@ -1579,14 +1580,14 @@ __global__ void __launch_bounds__(256) k_vae_keys(const uint32_t* __restrict__ c
             store_child(sk[quad], cur_key, a, b);
             if (quad == 0 && advance) store_child(next_slot, cur_key, a, b);
         }
-    }
-    if (lane == 63 && advance) {
-        const int32_t i = *step;
-        keys[D3P_VAE_KEY_STEP] = (uint32_t)i;
-        *step_out = i + 1;  // (step_out == step, or the new state's counter when the update is out of place)
+        if (lane == 63 && advance) {
+            const int32_t i = *step;
+            keys[D3P_VAE_KEY_STEP] = (uint32_t)i;
+            *step_out = i + 1;  // (step_out == step, or the new state's counter when the update is out of place)
+        }
     }
     __syncthreads();
-    {
+    if (kt) {
         // quad 0: block 0 of the gradient key's stream -> jax key; quads 1..n_sites (<= 15): split(perturbation_key, n_sites)
         const uint32_t* parent = quad == 0 ? sk[1] : sk[2];
         const bool site = quad >= 1 && quad <= n_sites;
