@@ -303,15 +303,17 @@ def test_evaluate_vs_oracle(gpu, O, B, D, H, Z, H2):
     assert abs(got - exp) <= 3e-5 * abs(exp)
 
 
-def test_vae_run_steps_native_loop_matches_stepwise_updates(gpu):
+# (the second shape is BASELINE configs[4]'s: the step's indices come out of its key launch, one sweep gathers the rows and checks their
+# exactness, the weight-gradient products go out grouped -- the launches of the bench leg; D = 35 takes the unfused run loop)
+@pytest.mark.parametrize("N,B,D,H,Z,steps,first", [(600, 64, 36, 20, 5, 7, 3), (9000, 4096, 784, 400, 50, 3, 1), (300, 40, 35, 12, 4, 4, 0)])
+def test_vae_run_steps_native_loop_matches_stepwise_updates(gpu, N, B, D, H, Z, steps, first):
     """DPSVI.run_steps for the VAE (d3p_dpvi_vae_run: the epoch body of examples/vae.py:227-246 as one native call -- per step
     fold_in, Feistel indices, row gather, update) walks the trajectory of get_batch + update, step by step, bit for bit (the
-    same kernels on the same batches), and leaves its input state untouched."""
+    same kernels on the same batches), twice the same, and leaves its input state untouched."""
     import d3p_amd.random as rng
     from d3p_amd.minibatch import subsample_batchify_data
     from d3p_amd.models import Adam, Trace_ELBO, VAEGuide, VAEModel
     from d3p_amd.svi import DPSVI
-    N, B, D, H, Z, steps, first = 600, 64, 36, 20, 5, 7, 3
     X = (torch.rand(N, D, generator=torch.Generator().manual_seed(1)) < 0.3).float().cuda()
     model = VAEModel(scale=1.0 / N)
     svi = DPSVI(model, VAEGuide(model), Adam(1e-2), Trace_ELBO(), 5.0, 0.8, num_obs_total=N, z_dim=Z, hidden_dim=H)
@@ -329,3 +331,5 @@ def test_vae_run_steps_native_loop_matches_stepwise_updates(gpu):
     assert int(new_st.optim_state[0]) == int(ref.optim_state[0]) == steps
     for a, b in zip([*st0.optim_state, st0.rng_key], before):
         assert torch.equal(a, b)
+    again, losses2 = svi.run_steps(st0, get_batch, bstate, first, steps)
+    assert torch.equal(again.optim_state[1], new_st.optim_state[1]) and torch.equal(losses2, losses)
