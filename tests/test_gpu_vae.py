@@ -186,6 +186,45 @@ def test_step_sums_on_the_bf16_pipe_with_binarised_and_grey_batches(lib, O, grey
     np.testing.assert_allclose(got[:P], esums[:P], rtol=2e-4, atol=2e-5 * np.abs(esums[:P]).max())
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_step_sums_random_shapes_vs_oracle(lib, O, seed):
+    """Forty random shapes per seed -- batch 1 .. 260, rows of 8 .. 784 features, hidden widths 4 .. 400 (one or two layers), 1 .. 50
+    latents, binarised or grey batches, with and without masked rows -- against the oracle's explicit per-example gradients: which
+    kernel a product takes (bf16 tiles, grouped or alone; the 64 x 64 fp32 kernel; packed or displaced heads), whether the clip factors
+    are applied inside the products or written back, how many tiles a product leaves, all follow from the shape."""
+    rs = np.random.default_rng(seed)
+    L = lib.load()
+    for _ in range(40):
+        B = int(rs.choice([1, 3, 17, 64, 97, 130, 200, 260]))
+        D = int(rs.choice([8, 12, 33, 64, 100, 200, 784]))
+        H = int(rs.choice([4, 7, 16, 40, 100, 400]))
+        Z = int(rs.choice([1, 2, 3, 8, 10, 50]))
+        H2 = int(rs.choice([0, 0, 5, 12, 200]))
+        if D * H > 200000 and B > 140:
+            B = 136   # (the oracle materialises B x P gradients)
+        masked = bool(rs.integers(2))
+        spec, P, params, X, eps = vae_problem(B, D, H, Z, B + D + H, 0.03 if (D > 100 or H > 50 or H2 > 50) else 0.3, H2)
+        if rs.integers(2):
+            X = rs.random((B, D)).astype(np.float32)
+        mask = (rs.random(B) < 0.7) if masked else None
+        _, norms0, _ = O.vae_step_sums(spec, params, X, eps, 1e30, None)
+        clip = float(np.median(norms0))
+        esums, enorms, eloss = O.vae_step_sums(spec, params, X, eps, clip, None if mask is None else mask.astype(np.float32))
+        model = lib.VaeModel(D, H, Z, 1.0, 1.0, H2)
+        ws = torch.empty(int(L.d3p_dpvi_vae_workspace(C.byref(model), B)), dtype=torch.uint8, device="cuda")
+        sums, norms, pxl = torch.empty(P + 2, device="cuda"), torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+        mt = None if mask is None else torch.tensor(mask).to(torch.uint8).cuda()
+        pt, Xt, et = torch.tensor(params).cuda(), torch.tensor(X).cuda(), torch.tensor(eps).cuda()
+        lib.check(L.d3p_vae_step_sums(lib.stream_ptr(), C.byref(model), lib.ptr(pt), lib.ptr(Xt), lib.ptr(mt), B, lib.ptr(et), None,
+                                      clip, lib.ptr(sums), lib.ptr(norms), lib.ptr(pxl), lib.ptr(ws), ws.numel()))
+        got, what = np_(sums), f"B={B} D={D} H={H} Z={Z} H2={H2} masked={masked}"
+        np.testing.assert_allclose(np_(norms), enorms, rtol=5e-5, err_msg=what)
+        np.testing.assert_allclose(np_(pxl), eloss, rtol=2e-5, atol=1e-5, err_msg=what)
+        assert got[P + 1] == esums[P + 1], what
+        assert abs(got[P] - esums[P]) <= 2e-5 * abs(esums[P]) + 1e-6, what
+        np.testing.assert_allclose(got[:P], esums[:P], rtol=2e-4, atol=2e-5 * np.abs(esums[:P]).max(), err_msg=what)
+
+
 def make_svi(Z, H, N, C=10.0, sigma=1.0, lr=1e-3, H2=0):
     from d3p_amd.models import Adam, Trace_ELBO, VAEGuide, VAEModel
     from d3p_amd.svi import DPSVI
