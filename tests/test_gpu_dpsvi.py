@@ -307,6 +307,38 @@ def test_fused_update_vs_oracle(rng, O, B, d, icpt, masked, onchip):
     assert int(st.optim_state[0]) == 0 and np.array_equal(np_(st.optim_state[1]), np.concatenate([loc, unc]))
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fused_update_random_shapes_vs_oracle(rng, O, seed):
+    """Thirty random shapes per seed -- 1 .. 1100 features with and without intercept, batches of 1 .. 3000, masked or not -- through
+    the one-step resident run against the oracle: the width decides the kernel (lean d = 512 forms, the generic kernel's scalar-load
+    tiles of 1 / 2 / 4 / 8 columns per lane and half, its full 16-byte-load tiles), the batch the workgroups and waves that get items."""
+    rs = np.random.default_rng(100 + seed)
+    N = 5000
+    for _ in range(30):
+        d = int(rs.choice([1, 3, 4, 8, 31, 64, 65, 128, 129, 200, 256, 257, 384, 500, 512, 513, 700, 1024, 1100]))
+        icpt = bool(rs.integers(2))
+        B = int(rs.choice([1, 2, 31, 64, 65, 200, 700, 1500, 3000]))
+        if d > 600 and B > 700:
+            B = 300   # (the oracle materialises B x P gradients)
+        masked = bool(rs.integers(2))
+        X, y, loc, unc, mask = make_problem(B, d, icpt, 19 * B + d, N, mask_frac=0.7 if masked else None)
+        D = d + int(icpt)
+        svi = make_svi(d, icpt, N, C=0.7, sigma=1.3, prior=1.5, lr=1e-2)
+        st = state_with(svi, rng.PRNGKey(4243), loc, unc)
+        gout = torch.empty(2 * D, device="cuda")
+        new_st, loss = svi._update_fused(st, torch.tensor(X).cuda(), torch.tensor(y).cuda(), mask=torch.tensor(mask).cuda() if masked else True,
+                                         _grad_out=gout)
+        spec = O.logreg_spec(d, icpt, 1.5, 3.0, lik_scale=N, obs_scale=N)
+        hy = O.Hyper(0.7, 1.3, 1e-2, 0.9, 0.999, 1e-8)
+        ost = O.LogregState(O.PRNGKey(4243), D, loc, unc)
+        eloss, egrad = O.logreg_update(spec, hy, ost, X, y, None if not masked else mask.astype(np.float32), None)
+        what = f"d={d} icpt={icpt} B={B} masked={masked}"
+        np.testing.assert_allclose(np_(gout), egrad, rtol=G_RTOL, atol=1e-6 * max(1e-30, float(np.abs(egrad).max())), err_msg=what)
+        assert abs(float(loss) - eloss) <= 2e-5 * abs(eloss) + 1e-6, what
+        assert np.array_equal(np_(new_st.rng_key).ravel(), ost.key), what
+        np.testing.assert_allclose(np_(new_st.optim_state[1]), ost.params, rtol=1e-5, atol=1e-6, err_msg=what)
+
+
 def test_fused_equals_staged_pipeline(rng):
     """update() (fused kernels) and the reference's literal five-stage composition agree."""
     B, d, N = 128, 512, 10**5
