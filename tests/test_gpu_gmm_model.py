@@ -141,6 +141,40 @@ def test_fused_update_matches_the_stage_composition(rng, B, K, d, masked):
     assert torch.equal(s_f2.optim_state[1], s_f.optim_state[1]) and float(l_f2) == float(l_f)
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fused_update_random_shapes_match_the_stage_composition(rng, seed):
+    """Twenty-five random shapes per seed -- 1 .. 32 components, 1 .. 256 dimensions, batches of 1 .. 1000, masked or not: the
+    shape picks the per-example kernel's instantiation (component pairs per wave x 64-dimension slots, paired or single threefry
+    calls, the full-tile form) -- fused update against the five stages run one by one (which the oracle tests pin)."""
+    rs = np.random.default_rng(200 + seed)
+    N = 10**5
+    for _ in range(25):
+        K = int(rs.choice([1, 2, 3, 5, 8, 16, 17, 32]))
+        d = int(rs.choice([1, 2, 10, 63, 64, 65, 128, 200, 256]))
+        if K > 16 and d > 128:
+            d = 128   # (the fused step's register tiles: K <= 16 with d <= 256, K <= 32 with d <= 128)
+        B = int(rs.choice([1, 33, 257, 1000]))
+        masked = bool(rs.integers(2))
+        X, params = problem(B, K, d, 7 + K + d)
+        mask = torch.tensor(np.random.default_rng(3).random(B) < 0.7).cuda() if masked else True
+        svi = make_svi(K, d, N, C=20.0, sigma=0.7, lr=1e-2)
+        st = state_with(svi, rng.PRNGKey(9), params, N)
+        Xt = torch.tensor(X).cuda()
+        s_f, l_f = svi._update_gmm_fused(st, Xt, mask=mask)
+        s_s, l_s = svi._update_staged(st, Xt, mask=mask)
+        what = f"K={K} d={d} B={B} masked={masked}"
+        if not np.isfinite(float(l_s)):   # (every row masked: both give NaN, svi.py:305)
+            assert not np.isfinite(float(l_f)), what
+            continue
+        assert abs(float(l_f) - float(l_s)) <= 2e-5 * abs(float(l_s)), what
+        assert torch.equal(s_f.rng_key, s_s.rng_key), what
+        # (m = 0.1 g: sums of up to 1000 clipped float32 gradients in two different orders -- fixed-point partial sums per wave against
+        # the stage-wise float sum: a column with cancellation differs by a few 1e-4 of its value)
+        np.testing.assert_allclose(np_(s_f.optim_state[2]), np_(s_s.optim_state[2]), rtol=5e-4, atol=4e-6 * float(s_s.optim_state[2].abs().max()),
+                                   err_msg=what)
+        np.testing.assert_allclose(np_(s_f.optim_state[1]), np_(s_s.optim_state[1]), rtol=1e-5, atol=2e-6, err_msg=what)
+
+
 def test_run_steps_walks_the_update_trajectory(rng):
     from d3p_amd.minibatch import subsample_batchify_data
     N, d, K, B, steps = 5000, 64, 16, 128, 5
