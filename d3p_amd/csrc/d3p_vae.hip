@@ -48,10 +48,18 @@ struct GemmArgs {
     int epi;          // epilogue: 0 store; 1 softplus (C = softplus(o), C2 = sigmoid(o) = its derivative); 2 C = o * C2;
                       // 3 (the dz product, C = [dz | du] of row stride 2 Z): dz = o + sc z, du = dz sd eps - sc with [z | sd] = ex_zu (same
                       // layout as C), eps dense B x Z (the backward pass through the reparametrised latent, svi.py:289-290 draw)
+                      // 4 (k_gemm_bf16x3<.., EPI4> only; the decoder's output layer, C = logits B x D): what k_vae_out does in a launch of
+                      // its own -- C = sc (sigmoid(o) - x) with x = ep_x (the batch, laid out like C; requested BEFORE the K loop: at
+                      // the end the tile's 32 KB would arrive in one burst with nothing left to overlap), and per row and group of 32
+                      // columns (one wave's share) the partial sums of x o - softplus(o) and of x^2 in ep_ll / ep_xx
+                      // ([ceil(N / 32)][M]), summed in fixed order (DPP) -- the norm kernel adds the groups (vae_out_finish_row)
     const float* ex_zu;
     const float* ex_eps;
     int ex_Z;
     float ex_sc;
+    const float* ep_x;
+    float* ep_ll;
+    float* ep_xx;
     // Two operands side by side that are not adjacent in memory (the pairs (Wl, Ws) / (bl, bs) of the flat parameter layout lie
     // H Z apart): columns n >= n_seg of B, of the bias and of C, and rows k >= k_seg of B, are displaced by a constant.  0 / 0 /
     // INT_MAX segments = plain GEMM.  Honoured by the scalar B fetch and by every store path.
@@ -558,7 +566,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& w0, uin
 }
 
 // one 128 x 64 tile (tx, ty) of K slab tz of the product g, by one 8-wave workgroup
-template <bool AK, bool BN>
+template <bool AK, bool BN, bool EPI4 = false>
 __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx, const int ty, const int tz)
 {
     __shared__ __attribute__((aligned(16))) unsigned short Ap[2][3][D3P_GTM][D3P_BLD];  // [buffer][plane][m][k]
@@ -571,6 +579,16 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
     float16v acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    float xpre[EPI4 ? 16 : 1];   // EPI4: this lane's 16 elements of ep_x, in flight during the K loop
+    if (EPI4) {
+        const int pcol = n0 + 32 * grp + (lane & 31);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = m0 + wr * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+            const bool ok = pcol < g.N && row < g.M;
+            xpre[v] = ok ? g.ep_x[(size_t)row * g.ldc + pcol] : 0.f;
+        }
+    }
 
     // ---- this thread's share of a slice (as in k_gemm_f32_w8): two float4 of A, one of B
     int a_m[2], a_k[2], b_n, b_k;
@@ -820,6 +838,48 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
 #undef D3P_MIX_STAGE
 #undef D3P_MIX_READ
     const int col = n0 + 32 * grp + (lane & 31);
+    if (EPI4) {   // (every lane stays for the row sums: a column beyond N contributes zeros)
+        const bool col_ok = col < g.N;
+        const float bv = (g.bias && col_ok) ? g.bias[col] : 0.f;
+        float ll[16], xx[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = m0 + wr * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+            const bool ok = col_ok && row < g.M;
+            const float o = __fmaf_rn(g.alpha, acc[v], bv), x = xpre[v];
+            // one exponential per element, as in k_vae_out: en = exp(-|o|); softplus(o) = max(o, 0) + log(1 + en)
+            const float en = __expf(-fabsf(o)), r = __builtin_amdgcn_rcpf(1.0f + en);
+            if (ok) g.C[(size_t)row * g.ldc + col] = g.ex_sc * ((o >= 0.0f ? r : en * r) - x);
+            ll[v] = ok ? x * o - (fmaxf(o, 0.0f) + __logf(1.0f + en)) : 0.f;
+            xx[v] = x * x;
+        }
+        // sums over the 32 columns of each half wave (lanes 0 - 31: rows + 0, lanes 32 - 63: rows + 4): four DPP steps inside the rows
+        // of 16 lanes, row_bcast:15 adds row 0 into row 1 and row 2 into row 3 -- lanes 31 and 63 hold the half sums
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            float a_ = ll[v], b_ = xx[v];
+            a_ += dpp_mov<0xB1>(a_); b_ += dpp_mov<0xB1>(b_);
+            a_ += dpp_mov<0x4E>(a_); b_ += dpp_mov<0x4E>(b_);
+            a_ += dpp_mov<0x141>(a_); b_ += dpp_mov<0x141>(b_);
+            a_ += dpp_mov<0x140>(a_); b_ += dpp_mov<0x140>(b_);
+            asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1"
+                : "+v"(a_), "+v"(b_));
+            ll[v] = a_; xx[v] = b_;
+        }
+        if ((lane & 31) == 31 && n0 + 32 * grp < g.N) {
+            const int cg = (n0 >> 5) + grp;   // this wave's group of 32 columns
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = m0 + wr * 32 + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+                if (row < g.M) {
+                    g.ep_ll[(size_t)cg * g.M + row] = ll[v];
+                    g.ep_xx[(size_t)cg * g.M + row] = xx[v];
+                }
+            }
+        }
+        return;
+    }
     if (col >= g.N) return;
     if (g.part) {
         float* out = g.part + (size_t)tz * g.M * g.N;
@@ -838,12 +898,12 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
     }
 }
 
-template <bool AK, bool BN>
+template <bool AK, bool BN, bool EPI4 = false>
 __global__ void __launch_bounds__(512) k_gemm_bf16x3(GemmArgs g)
 {
     int tx, ty, tz;
     xcd_tile(tx, ty, tz);
-    gemm_bf16x3_tile<AK, BN>(g, tx, ty, tz);
+    gemm_bf16x3_tile<AK, BN, EPI4>(g, tx, ty, tz);
 }
 
 // Several products of one operand form in ONE launch (the weight-gradient products of a step: independent of each other, each too
@@ -861,12 +921,31 @@ struct GemmGroup {
     unsigned slot[D3P_GROUP_MAX + 1];
     unsigned cnt[D3P_GROUP_MAX];         // workgroups of member p = gx gy splits
     unsigned gx[D3P_GROUP_MAX], gy[D3P_GROUP_MAX];
+    // one more workgroup behind the members', when asked for: *sum_out = sum of sum_in[0 .. sum_n - 1] in fixed order (the loss sum of
+    // a step whose output layer was fused -- NormArgs: the norm kernel in front of this launch completes px_loss, so it cannot sum it)
+    const float* sum_in;
+    float* sum_out;
+    unsigned sum_n;
 };
 
 template <bool AK, bool BN>
 __global__ void __launch_bounds__(512) k_gemm_bf16x3_group(GemmGroup q)
 {
-    const unsigned c = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    if (q.sum_in && blockIdx.x == 0) {   // (workgroup-uniform; the FIRST workgroup: dealt out last it would be the launch's tail)
+        __shared__ float part[512];
+        float sm = 0.f;
+        for (unsigned i = threadIdx.x; i < q.sum_n; i += 512) sm += q.sum_in[i];
+        part[threadIdx.x] = sm;
+        __syncthreads();
+        for (int off = 256; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *q.sum_out = part[0];
+        return;
+    }
+    const unsigned bid = blockIdx.x - (q.sum_in ? 1u : 0u);
+    const unsigned c = bid & 7u, j = bid >> 3;
     int p = 0;
 #pragma unroll
     for (int k = 1; k < D3P_GROUP_MAX; ++k) p += (j >= q.slot[k]) ? 1 : 0;
@@ -881,6 +960,9 @@ struct GemmGroupPlan {
     GemmGroup q;
     int n = 0;
     bool ak = false, bn = false;
+    const float* sum_in = nullptr;   // GemmGroup::sum_in / sum_out / sum_n
+    float* sum_out = nullptr;
+    unsigned sum_n = 0;
 };
 
 static int gemm_group_launch(hipStream_t s, GemmGroupPlan& G)
@@ -893,7 +975,8 @@ static int gemm_group_launch(hipStream_t s, GemmGroupPlan& G)
         else { G.q.cnt[p] = 0; G.q.gx[p] = G.q.gy[p] = 1; G.q.g[p] = G.q.g[0]; }
     }
     G.q.slot[D3P_GROUP_MAX] = slots;
-    const dim3 grid(8u * slots);
+    G.q.sum_in = G.sum_in; G.q.sum_out = G.sum_out; G.q.sum_n = G.sum_n;
+    const dim3 grid(8u * slots + (G.sum_in ? 1u : 0u));
     if (G.ak && G.bn) hipLaunchKernelGGL((k_gemm_bf16x3_group<true, true>), grid, dim3(512), 0, s, G.q);
     else if (G.ak) hipLaunchKernelGGL((k_gemm_bf16x3_group<true, false>), grid, dim3(512), 0, s, G.q);
     else if (G.bn) hipLaunchKernelGGL((k_gemm_bf16x3_group<false, true>), grid, dim3(512), 0, s, G.q);
@@ -977,6 +1060,8 @@ struct GemmOpts {
     GemmGroupPlan* group = nullptr; // (with splits_left) a product that takes the bf16 kernel is appended to the group instead of
     int force_splits = 0;           // being launched (gemm_group_launch), with force_splits K slabs instead of a count of its own
     const float* b_row_scale = nullptr;    // GemmArgs::b_row_scale: bf16 kernel with an n-fast B only (gemm_takes_bf16_nfast)
+    const float* ep_x = nullptr;    // epi 4 (with ex_sc): k-fast A, n-fast B on the bf16 kernel, unsplit (gemm_takes_bf16_nfast)
+    float *ep_ll = nullptr, *ep_xx = nullptr;
 };
 
 static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, const float* B, long long b_sk, long long b_sn,
@@ -1004,6 +1089,7 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     g.a_exact16 = a_exact16;
     g.a_exact_nonce = a_exact_nonce;
     g.b_row_scale = b_row_scale;
+    g.ep_x = o.ep_x; g.ep_ll = o.ep_ll; g.ep_xx = o.ep_xx;
     g.ex_zu = ex_zu; g.ex_eps = ex_eps; g.ex_Z = ex_Z; g.ex_sc = ex_sc;
     g.n_seg = jumps ? jumps->n_seg : 0x7fffffff;
     g.k_seg = jumps ? jumps->k_seg : 0x7fffffff;
@@ -1028,6 +1114,8 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     const bool big = va8 && vb8 && (M > 96 || (M > 32 && K >= 2048));
     static const bool fp32_mfma = getenv("D3P_GEMM_FP32_MFMA") != nullptr;  // developer switch: the fp32-MFMA kernel for the large products
     if (b_row_scale && !(big && !fp32_mfma && b_sn == 1)) return fail(D3P_E_INVALID_ARG, "gemm: b_row_scale on a product that does not take the bf16 kernel");
+    if (epi == 4 && !(big && !fp32_mfma && !part && a_sk == 1 && b_sn == 1 && o.ep_x && o.ep_ll && o.ep_xx))
+        return fail(D3P_E_INVALID_ARG, "gemm: epilogue 4 on a product that does not take the bf16 kernel unsplit");
     const int tm = big ? D3P_GTM : D3P_GT;
     const unsigned tiles = cdiv(N, D3P_GT) * cdiv(M, tm);
     int splits = 1;
@@ -1069,7 +1157,8 @@ static int gemm(hipStream_t s, const float* A, long long a_sm, long long a_sk, c
     }
     if (big && !fp32_mfma) {
         const bool ak = a_sk == 1, bn = b_sn == 1;
-        if (ak && bn) hipLaunchKernelGGL((k_gemm_bf16x3<true, true>), grid, dim3(512), 0, s, g);
+        if (epi == 4) hipLaunchKernelGGL((k_gemm_bf16x3<true, true, true>), grid, dim3(512), 0, s, g);
+        else if (ak && bn) hipLaunchKernelGGL((k_gemm_bf16x3<true, true>), grid, dim3(512), 0, s, g);
         else if (ak) hipLaunchKernelGGL((k_gemm_bf16x3<true, false>), grid, dim3(512), 0, s, g);
         else if (bn) hipLaunchKernelGGL((k_gemm_bf16x3<false, true>), grid, dim3(512), 0, s, g);
         else hipLaunchKernelGGL((k_gemm_bf16x3<false, false>), grid, dim3(512), 0, s, g);
@@ -1269,9 +1358,48 @@ struct NormArgs {
     float* cf;
     float* norms;  // nullable
     int scale_back;        // 0: the deltas stay as they are -- the weight-gradient products apply cf themselves (GemmArgs::b_row_scale)
-    const float* px_loss;  // the LAST workgroup of the launch sums px_loss and counts the unmasked examples into loss_n[0..1]
+    float* px_loss;        // the LAST workgroup of the launch sums px_loss and counts the unmasked examples into loss_n[0..1]
     float* loss_n;         // (fixed order; was a launch of its own)
+    // the output layer's epilogue left per-group partial sums instead of px_loss / x2 (GemmArgs::epi 4): every row's wave finishes
+    // them here (vae_out_finish_row) -- px_loss is then complete only when this launch ends, so the last workgroup leaves loss_n[0]
+    // alone and a later launch sums px_loss (k_vae_finalize / k_vae_tile_sums: vae_block_sum)
+    const float* ep_ll;    // nullable: [ep_groups][B]
+    const float* ep_xx;
+    const float* lat;
+    int ep_groups;         // <= 64
+    float ep_sc;
 };
+
+// (the finishing step of GemmArgs::epi 4 for one example: px_loss[i] = sc (lat_i - sum_g ll[g][i]) mask_i; returns |x_i|^2)
+__device__ __forceinline__ float vae_out_finish_row(const float* __restrict__ ep_ll, const float* __restrict__ ep_xx, int groups, uint32_t B,
+                                                    uint32_t i, int lane, const float* __restrict__ lat, float sc, bool live,
+                                                    float* __restrict__ px_loss)
+{
+    float l = 0.f, x = 0.f, sl, sx;
+    if (lane < groups) {
+        l = ep_ll[(size_t)lane * B + i];
+        x = ep_xx[(size_t)lane * B + i];
+    }
+    wave_sum2(l, x, sl, sx);
+    if (lane == 0) px_loss[i] = live ? sc * (lat[i] - sl) : 0.f;
+    return sx;
+}
+
+// sum of v[0 .. n - 1] by one workgroup of 256 threads, fixed order; lds: 256 floats; every thread gets the total
+__device__ __forceinline__ float vae_block_sum(const float* __restrict__ v, uint32_t n, float* lds)
+{
+    float s = 0.f;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) s += v[i];
+    lds[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) lds[threadIdx.x] += lds[threadIdx.x + off];
+        __syncthreads();
+    }
+    const float tot = lds[0];
+    __syncthreads();
+    return tot;
+}
 
 // this lane's share of a row's sum of squares (16-byte loads: elements 4 l .. 4 l + 3, + 256, ...; rows that cannot take them:
 // elements l, l + 64, ...), copying what it reads to `keep` when given -- the wave sums come later, all terms at once
@@ -1324,13 +1452,18 @@ __global__ void k_vae_norms(NormArgs a)
             if ((int)threadIdx.x < off) { l[threadIdx.x] += l[threadIdx.x + off]; c[threadIdx.x] += c[threadIdx.x + off]; }
             __syncthreads();
         }
-        if (threadIdx.x == 0) { a.loss_n[0] = l[0]; a.loss_n[1] = c[0]; }
+        if (threadIdx.x == 0) {
+            if (!a.ep_ll) a.loss_n[0] = l[0];   // (fused output layer: px_loss is being written by this very launch)
+            a.loss_n[1] = c[0];
+        }
         return;
     }
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (i >= a.B) return;
     float* keep = norm_stage + (size_t)(threadIdx.x >> 6) * a.stage;
+    const float x2_row = a.ep_ll ? vae_out_finish_row(a.ep_ll, a.ep_xx, a.ep_groups, a.B, i, lane, a.lat, a.ep_sc, !(a.mask && a.mask[i] == 0), a.px_loss)
+                                 : a.x2[i];
     // every term's loads first (per-lane partial sums: nothing waits for a wave sum between two terms), then all wave sums
     float pin[D3P_VAE_MAX_TERMS], pd[D3P_VAE_MAX_TERMS];
     {
@@ -1356,7 +1489,7 @@ __global__ void k_vae_norms(NormArgs a)
         if (t < a.n_terms) {
             float in2, d;
             wave_sum2(pin[t], pd[t], in2, d);
-            if (!a.t[t].in) in2 = a.x2[i];
+            if (!a.t[t].in) in2 = x2_row;
             n2 += (in2 + 1.0f) * d;
         }
     }
@@ -1401,6 +1534,18 @@ __global__ void __launch_bounds__(256) k_vae_loss_n(const float* __restrict__ px
     if (threadIdx.x == 0) { out[0] = l[0]; out[1] = c[0]; }
 }
 
+// the finishing step of GemmArgs::epi 4 as a launch of its own, where no norm kernel follows the forward pass (evaluate)
+__global__ void __launch_bounds__(256) k_vae_out_finish(const float* __restrict__ ep_ll, const float* __restrict__ ep_xx, int groups, uint32_t B,
+                                                        const float* __restrict__ lat, float sc, const uint8_t* __restrict__ mask,
+                                                        float* __restrict__ px_loss, float* __restrict__ x2)
+{
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= B) return;
+    const float xx = vae_out_finish_row(ep_ll, ep_xx, groups, B, i, lane, lat, sc, !(mask && mask[i] == 0), px_loss);
+    if (lane == 0) x2[i] = xx;
+}
+
 // mean, Gaussian mechanism, rescale (svi.py:343-346, :365-375), numpyro Adam (svi.py:379-393) over the P parameters
 #define D3P_VAE_MAX_BLOCKS 7  // [W | b] blocks of the flat layout: 2 nh + 3 with nh <= 2 hidden layers
 
@@ -1437,8 +1582,14 @@ __device__ __forceinline__ float vae_tile_sum(const VaeTiles& a, size_t col, flo
 }
 
 // sums[col] := the tile sums (stage API and data-parallel local sums: the sums leave the device function as one vector)
-__global__ void __launch_bounds__(256) k_vae_tile_sums(VaeTiles a, float* __restrict__ sums, size_t P)
+// px_loss != nullptr (fused output layer): sums[P] = sum_i px_loss[i] too (workgroup 0; the norm kernel could not: see NormArgs)
+__global__ void __launch_bounds__(256) k_vae_tile_sums(VaeTiles a, float* __restrict__ sums, size_t P, const float* __restrict__ px_loss, uint32_t B)
 {
+    __shared__ float lds[256];
+    if (px_loss && blockIdx.x == 0) {
+        const float tot = vae_block_sum(px_loss, B, lds);
+        if (threadIdx.x == 0) sums[P] = tot;
+    }
     const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col < P) sums[col] = vae_tile_sum(a, col, sums[col]);
 }
@@ -1460,17 +1611,23 @@ struct VaeFinalArgs {
     uint32_t B;
     d3p_dpsvi_hyper h;
     float obs_scale;
+    const float* px_loss;   // nullable (fused output layer, single-device update): the loss sum is taken here, sum_i px_loss[i] over
+    uint32_t B_local;       // B_local examples, instead of from sums[P] (NormArgs)
 };
 
-__global__ void k_vae_finalize(VaeFinalArgs a)
+__global__ void __launch_bounds__(256) k_vae_finalize(VaeFinalArgs a)
 {
     __shared__ float bc[2];  // Adam's bias corrections 1 - b^(i + 1): two powf per workgroup instead of per column
+    __shared__ float lsum[256];
     if (threadIdx.x < 2) bc[threadIdx.x] = 1.0f - powf(threadIdx.x ? a.h.b2 : a.h.b1, (float)(*a.step + 1));
     __syncthreads();
     const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const float n = a.sums[a.P + 1], Bf = (float)a.B;
     const float factor = (n == 0.f) ? 0.f : Bf / n;
-    if (col == 0 && a.loss_out) *a.loss_out = (a.sums[a.P] / Bf) * a.obs_scale * factor;
+    if (blockIdx.x == 0 && a.loss_out) {   // (workgroup-uniform)
+        const float ls = a.px_loss ? vae_block_sum(a.px_loss, a.B_local, lsum) : a.sums[a.P];
+        if (threadIdx.x == 0) *a.loss_out = (ls / Bf) * a.obs_scale * factor;
+    }
     if (col >= a.P) return;
     const float tot = vae_tile_sum(a.tiles, col, a.sums[col]);
     const float g = (tot / Bf + a.noise[col] * (a.h.dp_scale * (a.h.clip / n))) * a.obs_scale * factor;
@@ -1650,6 +1807,7 @@ struct VaeWorkspace {
     uint32_t* keys;  // 3 x 16 split + up to 14 x 16 site keys + jax key + step index (D3P_VAE_KEY_*)
     uint32_t* x_exact16;  // one word: the batch X is exactly bf16 (GemmArgs::a_exact16), set per forward pass
     float *wcat, *wcatT;  // the latent heads packed for the step (k_vae_keys): [Wl | Ws] (HE x 2 Z) and its transpose
+    float *ep_ll, *ep_xx; // per-group partial row sums of the output layer's epilogue (GemmArgs::epi 4): [ceil(D / 32)][B] each
 };
 
 // one step of the native run loop (d3p_dpvi_vae_run): the batch is rows of a resident table, chosen by the Feistel sampler
@@ -1702,6 +1860,8 @@ static size_t vae_carve(const d3p_vae_model* m, uint32_t B, char* base, VaeWorks
     q = take(64); if (ws) ws->x_exact16 = (uint32_t*)q;
     q = take((size_t)N.HE * 2 * Z); if (ws) ws->wcat = q;
     q = take((size_t)N.HE * 2 * Z); if (ws) ws->wcatT = q;
+    q = take((size_t)cdiv(D, 32) * B); if (ws) ws->ep_ll = q;
+    q = take((size_t)cdiv(D, 32) * B); if (ws) ws->ep_xx = q;
     return off;
 }
 
@@ -1762,9 +1922,12 @@ static unsigned vae_exact_blocks(size_t n4) { return (unsigned)(n4 / 1024 < 1 ? 
 
 static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const float* params, const float* X, const uint8_t* mask,
                                uint32_t B, const float* eps, float sc, const VaeWorkspace& ws, const uint32_t* jax_key = nullptr,
-                               uint32_t B_total = 0, uint32_t pos0 = 0, VaeStepPrep prep = VaeStepPrep(), const SiteNoiseArgs* noise = nullptr)
+                               uint32_t B_total = 0, uint32_t pos0 = 0, VaeStepPrep prep = VaeStepPrep(), const SiteNoiseArgs* noise = nullptr,
+                               bool* out_fused = nullptr)
 {
     // noise != nullptr: the Gaussian-mechanism noise of the update is drawn beside the latent kernel
+    // out_fused != nullptr: the caller's norm kernel finishes a fused output layer (*out_fused says whether there is one: ws.ep_ll /
+    // ws.ep_xx then hold per-group partial sums, px_loss / x2 do not exist yet); nullptr: px_loss and x2 are complete on return
     int rc;
     const VaeNet N = vae_net(m);
     const int D = N.D, Z = N.Z, HE = N.HE, nh = N.nh, Bi = (int)B;
@@ -1836,6 +1999,21 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
             ld_in = d.out;
         }
         const VaeDense& o = N.dec[nh];
+        // the output layer: when the product takes the bf16 kernel its epilogue does k_vae_out's work (GemmArgs::epi 4) instead of a
+        // launch behind it
+        static const bool no_fuse = getenv("D3P_VAE_NO_OUT_FUSE") != nullptr;   // developer switch (A/B), read once
+        const int groups = (int)cdiv(D, 32);
+        const bool fuse = !no_fuse && groups <= 64 && gemm_takes_bf16_nfast(in, ld_in, 1, params + o.W, D, 1, Bi, D, o.in, 0);
+        if (out_fused) *out_fused = fuse;
+        if (fuse) {
+            GemmOpts go;
+            go.epi = 4; go.ex_sc = sc; go.ep_x = X; go.ep_ll = ws.ep_ll; go.ep_xx = ws.ep_xx;
+            if ((rc = gemm(s, in, ld_in, 1, params + o.W, D, 1, ws.a, D, Bi, D, o.in, params + o.b, 1.f, 0, go))) return rc;   // a := da
+            if (!out_fused)
+                hipLaunchKernelGGL(k_vae_out_finish, rows, dim3(256), 0, s, (const float*)ws.ep_ll, (const float*)ws.ep_xx, groups, B, (const float*)ws.lat,
+                                   sc, mask, ws.px_loss, ws.x2);
+            return check_launch("d3p_vae forward");
+        }
         if ((rc = gemm(s, in, ld_in, 1, params + o.W, D, 1, ws.a, D, Bi, D, o.in, params + o.b, 1.f, 0))) return rc;
     }
     hipLaunchKernelGGL(k_vae_out, rows, dim3(256), 0, s, ws.a, X, mask, B, D, sc, (const float*)ws.lat, ws.px_loss, ws.x2);  // a := da
@@ -1846,7 +2024,7 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
 static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* params, const float* X, const uint8_t* mask,
                             uint32_t B, const float* eps_ext, const uint32_t* jax_key, float clip, const VaeWorkspace& ws,
                             float* norms_out, uint32_t B_total = 0, uint32_t pos0 = 0, int* w_splits = nullptr, VaeStepPrep prep = VaeStepPrep(),
-                            const SiteNoiseArgs* noise = nullptr)
+                            const SiteNoiseArgs* noise = nullptr, bool* loss_pending = nullptr)
 {
     // The split-K partial tiles of the weight-gradient products stay in ws.wpart.  w_splits != nullptr (single-device update):
     // w_splits[0 .. n_blocks - 1] says how many each, and k_vae_finalize sums them; otherwise ONE launch (k_vae_tile_sums) sums
@@ -1858,7 +2036,10 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     const float sc = m->inv_obs * m->scale;
     const float* eps = eps_ext ? eps_ext : ws.eps;  // (drawn inside k_vae_latent when not given)
     const dim3 rows(cdiv((uint64_t)B * 64, 256));
-    if ((rc = vae_enqueue_forward(s, m, params, X, mask, B, eps_ext, sc, ws, jax_key, B_total, pos0, prep, noise))) return rc;
+    // loss_pending (with w_splits, the single-device update): *loss_pending = the output layer was fused and ws.sums[P] is NOT the loss
+    // sum -- the caller's k_vae_finalize takes it from ws.px_loss; without w_splits the tile-sum launch below does
+    bool out_fused = false;
+    if ((rc = vae_enqueue_forward(s, m, params, X, mask, B, eps_ext, sc, ws, jax_key, B_total, pos0, prep, noise, &out_fused))) return rc;
     // ---- backward (data): delta_in = (delta_out W^T) . softplus'(pre) down the decoder
     {
         const float* delta = ws.a;
@@ -1945,6 +2126,7 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     na.x2 = ws.x2;
     na.mask = mask; na.B = B; na.clip = clip; na.cf = ws.cf; na.norms = norms_out;
     na.px_loss = ws.px_loss; na.loss_n = ws.sums + N.P;
+    if (out_fused) { na.ep_ll = ws.ep_ll; na.ep_xx = ws.ep_xx; na.lat = ws.lat; na.ep_groups = (int)cdiv(D, 32); na.ep_sc = sc; }
     {
         size_t stage_floats = na.scale_back ? 4 * (size_t)na.stage : 0;
         if (stage_floats < 512) stage_floats = 512;  // the last workgroup's loss / count reduction uses 2 x 256 floats
@@ -1977,8 +2159,16 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
         tile_splits[wg[b].blk] = left;
         if (b == n_wg - 1) tile_splits[wg[b].blk + 1] = left;
     }
+    bool loss_summed = false;   // (fused output layer: the group launch sums px_loss into S[P] beside its products)
+    if (group && out_fused && plan.n > 0) {
+        plan.sum_in = ws.px_loss; plan.sum_out = S + N.P; plan.sum_n = B;
+        loss_summed = true;
+    }
     if (group && (rc = gemm_group_launch(s, plan))) return rc;
-    if (!w_splits) hipLaunchKernelGGL(k_vae_tile_sums, dim3(cdiv(N.P, 256)), dim3(256), 0, s, vae_tiles(N, ws, tile_splits), S, N.P);
+    if (loss_pending) *loss_pending = out_fused && !loss_summed;
+    if (!w_splits)
+        hipLaunchKernelGGL(k_vae_tile_sums, dim3(cdiv(N.P, 256)), dim3(256), 0, s, vae_tiles(N, ws, tile_splits), S, N.P,
+                           (out_fused && !loss_summed) ? (const float*)ws.px_loss : (const float*)nullptr, B);
     return check_launch("d3p_vae sums");
 }
 
@@ -2135,16 +2325,18 @@ static SiteNoiseArgs vae_site_noise_args(const VaeNet& N, const VaeWorkspace& ws
 static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                           const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
                           void* workspace_dev, size_t workspace_bytes, bool derive_keys, const int* w_splits = nullptr,
-                          const d3p_dpsvi_state* from = nullptr);
+                          const d3p_dpsvi_state* from = nullptr, bool loss_pending = false);
 
 // advance = true (single-device update): the key kernel also writes the next state key and advances the step counter, so that
 // vae_apply_impl(derive_keys = false) has nothing left to launch for them
 static int vae_local_sums_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                                const float* X_dev, const uint8_t* mask_dev, uint32_t B_local, uint32_t B_total, uint32_t pos0,
                                const float* eps_dev, float* sums_dev, void* workspace_dev, size_t workspace_bytes, bool advance,
-                               int* w_splits = nullptr, const d3p_dpsvi_state* from = nullptr, const VaeRunStep* rs = nullptr)
+                               int* w_splits = nullptr, const d3p_dpsvi_state* from = nullptr, const VaeRunStep* rs = nullptr,
+                               bool* loss_pending = nullptr)
 {
     // rs != nullptr: X_dev is the batch BUFFER; the step's rows are gathered into it here (indices from the key launch)
+    // loss_pending (with w_splits): vae_enqueue_sums' -- the caller hands it on to vae_apply_impl
     if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_local_sums")) return rc;
     D3P_REQUIRE(X_dev && sums_dev, "d3p_dpvi_vae_local_sums: null pointer");
     D3P_REQUIRE(B_local >= 1 && (uint64_t)pos0 + B_local <= B_total, "d3p_dpvi_vae_local_sums: need 1 <= B_local and pos0 + B_local <= B_total");
@@ -2168,7 +2360,7 @@ static int vae_local_sums_impl(void* stream, const d3p_vae_model* model, const d
     // drawn here, beside the latent kernel
     const SiteNoiseArgs noise = vae_site_noise_args(vae_net(model), ws);
     if ((rc = vae_enqueue_sums(s, model, from ? from->params : state->params, X_dev, mask_dev, B_local, eps_dev, ws.keys + D3P_VAE_KEY_JAX, hyper->clip, ws, nullptr,
-                               B_total, pos0, w_splits, prep, w_splits ? &noise : nullptr)))
+                               B_total, pos0, w_splits, prep, w_splits ? &noise : nullptr, w_splits ? loss_pending : nullptr)))
         return rc;
     if (sums_dev != ws.sums)
         D3P_HIP_TRY(hipMemcpyAsync(sums_dev, ws.sums, (vae_net(model).P + 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -2195,8 +2387,10 @@ int d3p_dpvi_vae_apply(void* stream, const d3p_vae_model* model, const d3p_dpsvi
 // workspace and state, as in the single-device update)
 static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                           const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
-                          void* workspace_dev, size_t workspace_bytes, bool derive_keys, const int* w_splits, const d3p_dpsvi_state* from)
+                          void* workspace_dev, size_t workspace_bytes, bool derive_keys, const int* w_splits, const d3p_dpsvi_state* from,
+                          bool loss_pending)
 {
+    // loss_pending (single-device update): sums_dev[P] does not hold the loss sum -- k_vae_finalize takes it from ws.px_loss
     if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_apply")) return rc;
     D3P_REQUIRE(sums_dev && B_total >= 1 && B_local >= 1, "d3p_dpvi_vae_apply: null pointer or empty batch");
     if (workspace_bytes < d3p_dpvi_vae_workspace(model, B_local)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_apply: workspace too small");
@@ -2228,6 +2422,8 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
     f.B = B_total;
     f.h = *hyper;
     f.obs_scale = 1.0f / model->inv_obs;
+    f.px_loss = loss_pending ? ws.px_loss : nullptr;
+    f.B_local = B_local;
     hipLaunchKernelGGL(k_vae_finalize, dim3(cdiv(N.P, 256)), dim3(256), 0, s, f);
     return check_launch("d3p_dpvi_vae_apply");
 }
@@ -2248,11 +2444,12 @@ int d3p_dpvi_vae_update_from(void* stream, const d3p_vae_model* model, const d3p
     VaeWorkspace ws;
     vae_carve(model, B, (char*)workspace_dev, &ws);
     int w_splits[D3P_VAE_MAX_BLOCKS];
+    bool loss_pending = false;
     if (int rc = vae_local_sums_impl(stream, model, hyper, state, X_dev, mask_dev, B, B, 0, eps_dev, ws.sums, workspace_dev,
-                                     workspace_bytes, true, w_splits, from))
+                                     workspace_bytes, true, w_splits, from, nullptr, &loss_pending))
         return rc;
     return vae_apply_impl(stream, model, hyper, state, ws.sums, B, B, loss_dev, grad_out_dev, workspace_dev, workspace_bytes, false,
-                          w_splits, from);
+                          w_splits, from, loss_pending);
 }
 
 static int vae_update_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
@@ -2267,11 +2464,12 @@ static int vae_update_impl(void* stream, const d3p_vae_model* model, const d3p_d
     VaeWorkspace ws;
     vae_carve(model, B, (char*)workspace_dev, &ws);
     int w_splits[D3P_VAE_MAX_BLOCKS];  // split-K partial tiles of the weight gradients are summed by k_vae_finalize, not by reduction launches
+    bool loss_pending = false;
     if (int rc = vae_local_sums_impl(stream, model, hyper, state, X_dev, mask_dev, B, B, 0, eps_dev, ws.sums, workspace_dev,
-                                     workspace_bytes, true, w_splits, nullptr, rs))
+                                     workspace_bytes, true, w_splits, nullptr, rs, &loss_pending))
         return rc;
     return vae_apply_impl(stream, model, hyper, state, ws.sums, B, B, loss_dev, grad_out_dev, workspace_dev, workspace_bytes, false,
-                          w_splits);
+                          w_splits, nullptr, loss_pending);
 }
 
 int d3p_dpvi_vae_update(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
