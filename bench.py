@@ -374,6 +374,17 @@ def main():
     from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
     from d3p_amd.svi import DPSVI, DPSVIState
 
+    # stdout carries ONE thing, the JSON line: from here on file descriptor 1 is stderr for everybody in this process -- Python prints,
+    # libraries that write to stdout on their own (gloo announces its ranks there, RCCL can be made to) -- and the line goes out through
+    # the saved descriptor (emit)
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(text):
+        sys.stdout.flush()
+        os.write(json_fd, (text + "\n").encode())
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -714,12 +725,12 @@ def main():
         def give_up():
             if rank == 0:
                 if progress.get("m") is not None:   # the native headline leg is done: a leg BEHIND it stalled
-                    print(line(progress["m"], extra={"note": "a leg behind the headline leg did not finish within the watchdog limit and was "
+                    emit(line(progress["m"], extra={"note": "a leg behind the headline leg did not finish within the watchdog limit and was "
                                                              "cut; the headline figures are the native data-parallel loop's",
-                                                     "torch_loop": {"steps_per_sec": fb["steps_per_sec"], "value": fb["value"]}}), flush=True)
+                                                     "torch_loop": {"steps_per_sec": fb["steps_per_sec"], "value": fb["value"]}}))
                 else:
-                    print(line(fb, extra={"note": "native data-parallel loop did not finish within the watchdog limit; this is "
-                                                  "the Python-driven torch.distributed loop"}), flush=True)
+                    emit(line(fb, extra={"note": "native data-parallel loop did not finish within the watchdog limit; this is "
+                                                  "the Python-driven torch.distributed loop"}))
             os._exit(0)
         dog = threading.Timer(float(os.environ.get("D3P_BENCH_WATCHDOG_S", "240")), give_up)
         dog.daemon = True
@@ -730,12 +741,12 @@ def main():
             print(f"[bench] {e}", file=sys.stderr, flush=True)
             if rank == 0:
                 if progress.get("m") is not None:
-                    print(line(progress["m"], extra={"note": f"a leg behind the headline leg was stopped ({e}) and cut; the headline figures "
+                    emit(line(progress["m"], extra={"note": f"a leg behind the headline leg was stopped ({e}) and cut; the headline figures "
                                                              "are the native data-parallel loop's",
-                                                     "torch_loop": {"steps_per_sec": fb["steps_per_sec"], "value": fb["value"]}}), flush=True)
+                                                     "torch_loop": {"steps_per_sec": fb["steps_per_sec"], "value": fb["value"]}}))
                 else:
-                    print(line(fb, extra={"note": f"native data-parallel loop stopped ({e}); this is the Python-driven "
-                                                  "torch.distributed loop"}), flush=True)
+                    emit(line(fb, extra={"note": f"native data-parallel loop stopped ({e}); this is the Python-driven "
+                                                  "torch.distributed loop"}))
             os._exit(0)
         barrier()
         dog.cancel()
@@ -756,7 +767,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(d, args.batch_per_gpu, args.cpu_seconds, rows=200_000)
     if rank == 0:
-        print(line(m, cpu, extra), flush=True)
+        emit(line(m, cpu, extra))
 
 
 if __name__ == "__main__":
