@@ -27,6 +27,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (the host driver of this pool only supports dmabuf IPC: without this the exchange's hipIpcGetMemHandle fails; it must be in the
+# environment before the HIP runtime starts, also when the ranks come from torch.distributed.run and not from spawn_ranks)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, the fp32 matrix (= vector) peak
