@@ -191,6 +191,7 @@ SIGNATURES = {
     "d3p_xchg_simulate_peers": (C.c_int, [_V, _V, _U32]),
     "d3p_dpvi_logreg_run_xchg": (C.c_int, [_V, _V, _PM, _PH, _PS, _PB, _V, _V, _U32, _V, _V, _SZ]),
     "d3p_dpvi_logreg_set_run_form": (C.c_int, [C.c_int]),
+    "d3p_dpvi_logreg_chain_grid": (C.c_int, [_V, _V, C.c_int, _V, _V]),
     "d3p_dpvi_logreg_kernel_timing_enable": (C.c_int, [C.c_int]),
     "d3p_dpvi_logreg_kernel_timing_read": (C.c_int, [_V, _V, _V]),
     "d3p_comm_unique_id": (C.c_int, [_V, C.c_size_t]),
@@ -240,7 +241,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.d3p_abi_version() != 7:
+        if lib.d3p_abi_version() != 8:
             raise D3PError("libd3p_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -24,6 +24,7 @@
 
 #include <dlfcn.h>
 #include <mutex>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 #include <rccl/rccl.h>  // types only: the entry points are resolved at run time from the RCCL torch has loaded
@@ -288,11 +289,18 @@ __global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
             if (a.status[8 + k]) printf(" kind %d: step %u;", k, 0x1000u - a.status[8 + k]);
         printf("\n");
     }
-    if (tid == 0 && a.host_status) {
-        a.host_status[0] = aborted;
-        a.host_status[1] = a.status[1];
-        a.host_status[2] = a.host_tag;
-    }
+    // the run's status for the host: ONE 16-byte store {abort code | non-finite flag, tag} into THIS workspace's pinned slot
+    auto status_to_host = [&](uint32_t code) {
+        if (tid == 0 && a.host_status) {
+            d3p_u32x4 rec;
+            rec.x = code;
+            rec.y = a.status[1];
+            rec.z = (uint32_t)a.host_tag;
+            rec.w = (uint32_t)(a.host_tag >> 32);
+            *reinterpret_cast<d3p_u32x4*>(a.host_status) = rec;
+        }
+    };
+    status_to_host(aborted);
     if (aborted) {  // the pending sums are incomplete: leave the state where the run stopped
         if (tid == 0 && a.loss_out) *a.loss_out = __builtin_nanf("");
         return;
@@ -308,7 +316,15 @@ __global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
         }
         // (cannot happen once the launches are complete: every word of the final epoch was stored by the last updater.  Reported as
         // a stopped run rather than handed on silently.)
-        if (bad && a.host_status) a.host_status[0] = abort_code(D3P_ABORT_RELEASE, 0xfff, 4u);
+        if (bad) status_to_host(abort_code(D3P_ABORT_RELEASE, 0xfff, 4u));
+        // The run's counters: ONE writer, in the run's last kernel, from the schedule (k_run_init / the key-chain links leave the
+        // counts after the run's last prepared step there).  The step launches do not store them: a word that a different workgroup
+        // plain-stores every step keeps the value of whichever XCD's L2 is written back last (svi.py:379-393, :432-434: the
+        // returned state's optimiser step advances once per update).
+        if (tid == 0 && !bad) {
+            *a.adam_step = a.sched->adam_i;
+            if (a.batch_index) *a.batch_index = a.sched->batch_i;
+        }
         return;
     }
     long long nll = 0;
@@ -342,16 +358,81 @@ __global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
     }
 }
 
-// pinned host record of the last run's status words (written by k_flush): spares d3p_dpvi_logreg_run_status its copy
-static unsigned long long* host_status_record()
+// Pinned host records of the runs' status words (written by k_flush as ONE 16-byte store): spare d3p_dpvi_logreg_run_status its
+// copy.  One slot per WORKSPACE (keyed by the address of its status words) -- two in-process ranks on two streams
+// (XchgComm.local_group) each report into their own slot -- and every claim stamps the slot's expected tag with a fresh sequence
+// number, so a record is only ever read as the result of the LAST flush enqueued for that workspace: not a record of an earlier run
+// (a run form that ends without k_flush invalidates the slot and the reader copies the device words), not one of a workspace that
+// lived at the same address before.
+struct StatusSlots {
+    static constexpr int N = 256;
+    struct Entry { int slot; unsigned long long seq; bool valid; };
+    std::mutex mu;
+    unsigned long long* table = nullptr;   // N x 2 words {abort | nonfinite << 32, tag}
+    bool tried = false;
+    unsigned long long seq = 0;
+    int next = 0;
+    uintptr_t owner[N] = {};
+    std::unordered_map<uintptr_t, Entry> by_ws;
+    unsigned long long* base()
+    {
+        if (!tried) {
+            tried = true;
+            void* q = nullptr;
+            if (hipHostMalloc(&q, (size_t)N * 16, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
+            if (q) memset(q, 0, (size_t)N * 16);
+            table = (unsigned long long*)q;
+        }
+        return table;
+    }
+};
+static StatusSlots& status_slots() { static StatusSlots s; return s; }
+
+// the slot the run's k_flush will report into (nullptr: none -- the reader copies) and the tag it must carry
+static unsigned long long* status_slot_claim(const uint32_t* status_words, unsigned long long* tag_out)
 {
-    static unsigned long long* p = [] {
-        void* q = nullptr;
-        if (hipHostMalloc(&q, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return (unsigned long long*)nullptr; }
-        memset(q, 0, 64);
-        return (unsigned long long*)q;
-    }();
-    return p;
+    StatusSlots& S = status_slots();
+    std::lock_guard<std::mutex> lk(S.mu);
+    unsigned long long* t = S.base();
+    *tag_out = 0ull;
+    if (!t) return nullptr;
+    const uintptr_t key = (uintptr_t)status_words;
+    auto it = S.by_ws.find(key);
+    if (it == S.by_ws.end()) {
+        const int slot = S.next;
+        S.next = (S.next + 1) % StatusSlots::N;
+        if (S.owner[slot]) S.by_ws.erase(S.owner[slot]);   // (a pending flush of the evicted workspace carries ITS tag: never taken for ours)
+        S.owner[slot] = key;
+        it = S.by_ws.emplace(key, StatusSlots::Entry{slot, 0ull, false}).first;
+    }
+    it->second.seq = ++S.seq;
+    it->second.valid = true;
+    *tag_out = it->second.seq;
+    return t + 2 * (size_t)it->second.slot;
+}
+
+// a run form that ends without k_flush: whatever the slot holds is not this run's
+static void status_slot_invalidate(const uint32_t* status_words)
+{
+    StatusSlots& S = status_slots();
+    std::lock_guard<std::mutex> lk(S.mu);
+    auto it = S.by_ws.find((uintptr_t)status_words);
+    if (it != S.by_ws.end()) it->second.valid = false;
+}
+
+// after the stream is idle: the record of the workspace's last run, if its flush reported one
+static bool status_slot_read(const uint32_t* status_words, uint32_t* aborted, uint32_t* nonfinite)
+{
+    StatusSlots& S = status_slots();
+    std::lock_guard<std::mutex> lk(S.mu);
+    auto it = S.by_ws.find((uintptr_t)status_words);
+    if (it == S.by_ws.end() || !it->second.valid || !S.table) return false;
+    const volatile unsigned long long* rec = S.table + 2 * (size_t)it->second.slot;
+    const unsigned long long w0 = rec[0], w1 = rec[1];
+    if (w1 != it->second.seq) return false;
+    *aborted = (uint32_t)w0;
+    *nonfinite = (uint32_t)(w0 >> 32);
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -785,7 +866,6 @@ static inline int bit_length_u32(uint32_t v)
 
 // the run's sticky status words (StepFuse::status): behind the arrival counters of the chained launch
 static inline uint32_t* run_status_words(const Workspace& ws) { return ws.chain_bar + (size_t)(D3P_STEP_BATCH + 1) * D3P_BAR_WORDS; }
-
 // D3P_DBG: developer ablation / phase-stamp switches of the step kernel (0 in production); read once per process
 static int dev_dbg_flags()
 {
@@ -814,6 +894,13 @@ struct Ctx {
     uint32_t batch0 = 0;
     Workspace ws2;  // second slot buffer (slots / idx / skeys / noise) for the pipelined run loop
 };
+
+// zeroed status words for a run form that does not end with k_flush: the reader must not take an earlier run's pinned record
+static hipError_t reset_status_words(const Ctx& c)
+{
+    status_slot_invalidate(run_status_words(c.ws));
+    return hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s);
+}
 
 static int enqueue_sched_init(const Ctx& c)
 {
@@ -1822,7 +1909,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     cb[1].ws.acc = c.ws.acc;
     cb[1].ws.stamps = c.ws.stamps;
     if (num_steps == 0) {  // nothing to run: the key and the status words are still defined afterwards
-        D3P_HIP_TRY(hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s));
+        D3P_HIP_TRY(reset_status_words(c));
         const d3p_dpsvi_state* st0 = c.from ? c.from : c.st;
         D3P_HIP_TRY(hipMemcpyAsync(key_out, st0->rng_key + 16 * (st0->key_slot & 1), 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice, c.s));
         if (c.from) {
@@ -1919,6 +2006,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
         }
     }
     if (persist) {  // state, step counters and losses are already final: only the key is left
+        status_slot_invalidate(run_status_words(c.ws));
         hipLaunchKernelGGL(k_sched_finish, dim3(1), dim3(64), 0, c.s, (const Sched*)c.ws.sched, key_out);
         return check_launch("k_sched_finish");
     }
@@ -1952,8 +2040,7 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     fa.key_out = key_out;
     fa.status = run_status_words(c.ws);
     fa.dbg_print = (dev_dbg_flags() & 64) ? 1 : 0;
-    fa.host_status = host_status_record();
-    fa.host_tag = (unsigned long long)(uintptr_t)run_status_words(c.ws);
+    fa.host_status = status_slot_claim(run_status_words(c.ws), &fa.host_tag);
     fa.P = c.P;
     fa.B = (int)c.src->B;
     fa.dp_scale = c.h->dp_scale; fa.clip = c.h->clip; fa.obs_scale = 1.0f / c.m->inv_obs;
@@ -1963,17 +2050,10 @@ static int run_fused_steps(const Ctx& c, const float* X, const float* y, uint32_
     return check_launch("k_flush");
 }
 
-static int make_ctx(Ctx* c, void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
-                    const d3p_dpsvi_state* state, const d3p_batch_source* src, void* workspace_dev,
-                    size_t workspace_bytes)
+// launch geometry of the step kernels for this model and batch source (no device memory involved)
+static int fill_geometry(Ctx* c, const d3p_logreg_model* model, const d3p_batch_source* src)
 {
-    int rc = validate(model, hyper, state, src);
-    if (rc) return rc;
-    D3P_REQUIRE(workspace_dev, "null workspace");
-    const size_t need = carve(model, src, nullptr, nullptr);
-    if (workspace_bytes < need) return fail(D3P_E_WORKSPACE, "workspace too small (%zu < %zu)", workspace_bytes, need);
-    carve(model, src, (char*)workspace_dev, &c->ws, &c->ws2);
-    rc = main_geometry(model, src->B, &c->g);
+    int rc = main_geometry(model, src->B, &c->g);
     if (rc) return rc;
     if (need_owned_list(src)) {
         // a rank processes ~B * (rows held / rows total) positions (Poisson: <= B valid ones): size the grid for
@@ -1988,6 +2068,23 @@ static int make_ctx(Ctx* c, void* stream, const d3p_logreg_model* model, const d
     } else {
         c->items_expected = src->B;
     }
+    c->m = model;
+    c->src = src;
+    return D3P_OK;
+}
+
+static int make_ctx(Ctx* c, void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
+                    const d3p_dpsvi_state* state, const d3p_batch_source* src, void* workspace_dev,
+                    size_t workspace_bytes)
+{
+    int rc = validate(model, hyper, state, src);
+    if (rc) return rc;
+    D3P_REQUIRE(workspace_dev, "null workspace");
+    const size_t need = carve(model, src, nullptr, nullptr);
+    if (workspace_bytes < need) return fail(D3P_E_WORKSPACE, "workspace too small (%zu < %zu)", workspace_bytes, need);
+    carve(model, src, (char*)workspace_dev, &c->ws, &c->ws2);
+    rc = fill_geometry(c, model, src);
+    if (rc) return rc;
     c->s = (hipStream_t)stream;
     c->m = model;
     c->h = hyper;
@@ -2143,7 +2240,7 @@ int d3p_dpvi_logreg_acc_reset(void* stream, const d3p_logreg_model* model, const
     int rc = make_ctx(&c, stream, model, hyper, state, src, workspace_dev, workspace_bytes);
     if (rc) return rc;
     D3P_HIP_TRY(hipMemsetAsync(c.ws.acc, 0, 3 * (size_t)D3P_ACC_R * D3P_ACC_COLS(c.P) * sizeof(long long), c.s));
-    D3P_HIP_TRY(hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s));
+    D3P_HIP_TRY(reset_status_words(c));
     return D3P_OK;
 }
 
@@ -2438,7 +2535,7 @@ int d3p_dpvi_logreg_run(void* stream, const d3p_logreg_model* model, const d3p_d
     D3P_REQUIRE(src->row_lo == 0 && src->row_hi == src->n_rows, "d3p_dpvi_logreg_run is the single-GPU path");
     if (use_fused_step(c)) return run_fused_steps(c, X_dev, y_dev, num_steps, losses_dev);
     if ((rc = enqueue_sched_init(c))) return rc;
-    D3P_HIP_TRY(hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s));  // (no waits, no fixed-point sums: stays 0)
+    D3P_HIP_TRY(reset_status_words(c));  // (no waits, no fixed-point sums: stays 0)
     // Two-kernel steps (D3P_NO_FUSED_STEP): main + finalize per step; the key-chain step of the next batch rides in every
     // k_finalize launch as one extra workgroup.  (Running the chain or the sampler on an auxiliary stream was measured
     // slower -- 19.3-20.1 vs 17.6 us/step -- and is not kept.)
@@ -2525,6 +2622,22 @@ int d3p_dpvi_logreg_chain_status(void* stream, const d3p_logreg_model* model, co
     return D3P_OK;
 }
 
+int d3p_dpvi_logreg_chain_grid(const d3p_logreg_model* model, const d3p_batch_source* src, int data_parallel,
+                               uint32_t* workgroups_per_step_out, int32_t* waves_out)
+{
+    D3P_REQUIRE(model && src && workgroups_per_step_out && waves_out, "d3p_dpvi_logreg_chain_grid: null pointer");
+    Ctx c = Ctx();
+    if (int rc = fill_geometry(&c, model, src)) return rc;
+    *workgroups_per_step_out = 0u;
+    *waves_out = 0;
+    if (!use_chained_steps(c)) return D3P_OK;
+    const bool w16 = (!data_parallel || xchg_updater_form(c)) && chain_w16_enabled();
+    if (!lean_chain_ok(c, w16)) return D3P_OK;
+    *workgroups_per_step_out = w16 ? chain16_blocks(c.items_expected) : c.g.blocks;
+    *waves_out = w16 ? 16 : 8;
+    return D3P_OK;
+}
+
 int d3p_dpvi_logreg_run_status(void* stream, const d3p_logreg_model* model, const d3p_batch_source* src, void* workspace_dev,
                                size_t workspace_bytes, int32_t* aborted_out, int32_t* nonfinite_out)
 {
@@ -2534,13 +2647,12 @@ int d3p_dpvi_logreg_run_status(void* stream, const d3p_logreg_model* model, cons
     carve(model, src, (char*)workspace_dev, &ws);
     D3P_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     // the run's last launch (k_flush) left the words in a pinned host record, tagged with this workspace's status address
-    const volatile unsigned long long* rec = host_status_record();
-    if (rec && rec[2] == (unsigned long long)(uintptr_t)run_status_words(ws)) {
-        *aborted_out = (int32_t)rec[0];
-        *nonfinite_out = (int32_t)rec[1];
+    uint32_t words[2] = {0u, 0u};
+    if (status_slot_read(run_status_words(ws), &words[0], &words[1])) {
+        *aborted_out = (int32_t)words[0];
+        *nonfinite_out = (int32_t)words[1];
         return D3P_OK;
     }
-    uint32_t words[2] = {0u, 0u};
     D3P_HIP_TRY(hipMemcpy(words, run_status_words(ws), sizeof(words), hipMemcpyDeviceToHost));
     *aborted_out = (int32_t)words[0];
     *nonfinite_out = (int32_t)words[1];
@@ -2568,7 +2680,7 @@ int d3p_dpvi_logreg_time_main_kernel(void* stream, const d3p_logreg_model* model
         D3P_HIP_TRY(hipMemcpyAsync(c.ws.scratch_state + P, c.st->adam_m, P * sizeof(float), hipMemcpyDeviceToDevice, c.s));
         D3P_HIP_TRY(hipMemcpyAsync(c.ws.scratch_state + 2 * P, c.st->adam_v, P * sizeof(float), hipMemcpyDeviceToDevice, c.s));
         D3P_HIP_TRY(hipMemsetAsync(c.ws.acc, 0, 3 * (size_t)D3P_ACC_R * D3P_ACC_COLS(P) * sizeof(long long), c.s));
-        D3P_HIP_TRY(hipMemsetAsync(run_status_words(c.ws), 0, 16 * sizeof(uint32_t), c.s));
+        D3P_HIP_TRY(reset_status_words(c));
         st_scratch.params = c.ws.scratch_state;
         st_scratch.adam_m = c.ws.scratch_state + P;
         st_scratch.adam_v = c.ws.scratch_state + 2 * P;

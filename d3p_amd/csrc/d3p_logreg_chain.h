@@ -697,8 +697,8 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
                 lhh += __hip_atomic_load(sums + (size_t)r * PA + P + 2, __ATOMIC_RELAXED, D3P_AGENT);
             }
             if (a.losses && g > 0) a.losses[g - 1] = ((float)loss_join(lhh, lll) / (float)a.B) * a.obs_scale * factor;
-            *a.adam_step = ps->adam_i + 1;
-            if (a.batch_index) *a.batch_index = ps->batch_i + 1u;
+            // (the run's counters -- the optimiser's step, the batch index -- are written ONCE, by k_flush, from the schedule: a word
+            // that a different workgroup plain-stores every step is left with the value of whichever XCD's L2 is written back last)
         }
     }
     {
@@ -953,7 +953,17 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
     D3P_CSTAMP(11)
     if (tid == 0) {
         uint32_t* bar = a.bar + (size_t)step_t * D3P_BAR_WORDS;
-        const uint32_t nw = (uint32_t)a.nw, grp = bid % D3P_BAR_GROUPS, gsize = (nw + D3P_BAR_GROUPS - 1u - grp) / D3P_BAR_GROUPS;
+        // Arrival group = XCD.  The dispatcher deals workgroups to the 8 XCDs by blockIdx.x % 8; a step's workgroups are the nw
+        // consecutive indices from step_t * nw, so for W = 16 (per == nw) the group is taken from blockIdx.x itself and its size is the
+        // count of those indices with that residue -- for EVERY nw, not only multiples of 8 (bid % 8 names an XCD only then: at
+        // nw = 9, 17, 43 a group's counter line and its updater moved to another XCD every step).  nw < 8: one workgroup per group.
+        const uint32_t nw = (uint32_t)a.nw;
+        uint32_t grp = bid % D3P_BAR_GROUPS, gsize = (nw + D3P_BAR_GROUPS - 1u - grp) / D3P_BAR_GROUPS;
+        if (W16 && nw >= D3P_BAR_GROUPS) {
+            const uint32_t first = (uint32_t)step_t * nw;   // (< 2^31: K <= 128 steps of <= 256 workgroups)
+            grp = blockIdx.x % D3P_BAR_GROUPS;
+            gsize = (first + nw + D3P_BAR_GROUPS - 1u - grp) / D3P_BAR_GROUPS - (first + D3P_BAR_GROUPS - 1u - grp) / D3P_BAR_GROUPS;
+        }
         const uint32_t prev = __hip_atomic_fetch_add(bar + D3P_BAR_LINE * (1 + grp), 1u, __ATOMIC_RELAXED, D3P_AGENT);
         if (UPD) {
             // (measured and dropped: ONE counter per step, the last 8 workgroups to arrive as updaters -- one atomic round trip less
@@ -1143,9 +1153,8 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
                     collect(P + 2, hi_own, hi, p2);
                     if (alive) {
                         const float factor = factor0 + (poisoned ? __builtin_nanf("") : 0.0f);
+                        // (one address per step: no two workgroups ever store to the same word.  The run's counters are k_flush's.)
                         if (a.losses) a.losses[g] = ((float)loss_join(hi, tot) / Bf) * a.obs_scale * factor;
-                        *a.adam_step = ms->adam_i + 1;
-                        if (a.batch_index) *a.batch_index = ms->batch_i + 1u;
                     }
                 }
             }

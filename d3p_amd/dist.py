@@ -133,6 +133,14 @@ class HipEngine:
         self.loss = None
         return losses
 
+    def chain_grid(self, data_parallel):
+        """(workgroups per step, waves per workgroup) of the chained launch the native run loop takes for the shape of the last
+        run (d3p_dpvi_logreg_chain_grid; (0, 0): one launch per step).  For tests and measurements: nothing is launched."""
+        nw, waves = C.c_uint32(), C.c_int32()
+        check(_lib.load().d3p_dpvi_logreg_chain_grid(C.byref(self.model), C.byref(self.src), int(bool(data_parallel)), C.byref(nw),
+                                                     C.byref(waves)))
+        return int(nw.value), int(waves.value)
+
     STEP_BATCH = 32
 
     def plan(self, num_steps):

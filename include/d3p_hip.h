@@ -34,7 +34,7 @@ extern "C" {
 #define D3P_E_UNSUPPORTED (-3)
 #define D3P_E_WORKSPACE (-4)
 
-#define D3P_ABI_VERSION 7
+#define D3P_ABI_VERSION 8
 
 int d3p_abi_version(void);
 const char* d3p_last_error(void);
@@ -458,6 +458,13 @@ int d3p_dpvi_logreg_chain_status(void* stream, const d3p_logreg_model* model, co
  *                       (svi.py:342-346) give for a diverged model -- never finite garbage. */
 int d3p_dpvi_logreg_run_status(void* stream, const d3p_logreg_model* model, const d3p_batch_source* src,
                                void* workspace_dev, size_t workspace_bytes, int32_t* aborted_out, int32_t* nonfinite_out);
+
+/* ABI 8: launch geometry of the chained launch for this model and batch source, without running anything: workgroups per step
+ * (0: the shape takes the generic one-launch-per-step kernels) and waves per workgroup, for a single-rank run (data_parallel = 0)
+ * or a rank of a data-parallel run with the in-launch exchange (1: src->row_lo / row_hi give its share of the batch).  What the
+ * tests use to make sure they cover grids that are NOT a multiple of the 8 XCDs (arrival groups, updaters: DESIGN.md section 6u). */
+int d3p_dpvi_logreg_chain_grid(const d3p_logreg_model* model, const d3p_batch_source* src, int data_parallel,
+                               uint32_t* workgroups_per_step_out, int32_t* waves_out);
 
 /* Form of the run loops' launches: 0 (default) -- the chained launch where the shape has one: the steps of a prepared batch in
  * ONE launch whose workgroups hand over through arrival counters, which needs the launch's workgroups to make progress

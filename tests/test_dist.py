@@ -549,6 +549,7 @@ def test_xchg_on_one_rank_is_the_fold(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.coresident
 @pytest.mark.parametrize("world", [2])
 def test_xchg_virtual_ranks_on_streams_match_the_single_rank_run(gpu, world):
     """The exchange kernel and its protocol (folded rows into every inbox as self-validating words -- 32 data bits + the
@@ -613,6 +614,7 @@ def test_xchg_virtual_ranks_on_streams_match_the_single_rank_run(gpu, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.coresident
 @pytest.mark.parametrize("world,B,steps", [(8, 4096, 140), (4, 2048, 40), (3, 512, 24), (16, 4096, 20)])
 def test_xchg_updater_form_with_simulated_peers_runs_the_many_rank_paths(gpu, world, B, steps):
     """The data-parallel chained launch as rank 1 of a `world`-rank job on ONE GPU: the other ranks are played by
@@ -663,8 +665,9 @@ def test_xchg_updater_form_with_simulated_peers_runs_the_many_rank_paths(gpu, wo
 
 
 @pytest.mark.gpu
+@pytest.mark.coresident
 @pytest.mark.parametrize("suppress,maxB", [(False, 560), (False, 500), (True, 520)])
-def test_poisson_batches_sharded_over_two_virtual_ranks_match_the_single_rank_run(gpu, suppress, maxB):
+def test_poisson_batches_sharded_over_two_virtual_ranks_match_the_single_rank_run(gpu, O, suppress, maxB):
     """Data-parallel run on Poisson batches (poisson_batchify_data's sampler, minibatch.py:29-39, :103-131) with the one-shot exchange:
     every rank makes the mask of ITS rows only, the shards' counts travel through the exchange's count box
     (d3p_xchg_poisson_counts), truncation (maxB below the expected batch: the globally highest rows stay) and suppression act on
@@ -707,9 +710,109 @@ def test_poisson_batches_sharded_over_two_virtual_ranks_match_the_single_rank_ru
     if not np.isnan(b).any():
         np.testing.assert_allclose(a, b, rtol=2e-5)
         np.testing.assert_allclose(results[0][0].optim_state[1].cpu().numpy(), ref_state.optim_state[1].cpu().numpy(), rtol=2e-5, atol=2e-6)
+    # ... and against the ORACLE, so that the row survives a bug common to both HIP paths: poisson_sample_idxs + the truncate /
+    # suppress bookkeeping (minibatch.py:29-39, :119-124) and the masked update (svi.py:395-434) over the 16 steps
+    spec = O.logreg_spec(d, False, 1.0, 1.0, lik_scale=n, obs_scale=n)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    ost = O.LogregState(O.PRNGKey(3), d, np.zeros(d, np.float32), np.full(d, -2.0, np.float32))
+    Xn, yn = X.numpy(), y.numpy()
+    el, nvalids = [], []
+    for t in range(steps):
+        idx, nsel, nvalid = O.poisson_select(O.fold_in(O.PRNGKey(4), 2 + t), np.float32(q), n, maxB, suppress=suppress)
+        nvalids.append(nvalid)
+        mask = (np.arange(maxB) < nvalid).astype(np.float32)
+        el.append(O.logreg_update(spec, hy, ost, Xn[idx], yn[idx], mask)[0])
+    el = np.asarray(el, np.float32)
+    assert np.array_equal(np.isnan(a), np.isnan(el))
+    if suppress:
+        assert 0 in nvalids and np.isnan(el).any()       # (the case is what it says: some batch was suppressed)
+    ok = ~np.isnan(el)
+    np.testing.assert_allclose(a[ok], el[ok], rtol=5e-5)
+    assert np.array_equal(results[0][0].rng_key.cpu().numpy().ravel(), ost.key)
+    if ok.all():
+        np.testing.assert_allclose(results[0][0].optim_state[1].cpu().numpy(), ost.params, rtol=2e-4, atol=2e-5)
 
 
 @pytest.mark.gpu
+def test_run_status_is_per_workspace_with_two_runs_in_flight(gpu):
+    """The pinned host record k_flush reports a run's status words into is a slot PER WORKSPACE (one 16-byte store, tagged with the
+    sequence number of the flush that was enqueued last for that workspace): two engines whose runs are enqueued on two streams
+    before either is read back -- one on a table with a NaN row (status word 1: the non-finite marker, parameters NaN like the
+    reference's float sums), one clean -- each report their own status, in either order of reading, and again after a second
+    round in which the roles are swapped (a record of an earlier run is never taken for the last one's)."""
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    n, d, B, X, y = _xchg_problem()
+    svi, st0 = _xchg_svi(n, d)
+    Xbad = X.clone()
+    Xbad[:, 7] = float("nan")
+    tables = {False: (X.cuda(), y.cuda()), True: (Xbad.cuda(), y.cuda())}
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    engines = {}
+    for rnd, bad_first in enumerate([True, False, True]):
+        roles = [bad_first, not bad_first]
+        for r in range(2):
+            Xt, yt = tables[roles[r]]
+            # (round 0 builds the engines; later rounds reuse engine r -- and its workspace -- with the OTHER table's pointers)
+            engines[r] = ddist.FusedHipEngine(svi, Xt, yt, n, 0, n, L.D3P_BATCH_FEISTEL, B) if rnd == 0 else engines[r]
+            engines[r].X, engines[r].y = Xt, yt
+        torch.cuda.synchronize()
+        outs = []
+        for r in range(2):
+            with torch.cuda.stream(streams[r]):
+                outs.append(ddist.run_steps_native(engines[r], st0, rng.PRNGKey(4), 0, 5, comm=None))
+        torch.cuda.synchronize()
+        for r in ([1, 0] if rnd == 1 else [0, 1]):
+            code, nonfinite = ddist.native_run_status(engines[r])
+            assert code == 0 and nonfinite == roles[r], (rnd, r, code, nonfinite)
+            assert bool(torch.isnan(outs[r][0].optim_state[1]).any()) == roles[r]
+            assert int(outs[r][0].optim_state[0]) == 5
+
+
+@pytest.mark.gpu
+@pytest.mark.coresident
+def test_a_stopped_rank_and_a_running_one_in_one_process_report_their_own_codes(gpu):
+    """Two runs in flight in ONE process (what XchgComm.local_group is for), one of them stopped on purpose: rank 1 of a two-rank
+    job whose (simulated) peer answers only the first two of three exchanges -- the updaters' bounded wait for step 2's row runs
+    out (~ 25 s), the run stops, status word 0 names the wait -- while a one-rank run on another stream and workspace completes.
+    Each reads ITS code: the stopped run a non-zero one of kind `row of a peer`, the other 0 (round 4: one record per process,
+    three separate stores -- the last flush won)."""
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    n, d, B, X, y = _xchg_problem()
+    svi, st0 = _xchg_svi(n, d)
+    Xc, yc = X.cuda(), y.cuda()
+    world, rank, steps = 2, 1, 3
+    lo, hi = ddist.shard_rows(n, rank, world)
+    comms = ddist.XchgComm.local_group(world, 2 * d + 4)
+    solo = ddist.XchgComm(2 * d + 4)
+    s_peer, s_stop, s_ok = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    try:
+        stopped = ddist.FusedHipEngine(svi, Xc[lo:hi], yc[lo:hi], n, lo, hi, L.D3P_BATCH_FEISTEL, B)
+        fine = ddist.FusedHipEngine(svi, Xc, yc, n, 0, n, L.D3P_BATCH_FEISTEL, B)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s_peer):
+            comms[rank].simulate_peers(steps - 1)
+        with torch.cuda.stream(s_stop):
+            ddist.run_steps_native(stopped, st0, rng.PRNGKey(4), 0, steps, comm=comms[rank])
+        with torch.cuda.stream(s_ok):
+            ok_state, _ = ddist.run_steps_native(fine, st0, rng.PRNGKey(4), 0, steps, comm=solo)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s_ok):
+            code_ok, _ = ddist.native_run_status(fine)
+        with torch.cuda.stream(s_stop):
+            code_stop, _ = ddist.native_run_status(stopped)
+    finally:
+        for c in comms + [solo]:
+            c.close()
+    assert code_ok == 0 and int(ok_state.optim_state[0]) == steps
+    assert code_stop != 0 and "row" in L.describe_abort(code_stop), L.describe_abort(code_stop)
+
+
+@pytest.mark.gpu
+@pytest.mark.coresident
 @pytest.mark.parametrize("form", ["in_launch", "per_step"])
 def test_xchg_two_processes_over_hipipc(gpu, form):
     """The real thing -- one PROCESS per rank, inboxes mapped through hipIpc handles, system-scope rows across the process

@@ -230,6 +230,7 @@ np.savez(sys.argv[1], losses=losses.cpu().numpy(), params=st.optim_state[1].cpu(
 ''' % (ROOT,)
 
 
+@pytest.mark.coresident
 def test_chain_kernel_exchange_between_two_virtual_ranks_vs_oracle(gpu, O):
     """(iv, second half) two row-sharded ranks on two streams of ONE GPU, exchange inside the chained launch, at B = 4096
     (about 2048 positions per rank): the ranks' launches must be co-resident on the one GPU (tests/test_dist.py explains), so
@@ -381,6 +382,129 @@ def test_chain_kernel_small_and_ragged_grids_vs_oracle(gpu, O, B, icpt, sampler)
             idx, _, nvalid = O.poisson_select(bk, np.float32(B / N), N, maxB)
             mask = (np.arange(maxB) < nvalid).astype(np.float32)
         el.append(O.logreg_update(spec, hy, ost, Xn[idx], yn[idx], mask)[0])
+    _compare(new_st, losses, ost, el, steps)
+
+
+def _shard_oracle_trajectory(O, spec, hy, ost, Xn, yn, bkey, first, N, B, steps, lo, hi):
+    """The oracle's trajectory of ONE shard of a row-sharded job whose other ranks add all-zero rows to the exchange (what
+    d3p_xchg_simulate_peers plays): every step samples the GLOBAL batch (util.py:216-301); all B examples count (a Feistel batch
+    has no padding: n = B, factor 1, svi.py:305), the examples whose rows lie outside [lo, hi) contribute zero loss and zero
+    gradient; per-example noise stays keyed by the global batch position.  d3po_logreg_update's composition of the checker's stages
+    (svi.py:395-434), with the other ranks' rows zeroed between the per-example gradients and the clip."""
+    D = spec.d + spec.intercept
+    el, counts = [], []
+    for t in range(steps):
+        idx = O.feistel_sample(O.fold_in(bkey, first + t), N, B)
+        own = (idx >= lo) & (idx < hi)
+        counts.append(int(own.sum()))
+        ks = np.asarray(O.split(ost.key, 3)).reshape(3, 16)
+        jax_key = O.convert_to_jax_rng_key(ks[1])
+        eps = np.zeros((B, D), np.float32)                      # (only the shard's rows are looked at)
+        for p in np.flatnonzero(own):
+            eps[p] = O.tf_normal(O.px_sample_key(jax_key, B, int(p)), D)
+        px_loss, px_grads, n, factor = O.logreg_px_grads(spec, ost.params[:D], ost.params[D:], Xn[idx], yn[idx], eps)
+        assert n == B and factor == 1.0
+        px_loss[~own] = 0.0
+        px_grads[~own] = 0.0
+        loss, avg = O.combine(O.clip_rows(px_grads, hy.clip), px_loss)
+        g = O.perturb(ks[2], avg, [D, D], hy.dp_scale, hy.clip, n, 1.0 / spec.inv_obs, factor)
+        ost.params, ost.m, ost.v = O.adam(ost.params, ost.m, ost.v, g, ost.step.value, hy.lr, hy.b1, hy.b2, hy.adam_eps)
+        ost.step.value += 1
+        ost.key = ks[0].copy()
+        el.append(loss)
+    return el, counts
+
+
+@pytest.mark.parametrize("B,nw", [(171, 6), (280, 9), (531, 17), (1366, 43)])
+def test_updater_form_alone_on_grids_off_the_xcd_multiple_vs_oracle(gpu, O, B, nw):
+    """The data-parallel UPDATER form on grids that are NOT a multiple of the 8 XCDs -- 6, 9, 17, 43 workgroups per step: the
+    item counts of a rank of 512 / 3, 560 / 2, 4245 / 8 (a Poisson batch padded to its 0.99 quantile over 8 ranks) and 4096 / 3 --
+    with a world of one rank (the exchange with itself: no second stream, nothing that depends on the box), 140 steps across the
+    launch boundary, against the ORACLE trajectory: every loss, the final key, the parameters and the optimiser's step counter
+    (svi.py:379-393, :432-434).  Round 4's driver run returned step 12 of 16 at nw = 9: the counter was a per-step plain store from
+    a workgroup on a different XCD every step; it is k_flush's now."""
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    N, d, steps, first = 20_000, 512, 140, 1
+    X, y = _table(N, d, 300 + nw)
+    svi = _svi(d, False, N)
+    st = _state(svi, rng.PRNGKey(31), d, N)
+    eng = ddist.FusedHipEngine(svi, X.cuda(), y.cuda(), N, 0, N, L.D3P_BATCH_FEISTEL, B)
+    comm = ddist.XchgComm(2 * d + 4)
+    try:
+        new_st, losses = ddist.run_steps_native(eng, st, rng.PRNGKey(32), first, steps, comm=comm)
+        torch.cuda.synchronize()
+        code, _ = ddist.native_run_status(eng)
+    finally:
+        comm.close()
+    assert code == 0, L.describe_abort(code)
+    assert eng.chain_grid(True) == (nw, 16)
+    spec = O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    ost = _oracle_state(O, 31, d)
+    el = _oracle_losses_feistel(O, spec, hy, ost, X.numpy(), y.numpy(), O.PRNGKey(32), first, B, steps)
+    _compare(new_st, losses, ost, el, steps)
+
+
+@pytest.mark.coresident
+@pytest.mark.parametrize("world,B,nw", [(3, 512, 6), (2, 560, 9), (8, 4245, 17), (3, 4096, 43)])
+def test_updater_form_as_a_rank_of_many_on_grids_off_the_xcd_multiple_vs_oracle(gpu, O, world, B, nw):
+    """The same grids as rank 1 of a 3 / 2 / 8 / 3-rank job (d3p_xchg_simulate_peers plays the others: all-zero rows, one
+    workgroup on a second stream): the updaters' sends and their waits for 2 / 1 / 7 / 2 rows, row-sharded batches with position
+    lists whose length changes from step to step, 140 steps -- against the oracle's trajectory of that shard (the other ranks'
+    examples masked), not only against another HIP run."""
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    N, d, steps, first, rank = 20_000, 512, 140, 1, 1
+    X, y = _table(N, d, 400 + nw)
+    svi = _svi(d, False, N)
+    st = _state(svi, rng.PRNGKey(33), d, N)
+    lo, hi = ddist.shard_rows(N, rank, world)
+    comms = ddist.XchgComm.local_group(world, 2 * d + 4)
+    side = torch.cuda.Stream()
+    try:
+        eng = ddist.FusedHipEngine(svi, X[lo:hi].cuda(), y[lo:hi].cuda(), N, lo, hi, L.D3P_BATCH_FEISTEL, B)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            comms[rank].simulate_peers(steps)
+        new_st, losses = ddist.run_steps_native(eng, st, rng.PRNGKey(34), first, steps, comm=comms[rank])
+        torch.cuda.synchronize()
+        code, _ = ddist.native_run_status(eng)
+    finally:
+        for c in comms:
+            c.close()
+    assert code == 0, L.describe_abort(code)
+    assert eng.chain_grid(True) == (nw, 16)
+    spec = O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    ost = _oracle_state(O, 33, d)
+    el, counts = _shard_oracle_trajectory(O, spec, hy, ost, X.numpy(), y.numpy(), O.PRNGKey(34), first, N, B, steps, lo, hi)
+    assert min(counts) < max(counts)
+    _compare(new_st, losses, ost, el, steps)
+
+
+@pytest.mark.parametrize("B,nw", [(1100, 35), (2900, 91)])
+def test_chain_kernel_single_rank_grids_off_the_xcd_multiple_vs_oracle(gpu, O, B, nw):
+    """The single-rank 16-wave form at 35 and 91 workgroups per step (arrival group = blockIdx.x % 8 with a group size that
+    changes from step to step), 140 steps against the oracle."""
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    N, d, steps, first = 50_000, 512, 140, 0
+    X, y = _table(N, d, 500 + nw)
+    svi = _svi(d, False, N)
+    st = _state(svi, rng.PRNGKey(35), d, N)
+    eng = ddist.FusedHipEngine(svi, X.cuda(), y.cuda(), N, 0, N, L.D3P_BATCH_FEISTEL, B)
+    new_st, losses = ddist.run_steps_native(eng, st, rng.PRNGKey(36), first, steps, comm=None)
+    torch.cuda.synchronize()
+    assert ddist.native_run_status(eng) == (0, False)
+    assert eng.chain_grid(False) == (nw, 16)
+    spec = O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    ost = _oracle_state(O, 35, d)
+    el = _oracle_losses_feistel(O, spec, hy, ost, X.numpy(), y.numpy(), O.PRNGKey(36), first, B, steps)
     _compare(new_st, losses, ost, el, steps)
 
 
