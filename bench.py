@@ -428,7 +428,7 @@ def main():
         L.check(lib.d3p_dpvi_logreg_kernel_timing_read(C.byref(us), C.byref(launches), C.byref(steps)))
         return us.value, launches.value, steps.value
 
-    comm = None
+    comm = comm_x = comm_r = None
     dist_driver = "none"
     if not single and not os.environ.get("D3P_DIST_TWO_PHASE") and not os.environ.get("D3P_DIST_TORCH_LOOP"):
         # Preferred data-parallel driver: the native loop (one C call for the whole run; per step one launch and the
@@ -457,10 +457,105 @@ def main():
 
         def rccl_comm():
             return ddist.NativeComm()
-        if not os.environ.get("D3P_DIST_RCCL"):
-            comm = agreed(xchg_comm)
-        if comm is None:
-            comm = agreed(rccl_comm)
+        comm_x = None if os.environ.get("D3P_DIST_RCCL") else agreed(xchg_comm)
+        # (the RCCL communicator is made even when the exchange is available: the first-contact check below runs both)
+        comm_r = None if (share_gpu or (emu and comm_x is not None)) else agreed(rccl_comm)
+        comm = comm_x if comm_x is not None else comm_r
+
+    # ---------------------------------------------------------------- first contact: a CORRECTNESS run before any timed leg
+    # The first time these ranks meet over real links (xGMI, hipIpc-mapped uncached inboxes, RCCL) must not also be the first
+    # measurement: 8 data-parallel steps of the benchmark's shape on a small table with every driver -- the one-shot exchange
+    # inside the chained launch, the RCCL all-reduce of the native loop, the Python-driven torch.distributed loop -- then the
+    # returned states (step counter, key, parameters, Adam moments) are all-gathered and compared: replicas BITWISE equal across the
+    # real ranks (int64 sums are exact and the noise is added once from the same key: SURVEY 8e, F6), exchange = RCCL = torch to
+    # fp32 rounding (other workgroup partials).  A driver that fails here is dropped (exchange -> RCCL -> torch) instead of timed.
+    collective_check = None
+
+    def run_collective_check():
+        nonlocal comm
+        check_steps, n_rows = 8, 16384 * ranks
+        lo, hi = ddist.shard_rows(n_rows, rank, ranks)
+        X = torch.empty((hi - lo, d), dtype=torch.float32, device=dev)
+        y = torch.empty(hi - lo, dtype=torch.float32, device=dev)
+        L.check(lib.d3p_synth_logreg(L.stream_ptr(), 321, lo, hi - lo, d, L.ptr(X), L.ptr(y)))
+        model = LogisticRegression(d, prior_scale=1.0)
+        svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-2), Trace_ELBO(), clipping_threshold=1.0, dp_scale=1.0, num_obs_total=n_rows)
+        params = torch.cat([torch.zeros(D, device=dev), torch.full((D,), svi.guide.unconstrained_init_scale(), device=dev)])
+        state0 = DPSVIState(svi.optim.init(params), rng.PRNGKey(5), float(n_rows))
+        bkey = rng.PRNGKey(6)
+        engine = ddist.FusedHipEngine(svi, X, y, n_rows, lo, hi, L.D3P_BATCH_FEISTEL, Bg)
+
+        def signature(st):   # [step | key (16) | params, m, v as bit patterns]
+            step, par, m, v = st.optim_state
+            return torch.cat([step.reshape(1).to(torch.int32), st.rng_key.reshape(16).view(torch.int32), par.view(torch.int32),
+                              m.view(torch.int32), v.view(torch.int32)]).contiguous()
+
+        def gathered(sig):
+            if world == 1:
+                return [sig]
+            buf = sig.cpu() if share_gpu else sig      # (gloo rehearsal: host tensors)
+            out = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(out, buf)
+            return [o.to(dev) for o in out]
+
+        def drive(c, native):
+            rec = {"ran": False}
+            try:
+                if native:
+                    st, _ = ddist.run_steps_native(engine, state0, bkey, 0, check_steps, comm=c, collect_losses=False)
+                else:
+                    st, _ = ddist.run_steps(engine, state0, bkey, 0, check_steps, collect_losses=False)
+                torch.cuda.synchronize()
+                code = ddist.native_run_status(engine)[0] if native else 0
+            except Exception as e:  # noqa: BLE001 -- a failing driver is reported and dropped, never timed
+                rec["error"] = f"{type(e).__name__}: {e}"
+                st, code = None, -1
+            sig = signature(st) if st is not None else torch.full((17 + 3 * P,), -1, dtype=torch.int32, device=dev)
+            sigs = gathered(sig)
+            rec.update({"ran": st is not None, "status": int(code), "step": int(sig[0]),
+                        "replicas_bitwise": bool(all(torch.equal(sigs[0], o) for o in sigs[1:])) and st is not None})
+            return rec, (st.optim_state[1].clone() if st is not None else None)
+
+        def rel(a, b):
+            if a is None or b is None:
+                return None
+            return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+        t_rec, t_par = drive(None, False) if world > 1 else ({"ran": False, "note": "one process: no torch.distributed loop to compare"}, None)
+        x_rec, x_par = drive(comm_x, True) if comm_x is not None else ({"ran": False}, None)
+        r_rec, r_par = drive(comm_r, True) if comm_r is not None else ({"ran": False}, None)
+        ref = t_par if t_par is not None else (r_par if r_par is not None else x_par)
+        tol = 2e-4     # (parameters after 8 Adam steps of 1e-2; tests/test_dist.py holds the same paths to 1e-4 + 2e-6 absolute)
+
+        def good(rec, par):
+            ok = bool(rec.get("ran")) and rec["status"] == 0 and rec["step"] == check_steps and rec["replicas_bitwise"]
+            if ok and ref is not None and par is not None:
+                ok = rel(par, ref) <= tol
+            if world > 1:   # every rank takes the same decision
+                flag = torch.tensor([int(ok)], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = bool(int(flag[0]))
+            return ok
+        x_ok = good(x_rec, x_par) if comm_x is not None else False
+        r_ok = good(r_rec, r_par) if comm_r is not None else False
+        comm = comm_x if x_ok else (comm_r if r_ok else None)
+        for c in (comm_x, comm_r):
+            if c is not None and c is not comm:
+                c.close()
+        chosen = "xchg" if (comm is comm_x and comm is not None) else "rccl" if comm is not None else "torch"
+        return {"ranks": world, "emulated_ranks": emu or None, "steps": check_steps, "global_batch": Bg, "rows": n_rows,
+                "xchg_bitwise": x_rec.get("replicas_bitwise"), "vs_rccl": rel(x_par, r_par), "vs_torch": rel(x_par, t_par),
+                "rccl_vs_torch": rel(r_par, t_par), "tolerance": tol, "xchg": x_rec, "rccl": r_rec, "torch": t_rec,
+                "xchg_ok": x_ok if comm_x is not None else None, "rccl_ok": r_ok if comm_r is not None else None,
+                "driver_chosen": chosen,
+                "what": "replicas_bitwise: step counter, key, parameters and Adam moments all-gathered over the ranks, equal bit for bit; "
+                        "vs_*: max |difference| of the parameters / max |parameter| after the same 8 steps with the other driver"}
+
+    if not single and not os.environ.get("D3P_DIST_TWO_PHASE") and not os.environ.get("D3P_DIST_TORCH_LOOP") \
+            and not os.environ.get("D3P_BENCH_NO_COLLECTIVE_CHECK"):
+        collective_check = run_collective_check()
+        if rank == 0:
+            print("[bench] collective_check: " + json.dumps(collective_check), file=sys.stderr, flush=True)
     if not single:
         dist_driver = ("native loop, one-shot full-mesh exchange (d3p_xchg)" if isinstance(comm, ddist.XchgComm) else
                        "native loop, RCCL all-reduce" if comm is not None else "torch")
@@ -708,6 +803,8 @@ def main():
             "roofline": m["roofline"], "cpu_baseline": cpu,
             "workloads": aux or None,
         }
+        if collective_check is not None:
+            out["collective_check"] = collective_check
         if emu:
             out["note_emulate_world"] = (f"developer run: rank 0's share of an emulated {emu}-rank weak-scaling job on ONE GPU (exchange with "
                                          "itself); `value` counts the examples this GPU processed")

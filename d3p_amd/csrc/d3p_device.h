@@ -403,6 +403,22 @@ __device__ __forceinline__ double loss_join(long long hi, long long lo)
     return (double)hi * D3P_LOSS_HI_UNIT + (double)lo * (1.0 / D3P_LOSS_LO_SCALE);
 }
 
+// The loss of a batch with NO valid example (a suppressed Poisson batch, minibatch.py:119-122).  The reference multiplies every
+// example's loss by its mask (svi.py:271-281): 0 for finite parameters, but NaN * 0 = NaN once any parameter is not finite --
+// which is the state the first empty batch leaves (svi.py:365: C / 0 = inf).  The step kernels evaluate no masked
+// example, so their reporter asks the parameters the step ran with.  Cold path: one thread, only when n = 0.
+// x(c): parameter c as the step saw it.
+template <class X>
+__device__ inline float empty_batch_loss(int P, X x)
+{
+    bool bad = false;
+    for (int c = 0; c < P; ++c) {
+        const float v = x(c);
+        bad |= !(fabsf(v) <= 3.402823466e38f);
+    }
+    return bad ? __builtin_nanf("") : 0.0f;
+}
+
 // Position -> row of the Feistel permutation sampler (util.py:248-301): ten rounds over the (upper, lower) halves of the position,
 // cycle-walking until the value falls below the capacity.  rc: the 30 round constants (column 0 already forced odd).
 __device__ __forceinline__ uint32_t feistel_permute_dev(const uint32_t* rc, uint32_t capacity, int bits_lower,

@@ -352,7 +352,11 @@ __global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
             lll += a.acc_prev[(size_t)r * PA + a.P];
             lhh += a.acc_prev[(size_t)r * PA + a.P + 2];
         }
-        if (a.loss_out) *a.loss_out = ((float)loss_join(lhh, lll) / Bf) * a.obs_scale * factor;
+        if (a.loss_out) {
+            float lv = ((float)loss_join(lhh, lll) / Bf) * a.obs_scale * factor;
+            if (n == 0.0f) lv = empty_batch_loss(a.P, [&](int c) { return a.state_in[0][c]; });
+            *a.loss_out = lv;
+        }
         *a.adam_step = a.slot->adam_i + 1;
         if (a.batch_index) *a.batch_index = a.slot->batch_i + 1u;
     }

@@ -696,7 +696,11 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
                 lll += __hip_atomic_load(sums + (size_t)r * PA + P, __ATOMIC_RELAXED, D3P_AGENT);
                 lhh += __hip_atomic_load(sums + (size_t)r * PA + P + 2, __ATOMIC_RELAXED, D3P_AGENT);
             }
-            if (a.losses && g > 0) a.losses[g - 1] = ((float)loss_join(lhh, lll) / (float)a.B) * a.obs_scale * factor;
+            if (a.losses && g > 0) {
+                float lv = ((float)loss_join(lhh, lll) / (float)a.B) * a.obs_scale * factor;
+                if (n == 0.0f) lv = empty_batch_loss(P, [&](int c) { return __hip_atomic_load(a.state[in][0] + c, __ATOMIC_RELAXED, D3P_AGENT); });
+                a.losses[g - 1] = lv;
+            }
             // (the run's counters -- the optimiser's step, the batch index -- are written ONCE, by k_flush, from the schedule: a word
             // that a different workgroup plain-stores every step is left with the value of whichever XCD's L2 is written back last)
         }
@@ -959,7 +963,7 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
         // nw = 9, 17, 43 a group's counter line and its updater moved to another XCD every step).  nw < 8: one workgroup per group.
         const uint32_t nw = (uint32_t)a.nw;
         uint32_t grp = bid % D3P_BAR_GROUPS, gsize = (nw + D3P_BAR_GROUPS - 1u - grp) / D3P_BAR_GROUPS;
-        if (W16 && nw >= D3P_BAR_GROUPS) {
+        if (W16 && nw >= D3P_BAR_GROUPS && !(a.dbg & 0x1000)) {   // (D3P_DBG bit 0x1000: round 4's bid % 8 groups, for A/B runs)
             const uint32_t first = (uint32_t)step_t * nw;   // (< 2^31: K <= 128 steps of <= 256 workgroups)
             grp = blockIdx.x % D3P_BAR_GROUPS;
             gsize = (first + nw + D3P_BAR_GROUPS - 1u - grp) / D3P_BAR_GROUPS - (first + D3P_BAR_GROUPS - 1u - grp) / D3P_BAR_GROUPS;
@@ -1138,6 +1142,13 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
                         m = (1.0f - a.b1) * gr + a.b1 * m;
                         v = (1.0f - a.b2) * gr * gr + a.b2 * v;
                         x = x - a.lr * (m * inv_bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * inv_bc2) + a.adam_eps);
+                        if (!(fabsf(x) <= 3.402823466e38f)) {
+                            // (cold) the FIRST step that runs with a non-finite parameter, + 1, in status word 2 -- performed before the
+                            // parameter is published: what the reporter of an EMPTY batch's loss asks (empty_batch_loss, d3p_device.h)
+                            uint32_t expect = 0u;
+                            (void)__hip_atomic_compare_exchange_strong(a.status + 2, &expect, (uint32_t)g + 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, D3P_AGENT);
+                            __builtin_amdgcn_s_waitcnt(0);
+                        }
                         const unsigned long long nt = (unsigned long long)ntag << 32;
                         __hip_atomic_store(xout + c, nt | __float_as_uint(x), __ATOMIC_RELAXED, D3P_AGENT);
                         __hip_atomic_store(a.ll_state[1] + c, nt | __float_as_uint(m), __ATOMIC_RELAXED, D3P_AGENT);
@@ -1154,7 +1165,16 @@ __global__ void __launch_bounds__(64 * W_) k_logreg_chain(ChainArgs a)
                     if (alive) {
                         const float factor = factor0 + (poisoned ? __builtin_nanf("") : 0.0f);
                         // (one address per step: no two workgroups ever store to the same word.  The run's counters are k_flush's.)
-                        if (a.losses) a.losses[g] = ((float)loss_join(hi, tot) / Bf) * a.obs_scale * factor;
+                        if (a.losses) {
+                            float lv = ((float)loss_join(hi, tot) / Bf) * a.obs_scale * factor;
+                            // (n = 0: NaN once any parameter this step ran with was not finite.  The row the step's workgroups polled may
+                            // already belong to step g + 2 -- nothing waits for this thread -- so the updaters leave a mark instead: above)
+                            if (factor0 == 0.0f && !poisoned) {
+                                const uint32_t nf = __hip_atomic_load(a.status + 2, __ATOMIC_RELAXED, D3P_AGENT);
+                                if (nf != 0u && nf <= (uint32_t)g + 1u) lv = __builtin_nanf("");
+                            }
+                            a.losses[g] = lv;
+                        }
                     }
                 }
             }

@@ -770,7 +770,11 @@ __global__ void __launch_bounds__(D3P_MAIN_MAX_THREADS(V, NK)) k_logreg_main(Mai
                 lll += ld_x<CHAIN>(f.acc_prev + (size_t)r * PA + P);
                 lhh += ld_x<CHAIN>(f.acc_prev + (size_t)r * PA + P + 2);
             }
-            if (f.prev_loss_out) *f.prev_loss_out = ((float)loss_join(lhh, lll) / Bf) * a.obs_scale * factor;
+            if (f.prev_loss_out) {
+                float lv = ((float)loss_join(lhh, lll) / Bf) * a.obs_scale * factor;
+                if (n == 0.0f) lv = empty_batch_loss(P, [&](int c) { return ld_x<CHAIN>(f.params_in + c); });
+                *f.prev_loss_out = lv;
+            }
             *f.adam_step = f.prev_meta->adam_i + 1;
             if (f.batch_index) *f.batch_index = f.prev_meta->batch_i + 1u;
         }

@@ -28,6 +28,50 @@ def shard_rows(n_rows: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _runs_beside(a, b, spin_cycles=20_000_000):
+    """True if work on stream `b` completes while a spin kernel is still running on stream `a` (None = the current stream)."""
+    cur = torch.cuda.current_stream()
+    a = cur if a is None else a
+    b = cur if b is None else b
+    torch.cuda.synchronize()
+    x = torch.zeros(8, device="cuda")
+    ea, eb = torch.cuda.Event(), torch.cuda.Event()
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(spin_cycles)
+        ea.record()
+    with torch.cuda.stream(b):
+        x.add_(1.0)
+        eb.record()
+    eb.synchronize()
+    beside = not ea.query()
+    torch.cuda.synchronize()
+    return beside
+
+
+def concurrent_streams(n):
+    """`n` (<= 3) streams whose kernels run BESIDE each other's and beside the current stream's.  A HIP process has 4 hardware
+    queues by default (GPU_MAX_HW_QUEUES); further streams share them, and two streams that share a queue are serialised -- every
+    fourth stream of torch's pool shares the default stream's (tools/probes/stream_queue_probe.py).  Ranks that live in ONE process
+    on separate streams (XchgComm.local_group; d3p_xchg_simulate_peers on a side stream) wait for each other INSIDE their launches:
+    on two streams of one queue the second launch never starts and the bounded waits stop the run.  Streams are probed, not
+    assumed: a spin kernel on one, a small kernel on the other."""
+    if n > 3:
+        raise _lib.D3PError("concurrent_streams: a process has 4 hardware queues -- the current stream and at most 3 beside it")
+    _runs_beside(None, None, 1000)   # (first use of the spin kernel)
+    chosen = []
+    for _ in range(64):
+        if len(chosen) == n:
+            return chosen
+        s = torch.cuda.Stream()
+        if any(s.cuda_stream == c.cuda_stream for c in chosen):
+            continue
+        if _runs_beside(None, s) and all(_runs_beside(c, s) for c in chosen):
+            chosen.append(s)
+    if len(chosen) == n:
+        return chosen
+    raise _lib.D3PError(f"concurrent_streams: found only {len(chosen)} of {n} streams that run beside the current stream")
+
+
 class HipEngine:
     """local_sums / finalize through libd3p_hip.so for one rank's shard."""
 
@@ -300,7 +344,8 @@ class XchgComm:
     def local_group(cls, world, words):
         """`world` ranks inside ONE process (each drives its own stream): the inboxes are wired to each other directly
         (d3p_xchg_connect_local) instead of through hipIpc handles; kernels and protocol are those of the multi-process
-        path.  For tests on a single GPU and for single-process multi-stream use."""
+        path.  For tests on a single GPU and for single-process multi-stream use.  The ranks wait for each other inside their
+        launches, so their streams must not share a hardware queue: take them from `concurrent_streams`."""
         comms = [cls(words, _local=(r, world)) for r in range(world)]
         arr = (C.c_void_p * world)(*[c.handle for c in comms])
         for c in comms:

@@ -575,7 +575,7 @@ def test_xchg_virtual_ranks_on_streams_match_the_single_rank_run(gpu, world):
     ref_state, ref_losses = ddist.run_steps_native(single, st0, rng.PRNGKey(4), 2, steps, comm=None)
     ref_losses = ref_losses.clone()
     comms = ddist.XchgComm.local_group(world, 2 * d + 4)
-    streams = [torch.cuda.Stream() for _ in range(world)]
+    streams = ddist.concurrent_streams(world)
     try:
         # (a) the bare collective on random int64 rows, three epochs (both slot parities)
         accs = [torch.randint(-2**40, 2**40, (4, 2 * d + 4), generator=torch.Generator().manual_seed(100 + r), dtype=torch.int64).cuda()
@@ -645,7 +645,7 @@ def test_xchg_updater_form_with_simulated_peers_runs_the_many_rank_paths(gpu, wo
     finally:
         solo.close()
     comms = ddist.XchgComm.local_group(world, 2 * d + 4)
-    side = torch.cuda.Stream()
+    side = ddist.concurrent_streams(1)[0]
     try:
         eng = ddist.FusedHipEngine(svi, Xs, ys, n, lo, hi, L.D3P_BATCH_FEISTEL, B)
         torch.cuda.synchronize()
@@ -684,7 +684,7 @@ def test_poisson_batches_sharded_over_two_virtual_ranks_match_the_single_rank_ru
     ref_state, ref_losses = ddist.run_steps_native(single, st0, rng.PRNGKey(4), 2, steps, comm=None)
     ref_losses = ref_losses.clone()
     comms = ddist.XchgComm.local_group(world, 2 * d + 4)
-    streams = [torch.cuda.Stream() for _ in range(world)]
+    streams = ddist.concurrent_streams(world)
     try:
         engines, results = [], []
         for r in range(world):
@@ -748,7 +748,7 @@ def test_run_status_is_per_workspace_with_two_runs_in_flight(gpu):
     Xbad = X.clone()
     Xbad[:, 7] = float("nan")
     tables = {False: (X.cuda(), y.cuda()), True: (Xbad.cuda(), y.cuda())}
-    streams = [torch.cuda.Stream() for _ in range(2)]
+    streams = ddist.concurrent_streams(2)
     engines = {}
     for rnd, bad_first in enumerate([True, False, True]):
         roles = [bad_first, not bad_first]
@@ -788,7 +788,7 @@ def test_a_stopped_rank_and_a_running_one_in_one_process_report_their_own_codes(
     lo, hi = ddist.shard_rows(n, rank, world)
     comms = ddist.XchgComm.local_group(world, 2 * d + 4)
     solo = ddist.XchgComm(2 * d + 4)
-    s_peer, s_stop, s_ok = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    s_peer, s_stop, s_ok = ddist.concurrent_streams(3)
     try:
         stopped = ddist.FusedHipEngine(svi, Xc[lo:hi], yc[lo:hi], n, lo, hi, L.D3P_BATCH_FEISTEL, B)
         fine = ddist.FusedHipEngine(svi, Xc, yc, n, 0, n, L.D3P_BATCH_FEISTEL, B)

@@ -795,7 +795,8 @@ def test_chained_launch_is_reproducible_under_uneven_load(rng):
     _, gb = subsample_batchify_data((X, y), B)
     quiet_state, quiet_losses = svi.run_steps(st, gb, rng.PRNGKey(42), 0, steps)
     torch.cuda.synchronize()
-    side = torch.cuda.Stream()
+    from d3p_amd.dist import concurrent_streams
+    side = concurrent_streams(1)[0]
     mats = [torch.randn(n, n, device="cuda") for n in (512, 1024, 3072)]
     done = torch.cuda.Event()
     loud_state, loud_losses = svi.run_steps(st, gb, rng.PRNGKey(42), 0, steps, check_status=False)   # stays asynchronous

@@ -200,7 +200,7 @@ model = LogisticRegression(d)
 svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-2), Trace_ELBO(), 1.0, 0.7, N=N)
 st0 = DPSVIState(svi.optim.init(torch.cat([torch.zeros(d), torch.full((d,), -2.0)]).cuda()), rng.PRNGKey(21), float(N))
 comms = ddist.XchgComm.local_group(world, 2 * d + 4)
-streams = [torch.cuda.Stream() for _ in range(world)]
+streams = ddist.concurrent_streams(world)
 engines, results = [], []
 for r in range(world):
     lo, hi = ddist.shard_rows(N, r, world)
@@ -463,7 +463,7 @@ def test_updater_form_as_a_rank_of_many_on_grids_off_the_xcd_multiple_vs_oracle(
     st = _state(svi, rng.PRNGKey(33), d, N)
     lo, hi = ddist.shard_rows(N, rank, world)
     comms = ddist.XchgComm.local_group(world, 2 * d + 4)
-    side = torch.cuda.Stream()
+    side = ddist.concurrent_streams(1)[0]
     try:
         eng = ddist.FusedHipEngine(svi, X[lo:hi].cuda(), y[lo:hi].cuda(), N, lo, hi, L.D3P_BATCH_FEISTEL, B)
         torch.cuda.synchronize()

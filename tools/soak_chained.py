@@ -29,7 +29,8 @@ for name, (init, gb) in (("feistel", subsample_batchify_data((X, y), B)), ("pois
         print(f"{name} run {rep}: {steps} steps in {dt:.2f} s = {dt / steps * 1e6:.2f} us/step, last loss {float(losses[-1]):.3f}", flush=True)
     # third run under UNEVEN load: matrix products of changing size on a second stream compete for the CUs while the chained
     # launches run; a hand-off that depended on timing would show up as a different result
-    side = torch.cuda.Stream()
+    from d3p_amd.dist import concurrent_streams
+    side = concurrent_streams(1)[0]
     mats = [torch.randn(n, n, device="cuda") for n in (512, 1024, 3072)]
     done = torch.cuda.Event()
     s3, losses3 = svi.run_steps(st, gb, rng.PRNGKey(4), 0, steps, check_status=False)   # (asynchronous: the products below run beside it)

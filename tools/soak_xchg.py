@@ -25,7 +25,7 @@ model = LogisticRegression(d)
 svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-3), Trace_ELBO(), 1.0, 1.0, num_obs_total=N)
 st = DPSVIState(svi.optim.init(torch.cat([torch.zeros(d), torch.full((d,), -2.0)]).cuda()), rng.PRNGKey(3), float(N))
 eng = ddist.FusedHipEngine(svi, X, y, N, lo, hi, L.D3P_BATCH_FEISTEL, B)
-side = torch.cuda.Stream()
+side = ddist.concurrent_streams(1)[0]
 mats = [torch.randn(n, n, device="cuda") for n in (512, 1024, 3072)]
 
 
