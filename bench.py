@@ -280,11 +280,16 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
     return out
 
 
-def vae_dist_workload(dev, world, rank, group_barrier, share_gpu=False):
+def vae_dist_workload(dev, world, rank, group_barrier, share_gpu=False, emulate=0):
     """BASELINE configs[4] at N > 1 ("VAE ... 1 vs 8 GPU"): the epoch body of examples/vae.py:227-246 data-parallel -- the batch
-    sharded by position (4096 examples per GPU: weak scaling like the headline), ONE all-reduce of the P + 2 fp32 sums per step
-    (2.76 MB for 784-400-50; torch.distributed = RCCL over xGMI), the noise added once after it.  Every rank returns the timing;
-    rank 0's dictionary goes under `workloads`."""
+    sharded by position (4096 examples per GPU: weak scaling like the headline), ONE sum-all-reduce of the P + 2 fp32 sums per step
+    (2.76 MB for 784-400-50), the noise added once after it.  Drivers, each timed: the NATIVE loop (d3p_dpvi_vae_run_dist: one C
+    call for the run, RCCL on the library's communicator) with the reduce in ONE bucket in the stream and in TWO buckets on a second
+    stream (the decoder's sums travel while the encoder's weight-gradient products run), and the Python-driven loop over
+    torch.distributed.  The leg's figures are the fastest driver's; all are listed.  Before timing, 3 steps with every driver from the
+    same state: replicas bitwise equal over the ranks, drivers equal to fp32 rounding.
+    emulate = W (one GPU): rank 0's share of a W-rank job, no peers (a one-rank communicator): the rank-local cost, at the weak-scaling
+    share (4096 per GPU) and at the strong-scaling one (4096 / W)."""
     import torch
     import torch.distributed as dist
     import d3p_amd.random as rng
@@ -292,45 +297,104 @@ def vae_dist_workload(dev, world, rank, group_barrier, share_gpu=False):
     from d3p_amd.models import Adam, Trace_ELBO, VAEGuide, VAEModel
     from d3p_amd.svi import DPSVI
     out = {}
-    for tag, H2 in (("vae_config5", 0), ("vae_config5_400_200", 200)):
-        N, Bl, D, H, Z = 60000, 4096, 784, 400, 50
-        Bg = Bl * world
-        pos0 = Bl * rank
-        X = (torch.rand(Bl, 28, 28, generator=torch.Generator().manual_seed(1000 + rank)) < 0.3).float().to(dev)
-        model = VAEModel(scale=1.0 / N)
-        svi = DPSVI(model, VAEGuide(model), Adam(1e-3), Trace_ELBO(), 10.0, 1.0, num_obs_total=N, z_dim=Z,
-                    hidden_dim=(H, H2) if H2 else H)
-        st = svi.init(rng.PRNGKey(0), X)          # (a function of the key and the shapes: identical on every rank)
-        engine = ddist.VaeHipEngine(svi)
-        warm, steps = (8, 10) if share_gpu else (48, 40)
-        group_barrier()
-        st, _ = ddist.vae_run_steps(engine, st, X, Bg, pos0, warm, collect_losses=False)
-        group_barrier()
-        t0 = time.perf_counter()
-        st, losses = ddist.vae_run_steps(engine, st, X, Bg, pos0, steps)
-        group_barrier()
-        wall = time.perf_counter() - t0
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t[0])
-        hs = [H] + ([H2] if H2 else [])
-        dec, enc = [Z] + hs[::-1] + [D], [D] + hs
-        layers = list(zip(dec[:-1], dec[1:])) + list(zip(enc[:-1], enc[1:])) + [(hs[-1], 2 * Z)]
-        flops = 2 * Bl * (3 * sum(i * o for i, o in layers) - D * H)   # per RANK and step
-        Pn = int(st.optim_state[1].numel())
-        out[tag + f"_dp{world}"] = {
-            "workload": "BASELINE configs[4] data-parallel: VAE 784 -> %s -> 50 (P = %d), batch 4096 per GPU (global %d, sharded by position), "
-                        "C=10, sigma=1, Adam 1e-3; per step local sums -> one all-reduce(SUM) of %d fp32 -> apply" % (hs, Pn, Bg, Pn + 2),
-            "n_gpus": world, "steps": steps, "warmup": warm, "steps_per_sec": round(steps / wall, 2), "value": round(Bg * steps / wall, 1),
-            "unit": "examples/s (whole job)", "us_per_step": round(1e6 * wall / steps, 2), "final_loss": float(losses[-1]),
-            "collective": {"bytes_per_step": 4 * (Pn + 2), "backend": "gloo (shared-GPU rehearsal)" if share_gpu else "torch.distributed nccl = RCCL"},
-            "roofline": {"bound": "mfma", "achieved": round(flops * steps / wall / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
-                         "frac": round(flops * steps / wall / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "gemm_flop_per_step_and_gpu": flops,
-                         "frac_of_bf16_peak_over_6": round(flops * steps / wall / 1e12 / (MFMA_BF16_PEAK_TFLOPS / 6.0), 4),
-                         "timing": "wall clock between barriers around the steps (max over ranks): kernels + the collective"}}
-        del X, svi, st, engine
-        torch.cuda.empty_cache()
+    ranks = emulate or world
+    comm = None
+    if not share_gpu:
+        try:
+            comm = ddist.NativeComm()
+        except Exception as e:  # noqa: BLE001 -- the Python-driven loop remains
+            print(f"[bench] rank {rank}: no native communicator for the VAE legs ({e})", file=sys.stderr)
+    if world > 1:   # every rank takes the same drivers
+        flag = torch.tensor([int(comm is not None)], dtype=torch.int32, device=dev)
+        if share_gpu:
+            flag = flag.cpu()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not int(flag[0]) and comm is not None:
+            comm.close()
+            comm = None
+    shapes = [("vae_config5", 0, 4096), ("vae_config5_400_200", 200, 4096)]
+    if emulate:
+        shapes += [("vae_config5_strong_share", 0, 4096 // emulate)]
+    try:
+        for tag, H2, Bl in shapes:
+            N, D, H, Z = 60000, 784, 400, 50
+            Bg = Bl * ranks
+            pos0 = Bl * rank
+            X = (torch.rand(Bl, 28, 28, generator=torch.Generator().manual_seed(1000 + rank)) < 0.3).float().to(dev)
+            model = VAEModel(scale=1.0 / N)
+            svi = DPSVI(model, VAEGuide(model), Adam(1e-3), Trace_ELBO(), 10.0, 1.0, num_obs_total=N, z_dim=Z,
+                        hidden_dim=(H, H2) if H2 else H)
+            st0 = svi.init(rng.PRNGKey(0), X)          # (a function of the key and the shapes: identical on every rank)
+            drivers = [("torch_loop", {})] if (world > 1 or comm is None) else []
+            if comm is not None:
+                drivers += [("native_1_bucket", {"comm": comm, "buckets": 1}), ("native_2_buckets", {"comm": comm, "buckets": 2})]
+            # ---- correctness first: 3 steps per driver from the same state
+            check, ref = {}, None
+            for name, kw in drivers:
+                s3, l3 = ddist.vae_run_steps(ddist.VaeHipEngine(svi), st0, X, Bg, pos0, 3, **kw)
+                torch.cuda.synchronize()
+                sig = torch.cat([s3.optim_state[0].reshape(1).to(torch.int32), s3.rng_key.reshape(16).view(torch.int32),
+                                 s3.optim_state[1].view(torch.int32)]).contiguous()
+                same = True
+                if world > 1:
+                    buf = sig.cpu() if share_gpu else sig
+                    got = [torch.empty_like(buf) for _ in range(world)]
+                    dist.all_gather(got, buf)
+                    same = all(torch.equal(got[0], g) for g in got[1:])
+                par = s3.optim_state[1]
+                if ref is None:
+                    ref = par.clone()
+                check[name] = {"replicas_bitwise": bool(same), "step": int(s3.optim_state[0]),
+                               "max_rel_diff_vs_first_driver": float((par - ref).abs().max() / ref.abs().max())}
+            # ---- timing
+            warm, steps = (8, 10) if share_gpu else (48, 40)
+            timed = {}
+            for name, kw in drivers:
+                engine = ddist.VaeHipEngine(svi)
+                group_barrier()
+                st, _ = ddist.vae_run_steps(engine, st0, X, Bg, pos0, warm, collect_losses=False, **kw)
+                group_barrier()
+                t0 = time.perf_counter()
+                st, losses = ddist.vae_run_steps(engine, st, X, Bg, pos0, steps, **kw)
+                group_barrier()
+                wall = time.perf_counter() - t0
+                if world > 1:
+                    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+                    if share_gpu:
+                        t = t.cpu()
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    wall = float(t[0])
+                timed[name] = (wall, float(losses[-1]))
+                del engine
+            best = min(timed, key=lambda k: timed[k][0])
+            wall, final_loss = timed[best]
+            hs = [H] + ([H2] if H2 else [])
+            dec, enc = [Z] + hs[::-1] + [D], [D] + hs
+            layers = list(zip(dec[:-1], dec[1:])) + list(zip(enc[:-1], enc[1:])) + [(hs[-1], 2 * Z)]
+            flops = 2 * Bl * (3 * sum(i * o for i, o in layers) - D * H)   # per RANK and step
+            Pn = int(st0.optim_state[1].numel())
+            key = tag + (f"_rank_local_of_{emulate}" if emulate else f"_dp{world}")
+            B_done = Bl if emulate else Bg
+            out[key] = {
+                "workload": "BASELINE configs[4] data-parallel: VAE 784 -> %s -> 50 (P = %d), batch %d per GPU (global %d, sharded by position), "
+                            "C=10, sigma=1, Adam 1e-3; per step local sums -> one sum-all-reduce of %d fp32 -> apply (noise once)" % (hs, Pn, Bl, Bg, Pn + 2),
+                "n_gpus": world, "steps": steps, "warmup": warm, "driver": best, "steps_per_sec": round(steps / wall, 2),
+                "value": round(B_done * steps / wall, 1), "unit": "examples/s (whole job)" if not emulate else "examples/s (this rank's share)",
+                "us_per_step": round(1e6 * wall / steps, 2), "final_loss": final_loss,
+                "us_per_step_by_driver": {k: round(1e6 * v[0] / steps, 2) for k, v in timed.items()},
+                "collective_check": check,
+                "collective": {"bytes_per_step": 4 * (Pn + 2),
+                               "backend": ("none (one rank: the communicator has no peers)" if emulate else
+                                           "gloo (shared-GPU rehearsal)" if share_gpu else "RCCL: the library's communicator (native) / torch.distributed nccl (torch_loop)")},
+                "roofline": {"bound": "mfma", "achieved": round(flops * steps / wall / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
+                             "frac": round(flops * steps / wall / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "gemm_flop_per_step_and_gpu": flops,
+                             "frac_of_bf16_peak_over_6": round(flops * steps / wall / 1e12 / (MFMA_BF16_PEAK_TFLOPS / 6.0), 4),
+                             "timing": "wall clock between barriers around the steps (max over ranks): kernels + the collective"}}
+            del X, svi, st, st0
+            torch.cuda.empty_cache()
+    finally:
+        if comm is not None:
+            comm.close()
     return out
 
 
@@ -775,9 +839,9 @@ def main():
             del Xl, yl, gb_l, st_l, svi_l
         if single and rank == 0 and extra_legs and not args.no_aux_workloads:
             aux.update(aux_workloads(dev, None, want=("gmm", "vae", "vae2")))
-        if world > 1 and extra_legs and not args.no_aux_workloads and not aux:   # configs[4] at N > 1 (every rank takes part)
+        if (world > 1 or emu) and extra_legs and not args.no_aux_workloads and not aux:   # configs[4] at N > 1 (every rank takes part)
             try:
-                aux.update(vae_dist_workload(dev, world, rank, barrier, share_gpu))
+                aux.update(vae_dist_workload(dev, world, rank, barrier, share_gpu, emulate=emu))
             except Exception as e:  # noqa: BLE001 -- an auxiliary leg must not cost the headline line
                 aux["vae_config5_dp_error"] = f"{type(e).__name__}: {e}"
         if rank != 0:

@@ -181,6 +181,7 @@ SIGNATURES = {
     "d3p_dpvi_gmm_apply": (C.c_int, [_V, _V, _V, _V, _V, _U32, _U32, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_vae_local_sums": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _U32, _U32, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_vae_apply": (C.c_int, [_V, _V, _V, _V, _V, _U32, _U32, _V, _V, _V, C.c_size_t]),
+    "d3p_dpvi_vae_run_dist": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _U32, _U32, _U32, _U32, _V, C.c_int32, _V, C.c_size_t]),
     "d3p_dpvi_logreg_chain_status": (C.c_int, [_V, _V, _V, _V, C.c_size_t, _V]),
     "d3p_dpvi_logreg_run_status": (C.c_int, [_V, _V, _V, _V, C.c_size_t, _V, _V]),
     "d3p_xchg_create": (C.c_int, [_I32, _I32, _U32, _V, _V, _SZ]),

@@ -1655,6 +1655,14 @@ static const RcclApi* rccl_api()
     return state == 1 ? &api : nullptr;
 }
 
+int rccl_allreduce_f32(void* comm, float* buf, size_t count, hipStream_t s)
+{
+    const RcclApi* api = rccl_api();
+    if (!api) return fail(D3P_E_UNSUPPORTED, "librccl.so could not be loaded");
+    const ncclResult_t r = api->AllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)comm, s);
+    if (r != ncclSuccess) return fail(D3P_E_HIP, "ncclAllReduce: %s", api->GetErrorString(r));
+    return D3P_OK;
+}
 
 // ---- One-shot full-mesh exchange of the step message: xGMI is point to point (7 links per GPU), so for
 // a message of 8 KB the latency-optimal all-reduce is not a ring (2 (n - 1) dependent hops) but ONE hop: every rank folds its

@@ -62,4 +62,7 @@ inline int validate_model(const d3p_logreg_model* m, const void* y_dev, const ch
 
 inline unsigned cdiv(unsigned long long a, unsigned long long b) { return (unsigned)((a + b - 1) / b); }
 
+// in-place sum-all-reduce of `count` floats over the ranks of a d3p_comm_* communicator (RCCL, resolved at run time: d3p_dpvi.hip)
+int rccl_allreduce_f32(void* comm, float* buf, size_t count, hipStream_t s);
+
 }  // namespace d3p

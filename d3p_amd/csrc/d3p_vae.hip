@@ -12,6 +12,8 @@
 #include <type_traits>
 #include "d3p_device.h"
 #include "d3p_host.h"
+#include <mutex>
+#include <unordered_map>
 #include "d3p_logreg_kernel.h"  // px_sample_key
 
 namespace d3p {
@@ -1583,15 +1585,17 @@ __device__ __forceinline__ float vae_tile_sum(const VaeTiles& a, size_t col, flo
 
 // sums[col] := the tile sums (stage API and data-parallel local sums: the sums leave the device function as one vector)
 // px_loss != nullptr (fused output layer): sums[P] = sum_i px_loss[i] too (workgroup 0; the norm kernel could not: see NormArgs)
-__global__ void __launch_bounds__(256) k_vae_tile_sums(VaeTiles a, float* __restrict__ sums, size_t P, const float* __restrict__ px_loss, uint32_t B)
+// col0 .. col1 - 1: the columns of this launch (a bucket of the data-parallel step's reduce: VaeBuckets)
+__global__ void __launch_bounds__(256) k_vae_tile_sums(VaeTiles a, float* __restrict__ sums, size_t P, const float* __restrict__ px_loss, uint32_t B,
+                                                       size_t col0, size_t col1)
 {
     __shared__ float lds[256];
     if (px_loss && blockIdx.x == 0) {
         const float tot = vae_block_sum(px_loss, B, lds);
         if (threadIdx.x == 0) sums[P] = tot;
     }
-    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col < P) sums[col] = vae_tile_sum(a, col, sums[col]);
+    const size_t col = col0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col < col1) sums[col] = vae_tile_sum(a, col, sums[col]);
 }
 
 struct VaeFinalArgs {
@@ -2021,10 +2025,22 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
 }
 
 // forward + backward + norms + clipped sums into ws.sums[P + 2]; eps_dev given or drawn from jax_key
+// Data-parallel step (d3p_dpvi_vae_run_dist): the clipped sums leave the rank in TWO buckets, so that the reduce of the first
+// travels while the products of the second still run.  (Every clipped sum needs the clip factors, i.e. the whole backward pass:
+// what can overlap a reduce is the tail of the step -- the weight-gradient products, 63 of its 240 us at 4096 examples per rank.)
+// Bucket 0 = the decoder's leaves (columns 0 .. split - 1 of the flat layout), bucket 1 = the encoder's and the latent heads' +
+// [loss sum, count]; the weight-gradient products go out as one grouped launch per bucket, each followed by the tile sums of its
+// columns and `ready(bucket)` (the caller enqueues the reduce behind an event).
+struct VaeBuckets {
+    size_t split;
+    int (*ready)(void* ctx, int bucket);
+    void* ctx;
+};
+
 static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* params, const float* X, const uint8_t* mask,
                             uint32_t B, const float* eps_ext, const uint32_t* jax_key, float clip, const VaeWorkspace& ws,
                             float* norms_out, uint32_t B_total = 0, uint32_t pos0 = 0, int* w_splits = nullptr, VaeStepPrep prep = VaeStepPrep(),
-                            const SiteNoiseArgs* noise = nullptr, bool* loss_pending = nullptr)
+                            const SiteNoiseArgs* noise = nullptr, bool* loss_pending = nullptr, const VaeBuckets* bk = nullptr)
 {
     // The split-K partial tiles of the weight-gradient products stay in ws.wpart.  w_splits != nullptr (single-device update):
     // w_splits[0 .. n_blocks - 1] says how many each, and k_vae_finalize sums them; otherwise ONE launch (k_vae_tile_sums) sums
@@ -2133,42 +2149,53 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
         hipLaunchKernelGGL(k_vae_norms, dim3(rows.x + 1), dim3(256), stage_floats * sizeof(float), s, na);
     }
     // single-device update: the products go out as ONE grouped launch with a common K range per workgroup
+    // (bk: one grouped launch per bucket)
     static const bool no_group = getenv("D3P_VAE_NO_GROUP") != nullptr;   // developer switch (A/B), read once
-    GemmGroupPlan plan;
-    GemmGroupPlan* group = !no_group ? &plan : nullptr;
     int splits_here[D3P_VAE_MAX_BLOCKS] = {0};
     int* const tile_splits = w_splits ? w_splits : splits_here;
-    int group_splits = 0;
-    if (group) {
-        unsigned tiles = 0;
-        for (int b = 0; b < n_wg; ++b) tiles += cdiv(wg[b].out, D3P_GT) * cdiv(wg[b].in + 1, D3P_GTM);
-        group_splits = gemm_group_splits(tiles, Bi);
+    bool loss_summed = false;   // (fused output layer: a group launch sums px_loss into S[P] beside its products)
+    const int n_buckets = (bk && !no_group) ? 2 : 1;
+    for (int bucket = 0; bucket < n_buckets; ++bucket) {
+        auto in_bucket = [&](int b) { return n_buckets == 1 || (bucket == 0) == (wg[b].off < bk->split); };
+        GemmGroupPlan plan;
+        GemmGroupPlan* group = !no_group ? &plan : nullptr;
+        int group_splits = 0;
+        if (group) {
+            unsigned tiles = 0;
+            for (int b = 0; b < n_wg; ++b)
+                if (in_bucket(b)) tiles += cdiv(wg[b].out, D3P_GT) * cdiv(wg[b].in + 1, D3P_GTM);
+            group_splits = gemm_group_splits(tiles, Bi);
+        }
+        for (int b = 0; b < n_wg; ++b) {
+            if (!in_bucket(b)) continue;
+            float* part = ws.wpart + (size_t)D3P_WPART_SPLITS * wg[b].off;
+            const size_t part_floats = (size_t)D3P_WPART_SPLITS * (wg[b].in + 1) * wg[b].out;
+            int left = 0;
+            // (A = X^T: the flag of the forward pass holds -- same batch; the virtual row of ones is exact too)
+            const uint32_t* xflag = (wg[b].A == X && vae_exact_eligible(X, B, D)) ? ws.x_exact16 : nullptr;
+            GemmOpts o;   // A carries the virtual row of ones (bias gradient); tiles left unreduced; grouped; clip factors on B's rows
+            o.a_last_one = 1; o.part = part; o.part_floats = part_floats; o.splits_left = &left; o.jumps = wg[b].j;
+            o.a_exact16 = xflag; o.a_exact_nonce = vae_exact_nonce(false);
+            o.group = group; o.force_splits = group_splits; o.b_row_scale = scale_in_gemm ? ws.cf : nullptr;
+            if ((rc = gemm(s, wg[b].A, 1, wg[b].a_sk, wg[b].Bm, wg[b].ldb, 1, S + wg[b].off, wg[b].ldc, wg[b].in + 1, wg[b].out, Bi, nullptr, 1.f, 0, o)))
+                return rc;
+            tile_splits[wg[b].blk] = left;
+            if (b == n_wg - 1) tile_splits[wg[b].blk + 1] = left;
+        }
+        const bool last = bucket == n_buckets - 1;
+        if (group && out_fused && plan.n > 0 && last) {
+            plan.sum_in = ws.px_loss; plan.sum_out = S + N.P; plan.sum_n = B;
+            loss_summed = true;
+        }
+        if (group && (rc = gemm_group_launch(s, plan))) return rc;
+        if (!w_splits) {
+            const size_t c0 = (n_buckets == 2 && bucket == 1) ? bk->split : 0, c1 = (n_buckets == 2 && bucket == 0) ? bk->split : (size_t)N.P;
+            hipLaunchKernelGGL(k_vae_tile_sums, dim3(cdiv(c1 - c0, 256)), dim3(256), 0, s, vae_tiles(N, ws, tile_splits), S, N.P,
+                               (last && out_fused && !loss_summed) ? (const float*)ws.px_loss : (const float*)nullptr, B, c0, c1);
+            if (n_buckets == 2 && (rc = bk->ready(bk->ctx, bucket))) return rc;
+        }
     }
-    for (int b = 0; b < n_wg; ++b) {
-        float* part = ws.wpart + (size_t)D3P_WPART_SPLITS * wg[b].off;
-        const size_t part_floats = (size_t)D3P_WPART_SPLITS * (wg[b].in + 1) * wg[b].out;
-        int left = 0;
-        // (A = X^T: the flag of the forward pass holds -- same batch; the virtual row of ones is exact too)
-        const uint32_t* xflag = (wg[b].A == X && vae_exact_eligible(X, B, D)) ? ws.x_exact16 : nullptr;
-        GemmOpts o;   // A carries the virtual row of ones (bias gradient); tiles left unreduced; grouped; clip factors on B's rows
-        o.a_last_one = 1; o.part = part; o.part_floats = part_floats; o.splits_left = &left; o.jumps = wg[b].j;
-        o.a_exact16 = xflag; o.a_exact_nonce = vae_exact_nonce(false);
-        o.group = group; o.force_splits = group_splits; o.b_row_scale = scale_in_gemm ? ws.cf : nullptr;
-        if ((rc = gemm(s, wg[b].A, 1, wg[b].a_sk, wg[b].Bm, wg[b].ldb, 1, S + wg[b].off, wg[b].ldc, wg[b].in + 1, wg[b].out, Bi, nullptr, 1.f, 0, o)))
-            return rc;
-        tile_splits[wg[b].blk] = left;
-        if (b == n_wg - 1) tile_splits[wg[b].blk + 1] = left;
-    }
-    bool loss_summed = false;   // (fused output layer: the group launch sums px_loss into S[P] beside its products)
-    if (group && out_fused && plan.n > 0) {
-        plan.sum_in = ws.px_loss; plan.sum_out = S + N.P; plan.sum_n = B;
-        loss_summed = true;
-    }
-    if (group && (rc = gemm_group_launch(s, plan))) return rc;
     if (loss_pending) *loss_pending = out_fused && !loss_summed;
-    if (!w_splits)
-        hipLaunchKernelGGL(k_vae_tile_sums, dim3(cdiv(N.P, 256)), dim3(256), 0, s, vae_tiles(N, ws, tile_splits), S, N.P,
-                           (out_fused && !loss_summed) ? (const float*)ws.px_loss : (const float*)nullptr, B);
     return check_launch("d3p_vae sums");
 }
 
@@ -2325,7 +2352,7 @@ static SiteNoiseArgs vae_site_noise_args(const VaeNet& N, const VaeWorkspace& ws
 static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                           const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
                           void* workspace_dev, size_t workspace_bytes, bool derive_keys, const int* w_splits = nullptr,
-                          const d3p_dpsvi_state* from = nullptr, bool loss_pending = false);
+                          const d3p_dpsvi_state* from = nullptr, bool loss_pending = false, bool noise_drawn = false);
 
 // advance = true (single-device update): the key kernel also writes the next state key and advances the step counter, so that
 // vae_apply_impl(derive_keys = false) has nothing left to launch for them
@@ -2333,8 +2360,10 @@ static int vae_local_sums_impl(void* stream, const d3p_vae_model* model, const d
                                const float* X_dev, const uint8_t* mask_dev, uint32_t B_local, uint32_t B_total, uint32_t pos0,
                                const float* eps_dev, float* sums_dev, void* workspace_dev, size_t workspace_bytes, bool advance,
                                int* w_splits = nullptr, const d3p_dpsvi_state* from = nullptr, const VaeRunStep* rs = nullptr,
-                               bool* loss_pending = nullptr)
+                               bool* loss_pending = nullptr, bool draw_noise = false, const VaeBuckets* bk = nullptr)
 {
+    // draw_noise (with advance; the native data-parallel loop): the Gaussian-mechanism noise of the update is drawn beside the latent
+    // kernel although the sums leave the device function for a reduce -- it depends on the step's keys only
     // rs != nullptr: X_dev is the batch BUFFER; the step's rows are gathered into it here (indices from the key launch)
     // loss_pending (with w_splits): vae_enqueue_sums' -- the caller hands it on to vae_apply_impl
     if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_local_sums")) return rc;
@@ -2360,7 +2389,7 @@ static int vae_local_sums_impl(void* stream, const d3p_vae_model* model, const d
     // drawn here, beside the latent kernel
     const SiteNoiseArgs noise = vae_site_noise_args(vae_net(model), ws);
     if ((rc = vae_enqueue_sums(s, model, from ? from->params : state->params, X_dev, mask_dev, B_local, eps_dev, ws.keys + D3P_VAE_KEY_JAX, hyper->clip, ws, nullptr,
-                               B_total, pos0, w_splits, prep, w_splits ? &noise : nullptr, w_splits ? loss_pending : nullptr)))
+                               B_total, pos0, w_splits, prep, (w_splits || draw_noise) ? &noise : nullptr, w_splits ? loss_pending : nullptr, bk)))
         return rc;
     if (sums_dev != ws.sums)
         D3P_HIP_TRY(hipMemcpyAsync(sums_dev, ws.sums, (vae_net(model).P + 2) * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -2388,7 +2417,7 @@ int d3p_dpvi_vae_apply(void* stream, const d3p_vae_model* model, const d3p_dpsvi
 static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                           const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
                           void* workspace_dev, size_t workspace_bytes, bool derive_keys, const int* w_splits, const d3p_dpsvi_state* from,
-                          bool loss_pending)
+                          bool loss_pending, bool noise_drawn)
 {
     // loss_pending (single-device update): sums_dev[P] does not hold the loss sum -- k_vae_finalize takes it from ws.px_loss
     if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_apply")) return rc;
@@ -2400,7 +2429,7 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
     const VaeNet N = vae_net(model);
     int rc;
     if (derive_keys && (rc = vae_step_keys(s, model, state, ws, true))) return rc;
-    if (derive_keys || !w_splits) {  // (the single-device update drew the noise beside its latent kernel: vae_local_sums_impl)
+    if (derive_keys || (!w_splits && !noise_drawn)) {  // (the single-device update and the native data-parallel loop drew the noise beside their latent kernel: vae_local_sums_impl)
         const SiteNoiseArgs na = vae_site_noise_args(N, ws);
         hipLaunchKernelGGL(k_vae_site_noise, dim3(cdiv(na.blk_off[D3P_VAE_MAX_LEAVES], 256)), dim3(256), 0, s, na);
     }
@@ -2514,6 +2543,98 @@ int d3p_dpvi_vae_run(void* stream, const d3p_vae_model* model, const d3p_dpsvi_h
                                           nullptr, workspace_dev, workspace_bytes)))
                 return rc;
         }
+        st.key_slot ^= 1;
+    }
+    return D3P_OK;
+}
+
+// ---- the data-parallel epoch body as ONE call (examples/vae.py:227-246 with the batch sharded by position)
+namespace {
+struct VaeDistSide {   // per device: the stream the reduces travel on and the events that order them against the step's stream
+    hipStream_t cs = nullptr;
+    hipEvent_t ready[2] = {nullptr, nullptr}, done = nullptr;
+};
+static int vae_dist_side(VaeDistSide** out)
+{
+    static std::mutex mu;
+    static std::unordered_map<int, VaeDistSide> sides;
+    int dev = 0;
+    D3P_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    VaeDistSide& v = sides[dev];
+    if (!v.cs) {
+        D3P_HIP_TRY(hipStreamCreateWithFlags(&v.cs, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&v.ready[0], &v.ready[1], &v.done}) D3P_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    *out = &v;
+    return D3P_OK;
+}
+struct VaeDistStep {
+    hipStream_t s;
+    VaeDistSide* side;
+    void* comm;
+    float* sums;
+    size_t split, total;   // bucket 0 = [0, split), bucket 1 = [split, total)
+};
+static int vae_dist_bucket_ready(void* ctx, int bucket)
+{
+    // bucket 0: its reduce starts on the side stream as soon as its tile sums are complete -- the second bucket's products run beside it;
+    // bucket 1: behind the first on the same stream (a communicator runs one collective at a time anyway)
+    VaeDistStep* d = (VaeDistStep*)ctx;
+    D3P_HIP_TRY(hipEventRecord(d->side->ready[bucket], d->s));
+    D3P_HIP_TRY(hipStreamWaitEvent(d->side->cs, d->side->ready[bucket], 0));
+    const size_t lo = bucket == 0 ? 0 : d->split, hi = bucket == 0 ? d->split : d->total;
+    if (int rc = rccl_allreduce_f32(d->comm, d->sums + lo, hi - lo, d->side->cs)) return rc;
+    if (bucket == 1) {
+        D3P_HIP_TRY(hipEventRecord(d->side->done, d->side->cs));
+        D3P_HIP_TRY(hipStreamWaitEvent(d->s, d->side->done, 0));
+    }
+    return D3P_OK;
+}
+}  // namespace
+
+// num_steps x [local sums of the rank's B_local examples (positions pos0 .. of the global batch of B_total) -> sum-all-reduce of the
+// P + 2 fp32 sums over `comm` -> noise once + Adam, identical on every rank] on the RESIDENT shard X_local_dev, enqueued back to
+// back: no host work between steps, no per-step state or key copies (the state advances in place, its key ping-pongs between the
+// two slots of state->rng_key like d3p_dpvi_vae_run), the step's keys are derived once, the Gaussian-mechanism noise is drawn
+// beside the latent kernel (it depends on the keys only), and apply is ONE launch behind the reduce.
+// buckets = 2: the sums travel in two buckets on a second stream -- the decoder's leaves while the encoder's weight-gradient
+// products still run (VaeBuckets); 1: one all-reduce on `stream` itself; 0: the library's choice (1: see below).
+// comm = NULL: no collective (one rank; B_local == B_total).
+int d3p_dpvi_vae_run_dist(void* stream, void* comm, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+                          const float* X_local_dev, const uint8_t* mask_dev, uint32_t B_local, uint32_t B_total, uint32_t pos0,
+                          uint32_t num_steps, float* losses_dev, int32_t buckets, void* workspace_dev, size_t workspace_bytes)
+{
+    if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_run_dist")) return rc;
+    D3P_REQUIRE(X_local_dev, "d3p_dpvi_vae_run_dist: null pointer");
+    D3P_REQUIRE(B_local >= 1 && (uint64_t)pos0 + B_local <= B_total, "d3p_dpvi_vae_run_dist: need 1 <= B_local and pos0 + B_local <= B_total");
+    D3P_REQUIRE(comm || B_local == B_total, "d3p_dpvi_vae_run_dist: a shard of the batch needs a communicator");
+    D3P_REQUIRE(buckets >= 0 && buckets <= 2, "d3p_dpvi_vae_run_dist: buckets must be 0, 1 or 2");
+    if (workspace_bytes < d3p_dpvi_vae_workspace(model, B_local)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_run_dist: workspace too small");
+    VaeWorkspace ws;
+    vae_carve(model, B_local, (char*)workspace_dev, &ws);
+    const VaeNet N = vae_net(model);
+    hipStream_t s = (hipStream_t)stream;
+    static const int env_buckets = [] { const char* e = getenv("D3P_VAE_DP_BUCKETS"); return e ? atoi(e) : 0; }();   // developer switch (A/B), read once
+    // (the library's choice is ONE bucket: on one GPU the two-bucket form costs 40 us per step more -- two event hand-overs between the
+    // streams, one more grouped launch and tile-sum launch -- than the 30 us of products it can put beside a reduce;
+    // profiles/r05_vae_dp_loop_rank_local.jsonl.  bench.py --gpus N times both over real links.)
+    if (buckets == 0) buckets = (env_buckets == 1 || env_buckets == 2) ? env_buckets : 1;
+    VaeDistStep step = {s, nullptr, comm, ws.sums, N.enc[0].W, (size_t)N.P + 2};
+    const bool two = comm && buckets == 2 && step.split > 0 && step.split < (size_t)N.P;
+    if (two)
+        if (int rc = vae_dist_side(&step.side)) return rc;
+    const VaeBuckets bk = {step.split, vae_dist_bucket_ready, &step};
+    d3p_dpsvi_state st = *state;
+    for (uint32_t t = 0; t < num_steps; ++t) {
+        int rc;
+        if ((rc = vae_local_sums_impl(stream, model, hyper, &st, X_local_dev, mask_dev, B_local, B_total, pos0, nullptr, ws.sums, workspace_dev,
+                                      workspace_bytes, true, nullptr, nullptr, nullptr, nullptr, true, two ? &bk : nullptr)))
+            return rc;
+        if (comm && !two && (rc = rccl_allreduce_f32(comm, ws.sums, (size_t)N.P + 2, s))) return rc;
+        if ((rc = vae_apply_impl(stream, model, hyper, &st, ws.sums, B_total, B_local, losses_dev ? losses_dev + t : nullptr, nullptr, workspace_dev,
+                                 workspace_bytes, false, nullptr, nullptr, false, true)))
+            return rc;
         st.key_slot ^= 1;
     }
     return D3P_OK;

@@ -497,16 +497,29 @@ class VaeHipEngine:
         return new_state, self.loss[0]
 
 
-def vae_run_steps(engine, state, X_local, batch_size_total, pos0, num_steps, group=None, collect_losses=True):
+def vae_run_steps(engine, state, X_local, batch_size_total, pos0, num_steps, group=None, collect_losses=True, comm=None, buckets=0):
     """`num_steps` data-parallel VAE updates on the SAME resident batch shard (the epoch body of examples/vae.py:227-246 with the
-    batch sharded by position): per step local sums -> ONE all_reduce(SUM) of the P + 2 sums -> apply (noise once, after the
-    reduce, identical on every rank), the state advancing in the engine's own buffers -- no per-step state copies, nothing
-    synchronises the host.  Returns (new_state, losses[num_steps] or None)."""
+    batch sharded by position): per step local sums -> ONE sum-all-reduce of the P + 2 sums -> apply (noise once, after the
+    reduce, identical on every rank), the state advancing in the engine's own buffers.
+    `comm`: a NativeComm -- the whole run is ONE C call (d3p_dpvi_vae_run_dist): nothing happens on the host between steps, the
+    reduce is RCCL's on the library's communicator, in two buckets on a second stream (`buckets` = 2; 1: one all-reduce in the
+    stream; 0: the library's choice) so that the decoder's sums travel while the encoder's weight-gradient products run; with
+    `comm="local"` the same call without a collective (one rank).  comm=None: the Python-driven loop over `group`
+    (torch.distributed.all_reduce; any backend).  Returns (new_state, losses[num_steps] or None)."""
     import torch.distributed as dist
-    initialised = dist.is_available() and dist.is_initialized()
-    world = dist.get_world_size(group) if initialised else 1
+    from .svi import DPSVIState
     engine.begin(state, X_local, batch_size_total, pos0)
     losses = torch.empty(int(num_steps), dtype=torch.float32, device=engine.X.device) if collect_losses else None
+    if comm is not None:
+        handle = None if isinstance(comm, str) else comm.handle
+        check(_lib.load().d3p_dpvi_vae_run_dist(
+            stream_ptr(), handle, C.byref(engine.vm), C.byref(engine.hyper), C.byref(engine.st), ptr(engine.X), ptr(engine.mask),
+            engine.B_local, engine.B_total, engine.pos0, int(num_steps), ptr(losses), int(buckets), ptr(engine.ws), engine.ws.numel()))
+        new_state = DPSVIState((engine.step, engine.params, engine.m, engine.v), engine.keybuf[int(num_steps) & 1].reshape(4, 4).clone(),
+                               engine.observation_scale)
+        return new_state, losses
+    initialised = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if initialised else 1
     new_state = state
     for t in range(int(num_steps)):
         sums = engine.local_sums()

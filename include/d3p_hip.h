@@ -627,6 +627,19 @@ int d3p_dpvi_vae_apply(void* stream, const d3p_vae_model* model, const d3p_dpsvi
                        const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev,
                        void* workspace_dev, size_t workspace_bytes);
 
+/* ABI 8: the data-parallel epoch body as ONE call (examples/vae.py:227-246 with the batch sharded by position): num_steps x
+ * [d3p_dpvi_vae_local_sums on the RESIDENT shard X_local_dev -> sum-all-reduce of the P + 2 fp32 sums over `comm` (d3p_comm_*:
+ * RCCL; NULL = one rank) -> d3p_dpvi_vae_apply], enqueued back to back on `stream`: nothing waits for the host, the state advances
+ * in place (its key ends in slot (key_slot + num_steps) & 1 of state->rng_key, as d3p_dpvi_vae_run leaves it), the step's keys
+ * are derived once, the Gaussian-mechanism noise is drawn beside the latent kernel and apply is one launch behind the reduce.
+ * buckets = 2: the sums travel in two buckets on a second stream, the decoder's leaves while the encoder's weight-gradient products
+ * still run (every clipped sum needs the whole backward pass first: only the tail of the step can overlap a reduce); 1: one
+ * all-reduce on `stream`; 0: the library's choice.  losses_dev: num_steps floats or NULL. */
+int d3p_dpvi_vae_run_dist(void* stream, void* comm, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper,
+                          const d3p_dpsvi_state* state, const float* X_local_dev, const uint8_t* mask_dev, uint32_t B_local,
+                          uint32_t B_total, uint32_t pos0, uint32_t num_steps, float* losses_dev, int32_t buckets,
+                          void* workspace_dev, size_t workspace_bytes);
+
 /* Self-test of the wave-level sums the step kernels are built on (wave_sum / wave_sum2: DPP adds from inline assembly), taken
  * directly behind divergent branches: in_dev holds 64 floats per wave, out_dev[3 w + {0, 1, 2}] = the sum of wave w's inputs by
  * wave_sum, and the sums of x and 2 x by wave_sum2.  No reference counterpart (jnp.sum); tests/test_gpu_rng.py.  ABI 7. */

@@ -460,6 +460,63 @@ def test_vae_virtual_ranks_at_config4_batch_match_single_rank(gpu, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,D,H,Z,H2", [(4096, 784, 400, 50, 0), (512, 784, 400, 50, 200), (30, 12, 7, 3, 0)])
+def test_vae_native_data_parallel_loop_equals_the_update_by_update_run(gpu, B, D, H, Z, H2):
+    """d3p_dpvi_vae_run_dist -- the data-parallel epoch body of examples/vae.py:227-246 as ONE call -- on one rank: (a) without a
+    collective, (b) with a one-rank RCCL communicator and ONE all-reduce in the stream, (c) with the sums travelling in TWO buckets
+    on a second stream (the decoder's leaves while the encoder's weight-gradient products run; two grouped launches, two
+    tile-sum launches, events).  With one rank a reduce is the identity, so (a) and (b) must be BITWISE the Python-driven loop
+    (local_sums -> apply per step), (c) equal to fp32 rounding (other split-K order), and all, step for step, `DPSVI.update` (which tests/test_gpu_vae.py / test_gpu_configs.py pin to
+    the oracle): same keys, same losses, same parameters and moments, step counter = the number of steps."""
+    import d3p_amd.random as rng
+    from d3p_amd.dist import NativeComm, VaeHipEngine, vae_run_steps
+    from d3p_amd.models import Adam, Trace_ELBO, VAEGuide, VAEModel
+    from d3p_amd.svi import DPSVI, DPSVIState
+    N, steps = 60000, 4
+    r = np.random.default_rng(29)
+    hidden = (H, H2) if H2 else H
+    model = VAEModel(z_dim=Z, hidden_dim=hidden, scale=1.0 / N)
+
+    def make():
+        return DPSVI(model, VAEGuide(model), Adam(1e-2), Trace_ELBO(), 3.0, 0.8, num_obs_total=N)
+    X = torch.tensor((r.random((B, D)) < 0.4).astype(np.float32)).cuda()
+    st0 = make().init(rng.PRNGKey(83), X)
+    # update by update
+    svi, st, ref_losses = make(), st0, []
+    for _ in range(steps):
+        st, l = svi.update(st, X)
+        ref_losses.append(float(l))
+    py_state, py_losses = vae_run_steps(VaeHipEngine(make()), st0, X, B, 0, steps)
+    comm = NativeComm()
+    try:
+        runs = {"local": vae_run_steps(VaeHipEngine(make()), st0, X, B, 0, steps, comm="local"),
+                "rccl, one bucket": vae_run_steps(VaeHipEngine(make()), st0, X, B, 0, steps, comm=comm, buckets=1),
+                "rccl, two buckets": vae_run_steps(VaeHipEngine(make()), st0, X, B, 0, steps, comm=comm, buckets=2)}
+        torch.cuda.synchronize()
+    finally:
+        comm.close()
+    for name, (s2, losses) in runs.items():
+        assert torch.equal(s2.rng_key, st.rng_key) and int(s2.optim_state[0]) == steps, name
+        if "two buckets" in name:
+            # (one grouped launch per bucket: each chooses its own split of the batch axis for whole rounds of workgroups, so the
+            # split-K partial sums are added in another order than the one-launch form's -- fp32 rounding, not bit patterns)
+            np.testing.assert_allclose(losses.cpu().numpy(), py_losses.cpu().numpy(), rtol=2e-6, err_msg=name)
+            x2, m2, v2 = (t.cpu().numpy() for t in s2.optim_state[1:])
+            xr, mr, vr = (t.cpu().numpy() for t in py_state.optim_state[1:])
+            np.testing.assert_allclose(m2, mr, rtol=2e-4, atol=2e-5 * np.abs(mr).max(), err_msg=name)     # (the gradients themselves)
+            np.testing.assert_allclose(v2, vr, rtol=4e-4, atol=4e-5 * np.abs(vr).max(), err_msg=name)
+            # (Adam's step is lr m / (sqrt(v) + 1e-8): compared where the gradient is not negligible -- tests/test_gpu_vae.py)
+            big = np.abs(mr) > 1e-3 * np.abs(mr).max()
+            np.testing.assert_allclose(x2[big], xr[big], rtol=1e-4, atol=2e-5, err_msg=name)
+            continue
+        assert torch.equal(losses, py_losses), name
+        for a, b in zip(s2.optim_state[1:], py_state.optim_state[1:]):
+            assert torch.equal(a, b), name
+    np.testing.assert_allclose(py_losses.cpu().numpy(), np.asarray(ref_losses, np.float32), rtol=2e-6)
+    np.testing.assert_allclose(py_state.optim_state[1].cpu().numpy(), st.optim_state[1].cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,K,d,world", [(64, 3, 2, 2), (200, 16, 64, 4)])
 def test_gmm_virtual_ranks_on_one_gpu_match_single_rank(gpu, B, K, d, world):
     """The mixture-model step with the batch sharded by position over `world` virtual ranks on one device: per-example site
