@@ -508,6 +508,63 @@ def test_chain_kernel_single_rank_grids_off_the_xcd_multiple_vs_oracle(gpu, O, B
     _compare(new_st, losses, ost, el, steps)
 
 
+@pytest.mark.parametrize("B", [64, 4096])
+def test_runs_that_continue_each_other_walk_the_trajectory_of_one_run(gpu, O, B):
+    """`run_steps` is a function of the state (svi.py:395-434 returns a NEW state; the epoch loop of
+    examples/logistic_regression.py:186-191 calls one jit(fori_loop) per epoch on the state the last one returned): a sequence of
+    runs that continue each other -- 5, 20, 3, 140, 1, 30, 129 steps: runs that end inside and across the 128-step launches --
+    must walk the trajectory of ONE run of the total length: every loss, the parameters, the step counter, and the state key of
+    sum(steps) successive split(key, 3)[0] (svi.py:208-211) bit for bit against the oracle.  Then a run from ANOTHER key on the
+    same workspace and a run that re-starts from the first state: nothing a run leaves in the workspace may leak into the next
+    (written for the key chain's look-ahead, tools/experiments/r05_key_chain_lookahead.patch; kept as the test of the property)."""
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import subsample_batchify_data
+    N, d = 20_000, 512
+    X, y = _table(N, d, 72)
+    svi = _svi(d, False, N)
+    st0 = _state(svi, rng.PRNGKey(91), d, N)
+    _, gb = subsample_batchify_data((X.cuda(), y.cuda()), B)
+    lens = [5, 20, 3, 140, 1, 30, 129]
+    total = sum(lens)
+    one_state, one_losses = svi.run_steps(st0, gb, rng.PRNGKey(92), 0, total)
+    one_losses = one_losses.clone()
+    one_params = one_state.optim_state[1].clone()
+    one_key = one_state.rng_key.clone()
+    st, first, parts = st0, 0, []
+    for n in lens:
+        st, l = svi.run_steps(st, gb, rng.PRNGKey(92), first, n)
+        assert svi.last_run_status() == (False, False)
+        parts.append(l.clone())
+        first += n
+        key = O.PRNGKey(91)
+        for _ in range(first):
+            key = O.split(key, 3)[0]
+        assert np.array_equal(np_(st.rng_key).ravel(), np.asarray(key).ravel()), f"key after {first} steps"
+        assert int(st.optim_state[0]) == first
+    assert torch.equal(st.rng_key, one_key)
+    np.testing.assert_allclose(np_(torch.cat(parts)), np_(one_losses), rtol=1e-6)
+    np.testing.assert_allclose(np_(st.optim_state[1]), np_(one_params), rtol=1e-5, atol=1e-7)
+    # the oracle's trajectory over the first three runs (28 steps: every one of them started from a look-ahead record but the first)
+    spec = O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(1.0, 0.7, 1e-2, 0.9, 0.999, 1e-8)
+    ost = _oracle_state(O, 91, d)
+    el = _oracle_losses_feistel(O, spec, hy, ost, X.numpy(), y.numpy(), O.PRNGKey(92), 0, B, 28)
+    np.testing.assert_allclose(np_(torch.cat(parts))[:28], np.asarray(el, np.float32), rtol=LOSS_RTOL)
+    # another key on the same workspace, then the first state again: neither run may take the record that is there
+    other = _state(svi, rng.PRNGKey(93), d, N)
+    o_state, _ = svi.run_steps(other, gb, rng.PRNGKey(92), 0, 7)
+    key = O.PRNGKey(93)
+    for _ in range(7):
+        key = O.split(key, 3)[0]
+    assert np.array_equal(np_(o_state.rng_key).ravel(), np.asarray(key).ravel())
+    again, l_again = svi.run_steps(st0, gb, rng.PRNGKey(92), 0, 25)
+    assert torch.equal(l_again, torch.cat(parts)[:25]) or np.allclose(np_(l_again), np_(torch.cat(parts))[:25], rtol=1e-6)
+    key = O.PRNGKey(91)
+    for _ in range(25):
+        key = O.split(key, 3)[0]
+    assert np.array_equal(np_(again.rng_key).ravel(), np.asarray(key).ravel())
+
+
 @pytest.mark.parametrize("steps", [129, 255, 259, 385])
 def test_key_chain_links_across_launch_boundaries(gpu, O, steps):
     """The key chain of every batch of 128 steps but the first is made link by link in the tail of workgroup 0 of the launch
