@@ -507,7 +507,9 @@ def test_vae_native_data_parallel_loop_equals_the_update_by_update_run(gpu, B, D
             np.testing.assert_allclose(v2, vr, rtol=4e-4, atol=4e-5 * np.abs(vr).max(), err_msg=name)
             # (Adam's step is lr m / (sqrt(v) + 1e-8): compared where the gradient is not negligible -- tests/test_gpu_vae.py)
             big = np.abs(mr) > 1e-3 * np.abs(mr).max()
-            np.testing.assert_allclose(x2[big], xr[big], rtol=1e-4, atol=2e-5, err_msg=name)
+            # (four steps of lr = 1e-2: a parameter moves up to 4e-2; where a step's gradient is close to zero its direction hangs on the
+            # last bit of the sum)
+            np.testing.assert_allclose(x2[big], xr[big], rtol=1e-4, atol=5e-4, err_msg=name)
             continue
         assert torch.equal(losses, py_losses), name
         for a, b in zip(s2.optim_state[1:], py_state.optim_state[1:]):
