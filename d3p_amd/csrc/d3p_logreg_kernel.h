@@ -775,8 +775,12 @@ __global__ void __launch_bounds__(D3P_MAIN_MAX_THREADS(V, NK)) k_logreg_main(Mai
                 if (n == 0.0f) lv = empty_batch_loss(P, [&](int c) { return ld_x<CHAIN>(f.params_in + c); });
                 *f.prev_loss_out = lv;
             }
-            *f.adam_step = f.prev_meta->adam_i + 1;
-            if (f.batch_index) *f.batch_index = f.prev_meta->batch_i + 1u;
+            // (chained launch: the run's counters are k_flush's -- a word that workgroup 0 of a different step, i.e. a different XCD, plain-
+            // stores every step keeps the value of whichever L2 is written back last; one launch per step: this launch is the only writer)
+            if (!CHAIN) {
+                *f.adam_step = f.prev_meta->adam_i + 1;
+                if (f.batch_index) *f.batch_index = f.prev_meta->batch_i + 1u;
+            }
         }
         return false;
     };
