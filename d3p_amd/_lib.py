@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libd3p_hip.so")
-_SRC = [os.path.join(_HERE, "csrc", f) for f in ("d3p_rng.hip", "d3p_dpvi.hip", "d3p_stages.hip", "d3p_gmm.hip", "d3p_vae.hip")]
+_SRC = [os.path.join(_HERE, "csrc", f) for f in ("d3p_rng.hip", "d3p_dpvi.hip", "d3p_stages.hip", "d3p_gmm.hip", "d3p_vae.hip", "d3p_fmesh.hip")]
 _DEPS = _SRC + [os.path.join(_HERE, "csrc", f) for f in ("d3p_device.h", "d3p_host.h", "d3p_logreg_kernel.h", "d3p_logreg_chain.h", "d3p_logreg_persist.h", "d3p_logreg_wide.h")] + [
     os.path.join(os.path.dirname(_HERE), "include", "d3p_hip.h")]
 
@@ -181,7 +181,14 @@ SIGNATURES = {
     "d3p_dpvi_gmm_apply": (C.c_int, [_V, _V, _V, _V, _V, _U32, _U32, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_vae_local_sums": (C.c_int, [_V, _V, _V, _V, _V, _V, _U32, _U32, _U32, _V, _V, _V, C.c_size_t]),
     "d3p_dpvi_vae_apply": (C.c_int, [_V, _V, _V, _V, _V, _U32, _U32, _V, _V, _V, C.c_size_t]),
-    "d3p_dpvi_vae_run_dist": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _U32, _U32, _U32, _U32, _V, C.c_int32, _V, C.c_size_t]),
+    "d3p_dpvi_vae_run_dist": (C.c_int, [_V, _V, _V, _V, _V, _V, _V, _V, _U32, _U32, _U32, _U32, _V, C.c_int32, _V, C.c_size_t]),
+    "d3p_fmesh_create": (C.c_int, [C.c_int32, C.c_int32, C.c_uint64, _V, _V, C.c_size_t]),
+    "d3p_fmesh_connect": (C.c_int, [_V, _V, C.c_size_t]),
+    "d3p_fmesh_connect_local": (C.c_int, [_V, _V, C.c_int32]),
+    "d3p_fmesh_set_grid": (C.c_int, [_V, C.c_int32]),
+    "d3p_fmesh_allreduce": (C.c_int, [_V, _V, _V, C.c_uint64]),
+    "d3p_fmesh_status": (C.c_int, [_V, _V, _V]),
+    "d3p_fmesh_destroy": (C.c_int, [_V]),
     "d3p_dpvi_logreg_chain_status": (C.c_int, [_V, _V, _V, _V, C.c_size_t, _V]),
     "d3p_dpvi_logreg_run_status": (C.c_int, [_V, _V, _V, _V, C.c_size_t, _V, _V]),
     "d3p_xchg_create": (C.c_int, [_I32, _I32, _U32, _V, _V, _SZ]),

@@ -1,0 +1,294 @@
+// Full-mesh sum-all-reduce of a float vector over the GPUs of one node (d3p_fmesh_*): the collective of the data-parallel VAE step.
+//
+// The reference is single-device; a data-parallel DPSVI.update needs ONE sum over the ranks per step
+// (svi.py:343-346 is the only cross-example operation) -- for the VAE of examples/vae.py that is P + 2 = 688 886 floats, 2.76 MB.
+// xGMI is point to point: every GPU has a link to each of its 7 peers.  A ring all-reduce takes 2 (n - 1) dependent hops and loads one
+// link at a time; on a full mesh the same sum is TWO hops with every link busy:
+//
+//   reduce-scatter  rank r owns chunk r of the vector (ceil(n / world) elements).  Every rank stores its partial values of chunk o
+//                   straight into rank o's inbox (slot [parity][sender]) -- 1 / world of the vector per link;
+//   owner sum       the owner adds the world's partials of its chunk in RANK ORDER (one rank, one fixed order: every rank later
+//                   receives bit for bit the same sum -- replicas stay identical without a broadcast of parameters);
+//   all-gather      the owner stores the sums of its chunk into every peer's gather inbox -- again 1 / world of the vector per link.
+//
+// Arrival is signalled by the data: every float travels as ONE aligned 8-byte word {fp32 bits | 32-bit epoch tag} (performed whole;
+// the low-latency protocol of the step exchange, d3p_logreg_chain.h).  Twice the bytes of a flag-after-data protocol, but no release
+// fence -- on this chip a system-scope release is a write-back of the XCD's whole L2 -- and no second trip.  Slots are double-buffered
+// by the parity of the epoch: a rank can only send epoch e + 2 after it finished epoch e + 1, which needs every peer's sends of
+// e + 1, which those peers issue after they finished READING epoch e.
+// All waits are bounded and raise the status word (a stopped collective leaves the vector undefined and is reported).
+// One launch of grid-stride workgroups that must ALL be resident (a workgroup that has sent its share waits for the peers' words, some of
+// which only come once the peers have received the words of this launch's other workgroups): 512 of 256 threads, two per CU, on a GPU
+// of its own.  Ranks that SHARE a GPU (tests, rehearsals) must leave room for each other's kernels -- a compute kernel whose workgroup
+// takes a CU's whole register file can never start on a GPU whose every CU holds a waiting workgroup of this launch:
+// d3p_fmesh_set_grid (d3p_fmesh_connect_local sets 48).
+#include "d3p_device.h"
+#include "d3p_host.h"
+
+#include <new>
+
+namespace d3p {
+
+#define D3P_FMESH_MAX_WORLD 16
+#define D3P_FMESH_WGS 512   // two per CU (no LDS, 4 waves each): 131 072 threads, 5 elements of a 2.76 MB vector per thread (one rank, no peers:
+                            // 12.7 us with 512 workgroups, 20.5 with 256, 37.5 with 128 -- the passes are latency, so more threads)
+#define D3P_FMESH_WAIT_ROUNDS (1u << 24)   // polls of one word (~ 0.7 us each)
+
+struct FMesh {
+    int world, rank;
+    uint64_t n;        // floats of the vector
+    uint64_t chunk;    // ceil(n / world)
+    unsigned long long epoch;
+    int wgs;           // workgroups of a launch (d3p_fmesh_set_grid)
+    char* inbox;       // [scatter: 2 x world x chunk words | gather: 2 x world x chunk words | status: 16 words]
+    size_t inbox_bytes;
+    char* peer[D3P_FMESH_MAX_WORLD];
+    bool opened[D3P_FMESH_MAX_WORLD];
+};
+
+static size_t fmesh_region_words(int world, uint64_t chunk) { return (size_t)2 * world * chunk; }
+
+struct FMeshArgs {
+    float* buf;
+    uint64_t n, chunk;
+    int world, rank;
+    unsigned parity;
+    uint32_t tag;
+    char* peer[D3P_FMESH_MAX_WORLD];
+    size_t gather_off;      // bytes from the inbox's start to its gather region
+    uint32_t* status;       // this rank's status word (in its own inbox)
+};
+
+__device__ __forceinline__ void fm_store(char* base, size_t word, float v, uint32_t tag)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(base) + word, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// bounded wait for word `word` of the own inbox to carry `tag`; false: the bound ran out or the collective was stopped
+[[maybe_unused]] __device__ __forceinline__ bool fm_wait(const char* base, size_t word, uint32_t tag, uint32_t* status, float* out)
+{
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(base) + word;
+    for (uint32_t spins = 0; spins < D3P_FMESH_WAIT_ROUNDS; ++spins) {
+        const unsigned long long w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((uint32_t)(w >> 32) == tag) { *out = __uint_as_float((uint32_t)w); return true; }
+        if ((spins & 255u) == 255u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(256) k_fmesh_allreduce(FMeshArgs a)
+{
+    // Every loop keeps U independent memory operations of a thread in flight: a thread that loads, stores and polls one word at a time is
+    // bound by the latency of each (46 us for 688 886 floats with NO peer at all; 8 us like this).
+    constexpr int U = 4;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)gridDim.x * blockDim.x;
+    char* const mine = a.peer[a.rank];
+    const size_t sc_par = (size_t)a.parity * a.world * a.chunk;   // first word of this parity's slots in a region
+    // ---- reduce-scatter: my partial values of every other rank's chunk, into that rank's scatter slot [parity][my rank]
+    for (uint64_t i0 = tid; i0 < a.n; i0 += U * nthreads) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * nthreads;
+            v[u] = i < a.n ? a.buf[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * nthreads;
+            if (i >= a.n) continue;
+            const int o = (int)(i / a.chunk);
+            if (o != a.rank) fm_store(a.peer[o], sc_par + (size_t)a.rank * a.chunk + (i - (uint64_t)o * a.chunk), v[u], a.tag);
+        }
+    }
+    // ---- owner sum of my chunk in rank order, then all-gather: the sums into every peer's gather slot [parity][my rank]
+    const uint64_t lo = (uint64_t)a.rank * a.chunk, hi = lo + a.chunk < a.n ? lo + a.chunk : a.n;
+    bool ok = true;
+    for (uint64_t i = lo + tid; i < hi && ok; i += nthreads) {
+        const uint64_t j = i - lo;
+        // the world's partials of element j: all peers' words requested together, again and again until every one carries the tag
+        unsigned long long w[D3P_FMESH_MAX_WORLD];
+        bool all = false;
+        for (uint32_t spins = 0; spins < D3P_FMESH_WAIT_ROUNDS && !all; ++spins) {
+#pragma unroll
+            for (int r = 0; r < D3P_FMESH_MAX_WORLD; ++r)
+                if (r < a.world && r != a.rank)
+                    w[r] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(mine) + sc_par + (size_t)r * a.chunk + j, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_SYSTEM);
+            all = true;
+#pragma unroll
+            for (int r = 0; r < D3P_FMESH_MAX_WORLD; ++r)
+                if (r < a.world && r != a.rank) all = all && (uint32_t)(w[r] >> 32) == a.tag;
+            if (!all && (spins & 255u) == 255u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        }
+        if (!all) { ok = false; break; }
+        float s = 0.f;   // in RANK order: r = 0, 1, ... (the own partial in its place)
+#pragma unroll
+        for (int r = 0; r < D3P_FMESH_MAX_WORLD; ++r)
+            if (r < a.world) {
+                const float v = r == a.rank ? a.buf[i] : __uint_as_float((uint32_t)w[r]);
+                s = r == 0 ? v : s + v;
+            }
+        a.buf[i] = s;
+        for (int p = 0; p < a.world; ++p)
+            if (p != a.rank) fm_store(a.peer[p] + a.gather_off, sc_par + (size_t)a.rank * a.chunk + j, s, a.tag);
+    }
+    // ---- gather: the other chunks' sums from my gather slots, U words requested together
+    const unsigned long long* const gin = reinterpret_cast<const unsigned long long*>(mine + a.gather_off) + sc_par;
+    for (uint64_t i0 = tid; i0 < a.n && ok; i0 += U * nthreads) {
+        size_t word[U];
+        bool need[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * nthreads;
+            const int o = i < a.n ? (int)(i / a.chunk) : a.rank;
+            need[u] = i < a.n && o != a.rank;
+            word[u] = need[u] ? (size_t)o * a.chunk + (i - (uint64_t)o * a.chunk) : 0;
+        }
+        unsigned long long w[U];
+        bool all = false;
+        for (uint32_t spins = 0; spins < D3P_FMESH_WAIT_ROUNDS && !all; ++spins) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (need[u]) w[u] = __hip_atomic_load(gin + word[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            all = true;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (need[u]) all = all && (uint32_t)(w[u] >> 32) == a.tag;
+            if (!all && (spins & 255u) == 255u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        }
+        if (!all) { ok = false; break; }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (need[u]) a.buf[i0 + (uint64_t)u * nthreads] = __uint_as_float((uint32_t)w[u]);
+    }
+    if (!ok) {   // first code stays: 1 = a word of a peer did not come
+        uint32_t expect = 0u;
+        (void)__hip_atomic_compare_exchange_strong(a.status, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+int fmesh_enqueue_allreduce(hipStream_t s, void* fmesh, float* buf, uint64_t n)
+{
+    FMesh* x = (FMesh*)fmesh;
+    D3P_REQUIRE(x && buf, "d3p_fmesh_allreduce: null pointer");
+    D3P_REQUIRE(n == x->n, "d3p_fmesh_allreduce: the mesh was created for another vector length");
+    for (int p = 0; p < x->world; ++p) D3P_REQUIRE(x->peer[p], "d3p_fmesh_allreduce: the peers' inboxes are not mapped (d3p_fmesh_connect)");
+    FMeshArgs a;
+    memset(&a, 0, sizeof(a));
+    a.buf = buf;
+    a.n = x->n;
+    a.chunk = x->chunk;
+    a.world = x->world;
+    a.rank = x->rank;
+    const unsigned long long epoch = ++x->epoch;
+    a.parity = (unsigned)(epoch & 1ull);
+    a.tag = (uint32_t)epoch;
+    for (int p = 0; p < x->world; ++p) a.peer[p] = x->peer[p];
+    a.gather_off = fmesh_region_words(x->world, x->chunk) * sizeof(unsigned long long);
+    a.status = reinterpret_cast<uint32_t*>(x->inbox + 2 * a.gather_off);
+    hipLaunchKernelGGL(k_fmesh_allreduce, dim3((unsigned)x->wgs), dim3(256), 0, s, a);
+    return check_launch("k_fmesh_allreduce");
+}
+
+}  // namespace d3p
+
+using namespace d3p;
+
+extern "C" {
+
+int d3p_fmesh_create(int32_t world, int32_t rank, uint64_t n_floats, void** fmesh_out, uint8_t* handle_out, size_t handle_bytes)
+{
+    D3P_REQUIRE(fmesh_out && handle_out && handle_bytes >= sizeof(hipIpcMemHandle_t), "d3p_fmesh_create: null pointer or handle buffer < 64 bytes");
+    D3P_REQUIRE(world >= 1 && world <= D3P_FMESH_MAX_WORLD && rank >= 0 && rank < world && n_floats >= 1, "d3p_fmesh_create: bad arguments");
+    FMesh* x = new (std::nothrow) FMesh();
+    if (!x) return fail(D3P_E_HIP, "d3p_fmesh_create: out of host memory");
+    x->world = world;
+    x->rank = rank;
+    x->n = n_floats;
+    x->chunk = (n_floats + (uint64_t)world - 1) / (uint64_t)world;
+    x->epoch = 0;
+    x->wgs = D3P_FMESH_WGS;
+    x->inbox_bytes = 2 * fmesh_region_words(world, x->chunk) * sizeof(unsigned long long) + 64;
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, x->inbox_bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { delete x; return fail(D3P_E_HIP, "d3p_fmesh_create: hipExtMallocWithFlags: %s", hipGetErrorString(e)); }
+    x->inbox = (char*)p;
+    e = hipMemset(p, 0, x->inbox_bytes);   // (tag 0 is never waited for: epochs count from 1)
+    hipIpcMemHandle_t h;
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) { (void)hipFree(p); delete x; return fail(D3P_E_HIP, "d3p_fmesh_create: %s", hipGetErrorString(e)); }
+    memcpy(handle_out, &h, sizeof(h));
+    for (int i = 0; i < D3P_FMESH_MAX_WORLD; ++i) { x->peer[i] = nullptr; x->opened[i] = false; }
+    x->peer[rank] = x->inbox;
+    *fmesh_out = x;
+    return D3P_OK;
+}
+
+int d3p_fmesh_connect(void* fmesh, const uint8_t* handles, size_t handle_stride)
+{
+    D3P_REQUIRE(fmesh && handles && handle_stride >= sizeof(hipIpcMemHandle_t), "d3p_fmesh_connect: bad arguments");
+    FMesh* x = (FMesh*)fmesh;
+    for (int p = 0; p < x->world; ++p) {
+        if (p == x->rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)p * handle_stride, sizeof(h));
+        void* q = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return fail(D3P_E_HIP, "d3p_fmesh_connect: hipIpcOpenMemHandle(rank %d): %s", p, hipGetErrorString(e));
+        x->peer[p] = (char*)q;
+        x->opened[p] = true;
+    }
+    return D3P_OK;
+}
+
+int d3p_fmesh_connect_local(void* fmesh, void* const* peers, int32_t world)
+{
+    D3P_REQUIRE(fmesh && peers, "d3p_fmesh_connect_local: null pointer");
+    FMesh* x = (FMesh*)fmesh;
+    D3P_REQUIRE(world == x->world, "d3p_fmesh_connect_local: group size differs from the one the mesh was created for");
+    for (int p = 0; p < world; ++p) {
+        const FMesh* q = (const FMesh*)peers[p];
+        D3P_REQUIRE(q && q->rank == p && q->n == x->n && q->world == world, "d3p_fmesh_connect_local: peers must be the group's meshes in rank order");
+        x->peer[p] = q->inbox;
+    }
+    x->wgs = 48;   // the group's ranks share this GPU: see the header
+    return D3P_OK;
+}
+
+int d3p_fmesh_set_grid(void* fmesh, int32_t workgroups)
+{
+    D3P_REQUIRE(fmesh && workgroups >= 1 && workgroups <= 1024, "d3p_fmesh_set_grid: 1 <= workgroups <= 1024");
+    ((FMesh*)fmesh)->wgs = workgroups;
+    return D3P_OK;
+}
+
+int d3p_fmesh_allreduce(void* stream, void* fmesh, float* buf_dev, uint64_t n_floats)
+{
+    return fmesh_enqueue_allreduce((hipStream_t)stream, fmesh, buf_dev, n_floats);
+}
+
+int d3p_fmesh_status(void* stream, void* fmesh, int32_t* stopped_out)
+{
+    D3P_REQUIRE(fmesh && stopped_out, "d3p_fmesh_status: null pointer");
+    FMesh* x = (FMesh*)fmesh;
+    D3P_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    uint32_t w = 0;
+    D3P_HIP_TRY(hipMemcpy(&w, x->inbox + 2 * fmesh_region_words(x->world, x->chunk) * sizeof(unsigned long long), sizeof(w), hipMemcpyDeviceToHost));
+    *stopped_out = (int32_t)w;
+    return D3P_OK;
+}
+
+int d3p_fmesh_destroy(void* fmesh)
+{
+    if (!fmesh) return D3P_OK;
+    FMesh* x = (FMesh*)fmesh;
+    for (int p = 0; p < x->world; ++p)
+        if (x->opened[p]) (void)hipIpcCloseMemHandle(x->peer[p]);
+    (void)hipFree(x->inbox);
+    (void)hipGetLastError();
+    delete x;
+    return D3P_OK;
+}
+
+}  // extern "C"

@@ -65,4 +65,8 @@ inline unsigned cdiv(unsigned long long a, unsigned long long b) { return (unsig
 // in-place sum-all-reduce of `count` floats over the ranks of a d3p_comm_* communicator (RCCL, resolved at run time: d3p_dpvi.hip)
 int rccl_allreduce_f32(void* comm, float* buf, size_t count, hipStream_t s);
 
+// in-place sum-all-reduce of the n floats a d3p_fmesh_* mesh was created for (full-mesh reduce-scatter + all-gather over the peers'
+// hipIpc-mapped inboxes: d3p_fmesh.hip)
+int fmesh_enqueue_allreduce(hipStream_t s, void* fmesh, float* buf, uint64_t n);
+
 }  // namespace d3p

@@ -2601,14 +2601,17 @@ static int vae_dist_bucket_ready(void* ctx, int bucket)
 // buckets = 2: the sums travel in two buckets on a second stream -- the decoder's leaves while the encoder's weight-gradient
 // products still run (VaeBuckets); 1: one all-reduce on `stream` itself; 0: the library's choice (1: see below).
 // comm = NULL: no collective (one rank; B_local == B_total).
-int d3p_dpvi_vae_run_dist(void* stream, void* comm, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
+int d3p_dpvi_vae_run_dist(void* stream, void* comm, void* fmesh, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
                           const float* X_local_dev, const uint8_t* mask_dev, uint32_t B_local, uint32_t B_total, uint32_t pos0,
                           uint32_t num_steps, float* losses_dev, int32_t buckets, void* workspace_dev, size_t workspace_bytes)
 {
+    // fmesh != NULL: the step's collective is the full-mesh reduce-scatter + all-gather of d3p_fmesh.hip (one launch in the stream)
+    // instead of RCCL's all-reduce
+    D3P_REQUIRE(!(comm && fmesh), "d3p_dpvi_vae_run_dist: one collective, RCCL (comm) or the full mesh (fmesh), not both");
     if (int rc = vae_update_checks(model, hyper, state, workspace_dev, "d3p_dpvi_vae_run_dist")) return rc;
     D3P_REQUIRE(X_local_dev, "d3p_dpvi_vae_run_dist: null pointer");
     D3P_REQUIRE(B_local >= 1 && (uint64_t)pos0 + B_local <= B_total, "d3p_dpvi_vae_run_dist: need 1 <= B_local and pos0 + B_local <= B_total");
-    D3P_REQUIRE(comm || B_local == B_total, "d3p_dpvi_vae_run_dist: a shard of the batch needs a communicator");
+    D3P_REQUIRE(comm || fmesh || B_local == B_total, "d3p_dpvi_vae_run_dist: a shard of the batch needs a communicator");
     D3P_REQUIRE(buckets >= 0 && buckets <= 2, "d3p_dpvi_vae_run_dist: buckets must be 0, 1 or 2");
     if (workspace_bytes < d3p_dpvi_vae_workspace(model, B_local)) return fail(D3P_E_WORKSPACE, "d3p_dpvi_vae_run_dist: workspace too small");
     VaeWorkspace ws;
@@ -2632,6 +2635,7 @@ int d3p_dpvi_vae_run_dist(void* stream, void* comm, const d3p_vae_model* model, 
                                       workspace_bytes, true, nullptr, nullptr, nullptr, nullptr, true, two ? &bk : nullptr)))
             return rc;
         if (comm && !two && (rc = rccl_allreduce_f32(comm, ws.sums, (size_t)N.P + 2, s))) return rc;
+        if (fmesh && (rc = fmesh_enqueue_allreduce(s, fmesh, ws.sums, (uint64_t)N.P + 2))) return rc;
         if ((rc = vae_apply_impl(stream, model, hyper, &st, ws.sums, B_total, B_local, losses_dev ? losses_dev + t : nullptr, nullptr, workspace_dev,
                                  workspace_bytes, false, nullptr, nullptr, false, true)))
             return rc;

@@ -369,6 +369,69 @@ class XchgComm:
             self.handle = None
 
 
+class FMeshComm:
+    """Full-mesh sum-all-reduce of a float vector owned by libd3p_hip.so (d3p_fmesh_*, csrc/d3p_fmesh.hip): reduce-scatter + all-gather
+    over the peers' hipIpc-mapped inboxes, two hops with every xGMI link carrying 1 / world of the vector, rank-order sums (bitwise
+    identical results on every rank).  The collective of the data-parallel VAE step (`vae_run_steps(..., comm=FMeshComm(P + 2))`).
+    `n_floats`: the length of the vector (P + 2 for a model with P parameters).  Handles travel through torch.distributed, any
+    backend; `local_group` wires ranks that live in one process (tests: their streams from `concurrent_streams`)."""
+
+    def __init__(self, n_floats, group=None, _local=None):
+        import torch.distributed as dist
+        _lib.require_device()
+        lib = _lib.load()
+        if _local is not None:
+            self.rank, self.world = _local
+        else:
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.n = int(n_floats)
+        handle, buf = C.c_void_p(), (C.c_uint8 * 64)()
+        check(lib.d3p_fmesh_create(self.world, self.rank, self.n, C.byref(handle), buf, 64))
+        self.handle = handle
+        if _local is not None:
+            return
+        mine = bytes(buf)
+        if self.world > 1:
+            box = [None] * self.world
+            dist.all_gather_object(box, mine, group=group)
+        else:
+            box = [mine]
+        allh = (C.c_uint8 * (64 * self.world)).from_buffer_copy(b"".join(box))
+        check(lib.d3p_fmesh_connect(self.handle, allh, 64))
+        if self.world > 1:
+            dist.barrier(group=group)      # nobody writes into an inbox that its owner has not finished setting up
+
+    @classmethod
+    def local_group(cls, world, n_floats):
+        comms = [cls(n_floats, _local=(r, world)) for r in range(world)]
+        arr = (C.c_void_p * world)(*[c.handle for c in comms])
+        for c in comms:
+            check(_lib.load().d3p_fmesh_connect_local(c.handle, arr, world))
+        return comms
+
+    def set_grid(self, workgroups):
+        """Workgroups per launch (default one per CU).  Ranks that SHARE a GPU must leave room for each other's kernels: 48."""
+        check(_lib.load().d3p_fmesh_set_grid(self.handle, int(workgroups)))
+
+    def allreduce(self, vec):
+        """In-place sum over the ranks of a contiguous float32 tensor of n_floats elements, on the current stream."""
+        assert vec.dtype == torch.float32 and vec.is_contiguous() and vec.numel() == self.n
+        check(_lib.load().d3p_fmesh_allreduce(stream_ptr(), self.handle, ptr(vec), self.n))
+
+    def stopped(self):
+        """True if a bounded wait of an all-reduce on this mesh ran out (after synchronising the current stream)."""
+        w = C.c_int32(0)
+        check(_lib.load().d3p_fmesh_status(stream_ptr(), self.handle, C.byref(w)))
+        return bool(w.value)
+
+    def close(self):
+        if self.handle:
+            torch.cuda.synchronize()
+            check(_lib.load().d3p_fmesh_destroy(self.handle))
+            self.handle = None
+
+
 def run_steps_native(engine, state, batch_key, first_batch, num_steps, comm=None, collect_losses=True):
     """The whole data-parallel run in one C call: per step one kernel launch and ONE collective of the int64 accumulator
     on the same stream, no host work between steps.  `comm`: a NativeComm (RCCL ring all-reduce, d3p_dpvi_logreg_run_dist),
@@ -503,7 +566,8 @@ def vae_run_steps(engine, state, X_local, batch_size_total, pos0, num_steps, gro
     reduce, identical on every rank), the state advancing in the engine's own buffers.
     `comm`: a NativeComm -- the whole run is ONE C call (d3p_dpvi_vae_run_dist): nothing happens on the host between steps, the
     reduce is RCCL's on the library's communicator, in two buckets on a second stream (`buckets` = 2; 1: one all-reduce in the
-    stream; 0: the library's choice) so that the decoder's sums travel while the encoder's weight-gradient products run; with
+    stream; 0: the library's choice) so that the decoder's sums travel while the encoder's weight-gradient products run; a
+    FMeshComm: the same call with the full-mesh reduce-scatter + all-gather of d3p_fmesh.hip as the step's collective; with
     `comm="local"` the same call without a collective (one rank).  comm=None: the Python-driven loop over `group`
     (torch.distributed.all_reduce; any backend).  Returns (new_state, losses[num_steps] or None)."""
     import torch.distributed as dist
@@ -511,9 +575,10 @@ def vae_run_steps(engine, state, X_local, batch_size_total, pos0, num_steps, gro
     engine.begin(state, X_local, batch_size_total, pos0)
     losses = torch.empty(int(num_steps), dtype=torch.float32, device=engine.X.device) if collect_losses else None
     if comm is not None:
-        handle = None if isinstance(comm, str) else comm.handle
+        rccl = comm.handle if isinstance(comm, NativeComm) else None
+        mesh = comm.handle if isinstance(comm, FMeshComm) else None
         check(_lib.load().d3p_dpvi_vae_run_dist(
-            stream_ptr(), handle, C.byref(engine.vm), C.byref(engine.hyper), C.byref(engine.st), ptr(engine.X), ptr(engine.mask),
+            stream_ptr(), rccl, mesh, C.byref(engine.vm), C.byref(engine.hyper), C.byref(engine.st), ptr(engine.X), ptr(engine.mask),
             engine.B_local, engine.B_total, engine.pos0, int(num_steps), ptr(losses), int(buckets), ptr(engine.ws), engine.ws.numel()))
         new_state = DPSVIState((engine.step, engine.params, engine.m, engine.v), engine.keybuf[int(num_steps) & 1].reshape(4, 4).clone(),
                                engine.observation_scale)

@@ -634,11 +634,30 @@ int d3p_dpvi_vae_apply(void* stream, const d3p_vae_model* model, const d3p_dpsvi
  * are derived once, the Gaussian-mechanism noise is drawn beside the latent kernel and apply is one launch behind the reduce.
  * buckets = 2: the sums travel in two buckets on a second stream, the decoder's leaves while the encoder's weight-gradient products
  * still run (every clipped sum needs the whole backward pass first: only the tail of the step can overlap a reduce); 1: one
- * all-reduce on `stream`; 0: the library's choice.  losses_dev: num_steps floats or NULL. */
-int d3p_dpvi_vae_run_dist(void* stream, void* comm, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper,
+ * all-reduce on `stream`; 0: the library's choice.  fmesh (d3p_fmesh_*, below) instead of comm: the full-mesh collective, one
+ * launch in the stream.  losses_dev: num_steps floats or NULL. */
+int d3p_dpvi_vae_run_dist(void* stream, void* comm, void* fmesh, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper,
                           const d3p_dpsvi_state* state, const float* X_local_dev, const uint8_t* mask_dev, uint32_t B_local,
                           uint32_t B_total, uint32_t pos0, uint32_t num_steps, float* losses_dev, int32_t buckets,
                           void* workspace_dev, size_t workspace_bytes);
+
+/* ABI 8: full-mesh sum-all-reduce of a float vector over the GPUs of one node -- the collective of the data-parallel VAE step as
+ * the survey asks for it (for MB-sized messages on point-to-point xGMI a full-mesh reduce-scatter + all-gather: two
+ * hops with every link carrying 1 / world of the vector, where a ring takes 2 (world - 1) dependent hops).  The reference has no
+ * collective (single device).  Rank r owns chunk r of the vector: every rank stores its partials of chunk o into rank o's inbox,
+ * the owner adds the world's partials in RANK ORDER (every rank then receives bit for bit the same sums) and stores them into every
+ * peer's gather inbox.  A float travels as one 8-byte word {fp32 bits | epoch tag}: the data is its own arrival signal, no fence,
+ * no flag.  Inboxes are uncached device memory mapped into the peers with hipIpc handles (d3p_fmesh_create -> exchange the 64-byte
+ * handles -> d3p_fmesh_connect; d3p_fmesh_connect_local wires meshes that live in one process).  d3p_fmesh_allreduce: one launch on
+ * `stream`, in place, bounded waits; d3p_fmesh_status (after synchronising `stream`): non-zero when a wait ran out -- the vector of
+ * that and every later call is then undefined.  d3p_dpvi_vae_run_dist(..., fmesh) uses it instead of RCCL. */
+int d3p_fmesh_create(int32_t world, int32_t rank, uint64_t n_floats, void** fmesh_out, uint8_t* handle_out, size_t handle_bytes);
+int d3p_fmesh_connect(void* fmesh, const uint8_t* handles, size_t handle_stride);
+int d3p_fmesh_connect_local(void* fmesh, void* const* peers, int32_t world);
+int d3p_fmesh_set_grid(void* fmesh, int32_t workgroups);   /* workgroups per launch (default: one per CU; ranks that share a GPU: fewer) */
+int d3p_fmesh_allreduce(void* stream, void* fmesh, float* buf_dev, uint64_t n_floats);
+int d3p_fmesh_status(void* stream, void* fmesh, int32_t* stopped_out);
+int d3p_fmesh_destroy(void* fmesh);
 
 /* Self-test of the wave-level sums the step kernels are built on (wave_sum / wave_sum2: DPP adds from inline assembly), taken
  * directly behind divergent branches: in_dev holds 64 floats per wave, out_dev[3 w + {0, 1, 2}] = the sum of wave w's inputs by

@@ -870,6 +870,115 @@ def test_a_stopped_rank_and_a_running_one_in_one_process_report_their_own_codes(
     assert code_stop != 0 and "row" in L.describe_abort(code_stop), L.describe_abort(code_stop)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# full-mesh float all-reduce (d3p_fmesh_*): reduce-scatter + all-gather over the peers' inboxes, the VAE step's collective
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.coresident
+@pytest.mark.parametrize("world,n", [(2, 10_007), (3, 688_886), (3, 5), (1, 1000)])
+def test_fmesh_virtual_ranks_sum_in_rank_order_bit_for_bit(gpu, world, n):
+    """`world` ranks in ONE process on streams that run beside each other, inboxes wired directly: after the collective every
+    rank holds, bit for bit, the sum of the ranks' vectors taken in RANK order ((r0 + r1) + r2 in fp32) -- the property that keeps
+    data-parallel replicas identical without a parameter broadcast -- over five epochs (both slot parities, tags of earlier
+    epochs in the slots), with vectors whose length is not a multiple of the world size (ragged last chunk; n < world: ranks
+    that own nothing) and with NaN / Inf entries (bit patterns travel as they are)."""
+    from d3p_amd import dist as ddist
+    comms = ddist.FMeshComm.local_group(world, n)
+    streams = ddist.concurrent_streams(world) if world > 1 else [torch.cuda.current_stream()]
+    try:
+        vecs = [torch.randn(n, generator=torch.Generator().manual_seed(1000 * n + r)) for r in range(world)]
+        if n > 10:
+            vecs[0][3] = float("inf")
+            vecs[world - 1][7] = float("nan")
+        for e in range(5):
+            scaled = [v * float(e + 1) for v in vecs]
+            want = scaled[0].clone()
+            for v in scaled[1:]:
+                want = want + v
+            work = [v.cuda() for v in scaled]
+            torch.cuda.synchronize()
+            for r in range(world):
+                with torch.cuda.stream(streams[r]):
+                    comms[r].allreduce(work[r])
+            torch.cuda.synchronize()
+            for r in range(world):
+                assert not comms[r].stopped()
+                got = work[r].cpu()
+                assert torch.equal(torch.isnan(got), torch.isnan(want)), (e, r)
+                fin = ~torch.isnan(want)
+                assert torch.equal(got[fin].view(torch.int32), want[fin].view(torch.int32)), (e, r)
+    finally:
+        for c in comms:
+            c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.coresident
+@pytest.mark.parametrize("B,D,H,Z,H2,world", [(128, 784, 400, 50, 0, 2), (60, 12, 7, 3, 5, 3)])
+def test_vae_native_loop_over_the_full_mesh_with_virtual_ranks(gpu, B, D, H, Z, H2, world):
+    """The data-parallel VAE epoch body as ONE call per rank (d3p_dpvi_vae_run_dist) with the full-mesh all-reduce as its
+    collective: `world` ranks in one process, the batch sharded by position, each rank's whole run enqueued on its own stream.
+    Replicas bitwise identical (rank-order sums + noise once from the same key), trajectory = the single-device
+    update-by-update run to fp32 rounding: same keys, same losses, gradients (Adam's m) to 2e-4."""
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    from d3p_amd.models import Adam, Trace_ELBO, VAEGuide, VAEModel
+    from d3p_amd.svi import DPSVI
+    N, steps = 60000, 3
+    hidden = (H, H2) if H2 else H
+    model = VAEModel(z_dim=Z, hidden_dim=hidden, scale=1.0 / N)
+
+    def make():
+        return DPSVI(model, VAEGuide(model), Adam(1e-2), Trace_ELBO(), 3.0, 0.8, num_obs_total=N)
+    X = torch.tensor((np.random.default_rng(37).random((B, D)) < 0.4).astype(np.float32)).cuda()
+    st0 = make().init(rng.PRNGKey(87), X)
+    svi, ref, ref_losses = make(), st0, []
+    for _ in range(steps):
+        ref, l = svi.update(ref, X)
+        ref_losses.append(float(l))
+    P = int(st0.optim_state[1].numel())
+    comms = ddist.FMeshComm.local_group(world, P + 2)
+    streams = ddist.concurrent_streams(world)
+    try:
+        engines = [ddist.VaeHipEngine(make()) for _ in range(world)]
+        outs = []
+        torch.cuda.synchronize()
+        for r in range(world):
+            pos0, b_local = ddist.shard_batch(B, r, world)
+            with torch.cuda.stream(streams[r]):
+                outs.append(ddist.vae_run_steps(engines[r], st0, X[pos0:pos0 + b_local], B, pos0, steps, comm=comms[r]))
+        torch.cuda.synchronize()
+        for r in range(world):
+            assert not comms[r].stopped(), f"rank {r}: a bounded wait of the all-reduce ran out"
+    finally:
+        for c in comms:
+            c.close()
+    s0, l0 = outs[0]
+    for s2, l2 in outs[1:]:
+        assert torch.equal(s2.rng_key, s0.rng_key) and torch.equal(l2, l0)
+        for a, b in zip(s2.optim_state, s0.optim_state):
+            assert torch.equal(a, b)
+    assert torch.equal(s0.rng_key, ref.rng_key) and int(s0.optim_state[0]) == steps
+    np.testing.assert_allclose(l0.cpu().numpy(), np.asarray(ref_losses, np.float32), rtol=2e-5)
+    mr = ref.optim_state[2].cpu().numpy()
+    np.testing.assert_allclose(s0.optim_state[2].cpu().numpy(), mr, rtol=2e-4, atol=2e-5 * np.abs(mr).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.coresident
+def test_fmesh_two_processes_over_hipipc(gpu):
+    """The real thing -- one PROCESS per rank, inboxes mapped through hipIpc handles, system-scope tagged words across the
+    process boundary (tools/fmesh_two_rank_check.py): the bare collective on 10 007 and 688 886 floats over five epochs, then
+    three data-parallel VAE steps on the mesh against the single-process run.  On a one-GPU box both ranks share cuda:0: the two
+    launches (256 small workgroups each) must be co-resident; a run that a bounded wait stopped there is a property of the box."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fmesh_two_rank_check.py")], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and torch.cuda.device_count() < 2 and "stopped --" in r.stderr:
+        pytest.xfail("the two ranks' launches were not co-resident on the shared GPU: " + r.stderr[-300:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '"fmesh_two_rank_check": "ok"' in r.stdout, r.stdout[-2000:]
+
+
 @pytest.mark.gpu
 @pytest.mark.coresident
 @pytest.mark.parametrize("form", ["in_launch", "per_step"])
