@@ -344,8 +344,8 @@ def vae_dist_workload(dev, world, rank, group_barrier, share_gpu=False, emulate=
                 if not int(flag[0]) and mesh is not None:
                     mesh.close()
                     mesh = None
-                if mesh is not None:
-                    drivers.append(("native_full_mesh", {"comm": mesh}))
+                if mesh is not None:   # (fused: tile sums + collective + update in one launch; _3_launches: kept apart)
+                    drivers += [("native_full_mesh", {"comm": mesh}), ("native_full_mesh_3_launches", {"comm": mesh, "buckets": 1})]
             # ---- correctness first: 3 steps per driver from the same state
             check, ref = {}, None
             for name, kw in drivers:

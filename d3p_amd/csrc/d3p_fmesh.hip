@@ -22,48 +22,11 @@
 // of its own.  Ranks that SHARE a GPU (tests, rehearsals) must leave room for each other's kernels -- a compute kernel whose workgroup
 // takes a CU's whole register file can never start on a GPU whose every CU holds a waiting workgroup of this launch:
 // d3p_fmesh_set_grid (d3p_fmesh_connect_local sets 48).
-#include "d3p_device.h"
-#include "d3p_host.h"
+#include "d3p_fmesh.h"
 
 #include <new>
 
 namespace d3p {
-
-#define D3P_FMESH_MAX_WORLD 16
-#define D3P_FMESH_WGS 512   // two per CU (no LDS, 4 waves each): 131 072 threads, 5 elements of a 2.76 MB vector per thread (one rank, no peers:
-                            // 12.7 us with 512 workgroups, 20.5 with 256, 37.5 with 128 -- the passes are latency, so more threads)
-#define D3P_FMESH_WAIT_ROUNDS (1u << 24)   // polls of one word (~ 0.7 us each)
-
-struct FMesh {
-    int world, rank;
-    uint64_t n;        // floats of the vector
-    uint64_t chunk;    // ceil(n / world)
-    unsigned long long epoch;
-    int wgs;           // workgroups of a launch (d3p_fmesh_set_grid)
-    char* inbox;       // [scatter: 2 x world x chunk words | gather: 2 x world x chunk words | status: 16 words]
-    size_t inbox_bytes;
-    char* peer[D3P_FMESH_MAX_WORLD];
-    bool opened[D3P_FMESH_MAX_WORLD];
-};
-
-static size_t fmesh_region_words(int world, uint64_t chunk) { return (size_t)2 * world * chunk; }
-
-struct FMeshArgs {
-    float* buf;
-    uint64_t n, chunk;
-    int world, rank;
-    unsigned parity;
-    uint32_t tag;
-    char* peer[D3P_FMESH_MAX_WORLD];
-    size_t gather_off;      // bytes from the inbox's start to its gather region
-    uint32_t* status;       // this rank's status word (in its own inbox)
-};
-
-__device__ __forceinline__ void fm_store(char* base, size_t word, float v, uint32_t tag)
-{
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(base) + word, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 // bounded wait for word `word` of the own inbox to carry `tag`; false: the bound ran out or the collective was stopped
 [[maybe_unused]] __device__ __forceinline__ bool fm_wait(const char* base, size_t word, uint32_t tag, uint32_t* status, float* out)
@@ -175,18 +138,7 @@ int fmesh_enqueue_allreduce(hipStream_t s, void* fmesh, float* buf, uint64_t n)
     D3P_REQUIRE(n == x->n, "d3p_fmesh_allreduce: the mesh was created for another vector length");
     for (int p = 0; p < x->world; ++p) D3P_REQUIRE(x->peer[p], "d3p_fmesh_allreduce: the peers' inboxes are not mapped (d3p_fmesh_connect)");
     FMeshArgs a;
-    memset(&a, 0, sizeof(a));
-    a.buf = buf;
-    a.n = x->n;
-    a.chunk = x->chunk;
-    a.world = x->world;
-    a.rank = x->rank;
-    const unsigned long long epoch = ++x->epoch;
-    a.parity = (unsigned)(epoch & 1ull);
-    a.tag = (uint32_t)epoch;
-    for (int p = 0; p < x->world; ++p) a.peer[p] = x->peer[p];
-    a.gather_off = fmesh_region_words(x->world, x->chunk) * sizeof(unsigned long long);
-    a.status = reinterpret_cast<uint32_t*>(x->inbox + 2 * a.gather_off);
+    fmesh_next_args(x, buf, &a);
     hipLaunchKernelGGL(k_fmesh_allreduce, dim3((unsigned)x->wgs), dim3(256), 0, s, a);
     return check_launch("k_fmesh_allreduce");
 }

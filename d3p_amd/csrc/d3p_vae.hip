@@ -12,6 +12,7 @@
 #include <type_traits>
 #include "d3p_device.h"
 #include "d3p_host.h"
+#include "d3p_fmesh.h"
 #include <mutex>
 #include <unordered_map>
 #include "d3p_logreg_kernel.h"  // px_sample_key
@@ -1619,6 +1620,22 @@ struct VaeFinalArgs {
     uint32_t B_local;       // B_local examples, instead of from sums[P] (NormArgs)
 };
 
+// one parameter column of the update: mean + noise (svi.py:343-346, :365-375), rescale, numpyro Adam (svi.py:379-393)
+__device__ __forceinline__ void vae_finalize_col(const VaeFinalArgs& a, size_t col, float tot, float n, float factor, float bc0, float bc1)
+{
+    const float Bf = (float)a.B;
+    const float g = (tot / Bf + a.noise[col] * (a.h.dp_scale * (a.h.clip / n))) * a.obs_scale * factor;
+    if (a.grad_out) a.grad_out[col] = g;
+    float m = a.in_m[col], v = a.in_v[col];
+    m = (1.0f - a.h.b1) * g + a.h.b1 * m;
+    v = (1.0f - a.h.b2) * g * g + a.h.b2 * v;
+    const float mhat = m / bc0;
+    const float vhat = v / bc1;
+    a.params[col] = a.in_params[col] - a.h.lr * mhat / (sqrtf(vhat) + a.h.adam_eps);
+    a.adam_m[col] = m;
+    a.adam_v[col] = v;
+}
+
 __global__ void __launch_bounds__(256) k_vae_finalize(VaeFinalArgs a)
 {
     __shared__ float bc[2];  // Adam's bias corrections 1 - b^(i + 1): two powf per workgroup instead of per column
@@ -1633,17 +1650,121 @@ __global__ void __launch_bounds__(256) k_vae_finalize(VaeFinalArgs a)
         if (threadIdx.x == 0) *a.loss_out = (ls / Bf) * a.obs_scale * factor;
     }
     if (col >= a.P) return;
-    const float tot = vae_tile_sum(a.tiles, col, a.sums[col]);
-    const float g = (tot / Bf + a.noise[col] * (a.h.dp_scale * (a.h.clip / n))) * a.obs_scale * factor;
-    if (a.grad_out) a.grad_out[col] = g;
-    float m = a.in_m[col], v = a.in_v[col];
-    m = (1.0f - a.h.b1) * g + a.h.b1 * m;
-    v = (1.0f - a.h.b2) * g * g + a.h.b2 * v;
-    const float mhat = m / bc[0];
-    const float vhat = v / bc[1];
-    a.params[col] = a.in_params[col] - a.h.lr * mhat / (sqrtf(vhat) + a.h.adam_eps);
-    a.adam_m[col] = m;
-    a.adam_v[col] = v;
+    vae_finalize_col(a, col, vae_tile_sum(a.tiles, col, a.sums[col]), n, factor, bc[0], bc[1]);
+}
+
+// The data-parallel step's tile sums, full-mesh all-reduce (d3p_fmesh.hip: reduce-scatter, rank-order owner sums, all-gather as tagged
+// 8-byte words through the peers' hipIpc-mapped inboxes) and update in ONE launch: the scatter phase takes a column's value straight
+// from the split-K partial tiles (k_vae_tile_sums' work), the gather phase applies noise + Adam to a column the moment its sum over the
+// ranks has arrived (k_vae_finalize's work) -- two launches and two passes over the 2.76 MB of sums less per step.  The owner stores
+// its chunk's sums into its OWN gather slots too, so that every column (and the global example count every column's update needs) is
+// read the same way.  Same arithmetic, column by column, as tile sums -> d3p_fmesh_allreduce -> k_vae_finalize: bit for bit.
+__global__ void __launch_bounds__(256) k_vae_fmesh_step(FMeshArgs m, VaeFinalArgs f)
+{
+    constexpr int U = 4;
+    __shared__ float bc[2];
+    if (threadIdx.x < 2) bc[threadIdx.x] = 1.0f - powf(threadIdx.x ? f.h.b2 : f.h.b1, (float)(*f.step + 1));
+    __syncthreads();
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)gridDim.x * blockDim.x;
+    char* const mine = m.peer[m.rank];
+    const size_t sc_par = (size_t)m.parity * m.world * m.chunk;
+    auto local = [&](uint64_t i) { return i < (uint64_t)f.P ? vae_tile_sum(f.tiles, (size_t)i, f.sums[i]) : f.sums[i]; };   // [P]: loss sum, [P + 1]: count
+    // ---- reduce-scatter
+    for (uint64_t i0 = tid; i0 < m.n; i0 += U * nthreads) {
+        float v[U];
+        int o[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * nthreads;
+            o[u] = i < m.n ? (int)(i / m.chunk) : m.rank;
+            v[u] = o[u] != m.rank ? local(i) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * nthreads;
+            if (o[u] != m.rank) fm_store(m.peer[o[u]], sc_par + (size_t)m.rank * m.chunk + (i - (uint64_t)o[u] * m.chunk), v[u], m.tag);
+        }
+    }
+    // ---- owner sums of my chunk in rank order; the sums go to EVERY rank's gather slot [parity][my rank], mine included
+    const uint64_t lo = (uint64_t)m.rank * m.chunk, hi = lo + m.chunk < m.n ? lo + m.chunk : m.n;
+    bool ok = true;
+    for (uint64_t i = lo + tid; i < hi && ok; i += nthreads) {
+        const uint64_t j = i - lo;
+        const float own = local(i);
+        unsigned long long w[D3P_FMESH_MAX_WORLD];
+        bool all = m.world == 1;
+        for (uint32_t spins = 0; spins < D3P_FMESH_WAIT_ROUNDS && !all; ++spins) {
+#pragma unroll
+            for (int r = 0; r < D3P_FMESH_MAX_WORLD; ++r)
+                if (r < m.world && r != m.rank)
+                    w[r] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(mine) + sc_par + (size_t)r * m.chunk + j, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_SYSTEM);
+            all = true;
+#pragma unroll
+            for (int r = 0; r < D3P_FMESH_MAX_WORLD; ++r)
+                if (r < m.world && r != m.rank) all = all && (uint32_t)(w[r] >> 32) == m.tag;
+            if (!all && (spins & 255u) == 255u && __hip_atomic_load(m.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        }
+        if (!all) { ok = false; break; }
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < D3P_FMESH_MAX_WORLD; ++r)
+            if (r < m.world) {
+                const float v = r == m.rank ? own : __uint_as_float((uint32_t)w[r]);
+                s = r == 0 ? v : s + v;
+            }
+        for (int p = 0; p < m.world; ++p) fm_store(m.peer[p] + m.gather_off, sc_par + (size_t)m.rank * m.chunk + j, s, m.tag);
+    }
+    // ---- gather + update: the example count first (every column's update needs it), then U columns' sums requested together
+    const unsigned long long* const gin = reinterpret_cast<const unsigned long long*>(mine + m.gather_off) + sc_par;
+    auto gword = [&](uint64_t i) { const uint64_t o = i / m.chunk; return (size_t)o * m.chunk + (size_t)(i - o * m.chunk); };
+    float n = 0.f;
+    {
+        const size_t wn = gword((uint64_t)f.P + 1u);
+        bool have = false;
+        for (uint32_t spins = 0; spins < D3P_FMESH_WAIT_ROUNDS && ok; ++spins) {
+            const unsigned long long w = __hip_atomic_load(gin + wn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((uint32_t)(w >> 32) == m.tag) { n = __uint_as_float((uint32_t)w); have = true; break; }
+            if ((spins & 255u) == 255u && __hip_atomic_load(m.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        }
+        ok = ok && have;
+    }
+    const float Bf = (float)f.B, factor = (n == 0.f) ? 0.f : Bf / n;
+    for (uint64_t i0 = tid; i0 < m.n && ok; i0 += U * nthreads) {
+        size_t word[U];
+        bool need[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * nthreads;
+            need[u] = i <= (uint64_t)f.P;   // the P columns and the loss sum
+            word[u] = need[u] ? gword(i) : 0;
+        }
+        unsigned long long w[U];
+        bool all = false;
+        for (uint32_t spins = 0; spins < D3P_FMESH_WAIT_ROUNDS && !all; ++spins) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (need[u]) w[u] = __hip_atomic_load(gin + word[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            all = true;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (need[u]) all = all && (uint32_t)(w[u] >> 32) == m.tag;
+            if (!all && (spins & 255u) == 255u && __hip_atomic_load(m.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        }
+        if (!all) { ok = false; break; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!need[u]) continue;
+            const uint64_t i = i0 + (uint64_t)u * nthreads;
+            const float s = __uint_as_float((uint32_t)w[u]);
+            if (i < (uint64_t)f.P) vae_finalize_col(f, (size_t)i, s, n, factor, bc[0], bc[1]);
+            else if (f.loss_out) *f.loss_out = (s / Bf) * f.obs_scale * factor;
+        }
+    }
+    if (!ok) {
+        uint32_t expect = 0u;
+        (void)__hip_atomic_compare_exchange_strong(m.status, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // rows of the five delta arrays scaled by the clip factors in one launch
@@ -2412,6 +2533,35 @@ int d3p_dpvi_vae_apply(void* stream, const d3p_vae_model* model, const d3p_dpsvi
                           workspace_bytes, true);
 }
 
+// the arguments of the update of one step (k_vae_finalize, k_vae_fmesh_step)
+static VaeFinalArgs vae_final_args(const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state, const VaeWorkspace& ws,
+                                   const float* sums_dev, uint32_t B_total, uint32_t B_local, float* loss_dev, float* grad_out_dev, const int* w_splits,
+                                   const d3p_dpsvi_state* from, bool loss_pending)
+{
+    const VaeNet N = vae_net(model);
+    VaeFinalArgs f;
+    memset(&f, 0, sizeof(f));
+    f.sums = sums_dev;
+    f.tiles = vae_tiles(N, ws, w_splits);
+    f.noise = ws.noise;
+    f.in_params = from ? from->params : state->params;
+    f.in_m = from ? from->adam_m : state->adam_m;
+    f.in_v = from ? from->adam_v : state->adam_v;
+    f.params = state->params;
+    f.adam_m = state->adam_m;
+    f.adam_v = state->adam_v;
+    f.step = reinterpret_cast<const int32_t*>(ws.keys + D3P_VAE_KEY_STEP);  // the step index k_vae_keys saved before advancing it
+    f.loss_out = loss_dev;
+    f.grad_out = grad_out_dev;
+    f.P = N.P;
+    f.B = B_total;
+    f.h = *hyper;
+    f.obs_scale = 1.0f / model->inv_obs;
+    f.px_loss = loss_pending ? ws.px_loss : nullptr;
+    f.B_local = B_local;
+    return f;
+}
+
 // derive_keys = false: the keys of this update are already in the workspace (left there by d3p_dpvi_vae_local_sums on the same
 // workspace and state, as in the single-device update)
 static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper, const d3p_dpsvi_state* state,
@@ -2433,26 +2583,7 @@ static int vae_apply_impl(void* stream, const d3p_vae_model* model, const d3p_dp
         const SiteNoiseArgs na = vae_site_noise_args(N, ws);
         hipLaunchKernelGGL(k_vae_site_noise, dim3(cdiv(na.blk_off[D3P_VAE_MAX_LEAVES], 256)), dim3(256), 0, s, na);
     }
-    VaeFinalArgs f;
-    memset(&f, 0, sizeof(f));
-    f.sums = sums_dev;
-    f.tiles = vae_tiles(N, ws, w_splits);
-    f.noise = ws.noise;
-    f.in_params = from ? from->params : state->params;
-    f.in_m = from ? from->adam_m : state->adam_m;
-    f.in_v = from ? from->adam_v : state->adam_v;
-    f.params = state->params;
-    f.adam_m = state->adam_m;
-    f.adam_v = state->adam_v;
-    f.step = reinterpret_cast<const int32_t*>(ws.keys + D3P_VAE_KEY_STEP);  // the step index k_vae_keys saved before advancing it
-    f.loss_out = loss_dev;
-    f.grad_out = grad_out_dev;
-    f.P = N.P;
-    f.B = B_total;
-    f.h = *hyper;
-    f.obs_scale = 1.0f / model->inv_obs;
-    f.px_loss = loss_pending ? ws.px_loss : nullptr;
-    f.B_local = B_local;
+    const VaeFinalArgs f = vae_final_args(model, hyper, state, ws, sums_dev, B_total, B_local, loss_dev, grad_out_dev, w_splits, from, loss_pending);
     hipLaunchKernelGGL(k_vae_finalize, dim3(cdiv(N.P, 256)), dim3(256), 0, s, f);
     return check_launch("d3p_dpvi_vae_apply");
 }
@@ -2622,15 +2753,38 @@ int d3p_dpvi_vae_run_dist(void* stream, void* comm, void* fmesh, const d3p_vae_m
     // (the library's choice is ONE bucket: on one GPU the two-bucket form costs 40 us per step more -- two event hand-overs between the
     // streams, one more grouped launch and tile-sum launch -- than the 30 us of products it can put beside a reduce;
     // profiles/r05_vae_dp_loop_rank_local.jsonl.  bench.py --gpus N times both over real links.)
-    if (buckets == 0) buckets = (env_buckets == 1 || env_buckets == 2) ? env_buckets : 1;
+    if (buckets == 0 && !fmesh) buckets = (env_buckets == 1 || env_buckets == 2) ? env_buckets : 1;
     VaeDistStep step = {s, nullptr, comm, ws.sums, N.enc[0].W, (size_t)N.P + 2};
     const bool two = comm && buckets == 2 && step.split > 0 && step.split < (size_t)N.P;
     if (two)
         if (int rc = vae_dist_side(&step.side)) return rc;
     const VaeBuckets bk = {step.split, vae_dist_bucket_ready, &step};
     d3p_dpsvi_state st = *state;
+    // full mesh: the tile sums, the collective and the update as ONE launch (k_vae_fmesh_step); D3P_VAE_FMESH_UNFUSED=1 keeps them apart
+    static const bool fm_unfused = getenv("D3P_VAE_FMESH_UNFUSED") != nullptr;   // developer switch (A/B), read once
     for (uint32_t t = 0; t < num_steps; ++t) {
         int rc;
+        if (fmesh && !fm_unfused && buckets != 1) {   // (buckets = 1 with a mesh: tile sums, collective and update as three launches)
+            FMesh* x = (FMesh*)fmesh;
+            D3P_REQUIRE(x->n == (uint64_t)N.P + 2, "d3p_dpvi_vae_run_dist: the mesh was created for another vector length (P + 2)");
+            for (int p = 0; p < x->world; ++p) D3P_REQUIRE(x->peer[p], "d3p_dpvi_vae_run_dist: the peers' inboxes are not mapped (d3p_fmesh_connect)");
+            int w_splits[D3P_VAE_MAX_BLOCKS];
+            bool loss_pending = false;
+            // (the single-device update's local phase: the split-K partial tiles stay where they are, the noise is drawn beside the latent kernel)
+            if ((rc = vae_local_sums_impl(stream, model, hyper, &st, X_local_dev, mask_dev, B_local, B_total, pos0, nullptr, ws.sums, workspace_dev,
+                                          workspace_bytes, true, w_splits, nullptr, nullptr, &loss_pending)))
+                return rc;
+            if (loss_pending)   // (the loss sum is still per example -- the output layer's epilogue without the grouped launch: one more launch sums it)
+                hipLaunchKernelGGL(k_vae_loss_n, dim3(1), dim3(256), 0, s, (const float*)ws.px_loss, mask_dev, B_local, ws.sums + N.P);
+            const VaeFinalArgs f = vae_final_args(model, hyper, &st, ws, ws.sums, B_total, B_local, losses_dev ? losses_dev + t : nullptr, nullptr, w_splits,
+                                                  nullptr, false);
+            FMeshArgs ma;
+            fmesh_next_args(x, ws.sums, &ma);
+            hipLaunchKernelGGL(k_vae_fmesh_step, dim3((unsigned)x->wgs), dim3(256), 0, s, ma, f);
+            if ((rc = check_launch("k_vae_fmesh_step"))) return rc;
+            st.key_slot ^= 1;
+            continue;
+        }
         if ((rc = vae_local_sums_impl(stream, model, hyper, &st, X_local_dev, mask_dev, B_local, B_total, pos0, nullptr, ws.sums, workspace_dev,
                                       workspace_bytes, true, nullptr, nullptr, nullptr, nullptr, true, two ? &bk : nullptr)))
             return rc;

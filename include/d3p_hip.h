@@ -634,8 +634,10 @@ int d3p_dpvi_vae_apply(void* stream, const d3p_vae_model* model, const d3p_dpsvi
  * are derived once, the Gaussian-mechanism noise is drawn beside the latent kernel and apply is one launch behind the reduce.
  * buckets = 2: the sums travel in two buckets on a second stream, the decoder's leaves while the encoder's weight-gradient products
  * still run (every clipped sum needs the whole backward pass first: only the tail of the step can overlap a reduce); 1: one
- * all-reduce on `stream`; 0: the library's choice.  fmesh (d3p_fmesh_*, below) instead of comm: the full-mesh collective, one
- * launch in the stream.  losses_dev: num_steps floats or NULL. */
+ * all-reduce on `stream`; 0: the library's choice.  fmesh (d3p_fmesh_*, below) instead of comm: the full-mesh collective -- by
+ * default FUSED with the tile sums in front of it and the update behind it into one launch (k_vae_fmesh_step: the scatter phase reads
+ * the split-K partial tiles, the gather phase applies noise + Adam to a column the moment its sum has arrived); buckets = 1 keeps the
+ * three launches apart (same results bit for bit).  losses_dev: num_steps floats or NULL. */
 int d3p_dpvi_vae_run_dist(void* stream, void* comm, void* fmesh, const d3p_vae_model* model, const d3p_dpsvi_hyper* hyper,
                           const d3p_dpsvi_state* state, const float* X_local_dev, const uint8_t* mask_dev, uint32_t B_local,
                           uint32_t B_total, uint32_t pos0, uint32_t num_steps, float* losses_dev, int32_t buckets,

@@ -940,16 +940,26 @@ def test_vae_native_loop_over_the_full_mesh_with_virtual_ranks(gpu, B, D, H, Z, 
     comms = ddist.FMeshComm.local_group(world, P + 2)
     streams = ddist.concurrent_streams(world)
     try:
-        engines = [ddist.VaeHipEngine(make()) for _ in range(world)]
-        outs = []
-        torch.cuda.synchronize()
-        for r in range(world):
-            pos0, b_local = ddist.shard_batch(B, r, world)
-            with torch.cuda.stream(streams[r]):
-                outs.append(ddist.vae_run_steps(engines[r], st0, X[pos0:pos0 + b_local], B, pos0, steps, comm=comms[r]))
-        torch.cuda.synchronize()
-        for r in range(world):
-            assert not comms[r].stopped(), f"rank {r}: a bounded wait of the all-reduce ran out"
+        runs = {}
+        for form, buckets in (("fused", 0), ("three launches", 1)):
+            # fused (default): tile sums + collective + update as ONE launch per step; buckets = 1: k_vae_tile_sums -> k_fmesh_allreduce ->
+            # k_vae_finalize.  Same arithmetic column by column: bit for bit the same run.
+            engines = [ddist.VaeHipEngine(make()) for _ in range(world)]
+            outs = []
+            torch.cuda.synchronize()
+            for r in range(world):
+                pos0, b_local = ddist.shard_batch(B, r, world)
+                with torch.cuda.stream(streams[r]):
+                    outs.append(ddist.vae_run_steps(engines[r], st0, X[pos0:pos0 + b_local], B, pos0, steps, comm=comms[r], buckets=buckets))
+            torch.cuda.synchronize()
+            for r in range(world):
+                assert not comms[r].stopped(), f"{form}, rank {r}: a bounded wait of the all-reduce ran out"
+            runs[form] = outs
+        for (sa, la), (sb, lb) in zip(runs["fused"], runs["three launches"]):
+            assert torch.equal(la, lb) and torch.equal(sa.rng_key, sb.rng_key)
+            for a, b in zip(sa.optim_state, sb.optim_state):
+                assert torch.equal(a, b)
+        outs = runs["fused"]
     finally:
         for c in comms:
             c.close()

@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import d3p_amd.random as rng  # noqa: E402
-from d3p_amd.dist import NativeComm, VaeHipEngine, vae_run_steps  # noqa: E402
+from d3p_amd.dist import FMeshComm, NativeComm, VaeHipEngine, vae_run_steps  # noqa: E402
 from d3p_amd.models import Adam, Trace_ELBO, VAEGuide, VAEModel  # noqa: E402
 from d3p_amd.svi import DPSVI  # noqa: E402
 
@@ -28,8 +28,10 @@ def main():
             st = svi.init(rng.PRNGKey(0), X)
             Bg = B_local * world
             rec = {"hidden": [H] + ([H2] if H2 else []), "B_local": B_local, "B_total": Bg}
+            mesh = FMeshComm(int(st.optim_state[1].numel()) + 2)      # (one rank: no peers -- the launch-side cost of the full-mesh forms)
             for name, kw in (("python_loop", {}), ("native_no_collective", {"comm": "local"}), ("native_rccl_1_bucket", {"comm": comm, "buckets": 1}),
-                             ("native_rccl_2_buckets", {"comm": comm, "buckets": 2})):
+                             ("native_rccl_2_buckets", {"comm": comm, "buckets": 2}), ("native_full_mesh_fused", {"comm": mesh}),
+                             ("native_full_mesh_3_launches", {"comm": mesh, "buckets": 1})):
                 eng = VaeHipEngine(svi)
                 if name == "native_no_collective":   # (the call asks for a communicator when the rank holds a share: time it as a whole batch)
                     run = lambda k, c=False: vae_run_steps(eng, st, X, B_local, 0, k, collect_losses=c, **kw)  # noqa: E731
@@ -45,6 +47,7 @@ def main():
                     torch.cuda.synchronize()
                     best = min(best, (time.perf_counter() - t0) / 100)
                 rec[name + "_us_per_step"] = round(best * 1e6, 2)
+            mesh.close()
             out.append(rec)
             print(json.dumps(rec), flush=True)
     comm.close()
