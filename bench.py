@@ -228,7 +228,7 @@ def aux_workloads(dev, table7=None, want=("gmm", "vae", "vae2", "poisson")):
         Pn = int(st[0].optim_state[1].numel())
         out["vae_config5" + ("_400_200" if H2 else "")] = {
             "workload": "BASELINE configs[4]: VAE 784 -> %s -> 50 (P = %d), batch 4096, C=10, sigma=1, Adam 1e-3; one DPSVI.update "
-                        "(13 launches with one hidden layer) per step" % (hs, Pn),
+                        "per step%s" % (hs, Pn, "" if H2 else " (13 launches)"),
             "steps": steps, "warmup": 48, "steps_per_sec": round(steps / wall, 2), "value": round(B * steps / wall, 1),
             "unit": "examples/s", "us_per_step": round(1e6 * ev / steps, 2), "final_loss": float(run.loss),
             "us_per_step_blocks": [round(1e6 * b[1] / steps, 2) for b in blocks],
