@@ -11,7 +11,7 @@ processes itself -- fresh interpreters, before anything in the parent has touche
 A step = one DPSVI.update on one freshly sampled minibatch: key schedule -> Feistel subsampling
 -> fused per-example gradient / clip / sum -> Gaussian mechanism (ChaCha20) -> Adam.  Inputs
 (the synthetic table) are resident in HBM before the timed region.  Prints ONE JSON line:
-`value` is tied to --steps; `steady_state` (a fixed 4096-step leg) and `north_star_N1e7` (the same workload over a
+`value` is tied to --steps; `steady_state` (a fixed leg: the median of 5 x 1024 steps) and `north_star_N1e7` (the same workload over a
 10^7-row table) are measured in the same run whatever --steps is.  Order of the legs: steady_state first, then the
 headline leg (its own --warmup steps + exactly --steps timed steps, bracketed by barriers), then the others -- a short
 headline run as the very first GPU work of the process would be measured at the GPU's idle clocks (`leg_order` in the line).
@@ -44,6 +44,41 @@ VALU_PEAK_GINSTR = SIMDS * SHADER_GHZ / 2.0
 def algorithmic_bytes(B, d, P):
     """gathered feature rows + labels + indices, params read, gradient written+read."""
     return B * (4 * d + 4 + 4) + 3 * 4 * P
+
+
+VALU_MIX_CYCLES = 3.302        # profiles/r02_valu_probe.json: the step's noise mix (threefry2x32-20 + erf_inv, 460 executed instructions per
+                               # example) issues one wave64 VALU instruction per 3.30 cycles and SIMD at 4 waves per SIMD (16-wave workgroups)
+
+
+def copy_peak(dev, gib=2, repeats=5):
+    """the device-to-device copy rate of THIS box -- d3p_hbm_copy (16 B per lane, four loads in flight per thread) over
+    `gib` GiB, `repeats` timed copies between HIP events on the launch stream; bytes moved = read + written = 2 x size."""
+    import torch
+    import d3p_amd._lib as L
+    lib = L.load()
+    n = int(gib) << 30
+    src = torch.empty(n, dtype=torch.uint8, device=dev)
+    dst = torch.empty(n, dtype=torch.uint8, device=dev)
+    src.fill_(1)
+    for _ in range(2):
+        L.check(lib.d3p_hbm_copy(L.stream_ptr(), L.ptr(dst), L.ptr(src), n, 16))
+    torch.cuda.synchronize()
+    rates = []
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.d3p_hbm_copy(L.stream_ptr(), L.ptr(dst), L.ptr(src), n, 16))
+        e1.record()
+        torch.cuda.synchronize()
+        rates.append(2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    ok = bool(torch.equal(dst[:4096], src[:4096]) and int(dst[-1]) == 1)
+    del src, dst
+    torch.cuda.empty_cache()
+    rates.sort()
+    return {"GBps_median": round(rates[len(rates) // 2], 1), "GBps_best": round(rates[-1], 1), "GBps_all": [round(r, 1) for r in rates],
+            "bytes_copied": n, "repeats": repeats, "copied_correctly": ok,
+            "kernel": "k_hbm_copy<16 B per lane, 4 loads in flight> (d3p_hbm_copy), 4096 workgroups of 256 threads, grid-stride; rate = (read + "
+                      "written bytes) / HIP-event time"}
 
 
 def cpu_baseline(d, B, seconds, rows):
@@ -376,8 +411,11 @@ def vae_dist_workload(dev, world, rank, group_barrier, share_gpu=False, emulate=
             drivers = [(n_, k_) for n_, k_ in drivers if check[n_]["ok"]] or drivers[:1]   # (a driver that failed its check is not timed)
             # ---- timing
             warm, steps = (8, 10) if share_gpu else (48, 40)
-            timed = {}
+            timed, stopped_legs = {}, []
             for name, kw in drivers:
+                on_mesh = mesh is not None and kw.get("comm") is mesh
+                if on_mesh:   # (the status is read HERE, after the timed region, and agreed over the ranks: no rank raises alone)
+                    kw = dict(kw, check_status=False)
                 engine = ddist.VaeHipEngine(svi)
                 group_barrier()
                 st, _ = ddist.vae_run_steps(engine, st0, X, Bg, pos0, warm, collect_losses=False, **kw)
@@ -386,14 +424,25 @@ def vae_dist_workload(dev, world, rank, group_barrier, share_gpu=False, emulate=
                 st, losses = ddist.vae_run_steps(engine, st, X, Bg, pos0, steps, **kw)
                 group_barrier()
                 wall = time.perf_counter() - t0
+                halted = int(on_mesh and mesh.stopped())
                 if world > 1:
-                    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+                    t = torch.tensor([wall, float(halted)], dtype=torch.float64, device=dev)
                     if share_gpu:
                         t = t.cpu()
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    wall = float(t[0])
-                timed[name] = (wall, float(losses[-1]))
+                    wall, halted = float(t[0]), int(t[1])
                 del engine
+                if halted:    # a bounded wait of the collective ran out on some rank: the state is partly updated -- not a timing
+                    stopped_legs.append(name)
+                    print(f"[bench] rank {rank}: VAE driver {name} was stopped by a bounded wait during the timed run -- dropped", file=sys.stderr)
+                    continue
+                timed[name] = (wall, float(losses[-1]))
+            if not timed:
+                out[tag + f"_dp{world}"] = {"error": "every driver's timed run was stopped by a bounded wait", "stopped_drivers": stopped_legs,
+                                            "collective_check": check}
+                if mesh is not None:
+                    mesh.close()
+                continue
             best = min(timed, key=lambda k: timed[k][0])
             wall, final_loss = timed[best]
             hs = [H] + ([H2] if H2 else [])
@@ -410,7 +459,7 @@ def vae_dist_workload(dev, world, rank, group_barrier, share_gpu=False, emulate=
                 "value": round(B_done * steps / wall, 1), "unit": "examples/s (whole job)" if not emulate else "examples/s (this rank's share)",
                 "us_per_step": round(1e6 * wall / steps, 2), "final_loss": final_loss,
                 "us_per_step_by_driver": {k: round(1e6 * v[0] / steps, 2) for k, v in timed.items()},
-                "collective_check": check,
+                "collective_check": check, "drivers_stopped_while_timed": stopped_legs,
                 "collective": {"bytes_per_step": 4 * (Pn + 2),
                                "backend": ("none (one rank: the communicator has no peers)" if emulate else
                                            "gloo (torch_loop) / full mesh over hipIpc (native_full_mesh) -- shared-GPU rehearsal" if share_gpu else
@@ -450,7 +499,8 @@ def main():
                     help="skip the steady_state and north_star_N1e7 legs (profiling runs)")
     ap.add_argument("--no-aux-workloads", action="store_true",
                     help="skip the legs for the other BASELINE workloads (mixture model, VAE, Poisson sampler at N = 1e7)")
-    ap.add_argument("--steady-steps", type=int, default=4096)
+    ap.add_argument("--steady-steps", type=int, default=1024, help="steps per repeat of the steady_state leg (whole prepared batches of 128)")
+    ap.add_argument("--steady-repeats", type=int, default=5)
     ap.add_argument("--sampler", choices=["feistel", "poisson"], default="feistel",
                     help="feistel = subsample_batchify_data w/o replacement (headline); poisson = poisson_batchify_data "
                          "with q = B/N and the 0.99-quantile padding of examples/logistic_regression.py:126-127")
@@ -492,7 +542,11 @@ def main():
     share_gpu = bool(os.environ.get("D3P_BENCH_SHARE_GPU"))  # rehearsal: all ranks on cuda:0, gloo instead of RCCL (which refuses
     if share_gpu:                                               # two ranks on one device); the one-shot exchange works as usual,
         local_rank = 0                                          # as one launch per step: the in-launch form needs each rank's
-        os.environ.setdefault("D3P_XCHG_PER_STEP", "1")         # launch resident beside the others', which one GPU cannot give
+        # launch resident beside the others', which one GPU only gives to SMALL launches: D3P_BENCH_SHARE_GPU=inlaunch keeps the in-launch
+        # form (the production form of a real N-GPU run) for a rehearsal at a small shape, e.g. `--gpus 2 --batch-per-gpu 512 --steps 24
+        # --warmup 24 --no-extra-legs` (24 x 19 sixteen-wave workgroups per launch leave room for the other rank's launch)
+        if os.environ["D3P_BENCH_SHARE_GPU"] != "inlaunch":
+            os.environ.setdefault("D3P_XCHG_PER_STEP", "1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or (args.force_dist_loop and "RANK" in os.environ):
@@ -653,7 +707,9 @@ def main():
         if rank == 0:
             print("[bench] collective_check: " + json.dumps(collective_check), file=sys.stderr, flush=True)
     if not single:
-        dist_driver = ("native loop, one-shot full-mesh exchange (d3p_xchg)" if isinstance(comm, ddist.XchgComm) else
+        dist_driver = ("native loop, one-shot full-mesh exchange (d3p_xchg), " +
+                       ("one exchange launch behind every step launch (D3P_XCHG_PER_STEP)" if os.environ.get("D3P_XCHG_PER_STEP") else
+                        "inside the chained launch (updater form) where the shape has k_logreg_chain") if isinstance(comm, ddist.XchgComm) else
                        "native loop, RCCL all-reduce" if comm is not None else "torch")
 
     def make_workload(n_rows_total, native=True):
@@ -737,6 +793,14 @@ def main():
                 "avg_launch_us": round(us / launches, 3), "launches": launches, "steps_per_launch": round(ksteps / launches, 3),
                 "algorithmic_bytes_per_step": alg_step}
 
+    # the copy rate of THIS box beside the vendor's 8 TB/s (rank 0; < 0.1 s, before any leg)
+    box_copy = None
+    if rank == 0 and not os.environ.get("D3P_BENCH_NO_COPY_PEAK"):
+        try:
+            box_copy = copy_peak(dev)
+        except Exception as e:  # noqa: BLE001 -- a measurement aid must not cost the line
+            print(f"[bench] copy peak not measured ({type(e).__name__}: {e})", file=sys.stderr)
+
     aux = {}   # the other BASELINE workloads (single-GPU runs): filled by measure()
     progress = {}   # rank 0: the line's fields as soon as the headline leg of a measure() call is done (the legs behind it fill in)
 
@@ -751,11 +815,23 @@ def main():
         # shows the cold figure).  Every leg does its own warm-up steps and is bracketed by barriers.
         steady = None
         if extra_legs:
-            _, _, el_s, kt_s = timed_leg(run, state0, args.warmup + args.steps, 2048, args.steady_steps)
+            # "5 repeats, report median" -- five timed blocks of --steady-steps steps back to back (2048 warm-up steps in front
+            # of the first, one prepared batch of 128 in front of the others), each bracketed like the headline leg; the MEDIAN block is
+            # the leg's figure, all five are listed
+            reps, st_s, first_s = [], state0, args.warmup + args.steps
+            for i in range(args.steady_repeats):
+                warm_s = 2048 if i == 0 else 128
+                st_s, _, el_s, kt_s = timed_leg(run, st_s, first_s, warm_s, args.steady_steps)
+                first_s += warm_s + args.steady_steps
+                reps.append((el_s, kt_s))
+            del st_s
             if rank == 0:
+                el_s, kt_s = sorted(reps, key=lambda r: r[0])[len(reps) // 2]
                 sps = args.steady_steps / el_s
-                steady = {"steps": args.steady_steps, "warmup": 2048, "steps_per_sec": round(sps, 2), "value": round(Bg * sps, 1),
-                          "ms_per_step": round(1000.0 * el_s / args.steady_steps, 6), "kernel": kernel_record(kt_s, Bg // ranks)}
+                steady = {"steps": args.steady_steps, "repeats": len(reps), "warmup": 2048, "statistic": "median of the repeats",
+                          "steps_per_sec": round(sps, 2), "value": round(Bg * sps, 1),
+                          "ms_per_step": round(1000.0 * el_s / args.steady_steps, 6), "kernel": kernel_record(kt_s, Bg // ranks),
+                          "steps_per_sec_repeats": [round(args.steady_steps / r[0], 2) for r in reps]}
         # ---------------------------------------------------------------- headline leg (value is tied to --steps)
         state, losses, elapsed, kt = timed_leg(run, state0, 0, args.warmup, args.steps)
         steps_per_s = args.steps / elapsed
@@ -781,8 +857,10 @@ def main():
                                    "profiled_steps": rec.get("steps"), "hbm_bytes_per_step": per_step,
                                    "ratio_to_algorithmic": (round(per_step / krec["algorithmic_bytes_per_step"], 3)
                                                             if per_step is not None else None),
+                                   "split": rec.get("split"),
                                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at the named commit "
-                                           "(FETCH doubled per the gfx950 correction); not re-measured in this run"}
+                                           "(FETCH doubled per the gfx950 correction -- an UPPER bound: `split` says which part the correction "
+                                           "is calibrated for); not re-measured in this run"}
                 except Exception:  # noqa: BLE001
                     traffic, traffic_src = None, None
             if chained:
@@ -799,9 +877,33 @@ def main():
                 kname = "k_logreg_main<MODE 2> (one launch per DP-VI step) + the step's collective (k_xchg or ncclAllReduce) on the same stream"
             else:
                 kname = "k_logreg_main<MODE 2> (one launch per DP-VI step; torch.distributed.all_reduce between the launches)"
+            # ---- the kernel's OTHER bound, from counters: wave64 VALU instructions per step (SQ_INSTS_VALU of the step kernel, a
+            # rocprofv3 --pmc pass of this command kept under profiles/) over this run's kernel time per step
+            valu = None
+            vfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_logreg_valu_pmc.json")))
+            if chained and vfiles:
+                try:
+                    vrec = json.load(open(vfiles[-1]))
+                    ips = float(vrec["valu_instructions_per_step"])
+                    rate = ips / (krec["kernel_us_per_step"] * 1e-6) / 1e9      # G wave64 instructions / s, chip-wide
+                    valu = {"instructions_per_step": ips, "achieved_Ginstr_per_s": round(rate, 1),
+                            "peak_nominal_Ginstr_per_s": VALU_PEAK_GINSTR, "frac_of_nominal_issue": round(rate / VALU_PEAK_GINSTR, 4),
+                            "measured_mix_cycles_per_instruction_and_simd": VALU_MIX_CYCLES,
+                            "frac_of_measured_mix_rate": round(rate / (SIMDS * SHADER_GHZ / VALU_MIX_CYCLES), 4),
+                            "valu_floor_us_per_step_at_mix_rate": round(ips / (SIMDS * SHADER_GHZ / VALU_MIX_CYCLES) * 1e-3, 3),
+                            "active_valu_cycles_per_step": vrec.get("active_valu_cycles_per_step"),
+                            "source": {"file": "profiles/" + os.path.basename(vfiles[-1]), "commit": vrec.get("commit"),
+                                       "kernel": vrec.get("kernel"), "note": "SQ_INSTS_VALU per launch / steps per launch from a rocprofv3 --pmc "
+                                       "pass of this command; not re-counted in this run.  nominal = 2 cycles per wave64 instruction and SIMD; "
+                                       "mix rate = profiles/r02_valu_probe.json (the noise mix at 4 waves per SIMD)"}}
+                except Exception:  # noqa: BLE001
+                    valu = None
             roofline = {"bound": "hbm",
                         "kernel": kname,
                         "achieved": krec["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": krec["frac"],
+                        "peak_measured_copy": box_copy["GBps_median"] if box_copy else None,
+                        "frac_of_measured_copy": round(krec["achieved"] / box_copy["GBps_median"], 4) if box_copy else None,
+                        "measured_copy": box_copy, "valu": valu,
                         "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": round(krec["algorithmic_bytes_per_step"] * krec["steps_per_launch"], 1),
                         "algorithmic_bytes_per_step": krec["algorithmic_bytes_per_step"],
@@ -901,6 +1003,10 @@ def main():
         }
         if collective_check is not None:
             out["collective_check"] = collective_check
+            out["native_drivers"] = {"xchg_ran": bool(collective_check["xchg"].get("ran")), "xchg_ok": collective_check["xchg_ok"],
+                                     "rccl_ran": bool(collective_check["rccl"].get("ran")), "rccl_ok": collective_check["rccl_ok"],
+                                     "chosen": collective_check["driver_chosen"],
+                                     "all_dropped": collective_check["driver_chosen"] == "torch"}
         if emu:
             out["note_emulate_world"] = (f"developer run: rank 0's share of an emulated {emu}-rank weak-scaling job on ONE GPU (exchange with "
                                          "itself); `value` counts the examples this GPU processed")
@@ -909,8 +1015,21 @@ def main():
         return json.dumps(out)
 
     extra = None
+    # N > 1 with EVERY native driver dropped (the in-launch exchange and the native loop over RCCL both failed their first-contact
+    # check, or could not be created): the only loop left is the Python-driven torch.distributed one.  Its number is printed -- marked --
+    # and the process exits NON-ZERO, so that a torch-loop figure is never mistaken for the design's (D3P_BENCH_ALLOW_TORCH_ONLY=1, or
+    # one of the developer switches that ask for that loop, turns the exit code off).
+    torch_only = (world > 1 and comm is None and not os.environ.get("D3P_DIST_TWO_PHASE") and not os.environ.get("D3P_DIST_TORCH_LOOP")
+                  and not os.environ.get("D3P_BENCH_ALLOW_TORCH_ONLY"))
+    if torch_only and rank == 0:
+        print("[bench] ERROR: every native data-parallel driver was dropped (collective_check above); the line below is the Python-driven "
+              "torch.distributed loop and the exit code will be 3", file=sys.stderr, flush=True)
     if single or comm is None:
         m = measure(False, not args.no_extra_legs)
+        if torch_only and rank == 0:
+            extra = {"error": "every native data-parallel driver (d3p_xchg in-launch exchange, native loop over RCCL) was dropped by the "
+                              "first-contact check or could not be created; `value` is the Python-driven torch.distributed loop, NOT the "
+                              "design's data-parallel path; exit code 3"}
     else:
         # Data-parallel run with the native loop available.  The Python-driven loop (torch.distributed's own RCCL) is
         # measured FIRST and kept as the fallback line: should the native loop stall on some rank, a watchdog prints that
@@ -964,6 +1083,10 @@ def main():
         cpu = cpu_baseline(d, args.batch_per_gpu, args.cpu_seconds, rows=200_000)
     if rank == 0:
         emit(line(m, cpu, extra))
+    if torch_only and rank == 0:   # (rank 0 alone, and after its line: a launcher ends the other ranks when one exits non-zero)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(3)
 
 
 if __name__ == "__main__":

@@ -228,6 +228,7 @@ SIGNATURES = {
                                                    C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "d3p_selftest_wave_sums": (C.c_int, [_V, _V, _U32, _V]),
     "d3p_synth_logreg": (C.c_int, [_V, _U32, _U64, _U64, _I32, _V, _V]),
+    "d3p_hbm_copy": (C.c_int, [_V, _V, _V, _U64, _I32]),
 }
 
 _lib = None
@@ -249,7 +250,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.d3p_abi_version() != 8:
+        if lib.d3p_abi_version() != 9:
             raise D3PError("libd3p_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -315,7 +315,9 @@ __global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
             a.state_out[2][col] = __uint_as_float((uint32_t)wv);
         }
         // (cannot happen once the launches are complete: every word of the final epoch was stored by the last updater.  Reported as
-        // a stopped run rather than handed on silently.)
+        // a stopped run rather than handed on silently.  `bad` is per thread -- its own columns -- and only thread 0 reports and writes
+        // the counters: the workgroup votes first.)
+        bad = __syncthreads_or(bad) != 0;
         if (bad) status_to_host(abort_code(D3P_ABORT_RELEASE, 0xfff, 4u));
         // The run's counters: ONE writer, in the run's last kernel, from the schedule (k_run_init / the key-chain links leave the
         // counts after the run's last prepared step there).  The step launches do not store them: a word that a different workgroup

@@ -678,4 +678,43 @@ int d3p_synth_logreg(void* stream, uint32_t seed, uint64_t row0, uint64_t n_rows
     return check_launch("d3p_synth_logreg");
 }
 
+// ---- measurement aid ("also measure a device-to-device copy peak on the box and report both fractions")
+// A plain streaming copy: thread <-> W bytes per load, U loads in flight before the first store, grid-stride.  W = 16 is the
+// figure the guide quotes as the achievable HBM rate (float4 copy); W = 4 / 8 exist so that the FETCH_SIZE / WRITE_SIZE
+// counters can be calibrated per access width on a known byte count (tools/probes/fetch_calibration.py).
+extern "C++" {
+typedef unsigned int d3p_copy16 __attribute__((ext_vector_type(4)));
+template <typename T, int U>
+__global__ void __launch_bounds__(256) k_hbm_copy(T* __restrict__ dst, const T* __restrict__ src, uint64_t n)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+}  // extern "C++"
+
+int d3p_hbm_copy(void* stream, void* dst_dev, const void* src_dev, uint64_t bytes, int32_t bytes_per_lane)
+{
+    D3P_REQUIRE(dst_dev && src_dev, "d3p_hbm_copy: null pointer");
+    D3P_REQUIRE(bytes_per_lane == 4 || bytes_per_lane == 8 || bytes_per_lane == 16, "d3p_hbm_copy: bytes_per_lane must be 4, 8 or 16");
+    D3P_REQUIRE(bytes % 16 == 0 && ((uintptr_t)dst_dev % 16) == 0 && ((uintptr_t)src_dev % 16) == 0, "d3p_hbm_copy: 16-byte aligned buffers and size");
+    if (bytes == 0) return D3P_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = 256 * 8 * 2;   // 16 workgroups of 4 waves per CU: every SIMD full, the copy grid-strides
+    if (bytes_per_lane == 16)
+        hipLaunchKernelGGL((k_hbm_copy<d3p_copy16, 4>), dim3(grid), dim3(256), 0, s, (d3p_copy16*)dst_dev, (const d3p_copy16*)src_dev, bytes / 16);
+    else if (bytes_per_lane == 8)
+        hipLaunchKernelGGL((k_hbm_copy<unsigned long long, 4>), dim3(grid), dim3(256), 0, s, (unsigned long long*)dst_dev, (const unsigned long long*)src_dev, bytes / 8);
+    else
+        hipLaunchKernelGGL((k_hbm_copy<uint32_t, 4>), dim3(grid), dim3(256), 0, s, (uint32_t*)dst_dev, (const uint32_t*)src_dev, bytes / 4);
+    return check_launch("d3p_hbm_copy");
+}
+
 }  // extern "C"

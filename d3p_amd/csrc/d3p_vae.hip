@@ -15,6 +15,8 @@
 #include "d3p_fmesh.h"
 #include <mutex>
 #include <unordered_map>
+#include <map>
+#include <utility>
 #include "d3p_logreg_kernel.h"  // px_sample_key
 
 namespace d3p {
@@ -2152,6 +2154,13 @@ static int vae_enqueue_forward(hipStream_t s, const d3p_vae_model* m, const floa
 // Bucket 0 = the decoder's leaves (columns 0 .. split - 1 of the flat layout), bucket 1 = the encoder's and the latent heads' +
 // [loss sum, count]; the weight-gradient products go out as one grouped launch per bucket, each followed by the tile sums of its
 // columns and `ready(bucket)` (the caller enqueues the reduce behind an event).
+// developer switch (A/B), read once: the weight-gradient products launched one by one.  The two-bucket hand-over exists only in the
+// grouped form, so every caller that decides "two buckets" asks this predicate too (else no reduce would be enqueued at all).
+static bool vae_no_group()
+{
+    static const bool v = getenv("D3P_VAE_NO_GROUP") != nullptr;
+    return v;
+}
 struct VaeBuckets {
     size_t split;
     int (*ready)(void* ctx, int bucket);
@@ -2271,7 +2280,7 @@ static int vae_enqueue_sums(hipStream_t s, const d3p_vae_model* m, const float* 
     }
     // single-device update: the products go out as ONE grouped launch with a common K range per workgroup
     // (bk: one grouped launch per bucket)
-    static const bool no_group = getenv("D3P_VAE_NO_GROUP") != nullptr;   // developer switch (A/B), read once
+    const bool no_group = vae_no_group();
     int splits_here[D3P_VAE_MAX_BLOCKS] = {0};
     int* const tile_splits = w_splits ? w_splits : splits_here;
     bool loss_summed = false;   // (fused output layer: a group launch sums px_loss into S[P] beside its products)
@@ -2681,18 +2690,20 @@ int d3p_dpvi_vae_run(void* stream, const d3p_vae_model* model, const d3p_dpsvi_h
 
 // ---- the data-parallel epoch body as ONE call (examples/vae.py:227-246 with the batch sharded by position)
 namespace {
-struct VaeDistSide {   // per device: the stream the reduces travel on and the events that order them against the step's stream
+struct VaeDistSide {   // per (device, caller's stream): the stream the reduces travel on and the events that order them against the step's stream
     hipStream_t cs = nullptr;
     hipEvent_t ready[2] = {nullptr, nullptr}, done = nullptr;
 };
-static int vae_dist_side(VaeDistSide** out)
+static int vae_dist_side(hipStream_t caller, VaeDistSide** out)
 {
+    // keyed by the caller's stream too: in-process ranks (one stream each) and host threads must not share a side stream or re-record
+    // each other's events -- two ranks of one communicator on ONE side stream would wait for each other's reduce forever
     static std::mutex mu;
-    static std::unordered_map<int, VaeDistSide> sides;
+    static std::map<std::pair<int, hipStream_t>, VaeDistSide> sides;
     int dev = 0;
     D3P_HIP_TRY(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    VaeDistSide& v = sides[dev];
+    VaeDistSide& v = sides[std::make_pair(dev, caller)];
     if (!v.cs) {
         D3P_HIP_TRY(hipStreamCreateWithFlags(&v.cs, hipStreamNonBlocking));
         for (hipEvent_t* e : {&v.ready[0], &v.ready[1], &v.done}) D3P_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -2755,9 +2766,9 @@ int d3p_dpvi_vae_run_dist(void* stream, void* comm, void* fmesh, const d3p_vae_m
     // profiles/r05_vae_dp_loop_rank_local.jsonl.  bench.py --gpus N times both over real links.)
     if (buckets == 0 && !fmesh) buckets = (env_buckets == 1 || env_buckets == 2) ? env_buckets : 1;
     VaeDistStep step = {s, nullptr, comm, ws.sums, N.enc[0].W, (size_t)N.P + 2};
-    const bool two = comm && buckets == 2 && step.split > 0 && step.split < (size_t)N.P;
+    const bool two = comm && buckets == 2 && !vae_no_group() && step.split > 0 && step.split < (size_t)N.P;
     if (two)
-        if (int rc = vae_dist_side(&step.side)) return rc;
+        if (int rc = vae_dist_side(s, &step.side)) return rc;
     const VaeBuckets bk = {step.split, vae_dist_bucket_ready, &step};
     d3p_dpsvi_state st = *state;
     // full mesh: the tile sums, the collective and the update as ONE launch (k_vae_fmesh_step); D3P_VAE_FMESH_UNFUSED=1 keeps them apart

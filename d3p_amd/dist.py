@@ -49,17 +49,23 @@ def _runs_beside(a, b, spin_cycles=20_000_000):
 
 
 def concurrent_streams(n):
-    """`n` (<= 3) streams whose kernels run BESIDE each other's and beside the current stream's.  A HIP process has 4 hardware
+    """`n` streams whose kernels run BESIDE each other's and beside the current stream's (n <= 3 unless the process was started with
+    GPU_MAX_HW_QUEUES > 4 in its environment: then up to that many - 1).  A HIP process has 4 hardware
     queues by default (GPU_MAX_HW_QUEUES); further streams share them, and two streams that share a queue are serialised -- every
     fourth stream of torch's pool shares the default stream's (tools/probes/stream_queue_probe.py).  Ranks that live in ONE process
     on separate streams (XchgComm.local_group; d3p_xchg_simulate_peers on a side stream) wait for each other INSIDE their launches:
     on two streams of one queue the second launch never starts and the bounded waits stop the run.  Streams are probed, not
     assumed: a spin kernel on one, a small kernel on the other."""
-    if n > 3:
-        raise _lib.D3PError("concurrent_streams: a process has 4 hardware queues -- the current stream and at most 3 beside it")
+    import os
+    try:
+        queues = max(4, int(os.environ.get("GPU_MAX_HW_QUEUES", "4")))
+    except ValueError:
+        queues = 4
+    if n > queues - 1:
+        raise _lib.D3PError(f"concurrent_streams: a process has {queues} hardware queues -- the current stream and at most {queues - 1} beside it")
     _runs_beside(None, None, 1000)   # (first use of the spin kernel)
     chosen = []
-    for _ in range(64):
+    for _ in range(16 * queues):
         if len(chosen) == n:
             return chosen
         s = torch.cuda.Stream()
@@ -560,7 +566,8 @@ class VaeHipEngine:
         return new_state, self.loss[0]
 
 
-def vae_run_steps(engine, state, X_local, batch_size_total, pos0, num_steps, group=None, collect_losses=True, comm=None, buckets=0):
+def vae_run_steps(engine, state, X_local, batch_size_total, pos0, num_steps, group=None, collect_losses=True, comm=None, buckets=0,
+                  check_status=None, mask=None):
     """`num_steps` data-parallel VAE updates on the SAME resident batch shard (the epoch body of examples/vae.py:227-246 with the
     batch sharded by position): per step local sums -> ONE sum-all-reduce of the P + 2 sums -> apply (noise once, after the
     reduce, identical on every rank), the state advancing in the engine's own buffers.
@@ -569,10 +576,14 @@ def vae_run_steps(engine, state, X_local, batch_size_total, pos0, num_steps, gro
     stream; 0: the library's choice) so that the decoder's sums travel while the encoder's weight-gradient products run; a
     FMeshComm: the same call with the full-mesh reduce-scatter + all-gather of d3p_fmesh.hip as the step's collective; with
     `comm="local"` the same call without a collective (one rank).  comm=None: the Python-driven loop over `group`
-    (torch.distributed.all_reduce; any backend).  Returns (new_state, losses[num_steps] or None)."""
+    (torch.distributed.all_reduce; any backend).  Returns (new_state, losses[num_steps] or None).
+    `check_status` (default: on for a FMeshComm): after the run read the mesh's status word (a device synchronisation) and raise
+    D3PError when a bounded wait ran out -- the state is then partly updated in place and must not be used or timed.
+    `mask`: validity of the shard's examples (`update(..., mask=)`, svi.py:395; masked examples contribute nothing, the noise carries
+    B / n)."""
     import torch.distributed as dist
     from .svi import DPSVIState
-    engine.begin(state, X_local, batch_size_total, pos0)
+    engine.begin(state, X_local, batch_size_total, pos0, mask=mask)
     losses = torch.empty(int(num_steps), dtype=torch.float32, device=engine.X.device) if collect_losses else None
     if comm is not None:
         rccl = comm.handle if isinstance(comm, NativeComm) else None
@@ -580,6 +591,10 @@ def vae_run_steps(engine, state, X_local, batch_size_total, pos0, num_steps, gro
         check(_lib.load().d3p_dpvi_vae_run_dist(
             stream_ptr(), rccl, mesh, C.byref(engine.vm), C.byref(engine.hyper), C.byref(engine.st), ptr(engine.X), ptr(engine.mask),
             engine.B_local, engine.B_total, engine.pos0, int(num_steps), ptr(losses), int(buckets), ptr(engine.ws), engine.ws.numel()))
+        if mesh is not None and (check_status is None or check_status):
+            if comm.stopped():
+                raise _lib.D3PError("vae_run_steps: the full-mesh collective was stopped by a bounded wait (d3p_fmesh_status); "
+                                    "parameters and moments are partly updated")
         new_state = DPSVIState((engine.step, engine.params, engine.m, engine.v), engine.keybuf[int(num_steps) & 1].reshape(4, 4).clone(),
                                engine.observation_scale)
         return new_state, losses

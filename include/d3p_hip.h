@@ -34,7 +34,7 @@ extern "C" {
 #define D3P_E_UNSUPPORTED (-3)
 #define D3P_E_WORKSPACE (-4)
 
-#define D3P_ABI_VERSION 8
+#define D3P_ABI_VERSION 9
 
 int d3p_abi_version(void);
 const char* d3p_last_error(void);
@@ -656,7 +656,7 @@ int d3p_dpvi_vae_run_dist(void* stream, void* comm, void* fmesh, const d3p_vae_m
 int d3p_fmesh_create(int32_t world, int32_t rank, uint64_t n_floats, void** fmesh_out, uint8_t* handle_out, size_t handle_bytes);
 int d3p_fmesh_connect(void* fmesh, const uint8_t* handles, size_t handle_stride);
 int d3p_fmesh_connect_local(void* fmesh, void* const* peers, int32_t world);
-int d3p_fmesh_set_grid(void* fmesh, int32_t workgroups);   /* workgroups per launch (default: one per CU; ranks that share a GPU: fewer) */
+int d3p_fmesh_set_grid(void* fmesh, int32_t workgroups);   /* workgroups per launch (default 512 = two per CU, ALL resident together; D3P_FMESH_WGS overrides; ranks that share a GPU: fewer) */
 int d3p_fmesh_allreduce(void* stream, void* fmesh, float* buf_dev, uint64_t n_floats);
 int d3p_fmesh_status(void* stream, void* fmesh, int32_t* stopped_out);
 int d3p_fmesh_destroy(void* fmesh);
@@ -670,6 +670,11 @@ int d3p_selftest_wave_sums(void* stream, const float* in_dev, uint32_t n_waves, 
  * X[r][c] and y[r] are pure functions of (seed, global row, column). */
 int d3p_synth_logreg(void* stream, uint32_t seed, uint64_t row0, uint64_t n_rows, int32_t d,
                      float* X_dev, float* y_dev);
+
+/* ABI 9 -- measurement aid, not part of the reference's path: a streaming device-to-device copy of `bytes` (multiple of 16, both
+ * buffers 16-byte aligned) with `bytes_per_lane` = 16 (float4: the figure quoted as the achievable HBM rate, SURVEY 8(d) "also measure
+ * a device-to-device copy peak on the box"), 8 or 4 (to calibrate the FETCH_SIZE / WRITE_SIZE counters per access width). */
+int d3p_hbm_copy(void* stream, void* dst_dev, const void* src_dev, uint64_t bytes, int32_t bytes_per_lane);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/d3p_hip.h but not exported"
     assert declared == set(L.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
-    assert lib.d3p_abi_version() == 8
+    assert lib.d3p_abi_version() == 9
     assert isinstance(lib.d3p_device_count(), int)
 
 
