@@ -141,6 +141,7 @@ SIGNATURES = {
     "d3p_tf_randint": (C.c_int, [_V, _V, _U64, _I32, _I32, _V]),
     "d3p_logreg_evaluate_workspace": (_SZ, [_PM, _U32]),
     "d3p_logreg_evaluate": (C.c_int, [_V, _PM, _V, _V, _V, _U32, _V, _V, _V, _SZ]),
+    "d3p_logreg_evaluate_sites": (C.c_int, [_V, _PM, _V, _V, _V, _U32, _V, C.POINTER(C.c_int32), _I32, _V, _V, _SZ]),
     "d3p_gmm_log_prob": (C.c_int, [_V, _V, _U32, _I32, _V, _V, _V, _I32, _V]),
     "d3p_feistel_sample": (C.c_int, [_V, _V, _U32, _U32, _V]),
     "d3p_feistel_from_constants": (C.c_int, [_V, _V, _U32, _U32, _V]),
@@ -229,6 +230,7 @@ SIGNATURES = {
     "d3p_selftest_wave_sums": (C.c_int, [_V, _V, _U32, _V]),
     "d3p_synth_logreg": (C.c_int, [_V, _U32, _U64, _U64, _I32, _V, _V]),
     "d3p_hbm_copy": (C.c_int, [_V, _V, _V, _U64, _I32]),
+    "d3p_px_eps_sites": (C.c_int, [_V, _V, _U32, _U32, _U32, C.POINTER(C.c_int32), _I32, _V]),
 }
 
 _lib = None

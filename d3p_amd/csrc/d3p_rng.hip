@@ -133,6 +133,49 @@ __global__ void k_tf_stream(const uint32_t* __restrict__ key, uint64_t n, float 
     }
 }
 
+// Per-example, per-SITE guide noise of a multi-site mean-field guide (examples/logistic_regression.py:67-86; oracle d3po_px_eps_sites):
+// example p's key = split(jax_key, B_total)[p] (svi.py:289-290), guide seed = split(.)[1], then numpyro's seed handler advances
+// rng, site_key = split(rng) at every sample statement; eps row = [normal(site_key_0, (size_0,)) | normal(site_key_1, (size_1,)) | ...].
+// One workgroup per example: every thread derives the site keys (2 + 2 per site threefry calls: cheaper than a barrier and a
+// broadcast), then the threads share the sites' word pairs (words j and j + ceil(size / 2) of a site come from ONE threefry call).
+#define D3P_MAX_GUIDE_SITES 8
+struct EpsSitesArgs {
+    const uint32_t* jax_key;
+    uint32_t B_total, pos0, B_local;
+    int n_sites;
+    int32_t size[D3P_MAX_GUIDE_SITES];
+    int32_t row;     // sum of the sizes
+    float* eps;
+};
+
+__global__ void __launch_bounds__(256) k_px_eps_sites(EpsSitesArgs a)
+{
+    const uint32_t i = blockIdx.x;
+    if (i >= a.B_local) return;
+    const uint32_t p = a.pos0 + i, j0 = a.jax_key[0], j1 = a.jax_key[1];
+    const uint32_t px0 = tf_iota_word(j0, j1, 2ull * a.B_total, 2ull * p), px1 = tf_iota_word(j0, j1, 2ull * a.B_total, 2ull * p + 1);
+    uint32_t t, r0, r1;
+    threefry2x32(px0, px1, 0u, 2u, t, r0);   // split(key, 2): counts [0, 1 | 2, 3]; key 1 = (y1(0, 2), y1(1, 3)), key 0 = (y0(0, 2), y0(1, 3))
+    threefry2x32(px0, px1, 1u, 3u, t, r1);   // (r0, r1) = the guide seed
+    float* row = a.eps + (size_t)i * a.row;
+    int off = 0;
+    for (int s = 0; s < a.n_sites; ++s) {
+        uint32_t c0, c1, k0, k1;
+        threefry2x32(r0, r1, 0u, 2u, c0, k0);
+        threefry2x32(r0, r1, 1u, 3u, c1, k1);
+        r0 = c0; r1 = c1;                    // the handler's key after this site
+        const int n = a.size[s], half = (n + 1) >> 1;
+        for (int j = threadIdx.x; j < half; j += blockDim.x) {
+            const int j2 = j + half;
+            uint32_t wa, wb;
+            threefry2x32(k0, k1, (uint32_t)j, j2 < n ? (uint32_t)j2 : 0u, wa, wb);
+            row[off + j] = bits_to_normal(wa);
+            if (j2 < n) row[off + j2] = bits_to_normal(wb);
+        }
+        off += n;
+    }
+}
+
 __global__ void k_tf_fold_in(const uint32_t* __restrict__ key, uint32_t data, uint32_t* __restrict__ out)
 {
     uint32_t a, b;
@@ -531,6 +574,27 @@ int d3p_tf_split(void* stream, const uint32_t* key_dev, int num, uint32_t* out_k
     D3P_REQUIRE(num >= 0, "d3p_tf_split: num must be >= 0");
     if (num == 0) return D3P_OK;
     return d3p_tf_random_bits(stream, key_dev, 2ull * (uint64_t)num, out_keys_dev);
+}
+
+int d3p_px_eps_sites(void* stream, const uint32_t* jax_key_dev, uint32_t B_total, uint32_t pos0, uint32_t B_local, const int32_t* site_sizes_host,
+                     int32_t n_sites, float* eps_dev)
+{
+    D3P_REQUIRE(jax_key_dev && site_sizes_host && eps_dev, "d3p_px_eps_sites: null pointer");
+    D3P_REQUIRE(n_sites >= 1 && n_sites <= D3P_MAX_GUIDE_SITES, "d3p_px_eps_sites: 1 <= n_sites <= 8");
+    D3P_REQUIRE((uint64_t)pos0 + B_local <= B_total, "d3p_px_eps_sites: pos0 + B_local must not exceed B_total");
+    if (B_local == 0) return D3P_OK;
+    EpsSitesArgs a;
+    a.jax_key = jax_key_dev; a.B_total = B_total; a.pos0 = pos0; a.B_local = B_local; a.n_sites = n_sites; a.eps = eps_dev;
+    int64_t row = 0;
+    for (int s = 0; s < n_sites; ++s) {
+        D3P_REQUIRE(site_sizes_host[s] >= 1, "d3p_px_eps_sites: a site has at least one element (a scalar site has size 1)");
+        a.size[s] = site_sizes_host[s];
+        row += site_sizes_host[s];
+    }
+    D3P_REQUIRE(row <= 0x7fffffff, "d3p_px_eps_sites: row too long");
+    a.row = (int32_t)row;
+    hipLaunchKernelGGL(k_px_eps_sites, dim3(B_local), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("d3p_px_eps_sites");
 }
 
 int d3p_tf_fold_in(void* stream, const uint32_t* key_dev, uint32_t data, uint32_t* out_key_dev)

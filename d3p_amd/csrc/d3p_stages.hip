@@ -213,37 +213,55 @@ __global__ void k_adadp_commit(float* lr, const float* lr_next, int32_t* step)
 
 // ---- DPSVI.evaluate (svi.py:436-449): -ELBO of a batch with ONE guide draw
 // k_eval_latent: key plumbing, eps, z = loc + softplus(u) * eps, latent[D] = logq - logp summed -> lat[0]
+// sites: the guide's sample sites in program order (AutoDiagonalNormal / one-site guides: ONE site of D elements; the example's own
+// guide, examples/logistic_regression.py:67-86: 'w' (d) then 'intercept' (1)) -- numpyro's seed handler advances
+// rng, site_key = split(rng) per site, and a site's eps is normal(site_key, (size,)).
+struct EvalSites {
+    int n;
+    int size[8];
+};
 __global__ void __launch_bounds__(256) k_eval_latent(d3p_logreg_model m, const float* __restrict__ params,
                                                      const uint32_t* __restrict__ jax_key, float* __restrict__ z,
-                                                     float* __restrict__ lat)
+                                                     float* __restrict__ lat, EvalSites sites)
 {
     __shared__ float red[256];
     const int D = m.d + (m.intercept ? 1 : 0);
-    // rng_key_eval = split(key)[1]; guide_seed = split(.)[1]; sample key = split(.)[1]  (jax split(k, 2)[1] =
-    // (threefry(k, (0, 2))[1], threefry(k, (1, 3))[1]))
-    uint32_t k0 = jax_key[0], k1 = jax_key[1];
+    // rng_key_eval = split(key)[1]; guide_seed = split(.)[1]; then per site: rng, sample key = split(rng)  (jax split(k, 2)[1] =
+    // (threefry(k, (0, 2))[1], threefry(k, (1, 3))[1]), [0] = the first outputs)
+    uint32_t r0 = jax_key[0], r1 = jax_key[1];
 #pragma unroll
-    for (int lvl = 0; lvl < 3; ++lvl) {
+    for (int lvl = 0; lvl < 2; ++lvl) {
         uint32_t a, b0, b1;
-        threefry2x32(k0, k1, 0u, 2u, a, b0);
-        threefry2x32(k0, k1, 1u, 3u, a, b1);
-        k0 = b0;
-        k1 = b1;
+        threefry2x32(r0, r1, 0u, 2u, a, b0);
+        threefry2x32(r0, r1, 1u, 3u, a, b1);
+        r0 = b0;
+        r1 = b1;
     }
     float acc = 0.f;
-    for (int e = threadIdx.x; e < D; e += 256) {
-        const float eps = bits_to_normal(tf_iota_word(k0, k1, (uint64_t)D, (uint64_t)e));
-        float sc, dsc;
-        guide_scale(m.guide_transform, params[D + e], sc, dsc);
-        const float ps = (e < m.d) ? m.prior_w : m.prior_b;
-        const float zz = __fmaf_rn(sc, eps, params[e]);
-        z[e] = zz;
-        acc += (-0.5f * eps * eps - logf(sc)) - (-0.5f * (zz / ps) * (zz / ps) - logf(ps));
+    int off = 0;
+    for (int s = 0; s < sites.n; ++s) {
+        uint32_t c0, c1, k0, k1;
+        threefry2x32(r0, r1, 0u, 2u, c0, k0);
+        threefry2x32(r0, r1, 1u, 3u, c1, k1);
+        r0 = c0;
+        r1 = c1;
+        const int n = sites.size[s];
+        for (int j = threadIdx.x; j < n; j += 256) {
+            const int e = off + j;
+            const float eps = bits_to_normal(tf_iota_word(k0, k1, (uint64_t)n, (uint64_t)j));
+            float sc, dsc;
+            guide_scale(m.guide_transform, params[D + e], sc, dsc);
+            const float ps = (e < m.d) ? m.prior_w : m.prior_b;
+            const float zz = __fmaf_rn(sc, eps, params[e]);
+            z[e] = zz;
+            acc += (-0.5f * eps * eps - logf(sc)) - (-0.5f * (zz / ps) * (zz / ps) - logf(ps));
+        }
+        off += n;
     }
     red[threadIdx.x] = acc;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    for (int off2 = 128; off2 > 0; off2 >>= 1) {
+        if ((int)threadIdx.x < off2) red[threadIdx.x] += red[threadIdx.x + off2];
         __syncthreads();
     }
     if (threadIdx.x == 0) lat[0] = red[0];
@@ -578,6 +596,13 @@ int d3p_logreg_evaluate(void* stream, const d3p_logreg_model* model, const float
                         const float* y_dev, uint32_t B, const uint32_t* jax_key_dev, float* loss_dev, void* workspace_dev,
                         size_t workspace_bytes)
 {
+    return d3p_logreg_evaluate_sites(stream, model, params_dev, X_dev, y_dev, B, jax_key_dev, nullptr, 1, loss_dev, workspace_dev, workspace_bytes);
+}
+
+int d3p_logreg_evaluate_sites(void* stream, const d3p_logreg_model* model, const float* params_dev, const float* X_dev,
+                              const float* y_dev, uint32_t B, const uint32_t* jax_key_dev, const int32_t* site_sizes_host, int32_t n_sites,
+                              float* loss_dev, void* workspace_dev, size_t workspace_bytes)
+{
     D3P_REQUIRE(model && params_dev && X_dev && jax_key_dev && loss_dev && workspace_dev,
                 "d3p_logreg_evaluate: null pointer");
     D3P_REQUIRE(B >= 1, "d3p_logreg_evaluate: B must be >= 1");
@@ -585,11 +610,28 @@ int d3p_logreg_evaluate(void* stream, const d3p_logreg_model* model, const float
     if (workspace_bytes < d3p_logreg_evaluate_workspace(model, B))
         return fail(D3P_E_WORKSPACE, "d3p_logreg_evaluate: workspace too small");
     const size_t D = (size_t)model->d + (model->intercept ? 1 : 0);
+    EvalSites sites;
+    memset(&sites, 0, sizeof(sites));
+    if (!site_sizes_host) {
+        D3P_REQUIRE(n_sites == 1, "d3p_logreg_evaluate_sites: site sizes are needed for more than one site");
+        sites.n = 1;
+        sites.size[0] = (int)D;
+    } else {
+        D3P_REQUIRE(n_sites >= 1 && n_sites <= 8, "d3p_logreg_evaluate_sites: 1 <= n_sites <= 8");
+        size_t total = 0;
+        for (int i = 0; i < n_sites; ++i) {
+            D3P_REQUIRE(site_sizes_host[i] >= 1, "d3p_logreg_evaluate_sites: a site has at least one element");
+            sites.size[i] = site_sizes_host[i];
+            total += (size_t)site_sizes_host[i];
+        }
+        D3P_REQUIRE(total == D, "d3p_logreg_evaluate_sites: the site sizes must add up to the latent dimension (d + intercept)");
+        sites.n = n_sites;
+    }
     float* z = (float*)workspace_dev;
     float* ll = (float*)((char*)workspace_dev + align_up(D * sizeof(float), 256));
     float* lat = (float*)((char*)ll + align_up((size_t)B * sizeof(float), 256));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_eval_latent, dim3(1), dim3(256), 0, s, *model, params_dev, jax_key_dev, z, lat);
+    hipLaunchKernelGGL(k_eval_latent, dim3(1), dim3(256), 0, s, *model, params_dev, jax_key_dev, z, lat, sites);
     hipLaunchKernelGGL(k_eval_loglik, dim3(cdiv((uint64_t)B * 64, 256)), dim3(256), 0, s, *model, X_dev, y_dev,
                        (const float*)z, B, ll);
     hipLaunchKernelGGL(k_eval_finish, dim3(1), dim3(256), 0, s, *model, (const float*)ll, B, (const float*)lat, loss_dev);

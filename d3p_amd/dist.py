@@ -333,6 +333,7 @@ class XchgComm:
         handle, buf = C.c_void_p(), (C.c_uint8 * 64)()
         check(lib.d3p_xchg_create(self.world, self.rank, self.words, C.byref(handle), buf, 64))
         self.handle = handle
+        self.local = _local is not None   # (ranks of ONE process: a rank's run may only be waited for once every rank's is enqueued)
         if _local is not None:
             return
         mine = bytes(buf)
@@ -395,6 +396,7 @@ class FMeshComm:
         handle, buf = C.c_void_p(), (C.c_uint8 * 64)()
         check(lib.d3p_fmesh_create(self.world, self.rank, self.n, C.byref(handle), buf, 64))
         self.handle = handle
+        self.local = _local is not None   # (ranks of ONE process: a rank's run may only be waited for once every rank's is enqueued)
         if _local is not None:
             return
         mine = bytes(buf)
@@ -577,8 +579,10 @@ def vae_run_steps(engine, state, X_local, batch_size_total, pos0, num_steps, gro
     FMeshComm: the same call with the full-mesh reduce-scatter + all-gather of d3p_fmesh.hip as the step's collective; with
     `comm="local"` the same call without a collective (one rank).  comm=None: the Python-driven loop over `group`
     (torch.distributed.all_reduce; any backend).  Returns (new_state, losses[num_steps] or None).
-    `check_status` (default: on for a FMeshComm): after the run read the mesh's status word (a device synchronisation) and raise
-    D3PError when a bounded wait ran out -- the state is then partly updated in place and must not be used or timed.
+    `check_status` (default: on for a FMeshComm whose ranks are processes; off for `FMeshComm.local_group` -- ranks of one process enqueue
+    one after the other, so a rank's run can only be waited for once every rank's is enqueued: check `comm.stopped()` then): after
+    the run read the mesh's status word (a device synchronisation) and raise D3PError when a bounded wait ran out -- the state is then
+    partly updated in place and must not be used or timed.
     `mask`: validity of the shard's examples (`update(..., mask=)`, svi.py:395; masked examples contribute nothing, the noise carries
     B / n)."""
     import torch.distributed as dist
@@ -591,7 +595,7 @@ def vae_run_steps(engine, state, X_local, batch_size_total, pos0, num_steps, gro
         check(_lib.load().d3p_dpvi_vae_run_dist(
             stream_ptr(), rccl, mesh, C.byref(engine.vm), C.byref(engine.hyper), C.byref(engine.st), ptr(engine.X), ptr(engine.mask),
             engine.B_local, engine.B_total, engine.pos0, int(num_steps), ptr(losses), int(buckets), ptr(engine.ws), engine.ws.numel()))
-        if mesh is not None and (check_status is None or check_status):
+        if mesh is not None and (check_status if check_status is not None else not comm.local):
             if comm.stopped():
                 raise _lib.D3PError("vae_run_steps: the full-mesh collective was stopped by a bounded wait (d3p_fmesh_status); "
                                     "parameters and moments are partly updated")

@@ -179,6 +179,42 @@ class DiagonalNormalGuide:
         return (self.site + "_loc", self.site + "_std_log")
 
 
+class MeanFieldGuide:
+    """The hand-written mean-field guide of examples/logistic_regression.py:67-86: ONE sample site per latent site of the model, in the
+    model's order -- `sample('w', Normal(w_loc, exp(w_std_log)))`, then `sample('intercept', Normal(intercept_loc, exp(intercept_std_log)))`
+    -- i.e. four parameter leaves (zeros at init, :77-83).  What differs from a one-site guide over [w, intercept]:
+      * the parameter dict flattens in sorted-name order (svi.py:490): intercept_loc (1), intercept_std_log (1), w_loc (d), w_std_log (d);
+      * the Gaussian mechanism draws ONE KEY PER LEAF, split(key, 4) (svi.py:487-491);
+      * numpyro's seed handler gives every sample site its own key (rng, site_key = split(rng) per sample statement), so 'w' and
+        'intercept' take their eps from different threefry streams (d3p_px_eps_sites; this plumbing is UNPINNED).
+    The joint density is the same as the one-site guide's, so the per-example gradient kernels are shared; DPSVI runs this guide through
+    the five-stage composition (per-example gradients materialised)."""
+
+    transform = "exp"
+
+    def __init__(self, model):
+        if not getattr(model, "intercept", False):
+            raise ValueError("MeanFieldGuide: the model must have more than one latent site (LogisticRegression(intercept=True)); "
+                             "use DiagonalNormalGuide for a one-site model")
+        self.model = model
+
+    def sites(self, d):
+        """[(site name, size)] in the guide's program order."""
+        return [("w", int(d)), ("intercept", 1)]
+
+    def param_names(self):
+        return ("intercept_loc", "intercept_std_log", "w_loc", "w_std_log")     # tree_flatten order of the parameter dict
+
+    def leaf_sizes(self, d):
+        return [1, 1, int(d), int(d)]
+
+    @staticmethod
+    def tree_from_kernel(d, device=None):
+        """Index tensor: tree-ordered flat vector = kernel-ordered [w_loc, intercept_loc | w_std_log, intercept_std_log][index]."""
+        D = d + 1
+        return torch.cat([torch.tensor([d, D + d]), torch.arange(d), D + torch.arange(d)]).to(device=device, dtype=torch.long)
+
+
 class init_to_uniform:
     """numpyro.infer.init_to_uniform(radius=2): auto_loc ~ U(-radius, radius).  The draw uses the
     threefry key of ``DPSVI.init`` (numpyro's exact key plumbing is unpinned)."""

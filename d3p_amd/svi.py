@@ -17,7 +17,7 @@ from . import _lib
 from . import random as strong_rng
 from ._lib import BatchSource, DpsviHyper, DpsviState, GmmModel, LogregModel, VaeModel, check, ptr, stream_ptr
 from .optimizers import ADADP
-from .models import (SGD, Adam, AutoDiagonalNormal, DiagonalNormalGuide, GaussianMean, GaussianMixtureGuide,
+from .models import (SGD, Adam, AutoDiagonalNormal, DiagonalNormalGuide, GaussianMean, GaussianMixtureGuide, MeanFieldGuide,
                      GaussianMixtureModel, LogisticRegression, VAEGuide, VAEModel,
                      init_to_uniform, init_to_value)
 from .util import example_count
@@ -328,9 +328,9 @@ class DPSVI:
 
     def _require_logreg(self):
         if (not isinstance(self.model, (LogisticRegression, GaussianMean))
-                or not isinstance(self.guide, (AutoDiagonalNormal, DiagonalNormalGuide))):
+                or not isinstance(self.guide, (AutoDiagonalNormal, DiagonalNormalGuide, MeanFieldGuide))):
             raise _lib.D3PError("DPSVI: model must be d3p_amd.models.LogisticRegression or GaussianMean with an "
-                                "AutoDiagonalNormal or DiagonalNormalGuide guide (the model families built so far)")
+                                "AutoDiagonalNormal, DiagonalNormalGuide or MeanFieldGuide guide (the model families built so far)")
 
     def _labels(self, args):
         """The label vector of the batch, or None for families without labels (GaussianMean)."""
@@ -378,7 +378,12 @@ class DPSVI:
         d = int(X.shape[1])
         D = self.model.latent_dim(d)
         jax_rng_key = self._rng_suite.convert_to_jax_rng_key(rng_key)
-        if isinstance(self.guide, DiagonalNormalGuide):
+        if isinstance(self.guide, MeanFieldGuide):
+            # param("w_loc", zeros(d)), param("w_std_log", zeros(d)), param("intercept_loc", 0.), param("intercept_std_log", 0.)
+            # (examples/logistic_regression.py:77-83), flat in tree_flatten order of the dict
+            loc = torch.zeros(D, dtype=torch.float32, device=X.device)
+            unc = torch.zeros(D, dtype=torch.float32, device=X.device)
+        elif isinstance(self.guide, DiagonalNormalGuide):
             # param(<site>_loc, zeros(d)), param(<site>_std_log, zeros(d)) (simple_gaussian_posterior.py:77-79)
             loc = torch.zeros(D, dtype=torch.float32, device=X.device) + _as_device_f32(self.guide.init_loc, X.device)
             unc = torch.full((D,), self.guide.init_std_log, dtype=torch.float32, device=X.device)
@@ -433,6 +438,12 @@ class DPSVI:
             K = int(self.static_kwargs.get("k") or self.model.k)
             return {"alpha_log": p[:K].clone(), "mus_loc": p[K:].reshape(K, -1).clone()}
         D = p.numel() // 2
+        if isinstance(self.guide, MeanFieldGuide):
+            out, pos = {}, 0
+            for name, size in zip(self.guide.param_names(), self.guide.leaf_sizes(D - 1)):
+                out[name] = p[pos:pos + size].clone() if size > 1 else p[pos].clone()
+                pos += size
+            return out
         n_loc, n_scale = self.guide.param_names()
         if isinstance(self.guide, DiagonalNormalGuide):
             return {n_loc: p[:D].clone(), n_scale: p[D:].clone()}
@@ -488,9 +499,25 @@ class DPSVI:
         meta = torch.empty(2, dtype=torch.float32, device=X.device)
         ws = self._workspace(lib.d3p_logreg_px_grads_workspace(C.byref(model), B), X.device, "px")
         eps = kwargs.get("_eps")
+        multi = isinstance(self.guide, MeanFieldGuide)
+        if multi:
+            # the state's parameters are flat in tree order (four leaves); the kernels take [loc (D) | unconstrained scale (D)] with the
+            # intercept last; every sample site draws its eps from its own key (d3p_px_eps_sites)
+            perm = MeanFieldGuide.tree_from_kernel(d, X.device)
+            kern = torch.empty_like(params)
+            kern[perm] = params
+            params = kern
+            if eps is None:
+                sizes = (C.c_int32 * 2)(d, 1)
+                eps = torch.empty((B, D), dtype=torch.float32, device=X.device)
+                check(lib.d3p_px_eps_sites(stream_ptr(), ptr(jax_rng_key), B, 0, B, sizes, 2, ptr(eps)))
         check(lib.d3p_logreg_px_grads(stream_ptr(), C.byref(model), ptr(params), ptr(X), ptr(y), ptr(mask_t), B,
                                       ptr(eps), ptr(jax_rng_key), ptr(px_loss), ptr(px_grads), ptr(meta),
                                       ptr(ws), ws.numel()))
+        if multi:
+            grads = {"intercept_loc": px_grads[:, d], "intercept_std_log": px_grads[:, D + d],
+                     "w_loc": px_grads[:, :d], "w_std_log": px_grads[:, D:D + d]}
+            return dp_svi_state, px_loss, grads, meta[0], meta[1]
         n_loc, n_scale = self.guide.param_names()
         grads = {n_loc: px_grads[:, :D], n_scale: px_grads[:, D:]}
         return dp_svi_state, px_loss, grads, meta[0], meta[1]
@@ -954,6 +981,13 @@ class DPSVI:
         model = self._model_struct(d, kwargs, 1.0)
         ws = self._workspace(lib.d3p_logreg_evaluate_workspace(C.byref(model), B), X.device, "eval")
         loss = torch.empty(1, dtype=torch.float32, device=X.device)
+        if isinstance(self.guide, MeanFieldGuide):   # two sample sites, each with its own key; parameters into the kernels' order
+            kern = torch.empty_like(params)
+            kern[MeanFieldGuide.tree_from_kernel(d, X.device)] = params
+            sizes = (C.c_int32 * 2)(d, 1)
+            check(lib.d3p_logreg_evaluate_sites(stream_ptr(), C.byref(model), ptr(kern), ptr(X), ptr(y), B, ptr(jax_rng_key), sizes, 2,
+                                                ptr(loss), ptr(ws), ws.numel()))
+            return loss[0]
         check(lib.d3p_logreg_evaluate(stream_ptr(), C.byref(model), ptr(params), ptr(X), ptr(y), B, ptr(jax_rng_key),
                                       ptr(loss), ptr(ws), ws.numel()))
         return loss[0]

@@ -3,9 +3,10 @@
 examples/logistic_regression.py (model :49-66, training loop :118-204) on the d3p_amd surface.
 
 Differences to the reference script, all forced by the environment: the model is declared
-(d3p_amd.models.LogisticRegression) instead of traced from a NumPyro function, the guide is
-AutoDiagonalNormal (README.md:99) instead of the hand-written guide, and an epoch is one `run_steps` call (the
-reference's jit(fori_loop(...)) at :149-160).  As in the reference (:135-137) dp_scale is calibrated for --epsilon, with
+(d3p_amd.models.LogisticRegression) instead of traced from a NumPyro function, and an epoch is one `run_steps` call (the
+reference's jit(fori_loop(...)) at :149-160).  `--guide handwritten` is the script's OWN guide (:67-86: sample sites 'w' and
+'intercept', four parameter leaves with exp scales, one perturbation key per leaf) through the five-stage composition;
+`--guide auto` (default) is AutoDiagonalNormal (README.md:99) on the fused device-resident loop.  As in the reference (:135-137) dp_scale is calibrated for --epsilon, with
 d3p_amd.dputil on the restated Fourier accountant; --sigma gives it directly.
 """
 import argparse
@@ -20,7 +21,7 @@ import torch  # noqa: E402
 import d3p_amd._lib as L  # noqa: E402
 import d3p_amd.random as rng_suite  # noqa: E402
 from d3p_amd.minibatch import poisson_batchify_data, split_batchify_data  # noqa: E402
-from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO  # noqa: E402
+from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, MeanFieldGuide, Trace_ELBO  # noqa: E402
 from d3p_amd.svi import DPSVI  # noqa: E402
 
 
@@ -53,7 +54,8 @@ def main(args):
                                                              num_iter=num_iter_per_epoch * args.num_epochs)
         print("noise scale {:.4f} for epsilon {:.4f}, delta {:.2e}".format(dp_scale, eps, 1 / N**2))
     model = LogisticRegression(args.dimensions, prior_scale=1.0, intercept=True)
-    svi = DPSVI(model, AutoDiagonalNormal(model), Adam(args.learning_rate), Trace_ELBO(), dp_scale=dp_scale,
+    guide = MeanFieldGuide(model) if getattr(args, "guide", "auto") == "handwritten" else AutoDiagonalNormal(model)
+    svi = DPSVI(model, guide, Adam(args.learning_rate), Trace_ELBO(), dp_scale=dp_scale,
                 clipping_threshold=1., num_obs_total=N, rng_suite=rng_suite)
     svi_state = svi.init(svi_init_rng, *sample_batch)
 
@@ -70,7 +72,10 @@ def main(args):
         dpsvi_rng, test_fetch_rng = rng_suite.split(dpsvi_rng, 2)
         num_test_batches, test_state = test_init(rng_key=test_fetch_rng)
         params = svi.get_params(svi_state)
-        w, b = params["auto_loc"][:-1], params["auto_loc"][-1]
+        if "w_loc" in params:   # the hand-written guide's leaves
+            w, b = params["w_loc"], params["intercept_loc"]
+        else:
+            w, b = params["auto_loc"][:-1], params["auto_loc"][-1]
         test_loss, acc = 0.0, 0.0
         for j in range(num_test_batches):
             bx, by = test_fetch(j, test_state)
@@ -92,4 +97,6 @@ if __name__ == "__main__":
     parser.add_argument('-batch-size', default=200, type=int, help='batch size')
     parser.add_argument('-d', '--dimensions', default=4, type=int, help='data dimension')
     parser.add_argument('-N', '--num-samples', default=10000, type=int, help='data samples count')
+    parser.add_argument('--guide', choices=["auto", "handwritten"], default="auto",
+                        help="auto: AutoDiagonalNormal (README.md:99); handwritten: the reference script's own two-site guide (:67-86)")
     main(parser.parse_args())

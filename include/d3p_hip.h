@@ -671,6 +671,22 @@ int d3p_selftest_wave_sums(void* stream, const float* in_dev, uint32_t n_waves, 
 int d3p_synth_logreg(void* stream, uint32_t seed, uint64_t row0, uint64_t n_rows, int32_t d,
                      float* X_dev, float* y_dev);
 
+/* ABI 9 -- per-example, per-SITE guide noise of a multi-site mean-field guide (the logistic-regression example's own guide,
+ * examples/logistic_regression.py:67-86: `sample('w', Normal(w_loc, exp(w_std_log)))` then `sample('intercept', ...)`), replacing what
+ * jax.vmap + numpyro's `seed` handler draw inside svi.py:262-290: eps_dev[i] = [normal(site_key_0, (size_0,)) | normal(site_key_1, ...) | ...]
+ * for the examples at positions pos0 .. pos0 + B_local - 1 of a batch of B_total; example p's key = split(jax_key, B_total)[p], its guide
+ * seed = split(.)[1], the handler advances `rng, site_key = split(rng)` per sample statement (UNPINNED like the rest of numpyro's key
+ * plumbing; n_sites = 1 is the stream the fused kernels draw on chip).  site_sizes_host: n_sites <= 8 sizes (a scalar site: 1). */
+int d3p_px_eps_sites(void* stream, const uint32_t* jax_key_dev, uint32_t B_total, uint32_t pos0, uint32_t B_local,
+                     const int32_t* site_sizes_host, int32_t n_sites, float* eps_dev);
+
+/* ABI 9 -- d3p_logreg_evaluate for a guide with several sample sites (the example's own guide: 'w' (d) then 'intercept' (1)): the one
+ * guide draw of SVI.evaluate takes every site's eps from its own key, `rng, site_key = split(rng)` per sample statement; params_dev in the
+ * kernels' order [loc (D) | unconstrained scale (D)], latent elements in site order.  site_sizes_host = NULL, n_sites = 1: d3p_logreg_evaluate. */
+int d3p_logreg_evaluate_sites(void* stream, const d3p_logreg_model* model, const float* params_dev, const float* X_dev,
+                              const float* y_dev, uint32_t B, const uint32_t* jax_key_dev, const int32_t* site_sizes_host,
+                              int32_t n_sites, float* loss_dev, void* workspace_dev, size_t workspace_bytes);
+
 /* ABI 9 -- measurement aid, not part of the reference's path: a streaming device-to-device copy of `bytes` (multiple of 16, both
  * buffers 16-byte aligned) with `bytes_per_lane` = 16 (float4: the figure quoted as the achievable HBM rate, SURVEY 8(d) "also measure
  * a device-to-device copy peak on the box"), 8 or 4 (to calibrate the FETCH_SIZE / WRITE_SIZE counters per access width). */

@@ -391,6 +391,43 @@ D3P_API void d3po_px_sample_key(const uint32_t jax_key[2], uint32_t B, uint32_t 
     out[1] = s[3];
 }
 
+/* Multi-site guides (examples/logistic_regression.py:67-86: `sample('w', ...)` then `sample('intercept', ...)`): numpyro's `seed`
+ * handler advances its key at every sample statement, in program order -- rng, site_key = split(rng) -- starting from the guide
+ * seed of the example (as in d3po_px_sample_key, which is the n_sites = 1 case, and d3po_gmm_site_keys).  UNPINNED: numpyro's
+ * key plumbing is restated from its published behaviour, the reference holds no vector for it (header, "PARITY UNPINNED"). */
+D3P_API void d3po_px_site_keys(const uint32_t jax_key[2], uint32_t B, uint32_t p, int n_sites, uint32_t* out /* 2 n_sites */)
+{
+    uint32_t px[2], s[4], r[2];
+    px[0] = tf_iota_word(jax_key[0], jax_key[1], 2ull * B, 2ull * p);
+    px[1] = tf_iota_word(jax_key[0], jax_key[1], 2ull * B, 2ull * p + 1);
+    d3po_tf_split(px, 2, s); /* guide_seed = s[2..3] */
+    r[0] = s[2]; r[1] = s[3];
+    for (int site = 0; site < n_sites; ++site) {
+        d3po_tf_split(r, 2, s);
+        out[2 * site] = s[2]; out[2 * site + 1] = s[3];
+        r[0] = s[0]; r[1] = s[1];
+    }
+}
+
+/* eps[i] = [normal(site_key_0, (size_0,)) | normal(site_key_1, (size_1,)) | ...] for the examples at positions pos0 .. pos0 + B_local - 1
+ * of a batch of B_total (svi.py:289-290: one key per example from split(jax_key, B_total)); a scalar site (shape ()) has size 1. */
+D3P_API void d3po_px_eps_sites(const uint32_t jax_key[2], uint32_t B_total, uint32_t pos0, uint32_t B_local, const int32_t* site_sizes,
+                               int n_sites, float* eps)
+{
+    int D = 0;
+    for (int s = 0; s < n_sites; ++s) D += site_sizes[s];
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)B_local; ++i) {
+        uint32_t sk[2 * 16];
+        d3po_px_site_keys(jax_key, B_total, pos0 + (uint32_t)i, n_sites, sk);
+        float* e = eps + (size_t)i * D;
+        for (int s = 0; s < n_sites; ++s) {
+            d3po_tf_normal(sk + 2 * s, (uint64_t)site_sizes[s], e);
+            e += site_sizes[s];
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * Feistel sampler: d3p/util.py:216-301 (verbatim uint32 arithmetic).
  * ---------------------------------------------------------------------------------------- */
@@ -835,8 +872,20 @@ D3P_API float d3po_logreg_run_feistel(const d3po_logreg_spec* sp, const d3po_dps
 /* DPSVI.evaluate (svi.py:436-449) -> numpyro SVI.evaluate: `_, key = split(rng_key)`; -Trace_ELBO on the whole
  * batch with ONE guide draw: model_seed, guide_seed = split(key); sample key = split(guide_seed)[1]
  * (numpyro.handlers.seed); plate(N, B) scales the likelihood by N / B.  (numpyro plumbing UNPINNED.) */
+D3P_API float d3po_logreg_evaluate_sites(const d3po_logreg_spec* sp, const float* loc, const float* unc, const float* Xb,
+                                         const float* yb, int B, const uint32_t jax_key[2], const int32_t* site_sizes, int n_sites);
+
 D3P_API float d3po_logreg_evaluate(const d3po_logreg_spec* sp, const float* loc, const float* unc, const float* Xb,
                                    const float* yb, int B, const uint32_t jax_key[2])
+{
+    const int32_t D = sp->d + (sp->intercept ? 1 : 0);
+    return d3po_logreg_evaluate_sites(sp, loc, unc, Xb, yb, B, jax_key, &D, 1);   /* ONE site: `_auto_latent` / the one-site guides */
+}
+
+/* The same with the guide's sample sites in program order (examples/logistic_regression.py:67-86: 'w' (d), 'intercept' (1)): the seed
+ * handler advances rng, site_key = split(rng) per sample statement; loc / unc in the kernels' order = site order.  UNPINNED plumbing. */
+D3P_API float d3po_logreg_evaluate_sites(const d3po_logreg_spec* sp, const float* loc, const float* unc, const float* Xb,
+                                         const float* yb, int B, const uint32_t jax_key[2], const int32_t* site_sizes, int n_sites)
 {
     const int d = sp->d, D = sp->d + (sp->intercept ? 1 : 0);
     uint32_t s[4], k[2];
@@ -844,11 +893,15 @@ D3P_API float d3po_logreg_evaluate(const d3po_logreg_spec* sp, const float* loc,
     k[0] = s[2]; k[1] = s[3];                 /* rng_key_eval */
     d3po_tf_split(k, 2, s);
     k[0] = s[2]; k[1] = s[3];                 /* guide_seed */
-    d3po_tf_split(k, 2, s);
-    k[0] = s[2]; k[1] = s[3];                 /* key of the `_auto_latent` sample site */
     float* eps = (float*)malloc((size_t)D * sizeof(float));
     float* z = (float*)malloc((size_t)D * sizeof(float));
-    d3po_tf_normal(k, (uint64_t)D, eps);
+    for (int site = 0, off = 0; site < n_sites; ++site) {
+        d3po_tf_split(k, 2, s);               /* rng, key of this sample site */
+        uint32_t sk[2] = {s[2], s[3]};
+        k[0] = s[0]; k[1] = s[1];
+        d3po_tf_normal(sk, (uint64_t)site_sizes[site], eps + off);
+        off += site_sizes[site];
+    }
     double lq = 0.0, lp = 0.0;
     for (int j = 0; j < D; ++j) {
         float sc, dsc;

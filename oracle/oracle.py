@@ -75,6 +75,7 @@ def lib():
         _lib.d3po_logreg_px_loss_grad.restype = C.c_float
         _lib.d3po_logreg_update.restype = C.c_float
         _lib.d3po_logreg_evaluate.restype = C.c_float
+        _lib.d3po_logreg_evaluate_sites.restype = C.c_float
         _lib.d3po_logreg_run_feistel.restype = C.c_float
         _lib.d3po_digamma.restype = C.c_double
         _lib.d3po_digamma.argtypes = [C.c_double]
@@ -248,6 +249,23 @@ def px_eps(jax_key, B, D):
     return np.stack([tf_normal(px_sample_key(jax_key, B, p), D) for p in range(B)])
 
 
+def px_site_keys(jax_key, B, p, n_sites):
+    """Per-site sample keys of example p (numpyro's seed handler: rng, site_key = split(rng) at every sample statement). UNPINNED."""
+    out = np.empty(2 * n_sites, np.uint32)
+    lib().d3po_px_site_keys(_p(_u32(jax_key)), C.c_uint32(B), C.c_uint32(p), C.c_int(n_sites), _p(out))
+    return out.reshape(n_sites, 2)
+
+
+def px_eps_sites(jax_key, B_total, site_sizes, pos0=0, B_local=None):
+    """eps (B_local x sum(site_sizes)): every site's standard-normal draw from its OWN key, sites in the guide's program order."""
+    B_local = B_total - pos0 if B_local is None else B_local
+    sizes = np.ascontiguousarray(np.asarray(site_sizes, np.int32))
+    eps = np.empty((B_local, int(sizes.sum())), np.float32)
+    lib().d3po_px_eps_sites(_p(_u32(jax_key)), C.c_uint32(B_total), C.c_uint32(pos0), C.c_uint32(B_local), _p(sizes),
+                            C.c_int(sizes.size), _p(eps))
+    return eps
+
+
 # ------------------------------------------------------------------ samplers
 def feistel_constants(key):
     rc = np.empty(30, np.uint32)
@@ -389,6 +407,57 @@ def logreg_update(spec, hyper, st, Xb, yb, mask=None, eps=None):
     return float(loss), grad
 
 
+class MeanFieldLogregState:
+    """State of DPSVI with the example's OWN guide (examples/logistic_regression.py:67-86): four parameter leaves, flat in
+    tree_flatten order of the parameter dict (sorted names): intercept_loc (1), intercept_std_log (1), w_loc (d), w_std_log (d);
+    all initialised to zeros (`param("w_loc", zeros(d))`, `param("intercept_std_log", 0.)`)."""
+
+    def __init__(self, key, d):
+        self.key = _u32(key).reshape(16).copy()
+        self.d = d
+        self.params = np.zeros(2 * d + 2, np.float32)
+        self.m = np.zeros(2 * d + 2, np.float32)
+        self.v = np.zeros(2 * d + 2, np.float32)
+        self.step = 0
+
+    @staticmethod
+    def leaf_sizes(d):
+        return [1, 1, d, d]
+
+    @staticmethod
+    def tree_from_kernel(d):
+        """Index array: tree-ordered flat vector = kernel-ordered vector [w_loc, intercept_loc | w_std_log, intercept_std_log][perm]."""
+        D = d + 1
+        return np.concatenate([[d], [D + d], np.arange(d), D + np.arange(d)]).astype(np.int64)
+
+
+def meanfield_logreg_update(spec, hyper, st, Xb, yb, mask=None):
+    """One DPSVI.update (svi.py:395-434) of the logistic regression with intercept under the example's hand-written two-site
+    guide.  spec: logreg_spec(d, intercept=True, guide_exp=True, ...).  Stage by stage: split(key, 3) (svi.py:208-211); per-example,
+    per-SITE guide noise (px_eps_sites: 'w' then 'intercept'); per-example gradients (the joint density is the same as the
+    one-site guide's over [w, intercept]); the leaves in tree order; joint clip (svi.py:68-124); mean (:327-348); perturbation with ONE
+    KEY PER LEAF, split(key, 4) (:487-491); Adam.  Returns (loss, perturbed gradient in tree order)."""
+    d = spec.d
+    D = d + 1
+    assert spec.intercept and spec.guide_exp == 1
+    ks = split(st.key, 3)
+    jax_key = convert_to_jax_rng_key(ks[1])
+    B = Xb.shape[0]
+    eps = px_eps_sites(jax_key, B, [d, 1])
+    perm = MeanFieldLogregState.tree_from_kernel(d)
+    kern = np.empty(2 * D, np.float32)
+    kern[perm] = st.params
+    px_loss, px_grads, n, factor = logreg_px_grads(spec, kern[:D], kern[D:], Xb, yb, eps, mask)
+    px_tree = np.ascontiguousarray(px_grads[:, perm])
+    clipped = clip_rows(px_tree, hyper.clip)
+    loss, avg = combine(clipped, px_loss)
+    g = perturb(ks[2], avg, MeanFieldLogregState.leaf_sizes(d), hyper.dp_scale, hyper.clip, float(n), 1.0 / spec.inv_obs, factor)
+    st.params, st.m, st.v = adam(st.params, st.m, st.v, g, st.step, lr=hyper.lr, b1=hyper.b1, b2=hyper.b2, eps=hyper.adam_eps)
+    st.step += 1
+    st.key = _u32(ks[0]).reshape(16).copy()
+    return loss, g
+
+
 def logreg_run_feistel(spec, hyper, st, X, y, batch_key, first_batch, B, steps, threads=1):
     """`steps` DPSVI.update calls on Feistel minibatches of the resident table (X, y), all inside one C call on `threads`
     OpenMP threads (bench.py's cpu_baseline).  Advances `st` in place; returns the last loss."""
@@ -408,6 +477,18 @@ def logreg_evaluate(spec, loc, unc, Xb, yb, jax_key):
     yb = np.zeros(Xb.shape[0], np.float32) if yb is None else _f32(yb)
     return float(lib().d3po_logreg_evaluate(C.byref(spec), _p(loc), _p(unc), _p(Xb), _p(yb), C.c_int(Xb.shape[0]),
                                             _p(_u32(jax_key))))
+
+
+def meanfield_logreg_evaluate(spec, params_tree, Xb, yb, jax_key):
+    """DPSVI.evaluate under the example's two-site guide; params_tree in MeanFieldLogregState's order."""
+    d = spec.d
+    D = d + 1
+    kern = np.empty(2 * D, np.float32)
+    kern[MeanFieldLogregState.tree_from_kernel(d)] = _f32(params_tree)
+    Xb = _f32(Xb)
+    sizes = np.asarray([d, 1], np.int32)
+    return float(lib().d3po_logreg_evaluate_sites(C.byref(spec), _p(kern[:D].copy()), _p(kern[D:].copy()), _p(Xb), _p(_f32(yb)),
+                                                  C.c_int(Xb.shape[0]), _p(_u32(jax_key)), _p(sizes), C.c_int(2)))
 
 
 def tf_randint(key, n, minval, maxval):

@@ -108,6 +108,40 @@ def main():
     u["rng_key_after"] = ints(new_state.rng_key)
     out["update_logreg_B16_d8"] = u
 
+    # ---- the same update under the logistic-regression example's OWN model and guide (examples/logistic_regression.py:49-86: sample
+    # sites 'w' and 'intercept', four parameter leaves with exp scales): pins the order of the leaves, the one-key-per-leaf perturbation
+    # and the seed handler's per-site keys (oracle: O.meanfield_logreg_update / O.px_eps_sites)
+    def model2(batch_X, batch_y=None, num_obs_total=None):
+        z_w = numpyro.sample("w", dist.Normal(jnp.zeros((d,)), jnp.ones((d,))))
+        z_intercept = numpyro.sample("intercept", dist.Normal(0, 1))
+        logits = batch_X.dot(z_w) + z_intercept
+        with numpyro.plate("batch", num_obs_total, batch_X.shape[0]):
+            return numpyro.sample("obs", dist.Bernoulli(logits=logits), obs=batch_y)
+
+    def guide2(batch_X, batch_y=None, num_obs_total=None):
+        w_loc = numpyro.param("w_loc", jnp.zeros((d,)))
+        w_std = jnp.exp(numpyro.param("w_std_log", jnp.zeros((d,))))
+        numpyro.sample("w", dist.Normal(w_loc, w_std))
+        i_loc = numpyro.param("intercept_loc", 0.)
+        i_std = jnp.exp(numpyro.param("intercept_std_log", 0.))
+        numpyro.sample("intercept", dist.Normal(i_loc, i_std))
+
+    svi2 = DPSVI(model2, guide2, Adam(1e-2), Trace_ELBO(), clipping_threshold=1.0, dp_scale=1.0, num_obs_total=N)
+    state = svi2.init(k0, jnp.asarray(X), jnp.asarray(y))
+    u2 = {"X": floats(X), "y": floats(y), "shape": [B, d, N], "observation_scale": float(state.observation_scale),
+          "leaf_order": sorted(svi2.optim.get_params(state.optim_state)),   # tree_flatten of a dict: sorted keys (svi.py:490)
+          "init_params": {n: floats(v) for n, v in svi2.optim.get_params(state.optim_state).items()}}
+    state1, _keys = svi2._split_rng_key(state, 2)
+    _, px_loss, px_grads, n_el, factor = svi2._compute_per_example_gradients(state1, _keys[0], jnp.asarray(X), jnp.asarray(y))
+    u2["px_loss"] = floats(px_loss)
+    u2["px_grads"] = {n: floats(v) for n, v in px_grads.items()}
+    new_state, loss = svi2.update(state, jnp.asarray(X), jnp.asarray(y))
+    u2["loss"] = float(loss)
+    u2["params_after"] = {n: floats(v) for n, v in svi2.optim.get_params(new_state.optim_state).items()}
+    u2["rng_key_after"] = ints(new_state.rng_key)
+    u2["evaluate_after"] = float(svi2.evaluate(new_state, jnp.asarray(X), jnp.asarray(y)))
+    out["update_logreg_example_guide_B16_d8"] = u2
+
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)

@@ -887,3 +887,76 @@ def test_run_steps_falls_back_to_one_launch_per_step_when_the_chained_launch_is_
     monkeypatch.setattr(DPSVI, "last_run_status", lambda self: (True, False))
     with pytest.warns(RuntimeWarning), pytest.raises(L.D3PError):
         svi.run_steps(st, gb, rng.PRNGKey(72), 0, steps)
+
+
+# --------------------------------------------------------------------------- the example's own guide: two sample sites, four leaves
+@pytest.mark.parametrize("B,d", [(64, 512), (37, 9)])
+def test_example_guide_with_two_sites_vs_oracle(rng, O, B, d):
+    """examples/logistic_regression.py:49-86 as it stands in the reference: model with sites 'w' (d) and 'intercept', the hand-written
+    guide with exp-parametrised scales -- four parameter leaves in sorted-name order, ONE perturbation key per leaf (svi.py:487-491), every
+    sample site's eps from its own key.  Three masked updates at d = 512 + intercept through DPSVI.update (five-stage composition on the
+    HIP kernels) against O.meanfield_logreg_update: losses 2e-5, parameters / Adam moments 1e-4, keys bit-exact; the per-site eps kernel
+    (d3p_px_eps_sites) against the oracle's stream (rtol 2e-6, like rng.normal); evaluate; get_params' leaf names and shapes."""
+    import ctypes as C
+    import d3p_amd._lib as L
+    from d3p_amd.models import Adam, LogisticRegression, MeanFieldGuide, Trace_ELBO
+    from d3p_amd.svi import DPSVI
+    N, C_, sigma, lr = 5000, 0.8, 1.1, 1e-2
+    r = np.random.default_rng(100 + d)
+    X = r.normal(size=(B, d)).astype(np.float32)
+    y = (r.random(B) < 0.5).astype(np.float32)
+    mask = r.random(B) < 0.8
+    model = LogisticRegression(d, prior_scale=1.0, intercept=True, intercept_prior_scale=1.0)
+    svi = DPSVI(model, MeanFieldGuide(model), Adam(lr), Trace_ELBO(), C_, sigma, num_obs_total=N)
+    Xt, yt, mt = torch.tensor(X).cuda(), torch.tensor(y).cuda(), torch.tensor(mask).cuda()
+    st = svi.init(rng.PRNGKey(21), Xt, yt)
+    assert st.optim_state[1].numel() == 2 * d + 2 and float(st.optim_state[1].abs().max()) == 0.0 and st.observation_scale == N
+    par = svi.get_params(st)
+    assert sorted(par) == ["intercept_loc", "intercept_std_log", "w_loc", "w_std_log"]
+    assert par["w_loc"].shape == (d,) and par["intercept_std_log"].shape == ()
+
+    # the per-site eps stream
+    jk = O.convert_to_jax_rng_key(O.split(O.PRNGKey(21), 3)[1])
+    eps = torch.empty((B, d + 1), device="cuda")
+    sizes = (C.c_int32 * 2)(d, 1)
+    jk_dev = torch.from_numpy(np.ascontiguousarray(jk, np.uint32).view(np.int32)).cuda().view(torch.uint32)
+    L.check(L.load().d3p_px_eps_sites(L.stream_ptr(), L.ptr(jk_dev), B, 0, B, sizes, 2, L.ptr(eps)))
+    want = O.px_eps_sites(jk, B, [d, 1])
+    np.testing.assert_allclose(np_(eps), want, rtol=2e-6, atol=1e-7)
+    # (a shard of the batch: rows pos0 .. of the same stream)
+    part = torch.empty((5, d + 1), device="cuda")
+    L.check(L.load().d3p_px_eps_sites(L.stream_ptr(), L.ptr(jk_dev), B, 7, 5, sizes, 2, L.ptr(part)))
+    assert torch.equal(part, eps[7:12])
+
+    spec = O.logreg_spec(d, True, 1.0, 1.0, lik_scale=N, obs_scale=N, guide_exp=True)
+    hy = O.Hyper(C_, sigma, lr, 0.9, 0.999, 1e-8)
+    ost = O.MeanFieldLogregState(O.PRNGKey(21), d)
+    for step in range(3):
+        st, loss = svi.update(st, Xt, yt, mask=mt)
+        eloss, _ = O.meanfield_logreg_update(spec, hy, ost, X, y, mask.astype(np.float32))
+        assert abs(float(loss) - eloss) <= 2e-5 * abs(eloss), (step, float(loss), eloss)
+        assert np.array_equal(np_(st.rng_key).ravel(), ost.key)
+        close(np_(st.optim_state[2]), ost.m)
+        np.testing.assert_allclose(np_(st.optim_state[1]), ost.params, rtol=1e-4, atol=1e-6)
+    assert int(st.optim_state[0]) == 3
+    got = float(svi.evaluate(st, Xt, yt))
+    spec_e = O.logreg_spec(d, True, 1.0, 1.0, lik_scale=N, obs_scale=1.0, guide_exp=True)
+    exp = O.meanfield_logreg_evaluate(spec_e, np_(st.optim_state[1]), X, y, O.convert_to_jax_rng_key(O.split(ost.key, 1)[0]))
+    assert abs(got - exp) <= 2e-5 * abs(exp)
+
+
+def test_example_guide_four_leaves_get_four_noise_streams(rng, O):
+    """svi.py:487-491 with the example's guide: split(key, 4), leaf k += normal(site_key_k, shape_k) * scale -- the two scalar leaves take
+    word 0 of their own keys, not elements of a shared vector (bit-exact against the oracle's ChaCha stream)."""
+    from d3p_amd.models import Adam, LogisticRegression, MeanFieldGuide, Trace_ELBO
+    from d3p_amd.svi import DPSVI
+    d = 12
+    model = LogisticRegression(d, intercept=True)
+    svi = DPSVI(model, MeanFieldGuide(model), Adam(1e-3), Trace_ELBO(), 1.0, 1.0, num_obs_total=100)
+    zeros = {"intercept_loc": torch.zeros((), device="cuda"), "intercept_std_log": torch.zeros((), device="cuda"),
+             "w_loc": torch.zeros(d, device="cuda"), "w_std_log": torch.zeros(d, device="cuda")}
+    out = DPSVI.perturbation_function(rng, rng.PRNGKey(8), zeros, 1.0)
+    keys = O.split(O.PRNGKey(8), 4)
+    for k, name in enumerate(sorted(zeros)):
+        want = O.normal(keys[k], tuple(zeros[name].shape))
+        np.testing.assert_allclose(np_(out[name]), want, rtol=2e-6, atol=1e-7)

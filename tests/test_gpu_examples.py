@@ -10,11 +10,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_logistic_regression_example_learns(gpu):
+@pytest.mark.parametrize("guide", ["auto", "handwritten"])
+def test_logistic_regression_example_learns(gpu, guide):
+    """`handwritten`: the reference script's OWN guide (examples/logistic_regression.py:67-86: two sample sites, four leaves)."""
     spec = importlib.util.spec_from_file_location("ex_logreg", os.path.join(ROOT, "examples", "logistic_regression.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    args = argparse.Namespace(sigma=0.5, num_epochs=12, learning_rate=5e-2, batch_size=200, dimensions=4, num_samples=10000)
+    args = argparse.Namespace(sigma=0.5, num_epochs=12, learning_rate=5e-2, batch_size=200, dimensions=4, num_samples=10000, guide=guide)
     accs, train_losses = mod.main(args)
     assert len(accs) == 12
     # learns: held-out accuracy well above chance (the labels are noisy: ~0.77 is what the true weights reach)

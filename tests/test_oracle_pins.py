@@ -231,6 +231,65 @@ def test_logreg_gradient_vs_torch_autograd(O):
         assert np.abs(L - Lt.numpy()).max() / np.abs(Lt.numpy()).max() < 1e-6
 
 
+def test_example_guide_with_two_sites_vs_torch_autograd_and_the_stage_composition(O):
+    """The logistic-regression example's OWN model and guide (examples/logistic_regression.py:49-86): sites 'w' (d) and 'intercept'
+    (scalar), four parameter leaves w_loc / w_std_log / intercept_loc / intercept_std_log with exp-parametrised scales.  The oracle's
+    update (O.meanfield_logreg_update) against an independent composition: the ELBO written site by site with torch.distributions,
+    per-example gradients of the FOUR leaves by autograd, leaves concatenated in tree_flatten order of the parameter dict (sorted
+    names, svi.py:490), joint clip, mean, ONE perturbation key per leaf (split(key, 4), svi.py:491), Adam.  The per-site guide noise
+    is the oracle's (numpyro's seed-handler plumbing: UNPINNED); everything behind it is pinned here."""
+    import torch
+    import torch.distributions as dist
+    from torch.func import grad, vmap
+    d, B, N, C_, sigma, lr = 6, 9, 500, 0.7, 1.3, 1e-2
+    r = np.random.default_rng(11)
+    X = r.normal(size=(B, d)).astype(np.float32)
+    y = (r.random(B) < 0.5).astype(np.float32)
+    mask = np.array([1, 1, 0, 1, 1, 1, 1, 0, 1], np.float32)
+    spec = O.logreg_spec(d, True, 1.0, 1.0, lik_scale=N, obs_scale=N, guide_exp=True)
+    hy = O.Hyper(C_, sigma, lr, 0.9, 0.999, 1e-8)
+    st = O.MeanFieldLogregState(O.PRNGKey(4), d)
+    st.params[:] = (0.2 * r.normal(size=2 * d + 2)).astype(np.float32)
+    p0, key0 = st.params.copy(), st.key.copy()
+    loss, g = O.meanfield_logreg_update(spec, hy, st, X, y, mask)
+
+    ks = O.split(key0, 3)
+    eps = O.px_eps_sites(O.convert_to_jax_rng_key(ks[1]), B, [d, 1])          # [eps_w (d) | eps_intercept (1)]
+    assert np.array_equal(eps[3, :d], O.tf_normal(O.px_site_keys(O.convert_to_jax_rng_key(ks[1]), B, 3, 2)[0], d))
+    t = lambda a: torch.tensor(a, dtype=torch.float64)  # noqa: E731
+    leaves = {"intercept_loc": t(p0[0:1]), "intercept_std_log": t(p0[1:2]), "w_loc": t(p0[2:2 + d]), "w_std_log": t(p0[2 + d:])}
+
+    def px_loss(par, x, yv, e, m):
+        w = par["w_loc"] + torch.exp(par["w_std_log"]) * e[:d]
+        b = par["intercept_loc"] + torch.exp(par["intercept_std_log"]) * e[d:]
+        logq = dist.Normal(par["w_loc"], torch.exp(par["w_std_log"])).log_prob(w).sum() + \
+            dist.Normal(par["intercept_loc"], torch.exp(par["intercept_std_log"])).log_prob(b).sum()
+        logp = dist.Normal(0.0, 1.0).log_prob(w).sum() + dist.Normal(0.0, 1.0).log_prob(b).sum()
+        ll = -torch.nn.functional.binary_cross_entropy_with_logits(x @ w + b[0], yv, reduction="sum")
+        return (1.0 / N) * (-(logp + N * ll - logq)) * m
+
+    gs = vmap(grad(px_loss), in_dims=(None, 0, 0, 0, 0))(leaves, t(X), t(y), t(eps), t(mask))
+    n = float(mask.sum())
+    f = B / n
+    L = vmap(px_loss, in_dims=(None, 0, 0, 0, 0))(leaves, t(X), t(y), t(eps), t(mask)) * N * f
+    rows = torch.cat([gs[k].reshape(B, -1) for k in sorted(gs)], 1)            # tree_flatten: sorted dict keys
+    norms = rows.norm(dim=1)
+    rows = rows / torch.clamp(norms / C_, min=1.0)[:, None]
+    avg = rows.mean(0).numpy()
+    want_g = O.perturb(ks[2], avg.astype(np.float32), [1, 1, d, d], sigma, C_, n, float(N), f)
+    np.testing.assert_allclose(g, want_g, rtol=2e-5, atol=1e-6 * np.abs(want_g).max())
+    assert abs(loss - float(L.mean())) <= 2e-6 * abs(float(L.mean()))
+    x, m, v = O.adam(p0, np.zeros_like(p0), np.zeros_like(p0), want_g, 0, lr=lr)
+    np.testing.assert_allclose(st.params, x, rtol=1e-5, atol=1e-7)
+    assert st.step == 1 and np.array_equal(st.key, np.asarray(ks[0]).ravel())
+    # the four leaves get FOUR different noise streams: the two scalar leaves' noise is word 0 of their own keys
+    site_keys = O.split(ks[2], 4)
+    scale = sigma * C_ / n
+    noise = (want_g / (N * f) - avg) / scale
+    np.testing.assert_allclose(noise[0], O.normal(site_keys[0], (1,))[0], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(noise[2:2 + d], O.normal(site_keys[2], (d,)), rtol=1e-3, atol=1e-4)
+
+
 def test_adam_matches_jax_optimizers_formula(O):
     r = np.random.default_rng(1)
     x, m, v = r.normal(size=9), np.zeros(9), np.zeros(9)

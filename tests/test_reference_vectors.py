@@ -76,3 +76,34 @@ def test_update_logreg(O, ref):
     assert abs(loss - u["loss"]) <= 2e-5 * abs(u["loss"])
     np.testing.assert_allclose(st.params[:d], u["params_after_unconstrained"]["auto_loc"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(st.params[d:], u["params_after_unconstrained"]["auto_scale"], rtol=1e-5, atol=1e-6)
+
+
+def test_update_logreg_with_the_examples_own_guide(O, ref):
+    """examples/logistic_regression.py:49-86: two sample sites, four leaves -- per-example gradients leaf by leaf, the update, evaluate."""
+    u = ref.get("update_logreg_example_guide_B16_d8")
+    if u is None:
+        pytest.skip("the captured file predates this item")
+    B, d, N = u["shape"]
+    X = np.asarray(u["X"], np.float32).reshape(B, d)
+    y = np.asarray(u["y"], np.float32)
+    spec = O.logreg_spec(d, True, 1.0, 1.0, lik_scale=N, obs_scale=u["observation_scale"], guide_exp=True)
+    st = O.MeanFieldLogregState(O.PRNGKey(0), d)
+    names = ["intercept_loc", "intercept_std_log", "w_loc", "w_std_log"]
+    assert all(np.allclose(u["init_params"][n], 0.0) for n in names)
+    # stage 1 with the oracle's per-site eps
+    ks = O.split(O.PRNGKey(0), 3)
+    eps = O.px_eps_sites(O.convert_to_jax_rng_key(ks[1]), B, [d, 1])
+    px_loss, px_grads, _, _ = O.logreg_px_grads(spec, np.zeros(d + 1, np.float32), np.zeros(d + 1, np.float32), X, y, eps)
+    tree = px_grads[:, O.MeanFieldLogregState.tree_from_kernel(d)]
+    np.testing.assert_allclose(px_loss, u["px_loss"], rtol=2e-5)
+    got = {"intercept_loc": tree[:, 0], "intercept_std_log": tree[:, 1], "w_loc": tree[:, 2:2 + d], "w_std_log": tree[:, 2 + d:]}
+    for n in names:
+        np.testing.assert_allclose(got[n].ravel(), u["px_grads"][n], rtol=2e-5, atol=1e-6)
+    loss, _ = O.meanfield_logreg_update(spec, O.Hyper(1.0, 1.0, 1e-2, 0.9, 0.999, 1e-8), st, X, y)
+    assert st.key.tolist() == u["rng_key_after"]
+    assert abs(loss - u["loss"]) <= 2e-5 * abs(u["loss"])
+    flat = np.concatenate([np.ravel(u["params_after"][n]) for n in names])
+    np.testing.assert_allclose(st.params, flat, rtol=1e-5, atol=1e-6)
+    spec_e = O.logreg_spec(d, True, 1.0, 1.0, lik_scale=N, obs_scale=1.0, guide_exp=True)
+    ev = O.meanfield_logreg_evaluate(spec_e, st.params, X, y, O.convert_to_jax_rng_key(O.split(st.key, 1)[0]))
+    assert abs(ev - u["evaluate_after"]) <= 2e-5 * abs(u["evaluate_after"])
