@@ -377,7 +377,7 @@ def vae_dist_workload(dev, world, rank, group_barrier, share_gpu=False, emulate=
                     flag = flag.cpu()
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if not int(flag[0]) and mesh is not None:
-                    mesh.close()
+                    mesh.close(collective=False)   # (a peer has none: this rank gives its mesh up alone)
                     mesh = None
                 if mesh is not None:   # (fused: tile sums + collective + update in one launch; _3_launches: kept apart)
                     drivers += [("native_full_mesh", {"comm": mesh}), ("native_full_mesh_3_launches", {"comm": mesh, "buckets": 1})]
@@ -597,8 +597,11 @@ def main():
                 flag = torch.tensor([ok], dtype=torch.int32, device=dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 ok = int(flag[0])
-            if not ok and c is not None:
-                c.close()
+            if not ok and c is not None:    # (a peer has none: this rank gives its communicator up alone -- no teardown barrier)
+                if isinstance(c, (ddist.XchgComm, ddist.FMeshComm)):
+                    c.close(collective=False)
+                else:
+                    c.close()
                 c = None
             return c
 

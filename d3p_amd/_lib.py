@@ -190,12 +190,14 @@ SIGNATURES = {
     "d3p_fmesh_allreduce": (C.c_int, [_V, _V, _V, C.c_uint64]),
     "d3p_fmesh_status": (C.c_int, [_V, _V, _V]),
     "d3p_fmesh_destroy": (C.c_int, [_V]),
+    "d3p_fmesh_disconnect": (C.c_int, [_V]),
     "d3p_dpvi_logreg_chain_status": (C.c_int, [_V, _V, _V, _V, C.c_size_t, _V]),
     "d3p_dpvi_logreg_run_status": (C.c_int, [_V, _V, _V, _V, C.c_size_t, _V, _V]),
     "d3p_xchg_create": (C.c_int, [_I32, _I32, _U32, _V, _V, _SZ]),
     "d3p_xchg_connect": (C.c_int, [_V, _V, _SZ]),
     "d3p_xchg_connect_local": (C.c_int, [_V, _V, _I32]),
     "d3p_xchg_destroy": (C.c_int, [_V]),
+    "d3p_xchg_disconnect": (C.c_int, [_V]),
     "d3p_xchg_allreduce": (C.c_int, [_V, _V, _V, _I32]),
     "d3p_xchg_simulate_peers": (C.c_int, [_V, _V, _U32]),
     "d3p_dpvi_logreg_run_xchg": (C.c_int, [_V, _V, _PM, _PH, _PS, _PB, _V, _V, _U32, _V, _V, _SZ]),

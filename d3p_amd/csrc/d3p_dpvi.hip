@@ -2379,6 +2379,22 @@ int d3p_xchg_connect_local(void* xchg, void* const* peers, int32_t world)
     return D3P_OK;
 }
 
+// Unmap the peers' inboxes: the first half of a teardown (every rank disconnects -> barrier -> every rank destroys; a rank that frees
+// its inbox while a peer still has it mapped breaks the exporter's NEXT hipIpcGetMemHandle with dmabuf IPC).  Idempotent.
+int d3p_xchg_disconnect(void* xchg)
+{
+    if (!xchg) return D3P_OK;
+    Xchg* x = (Xchg*)xchg;
+    for (int p = 0; p < x->world; ++p)
+        if (x->opened[p]) {
+            (void)hipIpcCloseMemHandle(x->peer[p]);
+            x->opened[p] = false;
+            x->peer[p] = nullptr;
+        }
+    (void)hipGetLastError();
+    return D3P_OK;
+}
+
 int d3p_xchg_destroy(void* xchg)
 {
     if (!xchg) return D3P_OK;

@@ -231,6 +231,23 @@ int d3p_fmesh_status(void* stream, void* fmesh, int32_t* stopped_out)
     return D3P_OK;
 }
 
+// Unmap the peers' inboxes (the first half of a teardown: a rank must not FREE its inbox while a peer still has it mapped -- with
+// dmabuf IPC the exporter's next allocation + hipIpcGetMemHandle then fails with "invalid argument": every rank disconnects, the
+// ranks meet in a barrier, then every rank destroys).  Idempotent; the mesh cannot run a collective afterwards.
+int d3p_fmesh_disconnect(void* fmesh)
+{
+    if (!fmesh) return D3P_OK;
+    FMesh* x = (FMesh*)fmesh;
+    for (int p = 0; p < x->world; ++p)
+        if (x->opened[p]) {
+            (void)hipIpcCloseMemHandle(x->peer[p]);
+            x->opened[p] = false;
+            x->peer[p] = nullptr;
+        }
+    (void)hipGetLastError();
+    return D3P_OK;
+}
+
 int d3p_fmesh_destroy(void* fmesh)
 {
     if (!fmesh) return D3P_OK;

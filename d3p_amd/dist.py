@@ -314,6 +314,17 @@ class NativeComm:
             self.handle = None
 
 
+def _teardown_barrier(comm, collective, disconnect):
+    """First half of XchgComm / FMeshComm.close: every rank unmaps its peers' inboxes, then the ranks meet, and only then does anybody
+    free.  The barrier is skipped for single-process groups, one-rank jobs, and on request."""
+    import torch.distributed as dist
+    check(disconnect(comm.handle))
+    if collective is None:
+        collective = not comm.local and comm.world > 1
+    if collective and dist.is_available() and dist.is_initialized():
+        dist.barrier(group=getattr(comm, "group", None))
+
+
 class XchgComm:
     """One-shot full-mesh exchange owned by libd3p_hip.so (d3p_xchg_*): every rank's inbox is mapped into its peers with
     hipIpc handles (gathered here through torch.distributed, any backend), and the step's collective becomes ONE kernel
@@ -330,6 +341,7 @@ class XchgComm:
             self.rank = dist.get_rank(group) if dist.is_initialized() else 0
             self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.words = int(words)
+        self.group = group
         handle, buf = C.c_void_p(), (C.c_uint8 * 64)()
         check(lib.d3p_xchg_create(self.world, self.rank, self.words, C.byref(handle), buf, 64))
         self.handle = handle
@@ -369,9 +381,14 @@ class XchgComm:
         than the run, before the run."""
         check(_lib.load().d3p_xchg_simulate_peers(stream_ptr(), self.handle, int(num_exchanges)))
 
-    def close(self):
+    def close(self, collective=None):
+        """Teardown.  With the ranks in separate processes it is a COLLECTIVE (every rank calls it): unmap the peers' inboxes, meet in a
+        barrier, then free the own inbox -- a rank that frees its inbox while a peer still has it mapped breaks its own next
+        hipIpcGetMemHandle (dmabuf IPC: "invalid argument" on the next communicator).  `collective=False`: no barrier (a rank
+        that must give its communicator up ALONE, e.g. because a peer failed to create one)."""
         if self.handle:
             torch.cuda.synchronize()
+            _teardown_barrier(self, collective, _lib.load().d3p_xchg_disconnect)
             check(_lib.load().d3p_xchg_destroy(self.handle))
             self.handle = None
 
@@ -393,6 +410,7 @@ class FMeshComm:
             self.rank = dist.get_rank(group) if dist.is_initialized() else 0
             self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.n = int(n_floats)
+        self.group = group
         handle, buf = C.c_void_p(), (C.c_uint8 * 64)()
         check(lib.d3p_fmesh_create(self.world, self.rank, self.n, C.byref(handle), buf, 64))
         self.handle = handle
@@ -433,9 +451,11 @@ class FMeshComm:
         check(_lib.load().d3p_fmesh_status(stream_ptr(), self.handle, C.byref(w)))
         return bool(w.value)
 
-    def close(self):
+    def close(self, collective=None):
+        """Teardown; a COLLECTIVE when the ranks are separate processes (see XchgComm.close): unmap the peers, barrier, free."""
         if self.handle:
             torch.cuda.synchronize()
+            _teardown_barrier(self, collective, _lib.load().d3p_fmesh_disconnect)
             check(_lib.load().d3p_fmesh_destroy(self.handle))
             self.handle = None
 

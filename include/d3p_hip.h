@@ -524,6 +524,7 @@ int d3p_xchg_simulate_peers(void* stream, void* xchg, uint32_t num_exchanges);
 /* d3p_xchg_connect_local: the same for ranks that live in ONE process (one stream each): `peers` = the `world` exchange
   * objects of the group, in rank order; their inboxes are wired directly. */
 int d3p_xchg_connect_local(void* xchg, void* const* peers, int32_t world);
+int d3p_xchg_disconnect(void* xchg);   /* ABI 9: unmap the peers' inboxes; teardown = every rank disconnects -> barrier -> every rank destroys */
 int d3p_xchg_destroy(void* xchg);
 int d3p_xchg_allreduce(void* stream, void* xchg, long long* acc_dev, int32_t replicas);
 int d3p_dpvi_logreg_run_xchg(void* stream, void* xchg, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
@@ -659,6 +660,7 @@ int d3p_fmesh_connect_local(void* fmesh, void* const* peers, int32_t world);
 int d3p_fmesh_set_grid(void* fmesh, int32_t workgroups);   /* workgroups per launch (default 512 = two per CU, ALL resident together; D3P_FMESH_WGS overrides; ranks that share a GPU: fewer) */
 int d3p_fmesh_allreduce(void* stream, void* fmesh, float* buf_dev, uint64_t n_floats);
 int d3p_fmesh_status(void* stream, void* fmesh, int32_t* stopped_out);
+int d3p_fmesh_disconnect(void* fmesh);   /* ABI 9: as d3p_xchg_disconnect */
 int d3p_fmesh_destroy(void* fmesh);
 
 /* Self-test of the wave-level sums the step kernels are built on (wave_sum / wave_sum2: DPP adds from inline assembly), taken

@@ -26,6 +26,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_OBS, D, H, Z, STEPS = 60000, 784, 400, 50, 3
@@ -142,16 +143,20 @@ def rank_main():
                 scaled = [v * float(e + 1) for v in vecs]
                 want = _rank_order_sum(scaled)
                 work = scaled[rank].cuda()
+                torch.cuda.synchronize()
                 dist.barrier()
+                t0 = time.perf_counter()
                 comm.allreduce(work)
                 torch.cuda.synchronize()
+                if os.environ.get("D3P_FMESH_CHECK_VERBOSE"):
+                    print(f"rank {rank}: n = {n}, epoch {e}: {1e3 * (time.perf_counter() - t0):.2f} ms, stopped {comm.stopped()}", file=sys.stderr, flush=True)
                 good = bool(torch.equal(work.cpu(), want))
                 if not good:
                     print(f"rank {rank}: n = {n}, epoch {e}: the sum differs from the rank-order sum", file=sys.stderr, flush=True)
                 ok &= good
             stopped |= comm.stopped()
         finally:
-            comm.close()
+            comm.close(collective=sys.exc_info()[0] is None)   # (after an exception on this rank alone the peers are not in their close)
     B = b_local * world
     make, X = _problem(B)
     Xd = X.cuda()
@@ -212,7 +217,7 @@ def rank_main():
                               "final_loss": float(losses[-1])}), flush=True)
         dist.barrier()
     finally:
-        comm.close()
+        comm.close(collective=sys.exc_info()[0] is None)
         dist.destroy_process_group()
     return 0 if (ok and not stopped) else 1
 

@@ -54,7 +54,7 @@ def rank_main():
                 ok &= good
             stopped |= comm.stopped()
         finally:
-            comm.close()
+            comm.close(collective=sys.exc_info()[0] is None)   # (after an exception on this rank alone the peers are not in their close)
     # (b) the VAE loop
     N, B, D, H, Z, steps = 60000, 128, 784, 400, 50, 3
     X = torch.tensor((np.random.default_rng(31).random((B, D)) < 0.4).astype(np.float32)).cuda()
@@ -97,7 +97,7 @@ def rank_main():
                               "devices": torch.cuda.device_count(), "final_loss": float(res[0][1][-1])}), flush=True)
         dist.barrier()
     finally:
-        comm.close()
+        comm.close(collective=sys.exc_info()[0] is None)
         dist.destroy_process_group()
     return 0 if (ok and not stopped) else 1
 

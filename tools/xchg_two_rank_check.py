@@ -90,7 +90,7 @@ def rank_main():
                               "final_loss": float(res[0][1][-1])}), flush=True)
         dist.barrier()
     finally:
-        comm.close()
+        comm.close(collective=sys.exc_info()[0] is None)
         dist.destroy_process_group()
     return 0 if ok else 1
 
