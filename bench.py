@@ -77,7 +77,7 @@ def copy_peak(dev, gib=2, repeats=5):
     rates.sort()
     return {"GBps_median": round(rates[len(rates) // 2], 1), "GBps_best": round(rates[-1], 1), "GBps_all": [round(r, 1) for r in rates],
             "bytes_copied": n, "repeats": repeats, "copied_correctly": ok,
-            "kernel": "k_hbm_copy<16 B per lane, 4 loads in flight> (d3p_hbm_copy), 4096 workgroups of 256 threads, grid-stride; rate = (read + "
+            "kernel": "k_hbm_copy<16 B per lane, 4 loads in flight> (d3p_hbm_copy), 8192 workgroups of 256 threads, grid-stride, nontemporal loads and stores; rate = (read + "
                       "written bytes) / HIP-event time"}
 
 

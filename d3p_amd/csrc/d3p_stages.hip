@@ -726,7 +726,7 @@ int d3p_synth_logreg(void* stream, uint32_t seed, uint64_t row0, uint64_t n_rows
 // counters can be calibrated per access width on a known byte count (tools/probes/fetch_calibration.py).
 extern "C++" {
 typedef unsigned int d3p_copy16 __attribute__((ext_vector_type(4)));
-template <typename T, int U>
+template <typename T, int U, bool NT>
 __global__ void __launch_bounds__(256) k_hbm_copy(T* __restrict__ dst, const T* __restrict__ src, uint64_t n)
 {
     const uint64_t stride = (uint64_t)gridDim.x * 256;
@@ -734,9 +734,12 @@ __global__ void __launch_bounds__(256) k_hbm_copy(T* __restrict__ dst, const T* 
     for (; i + (U - 1) * stride < n; i += U * stride) {
         T v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
 #pragma unroll
-        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+        for (int u = 0; u < U; ++u) {
+            if (NT) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+            else dst[i + u * stride] = v[u];
+        }
     }
     for (; i < n; i += stride) dst[i] = src[i];
 }
@@ -749,13 +752,20 @@ int d3p_hbm_copy(void* stream, void* dst_dev, const void* src_dev, uint64_t byte
     D3P_REQUIRE(bytes % 16 == 0 && ((uintptr_t)dst_dev % 16) == 0 && ((uintptr_t)src_dev % 16) == 0, "d3p_hbm_copy: 16-byte aligned buffers and size");
     if (bytes == 0) return D3P_OK;
     hipStream_t s = (hipStream_t)stream;
-    const unsigned grid = 256 * 8 * 2;   // 16 workgroups of 4 waves per CU: every SIMD full, the copy grid-strides
-    if (bytes_per_lane == 16)
-        hipLaunchKernelGGL((k_hbm_copy<d3p_copy16, 4>), dim3(grid), dim3(256), 0, s, (d3p_copy16*)dst_dev, (const d3p_copy16*)src_dev, bytes / 16);
-    else if (bytes_per_lane == 8)
-        hipLaunchKernelGGL((k_hbm_copy<unsigned long long, 4>), dim3(grid), dim3(256), 0, s, (unsigned long long*)dst_dev, (const unsigned long long*)src_dev, bytes / 8);
-    else
-        hipLaunchKernelGGL((k_hbm_copy<uint32_t, 4>), dim3(grid), dim3(256), 0, s, (uint32_t*)dst_dev, (const uint32_t*)src_dev, bytes / 4);
+    // developer switches (probing the box's copy rate: tools/probes/copy_peak_probe.py), read per call: workgroups of the grid-stride
+    // launch (default 32 per CU) and plain instead of nontemporal loads / stores
+    const char* eg = getenv("D3P_COPY_GRID");
+    const unsigned grid = eg && atoi(eg) > 0 ? (unsigned)atoi(eg) : 256u * 32u;   // (8192: the best of the grids probed, profiles/r06_copy_peak_probe.json)
+    const bool nt = getenv("D3P_COPY_TEMPORAL") == nullptr;
+#define D3P_COPY_LAUNCH(T_, n_)                                                                                                   \
+    do {                                                                                                                          \
+        if (nt) hipLaunchKernelGGL((k_hbm_copy<T_, 4, true>), dim3(grid), dim3(256), 0, s, (T_*)dst_dev, (const T_*)src_dev, n_); \
+        else hipLaunchKernelGGL((k_hbm_copy<T_, 4, false>), dim3(grid), dim3(256), 0, s, (T_*)dst_dev, (const T_*)src_dev, n_);   \
+    } while (0)
+    if (bytes_per_lane == 16) D3P_COPY_LAUNCH(d3p_copy16, bytes / 16);
+    else if (bytes_per_lane == 8) D3P_COPY_LAUNCH(unsigned long long, bytes / 8);
+    else D3P_COPY_LAUNCH(uint32_t, bytes / 4);
+#undef D3P_COPY_LAUNCH
     return check_launch("d3p_hbm_copy");
 }
 

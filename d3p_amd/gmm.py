@@ -1,8 +1,9 @@
 """Gaussian mixture density: mirror of ``d3p.gmm.GaussianMixture`` (reference d3p/gmm.py:26-107) for the part
 that is on the DP-VI path, ``log_prob`` (``d3p_gmm_log_prob``).  The DP-VI step of the mixture MODEL of
 examples/gaussian_mixture_model.py (BASELINE config 3) lives in ``d3p_amd/csrc/d3p_gmm.hip`` behind
-``d3p_amd.models.GaussianMixtureModel`` / ``DPSVI``; ancestral sampling (``sample`` /
-``sample_with_intermediates``, d3p/gmm.py:88-95) is off the update path and not built."""
+``d3p_amd.models.GaussianMixtureModel`` / ``DPSVI``.  Ancestral sampling (``sample`` /
+``sample_with_intermediates``, d3p/gmm.py:88-95) is off the update path; it takes a ``jax.random`` key in the reference, i.e. a
+threefry key here (``d3p_amd.random.debug`` keys), and runs on the threefry stream kernels."""
 import torch
 
 from . import _lib
@@ -50,3 +51,34 @@ class GaussianMixture:
                                            ptr(pis), k, ptr(out)))
         batch_shape = tuple(x.shape[:x.dim() - len(self.event_shape)])
         return out[0] if single else out.reshape(batch_shape)
+
+    def sample(self, key, sample_shape=()):
+        """d3p/gmm.py:88-89."""
+        return self.sample_with_intermediates(key, sample_shape)[0]
+
+    def sample_with_intermediates(self, key, sample_shape=()):
+        """d3p/gmm.py:91-95: ``component_key, samples_key = split(key)``; ``zs ~ Categorical(pi)`` of shape ``sample_shape``;
+        ``xs = locs[zs] + scales[zs] * normal(samples_key, sample_shape + event_shape)``.  ``key``: a threefry key (2 x uint32 CUDA
+        tensor, ``d3p_amd.random.debug.PRNGKey``), as the reference takes a ``jax.random`` key.  The component draw restates numpyro's
+        ``CategoricalProbs.sample`` for probabilities: one uniform per draw against the cumulative sums, ``sum(cumsum(p) < u)``
+        (numpyro's plumbing: UNPINNED like the rest of it).  Returns ``(xs, (zs,))``."""
+        _lib.require_device()
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")      # (the debug suite warns on import: sampling from a density is not a privacy mechanism)
+            from .random import debug as tf
+        shape = tuple(int(s) for s in tuple(sample_shape))
+        keys = tf.split(key, 2)
+        component_key, samples_key = keys[0], keys[1]
+        n = 1
+        for s_ in shape:
+            n *= s_
+        dev = keys.device
+        cum = torch.cumsum(self.mixture_probabilities.to(dev), dim=-1)
+        u = tf.uniform(component_key, shape + (1,))
+        zs = (cum < u).sum(dim=-1)                                        # in [0, k - 1] (k when u > the last cumulative sum: clamped)
+        zs = zs.clamp_(max=self.num_components - 1)
+        locs, scales = self.locs.to(dev), self.scales.to(dev)
+        eps = tf.normal(samples_key, shape + self.event_shape)
+        xs = locs[zs] + scales[zs] * eps
+        return xs, (zs,)

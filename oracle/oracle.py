@@ -506,6 +506,22 @@ def gmm_log_prob(x, locs, scales, pis):
     return out
 
 
+def gmm_sample_with_intermediates(key, locs, scales, pis, sample_shape=()):
+    """d3p/gmm.py:91-95 on the oracle's threefry functions: component_key, samples_key = split(key); zs = sum(cumsum(pi) < u) with
+    u = uniform(component_key, sample_shape + (1,)) (numpyro's CategoricalProbs.sample for probabilities: UNPINNED);
+    xs = locs[zs] + scales[zs] * normal(samples_key, sample_shape + event_shape).  float32 throughout."""
+    locs, scales, pis = _f32(locs), _f32(scales), _f32(pis)
+    shape = tuple(int(s) for s in sample_shape)
+    n = int(np.prod(shape)) if shape else 1
+    ks = tf_split(key, 2)
+    u = tf_uniform(ks[0], n).reshape(shape + (1,))
+    cum = np.cumsum(pis, dtype=np.float32)
+    zs = np.minimum((cum < u).sum(axis=-1), len(pis) - 1)
+    ev = locs.shape[1:]
+    eps = tf_normal(ks[1], n * int(np.prod(ev))).reshape(shape + ev)
+    return (locs[zs] + scales[zs] * eps).astype(np.float32), zs
+
+
 def synth_logreg(seed, row0, nrows, d):
     X = np.empty((nrows, d), np.float32)
     y = np.empty(nrows, np.float32)

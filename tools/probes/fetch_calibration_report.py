@@ -20,7 +20,8 @@ moved = float(1 << 30)
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"bytes_moved_each_way_per_launch": moved, "by_kernel": {}}
 for k in fetch:
-    width = 16 if "ext_vector" in k or "vector" in k else 8 if "long" in k else 4
+    targ = k.split("k_hbm_copy<", 1)[1].split(",", 1)[0]          # the element type: the template's first argument
+    width = 16 if "vector" in targ else 8 if "long" in targ else 4
     out["by_kernel"][f"{width}_bytes_per_lane"] = {
         "kernel": k, "FETCH_SIZE_KiB": fetch[k], "WRITE_SIZE_KiB": write.get(k),
         "fetch_reported_over_moved": fetch[k] * 1024.0 / moved,
