@@ -249,7 +249,8 @@ def load():
         # torch bundles its own libamdhip64; import it first so that the loader binds this
         # library to the SAME HIP runtime instance (two runtimes in one process do not share a device)
         import torch  # noqa: F401
-        lib = C.CDLL(_SO)
+        # D3P_HIP_LIBRARY: a developer switch -- load another build of the library (diagnostic instantiations: tools/gemm_diag.sh)
+        lib = C.CDLL(os.environ.get("D3P_HIP_LIBRARY") or _SO)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res

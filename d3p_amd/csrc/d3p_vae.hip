@@ -558,11 +558,18 @@ __global__ void __launch_bounds__(512) k_gemm_f32_w8(GemmArgs g)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 #define D3P_BLD 40   // row stride of a plane in bf16 elements
+// DIAGNOSTIC builds only (tools/gemm_diag.sh compiles this file with -DD3P_GEMM_DIAG=<bits> into a library of its own; results are
+// WRONG, only the time matters): 1 no splitting arithmetic (all planes = the top halves), 2 no global loads behind the first two
+// slices, 4 no staging at all (no splitting, no LDS writes), 8 fragments read once, 16 no MFMAs.  0 = the product kernel.
+#ifndef D3P_GEMM_DIAG
+#define D3P_GEMM_DIAG 0
+#endif
 // the three bf16 parts of two fp32 values, as three words {part of x1 (high half) | part of x0 (low half)}
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& w0, uint32_t& w1, uint32_t& w2)
 {
     const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
     w0 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    if (D3P_GEMM_DIAG & 1) { w1 = w0; w2 = w0; return; }
     const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
     const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
     w1 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
@@ -644,6 +651,7 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
         constexpr int s = decltype(S)::value;
         float4 &a0 = s ? ra10 : ra00, &a1 = s ? ra11 : ra01, &bb = s ? rb1 : rb0;
         const int k0 = fk[s];
+        if ((D3P_GEMM_DIAG & 2) && k0 >= kbeg + 2 * D3P_GKB) { fk[s] = k0 + 2 * D3P_GKB; return; }
         if (b_scaled) {
             const int gk = k0 + b_k;
             (s ? rs1 : rs0) = g.b_row_scale[gk < g.K ? gk : g.K - 1];
@@ -667,6 +675,7 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
     auto stage = [&](auto S, int buf, int k0, auto EDGE, auto A1P) {  // register set S (slice starting at k0): edges applied, split, three planes -> LDS
         constexpr int s = decltype(S)::value;
         constexpr bool A1 = decltype(A1P)::value;   // A is exactly bf16: plane 0 alone
+        if ((D3P_GEMM_DIAG & 4) && k0 >= kbeg + 2 * D3P_GKB) return;
         float4 bb = s ? rb1 : rb0;
         if (BN) { const float c = s ? rs1 : rs0; bb = make_float4(bb.x * c, bb.y * c, bb.z * c, bb.w * c); }
         float4 o[2] = {s ? ra10 : ra00, s ? ra11 : ra01};
@@ -739,8 +748,10 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
     };
     struct Frag { bf16x8 a[2][3], b[2][3]; };   // [k step of 16][plane]
     const int fr = lane & 31, fh = lane >> 5;
+    bool frags_read = false;
     auto read_frags = [&](int buf, Frag& f, auto A1P) {
         constexpr bool A1 = decltype(A1P)::value;
+        if (D3P_GEMM_DIAG & 8) { if (frags_read) return; frags_read = true; }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -752,6 +763,7 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
     };
     auto mma_half = [&](const Frag& f, int ks, auto A1P) {   // smallest terms first
         constexpr bool A1 = decltype(A1P)::value;
+        if (D3P_GEMM_DIAG & 16) return;
         if (!A1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][2], f.b[ks][0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][0], f.b[ks][2], acc, 0, 0, 0);
         if (!A1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks][1], f.b[ks][1], acc, 0, 0, 0);
@@ -773,6 +785,7 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
     fetch(S0{});
     __syncthreads();
     read_frags(0, f0, A1P);
+    if (D3P_GEMM_DIAG & 8) f1 = f0;
     const int ns = (kend - kbeg + KB - 1) / KB;
     // one MFMA, then a share of the other work of the same half slice: the bf16 matrix pipe runs beside the vector unit and the LDS,
     // but only what stands BETWEEN two MFMAs in a wave's instruction stream can run beside them
