@@ -558,6 +558,17 @@ __global__ void __launch_bounds__(512) k_gemm_f32_w8(GemmArgs g)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 #define D3P_BLD 40   // row stride of a plane in bf16 elements
+// Chunk swizzle of the planes (round 6): a row's K slice is four 16-byte chunks (8 bf16 each); row r keeps chunk c at position
+// c ^ parity(r & 0x1c).  The fragment reads stay conflict-free (the ds_read_b128 lane groups still meet 16 distinct slots of the
+// 256-byte bank row), and the staging stores of the m-fast A and n-fast B forms -- lanes 4 rows apart writing the same word of
+// their rows, banks 16 r mod 32: 4-way, twice the LDS-array cycles (SQ_LDS_BANK_CONFLICT was 55 % of SQ_LDS_IDX_ACTIVE in the
+// grouped weight-gradient launch, profiles/r06_vae_gemm_pmc.json) -- become 2-way, which a ds_write_b32 hides
+// (MI355X_MICROARCH.md, LDS; the layouts were searched with the guide's bank model).
+#ifdef D3P_NO_PLANE_SWZ   // (A/B builds: the unswizzled layout of rounds 3 - 5)
+__device__ __forceinline__ int plane_swz(int) { return 0; }
+#else
+__device__ __forceinline__ int plane_swz(int row) { return (__builtin_popcount((unsigned)row & 0x1cu) & 1) << 3; }   // XOR into the k index
+#endif
 // DIAGNOSTIC builds only (tools/gemm_diag.sh compiles this file with -DD3P_GEMM_DIAG=<bits> into a library of its own; results are
 // WRONG, only the time matters): 1 no splitting arithmetic (all planes = the top halves), 2 no global loads behind the first two
 // slices, 4 no staging at all (no splitting, no LDS writes), 8 fragments read once, 16 no MFMAs.  0 = the product kernel.
@@ -615,6 +626,9 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
     }
     // n-fast B: columns 4 ng .. 4 ng + 3 at ONE k; lanes l and l ^ 8 hold k and k ^ 1 of the same columns (bit 3 of tid = bit 0 of k)
     if (BN) { b_n = 4 * ((tid & 7) + 8 * (tid >> 8)); b_k = (tid >> 3) & 31; } else { b_n = tid >> 3; b_k = 4 * (tid & 7); }
+    // where this thread's share goes in the swizzled planes (plane_swz: rows 4 mg .. 4 mg + 3 share one swizzle, b_n likewise)
+    const int a_kw[2] = {a_k[0] ^ plane_swz(a_m[0]), a_k[1] ^ plane_swz(a_m[1])};
+    const int b_sw = plane_swz(b_n);
     const int K4 = (g.K + 3) & ~3;
     const int ka_last = AK ? K4 - 4 : g.K - 1, kb_last = BN ? g.K - 1 : K4 - 4;
     const int m_last = AK ? m_real - 1 : ((m_real + 3) & ~3) - 4, n_last = g.N - (BN ? 4 : 1);
@@ -702,13 +716,13 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 if (A1) {
-                    *reinterpret_cast<uint2*>(&Ap[buf][0][a_m[r]][a_k[r]]) = make_uint2(top16(o[r].x, o[r].y), top16(o[r].z, o[r].w));
+                    *reinterpret_cast<uint2*>(&Ap[buf][0][a_m[r]][a_kw[r]]) = make_uint2(top16(o[r].x, o[r].y), top16(o[r].z, o[r].w));
                 } else {
                     uint32_t x[3], y[3];
                     split_pair(o[r].x, o[r].y, x[0], x[1], x[2]);
                     split_pair(o[r].z, o[r].w, y[0], y[1], y[2]);
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(&Ap[buf][p][a_m[r]][a_k[r]]) = make_uint2(x[p], y[p]);
+                    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(&Ap[buf][p][a_m[r]][a_kw[r]]) = make_uint2(x[p], y[p]);
                 }
             }
         } else {   // four rows at k = 2 kp (o[0]) and 2 kp + 1 (o[1]): one word per row and plane
@@ -716,11 +730,11 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (A1) {
-                    *reinterpret_cast<uint32_t*>(&Ap[buf][0][a_m[0] + i][a_k[0]]) = top16(lo4[i], hi4[i]);
+                    *reinterpret_cast<uint32_t*>(&Ap[buf][0][a_m[0] + i][a_kw[0]]) = top16(lo4[i], hi4[i]);
                 } else {
                     split_pair(lo4[i], hi4[i], w[0], w[1], w[2]);
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint32_t*>(&Ap[buf][p][a_m[0] + i][a_k[0]]) = w[p];
+                    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint32_t*>(&Ap[buf][p][a_m[0] + i][a_kw[0]]) = w[p];
                 }
             }
         }
@@ -731,7 +745,7 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
             const float got1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give1), 0x128, 0xF, 0xF, false));
             // this lane's two columns at (k even, k odd)
             const float e0 = odd ? got0 : bb.x, o0 = odd ? bb.z : got0, e1 = odd ? got1 : bb.y, o1 = odd ? bb.w : got1;
-            const int nn = b_n + (odd ? 2 : 0), kk = b_k & ~1;
+            const int nn = b_n + (odd ? 2 : 0), kk = (b_k & ~1) ^ b_sw;   // (rows nn, nn + 1 lie in b_n's group of four: one swizzle)
             split_pair(e0, o0, w[0], w[1], w[2]);
 #pragma unroll
             for (int p = 0; p < 3; ++p) *reinterpret_cast<uint32_t*>(&Bp[buf][p][nn][kk]) = w[p];
@@ -743,11 +757,12 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
             split_pair(bb.x, bb.y, x[0], x[1], x[2]);
             split_pair(bb.z, bb.w, y[0], y[1], y[2]);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(&Bp[buf][p][b_n][b_k]) = make_uint2(x[p], y[p]);
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(&Bp[buf][p][b_n][b_k ^ b_sw]) = make_uint2(x[p], y[p]);
         }
     };
     struct Frag { bf16x8 a[2][3], b[2][3]; };   // [k step of 16][plane]
     const int fr = lane & 31, fh = lane >> 5;
+    const int f_sw = plane_swz(fr);   // (the wave's rows 32 wr + fr / 32 grp + fr: bits 2 - 4 are fr's)
     bool frags_read = false;
     auto read_frags = [&](int buf, Frag& f, auto A1P) {
         constexpr bool A1 = decltype(A1P)::value;
@@ -757,8 +772,8 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 if (!A1 || p == 0)
-                    f.a[ks][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Ap[buf][p][32 * wr + fr][16 * ks + 8 * fh]));
-                f.b[ks][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Bp[buf][p][32 * grp + fr][16 * ks + 8 * fh]));
+                    f.a[ks][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Ap[buf][p][32 * wr + fr][(16 * ks + 8 * fh) ^ f_sw]));
+                f.b[ks][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(&Bp[buf][p][32 * grp + fr][(16 * ks + 8 * fh) ^ f_sw]));
             }
     };
     auto mma_half = [&](const Frag& f, int ks, auto A1P) {   // smallest terms first
