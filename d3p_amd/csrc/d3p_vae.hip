@@ -575,9 +575,21 @@ __device__ __forceinline__ int plane_swz(int row) { return (__builtin_popcount((
 #ifndef D3P_GEMM_DIAG
 #define D3P_GEMM_DIAG 0
 #endif
-// the three bf16 parts of two fp32 values, as three words {part of x1 (high half) | part of x0 (low half)}
+// the three bf16 parts of two fp32 values, as three words {part of x1 (high half) | part of x0 (low half)}: truncations (the top 8,
+// the next 8 and the last 8 bits of the 24-bit significand), so each remainder is exact.  11 vector instructions per pair:
+// 4 v_and, 4 v_sub (VOP2: 2.4 cycles each), 3 v_perm (4.3).
+// -DD3P_SPLIT_RNE (round 6, built and measured, NOT adopted): ROUND-TO-NEAREST parts -- x0 = rn(x), r = x - x0, x1 = rn(r),
+// s = r - x1, x2 = s: exact too for every |x| > 2^-110, and smaller parts -- as 3 v_cvt_pk_bf16_f32 (both elements at once, the
+// packed word the LDS wants) + 2 v_lshl + 2 v_and + 2 v_pk_add_f32 = 9 instructions per pair.  FEWER instructions (60 instead of 72
+// per wave and K slice) and SLOWER: h1 32.8 -> 34.3 us, the VAE update 249 -> 253.5 us on one box, alternating
+// (profiles/r06_split_rne_ab.txt) -- the converting and the packed instructions issue at the VOP3 / packed rate or worse
+// (profiles/r03_valu_opcodes.json: 4.3 cycles against 2.4), and beside the bf16 MFMAs issue time is what counts
+// (docs/experiments_r06.md section 3).
+typedef float d3p_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 d3p_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& w0, uint32_t& w1, uint32_t& w2)
 {
+#ifndef D3P_SPLIT_RNE
     const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
     w0 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
     if (D3P_GEMM_DIAG & 1) { w1 = w0; w2 = w0; return; }
@@ -586,6 +598,23 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& w0, uin
     w1 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
     const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
     w2 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+#else
+    // (the packed subtraction by name: left to itself the compiler takes v_pk_add_f32 for half of the pairs and two v_add_f32 for the rest)
+    auto pk_sub = [](d3p_f32x2 a, d3p_f32x2 b) {
+        d3p_f32x2 d;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+        return d;
+    };
+    const d3p_f32x2 x = {x0, x1};
+    w0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, d3p_bf16x2));
+    if (D3P_GEMM_DIAG & 1) { w1 = w0; w2 = w0; return; }
+    const d3p_f32x2 h0 = {__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u)};
+    const d3p_f32x2 r = pk_sub(x, h0);
+    w1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, d3p_bf16x2));
+    const d3p_f32x2 h1 = {__uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u)};
+    const d3p_f32x2 sres = pk_sub(r, h1);
+    w2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(sres, d3p_bf16x2));
+#endif
 }
 
 // one 128 x 64 tile (tx, ty) of K slab tz of the product g, by one 8-wave workgroup
@@ -804,10 +833,15 @@ __device__ __forceinline__ void gemm_bf16x3_tile(const GemmArgs& g, const int tx
     const int ns = (kend - kbeg + KB - 1) / KB;
     // one MFMA, then a share of the other work of the same half slice: the bf16 matrix pipe runs beside the vector unit and the LDS,
     // but only what stands BETWEEN two MFMAs in a wave's instruction stream can run beside them
+#ifndef D3P_SPLIT_RNE
+#define D3P_MIX_VALU 12
+#else
+#define D3P_MIX_VALU 10
+#endif
 #define D3P_MIX_STAGE()                                                                                     \
     _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                                                      \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  /* 1 MFMA */                                    \
-        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0); /* 12 VALU (splitting) */                       \
+        __builtin_amdgcn_sched_group_barrier(0x002, D3P_MIX_VALU, 0); /* the splitting's vector instructions */ \
         __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);  /* 2 LDS writes */                              \
     }
 #define D3P_MIX_READ()                                                                                      \
