@@ -22,7 +22,7 @@ the intercept FIRST, while this build's kernels keep it as the last latent colum
 ``jax.random.normal(key, (D,))`` (UNPINNED -- DESIGN.md section 2 -- until the capture script has been run)."""
 from . import _lib
 from .models import (AutoDiagonalNormal, DiagonalNormalGuide, GaussianMean, GaussianMixtureGuide,
-                     GaussianMixtureModel, LogisticRegression)
+                     GaussianMixtureModel, LogisticRegression, MeanFieldGuide)
 
 
 class FlatLayout:
@@ -141,9 +141,67 @@ def spec_from_sites(records):
                         f"{(obs['name'], obs['dist'], obs['shape'])}")
 
 
+def trace_guide(guide, *args, **kwargs):
+    """Run a hand-written guide once under numpyro's seed + trace handlers: its ``param`` and ``sample`` statements IN PROGRAM ORDER as
+    plain records ``{name, type, dist, shape}`` (the order of the sample statements is the order in which numpyro's seed handler hands
+    out the sites' keys: DESIGN.md section 4)."""
+    try:
+        import numpyro  # noqa: F401
+        from numpyro import handlers
+    except ImportError as e:
+        raise _lib.D3PError("d3p_amd.numpyro_adapter.trace_guide needs numpyro (absent here): " + str(e))
+    tr = handlers.trace(handlers.seed(guide, 0)).get_trace(*args, **kwargs)
+    records = []
+    for name, site in tr.items():
+        if site["type"] not in ("sample", "param"):
+            continue
+        base = site.get("fn")
+        while hasattr(base, "base_dist"):
+            base = base.base_dist
+        records.append({"name": name, "type": site["type"], "dist": type(base).__name__ if site["type"] == "sample" else None,
+                        "shape": tuple(getattr(site["value"], "shape", ()))})
+    return records
+
+
+def guide_spec_from_sites(spec, guide_records):
+    """The records of a hand-written guide (trace_guide) -> the guide spec this build has for it, or D3PError.  Recognised: the
+    examples' mean-field guides, whose every sample site ``s`` is ``Normal(param(s + '_loc'), exp(param(s + '_std_log')))``:
+    one site over the model's latent vector -> DiagonalNormalGuide (examples/simple_gaussian_posterior.py:67-82); the sites ``w``
+    THEN ``intercept`` of the logistic regression -> MeanFieldGuide (examples/logistic_regression.py:67-86: four leaves, one
+    perturbation key per leaf, the sites' eps keys in this program order)."""
+    samples = [r for r in guide_records if r["type"] == "sample"]
+    params = {r["name"]: r for r in guide_records if r["type"] == "param"}
+    names = [r["name"] for r in samples]
+    want = set()
+    for r in samples:
+        if r["dist"] != "Normal":
+            raise _lib.D3PError(f"numpyro adapter: guide site {r['name']} is {r['dist']}, not Normal")
+        want |= {r["name"] + "_loc", r["name"] + "_std_log"}
+    if set(params) != want:
+        raise _lib.D3PError(f"numpyro adapter: guide parameters {sorted(params)} are not the <site>_loc / <site>_std_log of its sites {names}")
+    for r in samples:
+        if params[r["name"] + "_loc"]["shape"] != r["shape"] or params[r["name"] + "_std_log"]["shape"] != r["shape"]:
+            raise _lib.D3PError(f"numpyro adapter: parameter shapes of guide site {r['name']} do not match the site's shape {r['shape']}")
+    if sorted(names) != sorted(spec.site_names()):
+        raise _lib.D3PError(f"numpyro adapter: guide sites {names} are not the model's latent sites {list(spec.site_names())}")
+    if len(names) == 1:
+        return DiagonalNormalGuide(spec, site=names[0])
+    if isinstance(spec, LogisticRegression) and spec.intercept:
+        gspec = MeanFieldGuide(spec)
+        order = [n for n, _ in gspec.sites(spec.d)]
+        # the model's OWN names may differ from 'w' / 'intercept': the vector site first, the scalar site second
+        vec_first = len(samples[0]["shape"]) == 1 and samples[1]["shape"] == ()
+        if not vec_first:
+            raise _lib.D3PError(f"numpyro adapter: the guide samples {names}; this build draws the sites' eps keys in the order "
+                                f"{order} (vector site, then intercept) -- another program order gives the sites other keys")
+        return gspec
+    raise _lib.D3PError(f"numpyro adapter: no built guide for the sample sites {names}")
+
+
 def from_numpyro(model, guide, *args, **kwargs):
     """numpyro model (+ ``numpyro.infer.autoguide.AutoDiagonalNormal`` instance or one of the examples' hand-written
-    guides, recognised by name) -> ``(model_spec, guide_spec, FlatLayout, num_obs_total)`` for ``d3p_amd.svi.DPSVI``."""
+    guides, traced and recognised by their sites and parameters) -> ``(model_spec, guide_spec, FlatLayout, num_obs_total)`` for
+    ``d3p_amd.svi.DPSVI``."""
     records = trace_model(model, *args, **kwargs)
     spec, layout, n_total = spec_from_sites(records)
     gname = type(guide).__name__
@@ -151,8 +209,8 @@ def from_numpyro(model, guide, *args, **kwargs):
         gspec = GaussianMixtureGuide(spec)
     elif gname == "AutoDiagonalNormal":
         gspec = AutoDiagonalNormal(spec, init_scale=float(getattr(guide, "_init_scale", 0.1)))
-    elif callable(guide) and isinstance(spec, GaussianMean):
-        gspec = DiagonalNormalGuide(spec)
+    elif callable(guide):
+        gspec = guide_spec_from_sites(spec, trace_guide(guide, *args, **kwargs))
     else:
         raise _lib.D3PError(f"numpyro adapter: guide {gname} is not AutoDiagonalNormal nor one of the examples' guides")
     return spec, gspec, layout, n_total

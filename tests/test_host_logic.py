@@ -201,6 +201,43 @@ def test_numpyro_adapter_maps_trace_records_to_the_built_families():
         trace_model(lambda: None)
 
 
+def test_numpyro_adapter_recognises_the_examples_hand_written_guides():
+    """guide_spec_from_sites: the records of a traced hand-written guide (param and sample statements in program order) -> the guide
+    spec.  The logistic-regression example's OWN guide (examples/logistic_regression.py:67-86) -> MeanFieldGuide; the one-site guide of
+    examples/simple_gaussian_posterior.py:67-82 -> DiagonalNormalGuide; anything else is refused with the reason."""
+    from d3p_amd._lib import D3PError
+    from d3p_amd.models import DiagonalNormalGuide, GaussianMean, LogisticRegression, MeanFieldGuide
+    from d3p_amd.numpyro_adapter import guide_spec_from_sites
+
+    def par(name, shape):
+        return {"name": name, "type": "param", "dist": None, "shape": tuple(shape)}
+
+    def smp(name, shape, dist="Normal"):
+        return {"name": name, "type": "sample", "dist": dist, "shape": tuple(shape)}
+    d = 5
+    lr = LogisticRegression(d, intercept=True)
+    example = [par("w_loc", (d,)), par("w_std_log", (d,)), smp("w", (d,)), par("intercept_loc", ()), par("intercept_std_log", ()),
+               smp("intercept", ())]
+    g = guide_spec_from_sites(lr, example)
+    assert isinstance(g, MeanFieldGuide) and g.param_names() == ("intercept_loc", "intercept_std_log", "w_loc", "w_std_log")
+    assert g.leaf_sizes(d) == [1, 1, d, d] and g.sites(d) == [("w", d), ("intercept", 1)]
+    assert MeanFieldGuide.tree_from_kernel(2).tolist() == [2, 5, 0, 1, 3, 4]      # kernel order [w0 w1 b | s0 s1 sb] -> tree order
+    with pytest.raises(D3PError, match="program order"):      # intercept sampled first: the sites would take each other's keys
+        guide_spec_from_sites(lr, [par("intercept_loc", ()), par("intercept_std_log", ()), smp("intercept", ()), par("w_loc", (d,)),
+                                   par("w_std_log", (d,)), smp("w", (d,))])
+    with pytest.raises(D3PError, match="parameters"):         # another parametrisation (a softplus scale, say)
+        guide_spec_from_sites(lr, [par("w_loc", (d,)), par("w_scale", (d,)), smp("w", (d,)), par("intercept_loc", ()),
+                                   par("intercept_std_log", ()), smp("intercept", ())])
+    with pytest.raises(D3PError, match="not Normal"):
+        guide_spec_from_sites(lr, [par("w_loc", (d,)), par("w_std_log", (d,)), smp("w", (d,), "Laplace"), par("intercept_loc", ()),
+                                   par("intercept_std_log", ()), smp("intercept", ())])
+    gm = GaussianMean(4)
+    g1 = guide_spec_from_sites(gm, [par("mu_loc", (4,)), par("mu_std_log", (4,)), smp("mu", (4,))])
+    assert isinstance(g1, DiagonalNormalGuide) and g1.param_names() == ("mu_loc", "mu_std_log")
+    with pytest.raises(ValueError):                           # MeanFieldGuide needs more than one site
+        MeanFieldGuide(LogisticRegression(3))
+
+
 # ---- d3p.util shape / type predicates (known answers of the reference's tests/test_util.py:30-327)
 
 def test_util_map_over_secondary_dims_with_sum():
