@@ -21,6 +21,7 @@ Checks (exit code 0 = all hold):
  (c) the oracle anchor: ONE data-parallel step with a mask that keeps 12 examples of every rank's shard (the kernels run at the
      full per-rank shape); Adam's first moment after it against  O.vae_step_sums  on exactly those examples (eps keyed by GLOBAL
      position) -> O.perturb (one key per leaf, noise once) -> O.adam."""
+import ctypes
 import json
 import os
 import socket
@@ -160,9 +161,8 @@ def rank_main():
     B = b_local * world
     make, X = _problem(B)
     Xd = X.cuda()
-    from d3p_amd.svi import DPSVI  # noqa: F401
     import d3p_amd._lib as L
-    P = int(L.load().d3p_vae_num_params(__import__("ctypes").byref(make()._vae_struct(D, {}, 1.0))))
+    P = int(L.load().d3p_vae_num_params(ctypes.byref(make()._vae_struct(D, {}, 1.0))))
     st0, params = _initial_state(make, P, 85)
     comm = ddist.FMeshComm(P + 2)
     if shared:
@@ -265,7 +265,7 @@ def virtual_main(world):
     B = b_local * world
     make, X = _problem(B)
     Xd = X.cuda()
-    P = int(L.load().d3p_vae_num_params(__import__("ctypes").byref(make()._vae_struct(D, {}, 1.0))))
+    P = int(L.load().d3p_vae_num_params(ctypes.byref(make()._vae_struct(D, {}, 1.0))))
     st0, params = _initial_state(make, P, 86)
     comms = ddist.FMeshComm.local_group(world, P + 2)
     for c in comms:
