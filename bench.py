@@ -384,7 +384,9 @@ def vae_dist_workload(dev, world, rank, group_barrier, share_gpu=False, emulate=
             # ---- correctness first: 3 steps per driver from the same state
             check, ref = {}, None
             for name, kw in drivers:
-                s3, l3 = ddist.vae_run_steps(ddist.VaeHipEngine(svi), st0, X, Bg, pos0, 3, **kw)
+                # (a mesh driver's status is read below and AGREED over the ranks: no rank raises alone in front of the all_gather)
+                kw3 = dict(kw, check_status=False) if (mesh is not None and kw.get("comm") is mesh) else kw
+                s3, l3 = ddist.vae_run_steps(ddist.VaeHipEngine(svi), st0, X, Bg, pos0, 3, **kw3)
                 torch.cuda.synchronize()
                 sig = torch.cat([s3.optim_state[0].reshape(1).to(torch.int32), s3.rng_key.reshape(16).view(torch.int32),
                                  s3.optim_state[1].view(torch.int32)]).contiguous()

@@ -70,9 +70,6 @@ class GaussianMixture:
         shape = tuple(int(s) for s in tuple(sample_shape))
         keys = tf.split(key, 2)
         component_key, samples_key = keys[0], keys[1]
-        n = 1
-        for s_ in shape:
-            n *= s_
         dev = keys.device
         cum = torch.cumsum(self.mixture_probabilities.to(dev), dim=-1)
         u = tf.uniform(component_key, shape + (1,))
