@@ -131,6 +131,52 @@ def test_single_rank_run_steps_skips_the_collective(O):
     np.testing.assert_allclose(losses.numpy(), ref_losses, rtol=1e-5)
 
 
+def _teardown_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import time
+    import torch.distributed as dist
+    from d3p_amd.dist import _teardown_barrier
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class FakeComm:     # what XchgComm / FMeshComm hand to the teardown: a handle, whether the ranks share a process, the world
+        handle, local, world, group = 1234, False, 2, None
+    log = []
+
+    def disconnect(handle):
+        log.append(("unmapped", time.monotonic()))
+        return 0
+    if rank == 1:
+        time.sleep(0.5)                       # the slow rank: still has its peer's inbox mapped while rank 0 is already closing
+    _teardown_barrier(FakeComm(), None, disconnect)
+    log.append(("may free", time.monotonic()))
+    alone = []
+    FakeComm.world = 2
+    t0 = time.monotonic()
+    if rank == 0:                             # a rank that closes ALONE (its peer has no communicator): no barrier, no waiting
+        _teardown_barrier(FakeComm(), False, lambda h: alone.append(h) or 0)
+    out[rank] = (log, alone, time.monotonic() - t0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_communicator_teardown_is_ordered_over_the_ranks():
+    """XchgComm.close / FMeshComm.close (d3p_amd.dist._teardown_barrier): every rank unmaps its peers' inboxes, the ranks meet, and
+    only then does anybody free its own inbox -- the order whose absence broke the next hipIpcGetMemHandle of a rank that was
+    first out of close() (round 6, found by the four-process GPU test).  World 2 on gloo, a stand-in communicator: rank 0 must not get
+    to 'may free' before the slow rank 1 has unmapped; `collective=False` does not wait for anybody."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 30500 + (os.getpid() % 2000)
+    mp.spawn(_teardown_worker, args=(2, port, out), nprocs=2, join=True)
+    (log0, alone0, dt0), (log1, _, _) = out[0], out[1]
+    unmapped1 = dict(log1)["unmapped"]
+    assert dict(log0)["unmapped"] < unmapped1                      # rank 0 was first to unmap (rank 1 slept) ...
+    assert dict(log0)["may free"] >= unmapped1                     # ... and still did not free before rank 1 had unmapped too
+    assert alone0 == [1234] and dt0 < 0.4                          # closing alone: disconnect called, nobody waited for
+
+
 # ------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 8])
