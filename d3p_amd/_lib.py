@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libd3p_hip.so")
 _SRC = [os.path.join(_HERE, "csrc", f) for f in ("d3p_rng.hip", "d3p_dpvi.hip", "d3p_stages.hip", "d3p_gmm.hip", "d3p_vae.hip", "d3p_fmesh.hip")]
-_DEPS = _SRC + [os.path.join(_HERE, "csrc", f) for f in ("d3p_device.h", "d3p_host.h", "d3p_logreg_kernel.h", "d3p_logreg_chain.h", "d3p_logreg_persist.h", "d3p_logreg_wide.h", "d3p_fmesh.h")] + [
+_DEPS = _SRC + [os.path.join(_HERE, "csrc", f) for f in ("d3p_device.h", "d3p_host.h", "d3p_logreg_kernel.h", "d3p_logreg_chain.h", "d3p_logreg_persist.h", "d3p_logreg_wide.h", "d3p_fmesh.h", "d3p_ipc_arena.h")] + [
     os.path.join(os.path.dirname(_HERE), "include", "d3p_hip.h")]
 
 D3P_BATCH_EXPLICIT, D3P_BATCH_FEISTEL, D3P_BATCH_POISSON = 0, 1, 2

@@ -21,6 +21,7 @@
 #include "d3p_logreg_persist.h"
 #include "d3p_logreg_chain.h"
 #include "d3p_logreg_wide.h"
+#include "d3p_ipc_arena.h"
 
 #include <dlfcn.h>
 #include <mutex>
@@ -1689,6 +1690,7 @@ struct Xchg {
     // ll[2][world][D3P_STEP_BATCH] words of 16 bytes, with its own epoch (one exchange per prepared batch of steps)
     size_t cbox_off;
     unsigned long long cepoch;
+    bool in_arena;                     // the inbox is a range of the process's hipIpc arena (d3p_ipc_arena.h)
 };
 
 static inline size_t xchg_inbox_bytes(int world, uint32_t words) { return align_up((size_t)2 * world * words * 16, 256); }
@@ -2324,7 +2326,7 @@ int d3p_comm_destroy(void* comm)
 
 int d3p_xchg_create(int32_t world, int32_t rank, uint32_t words, void** xchg_out, uint8_t* handle_out, size_t handle_bytes)
 {
-    D3P_REQUIRE(xchg_out && handle_out && handle_bytes >= sizeof(hipIpcMemHandle_t), "d3p_xchg_create: null pointer or handle buffer < 64 bytes");
+    D3P_REQUIRE(xchg_out && handle_out && handle_bytes >= D3P_IPC_HANDLE_BYTES, "d3p_xchg_create: null pointer or handle buffer < 80 bytes");
     D3P_REQUIRE(world >= 1 && world <= D3P_XCHG_MAX_WORLD && rank >= 0 && rank < world && words >= 1, "d3p_xchg_create: bad arguments");
     Xchg* x = new Xchg();
     x->world = world;
@@ -2334,15 +2336,12 @@ int d3p_xchg_create(int32_t world, int32_t rank, uint32_t words, void** xchg_out
     x->cbox_off = xchg_inbox_bytes(world, words);
     x->cepoch = 0;
     x->inbox_bytes = x->cbox_off + xchg_cbox_bytes(world);
-    void* p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(&p, x->inbox_bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) { delete x; return fail(D3P_E_HIP, "d3p_xchg_create: hipExtMallocWithFlags: %s", hipGetErrorString(e)); }
-    x->inbox = (char*)p;
-    e = hipMemset(p, 0, x->inbox_bytes);
-    hipIpcMemHandle_t h;
-    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
-    if (e != hipSuccess) { (void)hipFree(p); delete x; return fail(D3P_E_HIP, "d3p_xchg_create: %s", hipGetErrorString(e)); }
-    memcpy(handle_out, &h, sizeof(h));
+    // the inbox: a zeroed range of the process's hipIpc arena (d3p_ipc_arena.h), or an allocation of its own when it does not fit
+    IpcRange r;
+    if (int rc = ipc_range_create(x->inbox_bytes, &r, handle_out, "d3p_xchg_create")) { delete x; return rc; }
+    x->inbox = r.ptr;
+    x->inbox_bytes = r.bytes;
+    x->in_arena = r.in_arena;
     for (int i = 0; i < D3P_XCHG_MAX_WORLD; ++i) { x->peer[i] = nullptr; x->opened[i] = false; }
     x->peer[rank] = x->inbox;
     *xchg_out = x;
@@ -2351,17 +2350,11 @@ int d3p_xchg_create(int32_t world, int32_t rank, uint32_t words, void** xchg_out
 
 int d3p_xchg_connect(void* xchg, const uint8_t* handles, size_t handle_stride)
 {
-    D3P_REQUIRE(xchg && handles && handle_stride >= sizeof(hipIpcMemHandle_t), "d3p_xchg_connect: bad arguments");
+    D3P_REQUIRE(xchg && handles && handle_stride >= D3P_IPC_HANDLE_BYTES, "d3p_xchg_connect: bad arguments (handles are 80 bytes)");
     Xchg* x = (Xchg*)xchg;
     for (int p = 0; p < x->world; ++p) {
         if (p == x->rank) continue;
-        hipIpcMemHandle_t h;
-        memcpy(&h, handles + (size_t)p * handle_stride, sizeof(h));
-        void* q = nullptr;
-        const hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) return fail(D3P_E_HIP, "d3p_xchg_connect: hipIpcOpenMemHandle(rank %d): %s", p, hipGetErrorString(e));
-        x->peer[p] = (char*)q;
-        x->opened[p] = true;
+        if (int rc = ipc_peer_open(handles + (size_t)p * handle_stride, &x->peer[p], &x->opened[p], "d3p_xchg_connect", p)) return rc;
     }
     return D3P_OK;
 }
@@ -2386,12 +2379,11 @@ int d3p_xchg_disconnect(void* xchg)
     if (!xchg) return D3P_OK;
     Xchg* x = (Xchg*)xchg;
     for (int p = 0; p < x->world; ++p)
-        if (x->opened[p]) {
-            (void)hipIpcCloseMemHandle(x->peer[p]);
+        if (p != x->rank && x->peer[p]) {
+            ipc_peer_close(x->peer[p], x->opened[p]);   // (a range of a peer's arena stays mapped: nothing to undo)
             x->opened[p] = false;
             x->peer[p] = nullptr;
         }
-    (void)hipGetLastError();
     return D3P_OK;
 }
 
@@ -2400,9 +2392,10 @@ int d3p_xchg_destroy(void* xchg)
     if (!xchg) return D3P_OK;
     Xchg* x = (Xchg*)xchg;
     for (int p = 0; p < x->world; ++p)
-        if (x->opened[p]) (void)hipIpcCloseMemHandle(x->peer[p]);
-    (void)hipFree(x->inbox);
-    (void)hipGetLastError();
+        if (p != x->rank) ipc_peer_close(x->peer[p], x->opened[p]);
+    IpcRange r;
+    r.ptr = x->inbox; r.bytes = x->inbox_bytes; r.in_arena = x->in_arena;
+    ipc_range_destroy(&r);
     delete x;
     return D3P_OK;
 }

@@ -21,6 +21,7 @@ struct FMesh {
     size_t inbox_bytes;
     char* peer[D3P_FMESH_MAX_WORLD];
     bool opened[D3P_FMESH_MAX_WORLD];
+    bool in_arena;     // the inbox is a range of the process's hipIpc arena (d3p_ipc_arena.h)
 };
 
 inline size_t fmesh_region_words(int world, uint64_t chunk) { return (size_t)2 * world * chunk; }

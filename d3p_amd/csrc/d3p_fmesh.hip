@@ -23,8 +23,13 @@
 // takes a CU's whole register file can never start on a GPU whose every CU holds a waiting workgroup of this launch:
 // d3p_fmesh_set_grid (d3p_fmesh_connect_local sets 48).
 #include "d3p_fmesh.h"
+#include "d3p_ipc_arena.h"
 
+#include <array>
+#include <map>
+#include <mutex>
 #include <new>
+#include <vector>
 
 namespace d3p {
 
@@ -145,13 +150,149 @@ int fmesh_enqueue_allreduce(hipStream_t s, void* fmesh, float* buf, uint64_t n)
 
 }  // namespace d3p
 
+
+// ---- the process's hipIpc arena (d3p_ipc_arena.h)
+namespace {
+struct Arena {
+    std::mutex mu;
+    bool tried = false;
+    char* base = nullptr;
+    size_t bytes = 0;
+    hipIpcMemHandle_t handle;
+    std::vector<std::pair<size_t, size_t>> live;                 // (offset, bytes) of the ranges in use, in address order
+    std::map<std::array<uint8_t, 64>, char*> peers;              // arenas of other processes mapped here, by their hipIpc handle
+};
+Arena& arena() { static Arena a; return a; }
+
+// (under the arena's lock) the allocation + its ONE export; false: no arena (switched off, or the export failed)
+bool arena_ready(Arena& A)
+{
+    if (A.tried) return A.base != nullptr;
+    A.tried = true;
+    size_t mb = 256;
+    if (const char* e = getenv("D3P_IPC_ARENA_MB")) mb = (size_t)strtoull(e, nullptr, 10);
+    if (mb == 0) return false;
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, mb << 20, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipIpcGetMemHandle(&A.handle, p) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return false; }
+    A.base = (char*)p;
+    A.bytes = mb << 20;
+    return true;
+}
+}  // namespace
+
+namespace d3p {
+
+int ipc_range_create(size_t bytes, IpcRange* out, uint8_t handle_out[D3P_IPC_HANDLE_BYTES], const char* who)
+{
+    bytes = (bytes + 255) & ~(size_t)255;
+    memset(handle_out, 0, D3P_IPC_HANDLE_BYTES);
+    Arena& A = arena();
+    {
+        std::lock_guard<std::mutex> lk(A.mu);
+        if (arena_ready(A)) {   // first fit between the live ranges
+            size_t off = 0;
+            size_t at = 0;
+            bool found = false;
+            for (; at <= A.live.size(); ++at) {
+                const size_t end = at < A.live.size() ? A.live[at].first : A.bytes;
+                if (end >= off && end - off >= bytes) { found = true; break; }
+                if (at < A.live.size()) off = A.live[at].first + A.live[at].second;
+            }
+            if (found) {
+                A.live.insert(A.live.begin() + (long)at, std::make_pair(off, bytes));
+                out->ptr = A.base + off;
+                out->bytes = bytes;
+                out->in_arena = true;
+                memcpy(handle_out, &A.handle, sizeof(A.handle));
+                const uint64_t o = off, marker = 1;
+                memcpy(handle_out + 64, &o, 8);
+                memcpy(handle_out + 72, &marker, 8);
+            }
+        }
+    }
+    if (out->in_arena) {
+        const hipError_t e = hipMemset(out->ptr, 0, bytes);
+        if (e != hipSuccess) { ipc_range_destroy(out); return fail(D3P_E_HIP, "%s: hipMemset of the %zu-byte inbox: %s", who, bytes, hipGetErrorString(e)); }
+        return D3P_OK;
+    }
+    // no room in the arena (or no arena): an allocation and an export of its own
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) return fail(D3P_E_HIP, "%s: hipExtMallocWithFlags(%zu bytes): %s", who, bytes, hipGetErrorString(e));
+    const char* what = "hipMemset";
+    e = hipMemset(p, 0, bytes);
+    hipIpcMemHandle_t h;
+    if (e == hipSuccess) { what = "hipIpcGetMemHandle"; e = hipIpcGetMemHandle(&h, p); }
+    if (e != hipSuccess) { (void)hipFree(p); return fail(D3P_E_HIP, "%s: %s of the %zu-byte inbox: %s", who, what, bytes, hipGetErrorString(e)); }
+    memcpy(handle_out, &h, sizeof(h));
+    out->ptr = (char*)p;
+    out->bytes = bytes;
+    out->in_arena = false;
+    return D3P_OK;
+}
+
+void ipc_range_destroy(IpcRange* r)
+{
+    if (!r->ptr) return;
+    if (r->in_arena) {
+        Arena& A = arena();
+        std::lock_guard<std::mutex> lk(A.mu);
+        const size_t off = (size_t)(r->ptr - A.base);
+        for (size_t i = 0; i < A.live.size(); ++i)
+            if (A.live[i].first == off) { A.live.erase(A.live.begin() + (long)i); break; }
+    } else {
+        (void)hipFree(r->ptr);
+        (void)hipGetLastError();
+    }
+    r->ptr = nullptr;
+}
+
+int ipc_peer_open(const uint8_t handle[D3P_IPC_HANDLE_BYTES], char** ptr_out, bool* opened_out, const char* who, int peer_rank)
+{
+    uint64_t off = 0, marker = 0;
+    memcpy(&off, handle + 64, 8);
+    memcpy(&marker, handle + 72, 8);
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    if (marker == 1) {   // a range of the peer's arena: the arena is mapped once per process and kept
+        Arena& A = arena();
+        std::lock_guard<std::mutex> lk(A.mu);
+        std::array<uint8_t, 64> key;
+        memcpy(key.data(), handle, 64);
+        auto it = A.peers.find(key);
+        if (it == A.peers.end()) {
+            void* q = nullptr;
+            const hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) return fail(D3P_E_HIP, "%s: hipIpcOpenMemHandle(arena of rank %d): %s", who, peer_rank, hipGetErrorString(e));
+            it = A.peers.emplace(key, (char*)q).first;
+        }
+        *ptr_out = it->second + off;
+        *opened_out = false;
+        return D3P_OK;
+    }
+    void* q = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(D3P_E_HIP, "%s: hipIpcOpenMemHandle(rank %d): %s", who, peer_rank, hipGetErrorString(e));
+    *ptr_out = (char*)q;
+    *opened_out = true;
+    return D3P_OK;
+}
+
+void ipc_peer_close(char* ptr, bool opened)
+{
+    if (opened && ptr) { (void)hipIpcCloseMemHandle(ptr); (void)hipGetLastError(); }
+}
+
+}  // namespace d3p
+
 using namespace d3p;
 
 extern "C" {
 
 int d3p_fmesh_create(int32_t world, int32_t rank, uint64_t n_floats, void** fmesh_out, uint8_t* handle_out, size_t handle_bytes)
 {
-    D3P_REQUIRE(fmesh_out && handle_out && handle_bytes >= sizeof(hipIpcMemHandle_t), "d3p_fmesh_create: null pointer or handle buffer < 64 bytes");
+    D3P_REQUIRE(fmesh_out && handle_out && handle_bytes >= D3P_IPC_HANDLE_BYTES, "d3p_fmesh_create: null pointer or handle buffer < 80 bytes");
     D3P_REQUIRE(world >= 1 && world <= D3P_FMESH_MAX_WORLD && rank >= 0 && rank < world && n_floats >= 1, "d3p_fmesh_create: bad arguments");
     FMesh* x = new (std::nothrow) FMesh();
     if (!x) return fail(D3P_E_HIP, "d3p_fmesh_create: out of host memory");
@@ -162,15 +303,12 @@ int d3p_fmesh_create(int32_t world, int32_t rank, uint64_t n_floats, void** fmes
     x->epoch = 0;
     x->wgs = D3P_FMESH_WGS;
     x->inbox_bytes = 2 * fmesh_region_words(world, x->chunk) * sizeof(unsigned long long) + 64;
-    void* p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(&p, x->inbox_bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) { delete x; return fail(D3P_E_HIP, "d3p_fmesh_create: hipExtMallocWithFlags: %s", hipGetErrorString(e)); }
-    x->inbox = (char*)p;
-    e = hipMemset(p, 0, x->inbox_bytes);   // (tag 0 is never waited for: epochs count from 1)
-    hipIpcMemHandle_t h;
-    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
-    if (e != hipSuccess) { (void)hipFree(p); delete x; return fail(D3P_E_HIP, "d3p_fmesh_create: %s", hipGetErrorString(e)); }
-    memcpy(handle_out, &h, sizeof(h));
+    // the inbox: a zeroed range of the process's hipIpc arena (d3p_ipc_arena.h), or an allocation of its own when it does not fit
+    IpcRange r;
+    if (int rc = ipc_range_create(x->inbox_bytes, &r, handle_out, "d3p_fmesh_create")) { delete x; return rc; }   // (tag 0 is never waited for: epochs count from 1)
+    x->inbox = r.ptr;
+    x->inbox_bytes = r.bytes;
+    x->in_arena = r.in_arena;
     for (int i = 0; i < D3P_FMESH_MAX_WORLD; ++i) { x->peer[i] = nullptr; x->opened[i] = false; }
     x->peer[rank] = x->inbox;
     *fmesh_out = x;
@@ -179,17 +317,11 @@ int d3p_fmesh_create(int32_t world, int32_t rank, uint64_t n_floats, void** fmes
 
 int d3p_fmesh_connect(void* fmesh, const uint8_t* handles, size_t handle_stride)
 {
-    D3P_REQUIRE(fmesh && handles && handle_stride >= sizeof(hipIpcMemHandle_t), "d3p_fmesh_connect: bad arguments");
+    D3P_REQUIRE(fmesh && handles && handle_stride >= D3P_IPC_HANDLE_BYTES, "d3p_fmesh_connect: bad arguments (handles are 80 bytes)");
     FMesh* x = (FMesh*)fmesh;
     for (int p = 0; p < x->world; ++p) {
         if (p == x->rank) continue;
-        hipIpcMemHandle_t h;
-        memcpy(&h, handles + (size_t)p * handle_stride, sizeof(h));
-        void* q = nullptr;
-        const hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) return fail(D3P_E_HIP, "d3p_fmesh_connect: hipIpcOpenMemHandle(rank %d): %s", p, hipGetErrorString(e));
-        x->peer[p] = (char*)q;
-        x->opened[p] = true;
+        if (int rc = ipc_peer_open(handles + (size_t)p * handle_stride, &x->peer[p], &x->opened[p], "d3p_fmesh_connect", p)) return rc;
     }
     return D3P_OK;
 }
@@ -239,12 +371,11 @@ int d3p_fmesh_disconnect(void* fmesh)
     if (!fmesh) return D3P_OK;
     FMesh* x = (FMesh*)fmesh;
     for (int p = 0; p < x->world; ++p)
-        if (x->opened[p]) {
-            (void)hipIpcCloseMemHandle(x->peer[p]);
+        if (p != x->rank && x->peer[p]) {
+            ipc_peer_close(x->peer[p], x->opened[p]);   // (a range of a peer's arena stays mapped: nothing to undo)
             x->opened[p] = false;
             x->peer[p] = nullptr;
         }
-    (void)hipGetLastError();
     return D3P_OK;
 }
 
@@ -253,9 +384,10 @@ int d3p_fmesh_destroy(void* fmesh)
     if (!fmesh) return D3P_OK;
     FMesh* x = (FMesh*)fmesh;
     for (int p = 0; p < x->world; ++p)
-        if (x->opened[p]) (void)hipIpcCloseMemHandle(x->peer[p]);
-    (void)hipFree(x->inbox);
-    (void)hipGetLastError();
+        if (p != x->rank) ipc_peer_close(x->peer[p], x->opened[p]);
+    IpcRange r;
+    r.ptr = x->inbox; r.bytes = x->inbox_bytes; r.in_arena = x->in_arena;
+    ipc_range_destroy(&r);
     delete x;
     return D3P_OK;
 }

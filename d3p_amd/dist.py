@@ -314,6 +314,39 @@ class NativeComm:
             self.handle = None
 
 
+IPC_HANDLE_BYTES = 80   # what a communicator hands to its peers: the 64-byte hipIpc handle of the process's arena (or of the inbox's own
+                        # allocation) + the inbox's offset + a marker (csrc/d3p_ipc_arena.h)
+
+
+def _create_and_gather(comm, create, destroy, group):
+    """First half of XchgComm / FMeshComm.__init__: create the rank's side (its inbox and the 80-byte handle of it) and gather
+    the handles of all ranks -- with the ranks' SUCCESS gathered beside them, so that a rank whose creation failed does not leave its
+    peers waiting in the gather: every rank raises D3PError together (and gives back what it made), and a caller that falls back to
+    another driver (bench.py) does so on every rank.  Returns the handles in rank order, or None for a single-process group."""
+    import torch.distributed as dist
+    handle, buf = C.c_void_p(), (C.c_uint8 * IPC_HANDLE_BYTES)()
+    rc = create(handle, buf)
+    err = None if rc == 0 else ((_lib.load().d3p_last_error() or b"").decode(errors="replace") or f"error {rc}")
+    if comm.local:
+        if err:
+            raise _lib.D3PError("libd3p_hip: " + err)
+        comm.handle = handle
+        return None
+    mine = (bytes(buf) if err is None else None, err)
+    if comm.world > 1:
+        box = [None] * comm.world
+        dist.all_gather_object(box, mine, group=group)
+    else:
+        box = [mine]
+    failed = [(r, e) for r, (_, e) in enumerate(box) if e]
+    if failed:
+        if err is None:
+            destroy(handle)
+        raise _lib.D3PError("communicator not created: " + "; ".join(f"rank {r}: {e}" for r, e in failed))
+    comm.handle = handle
+    return [h for h, _ in box]
+
+
 def _teardown_barrier(comm, collective, disconnect):
     """First half of XchgComm / FMeshComm.close: every rank unmaps its peers' inboxes, then the ranks meet, and only then does anybody
     free.  The barrier is skipped for single-process groups, one-rank jobs, and on request."""
@@ -342,20 +375,14 @@ class XchgComm:
             self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.words = int(words)
         self.group = group
-        handle, buf = C.c_void_p(), (C.c_uint8 * 64)()
-        check(lib.d3p_xchg_create(self.world, self.rank, self.words, C.byref(handle), buf, 64))
-        self.handle = handle
+        self.handle = None
         self.local = _local is not None   # (ranks of ONE process: a rank's run may only be waited for once every rank's is enqueued)
-        if _local is not None:
+        box = _create_and_gather(self, lambda h, buf: lib.d3p_xchg_create(self.world, self.rank, self.words, C.byref(h), buf, IPC_HANDLE_BYTES),
+                                 lib.d3p_xchg_destroy, group)
+        if box is None:
             return
-        mine = bytes(buf)
-        if self.world > 1:
-            box = [None] * self.world
-            dist.all_gather_object(box, mine, group=group)
-        else:
-            box = [mine]
-        allh = (C.c_uint8 * (64 * self.world)).from_buffer_copy(b"".join(box))
-        check(lib.d3p_xchg_connect(self.handle, allh, 64))
+        allh = (C.c_uint8 * (IPC_HANDLE_BYTES * self.world)).from_buffer_copy(b"".join(box))
+        check(lib.d3p_xchg_connect(self.handle, allh, IPC_HANDLE_BYTES))
         if self.world > 1:
             dist.barrier(group=group)      # nobody writes into an inbox that its owner has not finished setting up
 
@@ -384,8 +411,10 @@ class XchgComm:
     def close(self, collective=None):
         """Teardown.  With the ranks in separate processes it is a COLLECTIVE (every rank calls it): unmap the peers' inboxes, meet in a
         barrier, then free the own inbox -- a rank that frees its inbox while a peer still has it mapped breaks its own next
-        hipIpcGetMemHandle (dmabuf IPC: "invalid argument" on the next communicator).  `collective=False`: no barrier (a rank
-        that must give its communicator up ALONE, e.g. because a peer failed to create one)."""
+        hipIpcGetMemHandle (dmabuf IPC: "invalid argument" on the next communicator).  As with any sequence of collectives, the ranks
+        close their communicators in the SAME order (the barrier is anonymous: two ranks closing two communicators in opposite orders
+        would pair the wrong halves -- tools/soak_teardown.py's first version did, and met the old failure again).
+        `collective=False`: no barrier (a rank that must give its communicator up ALONE, e.g. because a peer failed to create one)."""
         if self.handle:
             torch.cuda.synchronize()
             _teardown_barrier(self, collective, _lib.load().d3p_xchg_disconnect)
@@ -411,20 +440,14 @@ class FMeshComm:
             self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.n = int(n_floats)
         self.group = group
-        handle, buf = C.c_void_p(), (C.c_uint8 * 64)()
-        check(lib.d3p_fmesh_create(self.world, self.rank, self.n, C.byref(handle), buf, 64))
-        self.handle = handle
+        self.handle = None
         self.local = _local is not None   # (ranks of ONE process: a rank's run may only be waited for once every rank's is enqueued)
-        if _local is not None:
+        box = _create_and_gather(self, lambda h, buf: lib.d3p_fmesh_create(self.world, self.rank, self.n, C.byref(h), buf, IPC_HANDLE_BYTES),
+                                 lib.d3p_fmesh_destroy, group)
+        if box is None:
             return
-        mine = bytes(buf)
-        if self.world > 1:
-            box = [None] * self.world
-            dist.all_gather_object(box, mine, group=group)
-        else:
-            box = [mine]
-        allh = (C.c_uint8 * (64 * self.world)).from_buffer_copy(b"".join(box))
-        check(lib.d3p_fmesh_connect(self.handle, allh, 64))
+        allh = (C.c_uint8 * (IPC_HANDLE_BYTES * self.world)).from_buffer_copy(b"".join(box))
+        check(lib.d3p_fmesh_connect(self.handle, allh, IPC_HANDLE_BYTES))
         if self.world > 1:
             dist.barrier(group=group)      # nobody writes into an inbox that its owner has not finished setting up
 

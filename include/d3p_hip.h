@@ -35,6 +35,7 @@ extern "C" {
 #define D3P_E_WORKSPACE (-4)
 
 #define D3P_ABI_VERSION 9
+#define D3P_IPC_HANDLE_BYTES 80   /* what d3p_xchg_create / d3p_fmesh_create hand out for the peers (ABI 9) */
 
 int d3p_abi_version(void);
 const char* d3p_last_error(void);
@@ -494,7 +495,9 @@ int d3p_dpvi_logreg_kernel_timing_read(double* total_us_out, uint32_t* launches_
 /* One-shot full-mesh exchange over xGMI (ABI 3; SURVEY 5 / 8e: for a message of 8 KB one hop beats a ring's 2 (n - 1)).
  * Every rank owns an inbox (uncached device memory, double-buffered slots of self-validating words: 32 data bits + the
  * 32-bit tag of the exchange's epoch per 8-byte word, so that a row is its own arrival signal) that its peers map with hipIpc:
- *   d3p_xchg_create   allocates the inbox for messages of `words` int64 words and returns its 64-byte IPC handle;
+ *   d3p_xchg_create   allocates the inbox for messages of `words` int64 words and returns its 80-byte handle (ABI 9: D3P_IPC_HANDLE_BYTES --
+ *                     the inbox is a range of ONE hipIpc arena per process, exported once and mapped once by every peer: the handle is
+ *                     the arena's 64-byte hipIpc handle + the range's offset + a marker; handle_bytes / handle_stride >= 80);
  *   d3p_xchg_connect  takes the handles of ALL ranks (world x handle_stride bytes, the host layer gathers them, e.g. with
  *                     torch.distributed.all_gather_object) and maps the peers' inboxes;
  *   d3p_xchg_allreduce  enqueues ONE kernel: fold acc_dev[replicas][words] -> write the folded row into slot [rank] of every
@@ -650,8 +653,8 @@ int d3p_dpvi_vae_run_dist(void* stream, void* comm, void* fmesh, const d3p_vae_m
  * collective (single device).  Rank r owns chunk r of the vector: every rank stores its partials of chunk o into rank o's inbox,
  * the owner adds the world's partials in RANK ORDER (every rank then receives bit for bit the same sums) and stores them into every
  * peer's gather inbox.  A float travels as one 8-byte word {fp32 bits | epoch tag}: the data is its own arrival signal, no fence,
- * no flag.  Inboxes are uncached device memory mapped into the peers with hipIpc handles (d3p_fmesh_create -> exchange the 64-byte
- * handles -> d3p_fmesh_connect; d3p_fmesh_connect_local wires meshes that live in one process).  d3p_fmesh_allreduce: one launch on
+ * no flag.  Inboxes are uncached device memory mapped into the peers with hipIpc handles (d3p_fmesh_create -> exchange the 80-byte
+ * handles (D3P_IPC_HANDLE_BYTES, as d3p_xchg_create) -> d3p_fmesh_connect; d3p_fmesh_connect_local wires meshes that live in one process).  d3p_fmesh_allreduce: one launch on
  * `stream`, in place, bounded waits; d3p_fmesh_status (after synchronising `stream`): non-zero when a wait ran out -- the vector of
  * that and every later call is then undefined.  d3p_dpvi_vae_run_dist(..., fmesh) uses it instead of RCCL. */
 int d3p_fmesh_create(int32_t world, int32_t rank, uint64_t n_floats, void** fmesh_out, uint8_t* handle_out, size_t handle_bytes);
