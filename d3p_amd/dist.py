@@ -347,6 +347,24 @@ def _create_and_gather(comm, create, destroy, group):
     return [h for h, _ in box]
 
 
+def _connect_and_agree(comm, rc, destroy, group):
+    """Second half of XchgComm / FMeshComm.__init__: the ranks meet after mapping their peers' inboxes -- nobody writes into an inbox
+    that its owner has not finished setting up -- and they meet with the OUTCOME of the mapping: a rank that could not map a peer
+    does not leave the others behind a barrier, every rank raises D3PError together and gives its side back."""
+    import torch.distributed as dist
+    err = None if rc == 0 else ((_lib.load().d3p_last_error() or b"").decode(errors="replace") or f"error {rc}")
+    if comm.world > 1:
+        box = [None] * comm.world
+        dist.all_gather_object(box, err, group=group)
+    else:
+        box = [err]
+    failed = [(r, e) for r, e in enumerate(box) if e]
+    if failed:
+        destroy(comm.handle)
+        comm.handle = None
+        raise _lib.D3PError("communicator not connected: " + "; ".join(f"rank {r}: {e}" for r, e in failed))
+
+
 def _teardown_barrier(comm, collective, disconnect):
     """First half of XchgComm / FMeshComm.close: every rank unmaps its peers' inboxes, then the ranks meet, and only then does anybody
     free.  The barrier is skipped for single-process groups, one-rank jobs, and on request."""
@@ -382,9 +400,7 @@ class XchgComm:
         if box is None:
             return
         allh = (C.c_uint8 * (IPC_HANDLE_BYTES * self.world)).from_buffer_copy(b"".join(box))
-        check(lib.d3p_xchg_connect(self.handle, allh, IPC_HANDLE_BYTES))
-        if self.world > 1:
-            dist.barrier(group=group)      # nobody writes into an inbox that its owner has not finished setting up
+        _connect_and_agree(self, lib.d3p_xchg_connect(self.handle, allh, IPC_HANDLE_BYTES), lib.d3p_xchg_destroy, group)
 
     @classmethod
     def local_group(cls, world, words):
@@ -447,9 +463,7 @@ class FMeshComm:
         if box is None:
             return
         allh = (C.c_uint8 * (IPC_HANDLE_BYTES * self.world)).from_buffer_copy(b"".join(box))
-        check(lib.d3p_fmesh_connect(self.handle, allh, IPC_HANDLE_BYTES))
-        if self.world > 1:
-            dist.barrier(group=group)      # nobody writes into an inbox that its owner has not finished setting up
+        _connect_and_agree(self, lib.d3p_fmesh_connect(self.handle, allh, IPC_HANDLE_BYTES), lib.d3p_fmesh_destroy, group)
 
     @classmethod
     def local_group(cls, world, n_floats):

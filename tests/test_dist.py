@@ -160,6 +160,55 @@ def _teardown_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _creation_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from d3p_amd._lib import D3PError
+    from d3p_amd.dist import _connect_and_agree, _create_and_gather
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class FakeComm:
+        handle, local, world, group = None, False, 2, None
+    destroyed = []
+    rec = {}
+    try:    # rank 1 cannot create its side (an export that failed, say): BOTH ranks must raise, rank 0 must give its side back
+        _create_and_gather(FakeComm(), lambda h, buf: 0 if rank == 0 else -2, lambda h: destroyed.append("create") or 0, None)
+        rec["create"] = "no error"
+    except D3PError as e:
+        rec["create"] = str(e)
+    c = FakeComm()
+    c.handle = 77
+    try:    # rank 0 cannot map a peer: both raise, both give their sides back
+        _connect_and_agree(c, -2 if rank == 0 else 0, lambda h: destroyed.append("connect") or 0, None)
+        rec["connect"] = "no error"
+    except D3PError as e:
+        rec["connect"] = str(e)
+    ok = FakeComm()
+    box = _create_and_gather(ok, lambda h, buf: 0, lambda h: 0, None)      # and the good case still hands out the handles in rank order
+    _connect_and_agree(ok, 0, lambda h: 0, None)
+    out[rank] = (rec, destroyed, len(box), c.handle)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_communicator_creation_failures_are_raised_on_every_rank_together():
+    """XchgComm / FMeshComm.__init__ gather the OUTCOME of the local steps (create: inbox + export; connect: mapping the peers) with
+    the handles: a rank that fails does not leave its peers waiting in a collective -- every rank raises D3PError naming the failed
+    rank and gives its side back, so that a caller falling back to another driver (bench.py) does so on every rank."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 31000 + (os.getpid() % 2000)
+    mp.spawn(_creation_worker, args=(2, port, out), nprocs=2, join=True)
+    for rank in (0, 1):
+        rec, destroyed, n_handles, handle_after = out[rank]
+        assert "rank 1" in rec["create"] and "not created" in rec["create"]
+        assert "rank 0" in rec["connect"] and "not connected" in rec["connect"]
+        assert n_handles == 2 and handle_after is None
+    assert out[0][1] == ["create", "connect"] and out[1][1] == ["connect"]      # rank 1 had nothing to give back after its failed create
+
+
 def test_communicator_teardown_is_ordered_over_the_ranks():
     """XchgComm.close / FMeshComm.close (d3p_amd.dist._teardown_barrier): every rank unmaps its peers' inboxes, the ranks meet, and
     only then does anybody free its own inbox -- the order whose absence broke the next hipIpcGetMemHandle of a rank that was
