@@ -1137,8 +1137,8 @@ def test_fmesh_eight_virtual_ranks_at_the_config4_share_of_an_8_gpu_job(gpu):
 
 @pytest.mark.gpu
 @pytest.mark.coresident
-@pytest.mark.parametrize("form", ["in_launch", "per_step"])
-def test_xchg_two_processes_over_hipipc(gpu, form):
+@pytest.mark.parametrize("form,world", [("in_launch", 2), ("per_step", 2), ("in_launch", 4), ("per_step", 4)])
+def test_xchg_two_processes_over_hipipc(gpu, form, world):
     """The real thing -- one PROCESS per rank, inboxes mapped through hipIpc handles, system-scope rows across the process
     boundary (tools/xchg_two_rank_check.py spawns the two ranks itself, compares their replicas bit for bit after every run and
     rank 0's result with the single-rank run).  One process per GPU where two GPUs exist; on a one-GPU box both ranks share
@@ -1147,7 +1147,7 @@ def test_xchg_two_processes_over_hipipc(gpu, form):
     launch leave more than half of the GPU to the other rank, three consecutive runs on one exchange (both slot
     parities, tags of earlier runs in the slots); `per_step`: one exchange launch behind every step launch."""
     import subprocess
-    env = dict(os.environ, D3P_XCHG_CHECK_STEPS="12", D3P_XCHG_CHECK_REPEAT="3")
+    env = dict(os.environ, D3P_XCHG_CHECK_STEPS="12", D3P_XCHG_CHECK_REPEAT="3", D3P_XCHG_CHECK_WORLD=str(world))   # (world 4: round 6)
     if form == "per_step":
         env["D3P_XCHG_PER_STEP"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "xchg_two_rank_check.py")], capture_output=True, text=True,

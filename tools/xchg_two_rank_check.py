@@ -4,6 +4,7 @@ process boundaries.  The parent never touches a GPU; it starts two fresh rank pr
 checks their results against each other; rank 0 also computes the single-rank reference.
 
     python tools/xchg_two_rank_check.py            # one process per GPU when there are two, else both ranks on cuda:0
+    D3P_XCHG_CHECK_WORLD=4 python tools/xchg_two_rank_check.py      # four rank processes
 
 Exit code 0 = the bare collective summed exactly over three epochs and the row-sharded 24-step run ended with bitwise
 identical replicas that match the single-rank run to fp32 rounding."""
@@ -102,8 +103,9 @@ def main():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    world = int(os.environ.get("D3P_XCHG_CHECK_WORLD", "2"))   # (more than two processes: up to the 6 a GPU box allows on its card)
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)], env=env))
     rc = 0
