@@ -200,3 +200,28 @@ def test_wave_sums_behind_divergent_branches(rng):
     assert float(((got[:, 0] - ref).abs() / scale).max()) < 4e-6
     assert float(((got[:, 1] - ref).abs() / scale).max()) < 4e-6
     assert float(((got[:, 2] - 2 * ref).abs() / (2 * scale)).max()) < 4e-6
+
+
+@pytest.mark.parametrize("sizes", [[1], [7], [512, 1], [3, 1, 4], [1, 1, 1], [5, 5, 5, 5, 5, 5, 5, 5], [1023, 2]])
+def test_px_eps_sites_vs_oracle(gpu, O, sizes):
+    """d3p_px_eps_sites (the per-example, per-SITE guide noise of a guide with several sample statements: numpyro's seed handler hands
+    every site its own key) against the oracle's d3po_px_eps_sites for 1 .. 8 sites, odd and even sizes, scalar sites, and a shard of
+    the batch (rows pos0 .. of the same stream); one site = the stream the fused kernels draw on chip (O.px_eps)."""
+    import ctypes as C
+    import d3p_amd._lib as L
+    B, pos0, b_local = 37, 5, 19
+    jk = O.convert_to_jax_rng_key(O.split(O.PRNGKey(1234 + len(sizes)), 3)[1])
+    jk_dev = torch.from_numpy(np.ascontiguousarray(jk, np.uint32).view(np.int32)).cuda().view(torch.uint32)
+    arr = (C.c_int32 * len(sizes))(*sizes)
+    D = sum(sizes)
+    full = torch.empty((B, D), device="cuda")
+    L.check(L.load().d3p_px_eps_sites(L.stream_ptr(), L.ptr(jk_dev), B, 0, B, arr, len(sizes), L.ptr(full)))
+    want = O.px_eps_sites(jk, B, sizes)
+    np.testing.assert_allclose(full.cpu().numpy(), want, rtol=2e-6, atol=1e-7)
+    part = torch.empty((b_local, D), device="cuda")
+    L.check(L.load().d3p_px_eps_sites(L.stream_ptr(), L.ptr(jk_dev), B, pos0, b_local, arr, len(sizes), L.ptr(part)))
+    assert torch.equal(part, full[pos0:pos0 + b_local])
+    if len(sizes) == 1:
+        np.testing.assert_allclose(want, O.px_eps(jk, B, sizes[0]), rtol=0, atol=0)
+    with pytest.raises(ValueError):
+        L.check(L.load().d3p_px_eps_sites(L.stream_ptr(), L.ptr(jk_dev), B, 30, 19, arr, len(sizes), L.ptr(part)))   # pos0 + B_local > B_total
