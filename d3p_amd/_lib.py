@@ -232,6 +232,9 @@ SIGNATURES = {
     "d3p_selftest_wave_sums": (C.c_int, [_V, _V, _U32, _V]),
     "d3p_synth_logreg": (C.c_int, [_V, _U32, _U64, _U64, _I32, _V, _V]),
     "d3p_hbm_copy": (C.c_int, [_V, _V, _V, _U64, _I32]),
+    "d3p_dpvi_leaves_begin": (C.c_int, [_V, _V, _I32, _V, _V, _U32, _V, _V, _V, _V]),
+    "d3p_dpvi_leaves_finalize": (C.c_int, [_V, _PH, _V, _V, _V, C.POINTER(C.c_int32), _I32, _U32, C.c_float,
+                                           _V, _V, _V, _V, _V, _V, _V, _V, _V, _V]),
     "d3p_px_eps_sites": (C.c_int, [_V, _V, _U32, _U32, _U32, C.POINTER(C.c_int32), _I32, _V]),
 }
 

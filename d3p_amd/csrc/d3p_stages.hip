@@ -769,4 +769,157 @@ int d3p_hbm_copy(void* stream, void* dst_dev, const void* src_dev, uint64_t byte
     return check_launch("d3p_hbm_copy");
 }
 
+
+// ---- DPSVI.update for a parameter dict with SEVERAL leaves (the example's own guide: four leaves) around the fused clipped sums:
+// d3p_dpvi_leaves_begin (the step's keys + the parameters in the kernels' column order) -> d3p_px_eps_sites -> d3p_dpvi_logreg_local_sums
+// -> d3p_dpvi_leaves_finalize (mean, one noise key per leaf, rescaling, Adam).  Nine launches instead of the ~95 of the stage-wise composition.
+#define D3P_MAX_LEAVES 16
+extern "C++" {
+struct LeavesBeginArgs {
+    const uint32_t* key;
+    int n_leaves;
+    const float* params_tree;
+    const int32_t* col_of;
+    uint32_t P;
+    uint32_t* next_key;
+    uint32_t* jax_key;
+    uint32_t* leaf_keys;
+    float* params_kernel;
+};
+
+// Workgroup 0: (next key, gradient key, perturbation key) = split(state key, 3) (svi.py:413-415), the gradient key's two threefry
+// words (random/__init__.py:149-155) and split(perturbation key, n_leaves) (svi.py:491).  The others: kernel column col_of[j] <- leaf element j.
+__global__ void __launch_bounds__(64) k_leaves_begin(LeavesBeginArgs a)
+{
+    const int t = threadIdx.x;
+    if (blockIdx.x != 0) {
+        const uint32_t j = (blockIdx.x - 1) * 64u + t;
+        if (j < a.P) a.params_kernel[a.col_of[j]] = a.params_tree[j];
+        return;
+    }
+    __shared__ uint32_t kids[3][16];
+    if (t < 3) {
+        uint32_t parent[16], child[16];
+        load_key(a.key, parent);
+        derive_child(parent, (uint32_t)t, 0u, D3P_TAG_SPLIT, child);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) kids[t][w] = child[w];
+        if (t == 0) {
+#pragma unroll
+            for (int w = 0; w < 16; ++w) a.next_key[w] = child[w];
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t k[16], o[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) k[w] = kids[1][w];
+        keystream_block(k, 0u, o);
+        a.jax_key[0] = o[0];
+        a.jax_key[1] = o[1];
+    } else if (t - 1 < a.n_leaves) {
+        uint32_t parent[16], child[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) parent[w] = kids[2][w];
+        derive_child(parent, (uint32_t)(t - 1), 0u, D3P_TAG_SPLIT, child);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) a.leaf_keys[16 * (t - 1) + w] = child[w];
+    }
+}
+
+struct LeavesFinalArgs {
+    const float* sums;      // [P clipped sums, kernel column order | loss sum | n]
+    const int32_t* col_of;
+    const uint32_t* leaf_keys;
+    uint32_t leaf_off[D3P_MAX_LEAVES + 1];
+    int n_leaves;
+    uint32_t P, B;
+    float obs_scale;
+    d3p_dpsvi_hyper h;
+    const float *x_in, *m_in, *v_in;
+    const int32_t* step_in;
+    float *x_out, *m_out, *v_out;
+    int32_t* step_out;
+    float* loss_out;
+    float* grad_out;  // nullable
+};
+
+// One thread per leaf element j (tree order): svi.py:343-346 (mean), :365-366 + :487-488 (leaf += normal(leaf key) * scale: word e of the
+// leaf key's stream, as d3p_rng_normal draws it), :375 (rescaling), :379-393 (Adam).
+__global__ void __launch_bounds__(64) k_leaves_finalize(LeavesFinalArgs a)
+{
+    const uint32_t j = blockIdx.x * 64u + threadIdx.x;
+    const float n = a.sums[a.P + 1], Bf = (float)a.B;
+    const float factor = (n == 0.0f) ? 0.0f : Bf / n;  // svi.py:305
+    if (j < a.P) {
+        int leaf = 0;
+        while (leaf + 1 < a.n_leaves && j >= a.leaf_off[leaf + 1]) ++leaf;
+        const uint32_t e = j - a.leaf_off[leaf];
+        uint32_t k[16], o[16];
+        load_key(a.leaf_keys + 16 * leaf, k);
+        keystream_block(k, e >> 4, o);
+        uint32_t bits = o[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) bits = ((e & 15u) == (uint32_t)w) ? o[w] : bits;
+        const float z = bits_to_normal(bits);
+        const float avg = a.sums[a.col_of[j]] / Bf;
+        const float scale = a.h.dp_scale * (a.h.clip / n);  // (n == 0 -> inf, as the reference)
+        const float g = (avg + z * scale) * a.obs_scale * factor;
+        if (a.grad_out) a.grad_out[j] = g;
+        float x = a.x_in[j], m = a.m_in[j], v = a.v_in[j];
+        adam_update(x, m, v, g, *a.step_in, a.h);
+        a.x_out[j] = x;
+        a.m_out[j] = m;
+        a.v_out[j] = v;
+    }
+    if (j == 0) {
+        const float* x_in = a.x_in;
+        *a.loss_out = (n == 0.0f) ? empty_batch_loss((int)a.P, [x_in](int c) { return x_in[c]; }) : (a.sums[a.P] / Bf) * a.obs_scale * factor;
+        *a.step_out = *a.step_in + 1;
+    }
+}
+}  // extern "C++"
+
+int d3p_dpvi_leaves_begin(void* stream, const uint32_t* state_key_dev, int32_t n_leaves, const float* params_tree_dev,
+                          const int32_t* col_of_dev, uint32_t P, uint32_t* next_key_dev, uint32_t* jax_key_dev, uint32_t* leaf_keys_dev,
+                          float* params_kernel_dev)
+{
+    D3P_REQUIRE(state_key_dev && next_key_dev && jax_key_dev && leaf_keys_dev, "d3p_dpvi_leaves_begin: null key pointer");
+    D3P_REQUIRE(n_leaves >= 1 && n_leaves <= D3P_MAX_LEAVES, "d3p_dpvi_leaves_begin: 1 <= n_leaves <= 16");
+    D3P_REQUIRE(P == 0 || (params_tree_dev && col_of_dev && params_kernel_dev), "d3p_dpvi_leaves_begin: null parameter pointer");
+    LeavesBeginArgs a{state_key_dev, n_leaves, params_tree_dev, col_of_dev, P, next_key_dev, jax_key_dev, leaf_keys_dev, params_kernel_dev};
+    hipLaunchKernelGGL(k_leaves_begin, dim3(1 + cdiv(P, 64)), dim3(64), 0, (hipStream_t)stream, a);
+    return check_launch("d3p_dpvi_leaves_begin");
+}
+
+int d3p_dpvi_leaves_finalize(void* stream, const d3p_dpsvi_hyper* hyper, const float* sums_dev, const int32_t* col_of_dev,
+                             const uint32_t* leaf_keys_dev, const int32_t* leaf_sizes_host, int32_t n_leaves, uint32_t B, float obs_scale,
+                             const float* params_in_dev, const float* m_in_dev, const float* v_in_dev, const int32_t* step_in_dev,
+                             float* params_out_dev, float* m_out_dev, float* v_out_dev, int32_t* step_out_dev, float* loss_dev,
+                             float* grad_out_dev)
+{
+    D3P_REQUIRE(hyper && sums_dev && col_of_dev && leaf_keys_dev && leaf_sizes_host, "d3p_dpvi_leaves_finalize: null pointer");
+    D3P_REQUIRE(n_leaves >= 1 && n_leaves <= D3P_MAX_LEAVES, "d3p_dpvi_leaves_finalize: 1 <= n_leaves <= 16");
+    D3P_REQUIRE(params_in_dev && m_in_dev && v_in_dev && step_in_dev && params_out_dev && m_out_dev && v_out_dev && step_out_dev && loss_dev,
+                "d3p_dpvi_leaves_finalize: null state pointer");
+    D3P_REQUIRE(B >= 1, "d3p_dpvi_leaves_finalize: batch size must be >= 1");
+    D3P_REQUIRE(hyper->clip > 0.f, "The clipping threshold must be greater than 0.");
+    LeavesFinalArgs a{};
+    a.sums = sums_dev; a.col_of = col_of_dev; a.leaf_keys = leaf_keys_dev; a.n_leaves = n_leaves;
+    uint64_t off = 0;
+    for (int k = 0; k < n_leaves; ++k) {
+        D3P_REQUIRE(leaf_sizes_host[k] >= 0, "d3p_dpvi_leaves_finalize: negative leaf size");
+        a.leaf_off[k] = (uint32_t)off;
+        off += (uint64_t)leaf_sizes_host[k];
+    }
+    D3P_REQUIRE(off >= 1 && off <= 0x7FFFFFFFull, "d3p_dpvi_leaves_finalize: the leaves must hold 1 .. 2^31 - 1 elements");
+    for (int k = n_leaves; k <= D3P_MAX_LEAVES; ++k) a.leaf_off[k] = (uint32_t)off;
+    a.P = (uint32_t)off; a.B = B; a.obs_scale = obs_scale; a.h = *hyper;
+    a.x_in = params_in_dev; a.m_in = m_in_dev; a.v_in = v_in_dev; a.step_in = step_in_dev;
+    a.x_out = params_out_dev; a.m_out = m_out_dev; a.v_out = v_out_dev; a.step_out = step_out_dev;
+    a.loss_out = loss_dev; a.grad_out = grad_out_dev;
+    hipLaunchKernelGGL(k_leaves_finalize, dim3(cdiv(a.P, 64)), dim3(64), 0, (hipStream_t)stream, a);
+    return check_launch("d3p_dpvi_leaves_finalize");
+}
+
 }  // extern "C"

@@ -187,8 +187,8 @@ class MeanFieldGuide:
       * the Gaussian mechanism draws ONE KEY PER LEAF, split(key, 4) (svi.py:487-491);
       * numpyro's seed handler gives every sample site its own key (rng, site_key = split(rng) per sample statement), so 'w' and
         'intercept' take their eps from different threefry streams (d3p_px_eps_sites; this plumbing is UNPINNED).
-    The joint density is the same as the one-site guide's, so the per-example gradient kernels are shared; DPSVI runs this guide through
-    the five-stage composition (per-example gradients materialised)."""
+    The joint density is the same as the one-site guide's, so the per-example gradient kernels are shared; DPSVI.update runs this guide
+    around the fused clipped sums (DPSVI._update_leaves; the five-stage composition, _update_staged, is its check)."""
 
     transform = "exp"
 

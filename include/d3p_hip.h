@@ -685,6 +685,28 @@ int d3p_synth_logreg(void* stream, uint32_t seed, uint64_t row0, uint64_t n_rows
 int d3p_px_eps_sites(void* stream, const uint32_t* jax_key_dev, uint32_t B_total, uint32_t pos0, uint32_t B_local,
                      const int32_t* site_sizes_host, int32_t n_sites, float* eps_dev);
 
+/* ABI 9 -- DPSVI.update (d3p/svi.py:395-434) for a parameter dict with SEVERAL leaves around the fused clipped sums, e.g. the example's own
+ * guide (examples/logistic_regression.py:67-86: intercept_loc, intercept_std_log, w_loc, w_std_log), in nine launches:
+ *   d3p_dpvi_leaves_begin -> d3p_px_eps_sites -> d3p_dpvi_logreg_local_sums(eps) -> d3p_dpvi_leaves_finalize.
+ * The state's parameters / Adam moments are flat in TREE order (the leaves of the dict sorted by name, as jax.tree_util flattens it);
+ * col_of_dev[j] = the fused kernels' column ([loc (D) | unconstrained scale (D)], latent elements in site order) of tree element j.
+ * begin: (next_key, gradient key, perturbation key) = split(state key, 3) (svi.py:413-415); jax_key = the gradient key's two threefry words
+ * (random/__init__.py:149-155); leaf_keys[k] = split(perturbation key, n_leaves)[k] (svi.py:491); params_kernel[col_of[j]] = params_tree[j]. */
+int d3p_dpvi_leaves_begin(void* stream, const uint32_t* state_key_dev, int32_t n_leaves, const float* params_tree_dev,
+                          const int32_t* col_of_dev, uint32_t P, uint32_t* next_key_dev, uint32_t* jax_key_dev, uint32_t* leaf_keys_dev,
+                          float* params_kernel_dev);
+/* finalize: sums_dev = [P clipped sums in kernel column order | loss sum | number of valid examples] as d3p_dpvi_logreg_local_sums (or an
+ * all-reduce of it) leaves them.  Per tree element j of leaf k: g = (sums[col_of[j]] / B + normal(leaf_keys[k])[e] * dp_scale * clip / n)
+ * * obs_scale * (B / n) (svi.py:343-346, :365-375, :487-488), then numpyro's Adam (svi.py:379-393) from (params, m, v, step)_in into the
+ * _out arrays (the update is functional, the inputs are not written); loss = (loss sum / B) * obs_scale * B / n (svi.py:342, :306; n = 0: 0, or
+ * NaN when a parameter is not finite, as the masked sum gives there).  leaf_sizes_host: n_leaves <= 16 sizes in tree order; grad_out_dev
+ * (nullable): the perturbed gradient in tree order. */
+int d3p_dpvi_leaves_finalize(void* stream, const d3p_dpsvi_hyper* hyper, const float* sums_dev, const int32_t* col_of_dev,
+                             const uint32_t* leaf_keys_dev, const int32_t* leaf_sizes_host, int32_t n_leaves, uint32_t B, float obs_scale,
+                             const float* params_in_dev, const float* m_in_dev, const float* v_in_dev, const int32_t* step_in_dev,
+                             float* params_out_dev, float* m_out_dev, float* v_out_dev, int32_t* step_out_dev, float* loss_dev,
+                             float* grad_out_dev);
+
 /* ABI 9 -- d3p_logreg_evaluate for a guide with several sample sites (the example's own guide: 'w' (d) then 'intercept' (1)): the one
  * guide draw of SVI.evaluate takes every site's eps from its own key, `rng, site_key = split(rng)` per sample statement; params_dev in the
  * kernels' order [loc (D) | unconstrained scale (D)], latent elements in site order.  site_sizes_host = NULL, n_sites = 1: d3p_logreg_evaluate. */

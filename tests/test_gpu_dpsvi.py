@@ -894,8 +894,8 @@ def test_run_steps_falls_back_to_one_launch_per_step_when_the_chained_launch_is_
 def test_example_guide_with_two_sites_vs_oracle(rng, O, B, d):
     """examples/logistic_regression.py:49-86 as it stands in the reference: model with sites 'w' (d) and 'intercept', the hand-written
     guide with exp-parametrised scales -- four parameter leaves in sorted-name order, ONE perturbation key per leaf (svi.py:487-491), every
-    sample site's eps from its own key.  Three masked updates at d = 512 + intercept through DPSVI.update (five-stage composition on the
-    HIP kernels) against O.meanfield_logreg_update: losses 2e-5, parameters / Adam moments 1e-4, keys bit-exact; the per-site eps kernel
+    sample site's eps from its own key.  Three masked updates at d = 512 + intercept through DPSVI.update (the fused clipped sums between
+    d3p_dpvi_leaves_begin and d3p_dpvi_leaves_finalize) against O.meanfield_logreg_update: losses 2e-5, parameters / Adam moments 1e-4, keys bit-exact; the per-site eps kernel
     (d3p_px_eps_sites) against the oracle's stream (rtol 2e-6, like rng.normal); evaluate; get_params' leaf names and shapes."""
     import ctypes as C
     import d3p_amd._lib as L
@@ -943,6 +943,51 @@ def test_example_guide_with_two_sites_vs_oracle(rng, O, B, d):
     spec_e = O.logreg_spec(d, True, 1.0, 1.0, lik_scale=N, obs_scale=1.0, guide_exp=True)
     exp = O.meanfield_logreg_evaluate(spec_e, np_(st.optim_state[1]), X, y, O.convert_to_jax_rng_key(O.split(ost.key, 1)[0]))
     assert abs(got - exp) <= 2e-5 * abs(exp)
+
+
+@pytest.mark.parametrize("B,d,masked", [(200, 4, False), (64, 512, True), (4096, 512, False), (33, 70, True)])
+def test_example_guide_fused_update_vs_stage_composition(rng, B, d, masked):
+    """DPSVI.update with the example's guide runs around the FUSED clipped sums (d3p_dpvi_leaves_begin -> d3p_px_eps_sites ->
+    d3p_dpvi_logreg_local_sums -> d3p_dpvi_leaves_finalize, nine launches); the reference's five-stage composition (svi.py:413-434) on the
+    same state is its check: keys and step counter bit-exact, the perturbed gradient (the noise words are the same, the clipped sums
+    differ in fp32 summation order) 2e-5 of its largest element, loss 2e-5, state 1e-4.  Four updates, so that Adam moments and a moved
+    state key enter; then a batch with no valid example (svi.py:305: factor 0, C / 0 = inf -> NaN state in both)."""
+    from d3p_amd.models import Adam, LogisticRegression, MeanFieldGuide, Trace_ELBO
+    from d3p_amd.svi import DPSVI
+    N = 20000
+    r = np.random.default_rng(7 * d + B)
+    Xt = torch.tensor(r.normal(size=(B, d)).astype(np.float32)).cuda()
+    yt = torch.tensor((r.random(B) < 0.5).astype(np.float32)).cuda()
+    mt = torch.tensor(r.random(B) < 0.7).cuda() if masked else True
+    model = LogisticRegression(d, prior_scale=2.0, intercept=True, intercept_prior_scale=3.0)
+    svi = DPSVI(model, MeanFieldGuide(model), Adam(5e-2), Trace_ELBO(), 1.3, 0.9, num_obs_total=N)
+    assert svi._leaves_fusable()
+    st = svi.init(rng.PRNGKey(5), Xt, yt)
+    P = 2 * d + 2
+    for step in range(4):
+        g = torch.empty(P, device="cuda")
+        new, loss = svi.update(st, Xt, yt, mask=mt, _grad_out=g)
+        ref, ref_loss = svi._update_staged(st, Xt, yt, mask=mt)
+        assert torch.equal(new.rng_key, ref.rng_key) and int(new.optim_state[0]) == int(ref.optim_state[0]) == step + 1
+        assert abs(float(loss) - float(ref_loss)) <= 2e-5 * abs(float(ref_loss))
+        # the staged path's gradient: what moved m from the old state
+        m_old, m_ref = np_(st.optim_state[2]), np_(ref.optim_state[2])
+        g_ref = (m_ref - 0.9 * m_old) / np.float32(0.1)
+        np.testing.assert_allclose(np_(g), g_ref, rtol=0, atol=3e-5 * np.abs(g_ref).max())
+        for k in (1, 2, 3):
+            a, b = np_(new.optim_state[k]), np_(ref.optim_state[k])
+            np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-5 * max(np.abs(b).max(), 1e-30))
+        assert new.optim_state[1].data_ptr() != st.optim_state[1].data_ptr()      # (functional: the old state is untouched)
+        st = new
+    empty, loss0 = svi.update(st, Xt, yt, mask=False)
+    ref, ref_loss0 = svi._update_staged(st, Xt, yt, mask=False)
+    assert float(loss0) == float(ref_loss0) == 0.0
+    assert torch.equal(empty.rng_key, ref.rng_key)
+    assert np.array_equal(np.isnan(np_(empty.optim_state[1])), np.isnan(np_(ref.optim_state[1])))
+    assert np.isnan(np_(empty.optim_state[1])).any()
+    _, loss1 = svi.update(empty, Xt, yt, mask=False)       # (a masked sum over NaN parameters: NaN * 0 = NaN in the reference)
+    _, ref_loss1 = svi._update_staged(empty, Xt, yt, mask=False)
+    assert np.isnan(float(loss1)) and np.isnan(float(ref_loss1))
 
 
 def test_example_guide_four_leaves_get_four_noise_streams(rng, O):

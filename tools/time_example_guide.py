@@ -24,3 +24,11 @@ for name, guide in (("AutoDiagonalNormal (fused step)", AutoDiagonalNormal(model
             s, loss = svi.update(s, X, y)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"{name}: {dt / steps * 1e6:.1f} us per update (B = {B}, d = {d} + intercept), loss {float(loss):.4g}", flush=True)
+svi_staged = svi        # (the last one: MeanFieldGuide) -- the reference's five-stage composition on the same guide
+for phase in range(2):
+    s = st
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for t in range(steps):
+        s, loss = svi_staged._update_staged(s, X, y)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f"MeanFieldGuide through the five-stage composition: {dt / steps * 1e6:.1f} us per update, loss {float(loss):.4g}", flush=True)
