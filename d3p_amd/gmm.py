@@ -33,6 +33,24 @@ class GaussianMixture:
         self.event_shape = tuple(self.locs.shape[1:])
 
     @property
+    def mean(self):
+        """d3p/gmm.py:97-99, as written there: ``(mixture_probabilities * locs).sum()`` -- the weights broadcast against the LAST axis of
+        ``locs`` (k, d), so the expression only evaluates where d == k or d == 1 (and is a scalar, not the mixture's mean vector); kept
+        literally for callers that rely on it.  ``component_mean`` is the mixture's mean."""
+        return (self.mixture_probabilities * self.locs).sum()
+
+    @property
+    def variance(self):
+        """d3p/gmm.py:101-103 calls the ``mean`` PROPERTY's value (``self.mean()``), which raises TypeError in the reference whenever it is
+        read; here the same expression with the value itself: ``pi * (scales^2 + locs^2) - mean^2`` (same broadcasting caveat as ``mean``)."""
+        return (self.mixture_probabilities * (self.scales ** 2 + self.locs ** 2)) - self.mean ** 2
+
+    @property
+    def component_mean(self):
+        """sum_k pi_k loc_k, shape (d,) (no reference counterpart: what ``mean`` presumably meant)."""
+        return (self.mixture_probabilities.reshape(-1, *([1] * (self.locs.dim() - 1))) * self.locs).sum(dim=0)
+
+    @property
     def num_components(self):
         return self.mixture_probabilities.shape[-1]
 

@@ -84,3 +84,21 @@ class ADADP:
 
         new_i = step[0] if isinstance(i, torch.Tensor) else int(i) + 1
         return new_i, (unpack(xf), lr_t[0], unpack(sf), unpack(pf))
+
+
+def adadp(step_size=1e-3, tol=1.0, stability_check=True, alpha_min=0.9, alpha_max=1.1):
+    """d3p.optimizers.adadp (optimizers.py:29-112): the ``(init_fun, update_fun, get_params)`` triple in the style of
+    ``jax.example_libraries.optimizers`` that the reference's ``ADADP`` class wraps -- ``init(x0) -> (x0, lr, zeros_like(x0), x0)``,
+    ``update(i, g, state) -> state``, ``get_params(state) -> x`` -- over the same device step (``d3p_adadp_step``)."""
+    opt = ADADP(step_size, tol, stability_check, alpha_min, alpha_max)
+
+    def init(x0):
+        return opt.init(x0)[1]
+
+    def update(i, g, state):
+        return opt.update(g, (i, state))[1]
+
+    def get_params(state):
+        return state[0]
+
+    return init, update, get_params

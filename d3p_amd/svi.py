@@ -96,6 +96,22 @@ def _as_device_f32(x, device=None):
 
 
 # ------------------------------------------------------------------ module-level gradient manipulators
+def get_observations_scale(model, model_args, model_kwargs, params=None):
+    """d3p/svi.py:43-65 for the declared model families: the scale numpyro applies to the observed site's log-likelihood for THESE
+    arguments.  The reference traces the model and reads ``msg['scale']`` of the observed sites; the declared models have exactly one,
+    inside ``plate('batch', N, subsample_size=len(batch))``, so the scale is N / len(batch), or 1.0 when the call names no total count
+    (either way times the VAE's ``handlers.scale`` factor) -- read from the model's declaration (``num_obs_total``), not from a trace.  ``params`` is
+    accepted for the reference's signature (it substitutes them before tracing; the scale does not depend on them).  ``DPSVI.init`` calls
+    this on a one-element batch (svi.py:225-234): the scale is then N itself."""
+    kwargs = dict(model_kwargs or {})
+    n_total = model.num_obs_total(tuple(model_args), kwargs)
+    batch = example_count(model_args[0]) if len(model_args) else 1
+    scale = 1.0 if n_total is None else float(n_total) / float(max(int(batch), 1))
+    if isinstance(model, VAEModel):
+        scale *= float(model.scale)
+    return scale
+
+
 def full_norm(vector_parts, ord=2):
     """d3p/svi.py:68-87: norm over all leaves of a tree treated as one vector (0. if empty); `ord` as for
     numpy.linalg.norm of a vector (None = 2, 0, 1, +-inf, any other p)."""
@@ -403,9 +419,8 @@ class DPSVI:
         if self._clip_unscaled_observations:
             kw = dict(self.static_kwargs)
             kw.update(kwargs)
-            n_total = self.model.num_obs_total(args, kw)
-            # get_observations_scale on a one-element batch: plate(N, subsample_size=1) -> N (svi.py:225-234)
-            observation_scale = 1.0 if n_total is None else n_total
+            # a one-element batch: plate(N, subsample_size=1) -> N (svi.py:225-234)
+            observation_scale = get_observations_scale(self.model, (args[0][:1],) + tuple(args[1:]), kw)
         return DPSVIState(optim_state, rng_key, observation_scale)
 
     def _init_gmm(self, rng_key, *args, **kwargs):
@@ -418,8 +433,7 @@ class DPSVI:
         if self._clip_unscaled_observations:
             kw = dict(self.static_kwargs)
             kw.update(kwargs)
-            n_total = self.model.num_obs_total(args, kw)
-            observation_scale = 1.0 if n_total is None else n_total
+            observation_scale = get_observations_scale(self.model, (args[0][:1],) + tuple(args[1:]), kw)
         self._gmm_shape = (gm.K, gm.d)
         return DPSVIState(self.optim.init(params), rng_key, observation_scale)
 

@@ -76,6 +76,22 @@ def test_update_step_2_with_stability_check(gpu):
     assert abs(float(lr) - 0.9) < 1e-7              # 0.72005267 clipped by the lower bound
 
 
+def test_adadp_triple_is_the_class_without_the_step_counter(gpu):
+    """d3p/optimizers.py:29-112: `adadp(...)` returns (init_fun, update_fun(i, g, state), get_params) over the bare state
+    (x, lr, x_stepped, x_prev); the reference's own two-step known answers (tests/test_adadp_optimizer.py) through it."""
+    from d3p_amd.optimizers import adadp
+    init, update, get_params = adadp(1., tol=5., stability_check=False)
+    x, lr, x_stepped, x_prev = init(with_value(0.))
+    assert lr == 1.
+    tree_close(with_value(0.), x_stepped)
+    state = update(0, with_value(1.), (x, lr, x_stepped, x_prev))
+    tree_close(with_value(-0.5), get_params(state))
+    tree_close(with_value(-1.), state[2])
+    state = update(1, with_value(2.), state)
+    tree_close(with_value(-1.5), get_params(state))
+    assert abs(float(state[1]) - 1.018308251) < 1e-6
+
+
 @pytest.mark.parametrize("P,stability", [(1, True), (1000, True), (300000, False)])
 def test_trajectory_vs_oracle(gpu, O, P, stability):
     from d3p_amd.optimizers import ADADP

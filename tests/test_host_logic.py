@@ -282,3 +282,37 @@ def test_util_unvectorize_shape():
     assert util.unvectorize_shape(3, 2) == (1, 1)
     assert util.unvectorize_shape_1d(3) == (1,) and util.unvectorize_shape_2d(a) == (3, 2) and util.unvectorize_shape_3d(a) == (1, 3, 2)
     assert util.example_count(a) == 3 and util.example_count(torch.tensor([1])) == 1 and util.example_count(3.) == 1
+
+
+def test_get_observations_scale_for_the_declared_models():
+    """d3p/svi.py:43-65: the scale of the observed site for a given call -- plate(N, subsample_size = batch) gives N / batch; no total
+    count: 1; the VAE's handlers.scale factor multiplies either (examples/vae.py:95-105).  DPSVI.init asks for a one-element batch."""
+    import numpy as np
+    from d3p_amd.models import GaussianMean, GaussianMixtureModel, LogisticRegression, VAEModel
+    from d3p_amd.svi import get_observations_scale
+    X, y = np.zeros((8, 3), np.float32), np.zeros(8, np.float32)
+    lr = LogisticRegression(3)
+    assert get_observations_scale(lr, (X, y), {"N": 1000}, None) == 125.0
+    assert get_observations_scale(lr, (X[:1], y[:1]), {"num_obs_total": 1000}, None) == 1000.0
+    assert get_observations_scale(lr, (X, y, 40), {}, None) == 5.0
+    assert get_observations_scale(lr, (X, y), {}, None) == 1.0
+    assert get_observations_scale(GaussianMean(3), (X,), {"num_obs_total": 64}, {"mu_loc": 0}) == 8.0
+    assert get_observations_scale(GaussianMixtureModel(2), (X,), {"N": 16}) == 2.0
+    vae = VAEModel(z_dim=2, hidden_dim=4, scale=0.5)
+    assert get_observations_scale(vae, (X,), {"num_obs_total": 80}) == 5.0
+    assert get_observations_scale(vae, (X,), {}) == 0.5
+
+
+def test_gaussian_mixture_mean_and_variance_as_the_reference_writes_them():
+    """d3p/gmm.py:97-103, literally (the weights broadcast against the LAST axis of locs); `component_mean` is the mixture's mean."""
+    import numpy as np
+    from d3p_amd.gmm import GaussianMixture
+    locs = np.array([[1.0, 2.0], [3.0, 5.0]], np.float32)
+    scales = np.array([[1.0, 1.0], [2.0, 0.5]], np.float32)
+    pis = np.array([0.25, 0.75], np.float32)
+    g = GaussianMixture(locs, scales, pis)
+    assert abs(float(g.mean) - float((pis * locs).sum())) < 1e-6
+    want = pis * (scales ** 2 + locs ** 2) - float((pis * locs).sum()) ** 2
+    np.testing.assert_allclose(g.variance.numpy(), want, rtol=1e-6)
+    np.testing.assert_allclose(g.component_mean.numpy(), pis @ locs, rtol=1e-6)
+    assert g.num_components == 2
