@@ -298,12 +298,15 @@ class NativeComm:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         buf = (C.c_uint8 * 128)()
-        if self.rank == 0:
-            check(lib.d3p_comm_unique_id(buf, 128))
-        box = [bytes(buf)]
+        err = None
+        if self.rank == 0 and lib.d3p_comm_unique_id(buf, 128) != 0:
+            err = (lib.d3p_last_error() or b"").decode(errors="replace") or "d3p_comm_unique_id failed"
+        box = [(bytes(buf), err)]      # (rank 0's failure travels with the id: the other ranks are not left waiting in the broadcast)
         if self.world > 1:
             dist.broadcast_object_list(box, src=0, group=group)
-        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        if box[0][1]:
+            raise _lib.D3PError("RCCL communicator not created: rank 0: " + box[0][1])
+        ident = (C.c_uint8 * 128).from_buffer_copy(box[0][0])
         handle = C.c_void_p()
         check(lib.d3p_comm_init(ident, 128, self.world, self.rank, C.byref(handle)))
         self.handle = handle
