@@ -21,6 +21,13 @@ from . import _lib
 from ._lib import BatchSource, check, ptr, stream_ptr
 
 
+def _device_shard(t, what):
+    """A rank's shard of the table as the kernels take it: a contiguous CUDA tensor (a host pointer must never reach a kernel)."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise _lib.D3PError(f"{what}: the rank's shard must be a CUDA tensor")
+    return t.contiguous()
+
+
 def shard_rows(n_rows: int, rank: int, world: int):
     """Contiguous row range [lo, hi) of `rank`; the first n_rows % world ranks hold one extra row."""
     base, rem = divmod(int(n_rows), int(world))
@@ -84,7 +91,7 @@ class HipEngine:
     def __init__(self, svi, X_local, y_local, n_rows_global, row_lo, row_hi, kind, batch_size, q=0.0,
                  suppress=False, **model_kwargs):
         _lib.require_device()
-        self.svi, self.X, self.y = svi, X_local.contiguous(), y_local.contiguous()
+        self.svi, self.X, self.y = svi, _device_shard(X_local, "HipEngine: X"), _device_shard(y_local, "HipEngine: y")
         assert self.X.shape[0] == row_hi - row_lo
         self.n, self.lo, self.hi = int(n_rows_global), int(row_lo), int(row_hi)
         self.kind, self.B, self.q, self.suppress = kind, int(batch_size), float(q), bool(suppress)
@@ -594,7 +601,7 @@ class VaeHipEngine:
 
     def begin(self, state, X_local, batch_size_total, pos0, mask=None, eps=None):
         svi, lib = self.svi, _lib.load()
-        self.X = svi._vae_flat(X_local)
+        self.X = svi._vae_flat(_device_shard(X_local, "VaeHipEngine: X"))
         self.B_local, D = self.X.shape
         self.B_total, self.pos0 = int(batch_size_total), int(pos0)
         dev = self.X.device
@@ -689,7 +696,7 @@ class GmmHipEngine:
         svi, lib = self.svi, _lib.load()
         if eps is not None:
             raise _lib.D3PError("GmmHipEngine: the mixture model has no external-noise mode")
-        self.X = X_local.contiguous()
+        self.X = _device_shard(X_local, "GmmHipEngine: X")
         self.B_local, d = self.X.shape
         self.B_total, self.pos0 = int(batch_size_total), int(pos0)
         dev = self.X.device

@@ -95,6 +95,25 @@ def _as_device_f32(x, device=None):
     return t.to(torch.float32)
 
 
+def _batch_array(x):
+    """A batch argument as a contiguous CUDA tensor.  Device tensors pass through; host tensors and numpy arrays are moved to the
+    current device, floating types as float32 -- what jax does with a numpy argument at every call (x64 off) -- so that a HOST pointer
+    never reaches a kernel (a GPU memory fault, not a Python error)."""
+    if isinstance(x, torch.Tensor) and x.is_cuda:
+        return x.contiguous()
+    _lib.require_device()
+    t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+    if t.is_floating_point():
+        t = t.to(torch.float32)
+    return t.cuda().contiguous()
+
+
+def _mask_array(mask, device):
+    """An example mask (tensor, numpy array, list) as a contiguous uint8 tensor on ``device``."""
+    t = mask if isinstance(mask, torch.Tensor) else torch.as_tensor(np.asarray(mask))
+    return t.to(device=device, dtype=torch.uint8).contiguous()
+
+
 # ------------------------------------------------------------------ module-level gradient manipulators
 def get_observations_scale(model, model_args, model_kwargs, params=None):
     """d3p/svi.py:43-65 for the declared model families: the scale numpyro applies to the observed site's log-likelihood for THESE
@@ -276,7 +295,7 @@ class DPSVI:
     def _init_vae(self, rng_key, *args, **kwargs):
         _lib.require_device()
         lib = _lib.load()
-        X = self._vae_flat(args[0])
+        X = self._vae_flat(_batch_array(args[0]))
         vm = self._vae_struct(X.shape[1], kwargs, 1.0)
         P = int(lib.d3p_vae_num_params(C.byref(vm)))
         # stax.Dense(W_init=stax.randn(), b_init=normal()): every leaf ~ N(0, 0.01^2); the reference's key plumbing
@@ -295,14 +314,14 @@ class DPSVI:
             raise _lib.D3PError("VAE step: needs numpyro-style Adam and rng_suite=d3p_amd.random")
         _lib.require_device()
         lib = _lib.load()
-        X = self._vae_flat(args[0])
+        X = self._vae_flat(_batch_array(args[0]))
         B, D = X.shape
         dev = X.device
         vm = self._vae_struct(D, kwargs, svi_state.observation_scale)
         hyper = self._hyper()
         mask_t = None
         if not isinstance(mask, bool):
-            mask_t = mask.to(torch.uint8).contiguous()
+            mask_t = _mask_array(mask, X.device)
         elif mask is False:
             mask_t = torch.zeros(B, dtype=torch.uint8, device=dev)
         ws = self._workspace(lib.d3p_dpvi_vae_workspace(C.byref(vm), B), dev, "vae_step")
@@ -352,7 +371,7 @@ class DPSVI:
         """The label vector of the batch, or None for families without labels (GaussianMean)."""
         if not self.model.has_labels:
             return None
-        return args[1].contiguous().to(torch.float32)
+        return _batch_array(args[1]).to(torch.float32)
 
     def _model_struct(self, d, kwargs, observation_scale):
         kw = dict(self.static_kwargs)
@@ -390,7 +409,7 @@ class DPSVI:
             return self._init_vae(rng_key, *args, **kwargs)
         self._require_logreg()
         _lib.require_device()
-        X = args[0]
+        X = _batch_array(args[0])
         d = int(X.shape[1])
         D = self.model.latent_dim(d)
         jax_rng_key = self._rng_suite.convert_to_jax_rng_key(rng_key)
@@ -425,7 +444,7 @@ class DPSVI:
 
     def _init_gmm(self, rng_key, *args, **kwargs):
         _lib.require_device()
-        X = args[0]
+        X = _batch_array(args[0])
         gm = self._gmm_struct(int(X.shape[1]), kwargs, 1.0)
         # param('alpha_log', zeros(k)), param('mus_loc', zeros((k, d)))  (gaussian_mixture_model.py:79-83)
         params = torch.zeros(gm.K + gm.K * gm.d, dtype=torch.float32, device=X.device)
@@ -467,7 +486,7 @@ class DPSVI:
     def _compute_per_example_gradients_gmm(self, dp_svi_state, step_rng_key, *args, mask=True, **kwargs):
         _lib.require_device()
         lib = _lib.load()
-        X = args[0].contiguous()
+        X = _batch_array(args[0])
         B, d = X.shape
         gm = self._gmm_struct(d, kwargs, dp_svi_state.observation_scale)
         K, P = gm.K, gm.K + gm.K * d
@@ -477,7 +496,7 @@ class DPSVI:
             raise ValueError("GaussianMixtureModel: parameter vector does not match k and the data dimension")
         mask_t = None
         if not isinstance(mask, bool):
-            mask_t = mask.to(torch.uint8).contiguous()
+            mask_t = _mask_array(mask, X.device)
         elif mask is False:
             mask_t = torch.zeros(B, dtype=torch.uint8, device=X.device)
         px_loss = torch.empty(B, dtype=torch.float32, device=X.device)
@@ -496,7 +515,7 @@ class DPSVI:
         self._require_logreg()
         _lib.require_device()
         lib = _lib.load()
-        X = args[0].contiguous()
+        X = _batch_array(args[0])
         y = self._labels(args)
         B, d = X.shape
         D = self.model.latent_dim(d)
@@ -505,7 +524,7 @@ class DPSVI:
         model = self._model_struct(d, kwargs, dp_svi_state.observation_scale)
         mask_t = None
         if not isinstance(mask, bool):
-            mask_t = mask.to(torch.uint8).contiguous()
+            mask_t = _mask_array(mask, X.device)
         elif mask is False:
             mask_t = torch.zeros(B, dtype=torch.uint8, device=X.device)
         px_loss = torch.empty(B, dtype=torch.float32, device=X.device)
@@ -658,7 +677,7 @@ class DPSVI:
         """DPSVI.update for the mixture model through ``d3p_dpvi_gmm_update`` (one C call, no B x P tensor)."""
         _lib.require_device()
         lib = _lib.load()
-        X = args[0].contiguous()
+        X = _batch_array(args[0])
         B, d = X.shape
         dev = X.device
         gm = self._gmm_struct(d, kwargs, svi_state.observation_scale)
@@ -668,7 +687,7 @@ class DPSVI:
         keybuf[0].copy_(svi_state.rng_key.reshape(16))
         mask_t = None
         if not isinstance(mask, bool):
-            mask_t = mask.to(torch.uint8).contiguous()
+            mask_t = _mask_array(mask, X.device)
         elif mask is False:
             mask_t = torch.zeros(B, dtype=torch.uint8, device=dev)
         st = self._state_struct(keybuf, 0, (step, params, m, v))
@@ -686,7 +705,7 @@ class DPSVI:
         _lib.require_device()
         lib = _lib.load()
         X = info.dataset[0]
-        if not (X.is_contiguous() and X.dtype == torch.float32):
+        if not (X.is_cuda and X.is_contiguous() and X.dtype == torch.float32):
             raise _lib.D3PError("run_steps: dataset arrays must be contiguous float32 CUDA tensors")
         N, d = X.shape
         dev = X.device
@@ -725,7 +744,7 @@ class DPSVI:
         _lib.require_device()
         lib = _lib.load()
         X = self._vae_flat(info.dataset[0])
-        if not (X.is_contiguous() and X.dtype == torch.float32):
+        if not (X.is_cuda and X.is_contiguous() and X.dtype == torch.float32):
             raise _lib.D3PError("run_steps: dataset arrays must be contiguous float32 CUDA tensors")
         N, D = X.shape
         B = int(info.batch_size)
@@ -783,7 +802,7 @@ class DPSVI:
         summation order."""
         _lib.require_device()
         lib = _lib.load()
-        X = args[0].contiguous()
+        X = _batch_array(args[0])
         y = self._labels(args)
         B, d = X.shape
         D = self.model.latent_dim(d)
@@ -800,7 +819,7 @@ class DPSVI:
         hyper = self._hyper()
         mask_t = None
         if not isinstance(mask, bool):
-            mask_t = mask.to(torch.uint8).contiguous()
+            mask_t = _mask_array(mask, X.device)
         elif mask is False:
             mask_t = torch.zeros(B, dtype=torch.uint8, device=dev)
         src = BatchSource(_lib.D3P_BATCH_EXPLICIT, B, 0.0, 0, None, None,
@@ -841,7 +860,7 @@ class DPSVI:
     def _update_fused(self, svi_state, *args, mask=True, _eps=None, _grad_out=None, **kwargs):
         _lib.require_device()
         lib = _lib.load()
-        X = args[0].contiguous()
+        X = _batch_array(args[0])
         y = self._labels(args)
         B, d = X.shape
         D = self.model.latent_dim(d)
@@ -850,7 +869,7 @@ class DPSVI:
         hyper = self._hyper()
         mask_t = None
         if not isinstance(mask, bool):
-            mask_t = mask.to(torch.uint8).contiguous()
+            mask_t = _mask_array(mask, X.device)
         elif mask is False:
             mask_t = torch.zeros(B, dtype=torch.uint8, device=dev)
         src = BatchSource(_lib.D3P_BATCH_EXPLICIT, B, 0.0, 0, None, None,
@@ -925,8 +944,8 @@ class DPSVI:
         lib = _lib.load()
         X = info.dataset[0]
         y = info.dataset[1] if self.model.has_labels else None
-        if not (X.is_contiguous() and X.dtype == torch.float32
-                and (y is None or (y.is_contiguous() and y.dtype == torch.float32))):
+        if not (X.is_cuda and X.is_contiguous() and X.dtype == torch.float32
+                and (y is None or (y.is_cuda and y.is_contiguous() and y.dtype == torch.float32))):
             raise _lib.D3PError("run_steps: dataset arrays must be contiguous float32 CUDA tensors")
         N, d = X.shape
         dev = X.device
@@ -1023,7 +1042,7 @@ class DPSVI:
         if self._is_vae():
             _lib.require_device()
             lib = _lib.load()
-            X = self._vae_flat(args[0])
+            X = self._vae_flat(_batch_array(args[0]))
             B, D = X.shape
             jax_rng_key = self._rng_suite.convert_to_jax_rng_key(self._rng_suite.split(svi_state.rng_key, 1)[0]).contiguous()
             params = self.optim.get_params(svi_state.optim_state).contiguous()
@@ -1037,7 +1056,7 @@ class DPSVI:
         if self._is_gmm():
             _lib.require_device()
             lib = _lib.load()
-            X = args[0].contiguous()
+            X = _batch_array(args[0])
             B, d = X.shape
             jax_rng_key = self._rng_suite.convert_to_jax_rng_key(self._rng_suite.split(svi_state.rng_key, 1)[0]).contiguous()
             params = self.optim.get_params(svi_state.optim_state).contiguous()
@@ -1050,7 +1069,7 @@ class DPSVI:
         self._require_logreg()
         _lib.require_device()
         lib = _lib.load()
-        X = args[0].contiguous()
+        X = _batch_array(args[0])
         y = self._labels(args)
         B, d = X.shape
         # we split to have the same seed as `update` given an svi_state (svi.py:446-447)

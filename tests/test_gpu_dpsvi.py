@@ -1005,3 +1005,46 @@ def test_example_guide_four_leaves_get_four_noise_streams(rng, O):
     for k, name in enumerate(sorted(zeros)):
         want = O.normal(keys[k], tuple(zeros[name].shape))
         np.testing.assert_allclose(np_(out[name]), want, rtol=2e-6, atol=1e-7)
+
+
+# --------------------------------------------------------------------------- host arrays at the Python surface
+def test_host_arrays_are_moved_to_the_device_not_handed_to_kernels(rng):
+    """The reference takes numpy arrays at every call (jax moves them, float64 as float32 with x64 off).  Here a host pointer inside a
+    kernel would be a GPU memory fault: update / evaluate / init move host tensors and numpy arrays (batch, labels, mask) to the device
+    and give bit for bit what the same call gives on device tensors; a batchifier over a HOST table is refused by run_steps with an
+    error, not run."""
+    import d3p_amd._lib as L
+    from d3p_amd.minibatch import subsample_batchify_data
+    from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, MeanFieldGuide, Trace_ELBO
+    from d3p_amd.svi import DPSVI
+    B, d, N = 96, 24, 3000
+    r = np.random.default_rng(4)
+    X64 = r.normal(size=(B, d))                        # float64 on the host
+    y_int = (r.random(B) < 0.5).astype(np.int64)
+    mask_np = r.random(B) < 0.8
+    Xd, yd, md = torch.tensor(X64, dtype=torch.float32).cuda(), torch.tensor(y_int, dtype=torch.float32).cuda(), torch.tensor(mask_np).cuda()
+    for guide_cls, icpt in ((AutoDiagonalNormal, False), (MeanFieldGuide, True)):
+        model = LogisticRegression(d, intercept=icpt)
+        svi = DPSVI(model, guide_cls(model), Adam(1e-2), Trace_ELBO(), 1.0, 0.7, num_obs_total=N)
+        st_dev = svi.init(rng.PRNGKey(2), Xd, yd)
+        st_host = svi.init(rng.PRNGKey(2), X64, y_int)
+        assert st_host.optim_state[1].is_cuda and torch.equal(st_host.optim_state[1], st_dev.optim_state[1])
+        want, want_loss = svi.update(st_dev, Xd, yd, mask=md)
+        for Xa, ya, ma in ((X64, y_int, mask_np), (torch.tensor(X64), torch.tensor(y_int), torch.tensor(mask_np)),
+                           (Xd, yd, list(mask_np))):
+            got, loss = svi.update(st_dev, Xa, ya, mask=ma)
+            assert torch.equal(got.optim_state[1], want.optim_state[1]) and float(loss) == float(want_loss)
+            assert torch.equal(got.rng_key, want.rng_key)
+        assert float(svi.evaluate(want, X64, y_int)) == float(svi.evaluate(want, Xd, yd))
+    # the stage-wise path too
+    st2, px_loss, px_grads, n_el, factor = svi._compute_per_example_gradients(st_dev, rng.PRNGKey(9), X64, y_int, mask=mask_np)
+    st3, px_loss_d, px_grads_d, _, _ = svi._compute_per_example_gradients(st_dev, rng.PRNGKey(9), Xd, yd, mask=md)
+    assert torch.equal(px_loss, px_loss_d) and all(torch.equal(px_grads[k], px_grads_d[k]) for k in px_grads)
+    # a table on the host behind a batchifier: refused
+    model = LogisticRegression(d)
+    svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-2), Trace_ELBO(), 1.0, 0.7, num_obs_total=N)
+    table = (torch.tensor(r.normal(size=(N, d)), dtype=torch.float32), torch.zeros(N))
+    init_b, get_b = subsample_batchify_data(table, batch_size=B, rng_suite=rng)
+    _, bstate = init_b(rng.PRNGKey(1))
+    with pytest.raises(L.D3PError):
+        svi.run_steps(st_dev, get_b, bstate, 0, 3)
