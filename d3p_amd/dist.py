@@ -112,6 +112,8 @@ class HipEngine:
         self.hyper = self.svi._hyper()
         from .svi import _fresh_optim_state
         step0, params0, m0, v0 = state.optim_state
+        self.svi._require_sizes(params0.numel(), self.P)
+        self.svi._require_device_state(state)
         key0 = state.rng_key.reshape(16)
         n = params0.numel()
         self.keybuf = torch.empty((2, 16), dtype=torch.uint32, device=self.dev)
@@ -152,6 +154,8 @@ class HipEngine:
         key words] in 4-byte words --, raw addresses in the structs, no tensor views yet (_lean_views).  False: not applicable."""
         from ._lib import DpsviState
         step0, params0, m0, v0 = state.optim_state
+        self.svi._require_sizes(params0.numel(), self.P)
+        self.svi._require_device_state(state)
         key0 = state.rng_key.reshape(16)
         n = params0.numel()
         if not (params0.dtype == m0.dtype == v0.dtype == torch.float32 and m0.numel() == n and v0.numel() == n
@@ -607,11 +611,15 @@ class VaeHipEngine:
         dev = self.X.device
         self.vm = svi._vae_struct(D, self.model_kwargs, state.observation_scale)
         self.hyper = svi._hyper()
+        svi._require_device_state(state)
+        svi._require_sizes(state.optim_state[1].numel(), lib.d3p_vae_num_params(C.byref(self.vm)))
         self.step, self.params, self.m, self.v = (t.clone() for t in state.optim_state)
         self.keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
         self.keybuf[0].copy_(state.rng_key.reshape(16))
         self.st = svi._state_struct(self.keybuf, 0, (self.step, self.params, self.m, self.v))
-        self.mask = None if mask is None else mask.to(torch.uint8).contiguous()
+        if mask is not None and mask.numel() != self.B_local:
+            raise ValueError(f"mask: {mask.numel()} entries for a shard of {self.B_local} examples")
+        self.mask = None if mask is None else _device_shard(mask, "mask").to(torch.uint8).contiguous()
         self.eps = eps
         self.ws = svi._workspace(lib.d3p_dpvi_vae_workspace(C.byref(self.vm), self.B_local), dev, "vae_step")
         P = int(lib.d3p_vae_num_params(C.byref(self.vm)))
@@ -702,11 +710,15 @@ class GmmHipEngine:
         dev = self.X.device
         self.gm = svi._gmm_struct(d, self.model_kwargs, state.observation_scale)
         self.hyper = svi._hyper()
+        svi._require_device_state(state)
+        svi._require_sizes(state.optim_state[1].numel(), self.gm.K + self.gm.K * d)
         self.step, self.params, self.m, self.v = (t.clone() for t in state.optim_state)
         self.keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
         self.keybuf[0].copy_(state.rng_key.reshape(16))
         self.st = svi._state_struct(self.keybuf, 0, (self.step, self.params, self.m, self.v))
-        self.mask = None if mask is None else mask.to(torch.uint8).contiguous()
+        if mask is not None and mask.numel() != self.B_local:
+            raise ValueError(f"mask: {mask.numel()} entries for a shard of {self.B_local} examples")
+        self.mask = None if mask is None else _device_shard(mask, "mask").to(torch.uint8).contiguous()
         self.ws = svi._workspace(lib.d3p_dpvi_gmm_workspace(C.byref(self.gm), self.B_local), dev, "gmm_step")
         self.sums = torch.empty(self.params.numel() + 2, dtype=torch.float32, device=dev)
         self.loss = torch.empty(1, dtype=torch.float32, device=dev)

@@ -108,10 +108,12 @@ def _batch_array(x):
     return t.cuda().contiguous()
 
 
-def _mask_array(mask, device):
-    """An example mask (tensor, numpy array, list) as a contiguous uint8 tensor on ``device``."""
+def _mask_array(mask, device, B):
+    """An example mask (tensor, numpy array, list) as a contiguous uint8 tensor on ``device``: one entry per example of the batch."""
     t = mask if isinstance(mask, torch.Tensor) else torch.as_tensor(np.asarray(mask))
-    return t.to(device=device, dtype=torch.uint8).contiguous()
+    if t.numel() != int(B):
+        raise ValueError(f"mask: {t.numel()} entries for a batch of {int(B)} examples")
+    return t.to(device=device, dtype=torch.uint8).reshape(-1).contiguous()
 
 
 # ------------------------------------------------------------------ module-level gradient manipulators
@@ -321,7 +323,7 @@ class DPSVI:
         hyper = self._hyper()
         mask_t = None
         if not isinstance(mask, bool):
-            mask_t = _mask_array(mask, X.device)
+            mask_t = _mask_array(mask, X.device, B)
         elif mask is False:
             mask_t = torch.zeros(B, dtype=torch.uint8, device=dev)
         ws = self._workspace(lib.d3p_dpvi_vae_workspace(C.byref(vm), B), dev, "vae_step")
@@ -330,6 +332,7 @@ class DPSVI:
         step0, params0, m0, v0 = svi_state.optim_state
         key0 = svi_state.rng_key.reshape(16)
         n = params0.numel()
+        self._require_sizes(n, lib.d3p_vae_num_params(C.byref(vm)))
         if (params0.dtype == m0.dtype == v0.dtype == torch.float32 and m0.numel() == n and v0.numel() == n
                 and params0.is_contiguous() and m0.is_contiguous() and v0.is_contiguous() and key0.is_contiguous()
                 and key0.dtype == torch.uint32 and step0.dtype == torch.int32):
@@ -496,7 +499,7 @@ class DPSVI:
             raise ValueError("GaussianMixtureModel: parameter vector does not match k and the data dimension")
         mask_t = None
         if not isinstance(mask, bool):
-            mask_t = _mask_array(mask, X.device)
+            mask_t = _mask_array(mask, X.device, B)
         elif mask is False:
             mask_t = torch.zeros(B, dtype=torch.uint8, device=X.device)
         px_loss = torch.empty(B, dtype=torch.float32, device=X.device)
@@ -521,10 +524,11 @@ class DPSVI:
         D = self.model.latent_dim(d)
         jax_rng_key = self._rng_suite.convert_to_jax_rng_key(step_rng_key).contiguous()
         params = self.optim.get_params(dp_svi_state.optim_state).contiguous()
+        self._require_sizes(params.numel(), 2 * D, B, y)
         model = self._model_struct(d, kwargs, dp_svi_state.observation_scale)
         mask_t = None
         if not isinstance(mask, bool):
-            mask_t = _mask_array(mask, X.device)
+            mask_t = _mask_array(mask, X.device, B)
         elif mask is False:
             mask_t = torch.zeros(B, dtype=torch.uint8, device=X.device)
         px_loss = torch.empty(B, dtype=torch.float32, device=X.device)
@@ -682,12 +686,13 @@ class DPSVI:
         dev = X.device
         gm = self._gmm_struct(d, kwargs, svi_state.observation_scale)
         hyper = self._hyper()
+        self._require_sizes(svi_state.optim_state[1].numel(), gm.K + gm.K * d)
         step, params, m, v = _fresh_optim_state(svi_state.optim_state)
         keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
         keybuf[0].copy_(svi_state.rng_key.reshape(16))
         mask_t = None
         if not isinstance(mask, bool):
-            mask_t = _mask_array(mask, X.device)
+            mask_t = _mask_array(mask, X.device, B)
         elif mask is False:
             mask_t = torch.zeros(B, dtype=torch.uint8, device=dev)
         st = self._state_struct(keybuf, 0, (step, params, m, v))
@@ -711,6 +716,7 @@ class DPSVI:
         dev = X.device
         gm = self._gmm_struct(d, kwargs, svi_state.observation_scale)
         hyper = self._hyper()
+        self._require_sizes(svi_state.optim_state[1].numel(), gm.K + gm.K * d)
         step, params, m, v = _fresh_optim_state(svi_state.optim_state)
         keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
         keybuf[0].copy_(svi_state.rng_key.reshape(16))
@@ -751,6 +757,7 @@ class DPSVI:
         dev = X.device
         vm = self._vae_struct(D, kwargs, svi_state.observation_scale)
         hyper = self._hyper()
+        self._require_sizes(svi_state.optim_state[1].numel(), lib.d3p_vae_num_params(C.byref(vm)))
         step, params, m, v = _fresh_optim_state(svi_state.optim_state)
         keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
         keybuf[0].copy_(svi_state.rng_key.reshape(16))
@@ -765,8 +772,26 @@ class DPSVI:
         return (DPSVIState((step, params, m, v), keybuf[int(num_steps) & 1].reshape(4, 4), svi_state.observation_scale),
                 losses[:int(num_steps)])
 
+    @staticmethod
+    def _require_sizes(n_params, expected, B=None, y=None):
+        """The kernels take shapes from the batch and addresses from the state: a state for another model or feature count, or labels
+        of another length, would be read out of bounds."""
+        if int(n_params) != int(expected):
+            raise ValueError(f"the state holds {int(n_params)} parameters, this model on a batch of this shape has {int(expected)}")
+        if y is not None and B is not None and y.numel() != int(B):
+            raise ValueError(f"labels: {y.numel()} entries for a batch of {int(B)} examples")
+
+    @staticmethod
+    def _require_device_state(svi_state):
+        """The state's key and flat optimiser arrays are handed to kernels by address: they must be device tensors (a state that was
+        moved to the host, e.g. to save it, goes back with ``.cuda()`` first)."""
+        for t in (svi_state.rng_key,) + tuple(svi_state.optim_state):
+            if isinstance(t, torch.Tensor) and not t.is_cuda:
+                raise _lib.D3PError("DPSVI: the state's tensors must live on the GPU (found a host tensor in the state)")
+
     def update(self, svi_state, *args, mask=True, **kwargs):
         """One DP-VI step on a batch; returns ``(new_state, loss)`` (svi.py:395-434)."""
+        self._require_device_state(svi_state)
         if self._gmm_fusable():
             return self._update_gmm_fused(svi_state, *args, mask=mask, **kwargs)
         if self._is_vae():
@@ -810,6 +835,7 @@ class DPSVI:
         dev = X.device
         step0, params0, m0, v0 = svi_state.optim_state
         key0 = svi_state.rng_key.reshape(16)
+        self._require_sizes(params0.numel(), P, B, y)
         if not (X.dtype == torch.float32 and (y is None or y.dtype == torch.float32)
                 and params0.dtype == m0.dtype == v0.dtype == torch.float32 and params0.numel() == m0.numel() == v0.numel() == P
                 and params0.is_contiguous() and m0.is_contiguous() and v0.is_contiguous() and key0.is_contiguous()
@@ -819,7 +845,7 @@ class DPSVI:
         hyper = self._hyper()
         mask_t = None
         if not isinstance(mask, bool):
-            mask_t = _mask_array(mask, X.device)
+            mask_t = _mask_array(mask, X.device, B)
         elif mask is False:
             mask_t = torch.zeros(B, dtype=torch.uint8, device=dev)
         src = BatchSource(_lib.D3P_BATCH_EXPLICIT, B, 0.0, 0, None, None,
@@ -869,7 +895,7 @@ class DPSVI:
         hyper = self._hyper()
         mask_t = None
         if not isinstance(mask, bool):
-            mask_t = _mask_array(mask, X.device)
+            mask_t = _mask_array(mask, X.device, B)
         elif mask is False:
             mask_t = torch.zeros(B, dtype=torch.uint8, device=dev)
         src = BatchSource(_lib.D3P_BATCH_EXPLICIT, B, 0.0, 0, None, None,
@@ -877,6 +903,7 @@ class DPSVI:
         step0, params0, m0, v0 = svi_state.optim_state
         key0 = svi_state.rng_key.reshape(16)
         n = params0.numel()
+        self._require_sizes(n, 2 * D, B, y)
         if (_eps is None and _grad_out is None and X.dtype == torch.float32 and (y is None or y.dtype == torch.float32)
                 and params0.dtype == m0.dtype == v0.dtype == torch.float32 and m0.numel() == n and v0.numel() == n
                 and params0.is_contiguous() and m0.is_contiguous() and v0.is_contiguous() and key0.is_contiguous()
@@ -926,6 +953,7 @@ class DPSVI:
         caller then checks with ``DPSVI.last_run_status()`` before trusting the result.  A run that was stopped is run again,
         from the same (untouched) input state, with one launch per step (``d3p_dpvi_logreg_set_run_form``) before anything is
         raised: a stalled chained launch costs the caller time, not the result."""
+        self._require_device_state(svi_state)
         info = getattr(get_batch, "source", None)
         if info is None or info.rng_suite is not strong_rng or not (self._gmm_fusable() or self._is_vae() or self._fusable()):
             # no native loop for this combination (sampling with replacement, split_batchify_data's epochs, another rng_suite,
@@ -955,6 +983,7 @@ class DPSVI:
         step0, params0, m0, v0 = svi_state.optim_state
         key0 = svi_state.rng_key.reshape(16)
         n = params0.numel()
+        self._require_sizes(n, 2 * self.model.latent_dim(d), N, y)
         nl = max(num_steps, 1)
         if (params0.dtype == m0.dtype == v0.dtype == torch.float32 and m0.numel() == n
                 and v0.numel() == n and params0.is_contiguous() and m0.is_contiguous() and v0.is_contiguous()
@@ -1039,6 +1068,7 @@ class DPSVI:
     # ---------------------------------------------------------------- evaluate / accounting
     def evaluate(self, svi_state, *args, **kwargs):
         """ELBO loss of a batch at the current parameters (d3p/svi.py:436-449 -> numpyro SVI.evaluate)."""
+        self._require_device_state(svi_state)
         if self._is_vae():
             _lib.require_device()
             lib = _lib.load()
@@ -1048,6 +1078,7 @@ class DPSVI:
             params = self.optim.get_params(svi_state.optim_state).contiguous()
             vm = self._vae_struct(D, kwargs, 1.0)
             vm.scale = vm.scale / B                  # plate(N, B) scales every site by N / B instead of N
+            self._require_sizes(params.numel(), lib.d3p_vae_num_params(C.byref(vm)))
             ws = self._workspace(lib.d3p_dpvi_vae_workspace(C.byref(vm), B), X.device, "vae_step")
             loss = torch.empty(1, dtype=torch.float32, device=X.device)
             check(lib.d3p_vae_evaluate(stream_ptr(), C.byref(vm), ptr(params), ptr(X), B, ptr(jax_rng_key),
@@ -1061,6 +1092,7 @@ class DPSVI:
             jax_rng_key = self._rng_suite.convert_to_jax_rng_key(self._rng_suite.split(svi_state.rng_key, 1)[0]).contiguous()
             params = self.optim.get_params(svi_state.optim_state).contiguous()
             gm = self._gmm_struct(d, kwargs, 1.0)
+            self._require_sizes(params.numel(), gm.K + gm.K * d)
             ws = self._workspace(lib.d3p_gmm_evaluate_workspace(C.byref(gm), B), X.device, "gmm_eval")
             loss = torch.empty(1, dtype=torch.float32, device=X.device)
             check(lib.d3p_gmm_evaluate(stream_ptr(), C.byref(gm), ptr(params), ptr(X), B, ptr(jax_rng_key), ptr(loss),
@@ -1076,6 +1108,7 @@ class DPSVI:
         jax_rng_key = self._rng_suite.convert_to_jax_rng_key(self._rng_suite.split(svi_state.rng_key, 1)[0]).contiguous()
         params = self.optim.get_params(svi_state.optim_state).contiguous()
         model = self._model_struct(d, kwargs, 1.0)
+        self._require_sizes(params.numel(), 2 * self.model.latent_dim(d), B, y)
         ws = self._workspace(lib.d3p_logreg_evaluate_workspace(C.byref(model), B), X.device, "eval")
         loss = torch.empty(1, dtype=torch.float32, device=X.device)
         if isinstance(self.guide, MeanFieldGuide):   # two sample sites, each with its own key; parameters into the kernels' order

@@ -1048,3 +1048,57 @@ def test_host_arrays_are_moved_to_the_device_not_handed_to_kernels(rng):
     _, bstate = init_b(rng.PRNGKey(1))
     with pytest.raises(L.D3PError):
         svi.run_steps(st_dev, get_b, bstate, 0, 3)
+    # a state that went to the host (e.g. to be saved): refused until it is moved back
+    from d3p_amd.svi import DPSVIState
+    host_state = DPSVIState(tuple(t.cpu() for t in st_dev.optim_state), st_dev.rng_key.cpu(), st_dev.observation_scale)
+    with pytest.raises(L.D3PError):
+        svi.update(host_state, Xd, yd)
+    with pytest.raises(L.D3PError):
+        svi.evaluate(host_state, Xd, yd)
+
+
+def test_shapes_that_do_not_fit_the_state_are_python_errors(rng):
+    """The kernels take sizes from the batch and addresses from the state; a batch with another feature count, labels or a mask of
+    another length, or a state made for another model would be read out of bounds on the GPU: every entry point refuses them first."""
+    from d3p_amd.minibatch import subsample_batchify_data
+    from d3p_amd.models import (Adam, AutoDiagonalNormal, GaussianMixtureGuide, GaussianMixtureModel, LogisticRegression, MeanFieldGuide,
+                                Trace_ELBO, VAEGuide, VAEModel)
+    from d3p_amd.svi import DPSVI
+    B, d, N = 32, 12, 1000
+    X = torch.randn(B, d, device="cuda")
+    y = (torch.rand(B, device="cuda") < 0.5).float()
+    for guide_cls, icpt in ((AutoDiagonalNormal, False), (MeanFieldGuide, True)):
+        model = LogisticRegression(d, intercept=icpt)
+        svi = DPSVI(model, guide_cls(model), Adam(1e-2), Trace_ELBO(), 1.0, 0.7, num_obs_total=N)
+        st = svi.init(rng.PRNGKey(2), X, y)
+        svi.update(st, X, y)
+        wider = torch.randn(B, d + 3, device="cuda")
+        for call in (lambda: svi.update(st, wider, y), lambda: svi.evaluate(st, wider, y),
+                     lambda: svi.update(st, X, y[:-1]), lambda: svi.update(st, X, y, mask=torch.ones(B + 1, dtype=torch.bool)),
+                     lambda: svi._compute_per_example_gradients(st, rng.PRNGKey(1), wider, y)):
+            with pytest.raises(ValueError):
+                call()
+    table = (torch.randn(N, d + 1, device="cuda"), torch.zeros(N, device="cuda"))
+    model = LogisticRegression(d)
+    svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-2), Trace_ELBO(), 1.0, 0.7, num_obs_total=N)
+    st = svi.init(rng.PRNGKey(2), X, y)
+    init_b, get_b = subsample_batchify_data(table, batch_size=B, rng_suite=rng)
+    with pytest.raises(ValueError):
+        svi.run_steps(st, get_b, init_b(rng.PRNGKey(1))[1], 0, 3)
+    gmm = GaussianMixtureModel(3)
+    gsvi = DPSVI(gmm, GaussianMixtureGuide(gmm), Adam(1e-2), Trace_ELBO(), 1.0, 0.7, k=3, num_obs_total=N)
+    gst = gsvi.init(rng.PRNGKey(3), X)
+    gsvi.update(gst, X)
+    with pytest.raises(ValueError):
+        gsvi.update(gst, torch.randn(B, d + 1, device="cuda"))
+    with pytest.raises(ValueError):
+        gsvi.evaluate(gst, torch.randn(B, d + 1, device="cuda"))
+    vae = VAEModel(z_dim=4, hidden_dim=16, scale=1.0 / N)
+    vsvi = DPSVI(vae, VAEGuide(vae), Adam(1e-2), Trace_ELBO(), 1.0, 0.7, num_obs_total=N)
+    Xv = (torch.rand(B, 24, device="cuda") < 0.5).float()
+    vst = vsvi.init(rng.PRNGKey(4), Xv)
+    vsvi.update(vst, Xv)
+    with pytest.raises(ValueError):
+        vsvi.update(vst, (torch.rand(B, 28, device="cuda") < 0.5).float())
+    with pytest.raises(ValueError):
+        vsvi.evaluate(vst, (torch.rand(B, 28, device="cuda") < 0.5).float())
