@@ -337,18 +337,24 @@ __global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
     const float factor = (n == 0.0f) ? 0.0f : Bf / n;
     const float inv_B = 1.0f / Bf, inv_bc1 = 1.0f / a.slot->bc1, inv_bc2 = 1.0f / a.slot->bc2;
     const float noise_scale = a.dp_scale * (a.clip / n), out_scale = a.obs_scale * factor;
+    // (the parameters the step ran with, asked by the reporter of an EMPTY batch's loss below: state_in IS state_out after an odd number
+    //  of launches, so every thread notes what it reads before it stores -- thread 0 reading the columns afterwards saw updated ones)
+    int x_bad = 0;
     for (int col = tid; col < a.P; col += blockDim.x) {
         long long sll = 0;
         for (int r = 0; r < a.nrep; ++r) sll += a.acc_prev[(size_t)r * PA + col];
         const float tot = (float)((double)sll * a.inv_sg);
         const float g = __fmaf_rn(a.noise[col], noise_scale, tot * inv_B) * out_scale;
+        const float x0 = a.state_in[0][col];
+        x_bad |= !(fabsf(x0) <= 3.402823466e38f);
         const float mm = (1.0f - a.b1) * g + a.b1 * a.state_in[1][col];
         const float vv = (1.0f - a.b2) * g * g + a.b2 * a.state_in[2][col];
-        const float xx = a.state_in[0][col] - a.lr * (mm * inv_bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv * inv_bc2) + a.adam_eps);
+        const float xx = x0 - a.lr * (mm * inv_bc1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv * inv_bc2) + a.adam_eps);
         a.state_out[0][col] = xx;
         a.state_out[1][col] = mm;
         a.state_out[2][col] = vv;
     }
+    x_bad = __syncthreads_or(x_bad);
     if (tid == 0) {
         long long lll = 0, lhh = 0;
         for (int r = 0; r < a.nrep; ++r) {
@@ -357,7 +363,7 @@ __global__ void __launch_bounds__(1024) k_flush(FlushArgs a)
         }
         if (a.loss_out) {
             float lv = ((float)loss_join(lhh, lll) / Bf) * a.obs_scale * factor;
-            if (n == 0.0f) lv = empty_batch_loss(a.P, [&](int c) { return a.state_in[0][c]; });
+            if (n == 0.0f) lv = x_bad ? __builtin_nanf("") : 0.0f;   // empty_batch_loss (d3p_device.h) on the values noted above
             *a.loss_out = lv;
         }
         *a.adam_step = a.slot->adam_i + 1;

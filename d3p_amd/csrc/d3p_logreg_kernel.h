@@ -1187,9 +1187,26 @@ __global__ void __launch_bounds__(D3P_MAIN_MAX_THREADS(V, NK)) k_logreg_main(Mai
                 for (int w = 0; w < W; ++w) s += red[(size_t)w * P + c];
                 out[c] = s;
             }
+            // A parameter that is not finite makes the step's loss NaN even when NO example is valid: the reference multiplies every
+            // example's (NaN) loss by its mask, NaN * 0 = NaN (svi.py:271-281), while these kernels evaluate no masked example.
+            // Workgroup 0's loss partial carries it (the derived columns of the step's parameters are all in LDS: loc, s, sg, q, lc).
+            // (the vote goes through the reduction buffer, which has been read out by now: __syncthreads_or would add static LDS to a
+            //  kernel whose dynamic LDS may already be the CU's 160 KB)
+            int p_bad = 0;
+            if (bid == 0) {
+                for (int c = threadIdx.x; c < 5 * D; c += blockDim.x) p_bad |= !(fabsf(pk[c]) <= 3.402823466e38f);
+                const bool wave_bad = __any(p_bad);
+                __syncthreads();
+                if (lane == 0) red[wave] = wave_bad ? 1.0f : 0.0f;
+                __syncthreads();
+                p_bad = 0;
+                if (threadIdx.x == 0)
+                    for (int w = 0; w < W; ++w) p_bad |= red[w] != 0.0f;
+            }
             if (threadIdx.x < 2) {
                 float s = 0.f;
                 for (int w = 0; w < W; ++w) s += tail[2 * w + threadIdx.x];
+                if (threadIdx.x == 0 && p_bad) s = __builtin_nanf("");
                 out[P + threadIdx.x] = s;
             }
         }
@@ -1275,13 +1292,11 @@ static int main_geometry(const d3p_logreg_model* m, uint32_t B, MainGeom* g, boo
         g->full = true;
     }
     // rows too wide for the register-tiled kernel (NK == 0), or its spilling NK == 8 form: the column-chunked kernel of
-    // d3p_logreg_wide.h takes them when the caller runs the clip-and-accumulate stage of a logistic-regression model and its
-    // 4 accumulator rows fit the LDS
-    const bool wide_ok = allow_wide && m->family == D3P_FAMILY_LOGREG && (size_t)(4 * P + 8) * sizeof(float) <= 160 * 1024 &&
-                         getenv("D3P_NO_WIDE_KERNEL") == nullptr;
+    // d3p_logreg_wide.h takes them when the caller runs the clip-and-accumulate stage and its 4 accumulator rows fit the LDS
+    const bool wide_ok = allow_wide && (size_t)(4 * P + 8) * sizeof(float) <= 160 * 1024 && getenv("D3P_NO_WIDE_KERNEL") == nullptr;
     if (g->NK == 0 && !wide_ok)
-        return fail(D3P_E_UNSUPPORTED, "logreg kernel: latent dimension %d exceeds the supported maximum (%d)", D,
-                    2 * 64 * g->V * 8);
+        return fail(D3P_E_UNSUPPORTED, "step kernel: latent dimension %d: the register-tiled kernel holds at most %d columns for rows of this "
+                    "alignment%s", D, 2 * 64 * g->V * 8, allow_wide ? " and the column-chunked kernel's accumulator rows do not fit the LDS" : "");
     const bool too_wide = g->NK == 0;
     if (too_wide && wide_ok) g->NK = 8;  // placeholder: only the chunked kernel is launched with this geometry
     // waves per workgroup (default 16 = one 1024-thread workgroup per CU at 4 waves/SIMD), reduced until

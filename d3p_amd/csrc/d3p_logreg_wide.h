@@ -8,7 +8,8 @@
 // -- regenerating the guide noise in every pass (threefry + erf_inv: cheaper than keeping 8192 values per example anywhere)
 // and reading the derived columns from the global pack (L2-resident, 5 D floats).  LDS holds only the W accumulator rows
 // (W = 4: 128 KB at d = 4096).  Same formulas as k_logreg_main; sums are taken in a different order, so results agree with it
-// (and the oracle) to rounding, not bit for bit.  Logistic-regression family only.
+// (and the oracle) to rounding, not bit for bit.  Both likelihood families: for the Gaussian mean the residual x - z takes the place of
+// the feature (as in k_logreg_main), the chunk hands it out instead of x.
 #pragma once
 #include "d3p_logreg_kernel.h"
 
@@ -37,6 +38,7 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
     float* mine = acc + (size_t)wave * P;
     const float* pk = a.pack;         // [loc | s | sg | q | lc] x D
     const bool eps_from_mem = a.eps_ext != nullptr;
+    const bool gauss = a.family == D3P_FAMILY_GAUSS_MEAN;
     const bool vec_ok = !a.icpt && (d & 3) == 0 && (half & 3) == 0 && D == 2 * half &&
                         ((reinterpret_cast<uintptr_t>(a.X) | reinterpret_cast<uintptr_t>(pk) |
                           reinterpret_cast<uintptr_t>(a.eps_ext)) & 15u) == 0;
@@ -118,6 +120,10 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
                 }
                 z0[i] = __fmaf_rn(s0[i], e0[i], l0[i]);
                 z1[i] = __fmaf_rn(s1[i], e1[i], l1[i]);
+                if (gauss) {  // residuals take the place of the features: dloglik/dz = (x - z) / sigma^2
+                    x0[i] = ok0[i] ? x0[i] - z0[i] : 0.f;
+                    x1[i] = ok1[i] ? x1[i] - z1[i] : 0.f;
+                }
             }
         };
         // 4 consecutive entries of derived-column array `arr` (0 .. 4) for both halves of a chunk
@@ -145,16 +151,16 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c0 = cb + 4 * lane + i, c1 = c0 + half;
-                tp = __fmaf_rn(x0[i], z0[i], tp);
-                tp = __fmaf_rn(x1[i], z1[i], tp);
+                tp = __fmaf_rn(x0[i], gauss ? x0[i] : z0[i], tp);   // logit x . z, or the squared residual norm
+                tp = __fmaf_rn(x1[i], gauss ? x1[i] : z1[i], tp);
                 lp += ok0[i] ? __fmaf_rn(col_hz(c0) * z0[i], z0[i], __fmaf_rn(-0.5f * e0[i], e0[i], lc0[i])) : 0.f;
                 lp += ok1[i] ? __fmaf_rn(col_hz(c1) * z1[i], z1[i], __fmaf_rn(-0.5f * e1[i], e1[i], lc1[i])) : 0.f;
             }
         }
         const float t = wave_sum(tp);
         lp = wave_sum(lp);
-        const float A = a.A_scale * (sigmoid_f(t) - yv);
-        const float loglik = yv * t - softplus_f(t);
+        const float A = gauss ? 2.0f * a.A_scale * a.nh_inv_var : a.A_scale * (sigmoid_f(t) - yv);
+        const float loglik = gauss ? __fmaf_rn(a.nh_inv_var, t, -a.ll_const) : yv * t - softplus_f(t);
         const float L = a.inv_obs * (lp - a.lik_scale * loglik);  // svi.py:278-281
 
         if (PXG) {
@@ -239,9 +245,24 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
         for (int w = 0; w < W; ++w) s += acc[(size_t)w * P + c];
         out[c] = s;
     }
+    // (workgroup 0: a step parameter that is not finite makes the loss NaN even when no example is valid, as in k_logreg_main)
+    // (the vote goes through the accumulator rows, read out by now: the dynamic LDS may be all of the CU's 160 KB, no room for the
+    //  static word of __syncthreads_or)
+    int p_bad = 0;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < 5 * D; c += blockDim.x) p_bad |= !(fabsf(pk[c]) <= 3.402823466e38f);
+        const bool wave_bad = __any(p_bad);
+        __syncthreads();
+        if (lane == 0) acc[wave] = wave_bad ? 1.0f : 0.0f;
+        __syncthreads();
+        p_bad = 0;
+        if (threadIdx.x == 0)
+            for (int w = 0; w < W; ++w) p_bad |= acc[w] != 0.0f;
+    }
     if (threadIdx.x < 2) {
         float s = 0.f;
         for (int w = 0; w < W; ++w) s += tail[2 * w + threadIdx.x];
+        if (threadIdx.x == 0 && p_bad) s = __builtin_nanf("");
         out[P + threadIdx.x] = s;
     }
 }

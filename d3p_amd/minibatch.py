@@ -81,6 +81,9 @@ def poisson_batchify_data(dataset, q, max_batch_size, handle_oversized_batch="tr
     def get_batch(i, batchifier_state):
         """d3p/minibatch.py:104-131 -> (batch_tuple, mask)."""
         _lib.require_device()
+        if max_batch_size > num_records:
+            # d3p/minibatch.py:116: poisson_sample_idxs clamps its cutoff to N, then `assert len(idxs) == max_batch_size` fails
+            raise AssertionError("poisson_batchify_data: max_batch_size exceeds the number of records")
         rng_key = rng_suite.fold_in(batchifier_state, i)
         idxs, counts, ws, kind, cutoff = poisson_sample_idxs(rng_key, q, num_records, rng_suite, max_batch_size)
         check(_lib.load().d3p_poisson_select_rng(stream_ptr(), kind, ptr(rng_key.contiguous()), float(q),

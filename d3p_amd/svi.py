@@ -955,6 +955,8 @@ class DPSVI:
         raised: a stalled chained launch costs the caller time, not the result."""
         self._require_device_state(svi_state)
         info = getattr(get_batch, "source", None)
+        if info is not None and info.kind == _lib.D3P_BATCH_POISSON and int(info.batch_size) > example_count(info.dataset[0]):
+            raise AssertionError("poisson_batchify_data: max_batch_size exceeds the number of records")   # (as get_batch, minibatch.py:116)
         if info is None or info.rng_suite is not strong_rng or not (self._gmm_fusable() or self._is_vae() or self._fusable()):
             # no native loop for this combination (sampling with replacement, split_batchify_data's epochs, another rng_suite,
             # the stage-wise optimisers): the same steps through the API-parity path -- get_batch + update, one call each,

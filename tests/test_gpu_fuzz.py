@@ -1,0 +1,17 @@
+"""A fixed handful of the randomised cases of tests/fuzz_vs_oracle.py inside the suite: random model family / guide / shape / batch
+source / clipping threshold / noise scale / step count, HIP trajectory vs the oracle's (tolerances in that file).  Long sweeps are run
+by hand (`python tests/fuzz_vs_oracle.py first count`); profiles/ keeps their records."""
+import pytest
+
+from . import fuzz_vs_oracle as F
+
+pytestmark = pytest.mark.gpu
+
+
+# (0 .. 39, and the seeds of the sweep's first 440 that found something: 23 -- Gaussian mean with rows too wide for the register-tiled
+#  kernel; 119, 229, 335, 349 -- the loss of a FIRST empty batch read the updated parameters (k_flush in place); 259, 310, 326 -- the loss of
+#  an empty batch behind a NaN state on the column-chunked / two-kernel path; 275, 337 -- losses that are small differences of large sums)
+@pytest.mark.parametrize("seed", list(range(40)) + [119, 229, 259, 275, 310, 326, 335, 337, 349])
+def test_random_case_vs_oracle(gpu, O, seed):
+    c = F.run_case(F.draw_case(seed), O)
+    assert c["ok"], c

@@ -44,7 +44,7 @@ def problem(B, d, seed):
     return X, loc, unc
 
 
-@pytest.mark.parametrize("B,d", [(9, 4), (16, 100), (40, 512), (5, 1000)])
+@pytest.mark.parametrize("B,d", [(9, 4), (16, 100), (40, 512), (5, 1000), (6, 1500), (5, 2600)])   # (the last two: column-chunked kernel)
 @pytest.mark.parametrize("auto_guide", [False, True])
 @pytest.mark.parametrize("onchip", [False, True])
 def test_px_grads_vs_oracle(rng, O, B, d, auto_guide, onchip):
@@ -70,7 +70,7 @@ def test_px_grads_vs_oracle(rng, O, B, d, auto_guide, onchip):
     assert np.all(G[~mask] == 0) and not np.allclose(G[mask], 0)
 
 
-@pytest.mark.parametrize("B,d,masked", [(16, 4, False), (50, 96, True), (64, 512, False)])
+@pytest.mark.parametrize("B,d,masked", [(16, 4, False), (50, 96, True), (64, 512, False), (12, 1500, True), (9, 2600, False)])
 @pytest.mark.parametrize("onchip", [False, True])
 def test_fused_update_vs_oracle(rng, O, B, d, masked, onchip):
     N = 5000
