@@ -59,10 +59,14 @@ __device__ __forceinline__ double open_unit_d(uint32_t b) { return ((double)b + 
 
 __device__ __forceinline__ double gamma_sample_d(uint32_t k0, uint32_t k1, uint32_t comp, double alpha)
 {
+    // A concentration that is NaN or +inf (a diverged state: exp(alpha_log)) makes every acceptance test false: jax.random.gamma's
+    // while_loop condition is false on NaN too and returns NaN at once -- so does this; and the loop is bounded whatever comes in
+    // (acceptance >= 0.95 per attempt: 1024 misses do not happen), a kernel must not spin on a parameter value.
+    if (!(alpha < 1.7976931348623157e308)) return alpha;
     const double a = alpha < 1.0 ? alpha + 1.0 : alpha;
     const double dd = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
     double g = 0.0;
-    for (uint32_t attempt = 0; attempt < 0x7fffffffu; ++attempt) {
+    for (uint32_t attempt = 0; attempt < 1024u; ++attempt) {
         uint32_t b0, b1;
         threefry2x32(k0, k1, comp, attempt, b0, b1);
         const double x = (double)bits_to_normal(b0);
@@ -497,6 +501,10 @@ __global__ void __launch_bounds__(256, (KH * DS <= 8 ? 3 : KH * DS <= 16 ? 2 : 1
             const long long v = tid == 0 ? lo : tid == 1 ? (long long)red[P + 1] : hi;
             if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(out + P + tid), (unsigned long long)v);
         }
+        // (workgroup 0) so does a parameter that is not finite, even when no example is valid: the reference's masked sum is NaN * 0 = NaN
+        // there (svi.py:271-281), while this kernel evaluates no masked example
+        if (blockIdx.x == 0)
+            for (int c = tid; c < P; c += 256) bad |= !(fabsf(a.params[c]) <= 3.402823466e38f);
         // a non-finite partial poisons the count column: the update that reads it yields NaN like the reference's float sums
         if (bad) atomicAdd(reinterpret_cast<unsigned long long*>(out + P + 1), 1ull << 44);
     }

@@ -1027,10 +1027,13 @@ static inline double bits_to_open_unit_d(uint32_t b) { return ((double)b + 0.5) 
 /* Gamma(alpha, 1) draw for mixture component `comp`: Marsaglia & Tsang (2000); alpha < 1 boosted by U^(1/alpha). */
 D3P_API double d3po_gamma_sample(const uint32_t key[2], uint32_t comp, double alpha)
 {
+    /* NaN / +inf concentration (a diverged state): every acceptance test is false; jax.random.gamma's while_loop condition is false
+     * on NaN as well and returns NaN at once.  The loop is bounded in any case (acceptance >= 0.95 per attempt). */
+    if (!(alpha < 1.7976931348623157e308)) return alpha;
     const double a = alpha < 1.0 ? alpha + 1.0 : alpha;
     const double dd = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
     double g = 0.0;
-    for (uint32_t attempt = 0; attempt < 0x7fffffffu; ++attempt) {
+    for (uint32_t attempt = 0; attempt < 1024u; ++attempt) {
         uint32_t b[2];
         d3po_threefry2x32(key[0], key[1], comp, attempt, b);
         const double x = (double)bits_to_normal(b[0]);

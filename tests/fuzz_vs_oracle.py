@@ -9,7 +9,10 @@ restatement of d3p/svi.py:395-434 driven by the oracle's own samplers: state key
 losses and parameters (empty batches: svi.py:305, :365), final parameters
 (rtol 5e-4, atol 5e-5 of the largest) and step counter.
 
-    python tests/fuzz_vs_oracle.py [first_seed=0] [count=40] [out.jsonl]
+    python tests/fuzz_vs_oracle.py [update|gmm|vae|rng] [first_seed=0] [count=40] [out.jsonl]
+
+`gmm`: the mixture model's update (explicit batches with masks, Feistel runs) vs the oracle's stage composition; `rng`: split / fold_in /
+random_bits / randint / uniform / normal / Feistel / Poisson selection at random arguments, bit-exact (normal: 2e-6).
 
 `tests/test_gpu_fuzz.py` runs a fixed handful of seeds inside the suite; a long sweep is run by hand on a GPU box."""
 import json
@@ -165,7 +168,287 @@ def run_case(c, O, dump=False):
     return c
 
 
+# ------------------------------------------------------------------ the mixture model (BASELINE configs[2]'s family)
+def draw_gmm_case(seed):
+    r = np.random.default_rng(200_003 * seed + 29)
+    c = {"seed": int(seed), "family": "gmm"}
+    c["K"] = int(r.choice([2, 3, 5, 16, 17, 32]))
+    c["d"] = int(r.choice([1, 2, 3, 17, 64, 70, 128] + ([256] if c["K"] <= 16 else [])))
+    cap = max(int(3e5 / (c["K"] * c["d"])), 1)
+    c["B"] = int(min(int(r.choice([1, 2, 7, 33, 64, 200, 1000])), cap))
+    c["steps"] = int(r.choice([1, 2, 4])) if c["B"] * c["K"] * c["d"] <= 1e5 else 1
+    c["source"] = str(r.choice(["explicit", "feistel"]))
+    c["N"] = int(max(c["B"] * float(r.choice([1.0, 3.0, 50.0])), c["B"]))
+    c["clip"] = float(r.choice([1.0, 20.0, 1e6]))
+    c["sigma"] = float(r.choice([0.0, 0.7]))
+    c["lr"] = float(r.choice([1e-3, 1e-2]))
+    c["first"] = int(r.choice([0, 5]))
+    c["mask_keep"] = float(r.choice([1.0, 0.7, 0.0 if r.random() < 0.3 else 0.7]))
+    c["key"], c["bkey"] = int(r.integers(0, 2**31)), int(r.integers(0, 2**31))
+    return c
+
+
+def run_gmm_case(c, O, dump=False):
+    import torch
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import subsample_batchify_data
+    from d3p_amd.models import Adam, GaussianMixtureGuide, GaussianMixtureModel, Trace_ELBO
+    from d3p_amd.svi import DPSVI, DPSVIState
+    r = np.random.default_rng(c["seed"] + 11)
+    K, d, B, N, steps = c["K"], c["d"], c["B"], c["N"], c["steps"]
+    X = (r.normal(size=(N, d)) * 3).astype(np.float32)
+    params = np.concatenate([r.normal(size=K) * 0.4, r.normal(size=K * d) * 2]).astype(np.float32)
+    model = GaussianMixtureModel()
+    svi = DPSVI(model, GaussianMixtureGuide(model), Adam(c["lr"]), Trace_ELBO(), c["clip"], c["sigma"], k=K, d=d, num_obs_total=N)
+    st = DPSVIState(svi.optim.init(torch.tensor(params).cuda()), rng.PRNGKey(c["key"]), float(N))
+    spec = O.gmm_spec(K, d, 10.0, lik_scale=N, obs_scale=N)
+    Xd = torch.tensor(X).cuda()
+    key = O.PRNGKey(c["key"])
+    x, m, v = params.copy(), np.zeros_like(params), np.zeros_like(params)
+    el, mask = [], None
+
+    def oracle_step(i, Xb, mk):
+        nonlocal key, x, m, v
+        ks = O.split(key, 3)
+        L, G, n, f = O.gmm_px_grads(spec, x, Xb, O.convert_to_jax_rng_key(ks[1]), mk)
+        eloss, avg = O.combine(O.clip_rows(G, c["clip"]), L)
+        with np.errstate(all="ignore"):
+            g = O.perturb(ks[2], avg, [K, K * d], c["sigma"], c["clip"], n, N, f)
+        x, m, v = O.adam(x, m, v, g, i, lr=c["lr"])
+        key = ks[0]
+        return eloss
+    if c["source"] == "explicit":
+        mask = r.random(B) < c["mask_keep"]
+        use_mask = c["mask_keep"] < 1.0
+        losses = []
+        for t in range(steps):
+            idx = (np.arange(B) * 5 + 11 * t) % N
+            st, loss = svi.update(st, Xd[idx], mask=torch.tensor(mask).cuda() if use_mask else True)
+            losses.append(loss.reshape(()))
+            el.append(oracle_step(t, X[idx], mask.astype(np.float32) if use_mask else None))
+        losses = torch.stack(losses)
+    else:
+        _, gb = subsample_batchify_data((Xd,), B)
+        st, losses = svi.run_steps(st, gb, rng.PRNGKey(c["bkey"]), c["first"], steps)
+        for t in range(steps):
+            idx = O.feistel_sample(O.fold_in(O.PRNGKey(c["bkey"]), c["first"] + t), N, B)
+            el.append(oracle_step(t, X[idx], None))
+    torch.cuda.synchronize()
+    got_l, want_l = losses.detach().cpu().numpy().astype(np.float64), np.asarray(el, np.float64)
+    got_p = st.optim_state[1].detach().cpu().numpy()
+    why = []
+    if not np.array_equal(np.isnan(got_l), np.isnan(want_l)):
+        why.append(f"losses: NaN pattern differs ({got_l.tolist()} vs {want_l.tolist()})")
+    else:
+        fin = ~np.isnan(want_l)
+        bad = np.abs(got_l[fin] - want_l[fin]) > 1e-4 * np.abs(want_l[fin]) + 1e-6 * (K * d + N)
+        if bad.any():
+            k = int(np.argmax(bad))
+            why.append(f"loss {k}: {got_l[fin][k]!r} vs {want_l[fin][k]!r}")
+    if not np.array_equal(st.rng_key.cpu().numpy().ravel(), np.asarray(key).ravel()):
+        why.append("state key differs")
+    if int(st.optim_state[0]) != steps:
+        why.append(f"step counter {int(st.optim_state[0])} != {steps}")
+    if not np.array_equal(np.isnan(got_p), np.isnan(x)):
+        why.append("parameters: NaN pattern differs")
+    else:
+        fin = ~np.isnan(x)
+        scale = np.abs(x[fin]).max() if fin.any() else 0.0
+        bad = np.abs(got_p[fin] - x[fin]) > 1e-3 * np.abs(x[fin]) + 1e-4 * max(scale, 1e-30)
+        if bad.any():
+            k = int(np.argmax(np.abs(got_p[fin] - x[fin])))
+            why.append(f"parameter: {got_p[fin][k]!r} vs {x[fin][k]!r} (largest {scale:.3g}); {int(bad.sum())} of {int(fin.sum())} out of tolerance")
+    c["ok"], c["why"] = not why, "; ".join(why)
+    if mask is not None:
+        c["mask_sum"] = int(mask.sum())
+    return c
+
+
+# ------------------------------------------------------------------ the VAE (BASELINE configs[4]'s family)
+def draw_vae_case(seed):
+    r = np.random.default_rng(400_009 * seed + 37)
+    c = {"seed": int(seed), "family": "vae"}
+    c["D"] = int(r.choice([8, 12, 33, 64, 100, 200, 784]))
+    c["H"] = int(r.choice([4, 7, 16, 40, 100, 400]))
+    c["Z"] = int(r.choice([1, 2, 3, 8, 10, 50]))
+    c["H2"] = int(r.choice([0, 0, 5, 12, 200]))
+    c["B"] = int(r.choice([1, 3, 17, 64, 97, 130, 200]))
+    if c["D"] * c["H"] > 200000 and c["B"] > 64:
+        c["B"] = 64          # (the oracle materialises B x P gradients)
+    c["steps"] = int(r.choice([1, 2, 3]))
+    c["source"] = str(r.choice(["explicit", "explicit", "feistel"]))
+    c["N"] = int(c["B"] * int(r.choice([1, 3, 40])))
+    c["clip"] = float(r.choice([0.5, 3.0, 1e6]))
+    c["sigma"] = float(r.choice([0.0, 0.8]))
+    c["lr"] = float(r.choice([1e-3, 1e-2]))
+    c["first"] = int(r.choice([0, 9]))
+    c["grey"] = bool(r.random() < 0.4)
+    c["mask_keep"] = float(r.choice([1.0, 0.7, 0.0 if r.random() < 0.3 else 0.7]))
+    c["key"], c["bkey"] = int(r.integers(0, 2**31)), int(r.integers(0, 2**31))
+    return c
+
+
+def run_vae_case(c, O, dump=False):
+    import torch
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import subsample_batchify_data
+    from d3p_amd.models import Adam, Trace_ELBO, VAEGuide, VAEModel
+    from d3p_amd.svi import DPSVI, DPSVIState
+    r = np.random.default_rng(c["seed"] + 13)
+    D, H, Z, H2, B, N, steps = c["D"], c["H"], c["Z"], c["H2"], c["B"], c["N"], c["steps"]
+    spec = O.vae_spec(D, H, Z, scale=1.0, obs_scale=1.0, H2=H2)
+    P = O.vae_num_params(spec)
+    pscale = 0.03 if (D > 100 or H > 50 or H2 > 50) else 0.3
+    params = (r.normal(size=P) * pscale).astype(np.float32)
+    X = r.random((N, D)).astype(np.float32) if c["grey"] else (r.random((N, D)) < 0.3).astype(np.float32)
+    model = VAEModel(scale=1.0 / N)
+    svi = DPSVI(model, VAEGuide(model), Adam(c["lr"]), Trace_ELBO(), c["clip"], c["sigma"], num_obs_total=N, z_dim=Z,
+                hidden_dim=(H, H2) if H2 else H)
+    st = DPSVIState(svi.optim.init(torch.tensor(params).cuda()), rng.PRNGKey(c["key"]), 1.0)
+    Xd = torch.tensor(X).cuda()
+    sizes = O.vae_leaf_sizes(D, H, Z, H2)
+    key = O.PRNGKey(c["key"])
+    x, m, v = params.copy(), np.zeros(P, np.float32), np.zeros(P, np.float32)
+    el, mask = [], None
+
+    def oracle_step(i, Xb, mk):
+        nonlocal key, x, m, v
+        ks = O.split(key, 3)
+        eps = O.px_eps(O.convert_to_jax_rng_key(ks[1]), Xb.shape[0], Z)
+        with np.errstate(all="ignore"):
+            sums, _, _ = O.vae_step_sums(spec, x, Xb, eps, c["clip"], mk)
+            n = np.float32(sums[P + 1])
+            f = np.float32(0.0) if n == 0 else np.float32(Xb.shape[0]) / n
+            g = O.perturb(ks[2], sums[:P] / np.float32(Xb.shape[0]), sizes, c["sigma"], c["clip"], n, 1.0, f)
+            eloss = float(np.float32(sums[P]) / np.float32(Xb.shape[0]) * f)
+        x, m, v = O.adam(x, m, v, g, i, lr=c["lr"])
+        key = ks[0]
+        return eloss
+    if c["source"] == "explicit":
+        mask = r.random(B) < c["mask_keep"]
+        use_mask = c["mask_keep"] < 1.0
+        losses = []
+        for t in range(steps):
+            idx = (np.arange(B) * 3 + 7 * t) % N
+            st, loss = svi.update(st, Xd[idx], mask=torch.tensor(mask).cuda() if use_mask else True)
+            losses.append(loss.reshape(()))
+            el.append(oracle_step(t, X[idx], mask.astype(np.float32) if use_mask else None))
+        losses = torch.stack(losses)
+    else:
+        _, gb = subsample_batchify_data((Xd,), B)
+        st, losses = svi.run_steps(st, gb, rng.PRNGKey(c["bkey"]), c["first"], steps)
+        for t in range(steps):
+            idx = O.feistel_sample(O.fold_in(O.PRNGKey(c["bkey"]), c["first"] + t), N, B)
+            el.append(oracle_step(t, X[idx], None))
+    torch.cuda.synchronize()
+    got_l, want_l = losses.detach().cpu().numpy().astype(np.float64), np.asarray(el, np.float64)
+    got_p = st.optim_state[1].detach().cpu().numpy()
+    why = []
+    if not np.array_equal(np.isnan(got_l), np.isnan(want_l)):
+        why.append(f"losses: NaN pattern differs ({got_l.tolist()} vs {want_l.tolist()})")
+    else:
+        fin = ~np.isnan(want_l)
+        bad = np.abs(got_l[fin] - want_l[fin]) > 1e-4 * np.abs(want_l[fin]) + 1e-5
+        if bad.any():
+            k = int(np.argmax(bad))
+            why.append(f"loss {k}: {got_l[fin][k]!r} vs {want_l[fin][k]!r}")
+    if not np.array_equal(st.rng_key.cpu().numpy().ravel(), np.asarray(key).ravel()):
+        why.append("state key differs")
+    if int(st.optim_state[0]) != steps:
+        why.append(f"step counter {int(st.optim_state[0])} != {steps}")
+    if not np.array_equal(np.isnan(got_p), np.isnan(x)):
+        why.append(f"parameters: NaN pattern differs ({int(np.isnan(got_p).sum())} vs {int(np.isnan(x).sum())} of {P})")
+    else:
+        # Adam's early steps are lr g / (|g| + 1e-8): a component whose gradient is ~ 0 carries that component's relative error, so
+        # the parameters are compared to the size of a step (the moments would be tighter; the trajectory is short)
+        fin = ~np.isnan(x)
+        tol = 0.02 * c["lr"] * steps + 1e-4 * np.abs(x[fin])
+        bad = np.abs(got_p[fin] - x[fin]) > tol
+        if bad.mean() > 0.01:
+            k = int(np.argmax(np.abs(got_p[fin] - x[fin])))
+            why.append(f"parameter: {got_p[fin][k]!r} vs {x[fin][k]!r}; {int(bad.sum())} of {int(fin.sum())} out of tolerance")
+    c["ok"], c["why"] = not why, "; ".join(why)
+    if mask is not None:
+        c["mask_sum"] = int(mask.sum())
+    return c
+
+
+# ------------------------------------------------------------------ the samplers and the rng suite (integer work: bit-exact)
+def draw_rng_case(seed):
+    r = np.random.default_rng(300_007 * seed + 31)
+    c = {"seed": int(seed), "family": "rng"}
+    c["capacity"] = int(r.choice([1, 2, 3, 5, 16, 17, 255, 256, 257, 1000, 65536, 65537, 10**6, 10**7 + 3]))
+    c["n"] = int(min(c["capacity"], int(r.choice([1, 2, 7, 64, 1000, 4096, 50000]))))
+    c["N"] = int(r.choice([1, 2, 17, 1000, 4097, 100_000, 1_000_003]))
+    c["q"] = float(r.choice([0.0, 1e-4, 0.01, 0.3, 0.999, 1.0]))
+    c["cutoff"] = int(max(1, min(c["N"], int(r.choice([1, 5, 100, 5000, 10**6])))))
+    c["suppress"] = bool(r.random() < 0.5)
+    c["shape"] = [int(v) for v in r.choice([0, 1, 2, 3, 17, 64, 1000], size=int(r.integers(0, 3)))]
+    lo = int(r.choice([-5, 0, 1, -2**31, 100]))
+    c["minval"], c["maxval"] = lo, int(min(lo + int(r.choice([1, 2, 3, 7, 256, 1000, 2**16 + 1, 2**31 - 1])), 2**31 - 1))
+    c["fold"] = int(r.choice([0, 1, 77, 2**31, 2**32 - 1]))
+    c["num"] = int(r.choice([1, 2, 3, 17, 100]))
+    c["bits"] = int(r.choice([8, 16, 32, 64]))
+    c["key"] = int(r.integers(0, 2**31))
+    return c
+
+
+def run_rng_case(c, O, dump=False):
+    import torch
+    import d3p_amd.random as rng
+    from d3p_amd.util import feistel_indices
+    why = []
+    key, okey = rng.PRNGKey(c["key"]), O.PRNGKey(c["key"])
+    def same(name, got, want):
+        got = np.asarray(got.detach().cpu().numpy() if hasattr(got, "detach") else got)
+        want = np.asarray(want)
+        if got.shape != want.shape or not np.array_equal(got.astype(np.int64, casting="unsafe"), want.astype(np.int64, casting="unsafe")):
+            why.append(name)
+    shape = tuple(c["shape"])
+    same("split", rng.split(key, c["num"]).reshape(c["num"], 16), np.asarray(O.split(okey, c["num"])).reshape(c["num"], 16))
+    fk, ofk = rng.fold_in(key, c["fold"]), O.fold_in(okey, c["fold"])
+    same("fold_in", fk.reshape(16), np.asarray(ofk).reshape(16))
+    same("random_bits", rng.random_bits(fk, c["bits"], shape), O.random_bits(ofk, c["bits"], shape))
+    same("randint", rng.randint(fk, shape, c["minval"], c["maxval"]), O.randint(ofk, shape, c["minval"], c["maxval"]))
+    got_u, want_u = rng.uniform(fk, shape).cpu().numpy(), O.uniform(ofk, shape)
+    if got_u.shape != want_u.shape or not np.array_equal(got_u, want_u):
+        why.append("uniform")
+    got_n, want_n = rng.normal(fk, shape).cpu().numpy(), O.normal(ofk, shape)
+    if got_n.shape != want_n.shape or not np.allclose(got_n, want_n, rtol=2e-6, atol=1e-7):
+        why.append("normal")
+    same("convert_to_jax_rng_key", rng.convert_to_jax_rng_key(fk), O.convert_to_jax_rng_key(ofk))
+    same("feistel", feistel_indices(fk, c["capacity"], c["n"], rng), O.feistel_sample(ofk, c["capacity"], c["n"]))
+    # Poisson selection: indices of the selected rows first (ascending), padding behind; counts
+    import ctypes as C
+    import d3p_amd._lib as L
+    lib = L.load()
+    N, cutoff = c["N"], c["cutoff"]
+    idxs = torch.empty(max(cutoff, 1) + 16, dtype=torch.uint32, device="cuda")
+    counts = torch.empty(4, dtype=torch.uint32, device="cuda")
+    ws = torch.empty(int(lib.d3p_poisson_select_workspace(N)), dtype=torch.uint8, device="cuda")
+    L.check(lib.d3p_poisson_select(L.stream_ptr(), L.ptr(fk.contiguous()), float(c["q"]), N, cutoff, int(c["suppress"]), L.ptr(idxs), L.ptr(counts),
+                                   L.ptr(ws), ws.numel()))
+    want_idx, nsel, nvalid = O.poisson_select(ofk, np.float32(c["q"]), N, cutoff, c["suppress"])
+    cn = counts.cpu().numpy()
+    if int(cn[0]) != int(nsel) or int(cn[1]) != int(nvalid):
+        why.append(f"poisson counts {cn[:2].tolist()} vs {[int(nsel), int(nvalid)]}")
+    elif not np.array_equal(idxs[:int(nvalid)].cpu().numpy(), np.asarray(want_idx)[:int(nvalid)]):
+        why.append("poisson indices")
+    c["ok"], c["why"] = not why, "; ".join(why)
+    return c
+
+
+FAMILIES = {"update": (draw_case, None), "gmm": (draw_gmm_case, run_gmm_case), "vae": (draw_vae_case, run_vae_case),
+            "rng": (draw_rng_case, run_rng_case)}
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] in FAMILIES:
+        fam = sys.argv.pop(1)
+    else:
+        fam = "update"
+    draw, run = FAMILIES[fam]
+    run = run or run_case
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     out = open(sys.argv[3], "a") if len(sys.argv) > 3 else None
@@ -173,9 +456,9 @@ def main():
     O.build()
     bad = 0
     for seed in range(first, first + count):
-        c = draw_case(seed)
+        c = draw(seed)
         try:
-            c = run_case(c, O)
+            c = run(c, O)
         except Exception as e:  # noqa: BLE001 -- a sweep reports every case
             c["ok"], c["why"] = False, f"{type(e).__name__}: {e}"
         bad += 0 if c["ok"] else 1
@@ -184,7 +467,7 @@ def main():
         if out:
             out.write(line + "\n")
             out.flush()
-    print(json.dumps({"fuzz_vs_oracle": "ok" if bad == 0 else "MISMATCH", "cases": count, "failed": bad, "first_seed": first}), flush=True)
+    print(json.dumps({"fuzz_vs_oracle": "ok" if bad == 0 else "MISMATCH", "family": fam, "cases": count, "failed": bad, "first_seed": first}), flush=True)
     sys.exit(1 if bad else 0)
 
 

@@ -15,3 +15,23 @@ pytestmark = pytest.mark.gpu
 def test_random_case_vs_oracle(gpu, O, seed):
     c = F.run_case(F.draw_case(seed), O)
     assert c["ok"], c
+
+
+# (18, 37, 54: an empty batch behind a NaN state -- the reference's masked sum is NaN * 0 = NaN; 18 is also the case whose NaN
+#  concentration made the Marsaglia-Tsang loop of the Gamma sampler spin: it is bounded now, on the device and in the oracle)
+@pytest.mark.parametrize("seed", list(range(24)) + [37, 54, 73])
+def test_random_mixture_model_case_vs_oracle(gpu, O, seed):
+    c = F.run_gmm_case(F.draw_gmm_case(seed), O)
+    assert c["ok"], c
+
+
+@pytest.mark.parametrize("seed", list(range(20)))
+def test_random_vae_case_vs_oracle(gpu, O, seed):
+    c = F.run_vae_case(F.draw_vae_case(seed), O)
+    assert c["ok"], c
+
+
+@pytest.mark.parametrize("seed", list(range(30)))
+def test_random_rng_and_sampler_arguments_vs_oracle(gpu, O, seed):
+    c = F.run_rng_case(F.draw_rng_case(seed), O)
+    assert c["ok"], c
