@@ -26,9 +26,16 @@ static inline size_t main_lds_bytes(int D, int W) { return (size_t)(((5 * D + 3)
 __device__ __forceinline__ void guide_scale(int gexp, float u, float& s, float& ds)
 {
     if (gexp) {
-        s = ds = __expf(u);
+        s = ds = expf(u);   // (not __expf: exp2(u log2 e) carries |u| ulp of relative error, 2e-6 at u = 27 -- this is a scale, once per column)
     } else {
         s = softplus_f(u);
+        // softplus_f's log(1 + e) is exact to ~1e-7 ABSOLUTE: enough for a log-likelihood term, not for a scale that is divided by --
+        // below u ~ -16.6 the sum 1 + exp(u) rounds to 1 and the scale would be 0 (0 / 0 in the entropy gradient, log 0 in the loss).
+        // log1p(e) = e (1 - e / 2 + ...) there, which is what jax.nn.softplus (logaddexp) and the oracle's log1pf return.
+        if (u < -15.0f) {
+            const float e = expf(u);
+            s = e * (1.0f - 0.5f * e);
+        }
         ds = sigmoid_f(u);
     }
 }

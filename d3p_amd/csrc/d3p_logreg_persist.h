@@ -195,7 +195,8 @@ __global__ void __launch_bounds__(64 * D3P_PERSIST_W) k_logreg_persist(MainArgs 
             pk[col] = x;
         } else {
             const int e = col - D;
-            const float sp = softplus_f(x), sgm = sigmoid_f(x);
+            float sp, sgm;
+            guide_scale(0, x, sp, sgm);
             pk[D + e] = sp;
             pk[2 * D + e] = sgm;
             pk[3 * D + e] = a.inv_obs * sgm * __builtin_amdgcn_rcpf(sp);

@@ -46,6 +46,14 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
     const uint32_t n_items = a.plist ? *a.n_list : a.B;
     const uint32_t total_waves = gridDim.x * W;
     float loss_acc = 0.f, n_acc = 0.f;
+    // (materialising stage) loss * mask is NaN * 0 = NaN for a masked example once a parameter is not finite (svi.py:281): the
+    // register-tiled kernel gets there by computing the row and multiplying by 0, this one writes the rows it skips
+    float skipped = 0.f;
+    if (PXG) {
+        int p_bad = 0;
+        for (int c = threadIdx.x; c < 5 * D; c += blockDim.x) p_bad |= !(fabsf(pk[c]) <= 3.402823466e38f);
+        if (__syncthreads_or(p_bad)) skipped = __builtin_nanf("");   // (this instantiation runs without dynamic LDS)
+    }
 
     for (uint32_t item = blockIdx.x * W + wave; item < n_items; item += total_waves) {
         const uint32_t pp = a.plist ? a.plist[item] : item;
@@ -55,8 +63,8 @@ __global__ void __launch_bounds__(64 * D3P_WIDE_W) k_logreg_wide(MainArgs a)
         if (!(valid && own)) {  // wave-uniform
             if (PXG) {  // loss * mask => zero loss and gradient (svi.py:281)
                 float* gr = a.px_grads + (size_t)pp * P;
-                for (int c = lane; c < P; c += 64) gr[c] = 0.f;
-                if (lane == 0) a.px_loss[pp] = 0.f;
+                for (int c = lane; c < P; c += 64) gr[c] = skipped;
+                if (lane == 0) a.px_loss[pp] = skipped;
             }
             continue;
         }

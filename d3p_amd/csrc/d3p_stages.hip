@@ -45,7 +45,9 @@ __global__ void k_clip_rows(float* __restrict__ g, uint32_t B, uint32_t P, float
     float ss = 0.f;
     for (uint32_t j = lane; j < P; j += 64) ss = __fmaf_rn(r[j], r[j], ss);
     ss = wave_sum(ss);
-    const float scale = 1.0f / fmaxf(1.0f, __fsqrt_rn(ss) / c);  // svi.py:121-122
+    // svi.py:121-122; jnp.maximum propagates NaN (fmaxf returns the other operand): a row with a NaN entry is NaN throughout, as there
+    const float ratio = __fsqrt_rn(ss) / c;
+    const float scale = 1.0f / (ratio != ratio ? ratio : fmaxf(1.0f, ratio));
     for (uint32_t j = lane; j < P; j += 64) r[j] *= scale;
 }
 

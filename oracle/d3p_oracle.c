@@ -608,7 +608,8 @@ D3P_API int d3po_clip_rows(float* px_grads, int B, int P, float c)
         double ss = 0.0;
         for (int j = 0; j < P; ++j) ss += (double)g[j] * (double)g[j];
         float norm = (float)sqrt(ss);
-        float scale = 1.0f / fmaxf(1.0f, norm / c);
+        float ratio = norm / c;
+        float scale = 1.0f / (ratio != ratio ? ratio : fmaxf(1.0f, ratio)); /* jnp.maximum propagates NaN; fmaxf would not */
         for (int j = 0; j < P; ++j) g[j] *= scale;
     }
     return 0;
@@ -842,7 +843,8 @@ D3P_API float d3po_logreg_run_feistel(const d3po_logreg_spec* sp, const d3po_dps
             float* g = px_grads + (size_t)i * P;
             float ss = 0.0f;
             for (int j = 0; j < P; ++j) ss = fmaf(g[j], g[j], ss);
-            const float scale = 1.0f / fmaxf(1.0f, sqrtf(ss) / hy->clip);
+            const float ratio = sqrtf(ss) / hy->clip;
+            const float scale = 1.0f / (ratio != ratio ? ratio : fmaxf(1.0f, ratio));
             for (int j = 0; j < P; ++j) g[j] *= scale;
         }
         /* svi.py:343-346: mean over the batch axis (threads own column blocks, rows streamed) */

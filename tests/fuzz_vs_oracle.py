@@ -9,7 +9,7 @@ restatement of d3p/svi.py:395-434 driven by the oracle's own samplers: state key
 losses and parameters (empty batches: svi.py:305, :365), final parameters
 (rtol 5e-4, atol 5e-5 of the largest) and step counter.
 
-    python tests/fuzz_vs_oracle.py [update|gmm|vae|rng] [first_seed=0] [count=40] [out.jsonl]
+    python tests/fuzz_vs_oracle.py [update|staged|gmm|vae|rng] [first_seed=0] [count=40] [out.jsonl]
 
 `gmm`: the mixture model's update (explicit batches with masks, Feistel runs) vs the oracle's stage composition; `rng`: split / fold_in /
 random_bits / randint / uniform / normal / Feistel / Poisson selection at random arguments, bit-exact (normal: 2e-6).
@@ -29,6 +29,13 @@ if ROOT not in sys.path:
 LOSS_RTOL, PARAM_RTOL, PARAM_ATOL = 1e-4, 5e-4, 5e-5
 DIMS = [1, 2, 3, 5, 8, 17, 31, 64, 100, 255, 256, 257, 511, 512, 513, 700, 1024, 2048, 2049, 2600]
 BATCHES = [1, 2, 7, 32, 63, 64, 65, 200, 1000, 4096, 5000]
+
+
+def _far(got, want, tol):
+    """Elementwise: True where got and want differ by more than tol (equal infinities are equal; NaNs are compared separately)."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    with np.errstate(invalid="ignore"):
+        return ~((got == want) | (np.abs(got - want) <= tol))
 
 
 def draw_case(seed):
@@ -165,6 +172,119 @@ def run_case(c, O, dump=False):
         c["mask_sum"] = int(mask.sum()) if c["source"] != "feistel" else None
     c["ok"], c["why"] = not why, "; ".join(why)
     c["final_loss"] = float(want_l[-1]) if len(want_l) else None
+    return c
+
+
+# ------------------------------------------------------------------ the five-stage composition (SGD: no fused path) and evaluate
+def draw_staged_case(seed):
+    c = draw_case(7919 * seed + 3)
+    c["seed"], c["family_name"] = int(seed), "staged"
+    if c["guide"] == "meanfield":
+        c["guide"] = "auto"
+    c["source"] = "explicit"
+    # the stage-wise path materialises B x P per-example gradients on both sides
+    while c["B"] * c["d"] > 2e5:
+        c["B"] = max(c["B"] // 4, 1)
+    c["steps"] = min(c["steps"], 3)
+    c["N"] = max(c["N"], c["B"])
+    c["lr"] = min(c["lr"], 1e-2)
+    return c
+
+
+def run_staged_case(c, O, dump=False):
+    """DPSVI.update with SGD (the reference's tests' optimiser): per-example gradients -> clip -> mean -> one noise key per site -> step,
+    every stage a materialised tensor (d3p_logreg_px_grads incl. its column-chunked form, d3p_clip_rows, d3p_combine, d3p_perturb_apply,
+    d3p_sgd_step) vs the oracle's stage functions; then evaluate (svi.py:436-449) on the last state."""
+    import torch
+    import d3p_amd.random as rng
+    from d3p_amd.models import SGD, AutoDiagonalNormal, DiagonalNormalGuide, GaussianMean, LogisticRegression, Trace_ELBO
+    from d3p_amd.svi import DPSVI, DPSVIState
+    r = np.random.default_rng(c["seed"] + 23)
+    d, B, N, steps = c["d"], c["B"], c["N"], c["steps"]
+    gauss, icpt = c["family"] == "gauss", c["family"] == "logreg_icpt"
+    D = d + (1 if icpt else 0)
+    X = r.normal(size=(N, d)).astype(np.float32)
+    if gauss:
+        X = (1.0 + 0.5 * X).astype(np.float32)
+    y = None if gauss else (r.random(N) < 0.5).astype(np.float32)
+    exp_guide = gauss and c["guide"] != "auto"
+    if gauss:
+        model = GaussianMean(d, prior_scale=1.5, obs_scale=0.7)
+        guide = DiagonalNormalGuide(model) if exp_guide else AutoDiagonalNormal(model)
+        mk_spec = lambda obs: O.gauss_mean_spec(d, prior=1.5, lik_sigma=0.7, lik_scale=N, obs_scale=obs, guide_exp=exp_guide)
+    else:
+        model = LogisticRegression(d, prior_scale=1.0, intercept=icpt, intercept_prior_scale=2.0)
+        guide = AutoDiagonalNormal(model)
+        mk_spec = lambda obs: O.logreg_spec(d, icpt, 1.0, 2.0, lik_scale=N, obs_scale=obs)
+    spec = mk_spec(N)
+    svi = DPSVI(model, guide, SGD(c["lr"]), Trace_ELBO(), c["clip"], c["sigma"], num_obs_total=N, **({"d": d} if gauss else {}))
+    loc = (r.normal(size=D) * c["init_scale"]).astype(np.float32)
+    unc = (r.normal(size=D) * c["init_scale"] - 2.0).astype(np.float32)
+    x = np.concatenate([loc, unc])
+    st = DPSVIState(svi.optim.init(torch.tensor(x).cuda()), rng.PRNGKey(c["key"]), float(N))
+    Xd = torch.tensor(X).cuda()
+    yd = None if gauss else torch.tensor(y).cuda()
+    key = O.PRNGKey(c["key"])
+    mask = r.random(B) < c["mask_keep"]
+    use_mask = c["mask_keep"] < 1.0
+    got_l, want_l = [], []
+    chaotic = False
+    for t in range(steps):
+        idx = (np.arange(B) * 7 + 13 * t) % N
+        args = (Xd[idx],) if gauss else (Xd[idx], yd[idx])
+        st, loss = svi.update(st, *args, mask=torch.tensor(mask).cuda() if use_mask else True)
+        got_l.append(float(loss))
+        ks = O.split(key, 3)
+        eps = O.px_eps(O.convert_to_jax_rng_key(ks[1]), B, D)
+        with np.errstate(all="ignore"):
+            L, G, n, f = O.logreg_px_grads(spec, x[:D], x[D:], X[idx], None if gauss else y[idx], eps, mask.astype(np.float32) if use_mask else None)
+            eloss, avg = O.combine(O.clip_rows(G, c["clip"]), L)
+            g = O.perturb(ks[2], avg, [D, D], c["sigma"], c["clip"], n, N, f)
+            x = (x - np.float32(c["lr"]) * g).astype(np.float32)
+            if np.isfinite(G).all() and np.abs(G).max() > 1e9 * min(c["clip"], 1e3):
+                chaotic = True      # (a diverged run: per-example gradients of 1e12 clipped to C -- the directions of the clipped rows hang on the last bits)
+        want_l.append(eloss)
+        key = ks[0]
+    torch.cuda.synchronize()
+    got_l, want_l = np.asarray(got_l, np.float64), np.asarray(want_l, np.float64)
+    got_p = st.optim_state[1].detach().cpu().numpy()
+    why = []
+    if not np.array_equal(np.isnan(got_l), np.isnan(want_l)):
+        why.append(f"losses: NaN pattern differs ({got_l.tolist()} vs {want_l.tolist()})")
+    else:
+        fin = ~np.isnan(want_l)
+        with np.errstate(invalid="ignore"):
+            bad = _far(got_l[fin], want_l[fin], LOSS_RTOL * np.abs(want_l[fin]) + 1e-6 * (D + N))
+        if bad.any():
+            k = int(np.argmax(bad))
+            why.append(f"loss {k}: {got_l[fin][k]!r} vs {want_l[fin][k]!r}")
+    if not np.array_equal(st.rng_key.cpu().numpy().ravel(), np.asarray(key).ravel()):
+        why.append("state key differs")
+    if int(st.optim_state[0]) != steps:
+        why.append(f"step counter {int(st.optim_state[0])} != {steps}")
+    if not np.array_equal(np.isnan(got_p), np.isnan(x)):
+        why.append(f"parameters: NaN pattern differs ({int(np.isnan(got_p).sum())} vs {int(np.isnan(x).sum())})")
+    else:
+        fin = ~np.isnan(x)
+        finite = x[fin][np.isfinite(x[fin])]
+        scale = np.abs(finite).max() if finite.size else 0.0
+        with np.errstate(invalid="ignore"):
+            bad = _far(got_p[fin], x[fin], PARAM_RTOL * np.abs(x[fin]) + PARAM_ATOL * max(scale, 1e-30))
+        if bad.any() and not chaotic:
+            k = int(np.argmax(np.abs(got_p[fin] - x[fin])))
+            why.append(f"parameter: {got_p[fin][k]!r} vs {x[fin][k]!r} (largest {scale:.3g}); {int(bad.sum())} of {int(fin.sum())} out of tolerance")
+        # (scales below 1e-38 -- u < -87 -- flush to zero on the device (v_exp_f32 has no denormals): log s = -inf there, where a CPU
+        #  reference still holds a denormal; a state in that corner is not asked for its loss)
+        if fin.all() and np.isfinite(got_p).all() and (exp_guide or got_p[D:].min() > -80.0) and got_p[D:].max() < 80.0:
+            idx = (np.arange(B) * 3 + 1) % N
+            args = (Xd[idx],) if gauss else (Xd[idx], yd[idx])
+            got_e = float(svi.evaluate(st, *args))
+            want_e = O.logreg_evaluate(mk_spec(1.0), got_p[:D], got_p[D:], X[idx], None if gauss else y[idx],
+                                       O.convert_to_jax_rng_key(O.split(key, 1)[0]))
+            if not (got_e == want_e or abs(got_e - want_e) <= LOSS_RTOL * abs(want_e) + 1e-6 * (D + N) or (np.isnan(got_e) and np.isnan(want_e))):
+                why.append(f"evaluate: {got_e!r} vs {want_e!r}")
+    c["ok"], c["why"] = not why, "; ".join(why)
+    c["mask_sum"] = int(mask.sum()) if use_mask else B
     return c
 
 
@@ -438,7 +558,8 @@ def run_rng_case(c, O, dump=False):
     return c
 
 
-FAMILIES = {"update": (draw_case, None), "gmm": (draw_gmm_case, run_gmm_case), "vae": (draw_vae_case, run_vae_case),
+FAMILIES = {"update": (draw_case, None), "staged": (draw_staged_case, run_staged_case), "gmm": (draw_gmm_case, run_gmm_case),
+            "vae": (draw_vae_case, run_vae_case),
             "rng": (draw_rng_case, run_rng_case)}
 
 
