@@ -222,6 +222,7 @@ SIGNATURES = {
     "d3p_dpvi_logreg_prepare_buf": (C.c_int, [_V, _PM, _PH, _PS, _PB, _U32, C.c_int, _V, _SZ]),
     "d3p_dpvi_logreg_acc_layout": (C.c_int, [_PM, _PB, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "d3p_dpvi_logreg_acc_reset": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _SZ]),
+    "d3p_dpvi_logreg_fused_step_supported": (C.c_int, [_PM, _PB]),
     "d3p_dpvi_logreg_fused_step": (C.c_int, [_V, _PM, _PH, _PS, _PB, _U32, _U32, C.c_int, C.c_int, _U32, C.c_int, _V, _V,
                                              _V, C.c_int, _V, _SZ]),
     "d3p_dpvi_logreg_run": (C.c_int, [_V, _PM, _PH, _PS, _PB, _V, _V, _U32, _V, _V, _SZ]),

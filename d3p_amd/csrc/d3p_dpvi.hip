@@ -2254,6 +2254,16 @@ int d3p_dpvi_logreg_acc_layout(const d3p_logreg_model* model, const d3p_batch_so
     return D3P_OK;
 }
 
+int d3p_dpvi_logreg_fused_step_supported(const d3p_logreg_model* model, const d3p_batch_source* src)
+{
+    if (!model || !src) return 0;
+    Ctx c;
+    c.m = model;
+    c.src = src;
+    if (fill_geometry(&c, model, src) != D3P_OK) return 0;
+    return c.g.wide ? 0 : 1;
+}
+
 int d3p_dpvi_logreg_acc_reset(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
                               const d3p_dpsvi_state* state, const d3p_batch_source* src, void* workspace_dev,
                               size_t workspace_bytes)
@@ -2281,6 +2291,11 @@ int d3p_dpvi_logreg_fused_step(void* stream, const d3p_logreg_model* model, cons
     if (!flush_only)
         if (int rcm = validate_model(model, y_dev, "d3p_dpvi_logreg_fused_step")) return rcm;
     D3P_REQUIRE(t < D3P_STEP_BATCH && prev_t < D3P_STEP_BATCH, "slot index must be < 128");
+    // rows too wide for the register-tiled kernel have no one-launch step (the column-chunked kernel only leaves partial rows):
+    // launching it with that geometry would compute nonsense -- the caller takes the two-kernel steps (step_sums / step_finalize)
+    if (c.g.wide)
+        return fail(D3P_E_UNSUPPORTED, "d3p_dpvi_logreg_fused_step: rows of %d columns run as two-kernel steps (d3p_dpvi_logreg_step_sums / "
+                    "_step_finalize); ask d3p_dpvi_logreg_fused_step_supported first", c.D);
     Ctx cb[2] = {c, c};
     cb[1].ws = c.ws2;
     cb[1].ws.partials = c.ws.partials;

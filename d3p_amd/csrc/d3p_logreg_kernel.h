@@ -559,6 +559,7 @@ __global__ void __launch_bounds__(D3P_MAIN_MAX_THREADS(V, NK)) k_logreg_main(Mai
         }
     };
     bool prologue_done = false;
+    bool flush_params_bad = false;   // flush launch: a parameter the pending step ran with is not finite (set in front of finish_prologue)
     // returns true when the run was aborted and this WHOLE workgroup knows it (pipelined form); the 16-wave form learns it
     // behind the staging barrier (stage_aborted)
     auto finish_prologue = [&]() -> bool {
@@ -779,7 +780,9 @@ __global__ void __launch_bounds__(D3P_MAIN_MAX_THREADS(V, NK)) k_logreg_main(Mai
             }
             if (f.prev_loss_out) {
                 float lv = ((float)loss_join(lhh, lll) / Bf) * a.obs_scale * factor;
-                if (n == 0.0f) lv = empty_batch_loss(P, [&](int c) { return ld_x<CHAIN>(f.params_in + c); });
+                if (n == 0.0f)
+                    lv = (!CHAIN && f.flush_only) ? (flush_params_bad ? __builtin_nanf("") : 0.0f)
+                                                  : empty_batch_loss(P, [&](int c) { return ld_x<CHAIN>(f.params_in + c); });
                 *f.prev_loss_out = lv;
             }
             // (chained launch: the run's counters are k_flush's -- a word that workgroup 0 of a different step, i.e. a different XCD, plain-
@@ -954,6 +957,20 @@ __global__ void __launch_bounds__(D3P_MAIN_MAX_THREADS(V, NK)) k_logreg_main(Mai
     // that issues at 4 cycles per wave64 instruction.  Raising the wave priority lets the critical instructions go first.
     if (CHAIN && (a.dbg & 2)) __builtin_amdgcn_s_setprio(3);
     if (FUSE) {
+        // Flush launch (one workgroup): it publishes to the caller's arrays, which after an odd number of launches are also the
+        // arrays it READS -- the reporter of an empty batch's loss (thread 0, at the end of the prologue) would scan parameters the
+        // other threads have already replaced.  Every thread looks at its share first; the vote goes through the reduction buffer.
+        if (!CHAIN && a.fuse.flush_only && a.fuse.apply_prev && a.fuse.prev_loss_out) {
+            int bad = 0;
+            for (int c = threadIdx.x; c < P; c += blockDim.x) bad |= !(fabsf(a.fuse.params_in[c]) <= 3.402823466e38f);
+            const bool wave_bad = __any(bad);
+            if (lane == 0) red[wave] = wave_bad ? 1.0f : 0.0f;
+            __syncthreads();
+            bad = 0;
+            for (int w = 0; w < W; ++w) bad |= red[w] != 0.0f;
+            flush_params_bad = bad != 0;
+            __syncthreads();
+        }
         const bool aborted = finish_prologue();
         D3P_STAMP(2)
         if (a.fuse.flush_only || aborted) return;  // (aborted: uniform, decided behind the workgroup barrier of the poll)

@@ -247,6 +247,13 @@ class FusedHipEngine(HipEngine):
     def begin(self, state, batch_key, first_batch):
         super().begin(state, batch_key, first_batch)
         lib = _lib.load()
+        # rows too wide for the register-tiled kernel have no one-launch step: the engine then IS the two-kernel engine (float sums
+        # instead of the int64 accumulator; callers sum whatever local_sums hands them)
+        self.two_kernel = not lib.d3p_dpvi_logreg_fused_step_supported(C.byref(self.model), C.byref(self.src))
+        self.losses = None
+        if self.two_kernel:
+            self._loss_log = []
+            return
         off, words = C.c_size_t(), C.c_size_t()
         check(lib.d3p_dpvi_logreg_acc_layout(C.byref(self.model), C.byref(self.src), C.byref(off), C.byref(words)))
         self.acc = self.ws[off.value: off.value + 3 * words.value * 8].view(torch.int64).reshape(3, words.value)
@@ -261,6 +268,8 @@ class FusedHipEngine(HipEngine):
         self.losses = torch.zeros(max(int(num_steps), 1), dtype=torch.float32, device=self.dev)
 
     def _ensure_prepared(self):
+        if self.two_kernel:
+            return super()._ensure_prepared()
         if self.t >= self.prepared:
             k = self.STEP_BATCH if self.remaining is None else max(1, min(self.STEP_BATCH, self.remaining))
             self.buf ^= 1
@@ -279,11 +288,18 @@ class FusedHipEngine(HipEngine):
                                                      int(flush), ptr(self.ws), self.ws.numel()))
 
     def local_sums(self):
+        if self.two_kernel:
+            return super().local_sums()
         self._ensure_prepared()
         self._launch(False)
         return self.acc[self.g % 3]
 
     def finalize(self, sums):
+        if self.two_kernel:
+            loss = super().finalize(sums)
+            if self.losses is not None and self.done - 1 < self.losses.numel():
+                self.losses[self.done - 1].copy_(loss.reshape(()))
+            return None
         self.prev = (self.t, self.buf)
         self.g += 1
         self.t += 1
@@ -293,7 +309,7 @@ class FusedHipEngine(HipEngine):
         return None            # the loss of this step is written by the next launch
 
     def end(self):
-        if self.prev is not None:
+        if not self.two_kernel and self.prev is not None:
             self._launch(True)  # apply the update of the last step
         return super().end()
 

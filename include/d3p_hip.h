@@ -363,6 +363,9 @@ int d3p_dpvi_logreg_prepare_buf(void* stream, const d3p_logreg_model* model, con
                                 uint32_t num_steps, int buf, void* workspace_dev, size_t workspace_bytes);
 int d3p_dpvi_logreg_acc_layout(const d3p_logreg_model* model, const d3p_batch_source* src,
                                size_t* offset_bytes, size_t* words_per_buffer);
+/* 1 when the model's rows fit the one-launch step (d3p_dpvi_logreg_fused_step), 0 when they run as two-kernel steps (rows too wide for
+ * the register-tiled kernel: D > 2048, or D > 1024 unless d % 8 == 0 without intercept): fused_step then returns D3P_E_UNSUPPORTED.  ABI 9. */
+int d3p_dpvi_logreg_fused_step_supported(const d3p_logreg_model* model, const d3p_batch_source* src);
 int d3p_dpvi_logreg_acc_reset(void* stream, const d3p_logreg_model* model, const d3p_dpsvi_hyper* hyper,
                               const d3p_dpsvi_state* state, const d3p_batch_source* src,
                               void* workspace_dev, size_t workspace_bytes);

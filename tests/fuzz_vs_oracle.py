@@ -9,7 +9,7 @@ restatement of d3p/svi.py:395-434 driven by the oracle's own samplers: state key
 losses and parameters (empty batches: svi.py:305, :365), final parameters
 (rtol 5e-4, atol 5e-5 of the largest) and step counter.
 
-    python tests/fuzz_vs_oracle.py [update|staged|gmm|vae|rng] [first_seed=0] [count=40] [out.jsonl]
+    python tests/fuzz_vs_oracle.py [update|staged|gmm|vae|rng|batches|shards] [first_seed=0] [count=40] [out.jsonl]
 
 `gmm`: the mixture model's update (explicit batches with masks, Feistel runs) vs the oracle's stage composition; `rng`: split / fold_in /
 random_bits / randint / uniform / normal / Feistel / Poisson selection at random arguments, bit-exact (normal: 2e-6).
@@ -558,7 +558,194 @@ def run_rng_case(c, O, dump=False):
     return c
 
 
-FAMILIES = {"update": (draw_case, None), "staged": (draw_staged_case, run_staged_case), "gmm": (draw_gmm_case, run_gmm_case),
+# ------------------------------------------------------------------ row shards: the data-parallel split, ranks emulated one after another
+def draw_shards_case(seed):
+    c = draw_case(104_729 * seed + 7)
+    c["seed"] = int(seed)
+    r = np.random.default_rng(600_011 * seed + 43)
+    if c["family"] == "gauss":
+        c["family"] = "logreg"
+    c["guide"] = "auto"
+    c["source"] = str(r.choice(["feistel", "feistel", "poisson"]))
+    c["world"] = int(r.choice([1, 2, 3, 5, 8]))
+    c["engine"] = str(r.choice(["fused", "two_kernel"]))
+    c["steps"] = min(c["steps"], 20)
+    c["N"] = max(c["N"], c["world"], c["B"])
+    return c
+
+
+def run_shards_case(c, O, dump=False):
+    """SURVEY 8(e)'s split with the ranks emulated one after another in ONE process: the table row-sharded over `world` engines, every
+    engine evaluating the same sampler and processing the positions whose rows it holds, the ranks' sums added by hand (what the
+    all-reduce computes), noise and Adam once per replica -- against the ORACLE's single-device trajectory; replicas bitwise equal."""
+    import scipy.stats
+    import torch
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
+    from d3p_amd.svi import DPSVI, DPSVIState
+    r = np.random.default_rng(c["seed"] + 29)
+    d, B, N, steps, world = c["d"], c["B"], c["N"], c["steps"], c["world"]
+    icpt = c["family"] == "logreg_icpt"
+    D = d + (1 if icpt else 0)
+    P = 2 * D
+    X = r.normal(size=(N, d)).astype(np.float32)
+    y = (r.random(N) < 0.5).astype(np.float32)
+    model = LogisticRegression(d, prior_scale=1.0, intercept=icpt, intercept_prior_scale=2.0)
+    svi = DPSVI(model, AutoDiagonalNormal(model), Adam(c["lr"]), Trace_ELBO(), c["clip"], c["sigma"], num_obs_total=N)
+    spec = O.logreg_spec(d, icpt, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    hy = O.Hyper(c["clip"], c["sigma"], c["lr"], 0.9, 0.999, 1e-8)
+    loc0 = (r.normal(size=D) * c["init_scale"]).astype(np.float32)
+    unc0 = (r.normal(size=D) * c["init_scale"] - 2.0).astype(np.float32)
+    ost = O.LogregState(O.PRNGKey(c["key"]), D, loc0, unc0)
+    st0 = DPSVIState(svi.optim.init(torch.tensor(np.concatenate([loc0, unc0])).cuda()), rng.PRNGKey(c["key"]), float(N))
+    Xd, yd = torch.tensor(X).cuda(), torch.tensor(y).cuda()
+    bkey = rng.PRNGKey(c["bkey"])
+    poisson = c["source"] == "poisson"
+    q, maxB = 0.0, B
+    if poisson:
+        q = B / N
+        maxB = min(max(int(scipy.stats.poisson(N * q).ppf(c["quantile"])), 1), N)
+    cls = ddist.FusedHipEngine if c["engine"] == "fused" else ddist.HipEngine
+    engines = []
+    for rk in range(world):
+        lo, hi = ddist.shard_rows(N, rk, world)
+        engines.append(cls(svi, Xd[lo:hi], yd[lo:hi], N, lo, hi, L.D3P_BATCH_POISSON if poisson else L.D3P_BATCH_FEISTEL, maxB,
+                           q=q, suppress=c["suppress"]))
+    for e in engines:
+        e.begin(st0, bkey, c["first"])
+        e.plan(steps)
+    fused = c["engine"] == "fused"
+    step_losses = []
+    for _ in range(steps):
+        bufs = [e.local_sums() for e in engines]
+        total = torch.stack(bufs).sum(dim=0)
+        outs = []
+        for e, b in zip(engines, bufs):
+            b.copy_(total)
+            outs.append(e.finalize(b))
+        if not fused:
+            step_losses.append(torch.stack([o.reshape(()).clone() for o in outs]))     # (the two-kernel engine reports a step's loss at once)
+    finals = [e.end() for e in engines]
+    torch.cuda.synchronize()
+    per_rank_losses = [e.losses[:steps] for e in engines] if fused else list(torch.stack(step_losses).T)
+    el = []
+    for t in range(steps):
+        fk = O.fold_in(O.PRNGKey(c["bkey"]), c["first"] + t)
+        if poisson:
+            idx, nsel, nvalid = O.poisson_select(fk, np.float32(q), N, maxB, c["suppress"])
+            mask = (np.arange(maxB) < nvalid).astype(np.float32)
+            el.append(O.logreg_update(spec, hy, ost, X[idx], y[idx], mask)[0])
+        else:
+            idx = O.feistel_sample(fk, N, B)
+            el.append(O.logreg_update(spec, hy, ost, X[idx], y[idx])[0])
+    why = []
+    for f, e in zip(finals[1:], engines[1:]):
+        if not (torch.equal(f.optim_state[1], finals[0].optim_state[1]) and torch.equal(f.optim_state[2], finals[0].optim_state[2])
+                and torch.equal(f.rng_key, finals[0].rng_key)):
+            if not (torch.isnan(f.optim_state[1]).any() and torch.equal(torch.isnan(f.optim_state[1]), torch.isnan(finals[0].optim_state[1]))):
+                why.append("replicas differ")
+            break
+    st = finals[0]
+    for pl in per_rank_losses[1:]:
+        if not torch.equal(torch.nan_to_num(pl, nan=-1.0), torch.nan_to_num(per_rank_losses[0], nan=-1.0)):
+            why.append("the ranks report different losses")
+            break
+    got_l, want_l = per_rank_losses[0].cpu().numpy().astype(np.float64), np.asarray(el, np.float64)
+    got_p, want_p = st.optim_state[1].cpu().numpy(), ost.params
+    if not np.array_equal(np.isnan(got_l), np.isnan(want_l)):
+        why.append(f"losses: NaN pattern differs ({got_l.tolist()} vs {want_l.tolist()})")
+    else:
+        fin = ~np.isnan(want_l)
+        bad = _far(got_l[fin], want_l[fin], LOSS_RTOL * np.abs(want_l[fin]) + 1e-6 * (D + N))
+        if bad.any():
+            k = int(np.argmax(bad))
+            why.append(f"loss {k}: {got_l[fin][k]!r} vs {want_l[fin][k]!r}")
+    if not np.array_equal(st.rng_key.cpu().numpy().ravel(), ost.key):
+        why.append("state key differs")
+    if int(st.optim_state[0]) != steps:
+        why.append(f"step counter {int(st.optim_state[0])} != {steps}")
+    if not np.array_equal(np.isnan(got_p), np.isnan(want_p)):
+        why.append(f"parameters: NaN pattern differs ({int(np.isnan(got_p).sum())} vs {int(np.isnan(want_p).sum())})")
+    else:
+        fin = ~np.isnan(want_p)
+        scale = np.abs(want_p[fin]).max() if fin.any() else 0.0
+        bad = _far(got_p[fin], want_p[fin], PARAM_RTOL * np.abs(want_p[fin]) + PARAM_ATOL * max(scale, 1e-30))
+        if bad.any():
+            k = int(np.argmax(np.abs(got_p[fin] - want_p[fin])))
+            why.append(f"parameter: {got_p[fin][k]!r} vs {want_p[fin][k]!r}; {int(bad.sum())} of {int(fin.sum())} out of tolerance")
+    c["ok"], c["why"] = not why, "; ".join(why)
+    return c
+
+
+# ------------------------------------------------------------------ the batchifiers' get_batch (gathers: bit-exact)
+def draw_batches_case(seed):
+    r = np.random.default_rng(500_009 * seed + 41)
+    c = {"seed": int(seed), "family": "batches"}
+    c["N"] = int(r.choice([1, 2, 17, 100, 1000, 4097, 100_000]))
+    c["B"] = int(max(1, min(c["N"], int(r.choice([1, 2, 7, 64, 1000, 4096])))))
+    c["d"] = int(r.choice([1, 2, 3, 17, 64, 513]))
+    c["kind"] = str(r.choice(["without", "with", "split", "poisson"]))
+    c["i"] = int(r.choice([0, 1, 5, 1000]))
+    c["quantile"] = float(r.choice([0.5, 0.99]))
+    c["suppress"] = bool(r.random() < 0.4)
+    c["label_dtype"] = str(r.choice(["float32", "int32", "int64"]))
+    c["key"] = int(r.integers(0, 2**31))
+    return c
+
+
+def run_batches_case(c, O, dump=False):
+    import scipy.stats
+    import torch
+    import d3p_amd.random as rng
+    from d3p_amd.minibatch import poisson_batchify_data, split_batchify_data, subsample_batchify_data
+    r = np.random.default_rng(c["seed"] + 19)
+    N, B, d = c["N"], c["B"], c["d"]
+    X = r.normal(size=(N, d)).astype(np.float32)
+    y = (r.integers(0, 1000, size=N)).astype(c["label_dtype"])
+    table = (torch.tensor(X).cuda(), torch.tensor(y).cuda())
+    key, okey = rng.PRNGKey(c["key"]), O.PRNGKey(c["key"])
+    why = []
+    if c["kind"] in ("without", "with"):
+        init, gb = subsample_batchify_data(table, B, with_replacement=c["kind"] == "with")
+        nb, st = init(key)
+        if nb != N // B:
+            why.append("number of batches")
+        bx, by = gb(c["i"], st)
+        fk = O.fold_in(okey, c["i"])
+        idx = O.feistel_sample(fk, N, B) if c["kind"] == "without" else np.asarray(O.randint(fk, (B,), 0, N)).astype(np.int64)
+        want_x, want_y, want_m = X[idx], y[idx], None
+    elif c["kind"] == "split":
+        init, gb = split_batchify_data(table, B)
+        nb, st = init(key)
+        i = c["i"] % max(nb, 1)
+        bx, by = gb(i, st)
+        perm = O.feistel_sample(okey, N, N)
+        idx = perm[i * B:(i + 1) * B]
+        want_x, want_y, want_m = X[idx], y[idx], None
+    else:
+        q = min(1.0, B / N)
+        maxB = min(max(int(scipy.stats.poisson(N * q).ppf(c["quantile"])), 1), N)
+        init, gb = poisson_batchify_data(table, q, maxB, handle_oversized_batch="suppress" if c["suppress"] else "truncate")
+        _, st = init(key) if int(q * N) > 0 else (0, key)
+        (bx, by), mask = gb(c["i"], st)
+        idx, nsel, nvalid = O.poisson_select(O.fold_in(okey, c["i"]), np.float32(q), N, maxB, c["suppress"])
+        want_m = np.arange(maxB) < nvalid
+        want_x = np.where(want_m[:, None], X[idx], 0).astype(np.float32)       # (mask * taken, minibatch.py:127-129)
+        want_y = np.where(want_m, y[idx], 0).astype(y.dtype)
+        if not np.array_equal(mask.cpu().numpy(), want_m):
+            why.append("poisson mask")
+    gx, gy = bx.cpu().numpy(), by.cpu().numpy()
+    if gx.shape != want_x.shape or not np.array_equal(gx, want_x):
+        why.append("batch rows")
+    if gy.dtype != want_y.dtype or gy.shape != want_y.shape or not np.array_equal(gy, want_y):
+        why.append(f"batch labels ({gy.dtype} {gy.shape} vs {want_y.dtype} {want_y.shape})")
+    c["ok"], c["why"] = not why, "; ".join(why)
+    return c
+
+
+FAMILIES = {"batches": (draw_batches_case, run_batches_case), "shards": (draw_shards_case, run_shards_case), "update": (draw_case, None), "staged": (draw_staged_case, run_staged_case), "gmm": (draw_gmm_case, run_gmm_case),
             "vae": (draw_vae_case, run_vae_case),
             "rng": (draw_rng_case, run_rng_case)}
 

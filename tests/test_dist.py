@@ -1159,3 +1159,39 @@ def test_xchg_two_processes_over_hipipc(gpu, form, world):
         pytest.xfail("the two ranks' chained launches were not co-resident on the shared GPU: " + r.stderr[-300:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert '"xchg_two_rank_check": "ok"' in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_fused_engine_takes_two_kernel_steps_for_rows_too_wide_for_the_one_launch_kernel(gpu):
+    """d3p_dpvi_logreg_fused_step has no form for rows the register-tiled kernel cannot hold (D > 2048, or D > 1024 unless d % 8 == 0
+    without intercept): the C entry refuses them (it used to launch the one-launch kernel with the column-chunked geometry: NaN), the
+    support query says so, and FusedHipEngine runs such a model as the two-kernel engine -- same trajectory as HipEngine, bit for bit."""
+    import ctypes as C
+    import d3p_amd._lib as L
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
+    from d3p_amd.svi import DPSVI, DPSVIState
+    n, B, steps = 300, 24, 4
+    for d, icpt, wide in ((2049, False, True), (1025, False, True), (1024, True, False), (2048, False, False), (512, True, False)):
+        g = torch.Generator().manual_seed(d)
+        X = torch.randn(n, d, generator=g).cuda()
+        y = (torch.rand(n, generator=g) < 0.5).float().cuda()
+        model = LogisticRegression(d, intercept=icpt)
+        svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-2), Trace_ELBO(), 1.0, 0.5, num_obs_total=n)
+        D = d + int(icpt)
+        st0 = DPSVIState(svi.optim.init(torch.cat([torch.zeros(D), torch.full((D,), -2.0)]).cuda()), rng.PRNGKey(1), float(n))
+        fused = ddist.FusedHipEngine(svi, X, y, n, 0, n, L.D3P_BATCH_FEISTEL, B)
+        plain = ddist.HipEngine(svi, X, y, n, 0, n, L.D3P_BATCH_FEISTEL, B)
+        a, la = ddist.run_steps(fused, st0, rng.PRNGKey(2), 0, steps)
+        b, lb = ddist.run_steps(plain, st0, rng.PRNGKey(2), 0, steps)
+        assert fused.two_kernel == wide
+        assert bool(L.load().d3p_dpvi_logreg_fused_step_supported(C.byref(fused.model), C.byref(fused.src))) == (not wide)
+        assert bool(torch.isfinite(la).all()) and torch.equal(a.rng_key, b.rng_key) and int(a.optim_state[0]) == steps
+        if wide:
+            assert torch.equal(la, lb) and torch.equal(a.optim_state[1], b.optim_state[1])
+            rc = L.load().d3p_dpvi_logreg_fused_step(L.stream_ptr(), *fused._args, 0, 0, 0, 0, 0, 0, L.ptr(X), L.ptr(y), None, 0,
+                                                     L.ptr(fused.ws), fused.ws.numel())
+            assert rc == -3      # D3P_E_UNSUPPORTED
+        else:
+            np.testing.assert_allclose(la.cpu().numpy(), lb.cpu().numpy(), rtol=2e-5)
