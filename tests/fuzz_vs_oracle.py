@@ -9,7 +9,7 @@ restatement of d3p/svi.py:395-434 driven by the oracle's own samplers: state key
 losses and parameters (empty batches: svi.py:305, :365), final parameters
 (rtol 5e-4, atol 5e-5 of the largest) and step counter.
 
-    python tests/fuzz_vs_oracle.py [update|staged|gmm|vae|rng|batches|shards] [first_seed=0] [count=40] [out.jsonl]
+    python tests/fuzz_vs_oracle.py [update|staged|gmm|vae|rng|batches|shards|posshards] [first_seed=0] [count=40] [out.jsonl]
 
 `gmm`: the mixture model's update (explicit batches with masks, Feistel runs) vs the oracle's stage composition; `rng`: split / fold_in /
 random_bits / randint / uniform / normal / Feistel / Poisson selection at random arguments, bit-exact (normal: 2e-6).
@@ -679,6 +679,102 @@ def run_shards_case(c, O, dump=False):
     return c
 
 
+# ------------------------------------------------------------------ batch positions sharded over ranks (mixture model, VAE)
+def draw_posshards_case(seed):
+    r = np.random.default_rng(700_001 * seed + 47)
+    c = draw_vae_case(seed) if r.random() < 0.5 else draw_gmm_case(seed)
+    c["seed"] = int(seed)
+    c["world"] = int(r.choice([1, 2, 3, 5, 8]))
+    c["steps"] = min(int(c["steps"]), 2)
+    c["uneven"] = bool(r.random() < 0.3)       # shards of different sizes, some of them EMPTY
+    return c
+
+
+def run_posshards_case(c, O, dump=False):
+    """SURVEY 8(e) for the models whose BATCH is sharded by position (d3p_amd.dist.VaeHipEngine / GmmHipEngine): every emulated rank's
+    local sums over its positions, added by hand, applied once per replica -- against DPSVI.update on the whole batch (itself held to the
+    oracle by the `vae` / `gmm` families): keys and step bit-exact, replicas bitwise, loss and parameters to fp32 summation order."""
+    import torch
+    import d3p_amd.random as rng
+    from d3p_amd import dist as ddist
+    from d3p_amd.models import Adam, GaussianMixtureGuide, GaussianMixtureModel, Trace_ELBO, VAEGuide, VAEModel
+    from d3p_amd.svi import DPSVI, DPSVIState
+    r = np.random.default_rng(c["seed"] + 31)
+    B, N, world = c["B"], c["N"], c["world"]
+    vae = c["family"] == "vae"
+    if vae:
+        D, H, Z, H2 = c["D"], c["H"], c["Z"], c["H2"]
+        spec = O.vae_spec(D, H, Z, scale=1.0, obs_scale=1.0, H2=H2)
+        P = O.vae_num_params(spec)
+        params = (r.normal(size=P) * (0.03 if (D > 100 or H > 50 or H2 > 50) else 0.3)).astype(np.float32)
+        X = r.random((B, D)).astype(np.float32) if c["grey"] else (r.random((B, D)) < 0.3).astype(np.float32)
+        model = VAEModel(scale=1.0 / N)
+        svi = DPSVI(model, VAEGuide(model), Adam(c["lr"]), Trace_ELBO(), c["clip"], c["sigma"], num_obs_total=N, z_dim=Z,
+                    hidden_dim=(H, H2) if H2 else H)
+        obs = 1.0
+        make_engine = lambda: ddist.VaeHipEngine(svi)
+    else:
+        K, d = c["K"], c["d"]
+        P = K + K * d
+        X = (r.normal(size=(B, d)) * 3).astype(np.float32)
+        params = np.concatenate([r.normal(size=K) * 0.4, r.normal(size=K * d) * 2]).astype(np.float32)
+        model = GaussianMixtureModel()
+        svi = DPSVI(model, GaussianMixtureGuide(model), Adam(c["lr"]), Trace_ELBO(), c["clip"], c["sigma"], k=K, d=d, num_obs_total=N)
+        obs = float(N)
+        make_engine = lambda: ddist.GmmHipEngine(svi)
+    Xd = torch.tensor(X).cuda()
+    mask = r.random(B) < c["mask_keep"]
+    use_mask = c["mask_keep"] < 1.0
+    md = torch.tensor(mask).cuda() if use_mask else None
+    if c["uneven"] and world > 1:
+        cuts = np.sort(r.integers(0, B + 1, size=world - 1))
+        bounds = [0] + [int(v) for v in cuts] + [B]
+    else:
+        bounds = [ddist.shard_batch(B, rk, world)[0] for rk in range(world)] + [B]
+    st_ref = DPSVIState(svi.optim.init(torch.tensor(params).cuda()), rng.PRNGKey(c["key"]), obs)
+    states = [st_ref] * world
+    why = []
+    for t in range(c["steps"]):
+        st_ref, loss_ref = svi.update(st_ref, Xd, mask=md if use_mask else True)
+        engines = [make_engine() for _ in range(world)]
+        live = []
+        for rk, e in enumerate(engines):
+            lo, hi = bounds[rk], bounds[rk + 1]
+            if hi == lo:
+                continue          # (a rank without positions contributes nothing; d3p_amd.dist.vae_run_steps skips its kernels the same way)
+            e.begin(states[rk], Xd[lo:hi], B, lo, mask=None if md is None else md[lo:hi])
+            live.append((rk, e))
+        total = torch.stack([e.local_sums().clone() for _, e in live]).sum(dim=0)
+        outs = {}
+        for rk, e in live:
+            outs[rk] = e.apply(total.clone())
+        first = outs[live[0][0]]
+        for rk, (ns, ls) in outs.items():
+            if not (torch.equal(ns.rng_key, first[0].rng_key) and torch.equal(torch.nan_to_num(ns.optim_state[1], nan=7.0), torch.nan_to_num(first[0].optim_state[1], nan=7.0))):
+                why.append(f"step {t}: replicas differ (rank {rk})")
+                break
+        states = [first[0]] * world
+        got_l, want_l = float(first[1]), float(loss_ref)
+        if np.isnan(got_l) != np.isnan(want_l) or (not np.isnan(want_l) and not (got_l == want_l or abs(got_l - want_l) <= 1e-4 * abs(want_l) + 1e-5)):
+            why.append(f"step {t}: loss {got_l!r} vs {want_l!r}")
+        if not torch.equal(first[0].rng_key, st_ref.rng_key) or int(first[0].optim_state[0]) != int(st_ref.optim_state[0]):
+            why.append(f"step {t}: key or step counter differs")
+        a, b = first[0].optim_state[1].cpu().numpy(), st_ref.optim_state[1].cpu().numpy()
+        if not np.array_equal(np.isnan(a), np.isnan(b)):
+            why.append(f"step {t}: parameters: NaN pattern differs ({int(np.isnan(a).sum())} vs {int(np.isnan(b).sum())})")
+        else:
+            fin = ~np.isnan(b)
+            bad = _far(a[fin], b[fin], 0.02 * c["lr"] * (t + 1) + 1e-4 * np.abs(b[fin]))
+            if bad.mean() > 0.01:
+                why.append(f"step {t}: {int(bad.sum())} of {int(fin.sum())} parameters out of tolerance")
+        if why:
+            break
+    torch.cuda.synchronize()
+    c["ok"], c["why"] = not why, "; ".join(why)
+    c["mask_sum"] = int(mask.sum()) if use_mask else B
+    return c
+
+
 # ------------------------------------------------------------------ the batchifiers' get_batch (gathers: bit-exact)
 def draw_batches_case(seed):
     r = np.random.default_rng(500_009 * seed + 41)
@@ -745,7 +841,8 @@ def run_batches_case(c, O, dump=False):
     return c
 
 
-FAMILIES = {"batches": (draw_batches_case, run_batches_case), "shards": (draw_shards_case, run_shards_case), "update": (draw_case, None), "staged": (draw_staged_case, run_staged_case), "gmm": (draw_gmm_case, run_gmm_case),
+FAMILIES = {"batches": (draw_batches_case, run_batches_case), "shards": (draw_shards_case, run_shards_case),
+            "posshards": (draw_posshards_case, run_posshards_case), "update": (draw_case, None), "staged": (draw_staged_case, run_staged_case), "gmm": (draw_gmm_case, run_gmm_case),
             "vae": (draw_vae_case, run_vae_case),
             "rng": (draw_rng_case, run_rng_case)}
 

@@ -61,3 +61,9 @@ def test_random_row_sharded_case_vs_oracle(gpu, O, seed):
 def test_random_batchifier_case_vs_oracle(gpu, O, seed):
     c = F.run_batches_case(F.draw_batches_case(seed), O)
     assert c["ok"], c
+
+
+@pytest.mark.parametrize("seed", list(range(20)))
+def test_random_position_sharded_case_vs_the_whole_batch_update(gpu, O, seed):
+    c = F.run_posshards_case(F.draw_posshards_case(seed), O)
+    assert c["ok"], c
