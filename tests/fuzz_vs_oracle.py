@@ -188,6 +188,13 @@ def draw_staged_case(seed):
     c["steps"] = min(c["steps"], 3)
     c["N"] = max(c["N"], c["B"])
     c["lr"] = min(c["lr"], 1e-2)
+    r = np.random.default_rng(800_003 * seed + 53)
+    c["optim"] = str(r.choice(["sgd", "sgd", "adadp"]))
+    c["tol"] = float(r.choice([0.1, 1.0, 10.0]))
+    c["stability"] = bool(r.random() < 0.5)
+    if c["optim"] == "adadp":
+        c["steps"] = int(r.choice([2, 3, 4]))
+        c["lr"] = float(r.choice([1e-6, 1e-5]))      # (N-scaled gradients: ADADP adapts from here)
     return c
 
 
@@ -198,7 +205,9 @@ def run_staged_case(c, O, dump=False):
     import torch
     import d3p_amd.random as rng
     from d3p_amd.models import SGD, AutoDiagonalNormal, DiagonalNormalGuide, GaussianMean, LogisticRegression, Trace_ELBO
+    from d3p_amd.optimizers import ADADP
     from d3p_amd.svi import DPSVI, DPSVIState
+    adadp = c.get("optim") == "adadp"
     r = np.random.default_rng(c["seed"] + 23)
     d, B, N, steps = c["d"], c["B"], c["N"], c["steps"]
     gauss, icpt = c["family"] == "gauss", c["family"] == "logreg_icpt"
@@ -217,7 +226,8 @@ def run_staged_case(c, O, dump=False):
         guide = AutoDiagonalNormal(model)
         mk_spec = lambda obs: O.logreg_spec(d, icpt, 1.0, 2.0, lik_scale=N, obs_scale=obs)
     spec = mk_spec(N)
-    svi = DPSVI(model, guide, SGD(c["lr"]), Trace_ELBO(), c["clip"], c["sigma"], num_obs_total=N, **({"d": d} if gauss else {}))
+    optim = ADADP(c["lr"], tol=c["tol"], stability_check=c["stability"]) if adadp else SGD(c["lr"])
+    svi = DPSVI(model, guide, optim, Trace_ELBO(), c["clip"], c["sigma"], num_obs_total=N, **({"d": d} if gauss else {}))
     loc = (r.normal(size=D) * c["init_scale"]).astype(np.float32)
     unc = (r.normal(size=D) * c["init_scale"] - 2.0).astype(np.float32)
     x = np.concatenate([loc, unc])
@@ -240,19 +250,27 @@ def run_staged_case(c, O, dump=False):
             L, G, n, f = O.logreg_px_grads(spec, x[:D], x[D:], X[idx], None if gauss else y[idx], eps, mask.astype(np.float32) if use_mask else None)
             eloss, avg = O.combine(O.clip_rows(G, c["clip"]), L)
             g = O.perturb(ks[2], avg, [D, D], c["sigma"], c["clip"], n, N, f)
-            x = (x - np.float32(c["lr"]) * g).astype(np.float32)
+            if adadp:
+                if t == 0:
+                    olr, oxs, oxp = c["lr"], np.zeros(2 * D, np.float32), x.copy()
+                x, olr, oxs, oxp = O.adadp(x, olr, oxs, oxp, g, t, tol=c["tol"], stability_check=c["stability"])
+            else:
+                x = (x - np.float32(c["lr"]) * g).astype(np.float32)
             if np.isfinite(G).all() and np.abs(G).max() > 1e9 * min(c["clip"], 1e3):
                 chaotic = True      # (a diverged run: per-example gradients of 1e12 clipped to C -- the directions of the clipped rows hang on the last bits)
         want_l.append(eloss)
         key = ks[0]
     torch.cuda.synchronize()
     got_l, want_l = np.asarray(got_l, np.float64), np.asarray(want_l, np.float64)
-    got_p = st.optim_state[1].detach().cpu().numpy()
+    got_p = svi.optim.get_params(st.optim_state).detach().cpu().numpy()
     why = []
-    if not np.array_equal(np.isnan(got_l), np.isnan(want_l)):
-        why.append(f"losses: NaN pattern differs ({got_l.tolist()} vs {want_l.tolist()})")
+    if adadp and not (abs(float(st.optim_state[1][1]) - olr) <= 1e-4 * abs(olr) or (np.isnan(float(st.optim_state[1][1])) and np.isnan(olr))):
+        why.append(f"ADADP learning rate {float(st.optim_state[1][1])!r} vs {olr!r}")
+    # (an overflowing loss is inf or NaN depending on the order of the last additions: one class)
+    if not np.array_equal(np.isfinite(got_l), np.isfinite(want_l)):
+        why.append(f"losses: finite / non-finite pattern differs ({got_l.tolist()} vs {want_l.tolist()})")
     else:
-        fin = ~np.isnan(want_l)
+        fin = np.isfinite(want_l)
         with np.errstate(invalid="ignore"):
             bad = _far(got_l[fin], want_l[fin], LOSS_RTOL * np.abs(want_l[fin]) + 1e-6 * (D + N))
         if bad.any():

@@ -40,7 +40,7 @@ def test_random_rng_and_sampler_arguments_vs_oracle(gpu, O, seed):
 # (the five-stage composition with SGD, then evaluate.  84, 107: masked rows of the column-chunked materialising kernel behind a NaN state;
 #  176, 297: a scale below 6e-8 -- softplus(u) for u < -16.6 was 0 on the device: 1 + exp(u) rounds to 1; 95, 210: a row with a NaN entry is
 #  NaN throughout after clipping, jnp.maximum propagates NaN; 236: exp-parametrised scales of e^27 -- __expf carries |u| ulp)
-@pytest.mark.parametrize("seed", list(range(30)) + [84, 95, 107, 176, 210, 236, 297])
+@pytest.mark.parametrize("seed", list(range(30)) + [84, 95, 107, 153, 176, 210, 236, 297])   # (a third of them with ADADP)
 def test_random_stage_composition_case_vs_oracle(gpu, O, seed):
     c = F.run_staged_case(F.draw_staged_case(seed), O)
     assert c["ok"], c
