@@ -64,6 +64,7 @@ def draw_case(seed):
     c["init_scale"] = float(r.choice([0.0, 0.3]))
     c["key"], c["bkey"] = int(r.integers(0, 2**31)), int(r.integers(0, 2**31))
     c["unscale"] = bool(r.random() < 0.8)        # clip_unscaled_observations (svi.py:225-234): False = observation_scale 1
+    c["split_at"] = int(r.integers(1, c["steps"])) if (c["steps"] > 1 and r.random() < 0.5) else 0   # the run as two consecutive run_steps calls
     return c
 
 
@@ -130,7 +131,13 @@ def run_case(c, O, dump=False):
         losses = torch.stack(losses)
     elif c["source"] == "feistel":
         _, gb = subsample_batchify_data(table, B)
-        st, losses = svi.run_steps(st, gb, rng.PRNGKey(c["bkey"]), c["first"], steps)
+        k = c.get("split_at", 0)
+        if k:
+            st, l1 = svi.run_steps(st, gb, rng.PRNGKey(c["bkey"]), c["first"], k)
+            st, l2 = svi.run_steps(st, gb, rng.PRNGKey(c["bkey"]), c["first"] + k, steps - k)
+            losses = torch.cat([l1, l2])
+        else:
+            st, losses = svi.run_steps(st, gb, rng.PRNGKey(c["bkey"]), c["first"], steps)
         for t in range(steps):
             idx = O.feistel_sample(O.fold_in(O.PRNGKey(c["bkey"]), c["first"] + t), N, B)
             el.append(upd(spec, hy, ost, X[idx], None if gauss else y[idx])[0])
@@ -140,7 +147,13 @@ def run_case(c, O, dump=False):
             q = 1.0 / N
         maxB = min(max(int(scipy.stats.poisson(N * q).ppf(c["quantile"])), 1), N)   # (max_batch_size > N is an error, minibatch.py:116)
         _, gb = poisson_batchify_data(table, q, maxB, handle_oversized_batch="suppress" if c["suppress"] else "truncate")
-        st, losses = svi.run_steps(st, gb, rng.PRNGKey(c["bkey"]), c["first"], steps)
+        k = c.get("split_at", 0)
+        if k:
+            st, l1 = svi.run_steps(st, gb, rng.PRNGKey(c["bkey"]), c["first"], k)
+            st, l2 = svi.run_steps(st, gb, rng.PRNGKey(c["bkey"]), c["first"] + k, steps - k)
+            losses = torch.cat([l1, l2])
+        else:
+            st, losses = svi.run_steps(st, gb, rng.PRNGKey(c["bkey"]), c["first"], steps)
         for t in range(steps):
             idx, nsel, nvalid = O.poisson_select(O.fold_in(O.PRNGKey(c["bkey"]), c["first"] + t), np.float32(q), N, maxB, c["suppress"])
             mask = (np.arange(maxB) < nvalid).astype(np.float32)
@@ -590,6 +603,39 @@ def run_rng_case(c, O, dump=False):
         why.append(f"poisson counts {cn[:2].tolist()} vs {[int(nsel), int(nvalid)]}")
     elif not np.array_equal(idxs[:int(nvalid)].cpu().numpy(), np.asarray(want_idx)[:int(nvalid)]):
         why.append("poisson indices")
+    # the threefry suite (d3p/random/debug.py): jax.random's streams restated
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import d3p_amd.random.debug as dbg
+    seed32 = c["key"] & 0x7fffffff
+    tk, otk = dbg.PRNGKey(seed32), np.array([0, seed32], np.uint32)
+    same("tf split", dbg.split(tk, c["num"]).reshape(c["num"], 2), np.asarray(O.tf_split(otk, c["num"])).reshape(c["num"], 2))
+    tfk, otfk = dbg.fold_in(tk, c["fold"] & 0xffffffff), O.tf_fold_in(otk, c["fold"] & 0xffffffff)
+    same("tf fold_in", tfk.reshape(2), np.asarray(otfk).reshape(2))
+    n = int(np.prod(shape)) if shape else 1
+    gu, wu = dbg.uniform(tfk, shape).cpu().numpy().ravel(), np.asarray(O.tf_uniform(otfk, n)).ravel()[:n]
+    if gu.shape != wu.shape or not np.array_equal(gu, wu):
+        why.append("tf uniform")
+    gn, wn = dbg.normal(tfk, shape).cpu().numpy().ravel(), np.asarray(O.tf_normal(otfk, n)).ravel()[:n]
+    if gn.shape != wn.shape or not np.allclose(gn, wn, rtol=2e-6, atol=1e-7):
+        why.append("tf normal")
+    if n and c["maxval"] > c["minval"] and c["maxval"] - c["minval"] < 2**31 and abs(c["minval"]) < 2**31 - 1:
+        gi = dbg.randint(tfk, shape, c["minval"], c["maxval"]).cpu().numpy().ravel()
+        wi = np.asarray(O.tf_randint(otfk, n, c["minval"], c["maxval"])).ravel()[:n]
+        if gi.shape != wi.shape or not np.array_equal(gi.astype(np.int64), wi.astype(np.int64)):
+            why.append("tf randint")
+    # GaussianMixture.log_prob (d3p/gmm.py:71-86)
+    from d3p_amd.gmm import GaussianMixture
+    rr = np.random.default_rng(c["seed"] + 3)
+    K, dd, nb = int(rr.choice([1, 2, 4, 5, 16, 17, 64])), int(rr.choice([1, 2, 3, 64, 100])), int(rr.choice([1, 7, 300]))
+    locs, scales = rr.normal(size=(K, dd)).astype(np.float32) * 3, (0.2 + rr.random((K, dd))).astype(np.float32)
+    pis = rr.dirichlet(np.ones(K)).astype(np.float32)
+    xs = (rr.normal(size=(nb, dd)) * 3).astype(np.float32)
+    got_lp = GaussianMixture(locs, scales, pis).log_prob(torch.tensor(xs)).cpu().numpy()
+    want_lp = O.gmm_log_prob(xs, locs, scales, pis)
+    if got_lp.shape != want_lp.shape or not np.allclose(got_lp, want_lp, rtol=2e-5, atol=2e-5):
+        why.append("gmm log_prob")
     c["ok"], c["why"] = not why, "; ".join(why)
     return c
 
@@ -605,6 +651,8 @@ def draw_shards_case(seed):
     c["source"] = str(r.choice(["feistel", "feistel", "poisson"]))
     c["world"] = int(r.choice([1, 2, 3, 5, 8]))
     c["engine"] = str(r.choice(["fused", "two_kernel"]))
+    if c["world"] == 1 and r.random() < 0.6:
+        c["engine"] = "native"          # d3p_dpvi_logreg_run_dist_from without a communicator: the data-parallel native loop on one rank
     c["steps"] = min(c["steps"], 20)
     c["N"] = max(c["N"], c["world"], c["B"])
     return c
@@ -643,18 +691,30 @@ def run_shards_case(c, O, dump=False):
     if poisson:
         q = B / N
         maxB = min(max(int(scipy.stats.poisson(N * q).ppf(c["quantile"])), 1), N)
-    cls = ddist.FusedHipEngine if c["engine"] == "fused" else ddist.HipEngine
+    cls = ddist.HipEngine if c["engine"] == "two_kernel" else ddist.FusedHipEngine
     engines = []
     for rk in range(world):
         lo, hi = ddist.shard_rows(N, rk, world)
         engines.append(cls(svi, Xd[lo:hi], yd[lo:hi], N, lo, hi, L.D3P_BATCH_POISSON if poisson else L.D3P_BATCH_FEISTEL, maxB,
                            q=q, suppress=c["suppress"]))
-    for e in engines:
+    if c["engine"] == "native":
+        try:
+            st_n, losses_n = ddist.run_steps_native(engines[0], st0, bkey, c["first"], steps, comm=None)
+        except L.D3PError as e:
+            # rows too wide for the one-launch step: the native data-parallel loop says so (the torch loop's engines run them)
+            c["ok"], c["why"] = "needs the fused step" in str(e) and (D > 2048 or (D > 1024 and (icpt or d % 8))), f"refused: {e}"
+            return c
+        torch.cuda.synchronize()
+        code, _ = ddist.native_run_status(engines[0])
+        if code:
+            raise RuntimeError(f"native loop stopped: {L.describe_abort(code)}")
+        finals, per_rank_losses = [st_n], [losses_n[:steps]]
+    for e in engines if c["engine"] != "native" else []:
         e.begin(st0, bkey, c["first"])
         e.plan(steps)
     fused = c["engine"] == "fused"
     step_losses = []
-    for _ in range(steps):
+    for _ in range(steps if c["engine"] != "native" else 0):
         bufs = [e.local_sums() for e in engines]
         total = torch.stack(bufs).sum(dim=0)
         outs = []
@@ -663,9 +723,10 @@ def run_shards_case(c, O, dump=False):
             outs.append(e.finalize(b))
         if not fused:
             step_losses.append(torch.stack([o.reshape(()).clone() for o in outs]))     # (the two-kernel engine reports a step's loss at once)
-    finals = [e.end() for e in engines]
-    torch.cuda.synchronize()
-    per_rank_losses = [e.losses[:steps] for e in engines] if fused else list(torch.stack(step_losses).T)
+    if c["engine"] != "native":
+        finals = [e.end() for e in engines]
+        torch.cuda.synchronize()
+        per_rank_losses = [e.losses[:steps] for e in engines] if fused else list(torch.stack(step_losses).T)
     el = []
     for t in range(steps):
         fk = O.fold_in(O.PRNGKey(c["bkey"]), c["first"] + t)
@@ -873,39 +934,6 @@ def run_batches_case(c, O, dump=False):
         why.append("batch rows")
     if gy.dtype != want_y.dtype or gy.shape != want_y.shape or not np.array_equal(gy, want_y):
         why.append(f"batch labels ({gy.dtype} {gy.shape} vs {want_y.dtype} {want_y.shape})")
-    # the threefry suite (d3p/random/debug.py): jax.random's streams restated
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        import d3p_amd.random.debug as dbg
-    seed32 = c["key"] & 0x7fffffff
-    tk, otk = dbg.PRNGKey(seed32), np.array([0, seed32], np.uint32)
-    same("tf split", dbg.split(tk, c["num"]).reshape(c["num"], 2), np.asarray(O.tf_split(otk, c["num"])).reshape(c["num"], 2))
-    tfk, otfk = dbg.fold_in(tk, c["fold"] & 0xffffffff), O.tf_fold_in(otk, c["fold"] & 0xffffffff)
-    same("tf fold_in", tfk.reshape(2), np.asarray(otfk).reshape(2))
-    n = int(np.prod(shape)) if shape else 1
-    gu, wu = dbg.uniform(tfk, shape).cpu().numpy().ravel(), np.asarray(O.tf_uniform(otfk, n)).ravel()[:n]
-    if gu.shape != wu.shape or not np.array_equal(gu, wu):
-        why.append("tf uniform")
-    gn, wn = dbg.normal(tfk, shape).cpu().numpy().ravel(), np.asarray(O.tf_normal(otfk, n)).ravel()[:n]
-    if gn.shape != wn.shape or not np.allclose(gn, wn, rtol=2e-6, atol=1e-7):
-        why.append("tf normal")
-    if n and c["maxval"] > c["minval"] and c["maxval"] - c["minval"] < 2**31 and abs(c["minval"]) < 2**31 - 1:
-        gi = dbg.randint(tfk, shape, c["minval"], c["maxval"]).cpu().numpy().ravel()
-        wi = np.asarray(O.tf_randint(otfk, n, c["minval"], c["maxval"])).ravel()[:n]
-        if gi.shape != wi.shape or not np.array_equal(gi.astype(np.int64), wi.astype(np.int64)):
-            why.append("tf randint")
-    # GaussianMixture.log_prob (d3p/gmm.py:71-86)
-    from d3p_amd.gmm import GaussianMixture
-    rr = np.random.default_rng(c["seed"] + 3)
-    K, dd, nb = int(rr.choice([1, 2, 4, 5, 16, 17, 64])), int(rr.choice([1, 2, 3, 64, 100])), int(rr.choice([1, 7, 300]))
-    locs, scales = rr.normal(size=(K, dd)).astype(np.float32) * 3, (0.2 + rr.random((K, dd))).astype(np.float32)
-    pis = rr.dirichlet(np.ones(K)).astype(np.float32)
-    xs = (rr.normal(size=(nb, dd)) * 3).astype(np.float32)
-    got_lp = GaussianMixture(locs, scales, pis).log_prob(torch.tensor(xs)).cpu().numpy()
-    want_lp = O.gmm_log_prob(xs, locs, scales, pis)
-    if got_lp.shape != want_lp.shape or not np.allclose(got_lp, want_lp, rtol=2e-5, atol=2e-5):
-        why.append("gmm log_prob")
     c["ok"], c["why"] = not why, "; ".join(why)
     return c
 
