@@ -335,6 +335,8 @@ def draw_gmm_case(seed):
     c["B"] = int(min(int(r.choice([1, 2, 7, 33, 64, 200, 1000])), cap))
     c["steps"] = int(r.choice([1, 2, 4])) if c["B"] * c["K"] * c["d"] <= 1e5 else 1
     c["source"] = str(r.choice(["explicit", "feistel"]))
+    if c["source"] == "feistel" and c["B"] * c["K"] * c["d"] <= 3000 and r.random() < 0.5:
+        c["steps"] = int(r.choice([65, 70, 130]))       # across the native loop's batches of prepared steps
     c["N"] = int(max(c["B"] * float(r.choice([1.0, 3.0, 50.0])), c["B"]))
     c["clip"] = float(r.choice([1.0, 20.0, 1e6]))
     c["sigma"] = float(r.choice([0.0, 0.7]))
@@ -412,7 +414,10 @@ def run_gmm_case(c, O, dump=False):
         fin = ~np.isnan(x)
         scale = np.abs(x[fin]).max() if fin.any() else 0.0
         bad = np.abs(got_p[fin] - x[fin]) > 1e-3 * np.abs(x[fin]) + 1e-4 * max(scale, 1e-30)
-        if bad.any():
+        # (Adam's first steps are lr g / (|g| + 1e-8): a gradient component that is ~ 0 -- sums of float32 terms on the device, float64 in
+        #  the oracle -- may take the other sign: a handful of parameters one or two steps of lr apart is that, not a defect)
+        sign_flips = bad & (np.abs(got_p[fin] - x[fin]) <= 2.1 * c["lr"] * steps)
+        if (bad & ~sign_flips).any() or sign_flips.mean() > 0.005:
             k = int(np.argmax(np.abs(got_p[fin] - x[fin])))
             why.append(f"parameter: {got_p[fin][k]!r} vs {x[fin][k]!r} (largest {scale:.3g}); {int(bad.sum())} of {int(fin.sum())} out of tolerance")
     if np.isfinite(x).all() and np.isfinite(got_p).all():
