@@ -335,8 +335,6 @@ def draw_gmm_case(seed):
     c["B"] = int(min(int(r.choice([1, 2, 7, 33, 64, 200, 1000])), cap))
     c["steps"] = int(r.choice([1, 2, 4])) if c["B"] * c["K"] * c["d"] <= 1e5 else 1
     c["source"] = str(r.choice(["explicit", "feistel"]))
-    if c["source"] == "feistel" and c["B"] * c["K"] * c["d"] <= 3000 and r.random() < 0.5:
-        c["steps"] = int(r.choice([65, 70, 130]))       # across the native loop's batches of prepared steps
     c["N"] = int(max(c["B"] * float(r.choice([1.0, 3.0, 50.0])), c["B"]))
     c["clip"] = float(r.choice([1.0, 20.0, 1e6]))
     c["sigma"] = float(r.choice([0.0, 0.7]))
@@ -344,6 +342,9 @@ def draw_gmm_case(seed):
     c["first"] = int(r.choice([0, 5]))
     c["mask_keep"] = float(r.choice([1.0, 0.7, 0.0 if r.random() < 0.3 else 0.7]))
     c["key"], c["bkey"] = int(r.integers(0, 2**31)), int(r.integers(0, 2**31))
+    r2 = np.random.default_rng(900_007 * seed + 59)     # (later additions draw from their own stream: the earlier fields of a seed stay)
+    if c["source"] == "feistel" and c["B"] * c["K"] * c["d"] <= 3000 and r2.random() < 0.5:
+        c["steps"] = int(r2.choice([65, 70, 130]))       # across the native loop's batches of prepared steps
     return c
 
 
