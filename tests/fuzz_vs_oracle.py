@@ -163,12 +163,14 @@ def run_case(c, O, dump=False):
     got_l, want_l = losses.detach().cpu().numpy().astype(np.float64), np.asarray(el, np.float64)
     got_p, want_p = st.optim_state[1].detach().cpu().numpy(), ost.params
     why = []
+    # (two float32 trajectories with different summation orders drift apart with the number of steps: the tolerances grow with it)
+    drift = 1.0 + steps / 16.0
     both_nan = np.isnan(got_l) & np.isnan(want_l)
     if not np.array_equal(np.isnan(got_l), np.isnan(want_l)):
         why.append("losses: NaN pattern differs")
     else:
         # (the loss is a difference of sums over D latent terms and N-scaled likelihood terms: an absolute fp32 floor beside the rtol)
-        ok_l = both_nan | (np.abs(got_l - want_l) <= LOSS_RTOL * np.abs(want_l) + 1e-6 * (D + N))
+        ok_l = both_nan | (np.abs(got_l - want_l) <= drift * LOSS_RTOL * np.abs(want_l) + 1e-6 * (D + N))
         if not ok_l.all():
             k = int(np.argmin(ok_l))
             why.append(f"loss {k}: {got_l[k]!r} vs {want_l[k]!r}")
@@ -181,7 +183,7 @@ def run_case(c, O, dump=False):
     else:
         fin = ~np.isnan(want_p)
         scale = np.abs(want_p[fin]).max() if fin.any() else 0.0
-        bad = np.abs(got_p[fin] - want_p[fin]) > PARAM_RTOL * np.abs(want_p[fin]) + PARAM_ATOL * max(scale, 1e-30)
+        bad = np.abs(got_p[fin] - want_p[fin]) > drift * (PARAM_RTOL * np.abs(want_p[fin]) + PARAM_ATOL * max(scale, 1e-30))
         if bad.any():
             k = int(np.argmax(np.abs(got_p[fin] - want_p[fin])))
             why.append(f"parameter: {got_p[fin][k]!r} vs {want_p[fin][k]!r} (largest {scale:.3g}); {int(bad.sum())} of {int(fin.sum())} out of tolerance")
