@@ -9,7 +9,7 @@ restatement of d3p/svi.py:395-434 driven by the oracle's own samplers: state key
 losses and parameters (empty batches: svi.py:305, :365), final parameters
 (rtol 5e-4, atol 5e-5 of the largest) and step counter.
 
-    python tests/fuzz_vs_oracle.py [update|staged|gmm|vae|rng|batches|shards|posshards] [first_seed=0] [count=40] [out.jsonl]
+    python tests/fuzz_vs_oracle.py [update|big|staged|gmm|vae|rng|batches|shards|posshards] [first_seed=0] [count=40] [out.jsonl]
 
 `gmm`: the mixture model's update (explicit batches with masks, Feistel runs) vs the oracle's stage composition; `rng`: split / fold_in /
 random_bits / randint / uniform / normal / Feistel / Poisson selection at random arguments, bit-exact (normal: 2e-6).
@@ -86,14 +86,16 @@ def run_case(c, O, dump=False):
         X = (1.0 + 0.5 * X).astype(np.float32)
     y = None if gauss else (r.random(N) < 0.5).astype(np.float32)
     obs = float(N) if c.get("unscale", True) else 1.0
+    pw, pb, ls = c.get("prior_w", 1.0), c.get("prior_b", 2.0), c.get("lik_sigma", 0.7)
     if gauss:
-        model = GaussianMean(d, prior_scale=1.5, obs_scale=0.7)
+        pw = c.get("prior_w", 1.5)
+        model = GaussianMean(d, prior_scale=pw, obs_scale=ls)
         guide = AutoDiagonalNormal(model) if c["guide"] == "auto" else DiagonalNormalGuide(model)
-        spec = O.gauss_mean_spec(d, prior=1.5, lik_sigma=0.7, lik_scale=N, obs_scale=obs, guide_exp=c["guide"] != "auto")
+        spec = O.gauss_mean_spec(d, prior=pw, lik_sigma=ls, lik_scale=N, obs_scale=obs, guide_exp=c["guide"] != "auto")
     else:
-        model = LogisticRegression(d, prior_scale=1.0, intercept=icpt, intercept_prior_scale=2.0)
+        model = LogisticRegression(d, prior_scale=pw, intercept=icpt, intercept_prior_scale=pb)
         guide = MeanFieldGuide(model) if c["guide"] == "meanfield" else AutoDiagonalNormal(model)
-        spec = O.logreg_spec(d, icpt, 1.0, 2.0, lik_scale=N, obs_scale=obs, guide_exp=c["guide"] == "meanfield")
+        spec = O.logreg_spec(d, icpt, pw, pb, lik_scale=N, obs_scale=obs, guide_exp=c["guide"] == "meanfield")
     svi = DPSVI(model, guide, Adam(c["lr"]), Trace_ELBO(), c["clip"], c["sigma"], num_obs_total=N,
                 clip_unscaled_observations=c.get("unscale", True), **({"d": d} if gauss else {}))
     hy = O.Hyper(c["clip"], c["sigma"], c["lr"], 0.9, 0.999, 1e-8)
@@ -193,6 +195,23 @@ def run_case(c, O, dump=False):
         c["mask_sum"] = int(mask.sum()) if c["source"] != "feistel" else None
     c["ok"], c["why"] = not why, "; ".join(why)
     c["final_loss"] = float(want_l[-1]) if len(want_l) else None
+    return c
+
+
+# ------------------------------------------------------------------ large batches, random prior / likelihood scales
+def draw_big_case(seed):
+    c = draw_case(31 * seed + 5)
+    c["seed"] = int(seed)
+    r = np.random.default_rng(1_000_003 * seed + 61)
+    c["B"] = int(r.choice([5000, 8192, 16384, 32768, 100_000]))
+    c["d"] = int(r.choice([1, 2, 5, 17, 64, 100, 256, 512]))
+    budget = 8e7 / (c["B"] * c["d"])
+    c["steps"] = int(r.choice([s for s in (1, 2, 3, 5, 20) if s <= max(budget, 1)]))
+    c["N"] = int(c["B"] * int(r.choice([1, 2, 10])))
+    c["split_at"] = 0
+    c["prior_w"], c["prior_b"] = float(r.choice([0.1, 1.0, 10.0])), float(r.choice([0.5, 3.0]))
+    c["lik_sigma"] = float(r.choice([0.1, 0.7, 3.0]))
+    c["mask_keep"] = float(r.choice([1.0, 0.5]))
     return c
 
 
@@ -946,7 +965,7 @@ def run_batches_case(c, O, dump=False):
     return c
 
 
-FAMILIES = {"batches": (draw_batches_case, run_batches_case), "shards": (draw_shards_case, run_shards_case),
+FAMILIES = {"big": (draw_big_case, None), "batches": (draw_batches_case, run_batches_case), "shards": (draw_shards_case, run_shards_case),
             "posshards": (draw_posshards_case, run_posshards_case), "update": (draw_case, None), "staged": (draw_staged_case, run_staged_case), "gmm": (draw_gmm_case, run_gmm_case),
             "vae": (draw_vae_case, run_vae_case),
             "rng": (draw_rng_case, run_rng_case)}

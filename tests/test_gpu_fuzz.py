@@ -67,3 +67,10 @@ def test_random_batchifier_case_vs_oracle(gpu, O, seed):
 def test_random_position_sharded_case_vs_the_whole_batch_update(gpu, O, seed):
     c = F.run_posshards_case(F.draw_posshards_case(seed), O)
     assert c["ok"], c
+
+
+# (batches of 5000 .. 100 000 examples -- several examples per wave, more workgroups than CUs --, random prior and likelihood scales)
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_large_batch_case_vs_oracle(gpu, O, seed):
+    c = F.run_case(F.draw_big_case(seed), O)
+    assert c["ok"], c
