@@ -9,7 +9,7 @@ restatement of d3p/svi.py:395-434 driven by the oracle's own samplers: state key
 losses and parameters (empty batches: svi.py:305, :365), final parameters
 (rtol 5e-4, atol 5e-5 of the largest) and step counter.
 
-    python tests/fuzz_vs_oracle.py [update|big|staged|gmm|vae|rng|batches|shards|posshards] [first_seed=0] [count=40] [out.jsonl]
+    python tests/fuzz_vs_oracle.py [update|big|stepwise|staged|gmm|vae|rng|batches|shards|posshards] [first_seed=0] [count=40] [out.jsonl]
 
 `gmm`: the mixture model's update (explicit batches with masks, Feistel runs) vs the oracle's stage composition; `rng`: split / fold_in /
 random_bits / randint / uniform / normal / Feistel / Poisson selection at random arguments, bit-exact (normal: 2e-6).
@@ -143,6 +143,23 @@ def run_case(c, O, dump=False):
         for t in range(steps):
             idx = O.feistel_sample(O.fold_in(O.PRNGKey(c["bkey"]), c["first"] + t), N, B)
             el.append(upd(spec, hy, ost, X[idx], None if gauss else y[idx])[0])
+    elif c["source"] in ("with_replacement", "split"):
+        # batchifiers without a native loop: run_steps walks get_batch + update (DPSVI._run_steps_stepwise)
+        from d3p_amd.minibatch import split_batchify_data
+        if c["source"] == "split":
+            init_b, gb = split_batchify_data(table, B)
+            nb, bstate = init_b(rng.PRNGKey(c["bkey"]))
+            first = c["first"] % max(nb - steps + 1, 1)
+            steps = min(steps, nb - first)
+            perm = O.feistel_sample(O.PRNGKey(c["bkey"]), N, N)
+            batches = [perm[(first + t) * B:(first + t + 1) * B] for t in range(steps)]
+        else:
+            _, gb = subsample_batchify_data(table, B, with_replacement=True)
+            bstate, first = rng.PRNGKey(c["bkey"]), c["first"]
+            batches = [np.asarray(O.randint(O.fold_in(O.PRNGKey(c["bkey"]), first + t), (B,), 0, N)).astype(np.int64) for t in range(steps)]
+        st, losses = svi.run_steps(st, gb, bstate, first, steps)
+        for idx in batches:
+            el.append(upd(spec, hy, ost, X[idx], None if gauss else y[idx])[0])
     else:
         q = B / N
         if int(q * N) == 0:
@@ -195,6 +212,19 @@ def run_case(c, O, dump=False):
         c["mask_sum"] = int(mask.sum()) if c["source"] != "feistel" else None
     c["ok"], c["why"] = not why, "; ".join(why)
     c["final_loss"] = float(want_l[-1]) if len(want_l) else None
+    return c
+
+
+# ------------------------------------------------------------------ batchifiers without a native loop (sampling with replacement, epoch splits)
+def draw_stepwise_case(seed):
+    c = draw_case(53 * seed + 11)
+    c["seed"] = int(seed)
+    r = np.random.default_rng(1_100_009 * seed + 67)
+    c["source"] = str(r.choice(["with_replacement", "split"]))
+    c["steps"] = min(c["steps"], 5)
+    if c["source"] == "split":
+        c["N"] = max(c["N"], c["B"] * c["steps"])
+    c["split_at"] = 0
     return c
 
 
@@ -965,7 +995,7 @@ def run_batches_case(c, O, dump=False):
     return c
 
 
-FAMILIES = {"big": (draw_big_case, None), "batches": (draw_batches_case, run_batches_case), "shards": (draw_shards_case, run_shards_case),
+FAMILIES = {"big": (draw_big_case, None), "stepwise": (draw_stepwise_case, None), "batches": (draw_batches_case, run_batches_case), "shards": (draw_shards_case, run_shards_case),
             "posshards": (draw_posshards_case, run_posshards_case), "update": (draw_case, None), "staged": (draw_staged_case, run_staged_case), "gmm": (draw_gmm_case, run_gmm_case),
             "vae": (draw_vae_case, run_vae_case),
             "rng": (draw_rng_case, run_rng_case)}

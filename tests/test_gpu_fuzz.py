@@ -74,3 +74,10 @@ def test_random_position_sharded_case_vs_the_whole_batch_update(gpu, O, seed):
 def test_random_large_batch_case_vs_oracle(gpu, O, seed):
     c = F.run_case(F.draw_big_case(seed), O)
     assert c["ok"], c
+
+
+# (run_steps over the batchifiers that have no native loop: sampling with replacement, the epoch split)
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_stepwise_batchifier_case_vs_oracle(gpu, O, seed):
+    c = F.run_case(F.draw_stepwise_case(seed), O)
+    assert c["ok"], c
