@@ -206,6 +206,23 @@ def run_case(c, O, dump=False):
         if bad.any():
             k = int(np.argmax(np.abs(got_p[fin] - want_p[fin])))
             why.append(f"parameter: {got_p[fin][k]!r} vs {want_p[fin][k]!r} (largest {scale:.3g}); {int(bad.sum())} of {int(fin.sum())} out of tolerance")
+    # evaluate (svi.py:436-449) on a fresh batch at the state the trajectory reached (not in the corner where a scale underflows)
+    if not why and np.isfinite(got_p).all() and np.abs(got_p).max() < 80.0:
+        nb = min(B, N)
+        idx = (np.arange(nb) * 3 + 1) % N
+        args = (Xd[idx],) if gauss else (Xd[idx], yd[idx])
+        got_e = float(svi.evaluate(st, *args))
+        jk = O.convert_to_jax_rng_key(O.split(ost.key, 1)[0])
+        if gauss:
+            spec_e = O.gauss_mean_spec(d, prior=pw, lik_sigma=ls, lik_scale=N, obs_scale=1.0, guide_exp=c["guide"] != "auto")
+        else:
+            spec_e = O.logreg_spec(d, icpt, pw, pb, lik_scale=N, obs_scale=1.0, guide_exp=meanfield)
+        if meanfield:
+            want_e = O.meanfield_logreg_evaluate(spec_e, got_p, X[idx], y[idx], jk)
+        else:
+            want_e = O.logreg_evaluate(spec_e, got_p[:D], got_p[D:], X[idx], None if gauss else y[idx], jk)
+        if not (got_e == want_e or abs(got_e - want_e) <= LOSS_RTOL * abs(want_e) + 1e-6 * (D + N) or (np.isnan(got_e) and np.isnan(want_e))):
+            why.append(f"evaluate: {got_e!r} vs {want_e!r}")
     if dump:
         c["got_losses"], c["want_losses"] = [float(v) for v in got_l], [float(v) for v in want_l]
         c["got_nan_params"], c["want_nan_params"] = int(np.isnan(got_p).sum()), int(np.isnan(want_p).sum())
