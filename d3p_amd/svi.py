@@ -100,6 +100,8 @@ def _batch_array(x):
     current device, floating types as float32 -- what jax does with a numpy argument at every call (x64 off) -- so that a HOST pointer
     never reaches a kernel (a GPU memory fault, not a Python error)."""
     if isinstance(x, torch.Tensor) and x.is_cuda:
+        if x.is_floating_point() and x.dtype != torch.float32:
+            x = x.to(torch.float32)        # (the kernels read float32; a float64 / half batch is converted like a host one)
         return x.contiguous()
     _lib.require_device()
     t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
@@ -957,6 +959,13 @@ class DPSVI:
         info = getattr(get_batch, "source", None)
         if info is not None and info.kind == _lib.D3P_BATCH_POISSON and int(info.batch_size) > example_count(info.dataset[0]):
             raise AssertionError("poisson_batchify_data: max_batch_size exceeds the number of records")   # (as get_batch, minibatch.py:116)
+        if info is not None:
+            if any(not (isinstance(a, torch.Tensor) and a.is_cuda) for a in info.dataset):
+                raise _lib.D3PError("run_steps: the batchifier's dataset arrays must be CUDA tensors")
+            if any(a.dtype != torch.float32 or not a.is_contiguous() for a in info.dataset):
+                # (float64 / integer-labelled / strided tables: the native loops read contiguous float32 rows in place; get_batch + update
+                #  gather and convert per step)
+                return self._run_steps_stepwise(svi_state, get_batch, batchifier_state, first_batch, num_steps, **kwargs)
         if info is None or info.rng_suite is not strong_rng or not (self._gmm_fusable() or self._is_vae() or self._fusable()):
             # no native loop for this combination (sampling with replacement, split_batchify_data's epochs, another rng_suite,
             # the stage-wise optimisers): the same steps through the API-parity path -- get_batch + update, one call each,

@@ -1036,6 +1036,9 @@ def test_host_arrays_are_moved_to_the_device_not_handed_to_kernels(rng):
             assert torch.equal(got.optim_state[1], want.optim_state[1]) and float(loss) == float(want_loss)
             assert torch.equal(got.rng_key, want.rng_key)
         assert float(svi.evaluate(want, X64, y_int)) == float(svi.evaluate(want, Xd, yd))
+        # a float64 batch that already lives on the device is converted too (its bytes are not float32 rows)
+        got64, loss64 = svi.update(st_dev, torch.tensor(X64).cuda(), torch.tensor(y_int).cuda().double(), mask=md)
+        assert torch.equal(got64.optim_state[1], want.optim_state[1]) and float(loss64) == float(want_loss)
     # the stage-wise path too
     st2, px_loss, px_grads, n_el, factor = svi._compute_per_example_gradients(st_dev, rng.PRNGKey(9), X64, y_int, mask=mask_np)
     st3, px_loss_d, px_grads_d, _, _ = svi._compute_per_example_gradients(st_dev, rng.PRNGKey(9), Xd, yd, mask=md)
@@ -1048,6 +1051,18 @@ def test_host_arrays_are_moved_to_the_device_not_handed_to_kernels(rng):
     _, bstate = init_b(rng.PRNGKey(1))
     with pytest.raises(L.D3PError):
         svi.run_steps(st_dev, get_b, bstate, 0, 3)
+    # a device table that is not contiguous float32 (float64 features, integer labels): run_steps walks get_batch + update, which
+    # convert per step -- the same trajectory as the native loop over the float32 table
+    Xt = torch.tensor(r.normal(size=(N, d)), dtype=torch.float32)
+    yt = torch.tensor(r.integers(0, 2, size=N))
+    _, get_f32 = subsample_batchify_data((Xt.cuda(), yt.float().cuda()), batch_size=B, rng_suite=rng)
+    _, get_f64 = subsample_batchify_data((Xt.double().cuda(), yt.cuda()), batch_size=B, rng_suite=rng)
+    st_plain = svi.init(rng.PRNGKey(2), Xd, yd)
+    a, la = svi.run_steps(st_plain, get_f32, rng.PRNGKey(1), 0, 3)
+    b, lb = svi.run_steps(st_plain, get_f64, rng.PRNGKey(1), 0, 3)
+    assert torch.equal(a.rng_key, b.rng_key)
+    np.testing.assert_allclose(np_(lb), np_(la), rtol=2e-5)
+    np.testing.assert_allclose(np_(b.optim_state[1]), np_(a.optim_state[1]), rtol=1e-4, atol=1e-5)
     # a state that went to the host (e.g. to be saved): refused until it is moved back
     from d3p_amd.svi import DPSVIState
     host_state = DPSVIState(tuple(t.cpu() for t in st_dev.optim_state), st_dev.rng_key.cpu(), st_dev.observation_scale)
