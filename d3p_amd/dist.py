@@ -25,6 +25,8 @@ def _device_shard(t, what):
     """A rank's shard of the table as the kernels take it: a contiguous CUDA tensor (a host pointer must never reach a kernel)."""
     if not (isinstance(t, torch.Tensor) and t.is_cuda):
         raise _lib.D3PError(f"{what}: the rank's shard must be a CUDA tensor")
+    if t.is_floating_point() and t.dtype != torch.float32:
+        raise _lib.D3PError(f"{what}: the rank's shard must be float32 (found {t.dtype}): the kernels read it in place")
     return t.contiguous()
 
 

@@ -258,6 +258,15 @@ class Trace_ELBO:
         self.num_particles = 1
 
 
+def _flat_params(params):
+    """The optimisers' flat parameter vector: float32 (jax without x64 holds float32 whatever it is given; the kernels read float32),
+    on the device it is on -- numpy arrays and lists go to the current GPU."""
+    if not isinstance(params, torch.Tensor):
+        import numpy as np
+        params = torch.as_tensor(np.asarray(params, dtype=np.float32)).cuda()
+    return params if params.dtype == torch.float32 else params.to(torch.float32)
+
+
 class Adam:
     """numpyro.optim.Adam(step_size, b1=0.9, b2=0.999, eps=1e-8)."""
 
@@ -265,6 +274,7 @@ class Adam:
         self.step_size, self.b1, self.b2, self.eps = float(step_size), float(b1), float(b2), float(eps)
 
     def init(self, params: torch.Tensor):
+        params = _flat_params(params)
         dev = params.device
         return (torch.zeros((), dtype=torch.int32, device=dev), params,
                 torch.zeros_like(params), torch.zeros_like(params))
@@ -280,6 +290,7 @@ class SGD:
         self.step_size = float(step_size)
 
     def init(self, params):
+        params = _flat_params(params)
         return (torch.zeros((), dtype=torch.int32, device=params.device), params)
 
     def get_params(self, optim_state):

@@ -790,6 +790,8 @@ class DPSVI:
         for t in (svi_state.rng_key,) + tuple(svi_state.optim_state):
             if isinstance(t, torch.Tensor) and not t.is_cuda:
                 raise _lib.D3PError("DPSVI: the state's tensors must live on the GPU (found a host tensor in the state)")
+            if isinstance(t, torch.Tensor) and t.is_floating_point() and t.dtype != torch.float32:
+                raise _lib.D3PError(f"DPSVI: the state's float arrays must be float32 (found {t.dtype}): the kernels read them by address")
 
     def update(self, svi_state, *args, mask=True, **kwargs):
         """One DP-VI step on a batch; returns ``(new_state, loss)`` (svi.py:395-434)."""

@@ -1063,6 +1063,15 @@ def test_host_arrays_are_moved_to_the_device_not_handed_to_kernels(rng):
     assert torch.equal(a.rng_key, b.rng_key)
     np.testing.assert_allclose(np_(lb), np_(la), rtol=2e-5)
     np.testing.assert_allclose(np_(b.optim_state[1]), np_(a.optim_state[1]), rtol=1e-4, atol=1e-5)
+    # a float64 parameter vector: the optimiser's state is float32 whatever it is given (jax without x64); a state BUILT with float64
+    # arrays is refused (its bytes are not float32 parameters)
+    p64 = torch.tensor(np.concatenate([np.zeros(d), np.full(d, -2.0)]))           # float64, host
+    st64 = svi.optim.init(p64.cuda())
+    assert st64[1].dtype == torch.float32 and st64[2].dtype == torch.float32
+    assert svi.optim.init(p64.numpy())[1].is_cuda
+    from d3p_amd.svi import DPSVIState as _S
+    with pytest.raises(L.D3PError):
+        svi.update(_S((st64[0], p64.cuda(), st64[2], st64[3]), st_plain.rng_key, st_plain.observation_scale), Xd, yd)
     # a state that went to the host (e.g. to be saved): refused until it is moved back
     from d3p_amd.svi import DPSVIState
     host_state = DPSVIState(tuple(t.cpu() for t in st_dev.optim_state), st_dev.rng_key.cpu(), st_dev.observation_scale)
