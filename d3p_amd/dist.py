@@ -119,7 +119,8 @@ class HipEngine:
         key0 = state.rng_key.reshape(16)
         n = params0.numel()
         self.keybuf = torch.empty((2, 16), dtype=torch.uint32, device=self.dev)
-        self.bkey = batch_key.contiguous()
+        from . import random as _rng
+        self.bkey = _rng._key(batch_key)                  # (a 16-word CUDA key: anything else is a TypeError, not an address)
         self.frm = None
         if (not copy and params0.dtype == m0.dtype == v0.dtype == torch.float32 and m0.numel() == n and v0.numel() == n
                 and params0.is_contiguous() and m0.is_contiguous() and v0.is_contiguous() and key0.is_contiguous()
@@ -166,7 +167,8 @@ class HipEngine:
             return False
         self.model = self.svi._model_struct(self.d, self.model_kwargs, state.observation_scale)
         self.hyper = self.svi._hyper()
-        self.bkey = batch_key.contiguous()
+        from . import random as _rng
+        self.bkey = _rng._key(batch_key)                  # (a 16-word CUDA key: anything else is a TypeError, not an address)
         koff = (3 * n + nl + 1 + 3) & ~3
         buf = torch.empty(koff + 32, dtype=torch.float32, device=self.dev)
         base = buf.data_ptr()

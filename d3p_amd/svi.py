@@ -722,7 +722,7 @@ class DPSVI:
         step, params, m, v = _fresh_optim_state(svi_state.optim_state)
         keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
         keybuf[0].copy_(svi_state.rng_key.reshape(16))
-        bkey = batchifier_state.contiguous()
+        bkey = strong_rng._key(batchifier_state)          # (a 16-word CUDA key: anything else is a TypeError, not an address)
         st = self._state_struct(keybuf, 0, (step, params, m, v))
         B = int(info.batch_size)
         ws = self._workspace(lib.d3p_dpvi_gmm_workspace(C.byref(gm), B), dev, "gmm_step")
@@ -763,7 +763,7 @@ class DPSVI:
         step, params, m, v = _fresh_optim_state(svi_state.optim_state)
         keybuf = torch.empty((2, 16), dtype=torch.uint32, device=dev)
         keybuf[0].copy_(svi_state.rng_key.reshape(16))
-        bkey = batchifier_state.contiguous()
+        bkey = strong_rng._key(batchifier_state)          # (a 16-word CUDA key: anything else is a TypeError, not an address)
         st = self._state_struct(keybuf, 0, (step, params, m, v))
         ws = self._workspace(lib.d3p_dpvi_vae_workspace(C.byref(vm), B), dev, "vae_step")
         xb = torch.empty((B, D), dtype=torch.float32, device=dev)
@@ -992,7 +992,7 @@ class DPSVI:
         dev = X.device
         model = self._model_struct(d, kwargs, svi_state.observation_scale)
         hyper = self._hyper()
-        bkey = batchifier_state.contiguous()
+        bkey = strong_rng._key(batchifier_state)          # (a 16-word CUDA key: anything else is a TypeError, not an address)
         step0, params0, m0, v0 = svi_state.optim_state
         key0 = svi_state.rng_key.reshape(16)
         n = params0.numel()

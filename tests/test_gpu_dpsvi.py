@@ -1063,6 +1063,9 @@ def test_host_arrays_are_moved_to_the_device_not_handed_to_kernels(rng):
     assert torch.equal(a.rng_key, b.rng_key)
     np.testing.assert_allclose(np_(lb), np_(la), rtol=2e-5)
     np.testing.assert_allclose(np_(b.optim_state[1]), np_(a.optim_state[1]), rtol=1e-4, atol=1e-5)
+    # a batchifier state that is not a device key (here: a host copy of one): a TypeError, not a host address in a kernel
+    with pytest.raises(TypeError):
+        svi.run_steps(st_plain, get_f32, rng.PRNGKey(1).cpu(), 0, 3)
     # a float64 parameter vector: the optimiser's state is float32 whatever it is given (jax without x64); a state BUILT with float64
     # arrays is refused (its bytes are not float32 parameters)
     p64 = torch.tensor(np.concatenate([np.zeros(d), np.full(d, -2.0)]))           # float64, host
