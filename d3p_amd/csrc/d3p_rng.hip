@@ -422,14 +422,18 @@ k_poisson_write(const uint16_t* __restrict__ flags, const uint32_t* __restrict__
 // jnp.take(a, idx, axis=0): one wave per output row.
 // ------------------------------------------------------------------------------------------
 template <typename VEC>
-__global__ void k_take_rows(const char* __restrict__ table, uint32_t row_bytes, const uint32_t* __restrict__ idx,
+__global__ void k_take_rows(const char* __restrict__ table, uint64_t n_rows, uint32_t row_bytes, const uint32_t* __restrict__ idx,
                             uint32_t n, const uint32_t* __restrict__ valid_count, char* __restrict__ out)
 {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= n) return;
     const bool valid = valid_count ? (wave < *valid_count) : true;
-    const VEC* src = reinterpret_cast<const VEC*>(table + (size_t)idx[wave] * row_bytes);
+    // (an index past the table is clamped to its last row -- jnp.take's "clip" -- instead of being dereferenced: the samplers never
+    //  produce one, a caller's own index array might)
+    uint64_t row = idx[wave];
+    if (row >= n_rows) row = n_rows - 1;
+    const VEC* src = reinterpret_cast<const VEC*>(table + (size_t)row * row_bytes);
     VEC* dst = reinterpret_cast<VEC*>(out + (size_t)wave * row_bytes);
     const uint32_t nv = row_bytes / sizeof(VEC);
     VEC zero;
@@ -801,17 +805,17 @@ int d3p_poisson_shard_write(void* stream, uint32_t N, uint32_t row_lo, uint32_t 
 int d3p_take_rows(void* stream, const void* table_dev, uint64_t n_rows, uint32_t row_bytes, const uint32_t* idx_dev,
                   uint32_t n, const uint32_t* valid_count_dev, void* out_dev)
 {
-    (void)n_rows;
     D3P_REQUIRE(table_dev && idx_dev && (out_dev || n == 0), "d3p_take_rows: null pointer");
+    D3P_REQUIRE(n_rows >= 1 || n == 0, "d3p_take_rows: rows requested from an empty table");
     D3P_REQUIRE(row_bytes > 0 && row_bytes % 4 == 0, "d3p_take_rows: row_bytes must be a positive multiple of 4");
     if (n == 0) return D3P_OK;
     const dim3 grid(cdiv((uint64_t)n * 64, 256)), block(256);
     const bool vec16 = (row_bytes % 16 == 0) && (((uintptr_t)table_dev | (uintptr_t)out_dev) % 16 == 0);
     if (vec16)
-        hipLaunchKernelGGL(k_take_rows<uint4>, grid, block, 0, (hipStream_t)stream, (const char*)table_dev, row_bytes,
+        hipLaunchKernelGGL(k_take_rows<uint4>, grid, block, 0, (hipStream_t)stream, (const char*)table_dev, n_rows, row_bytes,
                            idx_dev, n, valid_count_dev, (char*)out_dev);
     else
-        hipLaunchKernelGGL(k_take_rows<uint32_t>, grid, block, 0, (hipStream_t)stream, (const char*)table_dev,
+        hipLaunchKernelGGL(k_take_rows<uint32_t>, grid, block, 0, (hipStream_t)stream, (const char*)table_dev, n_rows,
                            row_bytes, idx_dev, n, valid_count_dev, (char*)out_dev);
     return check_launch("d3p_take_rows");
 }

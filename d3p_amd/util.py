@@ -40,6 +40,10 @@ def take_rows(a: torch.Tensor, idx: torch.Tensor, valid_count: torch.Tensor = No
     if row_bytes % 4 != 0:
         raise _lib.D3PError("take_rows: row size must be a multiple of 4 bytes")
     out = torch.empty((n,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+    if not (isinstance(idx, torch.Tensor) and idx.is_cuda and idx.element_size() == 4 and not idx.is_floating_point()):
+        raise _lib.D3PError("take_rows: the indices must be a CUDA tensor of 32-bit integers")
+    if valid_count is not None and not (isinstance(valid_count, torch.Tensor) and valid_count.is_cuda and valid_count.element_size() == 4):
+        raise _lib.D3PError("take_rows: valid_count must be a CUDA tensor holding one 32-bit integer")
     idx = idx.contiguous()
     check(_lib.load().d3p_take_rows(stream_ptr(), ptr(a), n_rows, row_bytes, ptr(idx), n,
                                     ptr(valid_count), ptr(out)))

@@ -233,3 +233,20 @@ def test_take_rows_generic(rng):
         a = (torch.rand(shape, device="cuda") * 100).to(dtype)
         idx = torch.tensor([3, 0, 49, 3, 17], dtype=torch.int32, device="cuda").view(torch.uint32)
         assert torch.equal(take_rows(a, idx), a[np_(idx.view(torch.int32)).tolist()])
+
+
+def test_take_rows_never_dereferences_an_index_past_the_table(gpu):
+    """The samplers only produce valid rows; a caller's own index array may not: an index past the table is clamped to the last row
+    (jnp.take's "clip"), indices that are not a device tensor of 32-bit integers are refused -- neither becomes an address."""
+    import d3p_amd._lib as L
+    from d3p_amd.util import take_rows
+    a = torch.arange(40, dtype=torch.float32, device="cuda").reshape(10, 4)
+    idx = torch.tensor([0, 9, 10, 4_000_000_000 - 2**32, 3], dtype=torch.int32, device="cuda")      # 10 and 0xEE6B2800 are past the table
+    out = take_rows(a, idx.view(torch.uint32))
+    assert torch.equal(out, a[torch.tensor([0, 9, 9, 9, 3], device="cuda")])
+    with pytest.raises(L.D3PError):
+        take_rows(a, idx.cpu())
+    with pytest.raises(L.D3PError):
+        take_rows(a, idx.to(torch.int64))
+    with pytest.raises(L.D3PError):
+        take_rows(a.cpu(), idx)
