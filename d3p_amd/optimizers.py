@@ -67,6 +67,8 @@ class ADADP:
                 torch.zeros(0, dtype=torch.float32, device=dev)
 
         xf, gf, sf, pf = pack(x).clone(), pack(g), pack(x_stepped).clone(), pack(x_prev).clone()
+        if not (gf.numel() == sf.numel() == pf.numel() == xf.numel()):
+            raise ValueError("ADADP: gradient / state leaves do not have the parameters' sizes")
         lr_t = _dev_f32(lr, dev).reshape(1).clone()
         step = (i.to(device=dev, dtype=torch.int32).reshape(1).clone() if isinstance(i, torch.Tensor)
                 else torch.tensor([int(i)], dtype=torch.int32, device=dev))

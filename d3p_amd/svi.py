@@ -589,6 +589,8 @@ class DPSVI:
         outs = []
         for k, g in enumerate(leaves):
             g = _as_device_f32(g, px_loss.device)
+            if g.dim() < 1 or g.shape[0] != B:
+                raise ValueError(f"_combine_gradients: a gradient leaf with {g.shape[0] if g.dim() else 0} rows beside {B} per-example losses")
             rows = g.reshape(g.shape[0], -1).contiguous()
             avg = torch.empty(rows.shape[1], dtype=torch.float32, device=rows.device)
             check(lib.d3p_combine(stream_ptr(), ptr(rows), ptr(px_loss) if k == 0 else None, rows.shape[0],
@@ -653,6 +655,9 @@ class DPSVI:
         st = dp_svi_state.optim_state
         if isinstance(self.optim, ADADP):
             return self._update_state_optim_state(dp_svi_state, self.optim.update(g, st))
+        self._require_device_state(dp_svi_state)
+        if g.numel() != st[1].numel():
+            raise ValueError(f"_apply_gradient: a gradient of {g.numel()} elements for {st[1].numel()} parameters")
         step = st[0].clone()
         params = st[1].clone()
         if isinstance(self.optim, Adam):

@@ -1129,3 +1129,24 @@ def test_shapes_that_do_not_fit_the_state_are_python_errors(rng):
         vsvi.update(vst, (torch.rand(B, 28, device="cuda") < 0.5).float())
     with pytest.raises(ValueError):
         vsvi.evaluate(vst, (torch.rand(B, 28, device="cuda") < 0.5).float())
+
+
+def test_stage_methods_check_the_sizes_they_hand_to_kernels(rng):
+    """The five stage methods are public (the reference's tests call them): a gradient leaf with another number of rows than there
+    are losses, or a gradient that is shorter than the parameter vector, is a ValueError before a kernel reads past it."""
+    from d3p_amd.models import SGD, Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
+    from d3p_amd.optimizers import ADADP
+    from d3p_amd.svi import DPSVI
+    d, B = 6, 10
+    model = LogisticRegression(d)
+    X, y = torch.randn(B, d, device="cuda"), torch.zeros(B, device="cuda")
+    for optim in (Adam(1e-2), SGD(1e-2), ADADP(1e-2)):
+        svi = DPSVI(model, AutoDiagonalNormal(model), optim, Trace_ELBO(), 1.0, 0.5, num_obs_total=100)
+        st = svi.init(rng.PRNGKey(0), X, y)
+        with pytest.raises(ValueError):
+            svi._apply_gradient(st, {"auto_loc": torch.zeros(d, device="cuda"), "auto_scale": torch.zeros(d - 1, device="cuda")})
+        svi._apply_gradient(st, {"auto_loc": torch.zeros(d, device="cuda"), "auto_scale": torch.zeros(d, device="cuda")})
+    with pytest.raises(ValueError):
+        svi._combine_gradients({"auto_loc": torch.zeros(B + 2, d, device="cuda")}, torch.zeros(B, device="cuda"))
+    loss, avg = svi._combine_gradients({"auto_loc": torch.ones(B, d, device="cuda")}, torch.full((B,), 2.0, device="cuda"))
+    assert float(loss) == 2.0 and torch.equal(avg["auto_loc"], torch.ones(d, device="cuda"))
