@@ -142,7 +142,8 @@ int d3p_poisson_shard_write(void* stream, uint32_t N, uint32_t row_lo, uint32_t 
 
 /* jnp.take(a, idx, axis=0) for a row-major table (minibatch.py:126-129, :210, :233, :306).
  * If valid_count_dev != NULL, output rows >= *valid_count_dev are zero-filled (the mask multiply
- * of minibatch.py:127-129).  row_bytes must be a multiple of 4. */
+ * of minibatch.py:127-129).  row_bytes must be a multiple of 4.  An index >= n_rows is clamped to the last row
+ * (jnp.take's "clip"; the samplers never produce one), never dereferenced. */
 int d3p_take_rows(void* stream, const void* table_dev, uint64_t n_rows, uint32_t row_bytes,
                   const uint32_t* idx_dev, uint32_t n, const uint32_t* valid_count_dev,
                   void* out_dev);
