@@ -37,6 +37,13 @@ def _fresh_optim_state(optim_state):
     return step.clone(), params.clone(), m.clone(), v.clone()
 
 
+class SVIRunResult(NamedTuple):
+    """numpyro.infer.svi.SVIRunResult: what ``SVI.run`` returns."""
+    params: Any
+    state: Any
+    losses: Any
+
+
 class DPSVIState(NamedTuple):
     """d3p/svi.py:37-40."""
     optim_state: Any
@@ -1082,6 +1089,23 @@ class DPSVI:
         """The code of the bounded wait that stopped the last run (0: none), as text: which wait, at which step of its
         launch (d3p_logreg_kernel.h, D3P_ABORT_*).  Valid after ``last_run_status()``."""
         return _lib.describe_abort(getattr(self, "_last_abort_code", 0))
+
+    # ---------------------------------------------------------------- numpyro.infer.SVI.run (inherited by the reference's DPSVI)
+    def run(self, rng_key, num_steps, *args, progress_bar=False, stable_update=False, init_state=None, **kwargs):
+        """``numpyro.infer.SVI.run``, which the reference's DPSVI inherits: ``num_steps`` x ``update`` on the SAME arguments, from
+        ``init(rng_key, *args)`` or ``init_state``; returns ``SVIRunResult(params, state, losses)``.  ``progress_bar`` is accepted and
+        ignored (nothing is printed).  ``stable_update=True`` is refused: numpyro's ``stable_update`` evaluates the plain ELBO through
+        the optimiser (``eval_and_stable_update``) -- in the reference it would BYPASS the clip / noise pipeline, i.e. not be private."""
+        if stable_update:
+            raise NotImplementedError("DPSVI.run(stable_update=True): numpyro's stable_update steps on the unclipped, noise-free ELBO "
+                                      "gradient (it does not go through DPSVI.update); refused")
+        state = self.init(rng_key, *args, **kwargs) if init_state is None else init_state
+        losses = []
+        for _ in range(int(num_steps)):
+            state, loss = self.update(state, *args, **kwargs)
+            losses.append(loss.reshape(()))
+        dev = state.optim_state[1].device if isinstance(state.optim_state[1], torch.Tensor) else None
+        return SVIRunResult(self.get_params(state), state, torch.stack(losses) if losses else torch.empty(0, dtype=torch.float32, device=dev))
 
     # ---------------------------------------------------------------- evaluate / accounting
     def evaluate(self, svi_state, *args, **kwargs):
