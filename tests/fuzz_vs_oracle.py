@@ -31,6 +31,11 @@ DIMS = [1, 2, 3, 5, 8, 17, 31, 64, 100, 255, 256, 257, 511, 512, 513, 700, 1024,
 BATCHES = [1, 2, 7, 32, 63, 64, 65, 200, 1000, 4096, 5000]
 
 
+def _frac(flags):
+    """Fraction of True entries (0 for an empty array)."""
+    return float(np.mean(flags)) if np.size(flags) else 0.0
+
+
 def _far(got, want, tol):
     """Elementwise: True where got and want differ by more than tol (equal infinities are equal; NaNs are compared separately)."""
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
@@ -206,7 +211,7 @@ def run_case(c, O, dump=False):
         # (Adam's early steps are lr g / (|g| + 1e-8): a gradient component near 0 carries its own relative error into the step -- a
         #  handful of parameters a few per cent of a step apart is that)
         small = bad & (np.abs(got_p[fin] - want_p[fin]) <= 0.05 * c["lr"] * steps)
-        if (bad & ~small).any() or small.mean() > 0.005:
+        if (bad & ~small).any() or _frac(small) > 0.005:
             k = int(np.argmax(np.abs(got_p[fin] - want_p[fin])))
             why.append(f"parameter: {got_p[fin][k]!r} vs {want_p[fin][k]!r} (largest {scale:.3g}); {int(bad.sum())} of {int(fin.sum())} out of tolerance")
     # evaluate (svi.py:436-449) on a fresh batch at the state the trajectory reached (not in the corner where a scale underflows)
@@ -489,7 +494,7 @@ def run_gmm_case(c, O, dump=False):
         # (Adam's first steps are lr g / (|g| + 1e-8): a gradient component that is ~ 0 -- sums of float32 terms on the device, float64 in
         #  the oracle -- may take the other sign: a handful of parameters one or two steps of lr apart is that, not a defect)
         sign_flips = bad & (np.abs(got_p[fin] - x[fin]) <= 2.1 * c["lr"] * steps)
-        if (bad & ~sign_flips).any() or sign_flips.mean() > 0.005:
+        if (bad & ~sign_flips).any() or _frac(sign_flips) > 0.005:
             k = int(np.argmax(np.abs(got_p[fin] - x[fin])))
             why.append(f"parameter: {got_p[fin][k]!r} vs {x[fin][k]!r} (largest {scale:.3g}); {int(bad.sum())} of {int(fin.sum())} out of tolerance")
     if np.isfinite(x).all() and np.isfinite(got_p).all():
@@ -604,7 +609,7 @@ def run_vae_case(c, O, dump=False):
         fin = ~np.isnan(x)
         tol = 0.02 * c["lr"] * steps + 1e-4 * np.abs(x[fin])
         bad = np.abs(got_p[fin] - x[fin]) > tol
-        if bad.mean() > 0.01:
+        if _frac(bad) > 0.01:
             k = int(np.argmax(np.abs(got_p[fin] - x[fin])))
             why.append(f"parameter: {got_p[fin][k]!r} vs {x[fin][k]!r}; {int(bad.sum())} of {int(fin.sum())} out of tolerance")
     if np.isfinite(x).all() and np.isfinite(got_p).all():
@@ -939,7 +944,7 @@ def run_posshards_case(c, O, dump=False):
         else:
             fin = ~np.isnan(b)
             bad = _far(a[fin], b[fin], 0.02 * c["lr"] * (t + 1) + 1e-4 * np.abs(b[fin]))
-            if bad.mean() > 0.01:
+            if _frac(bad) > 0.01:
                 why.append(f"step {t}: {int(bad.sum())} of {int(fin.sum())} parameters out of tolerance")
         if why:
             break
