@@ -407,10 +407,13 @@ class DPSVI:
                           0.9, 0.999, 1e-8)
 
     def _workspace(self, nbytes, device, tag="ws"):
-        buf = self._ws.get(tag)
-        if buf is None or buf.numel() < nbytes or buf.device != device:
+        # one buffer per (purpose, device, STREAM): two streams that drive the same DPSVI object enqueue kernels that run beside each
+        # other -- they must not share scratch memory (the reference is functional: nothing is shared between calls)
+        key = (tag, str(device), torch.cuda.current_stream(device).cuda_stream)
+        buf = self._ws.get(key)
+        if buf is None or buf.numel() < nbytes:
             buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-            self._ws[tag] = buf
+            self._ws[key] = buf
         return buf
 
     # ---------------------------------------------------------------- init (svi.py:213-236)

@@ -670,7 +670,7 @@ def _check_no_wait_hit_its_bound(rng, N, d, B):
     lib = L.load()
     model = svi._model_struct(d, {}, float(N))
     src = L.BatchSource(L.D3P_BATCH_FEISTEL, B, 0.0, 0, None, None, None, N, 0, N)
-    ws = svi._ws["ws"]
+    ws = svi._workspace(0, X.device)          # (the run's buffer: the same purpose, device and stream)
     flag = C.c_int32(-1)
     L.check(lib.d3p_dpvi_logreg_chain_status(L.stream_ptr(), C.byref(model), C.byref(src), L.ptr(ws), ws.numel(), C.byref(flag)))
     assert flag.value == 0
@@ -1175,3 +1175,30 @@ def test_run_is_num_steps_updates_on_the_same_arguments(rng):
     assert int(more.state.optim_state[0]) == 7
     with pytest.raises(NotImplementedError):
         svi.run(rng.PRNGKey(3), 2, X, y, stable_update=True)
+
+
+def test_one_dpsvi_object_driven_from_two_streams(rng):
+    """The reference is functional (nothing shared between calls); here a DPSVI object owns scratch buffers.  They are per STREAM: two
+    streams that enqueue updates of different batches through the same object, beside each other, give what the same calls give one
+    after the other."""
+    from d3p_amd.models import Adam, AutoDiagonalNormal, LogisticRegression, Trace_ELBO
+    from d3p_amd.svi import DPSVI
+    B, d, N = 4096, 512, 100000
+    g = torch.Generator().manual_seed(1)
+    Xa, Xb = torch.randn(B, d, generator=g).cuda(), torch.randn(B, d, generator=g).cuda()
+    ya, yb = (torch.rand(B, generator=g) < 0.5).float().cuda(), (torch.rand(B, generator=g) < 0.5).float().cuda()
+    model = LogisticRegression(d)
+    svi = DPSVI(model, AutoDiagonalNormal(model), Adam(1e-2), Trace_ELBO(), 1.0, 0.5, num_obs_total=N)
+    st = svi.init(rng.PRNGKey(0), Xa, ya)
+    want_a, la = svi.update(st, Xa, ya)
+    want_b, lb = svi.update(st, Xb, yb)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(30):
+        with torch.cuda.stream(s1):
+            got_a, ga = svi.update(st, Xa, ya)
+        with torch.cuda.stream(s2):
+            got_b, gb = svi.update(st, Xb, yb)
+        torch.cuda.synchronize()
+        assert torch.equal(got_a.optim_state[1], want_a.optim_state[1]) and float(ga) == float(la)
+        assert torch.equal(got_b.optim_state[1], want_b.optim_state[1]) and float(gb) == float(lb)
