@@ -29,12 +29,14 @@ __device__ __forceinline__ void guide_scale(int gexp, float u, float& s, float& 
         s = ds = expf(u);   // (not __expf: exp2(u log2 e) carries |u| ulp of relative error, 2e-6 at u = 27 -- this is a scale, once per column)
     } else {
         s = softplus_f(u);
-        // softplus_f's log(1 + e) is exact to ~1e-7 ABSOLUTE: enough for a log-likelihood term, not for a scale that is divided by --
-        // below u ~ -16.6 the sum 1 + exp(u) rounds to 1 and the scale would be 0 (0 / 0 in the entropy gradient, log 0 in the loss).
-        // log1p(e) = e (1 - e / 2 + ...) there, which is what jax.nn.softplus (logaddexp) and the oracle's log1pf return.
-        if (u < -15.0f) {
-            const float e = expf(u);
-            s = e * (1.0f - 0.5f * e);
+        // softplus_f's log(1 + e) is exact to ~1e-7 ABSOLUTE: enough for a log-likelihood term, not for a SCALE, which enters the step
+        // through its logarithm and its reciprocal: at u = -6 (a posterior standard deviation of 2.5e-3) that is 3e-5 relative, at
+        // u = -15 20 %, and below u ~ -16.6 the sum 1 + exp(u) rounds to 1 and the scale is 0 (0 / 0, log 0).  Below u = -4 the scale is
+        // log1p's series e (1 - e/2 + e^2/3 - e^3/4 + e^4/5) (e < 0.0184: the next term is 4e-10 relative) -- what jax.nn.softplus
+        // (logaddexp) and the oracle's log1pf return.  (Five multiply-adds per column, only for such columns.)
+        if (u < -4.0f) {
+            const float e = u < -15.0f ? expf(u) : __expf(u);
+            s = e * __fmaf_rn(e, __fmaf_rn(e, __fmaf_rn(e, __fmaf_rn(e, 0.2f, -0.25f), 0.33333334f), -0.5f), 1.0f);
         }
         ds = sigmoid_f(u);
     }

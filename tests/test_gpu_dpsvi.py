@@ -1202,3 +1202,37 @@ def test_one_dpsvi_object_driven_from_two_streams(rng):
         torch.cuda.synchronize()
         assert torch.equal(got_a.optim_state[1], want_a.optim_state[1]) and float(ga) == float(la)
         assert torch.equal(got_b.optim_state[1], want_b.optim_state[1]) and float(gb) == float(lb)
+
+
+@pytest.mark.parametrize("d", [24, 512, 2600])
+def test_small_guide_scales_keep_their_relative_accuracy(rng, O, d):
+    """softplus(u) as a SCALE: `max(u, 0) + log(1 + exp(-|u|))` loses it below u ~ -4 (1e-7 absolute: 3e-5 relative at u = -6, 20 % at
+    u = -15, exactly 0 below -16.6 -- 0 / 0 and log 0 in the step).  Posterior standard deviations of 1e-3 .. 1e-7 are such u.  Per-example
+    gradients (those of the unconstrained scales carry 1 / s), the loss, evaluate and a fused update at u in [-60, -4] against the oracle
+    (jax.nn.softplus = logaddexp; log1pf there): 2e-5."""
+    B, N = 12, 1000
+    r = np.random.default_rng(d)
+    X = r.normal(size=(B, d)).astype(np.float32)
+    y = (r.random(B) < 0.5).astype(np.float32)
+    loc = (r.normal(size=d) * 0.3).astype(np.float32)
+    unc = r.choice(np.array([-4.5, -6.0, -9.0, -12.0, -14.9, -15.1, -16.7, -20.0, -40.0, -60.0], np.float32), size=d).astype(np.float32)
+    svi = make_svi(d, False, N, C=1e6, sigma=0.0, lr=1e-3)
+    st = state_with(svi, rng.PRNGKey(3), loc, unc)
+    eps = r.normal(size=(B, d)).astype(np.float32)
+    Xt, yt = torch.tensor(X).cuda(), torch.tensor(y).cuda()
+    _, px_loss, px_grads, n, f = svi._compute_per_example_gradients(st, rng.PRNGKey(4), Xt, yt, _eps=torch.tensor(eps).cuda())
+    spec = O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=N)
+    eL, eG, _, _ = O.logreg_px_grads(spec, loc, unc, X, y, eps)
+    G = np.concatenate([np_(px_grads["auto_loc"]), np_(px_grads["auto_scale"])], axis=1)
+    np.testing.assert_allclose(G, eG, rtol=2e-5, atol=2e-6 * np.abs(eG).max())
+    np.testing.assert_allclose(np_(px_loss), eL, rtol=2e-5)
+    assert np.isfinite(G).all() and np.abs(G[:, d:]).min() > 0          # (the entropy gradient -1/obs * ds/s is never 0 or NaN)
+    got = float(svi.evaluate(st, Xt, yt))
+    want = O.logreg_evaluate(O.logreg_spec(d, False, 1.0, 2.0, lik_scale=N, obs_scale=1.0), loc, unc, X, y,
+                             O.convert_to_jax_rng_key(O.split(O.PRNGKey(3), 1)[0]))
+    assert abs(got - want) <= 2e-5 * abs(want)
+    new, loss = svi.update(st, Xt, yt)
+    ost = O.LogregState(O.PRNGKey(3), d, loc, unc)
+    eloss, _ = O.logreg_update(spec, O.Hyper(1e6, 0.0, 1e-3, 0.9, 0.999, 1e-8), ost, X, y)
+    assert abs(float(loss) - eloss) <= 2e-5 * abs(eloss)
+    np.testing.assert_allclose(np_(new.optim_state[1]), ost.params, rtol=1e-4, atol=1e-6)
