@@ -70,6 +70,8 @@ def draw_case(seed):
     c["key"], c["bkey"] = int(r.integers(0, 2**31)), int(r.integers(0, 2**31))
     c["unscale"] = bool(r.random() < 0.8)        # clip_unscaled_observations (svi.py:225-234): False = observation_scale 1
     c["split_at"] = int(r.integers(1, c["steps"])) if (c["steps"] > 1 and r.random() < 0.5) else 0   # the run as two consecutive run_steps calls
+    r3 = np.random.default_rng(1_200_007 * seed + 71)      # (later additions draw from their own stream: the earlier fields of a seed stay)
+    c["unc_center"] = float(r3.choice([-2.0, -2.0, -6.0, -10.0, -14.0]))   # unconstrained scales around it: posterior std 0.13 .. 8e-7
     return c
 
 
@@ -113,7 +115,7 @@ def run_case(c, O, dump=False):
             ost.params[:] = params0
     else:
         loc0 = (r.normal(size=D) * c["init_scale"]).astype(np.float32)
-        unc0 = (r.normal(size=D) * c["init_scale"] - 2.0).astype(np.float32)
+        unc0 = (r.normal(size=D) * c["init_scale"] + c.get("unc_center", -2.0)).astype(np.float32)
         ost = O.LogregState(O.PRNGKey(c["key"]), D, loc0, unc0)
         params0 = np.concatenate([loc0, unc0])
     st = DPSVIState(svi.optim.init(torch.tensor(params0).cuda()), rng.PRNGKey(c["key"]), obs)
