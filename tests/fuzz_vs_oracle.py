@@ -423,6 +423,8 @@ def draw_gmm_case(seed):
     r2 = np.random.default_rng(900_007 * seed + 59)     # (later additions draw from their own stream: the earlier fields of a seed stay)
     if c["source"] == "feistel" and c["B"] * c["K"] * c["d"] <= 3000 and r2.random() < 0.5:
         c["steps"] = int(r2.choice([65, 70, 130]))       # across the native loop's batches of prepared steps
+    c["alpha_scale"] = float(r2.choice([0.4, 0.4, 1.5]))   # log-concentrations ~ N(0, alpha_scale^2): Dirichlet concentrations 0.05 .. 20 at 1.5
+    c["mu_scale"] = float(r2.choice([2.0, 2.0, 8.0]))
     return c
 
 
@@ -435,7 +437,7 @@ def run_gmm_case(c, O, dump=False):
     r = np.random.default_rng(c["seed"] + 11)
     K, d, B, N, steps = c["K"], c["d"], c["B"], c["N"], c["steps"]
     X = (r.normal(size=(N, d)) * 3).astype(np.float32)
-    params = np.concatenate([r.normal(size=K) * 0.4, r.normal(size=K * d) * 2]).astype(np.float32)
+    params = np.concatenate([r.normal(size=K) * c.get("alpha_scale", 0.4), r.normal(size=K * d) * c.get("mu_scale", 2.0)]).astype(np.float32)
     model = GaussianMixtureModel()
     svi = DPSVI(model, GaussianMixtureGuide(model), Adam(c["lr"]), Trace_ELBO(), c["clip"], c["sigma"], k=K, d=d, num_obs_total=N)
     st = DPSVIState(svi.optim.init(torch.tensor(params).cuda()), rng.PRNGKey(c["key"]), float(N))
@@ -445,10 +447,14 @@ def run_gmm_case(c, O, dump=False):
     x, m, v = params.copy(), np.zeros_like(params), np.zeros_like(params)
     el, mask = [], None
 
+    blown = False     # a per-example gradient that is not finite (a Gamma draw of 1e-317 under a concentration of 0.05 ...)
+
     def oracle_step(i, Xb, mk):
-        nonlocal key, x, m, v
+        nonlocal key, x, m, v, blown
         ks = O.split(key, 3)
         L, G, n, f = O.gmm_px_grads(spec, x, Xb, O.convert_to_jax_rng_key(ks[1]), mk)
+        if np.isfinite(x).all():       # (from FINITE parameters; a NaN state's NaN gradients are the empty-batch cases, held strictly)
+            blown = blown or not (np.isfinite(G).all() and np.isfinite(L).all())
         eloss, avg = O.combine(O.clip_rows(G, c["clip"]), L)
         with np.errstate(all="ignore"):
             g = O.perturb(ks[2], avg, [K, K * d], c["sigma"], c["clip"], n, N, f)
@@ -475,6 +481,11 @@ def run_gmm_case(c, O, dump=False):
     got_l, want_l = losses.detach().cpu().numpy().astype(np.float64), np.asarray(el, np.float64)
     got_p = st.optim_state[1].detach().cpu().numpy()
     why = []
+    if blown:
+        # The reference keeps such a step's damage to the columns the bad entries are in (inf * 0 = NaN after clipping); the fused
+        # kernels poison the whole step (count column -> NaN loss, NaN state: "never finite garbage").  Held to: not finite garbage.
+        c["ok"], c["why"] = bool(np.isnan(got_p).any()), "a non-finite per-example gradient: the step must not end in a finite state"
+        return c
     if not np.array_equal(np.isnan(got_l), np.isnan(want_l)):
         why.append(f"losses: NaN pattern differs ({got_l.tolist()} vs {want_l.tolist()})")
     else:
