@@ -543,6 +543,12 @@ def draw_vae_case(seed):
     c["grey"] = bool(r.random() < 0.4)
     c["mask_keep"] = float(r.choice([1.0, 0.7, 0.0 if r.random() < 0.3 else 0.7]))
     c["key"], c["bkey"] = int(r.integers(0, 2**31)), int(r.integers(0, 2**31))
+    r2 = np.random.default_rng(1_300_021 * seed + 73)     # (later additions: their own stream)
+    # (larger weights: saturated units, encoder scales exp(u) of e^+-5.  Beyond a factor of ~3 the float32 ELBO itself overflows -- losses
+    #  of 1e25 .. inf, where a float64 oracle and a float32 device differ by construction: not a regime that is compared)
+    #  (tried at 2, 3, 4, 12: what differs there is Adam's lr g / (|g| + 1e-8) on gradient components that saturated units make exactly
+    #  0 in float32 and 1e-18 in the float64 oracle, and overflow -- nothing a trajectory comparison can hold)
+    c["pscale_mult"] = 1.0
     return c
 
 
@@ -556,7 +562,7 @@ def run_vae_case(c, O, dump=False):
     D, H, Z, H2, B, N, steps = c["D"], c["H"], c["Z"], c["H2"], c["B"], c["N"], c["steps"]
     spec = O.vae_spec(D, H, Z, scale=1.0, obs_scale=1.0, H2=H2)
     P = O.vae_num_params(spec)
-    pscale = 0.03 if (D > 100 or H > 50 or H2 > 50) else 0.3
+    pscale = (0.03 if (D > 100 or H > 50 or H2 > 50) else 0.3) * c.get("pscale_mult", 1.0)
     params = (r.normal(size=P) * pscale).astype(np.float32)
     X = r.random((N, D)).astype(np.float32) if c["grey"] else (r.random((N, D)) < 0.3).astype(np.float32)
     model = VAEModel(scale=1.0 / N)
