@@ -372,3 +372,60 @@ def test_vae_run_steps_native_loop_matches_stepwise_updates(gpu, N, B, D, H, Z, 
         assert torch.equal(a, b)
     again, losses2 = svi.run_steps(st0, get_batch, bstate, first, steps)
     assert torch.equal(again.optim_state[1], new_st.optim_state[1]) and torch.equal(losses2, losses)
+
+
+@pytest.mark.parametrize("mult", [1.0, 2.0])
+def test_step_sums_vs_float32_autograd_where_float32_overflows(lib, mult):
+    """The oracle works in float64 inside; with weights large enough for per-example gradient norms of 1e20 .. 1e29 the FLOAT32 norm of an
+    example overflows (|g|^2 > 3.4e38): its clip factor is 1 / max(1, inf / C) = 0 and the example drops out -- in the reference (float32
+    jax) as on the device, not in the oracle.  A float32 torch.autograd restatement of the same ELBO (784-free small shape, one hidden
+    layer) is the comparator there: the same examples overflow, and the clipped sums agree; at ordinary weights all three agree."""
+    D, H, Z, B, clip = 100, 40, 50, 64, 0.5
+    r = np.random.default_rng(91)
+    sizes = [Z * H, H, H * D, D, D * H, H, H * Z, Z, H * Z, Z]        # decoder (V1, c1, V2, c2), encoder (W1, b1, Wl, bl, Ws, bs)
+    P = sum(sizes)
+    params = (r.normal(size=P) * 0.3 * mult).astype(np.float32)
+    X = (r.random((B, D)) < 0.3).astype(np.float32)
+    eps = r.normal(size=(B, Z)).astype(np.float32)
+
+    def autograd(dtype):
+        p = torch.tensor(params, dtype=dtype, device="cuda", requires_grad=True)
+        Xt, et = torch.tensor(X, dtype=dtype, device="cuda"), torch.tensor(eps, dtype=dtype, device="cuda")
+        one = torch.tensor(1.0, dtype=dtype, device="cuda")
+        sums, norms, pos, leaves = torch.zeros(P, dtype=dtype, device="cuda"), [], 0, []
+        for n in sizes:
+            leaves.append((pos, n))
+            pos += n
+        sp = torch.nn.functional.softplus
+        for i in range(B):
+            V1, c1, V2, c2, W1, b1, Wl, bl, Ws, bs = (p[o:o + n] for o, n in leaves)
+            h1 = sp(Xt[i] @ W1.reshape(D, H) + b1)
+            zl, u = h1 @ Wl.reshape(H, Z) + bl, h1 @ Ws.reshape(H, Z) + bs
+            z = zl + torch.exp(u) * et[i]
+            a = sp(z @ V1.reshape(Z, H) + c1) @ V2.reshape(H, D) + c2
+            loss = ((-0.5 * et[i] ** 2 - u) + 0.5 * z * z).sum() - (Xt[i] * a - sp(a)).sum()
+            g, = torch.autograd.grad(loss, p)
+            nrm = g.norm()
+            sums = sums + g * (1.0 / torch.maximum(one, nrm / clip))
+            norms.append(float(nrm.detach()))
+        return sums.detach().cpu().numpy(), np.array(norms)
+    s32, n32 = autograd(torch.float32)
+    s64, n64 = autograd(torch.float64)
+    L = lib.load()
+    model = lib.VaeModel(D, H, Z, 1.0, 1.0, 0)
+    ws = torch.empty(int(L.d3p_dpvi_vae_workspace(C.byref(model), B)), dtype=torch.uint8, device="cuda")
+    sums, norms, pxl = torch.empty(P + 2, device="cuda"), torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    pt, Xt, et = torch.tensor(params).cuda(), torch.tensor(X).cuda(), torch.tensor(eps).cuda()
+    lib.check(L.d3p_vae_step_sums(lib.stream_ptr(), C.byref(model), lib.ptr(pt), lib.ptr(Xt), None, B, lib.ptr(et), None, clip,
+                                  lib.ptr(sums), lib.ptr(norms), lib.ptr(pxl), lib.ptr(ws), ws.numel()))
+    hs, hn = np_(sums)[:P], np_(norms)
+    assert np.isfinite(s64).all() and np.isfinite(n64).all()
+    assert np.array_equal(np.isfinite(hn), np.isfinite(n32))                 # the same examples overflow in float32
+    assert np.isfinite(hs).all() and np.isfinite(s32).all()
+    np.testing.assert_allclose(hs, s32, rtol=0, atol=2e-3 * np.abs(s32).max())
+    if mult == 1.0:
+        assert np.isfinite(hn).all()
+        np.testing.assert_allclose(hs, s64, rtol=0, atol=2e-4 * np.abs(s64).max())
+        np.testing.assert_allclose(hn, n64, rtol=1e-4)
+    else:
+        assert 0 < (~np.isfinite(hn)).sum() < B                              # (the case is what it says: some, not all)
